@@ -1,0 +1,125 @@
+"""
+ctypes binding of ``libmpk.so`` (include/mpk.h).  There is NO CPU fallback: if the HIP library is missing or cannot be
+loaded every entry point of the package that needs it raises ``MPKLibraryError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmpk.so")
+
+MPK_ABI_VERSION = 1
+MP_TYPES = {"promp": 0, "dmp": 1, "prodmp": 2}
+PHASE_TYPES = {"linear": 0, "exp": 1}
+BASIS_TYPES = {"rbf": 0, "zero_rbf": 1, "prodmp": 2}
+CTRL_TYPES = {"motor": 0, "velocity": 1, "position": 2}
+PLANT_TYPES = {"static": 0, "double_integrator": 1}
+
+MPK_EINVAL, MPK_ENOTIMPL, MPK_EHIP, MPK_ERANGE, MPK_ENODEV = -1, -2, -3, -4, -5
+
+
+class MPKLibraryError(RuntimeError):
+    """libmpk.so is missing / failed to load / reported a HIP failure."""
+
+
+class mpk_config(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("device", C.c_int32),
+        ("mp_type", C.c_int32), ("phase_type", C.c_int32), ("basis_type", C.c_int32),
+        ("num_dof", C.c_int32), ("num_basis", C.c_int32), ("num_basis_outside", C.c_int32),
+        ("num_basis_zero_start", C.c_int32), ("num_basis_zero_goal", C.c_int32),
+        ("learn_tau", C.c_int32), ("learn_delay", C.c_int32),
+        ("auto_scale_basis", C.c_int32), ("relative_goal", C.c_int32),
+        ("disable_goal", C.c_int32), ("disable_weights", C.c_int32),
+        ("pre_compute_length_factor", C.c_int32), ("reserved0", C.c_int32),
+        ("tau", C.c_double), ("delay", C.c_double), ("alpha_phase", C.c_double),
+        ("tau_bound", C.c_double * 2), ("delay_bound", C.c_double * 2),
+        ("basis_bandwidth_factor", C.c_double), ("basis_alpha", C.c_double), ("basis_dt", C.c_double),
+        ("weights_scale", C.c_double), ("goal_scale", C.c_double), ("dmp_alpha", C.c_double),
+        ("dt", C.c_double), ("duration", C.c_double),
+    ]
+
+
+class mpk_rollout_cfg(C.Structure):
+    _fields_ = [
+        ("controller_type", C.c_int32), ("plant_type", C.c_int32), ("dt", C.c_double),
+        ("p_gains", C.POINTER(C.c_double)), ("d_gains", C.POINTER(C.c_double)),
+        ("act_low", C.POINTER(C.c_double)), ("act_high", C.POINTER(C.c_double)),
+    ]
+
+
+_vp, _i32, _dbl = C.c_void_p, C.c_int32, C.c_double
+
+# name -> (restype, argtypes); one row per symbol declared in include/mpk.h
+SIGNATURES = {
+    "mpk_last_error": (C.c_char_p, []),
+    "mpk_abi_version": (C.c_int, []),
+    "mpk_device_count": (C.c_int, []),
+    "mpk_create": (C.c_int, [C.POINTER(mpk_config), C.POINTER(_vp)]),
+    "mpk_destroy": (None, [_vp]),
+    "mpk_num_params": (C.c_int, [_vp]),
+    "mpk_num_steps": (C.c_int, [_vp]),
+    "mpk_num_dof": (C.c_int, [_vp]),
+    "mpk_params_bounds": (C.c_int, [_vp, _vp, _vp]),
+    "mpk_set_duration": (C.c_int, [_vp, _dbl, _dbl]),
+    "mpk_times": (C.c_int, [_vp, _vp]),
+    "mpk_trajectory": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _vp, _vp, _i32, _vp]),
+    "mpk_trajectory_actions": (C.c_int, [_vp, _vp, _vp, _vp, _dbl, C.POINTER(mpk_rollout_cfg), _vp, _vp,
+                                         _vp, _vp, _vp, _i32, _vp]),
+    "mpk_pd_rollout": (C.c_int, [_vp, C.POINTER(mpk_rollout_cfg), _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "mpk_replan_advance": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "mpk_traj_validity": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "mpk_prodmp_tables": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mpk_prodmp_indices": (C.c_int, [_vp, _dbl, _vp, _vp, _vp]),
+    "mpk_last_kernel": (C.c_char_p, [_vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libmpk.so (once) and bind every declared symbol; raise MPKLibraryError if that is impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MPKLibraryError(
+            f"{LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(hipcc --offload-arch=gfx950). fancy_gym_amd has no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the machine
+        raise MPKLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise MPKLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mpk_abi_version() != MPK_ABI_VERSION:
+        raise MPKLibraryError("libmpk.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    msg = load().mpk_last_error()
+    return msg.decode() if msg else ""
+
+
+def check(rc: int) -> int:
+    """Map a negative return code to the exception class the reference raises for the same condition."""
+    if rc >= 0:
+        return rc
+    msg = last_error()
+    if rc == MPK_EINVAL:
+        raise ValueError(msg)
+    if rc == MPK_ENOTIMPL:
+        raise NotImplementedError(msg)
+    if rc == MPK_ERANGE:
+        raise RuntimeError(msg)
+    raise MPKLibraryError(f"libmpk error {rc}: {msg}")

@@ -1,0 +1,620 @@
+// Host side of libmpk.so: configuration checks, float64 table pre-compute (construction time), device buffers,
+// and the extern "C" entry points declared in include/mpk.h.  Kernels live in mpk_kernels.hip.
+//
+// The table pre-compute follows the published ProDMP / RBF mathematics as restated in SURVEY.md Appendix A.4
+// (the reference delegates it to mp_pytorch's ProDMPBasisGenerator at construction:
+// fancy_gym/black_box/factory/basis_generator_factory.py:14-17).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <mutex>
+
+#include "mpk_internal.h"
+
+namespace mpk {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+#define MPK_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            set_error(std::string(#call) + ": " + hipGetErrorString(e_));                      \
+            return MPK_EHIP;                                                                   \
+        }                                                                                      \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------------------
+// times
+// ------------------------------------------------------------------------------------------------------------
+int steps_for(double duration, double dt) {
+    // python round(duration / dt): half-to-even on the double quotient
+    return (int)std::nearbyint(duration / dt);
+}
+
+std::vector<float> build_times(double duration, int T) {
+    // linspace(0, duration, T+1)[1:] in fp32: step = (end-start)/(steps-1); i < steps/2 -> start + step*i,
+    // else end - step*(steps-1-i); one rounding per op (this file is compiled with -ffp-contract=off).
+    const int steps = T + 1;
+    std::vector<float> out(T);
+    const float start = 0.f, end = (float)duration;
+    const float step = (end - start) / (float)(steps - 1);
+    for (int i = 1; i < steps; ++i) {
+        volatile float prod;
+        float v;
+        if (i < steps / 2) {
+            prod = step * (float)i;
+            v = start + prod;
+        } else {
+            prod = step * (float)(steps - 1 - i);
+            v = end - prod;
+        }
+        out[i - 1] = v;
+    }
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// phase helpers (float64, construction time)
+// ------------------------------------------------------------------------------------------------------------
+static double unbound_phase(const mpk_config& c, double t) {
+    const double s = (t - c.delay) / c.tau;
+    return c.phase_type == MPK_PHASE_LINEAR ? s : std::exp(-c.alpha_phase * s);
+}
+static double bound_phase(const mpk_config& c, double t) {
+    double s = (t - c.delay) / c.tau;
+    if (c.phase_type == MPK_PHASE_LINEAR) return std::fmin(std::fmax(s, 0.0), 1.0);
+    return std::exp(-c.alpha_phase * std::fmax(s, 0.0));
+}
+
+void build_rbf(const mpk_config& c, HostTables& t) {
+    int n = c.num_basis;
+    int outside = c.num_basis_outside;
+    if (c.basis_type == MPK_BASIS_ZERO_RBF) {
+        n += c.num_basis_zero_start + c.num_basis_zero_goal;
+        outside = 0;
+    }
+    t.n_total = n;
+    t.centers.assign(n, 0.0);
+    t.bw.assign(n, 0.0);
+    const double dist = n > 1 ? c.tau / (double)(n - 2 * outside - 1) : c.tau;
+    const double lo = -outside * dist + c.delay;
+    const double hi = c.tau + outside * dist + c.delay;
+    for (int k = 0; k < n; ++k) {
+        // numpy.linspace: start + k*step, last point pinned to the end value
+        double ct = n > 1 ? lo + k * ((hi - lo) / (double)(n - 1)) : lo;
+        if (n > 1 && k == n - 1) ct = hi;
+        t.centers[k] = unbound_phase(c, ct);
+    }
+    for (int k = 0; k < n; ++k) {
+        double gap = 1.0;  // single basis: no gap exists upstream; one phase unit (documented (?) in DESIGN.md)
+        if (n > 1) gap = k < n - 1 ? t.centers[k + 1] - t.centers[k] : t.centers[n - 1] - t.centers[n - 2];
+        t.bw[k] = c.basis_bandwidth_factor / (gap * gap);
+    }
+}
+
+static void rbf_row(const HostTables& t, double x, int n_used, int first, double* out) {
+    // normalised over ALL n_total RBFs, returns columns [first, first + n_used)
+    double sum = 0.0;
+    std::vector<double> b(t.n_total);
+    for (int k = 0; k < t.n_total; ++k) {
+        const double dx = x - t.centers[k];
+        b[k] = std::exp(-(dx * dx * t.bw[k]) / 2.0);
+        sum += b[k];
+    }
+    for (int k = 0; k < n_used; ++k) out[k] = t.n_total > 1 ? b[first + k] / sum : b[first + k];
+}
+
+void build_prodmp(const mpk_config& c, HostTables& t) {
+    build_rbf(c, t);  // plain RBFs over the exp phase
+    const int nb = c.num_basis, K = nb + 1;
+    const float sdt = (float)c.basis_dt / (float)c.tau;  // fp32 division, as the reference's fp32 tensor op
+    t.scaled_dt = sdt;
+    const int per_unit = (int)std::nearbyint(1.0 / (double)sdt);
+    const int N = c.pre_compute_length_factor * per_unit + 1;
+    t.n_pc = N;
+    t.y1.resize(N); t.y2.resize(N); t.dy1.resize(N); t.dy2.resize(N);
+    t.pos_basis.assign((size_t)N * K, 0.0);
+    t.vel_basis.assign((size_t)N * K, 0.0);
+    t.scale.assign(K, 0.0);
+    const double alpha = c.basis_alpha, half = 0.5 * alpha;
+    const double L = (double)c.pre_compute_length_factor;
+    const double step = L / (double)(N - 1);
+    std::vector<double> s(N), dp1((size_t)N * nb), dp2((size_t)N * nb), phi(nb);
+    std::vector<double> p1(nb, 0.0), p2(nb, 0.0);
+    for (int i = 0; i < N; ++i) {
+        s[i] = (i == N - 1) ? L : i * step;
+        const double e = std::exp(half * s[i]);
+        t.y1[i] = std::exp(-half * s[i]);
+        t.y2[i] = s[i] * t.y1[i];
+        t.dy1[i] = -half * t.y1[i];
+        t.dy2[i] = -half * t.y2[i] + t.y1[i];
+        const double pc_time = s[i] * c.tau + c.delay;
+        const double x = bound_phase(c, pc_time);
+        rbf_row(t, x, nb, 0, phi.data());
+        for (int k = 0; k < nb; ++k) {
+            dp1[(size_t)i * nb + k] = ((s[i] * e) * x) * phi[k];
+            dp2[(size_t)i * nb + k] = (e * x) * phi[k];
+        }
+        if (i > 0) {
+            const double ds = s[i] - s[i - 1];
+            for (int k = 0; k < nb; ++k) {  // cumulative trapezoid
+                p1[k] += ds * (dp1[(size_t)i * nb + k] + dp1[(size_t)(i - 1) * nb + k]) / 2.0;
+                p2[k] += ds * (dp2[(size_t)i * nb + k] + dp2[(size_t)(i - 1) * nb + k]) / 2.0;
+            }
+        }
+        const double q1 = (half * s[i] - 1.0) * e + 1.0;
+        const double q2 = half * (e - 1.0);
+        for (int k = 0; k < nb; ++k) {
+            t.pos_basis[(size_t)i * K + k] = p2[k] * t.y2[i] - p1[k] * t.y1[i];
+            t.vel_basis[(size_t)i * K + k] = p2[k] * t.dy2[i] - p1[k] * t.dy1[i];
+        }
+        t.pos_basis[(size_t)i * K + nb] = q2 * t.y2[i] - q1 * t.y1[i];
+        t.vel_basis[(size_t)i * K + nb] = q2 * t.dy2[i] - q1 * t.dy1[i];
+    }
+    for (int k = 0; k < K; ++k) {
+        double m = -std::numeric_limits<double>::infinity();
+        for (int i = 0; i < N; ++i) m = std::fmax(m, t.pos_basis[(size_t)i * K + k]);
+        t.scale[k] = 1.0 / m;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// handle
+// ------------------------------------------------------------------------------------------------------------
+struct CacheEntry {
+    bool valid = false;
+    uint32_t key = 0;  // bit pattern of the fp32 init_time
+    int T = 0;
+    SharedTables st;
+    uint64_t stamp = 0;
+};
+
+struct Handle {
+    mpk_config cfg{};
+    HostTables tab;
+    DevCfg dev{};
+    int num_cu = 256;
+    double duration = 0.0, dt = 0.0;
+    std::vector<float> times;
+    double* d_tab = nullptr;
+    float* d_times = nullptr;
+    int32_t* d_flag = nullptr;   // range-error flag written by kernels
+    int32_t* d_idx = nullptr;    // scratch for mpk_prodmp_indices
+    int idx_cap = 0;
+    static constexpr int kCache = 8;
+    CacheEntry cache[kCache];
+    uint64_t stamp = 0;
+    const char* last_kernel = "";
+};
+
+static int check_cfg(const mpk_config& c) {
+    if (c.abi_version != MPK_ABI_VERSION) { set_error("mpk_config.abi_version mismatch"); return MPK_EINVAL; }
+    if (c.mp_type < 0 || c.mp_type > 2) { set_error("unknown mp_type"); return MPK_EINVAL; }
+    if (c.phase_type < 0 || c.phase_type > 1) { set_error("unknown phase_type"); return MPK_EINVAL; }
+    if (c.basis_type < 0 || c.basis_type > 2) { set_error("unknown basis_type"); return MPK_EINVAL; }
+    if (c.num_dof < 0) { set_error("num_dof must be >= 0"); return MPK_EINVAL; }
+    if (c.num_basis < 1) { set_error("num_basis must be >= 1 (basis length 0 is not implemented upstream)"); return MPK_EINVAL; }
+    if (c.basis_type == MPK_BASIS_PRODMP && c.phase_type != MPK_PHASE_EXP) {
+        // factory/basis_generator_factory.py:16 asserts this
+        set_error("prodmp basis requires the exp phase generator");
+        return MPK_EINVAL;
+    }
+    if ((c.mp_type == MPK_MP_PRODMP) != (c.basis_type == MPK_BASIS_PRODMP)) {
+        // factory/trajectory_generator_factory.py:17 asserts the prodmp pairing
+        set_error("prodmp trajectory generator and prodmp basis generator must be used together");
+        return MPK_EINVAL;
+    }
+    if (!(c.tau > 0.0)) { set_error("tau must be > 0"); return MPK_EINVAL; }
+    if (!(c.dt > 0.0) || !(c.duration > 0.0)) { set_error("dt and duration must be > 0"); return MPK_EINVAL; }
+    if (c.basis_type == MPK_BASIS_PRODMP && (c.pre_compute_length_factor < 1 || c.pre_compute_length_factor > 6)) {
+        set_error("pre_compute_length_factor must be in [1, 6]");
+        return MPK_EINVAL;
+    }
+    if (c.basis_type == MPK_BASIS_RBF && c.num_basis > 1 && c.num_basis - 2 * c.num_basis_outside - 1 <= 0) {
+        set_error("num_basis_outside too large for num_basis");
+        return MPK_EINVAL;
+    }
+    if (c.mp_type == MPK_MP_PRODMP && c.disable_goal && c.disable_weights) {
+        set_error("disable_goal and disable_weights cannot both be set");
+        return MPK_EINVAL;
+    }
+    return MPK_OK;
+}
+
+static int local_per_dof(const mpk_config& c) {
+    switch (c.mp_type) {
+        case MPK_MP_PROMP: return c.num_basis;
+        case MPK_MP_DMP: return c.num_basis + 1;
+        default: return (c.disable_weights ? 0 : c.num_basis) + (c.disable_goal ? 0 : 1);
+    }
+}
+
+static void fill_devcfg(Handle* h) {
+    const mpk_config& c = h->cfg;
+    DevCfg& d = h->dev;
+    d = DevCfg{};
+    d.mp_type = c.mp_type; d.phase_type = c.phase_type; d.basis_type = c.basis_type;
+    d.D = c.num_dof; d.nb = c.num_basis; d.n_total = h->tab.n_total;
+    d.zs = c.basis_type == MPK_BASIS_ZERO_RBF ? c.num_basis_zero_start : 0;
+    const bool zero_pad = c.basis_type == MPK_BASIS_ZERO_RBF;
+    if (c.mp_type == MPK_MP_PRODMP) d.KT = c.num_basis + 3;          // weights, goal, y_b, v_b
+    else if (c.mp_type == MPK_MP_PROMP) d.KT = c.num_basis + (zero_pad ? 1 : 0);  // weights (+ init_pos)
+    else d.KT = c.num_basis;                                         // dmp forcing
+    d.KP = (d.KT + 3) / 4 * 4;
+    d.Kloc = local_per_dof(c);
+    d.off = (c.learn_tau ? 1 : 0) + (c.learn_delay ? 1 : 0);
+    d.P = d.off + d.D * d.Kloc;
+    d.T = steps_for(h->duration, h->dt);
+    d.learn_tau = c.learn_tau; d.learn_delay = c.learn_delay;
+    d.relative_goal = c.relative_goal; d.disable_goal = c.disable_goal; d.disable_weights = c.disable_weights;
+    d.n_pc = h->tab.n_pc; d.len_factor = c.pre_compute_length_factor;
+    d.tau = (float)c.tau; d.delay = (float)c.delay; d.alpha_phase = (float)c.alpha_phase;
+    d.scaled_dt = h->tab.scaled_dt;
+    d.tau_lo = (float)c.tau_bound[0]; d.tau_hi = (float)c.tau_bound[1];
+    d.delay_lo = (float)c.delay_bound[0]; d.delay_hi = (float)c.delay_bound[1];
+    d.ws = (float)c.weights_scale; d.gs = (float)c.goal_scale;
+    d.dmp_alpha = (float)c.dmp_alpha; d.dmp_beta = (float)(c.dmp_alpha / 4.0);
+    for (int k = 0; k <= kMaxKP; ++k) d.scale[k] = 0.f;
+    if (c.mp_type == MPK_MP_PRODMP && c.num_basis + 1 <= kMaxKP + 1) {
+        for (int k = 0; k <= c.num_basis; ++k) {
+            float s = k < c.num_basis ? (float)c.weights_scale : (float)c.goal_scale;
+            if (c.auto_scale_basis) s = (float)h->tab.scale[k] * s;  // fp32 product as the reference's tensor op
+            d.scale[k] = s;
+        }
+    }
+    d.tab = h->d_tab;
+    d.base_times = h->d_times;
+}
+
+static int upload_times(Handle* h) {
+    const int T = steps_for(h->duration, h->dt);
+    if (T < 1) { set_error("duration/dt gives no time steps"); return MPK_EINVAL; }
+    h->times = build_times(h->duration, T);
+    if (h->d_times) { (void)hipFree(h->d_times); h->d_times = nullptr; }
+    MPK_HIP(hipMalloc((void**)&h->d_times, sizeof(float) * T));
+    MPK_HIP(hipMemcpy(h->d_times, h->times.data(), sizeof(float) * T, hipMemcpyHostToDevice));
+    for (auto& e : h->cache) e.valid = false;
+    return MPK_OK;
+}
+
+static void free_handle(Handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    for (auto& e : h->cache) {
+        if (e.st.A) (void)hipFree(e.st.A);
+        if (e.st.aux) (void)hipFree(e.st.aux);
+    }
+    if (h->d_tab) (void)hipFree(h->d_tab);
+    if (h->d_times) (void)hipFree(h->d_times);
+    if (h->d_flag) (void)hipFree(h->d_flag);
+    if (h->d_idx) (void)hipFree(h->d_idx);
+    delete h;
+}
+
+static bool shared_phase(const Handle* h, const float* init_time) {
+    return !h->cfg.learn_tau && !h->cfg.learn_delay && init_time == nullptr;
+}
+
+static bool mfma_capable(const Handle* h) {
+    return h->dev.D >= 1 && h->dev.D <= kMaxD && h->dev.KP <= kMaxKP;
+}
+
+// returns the cached (or freshly built, enqueued on `stream`) shared tables for init_time
+static int get_shared(Handle* h, float init_time, void* stream, SharedTables* out) {
+    uint32_t key;
+    std::memcpy(&key, &init_time, 4);
+    const int T = h->dev.T;
+    ++h->stamp;
+    for (auto& e : h->cache) {
+        if (e.valid && e.key == key && e.T == T) { e.stamp = h->stamp; *out = e.st; return MPK_OK; }
+    }
+    CacheEntry* victim = &h->cache[0];
+    for (auto& e : h->cache) {
+        if (!e.valid) { victim = &e; break; }
+        if (e.stamp < victim->stamp) victim = &e;
+    }
+    // ProDMP range check on the host, with the same fp32 recipe the device uses (reference: RuntimeError)
+    if (h->cfg.mp_type == MPK_MP_PRODMP) {
+        const float tmax = h->times[T - 1] + init_time;
+        const float s = std::fmax((tmax - h->dev.delay) / h->dev.tau, 0.f);
+        if (s > (float)h->dev.len_factor) {
+            set_error("Time is beyond the pre-computation range. Set larger pre-computation factor");
+            return MPK_ERANGE;
+        }
+    }
+    int TS = 0, n_out = 0;
+    const size_t nf = shared_tables_floats(h->dev, &TS, &n_out);
+    if (victim->st.A && (victim->st.TS != TS || victim->st.n_out != n_out)) {
+        // a cached table may still be in use by an in-flight kernel on the caller's stream: wait before freeing
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        (void)hipFree(victim->st.A); (void)hipFree(victim->st.aux);
+        victim->st = SharedTables{};
+    }
+    if (!victim->st.A) {
+        MPK_HIP(hipMalloc((void**)&victim->st.A, nf * sizeof(float)));
+        MPK_HIP(hipMalloc((void**)&victim->st.aux, (size_t)TS * sizeof(float)));
+        victim->st.TS = TS; victim->st.n_out = n_out;
+    }
+    int rc = launch_build_shared(h->dev, init_time, victim->st, nullptr, h->d_flag, stream);
+    if (rc != MPK_OK) return rc;
+    victim->valid = true; victim->key = key; victim->T = T; victim->stamp = h->stamp;
+    *out = victim->st;
+    return MPK_OK;
+}
+
+static int fill_rollout(const Handle* h, const mpk_rollout_cfg* rc, RolloutDev* out) {
+    if (!rc) { set_error("rollout cfg is NULL"); return MPK_EINVAL; }
+    const int D = h->dev.D;
+    if (D > kMaxDofArgs) { set_error("num_dof too large for the rollout kernels"); return MPK_EINVAL; }
+    if (rc->controller_type < 0 || rc->controller_type > 2) { set_error("unknown controller_type"); return MPK_EINVAL; }
+    if (rc->plant_type < 0 || rc->plant_type > 1) { set_error("unknown plant_type"); return MPK_EINVAL; }
+    if (!rc->act_low || !rc->act_high) { set_error("act_low/act_high are required"); return MPK_EINVAL; }
+    if (rc->controller_type == MPK_CTRL_MOTOR && (!rc->p_gains || !rc->d_gains)) {
+        set_error("motor controller needs p_gains and d_gains");
+        return MPK_EINVAL;
+    }
+    out->controller_type = rc->controller_type; out->plant_type = rc->plant_type; out->dt = rc->dt;
+    for (int d = 0; d < D; ++d) {
+        out->pg[d] = rc->p_gains ? rc->p_gains[d] : 0.0;
+        out->dg[d] = rc->d_gains ? rc->d_gains[d] : 0.0;
+        out->lo[d] = rc->act_low[d]; out->hi[d] = rc->act_high[d];
+    }
+    return MPK_OK;
+}
+
+}  // namespace mpk
+
+using namespace mpk;
+
+// ============================================================================================================
+// extern "C"
+// ============================================================================================================
+extern "C" {
+
+const char* mpk_last_error(void) { return g_err.c_str(); }
+int mpk_abi_version(void) { return MPK_ABI_VERSION; }
+
+int mpk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mpk_create(const mpk_config* cfg, mpk_handle* out) {
+    if (!cfg || !out) { set_error("NULL argument"); return MPK_EINVAL; }
+    int rc = check_cfg(*cfg);
+    if (rc != MPK_OK) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device visible: libmpk has no CPU fallback");
+        return MPK_ENODEV;
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) { set_error("device ordinal out of range"); return MPK_EINVAL; }
+    MPK_HIP(hipSetDevice(cfg->device));
+    Handle* h = new Handle();
+    h->cfg = *cfg;
+    {   // the reference holds these constants as fp32 tensors / mixes them into fp32 tensor ops: quantise once so the
+        // float64 table build sees exactly the values the reference's arithmetic sees
+        mpk_config& q = h->cfg;
+        auto f32 = [](double v) { return (double)(float)v; };
+        q.tau = f32(q.tau); q.delay = f32(q.delay); q.alpha_phase = f32(q.alpha_phase);
+        q.basis_bandwidth_factor = f32(q.basis_bandwidth_factor); q.basis_alpha = f32(q.basis_alpha);
+        q.basis_dt = f32(q.basis_dt); q.weights_scale = f32(q.weights_scale); q.goal_scale = f32(q.goal_scale);
+        q.dmp_alpha = f32(q.dmp_alpha);
+    }
+    cfg = &h->cfg;
+    h->duration = cfg->duration; h->dt = cfg->dt;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) h->num_cu = prop.multiProcessorCount;
+    // tables
+    std::vector<double> packed;
+    if (cfg->basis_type == MPK_BASIS_PRODMP) {
+        build_prodmp(*cfg, h->tab);
+        const HostTables& t = h->tab;
+        packed.reserve((size_t)t.n_pc * (4 + 2 * (cfg->num_basis + 1)));
+        packed.insert(packed.end(), t.y1.begin(), t.y1.end());
+        packed.insert(packed.end(), t.y2.begin(), t.y2.end());
+        packed.insert(packed.end(), t.dy1.begin(), t.dy1.end());
+        packed.insert(packed.end(), t.dy2.begin(), t.dy2.end());
+        packed.insert(packed.end(), t.pos_basis.begin(), t.pos_basis.end());
+        packed.insert(packed.end(), t.vel_basis.begin(), t.vel_basis.end());
+    } else {
+        build_rbf(*cfg, h->tab);
+        packed.insert(packed.end(), h->tab.centers.begin(), h->tab.centers.end());
+        packed.insert(packed.end(), h->tab.bw.begin(), h->tab.bw.end());
+    }
+    auto fail = [&](int code) { free_handle(h); return code; };
+    if (hipMalloc((void**)&h->d_tab, packed.size() * sizeof(double)) != hipSuccess) { set_error("hipMalloc(tables) failed"); return fail(MPK_EHIP); }
+    if (hipMemcpy(h->d_tab, packed.data(), packed.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { set_error("hipMemcpy(tables) failed"); return fail(MPK_EHIP); }
+    if (hipMalloc((void**)&h->d_flag, sizeof(int32_t)) != hipSuccess) { set_error("hipMalloc(flag) failed"); return fail(MPK_EHIP); }
+    if (hipMemset(h->d_flag, 0, sizeof(int32_t)) != hipSuccess) { set_error("hipMemset(flag) failed"); return fail(MPK_EHIP); }
+    rc = upload_times(h);
+    if (rc != MPK_OK) return fail(rc);
+    fill_devcfg(h);
+    *out = reinterpret_cast<mpk_handle>(h);
+    return MPK_OK;
+}
+
+void mpk_destroy(mpk_handle hh) { free_handle(reinterpret_cast<Handle*>(hh)); }
+
+int mpk_num_params(mpk_handle hh) {
+    if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
+    return reinterpret_cast<Handle*>(hh)->dev.P;
+}
+int mpk_num_steps(mpk_handle hh) {
+    if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
+    return reinterpret_cast<Handle*>(hh)->dev.T;
+}
+int mpk_num_dof(mpk_handle hh) {
+    if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
+    return reinterpret_cast<Handle*>(hh)->dev.D;
+}
+
+int mpk_params_bounds(mpk_handle hh, float* low, float* high) {
+    if (!hh || !low || !high) { set_error("NULL argument"); return MPK_EINVAL; }
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    int i = 0;
+    if (h->cfg.learn_tau) { low[i] = (float)h->cfg.tau_bound[0]; high[i] = (float)h->cfg.tau_bound[1]; ++i; }
+    if (h->cfg.learn_delay) { low[i] = (float)h->cfg.delay_bound[0]; high[i] = (float)h->cfg.delay_bound[1]; ++i; }
+    for (; i < h->dev.P; ++i) { low[i] = -std::numeric_limits<float>::infinity(); high[i] = std::numeric_limits<float>::infinity(); }
+    return MPK_OK;
+}
+
+int mpk_set_duration(mpk_handle hh, double duration, double dt) {
+    if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (!(duration > 0.0) || !(dt > 0.0)) { set_error("dt and duration must be > 0"); return MPK_EINVAL; }
+    if (duration == h->duration && dt == h->dt) return MPK_OK;
+    MPK_HIP(hipSetDevice(h->cfg.device));
+    // tables of the previous grid may be in flight
+    MPK_HIP(hipDeviceSynchronize());
+    h->duration = duration; h->dt = dt;
+    int rc = upload_times(h);
+    if (rc != MPK_OK) return rc;
+    fill_devcfg(h);
+    return MPK_OK;
+}
+
+int mpk_times(mpk_handle hh, float* times) {
+    if (!hh || !times) { set_error("NULL argument"); return MPK_EINVAL; }
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    std::memcpy(times, h->times.data(), sizeof(float) * h->times.size());
+    return MPK_OK;
+}
+
+static int traj_common(Handle* h, const float* params, const float* init_pos, const float* init_vel,
+                       const float* init_time, double init_time_shared, float* pos, float* vel, float* actions,
+                       const RolloutDev* rd, const double* c_pos, const double* c_vel, int32_t B, void* stream) {
+    if (!params || !init_pos || !init_vel || !pos || !vel) { set_error("NULL buffer"); return MPK_EINVAL; }
+    if (B < 0) { set_error("B must be >= 0"); return MPK_EINVAL; }
+    if (B == 0 || h->dev.D == 0) return MPK_OK;
+    MPK_HIP(hipSetDevice(h->cfg.device));
+    if (shared_phase(h, init_time) && mfma_capable(h)) {
+        SharedTables st;
+        int rc = get_shared(h, (float)init_time_shared, stream, &st);
+        if (rc != MPK_OK) return rc;
+        return launch_traj_shared(h->dev, st, params, init_pos, init_vel, pos, vel, actions, rd, c_pos, c_vel, B,
+                                  h->num_cu, stream, &h->last_kernel);
+    }
+    if (actions) { set_error("fused actions need a shared-phase configuration with D <= 16 and <= 16 basis columns"); return MPK_EINVAL; }
+    return launch_traj_rows(h->dev, params, init_pos, init_vel, init_time, (float)init_time_shared, pos, vel,
+                            h->d_flag, B, h->num_cu, stream, &h->last_kernel);
+}
+
+int mpk_trajectory(mpk_handle hh, const float* params, const float* init_pos, const float* init_vel,
+                   const float* init_time, double init_time_shared, float* pos, float* vel, int32_t B,
+                   void* stream) {
+    if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
+    return traj_common(reinterpret_cast<Handle*>(hh), params, init_pos, init_vel, init_time, init_time_shared,
+                       pos, vel, nullptr, nullptr, nullptr, nullptr, B, stream);
+}
+
+int mpk_trajectory_actions(mpk_handle hh, const float* params, const float* init_pos, const float* init_vel,
+                           double init_time_shared, const mpk_rollout_cfg* rc, const double* c_pos,
+                           const double* c_vel, float* pos, float* vel, float* actions, int32_t B, void* stream) {
+    if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (!actions || !c_pos || !c_vel) { set_error("NULL buffer"); return MPK_EINVAL; }
+    if (h->cfg.mp_type == MPK_MP_DMP) { set_error("fused actions are not available for dmp"); return MPK_EINVAL; }
+    RolloutDev rd;
+    int r = fill_rollout(h, rc, &rd);
+    if (r != MPK_OK) return r;
+    if (rd.plant_type != MPK_PLANT_STATIC) { set_error("fused actions need MPK_PLANT_STATIC; use mpk_pd_rollout"); return MPK_EINVAL; }
+    return traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, actions, &rd, c_pos,
+                       c_vel, B, stream);
+}
+
+int mpk_pd_rollout(mpk_handle hh, const mpk_rollout_cfg* rc, const float* des_pos, const float* des_vel, double* q,
+                   double* qd, const int32_t* n_steps, float* actions, int32_t B, int32_t T, void* stream) {
+    if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (!des_pos || !des_vel || !q || !qd) { set_error("NULL buffer"); return MPK_EINVAL; }
+    if (B < 0 || T < 0) { set_error("B and T must be >= 0"); return MPK_EINVAL; }
+    RolloutDev rd;
+    int r = fill_rollout(h, rc, &rd);
+    if (r != MPK_OK) return r;
+    if (B == 0 || T == 0 || h->dev.D == 0) return MPK_OK;
+    MPK_HIP(hipSetDevice(h->cfg.device));
+    return launch_pd_rollout(rd, h->dev.D, des_pos, des_vel, q, qd, n_steps, actions, B, T, stream);
+}
+
+int mpk_replan_advance(mpk_handle hh, int32_t* traj_steps, int32_t* plan_steps, int32_t* seg_len, uint8_t* done,
+                       int32_t every, int32_t max_planning_times, int32_t horizon, int32_t T, int32_t B,
+                       void* stream) {
+    if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (!traj_steps || !plan_steps || !seg_len || !done) { set_error("NULL buffer"); return MPK_EINVAL; }
+    if (every < 1 || horizon < 1 || T < 1 || B < 0) { set_error("every, horizon, T must be >= 1"); return MPK_EINVAL; }
+    if (B == 0) return MPK_OK;
+    MPK_HIP(hipSetDevice(h->cfg.device));
+    return launch_replan_advance(traj_steps, plan_steps, seg_len, done, every, max_planning_times, horizon, T, B,
+                                 stream);
+}
+
+int mpk_traj_validity(mpk_handle hh, const float* pos, const float* params, const double* pos_low,
+                      const double* pos_high, int32_t check_tau_delay, const double tau_bound[2],
+                      const double delay_bound[2], uint8_t* valid, int32_t B, int32_t T, void* stream) {
+    if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (!pos || !pos_low || !pos_high || !valid) { set_error("NULL buffer"); return MPK_EINVAL; }
+    if (check_tau_delay && (!params || !tau_bound || !delay_bound)) { set_error("tau/delay check needs params and bounds"); return MPK_EINVAL; }
+    if (h->dev.D > kMaxDofArgs) { set_error("num_dof too large"); return MPK_EINVAL; }
+    if (B <= 0 || T <= 0) return MPK_OK;
+    MPK_HIP(hipSetDevice(h->cfg.device));
+    return launch_validity(pos, params, h->dev.P, h->dev.D, pos_low, pos_high, check_tau_delay, tau_bound,
+                           delay_bound, valid, B, T, stream);
+}
+
+int mpk_prodmp_tables(mpk_handle hh, double* y1, double* y2, double* dy1, double* dy2, double* pos_basis,
+                      double* vel_basis, double* scale) {
+    if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (h->cfg.basis_type != MPK_BASIS_PRODMP) { set_error("not a prodmp handle"); return MPK_EINVAL; }
+    const HostTables& t = h->tab;
+    auto cp = [](double* dst, const std::vector<double>& src) { if (dst) std::memcpy(dst, src.data(), src.size() * sizeof(double)); };
+    cp(y1, t.y1); cp(y2, t.y2); cp(dy1, t.dy1); cp(dy2, t.dy2);
+    cp(pos_basis, t.pos_basis); cp(vel_basis, t.vel_basis); cp(scale, t.scale);
+    return t.n_pc;
+}
+
+int mpk_prodmp_indices(mpk_handle hh, double init_time, int32_t* idx, int32_t* idx_init, void* stream) {
+    if (!hh || !idx || !idx_init) { set_error("NULL argument"); return MPK_EINVAL; }
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (h->cfg.mp_type != MPK_MP_PRODMP) { set_error("not a prodmp handle"); return MPK_EINVAL; }
+    if (h->cfg.learn_tau || h->cfg.learn_delay) { set_error("indices are per-episode when tau/delay are learned"); return MPK_EINVAL; }
+    if (!mfma_capable(h)) { set_error("configuration exceeds the shared-table kernel limits"); return MPK_EINVAL; }
+    MPK_HIP(hipSetDevice(h->cfg.device));
+    const int T = h->dev.T;
+    if (h->idx_cap < T + 1) {
+        if (h->d_idx) (void)hipFree(h->d_idx);
+        MPK_HIP(hipMalloc((void**)&h->d_idx, sizeof(int32_t) * (T + 1)));
+        h->idx_cap = T + 1;
+    }
+    int TS = 0, n_out = 0;
+    const size_t nf = shared_tables_floats(h->dev, &TS, &n_out);
+    SharedTables st;
+    MPK_HIP(hipMalloc((void**)&st.A, nf * sizeof(float)));
+    MPK_HIP(hipMalloc((void**)&st.aux, (size_t)TS * sizeof(float)));
+    st.TS = TS; st.n_out = n_out;
+    int rc = launch_build_shared(h->dev, (float)init_time, st, h->d_idx, h->d_flag, stream);
+    if (rc == MPK_OK) {
+        hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+        if (e == hipSuccess) e = hipMemcpy(idx, h->d_idx, sizeof(int32_t) * T, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(idx_init, h->d_idx + T, sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { set_error(hipGetErrorString(e)); rc = MPK_EHIP; }
+    }
+    (void)hipFree(st.A); (void)hipFree(st.aux);
+    return rc;
+}
+
+const char* mpk_last_kernel(mpk_handle hh) {
+    if (!hh) return "";
+    return reinterpret_cast<Handle*>(hh)->last_kernel;
+}
+
+}  // extern "C"

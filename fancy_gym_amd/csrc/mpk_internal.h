@@ -1,0 +1,87 @@
+// Internal declarations shared by the host side (mpk_host.cpp) and the gfx950 kernels (mpk_kernels.hip).
+// Not part of the public ABI (that is include/mpk.h).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "mpk.h"
+
+namespace mpk {
+
+constexpr int kMaxKP = 16;     // padded contraction length supported by the MFMA kernel (multiple of 4)
+constexpr int kMaxD = 16;      // DoF supported by the MFMA kernel (one 16-column tile per episode group)
+constexpr int kMaxDofArgs = 32;  // per-DoF constants carried in kernel arguments
+
+// ---- host-side float64 tables (construction time) ------------------------------------------------------------
+struct HostTables {
+    // normalised RBFs: centres in phase space and bandwidths (n_total entries incl. zero padding)
+    int n_total = 0;
+    std::vector<double> centers, bw;
+    // ProDMP pre-computed grid
+    int n_pc = 0;
+    float scaled_dt = 0.f;  // fp32: basis_dt / tau0, used bit-exactly by times_to_indices
+    std::vector<double> y1, y2, dy1, dy2, pos_basis, vel_basis, scale;  // pos/vel_basis: [n_pc, nb+1]
+};
+
+void build_rbf(const mpk_config& c, HostTables& t);
+void build_prodmp(const mpk_config& c, HostTables& t);
+// fp32 time grid linspace(0, duration, T+1)[1:] following torch's symmetric scalar recipe
+std::vector<float> build_times(double duration, int T);
+int steps_for(double duration, double dt);
+
+// ---- device-side configuration (kernel argument, by value) --------------------------------------------------
+struct DevCfg {
+    int mp_type, phase_type, basis_type;
+    int D, nb, n_total, zs;        // n_total: RBF count incl. zero padding; zs: zero-start offset
+    int KT, KP;                    // contraction length (learnable + boundary-condition columns), padded to 4
+    int P, Kloc, off;              // params per episode, local params per DoF, offset of the local block
+    int T;
+    int learn_tau, learn_delay, relative_goal, disable_goal, disable_weights;
+    int n_pc, len_factor;
+    float tau, delay, alpha_phase, scaled_dt;
+    float tau_lo, tau_hi, delay_lo, delay_hi;
+    float ws, gs, dmp_alpha, dmp_beta;
+    float scale[kMaxKP + 1];       // ProDMP weights_goal_scale per basis column (fp32)
+    // device tables
+    const double* tab;             // ProDMP: [y1|y2|dy1|dy2|pos_basis|vel_basis]; RBF: [centers|bw]
+    const float* base_times;       // [T]
+};
+
+struct RolloutDev {
+    int controller_type, plant_type;
+    double dt;
+    double pg[kMaxDofArgs], dg[kMaxDofArgs], lo[kMaxDofArgs], hi[kMaxDofArgs];
+};
+
+// shared-phase table workspace produced by k_build_shared and consumed by k_traj_shared
+struct SharedTables {
+    float* A = nullptr;    // [n_out][KP][TS]
+    float* aux = nullptr;  // [TS]
+    int TS = 0, n_out = 0;
+};
+
+struct Handle;  // defined in mpk_host.cpp
+
+// ---- launchers implemented in mpk_kernels.hip (all enqueue on `stream`, none synchronise) -------------------
+int launch_build_shared(const DevCfg& c, float init_time, const SharedTables& st, int32_t* idx_out,
+                        int32_t* range_flag, void* stream);
+int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* params, const float* init_pos,
+                       const float* init_vel, float* pos, float* vel, float* actions, const RolloutDev* rc,
+                       const double* c_pos, const double* c_vel, int B, int num_cu, void* stream,
+                       const char** kernel_name);
+int launch_traj_rows(const DevCfg& c, const float* params, const float* init_pos, const float* init_vel,
+                     const float* init_time, float init_time_shared, float* pos, float* vel, int32_t* range_flag,
+                     int B, int num_cu, void* stream, const char** kernel_name);
+int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const float* des_vel, double* q,
+                      double* qd, const int32_t* n_steps, float* actions, int B, int T, void* stream);
+int launch_replan_advance(int32_t* traj_steps, int32_t* plan_steps, int32_t* seg_len, uint8_t* done, int every,
+                          int max_planning_times, int horizon, int T, int B, void* stream);
+int launch_validity(const float* pos, const float* params, int P, int D, const double* lo, const double* hi,
+                    int check_td, const double* tb, const double* db, uint8_t* valid, int B, int T, void* stream);
+
+size_t shared_tables_floats(const DevCfg& c, int* TS, int* n_out);
+
+void set_error(const std::string& msg);
+
+}  // namespace mpk

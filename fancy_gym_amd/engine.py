@@ -1,0 +1,265 @@
+"""
+TrajectoryEngine -- thin, typed wrapper over one ``mpk_handle`` (include/mpk.h).
+
+It owns no arithmetic: every number it returns was produced by the HIP kernels in ``csrc/``.  PyTorch is used only for
+device memory and streams (tensors are passed to the C-ABI as raw device pointers).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (BASIS_TYPES, CTRL_TYPES, MP_TYPES, PHASE_TYPES, PLANT_TYPES, MPKLibraryError, mpk_config,
+                   mpk_rollout_cfg)
+
+_INF = float("inf")
+
+
+def _dptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _dvec(x, n: int):
+    """scalar or sequence -> (ctypes double[n], keep-alive)"""
+    a = np.ascontiguousarray(np.broadcast_to(np.asarray(x, dtype=np.float64), (n,)))
+    return a.ctypes.data_as(C.POINTER(C.c_double)), a
+
+
+class RolloutSpec:
+    """Controller + plant description for the device rollout (mpk_rollout_cfg)."""
+
+    def __init__(self, controller_type: str, num_dof: int, p_gains=1.0, d_gains=0.5, act_low=-_INF, act_high=_INF,
+                 plant: str = "static", dt: float = 0.0):
+        controller_type = controller_type.lower()
+        if controller_type not in CTRL_TYPES:
+            raise ValueError(f"controller type {controller_type!r} has no device implementation; "
+                             f"choose one of {list(CTRL_TYPES)}")
+        if plant not in PLANT_TYPES:
+            raise ValueError(f"unknown plant {plant!r}; choose one of {list(PLANT_TYPES)}")
+        self.controller_type, self.plant, self.num_dof, self.dt = controller_type, plant, num_dof, float(dt)
+        self._keep = []
+        self.c = mpk_rollout_cfg()
+        self.c.controller_type = CTRL_TYPES[controller_type]
+        self.c.plant_type = PLANT_TYPES[plant]
+        self.c.dt = float(dt)
+        for name, val in (("p_gains", p_gains), ("d_gains", d_gains), ("act_low", act_low), ("act_high", act_high)):
+            v = np.asarray(val, dtype=np.float64)
+            if v.ndim > 0 and v.shape != (num_dof,):
+                raise ValueError(f"Mismatch in dimension between {name} {v.shape} and the action dimension ({num_dof},)")
+            ptr, keep = _dvec(val, num_dof)
+            setattr(self.c, name, ptr)
+            self._keep.append(keep)
+
+
+class TrajectoryEngine:
+    """
+    One configured movement primitive on one GPU.  Constructor arguments mirror the kwarg groups the reference hands
+    to mp_pytorch (fancy_gym/utils/make_env_helpers.py:128-131; fancy_gym/envs/registry.py:62-129).
+    """
+
+    def __init__(self, mp_type: str, phase_type: str, basis_type: str, num_dof: int, num_basis: int, *, dt: float,
+                 duration: float, tau: float, delay: float = 0.0, alpha_phase: float = 3.0, learn_tau: bool = False,
+                 learn_delay: bool = False, tau_bound: Sequence[float] = (1e-5, _INF),
+                 delay_bound: Sequence[float] = (0.0, _INF), basis_bandwidth_factor: float = 3.0,
+                 num_basis_outside: int = 0, num_basis_zero_start: int = 0, num_basis_zero_goal: int = 0,
+                 basis_alpha: float = 25.0, basis_dt: float = 0.01, pre_compute_length_factor: int = 6,
+                 weights_scale: float = 1.0, goal_scale: float = 1.0, dmp_alpha: float = 25.0,
+                 auto_scale_basis: bool = False, relative_goal: bool = False, disable_goal: bool = False,
+                 disable_weights: bool = False, device: Union[int, torch.device, None] = None):
+        self._h = C.c_void_p()
+        self._lib = _lib.load()
+        for name, table, val in (("movement primitive", MP_TYPES, mp_type), ("phase generator", PHASE_TYPES, phase_type),
+                                 ("basis generator", BASIS_TYPES, basis_type)):
+            if val not in table:
+                raise ValueError(f"Specified {name} type {val} not supported, please choose one of {list(table)}.")
+        if device is None:
+            device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        if isinstance(device, torch.device):
+            device = device.index or 0
+        c = mpk_config()
+        c.abi_version = _lib.MPK_ABI_VERSION
+        c.device = int(device)
+        c.mp_type, c.phase_type, c.basis_type = MP_TYPES[mp_type], PHASE_TYPES[phase_type], BASIS_TYPES[basis_type]
+        c.num_dof, c.num_basis = int(num_dof), int(num_basis)
+        c.num_basis_outside = int(num_basis_outside)
+        c.num_basis_zero_start, c.num_basis_zero_goal = int(num_basis_zero_start), int(num_basis_zero_goal)
+        c.learn_tau, c.learn_delay = int(bool(learn_tau)), int(bool(learn_delay))
+        c.auto_scale_basis, c.relative_goal = int(bool(auto_scale_basis)), int(bool(relative_goal))
+        c.disable_goal, c.disable_weights = int(bool(disable_goal)), int(bool(disable_weights))
+        c.pre_compute_length_factor = int(pre_compute_length_factor)
+        c.tau, c.delay, c.alpha_phase = float(tau), float(delay), float(alpha_phase)
+        c.tau_bound[0], c.tau_bound[1] = float(tau_bound[0]), float(tau_bound[1])
+        c.delay_bound[0], c.delay_bound[1] = float(delay_bound[0]), float(delay_bound[1])
+        c.basis_bandwidth_factor, c.basis_alpha, c.basis_dt = float(basis_bandwidth_factor), float(basis_alpha), float(basis_dt)
+        c.weights_scale, c.goal_scale, c.dmp_alpha = float(weights_scale), float(goal_scale), float(dmp_alpha)
+        c.dt, c.duration = float(dt), float(duration)
+        self.config = c
+        self.mp_type, self.phase_type, self.basis_type = mp_type, phase_type, basis_type
+        self.device = torch.device("cuda", int(device))
+        _lib.check(self._lib.mpk_create(C.byref(c), C.byref(self._h)))
+        self.num_dof = self._lib.mpk_num_dof(self._h)
+        self.num_params = self._lib.mpk_num_params(self._h)
+
+    # ---- lifecycle ---------------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.mpk_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- shape / bounds ----------------------------------------------------------------------------------------
+    @property
+    def num_steps(self) -> int:
+        return self._lib.mpk_num_steps(self._h)
+
+    def params_bounds(self) -> np.ndarray:
+        """[2, P] float32 (traj_gen.get_params_bounds(), black_box_wrapper.py:122-127)."""
+        out = np.empty((2, self.num_params), np.float32)
+        _lib.check(self._lib.mpk_params_bounds(self._h, out[0].ctypes.data, out[1].ctypes.data))
+        return out
+
+    def set_duration(self, duration: float, dt: float):
+        _lib.check(self._lib.mpk_set_duration(self._h, float(duration), float(dt)))
+
+    def times(self) -> np.ndarray:
+        t = np.empty(self.num_steps, np.float32)
+        _lib.check(self._lib.mpk_times(self._h, t.ctypes.data))
+        return t
+
+    # ---- helpers -----------------------------------------------------------------------------------------------
+    def _f32(self, x, shape) -> torch.Tensor:
+        t = torch.as_tensor(x, dtype=torch.float32, device=self.device)
+        if t.shape != shape:
+            t = t.expand(shape)
+        return t.contiguous()
+
+    def _f64(self, x, shape) -> torch.Tensor:
+        t = torch.as_tensor(x, dtype=torch.float64, device=self.device)
+        if t.shape != shape:
+            t = t.expand(shape)
+        return t.contiguous()
+
+    @staticmethod
+    def _stream() -> int:
+        return torch.cuda.current_stream().cuda_stream
+
+    # ---- hot path ----------------------------------------------------------------------------------------------
+    def trajectory(self, params, init_pos, init_vel, init_time=0.0, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+                   ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """
+        params [B, P] -> (pos [B, T, D], vel [B, T, D]) float32 CUDA tensors.  ``init_time`` is a python float shared by
+        all episodes, or a tensor [B] of per-episode values.
+        """
+        params = torch.as_tensor(params, dtype=torch.float32, device=self.device)
+        if params.dim() == 1:
+            params = params[None]
+        params = params.contiguous()
+        B = params.shape[0]
+        if params.shape[1] != self.num_params:
+            raise ValueError(f"params has {params.shape[1]} entries per episode, expected {self.num_params}")
+        D, T = self.num_dof, self.num_steps
+        init_pos, init_vel = self._f32(init_pos, (B, D)), self._f32(init_vel, (B, D))
+        it_t = None
+        it_s = 0.0
+        if isinstance(init_time, torch.Tensor) and init_time.dim() > 0:
+            it_t = self._f32(init_time, (B,))
+        else:
+            it_s = float(init_time)
+        if out is None:
+            pos = torch.empty((B, T, D), dtype=torch.float32, device=self.device)
+            vel = torch.empty((B, T, D), dtype=torch.float32, device=self.device)
+        else:
+            pos, vel = out
+        _lib.check(self._lib.mpk_trajectory(self._h, params.data_ptr(), init_pos.data_ptr(), init_vel.data_ptr(),
+                                            _dptr(it_t), it_s, pos.data_ptr(), vel.data_ptr(), B, self._stream()))
+        return pos, vel
+
+    def trajectory_actions(self, params, init_pos, init_vel, spec: RolloutSpec, c_pos, c_vel, init_time: float = 0.0,
+                           out=None):
+        """Fused trajectory + open-loop controller actions for a state frozen over the plan (MPK_PLANT_STATIC)."""
+        params = torch.as_tensor(params, dtype=torch.float32, device=self.device)
+        if params.dim() == 1:
+            params = params[None]
+        params = params.contiguous()
+        B, D, T = params.shape[0], self.num_dof, self.num_steps
+        init_pos, init_vel = self._f32(init_pos, (B, D)), self._f32(init_vel, (B, D))
+        c_pos, c_vel = self._f64(c_pos, (B, D)), self._f64(c_vel, (B, D))
+        if out is None:
+            pos, vel, act = (torch.empty((B, T, D), dtype=torch.float32, device=self.device) for _ in range(3))
+        else:
+            pos, vel, act = out
+        _lib.check(self._lib.mpk_trajectory_actions(
+            self._h, params.data_ptr(), init_pos.data_ptr(), init_vel.data_ptr(), float(init_time), C.byref(spec.c),
+            c_pos.data_ptr(), c_vel.data_ptr(), pos.data_ptr(), vel.data_ptr(), act.data_ptr(), B, self._stream()))
+        return pos, vel, act
+
+    def pd_rollout(self, spec: RolloutSpec, des_pos: torch.Tensor, des_vel: torch.Tensor, q: torch.Tensor,
+                   qd: torch.Tensor, n_steps: Optional[torch.Tensor] = None, want_actions: bool = True):
+        """In-place closed-loop rollout; q, qd float64 [B, D] are updated to the state after the executed steps."""
+        B, T, D = des_pos.shape
+        assert des_pos.dtype == torch.float32 and des_vel.dtype == torch.float32
+        assert q.dtype == torch.float64 and qd.dtype == torch.float64 and q.is_contiguous() and qd.is_contiguous()
+        des_pos, des_vel = des_pos.contiguous(), des_vel.contiguous()
+        act = torch.empty((B, T, D), dtype=torch.float32, device=self.device) if want_actions else None
+        if n_steps is not None:
+            n_steps = n_steps.to(device=self.device, dtype=torch.int32).contiguous()
+        _lib.check(self._lib.mpk_pd_rollout(self._h, C.byref(spec.c), des_pos.data_ptr(), des_vel.data_ptr(),
+                                            q.data_ptr(), qd.data_ptr(), _dptr(n_steps), _dptr(act), B, T,
+                                            self._stream()))
+        return act
+
+    def replan_advance(self, traj_steps: torch.Tensor, plan_steps: torch.Tensor, done: torch.Tensor, every: int,
+                       max_planning_times: int, horizon: int) -> torch.Tensor:
+        """Integer replanning bookkeeping on device; returns seg_len int32 [B] and updates the state tensors in place."""
+        B = traj_steps.shape[0]
+        seg = torch.empty(B, dtype=torch.int32, device=self.device)
+        mpt = int(min(max_planning_times, 2 ** 31 - 1))
+        _lib.check(self._lib.mpk_replan_advance(self._h, traj_steps.data_ptr(), plan_steps.data_ptr(), seg.data_ptr(),
+                                                done.data_ptr(), int(every), mpt, int(horizon), self.num_steps, B,
+                                                self._stream()))
+        return seg
+
+    def traj_validity(self, pos: torch.Tensor, pos_low, pos_high, params: Optional[torch.Tensor] = None,
+                      tau_bound=None, delay_bound=None) -> torch.Tensor:
+        B, T, D = pos.shape
+        lo_p, lo_k = _dvec(pos_low, D)
+        hi_p, hi_k = _dvec(pos_high, D)
+        check = int(params is not None and tau_bound is not None and delay_bound is not None)
+        tb = (C.c_double * 2)(*(tau_bound if check else (0.0, 0.0)))
+        db = (C.c_double * 2)(*(delay_bound if check else (0.0, 0.0)))
+        valid = torch.empty(B, dtype=torch.uint8, device=self.device)
+        _lib.check(self._lib.mpk_traj_validity(self._h, pos.contiguous().data_ptr(), _dptr(params),
+                                               C.cast(lo_p, C.c_void_p), C.cast(hi_p, C.c_void_p), check,
+                                               C.cast(tb, C.c_void_p), C.cast(db, C.c_void_p), valid.data_ptr(), B, T,
+                                               self._stream()))
+        return valid.bool()
+
+    # ---- introspection -----------------------------------------------------------------------------------------
+    def prodmp_tables(self):
+        n = self._lib.mpk_prodmp_tables(self._h, None, None, None, None, None, None, None)
+        _lib.check(n)
+        K = self.config.num_basis + 1
+        arrs = [np.empty(n, np.float64) for _ in range(4)] + [np.empty((n, K), np.float64) for _ in range(2)] + \
+               [np.empty(K, np.float64)]
+        _lib.check(self._lib.mpk_prodmp_tables(self._h, *[a.ctypes.data for a in arrs]))
+        return dict(zip(("y1", "y2", "dy1", "dy2", "pos_basis", "vel_basis", "scale"), arrs))
+
+    def prodmp_indices(self, init_time: float = 0.0):
+        T = self.num_steps
+        idx = np.empty(T, np.int32)
+        ib = np.empty(1, np.int32)
+        _lib.check(self._lib.mpk_prodmp_indices(self._h, float(init_time), idx.ctypes.data, ib.ctypes.data,
+                                                self._stream()))
+        return idx, int(ib[0])
+
+    def last_kernel(self) -> str:
+        return self._lib.mpk_last_kernel(self._h).decode()

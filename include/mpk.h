@@ -1,0 +1,226 @@
+/*
+ * mpk.h -- C-ABI of the MI355X-native movement-primitive trajectory engine (libmpk.so, HIP/gfx950 inside).
+ *
+ * Drop-in boundary for ONE hot path of ALRhub/fancy_gym: MP parameter vector -> (pos, vel) trajectory -> per-step
+ * tracking-controller action.  Each entry point cites the reference interface it replaces (paths relative to the
+ * reference checkout).  Plain pointers and sizes only; no torch / C++ types cross this boundary.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative MPK_E* code on failure; mpk_last_error() returns a
+ *     thread-local, human-readable message for the last failure on the calling thread.  No exceptions cross the ABI.
+ *   - "dev" pointers are HIP device pointers on the handle's device; "host" pointers are ordinary host memory.
+ *     The caller owns every buffer.  `stream` is a hipStream_t passed as void* (NULL = the null stream); all device
+ *     work is enqueued on it and NOT synchronised -- the caller synchronises.
+ *   - a handle is not re-entrant (one caller at a time per handle); different handles may be used from different
+ *     threads.
+ *   - array layouts are C-contiguous: params [B, P], init_pos/init_vel [B, D], pos/vel/actions [B, T, D].
+ */
+#ifndef MPK_H
+#define MPK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPK_ABI_VERSION 1
+
+/* error codes */
+#define MPK_OK            0
+#define MPK_EINVAL       -1   /* bad argument / unsupported configuration (reference: ValueError / AssertionError) */
+#define MPK_ENOTIMPL     -2   /* reference raises NotImplementedError for this type string (rhythmic, smooth)     */
+#define MPK_EHIP         -3   /* a HIP runtime call failed                                                        */
+#define MPK_ERANGE       -4   /* ProDMP: time beyond the pre-computed range (reference: RuntimeError)              */
+#define MPK_ENODEV       -5   /* no usable GPU                                                                    */
+
+/* factory/trajectory_generator_factory.py:7-21 -- 'promp' | 'dmp' | 'prodmp' */
+#define MPK_MP_PROMP   0
+#define MPK_MP_DMP     1
+#define MPK_MP_PRODMP  2
+/* factory/phase_generator_factory.py:9-23 -- 'linear' | 'exp' */
+#define MPK_PHASE_LINEAR 0
+#define MPK_PHASE_EXP    1
+/* factory/basis_generator_factory.py:8-23 -- 'rbf' | 'zero_rbf' | 'prodmp' */
+#define MPK_BASIS_RBF       0
+#define MPK_BASIS_ZERO_RBF  1
+#define MPK_BASIS_PRODMP    2
+/* factory/controller_factory.py:9-21 -- 'motor' | 'velocity' | 'position'  ('metaworld' is host-only) */
+#define MPK_CTRL_MOTOR     0
+#define MPK_CTRL_VELOCITY  1
+#define MPK_CTRL_POSITION  2
+/* plants the rollout kernel can integrate on device */
+#define MPK_PLANT_STATIC             0  /* state never changes (test/test_black_box.py:50-56 ToyWrapper)            */
+#define MPK_PLANT_DOUBLE_INTEGRATOR  1  /* envs/classic_control/base_reacher/base_reacher_torque.py:25-26           */
+
+typedef struct mpk_handle_s* mpk_handle;
+
+/*
+ * Everything the reference passes to mp_pytorch's PhaseGenerator / BasisGenerator / MPInterface constructors through
+ * fancy_gym/utils/make_env_helpers.py:128-131 (kwarg groups of fancy_gym/envs/registry.py:62-129), plus the
+ * (duration, dt) pair of BlackBoxWrapper.__init__ -> traj_gen.set_duration (black_box_wrapper.py:57).
+ */
+typedef struct mpk_config {
+    int32_t abi_version;             /* = MPK_ABI_VERSION */
+    int32_t device;                  /* HIP device ordinal */
+    int32_t mp_type;                 /* MPK_MP_*    */
+    int32_t phase_type;              /* MPK_PHASE_* */
+    int32_t basis_type;              /* MPK_BASIS_* */
+    int32_t num_dof;                 /* action_dim  */
+    int32_t num_basis;               /* learnable basis functions per DoF */
+    int32_t num_basis_outside;       /* rbf only */
+    int32_t num_basis_zero_start;    /* zero_rbf only */
+    int32_t num_basis_zero_goal;     /* zero_rbf only */
+    int32_t learn_tau;
+    int32_t learn_delay;
+    int32_t auto_scale_basis;        /* prodmp */
+    int32_t relative_goal;           /* prodmp */
+    int32_t disable_goal;            /* prodmp */
+    int32_t disable_weights;         /* prodmp */
+    int32_t pre_compute_length_factor; /* prodmp, <= 6 */
+    int32_t reserved0;
+    double  tau;                     /* construction-time tau (also the value used when !learn_tau) */
+    double  delay;
+    double  alpha_phase;             /* exp phase */
+    double  tau_bound[2];
+    double  delay_bound[2];
+    double  basis_bandwidth_factor;
+    double  basis_alpha;             /* prodmp basis alpha */
+    double  basis_dt;                /* prodmp pre-compute grid step (mp_pytorch default 0.01) */
+    double  weights_scale;
+    double  goal_scale;
+    double  dmp_alpha;               /* dmp spring constant, beta = alpha/4 */
+    double  dt;                      /* env control step  (RawInterfaceWrapper.dt, raw_interface_wrapper.py:46-53) */
+    double  duration;                /* trajectory duration in seconds */
+} mpk_config;
+
+/* controller + plant description for the rollout (black_box_wrapper.py:175-203; controller/pd_controller.py:21-29) */
+typedef struct mpk_rollout_cfg {
+    int32_t controller_type;         /* MPK_CTRL_*  */
+    int32_t plant_type;              /* MPK_PLANT_* */
+    double  dt;                      /* plant integration step */
+    const double* p_gains;           /* host [D] */
+    const double* d_gains;           /* host [D] */
+    const double* act_low;           /* host [D]  env.action_space.low  (black_box_wrapper.py:178-179) */
+    const double* act_high;          /* host [D]  env.action_space.high */
+} mpk_rollout_cfg;
+
+/* ---- lifecycle ------------------------------------------------------------------------------------------------ */
+
+/* thread-local message of the last failing call on this thread */
+const char* mpk_last_error(void);
+
+/* ABI version of the loaded library */
+int mpk_abi_version(void);
+
+/* number of visible HIP devices (0 if none); never initialises a context */
+int mpk_device_count(void);
+
+/*
+ * Replaces: get_phase_generator + get_basis_generator + get_trajectory_generator (make_env_helpers.py:128-131) and
+ * traj_gen.set_duration(duration, dt) (black_box_wrapper.py:57).  Pre-computes the RBF centres / ProDMP tables on the
+ * host in float64 and uploads them.
+ */
+int mpk_create(const mpk_config* cfg, mpk_handle* out);
+void mpk_destroy(mpk_handle h);
+
+/* ---- shape queries -------------------------------------------------------------------------------------------- */
+int mpk_num_params(mpk_handle h);   /* P: [tau?][delay?] + D*num_basis (+ D goals for dmp/prodmp); <0 on error */
+int mpk_num_steps(mpk_handle h);    /* T = round(duration/dt) for the current duration                           */
+int mpk_num_dof(mpk_handle h);
+
+/* Replaces traj_gen.get_params_bounds() (black_box_wrapper.py:122-127): host float [P] each. */
+int mpk_params_bounds(mpk_handle h, float* low, float* high);
+
+/* Replaces traj_gen.set_duration(duration, dt) (black_box_wrapper.py:115). Changes T. */
+int mpk_set_duration(mpk_handle h, double duration, double dt);
+
+/* Copies the fp32 time grid linspace(0,duration,T+1)[1:] (without init_time) to host float [T]. */
+int mpk_times(mpk_handle h, float* times);
+
+/* ---- the hot path --------------------------------------------------------------------------------------------- */
+
+/*
+ * Replaces BlackBoxWrapper.get_trajectory (black_box_wrapper.py:96-120) for B episodes at once:
+ *   clip(params, bounds) -> set_params -> set_initial_conditions(init_time, init_pos, init_vel) -> get_traj_pos/vel.
+ *   params    dev float [B, P]
+ *   init_pos  dev float [B, D]    condition_pos / env.current_pos   (black_box_wrapper.py:110)
+ *   init_vel  dev float [B, D]    condition_vel / env.current_vel   (black_box_wrapper.py:111)
+ *   init_time dev float [B] or NULL; when NULL every episode uses `init_time_shared` (black_box_wrapper.py:107-108)
+ *   pos, vel  dev float [B, T, D] outputs
+ * Shared phase (no learned tau/delay, init_time == NULL) runs the MFMA kernel; otherwise the per-episode kernel.
+ */
+int mpk_trajectory(mpk_handle h, const float* params, const float* init_pos, const float* init_vel,
+                   const float* init_time, double init_time_shared,
+                   float* pos, float* vel, int32_t B, void* stream);
+
+/*
+ * Same, fused with the open-loop part of the step loop (black_box_wrapper.py:176-179): additionally writes
+ *   actions[b,t,:] = clip(controller(pos[b,t], vel[b,t], c_pos[b], c_vel[b]), act_low, act_high)
+ * for a state that does not change during the plan (MPK_PLANT_STATIC).  c_pos/c_vel dev double [B, D].
+ * Shared-phase configurations only.
+ */
+int mpk_trajectory_actions(mpk_handle h, const float* params, const float* init_pos, const float* init_vel,
+                           double init_time_shared, const mpk_rollout_cfg* rc,
+                           const double* c_pos, const double* c_vel,
+                           float* pos, float* vel, float* actions, int32_t B, void* stream);
+
+/*
+ * Replaces the per-step loop of BlackBoxWrapper.step (black_box_wrapper.py:175-203) for plants that live on the GPU:
+ *   for t < n_steps[b]: a = clip(controller(des_pos[b,t], des_vel[b,t], q[b], qd[b]), low, high); plant step
+ *   des_pos, des_vel dev float  [B, T, D]
+ *   q, qd            dev double [B, D]   in: state at plan start, out: state after the executed steps
+ *   n_steps          dev int32  [B] or NULL (NULL = T steps): the break index of black_box_wrapper.py:197
+ *   actions          dev float  [B, T, D] (steps >= n_steps[b] are written as 0); may be NULL
+ * Arithmetic is float64 without FMA contraction, exactly numpy's promotion in the reference.
+ */
+int mpk_pd_rollout(mpk_handle h, const mpk_rollout_cfg* rc, const float* des_pos, const float* des_vel,
+                   double* q, double* qd, const int32_t* n_steps, float* actions,
+                   int32_t B, int32_t T, void* stream);
+
+/*
+ * Integer replanning bookkeeping of BlackBoxWrapper.step for the schedule `t % every == 0`
+ * (envs/mujoco/box_pushing/mp_wrapper.py:89; black_box_wrapper.py:174,197,206):
+ *   plan_steps[b] += 1
+ *   seg_len[b]     = number of steps of this plan that are executed: first local t with
+ *                    (t+1+traj_steps[b]) >= horizon  (env truncates)  or
+ *                    ((t+1+traj_steps[b]) % every == 0 and plan_steps[b] < max_planning_times), else T
+ *   traj_steps[b] += seg_len[b];  done[b] = traj_steps[b] >= horizon
+ * All dev int32 [B] (done: uint8 [B]).  Episodes with done[b] != 0 on entry are left untouched (seg_len = 0).
+ */
+int mpk_replan_advance(mpk_handle h, int32_t* traj_steps, int32_t* plan_steps, int32_t* seg_len, uint8_t* done,
+                       int32_t every, int32_t max_planning_times, int32_t horizon, int32_t T,
+                       int32_t B, void* stream);
+
+/*
+ * Batched validity check (raw_interface_wrapper.py:55-72; envs/mujoco/table_tennis/table_tennis_env.py:303-309):
+ *   valid[b] = all_t,d( pos_low[d] <= pos[b,t,d] <= pos_high[d] )
+ *              and (check_tau_delay == 0 or (tau_lo <= params[b,0] <= tau_hi and delay_lo <= params[b,1] <= delay_hi))
+ * pos dev float [B,T,D]; params dev float [B,P]; pos_low/high host double [D]; valid dev uint8 [B].
+ */
+int mpk_traj_validity(mpk_handle h, const float* pos, const float* params, const double* pos_low,
+                      const double* pos_high, int32_t check_tau_delay, const double tau_bound[2],
+                      const double delay_bound[2], uint8_t* valid, int32_t B, int32_t T, void* stream);
+
+/* ---- introspection used by tests / bench ------------------------------------------------------------------------ */
+
+/*
+ * Copies the ProDMP pre-computed tables to host double arrays (any pointer may be NULL):
+ *   y1,y2,dy1,dy2 [N]; pos_basis, vel_basis [N, num_basis+1]; scale [num_basis+1].  Returns N (>0) or <0.
+ */
+int mpk_prodmp_tables(mpk_handle h, double* y1, double* y2, double* dy1, double* dy2,
+                      double* pos_basis, double* vel_basis, double* scale);
+
+/*
+ * Computes, with the device code path, the ProDMP table indices for the shared time grid + `init_time`
+ * (times_to_indices; the bit-exact integer part of the path).  idx host int32 [T]; idx_init host int32 [1].
+ */
+int mpk_prodmp_indices(mpk_handle h, double init_time, int32_t* idx, int32_t* idx_init, void* stream);
+
+/* Name of the kernel the last mpk_trajectory* call launched for its main pass (for profiling). */
+const char* mpk_last_kernel(mpk_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPK_H */

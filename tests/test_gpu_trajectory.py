@@ -1,0 +1,157 @@
+"""
+GPU parity tests proper: the HIP path (through the C-ABI, via fancy_gym_amd.TrajectoryEngine) against the CPU oracle on
+the same seeded inputs.  Tolerance: BASELINE.json north_star -- 1e-5 relative in fp32; stated as
+|gpu - oracle| <= 1e-5 * max|oracle| + 1e-5 * |oracle| per output array.  Integer parts (table indices) bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mp_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def close(got, ref, name, rtol=RTOL):
+    got = np.asarray(got, np.float64); ref = np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    scale = np.abs(ref).max() if ref.size else 1.0
+    err = np.abs(got - ref)
+    tol = rtol * scale + rtol * np.abs(ref)
+    bad = err > tol
+    assert not bad.any(), f"{name}: max err {err.max():.3e} (scale {scale:.3e}), {bad.sum()} / {bad.size} outside tol"
+
+
+def make_engine(pc, bc, tc, dt, duration, **kw):
+    from fancy_gym_amd import TrajectoryEngine
+    return TrajectoryEngine(
+        tc.trajectory_generator_type, pc.phase_generator_type, bc.basis_generator_type, tc.action_dim, bc.num_basis,
+        dt=dt, duration=duration, tau=pc.tau, delay=pc.delay, alpha_phase=pc.alpha_phase, learn_tau=pc.learn_tau,
+        learn_delay=pc.learn_delay, tau_bound=pc.tau_bound, delay_bound=pc.delay_bound,
+        basis_bandwidth_factor=bc.basis_bandwidth_factor, num_basis_outside=bc.num_basis_outside,
+        num_basis_zero_start=bc.num_basis_zero_start if bc.basis_generator_type == "zero_rbf" else 0,
+        num_basis_zero_goal=bc.num_basis_zero_goal if bc.basis_generator_type == "zero_rbf" else 0,
+        basis_alpha=bc.alpha, basis_dt=bc.dt, pre_compute_length_factor=bc.pre_compute_length_factor,
+        weights_scale=tc.weights_scale, goal_scale=tc.goal_scale, dmp_alpha=tc.alpha,
+        auto_scale_basis=tc.auto_scale_basis, relative_goal=tc.relative_goal, disable_goal=tc.disable_goal,
+        disable_weights=tc.disable_weights, **kw)
+
+
+def inputs(pc, bc, tc, B, seed=0):
+    rng = np.random.default_rng(seed)
+    P = O.num_params(pc, bc, tc)
+    params = rng.standard_normal((B, P)).astype(np.float32)
+    i = 0
+    if pc.learn_tau:
+        lo, hi = pc.tau_bound
+        params[:, i] = rng.uniform(lo, min(hi, lo + 2.0), B); i += 1
+    if pc.learn_delay:
+        lo, hi = pc.delay_bound
+        params[:, i] = rng.uniform(lo, min(hi, lo + 0.5), B); i += 1
+    ip = rng.uniform(-1, 1, (B, tc.action_dim)).astype(np.float32)
+    iv = rng.uniform(-1, 1, (B, tc.action_dim)).astype(np.float32)
+    return params, ip, iv
+
+
+CFG2 = (O.PhaseCfg("exp", tau=1.5, alpha_phase=3.0),
+        O.BasisCfg("prodmp", num_basis=5, basis_bandwidth_factor=2, alpha=10),
+        O.TrajCfg("prodmp", action_dim=7), 0.02, 2.0)
+CFG3 = (O.PhaseCfg("exp", tau=4.0, alpha_phase=2.0),
+        O.BasisCfg("rbf", num_basis=5, basis_bandwidth_factor=3),
+        O.TrajCfg("dmp", action_dim=7, alpha=25.0), 0.02, 4.0)
+CFG1 = (O.PhaseCfg("linear", tau=4.0),
+        O.BasisCfg("zero_rbf", num_basis=5, num_basis_zero_start=1, num_basis_zero_goal=0, basis_bandwidth_factor=3),
+        O.TrajCfg("promp", action_dim=5), 0.02, 4.0)
+CFG5 = (O.PhaseCfg("linear", tau=2.8),
+        O.BasisCfg("zero_rbf", num_basis=3, num_basis_zero_start=1, num_basis_zero_goal=1, basis_bandwidth_factor=3),
+        O.TrajCfg("promp", action_dim=7), 0.008, 2.8)
+CFG4 = (O.PhaseCfg("exp", tau=1.5, alpha_phase=3.0),
+        O.BasisCfg("prodmp", num_basis=5, basis_bandwidth_factor=3, alpha=10),
+        O.TrajCfg("prodmp", action_dim=7, weights_scale=0.3, goal_scale=0.3, auto_scale_basis=True, disable_goal=True),
+        0.02, 2.0)
+SHARED = {"cfg1_promp_reacher5d": CFG1, "cfg2_prodmp_boxpushing": CFG2, "cfg3_dmp_reacher7d": CFG3,
+          "cfg4_prodmp_replan": CFG4, "cfg5_promp_tabletennis": CFG5}
+
+
+@pytest.mark.parametrize("name", list(SHARED))
+@pytest.mark.parametrize("B", [1, 3, 64, 1000])
+@pytest.mark.parametrize("init_time", [0.0, 0.5])
+def test_shared_phase_matches_oracle(name, B, init_time):
+    pc, bc, tc, dt, duration = SHARED[name]
+    eng = make_engine(pc, bc, tc, dt, duration)
+    params, ip, iv = inputs(pc, bc, tc, B, seed=B)
+    pos, vel = eng.trajectory(params, ip, iv, init_time)
+    torch.cuda.synchronize()
+    assert eng.last_kernel().startswith("k_traj_shared")
+    for dtype in (np.float64, np.float32):
+        rp, rv = O.get_trajectory(pc, bc, tc, params, duration, dt, init_time, ip, iv, dtype=dtype)
+        close(pos.cpu().numpy(), rp, f"{name} pos vs oracle {dtype.__name__}")
+        close(vel.cpu().numpy(), rv, f"{name} vel vs oracle {dtype.__name__}")
+
+
+@pytest.mark.parametrize("init_time", [0.0, 0.02, 0.5, 1.0, 1.5])
+def test_prodmp_indices_bit_exact(init_time):
+    pc, bc, tc, dt, duration = CFG2
+    eng = make_engine(pc, bc, tc, dt, duration)
+    idx, idxb = eng.prodmp_indices(init_time)
+    tabs = O.prodmp_tables(pc, bc, np.float32)
+    times = O.make_times(duration, dt, init_time, dtype=np.float32)
+    ref = O.prodmp_indices(times, np.float32(pc.tau), np.float32(pc.delay), tabs.scaled_dt)
+    refb = O.prodmp_indices(np.array([init_time], np.float32), np.float32(pc.tau), np.float32(pc.delay), tabs.scaled_dt)
+    assert np.array_equal(idx, ref.astype(np.int32))
+    assert idxb == int(refb[0])
+    assert np.array_equal(eng.times(), O.make_times(duration, dt, 0.0, dtype=np.float32))
+
+
+def test_prodmp_tables_match_oracle_f64():
+    pc, bc, tc, dt, duration = CFG2
+    eng = make_engine(pc, bc, tc, dt, duration)
+    t = eng.prodmp_tables()
+    ref = O.prodmp_tables(pc, bc, np.float64)
+    for k, r in (("y1", ref.y1), ("y2", ref.y2), ("dy1", ref.dy1), ("dy2", ref.dy2), ("pos_basis", ref.pos_basis),
+                 ("vel_basis", ref.vel_basis), ("scale", ref.scale_factors)):
+        np.testing.assert_allclose(t[k], r, rtol=1e-12, atol=1e-14, err_msg=k)
+
+
+PER_ROW = {
+    "prodmp_learn_tau_delay": (O.PhaseCfg("exp", tau=1.5, alpha_phase=3.0, learn_tau=True, learn_delay=True,
+                                          tau_bound=(0.8, 1.5), delay_bound=(0.05, 0.15)),
+                               O.BasisCfg("prodmp", num_basis=3, basis_bandwidth_factor=3, alpha=25),
+                               O.TrajCfg("prodmp", action_dim=7, weights_scale=0.7, auto_scale_basis=True,
+                                         relative_goal=True, disable_goal=True), 0.008, 2.8),
+    "promp_learn_tau": (O.PhaseCfg("linear", tau=1.0, learn_tau=True, tau_bound=(0.04, 1.0)),
+                        O.BasisCfg("rbf", num_basis=10), O.TrajCfg("promp", action_dim=2), 0.02, 1.0),
+    "dmp_learn_delay": (O.PhaseCfg("exp", tau=1.0, learn_delay=True, delay_bound=(0.0, 0.96)),
+                        O.BasisCfg("rbf", num_basis=10), O.TrajCfg("dmp", action_dim=3), 0.02, 1.0),
+}
+
+
+@pytest.mark.parametrize("name", list(PER_ROW))
+@pytest.mark.parametrize("B", [1, 5, 257])
+def test_per_episode_phase_matches_oracle(name, B):
+    pc, bc, tc, dt, duration = PER_ROW[name]
+    eng = make_engine(pc, bc, tc, dt, duration)
+    params, ip, iv = inputs(pc, bc, tc, B, seed=B + 1)
+    pos, vel = eng.trajectory(params, ip, iv, 0.0)
+    torch.cuda.synchronize()
+    assert eng.last_kernel().startswith("k_traj_rows")
+    rp, rv = O.get_trajectory(pc, bc, tc, params, duration, dt, 0.0, ip, iv, dtype=np.float64)
+    close(pos.cpu().numpy(), rp, f"{name} pos")
+    close(vel.cpu().numpy(), rv, f"{name} vel", rtol=5e-5 if "promp" in name else RTOL)
+
+
+def test_per_episode_init_time_equals_shared_path_bitwise():
+    """the per-episode kernel's fmaf chain follows the MFMA accumulation order: identical bits"""
+    pc, bc, tc, dt, duration = CFG2
+    eng = make_engine(pc, bc, tc, dt, duration)
+    B = 130
+    params, ip, iv = inputs(pc, bc, tc, B, seed=7)
+    p0, v0 = eng.trajectory(params, ip, iv, 0.5)
+    it = torch.full((B,), 0.5, dtype=torch.float32, device="cuda")
+    p1, v1 = eng.trajectory(params, ip, iv, it)
+    torch.cuda.synchronize()
+    assert eng.last_kernel().startswith("k_traj_rows")
+    assert torch.equal(p0, p1)
+    assert torch.equal(v0, v1)

@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""
+bench.py -- headline benchmark of the MP hot path on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of synthetic episodes: ONE launch of the fused kernel
+(basis contraction on MFMA + ProDMP boundary conditions + PD tracking-controller actions) for BASELINE config 2:
+ProDMP, 7 DoF, 5 basis (+goal) per DoF, 100 steps, batch 4096 per GPU, inputs resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--eager] [--no-cpu]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Multi-GPU: episodes shard across ranks (independent units, no data-path collective):
+"scaling": "weak", value = all ranks' trajectories / max-over-ranks time.  The optional all-gather of the generated
+trajectories over RCCL/xGMI (north_star) is timed separately and reported under "allgather".
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+# BASELINE cfg2 (fancy_gym/envs/registry.py:105-128 + envs/mujoco/box_pushing/mp_wrapper.py:12-28)
+CFG = dict(num_dof=7, num_basis=5, dt=0.02, duration=2.0, tau=1.5, alpha_phase=3.0, basis_bandwidth_factor=2.0,
+           basis_alpha=10.0)
+P_GAINS = 0.01 * np.array([120., 120., 120., 120., 50., 30., 10.])
+D_GAINS = 0.01 * np.array([10., 10., 10., 10., 6., 5., 3.])
+T_STEPS, D, P = 100, 7, 42
+# algorithmic bytes per trajectory: 224 B in + 2*T*D*4 B (pos, vel) + T*D*4 B (torques)
+BYTES_PER_TRAJ = 224 + 2 * T_STEPS * D * 4 + T_STEPS * D * 4
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--batch", type=int, default=4096, help="episodes per GPU per step")
+    ap.add_argument("--eager", action="store_true", help="one host launch per step instead of one hipGraph of K steps")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-allgather", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(seconds: float, batch: int):
+    """The numpy oracle ("port") timed on this box's host cores, one thread, bounded sample of the same workload."""
+    from oracle import mp_oracle as O
+    pc = O.PhaseCfg("exp", tau=1.5, alpha_phase=3.0)
+    bc = O.BasisCfg("prodmp", num_basis=5, basis_bandwidth_factor=2, alpha=10)
+    tc = O.TrajCfg("prodmp", action_dim=7)
+    tabs = O.prodmp_tables(pc, bc, np.float32)
+    rng = np.random.default_rng(0)
+    params = rng.standard_normal((batch, P)).astype(np.float32)
+    ip = rng.uniform(-1, 1, (batch, D)).astype(np.float32)
+    iv = np.zeros((batch, D), np.float32)
+
+    def one(bsl):
+        pos, vel = O.get_trajectory(pc, bc, tc, params[bsl], 2.0, 0.02, 0.0, ip[bsl], iv[bsl], tables=tabs)
+        O.rollout(pos, vel, "motor", P_GAINS, D_GAINS, -1.0, 1.0, "static", 0.02, ip[bsl].astype(np.float64),
+                  iv[bsl].astype(np.float64))
+
+    # (i) batched: the whole batch per call (best-effort CPU)
+    one(slice(0, batch))
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds * 0.6:
+        one(slice(0, batch)); n += batch
+    batched = n / (time.perf_counter() - t0)
+    # (ii) reference-style: B = 1 per call in a Python loop (black_box_wrapper.py:96-120 execution model)
+    m, t1 = 0, time.perf_counter()
+    while time.perf_counter() - t1 < seconds * 0.4:
+        i = m % batch
+        one(slice(i, i + 1)); m += 1
+    ref_style = m / (time.perf_counter() - t1)
+    return {"value": batched, "unit": "trajectories/s", "cores": 1, "kind": "port",
+            "sample": f"numpy oracle (fp32), ProDMP 7-DoF/5 basis/100 steps + PD actions: {n} trajectories in "
+                      f"batches of {batch} over {seconds * 0.6:.0f} s; reference-style B=1 Python loop: "
+                      f"{ref_style:.0f} trajectories/s over {m} calls"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    dev = torch.device("cuda", local_rank)
+
+    from fancy_gym_amd import RolloutSpec, TrajectoryEngine
+    from fancy_gym_amd import _lib
+    import ctypes as C
+
+    eng = TrajectoryEngine("prodmp", "exp", "prodmp", device=local_rank, **CFG)
+    assert eng.num_steps == T_STEPS and eng.num_params == P
+    B, K, W = args.batch, args.steps, args.warmup
+    g = torch.Generator(device="cpu").manual_seed(1000 + rank if world > 1 else 0)
+    params = torch.randn((B, P), generator=g, dtype=torch.float32).to(dev)
+    init_pos = (torch.rand((B, D), generator=g, dtype=torch.float32) * 2 - 1).to(dev)
+    init_vel = torch.zeros((B, D), dtype=torch.float32, device=dev)
+    c_pos, c_vel = init_pos.double().contiguous(), init_vel.double().contiguous()
+    pos, vel, act = (torch.empty((B, T_STEPS, D), dtype=torch.float32, device=dev) for _ in range(3))
+    spec = RolloutSpec("motor", D, P_GAINS, D_GAINS, -1.0, 1.0, plant="static")
+
+    lib = _lib.load()
+    h, rcfg = eng._h, C.byref(spec.c)
+    ptrs = [t.data_ptr() for t in (params, init_pos, init_vel)]
+    outs = [t.data_ptr() for t in (pos, vel, act)]
+    cp, cv = c_pos.data_ptr(), c_vel.data_ptr()
+
+    def step(stream_ptr):
+        rc = lib.mpk_trajectory_actions(h, ptrs[0], ptrs[1], ptrs[2], 0.0, rcfg, cp, cv, outs[0], outs[1], outs[2], B,
+                                        stream_ptr)
+        if rc != 0:
+            raise RuntimeError(_lib.last_error())
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    stream = torch.cuda.current_stream()
+    sp = stream.cuda_stream
+    for _ in range(W):
+        step(sp)
+    torch.cuda.synchronize()
+
+    # ---- kernel duration, live, with HIP events on the launch stream -------------------------------------------
+    n_ev = 200
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+    for a, b in evs:
+        a.record(stream); step(sp); b.record(stream)
+    torch.cuda.synchronize()
+    durs = sorted(a.elapsed_time(b) * 1e-3 for a, b in evs)     # seconds
+    kern_avg = float(np.mean(durs[: int(n_ev * 0.9)]))            # drop the slowest 10 % (clock ramp / stragglers)
+
+    # ---- the timed region: EXACTLY K steps ------------------------------------------------------------------------
+    launch = "eager"
+    graph = None
+    if not args.eager:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(stream)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    for _ in range(K):
+                        step(side.cuda_stream)
+            stream.wait_stream(side)
+            torch.cuda.synchronize()
+            graph.replay()            # untimed: first replay uploads the executable graph
+            torch.cuda.synchronize()
+            launch = "hipgraph"
+        except Exception as e:  # pragma: no cover - depends on the runtime
+            print(f"[bench] hipGraph capture failed ({e}); falling back to eager launches", file=sys.stderr)
+            graph = None
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if graph is not None:
+        graph.replay()
+    else:
+        for _ in range(K):
+            step(sp)
+    torch.cuda.synchronize(); barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = world * B * K / elapsed
+
+    # ---- optional: generation + all-gather of (pos | vel) over RCCL/xGMI ------------------------------------------
+    allgather = None
+    if dist is not None and not args.no_allgather:
+        Kg = max(10, min(K, 200))
+        shard = torch.stack([pos, vel])                     # [2, B, T, D] view-copy target
+        full = torch.empty((world,) + tuple(shard.shape), dtype=torch.float32, device=dev)
+        for _ in range(5):
+            step(sp); shard[0].copy_(pos); shard[1].copy_(vel); dist.all_gather_into_tensor(full, shard)
+        barrier(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(Kg):
+            step(sp); shard[0].copy_(pos); shard[1].copy_(vel); dist.all_gather_into_tensor(full, shard)
+        torch.cuda.synchronize(); barrier()
+        e2 = time.perf_counter() - t1
+        t = torch.tensor([e2], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        e2 = float(t.item())
+        allgather = {"value": world * B * Kg / e2, "unit": "trajectories/s", "steps": Kg,
+                     "ms_per_step": e2 / Kg * 1e3, "bytes_gathered_per_gpu_per_step": int((world - 1) * shard.numel() * 4)}
+
+    if rank == 0:
+        achieved = BYTES_PER_TRAJ * B / kern_avg / 1e9
+        out = {
+            "metric": "MP trajectories/sec (7-DoF, 5 basis, 100 steps) at 1/2/4/8 GPUs; % roofline",
+            "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg2: ProDMP 7-DoF, 5 basis(+goal), 100 steps, exp phase tau=1.5, alpha=10; "
+                                   "trajectory (pos, vel) + PD tracking-controller actions, fused",
+                       "batch_per_gpu": B, "global_batch": world * B, "launch": launch,
+                       "sharding": f"dp{world} (independent episodes, no data-path collective)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": eng.last_kernel(), "kernel_avg_us": kern_avg * 1e6,
+                         "algorithmic_bytes_per_launch": BYTES_PER_TRAJ * B},
+        }
+        if allgather is not None:
+            out["allgather"] = allgather
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, B)
+        elif not args.no_cpu:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

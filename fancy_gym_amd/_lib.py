@@ -74,6 +74,10 @@ SIGNATURES = {
     "mpk_traj_validity": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp]),
     "mpk_prodmp_tables": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mpk_prodmp_indices": (C.c_int, [_vp, _dbl, _vp, _vp, _vp]),
+    "mpk_host_prodmp_tables": (C.c_int, [C.POINTER(mpk_config), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mpk_host_rbf": (C.c_int, [C.POINTER(mpk_config), _vp, _vp]),
+    "mpk_host_times": (C.c_int, [_dbl, _dbl, _vp, _i32]),
+    "mpk_host_num_params": (C.c_int, [C.POINTER(mpk_config)]),
     "mpk_last_kernel": (C.c_char_p, [_vp]),
 }
 

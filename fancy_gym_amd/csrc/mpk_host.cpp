@@ -234,6 +234,16 @@ static int local_per_dof(const mpk_config& c) {
     }
 }
 
+static void quantise(mpk_config& q) {
+    // the reference holds these constants as fp32 tensors / mixes them into fp32 tensor ops: quantise once so the
+    // float64 table build sees exactly the values the reference's arithmetic sees
+    auto f32 = [](double v) { return (double)(float)v; };
+    q.tau = f32(q.tau); q.delay = f32(q.delay); q.alpha_phase = f32(q.alpha_phase);
+    q.basis_bandwidth_factor = f32(q.basis_bandwidth_factor); q.basis_alpha = f32(q.basis_alpha);
+    q.basis_dt = f32(q.basis_dt); q.weights_scale = f32(q.weights_scale); q.goal_scale = f32(q.goal_scale);
+    q.dmp_alpha = f32(q.dmp_alpha);
+}
+
 static void fill_devcfg(Handle* h) {
     const mpk_config& c = h->cfg;
     DevCfg& d = h->dev;
@@ -398,15 +408,7 @@ int mpk_create(const mpk_config* cfg, mpk_handle* out) {
     MPK_HIP(hipSetDevice(cfg->device));
     Handle* h = new Handle();
     h->cfg = *cfg;
-    {   // the reference holds these constants as fp32 tensors / mixes them into fp32 tensor ops: quantise once so the
-        // float64 table build sees exactly the values the reference's arithmetic sees
-        mpk_config& q = h->cfg;
-        auto f32 = [](double v) { return (double)(float)v; };
-        q.tau = f32(q.tau); q.delay = f32(q.delay); q.alpha_phase = f32(q.alpha_phase);
-        q.basis_bandwidth_factor = f32(q.basis_bandwidth_factor); q.basis_alpha = f32(q.basis_alpha);
-        q.basis_dt = f32(q.basis_dt); q.weights_scale = f32(q.weights_scale); q.goal_scale = f32(q.goal_scale);
-        q.dmp_alpha = f32(q.dmp_alpha);
-    }
+    quantise(h->cfg);
     cfg = &h->cfg;
     h->duration = cfg->duration; h->dt = cfg->dt;
     hipDeviceProp_t prop;
@@ -610,6 +612,55 @@ int mpk_prodmp_indices(mpk_handle hh, double init_time, int32_t* idx, int32_t* i
     }
     (void)hipFree(st.A); (void)hipFree(st.aux);
     return rc;
+}
+
+int mpk_host_prodmp_tables(const mpk_config* cfg, double* y1, double* y2, double* dy1, double* dy2,
+                           double* pos_basis, double* vel_basis, double* scale, float* scaled_dt) {
+    if (!cfg) { set_error("NULL argument"); return MPK_EINVAL; }
+    int rc = check_cfg(*cfg);
+    if (rc != MPK_OK) return rc;
+    if (cfg->basis_type != MPK_BASIS_PRODMP) { set_error("not a prodmp configuration"); return MPK_EINVAL; }
+    mpk_config q = *cfg;
+    quantise(q);
+    HostTables t;
+    build_prodmp(q, t);
+    auto cp = [](double* dst, const std::vector<double>& src) { if (dst) std::memcpy(dst, src.data(), src.size() * sizeof(double)); };
+    cp(y1, t.y1); cp(y2, t.y2); cp(dy1, t.dy1); cp(dy2, t.dy2);
+    cp(pos_basis, t.pos_basis); cp(vel_basis, t.vel_basis); cp(scale, t.scale);
+    if (scaled_dt) *scaled_dt = t.scaled_dt;
+    return t.n_pc;
+}
+
+int mpk_host_rbf(const mpk_config* cfg, double* centers, double* bw) {
+    if (!cfg) { set_error("NULL argument"); return MPK_EINVAL; }
+    int rc = check_cfg(*cfg);
+    if (rc != MPK_OK) return rc;
+    mpk_config q = *cfg;
+    quantise(q);
+    HostTables t;
+    build_rbf(q, t);
+    if (centers) std::memcpy(centers, t.centers.data(), t.centers.size() * sizeof(double));
+    if (bw) std::memcpy(bw, t.bw.data(), t.bw.size() * sizeof(double));
+    return t.n_total;
+}
+
+int mpk_host_times(double duration, double dt, float* times, int32_t cap) {
+    if (!(duration > 0.0) || !(dt > 0.0)) { set_error("dt and duration must be > 0"); return MPK_EINVAL; }
+    const int T = steps_for(duration, dt);
+    if (T < 1) { set_error("duration/dt gives no time steps"); return MPK_EINVAL; }
+    if (times) {
+        if (cap < T) { set_error("times buffer too small"); return MPK_EINVAL; }
+        const std::vector<float> t = build_times(duration, T);
+        std::memcpy(times, t.data(), sizeof(float) * T);
+    }
+    return T;
+}
+
+int mpk_host_num_params(const mpk_config* cfg) {
+    if (!cfg) { set_error("NULL argument"); return MPK_EINVAL; }
+    int rc = check_cfg(*cfg);
+    if (rc != MPK_OK) return rc;
+    return (cfg->learn_tau ? 1 : 0) + (cfg->learn_delay ? 1 : 0) + cfg->num_dof * local_per_dof(*cfg);
 }
 
 const char* mpk_last_kernel(mpk_handle hh) {

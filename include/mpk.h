@@ -217,6 +217,20 @@ int mpk_prodmp_tables(mpk_handle h, double* y1, double* y2, double* dy1, double*
  */
 int mpk_prodmp_indices(mpk_handle h, double init_time, int32_t* idx, int32_t* idx_init, void* stream);
 
+/*
+ * Device-free views of the construction-time host logic (no GPU needed; used by the CPU test-suite):
+ *   mpk_host_prodmp_tables : the float64 ProDMP pre-compute for `cfg` (same outputs as mpk_prodmp_tables, plus the
+ *                            fp32 grid step `scaled_dt`); pass all-NULL outputs to query N.  Returns N or <0.
+ *   mpk_host_rbf           : RBF centres (phase space) and bandwidths, double [n_total] each.  Returns n_total or <0.
+ *   mpk_host_times         : fp32 time grid for (duration, dt) into times[cap].  Returns T or <0.
+ *   mpk_host_num_params    : P for `cfg` without creating a handle.
+ */
+int mpk_host_prodmp_tables(const mpk_config* cfg, double* y1, double* y2, double* dy1, double* dy2,
+                           double* pos_basis, double* vel_basis, double* scale, float* scaled_dt);
+int mpk_host_rbf(const mpk_config* cfg, double* centers, double* bw);
+int mpk_host_times(double duration, double dt, float* times, int32_t cap);
+int mpk_host_num_params(const mpk_config* cfg);
+
 /* Name of the kernel the last mpk_trajectory* call launched for its main pass (for profiling). */
 const char* mpk_last_kernel(mpk_handle h);
 

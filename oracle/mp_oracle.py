@@ -463,9 +463,14 @@ def prodmp_trajectory(pc: PhaseCfg, bc: BasisCfg, tc: TrajCfg, params: Array, ti
     v_b = (np.asarray(init_vel, f) * tau_b[:, None]).astype(f)
 
     tt = np.broadcast_to(times.astype(f), (B, times.shape[-1])) if times.ndim == 1 else times.astype(f)
-    idx = prodmp_indices(tt, tau, delay, tables.scaled_dt, bc.pre_compute_length_factor, f)           # [B, T]
+    # the table indices are the INTEGER part of the path: the reference computes them with fp32 tensor ops, so the
+    # fp32 recipe defines them for every `dtype` (a float64 quotient can fall on the other side of a .5 tie)
+    g = np.float32
+    idx = prodmp_indices(tt.astype(g), np.asarray(tau, g), np.asarray(delay, g), tables.scaled_dt,
+                         bc.pre_compute_length_factor, g)                                              # [B, T]
     it = np.broadcast_to(np.asarray(init_time, f), (B,)).astype(f)
-    idx_b = prodmp_indices(it[:, None], tau, delay, tables.scaled_dt, bc.pre_compute_length_factor, f)[:, 0]
+    idx_b = prodmp_indices(it.astype(g)[:, None], np.asarray(tau, g), np.asarray(delay, g), tables.scaled_dt,
+                           bc.pre_compute_length_factor, g)[:, 0]
 
     T1, T2, D1, D2 = (tables.y1.astype(f), tables.y2.astype(f), tables.dy1.astype(f), tables.dy2.astype(f))
     PB, VB = tables.pos_basis.astype(f), tables.vel_basis.astype(f)

@@ -4,9 +4,10 @@
 //
 //   k_build_shared   phase / exponential-kernel evaluation: per-time-step basis rows for a phase that all episodes
 //                    share (tau, delay, init_time equal) -> A tables [n_out][KP][TS] (k-major, fp32) + aux[TS]
-//   k_traj_shared    the [T x K] . [K x D] contraction on the matrix cores (v_mfma_f32_16x16x4_f32), 16 time steps x
-//                    16 (episode, DoF) columns per tile, fused epilogue (ProDMP vel scaling, ProMP finite-difference
-//                    velocity, DMP Euler integration, optional PD action), wave-private LDS transpose, float4 stores
+//   k_traj_tiles /   the [T x K] . [K x D] contraction on the matrix cores (v_mfma_f32_16x16x4_f32), 16 time steps x
+//   k_traj_stream    16 (episode, DoF) columns per tile, fused epilogue (ProMP finite-difference velocity, DMP Euler
+//                    integration, optional PD action), wave-private LDS transpose, float4 stores; tile-major for
+//                    cache-resident batches, episode-major (LDS-staged basis tables) for HBM-streaming batches
 //   k_traj_rows      per-episode phase (learned tau / delay, per-episode init_time): table gather / RBF evaluation
 //                    per row, fp32 fmaf chains in the same k order as the MFMA
 //   k_pd_rollout     tracking-controller + plant loop in float64 (black_box_wrapper.py:175-203)
@@ -14,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "mpk_internal.h"
 
@@ -74,21 +76,47 @@ __device__ __forceinline__ void prodmp_xi(const DevCfg& c, const ProdmpBC& bc, i
     xi[3] = bc.c * dy2 - bc.d * dy1;
 }
 
-// column k (< nb+3) of the ProDMP position / velocity rows at table index idx
+// Column k (< nb+3) of the ProDMP position / velocity rows at table index idx, as consumed by the contraction with the
+// RAW parameter column x = [w_0..w_{nb-1}, g, y_b, ydot_b]:
+//   k <  nb   : H_k  * weights_goal_scale[k]            (0 if the weights are disabled)
+//   k == nb   : H_g  * weights_goal_scale[nb]           (0 if the goal is disabled)
+//   k == nb+1 : xi1  (+ H_g for a relative goal: goal = scale*g + y_b)
+//   k == nb+2 : xi2 * tau                               (v_b = tau * ydot_b)
+// and the velocity row additionally carries the 1/tau of  vel = (...)/tau.  Everything is folded in float64 and
+// rounded ONCE to fp32.
 __device__ __forceinline__ void prodmp_col(const DevCfg& c, const ProdmpBC& bc, int idx, const double xi[4], int k,
-                                           float* h, float* hv) {
+                                           double tau, float* h, float* hv) {
     const int N = c.n_pc, K = c.nb + 1;
+    const double* PB = c.tab + 4 * (size_t)N;
+    const double* VB = PB + (size_t)N * K;
+    auto hcol = [&](int kk, double* hp, double* hvp) {
+        const double pb = PB[(size_t)bc.idxb * K + kk], vb = VB[(size_t)bc.idxb * K + kk];
+        *hp = PB[(size_t)idx * K + kk] - (xi[0] * pb + xi[1] * vb);
+        *hvp = VB[(size_t)idx * K + kk] - (xi[2] * pb + xi[3] * vb);
+    };
+    double p = 0.0, v = 0.0;
     if (k < K) {
-        const double* PB = c.tab + 4 * (size_t)N;
-        const double* VB = PB + (size_t)N * K;
-        const double pb = PB[(size_t)bc.idxb * K + k], vb = VB[(size_t)bc.idxb * K + k];
-        *h = (float)(PB[(size_t)idx * K + k] - (xi[0] * pb + xi[1] * vb));
-        *hv = (float)(VB[(size_t)idx * K + k] - (xi[2] * pb + xi[3] * vb));
+        const bool off = k < c.nb ? c.disable_weights != 0 : c.disable_goal != 0;
+        if (!off) {
+            hcol(k, &p, &v);
+            double sc = 0.0;   // static-index select: a dynamic index would spill the kernarg struct
+#pragma unroll
+            for (int kk = 0; kk <= kMaxKP; ++kk)
+                if (kk == k) sc = (double)c.scale[kk];
+            p *= sc; v *= sc;
+        }
     } else if (k == K) {
-        *h = (float)xi[0]; *hv = (float)xi[2];
+        p = xi[0]; v = xi[2];
+        if (c.relative_goal) {
+            double gp, gv;
+            hcol(c.nb, &gp, &gv);
+            p += gp; v += gv;
+        }
     } else {
-        *h = (float)xi[1]; *hv = (float)xi[3];
+        p = xi[1] * tau; v = xi[3] * tau;
     }
+    *h = (float)p;
+    *hv = (float)(v / tau);
 }
 
 // bounded phase in float64 from an fp32 time value and fp32-held tau/delay (promp / dmp rows)
@@ -142,7 +170,7 @@ __global__ void __launch_bounds__(256) k_build_shared(const DevCfg c, const floa
             prodmp_xi(c, bc, idx, xi);
             for (int k = 0; k < c.KT; ++k) {
                 float h, hv;
-                prodmp_col(c, bc, idx, xi, k, &h, &hv);
+                prodmp_col(c, bc, idx, xi, k, (double)c.tau, &h, &hv);
                 A[(size_t)(0 * KP + k) * TS + t] = h;
                 A[(size_t)(1 * KP + k) * TS + t] = hv;
             }
@@ -168,7 +196,7 @@ __global__ void __launch_bounds__(256) k_build_shared(const DevCfg c, const floa
         for (int t = tid; t < T; t += 256) {
             const float time = c.base_times[t] + init_time;
             const double x = phase_f64(c, time, c.tau, c.delay, nullptr);
-            rbf_cols(c, x, x, A + t, TS);
+            rbf_cols(c, x, x * (double)c.ws, A + t, TS);
             if (t < T - 1) {
                 const float s0 = scaled_time(time, c.delay, c.tau);
                 const float s1 = scaled_time(c.base_times[t + 1] + init_time, c.delay, c.tau);
@@ -191,7 +219,22 @@ int launch_build_shared(const DevCfg& c, float init_time, const SharedTables& st
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// k_traj_shared: MFMA contraction + fused epilogues
+// The [T x K] . [K x D] contraction on the matrix cores (v_mfma_f32_16x16x4_f32) + fused epilogues.
+//
+// Tile = 16 time steps x 16 (episode, DoF) columns, K = 4*KM <= 16.  A fragments = basis rows (with weights_scale /
+// goal_scale / tau / relative goal folded in at build time); B fragments = RAW parameters / boundary conditions
+// gathered from HBM/L2 in fragment layout (wave-uniform base pointers + lane-constant 32-bit offsets, straight-line
+// code, prefetched one episode group ahead).  The C tile is transposed through a wave-private LDS buffer so that
+// every output array of a tile leaves as ONE coalesced float4 store instruction.  Wave-level indices live in SGPRs.
+//
+// Two work decompositions of the same tile code (tools/store_probe.hip, profiles/r01_store_patterns.md):
+//   k_traj_tiles   tile-major: a wave owns ONE row tile (A fragments stay in registers) and walks episode groups.
+//                  Maximum parallelism for small batches whose outputs stay cache resident.
+//   k_traj_stream  episode-major: a wave owns an episode group and walks its row tiles in order, A fragments come
+//                  from a per-workgroup LDS copy of the basis tables.  Every wave writes long contiguous runs,
+//                  which is what the HBM write path needs at large batch (4.9 vs 3.0 TB/s for the same bytes).
+//                  DMP always runs here (the Euler recurrence is serial in t).
+// CT: fused controller (-1 none, MPK_CTRL_* otherwise).
 // ------------------------------------------------------------------------------------------------------------
 struct TrajArgs {
     DevCfg c;
@@ -207,200 +250,343 @@ struct TrajArgs {
     const double* c_pos;
     const double* c_vel;
     int B, sh, G, vec_ok;
-    int wave_floats, xtile_floats;
+    unsigned inv_seg4;     // 65536 / (4*D) + 1
 };
 
 struct ActArgs {
-    int controller_type;
     double pg[kMaxD], dg[kMaxD], lo[kMaxD], hi[kMaxD];
 };
 
-enum : int { XK_ZERO = 0, XK_PARAM = 1, XK_GOAL = 2, XK_IPOS = 3, XK_IVEL = 4 };
+constexpr int kStageStride = 256;   // floats between output arrays in the wave's LDS staging area (>= NTW*16*D)
+constexpr int kStageFloats = 4 * kStageStride;   // pos | vel | actions or DMP forcing | controller constants
 
-template <int MP, bool ACT>
-__global__ void __launch_bounds__(256) k_traj_shared(const TrajArgs a, const ActArgs act) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+enum : int { XK_ZERO = 0, XK_PARAM = 1, XK_IPOS = 2, XK_IVEL = 3 };
+
+// which raw input feeds element k of a DoF's extended parameter column, and its offset inside the DoF's local block
+template <int MP>
+__device__ __forceinline__ int x_kind(const DevCfg& c, int k, int* loc) {
+    *loc = 0;
+    if (MP == MPK_MP_PRODMP) {
+        const int nb = c.nb;
+        if (k < nb) { *loc = k; return c.disable_weights ? XK_ZERO : XK_PARAM; }
+        if (k == nb) { *loc = c.disable_weights ? 0 : nb; return c.disable_goal ? XK_ZERO : XK_PARAM; }
+        if (k == nb + 1) return XK_IPOS;
+        if (k == nb + 2) return XK_IVEL;
+        return XK_ZERO;
+    } else if (MP == MPK_MP_PROMP) {
+        if (k < c.nb) { *loc = k; return XK_PARAM; }
+        if (k == c.nb && c.KT > c.nb) return XK_IPOS;
+        return XK_ZERO;
+    } else {
+        if (k < c.nb) { *loc = k; return XK_PARAM; }
+        return XK_ZERO;
+    }
+}
+
+// lane-constant description of a lane's role in the 16x16 tile machinery
+template <int KM>
+struct LaneMap {
+    int col, q, bl, d, dsafe, NTW;
+    bool dvalid;
+    bool isp[KM], isip[KM], isiv[KM];
+    unsigned poff[KM];   // element offset of B-fragment element m inside the group's params block
+    unsigned ioff;       // element offset inside the group's init_pos / init_vel / c_pos / c_vel block
+    unsigned wofs;       // LDS transpose: write offset of (row 4q, this column)
+    int sseg, w4;        // episode-in-group and float offset of the float4 this lane stores
+    unsigned rofs, gofs; // LDS read offset / global offset (relative to the tile base) of that float4
+};
+
+template <int MP, int KM>
+__device__ __forceinline__ LaneMap<KM> make_lane_map(const TrajArgs& a, int lane) {
+    const DevCfg& c = a.c;
+    LaneMap<KM> L;
+    const int D = c.D, SEG = 16 * D, DP = 1 << a.sh;
+    L.NTW = 16 >> a.sh;
+    L.col = lane & 15; L.q = lane >> 4;
+    L.bl = L.col >> a.sh; L.d = L.col & (DP - 1);
+    L.dvalid = L.d < D;
+    L.dsafe = L.dvalid ? L.d : D - 1;
+#pragma unroll
+    for (int m = 0; m < KM; ++m) {
+        int loc;
+        const int kind = x_kind<MP>(c, 4 * m + L.q, &loc);
+        L.isp[m] = L.dvalid && kind == XK_PARAM;
+        L.isip[m] = L.dvalid && kind == XK_IPOS;
+        L.isiv[m] = L.dvalid && kind == XK_IVEL;
+        L.poff[m] = (unsigned)(L.bl * c.P + c.off + L.dsafe * c.Kloc + loc);
+    }
+    L.ioff = (unsigned)(L.bl * D + L.dsafe);
+    L.wofs = (unsigned)(L.bl * SEG + 4 * L.q * D + L.d);
+    const int seg4 = SEG >> 2;
+    L.sseg = (int)(((unsigned)lane * a.inv_seg4) >> 16);
+    L.w4 = (lane - L.sseg * seg4) * 4;
+    L.rofs = (unsigned)(L.sseg * SEG + L.w4);
+    L.gofs = (unsigned)(L.sseg * c.T * D + L.w4);
+    return L;
+}
+
+// raw inputs of one episode group for this lane (plain loads, no control flow)
+template <int KM>
+struct GroupIn {
+    float raw[KM];
+    float ip, iv;
+    double cp, cv;
+};
+
+template <int MP, bool ACT, int KM>
+__device__ __forceinline__ GroupIn<KM> load_group(const TrajArgs& a, const LaneMap<KM>& L, int g) {
+    const DevCfg& c = a.c;
+    GroupIn<KM> in;
+    // the last group may be ragged: clamp its missing episodes onto the group's first one (computed, never stored)
+    const int b0 = g * L.NTW;
+    const bool bv = b0 + L.bl < a.B;
+    const float* pb = a.params + (size_t)b0 * c.P;
+    const unsigned io = bv ? L.ioff : (unsigned)L.dsafe;
+#pragma unroll
+    for (int m = 0; m < KM; ++m) in.raw[m] = pb[bv ? L.poff[m] : L.poff[m] - L.bl * c.P];
+    in.ip = MP != MPK_MP_DMP ? (a.init_pos + (size_t)b0 * c.D)[io] : 0.0f;
+    in.iv = MP == MPK_MP_PRODMP ? (a.init_vel + (size_t)b0 * c.D)[io] : 0.0f;
+    in.cp = 0.0; in.cv = 0.0;
+    if (ACT) { in.cp = (a.c_pos + (size_t)b0 * c.D)[io]; in.cv = (a.c_vel + (size_t)b0 * c.D)[io]; }
+    return in;
+}
+
+template <int KM>
+__device__ __forceinline__ void finish_group(const LaneMap<KM>& L, const GroupIn<KM>& in, float (&xb)[KM]) {
+#pragma unroll
+    for (int m = 0; m < KM; ++m) xb[m] = L.isp[m] ? in.raw[m] : (L.isip[m] ? in.ip : (L.isiv[m] ? in.iv : 0.0f));
+}
+
+// park the controller constants of every DoF in the wave's 4th staging slot (static kernarg indices: no spill)
+__device__ __forceinline__ void park_gains(const ActArgs& act, int lane, int d, float* sSt) {
+    double pgd = 0.0, dgd = 0.0, lod = 0.0, hid = 0.0;
+#pragma unroll
+    for (int dd = 0; dd < kMaxD; ++dd)
+        if (dd == d) { pgd = act.pg[dd]; dgd = act.dg[dd]; lod = act.lo[dd]; hid = act.hi[dd]; }
+    if (lane < 16) {
+        double* sg = reinterpret_cast<double*>(sSt + 3 * kStageStride);
+        sg[lane] = pgd; sg[16 + lane] = dgd; sg[32 + lane] = lod; sg[48 + lane] = hid;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// epilogue of one C tile into the wave-private LDS transpose buffer (rows beyond T land in rows never stored)
+template <int MP, int CT>
+__device__ __forceinline__ void tile_epilogue(const f32x4& acc0, const f32x4& acc1, const f32x4& acc2,
+                                              const float (&dtd)[4], double cp, double cv, const double* sg,
+                                              float* sSt, unsigned wofs, int D) {
+    double pgd = 0.0, dgd = 0.0, lod = 0.0, hid = 0.0;
+    if (CT >= 0) { pgd = sg[0]; dgd = sg[16]; lod = sg[32]; hid = sg[48]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float p = acc0[r];
+        float v;
+        if (MP == MPK_MP_PRODMP) v = acc1[r];            // 1/tau is folded into the velocity rows
+        else v = (acc1[r] - acc2[r]) / dtd[r];           // forward difference of fp32 positions
+        float* w = sSt + wofs + r * D;
+        w[0] = p;
+        w[kStageStride] = v;
+        if (CT >= 0) {
+            // float64 without FMA: numpy's promotion in pd_controller.py:21-29 (fp32 desired (+) fp64 state)
+            double u;
+            if (CT == MPK_CTRL_MOTOR) u = pgd * ((double)p - cp) + dgd * ((double)v - cv);
+            else if (CT == MPK_CTRL_POSITION) u = (double)p;
+            else u = (double)v;
+            u = fmin(fmax(u, lod), hid);
+            w[2 * kStageStride] = (float)u;
+        }
+    }
+}
+
+// generic (slow) tile store: partial last row tile whose length is not a multiple of 4, or unaligned outputs.
+// Takes plain values (a reference to the kernarg struct would force the whole struct into scratch).
+__device__ __noinline__ void store_tile_generic(float* pos, float* vel, float* actions, int nst, int B, int T, int D,
+                                                int NTW, const float* sSt, int lane, int b0, int rt, int rows) {
+    const int SEG = 16 * D, len = rows * D;
+    for (int j = 0; j < nst; ++j) {
+        float* outp = j == 0 ? pos : (j == 1 ? vel : actions);
+        for (int sb = 0; sb < NTW; ++sb) {
+            const int bb = b0 + sb;
+            if (bb >= B) continue;
+            float* gp = outp + ((size_t)bb * T + rt * 16) * D;
+            for (int e = lane; e < len; e += 64) gp[e] = sSt[j * kStageStride + sb * SEG + e];
+        }
+    }
+}
+
+// one coalesced float4 store per output array (every (episode, output) segment of a row tile is contiguous in HBM)
+template <int NST, int KM>
+__device__ __forceinline__ void tile_store(const TrajArgs& a, const LaneMap<KM>& L, const float* sSt, int lane,
+                                           int b0, int rt, int rows) {
+    const int D = a.c.D, T = a.c.T, len = rows * D;
+    if (a.vec_ok && (len & 3) == 0) {
+        if (L.sseg < L.NTW && L.w4 < len && b0 + L.sseg < a.B) {
+            const size_t gb = ((size_t)b0 * T + rt * 16) * D;
+            *reinterpret_cast<float4*>(a.pos + gb + L.gofs) = *reinterpret_cast<const float4*>(sSt + L.rofs);
+            *reinterpret_cast<float4*>(a.vel + gb + L.gofs) =
+                *reinterpret_cast<const float4*>(sSt + kStageStride + L.rofs);
+            if (NST > 2)
+                *reinterpret_cast<float4*>(a.actions + gb + L.gofs) =
+                    *reinterpret_cast<const float4*>(sSt + 2 * kStageStride + L.rofs);
+        }
+    } else {
+        store_tile_generic(a.pos, a.vel, a.actions, NST, a.B, T, D, L.NTW, sSt, lane, b0, rt, rows);
+    }
+}
+
+// ---- tile-major ------------------------------------------------------------------------------------------------
+template <int MP, int CT, int KM>
+__global__ void __launch_bounds__(256) k_traj_tiles(const TrajArgs a, const ActArgs act) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * kStageFloats];
+    static_assert(MP != MPK_MP_DMP, "dmp runs in k_traj_stream");
+    constexpr bool ACT = CT >= 0;
+    constexpr int NOUT = MP == MPK_MP_PRODMP ? 2 : 3;
+    constexpr int NST = 2 + (ACT ? 1 : 0);
+    const DevCfg& c = a.c;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform -> SGPR
+    const int KP = 4 * KM, TS = a.TS, D = c.D, T = c.T;
+    float* sSt = smem + wave * kStageFloats;
+    const LaneMap<KM> L = make_lane_map<MP, KM>(a, lane);
+    const int NRT = (T + 15) >> 4;
+    const int wid = blockIdx.x * 4 + wave, Wn = gridDim.x * 4;
+    const int rt = wid % NRT;             // Wn % NRT == 0: this wave owns row tile rt for every item
+    const int gstride = Wn / NRT;
+    int g = wid / NRT;
+    if (g >= a.G) return;
+    // basis rows of this row tile, MFMA A-fragment layout: lane (t = col, k = 4m + q)
+    float af[NOUT][KM];
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j)
+#pragma unroll
+        for (int m = 0; m < KM; ++m) af[j][m] = a.A[(size_t)(j * KP + 4 * m + L.q) * TS + rt * 16 + L.col];
+    float dtd[4] = {1.f, 1.f, 1.f, 1.f};
+    if (MP == MPK_MP_PROMP) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dtd[r] = a.aux[rt * 16 + 4 * L.q + r];
+    }
+    const int rows = min(16, T - rt * 16);
+    if (ACT) park_gains(act, lane, L.d, sSt);
+    const double* sg = reinterpret_cast<const double*>(sSt + 3 * kStageStride) + (L.dvalid ? L.d : 0);
+
+    float xb[KM];
+    GroupIn<KM> cur = load_group<MP, ACT, KM>(a, L, g);
+    finish_group<KM>(L, cur, xb);
+    double cp = cur.cp, cv = cur.cv;
+    while (g < a.G) {
+        // 1. issue the NEXT group's loads (consumed at the bottom of this iteration)
+        const int gn = g + gstride;
+        const GroupIn<KM> nxt = load_group<MP, ACT, KM>(a, L, gn < a.G ? gn : g);
+        // 2. matrix cores: C[t, col] = sum_k A[t, k] * X[k, col]
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < KM; ++m) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][m], xb[m], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][m], xb[m], acc1, 0, 0, 0);
+            if (NOUT > 2) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[NOUT > 2 ? 2 : 0][m], xb[m], acc2, 0, 0, 0);
+        }
+        // 3. epilogue -> LDS transpose; 4. coalesced stores
+        if (L.dvalid) tile_epilogue<MP, CT>(acc0, acc1, acc2, dtd, cp, cv, sg, sSt, L.wofs, D);
+        __builtin_amdgcn_wave_barrier();
+        tile_store<NST, KM>(a, L, sSt, lane, g * L.NTW, rt, rows);
+        __builtin_amdgcn_wave_barrier();
+        // 5. finish the prefetched fragments for the next iteration
+        finish_group<KM>(L, nxt, xb);
+        cp = nxt.cp; cv = nxt.cv;
+        g = gn;
+    }
+}
+
+// ---- episode-major ---------------------------------------------------------------------------------------------
+template <int MP, int CT, int KM>
+__global__ void __launch_bounds__(256) k_traj_stream(const TrajArgs a, const ActArgs act) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * kStageFloats];
+    extern __shared__ __attribute__((aligned(16))) float sTab[];   // [NOUT][KP][TS] basis rows + [TS] aux
+    constexpr bool ACT = CT >= 0;
     constexpr int NOUT = MP == MPK_MP_PRODMP ? 2 : (MP == MPK_MP_PROMP ? 3 : 1);
     constexpr int NST = 2 + (ACT ? 1 : 0);
     const DevCfg& c = a.c;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int KP = c.KP, KM = KP >> 2, TS = a.TS, D = c.D, T = c.T, P = c.P, B = a.B;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int KP = 4 * KM, TS = a.TS, D = c.D, T = c.T, B = a.B;
     const int SEG = 16 * D;
-    const int sh = a.sh, DP = 1 << sh, NTW = 16 >> sh;
-
-    float* sA = smem;                               // [NOUT][KP][TS]
-    float* sAux = sA + NOUT * KP * TS;              // [TS]
-    float* sW = sAux + TS + wave * a.wave_floats;   // wave-private
-    float* sX = sW;                                 // [KP][17]
-    float* sSt = sW + a.xtile_floats;               // [NTW][NST][SEG]
-    float* sF = sSt + NTW * NST * SEG;              // DMP only: [NTW][SEG]
-
+    float* sSt = smem + wave * kStageFloats;
+    float* sA = sTab;
+    float* sAux = sTab + NOUT * KP * TS;
     {   // stage the shared basis tables through LDS once per workgroup
         const float4* src = reinterpret_cast<const float4*>(a.A);
         float4* dst = reinterpret_cast<float4*>(sA);
         const int n4 = (NOUT * KP * TS) >> 2;
-        for (int i = tid; i < n4; i += 256) dst[i] = src[i];
+        for (int i = threadIdx.x; i < n4; i += 256) dst[i] = src[i];
         const float4* s2 = reinterpret_cast<const float4*>(a.aux);
         float4* d2 = reinterpret_cast<float4*>(sAux);
-        for (int i = tid; i < (TS >> 2); i += 256) d2[i] = s2[i];
+        for (int i = threadIdx.x; i < (TS >> 2); i += 256) d2[i] = s2[i];
     }
     __syncthreads();
-
-    // ---- lane constants -------------------------------------------------------------------------------
-    const int col = lane & 15, q = lane >> 4;
-    const int bl = col >> sh, d = col & (DP - 1);
-    const bool dvalid = d < D;
-
-    // X-tile element(s) this lane fetches: e -> (column xc, k xk), consecutive lanes walk k (contiguous params)
-    int xkind[4], xoff[4], xbl[4], xd[4], xlds[4];
-    float xscale[4];
-    const unsigned inv = 65536u / (unsigned)KP + 1u;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int e = lane + 64 * i;
-        int kind = XK_ZERO, off = 0;
-        float scale = 1.0f;
-        const int xc = (int)(((unsigned)e * inv) >> 16);
-        const int xk = e - xc * KP;
-        const int ebl = xc >> sh, ed = xc & (DP - 1);
-        if (e < 16 * KP && ed < D) {
-            if (MP == MPK_MP_PRODMP) {
-                const int nb = c.nb;
-                if (xk < nb) {
-                    if (!c.disable_weights) { kind = XK_PARAM; off = c.off + ed * c.Kloc + xk; scale = c.scale[xk]; }
-                } else if (xk == nb) {
-                    kind = XK_GOAL; off = c.off + ed * c.Kloc + (c.disable_weights ? 0 : nb); scale = c.scale[nb];
-                } else if (xk == nb + 1) {
-                    kind = XK_IPOS;
-                } else if (xk == nb + 2) {
-                    kind = XK_IVEL;
-                }
-            } else if (MP == MPK_MP_PROMP) {
-                if (xk < c.nb) { kind = XK_PARAM; off = c.off + ed * c.Kloc + xk; }
-                else if (xk == c.nb && c.KT > c.nb) kind = XK_IPOS;
-            } else {
-                if (xk < c.nb) { kind = XK_PARAM; off = c.off + ed * c.Kloc + xk; scale = c.ws; }
-            }
-        }
-        xkind[i] = kind; xoff[i] = off; xbl[i] = ebl; xd[i] = ed; xscale[i] = scale;
-        xlds[i] = e < 16 * KP ? xk * 17 + xc : -1;
-    }
-    auto loadx = [&](int i, int b0) -> float {
-        const int b = b0 + xbl[i];
-        if (xkind[i] == XK_ZERO || b >= B) return 0.0f;
-        switch (xkind[i]) {
-            case XK_PARAM: return a.params[(size_t)b * P + xoff[i]] * xscale[i];
-            case XK_GOAL: {
-                float v = c.disable_goal ? 0.0f : a.params[(size_t)b * P + xoff[i]] * xscale[i];
-                if (c.relative_goal) v = v + a.init_pos[(size_t)b * D + xd[i]];
-                return v;
-            }
-            case XK_IPOS: return a.init_pos[(size_t)b * D + xd[i]];
-            default: return a.init_vel[(size_t)b * D + xd[i]] * c.tau;
-        }
-    };
-
-    // store mapping: float4 chunk i of the staging area -> (segment, chunk in segment)
-    const int seg4 = SEG >> 2;               // float4 per full segment (= 4*D)
-    const int total4 = NTW * NST * seg4;     // <= 192
-    int sseg[3], soff[3];
-    {
-        const unsigned inv2 = 65536u / (unsigned)seg4 + 1u;
-#pragma unroll
-        for (int it = 0; it < 3; ++it) {
-            const int i = lane + 64 * it;
-            const int s = (int)(((unsigned)i * inv2) >> 16);
-            sseg[it] = i < total4 ? s : -1;
-            soff[it] = i - s * seg4;
-        }
-    }
-
+    const LaneMap<KM> L = make_lane_map<MP, KM>(a, lane);
     const int NRT = (T + 15) >> 4;
-    const int gw = blockIdx.x * 4 + wave, gstride = gridDim.x * 4;
-    float xv[4];
-    if (gw < a.G) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xv[i] = loadx(i, gw * NTW);
-    }
+    // XCD-contiguous virtual block id (workgroup b runs on XCD b % 8): neighbouring episode groups share an L2
+    const int nb8 = gridDim.x >> 3;
+    const int vb = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * nb8 + (blockIdx.x >> 3) : blockIdx.x;
+    const int gstride = gridDim.x * 4;
+    int g = vb * 4 + wave;
+    if (g >= a.G) return;
+    if (ACT) park_gains(act, lane, L.d, sSt);
+    const double* sg = reinterpret_cast<const double*>(sSt + 3 * kStageStride) + (L.dvalid ? L.d : 0);
+    const float* ap = sA + L.q * TS + L.col;
 
-    for (int g = gw; g < a.G; g += gstride) {
-        const int b0 = g * NTW;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (xlds[i] >= 0) sX[xlds[i]] = xv[i];
+    float xb[KM];
+    GroupIn<KM> cur = load_group<MP, ACT, KM>(a, L, g);
+    finish_group<KM>(L, cur, xb);
+    double cp = cur.cp, cv = cur.cv;
+    while (g < a.G) {
+        const int b0 = g * L.NTW;
         const int gn = g + gstride;
-        if (gn < a.G) {  // prefetch the next group's parameters under this group's matrix work
-#pragma unroll
-            for (int i = 0; i < 4; ++i) xv[i] = loadx(i, gn * NTW);
-        }
-        const int b = b0 + bl;
-        const bool cvalid = dvalid && b < B;
-        double cp = 0.0, cv = 0.0;
-        if (ACT) {
-            if (cvalid) { cp = a.c_pos[(size_t)b * D + d]; cv = a.c_vel[(size_t)b * D + d]; }
-        }
-        float ey = 0.f, ez = 0.f, eg = 0.f;   // DMP Euler state (lanes q == 0)
+        const GroupIn<KM> nxt = load_group<MP, ACT, KM>(a, L, gn < a.G ? gn : g);
+        float ey = 0.f, ez = 0.f, eg = 0.f;
+        const bool eul = MP == MPK_MP_DMP && L.dvalid && L.q == 0 && b0 + L.bl < B;
         if (MP == MPK_MP_DMP) {
-            if (cvalid && q == 0) {
-                ey = a.init_pos[(size_t)b * D + d];
-                ez = a.init_vel[(size_t)b * D + d] * c.tau;
-                eg = a.params[(size_t)b * P + c.off + d * c.Kloc + c.nb] * c.gs;
+            if (eul) {
+                const int b = b0 + L.bl;
+                ey = a.init_pos[(size_t)b * D + L.d];
+                ez = a.init_vel[(size_t)b * D + L.d] * c.tau;
+                eg = a.params[(size_t)b * c.P + c.off + L.d * c.Kloc + c.nb] * c.gs;
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        float xb[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) xb[m] = m < KM ? sX[(4 * m + q) * 17 + col] : 0.0f;
-
         for (int rt = 0; rt < NRT; ++rt) {
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-            const float* ap = sA + q * TS + rt * 16 + col;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                if (m < KM) {
-                    const float* am = ap + (4 * m) * TS;
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[0], xb[m], acc0, 0, 0, 0);
-                    if (NOUT > 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[KP * TS], xb[m], acc1, 0, 0, 0);
-                    if (NOUT > 2) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[2 * KP * TS], xb[m], acc2, 0, 0, 0);
-                }
-            }
             const int rows = min(16, T - rt * 16);
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < KM; ++m) {
+                const float* am = ap + (4 * m) * TS + rt * 16;
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[0], xb[m], acc0, 0, 0, 0);
+                if (NOUT > 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[KP * TS], xb[m], acc1, 0, 0, 0);
+                if (NOUT > 2) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[2 * KP * TS], xb[m], acc2, 0, 0, 0);
+            }
             if (MP != MPK_MP_DMP) {
+                float dtd[4] = {1.f, 1.f, 1.f, 1.f};
+                if (MP == MPK_MP_PROMP) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int tl = 4 * q + r, t = rt * 16 + tl;
-                    if (cvalid && t < T) {
-                        const float p = acc0[r];
-                        float v;
-                        if (MP == MPK_MP_PRODMP) v = acc1[r] / c.tau;
-                        else v = (acc1[r] - acc2[r]) / sAux[t];
-                        sSt[(bl * NST + 0) * SEG + tl * D + d] = p;
-                        sSt[(bl * NST + 1) * SEG + tl * D + d] = v;
-                        if (ACT) {
-                            double u;
-                            if (act.controller_type == MPK_CTRL_MOTOR)
-                                u = act.pg[d] * ((double)p - cp) + act.dg[d] * ((double)v - cv);
-                            else if (act.controller_type == MPK_CTRL_POSITION) u = (double)p;
-                            else u = (double)v;
-                            u = fmin(fmax(u, act.lo[d]), act.hi[d]);
-                            sSt[(bl * NST + 2) * SEG + tl * D + d] = (float)u;
-                        }
-                    }
+                    for (int r = 0; r < 4; ++r) dtd[r] = sAux[rt * 16 + 4 * L.q + r];
                 }
+                if (L.dvalid) tile_epilogue<MP, CT>(acc0, acc1, acc2, dtd, cp, cv, sg, sSt, L.wofs, D);
             } else {
-                if (cvalid) {
+                // DMP: forcing tile -> LDS, then explicit Euler in scaled time on lanes (q == 0), serial in t;
+                // one rounding per op (no FMA), first sample = initial condition
+                float* sF = sSt + 2 * kStageStride;
+                if (L.dvalid) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sF[bl * SEG + (4 * q + r) * D + d] = acc0[r];
+                    for (int r = 0; r < 4; ++r) sF[L.wofs + r * D] = acc0[r];
                 }
                 __builtin_amdgcn_wave_barrier();
-                if (cvalid && q == 0) {
-                    // explicit Euler in scaled time, one rounding per op (no FMA), first sample = initial condition
+                if (eul) {
                     for (int tl = 0; tl < rows; ++tl) {
                         const int t = rt * 16 + tl;
-                        sSt[(bl * 2 + 0) * SEG + tl * D + d] = ey;
-                        sSt[(bl * 2 + 1) * SEG + tl * D + d] = ez / c.tau;
+                        const int o = L.bl * SEG + tl * D + L.d;
+                        sSt[o] = ey;
+                        sSt[kStageStride + o] = ez / c.tau;
                         if (t < T - 1) {
-                            const float f = sF[bl * SEG + tl * D + d], ds = sAux[t];
+                            const float f = sF[o], ds = sAux[t];
                             const float t1 = eg - ey;
                             const float t2 = c.dmp_beta * t1;
                             const float t3 = t2 - ez;
@@ -413,43 +599,65 @@ __global__ void __launch_bounds__(256) k_traj_shared(const TrajArgs a, const Act
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            // coalesced stores: every (episode, output) segment of this row tile is contiguous in HBM
-            const int len = rows * D;
-#pragma unroll
-            for (int it = 0; it < 3; ++it) {
-                const int s = sseg[it];
-                if (s >= 0) {
-                    const int sb = s / NST, j = s - sb * NST;
-                    const int bb = b0 + sb, w4 = soff[it] * 4;
-                    if (bb < B && w4 < len) {
-                        float* outp = j == 0 ? a.pos : (j == 1 ? a.vel : a.actions);
-                        float* gp = outp + ((size_t)bb * T + rt * 16) * D + w4;
-                        const float4 val = *reinterpret_cast<const float4*>(sSt + s * SEG + w4);
-                        if (a.vec_ok && w4 + 4 <= len) {
-                            *reinterpret_cast<float4*>(gp) = val;
-                        } else {
-                            const float vv[4] = {val.x, val.y, val.z, val.w};
-                            for (int e = 0; e < 4 && w4 + e < len; ++e) gp[e] = vv[e];
-                        }
-                    }
-                }
-            }
+            tile_store<NST, KM>(a, L, sSt, lane, b0, rt, rows);
             __builtin_amdgcn_wave_barrier();
         }
+        finish_group<KM>(L, nxt, xb);
+        cp = nxt.cp; cv = nxt.cv;
+        g = gn;
     }
 }
 
-template <int MP, bool ACT>
-static int launch_traj_shared_t(const TrajArgs& ta, const ActArgs& aa, int blocks, size_t lds, void* stream) {
-    auto kern = k_traj_shared<MP, ACT>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return MPK_EHIP; }
+template <int MP, int CT>
+static int launch_traj_t(const TrajArgs& ta, const ActArgs& aa, bool stream_mode, int blocks, size_t lds,
+                         void* stream) {
+    const dim3 g(blocks), b(256);
+    hipStream_t s = (hipStream_t)stream;
+    const int km = ta.c.KP / 4;
+    if (stream_mode) {
+        switch (km) {
+            case 1: hipLaunchKernelGGL((k_traj_stream<MP, CT, 1>), g, b, lds, s, ta, aa); break;
+            case 2: hipLaunchKernelGGL((k_traj_stream<MP, CT, 2>), g, b, lds, s, ta, aa); break;
+            case 3: hipLaunchKernelGGL((k_traj_stream<MP, CT, 3>), g, b, lds, s, ta, aa); break;
+            default: hipLaunchKernelGGL((k_traj_stream<MP, CT, 4>), g, b, lds, s, ta, aa); break;
+        }
+    } else {
+        if constexpr (MP != MPK_MP_DMP) {
+            switch (km) {
+                case 1: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 1>), g, b, 0, s, ta, aa); break;
+                case 2: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 2>), g, b, 0, s, ta, aa); break;
+                case 3: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 3>), g, b, 0, s, ta, aa); break;
+                default: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 4>), g, b, 0, s, ta, aa); break;
+            }
+        }
     }
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, (hipStream_t)stream, ta, aa);
     MPK_LAUNCH_CHECK();
     return MPK_OK;
+}
+
+template <int MP>
+static int launch_traj_ct(const TrajArgs& ta, const ActArgs& aa, int ct, bool stream_mode, int blocks, size_t lds,
+                          void* stream) {
+    if constexpr (MP != MPK_MP_DMP) {
+        switch (ct) {
+            case MPK_CTRL_MOTOR: return launch_traj_t<MP, MPK_CTRL_MOTOR>(ta, aa, stream_mode, blocks, lds, stream);
+            case MPK_CTRL_VELOCITY: return launch_traj_t<MP, MPK_CTRL_VELOCITY>(ta, aa, stream_mode, blocks, lds, stream);
+            case MPK_CTRL_POSITION: return launch_traj_t<MP, MPK_CTRL_POSITION>(ta, aa, stream_mode, blocks, lds, stream);
+            default: break;
+        }
+    }
+    return launch_traj_t<MP, -1>(ta, aa, stream_mode, blocks, lds, stream);
+}
+
+// 0 = automatic, 1 = force tile-major, 2 = force episode-major (MPK_MAPPING environment variable, for A/B runs)
+static int mapping_override() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MPK_MAPPING");
+        v = e ? atoi(e) : 0;
+        if (v < 0 || v > 2) v = 0;
+    }
+    return v;
 }
 
 int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* params, const float* init_pos,
@@ -469,35 +677,55 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     const bool act = actions != nullptr;
     const int nst = 2 + (act ? 1 : 0);
     const int SEG = 16 * c.D;
-    ta.xtile_floats = (c.KP * 17 + 3) / 4 * 4;
-    ta.wave_floats = ta.xtile_floats + NTW * nst * SEG + (c.mp_type == MPK_MP_DMP ? NTW * SEG : 0);
+    ta.inv_seg4 = 65536u / (unsigned)(SEG / 4) + 1u;
     auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     ta.vec_ok = ((c.T * c.D) % 4 == 0) && aligned16(pos) && aligned16(vel) && (!act || aligned16(actions));
     ActArgs aa{};
+    int ct = -1;
     if (act) {
-        aa.controller_type = rc->controller_type;
+        ct = rc->controller_type;
         for (int d = 0; d < c.D; ++d) { aa.pg[d] = rc->pg[d]; aa.dg[d] = rc->dg[d]; aa.lo[d] = rc->lo[d]; aa.hi[d] = rc->hi[d]; }
     }
-    const size_t lds = ((size_t)st.n_out * c.KP * st.TS + st.TS + 4 * (size_t)ta.wave_floats) * sizeof(float);
-    if (lds > 160 * 1024) { set_error("trajectory too long for the shared-table kernel's LDS budget"); return MPK_EINVAL; }
-    int per_cu = (int)((160 * 1024) / lds);
-    per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
-    int blocks = (ta.G + 3) / 4;
-    const int cap = num_cu * per_cu;
-    if (blocks > cap) blocks = cap;
+    const int NRT = (c.T + 15) / 16;
+    const long max_waves = (long)num_cu * 32;     // 8 waves per SIMD resident
+    // work decomposition: episode-major once the outputs stop being cache resident (or when it is the only option)
+    const size_t table_bytes = ((size_t)st.n_out * c.KP * st.TS + st.TS) * sizeof(float);
+    const double out_bytes = (double)B * c.T * c.D * 4.0 * nst;
+    bool stream_mode = c.mp_type == MPK_MP_DMP || out_bytes > 96.0 * 1024 * 1024;
+    const int ov = mapping_override();
+    if (c.mp_type != MPK_MP_DMP && ov == 1) stream_mode = false;
+    if (ov == 2) stream_mode = true;
+    if (stream_mode && table_bytes + 4 * kStageFloats * sizeof(float) > 64 * 1024) {
+        if (c.mp_type == MPK_MP_DMP) { set_error("trajectory too long for the episode-major kernel's LDS budget"); return MPK_EINVAL; }
+        stream_mode = false;
+    }
+    int blocks;
+    size_t lds = 0;
+    if (stream_mode) {
+        lds = table_bytes;
+        const long waves = ta.G < max_waves ? ta.G : max_waves;
+        blocks = (int)((waves + 3) / 4);
+        if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;                  // XCD-contiguous remap needs a multiple of 8
+    } else {
+        const long items = (long)ta.G * NRT;
+        const long ipw = (items + max_waves - 1) / max_waves;            // items per wave, balanced
+        const long waves = (items + ipw - 1) / ipw;
+        blocks = (int)((waves + 3) / 4);
+        blocks = (blocks + NRT - 1) / NRT * NRT;                         // #waves % NRT == 0
+    }
     if (blocks < 1) blocks = 1;
     switch (c.mp_type) {
         case MPK_MP_PRODMP:
-            if (act) { *kernel_name = "k_traj_shared<prodmp,act>"; return launch_traj_shared_t<MPK_MP_PRODMP, true>(ta, aa, blocks, lds, stream); }
-            *kernel_name = "k_traj_shared<prodmp>";
-            return launch_traj_shared_t<MPK_MP_PRODMP, false>(ta, aa, blocks, lds, stream);
+            *kernel_name = stream_mode ? (act ? "k_traj_stream<prodmp,act>" : "k_traj_stream<prodmp>")
+                                       : (act ? "k_traj_tiles<prodmp,act>" : "k_traj_tiles<prodmp>");
+            return launch_traj_ct<MPK_MP_PRODMP>(ta, aa, ct, stream_mode, blocks, lds, stream);
         case MPK_MP_PROMP:
-            if (act) { *kernel_name = "k_traj_shared<promp,act>"; return launch_traj_shared_t<MPK_MP_PROMP, true>(ta, aa, blocks, lds, stream); }
-            *kernel_name = "k_traj_shared<promp>";
-            return launch_traj_shared_t<MPK_MP_PROMP, false>(ta, aa, blocks, lds, stream);
+            *kernel_name = stream_mode ? (act ? "k_traj_stream<promp,act>" : "k_traj_stream<promp>")
+                                       : (act ? "k_traj_tiles<promp,act>" : "k_traj_tiles<promp>");
+            return launch_traj_ct<MPK_MP_PROMP>(ta, aa, ct, stream_mode, blocks, lds, stream);
         default:
-            *kernel_name = "k_traj_shared<dmp>";
-            return launch_traj_shared_t<MPK_MP_DMP, false>(ta, aa, blocks, lds, stream);
+            *kernel_name = "k_traj_stream<dmp>";
+            return launch_traj_ct<MPK_MP_DMP>(ta, aa, -1, true, blocks, lds, stream);
     }
 }
 
@@ -542,23 +770,23 @@ __global__ void __launch_bounds__(256) k_traj_rows(const RowArgs a) {
         for (int e = tid; e < D * KT; e += nt) {
             const int dd = e / KT, k = e - dd * KT;
             float v = 0.0f;
+            // RAW parameters / boundary conditions: every scale lives in the basis rows (see prodmp_col)
             if (MP == MPK_MP_PRODMP) {
                 const int nb = c.nb;
                 if (k < nb) {
-                    if (!c.disable_weights) v = prm[c.off + dd * c.Kloc + k] * c.scale[k];
+                    if (!c.disable_weights) v = prm[c.off + dd * c.Kloc + k];
                 } else if (k == nb) {
-                    if (!c.disable_goal) v = prm[c.off + dd * c.Kloc + (c.disable_weights ? 0 : nb)] * c.scale[nb];
-                    if (c.relative_goal) v = v + a.init_pos[(size_t)b * D + dd];
+                    if (!c.disable_goal) v = prm[c.off + dd * c.Kloc + (c.disable_weights ? 0 : nb)];
                 } else if (k == nb + 1) {
                     v = a.init_pos[(size_t)b * D + dd];
                 } else {
-                    v = a.init_vel[(size_t)b * D + dd] * tau;
+                    v = a.init_vel[(size_t)b * D + dd];
                 }
             } else if (MP == MPK_MP_PROMP) {
                 if (k < c.nb) v = prm[c.off + dd * c.Kloc + k];
                 else v = a.init_pos[(size_t)b * D + dd];
             } else {
-                v = prm[c.off + dd * c.Kloc + k] * c.ws;
+                v = prm[c.off + dd * c.Kloc + k];
             }
             sX[e] = v;
         }
@@ -577,7 +805,7 @@ __global__ void __launch_bounds__(256) k_traj_rows(const RowArgs a) {
                 prodmp_xi(c, bc, idx, xi);
                 for (int k = 0; k < KT; ++k) {
                     float h, hv;
-                    prodmp_col(c, bc, idx, xi, k, &h, &hv);
+                    prodmp_col(c, bc, idx, xi, k, (double)tau, &h, &hv);
                     sH[t * KT + k] = h;
                     sH[(T + t) * KT + k] = hv;
                 }
@@ -586,7 +814,7 @@ __global__ void __launch_bounds__(256) k_traj_rows(const RowArgs a) {
             for (int t = tid; t < T; t += nt) {
                 const float time = c.base_times[t] + it;
                 const double x = phase_f64(c, time, tau, delay, nullptr);
-                rbf_cols(c, x, MP == MPK_MP_PROMP ? (double)c.ws : x, sH + t * KT, 1);
+                rbf_cols(c, x, MP == MPK_MP_PROMP ? (double)c.ws : x * (double)c.ws, sH + t * KT, 1);
                 if (MP == MPK_MP_PROMP) {
                     if (KT > c.nb) sH[t * KT + c.nb] = 1.0f;
                     sT[t] = time;
@@ -607,7 +835,7 @@ __global__ void __launch_bounds__(256) k_traj_rows(const RowArgs a) {
             }
             if (MP == MPK_MP_PRODMP) {
                 a.pos[(size_t)b * T * D + e] = accp;
-                a.vel[(size_t)b * T * D + e] = accv / tau;
+                a.vel[(size_t)b * T * D + e] = accv;
             } else {
                 sP[e] = accp;
                 if (MP == MPK_MP_PROMP) a.pos[(size_t)b * T * D + e] = accp;

@@ -93,7 +93,7 @@ def test_shared_phase_matches_oracle(name, B, init_time):
     params, ip, iv = inputs(pc, bc, tc, B, seed=B)
     pos, vel = eng.trajectory(params, ip, iv, init_time)
     torch.cuda.synchronize()
-    assert eng.last_kernel().startswith("k_traj_shared")
+    assert eng.last_kernel().startswith("k_traj_")
     for dtype in (np.float64, np.float32):
         rp, rv = O.get_trajectory(pc, bc, tc, params, duration, dt, init_time, ip, iv, dtype=dtype)
         close(pos.cpu().numpy(), rp, f"{name} pos vs oracle {dtype.__name__}")

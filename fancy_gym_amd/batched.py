@@ -1,0 +1,164 @@
+"""
+BatchedBlackBox -- the batched sibling of BlackBoxWrapper: B independent episodes of ONE movement-primitive
+configuration evaluated at once on one GPU (the reference always runs B = 1: black_box_wrapper.py:96-120,175-203).
+
+One ``step(params[B, P])`` does what ``BlackBoxWrapper.step`` does for every episode:
+    plan      get_trajectory: clip -> (frozen tau/delay) -> boundary conditions -> (pos, vel)[B, T, D]     [HIP]
+    validity  optional joint-limit / bound check (raw_interface_wrapper.py:55-72)                         [HIP]
+    schedule  integer replanning bookkeeping for the schedule ``t % every == 0``                            [HIP]
+    execute   tracking controller + plant loop for the executed steps (plants that live on the GPU)        [HIP]
+and returns everything as CUDA tensors.  Environments that cannot live on the GPU (MuJoCo) consume ``des_pos`` /
+``des_vel`` on the host instead (``plant=None``).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from .black_box.controller.base_controller import BaseController
+from .engine import RolloutSpec, TrajectoryEngine
+from .mp.traj import MPInterface
+
+
+class BatchedBlackBox:
+
+    def __init__(self, trajectory_generator: MPInterface, tracking_controller: BaseController, num_envs: int,
+                 dt: float, duration: float, act_low=-math.inf, act_high=math.inf,
+                 plant: Optional[str] = "double_integrator", replanning_every: Optional[int] = None,
+                 max_planning_times: Union[int, float] = math.inf, condition_on_desired: bool = False,
+                 max_episode_steps: Optional[int] = None, pos_limits: Optional[Sequence] = None,
+                 check_tau_delay: bool = False, device=None):
+        """
+        trajectory_generator / tracking_controller: the objects the factories return (``get_trajectory_generator``,
+        ``get_controller``).  ``replanning_every = n`` is the schedule ``lambda pos, vel, obs, action, t: t % n == 0``
+        (e.g. envs/mujoco/box_pushing/mp_wrapper.py:89).  ``pos_limits = (low[D], high[D])`` enables the batched
+        validity check (envs/mujoco/table_tennis/table_tennis_env.py:303-309).
+        """
+        self.traj_gen = trajectory_generator
+        self.tracking_controller = tracking_controller
+        self.B, self.dt, self.duration = int(num_envs), float(dt), float(duration)
+        if device is not None:
+            self.traj_gen._device = device
+        self.traj_gen.set_duration(self.duration, self.dt)
+        self.engine: TrajectoryEngine = self.traj_gen.engine()
+        self.device = self.engine.device
+        self.D, self.T = self.engine.num_dof, self.engine.num_steps
+        self.horizon = int(max_episode_steps) if max_episode_steps is not None else self.T
+        self.do_replanning = replanning_every is not None
+        self.every = int(replanning_every) if self.do_replanning else self.horizon + 1
+        self.max_planning_times = max_planning_times
+        self.condition_on_desired = bool(condition_on_desired)
+        self.plant = plant
+        self.pos_limits = pos_limits
+        self.check_tau_delay = bool(check_tau_delay)
+        ctype = getattr(tracking_controller, "device_type", None)
+        self.spec = None
+        if plant is not None:
+            if ctype is None:
+                raise ValueError(f"{type(tracking_controller).__name__} has no device implementation; use plant=None "
+                                 f"and step the environments on the host")
+            self.spec = RolloutSpec(ctype, self.D, getattr(tracking_controller, "p_gains", 0.0),
+                                    getattr(tracking_controller, "d_gains", 0.0), act_low, act_high, plant=plant,
+                                    dt=self.dt)
+        phase = self.traj_gen.phase_gn
+        self.tau_bound = getattr(phase, "tau_bound", [-np.inf, np.inf])
+        self.delay_bound = getattr(phase, "delay_bound", [-np.inf, np.inf])
+        self._n_phase = int(phase.learn_tau) + int(phase.learn_delay)
+        i32 = dict(dtype=torch.int32, device=self.device)
+        self.traj_steps = torch.zeros(self.B, **i32)
+        self.plan_steps = torch.zeros(self.B, **i32)
+        self.done = torch.zeros(self.B, dtype=torch.uint8, device=self.device)
+        self.q = torch.zeros((self.B, self.D), dtype=torch.float64, device=self.device)
+        self.qd = torch.zeros_like(self.q)
+        self.condition_pos = None
+        self.condition_vel = None
+        self._frozen_phase = None
+        self._lockstep = 0          # traj_steps of every live episode while the schedule keeps them in lockstep
+
+    # ---- episode control ---------------------------------------------------------------------------------------------
+    def reset(self, init_pos=None, init_vel=None):
+        """start B new episodes from plant state (init_pos, init_vel) [B, D] (default zeros)"""
+        self.traj_steps.zero_(); self.plan_steps.zero_(); self.done.zero_()
+        z = torch.zeros((self.B, self.D), dtype=torch.float64, device=self.device)
+        self.q = z.clone() if init_pos is None else torch.as_tensor(init_pos, dtype=torch.float64,
+                                                                    device=self.device).expand(self.B, self.D).contiguous().clone()
+        self.qd = z.clone() if init_vel is None else torch.as_tensor(init_vel, dtype=torch.float64,
+                                                                     device=self.device).expand(self.B, self.D).contiguous().clone()
+        self.condition_pos = self.condition_vel = None
+        self._frozen_phase = None
+        self._lockstep = 0
+        self.traj_gen.reset()
+        return self.q, self.qd
+
+    @property
+    def current_pos(self) -> torch.Tensor:
+        return self.q
+
+    @property
+    def current_vel(self) -> torch.Tensor:
+        return self.qd
+
+    def params_bounds(self) -> np.ndarray:
+        return self.engine.params_bounds()
+
+    # ---- plan ----------------------------------------------------------------------------------------------------------
+    def get_trajectory(self, params) -> Dict[str, torch.Tensor]:
+        params = torch.as_tensor(params, dtype=torch.float32, device=self.device)
+        if params.shape != (self.B, self.engine.num_params):
+            raise ValueError(f"params must be [{self.B}, {self.engine.num_params}], got {tuple(params.shape)}")
+        if self._n_phase:
+            # tau / delay are frozen by the first plan of an episode (mp_pytorch 'finalize'; pinned by
+            # test/test_replanning_sequencing.py:231-335): later plans reuse them
+            if self._frozen_phase is None:
+                lo = torch.as_tensor(self.engine.params_bounds(), device=self.device)
+                head = torch.minimum(torch.maximum(params[:, :self._n_phase], lo[0, :self._n_phase]),
+                                     lo[1, :self._n_phase])
+                self._frozen_phase = head.clone()
+            params = params.clone()
+            params[:, :self._n_phase] = self._frozen_phase
+        cond_pos = self.condition_pos if self.condition_pos is not None else self.q.float()
+        cond_vel = self.condition_vel if self.condition_vel is not None else self.qd.float()
+        if self.do_replanning and self._lockstep is None:
+            init_time = (self.traj_steps.double() * self.dt).float()     # per-episode
+        else:
+            init_time = float(self._lockstep * self.dt) if self.do_replanning else 0.0
+        pos, vel = self.engine.trajectory(params, cond_pos, cond_vel, init_time)
+        return {"params": params, "des_pos": pos, "des_vel": vel}
+
+    # ---- plan + execute ----------------------------------------------------------------------------------------------
+    def step(self, params) -> Dict[str, torch.Tensor]:
+        out = self.get_trajectory(params)
+        pos, vel = out["des_pos"], out["des_vel"]
+        was_done = self.done.bool()
+        valid = torch.ones(self.B, dtype=torch.bool, device=self.device)
+        if self.pos_limits is not None:
+            valid = self.engine.traj_validity(pos, self.pos_limits[0], self.pos_limits[1],
+                                              out["params"] if self.check_tau_delay else None,
+                                              self.tau_bound if self.check_tau_delay else None,
+                                              self.delay_bound if self.check_tau_delay else None)
+        if not bool(valid.all()):
+            # invalid plans terminate their episode without executing a step (black_box_wrapper.py:169-172)
+            self.done |= (~valid).to(torch.uint8)
+        mpt = self.max_planning_times if math.isfinite(self.max_planning_times) else 2 ** 31 - 1
+        seg = self.engine.replan_advance(self.traj_steps, self.plan_steps, self.done, self.every, int(mpt),
+                                         self.horizon)
+        out.update(valid=valid, trajectory_length=seg, done=self.done.bool(), terminated=~valid & ~was_done,
+                   truncated=self.done.bool() & valid)
+        if self.spec is not None:
+            out["step_actions"] = self.engine.pd_rollout(self.spec, pos, vel, self.q, self.qd, n_steps=seg)
+        if self.condition_on_desired:
+            last = (seg.long() - 1).clamp_(min=0)[:, None, None].expand(-1, 1, self.D)
+            self.condition_pos = pos.gather(1, last)[:, 0].contiguous()
+            self.condition_vel = vel.gather(1, last)[:, 0].contiguous()
+        if self.do_replanning and self._lockstep is not None:
+            live = ~self.done.bool() | ~was_done
+            s = seg[live]
+            if s.numel() and bool((s == s[0]).all()) and bool(valid.all()):
+                self._lockstep += int(s[0])
+            else:
+                self._lockstep = None      # episodes drifted apart: per-episode init_time from now on
+        out.update(current_pos=self.q, current_vel=self.qd)
+        return out

@@ -162,8 +162,8 @@ def linear_left_bound(times: Array, tau, delay, dtype=np.float32) -> Array:
 
 def phase(pc: PhaseCfg, times: Array, tau=None, delay=None, dtype=np.float32) -> Array:
     """bounded phase: linear -> clip(s,0,1); exp -> exp(-alpha_phase * max(s,0))."""
-    tau = pc.tau if tau is None else tau
-    delay = pc.delay if delay is None else delay
+    tau = _q(pc.tau, dtype) if tau is None else tau
+    delay = _q(pc.delay, dtype) if delay is None else delay
     if pc.phase_generator_type == "linear":
         return np.clip(linear_unbound(times, tau, delay, dtype), dtype(0), dtype(1)).astype(dtype)
     if pc.phase_generator_type == "exp":
@@ -172,8 +172,8 @@ def phase(pc: PhaseCfg, times: Array, tau=None, delay=None, dtype=np.float32) ->
 
 
 def unbound_phase(pc: PhaseCfg, times: Array, tau=None, delay=None, dtype=np.float32) -> Array:
-    tau = pc.tau if tau is None else tau
-    delay = pc.delay if delay is None else delay
+    tau = _q(pc.tau, dtype) if tau is None else tau
+    delay = _q(pc.delay, dtype) if delay is None else delay
     s = linear_unbound(times, tau, delay, dtype)
     if pc.phase_generator_type == "linear":
         return s

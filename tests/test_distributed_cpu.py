@@ -1,0 +1,71 @@
+"""
+CPU suite, part 3: the N > 1 path (episode sharding + the single all-gather) with world_size 2 on the gloo backend.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, B, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from fancy_gym_amd import distributed as D
+    r, w, _ = D.init("gloo")
+    assert (r, w) == (rank, world)
+    T, Dof = 6, 3
+    full = torch.arange(B * T * Dof, dtype=torch.float32).reshape(B, T, Dof)
+    a, b = D.shard_bounds(B, rank, world)
+    pos_local = D.shard(full)                       # stands in for the trajectories this rank generated
+    assert pos_local.shape[0] == b - a
+    vel_local = -pos_local
+    pos_all, vel_all = D.gather_trajectories(pos_local, vel_local, B)
+    ok = torch.equal(pos_all, full) and torch.equal(vel_all, -full)
+    rows = D.all_gather_rows(torch.full((b - a, 2), float(rank)), B)
+    ok = ok and rows.shape == (B, 2) and float(rows[:a + 1].min()) >= 0
+    expected = torch.cat([torch.full((D.shard_bounds(B, k, world)[1] - D.shard_bounds(B, k, world)[0], 2), float(k))
+                          for k in range(world)])
+    ok = ok and torch.equal(rows, expected)
+    dist.barrier()
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [8, 7, 1])
+def test_shard_and_all_gather_world2(B):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, B, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]
+
+
+def test_shard_bounds_cover_the_batch_exactly():
+    from fancy_gym_amd.distributed import shard_bounds
+    for B in (0, 1, 7, 8, 4096, 65536, 65537):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(B, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,441 @@
+"""
+GPU suite, part 2: the drop-in surface (BlackBoxWrapper / make_bb on the reference's toy fixture env), the device
+rollout kernels against the oracle (bit-exact in float64), the integer replanning state (bit-exact), the batched
+validity check, the committed golden fixtures, and size-independent properties at BASELINE's full batch sizes.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fancy_gym_amd
+from fancy_gym_amd import BatchedBlackBox, RolloutSpec
+from fancy_gym_amd.black_box.factory import (get_basis_generator, get_controller, get_phase_generator,
+                                             get_trajectory_generator)
+from oracle import mp_oracle as O
+from tests.golden.make_golden import CONFIGS
+from tests.test_gpu_trajectory import CFG2, CFG3, CFG4, CFG5, close, fd_atol, inputs, make_engine
+from tests.toy_env import DoubleIntegratorWrapper, ToyWrapper, register_toys
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+SEED = 1
+PG = 0.01 * np.array([120., 120., 120., 120., 50., 30., 10.])
+DG = 0.01 * np.array([10., 10., 10., 10., 6., 5., 3.])
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _toys():
+    register_toys()
+
+
+def toy_bb(mp_type, bb=None, phase=None, basis=None, traj=None, env_id="toy-v0", wrapper=ToyWrapper, **kw):
+    basis_type = "prodmp" if mp_type == "prodmp" else "rbf"
+    phase_type = "exp" if mp_type in ("prodmp", "dmp") else "linear"
+    return fancy_gym_amd.make_bb(env_id, [wrapper], dict(bb or {}),
+                                 {"trajectory_generator_type": mp_type, **(traj or {})}, {"controller_type": "motor"},
+                                 {"phase_generator_type": phase_type, **(phase or {})},
+                                 {"basis_generator_type": basis_type, **(basis or {})}, **kw)
+
+
+# ---- golden fixtures through the HIP path ----------------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_hip_path_reproduces_golden(name):
+    cfg = CONFIGS[name]
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    pc, bc, tc, dt = cfg["pc"], cfg["bc"], cfg["tc"], cfg["dt"]
+    eng = make_engine(pc, bc, tc, dt, cfg["duration"])
+    fd = tc.trajectory_generator_type == "promp"
+    for k, it in enumerate(z["init_times"]):
+        pos, vel = eng.trajectory(z["params"], z["init_pos"], z["init_vel"], float(it))
+        for ref_p, ref_v in ((z[f"pos32_{k}"], z[f"vel32_{k}"]), (z[f"tpos_{k}"], z[f"tvel_{k}"])):
+            close(pos.cpu().numpy(), ref_p, f"{name} pos")
+            close(vel.cpu().numpy(), ref_v, f"{name} vel", atol=fd_atol(ref_p, dt) if fd else 0.0)
+        if f"idx_{k}" in z.files and not (pc.learn_tau or pc.learn_delay):
+            idx, idxb = eng.prodmp_indices(float(it))
+            assert np.array_equal(idx, z[f"idx_{k}"][0]) and idxb == int(z[f"idxb_{k}"][0])
+
+
+# ---- BlackBoxWrapper on the reference's toy fixture ------------------------------------------------------------------
+@pytest.mark.parametrize("mp_type", ["promp", "dmp", "prodmp"])
+@pytest.mark.parametrize("verbose", [1, 2])
+def test_step_contract_and_verbosity(mp_type, verbose):
+    """test/test_black_box.py:88-135: info keys, trajectory_length == max_episode_steps"""
+    env = toy_bb(mp_type, {"verbose": verbose})
+    for _ in range(2):
+        env.reset(seed=SEED)
+        obs, reward, terminated, truncated, info = env.step(env.action_space.sample())
+        assert info["trajectory_length"] == env.spec.max_episode_steps == 50
+        assert truncated and not terminated and reward == 50.0
+        assert obs.shape == env.observation_space.shape
+        assert "toy" in info and len(info["toy"]) == 50
+        keys = ["positions", "velocities", "step_actions", "step_observations", "step_rewards"]
+        assert all((k in info) == (verbose >= 2) for k in keys)
+        if verbose >= 2:
+            assert info["positions"].shape == (50, 1) and info["positions"].dtype == np.float32
+            assert info["step_actions"].shape == (50, 1)
+
+
+@pytest.mark.parametrize("mp_type", ["promp", "dmp", "prodmp"])
+@pytest.mark.parametrize("agg", [np.sum, np.mean, np.median, lambda x: np.mean(x[::2])])
+def test_reward_aggregation(mp_type, agg):
+    """test/test_black_box.py:138-150"""
+    env = toy_bb(mp_type, {"reward_aggregation": agg})
+    env.reset(seed=SEED)
+    _, reward, *_ = env.step(env.action_space.sample())
+    assert reward == agg(np.ones(50, ))
+
+
+@pytest.mark.parametrize("mp_type", ["promp", "prodmp"])
+@pytest.mark.parametrize("tau", [0.25, 0.5, 0.75, 1])
+def test_learn_tau(mp_type, tau):
+    """test/test_black_box.py:219-261, exact plateau after tau for the linear phase"""
+    env = toy_bb(mp_type, {"verbose": 2}, {"learn_tau": True, "learn_delay": False})
+    env.reset(seed=SEED)
+    done = True
+    for _ in range(3):
+        if done:
+            env.reset(seed=SEED)
+        action = env.action_space.sample()
+        action[0] = tau
+        _, _, terminated, truncated, info = env.step(action)
+        done = terminated or truncated
+        assert info["trajectory_length"] == 50
+        n = int(np.round(tau / env.dt))
+        pos, vel = info["positions"].flatten(), info["velocities"].flatten()
+        if mp_type == "promp":
+            assert np.all(pos[n:] == pos[-1]) and np.all(vel[n:] == vel[-1])
+        assert np.all(pos[:n - 1] != pos[-1]) and np.all(vel[:n - 2] != vel[-1])
+
+
+@pytest.mark.parametrize("mp_type", ["promp", "prodmp"])
+@pytest.mark.parametrize("delay", [0, 0.25, 0.5, 0.75])
+def test_learn_delay(mp_type, delay):
+    """test/test_black_box.py:266-307, exact plateau before the delay"""
+    env = toy_bb(mp_type, {"verbose": 2}, {"learn_tau": False, "learn_delay": True})
+    env.reset(seed=SEED)
+    action = env.action_space.sample()
+    action[0] = delay
+    _, _, _, _, info = env.step(action)
+    n = int(np.round(delay / env.dt))
+    pos, vel = info["positions"].flatten(), info["velocities"].flatten()
+    assert np.all(pos[:max(1, n - 1)] == pos[0]) and np.all(vel[:max(1, n - 2)] == vel[0])
+    assert np.all(pos[max(1, n):] != pos[0]) and np.all(vel[max(1, n)] != vel[0])
+
+
+@pytest.mark.parametrize("mp_type", ["promp", "prodmp"])
+@pytest.mark.parametrize("tau,delay", [(0.25, 0.25), (0.5, 0.5), (0.25, 0.75), (0.75, 0.25)])
+def test_learn_tau_and_delay(mp_type, tau, delay):
+    """test/test_black_box.py:312-368: action[0] = tau, action[1] = delay"""
+    env = toy_bb(mp_type, {"verbose": 2}, {"learn_tau": True, "learn_delay": True})
+    env.reset(seed=SEED)
+    action = env.action_space.sample()
+    action[0], action[1] = tau, delay
+    _, _, _, _, info = env.step(action)
+    nt, nd = int(np.round(tau / env.dt)), int(np.round(delay / env.dt))
+    pos, vel = info["positions"].flatten(), info["velocities"].flatten()
+    if mp_type == "promp":
+        assert np.all(pos[nd + nt:] == pos[-1]) and np.all(vel[nd + nt:] == vel[-1])
+    assert np.all(pos[:nd - 1] == pos[0]) and np.all(vel[:nd - 2] == vel[0])
+    ap, av = pos[nd: nd + nt - 1], vel[nd: nd + nt - 2]
+    assert np.all(ap != pos[-1]) and np.all(ap != pos[0]) and np.all(av != vel[-1]) and np.all(av != vel[0])
+
+
+@pytest.mark.parametrize("mp_type", ["promp", "dmp"])
+def test_learn_sub_trajectories(mp_type):
+    """test/test_replanning_sequencing.py:64-109: plan length == round(tau / dt)"""
+    env = fancy_gym_amd.make_bb("toy-v0", [ToyWrapper], {"learn_sub_trajectories": True, "verbose": 2},
+                                {"trajectory_generator_type": mp_type}, {"controller_type": "motor"},
+                                {"phase_generator_type": "exp"}, {"basis_generator_type": "rbf"})
+    assert env.learn_sub_trajectories and env.traj_gen.learn_tau
+    env.reset(seed=SEED)
+    done = True
+    for _ in range(10):
+        if done:
+            env.reset(seed=SEED)
+        action = env.action_space.sample()
+        _, _, terminated, truncated, info = env.step(action)
+        done = terminated or truncated
+        n = info["trajectory_length"]
+        clipped = np.clip(action[0], *env.tau_bound)
+        if not done:
+            assert n == np.round(clipped / env.dt) == np.round(env.traj_gen.tau.numpy() / env.dt)
+        else:
+            assert n <= np.round(clipped / env.dt)
+
+
+@pytest.mark.parametrize("mp_type", ["promp", "prodmp"])
+@pytest.mark.parametrize("max_planning_times", [1, 2, 3, 4])
+@pytest.mark.parametrize("sub", [5, 10])
+def test_max_planning_times(mp_type, max_planning_times, sub):
+    """test/test_replanning_sequencing.py:165-194: #step() calls per episode == max_planning_times"""
+    env = toy_bb(mp_type, {"max_planning_times": max_planning_times, "verbose": 2,
+                           "replanning_schedule": lambda pos, vel, obs, action, t: t % sub == 0})
+    env.reset(seed=SEED)
+    done, n, lengths = False, 0, []
+    while not done:
+        _, _, terminated, truncated, info = env.step(env.action_space.sample())
+        done = terminated or truncated
+        lengths.append(info["trajectory_length"])
+        n += 1
+    assert n == max_planning_times
+    assert lengths == [k for _, k in O.replanning_segments(50, sub, max_planning_times)]
+
+
+@pytest.mark.parametrize("mp_type", ["promp", "prodmp"])
+@pytest.mark.parametrize("delay", [0.1, 0.25, 0.5])
+def test_replanning_with_learn_delay(mp_type, delay):
+    """test/test_replanning_sequencing.py:231-282: the delay plateau only shows in the first plan"""
+    sub, mpt = 10, 3
+    env = toy_bb(mp_type, {"max_planning_times": mpt, "verbose": 2,
+                           "replanning_schedule": lambda pos, vel, obs, action, t: t % sub == 0},
+                 {"learn_tau": False, "learn_delay": True})
+    env.reset(seed=SEED)
+    done, k = False, 0
+    while not done:
+        action = env.action_space.sample()
+        action[0] = delay
+        _, _, terminated, truncated, info = env.step(action)
+        done = terminated or truncated
+        n = int(np.round(delay / env.dt))
+        pos, vel = info["positions"].flatten(), info["velocities"].flatten()
+        if k == 0:
+            assert np.all(pos[:max(1, n - 1)] == pos[0]) and np.all(vel[:max(1, n - 2)] == vel[0])
+        elif n < sub:
+            assert np.all(pos[1:max(1, n - 1)] != pos[0])
+        assert np.all(pos[max(1, n):] != pos[0])
+        k += 1
+    assert k == mpt
+
+
+def test_single_episode_step_matches_oracle_on_a_closed_loop_plant():
+    """BlackBoxWrapper.step end to end on the double integrator: desired trajectory from the HIP kernels, host PD loop"""
+    env = fancy_gym_amd.make_bb("dint-v0", [DoubleIntegratorWrapper], {"verbose": 2},
+                                {"trajectory_generator_type": "prodmp"},
+                                {"controller_type": "motor", "p_gains": PG, "d_gains": DG},
+                                {"phase_generator_type": "exp", "tau": 1.5},
+                                {"basis_generator_type": "prodmp", "num_basis": 5, "alpha": 10,
+                                 "basis_bandwidth_factor": 2})
+    env.reset(seed=3)
+    q0, qd0 = env.get_wrapper_attr("current_pos"), env.get_wrapper_attr("current_vel")
+    action = env.action_space.sample()
+    _, ret, terminated, truncated, info = env.step(action)
+    pc, bc, tc, dt, dur = CFG2
+    rp, rv = O.get_trajectory(pc, bc, tc, action[None], dur, dt, 0.0, q0[None], qd0[None], dtype=np.float64)
+    close(info["positions"][None], rp, "positions")
+    close(info["velocities"][None], rv, "velocities")
+    # host controller on the device trajectory == oracle rollout on the same trajectory, bit for bit
+    ra, rq, rqd = O.rollout(info["positions"][None], info["velocities"][None], "motor", PG, DG, -1.0, 1.0,
+                            "double_integrator", dt, q0[None], qd0[None])
+    assert np.array_equal(info["step_actions"], ra[0])
+    assert np.array_equal(env.get_wrapper_attr("current_pos"), rq[0])
+    assert info["trajectory_length"] == 100 and truncated
+
+
+# ---- device rollout / fused actions ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("controller", ["motor", "position", "velocity"])
+@pytest.mark.parametrize("plant", ["static", "double_integrator"])
+@pytest.mark.parametrize("B", [1, 37, 1000])
+def test_pd_rollout_is_bit_exact_in_float64(controller, plant, B):
+    pc, bc, tc, dt, dur = CFG2
+    eng = make_engine(pc, bc, tc, dt, dur)
+    params, ip, iv = inputs(pc, bc, tc, B, seed=11)
+    pos, vel = eng.trajectory(params, ip, iv, 0.0)
+    rng = np.random.default_rng(B)
+    n_steps = rng.integers(0, 101, B).astype(np.int32)
+    q0, qd0 = ip.astype(np.float64), iv.astype(np.float64)
+    q = torch.tensor(q0, device="cuda"); qd = torch.tensor(qd0, device="cuda")
+    spec = RolloutSpec(controller, 7, PG, DG, -1.0, 1.0, plant=plant, dt=dt)
+    act = eng.pd_rollout(spec, pos, vel, q, qd, n_steps=torch.tensor(n_steps))
+    ra, rq, rqd = O.rollout(pos.cpu().numpy(), vel.cpu().numpy(), controller, PG, DG, -1.0, 1.0, plant, dt, q0, qd0,
+                            n_steps=n_steps)
+    assert np.array_equal(act.cpu().numpy(), ra.astype(np.float32))
+    assert np.array_equal(q.cpu().numpy(), rq) and np.array_equal(qd.cpu().numpy(), rqd)
+
+
+@pytest.mark.parametrize("cfg", [CFG2, CFG5], ids=["prodmp", "promp"])
+@pytest.mark.parametrize("controller", ["motor", "position", "velocity"])
+@pytest.mark.parametrize("mapping", ["1", "2"])
+def test_fused_actions_are_bit_exact(cfg, controller, mapping, monkeypatch):
+    pc, bc, tc, dt, dur = cfg
+    eng = make_engine(pc, bc, tc, dt, dur)
+    B = 131
+    params, ip, iv = inputs(pc, bc, tc, B, seed=5)
+    cpos = np.random.default_rng(1).uniform(-1, 1, (B, 7))
+    cvel = np.random.default_rng(2).uniform(-1, 1, (B, 7))
+    spec = RolloutSpec(controller, 7, PG, DG, -0.8, 0.9, plant="static")
+    pos, vel, act = eng.trajectory_actions(params, ip, iv, spec, cpos, cvel, 0.5)
+    p2, v2 = eng.trajectory(params, ip, iv, 0.5)
+    assert torch.equal(pos, p2) and torch.equal(vel, v2)
+    ra, _, _ = O.rollout(pos.cpu().numpy(), vel.cpu().numpy(), controller, PG, DG, -0.8, 0.9, "static", dt, cpos, cvel)
+    assert np.array_equal(act.cpu().numpy(), ra.astype(np.float32))
+
+
+def test_fused_actions_rejects_what_it_cannot_fuse():
+    pc, bc, tc, dt, dur = CFG3
+    eng = make_engine(pc, bc, tc, dt, dur)
+    params, ip, iv = inputs(pc, bc, tc, 4)
+    with pytest.raises(ValueError):
+        eng.trajectory_actions(params, ip, iv, RolloutSpec("motor", 7, 1.0, 0.1, -1, 1), ip, iv)
+    with pytest.raises(ValueError):
+        RolloutSpec("metaworld", 7)
+    with pytest.raises(ValueError):
+        RolloutSpec("motor", 7, p_gains=np.ones(3))
+
+
+# ---- integer replanning state, validity ------------------------------------------------------------------------------
+@pytest.mark.parametrize("every,mpt,horizon", [(25, 4, 100), (5, 3, 50), (10, 1, 50), (7, 100, 50), (25, 2, 100)])
+def test_replan_advance_is_bit_exact(every, mpt, horizon):
+    pc, bc, tc, dt, dur = CFG4
+    eng = make_engine(pc, bc, tc, dt, dur)
+    B = 257
+    ts = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ps = torch.zeros_like(ts)
+    done = torch.zeros(B, dtype=torch.uint8, device="cuda")
+    ref = O.replanning_segments(horizon, every, mpt)
+    for k, (start, n) in enumerate(ref):
+        assert int(ts[0]) == start
+        seg = eng.replan_advance(ts, ps, done, every, mpt, horizon)
+        assert torch.all(seg == n) and torch.all(ps == k + 1) and torch.all(ts == start + n)
+        assert bool(done.all()) == (k == len(ref) - 1)
+    seg = eng.replan_advance(ts, ps, done, every, mpt, horizon)      # finished episodes are left alone
+    assert torch.all(seg == 0) and torch.all(ps == len(ref))
+
+
+def test_traj_validity_matches_reference_rule():
+    """table_tennis_env.py:303-309 incl. the quirk that action[0], action[1] are compared to the tau/delay bounds"""
+    pc, bc, tc, dt, dur = CFG5
+    eng = make_engine(pc, bc, tc, dt, dur)
+    B = 300
+    params, ip, iv = inputs(pc, bc, tc, B, seed=9)
+    params[:, 0] = np.random.default_rng(0).uniform(0.5, 1.8, B)
+    params[:, 1] = np.random.default_rng(1).uniform(0.0, 0.2, B)
+    pos, _ = eng.trajectory(params, ip, iv, 0.0)
+    lo = np.array([-2.6, -2.0, -2.8, -0.9, -4.8, -1.6, -2.2])
+    hi = np.array([2.6, 2.0, 2.8, 3.1, 1.3, 1.6, 2.2])
+    p = pos.cpu().numpy().astype(np.float64)
+    want_pos = np.all((p >= lo) & (p <= hi), axis=(1, 2))
+    got = eng.traj_validity(pos, lo, hi).cpu().numpy()
+    assert np.array_equal(got, want_pos) and 0 < want_pos.sum() < B
+    tb, db = [0.8, 1.5], [0.05, 0.15]
+    want = want_pos & (params[:, 0] >= tb[0]) & (params[:, 0] <= tb[1]) & (params[:, 1] >= db[0]) & (params[:, 1] <= db[1])
+    got = eng.traj_validity(pos, lo, hi, torch.tensor(params, device="cuda"), tb, db).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+# ---- BatchedBlackBox --------------------------------------------------------------------------------------------------
+def _batched(cfg, B, **kw):
+    pc, bc, tc, dt, dur = cfg
+    pg = get_phase_generator(pc.phase_generator_type, tau=pc.tau, alpha_phase=pc.alpha_phase,
+                             learn_tau=pc.learn_tau, learn_delay=pc.learn_delay, tau_bound=list(pc.tau_bound),
+                             delay_bound=list(pc.delay_bound))
+    bkw = dict(num_basis=bc.num_basis, basis_bandwidth_factor=bc.basis_bandwidth_factor)
+    if bc.basis_generator_type == "prodmp":
+        bkw["alpha"] = bc.alpha
+    bg = get_basis_generator(bc.basis_generator_type, pg, **bkw)
+    tkw = dict(weights_scale=tc.weights_scale)
+    if tc.trajectory_generator_type == "prodmp":
+        tkw.update(goal_scale=tc.goal_scale, auto_scale_basis=tc.auto_scale_basis, disable_goal=tc.disable_goal,
+                   relative_goal=tc.relative_goal)
+    tg = get_trajectory_generator(tc.trajectory_generator_type, tc.action_dim, bg, **tkw)
+    ctrl = get_controller("motor", p_gains=PG, d_gains=DG)
+    return BatchedBlackBox(tg, ctrl, B, dt, dur, act_low=-1.0, act_high=1.0, **kw)
+
+
+def test_batched_episode_equals_oracle_closed_loop():
+    B = 64
+    bb = _batched(CFG2, B, plant="double_integrator")
+    rng = np.random.default_rng(0)
+    q0 = rng.uniform(-1, 1, (B, 7))
+    bb.reset(q0)
+    params = rng.standard_normal((B, 42)).astype(np.float32)
+    out = bb.step(params)
+    pc, bc, tc, dt, dur = CFG2
+    rp, rv = O.get_trajectory(pc, bc, tc, params, dur, dt, 0.0, q0.astype(np.float32), np.zeros((B, 7), np.float32),
+                              dtype=np.float64)
+    close(out["des_pos"].cpu().numpy(), rp, "des_pos")
+    close(out["des_vel"].cpu().numpy(), rv, "des_vel")
+    ra, rq, rqd = O.rollout(out["des_pos"].cpu().numpy(), out["des_vel"].cpu().numpy(), "motor", PG, DG, -1.0, 1.0,
+                            "double_integrator", dt, q0, np.zeros((B, 7)))
+    assert np.array_equal(out["step_actions"].cpu().numpy(), ra.astype(np.float32))
+    assert np.array_equal(out["current_pos"].cpu().numpy(), rq)
+    assert torch.all(out["trajectory_length"] == 100) and bool(out["done"].all())
+
+
+def test_batched_replanning_follows_the_single_episode_sequence():
+    """cfg4: schedule t % 25 == 0, max_planning_times 4, condition_on_desired (box_pushing/mp_wrapper.py:87-91)"""
+    B = 48
+    bb = _batched(CFG4, B, plant="double_integrator", replanning_every=25, max_planning_times=4,
+                  condition_on_desired=True)
+    rng = np.random.default_rng(2)
+    q0 = rng.uniform(-1, 1, (B, 7))
+    bb.reset(q0)
+    pc, bc, tc, dt, dur = CFG4
+    cond_p, cond_v = q0.astype(np.float32), np.zeros((B, 7), np.float32)
+    q, qd = q0.copy(), np.zeros((B, 7))
+    for k, (start, n) in enumerate(O.replanning_segments(100, 25, 4)):
+        params = rng.standard_normal((B, 35)).astype(np.float32)
+        out = bb.step(params)
+        assert torch.all(out["trajectory_length"] == n) and int(bb.traj_steps[0]) == start + n
+        assert int(bb.plan_steps[0]) == k + 1 and bool(out["done"].all()) == (k == 3)
+        rp, rv = O.get_trajectory(pc, bc, tc, params, dur, dt, start * dt, cond_p, cond_v, dtype=np.float64)
+        close(out["des_pos"].cpu().numpy(), rp, f"plan {k} pos")
+        close(out["des_vel"].cpu().numpy(), rv, f"plan {k} vel")
+        dp, dv = out["des_pos"].cpu().numpy(), out["des_vel"].cpu().numpy()
+        ra, q, qd = O.rollout(dp, dv, "motor", PG, DG, -1.0, 1.0, "double_integrator", dt, q, qd,
+                              n_steps=np.full(B, n))
+        assert np.array_equal(out["step_actions"].cpu().numpy(), ra.astype(np.float32))
+        assert np.array_equal(out["current_pos"].cpu().numpy(), q)
+        cond_p, cond_v = dp[:, n - 1], dv[:, n - 1]           # condition on the desired state where the plan broke
+
+
+def test_batched_learned_tau_delay_freeze_after_first_plan():
+    cfg = (O.PhaseCfg("exp", tau=1.0, alpha_phase=3.0, learn_tau=True, learn_delay=True, tau_bound=(0.5, 1.0),
+                      delay_bound=(0.0, 0.2)),
+           O.BasisCfg("prodmp", num_basis=4, alpha=25), O.TrajCfg("prodmp", action_dim=7), 0.02, 1.0)
+    B = 16
+    bb = _batched(cfg, B, plant="static", replanning_every=10, max_planning_times=3)
+    bb.reset(np.ones((B, 7)))
+    rng = np.random.default_rng(3)
+    p1 = rng.standard_normal((B, 37)).astype(np.float32)
+    p1[:, 0], p1[:, 1] = rng.uniform(0.3, 1.2, B), rng.uniform(0.0, 0.3, B)
+    o1 = bb.step(p1)
+    frozen = o1["params"][:, :2].cpu().numpy()
+    assert np.all(frozen[:, 0] >= 0.5) and np.all(frozen[:, 0] <= 1.0) and np.all(frozen[:, 1] <= np.float32(0.2))
+    p2 = rng.standard_normal((B, 37)).astype(np.float32)
+    p2[:, 0], p2[:, 1] = 0.77, 0.11
+    o2 = bb.step(p2)
+    assert np.array_equal(o2["params"][:, :2].cpu().numpy(), frozen)
+    pc, bc, tc, dt, dur = cfg
+    full = p2.copy(); full[:, :2] = frozen
+    rp, _ = O.get_trajectory(pc, bc, tc, full, dur, dt, 10 * dt, np.ones((B, 7), np.float32),
+                             np.zeros((B, 7), np.float32), dtype=np.float64)
+    close(o2["des_pos"].cpu().numpy(), rp, "second plan")
+
+
+# ---- size-independent properties at BASELINE's full sizes ------------------------------------------------------------
+@pytest.mark.parametrize("cfg,B", [(CFG2, 4096), (CFG3, 16384), (CFG4, 8192), (CFG5, 8192), (CFG2, 262144)],
+                         ids=["cfg2_4096", "cfg3_16384", "cfg4_shard8192", "cfg5_shard8192", "cfg2_262144_stream"])
+def test_full_size_properties(cfg, B):
+    """
+    linearity in the parameters (ProMP / ProDMP / DMP are linear maps of [w, g, y_b, v_b]), batch-order invariance
+    (episodes are independent: a permuted batch gives permuted rows bit for bit) and agreement of a random sample of
+    rows with the oracle
+    """
+    pc, bc, tc, dt, dur = cfg
+    eng = make_engine(pc, bc, tc, dt, dur)
+    params, ip, iv = inputs(pc, bc, tc, B, seed=B % 97)
+    P = torch.tensor(params, device="cuda"); IP = torch.tensor(ip, device="cuda"); IV = torch.tensor(iv, device="cuda")
+    pos, vel = eng.trajectory(P, IP, IV, 0.0)
+    assert torch.isfinite(pos).all() and torch.isfinite(vel).all()
+    perm = torch.randperm(B, device="cuda", generator=torch.Generator(device="cuda").manual_seed(0))
+    pp, vp = eng.trajectory(P[perm], IP[perm], IV[perm], 0.0)
+    assert torch.equal(pp, pos[perm]) and torch.equal(vp, vel[perm])
+    p2, v2 = eng.trajectory(2 * P, 2 * IP, 2 * IV, 0.0)                   # scaling by 2 is exact in binary fp
+    assert torch.equal(p2, 2 * pos) and torch.equal(v2, 2 * vel)
+    rows = np.random.default_rng(0).choice(B, 64, replace=False)
+    rp, rv = O.get_trajectory(pc, bc, tc, params[rows], dur, dt, 0.0, ip[rows], iv[rows], dtype=np.float64)
+    fd = tc.trajectory_generator_type == "promp"
+    close(pos[rows].cpu().numpy(), rp, "sample pos")
+    close(vel[rows].cpu().numpy(), rv, "sample vel", atol=fd_atol(rp, dt) if fd else 0.0)

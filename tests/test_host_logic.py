@@ -1,0 +1,362 @@
+"""
+CPU suite, part 2: host logic of the product (no GPU needed) -- factories and their error behaviour, parameter
+bookkeeping, config merging, make_bb wiring, the C-ABI surface (every symbol of include/mpk.h resolves), the
+device-free construction-time pre-compute against the oracle, and the loud failure without a GPU.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import fancy_gym_amd
+from fancy_gym_amd import _gym, _lib
+from fancy_gym_amd.black_box.controller import (BaseController, MetaWorldController, PDController, PosController,
+                                                VelController)
+from fancy_gym_amd.black_box.factory import (get_basis_generator, get_controller, get_phase_generator,
+                                             get_trajectory_generator)
+from fancy_gym_amd.black_box.raw_interface_wrapper import RawInterfaceWrapper
+from fancy_gym_amd.envs.registry import _BB_DEFAULTS, fancy_id, nested_update, resolve_mp_config
+from oracle import mp_oracle as O
+from tests.toy_env import ToyEnv, ToyWrapper, register_toys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HAVE_GPU = torch.cuda.is_available()
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _toys():
+    register_toys()
+
+
+# ---- C-ABI ---------------------------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "mpk.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(mpk_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    lib = C.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libmpk.so does not export {name}"
+    assert declared == set(_lib.SIGNATURES), "ctypes signature table and include/mpk.h disagree"
+    assert _lib.load().mpk_abi_version() == 1
+
+
+def test_config_struct_layout_matches_header():
+    # 18 int32 + 15 doubles, no padding surprises
+    assert C.sizeof(_lib.mpk_config) == 18 * 4 + 15 * 8
+
+
+def _cfg(mp="prodmp", phase="exp", basis="prodmp", D=7, nb=5, **kw):
+    c = _lib.mpk_config()
+    c.abi_version = 1
+    c.mp_type, c.phase_type, c.basis_type = _lib.MP_TYPES[mp], _lib.PHASE_TYPES[phase], _lib.BASIS_TYPES[basis]
+    c.num_dof, c.num_basis = D, nb
+    c.tau, c.alpha_phase, c.basis_bandwidth_factor, c.basis_alpha, c.basis_dt = 1.5, 3.0, 2.0, 10.0, 0.01
+    c.pre_compute_length_factor = 6
+    c.weights_scale = c.goal_scale = 1.0
+    c.dmp_alpha = 25.0
+    c.dt, c.duration = 0.02, 2.0
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def test_host_prodmp_tables_match_oracle_float64():
+    lib = _lib.load()
+    cfg = _cfg()
+    n = lib.mpk_host_prodmp_tables(C.byref(cfg), *[None] * 8)
+    assert n == 901
+    arrs = [np.empty(n) for _ in range(4)] + [np.empty((n, 6)) for _ in range(2)] + [np.empty(6)]
+    sdt = C.c_float()
+    assert lib.mpk_host_prodmp_tables(C.byref(cfg), *[a.ctypes.data for a in arrs], C.addressof(sdt)) == n
+    ref = O.prodmp_tables(O.PhaseCfg("exp", tau=1.5, alpha_phase=3.0),
+                          O.BasisCfg("prodmp", num_basis=5, basis_bandwidth_factor=2, alpha=10), np.float64)
+    for got, want in zip(arrs, (ref.y1, ref.y2, ref.dy1, ref.dy2, ref.pos_basis, ref.vel_basis, ref.scale_factors)):
+        np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-12)
+    assert np.float32(sdt.value) == np.float32(ref.scaled_dt)
+
+
+@pytest.mark.parametrize("phase,basis,nb,extra", [("linear", "zero_rbf", 5, dict(num_basis_zero_start=1)),
+                                                  ("exp", "rbf", 5, {}), ("linear", "rbf", 10, dict(num_basis_outside=1)),
+                                                  ("linear", "zero_rbf", 3, dict(num_basis_zero_start=1, num_basis_zero_goal=1))])
+def test_host_rbf_matches_oracle(phase, basis, nb, extra):
+    lib = _lib.load()
+    cfg = _cfg("promp", phase, basis, 7, nb, tau=2.8, alpha_phase=2.0, basis_bandwidth_factor=3.0, **extra)
+    n = lib.mpk_host_rbf(C.byref(cfg), None, None)
+    cen, bw = np.empty(n), np.empty(n)
+    lib.mpk_host_rbf(C.byref(cfg), cen.ctypes.data, bw.ctypes.data)
+    bc = O.BasisCfg(basis, num_basis=nb, basis_bandwidth_factor=3.0, num_basis_outside=extra.get("num_basis_outside", 0),
+                    num_basis_zero_start=extra.get("num_basis_zero_start", 0),
+                    num_basis_zero_goal=extra.get("num_basis_zero_goal", 0))
+    rc, rb = O.rbf_centers_bandwidth(O.PhaseCfg(phase, tau=2.8, alpha_phase=2.0), bc, np.float64)
+    assert n == O.rbf_total_basis(bc)
+    np.testing.assert_allclose(cen, rc, rtol=1e-13)
+    np.testing.assert_allclose(bw, rb, rtol=1e-12)
+
+
+@pytest.mark.parametrize("duration,dt", [(2.0, 0.02), (4.0, 0.02), (2.8, 0.008), (1.0, 0.02), (0.74, 0.02), (6.0, 0.005)])
+def test_host_time_grid_is_bit_identical_to_oracle(duration, dt):
+    lib = _lib.load()
+    T = lib.mpk_host_times(duration, dt, None, 0)
+    assert T == O.num_steps(duration, dt)
+    t = np.empty(T, np.float32)
+    assert lib.mpk_host_times(duration, dt, t.ctypes.data, T) == T
+    assert np.array_equal(t, O.make_times(duration, dt, 0.0))
+
+
+@pytest.mark.parametrize("mp,basis", [("promp", "rbf"), ("dmp", "rbf"), ("prodmp", "prodmp")])
+@pytest.mark.parametrize("D", [0, 1, 5])
+@pytest.mark.parametrize("lt,ld", [(0, 0), (1, 0), (1, 1)])
+def test_host_num_params(mp, basis, D, lt, ld):
+    cfg = _cfg(mp, "exp", basis, D, 3, learn_tau=lt, learn_delay=ld)
+    assert _lib.load().mpk_host_num_params(C.byref(cfg)) == D * 3 + lt + ld + (D if "dmp" in mp else 0)
+
+
+def test_bad_configs_are_rejected_with_messages():
+    lib = _lib.load()
+    for bad, frag in ((_cfg(basis="prodmp", phase="linear"), "exp phase"), (_cfg(mp="promp", basis="prodmp"), "together"),
+                      (_cfg(nb=0), "num_basis"), (_cfg(abi_version=99), "abi_version"),
+                      (_cfg(pre_compute_length_factor=7), "pre_compute_length_factor")):
+        assert lib.mpk_host_num_params(C.byref(bad)) == _lib.MPK_EINVAL
+        assert frag in _lib.last_error()
+    with pytest.raises(ValueError):
+        _lib.check(_lib.MPK_EINVAL)
+    with pytest.raises(RuntimeError):
+        _lib.check(_lib.MPK_ERANGE)
+
+
+@pytest.mark.skipif(HAVE_GPU, reason="checks the no-GPU failure mode")
+def test_product_fails_loudly_without_a_gpu():
+    assert _lib.load().mpk_device_count() == 0
+    with pytest.raises(fancy_gym_amd.MPKLibraryError, match="no CPU fallback"):
+        fancy_gym_amd.TrajectoryEngine("prodmp", "exp", "prodmp", 7, 5, dt=0.02, duration=2.0, tau=1.5)
+    register_toys()
+    env = fancy_gym_amd.make_bb("toy-v0", [ToyWrapper], {}, {"trajectory_generator_type": "promp"},
+                                {"controller_type": "motor"}, {"phase_generator_type": "linear"},
+                                {"basis_generator_type": "rbf"})
+    env.reset(seed=1)
+    with pytest.raises(fancy_gym_amd.MPKLibraryError):
+        env.step(env.action_space.sample())
+
+
+def test_product_never_imports_the_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, "fancy_gym_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(root, f)).read()
+                assert "mp_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+# ---- factories (reference fancy_gym/black_box/factory/*.py) --------------------------------------------------------
+def test_factory_type_strings_and_errors():
+    assert get_phase_generator("LINEAR").type_name == "linear"
+    assert get_phase_generator("exp", alpha_phase=2).alpha_phase == 2
+    for t in ("rhythmic", "smooth"):
+        with pytest.raises(NotImplementedError):
+            get_phase_generator(t)
+    with pytest.raises(ValueError):
+        get_phase_generator("foo")
+    pg = get_phase_generator("exp")
+    assert get_basis_generator("rbf", pg).type_name == "rbf"
+    assert get_basis_generator("zero_rbf", pg, num_basis=5, num_basis_zero_start=1).num_basis == 5
+    assert get_basis_generator("prodmp", pg).type_name == "prodmp"
+    with pytest.raises(AssertionError):
+        get_basis_generator("prodmp", get_phase_generator("linear"))
+    with pytest.raises(NotImplementedError):
+        get_basis_generator("rhythmic", pg)
+    with pytest.raises(ValueError):
+        get_basis_generator("foo", pg)
+    for t, cls in (("motor", PDController), ("velocity", VelController), ("position", PosController),
+                   ("metaworld", MetaWorldController)):
+        assert isinstance(get_controller(t), cls)
+    with pytest.raises(ValueError):
+        get_controller("foo")
+    bg = get_basis_generator("rbf", pg)
+    assert get_trajectory_generator("promp", 3, bg).mp_type == "promp"
+    assert get_trajectory_generator("DMP", 3, bg).mp_type == "dmp"
+    with pytest.raises(AssertionError):
+        get_trajectory_generator("prodmp", 3, bg)
+    with pytest.raises(ValueError):
+        get_trajectory_generator("idmp", 3, bg)
+
+
+def test_controllers_match_reference_formulas():
+    """test/test_controller.py:14-73"""
+    rng = np.random.default_rng(0)
+    for p, d in ((0, 0), (0.5, 0.5), (np.array([1., 2.]), np.array([.1, .2]))):
+        c = get_controller("motor", p_gains=p, d_gains=d)
+        for _ in range(5):
+            qd_, vd_, q, v = (rng.uniform(-1, 1, 2) for _ in range(4))
+            assert np.array_equal(c.get_action(qd_, vd_, q, v), p * (qd_ - q) + d * (vd_ - v))
+            assert np.array_equal(c(qd_, vd_, q, v), c.get_action(qd_, vd_, q, v))
+    c = get_controller("motor")
+    with pytest.raises(ValueError):
+        c.get_action(np.ones(2), np.ones(2), np.ones(3), np.ones(2))
+    with pytest.raises(ValueError):
+        c.get_action(np.ones(2), np.ones(2), np.ones(2), np.ones(3))
+    a, b = np.array([1., 2.]), np.array([3., 4.])
+    assert get_controller("position").get_action(a, b, None, None) is a
+    assert get_controller("velocity").get_action(a, b, None, None) is b
+    mw = get_controller("metaworld")
+    assert np.array_equal(mw.get_action(np.array([1., 2., 3., 9.]), None, np.array([.5, .5, .5, 0.]), None),
+                          np.array([.5, 1.5, 2.5, 9.]))
+    with pytest.raises(ValueError):
+        mw.get_action(np.ones(4), None, np.ones(5), None)
+    with pytest.raises(NotImplementedError):
+        BaseController().get_action(None, None, None, None)
+
+
+# ---- parameter bookkeeping --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mp_type", ["promp", "dmp", "prodmp"])
+@pytest.mark.parametrize("num_dof", [0, 1, 2, 5])
+@pytest.mark.parametrize("num_basis", [1, 2, 5])
+@pytest.mark.parametrize("learn_tau", [True, False])
+@pytest.mark.parametrize("learn_delay", [True, False])
+def test_action_space_dimension(mp_type, num_dof, num_basis, learn_tau, learn_delay):
+    """test/test_black_box.py:168-193, through make_bb on the toy env (construction needs no GPU)"""
+    basis = "prodmp" if mp_type == "prodmp" else "rbf"
+    env = fancy_gym_amd.make_bb("toy-v0", [ToyWrapper], {},
+                                {"trajectory_generator_type": mp_type, "action_dim": num_dof},
+                                {"controller_type": "motor"},
+                                {"phase_generator_type": "exp", "learn_tau": learn_tau, "learn_delay": learn_delay},
+                                {"basis_generator_type": basis, "num_basis": num_basis})
+    extra = num_dof if "dmp" in mp_type else 0
+    assert env.action_space.shape[0] == num_dof * num_basis + int(learn_tau) + int(learn_delay) + extra
+
+
+def test_param_bounds_and_derived_defaults():
+    """make_env_helpers.py:110-126: tau = duration, tau_bound = [2 dt, duration], delay_bound = [0, duration - 2 dt]"""
+    env = fancy_gym_amd.make_bb("toy-v0", [ToyWrapper], {}, {"trajectory_generator_type": "promp"},
+                                {"controller_type": "motor"},
+                                {"phase_generator_type": "linear", "learn_tau": True, "learn_delay": True},
+                                {"basis_generator_type": "rbf"})
+    assert env.duration == pytest.approx(1.0) and float(env.traj_gen.tau) == pytest.approx(1.0)
+    assert env.tau_bound == [0.04, 1.0] and env.delay_bound == [0, pytest.approx(0.96)]
+    lo, hi = env.action_space.low, env.action_space.high
+    assert lo[0] == pytest.approx(0.04) and hi[0] == pytest.approx(1.0) and lo[1] == 0 and hi[1] == pytest.approx(0.96)
+    assert np.all(np.isinf(lo[2:])) and np.all(np.isinf(hi[2:]))
+    assert env.traj_gen.learn_tau and env.traj_gen.num_params == 12
+    # without learned tau / delay the wrapper falls back to infinite bounds (black_box_wrapper.py:60-65)
+    env2 = fancy_gym_amd.make_bb("toy-v0", [ToyWrapper], {}, {"trajectory_generator_type": "promp"},
+                                 {"controller_type": "motor"}, {"phase_generator_type": "linear"},
+                                 {"basis_generator_type": "rbf"})
+    assert env2.tau_bound == [-np.inf, np.inf] and env2.delay_bound == [-np.inf, np.inf]
+
+
+def test_phase_parameters_freeze_until_reset():
+    pg = get_phase_generator("exp", tau=1.0, learn_tau=True, learn_delay=True)
+    rest = pg.set_params(np.array([0.5, 0.1, 7.0, 8.0], np.float32))
+    assert list(rest) == [7.0, 8.0] and float(pg.tau) == 0.5 and float(pg.delay) == pytest.approx(0.1)
+    pg.set_params(np.array([0.9, 0.3, 1.0, 2.0], np.float32))      # frozen: a later plan cannot change them
+    assert float(pg.tau) == 0.5 and float(pg.delay) == pytest.approx(0.1)
+    pg.reset()
+    pg.set_params(np.array([0.9, 0.3, 1.0, 2.0], np.float32))
+    assert float(pg.tau) == pytest.approx(0.9)
+
+
+# ---- wiring errors ----------------------------------------------------------------------------------------------------
+def test_missing_wrapper_raises_value_error():
+    """test/test_black_box.py:68-71"""
+    with pytest.raises(ValueError):
+        fancy_gym_amd.make_bb("toy-v0", [], {}, {}, {}, {}, {})
+
+
+def test_sub_trajectories_and_replanning_are_exclusive():
+    with pytest.raises(ValueError):
+        fancy_gym_amd.make_bb("toy-v0", [ToyWrapper], {"learn_sub_trajectories": True,
+                                                       "replanning_schedule": lambda *a: False},
+                              {"trajectory_generator_type": "promp"}, {"controller_type": "motor"},
+                              {"phase_generator_type": "linear"}, {"basis_generator_type": "rbf"})
+
+
+def test_time_limit_mismatch_asserts():
+    with pytest.raises(AssertionError):
+        fancy_gym_amd.make_bb("toy-v0", [ToyWrapper], {}, {"trajectory_generator_type": "promp", "duration": 2.0},
+                              {"controller_type": "motor"}, {"phase_generator_type": "linear"},
+                              {"basis_generator_type": "rbf"}, time_limit=1.0)
+
+
+def test_context_mask_and_time_aware_observation():
+    env = fancy_gym_amd.make_bb("toy-v0", [ToyWrapper], {}, {"trajectory_generator_type": "promp"},
+                                {"controller_type": "motor"}, {"phase_generator_type": "linear"},
+                                {"basis_generator_type": "rbf"})
+    assert env.return_context_observation and env.observation_space.shape == (1,)
+    obs, _ = env.reset(seed=1)
+    assert obs.shape == (1,) and obs.dtype == env.observation_space.dtype
+    env = fancy_gym_amd.make_bb("toy-v0", [ToyWrapper], {"replanning_schedule": lambda p, v, o, a, t: t % 10 == 0},
+                                {"trajectory_generator_type": "promp"}, {"controller_type": "motor"},
+                                {"phase_generator_type": "linear"}, {"basis_generator_type": "rbf"})
+    assert env.do_replanning and not env.return_context_observation
+    assert env.observation_space.shape == (2,)           # TimeAwareObservation was added (make_env_helpers.py:95-97)
+    obs, _ = env.reset(seed=1)
+    assert obs.shape == (2,) and obs[-1] == 0.0
+
+
+def test_env_kwargs_are_forwarded():
+    """test/test_black_box.py:196-216"""
+    c, d = [1.0], {"a": 1}
+    env = fancy_gym_amd.make_bb("toy-v0", [ToyWrapper], {}, {"trajectory_generator_type": "promp"},
+                                {"controller_type": "motor"}, {"phase_generator_type": "exp"},
+                                {"basis_generator_type": "rbf"}, a=1, b=1.0, c=c, d=d)
+    assert env.a == 1 and env.b == 1.0 and env.c == c and env.d == d
+
+
+def test_base_wrapper_without_state_raises_not_implemented():
+    """test/test_black_box.py:74-85 (the failure happens before any trajectory is generated)"""
+    env = fancy_gym_amd.make_bb("toy-v0", [RawInterfaceWrapper], {}, {"trajectory_generator_type": "promp"},
+                                {"controller_type": "motor"}, {"phase_generator_type": "exp"},
+                                {"basis_generator_type": "rbf"})
+    env.reset(seed=1)
+    with pytest.raises(NotImplementedError):
+        env.step(env.action_space.sample())
+
+
+# ---- config front-end (reference fancy_gym/envs/registry.py) -----------------------------------------------------------
+def test_nested_update_replaces_blocks_that_name_a_type():
+    base = {"basis_generator_kwargs": {"basis_generator_type": "zero_rbf", "num_basis": 5, "num_basis_zero_start": 1}}
+    out = nested_update(base, {"basis_generator_kwargs": {"basis_generator_type": "rbf"}})
+    assert out["basis_generator_kwargs"] == {"basis_generator_type": "rbf"}            # defaults of the old type dropped
+    base = {"basis_generator_kwargs": {"basis_generator_type": "zero_rbf", "num_basis": 5}}
+    out = nested_update(base, {"basis_generator_kwargs": {"num_basis": 3}})
+    assert out["basis_generator_kwargs"] == {"basis_generator_type": "zero_rbf", "num_basis": 3}
+
+
+def test_resolve_mp_config_reproduces_baseline_constants():
+    """SURVEY Appendix B rows 2 and 4 (box_pushing/mp_wrapper.py:9-92)"""
+    pg = 0.01 * np.array([120., 120., 120., 120., 50., 30., 10.])
+    mp_config = {"ProDMP": {"controller_kwargs": {"p_gains": pg}, "basis_generator_kwargs": {"basis_bandwidth_factor": 2}}}
+    cfg = resolve_mp_config("ProDMP", mp_config)
+    assert cfg["phase_generator_kwargs"] == {"phase_generator_type": "exp", "tau": 1.5}
+    assert cfg["basis_generator_kwargs"] == {"basis_generator_type": "prodmp", "alpha": 10, "num_basis": 5,
+                                             "basis_bandwidth_factor": 2}
+    assert cfg["controller_kwargs"]["controller_type"] == "motor" and cfg["controller_kwargs"]["d_gains"] == 0.1
+    assert np.array_equal(cfg["controller_kwargs"]["p_gains"], pg)
+    assert _BB_DEFAULTS["ProDMP"]["basis_generator_kwargs"] == {"basis_generator_type": "prodmp", "alpha": 10,
+                                                                "num_basis": 5}, "defaults must not be mutated"
+    cfg = resolve_mp_config("ProMP", {"ProMP": {"inherit_defaults": False, "wrappers": []}})
+    assert cfg == {"wrappers": []}
+    cfg = resolve_mp_config("DMP", {}, {"phase_generator_kwargs": {"alpha_phase": 2}},
+                            {"black_box_kwargs": {"verbose": 2}})
+    assert cfg["phase_generator_kwargs"] == {"phase_generator_type": "exp", "alpha_phase": 2}
+    assert cfg["black_box_kwargs"] == {"verbose": 2}
+
+
+def test_fancy_id_scheme_and_registration():
+    assert fancy_id("fancy/BoxPushingDense-v0", "ProDMP") == ("fancy", "BoxPushingDense-v0",
+                                                              "fancy_ProDMP/BoxPushingDense-v0")
+    assert fancy_id("Reacher-v2", "DMP")[2] == "gym_DMP/Reacher-v2"
+    with pytest.raises(ValueError):
+        fancy_id("a/b/c-v0", "DMP")
+    with pytest.raises(AssertionError):
+        fancy_id("a/b", "DMP")
+    if "unit/Toy-v0" not in _gym.registry:
+        fancy_gym_amd.register("unit/Toy-v0", "tests.toy_env:ToyEnv", mp_wrapper=ToyWrapper, max_episode_steps=50)
+    assert "unit_ProMP/Toy-v0" in fancy_gym_amd.ALL_MOVEMENT_PRIMITIVE_ENVIRONMENTS["ProMP"]
+    assert "unit_ProDMP/Toy-v0" in fancy_gym_amd.MOVEMENT_PRIMITIVE_ENVIRONMENTS_FOR_NS["unit"]["all"]
+    env = _gym.make("unit_ProMP/Toy-v0")
+    assert env.action_space.shape == (5,) and env.traj_gen.mp_type == "promp"     # 1 DoF x 5 basis
+    env = _gym.make("unit_ProDMP/Toy-v0", mp_config_override={"basis_generator_kwargs": {"num_basis": 3}})
+    assert env.action_space.shape == (4,) and float(env.traj_gen.tau) == 1.5

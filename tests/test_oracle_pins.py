@@ -1,0 +1,238 @@
+"""
+CPU suite, part 1: what pins the ORACLE (oracle/mp_oracle.py), since the reference's arithmetic (mp_pytorch) cannot be
+imported or compiled here ("parity unpinned"):
+  * committed golden fixtures (tests/golden/*.npz) incl. a second, torch-CPU formulation
+  * an independent SciPy ODE solve of the ProDMP / DMP dynamics
+  * the reference's own behavioural tests, restated: action-dim formula, parameter order, tau / delay plateaus with
+    ``==``, PD formula with ``array_equal``, planning counts
+"""
+import os
+
+import numpy as np
+import pytest
+from scipy.integrate import solve_ivp
+
+from oracle import mp_oracle as O
+from tests.golden.make_golden import CONFIGS
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# ---- golden fixtures -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_oracle_reproduces_golden(name):
+    cfg = CONFIGS[name]
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    pc, bc, tc = cfg["pc"], cfg["bc"], cfg["tc"]
+    for k, it in enumerate(z["init_times"]):
+        p, v = O.get_trajectory(pc, bc, tc, z["params"], cfg["duration"], cfg["dt"], float(it), z["init_pos"],
+                                z["init_vel"], dtype=np.float32)
+        np.testing.assert_allclose(p, z[f"pos32_{k}"], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(v, z[f"vel32_{k}"], rtol=2e-6, atol=2e-5)
+        assert p.dtype == np.float32 and p.shape == (z["params"].shape[0], O.num_steps(cfg["duration"], cfg["dt"]),
+                                                     tc.action_dim)
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_oracle_agrees_with_torch_formulation(name):
+    """two independent restatements (numpy vs torch CPU fp32 in the recalled mp_pytorch op order)"""
+    cfg = CONFIGS[name]
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    fd = cfg["tc"].trajectory_generator_type == "promp"
+    for k in range(len(z["init_times"])):
+        sp, sv = np.abs(z[f"pos32_{k}"]).max(), np.abs(z[f"vel32_{k}"]).max()
+        assert np.abs(z[f"pos32_{k}"] - z[f"tpos_{k}"]).max() <= 5e-6 * sp
+        # ProMP velocity = forward difference of fp32 positions: conditioning 1/dt (see tests/test_gpu_trajectory.py)
+        tol_v = 1e-5 * sv + (2 * np.finfo(np.float32).eps * sp / cfg["dt"] if fd else 0.0)
+        assert np.abs(z[f"vel32_{k}"] - z[f"tvel_{k}"]).max() <= tol_v
+        assert z[f"err64_{k}"][0] < 5e-6            # fp32 oracle vs fp64 oracle, relative to the array maximum
+    # the oracle's scalar linspace recipe vs torch's vectorised kernel: <= 2 ulp, and the ProDMP table indices
+    # (asserted identical inside make_golden.py) do not move
+    assert np.abs(z["times_torch"] - z["times_oracle"]).max() <= 2.4e-7 * max(1.0, cfg["duration"])
+
+
+def test_golden_indices_are_what_the_oracle_computes():
+    cfg = CONFIGS["cfg4_prodmp_replan"]
+    z = np.load(os.path.join(GOLD, "cfg4_prodmp_replan.npz"))
+    tabs = O.prodmp_tables(cfg["pc"], cfg["bc"], np.float32)
+    for k, it in enumerate(z["init_times"]):
+        times = O.make_times(cfg["duration"], cfg["dt"], float(it))
+        idx = O.prodmp_indices(times, np.float32(1.5), np.float32(0.0), tabs.scaled_dt)
+        assert np.array_equal(idx.astype(np.int32), z[f"idx_{k}"][0])
+        # dt = 0.02 on a 0.01 grid: every index is an exact multiple -> 2 * step + init offset
+        assert np.array_equal(idx, 2 * np.arange(1, 101) + int(round(float(it) / 0.01)))
+
+
+# ---- independent maths -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("init_time", [0.0, 0.5, 1.0])
+def test_prodmp_closed_form_solves_the_ode(init_time):
+    """tau^2 y'' = alpha (beta (g - y) - tau y') + x Phi(x)^T w from the boundary condition at init_time"""
+    pc = O.PhaseCfg("exp", tau=1.5, alpha_phase=3.0)
+    bc = O.BasisCfg("prodmp", num_basis=5, basis_bandwidth_factor=2, alpha=10)
+    tc = O.TrajCfg("prodmp", action_dim=1)
+    rng = np.random.default_rng(3)
+    params = rng.standard_normal((1, 6))
+    y0, v0 = 0.3, -0.2
+    times = O.make_times(2.0, 0.02, init_time, dtype=np.float64)
+    pos, vel = O.prodmp_trajectory(pc, bc, tc, params, times, init_time, np.array([[y0]]), np.array([[v0]]),
+                                   dtype=np.float64)
+    w, g = params[0, :5], params[0, 5]
+    alpha, beta, tau = 10.0, 2.5, 1.5
+    rb = O.BasisCfg(**{**bc.__dict__, "basis_generator_type": "rbf"})
+
+    def rhs(t, s):
+        y, z = s
+        tt = np.array([t])
+        f = O.phase(pc, tt, dtype=np.float64)[0] * (O.rbf_basis(pc, rb, tt, dtype=np.float64)[0] @ w)
+        return [z / tau, (alpha * (beta * (g - y) - z) + f) / tau]
+
+    sol = solve_ivp(rhs, [init_time, times[-1]], [y0, v0 * tau], t_eval=times, rtol=1e-10, atol=1e-12)
+    assert np.abs(sol.y[0] - pos[0, :, 0]).max() < 2e-5      # residual = trapezoid rule on the dt = 0.01 grid
+    assert np.abs(sol.y[1] / tau - vel[0, :, 0]).max() < 1e-4
+
+
+def test_dmp_euler_converges_to_the_ode():
+    pc = O.PhaseCfg("exp", tau=2.0, alpha_phase=2.0)
+    bc = O.BasisCfg("rbf", num_basis=5)
+    tc = O.TrajCfg("dmp", action_dim=1, alpha=25.0)
+    rng = np.random.default_rng(5)
+    params = rng.standard_normal((1, 6)) * np.array([50, 50, 50, 50, 50, 1.0])
+    errs = []
+    for dt in (0.004, 0.002, 0.001):
+        times = O.make_times(2.0, dt, 0.0, dtype=np.float64)
+        pos, vel = O.dmp_trajectory(pc, bc, tc, params, times, np.array([[0.1]]), np.array([[0.0]]), dtype=np.float64)
+        w, g = params[0, :5], params[0, 5]
+
+        def rhs(t, s):
+            y, z = s
+            tt = np.array([t])
+            f = O.phase(pc, tt, dtype=np.float64)[0] * (O.rbf_basis(pc, bc, tt, dtype=np.float64)[0] @ w)
+            return [z / 2.0, (25.0 * (6.25 * (g - y) - z) + f) / 2.0]
+
+        sol = solve_ivp(rhs, [times[0], times[-1]], [0.1, 0.0], t_eval=times, rtol=1e-10, atol=1e-12)
+        errs.append(np.abs(sol.y[0] - pos[0, :, 0]).max())
+    assert errs[1] < 0.6 * errs[0] and errs[2] < 0.6 * errs[1]     # first-order convergence of explicit Euler
+
+
+# ---- the reference's behavioural pins, restated ----------------------------------------------------------------------
+@pytest.mark.parametrize("mp_type", ["promp", "dmp", "prodmp"])
+@pytest.mark.parametrize("num_dof", [0, 1, 2, 5])
+@pytest.mark.parametrize("num_basis", [1, 2, 5])
+@pytest.mark.parametrize("learn_tau", [True, False])
+@pytest.mark.parametrize("learn_delay", [True, False])
+def test_action_dim_formula(mp_type, num_dof, num_basis, learn_tau, learn_delay):
+    """test/test_black_box.py:168-193"""
+    pc = O.PhaseCfg("exp", learn_tau=learn_tau, learn_delay=learn_delay)
+    bc = O.BasisCfg("prodmp" if mp_type == "prodmp" else "rbf", num_basis=num_basis)
+    tc = O.TrajCfg(mp_type, action_dim=num_dof)
+    expect = num_dof * num_basis + int(learn_tau) + int(learn_delay) + (num_dof if "dmp" in mp_type else 0)
+    assert O.num_params(pc, bc, tc) == expect
+    assert O.params_bounds(pc, bc, tc).shape == (2, expect)
+
+
+def _toy(mp_type, learn_tau, learn_delay):
+    """make_bb('toy-v0', ...) with mp_pytorch defaults: 1 DoF, 10 basis, tau = duration = 1.0, dt = 0.02"""
+    linear = mp_type == "promp"
+    pc = O.PhaseCfg("linear" if linear else "exp", tau=1.0, learn_tau=learn_tau, learn_delay=learn_delay,
+                    tau_bound=(0.04, 1.0), delay_bound=(0.0, 0.96))
+    bc = O.BasisCfg("rbf" if linear else "prodmp", num_basis=10)
+    return pc, bc, O.TrajCfg(mp_type, action_dim=1)
+
+
+@pytest.mark.parametrize("mp_type", ["promp", "prodmp"])
+@pytest.mark.parametrize("tau", [0.25, 0.5, 0.75, 1.0])
+def test_learn_tau_plateau(mp_type, tau):
+    """test/test_black_box.py:219-261 -- param order: action[0] = tau"""
+    pc, bc, tc = _toy(mp_type, True, False)
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal((1, O.num_params(pc, bc, tc))).astype(np.float32)
+    a[0, 0] = tau
+    pos, vel = O.get_trajectory(pc, bc, tc, a, 1.0, 0.02, 0.0, np.ones((1, 1)), np.zeros((1, 1)))
+    pos, vel = pos.flatten(), vel.flatten()
+    n = int(np.round(tau / 0.02))
+    assert pos.shape == (50,)
+    if mp_type == "promp":                      # exact plateau only for the linear phase
+        assert np.all(pos[n:] == pos[-1]) and np.all(vel[n:] == vel[-1])
+    assert np.all(pos[:n - 1] != pos[-1]) and np.all(vel[:n - 2] != vel[-1])
+
+
+@pytest.mark.parametrize("mp_type", ["promp", "prodmp"])
+@pytest.mark.parametrize("delay", [0, 0.25, 0.5, 0.75])
+def test_learn_delay_plateau(mp_type, delay):
+    """test/test_black_box.py:266-307"""
+    pc, bc, tc = _toy(mp_type, False, True)
+    rng = np.random.default_rng(2)
+    a = rng.standard_normal((1, O.num_params(pc, bc, tc))).astype(np.float32)
+    a[0, 0] = delay
+    pos, vel = O.get_trajectory(pc, bc, tc, a, 1.0, 0.02, 0.0, np.ones((1, 1)), np.zeros((1, 1)))
+    pos, vel = pos.flatten(), vel.flatten()
+    n = int(np.round(delay / 0.02))
+    assert np.all(pos[:max(1, n - 1)] == pos[0]) and np.all(vel[:max(1, n - 2)] == vel[0])
+    assert np.all(pos[max(1, n):] != pos[0]) and np.all(vel[max(1, n)] != vel[0])
+
+
+@pytest.mark.parametrize("mp_type", ["promp", "prodmp"])
+@pytest.mark.parametrize("tau", [0.25, 0.5, 0.75])
+@pytest.mark.parametrize("delay", [0.25, 0.5])
+def test_learn_tau_and_delay_plateaus(mp_type, tau, delay):
+    """test/test_black_box.py:312-368 -- action[0] = tau, action[1] = delay"""
+    if 1.0 < delay + tau:
+        pytest.skip("as in the reference")
+    pc, bc, tc = _toy(mp_type, True, True)
+    rng = np.random.default_rng(4)
+    a = rng.standard_normal((1, O.num_params(pc, bc, tc))).astype(np.float32)
+    a[0, 0], a[0, 1] = tau, delay
+    pos, vel = O.get_trajectory(pc, bc, tc, a, 1.0, 0.02, 0.0, np.ones((1, 1)), np.zeros((1, 1)))
+    pos, vel = pos.flatten(), vel.flatten()
+    nt, nd = int(np.round(tau / 0.02)), int(np.round(delay / 0.02))
+    if mp_type == "promp":
+        assert np.all(pos[nd + nt:] == pos[-1]) and np.all(vel[nd + nt:] == vel[-1])
+    assert np.all(pos[:nd - 1] == pos[0]) and np.all(vel[:nd - 2] == vel[0])
+    act_p, act_v = pos[nd: nd + nt - 1], vel[nd: nd + nt - 2]
+    assert np.all(act_p != pos[-1]) and np.all(act_p != pos[0])
+    assert np.all(act_v != vel[-1]) and np.all(act_v != vel[0])
+
+
+def test_sub_trajectory_length_is_round_tau_over_dt():
+    """test/test_replanning_sequencing.py:104-105"""
+    pc, bc, tc = _toy("promp", True, False)
+    for tau in (0.1, 0.33, 0.5, 0.97):
+        a = np.zeros((1, O.num_params(pc, bc, tc)), np.float32)
+        a[0, 0] = tau
+        pos, _ = O.get_trajectory(pc, bc, tc, a, None, 0.02, 0.0, np.ones((1, 1)), np.zeros((1, 1)))
+        assert pos.shape[1] == int(np.round(np.float32(tau) / 0.02))
+
+
+@pytest.mark.parametrize("pd", [(0, 0), (0.5, 0.5), (1.0, -0.25), (np.array([1.0, 2.0]), np.array([0.1, 0.2]))])
+def test_pd_formula_is_exact(pd):
+    """test/test_controller.py:30-44"""
+    p, d = pd
+    rng = np.random.default_rng(0)
+    for _ in range(10):
+        q_d, qd_d, q, qd = (rng.uniform(-1, 1, 2) for _ in range(4))
+        assert np.array_equal(O.pd_action(p, d, q_d, qd_d, q, qd), p * (q_d - q) + d * (qd_d - qd))
+
+
+def test_controller_shape_mismatch_raises():
+    """test/test_controller.py:47-54, :68-73"""
+    with pytest.raises(ValueError):
+        O.pd_action(1, 1, np.ones(2), np.ones(2), np.ones(3), np.ones(2))
+    with pytest.raises(ValueError):
+        O.pd_action(1, 1, np.ones(2), np.ones(2), np.ones(2), np.ones(3))
+    with pytest.raises(ValueError):
+        O.metaworld_action(np.ones(4), None, np.ones(5), None)
+    a = O.metaworld_action(np.array([1., 2., 3., 9.]), None, np.array([.5, .5, .5, 0.]), None)
+    assert np.array_equal(a, np.array([.5, 1.5, 2.5, 9.]))
+
+
+@pytest.mark.parametrize("max_planning_times", [1, 2, 3, 4])
+@pytest.mark.parametrize("every", [5, 10, 25])
+def test_planning_counts(max_planning_times, every):
+    """test/test_replanning_sequencing.py:165-194,338-364: #step() calls per episode == max_planning_times"""
+    horizon = 50 if every < 25 else 100
+    segs = O.replanning_segments(horizon, every, max_planning_times)
+    assert len(segs) == max_planning_times
+    assert sum(n for _, n in segs) == horizon
+    for k, (start, n) in enumerate(segs):
+        assert start == k * every
+        assert n == (every if k < max_planning_times - 1 else horizon - start)

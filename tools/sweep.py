@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""
+Per-configuration throughput sweep on one MI355X (HIP events on the launch stream, median of N launches):
+every BASELINE.json config shape through the C-ABI, the closed-loop rollout kernel, and the PCIe-inclusive rate
+(host numpy in -> host numpy out) for cfg2.   python tools/sweep.py > profiles/rNN_sweep.md
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from fancy_gym_amd import RolloutSpec, TrajectoryEngine  # noqa: E402
+
+PG = 0.01 * np.array([120., 120., 120., 120., 50., 30., 10.])
+DG = 0.01 * np.array([10., 10., 10., 10., 6., 5., 3.])
+TT_P = 0.5 * np.array([1.0, 4.0, 2.0, 4.0, 1.0, 4.0, 1.0])
+TT_D = 0.5 * np.array([0.1, 0.4, 0.2, 0.4, 0.1, 0.4, 0.1])
+
+
+def ev_time(fn, n=50, warm=10):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in evs:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    return float(np.median([a.elapsed_time(b) for a, b in evs])) * 1e-3
+
+
+def row(name, B, T, D, P, t, bytes_per_traj, kernel):
+    print(f"| {name} | {B} | {t * 1e6:.1f} | {B / t:.3e} | {bytes_per_traj} | {B * bytes_per_traj / t / 1e9:.0f} | "
+          f"{B * bytes_per_traj / t / 8e12 * 100:.1f} % | `{kernel}` |")
+
+
+def main():
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(0)
+    print("| config | batch | kernel us | trajectories/s | alg. bytes/traj | GB/s | of 8 TB/s | kernel |")
+    print("|---|---|---|---|---|---|---|---|")
+    cfgs = [
+        ("cfg2 ProDMP 7x5x100, traj only", dict(mp_type="prodmp", phase_type="exp", basis_type="prodmp", num_dof=7,
+          num_basis=5, dt=0.02, duration=2.0, tau=1.5, alpha_phase=3.0, basis_bandwidth_factor=2.0, basis_alpha=10.0),
+         [4096, 65536, 1048576], None),
+        ("cfg2 ProDMP + PD actions (fused)", dict(mp_type="prodmp", phase_type="exp", basis_type="prodmp", num_dof=7,
+          num_basis=5, dt=0.02, duration=2.0, tau=1.5, alpha_phase=3.0, basis_bandwidth_factor=2.0, basis_alpha=10.0),
+         [4096, 65536, 1048576], (PG, DG)),
+        ("cfg3 DMP 7x5x200 (Euler)", dict(mp_type="dmp", phase_type="exp", basis_type="rbf", num_dof=7, num_basis=5,
+          dt=0.02, duration=4.0, tau=4.0, alpha_phase=2.0, dmp_alpha=25.0), [16384, 262144], None),
+        ("cfg4 ProDMP replan plan (P=35)", dict(mp_type="prodmp", phase_type="exp", basis_type="prodmp", num_dof=7,
+          num_basis=5, dt=0.02, duration=2.0, tau=1.5, alpha_phase=3.0, basis_bandwidth_factor=3.0, basis_alpha=10.0,
+          weights_scale=0.3, goal_scale=0.3, auto_scale_basis=True, disable_goal=True), [8192, 65536], None),
+        ("cfg5 ProMP TT 7x3x350 + PD actions", dict(mp_type="promp", phase_type="linear", basis_type="zero_rbf",
+          num_dof=7, num_basis=3, num_basis_zero_start=1, num_basis_zero_goal=1, dt=0.008, duration=2.8, tau=2.8),
+         [1024, 8192, 65536], (TT_P, TT_D)),
+        ("cfg1 ProMP Reacher5d 5x5x200", dict(mp_type="promp", phase_type="linear", basis_type="zero_rbf", num_dof=5,
+          num_basis=5, num_basis_zero_start=1, dt=0.02, duration=4.0, tau=4.0), [1, 4096], None),
+    ]
+    for name, kw, batches, gains in cfgs:
+        eng = TrajectoryEngine(device=0, **kw)
+        T, D, P = eng.num_steps, eng.num_dof, eng.num_params
+        for B in batches:
+            params = torch.randn((B, P), generator=g).to(dev)
+            ip = (torch.rand((B, D), generator=g) * 2 - 1).to(dev)
+            iv = torch.zeros((B, D), device=dev)
+            if gains is None:
+                out = (torch.empty((B, T, D), device=dev), torch.empty((B, T, D), device=dev))
+                t = ev_time(lambda: eng.trajectory(params, ip, iv, 0.0, out=out))
+                nbytes = P * 4 + 2 * D * 4 + 2 * T * D * 4
+            else:
+                spec = RolloutSpec("motor", D, gains[0], gains[1], -1.0, 1.0, plant="static")
+                cp, cv = ip.double(), iv.double()
+                out = tuple(torch.empty((B, T, D), device=dev) for _ in range(3))
+                t = ev_time(lambda: eng.trajectory_actions(params, ip, iv, spec, cp, cv, 0.0, out=out))
+                nbytes = P * 4 + 2 * D * 4 + 3 * T * D * 4
+            row(name, B, T, D, P, t, nbytes, eng.last_kernel())
+            del out, params
+        del eng
+    # closed-loop rollout kernel on cfg2 trajectories (reads pos, vel; writes actions)
+    eng = TrajectoryEngine(device=0, **cfgs[0][1])
+    for B in (4096, 65536):
+        params = torch.randn((B, 42), generator=g).to(dev)
+        ip = (torch.rand((B, 7), generator=g) * 2 - 1).to(dev)
+        iv = torch.zeros((B, 7), device=dev)
+        pos, vel = eng.trajectory(params, ip, iv, 0.0)
+        spec = RolloutSpec("motor", 7, PG, DG, -1.0, 1.0, plant="double_integrator", dt=0.02)
+        q, qd = ip.double().contiguous(), iv.double().contiguous()
+        t = ev_time(lambda: eng.pd_rollout(spec, pos, vel, q, qd))
+        row("k_pd_rollout (double integrator, T=100)", B, 100, 7, 42, t, 3 * 100 * 7 * 4 + 4 * 7 * 8, "k_pd_rollout")
+    # PCIe-inclusive: host numpy params -> device -> kernel -> host numpy pos, vel
+    B = 4096
+    params = np.random.default_rng(0).standard_normal((B, 42)).astype(np.float32)
+    ip = np.random.default_rng(1).uniform(-1, 1, (B, 7)).astype(np.float32)
+    iv = np.zeros((B, 7), np.float32)
+
+    def host_roundtrip():
+        p, v = eng.trajectory(params, ip, iv, 0.0)
+        return p.cpu().numpy(), v.cpu().numpy()
+    for _ in range(5):
+        host_roundtrip()
+    t0 = time.perf_counter()
+    n = 30
+    for _ in range(n):
+        host_roundtrip()
+    t = (time.perf_counter() - t0) / n
+    print(f"\nPCIe-inclusive (pageable host numpy in / out, cfg2 trajectory only, B = {B}): {t * 1e3:.2f} ms per call = "
+          f"{B / t:.3e} trajectories/s")
+
+
+if __name__ == "__main__":
+    main()

@@ -269,14 +269,6 @@ static void fill_devcfg(Handle* h) {
     d.delay_lo = (float)c.delay_bound[0]; d.delay_hi = (float)c.delay_bound[1];
     d.ws = (float)c.weights_scale; d.gs = (float)c.goal_scale;
     d.dmp_alpha = (float)c.dmp_alpha; d.dmp_beta = (float)(c.dmp_alpha / 4.0);
-    for (int k = 0; k <= kMaxKP; ++k) d.scale[k] = 0.f;
-    if (c.mp_type == MPK_MP_PRODMP && c.num_basis + 1 <= kMaxKP + 1) {
-        for (int k = 0; k <= c.num_basis; ++k) {
-            float s = k < c.num_basis ? (float)c.weights_scale : (float)c.goal_scale;
-            if (c.auto_scale_basis) s = (float)h->tab.scale[k] * s;  // fp32 product as the reference's tensor op
-            d.scale[k] = s;
-        }
-    }
     d.tab = h->d_tab;
     d.base_times = h->d_times;
 }
@@ -425,6 +417,12 @@ int mpk_create(const mpk_config* cfg, mpk_handle* out) {
         packed.insert(packed.end(), t.dy2.begin(), t.dy2.end());
         packed.insert(packed.end(), t.pos_basis.begin(), t.pos_basis.end());
         packed.insert(packed.end(), t.vel_basis.begin(), t.vel_basis.end());
+        for (int k = 0; k <= cfg->num_basis; ++k) {
+            // weights_goal_scale[k]: an fp32 tensor product in the reference (scale_factor * weights/goal scale)
+            float sc = k < cfg->num_basis ? (float)cfg->weights_scale : (float)cfg->goal_scale;
+            if (cfg->auto_scale_basis) sc = (float)t.scale[k] * sc;
+            packed.push_back((double)sc);
+        }
     } else {
         build_rbf(*cfg, h->tab);
         packed.insert(packed.end(), h->tab.centers.begin(), h->tab.centers.end());
@@ -492,9 +490,9 @@ int mpk_times(mpk_handle hh, float* times) {
 static int traj_common(Handle* h, const float* params, const float* init_pos, const float* init_vel,
                        const float* init_time, double init_time_shared, float* pos, float* vel, float* actions,
                        const RolloutDev* rd, const double* c_pos, const double* c_vel, int32_t B, void* stream) {
-    if (!params || !init_pos || !init_vel || !pos || !vel) { set_error("NULL buffer"); return MPK_EINVAL; }
     if (B < 0) { set_error("B must be >= 0"); return MPK_EINVAL; }
-    if (B == 0 || h->dev.D == 0) return MPK_OK;
+    if (B == 0 || h->dev.D == 0) return MPK_OK;     // empty batch: nothing to do (buffers may be NULL)
+    if (!params || !init_pos || !init_vel || !pos || !vel) { set_error("NULL buffer"); return MPK_EINVAL; }
     MPK_HIP(hipSetDevice(h->cfg.device));
     if (shared_phase(h, init_time) && mfma_capable(h)) {
         SharedTables st;

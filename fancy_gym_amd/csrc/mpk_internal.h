@@ -42,9 +42,8 @@ struct DevCfg {
     float tau, delay, alpha_phase, scaled_dt;
     float tau_lo, tau_hi, delay_lo, delay_hi;
     float ws, gs, dmp_alpha, dmp_beta;
-    float scale[kMaxKP + 1];       // ProDMP weights_goal_scale per basis column (fp32)
     // device tables
-    const double* tab;             // ProDMP: [y1|y2|dy1|dy2|pos_basis|vel_basis]; RBF: [centers|bw]
+    const double* tab;             // ProDMP: [y1|y2|dy1|dy2|pos_basis|vel_basis|weights_goal_scale]; RBF: [centers|bw]
     const float* base_times;       // [T]
 };
 

@@ -99,10 +99,7 @@ __device__ __forceinline__ void prodmp_col(const DevCfg& c, const ProdmpBC& bc, 
         const bool off = k < c.nb ? c.disable_weights != 0 : c.disable_goal != 0;
         if (!off) {
             hcol(k, &p, &v);
-            double sc = 0.0;   // static-index select: a dynamic index would spill the kernarg struct
-#pragma unroll
-            for (int kk = 0; kk <= kMaxKP; ++kk)
-                if (kk == k) sc = (double)c.scale[kk];
+            const double sc = (VB + (size_t)N * K)[k];   // weights_goal_scale[k], appended to the device tables
             p *= sc; v *= sc;
         }
     } else if (k == K) {

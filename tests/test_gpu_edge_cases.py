@@ -1,0 +1,178 @@
+"""
+GPU suite, part 3: edge cases -- every DoF count / basis count / horizon shape class of the tile machinery (ragged last
+episode group, partial last row tile, unaligned outputs -> generic store path, D or K beyond the MFMA kernel's limits ->
+per-episode kernel), empty batches, bound clipping, range errors, and both work decompositions.
+"""
+import numpy as np
+import pytest
+import torch
+
+from fancy_gym_amd import RolloutSpec, TrajectoryEngine
+from oracle import mp_oracle as O
+from tests.test_gpu_trajectory import close, fd_atol, inputs, make_engine
+
+pytestmark = pytest.mark.gpu
+
+
+def cfg_for(mp, D, nb, T, dt=0.02, **tkw):
+    dur = T * dt
+    if mp == "prodmp":
+        return (O.PhaseCfg("exp", tau=dur * 0.75, alpha_phase=3.0), O.BasisCfg("prodmp", num_basis=nb, alpha=10),
+                O.TrajCfg("prodmp", action_dim=D, **tkw), dt, dur)
+    if mp == "dmp":
+        return (O.PhaseCfg("exp", tau=dur, alpha_phase=2.0), O.BasisCfg("rbf", num_basis=nb),
+                O.TrajCfg("dmp", action_dim=D, alpha=25.0, weights_scale=0.8, goal_scale=1.2), dt, dur)
+    return (O.PhaseCfg("linear", tau=dur), O.BasisCfg("zero_rbf", num_basis=nb, num_basis_zero_start=1,
+                                                      num_basis_zero_goal=1),
+            O.TrajCfg("promp", action_dim=D, weights_scale=0.9), dt, dur)
+
+
+def check(cfg, B, init_time=0.0, expect_kernel=None, seed=0):
+    pc, bc, tc, dt, dur = cfg
+    eng = make_engine(pc, bc, tc, dt, dur)
+    params, ip, iv = inputs(pc, bc, tc, B, seed=seed)
+    pos, vel = eng.trajectory(params, ip, iv, init_time)
+    torch.cuda.synchronize()
+    if expect_kernel:
+        assert eng.last_kernel().startswith(expect_kernel), eng.last_kernel()
+    rp, rv = O.get_trajectory(pc, bc, tc, params, dur, dt, init_time, ip, iv, dtype=np.float64)
+    close(pos.cpu().numpy(), rp, "pos")
+    close(vel.cpu().numpy(), rv, "vel", atol=fd_atol(rp, dt) if tc.trajectory_generator_type == "promp" else 0.0)
+    return eng
+
+
+@pytest.mark.parametrize("mp", ["prodmp", "promp", "dmp"])
+@pytest.mark.parametrize("D", [1, 2, 3, 4, 5, 7, 8, 9, 16])
+@pytest.mark.parametrize("mapping", ["1", "2"])
+def test_every_dof_class(mp, D, mapping, monkeypatch):
+    monkeypatch.setenv("MPK_MAPPING", mapping)
+    for B in (1, 17):
+        check(cfg_for(mp, D, 4, 36), B, expect_kernel="k_traj_", seed=D + B)
+
+
+@pytest.mark.parametrize("mp,nb", [("prodmp", 1), ("prodmp", 2), ("prodmp", 6), ("prodmp", 9), ("prodmp", 13),
+                                   ("promp", 1), ("promp", 4), ("promp", 8), ("promp", 15), ("dmp", 1), ("dmp", 7),
+                                   ("dmp", 12), ("dmp", 16)])
+def test_every_contraction_length(mp, nb):
+    """KM = 1..4 k-chunks of the MFMA"""
+    eng = check(cfg_for(mp, 3, nb, 40), 9, expect_kernel="k_traj_", seed=nb)
+    assert not eng.last_kernel().startswith("k_traj_rows")
+
+
+@pytest.mark.parametrize("mp", ["prodmp", "promp", "dmp"])
+@pytest.mark.parametrize("T", [2, 3, 15, 16, 17, 31, 33, 50, 101])
+@pytest.mark.parametrize("D", [1, 7])
+def test_every_horizon_class(mp, T, D):
+    """partial last row tile; T*D % 4 != 0 (unaligned outputs) takes the generic store path"""
+    for mapping in ("1", "2"):
+        import os
+        os.environ["MPK_MAPPING"] = mapping
+        try:
+            check(cfg_for(mp, D, 3, T), 5, seed=T)
+        finally:
+            os.environ.pop("MPK_MAPPING", None)
+
+
+@pytest.mark.parametrize("mp", ["prodmp", "promp", "dmp"])
+def test_limits_fall_back_to_the_per_episode_kernel(mp):
+    check(cfg_for(mp, 17, 4, 20), 6, expect_kernel="k_traj_rows")          # D > 16
+    check(cfg_for(mp, 2, 20, 20), 6, expect_kernel="k_traj_rows")          # more than 16 basis columns
+    check(cfg_for(mp, 40, 3, 24), 3, expect_kernel="k_traj_rows")
+
+
+@pytest.mark.parametrize("flags", [dict(disable_goal=True), dict(disable_weights=True), dict(relative_goal=True),
+                                   dict(relative_goal=True, disable_goal=True), dict(auto_scale_basis=True),
+                                   dict(auto_scale_basis=True, weights_scale=0.3, goal_scale=2.0, relative_goal=True)])
+@pytest.mark.parametrize("init_time", [0.0, 0.3])
+def test_prodmp_flags(flags, init_time):
+    cfg = cfg_for("prodmp", 5, 4, 60, **flags)
+    check(cfg, 11, init_time, expect_kernel="k_traj_")
+    # same flags through the per-episode kernel, bit for bit
+    pc, bc, tc, dt, dur = cfg
+    eng = make_engine(pc, bc, tc, dt, dur)
+    params, ip, iv = inputs(pc, bc, tc, 11, seed=3)
+    p0, v0 = eng.trajectory(params, ip, iv, init_time)
+    p1, v1 = eng.trajectory(params, ip, iv, torch.full((11,), init_time, device="cuda"))
+    assert eng.last_kernel().startswith("k_traj_rows")
+    assert torch.equal(p0, p1) and torch.equal(v0, v1)
+
+
+def test_empty_and_single_episode_batches():
+    pc, bc, tc, dt, dur = cfg_for("prodmp", 7, 5, 100)
+    eng = make_engine(pc, bc, tc, dt, dur)
+    pos, vel = eng.trajectory(np.zeros((0, 42), np.float32), np.zeros((0, 7), np.float32), np.zeros((0, 7), np.float32))
+    assert pos.shape == (0, 100, 7) and vel.shape == (0, 100, 7)
+    p1, _ = eng.trajectory(np.ones(42, np.float32), np.zeros(7, np.float32), np.zeros(7, np.float32))   # 1-D params
+    assert p1.shape == (1, 100, 7)
+    with pytest.raises(ValueError):
+        eng.trajectory(np.zeros((2, 41), np.float32), np.zeros((2, 7)), np.zeros((2, 7)))
+
+
+def test_learned_tau_delay_are_clipped_to_their_bounds():
+    """np.clip(action, low, high) of black_box_wrapper.py:104-105 happens inside the kernel"""
+    pc = O.PhaseCfg("linear", tau=1.0, learn_tau=True, learn_delay=True, tau_bound=(0.3, 0.8), delay_bound=(0.1, 0.2))
+    bc, tc = O.BasisCfg("rbf", num_basis=6), O.TrajCfg("promp", action_dim=2)
+    eng = make_engine(pc, bc, tc, 0.02, 1.0)
+    B = 64
+    params, ip, iv = inputs(pc, bc, tc, B, seed=1)
+    params[:, 0] = np.linspace(0.05, 1.5, B)        # far outside [0.3, 0.8] on both sides
+    params[:, 1] = np.linspace(0.0, 0.5, B)
+    pos, vel = eng.trajectory(params, ip, iv, 0.0)
+    rp, rv = O.get_trajectory(pc, bc, tc, params, 1.0, 0.02, 0.0, ip, iv, dtype=np.float64, clip=True)
+    close(pos.cpu().numpy(), rp, "clipped pos")
+    clipped = np.clip(params, *O.params_bounds(pc, bc, tc))
+    assert not np.array_equal(clipped, params)
+
+
+def test_prodmp_time_beyond_precompute_range_raises():
+    """mp_pytorch: RuntimeError('Time is beyond the pre-computation range...')"""
+    eng = TrajectoryEngine("prodmp", "exp", "prodmp", 2, 3, dt=0.02, duration=2.0, tau=0.3, basis_alpha=10.0)
+    with pytest.raises(RuntimeError, match="pre-computation range"):
+        eng.trajectory(np.zeros((4, 8), np.float32), np.zeros((4, 2)), np.zeros((4, 2)), 0.0)     # 2.0 / 0.3 > 6
+
+
+def test_set_duration_changes_the_horizon():
+    pc, bc, tc, dt, dur = cfg_for("promp", 3, 4, 50)
+    eng = make_engine(pc, bc, tc, dt, dur)
+    params, ip, iv = inputs(pc, bc, tc, 7)
+    assert eng.trajectory(params, ip, iv)[0].shape == (7, 50, 3)
+    eng.set_duration(0.5, dt)
+    assert eng.num_steps == 25
+    pos, vel = eng.trajectory(params, ip, iv)
+    rp, rv = O.get_trajectory(pc, bc, tc, params, 0.5, dt, 0.0, ip, iv, dtype=np.float64)
+    close(pos.cpu().numpy(), rp, "pos after set_duration")
+    assert np.array_equal(eng.times(), O.make_times(0.5, dt, 0.0))
+
+
+def test_many_init_times_cycle_the_table_cache():
+    pc, bc, tc, dt, dur = cfg_for("prodmp", 4, 5, 64)
+    eng = make_engine(pc, bc, tc, dt, dur)
+    params, ip, iv = inputs(pc, bc, tc, 9)
+    first = {}
+    for rnd in range(2):
+        for k in range(12):                  # more distinct init_times than cache slots (8)
+            it = k * dt
+            pos, vel = eng.trajectory(params, ip, iv, it)
+            if rnd == 0:
+                rp, rv = O.get_trajectory(pc, bc, tc, params, dur, dt, it, ip, iv, dtype=np.float64)
+                close(pos.cpu().numpy(), rp, f"init_time {it}")
+                first[k] = pos.clone()
+            else:
+                assert torch.equal(pos, first[k])
+
+
+@pytest.mark.parametrize("D,T", [(3, 10), (7, 33)])
+def test_fused_actions_on_unaligned_shapes(D, T):
+    cfg = cfg_for("prodmp", D, 3, T)
+    pc, bc, tc, dt, dur = cfg
+    eng = make_engine(pc, bc, tc, dt, dur)
+    B = 13
+    params, ip, iv = inputs(pc, bc, tc, B)
+    pg, dg = np.linspace(0.5, 1.5, D), np.linspace(0.05, 0.2, D)
+    spec = RolloutSpec("motor", D, pg, dg, -0.7, 0.7, plant="static")
+    pos, vel, act = eng.trajectory_actions(params, ip, iv, spec, ip.astype(np.float64), iv.astype(np.float64))
+    ra, _, _ = O.rollout(pos.cpu().numpy(), vel.cpu().numpy(), "motor", pg, dg, -0.7, 0.7, "static", dt,
+                         ip.astype(np.float64), iv.astype(np.float64))
+    assert np.array_equal(act.cpu().numpy(), ra.astype(np.float32))
+    rp, _ = O.get_trajectory(pc, bc, tc, params, dur, dt, 0.0, ip, iv, dtype=np.float64)
+    close(pos.cpu().numpy(), rp, "pos")

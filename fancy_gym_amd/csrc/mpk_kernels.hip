@@ -509,18 +509,87 @@ __global__ void __launch_bounds__(256) k_traj_tiles(const TrajArgs a, const ActA
 }
 
 // ---- episode-major ---------------------------------------------------------------------------------------------
+// all row tiles of one episode group, in order (shared by the two input-staging variants of k_traj_stream)
 template <int MP, int CT, int KM>
-__global__ void __launch_bounds__(256) k_traj_stream(const TrajArgs a, const ActArgs act) {
-    __shared__ __attribute__((aligned(16))) float smem[4 * kStageFloats];
-    extern __shared__ __attribute__((aligned(16))) float sTab[];   // [NOUT][KP][TS] basis rows + [TS] aux
+__device__ __forceinline__ void stream_group(const TrajArgs& a, const LaneMap<KM>& L, const float* ap,
+                                             const float* sAux, const double* sg, float* sSt, int lane, int b0,
+                                             const float (&xb)[KM], double cp, double cv, float ey, float ez,
+                                             float eg, bool eul) {
     constexpr bool ACT = CT >= 0;
     constexpr int NOUT = MP == MPK_MP_PRODMP ? 2 : (MP == MPK_MP_PROMP ? 3 : 1);
     constexpr int NST = 2 + (ACT ? 1 : 0);
     const DevCfg& c = a.c;
+    const int KP = 4 * KM, TS = a.TS, D = c.D, T = c.T, SEG = 16 * D;
+    const int NRT = (T + 15) >> 4;
+    for (int rt = 0; rt < NRT; ++rt) {
+        const int rows = min(16, T - rt * 16);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < KM; ++m) {
+            const float* am = ap + (4 * m) * TS + rt * 16;
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[0], xb[m], acc0, 0, 0, 0);
+            if (NOUT > 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[KP * TS], xb[m], acc1, 0, 0, 0);
+            if (NOUT > 2) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[2 * KP * TS], xb[m], acc2, 0, 0, 0);
+        }
+        if (MP != MPK_MP_DMP) {
+            float dtd[4] = {1.f, 1.f, 1.f, 1.f};
+            if (MP == MPK_MP_PROMP) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dtd[r] = sAux[rt * 16 + 4 * L.q + r];
+            }
+            if (L.dvalid) tile_epilogue<MP, CT>(acc0, acc1, acc2, dtd, cp, cv, sg, sSt, L.wofs, D);
+        } else {
+            // DMP: forcing tile -> LDS, then explicit Euler in scaled time on lanes (q == 0), serial in t;
+            // one rounding per op (no FMA), first sample = initial condition
+            float* sF = sSt + 2 * kStageStride;
+            if (L.dvalid) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sF[L.wofs + r * D] = acc0[r];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (eul) {
+                for (int tl = 0; tl < rows; ++tl) {
+                    const int t = rt * 16 + tl;
+                    const int o = L.bl * SEG + tl * D + L.d;
+                    sSt[o] = ey;
+                    sSt[kStageStride + o] = ez / c.tau;
+                    if (t < T - 1) {
+                        const float f = sF[o], ds = sAux[t];
+                        const float t1 = eg - ey;
+                        const float t2 = c.dmp_beta * t1;
+                        const float t3 = t2 - ez;
+                        const float t4 = c.dmp_alpha * t3;
+                        const float acc = t4 + f;
+                        ez = ez + ds * acc;
+                        ey = ey + ds * ez;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        tile_store<NST, KM, false>(a, L, sSt, lane, b0, rt, rows);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+constexpr int kChunkGroups = 4;   // episode groups whose inputs one bulk read brings in (BULK variant)
+
+// BULK = false: the raw inputs of the next episode group are gathered per lane straight from HBM (as tile-major).
+// BULK = true : a wave owns CHUNKS of kChunkGroups consecutive groups; the chunk's params / init_pos / init_vel
+//               (/ c_pos / c_vel) blocks are contiguous in HBM and are read with a handful of coalesced float4 loads
+//               one chunk ahead, parked in registers, and committed to a double-buffered wave-private LDS image from
+//               which the B fragments are gathered.  Rationale: at HBM-streaming batch sizes the
+//               scattered 336-byte parameter reads interleaved with the write stream cost ~35 % of the bandwidth.
+template <int MP, int CT, int KM, bool BULK>
+__global__ void __launch_bounds__(256) k_traj_stream(const TrajArgs a, const ActArgs act) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * kStageFloats];
+    extern __shared__ __attribute__((aligned(16))) float sTab[];   // [NOUT][KP][TS] rows + [TS] aux (+ chunk images)
+    constexpr bool ACT = CT >= 0;
+    constexpr int NOUT = MP == MPK_MP_PRODMP ? 2 : (MP == MPK_MP_PROMP ? 3 : 1);
+    const DevCfg& c = a.c;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int KP = 4 * KM, TS = a.TS, D = c.D, T = c.T, B = a.B;
-    const int SEG = 16 * D;
+    const int KP = 4 * KM, TS = a.TS, D = c.D, B = a.B, P = c.P;
     float* sSt = smem + wave * kStageFloats;
     float* sA = sTab;
     float* sAux = sTab + NOUT * KP * TS;
@@ -535,102 +604,161 @@ __global__ void __launch_bounds__(256) k_traj_stream(const TrajArgs a, const Act
     }
     __syncthreads();
     const LaneMap<KM> L = make_lane_map<MP, KM>(a, lane);
-    const int NRT = (T + 15) >> 4;
     // XCD-contiguous virtual block id (workgroup b runs on XCD b % 8): neighbouring episode groups share an L2
     const int nb8 = gridDim.x >> 3;
     const int vb = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * nb8 + (blockIdx.x >> 3) : blockIdx.x;
-    const int gstride = gridDim.x * 4;
-    int g = vb * 4 + wave;
-    if (g >= a.G) return;
-    if (ACT) park_gains(act, lane, L.d, sSt);
-    const double* sg = reinterpret_cast<const double*>(sSt + 3 * kStageStride) + (L.dvalid ? L.d : 0);
+    const int wstride = gridDim.x * 4;
+    const int w0 = vb * 4 + wave;
     const float* ap = sA + L.q * TS + L.col;
+    const double* sg = reinterpret_cast<const double*>(sSt + 3 * kStageStride) + (L.dvalid ? L.d : 0);
 
-    float xb[KM];
-    GroupIn<KM> cur = load_group<MP, ACT, KM>(a, L, g);
-    finish_group<KM>(L, cur, xb);
-    double cp = cur.cp, cv = cur.cv;
-    while (g < a.G) {
-        const int b0 = g * L.NTW;
-        const int gn = g + gstride;
-        const GroupIn<KM> nxt = load_group<MP, ACT, KM>(a, L, gn < a.G ? gn : g);
-        float ey = 0.f, ez = 0.f, eg = 0.f;
-        const bool eul = MP == MPK_MP_DMP && L.dvalid && L.q == 0 && b0 + L.bl < B;
-        if (MP == MPK_MP_DMP) {
-            if (eul) {
-                const int b = b0 + L.bl;
-                ey = a.init_pos[(size_t)b * D + L.d];
-                ez = a.init_vel[(size_t)b * D + L.d] * c.tau;
-                eg = a.params[(size_t)b * c.P + c.off + L.d * c.Kloc + c.nb] * c.gs;
-            }
-        }
-        for (int rt = 0; rt < NRT; ++rt) {
-            const int rows = min(16, T - rt * 16);
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int m = 0; m < KM; ++m) {
-                const float* am = ap + (4 * m) * TS + rt * 16;
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[0], xb[m], acc0, 0, 0, 0);
-                if (NOUT > 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[KP * TS], xb[m], acc1, 0, 0, 0);
-                if (NOUT > 2) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[2 * KP * TS], xb[m], acc2, 0, 0, 0);
-            }
-            if (MP != MPK_MP_DMP) {
-                float dtd[4] = {1.f, 1.f, 1.f, 1.f};
-                if (MP == MPK_MP_PROMP) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) dtd[r] = sAux[rt * 16 + 4 * L.q + r];
-                }
-                if (L.dvalid) tile_epilogue<MP, CT>(acc0, acc1, acc2, dtd, cp, cv, sg, sSt, L.wofs, D);
-            } else {
-                // DMP: forcing tile -> LDS, then explicit Euler in scaled time on lanes (q == 0), serial in t;
-                // one rounding per op (no FMA), first sample = initial condition
-                float* sF = sSt + 2 * kStageStride;
-                if (L.dvalid) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) sF[L.wofs + r * D] = acc0[r];
-                }
-                __builtin_amdgcn_wave_barrier();
+    if (!BULK) {
+        int g = w0;
+        if (g >= a.G) return;
+        if (ACT) park_gains(act, lane, L.d, sSt);
+        float xb[KM];
+        GroupIn<KM> cur = load_group<MP, ACT, KM>(a, L, g);
+        finish_group<KM>(L, cur, xb);
+        double cp = cur.cp, cv = cur.cv;
+        while (g < a.G) {
+            const int b0 = g * L.NTW;
+            const int gn = g + wstride;
+            const GroupIn<KM> nxt = load_group<MP, ACT, KM>(a, L, gn < a.G ? gn : g);
+            float ey = 0.f, ez = 0.f, eg = 0.f;
+            const bool eul = MP == MPK_MP_DMP && L.dvalid && L.q == 0 && b0 + L.bl < B;
+            if (MP == MPK_MP_DMP) {
                 if (eul) {
-                    for (int tl = 0; tl < rows; ++tl) {
-                        const int t = rt * 16 + tl;
-                        const int o = L.bl * SEG + tl * D + L.d;
-                        sSt[o] = ey;
-                        sSt[kStageStride + o] = ez / c.tau;
-                        if (t < T - 1) {
-                            const float f = sF[o], ds = sAux[t];
-                            const float t1 = eg - ey;
-                            const float t2 = c.dmp_beta * t1;
-                            const float t3 = t2 - ez;
-                            const float t4 = c.dmp_alpha * t3;
-                            const float acc = t4 + f;
-                            ez = ez + ds * acc;
-                            ey = ey + ds * ez;
-                        }
+                    const int b = b0 + L.bl;
+                    ey = a.init_pos[(size_t)b * D + L.d];
+                    ez = a.init_vel[(size_t)b * D + L.d] * c.tau;
+                    eg = a.params[(size_t)b * P + c.off + L.d * c.Kloc + c.nb] * c.gs;
+                }
+            }
+            stream_group<MP, CT, KM>(a, L, ap, sAux, sg, sSt, lane, b0, xb, cp, cv, ey, ez, eg, eul);
+            finish_group<KM>(L, nxt, xb);
+            cp = nxt.cp; cv = nxt.cv;
+            g = gn;
+        }
+    } else {
+        constexpr int CH = kChunkGroups;
+        const int NTW = L.NTW, EPC = CH * NTW;                 // episodes per chunk
+        const int NCH = (B + EPC - 1) / EPC;
+        int ch = w0;
+        if (ch >= NCH) return;
+        if (ACT) park_gains(act, lane, L.d, sSt);
+        // chunk image (floats): [params EPC*P | init_pos EPC*D | init_vel EPC*D | c_pos 2*EPC*D | c_vel 2*EPC*D]
+        const int offIP = EPC * P, offIV = offIP + EPC * D, offCP = offIV + EPC * D, offCV = offCP + 2 * EPC * D;
+        const int img = offCV + 2 * EPC * D;
+        float* sImg = sAux + TS + wave * (2 * img);
+        const int nP4 = (EPC * P) >> 2, nI4 = (EPC * D) >> 2, nC4 = (EPC * D) >> 1;    // float4 per block
+        f32x4 rp0 = {0, 0, 0, 0}, rp1 = rp0, rip = rp0, riv = rp0, rcp = rp0, rcv = rp0;
+        auto issue = [&](int chn) {       // coalesced float4 reads of a FULL chunk (ragged chunks are read below)
+            const size_t e0 = (size_t)chn * EPC;
+            const f32x4* p4 = reinterpret_cast<const f32x4*>(a.params + e0 * P);
+            const f32x4* i4 = reinterpret_cast<const f32x4*>(a.init_pos + e0 * D);
+            const f32x4* v4 = reinterpret_cast<const f32x4*>(a.init_vel + e0 * D);
+            if (lane < nP4) rp0 = p4[lane];
+            if (lane + 64 < nP4) rp1 = p4[lane + 64];
+            if (lane < nI4) { rip = i4[lane]; riv = v4[lane]; }
+            if (ACT) {
+                if (lane < nC4) {
+                    rcp = reinterpret_cast<const f32x4*>(a.c_pos + e0 * D)[lane];
+                    rcv = reinterpret_cast<const f32x4*>(a.c_vel + e0 * D)[lane];
+                }
+            }
+        };
+        auto commit = [&](float* buf) {
+            f32x4* b4 = reinterpret_cast<f32x4*>(buf);
+            if (lane < nP4) b4[lane] = rp0;
+            if (lane + 64 < nP4) b4[lane + 64] = rp1;
+            if (lane < nI4) { b4[(offIP >> 2) + lane] = rip; b4[(offIV >> 2) + lane] = riv; }
+            if (ACT) {
+                if (lane < nC4) { b4[(offCP >> 2) + lane] = rcp; b4[(offCV >> 2) + lane] = rcv; }
+            }
+        };
+        auto read_ragged = [&](int chn, float* buf) {   // last, incomplete chunk: element-wise, bounds-checked
+            const size_t e0 = (size_t)chn * EPC;
+            const int ne = B - (int)e0;
+            for (int e = lane; e < ne * P; e += 64) buf[e] = a.params[e0 * P + e];
+            for (int e = lane; e < ne * D; e += 64) {
+                buf[offIP + e] = a.init_pos[e0 * D + e];
+                buf[offIV + e] = a.init_vel[e0 * D + e];
+                if (ACT) {
+                    reinterpret_cast<double*>(buf + offCP)[e] = a.c_pos[e0 * D + e];
+                    reinterpret_cast<double*>(buf + offCV)[e] = a.c_vel[e0 * D + e];
+                }
+            }
+        };
+        auto full = [&](int chn) { return (chn + 1) * EPC <= B; };
+        int cur = 0;
+        if (full(ch)) { issue(ch); commit(sImg); } else read_ragged(ch, sImg);
+        __builtin_amdgcn_wave_barrier();
+        while (ch < NCH) {
+            const int chn = ch + wstride;
+            const bool have_next = chn < NCH, next_full = have_next && full(chn);
+            if (next_full) issue(chn);                      // in flight under this chunk's CH groups
+            const float* buf = sImg + cur * img;
+            for (int j = 0; j < CH; ++j) {
+                const int g = ch * CH + j;
+                if (g >= a.G) break;
+                const int b0 = g * NTW;
+                const float* pj = buf + j * NTW * P;
+                const unsigned io = (unsigned)(j * NTW * D) + L.ioff;
+                float xb[KM];
+                const float ip = buf[offIP + io], iv = buf[offIV + io];
+#pragma unroll
+                for (int m = 0; m < KM; ++m) {
+                    const float raw = pj[L.poff[m]];
+                    xb[m] = L.isp[m] ? raw : (L.isip[m] ? ip : (L.isiv[m] ? iv : 0.0f));
+                }
+                double cp = 0.0, cv = 0.0;
+                if (ACT) {
+                    cp = reinterpret_cast<const double*>(buf + offCP)[io];
+                    cv = reinterpret_cast<const double*>(buf + offCV)[io];
+                }
+                float ey = 0.f, ez = 0.f, eg = 0.f;
+                const bool eul = MP == MPK_MP_DMP && L.dvalid && L.q == 0 && b0 + L.bl < B;
+                if (MP == MPK_MP_DMP) {
+                    if (eul) {
+                        ey = ip;
+                        ez = iv * c.tau;
+                        eg = pj[L.bl * P + c.off + L.d * c.Kloc + c.nb] * c.gs;
                     }
                 }
+                stream_group<MP, CT, KM>(a, L, ap, sAux, sg, sSt, lane, b0, xb, cp, cv, ey, ez, eg, eul);
             }
-            __builtin_amdgcn_wave_barrier();
-            tile_store<NST, KM, false>(a, L, sSt, lane, b0, rt, rows);
-            __builtin_amdgcn_wave_barrier();
+            if (have_next) {
+                float* nb = sImg + (cur ^ 1) * img;
+                if (next_full) commit(nb); else read_ragged(chn, nb);
+                __builtin_amdgcn_wave_barrier();
+            }
+            cur ^= 1;
+            ch = chn;
         }
-        finish_group<KM>(L, nxt, xb);
-        cp = nxt.cp; cv = nxt.cv;
-        g = gn;
     }
 }
 
 template <int MP, int CT>
-static int launch_traj_t(const TrajArgs& ta, const ActArgs& aa, bool stream_mode, bool write_through, int blocks,
-                         size_t lds, void* stream) {
+static int launch_traj_t(const TrajArgs& ta, const ActArgs& aa, bool stream_mode, bool write_through, bool bulk,
+                         int blocks, size_t lds, void* stream) {
     const dim3 g(blocks), b(256);
     hipStream_t s = (hipStream_t)stream;
     const int km = ta.c.KP / 4;
     if (stream_mode) {
-        switch (km) {
-            case 1: hipLaunchKernelGGL((k_traj_stream<MP, CT, 1>), g, b, lds, s, ta, aa); break;
-            case 2: hipLaunchKernelGGL((k_traj_stream<MP, CT, 2>), g, b, lds, s, ta, aa); break;
-            case 3: hipLaunchKernelGGL((k_traj_stream<MP, CT, 3>), g, b, lds, s, ta, aa); break;
-            default: hipLaunchKernelGGL((k_traj_stream<MP, CT, 4>), g, b, lds, s, ta, aa); break;
+        if (bulk) {
+            switch (km) {
+                case 1: hipLaunchKernelGGL((k_traj_stream<MP, CT, 1, true>), g, b, lds, s, ta, aa); break;
+                case 2: hipLaunchKernelGGL((k_traj_stream<MP, CT, 2, true>), g, b, lds, s, ta, aa); break;
+                case 3: hipLaunchKernelGGL((k_traj_stream<MP, CT, 3, true>), g, b, lds, s, ta, aa); break;
+                default: hipLaunchKernelGGL((k_traj_stream<MP, CT, 4, true>), g, b, lds, s, ta, aa); break;
+            }
+        } else {
+            switch (km) {
+                case 1: hipLaunchKernelGGL((k_traj_stream<MP, CT, 1, false>), g, b, lds, s, ta, aa); break;
+                case 2: hipLaunchKernelGGL((k_traj_stream<MP, CT, 2, false>), g, b, lds, s, ta, aa); break;
+                case 3: hipLaunchKernelGGL((k_traj_stream<MP, CT, 3, false>), g, b, lds, s, ta, aa); break;
+                default: hipLaunchKernelGGL((k_traj_stream<MP, CT, 4, false>), g, b, lds, s, ta, aa); break;
+            }
         }
     } else {
         if constexpr (MP != MPK_MP_DMP) {
@@ -657,27 +785,23 @@ static int launch_traj_t(const TrajArgs& ta, const ActArgs& aa, bool stream_mode
 
 template <int MP>
 static int launch_traj_ct(const TrajArgs& ta, const ActArgs& aa, int ct, bool stream_mode, bool write_through,
-                          int blocks, size_t lds, void* stream) {
+                          bool bulk, int blocks, size_t lds, void* stream) {
     if constexpr (MP != MPK_MP_DMP) {
         switch (ct) {
-            case MPK_CTRL_MOTOR: return launch_traj_t<MP, MPK_CTRL_MOTOR>(ta, aa, stream_mode, write_through, blocks, lds, stream);
-            case MPK_CTRL_VELOCITY: return launch_traj_t<MP, MPK_CTRL_VELOCITY>(ta, aa, stream_mode, write_through, blocks, lds, stream);
-            case MPK_CTRL_POSITION: return launch_traj_t<MP, MPK_CTRL_POSITION>(ta, aa, stream_mode, write_through, blocks, lds, stream);
+            case MPK_CTRL_MOTOR: return launch_traj_t<MP, MPK_CTRL_MOTOR>(ta, aa, stream_mode, write_through, bulk, blocks, lds, stream);
+            case MPK_CTRL_VELOCITY: return launch_traj_t<MP, MPK_CTRL_VELOCITY>(ta, aa, stream_mode, write_through, bulk, blocks, lds, stream);
+            case MPK_CTRL_POSITION: return launch_traj_t<MP, MPK_CTRL_POSITION>(ta, aa, stream_mode, write_through, bulk, blocks, lds, stream);
             default: break;
         }
     }
-    return launch_traj_t<MP, -1>(ta, aa, stream_mode, write_through, blocks, lds, stream);
+    return launch_traj_t<MP, -1>(ta, aa, stream_mode, write_through, bulk, blocks, lds, stream);
 }
 
 // 0 = automatic, 1 = force tile-major, 2 = force episode-major (MPK_MAPPING environment variable, for A/B runs)
 static int mapping_override() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("MPK_MAPPING");
-        v = e ? atoi(e) : 0;
-        if (v < 0 || v > 2) v = 0;
-    }
-    return v;
+    const char* e = getenv("MPK_MAPPING");   // read per launch: tests flip it at run time
+    const int v = e ? atoi(e) : 0;
+    return (v < 0 || v > 2) ? 0 : v;
 }
 
 int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* params, const float* init_pos,
@@ -724,9 +848,24 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     if (const char* e = getenv("MPK_WRITE_THROUGH")) write_through = atoi(e) != 0 && !stream_mode;
     int blocks;
     size_t lds = 0;
+    bool bulk = false;
     if (stream_mode) {
         lds = table_bytes;
-        const long waves = ta.G < max_waves ? ta.G : max_waves;
+        // bulk input staging: chunk blocks must be float4-sized / aligned and fit the per-lane register image
+        const int EPC = kChunkGroups * NTW;
+        const size_t img_floats = (size_t)EPC * (c.P + 2 * c.D + 4 * c.D);
+        const size_t lds_bulk = table_bytes + 4 * 2 * img_floats * sizeof(float);
+        bulk = (EPC * c.P) % 4 == 0 && (EPC * c.D) % 4 == 0 && (EPC * c.P) / 4 <= 128 && (EPC * c.D) / 2 <= 64 &&
+               aligned16(params) && aligned16(init_pos) && aligned16(init_vel) &&
+               (!act || (aligned16(c_pos) && aligned16(c_vel))) &&
+               lds_bulk + 4 * kStageFloats * sizeof(float) <= 64 * 1024;
+        // MPK_BULK=0 disables, =2 forces it below the size threshold too (tests); default: HBM-streaming sizes only
+        int bulk_mode = 1;
+        if (const char* e = getenv("MPK_BULK")) bulk_mode = atoi(e);
+        bulk = bulk && bulk_mode != 0 && (bulk_mode == 2 || out_bytes > 96.0 * 1024 * 1024);
+        long units = ta.G;
+        if (bulk) { lds = lds_bulk; units = (ta.G + kChunkGroups - 1) / kChunkGroups; }
+        const long waves = units < max_waves ? units : max_waves;
         blocks = (int)((waves + 3) / 4);
         if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;                  // XCD-contiguous remap needs a multiple of 8
     } else {
@@ -741,14 +880,14 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         case MPK_MP_PRODMP:
             *kernel_name = stream_mode ? (act ? "k_traj_stream<prodmp,act>" : "k_traj_stream<prodmp>")
                                        : (act ? "k_traj_tiles<prodmp,act>" : "k_traj_tiles<prodmp>");
-            return launch_traj_ct<MPK_MP_PRODMP>(ta, aa, ct, stream_mode, write_through, blocks, lds, stream);
+            return launch_traj_ct<MPK_MP_PRODMP>(ta, aa, ct, stream_mode, write_through, bulk, blocks, lds, stream);
         case MPK_MP_PROMP:
             *kernel_name = stream_mode ? (act ? "k_traj_stream<promp,act>" : "k_traj_stream<promp>")
                                        : (act ? "k_traj_tiles<promp,act>" : "k_traj_tiles<promp>");
-            return launch_traj_ct<MPK_MP_PROMP>(ta, aa, ct, stream_mode, write_through, blocks, lds, stream);
+            return launch_traj_ct<MPK_MP_PROMP>(ta, aa, ct, stream_mode, write_through, bulk, blocks, lds, stream);
         default:
             *kernel_name = "k_traj_stream<dmp>";
-            return launch_traj_ct<MPK_MP_DMP>(ta, aa, -1, true, false, blocks, lds, stream);
+            return launch_traj_ct<MPK_MP_DMP>(ta, aa, -1, true, false, bulk, blocks, lds, stream);
     }
 }
 

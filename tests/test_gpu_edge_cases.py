@@ -176,3 +176,25 @@ def test_fused_actions_on_unaligned_shapes(D, T):
     assert np.array_equal(act.cpu().numpy(), ra.astype(np.float32))
     rp, _ = O.get_trajectory(pc, bc, tc, params, dur, dt, 0.0, ip, iv, dtype=np.float64)
     close(pos.cpu().numpy(), rp, "pos")
+
+
+@pytest.mark.parametrize("mp", ["prodmp", "promp", "dmp"])
+@pytest.mark.parametrize("B", [1, 7, 8, 9, 67])
+def test_bulk_input_staging_on_ragged_batches(mp, B, monkeypatch):
+    """episode-major kernel with chunked LDS input staging, forced at small sizes: full, ragged and single chunks"""
+    monkeypatch.setenv("MPK_MAPPING", "2")
+    monkeypatch.setenv("MPK_BULK", "2")
+    eng = check(cfg_for(mp, 7, 5, 40), B, expect_kernel="k_traj_stream", seed=B)
+    if mp != "dmp":
+        cfg = cfg_for(mp, 7, 5, 40)
+        pc, bc, tc, dt, dur = cfg
+        params, ip, iv = inputs(pc, bc, tc, B, seed=B)
+        pg, dg = np.linspace(0.5, 1.5, 7), np.linspace(0.05, 0.2, 7)
+        spec = RolloutSpec("motor", 7, pg, dg, -0.7, 0.7, plant="static")
+        cp = np.random.default_rng(B).uniform(-1, 1, (B, 7)); cv = np.random.default_rng(B + 1).uniform(-1, 1, (B, 7))
+        pos, vel, act = eng.trajectory_actions(params, ip, iv, spec, cp, cv)
+        ra, _, _ = O.rollout(pos.cpu().numpy(), vel.cpu().numpy(), "motor", pg, dg, -0.7, 0.7, "static", dt, cp, cv)
+        assert np.array_equal(act.cpu().numpy(), ra.astype(np.float32))
+        monkeypatch.setenv("MPK_BULK", "0")
+        p2, v2, a2 = eng.trajectory_actions(params, ip, iv, spec, cp, cv)
+        assert torch.equal(pos, p2) and torch.equal(vel, v2) and torch.equal(act, a2)

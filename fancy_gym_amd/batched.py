@@ -129,7 +129,51 @@ class BatchedBlackBox:
         return {"params": params, "des_pos": pos, "des_vel": vel}
 
     # ---- plan + execute ----------------------------------------------------------------------------------------------
-    def step(self, params) -> Dict[str, torch.Tensor]:
+    def _can_fuse(self) -> bool:
+        """one launch for plan + execute: shared phase, double-integrator plant, no validity gate, MFMA-capable shape"""
+        cfg = self.engine.config
+        return (self.spec is not None and self.plant == "double_integrator" and self.pos_limits is None
+                and self._n_phase == 0 and self.engine.mp_type != "dmp" and self.D <= 16
+                and (not self.do_replanning or self._lockstep is not None)
+                and (cfg.num_basis + 3 if self.engine.mp_type == "prodmp" else cfg.num_basis + 1) <= 16)
+
+    def _step_fused(self, params) -> Dict[str, torch.Tensor]:
+        params = torch.as_tensor(params, dtype=torch.float32, device=self.device)
+        if params.shape != (self.B, self.engine.num_params):
+            raise ValueError(f"params must be [{self.B}, {self.engine.num_params}], got {tuple(params.shape)}")
+        was_done = self.done.bool()
+        cond_pos = self.condition_pos if self.condition_pos is not None else self.q.float()
+        cond_vel = self.condition_vel if self.condition_vel is not None else self.qd.float()
+        init_time = float(self._lockstep * self.dt) if self.do_replanning else 0.0
+        mpt = self.max_planning_times if math.isfinite(self.max_planning_times) else 2 ** 31 - 1
+        seg = self.engine.replan_advance(self.traj_steps, self.plan_steps, self.done, self.every, int(mpt),
+                                         self.horizon)
+        pos, vel, act = self.engine.trajectory_rollout(params, cond_pos, cond_vel, self.spec, self.q, self.qd,
+                                                       n_steps=seg, init_time=init_time)
+        valid = torch.ones(self.B, dtype=torch.bool, device=self.device)
+        return self._finish(dict(params=params, des_pos=pos, des_vel=vel, step_actions=act), seg, valid, was_done)
+
+    def _finish(self, out, seg, valid, was_done) -> Dict[str, torch.Tensor]:
+        pos, vel = out["des_pos"], out["des_vel"]
+        out.update(valid=valid, trajectory_length=seg, done=self.done.bool(), terminated=~valid & ~was_done,
+                   truncated=self.done.bool() & valid)
+        if self.condition_on_desired:
+            last = (seg.long() - 1).clamp_(min=0)[:, None, None].expand(-1, 1, self.D)
+            self.condition_pos = pos.gather(1, last)[:, 0].contiguous()
+            self.condition_vel = vel.gather(1, last)[:, 0].contiguous()
+        if self.do_replanning and self._lockstep is not None:
+            live = ~self.done.bool() | ~was_done
+            s = seg[live]
+            if s.numel() and bool((s == s[0]).all()) and bool(valid.all()):
+                self._lockstep += int(s[0])
+            else:
+                self._lockstep = None      # episodes drifted apart: per-episode init_time from now on
+        out.update(current_pos=self.q, current_vel=self.qd)
+        return out
+
+    def step(self, params, fuse: bool = True) -> Dict[str, torch.Tensor]:
+        if fuse and self._can_fuse():
+            return self._step_fused(params)
         out = self.get_trajectory(params)
         pos, vel = out["des_pos"], out["des_vel"]
         was_done = self.done.bool()
@@ -145,20 +189,6 @@ class BatchedBlackBox:
         mpt = self.max_planning_times if math.isfinite(self.max_planning_times) else 2 ** 31 - 1
         seg = self.engine.replan_advance(self.traj_steps, self.plan_steps, self.done, self.every, int(mpt),
                                          self.horizon)
-        out.update(valid=valid, trajectory_length=seg, done=self.done.bool(), terminated=~valid & ~was_done,
-                   truncated=self.done.bool() & valid)
         if self.spec is not None:
             out["step_actions"] = self.engine.pd_rollout(self.spec, pos, vel, self.q, self.qd, n_steps=seg)
-        if self.condition_on_desired:
-            last = (seg.long() - 1).clamp_(min=0)[:, None, None].expand(-1, 1, self.D)
-            self.condition_pos = pos.gather(1, last)[:, 0].contiguous()
-            self.condition_vel = vel.gather(1, last)[:, 0].contiguous()
-        if self.do_replanning and self._lockstep is not None:
-            live = ~self.done.bool() | ~was_done
-            s = seg[live]
-            if s.numel() and bool((s == s[0]).all()) and bool(valid.all()):
-                self._lockstep += int(s[0])
-            else:
-                self._lockstep = None      # episodes drifted apart: per-episode init_time from now on
-        out.update(current_pos=self.q, current_vel=self.qd)
-        return out
+        return self._finish(out, seg, valid, was_done)

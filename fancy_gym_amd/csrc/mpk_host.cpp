@@ -489,7 +489,8 @@ int mpk_times(mpk_handle hh, float* times) {
 
 static int traj_common(Handle* h, const float* params, const float* init_pos, const float* init_vel,
                        const float* init_time, double init_time_shared, float* pos, float* vel, float* actions,
-                       const RolloutDev* rd, const double* c_pos, const double* c_vel, int32_t B, void* stream) {
+                       const RolloutDev* rd, const double* c_pos, const double* c_vel, int32_t B, void* stream,
+                       double* q_state = nullptr, double* qd_state = nullptr, const int32_t* n_steps = nullptr) {
     if (B < 0) { set_error("B must be >= 0"); return MPK_EINVAL; }
     if (B == 0 || h->dev.D == 0) return MPK_OK;     // empty batch: nothing to do (buffers may be NULL)
     if (!params || !init_pos || !init_vel || !pos || !vel) { set_error("NULL buffer"); return MPK_EINVAL; }
@@ -498,8 +499,8 @@ static int traj_common(Handle* h, const float* params, const float* init_pos, co
         SharedTables st;
         int rc = get_shared(h, (float)init_time_shared, stream, &st);
         if (rc != MPK_OK) return rc;
-        return launch_traj_shared(h->dev, st, params, init_pos, init_vel, pos, vel, actions, rd, c_pos, c_vel, B,
-                                  h->num_cu, stream, &h->last_kernel);
+        return launch_traj_shared(h->dev, st, params, init_pos, init_vel, pos, vel, actions, rd, c_pos, c_vel,
+                                  q_state, qd_state, n_steps, B, h->num_cu, stream, &h->last_kernel);
     }
     if (actions) { set_error("fused actions need a shared-phase configuration with D <= 16 and <= 16 basis columns"); return MPK_EINVAL; }
     return launch_traj_rows(h->dev, params, init_pos, init_vel, init_time, (float)init_time_shared, pos, vel,
@@ -527,6 +528,23 @@ int mpk_trajectory_actions(mpk_handle hh, const float* params, const float* init
     if (rd.plant_type != MPK_PLANT_STATIC) { set_error("fused actions need MPK_PLANT_STATIC; use mpk_pd_rollout"); return MPK_EINVAL; }
     return traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, actions, &rd, c_pos,
                        c_vel, B, stream);
+}
+
+int mpk_trajectory_rollout(mpk_handle hh, const float* params, const float* init_pos, const float* init_vel,
+                           double init_time_shared, const mpk_rollout_cfg* rc, double* q, double* qd,
+                           const int32_t* n_steps, float* pos, float* vel, float* actions, int32_t B, void* stream) {
+    if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (B == 0) return MPK_OK;
+    if (!actions || !q || !qd) { set_error("NULL buffer"); return MPK_EINVAL; }
+    if (h->cfg.mp_type == MPK_MP_DMP) { set_error("the fused rollout is not available for dmp; use mpk_trajectory + mpk_pd_rollout"); return MPK_EINVAL; }
+    RolloutDev rd;
+    int r = fill_rollout(h, rc, &rd);
+    if (r != MPK_OK) return r;
+    if (rd.plant_type != MPK_PLANT_DOUBLE_INTEGRATOR) { set_error("the fused rollout integrates MPK_PLANT_DOUBLE_INTEGRATOR; for a frozen state use mpk_trajectory_actions"); return MPK_EINVAL; }
+    if (!shared_phase(h, nullptr) || !mfma_capable(h)) { set_error("the fused rollout needs a shared-phase configuration with D <= 16 and <= 16 basis columns"); return MPK_EINVAL; }
+    return traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, actions, &rd, nullptr,
+                       nullptr, B, stream, q, qd, n_steps);
 }
 
 int mpk_pd_rollout(mpk_handle hh, const mpk_rollout_cfg* rc, const float* des_pos, const float* des_vel, double* q,

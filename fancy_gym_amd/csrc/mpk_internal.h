@@ -67,8 +67,8 @@ int launch_build_shared(const DevCfg& c, float init_time, const SharedTables& st
                         int32_t* range_flag, void* stream);
 int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* params, const float* init_pos,
                        const float* init_vel, float* pos, float* vel, float* actions, const RolloutDev* rc,
-                       const double* c_pos, const double* c_vel, int B, int num_cu, void* stream,
-                       const char** kernel_name);
+                       const double* c_pos, const double* c_vel, double* q_state, double* qd_state,
+                       const int32_t* n_steps, int B, int num_cu, void* stream, const char** kernel_name);
 int launch_traj_rows(const DevCfg& c, const float* params, const float* init_pos, const float* init_vel,
                      const float* init_time, float init_time_shared, float* pos, float* vel, int32_t* range_flag,
                      int B, int num_cu, void* stream, const char** kernel_name);

@@ -231,7 +231,8 @@ int launch_build_shared(const DevCfg& c, float init_time, const SharedTables& st
 //                  from a per-workgroup LDS copy of the basis tables.  Every wave writes long contiguous runs,
 //                  which is what the HBM write path needs at large batch (4.9 vs 3.0 TB/s for the same bytes).
 //                  DMP always runs here (the Euler recurrence is serial in t).
-// CT: fused controller (-1 none, MPK_CTRL_* otherwise).
+// CT: fused controller: -1 none; MPK_CTRL_* (0..2) = open loop against a frozen state (c_pos, c_vel);
+//     3 + MPK_CTRL_* = CLOSED loop with the double-integrator plant integrated in the kernel (episode-major only).
 // ------------------------------------------------------------------------------------------------------------
 struct TrajArgs {
     DevCfg c;
@@ -248,6 +249,11 @@ struct TrajArgs {
     const double* c_vel;
     int B, sh, G, vec_ok;
     unsigned inv_seg4;     // 65536 / (4*D) + 1
+    // closed-loop rollout fused into the episode-major kernel (CT >= 3)
+    double* q_state;       // [B, D] plant position, in/out
+    double* qd_state;      // [B, D] plant velocity, in/out
+    const int32_t* n_steps;  // [B] executed steps of this plan (NULL = T)
+    double plant_dt;
 };
 
 struct ActArgs {
@@ -373,7 +379,7 @@ __device__ __forceinline__ void tile_epilogue(const f32x4& acc0, const f32x4& ac
                                               const float (&dtd)[4], double cp, double cv, const double* sg,
                                               float* sSt, unsigned wofs, int D) {
     double pgd = 0.0, dgd = 0.0, lod = 0.0, hid = 0.0;
-    if (CT >= 0) { pgd = sg[0]; dgd = sg[16]; lod = sg[32]; hid = sg[48]; }
+    if (CT >= 0 && CT < 3) { pgd = sg[0]; dgd = sg[16]; lod = sg[32]; hid = sg[48]; }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const float p = acc0[r];
@@ -383,7 +389,7 @@ __device__ __forceinline__ void tile_epilogue(const f32x4& acc0, const f32x4& ac
         float* w = sSt + wofs + r * D;
         w[0] = p;
         w[kStageStride] = v;
-        if (CT >= 0) {
+        if (CT >= 0 && CT < 3) {
             // float64 without FMA: numpy's promotion in pd_controller.py:21-29 (fp32 desired (+) fp64 state)
             double u;
             if (CT == MPK_CTRL_MOTOR) u = pgd * ((double)p - cp) + dgd * ((double)v - cv);
@@ -450,6 +456,7 @@ template <int MP, int CT, int KM, bool WT>
 __global__ void __launch_bounds__(256) k_traj_tiles(const TrajArgs a, const ActArgs act) {
     __shared__ __attribute__((aligned(16))) float smem[4 * kStageFloats];
     static_assert(MP != MPK_MP_DMP, "dmp runs in k_traj_stream");
+    static_assert(CT < 3, "closed-loop rollouts run in k_traj_stream");
     constexpr bool ACT = CT >= 0;
     constexpr int NOUT = MP == MPK_MP_PRODMP ? 2 : 3;
     constexpr int NST = 2 + (ACT ? 1 : 0);
@@ -514,8 +521,9 @@ template <int MP, int CT, int KM>
 __device__ __forceinline__ void stream_group(const TrajArgs& a, const LaneMap<KM>& L, const float* ap,
                                              const float* sAux, const double* sg, float* sSt, int lane, int b0,
                                              const float (&xb)[KM], double cp, double cv, float ey, float ez,
-                                             float eg, bool eul) {
+                                             float eg, bool eul, double& qs, double& qds, int nst, bool serial) {
     constexpr bool ACT = CT >= 0;
+    constexpr bool CLOSED = CT >= 3;
     constexpr int NOUT = MP == MPK_MP_PRODMP ? 2 : (MP == MPK_MP_PROMP ? 3 : 1);
     constexpr int NST = 2 + (ACT ? 1 : 0);
     const DevCfg& c = a.c;
@@ -538,6 +546,29 @@ __device__ __forceinline__ void stream_group(const TrajArgs& a, const LaneMap<KM
                 for (int r = 0; r < 4; ++r) dtd[r] = sAux[rt * 16 + 4 * L.q + r];
             }
             if (L.dvalid) tile_epilogue<MP, CT>(acc0, acc1, acc2, dtd, cp, cv, sg, sSt, L.wofs, D);
+            if (CLOSED) {
+                // the step loop of black_box_wrapper.py:175-203 on the reference's torque double integrator
+                // (base_reacher_torque.py:25-26), serial in t on the lanes (q == 0); float64, no FMA
+                __builtin_amdgcn_wave_barrier();
+                if (serial) {
+                    const double pgd = sg[0], dgd = sg[16], lod = sg[32], hid = sg[48], dtp = a.plant_dt;
+                    for (int tl = 0; tl < rows; ++tl) {
+                        const int t = rt * 16 + tl;
+                        const int o = L.bl * SEG + tl * D + L.d;
+                        double u = 0.0;
+                        if (t < nst) {
+                            const double dp = (double)sSt[o], dv = (double)sSt[kStageStride + o];
+                            if (CT - 3 == MPK_CTRL_MOTOR) u = pgd * (dp - qs) + dgd * (dv - qds);
+                            else if (CT - 3 == MPK_CTRL_POSITION) u = dp;
+                            else u = dv;
+                            u = fmin(fmax(u, lod), hid);
+                            qds = qds + dtp * u;
+                            qs = qs + dtp * qds;
+                        }
+                        sSt[2 * kStageStride + o] = (float)u;
+                    }
+                }
+            }
         } else {
             // DMP: forcing tile -> LDS, then explicit Euler in scaled time on lanes (q == 0), serial in t;
             // one rounding per op (no FMA), first sample = initial condition
@@ -584,7 +615,8 @@ template <int MP, int CT, int KM, bool BULK>
 __global__ void __launch_bounds__(256) k_traj_stream(const TrajArgs a, const ActArgs act) {
     __shared__ __attribute__((aligned(16))) float smem[4 * kStageFloats];
     extern __shared__ __attribute__((aligned(16))) float sTab[];   // [NOUT][KP][TS] rows + [TS] aux (+ chunk images)
-    constexpr bool ACT = CT >= 0;
+    constexpr bool ACT = CT >= 0 && CT < 3;   // open loop: frozen state (c_pos, c_vel) is an input
+    constexpr bool CLOSED = CT >= 3;          // closed loop: plant state (q, qd) is read, integrated and written back
     constexpr int NOUT = MP == MPK_MP_PRODMP ? 2 : (MP == MPK_MP_PROMP ? 3 : 1);
     const DevCfg& c = a.c;
     const int lane = threadIdx.x & 63;
@@ -615,7 +647,7 @@ __global__ void __launch_bounds__(256) k_traj_stream(const TrajArgs a, const Act
     if (!BULK) {
         int g = w0;
         if (g >= a.G) return;
-        if (ACT) park_gains(act, lane, L.d, sSt);
+        if (CT >= 0) park_gains(act, lane, L.d, sSt);
         float xb[KM];
         GroupIn<KM> cur = load_group<MP, ACT, KM>(a, L, g);
         finish_group<KM>(L, cur, xb);
@@ -634,7 +666,23 @@ __global__ void __launch_bounds__(256) k_traj_stream(const TrajArgs a, const Act
                     eg = a.params[(size_t)b * P + c.off + L.d * c.Kloc + c.nb] * c.gs;
                 }
             }
-            stream_group<MP, CT, KM>(a, L, ap, sAux, sg, sSt, lane, b0, xb, cp, cv, ey, ez, eg, eul);
+            const bool serial = CLOSED && L.dvalid && L.q == 0 && b0 + L.bl < B;
+            double qs = 0.0, qds = 0.0;
+            int nst = c.T;
+            if (CLOSED) {
+                if (serial) {
+                    const size_t si = (size_t)(b0 + L.bl) * D + L.d;
+                    qs = a.q_state[si]; qds = a.qd_state[si];
+                    if (a.n_steps) nst = a.n_steps[b0 + L.bl];
+                }
+            }
+            stream_group<MP, CT, KM>(a, L, ap, sAux, sg, sSt, lane, b0, xb, cp, cv, ey, ez, eg, eul, qs, qds, nst, serial);
+            if (CLOSED) {
+                if (serial) {
+                    const size_t si = (size_t)(b0 + L.bl) * D + L.d;
+                    a.q_state[si] = qs; a.qd_state[si] = qds;
+                }
+            }
             finish_group<KM>(L, nxt, xb);
             cp = nxt.cp; cv = nxt.cv;
             g = gn;
@@ -645,7 +693,7 @@ __global__ void __launch_bounds__(256) k_traj_stream(const TrajArgs a, const Act
         const int NCH = (B + EPC - 1) / EPC;
         int ch = w0;
         if (ch >= NCH) return;
-        if (ACT) park_gains(act, lane, L.d, sSt);
+        if (CT >= 0) park_gains(act, lane, L.d, sSt);
         // chunk image (floats): [params EPC*P | init_pos EPC*D | init_vel EPC*D | c_pos 2*EPC*D | c_vel 2*EPC*D]
         const int offIP = EPC * P, offIV = offIP + EPC * D, offCP = offIV + EPC * D, offCV = offCP + 2 * EPC * D;
         const int img = offCV + 2 * EPC * D;
@@ -725,7 +773,24 @@ __global__ void __launch_bounds__(256) k_traj_stream(const TrajArgs a, const Act
                         eg = pj[L.bl * P + c.off + L.d * c.Kloc + c.nb] * c.gs;
                     }
                 }
-                stream_group<MP, CT, KM>(a, L, ap, sAux, sg, sSt, lane, b0, xb, cp, cv, ey, ez, eg, eul);
+                const bool serial = CLOSED && L.dvalid && L.q == 0 && b0 + L.bl < B;
+                double qs = 0.0, qds = 0.0;
+                int nst = c.T;
+                if (CLOSED) {
+                    if (serial) {
+                        const size_t si = (size_t)(b0 + L.bl) * D + L.d;
+                        qs = a.q_state[si]; qds = a.qd_state[si];
+                        if (a.n_steps) nst = a.n_steps[b0 + L.bl];
+                    }
+                }
+                stream_group<MP, CT, KM>(a, L, ap, sAux, sg, sSt, lane, b0, xb, cp, cv, ey, ez, eg, eul, qs, qds, nst,
+                                         serial);
+                if (CLOSED) {
+                    if (serial) {
+                        const size_t si = (size_t)(b0 + L.bl) * D + L.d;
+                        a.q_state[si] = qs; a.qd_state[si] = qds;
+                    }
+                }
             }
             if (have_next) {
                 float* nb = sImg + (cur ^ 1) * img;
@@ -761,7 +826,7 @@ static int launch_traj_t(const TrajArgs& ta, const ActArgs& aa, bool stream_mode
             }
         }
     } else {
-        if constexpr (MP != MPK_MP_DMP) {
+        if constexpr (MP != MPK_MP_DMP && CT < 3) {
             if (write_through) {
                 switch (km) {
                     case 1: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 1, true>), g, b, 0, s, ta, aa); break;
@@ -791,6 +856,9 @@ static int launch_traj_ct(const TrajArgs& ta, const ActArgs& aa, int ct, bool st
             case MPK_CTRL_MOTOR: return launch_traj_t<MP, MPK_CTRL_MOTOR>(ta, aa, stream_mode, write_through, bulk, blocks, lds, stream);
             case MPK_CTRL_VELOCITY: return launch_traj_t<MP, MPK_CTRL_VELOCITY>(ta, aa, stream_mode, write_through, bulk, blocks, lds, stream);
             case MPK_CTRL_POSITION: return launch_traj_t<MP, MPK_CTRL_POSITION>(ta, aa, stream_mode, write_through, bulk, blocks, lds, stream);
+            case 3 + MPK_CTRL_MOTOR: return launch_traj_t<MP, 3 + MPK_CTRL_MOTOR>(ta, aa, true, false, bulk, blocks, lds, stream);
+            case 3 + MPK_CTRL_VELOCITY: return launch_traj_t<MP, 3 + MPK_CTRL_VELOCITY>(ta, aa, true, false, bulk, blocks, lds, stream);
+            case 3 + MPK_CTRL_POSITION: return launch_traj_t<MP, 3 + MPK_CTRL_POSITION>(ta, aa, true, false, bulk, blocks, lds, stream);
             default: break;
         }
     }
@@ -806,9 +874,11 @@ static int mapping_override() {
 
 int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* params, const float* init_pos,
                        const float* init_vel, float* pos, float* vel, float* actions, const RolloutDev* rc,
-                       const double* c_pos, const double* c_vel, int B, int num_cu, void* stream,
-                       const char** kernel_name) {
+                       const double* c_pos, const double* c_vel, double* q_state, double* qd_state,
+                       const int32_t* n_steps, int B, int num_cu, void* stream, const char** kernel_name) {
     TrajArgs ta;
+    const bool closed = q_state != nullptr;
+    ta.q_state = q_state; ta.qd_state = qd_state; ta.n_steps = n_steps; ta.plant_dt = rc ? rc->dt : 0.0;
     ta.c = c; ta.A = st.A; ta.aux = st.aux; ta.TS = st.TS;
     ta.params = params; ta.init_pos = init_pos; ta.init_vel = init_vel;
     ta.pos = pos; ta.vel = vel; ta.actions = actions; ta.c_pos = c_pos; ta.c_vel = c_vel;
@@ -827,7 +897,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     ActArgs aa{};
     int ct = -1;
     if (act) {
-        ct = rc->controller_type;
+        ct = rc->controller_type + (closed ? 3 : 0);
         for (int d = 0; d < c.D; ++d) { aa.pg[d] = rc->pg[d]; aa.dg[d] = rc->dg[d]; aa.lo[d] = rc->lo[d]; aa.hi[d] = rc->hi[d]; }
     }
     const int NRT = (c.T + 15) / 16;
@@ -835,12 +905,12 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     // work decomposition: episode-major once the outputs stop being cache resident (or when it is the only option)
     const size_t table_bytes = ((size_t)st.n_out * c.KP * st.TS + st.TS) * sizeof(float);
     const double out_bytes = (double)B * c.T * c.D * 4.0 * nst;
-    bool stream_mode = c.mp_type == MPK_MP_DMP || out_bytes > 96.0 * 1024 * 1024;
+    bool stream_mode = c.mp_type == MPK_MP_DMP || closed || out_bytes > 96.0 * 1024 * 1024;
     const int ov = mapping_override();
-    if (c.mp_type != MPK_MP_DMP && ov == 1) stream_mode = false;
+    if (c.mp_type != MPK_MP_DMP && !closed && ov == 1) stream_mode = false;
     if (ov == 2) stream_mode = true;
     if (stream_mode && table_bytes + 4 * kStageFloats * sizeof(float) > 64 * 1024) {
-        if (c.mp_type == MPK_MP_DMP) { set_error("trajectory too long for the episode-major kernel's LDS budget"); return MPK_EINVAL; }
+        if (c.mp_type == MPK_MP_DMP || closed) { set_error("trajectory too long for the episode-major kernel's LDS budget"); return MPK_EINVAL; }
         stream_mode = false;
     }
     // write-through stores for the cache-resident tile-major case (MPK_WRITE_THROUGH=0/1 overrides, for A/B runs)
@@ -857,7 +927,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         const size_t lds_bulk = table_bytes + 4 * 2 * img_floats * sizeof(float);
         bulk = (EPC * c.P) % 4 == 0 && (EPC * c.D) % 4 == 0 && (EPC * c.P) / 4 <= 128 && (EPC * c.D) / 2 <= 64 &&
                aligned16(params) && aligned16(init_pos) && aligned16(init_vel) &&
-               (!act || (aligned16(c_pos) && aligned16(c_vel))) &&
+               (!act || closed || (aligned16(c_pos) && aligned16(c_vel))) &&
                lds_bulk + 4 * kStageFloats * sizeof(float) <= 64 * 1024;
         // MPK_BULK=0 disables, =2 forces it below the size threshold too (tests); default: HBM-streaming sizes only
         int bulk_mode = 1;
@@ -878,11 +948,11 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     if (blocks < 1) blocks = 1;
     switch (c.mp_type) {
         case MPK_MP_PRODMP:
-            *kernel_name = stream_mode ? (act ? "k_traj_stream<prodmp,act>" : "k_traj_stream<prodmp>")
+            *kernel_name = closed ? "k_traj_stream<prodmp,closed>" : stream_mode ? (act ? "k_traj_stream<prodmp,act>" : "k_traj_stream<prodmp>")
                                        : (act ? "k_traj_tiles<prodmp,act>" : "k_traj_tiles<prodmp>");
             return launch_traj_ct<MPK_MP_PRODMP>(ta, aa, ct, stream_mode, write_through, bulk, blocks, lds, stream);
         case MPK_MP_PROMP:
-            *kernel_name = stream_mode ? (act ? "k_traj_stream<promp,act>" : "k_traj_stream<promp>")
+            *kernel_name = closed ? "k_traj_stream<promp,closed>" : stream_mode ? (act ? "k_traj_stream<promp,act>" : "k_traj_stream<promp>")
                                        : (act ? "k_traj_tiles<promp,act>" : "k_traj_tiles<promp>");
             return launch_traj_ct<MPK_MP_PROMP>(ta, aa, ct, stream_mode, write_through, bulk, blocks, lds, stream);
         default:

@@ -202,6 +202,31 @@ class TrajectoryEngine:
             c_pos.data_ptr(), c_vel.data_ptr(), pos.data_ptr(), vel.data_ptr(), act.data_ptr(), B, self._stream()))
         return pos, vel, act
 
+    def trajectory_rollout(self, params, init_pos, init_vel, spec: RolloutSpec, q: torch.Tensor, qd: torch.Tensor,
+                           n_steps: Optional[torch.Tensor] = None, init_time: float = 0.0, out=None):
+        """
+        One fused launch: trajectory + closed-loop controller / double-integrator rollout (BlackBoxWrapper.step for a
+        GPU-resident plant).  q, qd float64 [B, D] are updated in place.  Returns (pos, vel, actions).
+        """
+        params = torch.as_tensor(params, dtype=torch.float32, device=self.device)
+        if params.dim() == 1:
+            params = params[None]
+        params = params.contiguous()
+        B, D, T = params.shape[0], self.num_dof, self.num_steps
+        init_pos, init_vel = self._f32(init_pos, (B, D)), self._f32(init_vel, (B, D))
+        assert q.dtype == torch.float64 and qd.dtype == torch.float64 and q.is_contiguous() and qd.is_contiguous()
+        if out is None:
+            pos, vel, act = (torch.empty((B, T, D), dtype=torch.float32, device=self.device) for _ in range(3))
+        else:
+            pos, vel, act = out
+        if n_steps is not None:
+            n_steps = n_steps.to(device=self.device, dtype=torch.int32).contiguous()
+        _lib.check(self._lib.mpk_trajectory_rollout(
+            self._h, params.data_ptr(), init_pos.data_ptr(), init_vel.data_ptr(), float(init_time), C.byref(spec.c),
+            q.data_ptr(), qd.data_ptr(), _dptr(n_steps), pos.data_ptr(), vel.data_ptr(), act.data_ptr(), B,
+            self._stream()))
+        return pos, vel, act
+
     def pd_rollout(self, spec: RolloutSpec, des_pos: torch.Tensor, des_vel: torch.Tensor, q: torch.Tensor,
                    qd: torch.Tensor, n_steps: Optional[torch.Tensor] = None, want_actions: bool = True):
         """In-place closed-loop rollout; q, qd float64 [B, D] are updated to the state after the executed steps."""

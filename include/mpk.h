@@ -166,6 +166,19 @@ int mpk_trajectory_actions(mpk_handle h, const float* params, const float* init_
                            float* pos, float* vel, float* actions, int32_t B, void* stream);
 
 /*
+ * One fused launch for BlackBoxWrapper.step (black_box_wrapper.py:150-217) on a GPU-resident plant:
+ * get_trajectory (:96-120) + the controller / clip / plant loop (:175-203) for the reference's torque double integrator
+ * (envs/classic_control/base_reacher/base_reacher_torque.py:25-26), without re-reading the trajectory:
+ *   q, qd     dev double [B, D]  in: plant state at plan start, out: state after the executed steps
+ *   n_steps   dev int32 [B] or NULL (= T): the break index of :197 (see mpk_replan_advance)
+ *   pos, vel, actions dev float [B, T, D] outputs (actions beyond n_steps[b] are 0)
+ * Shared-phase, non-dmp configurations only; numerically identical to mpk_trajectory followed by mpk_pd_rollout.
+ */
+int mpk_trajectory_rollout(mpk_handle h, const float* params, const float* init_pos, const float* init_vel,
+                           double init_time_shared, const mpk_rollout_cfg* rc, double* q, double* qd,
+                           const int32_t* n_steps, float* pos, float* vel, float* actions, int32_t B, void* stream);
+
+/*
  * Replaces the per-step loop of BlackBoxWrapper.step (black_box_wrapper.py:175-203) for plants that live on the GPU:
  *   for t < n_steps[b]: a = clip(controller(des_pos[b,t], des_vel[b,t], q[b], qd[b]), low, high); plant step
  *   des_pos, des_vel dev float  [B, T, D]

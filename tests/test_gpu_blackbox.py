@@ -272,6 +272,41 @@ def test_fused_actions_are_bit_exact(cfg, controller, mapping, monkeypatch):
     assert np.array_equal(act.cpu().numpy(), ra.astype(np.float32))
 
 
+@pytest.mark.parametrize("cfg", [CFG2, CFG5, CFG4], ids=["prodmp", "promp", "prodmp_replan"])
+@pytest.mark.parametrize("controller", ["motor", "position", "velocity"])
+@pytest.mark.parametrize("B", [1, 9, 200])
+@pytest.mark.parametrize("bulk", ["0", "2"])
+def test_fused_closed_loop_rollout_is_bit_exact(cfg, controller, B, bulk, monkeypatch):
+    """one launch (trajectory + controller + double-integrator plant) == mpk_trajectory + mpk_pd_rollout == oracle"""
+    monkeypatch.setenv("MPK_BULK", bulk)
+    pc, bc, tc, dt, dur = cfg
+    eng = make_engine(pc, bc, tc, dt, dur)
+    params, ip, iv = inputs(pc, bc, tc, B, seed=B)
+    rng = np.random.default_rng(B)
+    q0, qd0 = rng.uniform(-1, 1, (B, 7)), rng.uniform(-0.2, 0.2, (B, 7))
+    T = eng.num_steps
+    n_steps = rng.integers(0, T + 1, B).astype(np.int32)
+    spec = RolloutSpec(controller, 7, PG, DG, -0.9, 0.9, plant="double_integrator", dt=dt)
+    q, qd = torch.tensor(q0, device="cuda"), torch.tensor(qd0, device="cuda")
+    pos, vel, act = eng.trajectory_rollout(params, ip, iv, spec, q, qd, n_steps=torch.tensor(n_steps), init_time=0.5)
+    assert eng.last_kernel().endswith("closed>")
+    p2, v2 = eng.trajectory(params, ip, iv, 0.5)
+    q2, qd2 = torch.tensor(q0, device="cuda"), torch.tensor(qd0, device="cuda")
+    a2 = eng.pd_rollout(spec, p2, v2, q2, qd2, n_steps=torch.tensor(n_steps))
+    assert torch.equal(pos, p2) and torch.equal(vel, v2) and torch.equal(act, a2)
+    assert torch.equal(q, q2) and torch.equal(qd, qd2)
+    ra, rq, rqd = O.rollout(pos.cpu().numpy(), vel.cpu().numpy(), controller, PG, DG, -0.9, 0.9, "double_integrator",
+                            dt, q0, qd0, n_steps=n_steps)
+    assert np.array_equal(act.cpu().numpy(), ra.astype(np.float32))
+    assert np.array_equal(q.cpu().numpy(), rq) and np.array_equal(qd.cpu().numpy(), rqd)
+    # n_steps = NULL executes the whole plan
+    q3, qd3 = torch.tensor(q0, device="cuda"), torch.tensor(qd0, device="cuda")
+    _, _, a3 = eng.trajectory_rollout(params, ip, iv, spec, q3, qd3, init_time=0.5)
+    ra, rq, _ = O.rollout(pos.cpu().numpy(), vel.cpu().numpy(), controller, PG, DG, -0.9, 0.9, "double_integrator", dt,
+                          q0, qd0)
+    assert np.array_equal(a3.cpu().numpy(), ra.astype(np.float32)) and np.array_equal(q3.cpu().numpy(), rq)
+
+
 def test_fused_actions_rejects_what_it_cannot_fuse():
     pc, bc, tc, dt, dur = CFG3
     eng = make_engine(pc, bc, tc, dt, dur)
@@ -388,6 +423,27 @@ def test_batched_replanning_follows_the_single_episode_sequence():
         assert np.array_equal(out["step_actions"].cpu().numpy(), ra.astype(np.float32))
         assert np.array_equal(out["current_pos"].cpu().numpy(), q)
         cond_p, cond_v = dp[:, n - 1], dv[:, n - 1]           # condition on the desired state where the plan broke
+
+
+def test_batched_fused_and_unfused_steps_agree_bitwise():
+    rng = np.random.default_rng(5)
+    B = 40
+    q0 = rng.uniform(-1, 1, (B, 7))
+    outs = []
+    for fuse in (True, False):
+        bb = _batched(CFG4, B, plant="double_integrator", replanning_every=25, max_planning_times=4,
+                      condition_on_desired=True)
+        bb.reset(q0)
+        r = np.random.default_rng(6)
+        seq = []
+        for _ in range(4):
+            o = bb.step(r.standard_normal((B, 35)).astype(np.float32), fuse=fuse)
+            seq.append({k: o[k].clone() for k in ("des_pos", "des_vel", "step_actions", "current_pos", "trajectory_length")})
+        outs.append(seq)
+        assert bb.engine.last_kernel().endswith("closed>") == fuse or not fuse
+    for a, b in zip(*outs):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
 
 
 def test_batched_learned_tau_delay_freeze_after_first_plan():

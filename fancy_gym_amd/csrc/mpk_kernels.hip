@@ -932,7 +932,11 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         // MPK_BULK=0 disables, =2 forces it below the size threshold too (tests); default: HBM-streaming sizes only
         int bulk_mode = 1;
         if (const char* e = getenv("MPK_BULK")) bulk_mode = atoi(e);
-        bulk = bulk && bulk_mode != 0 && (bulk_mode == 2 || out_bytes > 96.0 * 1024 * 1024);
+        // automatic: only when the outputs stream to HBM AND the 4x coarser work units still fill the chip; the
+        // latency-bound DMP recurrence prefers occupancy over input staging
+        const long chunks = (ta.G + kChunkGroups - 1) / kChunkGroups;
+        const bool auto_ok = out_bytes > 96.0 * 1024 * 1024 && chunks >= max_waves / 2 && c.mp_type != MPK_MP_DMP;
+        bulk = bulk && bulk_mode != 0 && (bulk_mode == 2 || auto_ok);
         long units = ta.G;
         if (bulk) { lds = lds_bulk; units = (ta.G + kChunkGroups - 1) / kChunkGroups; }
         const long waves = units < max_waves ? units : max_waves;

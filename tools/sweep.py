@@ -92,6 +92,18 @@ def main():
         q, qd = ip.double().contiguous(), iv.double().contiguous()
         t = ev_time(lambda: eng.pd_rollout(spec, pos, vel, q, qd))
         row("k_pd_rollout (double integrator, T=100)", B, 100, 7, 42, t, 3 * 100 * 7 * 4 + 4 * 7 * 8, "k_pd_rollout")
+    # fused closed-loop step: trajectory + PD + double-integrator plant in one launch
+    for B in (4096, 65536, 1048576):
+        params = torch.randn((B, 42), generator=g).to(dev)
+        ip = (torch.rand((B, 7), generator=g) * 2 - 1).to(dev)
+        iv = torch.zeros((B, 7), device=dev)
+        spec = RolloutSpec("motor", 7, PG, DG, -1.0, 1.0, plant="double_integrator", dt=0.02)
+        q, qd = ip.double().contiguous(), iv.double().contiguous()
+        out = tuple(torch.empty((B, 100, 7), device=dev) for _ in range(3))
+        t = ev_time(lambda: eng.trajectory_rollout(params, ip, iv, spec, q, qd, out=out), n=20 if B > 100000 else 50)
+        row("cfg2 fused CLOSED-loop step (traj + PD + plant)", B, 100, 7, 42, t, 224 + 3 * 2800 + 4 * 7 * 8,
+            eng.last_kernel())
+        del out, params
     # PCIe-inclusive: host numpy params -> device -> kernel -> host numpy pos, vel
     B = 4096
     params = np.random.default_rng(0).standard_normal((B, 42)).astype(np.float32)

@@ -944,7 +944,8 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;                  // XCD-contiguous remap needs a multiple of 8
     } else {
         const long items = (long)ta.G * NRT;
-        const long ipw = (items + max_waves - 1) / max_waves;            // items per wave, balanced
+        long ipw = (items + max_waves - 1) / max_waves;                  // items per wave, balanced
+        if (const char* e = getenv("MPK_IPW")) { const long v = atol(e); if (v > 0) ipw = v; }   // A/B runs
         const long waves = (items + ipw - 1) / ipw;
         blocks = (int)((waves + 3) / 4);
         blocks = (blocks + NRT - 1) / NRT * NRT;                         // #waves % NRT == 0

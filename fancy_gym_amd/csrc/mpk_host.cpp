@@ -306,6 +306,27 @@ static bool mfma_capable(const Handle* h) {
     return h->dev.D >= 1 && h->dev.D <= kMaxD && h->dev.KP <= kMaxKP;
 }
 
+// Allocate every cache slot's table for the current (T, KP) up front: a cache miss later only launches the builder
+// kernel, never hipMalloc -- so trajectory calls stay legal inside a hipGraph stream capture.
+static int prealloc_cache(Handle* h) {
+    if (!mfma_capable(h)) return MPK_OK;
+    int TS = 0, n_out = 0;
+    const size_t nf = shared_tables_floats(h->dev, &TS, &n_out);
+    for (auto& e : h->cache) {
+        if (e.st.A && (e.st.TS != TS || e.st.n_out != n_out)) {
+            (void)hipFree(e.st.A); (void)hipFree(e.st.aux);
+            e.st = SharedTables{};
+        }
+        if (!e.st.A) {
+            MPK_HIP(hipMalloc((void**)&e.st.A, nf * sizeof(float)));
+            MPK_HIP(hipMalloc((void**)&e.st.aux, (size_t)TS * sizeof(float)));
+            e.st.TS = TS; e.st.n_out = n_out;
+        }
+        e.valid = false;
+    }
+    return MPK_OK;
+}
+
 // returns the cached (or freshly built, enqueued on `stream`) shared tables for init_time
 static int get_shared(Handle* h, float init_time, void* stream, SharedTables* out) {
     uint32_t key;
@@ -436,6 +457,8 @@ int mpk_create(const mpk_config* cfg, mpk_handle* out) {
     rc = upload_times(h);
     if (rc != MPK_OK) return fail(rc);
     fill_devcfg(h);
+    rc = prealloc_cache(h);
+    if (rc != MPK_OK) return fail(rc);
     *out = reinterpret_cast<mpk_handle>(h);
     return MPK_OK;
 }
@@ -477,7 +500,7 @@ int mpk_set_duration(mpk_handle hh, double duration, double dt) {
     int rc = upload_times(h);
     if (rc != MPK_OK) return rc;
     fill_devcfg(h);
-    return MPK_OK;
+    return prealloc_cache(h);
 }
 
 int mpk_times(mpk_handle hh, float* times) {

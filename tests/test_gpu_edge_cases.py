@@ -198,3 +198,30 @@ def test_bulk_input_staging_on_ragged_batches(mp, B, monkeypatch):
         monkeypatch.setenv("MPK_BULK", "0")
         p2, v2, a2 = eng.trajectory_actions(params, ip, iv, spec, cp, cv)
         assert torch.equal(pos, p2) and torch.equal(vel, v2) and torch.equal(act, a2)
+
+
+def test_calls_are_capturable_in_a_hip_graph_even_on_a_table_cache_miss():
+    """no hipMalloc / synchronisation on the hot path: a replanning sequence (new init_time every plan -> builder kernel
+    + trajectory kernel) captured once and replayed"""
+    pc, bc, tc, dt, dur = cfg_for("prodmp", 7, 5, 100)
+    eng = make_engine(pc, bc, tc, dt, dur)
+    B = 33
+    params, ip, iv = inputs(pc, bc, tc, B, seed=2)
+    P, IP, IV = (torch.tensor(x, device="cuda") for x in (params, ip, iv))
+    outs = [(torch.empty((B, 100, 7), device="cuda"), torch.empty((B, 100, 7), device="cuda")) for _ in range(4)]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for k in range(4):
+                eng.trajectory(P, IP, IV, 0.5 * k, out=outs[k])         # init_times never used before: cache misses
+    torch.cuda.current_stream().wait_stream(side)
+    for o in outs:
+        o[0].zero_(); o[1].zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    for k in range(4):
+        rp, rv = O.get_trajectory(pc, bc, tc, params, dur, dt, 0.5 * k, ip, iv, dtype=np.float64)
+        close(outs[k][0].cpu().numpy(), rp, f"plan {k} pos")
+        close(outs[k][1].cpu().numpy(), rv, f"plan {k} vel")

@@ -552,20 +552,26 @@ __device__ __forceinline__ void stream_group(const TrajArgs& a, const LaneMap<KM
                 __builtin_amdgcn_wave_barrier();
                 if (serial) {
                     const double pgd = sg[0], dgd = sg[16], lod = sg[32], hid = sg[48], dtp = a.plant_dt;
-                    for (int tl = 0; tl < rows; ++tl) {
-                        const int t = rt * 16 + tl;
-                        const int o = L.bl * SEG + tl * D + L.d;
-                        double u = 0.0;
-                        if (t < nst) {
-                            const double dp = (double)sSt[o], dv = (double)sSt[kStageStride + o];
-                            if (CT - 3 == MPK_CTRL_MOTOR) u = pgd * (dp - qs) + dgd * (dv - qds);
-                            else if (CT - 3 == MPK_CTRL_POSITION) u = dp;
-                            else u = dv;
-                            u = fmin(fmax(u, lod), hid);
-                            qds = qds + dtp * u;
-                            qs = qs + dtp * qds;
+                    const int o0 = L.bl * SEG + L.d;
+                    float pr[16], vr[16];
+#pragma unroll
+                    for (int tl = 0; tl < 16; ++tl) { pr[tl] = sSt[o0 + tl * D]; vr[tl] = sSt[kStageStride + o0 + tl * D]; }
+#pragma unroll
+                    for (int tl = 0; tl < 16; ++tl) {
+                        if (tl < rows) {
+                            const int t = rt * 16 + tl;
+                            double u = 0.0;
+                            if (t < nst) {
+                                const double dp = (double)pr[tl], dv = (double)vr[tl];
+                                if (CT - 3 == MPK_CTRL_MOTOR) u = pgd * (dp - qs) + dgd * (dv - qds);
+                                else if (CT - 3 == MPK_CTRL_POSITION) u = dp;
+                                else u = dv;
+                                u = fmin(fmax(u, lod), hid);
+                                qds = qds + dtp * u;
+                                qs = qs + dtp * qds;
+                            }
+                            sSt[2 * kStageStride + o0 + tl * D] = (float)u;
                         }
-                        sSt[2 * kStageStride + o] = (float)u;
                     }
                 }
             }
@@ -579,21 +585,37 @@ __device__ __forceinline__ void stream_group(const TrajArgs& a, const LaneMap<KM
             }
             __builtin_amdgcn_wave_barrier();
             if (eul) {
-                for (int tl = 0; tl < rows; ++tl) {
-                    const int t = rt * 16 + tl;
-                    const int o = L.bl * SEG + tl * D + L.d;
-                    sSt[o] = ey;
-                    sSt[kStageStride + o] = ez / c.tau;
-                    if (t < T - 1) {
-                        const float f = sF[o], ds = sAux[t];
-                        const float t1 = eg - ey;
-                        const float t2 = c.dmp_beta * t1;
-                        const float t3 = t2 - ez;
-                        const float t4 = c.dmp_alpha * t3;
-                        const float acc = t4 + f;
-                        ez = ez + ds * acc;
-                        ey = ey + ds * ez;
+                // the tile's 16 forcing values and scaled-time steps are fetched up front, so the recurrence itself is a
+                // pure register chain; the lanes only park z here -- vel = z / tau is applied by ALL lanes below
+                const int o0 = L.bl * SEG + L.d;
+                float fr[16], dsr[16];
+#pragma unroll
+                for (int tl = 0; tl < 16; ++tl) { fr[tl] = sF[o0 + tl * D]; dsr[tl] = sAux[rt * 16 + tl]; }
+#pragma unroll
+                for (int tl = 0; tl < 16; ++tl) {
+                    if (tl < rows) {
+                        const int t = rt * 16 + tl;
+                        sSt[o0 + tl * D] = ey;
+                        sSt[kStageStride + o0 + tl * D] = ez;
+                        if (t < T - 1) {
+                            const float t1 = eg - ey;
+                            const float t2 = c.dmp_beta * t1;
+                            const float t3 = t2 - ez;
+                            const float t4 = c.dmp_alpha * t3;
+                            const float acc = t4 + fr[tl];
+                            ez = ez + dsr[tl] * acc;
+                            ey = ey + dsr[tl] * ez;
+                        }
                     }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // vel = z / tau (IEEE divide, as the reference's tensor op) on every lane that holds staged data
+            if (L.dvalid) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float* w = sSt + kStageStride + L.wofs + r * D;
+                    *w = *w / c.tau;
                 }
             }
         }

@@ -33,10 +33,12 @@ def _toys():
 def toy_bb(mp_type, bb=None, phase=None, basis=None, traj=None, env_id="toy-v0", wrapper=ToyWrapper, **kw):
     basis_type = "prodmp" if mp_type == "prodmp" else "rbf"
     phase_type = "exp" if mp_type in ("prodmp", "dmp") else "linear"
-    return fancy_gym_amd.make_bb(env_id, [wrapper], dict(bb or {}),
-                                 {"trajectory_generator_type": mp_type, **(traj or {})}, {"controller_type": "motor"},
-                                 {"phase_generator_type": phase_type, **(phase or {})},
-                                 {"basis_generator_type": basis_type, **(basis or {})}, **kw)
+    env = fancy_gym_amd.make_bb(env_id, [wrapper], dict(bb or {}),
+                                {"trajectory_generator_type": mp_type, **(traj or {})}, {"controller_type": "motor"},
+                                {"phase_generator_type": phase_type, **(phase or {})},
+                                {"basis_generator_type": basis_type, **(basis or {})}, **kw)
+    env.action_space.seed(SEED)      # the reference samples unseeded; fixed here so that failures reproduce
+    return env
 
 
 # ---- golden fixtures through the HIP path ----------------------------------------------------------------------------

@@ -11,6 +11,7 @@ from .engine import RolloutSpec, TrajectoryEngine  # noqa: F401
 from .black_box.black_box_wrapper import BlackBoxWrapper  # noqa: F401
 from .black_box.raw_interface_wrapper import RawInterfaceWrapper  # noqa: F401
 from .batched import BatchedBlackBox  # noqa: F401
+from .vector import VectorBlackBox  # noqa: F401
 from .envs.registry import (ALL_MOVEMENT_PRIMITIVE_ENVIRONMENTS, MOVEMENT_PRIMITIVE_ENVIRONMENTS_FOR_NS,  # noqa: F401
                             register, upgrade)
 from .utils.make_env_helpers import make_bb  # noqa: F401

@@ -132,8 +132,8 @@ class BlackBoxWrapper(ObservationWrapper):
             return self.condition_pos, self.condition_vel
         return self.env.get_wrapper_attr("current_pos"), self.env.get_wrapper_attr("current_vel")
 
-    def get_trajectory(self, action: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
-        """MP parameters -> desired (position [T, D], velocity [T, D]) float32 (reference :96-120)"""
+    def _stage_plan(self, action: np.ndarray) -> None:
+        """push parameters, boundary condition and duration of the next plan into the trajectory generator"""
         gen, box = self.traj_gen, self.traj_gen_action_space
         plan_duration = self.duration
         if self.learn_sub_trajectories:
@@ -143,7 +143,11 @@ class BlackBoxWrapper(ObservationWrapper):
         start = np.array(self.current_traj_steps * self.dt if self.do_replanning else 0)
         gen.set_initial_conditions(start, *self._boundary_condition())
         gen.set_duration(plan_duration, self.dt)
-        return get_numpy(gen.get_traj_pos()), get_numpy(gen.get_traj_vel())
+
+    def get_trajectory(self, action: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """MP parameters -> desired (position [T, D], velocity [T, D]) float32 (reference :96-120)"""
+        self._stage_plan(action)
+        return get_numpy(self.traj_gen.get_traj_pos()), get_numpy(self.traj_gen.get_traj_vel())
 
     # ---- track ---------------------------------------------------------------------------------------------------------
     def _wants_new_plan(self, obs, action, local_t: int) -> bool:
@@ -174,7 +178,10 @@ class BlackBoxWrapper(ObservationWrapper):
 
     def step(self, action: np.ndarray):
         """plan on the GPU, gate through the env's validity hooks, track on the env (reference :150-217)"""
-        position, velocity = self.get_trajectory(action)
+        return self.step_planned(action, *self.get_trajectory(action))
+
+    def step_planned(self, action: np.ndarray, position: np.ndarray, velocity: np.ndarray):
+        """``step`` for a plan that was generated elsewhere (``VectorBlackBox`` plans all its envs in one launch)"""
         position, velocity = self.env.set_episode_arguments(action, position, velocity)
         valid, position, velocity = self.env.preprocessing_and_validity_callback(
             action, position, velocity, self.tau_bound, self.delay_bound)

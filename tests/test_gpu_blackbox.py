@@ -497,3 +497,39 @@ def test_full_size_properties(cfg, B):
     fd = tc.trajectory_generator_type == "promp"
     close(pos[rows].cpu().numpy(), rp, "sample pos")
     close(vel[rows].cpu().numpy(), rv, "sample vel", atol=fd_atol(rp, dt) if fd else 0.0)
+
+
+# ---- host env bridge --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mp_type,replan", [("prodmp", False), ("prodmp", True), ("promp", True), ("dmp", False)])
+@pytest.mark.parametrize("workers", [0, 3])
+def test_vector_black_box_equals_individual_wrappers(mp_type, replan, workers):
+    """N host envs planned in ONE launch and tracked on the host == N independent BlackBoxWrapper episodes, bit for bit"""
+    from fancy_gym_amd import VectorBlackBox
+    bb = {"verbose": 2}
+    if replan:
+        bb.update(replanning_schedule=lambda pos, vel, obs, action, t: t % 20 == 0, max_planning_times=3,
+                  condition_on_desired=True)
+    N = 5
+
+    def make():
+        return fancy_gym_amd.make_bb("dint-v0", [DoubleIntegratorWrapper], dict(bb),
+                                     {"trajectory_generator_type": mp_type},
+                                     {"controller_type": "motor", "p_gains": PG, "d_gains": DG},
+                                     {"phase_generator_type": "exp" if "dmp" in mp_type else "linear"},
+                                     {"basis_generator_type": "prodmp" if mp_type == "prodmp" else "rbf", "num_basis": 4})
+    vec = VectorBlackBox([make() for _ in range(N)], num_workers=workers)
+    solo = [make() for _ in range(N)]
+    vec.reset(seed=11)
+    for i, e in enumerate(solo):
+        e.reset(seed=11 + i)
+    rng = np.random.default_rng(0)
+    for _ in range(3 if replan else 1):
+        actions = rng.standard_normal((N, vec.action_space.shape[0]))
+        obs, rew, term, trunc, infos = vec.step(actions)
+        for i, e in enumerate(solo):
+            o, r, te, tr, info = e.step(actions[i])
+            assert np.array_equal(o, obs[i]) and r == rew[i] and te == term[i] and tr == trunc[i]
+            assert info["trajectory_length"] == infos[i]["trajectory_length"]
+            for k in ("positions", "velocities", "step_actions"):
+                assert np.array_equal(info[k], infos[i][k]), k
+    vec.close()

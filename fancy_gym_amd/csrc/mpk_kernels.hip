@@ -1204,8 +1204,134 @@ __global__ void __launch_bounds__(256) k_pd_rollout(const RolloutDev rc, const i
     QD[e] = qd;
 }
 
+// Tile-streaming variant (D <= 16, float4-aligned trajectories): a wave owns a group of 16/DP episodes and walks their
+// 16-step row tiles in order -- coalesced float4 loads of the desired (pos, vel) pieces one tile ahead, wave-private
+// LDS image, the serial controller + plant recurrence on the lanes (q == 0) as a register chain (float64, no FMA),
+// coalesced float4 store of the actions.  Same arithmetic, same bits as k_pd_rollout.
+struct PdArgs {
+    RolloutDev rc;
+    const float* des_pos;
+    const float* des_vel;
+    double* Q;
+    double* QD;
+    const int32_t* n_steps;
+    float* actions;
+    int D, sh, B, T, G;
+    unsigned inv_seg4;
+};
+
+__global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * 3 * kStageStride];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* sSt = smem + wave * (3 * kStageStride);      // desired pos | desired vel | actions
+    const int D = a.D, T = a.T, B = a.B, SEG = 16 * D, DP = 1 << a.sh, NTW = 16 >> a.sh;
+    const int col = lane & 15, bl = col >> a.sh, d = col & (DP - 1);
+    const bool lane_serial = lane < 16 && d < D;
+    const int seg4 = SEG >> 2;
+    const int sseg = (int)(((unsigned)lane * a.inv_seg4) >> 16);
+    const int w4 = (lane - sseg * seg4) * 4;
+    const unsigned rofs = (unsigned)(sseg * SEG + w4);
+    const size_t gofs = (size_t)sseg * T * D + w4;
+    const int NRT = (T + 15) >> 4;
+    double pgd = 0.0, dgd = 0.0, lod = 0.0, hid = 0.0;
+#pragma unroll
+    for (int dd = 0; dd < kMaxD; ++dd)
+        if (dd == d) { pgd = a.rc.pg[dd]; dgd = a.rc.dg[dd]; lod = a.rc.lo[dd]; hid = a.rc.hi[dd]; }
+    const double dtp = a.rc.dt;
+    const int nb8 = gridDim.x >> 3;
+    const int vb = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * nb8 + (blockIdx.x >> 3) : blockIdx.x;
+    for (int g = vb * 4 + wave; g < a.G; g += gridDim.x * 4) {
+        const int b0 = g * NTW;
+        const bool serial = lane_serial && b0 + bl < B;
+        const bool mover = sseg < NTW && b0 + sseg < B;
+        double qs = 0.0, qds = 0.0;
+        int nst = T;
+        if (serial) {
+            const size_t si = (size_t)(b0 + bl) * D + d;
+            qs = a.Q[si]; qds = a.QD[si];
+            if (a.n_steps) nst = min(a.n_steps[b0 + bl], T);
+        }
+        const float* gp = a.des_pos + (size_t)b0 * T * D + gofs;
+        const float* gv = a.des_vel + (size_t)b0 * T * D + gofs;
+        f32x4 lp = {0, 0, 0, 0}, lv = {0, 0, 0, 0};
+        if (mover && w4 < min(16, T) * D) { lp = *reinterpret_cast<const f32x4*>(gp); lv = *reinterpret_cast<const f32x4*>(gv); }
+        for (int rt = 0; rt < NRT; ++rt) {
+            const int rows = min(16, T - rt * 16);
+            const bool mine = mover && w4 < rows * D;
+            if (mine) {
+                *reinterpret_cast<f32x4*>(sSt + rofs) = lp;
+                *reinterpret_cast<f32x4*>(sSt + kStageStride + rofs) = lv;
+            }
+            if (rt + 1 < NRT) {   // next tile's pieces travel under this tile's recurrence
+                const int rows_n = min(16, T - (rt + 1) * 16);
+                if (mover && w4 < rows_n * D) {
+                    lp = *reinterpret_cast<const f32x4*>(gp + (size_t)(rt + 1) * SEG);
+                    lv = *reinterpret_cast<const f32x4*>(gv + (size_t)(rt + 1) * SEG);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (serial) {
+                const int o0 = bl * SEG + d;
+                float pr[16], vr[16];
+#pragma unroll
+                for (int tl = 0; tl < 16; ++tl) { pr[tl] = sSt[o0 + tl * D]; vr[tl] = sSt[kStageStride + o0 + tl * D]; }
+#pragma unroll
+                for (int tl = 0; tl < 16; ++tl) {
+                    if (tl < rows) {
+                        const int t = rt * 16 + tl;
+                        double u = 0.0;
+                        if (t < nst) {
+                            const double dp = (double)pr[tl], dv = (double)vr[tl];
+                            if (a.rc.controller_type == MPK_CTRL_MOTOR) u = pgd * (dp - qs) + dgd * (dv - qds);
+                            else if (a.rc.controller_type == MPK_CTRL_POSITION) u = dp;
+                            else u = dv;
+                            u = fmin(fmax(u, lod), hid);
+                            if (a.rc.plant_type == MPK_PLANT_DOUBLE_INTEGRATOR) {
+                                qds = qds + dtp * u;
+                                qs = qs + dtp * qds;
+                            }
+                        }
+                        sSt[2 * kStageStride + o0 + tl * D] = (float)u;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (a.actions && mine)
+                *reinterpret_cast<f32x4*>(a.actions + (size_t)b0 * T * D + gofs + (size_t)rt * SEG) =
+                    *reinterpret_cast<const f32x4*>(sSt + 2 * kStageStride + rofs);
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (serial) {
+            const size_t si = (size_t)(b0 + bl) * D + d;
+            a.Q[si] = qs; a.QD[si] = qds;
+        }
+    }
+}
+
 int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const float* des_vel, double* q, double* qd,
                       const int32_t* n_steps, float* actions, int B, int T, void* stream) {
+    auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    const int last_rows = T - (T - 1) / 16 * 16;
+    const bool tiles_ok = D >= 1 && D <= kMaxD && (T * D) % 4 == 0 && (last_rows * D) % 4 == 0 && aligned16(des_pos) &&
+                          aligned16(des_vel) && (!actions || aligned16(actions)) && !getenv("MPK_PD_SIMPLE");
+    if (tiles_ok) {
+        PdArgs pa;
+        pa.rc = rc; pa.des_pos = des_pos; pa.des_vel = des_vel; pa.Q = q; pa.QD = qd; pa.n_steps = n_steps;
+        pa.actions = actions; pa.D = D; pa.B = B; pa.T = T;
+        int sh = 0;
+        while ((1 << sh) < D) ++sh;
+        pa.sh = sh;
+        const int NTW = 16 >> sh;
+        pa.G = (B + NTW - 1) / NTW;
+        pa.inv_seg4 = 65536u / (unsigned)(4 * D) + 1u;
+        int blocks = (pa.G + 3) / 4;
+        if (blocks > 2048) blocks = 2048;
+        if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;
+        hipLaunchKernelGGL(k_pd_rollout_tiles, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pa);
+        MPK_LAUNCH_CHECK();
+        return MPK_OK;
+    }
     const long n = (long)B * D;
     const int blocks = (int)((n + 255) / 256);
     hipLaunchKernelGGL(k_pd_rollout, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rc, D, des_pos, des_vel, q, qd,

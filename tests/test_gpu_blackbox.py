@@ -239,7 +239,10 @@ def test_single_episode_step_matches_oracle_on_a_closed_loop_plant():
 @pytest.mark.parametrize("controller", ["motor", "position", "velocity"])
 @pytest.mark.parametrize("plant", ["static", "double_integrator"])
 @pytest.mark.parametrize("B", [1, 37, 1000])
-def test_pd_rollout_is_bit_exact_in_float64(controller, plant, B):
+@pytest.mark.parametrize("simple", [False, True])
+def test_pd_rollout_is_bit_exact_in_float64(controller, plant, B, simple, monkeypatch):
+    if simple:
+        monkeypatch.setenv("MPK_PD_SIMPLE", "1")      # the generic one-lane-per-(episode, DoF) kernel
     pc, bc, tc, dt, dur = CFG2
     eng = make_engine(pc, bc, tc, dt, dur)
     params, ip, iv = inputs(pc, bc, tc, B, seed=11)
@@ -307,6 +310,31 @@ def test_fused_closed_loop_rollout_is_bit_exact(cfg, controller, B, bulk, monkey
     ra, rq, _ = O.rollout(pos.cpu().numpy(), vel.cpu().numpy(), controller, PG, DG, -0.9, 0.9, "double_integrator", dt,
                           q0, qd0)
     assert np.array_equal(a3.cpu().numpy(), ra.astype(np.float32)) and np.array_equal(q3.cpu().numpy(), rq)
+
+
+@pytest.mark.parametrize("D,T", [(1, 50), (3, 10), (4, 17), (16, 40), (5, 100), (20, 12)])
+def test_pd_rollout_on_every_shape_class(D, T):
+    """tile-streaming kernel (D <= 16, float4-aligned) and the generic kernel (everything else) against the oracle"""
+    from tests.test_gpu_edge_cases import cfg_for
+    pc, bc, tc, dt, dur = cfg_for("promp", D, 3, T)
+    eng = make_engine(pc, bc, tc, dt, dur)
+    B = 23
+    params, ip, iv = inputs(pc, bc, tc, B, seed=D)
+    pos, vel = eng.trajectory(params, ip, iv, 0.0)
+    pg, dg = np.linspace(0.5, 1.5, D), np.linspace(0.05, 0.2, D)
+    n_steps = np.random.default_rng(T).integers(0, T + 1, B).astype(np.int32)
+    q0, qd0 = ip.astype(np.float64), iv.astype(np.float64)
+    q, qd = torch.tensor(q0, device="cuda"), torch.tensor(qd0, device="cuda")
+    spec = RolloutSpec("motor", D, pg, dg, -0.6, 0.6, plant="double_integrator", dt=dt)
+    act = eng.pd_rollout(spec, pos, vel, q, qd, n_steps=torch.tensor(n_steps))
+    ra, rq, rqd = O.rollout(pos.cpu().numpy(), vel.cpu().numpy(), "motor", pg, dg, -0.6, 0.6, "double_integrator", dt,
+                            q0, qd0, n_steps=n_steps)
+    assert np.array_equal(act.cpu().numpy(), ra.astype(np.float32))
+    assert np.array_equal(q.cpu().numpy(), rq) and np.array_equal(qd.cpu().numpy(), rqd)
+    q2, qd2 = torch.tensor(q0, device="cuda"), torch.tensor(qd0, device="cuda")
+    assert eng.pd_rollout(spec, pos, vel, q2, qd2, want_actions=False) is None      # state-only rollout
+    _, rq, _ = O.rollout(pos.cpu().numpy(), vel.cpu().numpy(), "motor", pg, dg, -0.6, 0.6, "double_integrator", dt, q0, qd0)
+    assert np.array_equal(q2.cpu().numpy(), rq)
 
 
 def test_fused_actions_rejects_what_it_cannot_fuse():

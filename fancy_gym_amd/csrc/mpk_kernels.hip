@@ -187,7 +187,8 @@ __global__ void __launch_bounds__(256) k_build_shared(const DevCfg c, const floa
                 A[(size_t)(1 * KP + k) * TS + t] = A[(size_t)k * TS + th];
                 A[(size_t)(2 * KP + k) * TS + t] = A[(size_t)k * TS + tl];
             }
-            aux[t] = (c.base_times[th] + init_time) - (c.base_times[tl] + init_time);
+            // reciprocal of the fp32 time step (one IEEE divide per row here instead of one per output element later)
+            aux[t] = 1.0f / ((c.base_times[th] + init_time) - (c.base_times[tl] + init_time));
         }
     } else {  // DMP: forcing rows phi*x, aux = diff of the fp32 scaled times
         for (int t = tid; t < T; t += 256) {
@@ -248,7 +249,12 @@ struct TrajArgs {
     const double* c_pos;
     const double* c_vel;
     int B, sh, G, vec_ok;
-    unsigned inv_seg4;     // 65536 / (4*D) + 1
+    // LDS staging geometry: `pitch` floats per episode (16*D, +4 when the image is shifted), `cps` float4 chunks per
+    // episode segment, inv_cps = 65536 / cps + 1.  shifted: T*D is not a multiple of 4, so episode b starts
+    // ((b & 3) * (T*D & 3)) & 3 floats past a 16-byte boundary; its tile image is staged with the same offset so
+    // that 16-byte-aligned LDS chunks map onto 16-byte-aligned HBM chunks (partial chunks at both ends go scalar)
+    int pitch, cps, shifted, td3;
+    unsigned inv_cps;
     // closed-loop rollout fused into the episode-major kernel (CT >= 3)
     double* q_state;       // [B, D] plant position, in/out
     double* qd_state;      // [B, D] plant velocity, in/out
@@ -303,7 +309,7 @@ template <int MP, int KM>
 __device__ __forceinline__ LaneMap<KM> make_lane_map(const TrajArgs& a, int lane) {
     const DevCfg& c = a.c;
     LaneMap<KM> L;
-    const int D = c.D, SEG = 16 * D, DP = 1 << a.sh;
+    const int D = c.D, DP = 1 << a.sh;
     L.NTW = 16 >> a.sh;
     L.col = lane & 15; L.q = lane >> 4;
     L.bl = L.col >> a.sh; L.d = L.col & (DP - 1);
@@ -319,13 +325,17 @@ __device__ __forceinline__ LaneMap<KM> make_lane_map(const TrajArgs& a, int lane
         L.poff[m] = (unsigned)(L.bl * c.P + c.off + L.dsafe * c.Kloc + loc);
     }
     L.ioff = (unsigned)(L.bl * D + L.dsafe);
-    L.wofs = (unsigned)(L.bl * SEG + 4 * L.q * D + L.d);
-    const int seg4 = SEG >> 2;
-    L.sseg = (int)(((unsigned)lane * a.inv_seg4) >> 16);
-    L.w4 = (lane - L.sseg * seg4) * 4;
-    L.rofs = (unsigned)(L.sseg * SEG + L.w4);
+    L.wofs = (unsigned)(L.bl * a.pitch + 4 * L.q * D + L.d);
+    L.sseg = (int)(((unsigned)lane * a.inv_cps) >> 16);
+    L.w4 = (lane - L.sseg * a.cps) * 4;
+    L.rofs = (unsigned)(L.sseg * a.pitch + L.w4);
     L.gofs = (unsigned)(L.sseg * c.T * D + L.w4);
     return L;
+}
+
+// floats by which episode b's trajectories start past a 16-byte boundary (0 unless the image is shifted)
+__device__ __forceinline__ unsigned ep_shift(const TrajArgs& a, int b) {
+    return a.shifted ? (((unsigned)b & 3u) * (unsigned)a.td3) & 3u : 0u;
 }
 
 // raw inputs of one episode group for this lane (plain loads, no control flow)
@@ -385,7 +395,7 @@ __device__ __forceinline__ void tile_epilogue(const f32x4& acc0, const f32x4& ac
         const float p = acc0[r];
         float v;
         if (MP == MPK_MP_PRODMP) v = acc1[r];            // 1/tau is folded into the velocity rows
-        else v = (acc1[r] - acc2[r]) / dtd[r];           // forward difference of fp32 positions
+        else v = (acc1[r] - acc2[r]) * dtd[r];           // forward difference of fp32 positions x (1 / dt)
         float* w = sSt + wofs + r * D;
         w[0] = p;
         w[kStageStride] = v;
@@ -405,7 +415,7 @@ __device__ __forceinline__ void tile_epilogue(const f32x4& acc0, const f32x4& ac
 // Takes plain values (a reference to the kernarg struct would force the whole struct into scratch).
 __device__ __noinline__ void store_tile_generic(float* pos, float* vel, float* actions, int nst, int B, int T, int D,
                                                 int NTW, const float* sSt, int lane, int b0, int rt, int rows) {
-    const int SEG = 16 * D, len = rows * D;
+    const int SEG = 16 * D, len = rows * D;      // generic path: never shifted, pitch == SEG
     for (int j = 0; j < nst; ++j) {
         float* outp = j == 0 ? pos : (j == 1 ? vel : actions);
         for (int sb = 0; sb < NTW; ++sb) {
@@ -435,16 +445,29 @@ template <int NST, int KM, bool WT>
 __device__ __forceinline__ void tile_store(const TrajArgs& a, const LaneMap<KM>& L, const float* sSt, int lane,
                                            int b0, int rt, int rows) {
     const int D = a.c.D, T = a.c.T, len = rows * D;
-    if (a.vec_ok && (len & 3) == 0) {
-        if (L.sseg < L.NTW && L.w4 < len && b0 + L.sseg < a.B) {
-            const size_t gb = ((size_t)b0 * T + rt * 16) * D;
+    if (a.vec_ok) {
+        const int bb = b0 + L.sseg;
+        const int lo = (int)ep_shift(a, bb), hi = lo + len, c0 = L.w4;   // valid elements of the padded segment
+        if (L.sseg < L.NTW && bb < a.B && c0 < hi && c0 + 4 > lo) {
+            const size_t go = ((size_t)bb * T + rt * 16) * D - lo + c0;    // 16-byte aligned by construction
             const f32x4 d0 = *reinterpret_cast<const f32x4*>(sSt + L.rofs);
             const f32x4 d1 = *reinterpret_cast<const f32x4*>(sSt + kStageStride + L.rofs);
             f32x4 d2 = d0;
             if (NST > 2) d2 = *reinterpret_cast<const f32x4*>(sSt + 2 * kStageStride + L.rofs);
-            store16<WT>(a.pos + gb + L.gofs, d0);
-            store16<WT>(a.vel + gb + L.gofs, d1);
-            if (NST > 2) store16<WT>(a.actions + gb + L.gofs, d2);
+            if (c0 >= lo && c0 + 4 <= hi) {
+                store16<WT>(a.pos + go, d0);
+                store16<WT>(a.vel + go, d1);
+                if (NST > 2) store16<WT>(a.actions + go, d2);
+            } else {                                   // the (at most two) partial chunks of a segment
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (c0 + e >= lo && c0 + e < hi) {
+                        a.pos[go + e] = d0[e];
+                        a.vel[go + e] = d1[e];
+                        if (NST > 2) a.actions[go + e] = d2[e];
+                    }
+                }
+            }
         }
     } else {
         store_tile_generic(a.pos, a.vel, a.actions, NST, a.B, T, D, L.NTW, sSt, lane, b0, rt, rows);
@@ -504,7 +527,8 @@ __global__ void __launch_bounds__(256) k_traj_tiles(const TrajArgs a, const ActA
             if (NOUT > 2) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[NOUT > 2 ? 2 : 0][m], xb[m], acc2, 0, 0, 0);
         }
         // 3. epilogue -> LDS transpose; 4. coalesced stores
-        if (L.dvalid) tile_epilogue<MP, CT>(acc0, acc1, acc2, dtd, cp, cv, sg, sSt, L.wofs, D);
+        if (L.dvalid)
+            tile_epilogue<MP, CT>(acc0, acc1, acc2, dtd, cp, cv, sg, sSt, L.wofs + ep_shift(a, g * L.NTW + L.bl), D);
         __builtin_amdgcn_wave_barrier();
         tile_store<NST, KM, WT>(a, L, sSt, lane, g * L.NTW, rt, rows);
         __builtin_amdgcn_wave_barrier();
@@ -527,8 +551,11 @@ __device__ __forceinline__ void stream_group(const TrajArgs& a, const LaneMap<KM
     constexpr int NOUT = MP == MPK_MP_PRODMP ? 2 : (MP == MPK_MP_PROMP ? 3 : 1);
     constexpr int NST = 2 + (ACT ? 1 : 0);
     const DevCfg& c = a.c;
-    const int KP = 4 * KM, TS = a.TS, D = c.D, T = c.T, SEG = 16 * D;
+    const int KP = 4 * KM, TS = a.TS, D = c.D, T = c.T;
     const int NRT = (T + 15) >> 4;
+    const unsigned shw = ep_shift(a, b0 + L.bl);          // this column's episode image offset (same for every tile)
+    const unsigned wofs = L.wofs + shw;
+    const int o0 = L.bl * a.pitch + L.d + (int)shw;       // (row 0, this column) for the serial recurrences
     for (int rt = 0; rt < NRT; ++rt) {
         const int rows = min(16, T - rt * 16);
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
@@ -545,14 +572,13 @@ __device__ __forceinline__ void stream_group(const TrajArgs& a, const LaneMap<KM
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dtd[r] = sAux[rt * 16 + 4 * L.q + r];
             }
-            if (L.dvalid) tile_epilogue<MP, CT>(acc0, acc1, acc2, dtd, cp, cv, sg, sSt, L.wofs, D);
+            if (L.dvalid) tile_epilogue<MP, CT>(acc0, acc1, acc2, dtd, cp, cv, sg, sSt, wofs, D);
             if (CLOSED) {
                 // the step loop of black_box_wrapper.py:175-203 on the reference's torque double integrator
                 // (base_reacher_torque.py:25-26), serial in t on the lanes (q == 0); float64, no FMA
                 __builtin_amdgcn_wave_barrier();
                 if (serial) {
                     const double pgd = sg[0], dgd = sg[16], lod = sg[32], hid = sg[48], dtp = a.plant_dt;
-                    const int o0 = L.bl * SEG + L.d;
                     float pr[16], vr[16];
 #pragma unroll
                     for (int tl = 0; tl < 16; ++tl) { pr[tl] = sSt[o0 + tl * D]; vr[tl] = sSt[kStageStride + o0 + tl * D]; }
@@ -581,13 +607,12 @@ __device__ __forceinline__ void stream_group(const TrajArgs& a, const LaneMap<KM
             float* sF = sSt + 2 * kStageStride;
             if (L.dvalid) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sF[L.wofs + r * D] = acc0[r];
+                for (int r = 0; r < 4; ++r) sF[wofs + r * D] = acc0[r];
             }
             __builtin_amdgcn_wave_barrier();
             if (eul) {
                 // the tile's 16 forcing values and scaled-time steps are fetched up front, so the recurrence itself is a
                 // pure register chain; the lanes only park z here -- vel = z / tau is applied by ALL lanes below
-                const int o0 = L.bl * SEG + L.d;
                 float fr[16], dsr[16];
 #pragma unroll
                 for (int tl = 0; tl < 16; ++tl) { fr[tl] = sF[o0 + tl * D]; dsr[tl] = sAux[rt * 16 + tl]; }
@@ -614,7 +639,7 @@ __device__ __forceinline__ void stream_group(const TrajArgs& a, const LaneMap<KM
             if (L.dvalid) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float* w = sSt + kStageStride + L.wofs + r * D;
+                    float* w = sSt + kStageStride + wofs + r * D;
                     *w = *w / c.tau;
                 }
             }
@@ -912,10 +937,17 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     ta.G = (B + NTW - 1) / NTW;
     const bool act = actions != nullptr;
     const int nst = 2 + (act ? 1 : 0);
-    const int SEG = 16 * c.D;
-    ta.inv_seg4 = 65536u / (unsigned)(SEG / 4) + 1u;
+    const int SEG = 16 * c.D, seg4 = SEG / 4, TD = c.T * c.D;
     auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
-    ta.vec_ok = ((c.T * c.D) % 4 == 0) && aligned16(pos) && aligned16(vel) && (!act || aligned16(actions));
+    const bool ptr_ok = aligned16(pos) && aligned16(vel) && (!act || aligned16(actions));
+    // T*D % 4 != 0: episodes start 0..3 floats past a 16-byte boundary -> shifted staging image (one spare chunk per
+    // episode segment), if the segments of a group still fit the 64 lanes of a wave
+    ta.shifted = (TD % 4 != 0 && NTW * (seg4 + 1) <= 64 && NTW * (SEG + 4) <= kStageStride) ? 1 : 0;
+    ta.td3 = TD & 3;
+    ta.pitch = ta.shifted ? SEG + 4 : SEG;
+    ta.cps = ta.shifted ? seg4 + 1 : seg4;
+    ta.inv_cps = 65536u / (unsigned)ta.cps + 1u;
+    ta.vec_ok = ptr_ok && (TD % 4 == 0 || ta.shifted);
     ActArgs aa{};
     int ct = -1;
     if (act) {
@@ -1105,7 +1137,7 @@ __global__ void __launch_bounds__(256) k_traj_rows(const RowArgs a) {
             for (int e = tid; e < T * D; e += nt) {
                 const int t = e / D, dd = e - t * D;
                 const int th = t < T - 1 ? t + 1 : T - 1, tl = t < T - 1 ? t : T - 2;
-                a.vel[(size_t)b * T * D + e] = (sP[th * D + dd] - sP[tl * D + dd]) / (sT[th] - sT[tl]);
+                a.vel[(size_t)b * T * D + e] = (sP[th * D + dd] - sP[tl * D + dd]) * (1.0f / (sT[th] - sT[tl]));
             }
         } else if (MP == MPK_MP_DMP) {
             __syncthreads();

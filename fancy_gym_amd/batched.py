@@ -77,6 +77,7 @@ class BatchedBlackBox:
         self.condition_vel = None
         self._frozen_phase = None
         self._lockstep = 0          # traj_steps of every live episode while the schedule keeps them in lockstep
+        self._host_plans = 0
 
     # ---- episode control ---------------------------------------------------------------------------------------------
     def reset(self, init_pos=None, init_vel=None):
@@ -90,6 +91,7 @@ class BatchedBlackBox:
         self.condition_pos = self.condition_vel = None
         self._frozen_phase = None
         self._lockstep = 0
+        self._host_plans = 0
         self.traj_gen.reset()
         return self.q, self.qd
 
@@ -129,6 +131,17 @@ class BatchedBlackBox:
         return {"params": params, "des_pos": pos, "des_vel": vel}
 
     # ---- plan + execute ----------------------------------------------------------------------------------------------
+    def _host_segment(self) -> int:
+        """host mirror of the integer rule for episodes that move in lockstep (no device read-back)"""
+        cur = self._lockstep
+        if cur >= self.horizon:
+            return 0
+        self._host_plans += 1
+        g_break = self.horizon
+        if self._host_plans < self.max_planning_times:
+            g_break = min((cur // self.every + 1) * self.every, self.horizon)
+        return max(1, min(g_break - cur, self.T))
+
     def _can_fuse(self) -> bool:
         """one launch for plan + execute: shared phase, double-integrator plant, no validity gate, MFMA-capable shape"""
         cfg = self.engine.config
@@ -162,12 +175,17 @@ class BatchedBlackBox:
             self.condition_pos = pos.gather(1, last)[:, 0].contiguous()
             self.condition_vel = vel.gather(1, last)[:, 0].contiguous()
         if self.do_replanning and self._lockstep is not None:
-            live = ~self.done.bool() | ~was_done
-            s = seg[live]
-            if s.numel() and bool((s == s[0]).all()) and bool(valid.all()):
-                self._lockstep += int(s[0])
+            if self.pos_limits is None:
+                # no validity gate: every episode follows the same integer sequence, which the host can mirror without
+                # reading the device state back (k_replan_advance's rule, black_box_wrapper.py:174,197,206)
+                self._lockstep += self._host_segment()
             else:
-                self._lockstep = None      # episodes drifted apart: per-episode init_time from now on
+                live = ~self.done.bool() | ~was_done
+                s = seg[live]
+                if s.numel() and bool((s == s[0]).all()) and bool(valid.all()):
+                    self._lockstep += int(s[0])
+                else:
+                    self._lockstep = None      # episodes drifted apart: per-episode init_time from now on
         out.update(current_pos=self.q, current_vel=self.qd)
         return out
 

@@ -1,0 +1,106 @@
+"""
+GPU suite, part 4: seeded random configurations (movement primitive, DoF, basis count, horizon, dt, phase constants,
+ProDMP flags, batch size, init_time, work decomposition) against the float64 oracle -- every kernel variant gets hit
+with shapes nobody hand-picked.
+"""
+import numpy as np
+import pytest
+import torch
+
+from fancy_gym_amd import RolloutSpec
+from oracle import mp_oracle as O
+from tests.test_gpu_trajectory import close, fd_atol, inputs, make_engine
+
+pytestmark = pytest.mark.gpu
+
+
+def random_case(rng):
+    mp = rng.choice(["prodmp", "promp", "dmp"])
+    D = int(rng.integers(1, 17))
+    T = int(rng.integers(2, 131))
+    dt = float(rng.choice([0.008, 0.01, 0.02, 0.05]))
+    dur = T * dt
+    learn = bool(rng.random() < 0.25)
+    pkw = {}
+    if learn:
+        pkw = dict(learn_tau=bool(rng.random() < 0.7), learn_delay=bool(rng.random() < 0.5))
+        if not (pkw["learn_tau"] or pkw["learn_delay"]):
+            pkw["learn_tau"] = True
+        pkw.update(tau_bound=(0.4 * dur, dur), delay_bound=(0.0, 0.3 * dur))
+    if mp == "prodmp":
+        nb = int(rng.integers(1, 14))
+        pc = O.PhaseCfg("exp", tau=float(rng.uniform(0.5, 1.0)) * dur, alpha_phase=float(rng.uniform(1.5, 4.0)), **pkw)
+        bc = O.BasisCfg("prodmp", num_basis=nb, alpha=float(rng.choice([10.0, 25.0])),
+                        basis_bandwidth_factor=float(rng.uniform(1.5, 4.0)))
+        dg, dw = bool(rng.random() < 0.3), False
+        if not dg:
+            dw = bool(rng.random() < 0.15)
+        tc = O.TrajCfg("prodmp", action_dim=D, weights_scale=float(rng.uniform(0.2, 1.5)),
+                       goal_scale=float(rng.uniform(0.2, 1.5)), auto_scale_basis=bool(rng.random() < 0.4),
+                       relative_goal=bool(rng.random() < 0.4), disable_goal=dg, disable_weights=dw)
+    elif mp == "promp":
+        nb = int(rng.integers(1, 13))
+        zero = bool(rng.random() < 0.6)
+        pc = O.PhaseCfg(str(rng.choice(["linear", "exp"])), tau=float(rng.uniform(0.5, 1.0)) * dur,
+                        alpha_phase=float(rng.uniform(1.5, 4.0)), **pkw)
+        bc = O.BasisCfg("zero_rbf" if zero else "rbf", num_basis=nb, num_basis_zero_start=int(rng.integers(0, 3)) if zero else 0,
+                        num_basis_zero_goal=int(rng.integers(0, 2)) if zero else 0,
+                        num_basis_outside=0 if zero or nb < 4 else int(rng.integers(0, 2)),
+                        basis_bandwidth_factor=float(rng.uniform(1.5, 4.0)))
+        tc = O.TrajCfg("promp", action_dim=D, weights_scale=float(rng.uniform(0.2, 1.5)))
+        T = max(T, 2)
+    else:
+        nb = int(rng.integers(1, 17))
+        pc = O.PhaseCfg("exp", tau=float(rng.uniform(0.7, 1.0)) * dur, alpha_phase=float(rng.uniform(1.5, 3.0)), **pkw)
+        bc = O.BasisCfg("rbf", num_basis=nb, basis_bandwidth_factor=float(rng.uniform(2.0, 4.0)))
+        tc = O.TrajCfg("dmp", action_dim=D, alpha=float(rng.choice([10.0, 25.0])),
+                       weights_scale=float(rng.uniform(0.5, 20.0)), goal_scale=float(rng.uniform(0.5, 1.5)))
+    B = int(rng.choice([1, 2, 3, 5, 16, 33, 100, 257]))
+    init_time = 0.0 if rng.random() < 0.5 else float(rng.integers(1, max(2, T // 3))) * dt
+    return pc, bc, tc, dt, dur, B, init_time
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_random_configuration_matches_oracle(seed, monkeypatch):
+    rng = np.random.default_rng(10_000 + seed)
+    pc, bc, tc, dt, dur, B, init_time = random_case(rng)
+    monkeypatch.setenv("MPK_MAPPING", str(rng.choice(["0", "1", "2"])))
+    monkeypatch.setenv("MPK_BULK", str(rng.choice(["0", "2"])))
+    if tc.trajectory_generator_type == "prodmp":
+        # keep the plan inside the pre-computed range (6 tau): reference raises otherwise
+        tau_min = pc.tau_bound[0] if pc.learn_tau else pc.tau
+        if (dur + init_time) / tau_min > 5.9:
+            init_time = 0.0
+        if dur / tau_min > 5.9:
+            pytest.skip("beyond the ProDMP pre-computation range")
+    eng = make_engine(pc, bc, tc, dt, dur)
+    params, ip, iv = inputs(pc, bc, tc, B, seed=seed)
+    if pc.learn_tau:
+        params[:, 0] = rng.uniform(pc.tau_bound[0], pc.tau_bound[1], B)
+    if pc.learn_delay:
+        params[:, int(pc.learn_tau)] = rng.uniform(pc.delay_bound[0], pc.delay_bound[1], B)
+    pos, vel = eng.trajectory(params, ip, iv, init_time)
+    torch.cuda.synchronize()
+    rp, rv = O.get_trajectory(pc, bc, tc, params, dur, dt, init_time, ip, iv, dtype=np.float64)
+    assert np.isfinite(rp).all()
+    close(pos.cpu().numpy(), rp, f"pos [{eng.last_kernel()}]")
+    fd = tc.trajectory_generator_type == "promp"
+    close(vel.cpu().numpy(), rv, f"vel [{eng.last_kernel()}]", atol=fd_atol(rp, dt) if fd else 0.0)
+    # the rollout kernels on the same trajectory, bit-exact
+    pg, dg = rng.uniform(0.2, 2.0, tc.action_dim), rng.uniform(0.02, 0.3, tc.action_dim)
+    n_steps = rng.integers(0, pos.shape[1] + 1, B).astype(np.int32)
+    q0, qd0 = rng.uniform(-1, 1, (B, tc.action_dim)), rng.uniform(-0.3, 0.3, (B, tc.action_dim))
+    q, qd = torch.tensor(q0, device="cuda"), torch.tensor(qd0, device="cuda")
+    spec = RolloutSpec("motor", tc.action_dim, pg, dg, -0.8, 0.8, plant="double_integrator", dt=dt)
+    act = eng.pd_rollout(spec, pos, vel, q, qd, n_steps=torch.tensor(n_steps))
+    ra, rq, rqd = O.rollout(pos.cpu().numpy(), vel.cpu().numpy(), "motor", pg, dg, -0.8, 0.8, "double_integrator", dt,
+                            q0, qd0, n_steps=n_steps)
+    assert np.array_equal(act.cpu().numpy(), ra.astype(np.float32))
+    assert np.array_equal(q.cpu().numpy(), rq) and np.array_equal(qd.cpu().numpy(), rqd)
+    shared = not (pc.learn_tau or pc.learn_delay)
+    if shared and tc.trajectory_generator_type != "dmp" and eng.last_kernel().startswith(("k_traj_tiles", "k_traj_stream")):
+        q2, qd2 = torch.tensor(q0, device="cuda"), torch.tensor(qd0, device="cuda")
+        p2, v2, a2 = eng.trajectory_rollout(params, ip, iv, spec, q2, qd2, n_steps=torch.tensor(n_steps),
+                                            init_time=init_time)
+        assert torch.equal(p2, pos) and torch.equal(v2, vel) and torch.equal(a2, act)
+        assert torch.equal(q2, q) and torch.equal(qd2, qd)

@@ -850,13 +850,220 @@ __global__ void __launch_bounds__(256) k_traj_stream(const TrajArgs a, const Act
     }
 }
 
+// ---- episode-major, four groups per wave: the serial-recurrence variants ---------------------------------------------
+// DMP (Euler recurrence) and the closed-loop rollout (controller + plant recurrence) are serial in t and run on the
+// 16 lanes that hold row 0 of a column.  Here a wave owns FOUR consecutive episode groups at once: per row tile it
+// produces the four C tiles back to back on the matrix cores, then lane quarter q runs group q's recurrence, so the four
+// recurrences advance in parallel (4x fewer serial instructions per episode), then the four tiles leave as coalesced
+// float4 stores.  Same arithmetic and bits as k_traj_stream.
+constexpr int kQuad = 4;
+
+template <int MP, int CT, int KM>
+__global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActArgs act) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * kQuad * 3 * kStageStride];   // per wave: 4 x (pos|vel|act or force)
+    __shared__ double sgain[4][64];
+    extern __shared__ __attribute__((aligned(16))) float sTab[];   // [NOUT][KP][TS] rows + [TS] aux
+    constexpr bool CLOSED = CT >= 3;
+    static_assert(MP == MPK_MP_DMP || CLOSED, "k_traj_quad is for the serial-recurrence variants");
+    constexpr int NOUT = MP == MPK_MP_PRODMP ? 2 : (MP == MPK_MP_PROMP ? 3 : 1);
+    constexpr int NST = CLOSED ? 3 : 2;
+    const DevCfg& c = a.c;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int KP = 4 * KM, TS = a.TS, D = c.D, B = a.B, P = c.P, T = c.T;
+    float* sW = smem + wave * (kQuad * 3 * kStageStride);
+    float* sA = sTab;
+    float* sAux = sTab + NOUT * KP * TS;
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.A);
+        float4* dst = reinterpret_cast<float4*>(sA);
+        const int n4 = (NOUT * KP * TS) >> 2;
+        for (int i = threadIdx.x; i < n4; i += 256) dst[i] = src[i];
+        const float4* s2 = reinterpret_cast<const float4*>(a.aux);
+        float4* d2 = reinterpret_cast<float4*>(sAux);
+        for (int i = threadIdx.x; i < (TS >> 2); i += 256) d2[i] = s2[i];
+    }
+    __syncthreads();
+    const LaneMap<KM> L = make_lane_map<MP, KM>(a, lane);
+    const int NTW = L.NTW, NRT = (T + 15) >> 4;
+    const int nb8 = gridDim.x >> 3;
+    const int vb = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * nb8 + (blockIdx.x >> 3) : blockIdx.x;
+    const int ustride = gridDim.x * 4;
+    const int NU = (a.G + kQuad - 1) / kQuad;
+    int u = vb * 4 + wave;
+    if (u >= NU) return;
+    const float* ap = sA + L.q * TS + L.col;
+    double pgd = 0.0, dgd = 0.0, lod = 0.0, hid = 0.0;
+    if (CLOSED) {
+#pragma unroll
+        for (int dd = 0; dd < kMaxD; ++dd)
+            if (dd == L.d) { pgd = act.pg[dd]; dgd = act.dg[dd]; lod = act.lo[dd]; hid = act.hi[dd]; }
+    }
+    (void)sgain;
+
+    float xb[kQuad][KM];
+    GroupIn<KM> nx[kQuad];
+#pragma unroll
+    for (int j = 0; j < kQuad; ++j) {
+        const int g = u * kQuad + j;
+        nx[j] = load_group<MP, false, KM>(a, L, g < a.G ? g : a.G - 1);
+    }
+    while (u < NU) {
+        const int g0 = u * kQuad;
+#pragma unroll
+        for (int j = 0; j < kQuad; ++j) finish_group<KM>(L, nx[j], xb[j]);
+        const int un = u + ustride;
+        if (un < NU) {
+#pragma unroll
+            for (int j = 0; j < kQuad; ++j) {
+                const int g = un * kQuad + j;
+                nx[j] = load_group<MP, false, KM>(a, L, g < a.G ? g : a.G - 1);
+            }
+        }
+        // this lane's recurrence: group g0 + q, column (bl, d)
+        const int gq = g0 + L.q, bq = gq * NTW + L.bl;
+        const bool serial = L.dvalid && gq < a.G && bq < B;
+        const int oq = L.bl * a.pitch + L.d + (int)ep_shift(a, bq);      // (row 0, this column) in group q's image
+        float* sQ = sW + L.q * (3 * kStageStride);
+        double qs = 0.0, qds = 0.0;
+        int nst = T;
+        float ey = 0.f, ez = 0.f, eg = 0.f;
+        if (serial) {
+            const size_t si = (size_t)bq * D + L.d;
+            if (CLOSED) {
+                qs = a.q_state[si]; qds = a.qd_state[si];
+                if (a.n_steps) nst = a.n_steps[bq];
+            } else {
+                ey = a.init_pos[si];
+                ez = a.init_vel[si] * c.tau;
+                eg = a.params[(size_t)bq * P + c.off + L.d * c.Kloc + c.nb] * c.gs;
+            }
+        }
+        for (int rt = 0; rt < NRT; ++rt) {
+            const int rows = min(16, T - rt * 16);
+            // 1. four C tiles on the matrix cores -> four staging images
+#pragma unroll
+            for (int j = 0; j < kQuad; ++j) {
+                if (g0 + j < a.G) {
+                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int m = 0; m < KM; ++m) {
+                        const float* am = ap + (4 * m) * TS + rt * 16;
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[0], xb[j][m], acc0, 0, 0, 0);
+                        if (NOUT > 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[KP * TS], xb[j][m], acc1, 0, 0, 0);
+                        if (NOUT > 2) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[2 * KP * TS], xb[j][m], acc2, 0, 0, 0);
+                    }
+                    float* sJ = sW + j * (3 * kStageStride);
+                    const unsigned wofs = L.wofs + ep_shift(a, (g0 + j) * NTW + L.bl);
+                    if (L.dvalid) {
+                        if (MP == MPK_MP_DMP) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) sJ[2 * kStageStride + wofs + r * D] = acc0[r];
+                        } else {
+                            float dtd[4] = {1.f, 1.f, 1.f, 1.f};
+                            if (MP == MPK_MP_PROMP) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) dtd[r] = sAux[rt * 16 + 4 * L.q + r];
+                            }
+                            tile_epilogue<MP, CT>(acc0, acc1, acc2, dtd, 0.0, 0.0, nullptr, sJ, wofs, D);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // 2. four recurrences in parallel, one per lane quarter (float64 / fp32 without FMA, as k_traj_stream)
+            if (serial) {
+                if (CLOSED) {
+                    float pr[16], vr[16];
+#pragma unroll
+                    for (int tl = 0; tl < 16; ++tl) { pr[tl] = sQ[oq + tl * D]; vr[tl] = sQ[kStageStride + oq + tl * D]; }
+#pragma unroll
+                    for (int tl = 0; tl < 16; ++tl) {
+                        if (tl < rows) {
+                            const int t = rt * 16 + tl;
+                            double uu = 0.0;
+                            if (t < nst) {
+                                const double dp = (double)pr[tl], dv = (double)vr[tl];
+                                if (CT - 3 == MPK_CTRL_MOTOR) uu = pgd * (dp - qs) + dgd * (dv - qds);
+                                else if (CT - 3 == MPK_CTRL_POSITION) uu = dp;
+                                else uu = dv;
+                                uu = fmin(fmax(uu, lod), hid);
+                                qds = qds + a.plant_dt * uu;
+                                qs = qs + a.plant_dt * qds;
+                            }
+                            sQ[2 * kStageStride + oq + tl * D] = (float)uu;
+                        }
+                    }
+                } else {
+                    float fr[16], dsr[16];
+#pragma unroll
+                    for (int tl = 0; tl < 16; ++tl) { fr[tl] = sQ[2 * kStageStride + oq + tl * D]; dsr[tl] = sAux[rt * 16 + tl]; }
+#pragma unroll
+                    for (int tl = 0; tl < 16; ++tl) {
+                        if (tl < rows) {
+                            const int t = rt * 16 + tl;
+                            sQ[oq + tl * D] = ey;
+                            sQ[kStageStride + oq + tl * D] = ez;
+                            if (t < T - 1) {
+                                const float t1 = eg - ey;
+                                const float t2 = c.dmp_beta * t1;
+                                const float t3 = t2 - ez;
+                                const float t4 = c.dmp_alpha * t3;
+                                const float acc = t4 + fr[tl];
+                                ez = ez + dsr[tl] * acc;
+                                ey = ey + dsr[tl] * ez;
+                            }
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (MP == MPK_MP_DMP) {
+                // vel = z / tau (IEEE divide) on every lane, for the four images
+                if (L.dvalid) {
+#pragma unroll
+                    for (int j = 0; j < kQuad; ++j) {
+                        float* sJ = sW + j * (3 * kStageStride) + kStageStride + L.wofs +
+                                    ep_shift(a, (g0 + j) * NTW + L.bl);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sJ[r * D] = sJ[r * D] / c.tau;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            // 3. coalesced stores of the four tiles
+#pragma unroll
+            for (int j = 0; j < kQuad; ++j)
+                if (g0 + j < a.G)
+                    tile_store<NST, KM, false>(a, L, sW + j * (3 * kStageStride), lane, (g0 + j) * NTW, rt, rows);
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (CLOSED) {
+            if (serial) {
+                const size_t si = (size_t)bq * D + L.d;
+                a.q_state[si] = qs; a.qd_state[si] = qds;
+            }
+        }
+        u = un;
+    }
+}
+
 template <int MP, int CT>
 static int launch_traj_t(const TrajArgs& ta, const ActArgs& aa, bool stream_mode, bool write_through, bool bulk,
-                         int blocks, size_t lds, void* stream) {
+                         bool quad, int blocks, size_t lds, void* stream) {
     const dim3 g(blocks), b(256);
     hipStream_t s = (hipStream_t)stream;
     const int km = ta.c.KP / 4;
-    if (stream_mode) {
+    if (stream_mode && quad) {
+        if constexpr (MP == MPK_MP_DMP || CT >= 3) {
+            switch (km) {
+                case 1: hipLaunchKernelGGL((k_traj_quad<MP, CT, 1>), g, b, lds, s, ta, aa); break;
+                case 2: hipLaunchKernelGGL((k_traj_quad<MP, CT, 2>), g, b, lds, s, ta, aa); break;
+                case 3: hipLaunchKernelGGL((k_traj_quad<MP, CT, 3>), g, b, lds, s, ta, aa); break;
+                default: hipLaunchKernelGGL((k_traj_quad<MP, CT, 4>), g, b, lds, s, ta, aa); break;
+            }
+        }
+    } else if (stream_mode) {
         if (bulk) {
             switch (km) {
                 case 1: hipLaunchKernelGGL((k_traj_stream<MP, CT, 1, true>), g, b, lds, s, ta, aa); break;
@@ -897,19 +1104,19 @@ static int launch_traj_t(const TrajArgs& ta, const ActArgs& aa, bool stream_mode
 
 template <int MP>
 static int launch_traj_ct(const TrajArgs& ta, const ActArgs& aa, int ct, bool stream_mode, bool write_through,
-                          bool bulk, int blocks, size_t lds, void* stream) {
+                          bool bulk, bool quad, int blocks, size_t lds, void* stream) {
     if constexpr (MP != MPK_MP_DMP) {
         switch (ct) {
-            case MPK_CTRL_MOTOR: return launch_traj_t<MP, MPK_CTRL_MOTOR>(ta, aa, stream_mode, write_through, bulk, blocks, lds, stream);
-            case MPK_CTRL_VELOCITY: return launch_traj_t<MP, MPK_CTRL_VELOCITY>(ta, aa, stream_mode, write_through, bulk, blocks, lds, stream);
-            case MPK_CTRL_POSITION: return launch_traj_t<MP, MPK_CTRL_POSITION>(ta, aa, stream_mode, write_through, bulk, blocks, lds, stream);
-            case 3 + MPK_CTRL_MOTOR: return launch_traj_t<MP, 3 + MPK_CTRL_MOTOR>(ta, aa, true, false, bulk, blocks, lds, stream);
-            case 3 + MPK_CTRL_VELOCITY: return launch_traj_t<MP, 3 + MPK_CTRL_VELOCITY>(ta, aa, true, false, bulk, blocks, lds, stream);
-            case 3 + MPK_CTRL_POSITION: return launch_traj_t<MP, 3 + MPK_CTRL_POSITION>(ta, aa, true, false, bulk, blocks, lds, stream);
+            case MPK_CTRL_MOTOR: return launch_traj_t<MP, MPK_CTRL_MOTOR>(ta, aa, stream_mode, write_through, bulk, quad, blocks, lds, stream);
+            case MPK_CTRL_VELOCITY: return launch_traj_t<MP, MPK_CTRL_VELOCITY>(ta, aa, stream_mode, write_through, bulk, quad, blocks, lds, stream);
+            case MPK_CTRL_POSITION: return launch_traj_t<MP, MPK_CTRL_POSITION>(ta, aa, stream_mode, write_through, bulk, quad, blocks, lds, stream);
+            case 3 + MPK_CTRL_MOTOR: return launch_traj_t<MP, 3 + MPK_CTRL_MOTOR>(ta, aa, true, false, bulk, quad, blocks, lds, stream);
+            case 3 + MPK_CTRL_VELOCITY: return launch_traj_t<MP, 3 + MPK_CTRL_VELOCITY>(ta, aa, true, false, bulk, quad, blocks, lds, stream);
+            case 3 + MPK_CTRL_POSITION: return launch_traj_t<MP, 3 + MPK_CTRL_POSITION>(ta, aa, true, false, bulk, quad, blocks, lds, stream);
             default: break;
         }
     }
-    return launch_traj_t<MP, -1>(ta, aa, stream_mode, write_through, bulk, blocks, lds, stream);
+    return launch_traj_t<MP, -1>(ta, aa, stream_mode, write_through, bulk, quad, blocks, lds, stream);
 }
 
 // 0 = automatic, 1 = force tile-major, 2 = force episode-major (MPK_MAPPING environment variable, for A/B runs)
@@ -973,7 +1180,18 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     int blocks;
     size_t lds = 0;
     bool bulk = false;
-    if (stream_mode) {
+    // serial-recurrence variants (DMP, closed loop): four groups per wave, recurrences in parallel on the lane quarters
+    // (MPK_QUAD=0 falls back to k_traj_stream, for A/B runs); needs its 52 KB of staging + the tables within 64 KB
+    bool quad = stream_mode && (c.mp_type == MPK_MP_DMP || closed) &&
+                table_bytes + (4 * kQuad * 3 * kStageStride) * sizeof(float) + 4 * 64 * sizeof(double) <= 64 * 1024;
+    if (const char* e = getenv("MPK_QUAD")) quad = quad && atoi(e) != 0;
+    if (quad) {
+        lds = table_bytes;
+        const long units = (ta.G + kQuad - 1) / kQuad;
+        const long waves = units < max_waves ? units : max_waves;
+        blocks = (int)((waves + 3) / 4);
+        if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;
+    } else if (stream_mode) {
         lds = table_bytes;
         // bulk input staging: chunk blocks must be float4-sized / aligned and fit the per-lane register image
         const int EPC = kChunkGroups * NTW;
@@ -1007,16 +1225,16 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     if (blocks < 1) blocks = 1;
     switch (c.mp_type) {
         case MPK_MP_PRODMP:
-            *kernel_name = closed ? "k_traj_stream<prodmp,closed>" : stream_mode ? (act ? "k_traj_stream<prodmp,act>" : "k_traj_stream<prodmp>")
+            *kernel_name = closed ? (quad ? "k_traj_quad<prodmp,closed>" : "k_traj_stream<prodmp,closed>") : stream_mode ? (act ? "k_traj_stream<prodmp,act>" : "k_traj_stream<prodmp>")
                                        : (act ? "k_traj_tiles<prodmp,act>" : "k_traj_tiles<prodmp>");
-            return launch_traj_ct<MPK_MP_PRODMP>(ta, aa, ct, stream_mode, write_through, bulk, blocks, lds, stream);
+            return launch_traj_ct<MPK_MP_PRODMP>(ta, aa, ct, stream_mode, write_through, bulk, quad, blocks, lds, stream);
         case MPK_MP_PROMP:
-            *kernel_name = closed ? "k_traj_stream<promp,closed>" : stream_mode ? (act ? "k_traj_stream<promp,act>" : "k_traj_stream<promp>")
+            *kernel_name = closed ? (quad ? "k_traj_quad<promp,closed>" : "k_traj_stream<promp,closed>") : stream_mode ? (act ? "k_traj_stream<promp,act>" : "k_traj_stream<promp>")
                                        : (act ? "k_traj_tiles<promp,act>" : "k_traj_tiles<promp>");
-            return launch_traj_ct<MPK_MP_PROMP>(ta, aa, ct, stream_mode, write_through, bulk, blocks, lds, stream);
+            return launch_traj_ct<MPK_MP_PROMP>(ta, aa, ct, stream_mode, write_through, bulk, quad, blocks, lds, stream);
         default:
-            *kernel_name = "k_traj_stream<dmp>";
-            return launch_traj_ct<MPK_MP_DMP>(ta, aa, -1, true, false, bulk, blocks, lds, stream);
+            *kernel_name = quad ? "k_traj_quad<dmp>" : "k_traj_stream<dmp>";
+            return launch_traj_ct<MPK_MP_DMP>(ta, aa, -1, true, false, bulk, quad, blocks, lds, stream);
     }
 }
 

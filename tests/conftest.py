@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    # the suites bind libmpk.so through ctypes: (re)build it if the checkout has none or the sources are newer
+    import __graft_entry__ as entry
+    if not os.path.exists(entry.LIB):
+        entry.build()
 
 
 def _has_gpu() -> bool:

@@ -1184,7 +1184,12 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     // (MPK_QUAD=0 falls back to k_traj_stream, for A/B runs); needs its 52 KB of staging + the tables within 64 KB
     bool quad = stream_mode && (c.mp_type == MPK_MP_DMP || closed) &&
                 table_bytes + (4 * kQuad * 3 * kStageStride) * sizeof(float) + 4 * 64 * sizeof(double) <= 64 * 1024;
-    if (const char* e = getenv("MPK_QUAD")) quad = quad && atoi(e) != 0;
+    {   // automatic: only when the 4x coarser work units still give every CU a few waves (MPK_QUAD: 0 off, 2 force)
+        int quad_mode = 1;
+        if (const char* e = getenv("MPK_QUAD")) quad_mode = atoi(e);
+        const long units = (ta.G + kQuad - 1) / kQuad;
+        quad = quad && quad_mode != 0 && (quad_mode == 2 || units >= (long)num_cu * 4);
+    }
     if (quad) {
         lds = table_bytes;
         const long units = (ta.G + kQuad - 1) / kQuad;

@@ -280,7 +280,7 @@ def test_fused_actions_are_bit_exact(cfg, controller, mapping, monkeypatch):
 @pytest.mark.parametrize("cfg", [CFG2, CFG5, CFG4], ids=["prodmp", "promp", "prodmp_replan"])
 @pytest.mark.parametrize("controller", ["motor", "position", "velocity"])
 @pytest.mark.parametrize("B", [1, 9, 200])
-@pytest.mark.parametrize("bulk,quad", [("0", "1"), ("0", "0"), ("2", "0")])
+@pytest.mark.parametrize("bulk,quad", [("0", "2"), ("0", "0"), ("2", "0")])
 def test_fused_closed_loop_rollout_is_bit_exact(cfg, controller, B, bulk, quad, monkeypatch):
     """one launch (trajectory + controller + double-integrator plant) == mpk_trajectory + mpk_pd_rollout == oracle;
     k_traj_quad (four recurrences per wave) and both input-staging variants of k_traj_stream"""

@@ -182,6 +182,8 @@ struct Handle {
     double duration = 0.0, dt = 0.0;
     std::vector<float> times;
     double* d_tab = nullptr;
+    size_t rows_off = 0;           // ProDMP: offset (doubles) of the row-interleaved table copy inside d_tab
+    int row_stride = 0;            // doubles per row of that copy (0: none)
     float* d_times = nullptr;
     int32_t* d_flag = nullptr;   // range-error flag written by kernels
     int32_t* d_idx = nullptr;    // scratch for mpk_prodmp_indices
@@ -270,6 +272,8 @@ static void fill_devcfg(Handle* h) {
     d.ws = (float)c.weights_scale; d.gs = (float)c.goal_scale;
     d.dmp_alpha = (float)c.dmp_alpha; d.dmp_beta = (float)(c.dmp_alpha / 4.0);
     d.tab = h->d_tab;
+    d.tab_rows = h->row_stride ? h->d_tab + h->rows_off : nullptr;
+    d.row_stride = h->row_stride;
     d.base_times = h->d_times;
 }
 
@@ -443,6 +447,27 @@ int mpk_create(const mpk_config* cfg, mpk_handle* out) {
             float sc = k < cfg->num_basis ? (float)cfg->weights_scale : (float)cfg->goal_scale;
             if (cfg->auto_scale_basis) sc = (float)t.scale[k] * sc;
             packed.push_back((double)sc);
+        }
+        // second copy for the per-episode-phase kernel, one table index per 128 / 256-byte row so a lane fetches its
+        // whole row from one or two cache lines: [y1 y2 dy1 dy2 | pos_basis[0..KS-2) | vel_basis[0..KS-2)], KS = 8 or
+        // 16 contraction columns, columns past the last one repeat it
+        const int K = cfg->num_basis + 1;
+        if (K + 2 <= 16) {
+            const int KS = K + 2 <= 8 ? 8 : 16, KB = KS - 2, RS = 2 * KS;
+            while (packed.size() % 32) packed.push_back(0.0);
+            h->rows_off = packed.size();
+            h->row_stride = RS;
+            packed.resize(packed.size() + (size_t)t.n_pc * RS, 0.0);
+            double* rows = packed.data() + h->rows_off;
+            for (int i = 0; i < t.n_pc; ++i) {
+                double* r = rows + (size_t)i * RS;
+                r[0] = t.y1[i]; r[1] = t.y2[i]; r[2] = t.dy1[i]; r[3] = t.dy2[i];
+                for (int kk = 0; kk < KB; ++kk) {
+                    const int kc = kk < K ? kk : K - 1;
+                    r[4 + kk] = t.pos_basis[(size_t)i * K + kc];
+                    r[4 + KB + kk] = t.vel_basis[(size_t)i * K + kc];
+                }
+            }
         }
     } else {
         build_rbf(*cfg, h->tab);

@@ -85,7 +85,7 @@ __device__ __forceinline__ void prodmp_xi(const DevCfg& c, const ProdmpBC& bc, i
 // and the velocity row additionally carries the 1/tau of  vel = (...)/tau.  Everything is folded in float64 and
 // rounded ONCE to fp32.
 __device__ __forceinline__ void prodmp_col(const DevCfg& c, const ProdmpBC& bc, int idx, const double xi[4], int k,
-                                           double tau, float* h, float* hv) {
+                                           double tau, double inv_tau, float* h, float* hv) {
     const int N = c.n_pc, K = c.nb + 1;
     const double* PB = c.tab + 4 * (size_t)N;
     const double* VB = PB + (size_t)N * K;
@@ -113,16 +113,147 @@ __device__ __forceinline__ void prodmp_col(const DevCfg& c, const ProdmpBC& bc, 
         p = xi[1] * tau; v = xi[3] * tau;
     }
     *h = (float)p;
-    *hv = (float)(v / tau);
+    *hv = (float)(v * inv_tau);
+}
+
+// The same columns for one time step, all KS at once, from the row-interleaved table copy (prodmp_col walks k with a
+// round trip to memory per column and a cache line per value).  pbb / vbb / sc: basis rows at the boundary index and the
+// scale row, loaded once per episode by prodmp_boundary_rows.  Expression for expression the arithmetic of prodmp_col:
+// identical bits.
+template <int KS>
+__device__ __forceinline__ void prodmp_load_row(const DevCfg& c, int idx, double (&y)[4], double (&pb)[KS - 2],
+                                                double (&vb)[KS - 2]) {
+    // one row of the interleaved table copy: 2 * KS doubles, 16-byte loads
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2* r = reinterpret_cast<const d2*>(c.tab_rows + (size_t)idx * (2 * KS));
+    double v[2 * KS];
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+        const d2 q = r[i];
+        v[2 * i] = q.x; v[2 * i + 1] = q.y;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = v[i];
+#pragma unroll
+    for (int kk = 0; kk < KS - 2; ++kk) { pb[kk] = v[4 + kk]; vb[kk] = v[4 + (KS - 2) + kk]; }
+}
+
+template <int KS>
+__device__ __forceinline__ void prodmp_boundary_rows(const DevCfg& c, int idxb, double (&pbb)[KS - 2],
+                                                     double (&vbb)[KS - 2], double (&sc)[KS - 2]) {
+    const int N = c.n_pc, K = c.nb + 1;
+    double y[4];
+    prodmp_load_row<KS>(c, idxb, y, pbb, vbb);
+    const double* S = c.tab + 4 * (size_t)N + 2 * (size_t)N * K;   // weights_goal_scale
+#pragma unroll
+    for (int kk = 0; kk < KS - 2; ++kk) sc[kk] = S[kk < K ? kk : K - 1];
+}
+
+template <int KS>
+__device__ __forceinline__ void prodmp_row(const DevCfg& c, const ProdmpBC& bc, const double (&pbb)[KS - 2],
+                                           const double (&vbb)[KS - 2], const double (&sc)[KS - 2], int idx,
+                                           double tau, double inv_tau, float (&h)[KS], float (&hv)[KS]) {
+    const int K = c.nb + 1;
+    double y[4], hp[KS - 2], hvp[KS - 2];
+    prodmp_load_row<KS>(c, idx, y, hp, hvp);
+    const double y1 = y[0], y2 = y[1], dy1 = y[2], dy2 = y[3];
+    double xi[4];
+    xi[0] = bc.a * y1 - bc.b * y2;
+    xi[1] = bc.c * y2 - bc.d * y1;
+    xi[2] = bc.a * dy1 - bc.b * dy2;
+    xi[3] = bc.c * dy2 - bc.d * dy1;
+#pragma unroll
+    for (int kk = 0; kk < KS - 2; ++kk) {
+        hp[kk] = hp[kk] - (xi[0] * pbb[kk] + xi[1] * vbb[kk]);
+        hvp[kk] = hvp[kk] - (xi[2] * pbb[kk] + xi[3] * vbb[kk]);
+    }
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+        double p = 0.0, v = 0.0;
+        if (k < K) {
+            if (k < KS - 2) {
+                const bool off = k < c.nb ? c.disable_weights != 0 : c.disable_goal != 0;
+                if (!off) { p = hp[k] * sc[k]; v = hvp[k] * sc[k]; }
+            }
+        } else if (k == K) {
+            p = xi[0]; v = xi[2];
+            if (c.relative_goal && k >= 1 && k - 1 < KS - 2) { p += hp[k - 1]; v += hvp[k - 1]; }
+        } else if (k == K + 1) {
+            p = xi[1] * tau; v = xi[3] * tau;
+        }
+        h[k] = (float)p;
+        hv[k] = (float)(v * inv_tau);
+    }
+}
+
+// Lean float64 helpers for the basis rows.  The library exp()/divide carry special-case handling the rows never need
+// (arguments are finite and <= 0, divisors are positive and normal); these keep ~1e-15 relative accuracy, far inside
+// the single rounding to fp32 that follows, at a third of the instructions.  Every basis row on the device -- shared
+// tables and per-episode rows alike -- goes through the same two functions, so the two paths agree bit for bit.
+// coefficients of exp_nonpos: [0] log2(e), [1..2] -ln2 split hi / lo, [3..14] Taylor 1/11! .. 1/0! (remainder < 7e-15
+// for |r| <= ln2/2).  ExpLiteral folds them into the instruction stream; ExpRegs holds them in registers loaded once
+// per kernel (64-bit literals cost a move per use and the scalar registers that would hold them are the scarce ones
+// in the per-episode kernel).  Same values, same operation order: same bits.
+__device__ double kExpTab[15] = {   // not const: a const table would be folded back into literals
+    1.4426950408889634074, -6.93147180369123816490e-01, -1.90821492927058770002e-10,
+    2.50521083854417187751e-08, 2.75573192239858906526e-07, 2.75573192239858906526e-06, 2.48015873015873015873e-05,
+    1.98412698412698412698e-04, 1.38888888888888888889e-03, 8.33333333333333333333e-03, 4.16666666666666666667e-02,
+    1.66666666666666666667e-01, 0.5, 1.0, 1.0};
+
+struct ExpLiteral {
+    __device__ __forceinline__ double operator[](int i) const {
+        constexpr double t[15] = {
+            1.4426950408889634074, -6.93147180369123816490e-01, -1.90821492927058770002e-10,
+            2.50521083854417187751e-08, 2.75573192239858906526e-07, 2.75573192239858906526e-06,
+            2.48015873015873015873e-05, 1.98412698412698412698e-04, 1.38888888888888888889e-03,
+            8.33333333333333333333e-03, 4.16666666666666666667e-02, 1.66666666666666666667e-01, 0.5, 1.0, 1.0};
+        return t[i];
+    }
+};
+
+struct ExpRegs {
+    double t[15];
+    __device__ __forceinline__ void load() {
+#pragma unroll
+        for (int i = 0; i < 15; ++i) {
+            t[i] = kExpTab[i];
+            asm volatile("" : "+v"(t[i]));      // vector registers: the scalar file is what this kernel runs out of
+        }
+    }
+    __device__ __forceinline__ double operator[](int i) const { return t[i]; }
+};
+
+template <class CF>
+__device__ __forceinline__ double exp_nonpos(double x, const CF& cf) {
+    x = fmax(x, -700.0);                                        // exp(-700) ~ 1e-304: still normal, rounds to 0.0f
+    const double n = rint(x * cf[0]);
+    double r = fma(n, cf[1], x);
+    r = fma(n, cf[2], r);
+    double p = cf[3];
+#pragma unroll
+    for (int i = 4; i < 15; ++i) p = fma(p, r, cf[i]);
+    return ldexp(p, (int)n);
+}
+
+__device__ __forceinline__ double exp_nonpos(double x) { return exp_nonpos(x, ExpLiteral()); }
+
+__device__ __forceinline__ double div_pos(double num, double den) {
+    double y = __builtin_amdgcn_rcp(den);                       // v_rcp_f64 seed, two Newton steps, one residual fix-up
+    y = fma(fma(-den, y, 1.0), y, y);
+    y = fma(fma(-den, y, 1.0), y, y);
+    const double q = num * y;
+    return fma(fma(-den, q, num), y, q);
 }
 
 // bounded phase in float64 from an fp32 time value and fp32-held tau/delay (promp / dmp rows)
-__device__ __forceinline__ double phase_f64(const DevCfg& c, float time, float tau, float delay, double* s_out) {
-    const double s = ((double)time - (double)delay) / (double)tau;
-    if (s_out) *s_out = s;
+template <class CF>
+__device__ __forceinline__ double phase_f64(const DevCfg& c, float time, float tau, float delay, const CF& cf) {
+    const double s = div_pos((double)time - (double)delay, (double)tau);
     if (c.phase_type == MPK_PHASE_LINEAR) return fmin(fmax(s, 0.0), 1.0);
-    return exp(-(double)c.alpha_phase * fmax(s, 0.0));
+    return exp_nonpos(-(double)c.alpha_phase * fmax(s, 0.0), cf);
 }
+
+
 
 // normalised RBF row: writes nb learnable columns scaled by `mul` (column zs.. of the zero-padded family)
 __device__ __forceinline__ void rbf_cols(const DevCfg& c, double x, double mul, float* out, int stride) {
@@ -131,13 +262,60 @@ __device__ __forceinline__ void rbf_cols(const DevCfg& c, double x, double mul, 
     double sum = 0.0;
     for (int k = 0; k < c.n_total; ++k) {
         const double dx = x - cen[k];
-        sum += exp(-(dx * dx * bw[k]) / 2.0);
+        sum += exp_nonpos(-(dx * dx * bw[k]) * 0.5);
     }
+    const double scale = c.n_total > 1 ? div_pos(mul, sum) : mul;
     for (int k = 0; k < c.nb; ++k) {
         const double dx = x - cen[c.zs + k];
-        double v = exp(-(dx * dx * bw[c.zs + k]) / 2.0);
-        if (c.n_total > 1) v = v / sum;
-        out[(size_t)k * stride] = (float)(v * mul);
+        out[(size_t)k * stride] = (float)(exp_nonpos(-(dx * dx * bw[c.zs + k]) * 0.5) * scale);
+    }
+}
+
+// rbf_cols into a register row of KS columns (static indices only): columns nb.. stay as the caller set them; the
+// promp "+ init_pos" column nb is set to 1 when the configuration has it.  Same arithmetic as rbf_cols.  cen / bw: the
+// caller's LDS copy of the centres / bandwidths (a load from c.tab would sit in the memory queue behind the stores).
+template <int KS, class CF>
+__device__ __forceinline__ void rbf_row(const DevCfg& c, const double* cen, const double* bw, double x, double mul,
+                                        float (&h)[KS], const CF& cf) {
+    constexpr int NE = KS + 2;
+    if (c.zs <= 2 && c.n_total <= NE) {
+        // every RBF once: the learnable columns are e[zs .. zs + nb)
+        double e[NE], sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            e[k] = 0.0;
+            if (k < c.n_total) {
+                const double dx = x - cen[k];
+                e[k] = exp_nonpos(-(dx * dx * bw[k]) * 0.5, cf);
+                sum += e[k];
+            }
+        }
+        const double scale = c.n_total > 1 ? div_pos(mul, sum) : mul;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            if (k < c.nb) {
+                const double v = c.zs == 0 ? e[k] : (c.zs == 1 ? e[k + 1] : e[k + 2]);
+                h[k] = (float)(v * scale);
+            } else if (k == c.nb && c.KT > c.nb) {
+                h[k] = 1.0f;
+            }
+        }
+        return;
+    }
+    double sum = 0.0;
+    for (int k = 0; k < c.n_total; ++k) {
+        const double dx = x - cen[k];
+        sum += exp_nonpos(-(dx * dx * bw[k]) * 0.5, cf);
+    }
+    const double scale = c.n_total > 1 ? div_pos(mul, sum) : mul;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+        if (k < c.nb) {
+            const double dx = x - cen[c.zs + k];
+            h[k] = (float)(exp_nonpos(-(dx * dx * bw[c.zs + k]) * 0.5, cf) * scale);
+        } else if (k == c.nb && c.KT > c.nb) {
+            h[k] = 1.0f;
+        }
     }
 }
 
@@ -167,7 +345,7 @@ __global__ void __launch_bounds__(256) k_build_shared(const DevCfg c, const floa
             prodmp_xi(c, bc, idx, xi);
             for (int k = 0; k < c.KT; ++k) {
                 float h, hv;
-                prodmp_col(c, bc, idx, xi, k, (double)c.tau, &h, &hv);
+                prodmp_col(c, bc, idx, xi, k, (double)c.tau, div_pos(1.0, (double)c.tau), &h, &hv);
                 A[(size_t)(0 * KP + k) * TS + t] = h;
                 A[(size_t)(1 * KP + k) * TS + t] = hv;
             }
@@ -175,7 +353,7 @@ __global__ void __launch_bounds__(256) k_build_shared(const DevCfg c, const floa
     } else if (c.mp_type == MPK_MP_PROMP) {
         for (int t = tid; t < T; t += 256) {
             const float time = c.base_times[t] + init_time;
-            const double x = phase_f64(c, time, c.tau, c.delay, nullptr);
+            const double x = phase_f64(c, time, c.tau, c.delay, ExpLiteral());
             rbf_cols(c, x, (double)c.ws, A + t, TS);
             if (c.KT > c.nb) A[(size_t)c.nb * TS + t] = 1.0f;  // zero-padded family: + init_pos
         }
@@ -193,7 +371,7 @@ __global__ void __launch_bounds__(256) k_build_shared(const DevCfg c, const floa
     } else {  // DMP: forcing rows phi*x, aux = diff of the fp32 scaled times
         for (int t = tid; t < T; t += 256) {
             const float time = c.base_times[t] + init_time;
-            const double x = phase_f64(c, time, c.tau, c.delay, nullptr);
+            const double x = phase_f64(c, time, c.tau, c.delay, ExpLiteral());
             rbf_cols(c, x, x * (double)c.ws, A + t, TS);
             if (t < T - 1) {
                 const float s0 = scaled_time(time, c.delay, c.tau);
@@ -1319,7 +1497,7 @@ __global__ void __launch_bounds__(256) k_traj_rows(const RowArgs a) {
                 prodmp_xi(c, bc, idx, xi);
                 for (int k = 0; k < KT; ++k) {
                     float h, hv;
-                    prodmp_col(c, bc, idx, xi, k, (double)tau, &h, &hv);
+                    prodmp_col(c, bc, idx, xi, k, (double)tau, div_pos(1.0, (double)tau), &h, &hv);
                     sH[t * KT + k] = h;
                     sH[(T + t) * KT + k] = hv;
                 }
@@ -1327,7 +1505,7 @@ __global__ void __launch_bounds__(256) k_traj_rows(const RowArgs a) {
         } else {
             for (int t = tid; t < T; t += nt) {
                 const float time = c.base_times[t] + it;
-                const double x = phase_f64(c, time, tau, delay, nullptr);
+                const double x = phase_f64(c, time, tau, delay, ExpLiteral());
                 rbf_cols(c, x, MP == MPK_MP_PROMP ? (double)c.ws : x * (double)c.ws, sH + t * KT, 1);
                 if (MP == MPK_MP_PROMP) {
                     if (KT > c.nb) sH[t * KT + c.nb] = 1.0f;
@@ -1394,12 +1572,394 @@ __global__ void __launch_bounds__(256) k_traj_rows(const RowArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// k_traj_phase: per-episode phase (learned tau / delay, per-episode init_time), one WAVE per episode, no workgroup
+// barriers in the episode loop (D * KS <= 256 with KS = 8 or 16 contraction columns).
+//   promp / prodmp -- lane <-> time step, 64 steps a round:
+//     1. the lane builds ITS basis row H[t][:] in registers (same device functions as k_build_shared, so a per-episode
+//        phase equal to the shared one gives identical bits); table loads for the row are issued together
+//     2. for every DoF the raw parameter column X[d][:] is broadcast from LDS and the fmaf chain runs in ascending k
+//        (the MFMA accumulation order); promp takes its forward difference from the next lane (lane 63 of a
+//        non-final round only feeds lane 62)
+//     3. the round's [64][D] block of pos / vel -- one contiguous run in HBM -- is staged in the wave's LDS slice at
+//        the run's 16-byte phase and leaves as float4 stores
+//     the next episode's header and parameter columns are fetched while the rows are built (before this episode's
+//     stores enter the in-order memory queue)
+//   dmp -- rows to LDS, forcing by lane <-> element, the Euler recurrence on D lanes, coalesced copy-out
+// ------------------------------------------------------------------------------------------------------------
+struct PhaseArgs {
+    DevCfg c;
+    const float* params;
+    const float* init_pos;
+    const float* init_vel;
+    const float* init_time;
+    float init_time_shared;
+    float* pos;
+    float* vel;
+    int32_t* flag;
+    int B, wave_floats, t_pad, x_pad, o_pad, c_pad;
+};
+
+template <int MP>
+__device__ __forceinline__ float phase_x_value(const DevCfg& c, const float* __restrict__ prm,
+                                               const float* __restrict__ ip, const float* __restrict__ iv, int dd, int k,
+                                               int ks) {
+    // RAW parameters / boundary conditions: every scale lives in the basis rows (see prodmp_col)
+    if (MP == MPK_MP_DMP) {
+        // the chain sees the weights only; goal, y0, ydot0 travel in the last three (otherwise zero) columns
+        if (k < c.nb) return prm[c.off + dd * c.Kloc + k];
+        if (k == ks - 3) return prm[c.off + dd * c.Kloc + c.nb];
+        if (k == ks - 2) return ip[dd];
+        return k == ks - 1 ? iv[dd] : 0.0f;
+    }
+    if (k >= c.KT) return 0.0f;
+    if (MP == MPK_MP_PRODMP) {
+        const int nb = c.nb;
+        if (k < nb) return c.disable_weights ? 0.0f : prm[c.off + dd * c.Kloc + k];
+        if (k == nb) return c.disable_goal ? 0.0f : prm[c.off + dd * c.Kloc + (c.disable_weights ? 0 : nb)];
+        return k == nb + 1 ? ip[dd] : iv[dd];
+    }
+    return k < c.nb ? prm[c.off + dd * c.Kloc + k] : ip[dd];
+}
+
+template <int KQ>
+__device__ __forceinline__ float row_chain(const float* __restrict__ row, const float (&x)[KQ * 4]) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < KQ; ++j) {
+        const float4 h = *reinterpret_cast<const float4*>(row + 4 * j);
+        acc = fmaf(h.x, x[4 * j + 0], acc);
+        acc = fmaf(h.y, x[4 * j + 1], acc);
+        acc = fmaf(h.z, x[4 * j + 2], acc);
+        acc = fmaf(h.w, x[4 * j + 3], acc);
+    }
+    return acc;
+}
+
+// episode header + parameter columns, one episode ahead (shared by both per-episode-phase kernels)
+template <int MP, int KS>
+struct PhaseFetch {
+    static constexpr int NX = 4;                        // D * KS <= 256 values, one per lane and round
+    float tau_raw, delay_raw, it;
+    float xv[NX];
+    __device__ __forceinline__ void issue(const PhaseArgs& a, int bb, int lane) {
+        const DevCfg& c = a.c;
+        const float* prm = a.params + (size_t)bb * c.P;
+        const float* ip = a.init_pos + (size_t)bb * c.D;
+        const float* iv = a.init_vel + (size_t)bb * c.D;
+        int o = 0;
+        tau_raw = c.tau; delay_raw = c.delay;
+        if (c.learn_tau) { tau_raw = prm[o]; ++o; }
+        if (c.learn_delay) delay_raw = prm[o];
+        it = a.init_time ? a.init_time[bb] : a.init_time_shared;
+#pragma unroll
+        for (int r = 0; r < NX; ++r) {
+            const int e = lane + 64 * r;
+            const int dd = e / KS, k = e - dd * KS;
+            xv[r] = e < c.D * KS ? phase_x_value<MP>(c, prm, ip, iv, dd, k, KS) : 0.0f;
+        }
+    }
+    __device__ __forceinline__ void park(float* sx, int n, int lane) const {
+#pragma unroll
+        for (int r = 0; r < NX; ++r) {
+            const int e = lane + 64 * r;
+            if (e < n) sx[e] = xv[r];
+        }
+    }
+};
+
+// n floats staged at so[sh ...] (sh = 16-byte phase of the destination) -> out[0 .. n): float4 body, dword head / tail
+__device__ __forceinline__ void flush_span(const float* __restrict__ so, float* __restrict__ out, int n, int sh,
+                                           int lane) {
+    float* base = out - sh;                              // 16-byte aligned
+    const int end = sh + n;
+    const int q0 = (sh + 3) >> 2, q1 = end >> 2;
+    for (int q = q0 + lane; q < q1; q += 64)
+        *reinterpret_cast<float4*>(base + 4 * q) = *reinterpret_cast<const float4*>(so + 4 * q);
+    const int head_end = 4 * q0 < end ? 4 * q0 : end;
+    if (lane < head_end - sh) base[sh + lane] = so[sh + lane];
+    const int tail = 4 * q1 > head_end ? 4 * q1 : head_end;
+    if (lane < end - tail) base[tail + lane] = so[tail + lane];
+}
+
+template <int MP, int KQ>
+__global__ void __launch_bounds__(256) k_traj_phase(const PhaseArgs a) {
+    static_assert(MP != MPK_MP_DMP, "dmp has its own kernel");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const DevCfg& c = a.c;
+    constexpr int KS = KQ * 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wpb = (int)(blockDim.x >> 6);
+    const int D = c.D, T = c.T, KT = c.KT;
+    double* sCen = reinterpret_cast<double*>(smem);     // [c_pad / 2] RBF centres | bandwidths, shared by the workgroup
+    float* sBT = smem + a.c_pad;                        // [t_pad] base times, shared by the workgroup
+    float* sX = sBT + a.t_pad + (size_t)wave * a.wave_floats;    // [2][x_pad]
+    float* sO0 = sX + 2 * a.x_pad;                      // [o_pad] pos staging: [sh + lane * D + d]
+    float* sO1 = sO0 + a.o_pad;                         // [o_pad] vel staging
+    for (int t = threadIdx.x; t < T; t += blockDim.x) sBT[t] = c.base_times[t];
+    if (MP != MPK_MP_PRODMP)
+        for (int k = threadIdx.x; k < 2 * c.n_total; k += blockDim.x) sCen[k] = c.tab[k];
+    __syncthreads();
+
+    const int stride = (int)gridDim.x * wpb;
+    int b = (int)blockIdx.x * wpb + wave;
+    PhaseFetch<MP, KS> cur;
+    if (b < a.B) {
+        cur.issue(a, b, lane);
+        cur.park(sX, D * KS, lane);
+    }
+    constexpr int kStep = MP == MPK_MP_PROMP ? 63 : 64;
+    ExpRegs ec;
+    if (MP == MPK_MP_PROMP) ec.load();
+    int slot = 0;
+    for (; b < a.B; b += stride, slot ^= 1) {
+        // np.clip(action, low, high): only tau / delay carry finite bounds (black_box_wrapper.py:104-105)
+        const float tau = c.learn_tau ? fminf(fmaxf(cur.tau_raw, c.tau_lo), c.tau_hi) : c.tau;
+        const float delay = c.learn_delay ? fminf(fmaxf(cur.delay_raw, c.delay_lo), c.delay_hi) : c.delay;
+        const float it = cur.it;
+        PhaseFetch<MP, KS> nxt;
+        nxt.tau_raw = 0.0f; nxt.delay_raw = 0.0f; nxt.it = 0.0f;
+#pragma unroll
+        for (int r = 0; r < PhaseFetch<MP, KS>::NX; ++r) nxt.xv[r] = 0.0f;
+        const bool more = b + stride < a.B;
+        if (more) nxt.issue(a, b + stride, lane);
+
+        ProdmpBC bc;
+        double pbb[KS - 2], vbb[KS - 2], sc[KS - 2], inv_tau = 0.0;
+        if (MP == MPK_MP_PRODMP) {
+            const float sb = scaled_time(it, delay, tau);
+            const int idxb = min(prodmp_index(sb, c.scaled_dt), c.n_pc - 1);
+            prodmp_bc(c, idxb, bc);
+            prodmp_boundary_rows<KS>(c, idxb, pbb, vbb, sc);
+            inv_tau = div_pos(1.0, (double)tau);
+        }
+        const float* xs = sX + slot * a.x_pad;
+        float* const out_pos = a.pos + (size_t)b * T * D;
+        float* const out_vel = a.vel + (size_t)b * T * D;
+        bool parked = false;
+        for (int r0 = 0; r0 < T; r0 += kStep) {
+            const bool final_round = T - r0 <= 64;
+            const int nout = final_round ? T - r0 : kStep;
+            const int t = r0 + lane < T ? r0 + lane : T - 1;
+            float h[KS], hv[KS], rdt = 0.0f;
+            const float time = sBT[t] + it;
+            if (MP == MPK_MP_PRODMP) {
+                const float s = scaled_time(time, delay, tau);
+                if (s > (float)c.len_factor) atomicOr(a.flag, 1);
+                const int idx = min(prodmp_index(s, c.scaled_dt), c.n_pc - 1);
+                prodmp_row<KS>(c, bc, pbb, vbb, sc, idx, (double)tau, inv_tau, h, hv);
+            } else {
+                const double x = phase_f64(c, time, tau, delay, ec);
+#pragma unroll
+                for (int k = 0; k < KS; ++k) h[k] = 0.0f;
+                rbf_row<KS>(c, sCen, sCen + c.n_total, x, (double)c.ws, h, ec);
+                const int th = t < T - 1 ? t + 1 : T - 1, tl = t < T - 1 ? t : T - 2;
+                rdt = 1.0f / ((sBT[th] + it) - (sBT[tl] + it));
+            }
+            if (!parked) {
+                // collect the prefetch (nothing but loads is outstanding here) and park it for the next turn
+                nxt.park(sX + (slot ^ 1) * a.x_pad, more ? D * KS : 0, lane);
+                parked = true;
+            }
+            float* const gp = out_pos + (size_t)r0 * D;
+            const int sh = (int)((reinterpret_cast<uintptr_t>(gp) >> 2) & 3);
+            const bool keep = lane < nout;
+            for (int d = 0; d < D; ++d) {
+                float x[KS];
+#pragma unroll
+                for (int j = 0; j < KQ; ++j) {
+                    const float4 v = *reinterpret_cast<const float4*>(xs + d * KS + 4 * j);
+                    x[4 * j + 0] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
+                }
+                float p = 0.0f, v = 0.0f;
+#pragma unroll
+                for (int k = 0; k < KS; ++k) p = fmaf(h[k], x[k], p);
+                if (MP == MPK_MP_PRODMP) {
+#pragma unroll
+                    for (int k = 0; k < KS; ++k) v = fmaf(hv[k], x[k], v);
+                } else {
+                    const float nx = __shfl_down(p, 1);
+                    v = (nx - p) * rdt;
+                    const float pv = __shfl_up(v, 1);          // last row repeats the difference before it
+                    if (r0 + lane == T - 1) v = pv;
+                }
+                if (keep) {
+                    sO0[sh + lane * D + d] = p;
+                    sO1[sh + lane * D + d] = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            flush_span(sO0, gp, nout * D, sh, lane);
+            flush_span(sO1, out_vel + (size_t)r0 * D, nout * D, sh, lane);
+            __builtin_amdgcn_wave_barrier();
+            if (final_round) break;
+        }
+        cur = nxt;
+    }
+}
+
+template <int KQ>
+__global__ void __launch_bounds__(256) k_traj_phase_dmp(const PhaseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const DevCfg& c = a.c;
+    constexpr int KS = KQ * 4;
+    constexpr int MP = MPK_MP_DMP;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wpb = (int)(blockDim.x >> 6);
+    const int D = c.D, T = c.T;
+    float* sBT = smem + a.c_pad;                        // [t_pad] base times, shared by the workgroup
+    float* sH = sBT + a.t_pad + (size_t)wave * a.wave_floats;    // [T][KS]
+    float* sA = sH + T * KS;                            // [t_pad] ds
+    float* sX = sA + a.t_pad;                           // [2][D][KS]  this episode's / the next episode's columns
+    float* sP = sX + 2 * a.x_pad;                       // [T*D] forcing -> pos
+    float* sV = sP + T * D;                             // [T*D] vel
+    const int rows_per_pass = 64 / D;
+    const int ld = lane % D, lt = lane / D;
+    const bool lane_on = lt < rows_per_pass;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) sBT[t] = c.base_times[t];
+    __syncthreads();
+
+    const int stride = (int)gridDim.x * wpb;
+    int b = (int)blockIdx.x * wpb + wave;
+    PhaseFetch<MP, KS> cur;
+    if (b < a.B) {
+        cur.issue(a, b, lane);
+        cur.park(sX, D * KS, lane);
+    }
+    int slot = 0;
+    for (; b < a.B; b += stride, slot ^= 1) {
+        const float tau = c.learn_tau ? fminf(fmaxf(cur.tau_raw, c.tau_lo), c.tau_hi) : c.tau;
+        const float delay = c.learn_delay ? fminf(fmaxf(cur.delay_raw, c.delay_lo), c.delay_hi) : c.delay;
+        const float it = cur.it;
+        PhaseFetch<MP, KS> nxt;
+        nxt.tau_raw = 0.0f; nxt.delay_raw = 0.0f; nxt.it = 0.0f;
+#pragma unroll
+        for (int r = 0; r < PhaseFetch<MP, KS>::NX; ++r) nxt.xv[r] = 0.0f;
+        const bool more = b + stride < a.B;
+        if (more) nxt.issue(a, b + stride, lane);
+        for (int t = lane; t < T; t += 64) {
+            const float time = sBT[t] + it;
+            const double x = phase_f64(c, time, tau, delay, ExpLiteral());
+            float* row = sH + t * KS;
+            for (int k = c.nb; k < KS; ++k) row[k] = 0.0f;
+            rbf_cols(c, x, x * (double)c.ws, row, 1);
+            if (t < T - 1) sA[t] = scaled_time(sBT[t + 1] + it, delay, tau) - scaled_time(time, delay, tau);
+        }
+        nxt.park(sX + (slot ^ 1) * a.x_pad, more ? D * KS : 0, lane);
+        __builtin_amdgcn_wave_barrier();
+        float x[KS];
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(sX + slot * a.x_pad + ld * KS + 4 * j);
+            x[4 * j + 0] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
+        }
+        const float dmp_g = x[KS - 3], dmp_y = x[KS - 2], dmp_yd = x[KS - 1];
+        x[KS - 3] = 0.0f; x[KS - 2] = 0.0f; x[KS - 1] = 0.0f;
+        const size_t ob = (size_t)b * T * D;
+        for (int t0 = 0; t0 < T; t0 += rows_per_pass) {
+            const int t = t0 + lt;
+            const bool on = lane_on && t < T;
+            const int tc = on ? t : 0;
+            const float f = row_chain<KQ>(sH + tc * KS, x);
+            if (on) sP[tc * D + ld] = f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < D) {
+            const int dd = lane;               // lanes 0..D-1 have ld == lane
+            float y = dmp_y;
+            float z = dmp_yd * tau;
+            const float g = dmp_g * c.gs;
+            for (int t = 0; t < T; ++t) {
+                const float f = sP[t * D + dd];
+                sP[t * D + dd] = y;
+                sV[t * D + dd] = z / tau;
+                if (t < T - 1) {
+                    const float ds = sA[t];
+                    const float t1 = g - y;
+                    const float t2 = c.dmp_beta * t1;
+                    const float t3 = t2 - z;
+                    const float t4 = c.dmp_alpha * t3;
+                    const float acc = t4 + f;
+                    z = z + ds * acc;
+                    y = y + ds * z;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int e = lane; e < T * D; e += 64) {
+            a.pos[ob + e] = sP[e];
+            a.vel[ob + e] = sV[e];
+        }
+        __builtin_amdgcn_wave_barrier();   // this episode's LDS reads are issued before the next one's writes
+        cur = nxt;
+    }
+}
+
+static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu, void* stream,
+                             const char** kernel_name) {
+    PhaseArgs pa = base;
+    const bool dmp = c.mp_type == MPK_MP_DMP;
+    const int need = c.KT + (dmp ? 3 : 0);   // dmp: + goal, y0, ydot0 columns
+    if (need > 16 || c.D > 64) return MPK_ENOTIMPL;
+    const int KQ = need <= 4 && c.mp_type == MPK_MP_PROMP ? 1 : (need <= 8 ? 2 : 4), KS = KQ * 4;
+    if (c.D * KS > 256) return MPK_ENOTIMPL;
+    if (c.mp_type == MPK_MP_PRODMP && (!c.tab_rows || c.row_stride != 2 * KS)) return MPK_ENOTIMPL;
+    pa.t_pad = (c.T + 3) / 4 * 4;
+    pa.x_pad = c.D * KS;
+    pa.o_pad = (64 * c.D + 4 + 3) / 4 * 4;
+    if (dmp) pa.wave_floats = c.T * KS + pa.t_pad + 2 * pa.x_pad + (2 * c.T * c.D + 3) / 4 * 4;
+    else pa.wave_floats = 2 * pa.x_pad + 2 * pa.o_pad;
+    pa.c_pad = c.mp_type == MPK_MP_PRODMP ? 0 : (4 * c.n_total + 3) / 4 * 4;
+    const size_t wave_bytes = (size_t)pa.wave_floats * sizeof(float);
+    const size_t shared_bytes = (size_t)(pa.t_pad + pa.c_pad) * sizeof(float);
+    if (wave_bytes + shared_bytes > 160 * 1024) return MPK_ENOTIMPL;
+    int wpb = (int)((64 * 1024 - shared_bytes) / wave_bytes);
+    wpb = wpb > 4 ? 4 : (wpb < 1 ? 1 : wpb);
+    const size_t lds = wave_bytes * wpb + shared_bytes;
+    int per_cu = (int)(160 * 1024 / lds);
+    per_cu = per_cu > 32 / wpb ? 32 / wpb : per_cu;
+    long blocks = ((long)pa.B + wpb - 1) / wpb;
+    if (blocks > (long)num_cu * per_cu) blocks = (long)num_cu * per_cu;
+    auto go = [&](auto kern) -> int {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return MPK_EHIP; }
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * wpb), lds, (hipStream_t)stream, pa);
+        MPK_LAUNCH_CHECK();
+        return MPK_OK;
+    };
+    switch (c.mp_type) {
+        case MPK_MP_PRODMP:
+            *kernel_name = "k_traj_phase<prodmp>";
+            return KQ == 2 ? go(k_traj_phase<MPK_MP_PRODMP, 2>) : go(k_traj_phase<MPK_MP_PRODMP, 4>);
+        case MPK_MP_PROMP:
+            *kernel_name = "k_traj_phase<promp>";
+            if (KQ == 1) return go(k_traj_phase<MPK_MP_PROMP, 1>);
+            return KQ == 2 ? go(k_traj_phase<MPK_MP_PROMP, 2>) : go(k_traj_phase<MPK_MP_PROMP, 4>);
+        default:
+            *kernel_name = "k_traj_phase<dmp>";
+            return KQ == 2 ? go(k_traj_phase_dmp<2>) : go(k_traj_phase_dmp<4>);
+    }
+}
+
 int launch_traj_rows(const DevCfg& c, const float* params, const float* init_pos, const float* init_vel,
                      const float* init_time, float init_time_shared, float* pos, float* vel, int32_t* range_flag,
                      int B, int num_cu, void* stream, const char** kernel_name) {
     if (c.mp_type == MPK_MP_PROMP && c.T < 2) {
         set_error("promp needs at least two time steps for the finite-difference velocity");
         return MPK_EINVAL;
+    }
+    // wave-per-episode kernel whenever the shape fits it (MPK_PHASE=0: the workgroup-per-episode kernel below)
+    bool wave_kernel = true;
+    if (const char* e = getenv("MPK_PHASE")) wave_kernel = atoi(e) != 0;
+    if (wave_kernel) {
+        PhaseArgs pa{c, params, init_pos, init_vel, init_time, init_time_shared, pos, vel, range_flag, B, 0, 0, 0, 0, 0};
+        const int rc = launch_traj_phase(c, pa, num_cu, stream, kernel_name);
+        if (rc != MPK_ENOTIMPL) return rc;
     }
     const int nrow = c.mp_type == MPK_MP_PRODMP ? 2 : 1;
     const size_t floats = (size_t)c.D * c.KT + (size_t)nrow * c.T * c.KT + (size_t)c.T * c.D +

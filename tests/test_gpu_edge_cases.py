@@ -56,7 +56,7 @@ def test_every_dof_class(mp, D, mapping, monkeypatch):
 def test_every_contraction_length(mp, nb):
     """KM = 1..4 k-chunks of the MFMA"""
     eng = check(cfg_for(mp, 3, nb, 40), 9, expect_kernel="k_traj_", seed=nb)
-    assert not eng.last_kernel().startswith("k_traj_rows")
+    assert not eng.last_kernel().startswith(("k_traj_rows", "k_traj_phase"))
 
 
 @pytest.mark.parametrize("mp", ["prodmp", "promp", "dmp"])
@@ -75,9 +75,9 @@ def test_every_horizon_class(mp, T, D):
 
 @pytest.mark.parametrize("mp", ["prodmp", "promp", "dmp"])
 def test_limits_fall_back_to_the_per_episode_kernel(mp):
-    check(cfg_for(mp, 17, 4, 20), 6, expect_kernel="k_traj_rows")          # D > 16
+    check(cfg_for(mp, 17, 4, 20), 6, expect_kernel="k_traj_phase")         # D > 16: wave per episode
     check(cfg_for(mp, 2, 20, 20), 6, expect_kernel="k_traj_rows")          # more than 16 basis columns
-    check(cfg_for(mp, 40, 3, 24), 3, expect_kernel="k_traj_rows")
+    check(cfg_for(mp, 40, 9, 24), 3, expect_kernel="k_traj_rows")          # D * KS > 256
 
 
 @pytest.mark.parametrize("flags", [dict(disable_goal=True), dict(disable_weights=True), dict(relative_goal=True),
@@ -93,7 +93,7 @@ def test_prodmp_flags(flags, init_time):
     params, ip, iv = inputs(pc, bc, tc, 11, seed=3)
     p0, v0 = eng.trajectory(params, ip, iv, init_time)
     p1, v1 = eng.trajectory(params, ip, iv, torch.full((11,), init_time, device="cuda"))
-    assert eng.last_kernel().startswith("k_traj_rows")
+    assert eng.last_kernel().startswith("k_traj_phase")
     assert torch.equal(p0, p1) and torch.equal(v0, v1)
 
 
@@ -239,3 +239,38 @@ def test_dmp_quad_and_stream_kernels_agree_bitwise_and_match_oracle(quad, D, T, 
     monkeypatch.setenv("MPK_QUAD", "0")
     p0, v0 = eng.trajectory(params, ip, iv, 0.0)
     assert torch.equal(p0, p1) and torch.equal(v0, v1)
+
+
+@pytest.mark.parametrize("mp", ["prodmp", "promp", "dmp"])
+@pytest.mark.parametrize("D,nb,T", [(1, 3, 30), (3, 9, 41), (7, 5, 100), (9, 4, 33), (16, 12, 20), (17, 4, 20),
+                                    (32, 3, 12), (64, 1, 7)])
+def test_per_episode_kernels_agree_bitwise(mp, D, nb, T, monkeypatch):
+    """wave-per-episode (k_traj_phase) and workgroup-per-episode (k_traj_rows) kernels, per-episode init_time: same
+    bits from both, and equal to the shared-phase kernels when every episode carries the same init_time"""
+    if mp == "prodmp" and nb + 3 > 16:
+        pytest.skip("more than 16 contraction columns")
+    pc, bc, tc, dt, dur = cfg_for(mp, D, nb, T)
+    eng = make_engine(pc, bc, tc, dt, dur)
+    B = 37
+    params, ip, iv = inputs(pc, bc, tc, B, seed=D * 100 + nb)
+    it = torch.full((B,), 0.25 if mp == "prodmp" else 0.0, dtype=torch.float32, device="cuda")
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MPK_PHASE", mode)
+        p, v = eng.trajectory(params, ip, iv, it)
+        torch.cuda.synchronize()
+        outs[mode] = (p.clone(), v.clone(), eng.last_kernel())
+    KT = nb + {"prodmp": 3, "promp": 1, "dmp": 3}[mp]      # dmp: goal, y0, ydot0 ride in three extra columns
+    KS = 4 if (mp == "promp" and KT <= 4) else (8 if KT <= 8 else 16)
+    wave_ok = KT <= 16 and D <= 64 and D * KS <= 256
+    assert outs["0"][2].startswith("k_traj_rows")
+    if wave_ok:
+        assert outs["1"][2].startswith("k_traj_phase"), outs["1"][2]
+    assert torch.equal(outs["1"][0], outs["0"][0]) and torch.equal(outs["1"][1], outs["0"][1])
+    if D <= 16:
+        p0, v0 = eng.trajectory(params, ip, iv, float(it[0]))
+        assert not eng.last_kernel().startswith(("k_traj_rows", "k_traj_phase"))
+        assert torch.equal(p0, outs["1"][0]) and torch.equal(v0, outs["1"][1])
+    rp, rv = O.get_trajectory(pc, bc, tc, params, dur, dt, float(it[0]), ip, iv, dtype=np.float64)
+    close(outs["1"][0].cpu().numpy(), rp, "pos")
+    close(outs["1"][1].cpu().numpy(), rv, "vel", atol=fd_atol(rp, dt) if mp == "promp" else 0.0)

@@ -146,7 +146,7 @@ def test_per_episode_phase_matches_oracle(name, B):
     params, ip, iv = inputs(pc, bc, tc, B, seed=B + 1)
     pos, vel = eng.trajectory(params, ip, iv, 0.0)
     torch.cuda.synchronize()
-    assert eng.last_kernel().startswith("k_traj_rows")
+    assert eng.last_kernel().startswith("k_traj_phase")
     rp, rv = O.get_trajectory(pc, bc, tc, params, duration, dt, 0.0, ip, iv, dtype=np.float64)
     close(pos.cpu().numpy(), rp, f"{name} pos")
     close(vel.cpu().numpy(), rv, f"{name} vel", atol=fd_atol(rp, dt) if "promp" in name else 0.0)
@@ -162,6 +162,6 @@ def test_per_episode_init_time_equals_shared_path_bitwise():
     it = torch.full((B,), 0.5, dtype=torch.float32, device="cuda")
     p1, v1 = eng.trajectory(params, ip, iv, it)
     torch.cuda.synchronize()
-    assert eng.last_kernel().startswith("k_traj_rows")
+    assert eng.last_kernel().startswith("k_traj_phase")
     assert torch.equal(p0, p1)
     assert torch.equal(v0, v1)

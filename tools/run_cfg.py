@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Run one BASELINE configuration N times (for rocprofv3):  python tools/run_cfg.py <cfg2|cfg2act|cfg2closed|cfg3|cfg4|cfg5> B N"""
+"""Run one BASELINE configuration N times (for rocprofv3):  python tools/run_cfg.py <cfg2|cfg2act|cfg2closed|cfg3|cfg4|cfg5|cfg5tau|cfg2tau> B N"""
 import os
 import sys
 
@@ -24,6 +24,13 @@ KW = {
                  weights_scale=0.3, goal_scale=0.3, auto_scale_basis=True, disable_goal=True),
     "cfg5": dict(mp_type="promp", phase_type="linear", basis_type="zero_rbf", num_dof=7, num_basis=3,
                  num_basis_zero_start=1, num_basis_zero_goal=1, dt=0.008, duration=2.8, tau=2.8),
+    # per-episode phase (learned tau / delay): the k_traj_phase kernels
+    "cfg5tau": dict(mp_type="promp", phase_type="linear", basis_type="zero_rbf", num_dof=7, num_basis=3,
+                    num_basis_zero_start=1, num_basis_zero_goal=1, dt=0.008, duration=2.8, tau=2.8, learn_tau=True,
+                    learn_delay=True, tau_bound=(0.5, 2.8), delay_bound=(0.05, 0.15)),
+    "cfg2tau": dict(mp_type="prodmp", phase_type="exp", basis_type="prodmp", num_dof=7, num_basis=5, dt=0.02,
+                    duration=2.0, tau=1.5, alpha_phase=3.0, basis_bandwidth_factor=2.0, basis_alpha=10.0,
+                    learn_tau=True, tau_bound=(0.5, 2.0)),
 }
 
 
@@ -34,7 +41,11 @@ def main():
     eng = TrajectoryEngine(device=0, **KW[base])
     T, D, P = eng.num_steps, eng.num_dof, eng.num_params
     g = torch.Generator().manual_seed(0)
-    params = torch.randn((B, P), generator=g).cuda()
+    params = torch.randn((B, P), generator=g)
+    if base.endswith("tau"):
+        n_ph = P - D * ((P - 0) // D)
+        params[:, :n_ph] = torch.rand((B, n_ph), generator=g) * 0.5 + 0.8
+    params = params.cuda()
     ip = (torch.rand((B, D), generator=g) * 2 - 1).cuda()
     iv = torch.zeros((B, D), device="cuda")
     gains = (TT_P, TT_D) if base == "cfg5" else (PG, DG)

@@ -138,46 +138,57 @@ __device__ __forceinline__ void prodmp_load_row(const DevCfg& c, int idx, double
     for (int kk = 0; kk < KS - 2; ++kk) { pb[kk] = v[4 + kk]; vb[kk] = v[4 + (KS - 2) + kk]; }
 }
 
+// per-episode boundary block in the wave's LDS slice: [a b c d | pos_basis_b[KS-2] | vel_basis_b[KS-2] | scale[KS-2]]
 template <int KS>
-__device__ __forceinline__ void prodmp_boundary_rows(const DevCfg& c, int idxb, double (&pbb)[KS - 2],
-                                                     double (&vbb)[KS - 2], double (&sc)[KS - 2]) {
+__device__ __forceinline__ void prodmp_boundary_rows(const DevCfg& c, int idxb, double* sB, int lane) {
     const int N = c.n_pc, K = c.nb + 1;
-    double y[4];
+    double y[4], pbb[KS - 2], vbb[KS - 2];
     prodmp_load_row<KS>(c, idxb, y, pbb, vbb);
     const double* S = c.tab + 4 * (size_t)N + 2 * (size_t)N * K;   // weights_goal_scale
+    const double det = y[0] * y[3] - y[1] * y[2];                  // as prodmp_bc
+    if (lane == 0) {
+        sB[0] = y[3] / det; sB[1] = y[2] / det; sB[2] = y[0] / det; sB[3] = y[1] / det;
 #pragma unroll
-    for (int kk = 0; kk < KS - 2; ++kk) sc[kk] = S[kk < K ? kk : K - 1];
+        for (int kk = 0; kk < KS - 2; ++kk) {
+            sB[4 + kk] = pbb[kk];
+            sB[4 + (KS - 2) + kk] = vbb[kk];
+            sB[4 + 2 * (KS - 2) + kk] = S[kk < K ? kk : K - 1];
+        }
+    }
 }
 
 template <int KS>
-__device__ __forceinline__ void prodmp_row(const DevCfg& c, const ProdmpBC& bc, const double (&pbb)[KS - 2],
-                                           const double (&vbb)[KS - 2], const double (&sc)[KS - 2], int idx,
-                                           double tau, double inv_tau, float (&h)[KS], float (&hv)[KS]) {
+__device__ __forceinline__ void prodmp_row(const DevCfg& c, const double* sB, int idx, double tau, double inv_tau,
+                                           float (&h)[KS], float (&hv)[KS]) {
     const int K = c.nb + 1;
-    double y[4], hp[KS - 2], hvp[KS - 2];
+    constexpr int KB = KS - 2;
+    double y[4], hp[KB], hvp[KB];
     prodmp_load_row<KS>(c, idx, y, hp, hvp);
     const double y1 = y[0], y2 = y[1], dy1 = y[2], dy2 = y[3];
+    const double ba = sB[0], bb = sB[1], bcc = sB[2], bd = sB[3];
     double xi[4];
-    xi[0] = bc.a * y1 - bc.b * y2;
-    xi[1] = bc.c * y2 - bc.d * y1;
-    xi[2] = bc.a * dy1 - bc.b * dy2;
-    xi[3] = bc.c * dy2 - bc.d * dy1;
+    xi[0] = ba * y1 - bb * y2;
+    xi[1] = bcc * y2 - bd * y1;
+    xi[2] = ba * dy1 - bb * dy2;
+    xi[3] = bcc * dy2 - bd * dy1;
 #pragma unroll
-    for (int kk = 0; kk < KS - 2; ++kk) {
-        hp[kk] = hp[kk] - (xi[0] * pbb[kk] + xi[1] * vbb[kk]);
-        hvp[kk] = hvp[kk] - (xi[2] * pbb[kk] + xi[3] * vbb[kk]);
+    for (int kk = 0; kk < KB; ++kk) {
+        const double pbb = sB[4 + kk], vbb = sB[4 + KB + kk];
+        hp[kk] = hp[kk] - (xi[0] * pbb + xi[1] * vbb);
+        hvp[kk] = hvp[kk] - (xi[2] * pbb + xi[3] * vbb);
     }
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
         double p = 0.0, v = 0.0;
         if (k < K) {
-            if (k < KS - 2) {
+            if (k < KB) {
                 const bool off = k < c.nb ? c.disable_weights != 0 : c.disable_goal != 0;
-                if (!off) { p = hp[k] * sc[k]; v = hvp[k] * sc[k]; }
+                const double sc = sB[4 + 2 * KB + (k < KB ? k : 0)];
+                if (!off) { p = hp[k] * sc; v = hvp[k] * sc; }
             }
         } else if (k == K) {
             p = xi[0]; v = xi[2];
-            if (c.relative_goal && k >= 1 && k - 1 < KS - 2) { p += hp[k - 1]; v += hvp[k - 1]; }
+            if (c.relative_goal && k >= 1 && k - 1 < KB) { p += hp[k - 1]; v += hvp[k - 1]; }
         } else if (k == K + 1) {
             p = xi[1] * tau; v = xi[3] * tau;
         }
@@ -1697,6 +1708,7 @@ __global__ void __launch_bounds__(256) k_traj_phase(const PhaseArgs a) {
     float* sX = sBT + a.t_pad + (size_t)wave * a.wave_floats;    // [2][x_pad]
     float* sO0 = sX + 2 * a.x_pad;                      // [o_pad] pos staging: [sh + lane * D + d]
     float* sO1 = sO0 + a.o_pad;                         // [o_pad] vel staging
+    double* sB = reinterpret_cast<double*>(sO1 + a.o_pad);   // prodmp: [4 + 3 * (KS - 2)] boundary block
     for (int t = threadIdx.x; t < T; t += blockDim.x) sBT[t] = c.base_times[t];
     if (MP != MPK_MP_PRODMP)
         for (int k = threadIdx.x; k < 2 * c.n_total; k += blockDim.x) sCen[k] = c.tab[k];
@@ -1725,14 +1737,13 @@ __global__ void __launch_bounds__(256) k_traj_phase(const PhaseArgs a) {
         const bool more = b + stride < a.B;
         if (more) nxt.issue(a, b + stride, lane);
 
-        ProdmpBC bc;
-        double pbb[KS - 2], vbb[KS - 2], sc[KS - 2], inv_tau = 0.0;
+        double inv_tau = 0.0;
         if (MP == MPK_MP_PRODMP) {
             const float sb = scaled_time(it, delay, tau);
             const int idxb = min(prodmp_index(sb, c.scaled_dt), c.n_pc - 1);
-            prodmp_bc(c, idxb, bc);
-            prodmp_boundary_rows<KS>(c, idxb, pbb, vbb, sc);
+            prodmp_boundary_rows<KS>(c, idxb, sB, lane);
             inv_tau = div_pos(1.0, (double)tau);
+            __builtin_amdgcn_wave_barrier();
         }
         const float* xs = sX + slot * a.x_pad;
         float* const out_pos = a.pos + (size_t)b * T * D;
@@ -1748,7 +1759,7 @@ __global__ void __launch_bounds__(256) k_traj_phase(const PhaseArgs a) {
                 const float s = scaled_time(time, delay, tau);
                 if (s > (float)c.len_factor) atomicOr(a.flag, 1);
                 const int idx = min(prodmp_index(s, c.scaled_dt), c.n_pc - 1);
-                prodmp_row<KS>(c, bc, pbb, vbb, sc, idx, (double)tau, inv_tau, h, hv);
+                prodmp_row<KS>(c, sB, idx, (double)tau, inv_tau, h, hv);
             } else {
                 const double x = phase_f64(c, time, tau, delay, ec);
 #pragma unroll
@@ -1910,7 +1921,7 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
     pa.x_pad = c.D * KS;
     pa.o_pad = (64 * c.D + 4 + 3) / 4 * 4;
     if (dmp) pa.wave_floats = c.T * KS + pa.t_pad + 2 * pa.x_pad + (2 * c.T * c.D + 3) / 4 * 4;
-    else pa.wave_floats = 2 * pa.x_pad + 2 * pa.o_pad;
+    else pa.wave_floats = 2 * pa.x_pad + 2 * pa.o_pad + (c.mp_type == MPK_MP_PRODMP ? (2 * (4 + 3 * (KS - 2)) + 3) / 4 * 4 : 0);
     pa.c_pad = c.mp_type == MPK_MP_PRODMP ? 0 : (4 * c.n_total + 3) / 4 * 4;
     const size_t wave_bytes = (size_t)pa.wave_floats * sizeof(float);
     const size_t shared_bytes = (size_t)(pa.t_pad + pa.c_pad) * sizeof(float);

@@ -30,12 +30,16 @@ class BatchedBlackBox:
                  plant: Optional[str] = "double_integrator", replanning_every: Optional[int] = None,
                  max_planning_times: Union[int, float] = math.inf, condition_on_desired: bool = False,
                  max_episode_steps: Optional[int] = None, pos_limits: Optional[Sequence] = None,
-                 check_tau_delay: bool = False, device=None):
+                 check_tau_delay: bool = False, reward: Optional[str] = None, steps_before_reward: int = 199,
+                 device=None):
         """
         trajectory_generator / tracking_controller: the objects the factories return (``get_trajectory_generator``,
         ``get_controller``).  ``replanning_every = n`` is the schedule ``lambda pos, vel, obs, action, t: t % n == 0``
         (e.g. envs/mujoco/box_pushing/mp_wrapper.py:89).  ``pos_limits = (low[D], high[D])`` enables the batched
-        validity check (envs/mujoco/table_tennis/table_tennis_env.py:303-309).
+        validity check (envs/mujoco/table_tennis/table_tennis_env.py:303-309).  ``reward = "simple_reacher"`` adds the
+        per-step reward of the reference's SimpleReacher (envs/classic_control/simple_reacher/simple_reacher.py:56-72)
+        to the device rollout: ``step`` then also returns ``step_rewards [B, T]`` and their sum ``rewards [B]``
+        (the default ``reward_aggregation = np.sum`` of black_box_wrapper.py:24); goals are given to ``reset``.
         """
         self.traj_gen = trajectory_generator
         self.tracking_controller = tracking_controller
@@ -54,6 +58,13 @@ class BatchedBlackBox:
         self.plant = plant
         self.pos_limits = pos_limits
         self.check_tau_delay = bool(check_tau_delay)
+        if reward not in (None, "simple_reacher"):
+            raise ValueError(f"unknown device reward {reward!r}")
+        if reward is not None and plant != "double_integrator":
+            raise ValueError("the simple_reacher reward needs plant='double_integrator'")
+        self.reward = reward
+        self.steps_before_reward = int(steps_before_reward)
+        self.goal = None
         ctype = getattr(tracking_controller, "device_type", None)
         self.spec = None
         if plant is not None:
@@ -80,8 +91,13 @@ class BatchedBlackBox:
         self._host_plans = 0
 
     # ---- episode control ---------------------------------------------------------------------------------------------
-    def reset(self, init_pos=None, init_vel=None):
-        """start B new episodes from plant state (init_pos, init_vel) [B, D] (default zeros)"""
+    def reset(self, init_pos=None, init_vel=None, goal=None):
+        """start B new episodes from plant state (init_pos, init_vel) [B, D] (default zeros); goal [B, 2] for the
+        simple_reacher reward"""
+        if self.reward is not None:
+            if goal is None:
+                raise ValueError("reward='simple_reacher' needs goal [B, 2] at reset")
+            self.goal = torch.as_tensor(goal, dtype=torch.float64, device=self.device).expand(self.B, 2).contiguous()
         self.traj_steps.zero_(); self.plan_steps.zero_(); self.done.zero_()
         z = torch.zeros((self.B, self.D), dtype=torch.float64, device=self.device)
         self.q = z.clone() if init_pos is None else torch.as_tensor(init_pos, dtype=torch.float64,
@@ -146,7 +162,7 @@ class BatchedBlackBox:
         """one launch for plan + execute: shared phase, double-integrator plant, no validity gate, MFMA-capable shape"""
         cfg = self.engine.config
         return (self.spec is not None and self.plant == "double_integrator" and self.pos_limits is None
-                and self._n_phase == 0 and self.engine.mp_type != "dmp" and self.D <= 16
+                and self.reward is None and self._n_phase == 0 and self.engine.mp_type != "dmp" and self.D <= 16
                 and (not self.do_replanning or self._lockstep is not None)
                 and (cfg.num_basis + 3 if self.engine.mp_type == "prodmp" else cfg.num_basis + 1) <= 16)
 
@@ -207,6 +223,11 @@ class BatchedBlackBox:
         mpt = self.max_planning_times if math.isfinite(self.max_planning_times) else 2 ** 31 - 1
         seg = self.engine.replan_advance(self.traj_steps, self.plan_steps, self.done, self.every, int(mpt),
                                          self.horizon)
-        if self.spec is not None:
+        if self.reward is not None:
+            act, rew = self.engine.reacher_rollout(self.spec, pos, vel, self.q, self.qd, self.goal, n_steps=seg,
+                                                   step0=self.traj_steps - seg,
+                                                   steps_before_reward=self.steps_before_reward)
+            out.update(step_actions=act, step_rewards=rew, rewards=rew.sum(dim=1))
+        elif self.spec is not None:
             out["step_actions"] = self.engine.pd_rollout(self.spec, pos, vel, self.q, self.qd, n_steps=seg)
         return self._finish(out, seg, valid, was_done)

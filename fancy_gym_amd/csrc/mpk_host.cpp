@@ -609,6 +609,27 @@ int mpk_pd_rollout(mpk_handle hh, const mpk_rollout_cfg* rc, const float* des_po
     return launch_pd_rollout(rd, h->dev.D, des_pos, des_vel, q, qd, n_steps, actions, B, T, stream);
 }
 
+int mpk_reacher_rollout(mpk_handle hh, const mpk_rollout_cfg* rc, const float* des_pos, const float* des_vel,
+                        double* q, double* qd, const int32_t* n_steps, const int32_t* step0, const double* goal,
+                        int32_t steps_before_reward, float* actions, double* rewards, int32_t B, int32_t T,
+                        void* stream) {
+    if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (B < 0 || T < 0) { set_error("B and T must be >= 0"); return MPK_EINVAL; }
+    RolloutDev rd;
+    int r = fill_rollout(h, rc, &rd);
+    if (r != MPK_OK) return r;
+    if (rd.plant_type != MPK_PLANT_DOUBLE_INTEGRATOR) {
+        set_error("the reacher reward needs the torque double-integrator plant");
+        return MPK_EINVAL;
+    }
+    if (B == 0 || T == 0 || h->dev.D == 0) return MPK_OK;
+    if (!des_pos || !des_vel || !q || !qd || !goal || !rewards) { set_error("NULL buffer"); return MPK_EINVAL; }
+    MPK_HIP(hipSetDevice(h->cfg.device));
+    return launch_reacher_rollout(rd, h->dev.D, des_pos, des_vel, q, qd, n_steps, step0, goal, steps_before_reward,
+                                  actions, rewards, B, T, stream);
+}
+
 int mpk_replan_advance(mpk_handle hh, int32_t* traj_steps, int32_t* plan_steps, int32_t* seg_len, uint8_t* done,
                        int32_t every, int32_t max_planning_times, int32_t horizon, int32_t T, int32_t B,
                        void* stream) {

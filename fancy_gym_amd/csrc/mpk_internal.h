@@ -76,6 +76,9 @@ int launch_traj_rows(const DevCfg& c, const float* params, const float* init_pos
                      int B, int num_cu, void* stream, const char** kernel_name);
 int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const float* des_vel, double* q,
                       double* qd, const int32_t* n_steps, float* actions, int B, int T, void* stream);
+int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos, const float* des_vel, double* q,
+                           double* qd, const int32_t* n_steps, const int32_t* step0, const double* goal,
+                           int steps_before_reward, float* actions, double* rewards, int B, int T, void* stream);
 int launch_replan_advance(int32_t* traj_steps, int32_t* plan_steps, int32_t* seg_len, uint8_t* done, int every,
                           int max_planning_times, int horizon, int T, int B, void* stream);
 int launch_validity(const float* pos, const float* params, int P, int D, const double* lo, const double* hi,

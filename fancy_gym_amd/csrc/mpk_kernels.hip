@@ -2135,6 +2135,86 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// k_reacher_rollout: k_pd_rollout + SimpleReacherEnv's per-step reward (simple_reacher.py:56-72): one lane per
+// episode (the reward couples the DoFs: cumulative joint angles -> end effector, base_reacher.py:97-104), plant
+// state in an LDS column per lane, float64 without FMA contraction
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_reacher_rollout(const RolloutDev rc, const int D,
+                                                        const float* __restrict__ des_pos,
+                                                        const float* __restrict__ des_vel, double* __restrict__ Q,
+                                                        double* __restrict__ QD, const int32_t* __restrict__ n_steps,
+                                                        const int32_t* __restrict__ step0,
+                                                        const double* __restrict__ goal, const int steps_before_reward,
+                                                        float* __restrict__ actions, double* __restrict__ rewards,
+                                                        const int B, const int T) {
+    extern __shared__ __attribute__((aligned(16))) double sst[];   // [2][D][64]
+    const int lane = threadIdx.x;
+    const int b = (int)blockIdx.x * 64 + lane;
+    if (b >= B) return;
+    double* sq = sst + lane;
+    double* sqd = sst + (size_t)D * 64 + lane;
+    for (int d = 0; d < D; ++d) {
+        sq[d * 64] = Q[(size_t)b * D + d];
+        sqd[d * 64] = QD[(size_t)b * D + d];
+    }
+    int n = n_steps ? n_steps[b] : T;
+    n = n < T ? n : T;
+    const int s0 = step0 ? step0[b] : 0;
+    const double gx = goal[2 * (size_t)b], gy = goal[2 * (size_t)b + 1];
+    const double dt = rc.dt;
+    for (int t = 0; t < T; ++t) {
+        const size_t row = ((size_t)b * T + t) * D;
+        if (t >= n) {
+            if (actions) for (int d = 0; d < D; ++d) actions[row + d] = 0.0f;
+            rewards[(size_t)b * T + t] = 0.0;
+            continue;
+        }
+        double ang = 0.0, ex = 0.0, ey = 0.0, ctrl = 0.0;
+        for (int d = 0; d < D; ++d) {
+            const double dp = (double)des_pos[row + d], dv = (double)des_vel[row + d];
+            double q = sq[d * 64], qd = sqd[d * 64];
+            const double pg = rc.pg[d], dg = rc.dg[d];   // d is wave-uniform: scalar loads from the kernarg segment
+            double u;
+            if (rc.controller_type == MPK_CTRL_MOTOR) u = pg * (dp - q) + dg * (dv - qd);
+            else if (rc.controller_type == MPK_CTRL_POSITION) u = dp;
+            else u = dv;
+            u = fmin(fmax(u, rc.lo[d]), rc.hi[d]);
+            qd = qd + dt * u;                  // base_reacher_torque.py:25-26
+            q = q + dt * qd;
+            sq[d * 64] = q; sqd[d * 64] = qd;
+            if (actions) actions[row + d] = (float)u;
+            ang = d == 0 ? q : ang + q;        // np.cumsum(joint_angles)
+            const double cx = cos(ang), sy = sin(ang);
+            ex = d == 0 ? cx : ex + cx;        // unit link lengths (base_reacher.py:19), cumsum over the links
+            ey = d == 0 ? sy : ey + sy;
+            ctrl = d == 0 ? u * u : ctrl + u * u;
+        }
+        double rdist = 0.0;
+        if (s0 + t >= steps_before_reward) {
+            const double dx = ex - gx, dy = ey - gy;
+            rdist = 0.0 - sqrt(dx * dx + dy * dy);
+        }
+        rewards[(size_t)b * T + t] = rdist - ctrl;
+    }
+    for (int d = 0; d < D; ++d) {
+        Q[(size_t)b * D + d] = sq[d * 64];
+        QD[(size_t)b * D + d] = sqd[d * 64];
+    }
+}
+
+int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
+                           const float* des_vel, double* q, double* qd, const int32_t* n_steps, const int32_t* step0,
+                           const double* goal, int steps_before_reward, float* actions, double* rewards, int B, int T,
+                           void* stream) {
+    const size_t lds = (size_t)2 * D * 64 * sizeof(double);
+    if (lds > 64 * 1024) { set_error("reacher rollout supports at most 64 links"); return MPK_EINVAL; }
+    hipLaunchKernelGGL(k_reacher_rollout, dim3((B + 63) / 64), dim3(64), lds, (hipStream_t)stream, rc, D, des_pos,
+                       des_vel, q, qd, n_steps, step0, goal, steps_before_reward, actions, rewards, B, T);
+    MPK_LAUNCH_CHECK();
+    return MPK_OK;
+}
+
 int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const float* des_vel, double* q, double* qd,
                       const int32_t* n_steps, float* actions, int B, int T, void* stream) {
     auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };

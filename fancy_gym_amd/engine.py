@@ -242,6 +242,31 @@ class TrajectoryEngine:
                                             self._stream()))
         return act
 
+    def reacher_rollout(self, spec: RolloutSpec, des_pos: torch.Tensor, des_vel: torch.Tensor, q: torch.Tensor,
+                        qd: torch.Tensor, goal: torch.Tensor, n_steps: Optional[torch.Tensor] = None,
+                        step0: Optional[torch.Tensor] = None, steps_before_reward: int = 199,
+                        want_actions: bool = True):
+        """
+        pd_rollout + SimpleReacherEnv's per-step reward (simple_reacher.py:56-72) on the torque double integrator:
+        returns (actions float32 [B, T, D] or None, rewards float64 [B, T]); q, qd are updated in place.
+        """
+        B, T, D = des_pos.shape
+        assert des_pos.dtype == torch.float32 and des_vel.dtype == torch.float32
+        assert q.dtype == torch.float64 and qd.dtype == torch.float64 and q.is_contiguous() and qd.is_contiguous()
+        des_pos, des_vel = des_pos.contiguous(), des_vel.contiguous()
+        goal = torch.as_tensor(goal, dtype=torch.float64, device=self.device).expand(B, 2).contiguous()
+        act = torch.empty((B, T, D), dtype=torch.float32, device=self.device) if want_actions else None
+        rew = torch.empty((B, T), dtype=torch.float64, device=self.device)
+        if n_steps is not None:
+            n_steps = n_steps.to(device=self.device, dtype=torch.int32).contiguous()
+        if step0 is not None:
+            step0 = step0.to(device=self.device, dtype=torch.int32).contiguous()
+        _lib.check(self._lib.mpk_reacher_rollout(self._h, C.byref(spec.c), des_pos.data_ptr(), des_vel.data_ptr(),
+                                                 q.data_ptr(), qd.data_ptr(), _dptr(n_steps), _dptr(step0),
+                                                 goal.data_ptr(), int(steps_before_reward), _dptr(act),
+                                                 rew.data_ptr(), B, T, self._stream()))
+        return act, rew
+
     def replan_advance(self, traj_steps: torch.Tensor, plan_steps: torch.Tensor, done: torch.Tensor, every: int,
                        max_planning_times: int, horizon: int) -> torch.Tensor:
         """Integer replanning bookkeeping on device; returns seg_len int32 [B] and updates the state tensors in place."""

@@ -192,6 +192,25 @@ int mpk_pd_rollout(mpk_handle h, const mpk_rollout_cfg* rc, const float* des_pos
                    int32_t B, int32_t T, void* stream);
 
 /*
+ * mpk_pd_rollout for the reference's SimpleReacher family, reward included: the step loop of BlackBoxWrapper.step
+ * (black_box_wrapper.py:175-203) around BaseReacherTorqueEnv.step (envs/classic_control/base_reacher/
+ * base_reacher_torque.py:20-37) with SimpleReacherEnv._get_reward (envs/classic_control/simple_reacher/
+ * simple_reacher.py:56-72) and the end effector of BaseReacherEnv._update_joints (base_reacher/base_reacher.py:97-104,
+ * unit link lengths :19).  Per executed step t < n_steps[b], with a the clipped controller output:
+ *   qd += dt*a ; q += dt*qd ; ee = sum_links (cos, sin)(cumsum(q))
+ *   rewards[b,t] = -(step0[b] + t >= steps_before_reward ? ||ee - goal[b]|| : 0) - sum_d a_d^2
+ *   goal     dev double [B, 2]      target of each episode
+ *   step0    dev int32  [B] or NULL env step counter at the start of this call (NULL = 0); the reference starts paying
+ *                                   the distance term at step 199 (simple_reacher.py:30)
+ *   rewards  dev double [B, T]      (0 for steps >= n_steps[b]);  actions dev float [B, T, D] or NULL
+ * q, qd, n_steps as mpk_pd_rollout.  rc->plant_type must be MPK_PLANT_DOUBLE_INTEGRATOR.  float64, no FMA contraction.
+ */
+int mpk_reacher_rollout(mpk_handle h, const mpk_rollout_cfg* rc, const float* des_pos, const float* des_vel,
+                        double* q, double* qd, const int32_t* n_steps, const int32_t* step0, const double* goal,
+                        int32_t steps_before_reward, float* actions, double* rewards, int32_t B, int32_t T,
+                        void* stream);
+
+/*
  * Integer replanning bookkeeping of BlackBoxWrapper.step for the schedule `t % every == 0`
  * (envs/mujoco/box_pushing/mp_wrapper.py:89; black_box_wrapper.py:174,197,206):
  *   plan_steps[b] += 1

@@ -603,6 +603,60 @@ def rollout(des_pos: Array, des_vel: Array, controller: str, p_gains, d_gains, a
     return actions, q, qd
 
 
+def reacher_rollout(des_pos: Array, des_vel: Array, controller: str, p_gains, d_gains, act_low, act_high, dt: float,
+                    pos0: Array, vel0: Array, goal: Array, n_steps: Optional[Array] = None,
+                    step0: Optional[Array] = None, steps_before_reward: int = 199):
+    """
+    `rollout` on the torque double integrator plus the reward of the reference's SimpleReacher:
+      plant   BaseReacherTorqueEnv.step, envs/classic_control/base_reacher/base_reacher_torque.py:20-37
+              (vel += dt*a; pos += dt*vel; then reward; then the step counter advances)
+      joints  BaseReacherEnv._update_joints, base_reacher/base_reacher.py:97-104: angles = cumsum(q),
+              end effector = cumsum over the links of link_length * (cos, sin), link lengths 1 (:19)
+      reward  SimpleReacherEnv._get_reward, simple_reacher/simple_reacher.py:56-72:
+              -(||ee - goal|| if steps >= steps_before_reward else 0) - sum(action ** 2), steps_before_reward = 199 (:30)
+    `action` is what BlackBoxWrapper passes to env.step: the clipped controller output (black_box_wrapper.py:176-181).
+    goal [B, 2]; step0 [B] = env step counter when this call starts.  float64.
+    Returns actions [B, T, D], rewards [B, T], final pos, final vel.
+    """
+    des_pos = np.asarray(des_pos); des_vel = np.asarray(des_vel)
+    B, T, D = des_pos.shape
+    q = np.array(np.broadcast_to(np.asarray(pos0, np.float64), (B, D)))
+    qd = np.array(np.broadcast_to(np.asarray(vel0, np.float64), (B, D)))
+    goal = np.array(np.broadcast_to(np.asarray(goal, np.float64), (B, 2)))
+    lo = np.asarray(act_low, np.float64); hi = np.asarray(act_high, np.float64)
+    pg = np.asarray(p_gains, np.float64); dg = np.asarray(d_gains, np.float64)
+    actions = np.zeros((B, T, D), np.float64)
+    rewards = np.zeros((B, T), np.float64)
+    n = np.full(B, T) if n_steps is None else np.asarray(n_steps)
+    s0 = np.zeros(B, np.int64) if step0 is None else np.asarray(step0, np.int64)
+    for t in range(T):
+        live = t < n
+        if controller == "motor":
+            a = pg * (des_pos[:, t] - q) + dg * (des_vel[:, t] - qd)
+        elif controller == "position":
+            a = des_pos[:, t].astype(np.float64)
+        elif controller == "velocity":
+            a = des_vel[:, t].astype(np.float64)
+        else:
+            raise ValueError(controller)
+        a = np.clip(a, lo, hi)
+        qd_n = qd + dt * a
+        q_n = q + dt * qd_n
+        angles = np.cumsum(q_n, axis=1)
+        ee = np.stack([np.cumsum(np.cos(angles), axis=1)[:, -1], np.cumsum(np.sin(angles), axis=1)[:, -1]], axis=1)
+        diff = ee - goal
+        dist = np.sqrt(diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1])
+        ctrl = np.zeros(B)
+        for d in range(D):                      # (action ** 2).sum() of a short vector: left to right
+            ctrl = a[:, d] * a[:, d] if d == 0 else ctrl + a[:, d] * a[:, d]
+        r = np.where(s0 + t >= steps_before_reward, 0.0 - dist, 0.0) - ctrl
+        actions[:, t] = np.where(live[:, None], a, 0.0)
+        rewards[:, t] = np.where(live, r, 0.0)
+        qd = np.where(live[:, None], qd_n, qd)
+        q = np.where(live[:, None], q_n, q)
+    return actions, rewards, q, qd
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # replanning bookkeeping (black_box_wrapper.py:107-108,174,197-206) -- INTEGER state, bit-exact part
 # ----------------------------------------------------------------------------------------------------------------------

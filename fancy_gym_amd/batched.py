@@ -89,6 +89,7 @@ class BatchedBlackBox:
         self._frozen_phase = None
         self._lockstep = 0          # traj_steps of every live episode while the schedule keeps them in lockstep
         self._host_plans = 0
+        self._const_flags = None    # (all-True, all-False) [B], shared by every fused step's result
 
     # ---- episode control ---------------------------------------------------------------------------------------------
     def reset(self, init_pos=None, init_vel=None, goal=None):
@@ -167,10 +168,11 @@ class BatchedBlackBox:
                 and (cfg.num_basis + 3 if self.engine.mp_type == "prodmp" else cfg.num_basis + 1) <= 16)
 
     def _step_fused(self, params) -> Dict[str, torch.Tensor]:
+        """plan + execute in one launch; four device operations per plan (integer state, trajectory + rollout, condition
+        gather, the bool view of `done`) -- at a few thousand episodes the step is bound by their launch cost"""
         params = torch.as_tensor(params, dtype=torch.float32, device=self.device)
         if params.shape != (self.B, self.engine.num_params):
             raise ValueError(f"params must be [{self.B}, {self.engine.num_params}], got {tuple(params.shape)}")
-        was_done = self.done.bool()
         cond_pos = self.condition_pos if self.condition_pos is not None else self.q.float()
         cond_vel = self.condition_vel if self.condition_vel is not None else self.qd.float()
         init_time = float(self._lockstep * self.dt) if self.do_replanning else 0.0
@@ -179,8 +181,18 @@ class BatchedBlackBox:
                                          self.horizon)
         pos, vel, act = self.engine.trajectory_rollout(params, cond_pos, cond_vel, self.spec, self.q, self.qd,
                                                        n_steps=seg, init_time=init_time)
-        valid = torch.ones(self.B, dtype=torch.bool, device=self.device)
-        return self._finish(dict(params=params, des_pos=pos, des_vel=vel, step_actions=act), seg, valid, was_done)
+        if self.condition_on_desired:
+            self.condition_pos, self.condition_vel = self.engine.condition_gather(pos, vel, seg)
+        if self.do_replanning:
+            self._lockstep += self._host_segment()      # no validity gate here: the host mirrors the integer rule
+        done = self.done.bool()
+        if self._const_flags is None:
+            self._const_flags = (torch.ones(self.B, dtype=torch.bool, device=self.device),
+                                 torch.zeros(self.B, dtype=torch.bool, device=self.device))
+        valid, never = self._const_flags
+        # nothing can invalidate a plan on this path: terminated stays False, truncated is `done`
+        return dict(params=params, des_pos=pos, des_vel=vel, step_actions=act, valid=valid, trajectory_length=seg,
+                    done=done, terminated=never, truncated=done, current_pos=self.q, current_vel=self.qd)
 
     def _finish(self, out, seg, valid, was_done) -> Dict[str, torch.Tensor]:
         pos, vel = out["des_pos"], out["des_vel"]
@@ -231,3 +243,53 @@ class BatchedBlackBox:
         elif self.spec is not None:
             out["step_actions"] = self.engine.pd_rollout(self.spec, pos, vel, self.q, self.qd, n_steps=seg)
         return self._finish(out, seg, valid, was_done)
+
+
+    # ---- whole episodes as one hipGraph ----------------------------------------------------------------------------------
+    def capture_episode(self, n_plans: int, with_goal: bool = False) -> "EpisodeGraph":
+        """
+        Capture ``reset`` + ``n_plans`` calls of ``step`` into one hipGraph.  At B of a few thousand a plan costs ~100 us of
+        Python / ctypes / allocator work around ~20 us of kernels; a replay pays one graph launch for the whole
+        episode.  Requirements: a device-resident plant (``plant != None``) and a schedule the host can mirror without
+        reading device state (no validity gate), so that capture never synchronises.
+
+        Write the inputs into the returned object's static buffers (``init_pos``, ``init_vel``, ``params[k]``, ``goal``),
+        call ``replay()``, read ``outs[k]`` (the dicts ``step`` returned during capture; their tensors are rewritten by
+        every replay).
+        """
+        if self.spec is None or self.pos_limits is not None:
+            raise ValueError("capture_episode needs a device plant and no validity gate (both would need the host)")
+        return EpisodeGraph(self, int(n_plans), with_goal)
+
+
+class EpisodeGraph:
+    def __init__(self, bb: BatchedBlackBox, n_plans: int, with_goal: bool):
+        self.bb = bb
+        dev = bb.device
+        self.init_pos = torch.zeros((bb.B, bb.D), dtype=torch.float64, device=dev)
+        self.init_vel = torch.zeros((bb.B, bb.D), dtype=torch.float64, device=dev)
+        self.goal = torch.zeros((bb.B, 2), dtype=torch.float64, device=dev) if (with_goal or bb.reward) else None
+        self.params = [torch.zeros((bb.B, bb.engine.num_params), dtype=torch.float32, device=dev)
+                       for _ in range(n_plans)]
+        self.outs = []
+
+        def episode():
+            kw = {"goal": self.goal} if self.goal is not None else {}
+            bb.reset(self.init_pos, self.init_vel, **kw)
+            return [bb.step(p) for p in self.params]
+
+        # one eager pass on a side stream first (allocator warm-up, lazy initialisation), then the capture
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            episode()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.outs = episode()
+        torch.cuda.synchronize(dev)
+
+    def replay(self):
+        self.graph.replay()
+        return self.outs

@@ -172,6 +172,12 @@ struct CacheEntry {
     int T = 0;
     SharedTables st;
     uint64_t stamp = 0;
+    // pinned: a captured graph reads this slot, it is never evicted (mpk_unpin_tables / mpk_set_duration release it).
+    // deferred: the table was built while a stream capture was active -- the builder kernel is a node of THAT graph, so
+    // the content exists only after a replay (and every replay rewrites it); it serves launches of that capture only.
+    // A table built eagerly and later used by a capture is pinned but not deferred: its content is already there.
+    bool pinned = false, deferred = false;
+    unsigned long long capture_id = 0;
 };
 
 struct Handle {
@@ -188,7 +194,7 @@ struct Handle {
     int32_t* d_flag = nullptr;   // range-error flag written by kernels
     int32_t* d_idx = nullptr;    // scratch for mpk_prodmp_indices
     int idx_cap = 0;
-    static constexpr int kCache = 8;
+    static constexpr int kCache = 16;
     CacheEntry cache[kCache];
     uint64_t stamp = 0;
     const char* last_kernel = "";
@@ -284,7 +290,7 @@ static int upload_times(Handle* h) {
     if (h->d_times) { (void)hipFree(h->d_times); h->d_times = nullptr; }
     MPK_HIP(hipMalloc((void**)&h->d_times, sizeof(float) * T));
     MPK_HIP(hipMemcpy(h->d_times, h->times.data(), sizeof(float) * T, hipMemcpyHostToDevice));
-    for (auto& e : h->cache) e.valid = false;
+    for (auto& e : h->cache) { e.valid = false; e.pinned = false; e.deferred = false; }
     return MPK_OK;
 }
 
@@ -326,7 +332,7 @@ static int prealloc_cache(Handle* h) {
             MPK_HIP(hipMalloc((void**)&e.st.aux, (size_t)TS * sizeof(float)));
             e.st.TS = TS; e.st.n_out = n_out;
         }
-        e.valid = false;
+        e.valid = false; e.pinned = false; e.deferred = false;
     }
     return MPK_OK;
 }
@@ -337,13 +343,29 @@ static int get_shared(Handle* h, float init_time, void* stream, SharedTables* ou
     std::memcpy(&key, &init_time, 4);
     const int T = h->dev.T;
     ++h->stamp;
-    for (auto& e : h->cache) {
-        if (e.valid && e.key == key && e.T == T) { e.stamp = h->stamp; *out = e.st; return MPK_OK; }
+    bool capturing = false;
+    unsigned long long cap_id = 0;
+    {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamGetCaptureInfo((hipStream_t)stream, &cs, &cap_id) == hipSuccess) capturing = cs == hipStreamCaptureStatusActive;
+        else (void)hipGetLastError();
     }
-    CacheEntry* victim = &h->cache[0];
     for (auto& e : h->cache) {
+        if (!e.valid || e.key != key || e.T != T) continue;
+        if (e.deferred && !(capturing && e.capture_id == cap_id)) continue;
+        if (capturing) e.pinned = true;
+        e.stamp = h->stamp; *out = e.st;
+        return MPK_OK;
+    }
+    CacheEntry* victim = nullptr;
+    for (auto& e : h->cache) {
+        if (e.pinned) continue;
         if (!e.valid) { victim = &e; break; }
-        if (e.stamp < victim->stamp) victim = &e;
+        if (!victim || e.stamp < victim->stamp) victim = &e;
+    }
+    if (!victim) {
+        set_error("every shared-table slot is pinned by a captured graph: release them with mpk_unpin_tables");
+        return MPK_EINVAL;
     }
     // ProDMP range check on the host, with the same fp32 recipe the device uses (reference: RuntimeError)
     if (h->cfg.mp_type == MPK_MP_PRODMP) {
@@ -370,6 +392,7 @@ static int get_shared(Handle* h, float init_time, void* stream, SharedTables* ou
     int rc = launch_build_shared(h->dev, init_time, victim->st, nullptr, h->d_flag, stream);
     if (rc != MPK_OK) return rc;
     victim->valid = true; victim->key = key; victim->T = T; victim->stamp = h->stamp;
+    victim->pinned = capturing; victim->deferred = capturing; victim->capture_id = cap_id;
     *out = victim->st;
     return MPK_OK;
 }
@@ -528,6 +551,14 @@ int mpk_set_duration(mpk_handle hh, double duration, double dt) {
     return prealloc_cache(h);
 }
 
+int mpk_unpin_tables(mpk_handle hh) {
+    if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    for (auto& e : h->cache)
+        if (e.pinned) { e.pinned = false; if (e.deferred) e.valid = false; e.deferred = false; }
+    return MPK_OK;
+}
+
 int mpk_times(mpk_handle hh, float* times) {
     if (!hh || !times) { set_error("NULL argument"); return MPK_EINVAL; }
     Handle* h = reinterpret_cast<Handle*>(hh);
@@ -641,6 +672,17 @@ int mpk_replan_advance(mpk_handle hh, int32_t* traj_steps, int32_t* plan_steps, 
     MPK_HIP(hipSetDevice(h->cfg.device));
     return launch_replan_advance(traj_steps, plan_steps, seg_len, done, every, max_planning_times, horizon, T, B,
                                  stream);
+}
+
+int mpk_condition_gather(mpk_handle hh, const float* pos, const float* vel, const int32_t* seg_len, float* cond_pos,
+                         float* cond_vel, int32_t B, int32_t T, void* stream) {
+    if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (B < 0 || T < 1) { set_error("B must be >= 0 and T >= 1"); return MPK_EINVAL; }
+    if (B == 0 || h->dev.D == 0) return MPK_OK;
+    if (!pos || !vel || !seg_len || !cond_pos || !cond_vel) { set_error("NULL buffer"); return MPK_EINVAL; }
+    MPK_HIP(hipSetDevice(h->cfg.device));
+    return launch_condition_gather(pos, vel, seg_len, cond_pos, cond_vel, B, T, h->dev.D, stream);
 }
 
 int mpk_traj_validity(mpk_handle hh, const float* pos, const float* params, const double* pos_low,

@@ -76,6 +76,8 @@ int launch_traj_rows(const DevCfg& c, const float* params, const float* init_pos
                      int B, int num_cu, void* stream, const char** kernel_name);
 int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const float* des_vel, double* q,
                       double* qd, const int32_t* n_steps, float* actions, int B, int T, void* stream);
+int launch_condition_gather(const float* pos, const float* vel, const int32_t* seg_len, float* cond_pos, float* cond_vel,
+                            int B, int T, int D, void* stream);
 int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos, const float* des_vel, double* q,
                            double* qd, const int32_t* n_steps, const int32_t* step0, const double* goal,
                            int steps_before_reward, float* actions, double* rewards, int B, int T, void* stream);

@@ -2281,6 +2281,29 @@ int launch_replan_advance(int32_t* traj_steps, int32_t* plan_steps, int32_t* seg
     return MPK_OK;
 }
 
+// condition_on_desired (black_box_wrapper.py:199-201): the desired state at the last executed step of this plan
+__global__ void __launch_bounds__(256) k_condition_gather(const float* __restrict__ pos, const float* __restrict__ vel,
+                                                          const int32_t* __restrict__ seg_len,
+                                                          float* __restrict__ cond_pos, float* __restrict__ cond_vel,
+                                                          const int B, const int T, const int D) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)B * D) return;
+    const int b = (int)(e / D), d = (int)(e - (long)b * D);
+    int t = seg_len[b] - 1;
+    t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+    const size_t src = ((size_t)b * T + t) * D + d;
+    cond_pos[e] = pos[src];
+    cond_vel[e] = vel[src];
+}
+
+int launch_condition_gather(const float* pos, const float* vel, const int32_t* seg_len, float* cond_pos, float* cond_vel,
+                            int B, int T, int D, void* stream) {
+    hipLaunchKernelGGL(k_condition_gather, dim3((unsigned)(((long)B * D + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       pos, vel, seg_len, cond_pos, cond_vel, B, T, D);
+    MPK_LAUNCH_CHECK();
+    return MPK_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // validity reduction: one wave per episode
 // ------------------------------------------------------------------------------------------------------------

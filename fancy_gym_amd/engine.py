@@ -267,6 +267,20 @@ class TrajectoryEngine:
                                                  rew.data_ptr(), B, T, self._stream()))
         return act, rew
 
+    def condition_gather(self, pos: torch.Tensor, vel: torch.Tensor, seg_len: torch.Tensor,
+                         out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+        """desired (pos, vel) [B, D] at the last executed step of each episode (condition_on_desired)"""
+        B, T, D = pos.shape
+        cp, cv = out if out is not None else (torch.empty((B, D), dtype=torch.float32, device=self.device),
+                                              torch.empty((B, D), dtype=torch.float32, device=self.device))
+        _lib.check(self._lib.mpk_condition_gather(self._h, pos.data_ptr(), vel.data_ptr(), seg_len.data_ptr(),
+                                                  cp.data_ptr(), cv.data_ptr(), B, T, self._stream()))
+        return cp, cv
+
+    def unpin_tables(self):
+        """release the basis-table slots pinned by captured graphs (mpk.h: mpk_unpin_tables); those graphs are dead then"""
+        _lib.check(self._lib.mpk_unpin_tables(self._h))
+
     def replan_advance(self, traj_steps: torch.Tensor, plan_steps: torch.Tensor, done: torch.Tensor, every: int,
                        max_planning_times: int, horizon: int) -> torch.Tensor:
         """Integer replanning bookkeeping on device; returns seg_len int32 [B] and updates the state tensors in place."""

@@ -135,6 +135,17 @@ int mpk_params_bounds(mpk_handle h, float* low, float* high);
 /* Replaces traj_gen.set_duration(duration, dt) (black_box_wrapper.py:115). Changes T. */
 int mpk_set_duration(mpk_handle h, double duration, double dt);
 
+/*
+ * Stream capture (hipGraph): every trajectory call only enqueues kernels, so a sequence of calls may be captured and
+ * replayed.  The per-init_time basis table a shared-phase call needs lives in one of 16 slots per handle; a slot a
+ * captured call uses is pinned (never evicted).  If the table already exists (an eager call with the same init_time ran
+ * before -- finish it, e.g. synchronise, before replaying) the graph just reads it; otherwise its builder becomes a node
+ * of the captured graph and the slot serves that graph only.  mpk_unpin_tables releases all pinned slots once the graphs
+ * that used them are destroyed; mpk_set_duration does so implicitly (graphs captured for the previous time grid must
+ * not be replayed).
+ */
+int mpk_unpin_tables(mpk_handle h);
+
 /* Copies the fp32 time grid linspace(0,duration,T+1)[1:] (without init_time) to host float [T]. */
 int mpk_times(mpk_handle h, float* times);
 
@@ -223,6 +234,15 @@ int mpk_reacher_rollout(mpk_handle h, const mpk_rollout_cfg* rc, const float* de
 int mpk_replan_advance(mpk_handle h, int32_t* traj_steps, int32_t* plan_steps, int32_t* seg_len, uint8_t* done,
                        int32_t every, int32_t max_planning_times, int32_t horizon, int32_t T,
                        int32_t B, void* stream);
+
+/*
+ * condition_on_desired (black_box_wrapper.py:199-201: the next plan starts from the DESIRED state at the last executed
+ * step instead of the measured one):  cond_pos[b] = pos[b, seg_len[b]-1], cond_vel[b] = vel[b, seg_len[b]-1]
+ * (index clamped to [0, T-1]; episodes with seg_len 0 get row 0).  pos, vel dev float [B,T,D]; seg_len dev int32 [B]
+ * (mpk_replan_advance); cond_pos, cond_vel dev float [B,D].
+ */
+int mpk_condition_gather(mpk_handle h, const float* pos, const float* vel, const int32_t* seg_len, float* cond_pos,
+                         float* cond_vel, int32_t B, int32_t T, void* stream);
 
 /*
  * Batched validity check (raw_interface_wrapper.py:55-72; envs/mujoco/table_tennis/table_tennis_env.py:303-309):

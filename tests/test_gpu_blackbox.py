@@ -643,3 +643,49 @@ def test_batched_simple_reacher_equals_single_episode_wrapper(mp_type):
         assert np.all(np.abs(out["step_rewards"][b].cpu().numpy() - sr) <= 1e-12 * (1 + np.abs(sr)))
         assert abs(float(out["rewards"][b]) - returns[b]) <= 1e-10 * (1 + abs(returns[b]))
         assert np.any(sr[199:] != sr[198])       # the distance term switched on at step 199
+
+
+# ---- whole episodes as one hipGraph ------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("replan", [True, False])
+def test_captured_episode_replays_bit_identically(replan):
+    """reset + every plan of an episode captured once, replayed with new inputs: same bits as the eager calls; the basis
+    tables of the four init_times are rebuilt by the graph itself (pinned slots), eager calls in between do not disturb"""
+    B = 96
+    kw = dict(plant="double_integrator")
+    if replan:
+        kw.update(replanning_every=25, max_planning_times=4, condition_on_desired=True)
+    n_plans = 4 if replan else 1
+    bb = _batched(CFG4 if replan else CFG2, B, **kw)
+    P = bb.engine.num_params
+    ep = bb.capture_episode(n_plans)
+    ref = _batched(CFG4 if replan else CFG2, B, **kw)
+    rng = np.random.default_rng(3)
+    for trial in range(3):
+        q0 = rng.uniform(-1, 1, (B, 7))
+        plans = [rng.standard_normal((B, P)).astype(np.float32) for _ in range(n_plans)]
+        ep.init_pos.copy_(torch.tensor(q0)); ep.init_vel.zero_()
+        for k in range(n_plans):
+            ep.params[k].copy_(torch.tensor(plans[k]))
+        outs = ep.replay()
+        torch.cuda.synchronize()
+        got = [{k: v.clone() for k, v in o.items() if torch.is_tensor(v)} for o in outs]
+        ref.reset(q0)
+        for k in range(n_plans):
+            want = ref.step(plans[k])
+            for key in ("des_pos", "des_vel", "step_actions", "trajectory_length", "done"):
+                assert torch.equal(got[k][key], want[key]), (trial, k, key)
+        # current_pos / current_vel are the plant state tensors themselves: compare after the last plan
+        assert torch.equal(got[-1]["current_pos"], ref.q) and torch.equal(got[-1]["current_vel"], ref.qd)
+        assert bool(got[-1]["done"].all())
+        # an eager call with yet another init_time between replays must not corrupt the graph's tables
+        ref.engine.trajectory(torch.tensor(plans[0], device="cuda"), torch.zeros((B, 7), device="cuda"),
+                              torch.zeros((B, 7), device="cuda"), 0.02 * (trial + 1))
+    bb.engine.unpin_tables()
+
+
+@pytest.mark.gpu
+def test_capture_episode_requirements():
+    bb = _batched(CFG2, 8, plant=None)
+    with pytest.raises(ValueError):
+        bb.capture_episode(1)

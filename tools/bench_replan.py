@@ -3,7 +3,7 @@
 cfg4 end to end on one GPU: fancy_ProDMP/BoxPushingDenseReplan-style episodes (4 plans x 25 steps of a 100-step horizon,
 schedule t % 25 == 0, condition_on_desired, P = 35) for B episodes with the reference's torque double integrator as the
 GPU-resident plant, through BatchedBlackBox (integer state kernel + one fused plan/execute launch per plan).
-    python tools/bench_replan.py [B] [episodes]
+    python tools/bench_replan.py [B] [episodes] [--graph]
 """
 import os
 import sys
@@ -23,8 +23,9 @@ DG = 0.01 * np.array([10., 10., 10., 10., 6., 5., 3.])
 
 
 def main():
-    B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
-    episodes = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+    pos_args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    B = int(pos_args[0]) if len(pos_args) > 0 else 8192
+    episodes = int(pos_args[1]) if len(pos_args) > 1 else 50
     torch.cuda.set_device(0)
     pg = get_phase_generator("exp", tau=1.5, alpha_phase=3)
     bg = get_basis_generator("prodmp", pg, num_basis=5, alpha=10, basis_bandwidth_factor=3)
@@ -43,6 +44,14 @@ def main():
             out = bb.step(plans[k])
         return out
 
+    if "--graph" in sys.argv:
+        ep = bb.capture_episode(4)
+        ep.init_pos.copy_(q0)
+        for k in range(4):
+            ep.params[k].copy_(plans[k])
+
+        def episode():     # noqa: F811 - one graph launch per episode batch
+            return ep.replay()[-1]
     for _ in range(3):
         out = episode()
     assert bool(out["done"].all()) and int(bb.traj_steps[0]) == 100
@@ -53,7 +62,8 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / episodes
     print(f"cfg4 replanning episodes, B = {B}: {dt * 1e3:.3f} ms per batch of episodes (4 plans) = {B / dt:.3e} episodes/s"
-          f" = {4 * B / dt:.3e} plans/s; kernel of the last plan: {bb.engine.last_kernel()}")
+          f" = {4 * B / dt:.3e} plans/s; kernel of the last plan: {bb.engine.last_kernel()}"
+          f"{' (one hipGraph per episode batch)' if '--graph' in sys.argv else ''}")
 
 
 if __name__ == "__main__":

@@ -274,3 +274,12 @@ def test_per_episode_kernels_agree_bitwise(mp, D, nb, T, monkeypatch):
     rp, rv = O.get_trajectory(pc, bc, tc, params, dur, dt, float(it[0]), ip, iv, dtype=np.float64)
     close(outs["1"][0].cpu().numpy(), rp, "pos")
     close(outs["1"][1].cpu().numpy(), rv, "vel", atol=fd_atol(rp, dt) if mp == "promp" else 0.0)
+
+
+def test_batches_beyond_2_31_output_elements():
+    """every kernel family with more than 2^31 output elements per array (64-bit addressing); ~60 GB of HBM"""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80 * 2 ** 30:
+        pytest.skip("needs 80 GB of free device memory")
+    from tools import big_batch_check
+    big_batch_check.main()

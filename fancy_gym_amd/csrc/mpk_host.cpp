@@ -188,8 +188,9 @@ struct Handle {
     double duration = 0.0, dt = 0.0;
     std::vector<float> times;
     double* d_tab = nullptr;
-    size_t rows_off = 0;           // ProDMP: offset (doubles) of the row-interleaved table copy inside d_tab
-    int row_stride = 0;            // doubles per row of that copy (0: none)
+    std::vector<float> rows32;     // ProDMP: fp32 row table of the per-episode-phase kernel (see mpk_create)
+    float* d_rows32 = nullptr;
+    int rows32_stride = 0;
     float* d_times = nullptr;
     int32_t* d_flag = nullptr;   // range-error flag written by kernels
     int32_t* d_idx = nullptr;    // scratch for mpk_prodmp_indices
@@ -278,8 +279,8 @@ static void fill_devcfg(Handle* h) {
     d.ws = (float)c.weights_scale; d.gs = (float)c.goal_scale;
     d.dmp_alpha = (float)c.dmp_alpha; d.dmp_beta = (float)(c.dmp_alpha / 4.0);
     d.tab = h->d_tab;
-    d.tab_rows = h->row_stride ? h->d_tab + h->rows_off : nullptr;
-    d.row_stride = h->row_stride;
+    d.rows32 = h->d_rows32;
+    d.rows32_stride = h->rows32_stride;
     d.base_times = h->d_times;
 }
 
@@ -302,6 +303,7 @@ static void free_handle(Handle* h) {
         if (e.st.aux) (void)hipFree(e.st.aux);
     }
     if (h->d_tab) (void)hipFree(h->d_tab);
+    if (h->d_rows32) (void)hipFree(h->d_rows32);
     if (h->d_times) (void)hipFree(h->d_times);
     if (h->d_flag) (void)hipFree(h->d_flag);
     if (h->d_idx) (void)hipFree(h->d_idx);
@@ -471,25 +473,21 @@ int mpk_create(const mpk_config* cfg, mpk_handle* out) {
             if (cfg->auto_scale_basis) sc = (float)t.scale[k] * sc;
             packed.push_back((double)sc);
         }
-        // second copy for the per-episode-phase kernel, one table index per 128 / 256-byte row so a lane fetches its
-        // whole row from one or two cache lines: [y1 y2 dy1 dy2 | pos_basis[0..KS-2) | vel_basis[0..KS-2)], KS = 8 or
-        // 16 contraction columns, columns past the last one repeat it
+        // fp32 row table for the per-episode-phase kernel, one table index per 64 / 128-byte row:
+        // [Psi_0 .. Psi_nb, y1, y2, 0.. | dPsi_0 .. dPsi_nb, dy1, dy2, 0..], KS = 8 or 16 columns each
         const int K = cfg->num_basis + 1;
         if (K + 2 <= 16) {
-            const int KS = K + 2 <= 8 ? 8 : 16, KB = KS - 2, RS = 2 * KS;
-            while (packed.size() % 32) packed.push_back(0.0);
-            h->rows_off = packed.size();
-            h->row_stride = RS;
-            packed.resize(packed.size() + (size_t)t.n_pc * RS, 0.0);
-            double* rows = packed.data() + h->rows_off;
+            const int KS = K + 2 <= 8 ? 8 : 16;
+            h->rows32.assign((size_t)t.n_pc * 2 * KS, 0.0f);
+            h->rows32_stride = 2 * KS;
             for (int i = 0; i < t.n_pc; ++i) {
-                double* r = rows + (size_t)i * RS;
-                r[0] = t.y1[i]; r[1] = t.y2[i]; r[2] = t.dy1[i]; r[3] = t.dy2[i];
-                for (int kk = 0; kk < KB; ++kk) {
-                    const int kc = kk < K ? kk : K - 1;
-                    r[4 + kk] = t.pos_basis[(size_t)i * K + kc];
-                    r[4 + KB + kk] = t.vel_basis[(size_t)i * K + kc];
+                float* r = h->rows32.data() + (size_t)i * 2 * KS;
+                for (int kk = 0; kk < K; ++kk) {
+                    r[kk] = (float)t.pos_basis[(size_t)i * K + kk];
+                    r[KS + kk] = (float)t.vel_basis[(size_t)i * K + kk];
                 }
+                r[K] = (float)t.y1[i]; r[K + 1] = (float)t.y2[i];
+                r[KS + K] = (float)t.dy1[i]; r[KS + K + 1] = (float)t.dy2[i];
             }
         }
     } else {
@@ -500,6 +498,10 @@ int mpk_create(const mpk_config* cfg, mpk_handle* out) {
     auto fail = [&](int code) { free_handle(h); return code; };
     if (hipMalloc((void**)&h->d_tab, packed.size() * sizeof(double)) != hipSuccess) { set_error("hipMalloc(tables) failed"); return fail(MPK_EHIP); }
     if (hipMemcpy(h->d_tab, packed.data(), packed.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { set_error("hipMemcpy(tables) failed"); return fail(MPK_EHIP); }
+    if (!h->rows32.empty()) {
+        if (hipMalloc((void**)&h->d_rows32, h->rows32.size() * sizeof(float)) != hipSuccess) { set_error("hipMalloc(row table) failed"); return fail(MPK_EHIP); }
+        if (hipMemcpy(h->d_rows32, h->rows32.data(), h->rows32.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { set_error("hipMemcpy(row table) failed"); return fail(MPK_EHIP); }
+    }
     if (hipMalloc((void**)&h->d_flag, sizeof(int32_t)) != hipSuccess) { set_error("hipMalloc(flag) failed"); return fail(MPK_EHIP); }
     if (hipMemset(h->d_flag, 0, sizeof(int32_t)) != hipSuccess) { set_error("hipMemset(flag) failed"); return fail(MPK_EHIP); }
     rc = upload_times(h);

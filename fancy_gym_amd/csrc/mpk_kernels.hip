@@ -116,87 +116,6 @@ __device__ __forceinline__ void prodmp_col(const DevCfg& c, const ProdmpBC& bc, 
     *hv = (float)(v * inv_tau);
 }
 
-// The same columns for one time step, all KS at once, from the row-interleaved table copy (prodmp_col walks k with a
-// round trip to memory per column and a cache line per value).  pbb / vbb / sc: basis rows at the boundary index and the
-// scale row, loaded once per episode by prodmp_boundary_rows.  Expression for expression the arithmetic of prodmp_col:
-// identical bits.
-template <int KS>
-__device__ __forceinline__ void prodmp_load_row(const DevCfg& c, int idx, double (&y)[4], double (&pb)[KS - 2],
-                                                double (&vb)[KS - 2]) {
-    // one row of the interleaved table copy: 2 * KS doubles, 16-byte loads
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    const d2* r = reinterpret_cast<const d2*>(c.tab_rows + (size_t)idx * (2 * KS));
-    double v[2 * KS];
-#pragma unroll
-    for (int i = 0; i < KS; ++i) {
-        const d2 q = r[i];
-        v[2 * i] = q.x; v[2 * i + 1] = q.y;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) y[i] = v[i];
-#pragma unroll
-    for (int kk = 0; kk < KS - 2; ++kk) { pb[kk] = v[4 + kk]; vb[kk] = v[4 + (KS - 2) + kk]; }
-}
-
-// per-episode boundary block in the wave's LDS slice: [a b c d | pos_basis_b[KS-2] | vel_basis_b[KS-2] | scale[KS-2]]
-template <int KS>
-__device__ __forceinline__ void prodmp_boundary_rows(const DevCfg& c, int idxb, double* sB, int lane) {
-    const int N = c.n_pc, K = c.nb + 1;
-    double y[4], pbb[KS - 2], vbb[KS - 2];
-    prodmp_load_row<KS>(c, idxb, y, pbb, vbb);
-    const double* S = c.tab + 4 * (size_t)N + 2 * (size_t)N * K;   // weights_goal_scale
-    const double det = y[0] * y[3] - y[1] * y[2];                  // as prodmp_bc
-    if (lane == 0) {
-        sB[0] = y[3] / det; sB[1] = y[2] / det; sB[2] = y[0] / det; sB[3] = y[1] / det;
-#pragma unroll
-        for (int kk = 0; kk < KS - 2; ++kk) {
-            sB[4 + kk] = pbb[kk];
-            sB[4 + (KS - 2) + kk] = vbb[kk];
-            sB[4 + 2 * (KS - 2) + kk] = S[kk < K ? kk : K - 1];
-        }
-    }
-}
-
-template <int KS>
-__device__ __forceinline__ void prodmp_row(const DevCfg& c, const double* sB, int idx, double tau, double inv_tau,
-                                           float (&h)[KS], float (&hv)[KS]) {
-    const int K = c.nb + 1;
-    constexpr int KB = KS - 2;
-    double y[4], hp[KB], hvp[KB];
-    prodmp_load_row<KS>(c, idx, y, hp, hvp);
-    const double y1 = y[0], y2 = y[1], dy1 = y[2], dy2 = y[3];
-    const double ba = sB[0], bb = sB[1], bcc = sB[2], bd = sB[3];
-    double xi[4];
-    xi[0] = ba * y1 - bb * y2;
-    xi[1] = bcc * y2 - bd * y1;
-    xi[2] = ba * dy1 - bb * dy2;
-    xi[3] = bcc * dy2 - bd * dy1;
-#pragma unroll
-    for (int kk = 0; kk < KB; ++kk) {
-        const double pbb = sB[4 + kk], vbb = sB[4 + KB + kk];
-        hp[kk] = hp[kk] - (xi[0] * pbb + xi[1] * vbb);
-        hvp[kk] = hvp[kk] - (xi[2] * pbb + xi[3] * vbb);
-    }
-#pragma unroll
-    for (int k = 0; k < KS; ++k) {
-        double p = 0.0, v = 0.0;
-        if (k < K) {
-            if (k < KB) {
-                const bool off = k < c.nb ? c.disable_weights != 0 : c.disable_goal != 0;
-                const double sc = sB[4 + 2 * KB + (k < KB ? k : 0)];
-                if (!off) { p = hp[k] * sc; v = hvp[k] * sc; }
-            }
-        } else if (k == K) {
-            p = xi[0]; v = xi[2];
-            if (c.relative_goal && k >= 1 && k - 1 < KB) { p += hp[k - 1]; v += hvp[k - 1]; }
-        } else if (k == K + 1) {
-            p = xi[1] * tau; v = xi[3] * tau;
-        }
-        h[k] = (float)p;
-        hv[k] = (float)(v * inv_tau);
-    }
-}
-
 // Lean float64 helpers for the basis rows.  The library exp()/divide carry special-case handling the rows never need
 // (arguments are finite and <= 0, divisors are positive and normal); these keep ~1e-15 relative accuracy, far inside
 // the single rounding to fp32 that follows, at a third of the instructions.  Every basis row on the device -- shared
@@ -1587,8 +1506,12 @@ __global__ void __launch_bounds__(256) k_traj_rows(const RowArgs a) {
 // k_traj_phase: per-episode phase (learned tau / delay, per-episode init_time), one WAVE per episode, no workgroup
 // barriers in the episode loop (D * KS <= 256 with KS = 8 or 16 contraction columns).
 //   promp / prodmp -- lane <-> time step, 64 steps a round:
-//     1. the lane builds ITS basis row H[t][:] in registers (same device functions as k_build_shared, so a per-episode
-//        phase equal to the shared one gives identical bits); table loads for the row are issued together
+//     1. the lane gets ITS basis row in registers.  promp: fp64 phase + RBF evaluation with the device functions of
+//        k_build_shared (a per-episode phase equal to the shared one gives identical bits).  prodmp: the reference's
+//        own form  pos = c1*y1 + c2*y2 + Psi.wg   -- the row is a plain gather of [Psi | y1 y2] at the
+//        lane's table index from an fp32 row table (one 64-byte line), the boundary conditions enter through
+//        (c1, c2), solved per (episode, DoF) in float64; folding them into the rows (what the shared-phase kernels
+//        do, because there it is free) would cost a float64 update per (episode, step, column)
 //     2. for every DoF the raw parameter column X[d][:] is broadcast from LDS and the fmaf chain runs in ascending k
 //        (the MFMA accumulation order); promp takes its forward difference from the next lane (lane 63 of a
 //        non-final round only feeds lane 62)
@@ -1608,7 +1531,7 @@ struct PhaseArgs {
     float* pos;
     float* vel;
     int32_t* flag;
-    int B, wave_floats, t_pad, x_pad, o_pad, c_pad;
+    int B, wave_floats, t_pad, x_pad, o_pad, c_pad, tab_pad;
 };
 
 template <int MP>
@@ -1693,9 +1616,12 @@ __device__ __forceinline__ void flush_span(const float* __restrict__ so, float* 
     if (lane < end - tail) base[tail + lane] = so[tail + lane];
 }
 
-template <int MP, int KQ>
-__global__ void __launch_bounds__(256) k_traj_phase(const PhaseArgs a) {
+// TL (prodmp): the fp32 row table is staged in the workgroup's LDS (row stride 2*KS + 4 floats: 16-byte aligned rows
+// spread over the banks) and the workgroup is up to 16 waves, so row and boundary gathers never enter the memory queue
+template <int MP, int KQ, bool TL>
+__global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs a) {
     static_assert(MP != MPK_MP_DMP, "dmp has its own kernel");
+    static_assert(!TL || MP == MPK_MP_PRODMP, "only prodmp has a row table");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevCfg& c = a.c;
     constexpr int KS = KQ * 4;
@@ -1705,14 +1631,32 @@ __global__ void __launch_bounds__(256) k_traj_phase(const PhaseArgs a) {
     const int D = c.D, T = c.T, KT = c.KT;
     double* sCen = reinterpret_cast<double*>(smem);     // [c_pad / 2] RBF centres | bandwidths, shared by the workgroup
     float* sBT = smem + a.c_pad;                        // [t_pad] base times, shared by the workgroup
-    float* sX = sBT + a.t_pad + (size_t)wave * a.wave_floats;    // [2][x_pad]
+    float* sTab = sBT + a.t_pad;                        // TL: [n_pc][2*KS + 4] row table, shared by the workgroup
+    float* sX = sTab + a.tab_pad + (size_t)wave * a.wave_floats;  // [2][x_pad]
     float* sO0 = sX + 2 * a.x_pad;                      // [o_pad] pos staging: [sh + lane * D + d]
     float* sO1 = sO0 + a.o_pad;                         // [o_pad] vel staging
-    double* sB = reinterpret_cast<double*>(sO1 + a.o_pad);   // prodmp: [4 + 3 * (KS - 2)] boundary block
+    float* sXf = sO1 + a.o_pad;                         // prodmp: [x_pad] finished columns [wg .. , c1, c2]
+    float* sWgs = smem;                                 // prodmp: weights_goal_scale[nb + 1] (in place of sCen)
     for (int t = threadIdx.x; t < T; t += blockDim.x) sBT[t] = c.base_times[t];
-    if (MP != MPK_MP_PRODMP)
+    if (MP != MPK_MP_PRODMP) {
         for (int k = threadIdx.x; k < 2 * c.n_total; k += blockDim.x) sCen[k] = c.tab[k];
+    } else {
+        const double* S = c.tab + 4 * (size_t)c.n_pc + 2 * (size_t)c.n_pc * (c.nb + 1);
+        for (int k = threadIdx.x; k <= c.nb; k += blockDim.x) {
+            const bool off = k < c.nb ? c.disable_weights != 0 : c.disable_goal != 0;
+            sWgs[k] = off ? 0.0f : (float)S[k];
+        }
+        if (TL) {
+            const float4* src = reinterpret_cast<const float4*>(c.rows32);
+            for (int i = threadIdx.x; i < c.n_pc * (2 * KQ); i += blockDim.x) {
+                const int r = i / (2 * KQ), j = i - r * (2 * KQ);
+                *reinterpret_cast<float4*>(sTab + r * (2 * KS + 4) + 4 * j) = src[i];
+            }
+        }
+    }
     __syncthreads();
+    const float* const rows = TL ? sTab : c.rows32;
+    constexpr int kRow = TL ? 2 * KS + 4 : 2 * KS;
 
     const int stride = (int)gridDim.x * wpb;
     int b = (int)blockIdx.x * wpb + wave;
@@ -1737,15 +1681,42 @@ __global__ void __launch_bounds__(256) k_traj_phase(const PhaseArgs a) {
         const bool more = b + stride < a.B;
         if (more) nxt.issue(a, b + stride, lane);
 
-        double inv_tau = 0.0;
+        float inv_tau = 0.0f;
+        const float* xs = sX + slot * a.x_pad;
         if (MP == MPK_MP_PRODMP) {
+            // boundary conditions, one lane per DoF (SURVEY A.5 / mp_pytorch ProDMP): wg = scale * [w; g] in fp32 as
+            // the reference forms it, then the 2x2 solve for (c1, c2) in float64 from the table row at the boundary
+            // index.  The lane's finished column [wg_0 .. wg_{K-1}, c1, c2] goes to sXf.
             const float sb = scaled_time(it, delay, tau);
             const int idxb = min(prodmp_index(sb, c.scaled_dt), c.n_pc - 1);
-            prodmp_boundary_rows<KS>(c, idxb, sB, lane);
-            inv_tau = div_pos(1.0, (double)tau);
+            inv_tau = 1.0f / tau;
+            if (lane < D) {
+                const int K = c.nb + 1;
+                const float* raw = xs + lane * KS;
+                const float* rb = rows + (size_t)idxb * kRow;
+                const float yb = raw[K < KS ? K : 0], ydb = raw[K + 1 < KS ? K + 1 : 0];
+                double pb = 0.0, vb = 0.0;
+                float* xf = sXf + lane * KS;
+#pragma unroll
+                for (int k = 0; k < KS; ++k) {
+                    float wg = 0.0f;
+                    if (k < K) {
+                        wg = raw[k] * sWgs[k];                                   // 0 * scale when the column is disabled
+                        if (k == c.nb && c.relative_goal) wg = wg + yb;          // g += init_pos
+                        pb += (double)rb[k] * (double)wg;
+                        vb += (double)rb[KS + k] * (double)wg;
+                    }
+                    xf[k] = wg;
+                }
+                const double y1b = rb[K], y2b = rb[K + 1], dy1b = rb[KS + K], dy2b = rb[KS + K + 1];
+                const double det = y1b * dy2b - y2b * dy1b;
+                const double pr = (double)yb - pb, vr = (double)(tau * ydb) - vb;
+                xf[K] = (float)((dy2b * pr - y2b * vr) / det);
+                xf[K + 1] = (float)((y1b * vr - dy1b * pr) / det);
+            }
             __builtin_amdgcn_wave_barrier();
+            xs = sXf;
         }
-        const float* xs = sX + slot * a.x_pad;
         float* const out_pos = a.pos + (size_t)b * T * D;
         float* const out_vel = a.vel + (size_t)b * T * D;
         bool parked = false;
@@ -1759,7 +1730,13 @@ __global__ void __launch_bounds__(256) k_traj_phase(const PhaseArgs a) {
                 const float s = scaled_time(time, delay, tau);
                 if (s > (float)c.len_factor) atomicOr(a.flag, 1);
                 const int idx = min(prodmp_index(s, c.scaled_dt), c.n_pc - 1);
-                prodmp_row<KS>(c, sB, idx, (double)tau, inv_tau, h, hv);
+                const float4* row = reinterpret_cast<const float4*>(rows + (size_t)idx * kRow);
+#pragma unroll
+                for (int j = 0; j < KQ; ++j) {
+                    const float4 p4 = row[j], v4 = row[KQ + j];
+                    h[4 * j] = p4.x; h[4 * j + 1] = p4.y; h[4 * j + 2] = p4.z; h[4 * j + 3] = p4.w;
+                    hv[4 * j] = v4.x; hv[4 * j + 1] = v4.y; hv[4 * j + 2] = v4.z; hv[4 * j + 3] = v4.w;
+                }
             } else {
                 const double x = phase_f64(c, time, tau, delay, ec);
 #pragma unroll
@@ -1789,6 +1766,7 @@ __global__ void __launch_bounds__(256) k_traj_phase(const PhaseArgs a) {
                 if (MP == MPK_MP_PRODMP) {
 #pragma unroll
                     for (int k = 0; k < KS; ++k) v = fmaf(hv[k], x[k], v);
+                    v = v * inv_tau;
                 } else {
                     const float nx = __shfl_down(p, 1);
                     v = (nx - p) * rdt;
@@ -1916,18 +1894,32 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
     if (need > 16 || c.D > 64) return MPK_ENOTIMPL;
     const int KQ = need <= 4 && c.mp_type == MPK_MP_PROMP ? 1 : (need <= 8 ? 2 : 4), KS = KQ * 4;
     if (c.D * KS > 256) return MPK_ENOTIMPL;
-    if (c.mp_type == MPK_MP_PRODMP && (!c.tab_rows || c.row_stride != 2 * KS)) return MPK_ENOTIMPL;
+    if (c.mp_type == MPK_MP_PRODMP && (!c.rows32 || c.rows32_stride != 2 * KS)) return MPK_ENOTIMPL;
     pa.t_pad = (c.T + 3) / 4 * 4;
     pa.x_pad = c.D * KS;
     pa.o_pad = (64 * c.D + 4 + 3) / 4 * 4;
     if (dmp) pa.wave_floats = c.T * KS + pa.t_pad + 2 * pa.x_pad + (2 * c.T * c.D + 3) / 4 * 4;
-    else pa.wave_floats = 2 * pa.x_pad + 2 * pa.o_pad + (c.mp_type == MPK_MP_PRODMP ? (2 * (4 + 3 * (KS - 2)) + 3) / 4 * 4 : 0);
-    pa.c_pad = c.mp_type == MPK_MP_PRODMP ? 0 : (4 * c.n_total + 3) / 4 * 4;
+    else pa.wave_floats = 2 * pa.x_pad + 2 * pa.o_pad + (c.mp_type == MPK_MP_PRODMP ? pa.x_pad : 0);
+    pa.c_pad = c.mp_type == MPK_MP_PRODMP ? (c.nb + 1 + 3) / 4 * 4 : (4 * c.n_total + 3) / 4 * 4;
     const size_t wave_bytes = (size_t)pa.wave_floats * sizeof(float);
-    const size_t shared_bytes = (size_t)(pa.t_pad + pa.c_pad) * sizeof(float);
+    size_t shared_bytes = (size_t)(pa.t_pad + pa.c_pad) * sizeof(float);
     if (wave_bytes + shared_bytes > 160 * 1024) return MPK_ENOTIMPL;
     int wpb = (int)((64 * 1024 - shared_bytes) / wave_bytes);
     wpb = wpb > 4 ? 4 : (wpb < 1 ? 1 : wpb);
+    // prodmp: stage the row table in LDS when it leaves room for at least 8 waves (MPK_PHASE_TABLE=0: gather from L2)
+    bool lds_table = false;
+    if (c.mp_type == MPK_MP_PRODMP) {
+        const size_t tab_bytes = (size_t)c.n_pc * (2 * KS + 4) * sizeof(float);
+        const size_t room = 160 * 1024 - shared_bytes;
+        lds_table = tab_bytes + 8 * wave_bytes <= room && (long)pa.B >= (long)num_cu * 8;
+        if (const char* e = getenv("MPK_PHASE_TABLE")) lds_table = lds_table && atoi(e) != 0;
+        if (lds_table) {
+            pa.tab_pad = c.n_pc * (2 * KS + 4);
+            shared_bytes += tab_bytes;
+            wpb = (int)((160 * 1024 - shared_bytes) / wave_bytes);
+            wpb = wpb > 16 ? 16 : wpb;
+        }
+    }
     const size_t lds = wave_bytes * wpb + shared_bytes;
     int per_cu = (int)(160 * 1024 / lds);
     per_cu = per_cu > 32 / wpb ? 32 / wpb : per_cu;
@@ -1945,12 +1937,16 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
     };
     switch (c.mp_type) {
         case MPK_MP_PRODMP:
+            if (lds_table) {
+                *kernel_name = "k_traj_phase<prodmp,lds>";
+                return KQ == 2 ? go(k_traj_phase<MPK_MP_PRODMP, 2, true>) : go(k_traj_phase<MPK_MP_PRODMP, 4, true>);
+            }
             *kernel_name = "k_traj_phase<prodmp>";
-            return KQ == 2 ? go(k_traj_phase<MPK_MP_PRODMP, 2>) : go(k_traj_phase<MPK_MP_PRODMP, 4>);
+            return KQ == 2 ? go(k_traj_phase<MPK_MP_PRODMP, 2, false>) : go(k_traj_phase<MPK_MP_PRODMP, 4, false>);
         case MPK_MP_PROMP:
             *kernel_name = "k_traj_phase<promp>";
-            if (KQ == 1) return go(k_traj_phase<MPK_MP_PROMP, 1>);
-            return KQ == 2 ? go(k_traj_phase<MPK_MP_PROMP, 2>) : go(k_traj_phase<MPK_MP_PROMP, 4>);
+            if (KQ == 1) return go(k_traj_phase<MPK_MP_PROMP, 1, false>);
+            return KQ == 2 ? go(k_traj_phase<MPK_MP_PROMP, 2, false>) : go(k_traj_phase<MPK_MP_PROMP, 4, false>);
         default:
             *kernel_name = "k_traj_phase<dmp>";
             return KQ == 2 ? go(k_traj_phase_dmp<2>) : go(k_traj_phase_dmp<4>);
@@ -1968,7 +1964,7 @@ int launch_traj_rows(const DevCfg& c, const float* params, const float* init_pos
     bool wave_kernel = true;
     if (const char* e = getenv("MPK_PHASE")) wave_kernel = atoi(e) != 0;
     if (wave_kernel) {
-        PhaseArgs pa{c, params, init_pos, init_vel, init_time, init_time_shared, pos, vel, range_flag, B, 0, 0, 0, 0, 0};
+        PhaseArgs pa{c, params, init_pos, init_vel, init_time, init_time_shared, pos, vel, range_flag, B, 0, 0, 0, 0, 0, 0};
         const int rc = launch_traj_phase(c, pa, num_cu, stream, kernel_name);
         if (rc != MPK_ENOTIMPL) return rc;
     }

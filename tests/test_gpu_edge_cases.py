@@ -87,14 +87,19 @@ def test_limits_fall_back_to_the_per_episode_kernel(mp):
 def test_prodmp_flags(flags, init_time):
     cfg = cfg_for("prodmp", 5, 4, 60, **flags)
     check(cfg, 11, init_time, expect_kernel="k_traj_")
-    # same flags through the per-episode kernel, bit for bit
+    # same flags through the per-episode kernel (the reference's c1 / c2 form): against the oracle, and equal to the
+    # shared-phase result up to rounding
     pc, bc, tc, dt, dur = cfg
     eng = make_engine(pc, bc, tc, dt, dur)
     params, ip, iv = inputs(pc, bc, tc, 11, seed=3)
     p0, v0 = eng.trajectory(params, ip, iv, init_time)
     p1, v1 = eng.trajectory(params, ip, iv, torch.full((11,), init_time, device="cuda"))
     assert eng.last_kernel().startswith("k_traj_phase")
-    assert torch.equal(p0, p1) and torch.equal(v0, v1)
+    rp, rv = O.get_trajectory(pc, bc, tc, params, dur, dt, init_time, ip, iv, dtype=np.float64)
+    close(p1.cpu().numpy(), rp, "pos"); close(v1.cpu().numpy(), rv, "vel")
+    for a, b in ((p0, p1), (v0, v1)):
+        a, b = a.cpu().numpy().astype(np.float64), b.cpu().numpy().astype(np.float64)
+        assert np.abs(a - b).max() <= 2e-6 * np.abs(a).max()
 
 
 def test_empty_and_single_episode_batches():
@@ -246,7 +251,8 @@ def test_dmp_quad_and_stream_kernels_agree_bitwise_and_match_oracle(quad, D, T, 
                                     (32, 3, 12), (64, 1, 7)])
 def test_per_episode_kernels_agree_bitwise(mp, D, nb, T, monkeypatch):
     """wave-per-episode (k_traj_phase) and workgroup-per-episode (k_traj_rows) kernels, per-episode init_time: same
-    bits from both, and equal to the shared-phase kernels when every episode carries the same init_time"""
+    bits from both and from the shared-phase kernels when every episode carries the same init_time (prodmp's
+    wave-per-episode kernel uses the reference's c1 / c2 form: equal to rounding)"""
     if mp == "prodmp" and nb + 3 > 16:
         pytest.skip("more than 16 contraction columns")
     pc, bc, tc, dt, dur = cfg_for(mp, D, nb, T)
@@ -266,11 +272,17 @@ def test_per_episode_kernels_agree_bitwise(mp, D, nb, T, monkeypatch):
     assert outs["0"][2].startswith("k_traj_rows")
     if wave_ok:
         assert outs["1"][2].startswith("k_traj_phase"), outs["1"][2]
-    assert torch.equal(outs["1"][0], outs["0"][0]) and torch.equal(outs["1"][1], outs["0"][1])
+    def same(a, b):
+        if mp != "prodmp" or not outs["1"][2].startswith("k_traj_phase"):
+            return torch.equal(a, b)
+        a, b = a.cpu().numpy().astype(np.float64), b.cpu().numpy().astype(np.float64)      # c1 / c2 form vs folded rows
+        return np.abs(a - b).max() <= 2e-6 * np.abs(a).max()
+    assert same(outs["0"][0], outs["1"][0]) and same(outs["0"][1], outs["1"][1])
     if D <= 16:
         p0, v0 = eng.trajectory(params, ip, iv, float(it[0]))
         assert not eng.last_kernel().startswith(("k_traj_rows", "k_traj_phase"))
-        assert torch.equal(p0, outs["1"][0]) and torch.equal(v0, outs["1"][1])
+        assert same(p0, outs["1"][0]) and same(v0, outs["1"][1])
+        assert torch.equal(p0, outs["0"][0]) and torch.equal(v0, outs["0"][1])       # folded rows in both
     rp, rv = O.get_trajectory(pc, bc, tc, params, dur, dt, float(it[0]), ip, iv, dtype=np.float64)
     close(outs["1"][0].cpu().numpy(), rp, "pos")
     close(outs["1"][1].cpu().numpy(), rv, "vel", atol=fd_atol(rp, dt) if mp == "promp" else 0.0)
@@ -283,3 +295,31 @@ def test_batches_beyond_2_31_output_elements():
         pytest.skip("needs 80 GB of free device memory")
     from tools import big_batch_check
     big_batch_check.main()
+
+
+@pytest.mark.parametrize("name", ["prodmp_learn_tau_delay", "cfg2_learn_tau"])
+def test_prodmp_row_table_in_lds_or_l2_same_bits(name, monkeypatch):
+    """k_traj_phase<prodmp> gathers its fp32 rows from an LDS copy of the table when that fits beside 8 waves, else
+    from L2: same arithmetic, same bits; both against the oracle"""
+    from tests.test_gpu_trajectory import PER_ROW
+    if name == "cfg2_learn_tau":
+        cfg = (O.PhaseCfg("exp", tau=1.5, alpha_phase=3.0, learn_tau=True, tau_bound=(0.5, 2.0)),
+               O.BasisCfg("prodmp", num_basis=5, basis_bandwidth_factor=2, alpha=10), O.TrajCfg("prodmp", action_dim=7),
+               0.02, 2.0)
+    else:
+        cfg = PER_ROW[name]
+    pc, bc, tc, dt, dur = cfg
+    eng = make_engine(pc, bc, tc, dt, dur)
+    B = 2500
+    params, ip, iv = inputs(pc, bc, tc, B, seed=2)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MPK_PHASE_TABLE", mode)
+        p, v = eng.trajectory(params, ip, iv, 0.0)
+        torch.cuda.synchronize()
+        outs[mode] = (p.clone(), v.clone(), eng.last_kernel())
+    assert outs["0"][2] == "k_traj_phase<prodmp>"
+    assert outs["1"][2] == "k_traj_phase<prodmp,lds>", outs["1"][2]
+    assert torch.equal(outs["0"][0], outs["1"][0]) and torch.equal(outs["0"][1], outs["1"][1])
+    rp, rv = O.get_trajectory(pc, bc, tc, params, dur, dt, 0.0, ip, iv, dtype=np.float64)
+    close(outs["1"][0].cpu().numpy(), rp, "pos"); close(outs["1"][1].cpu().numpy(), rv, "vel")

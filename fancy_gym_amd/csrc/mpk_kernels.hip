@@ -1531,7 +1531,7 @@ struct PhaseArgs {
     float* pos;
     float* vel;
     int32_t* flag;
-    int B, wave_floats, t_pad, x_pad, o_pad, c_pad, tab_pad;
+    int B, wave_floats, t_pad, x_pad, o_pad, c_pad, tab_pad, chunk, img_pad;
 };
 
 template <int MP>
@@ -1632,10 +1632,10 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
     double* sCen = reinterpret_cast<double*>(smem);     // [c_pad / 2] RBF centres | bandwidths, shared by the workgroup
     float* sBT = smem + a.c_pad;                        // [t_pad] base times, shared by the workgroup
     float* sTab = sBT + a.t_pad;                        // TL: [n_pc][2*KS + 4] row table, shared by the workgroup
-    float* sX = sTab + a.tab_pad + (size_t)wave * a.wave_floats;  // [2][x_pad]
-    float* sO0 = sX + 2 * a.x_pad;                      // [o_pad] pos staging: [sh + lane * D + d]
+    float* sImg = sTab + a.tab_pad + (size_t)wave * a.wave_floats;  // [2][img_pad] inputs of this / the next chunk
+    float* sO0 = sImg + 2 * a.img_pad;                  // [o_pad] pos staging: [sh + lane * D + d]
     float* sO1 = sO0 + a.o_pad;                         // [o_pad] vel staging
-    float* sXf = sO1 + a.o_pad;                         // prodmp: [x_pad] finished columns [wg .. , c1, c2]
+    float* sXf = sO1 + a.o_pad;                         // [x_pad] this episode's columns (prodmp: [wg .. , c1, c2])
     float* sWgs = smem;                                 // prodmp: weights_goal_scale[nb + 1] (in place of sCen)
     for (int t = threadIdx.x; t < T; t += blockDim.x) sBT[t] = c.base_times[t];
     if (MP != MPK_MP_PRODMP) {
@@ -1658,133 +1658,167 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
     const float* const rows = TL ? sTab : c.rows32;
     constexpr int kRow = TL ? 2 * KS + 4 : 2 * KS;
 
-    const int stride = (int)gridDim.x * wpb;
-    int b = (int)blockIdx.x * wpb + wave;
-    PhaseFetch<MP, KS> cur;
-    if (b < a.B) {
-        cur.issue(a, b, lane);
-        cur.park(sX, D * KS, lane);
+    // A wave owns chunks of E consecutive episodes.  A chunk's inputs -- E parameter rows, E boundary positions /
+    // velocities, E init_times: each one contiguous run -- are fetched with coalesced loads one chunk ahead and
+    // collected once per chunk (into the other half of the wave's input image), right after the rows of the chunk's
+    // last episode are built: the memory queue is in order, so collecting a load also waits for every store issued
+    // before it, and that wait is paid per chunk instead of per episode.
+    const int E = a.chunk, P = c.P;
+    const int img_floats = a.img_pad;
+    constexpr int NLP = 5;                              // E * P <= 320 parameter values per chunk
+    const int nchunks = (a.B + E - 1) / E;
+    const int cstride = (int)gridDim.x * wpb;
+    int ch = (int)blockIdx.x * wpb + wave;
+    float lp[NLP], lip = 0.0f, liv = 0.0f, lit = 0.0f;
+    auto issue_chunk = [&](int cc) {
+        const int b0 = cc * E, ne = min(E, a.B - b0);
+        const float* prm = a.params + (size_t)b0 * P;
+#pragma unroll
+        for (int r = 0; r < NLP; ++r) lp[r] = lane + 64 * r < ne * P ? prm[lane + 64 * r] : 0.0f;
+        lip = lane < ne * D ? a.init_pos[(size_t)b0 * D + lane] : 0.0f;
+        liv = lane < ne * D ? a.init_vel[(size_t)b0 * D + lane] : 0.0f;
+        lit = a.init_time && lane < ne ? a.init_time[b0 + lane] : a.init_time_shared;
+    };
+    auto park_chunk = [&](float* img) {
+#pragma unroll
+        for (int r = 0; r < NLP; ++r)
+            if (lane + 64 * r < E * P) img[lane + 64 * r] = lp[r];
+        if (lane < E * D) { img[E * P + lane] = lip; img[E * P + E * D + lane] = liv; }
+        if (lane < E) img[E * P + 2 * E * D + lane] = lit;
+    };
+    if (ch < nchunks) {
+        issue_chunk(ch);
+        park_chunk(sImg);
     }
     constexpr int kStep = MP == MPK_MP_PROMP ? 63 : 64;
     ExpRegs ec;
     if (MP == MPK_MP_PROMP) ec.load();
     int slot = 0;
-    for (; b < a.B; b += stride, slot ^= 1) {
-        // np.clip(action, low, high): only tau / delay carry finite bounds (black_box_wrapper.py:104-105)
-        const float tau = c.learn_tau ? fminf(fmaxf(cur.tau_raw, c.tau_lo), c.tau_hi) : c.tau;
-        const float delay = c.learn_delay ? fminf(fmaxf(cur.delay_raw, c.delay_lo), c.delay_hi) : c.delay;
-        const float it = cur.it;
-        PhaseFetch<MP, KS> nxt;
-        nxt.tau_raw = 0.0f; nxt.delay_raw = 0.0f; nxt.it = 0.0f;
-#pragma unroll
-        for (int r = 0; r < PhaseFetch<MP, KS>::NX; ++r) nxt.xv[r] = 0.0f;
-        const bool more = b + stride < a.B;
-        if (more) nxt.issue(a, b + stride, lane);
-
-        float inv_tau = 0.0f;
-        const float* xs = sX + slot * a.x_pad;
-        if (MP == MPK_MP_PRODMP) {
-            // boundary conditions, one lane per DoF (SURVEY A.5 / mp_pytorch ProDMP): wg = scale * [w; g] in fp32 as
-            // the reference forms it, then the 2x2 solve for (c1, c2) in float64 from the table row at the boundary
-            // index.  The lane's finished column [wg_0 .. wg_{K-1}, c1, c2] goes to sXf.
-            const float sb = scaled_time(it, delay, tau);
-            const int idxb = min(prodmp_index(sb, c.scaled_dt), c.n_pc - 1);
-            inv_tau = 1.0f / tau;
-            if (lane < D) {
-                const int K = c.nb + 1;
-                const float* raw = xs + lane * KS;
-                const float* rb = rows + (size_t)idxb * kRow;
-                const float yb = raw[K < KS ? K : 0], ydb = raw[K + 1 < KS ? K + 1 : 0];
-                double pb = 0.0, vb = 0.0;
-                float* xf = sXf + lane * KS;
-#pragma unroll
-                for (int k = 0; k < KS; ++k) {
-                    float wg = 0.0f;
-                    if (k < K) {
-                        wg = raw[k] * sWgs[k];                                   // 0 * scale when the column is disabled
-                        if (k == c.nb && c.relative_goal) wg = wg + yb;          // g += init_pos
-                        pb += (double)rb[k] * (double)wg;
-                        vb += (double)rb[KS + k] * (double)wg;
-                    }
-                    xf[k] = wg;
-                }
-                const double y1b = rb[K], y2b = rb[K + 1], dy1b = rb[KS + K], dy2b = rb[KS + K + 1];
-                const double det = y1b * dy2b - y2b * dy1b;
-                const double pr = (double)yb - pb, vr = (double)(tau * ydb) - vb;
-                xf[K] = (float)((dy2b * pr - y2b * vr) / det);
-                xf[K + 1] = (float)((y1b * vr - dy1b * pr) / det);
-            }
-            __builtin_amdgcn_wave_barrier();
-            xs = sXf;
-        }
-        float* const out_pos = a.pos + (size_t)b * T * D;
-        float* const out_vel = a.vel + (size_t)b * T * D;
-        bool parked = false;
-        for (int r0 = 0; r0 < T; r0 += kStep) {
-            const bool final_round = T - r0 <= 64;
-            const int nout = final_round ? T - r0 : kStep;
-            const int t = r0 + lane < T ? r0 + lane : T - 1;
-            float h[KS], hv[KS], rdt = 0.0f;
-            const float time = sBT[t] + it;
+    for (; ch < nchunks; ch += cstride, slot ^= 1) {
+        const float* img = sImg + slot * img_floats;
+        const int b0 = ch * E, ne = min(E, a.B - b0);
+        const bool more = ch + cstride < nchunks;
+        if (more) issue_chunk(ch + cstride);
+        __builtin_amdgcn_wave_barrier();
+        for (int e = 0; e < ne; ++e) {
+            const int b = b0 + e;
+            const float* prm = img + e * P;
+            const float* ipe = img + E * P + e * D;
+            const float* ive = ipe + E * D;
+            // np.clip(action, low, high): only tau / delay carry finite bounds (black_box_wrapper.py:104-105)
+            float tau = c.tau, delay = c.delay;
+            if (c.learn_tau) tau = fminf(fmaxf(prm[0], c.tau_lo), c.tau_hi);
+            if (c.learn_delay) delay = fminf(fmaxf(prm[c.learn_tau ? 1 : 0], c.delay_lo), c.delay_hi);
+            const float it = img[E * P + 2 * E * D + e];
+            float inv_tau = 0.0f;
             if (MP == MPK_MP_PRODMP) {
-                const float s = scaled_time(time, delay, tau);
-                if (s > (float)c.len_factor) atomicOr(a.flag, 1);
-                const int idx = min(prodmp_index(s, c.scaled_dt), c.n_pc - 1);
-                const float4* row = reinterpret_cast<const float4*>(rows + (size_t)idx * kRow);
+                // boundary conditions, one lane per DoF (SURVEY A.5 / mp_pytorch ProDMP): wg = scale * [w; g] in fp32
+                // as the reference forms it, then the 2x2 solve for (c1, c2) in float64 from the table row at the
+                // boundary index.  The lane's finished column [wg_0 .. wg_{K-1}, c1, c2] goes to sXf.
+                const float sb = scaled_time(it, delay, tau);
+                const int idxb = min(prodmp_index(sb, c.scaled_dt), c.n_pc - 1);
+                inv_tau = 1.0f / tau;
+                if (lane < D) {
+                    const int K = c.nb + 1;
+                    const float* loc = prm + c.off + lane * c.Kloc;
+                    const float* rb = rows + (size_t)idxb * kRow;
+                    const float yb = ipe[lane], ydb = ive[lane];
+                    double pb = 0.0, vb = 0.0;
+                    float* xf = sXf + lane * KS;
 #pragma unroll
-                for (int j = 0; j < KQ; ++j) {
-                    const float4 p4 = row[j], v4 = row[KQ + j];
-                    h[4 * j] = p4.x; h[4 * j + 1] = p4.y; h[4 * j + 2] = p4.z; h[4 * j + 3] = p4.w;
-                    hv[4 * j] = v4.x; hv[4 * j + 1] = v4.y; hv[4 * j + 2] = v4.z; hv[4 * j + 3] = v4.w;
+                    for (int k = 0; k < KS; ++k) {
+                        float wg = 0.0f;
+                        if (k < K) {
+                            // a disabled block has no parameters (the goal then sits at local index 0) and scale 0
+                            const bool have = k < c.nb ? !c.disable_weights : !c.disable_goal;
+                            const int li = k < c.nb ? k : (c.disable_weights ? 0 : c.nb);
+                            wg = have ? loc[li] * sWgs[k] : 0.0f;
+                            if (k == c.nb && c.relative_goal) wg = wg + yb;      // g += init_pos
+                            pb += (double)rb[k] * (double)wg;
+                            vb += (double)rb[KS + k] * (double)wg;
+                        }
+                        xf[k] = wg;
+                    }
+                    const double y1b = rb[K], y2b = rb[K + 1], dy1b = rb[KS + K], dy2b = rb[KS + K + 1];
+                    const double det = y1b * dy2b - y2b * dy1b;
+                    const double pr = (double)yb - pb, vr = (double)(tau * ydb) - vb;
+                    xf[K] = (float)((dy2b * pr - y2b * vr) / det);
+                    xf[K + 1] = (float)((y1b * vr - dy1b * pr) / det);
                 }
             } else {
-                const double x = phase_f64(c, time, tau, delay, ec);
-#pragma unroll
-                for (int k = 0; k < KS; ++k) h[k] = 0.0f;
-                rbf_row<KS>(c, sCen, sCen + c.n_total, x, (double)c.ws, h, ec);
-                const int th = t < T - 1 ? t + 1 : T - 1, tl = t < T - 1 ? t : T - 2;
-                rdt = 1.0f / ((sBT[th] + it) - (sBT[tl] + it));
-            }
-            if (!parked) {
-                // collect the prefetch (nothing but loads is outstanding here) and park it for the next turn
-                nxt.park(sX + (slot ^ 1) * a.x_pad, more ? D * KS : 0, lane);
-                parked = true;
-            }
-            float* const gp = out_pos + (size_t)r0 * D;
-            const int sh = (int)((reinterpret_cast<uintptr_t>(gp) >> 2) & 3);
-            const bool keep = lane < nout;
-            for (int d = 0; d < D; ++d) {
-                float x[KS];
-#pragma unroll
-                for (int j = 0; j < KQ; ++j) {
-                    const float4 v = *reinterpret_cast<const float4*>(xs + d * KS + 4 * j);
-                    x[4 * j + 0] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
+                // raw parameter columns [w_0 .. w_{nb-1}, init_pos (zero-padded family), 0 ..] per DoF
+                for (int i = lane; i < D * KS; i += 64) {
+                    const int dd = i / KS, k = i - dd * KS;
+                    float v = 0.0f;
+                    if (k < c.nb) v = prm[c.off + dd * c.Kloc + k];
+                    else if (k < KT) v = ipe[dd];
+                    sXf[i] = v;
                 }
-                float p = 0.0f, v = 0.0f;
-#pragma unroll
-                for (int k = 0; k < KS; ++k) p = fmaf(h[k], x[k], p);
+            }
+            __builtin_amdgcn_wave_barrier();
+            float* const out_pos = a.pos + (size_t)b * T * D;
+            float* const out_vel = a.vel + (size_t)b * T * D;
+            for (int r0 = 0; r0 < T; r0 += kStep) {
+                const bool final_round = T - r0 <= 64;
+                const int nout = final_round ? T - r0 : kStep;
+                const int t = r0 + lane < T ? r0 + lane : T - 1;
+                float h[KS], hv[KS], rdt = 0.0f;
+                const float time = sBT[t] + it;
                 if (MP == MPK_MP_PRODMP) {
+                    const float s = scaled_time(time, delay, tau);
+                    if (s > (float)c.len_factor) atomicOr(a.flag, 1);
+                    const int idx = min(prodmp_index(s, c.scaled_dt), c.n_pc - 1);
+                    const float4* row = reinterpret_cast<const float4*>(rows + (size_t)idx * kRow);
 #pragma unroll
-                    for (int k = 0; k < KS; ++k) v = fmaf(hv[k], x[k], v);
-                    v = v * inv_tau;
+                    for (int j = 0; j < KQ; ++j) {
+                        const float4 p4 = row[j], v4 = row[KQ + j];
+                        h[4 * j] = p4.x; h[4 * j + 1] = p4.y; h[4 * j + 2] = p4.z; h[4 * j + 3] = p4.w;
+                        hv[4 * j] = v4.x; hv[4 * j + 1] = v4.y; hv[4 * j + 2] = v4.z; hv[4 * j + 3] = v4.w;
+                    }
                 } else {
-                    const float nx = __shfl_down(p, 1);
-                    v = (nx - p) * rdt;
-                    const float pv = __shfl_up(v, 1);          // last row repeats the difference before it
-                    if (r0 + lane == T - 1) v = pv;
+                    const double x = phase_f64(c, time, tau, delay, ec);
+#pragma unroll
+                    for (int k = 0; k < KS; ++k) h[k] = 0.0f;
+                    rbf_row<KS>(c, sCen, sCen + c.n_total, x, (double)c.ws, h, ec);
+                    const int th = t < T - 1 ? t + 1 : T - 1, tl = t < T - 1 ? t : T - 2;
+                    rdt = 1.0f / ((sBT[th] + it) - (sBT[tl] + it));
                 }
-                if (keep) {
-                    sO0[sh + lane * D + d] = p;
-                    sO1[sh + lane * D + d] = v;
+                if (more && e == ne - 1 && r0 == 0) park_chunk(sImg + (slot ^ 1) * img_floats);
+                float* const gp = out_pos + (size_t)r0 * D;
+                const int sh = (int)((reinterpret_cast<uintptr_t>(gp) >> 2) & 3);
+                const bool keep = lane < nout;
+                for (int d = 0; d < D; ++d) {
+                    float x[KS];
+#pragma unroll
+                    for (int j = 0; j < KQ; ++j) {
+                        const float4 v = *reinterpret_cast<const float4*>(sXf + d * KS + 4 * j);
+                        x[4 * j + 0] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
+                    }
+                    float p = 0.0f, v = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < KS; ++k) p = fmaf(h[k], x[k], p);
+                    if (MP == MPK_MP_PRODMP) {
+#pragma unroll
+                        for (int k = 0; k < KS; ++k) v = fmaf(hv[k], x[k], v);
+                        v = v * inv_tau;
+                    } else {
+                        const float nx = __shfl_down(p, 1);
+                        v = (nx - p) * rdt;
+                        const float pv = __shfl_up(v, 1);      // last row repeats the difference before it
+                        if (r0 + lane == T - 1) v = pv;
+                    }
+                    if (keep) {
+                        sO0[sh + lane * D + d] = p;
+                        sO1[sh + lane * D + d] = v;
+                    }
                 }
+                __builtin_amdgcn_wave_barrier();
+                flush_span(sO0, gp, nout * D, sh, lane);
+                flush_span(sO1, out_vel + (size_t)r0 * D, nout * D, sh, lane);
+                __builtin_amdgcn_wave_barrier();
+                if (final_round) break;
             }
-            __builtin_amdgcn_wave_barrier();
-            flush_span(sO0, gp, nout * D, sh, lane);
-            flush_span(sO1, out_vel + (size_t)r0 * D, nout * D, sh, lane);
-            __builtin_amdgcn_wave_barrier();
-            if (final_round) break;
         }
-        cur = nxt;
     }
 }
 
@@ -1899,7 +1933,17 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
     pa.x_pad = c.D * KS;
     pa.o_pad = (64 * c.D + 4 + 3) / 4 * 4;
     if (dmp) pa.wave_floats = c.T * KS + pa.t_pad + 2 * pa.x_pad + (2 * c.T * c.D + 3) / 4 * 4;
-    else pa.wave_floats = 2 * pa.x_pad + 2 * pa.o_pad + (c.mp_type == MPK_MP_PRODMP ? pa.x_pad : 0);
+    else {
+        // chunks of up to 4 consecutive episodes whose parameter rows fit the loader's 5 x 64 values and whose boundary
+        // states fit one 64-lane load
+        int E = 320 / c.P;
+        E = E > 4 ? 4 : E;
+        E = E > 64 / c.D ? 64 / c.D : E;
+        if (E < 1) return MPK_ENOTIMPL;
+        pa.chunk = E;
+        pa.img_pad = (E * (c.P + 2 * c.D + 1) + 3) / 4 * 4;
+        pa.wave_floats = 2 * pa.img_pad + 2 * pa.o_pad + pa.x_pad;
+    }
     pa.c_pad = c.mp_type == MPK_MP_PRODMP ? (c.nb + 1 + 3) / 4 * 4 : (4 * c.n_total + 3) / 4 * 4;
     const size_t wave_bytes = (size_t)pa.wave_floats * sizeof(float);
     size_t shared_bytes = (size_t)(pa.t_pad + pa.c_pad) * sizeof(float);
@@ -1923,7 +1967,16 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
     const size_t lds = wave_bytes * wpb + shared_bytes;
     int per_cu = (int)(160 * 1024 / lds);
     per_cu = per_cu > 32 / wpb ? 32 / wpb : per_cu;
-    long blocks = ((long)pa.B + wpb - 1) / wpb;
+    if (!dmp) {
+        // chunks cost balance (a wave's work is quantised in E episodes): only when every resident wave still gets >= 4
+        const long resident = (long)num_cu * per_cu * wpb;
+        int E = pa.chunk;
+        while (E > 1 && (long)pa.B / E < 4 * resident) E >>= 1;
+        if (const char* e = getenv("MPK_PHASE_CHUNK")) { const int v = atoi(e); if (v >= 1 && v <= pa.chunk) E = v; }
+        pa.chunk = E;
+    }
+    const long units = dmp ? (long)pa.B : ((long)pa.B + pa.chunk - 1) / pa.chunk;
+    long blocks = (units + wpb - 1) / wpb;
     if (blocks > (long)num_cu * per_cu) blocks = (long)num_cu * per_cu;
     auto go = [&](auto kern) -> int {
         if (lds > 64 * 1024) {
@@ -1964,7 +2017,7 @@ int launch_traj_rows(const DevCfg& c, const float* params, const float* init_pos
     bool wave_kernel = true;
     if (const char* e = getenv("MPK_PHASE")) wave_kernel = atoi(e) != 0;
     if (wave_kernel) {
-        PhaseArgs pa{c, params, init_pos, init_vel, init_time, init_time_shared, pos, vel, range_flag, B, 0, 0, 0, 0, 0, 0};
+        PhaseArgs pa{c, params, init_pos, init_vel, init_time, init_time_shared, pos, vel, range_flag, B, 0, 0, 0, 0, 0, 0, 0, 0};
         const int rc = launch_traj_phase(c, pa, num_cu, stream, kernel_name);
         if (rc != MPK_ENOTIMPL) return rc;
     }

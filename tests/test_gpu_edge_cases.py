@@ -323,3 +323,27 @@ def test_prodmp_row_table_in_lds_or_l2_same_bits(name, monkeypatch):
     assert torch.equal(outs["0"][0], outs["1"][0]) and torch.equal(outs["0"][1], outs["1"][1])
     rp, rv = O.get_trajectory(pc, bc, tc, params, dur, dt, 0.0, ip, iv, dtype=np.float64)
     close(outs["1"][0].cpu().numpy(), rp, "pos"); close(outs["1"][1].cpu().numpy(), rv, "vel")
+
+
+@pytest.mark.parametrize("name", ["prodmp_learn_tau_delay", "promp_learn_tau"])
+@pytest.mark.parametrize("B", [1, 7, 130])
+def test_per_episode_chunking_is_invisible(name, B, monkeypatch):
+    """a wave's episodes are fetched in chunks of 1, 2 or 4 consecutive episodes (ragged last chunk): same bits"""
+    from tests.test_gpu_trajectory import PER_ROW
+    pc, bc, tc, dt, dur = PER_ROW[name]
+    eng = make_engine(pc, bc, tc, dt, dur)
+    params, ip, iv = inputs(pc, bc, tc, B, seed=B)
+    it = torch.tensor(np.random.default_rng(B).integers(0, 4, B) * dt, dtype=torch.float32, device="cuda")
+    ref = None
+    for chunk in ("1", "2", "4"):
+        monkeypatch.setenv("MPK_PHASE_CHUNK", chunk)
+        p, v = eng.trajectory(params, ip, iv, it)
+        torch.cuda.synchronize()
+        assert eng.last_kernel().startswith("k_traj_phase")
+        if ref is None:
+            ref = (p.clone(), v.clone())
+        assert torch.equal(p, ref[0]) and torch.equal(v, ref[1]), chunk
+    for b in range(min(B, 5)):
+        rp, rv = O.get_trajectory(pc, bc, tc, params[b:b + 1], dur, dt, float(it[b]), ip[b:b + 1], iv[b:b + 1],
+                                  dtype=np.float64)
+        close(ref[0][b:b + 1].cpu().numpy(), rp, "pos")

@@ -78,6 +78,7 @@ SIGNATURES = {
                                       _vp, _i32, _i32, _vp]),
     "mpk_replan_advance": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "mpk_traj_validity": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "mpk_traj_validity_penalty": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "mpk_prodmp_tables": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mpk_prodmp_indices": (C.c_int, [_vp, _dbl, _vp, _vp, _vp]),
     "mpk_host_prodmp_tables": (C.c_int, [C.POINTER(mpk_config), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -225,10 +225,12 @@ class BatchedBlackBox:
         was_done = self.done.bool()
         valid = torch.ones(self.B, dtype=torch.bool, device=self.device)
         if self.pos_limits is not None:
-            valid = self.engine.traj_validity(pos, self.pos_limits[0], self.pos_limits[1],
-                                              out["params"] if self.check_tau_delay else None,
-                                              self.tau_bound if self.check_tau_delay else None,
-                                              self.delay_bound if self.check_tau_delay else None)
+            # `params` as the caller passed them: the reference checks the raw action, not the clipped one
+            raw = torch.as_tensor(params, dtype=torch.float32, device=self.device)
+            valid, out["invalid_penalty"] = self.engine.traj_validity(
+                pos, self.pos_limits[0], self.pos_limits[1], raw if self.check_tau_delay else None,
+                self.tau_bound if self.check_tau_delay else None,
+                self.delay_bound if self.check_tau_delay else None, with_penalty=True)
         if not bool(valid.all()):
             # invalid plans terminate their episode without executing a step (black_box_wrapper.py:169-172)
             self.done |= (~valid).to(torch.uint8)

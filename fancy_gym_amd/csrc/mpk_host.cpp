@@ -698,7 +698,22 @@ int mpk_traj_validity(mpk_handle hh, const float* pos, const float* params, cons
     if (B <= 0 || T <= 0) return MPK_OK;
     MPK_HIP(hipSetDevice(h->cfg.device));
     return launch_validity(pos, params, h->dev.P, h->dev.D, pos_low, pos_high, check_tau_delay, tau_bound,
-                           delay_bound, valid, B, T, stream);
+                           delay_bound, valid, nullptr, B, T, stream);
+}
+
+int mpk_traj_validity_penalty(mpk_handle hh, const float* pos, const float* params, const double* pos_low,
+                              const double* pos_high, int32_t check_tau_delay, const double tau_bound[2],
+                              const double delay_bound[2], uint8_t* valid, double* penalty, int32_t B, int32_t T,
+                              void* stream) {
+    if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (!pos || !pos_low || !pos_high || !valid || !penalty) { set_error("NULL buffer"); return MPK_EINVAL; }
+    if (check_tau_delay && (!params || !tau_bound || !delay_bound)) { set_error("tau/delay check needs params and bounds"); return MPK_EINVAL; }
+    if (h->dev.D > kMaxDofArgs) { set_error("num_dof too large"); return MPK_EINVAL; }
+    if (B <= 0 || T <= 0) return MPK_OK;
+    MPK_HIP(hipSetDevice(h->cfg.device));
+    return launch_validity(pos, params, h->dev.P, h->dev.D, pos_low, pos_high, check_tau_delay, tau_bound,
+                           delay_bound, valid, penalty, B, T, stream);
 }
 
 int mpk_prodmp_tables(mpk_handle hh, double* y1, double* y2, double* dy1, double* dy2, double* pos_basis,

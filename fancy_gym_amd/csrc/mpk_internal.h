@@ -84,7 +84,8 @@ int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos, co
 int launch_replan_advance(int32_t* traj_steps, int32_t* plan_steps, int32_t* seg_len, uint8_t* done, int every,
                           int max_planning_times, int horizon, int T, int B, void* stream);
 int launch_validity(const float* pos, const float* params, int P, int D, const double* lo, const double* hi,
-                    int check_td, const double* tb, const double* db, uint8_t* valid, int B, int T, void* stream);
+                    int check_td, const double* tb, const double* db, uint8_t* valid, double* penalty, int B, int T,
+                    void* stream);
 
 size_t shared_tables_floats(const DevCfg& c, int* TS, int* n_out);
 

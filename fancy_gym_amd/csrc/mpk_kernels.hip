@@ -2363,33 +2363,58 @@ struct ValidArgs {
 };
 
 __global__ void __launch_bounds__(256) k_validity(const ValidArgs v, const float* __restrict__ pos,
-                                                  const float* __restrict__ params, uint8_t* __restrict__ valid) {
+                                                  const float* __restrict__ params, uint8_t* __restrict__ valid,
+                                                  double* __restrict__ penalty) {
+    __shared__ double s_lo[kMaxDofArgs], s_hi[kMaxDofArgs];   // a lane-dependent index into the kernarg arrays would
+    if (threadIdx.x < (unsigned)v.D) {                         // push the whole struct to scratch
+        const double* lo = v.lo;
+        const double* hi = v.hi;
+        s_lo[threadIdx.x] = lo[threadIdx.x];
+        s_hi[threadIdx.x] = hi[threadIdx.x];
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= v.B) return;
     const int n = v.T * v.D;
     const float* p = pos + (size_t)b * n;
     bool ok = true;
+    double over = 0.0, under = 0.0;
     for (int e = lane; e < n; e += 64) {
         const int d = e % v.D;
         const double x = (double)p[e];
-        ok = ok && (x >= v.lo[d]) && (x <= v.hi[d]);
+        ok = ok && (x >= s_lo[d]) && (x <= s_hi[d]);
+        over += fmax(x - s_hi[d], 0.0);
+        under += fmax(s_lo[d] - x, 0.0);
     }
-    if (v.check_td && lane == 0) {
+    double tpen = 0.0;
+    if (v.check_td) {
         const double tau = (double)params[(size_t)b * v.P], delay = (double)params[(size_t)b * v.P + 1];
-        ok = ok && tau >= v.tb[0] && tau <= v.tb[1] && delay >= v.db[0] && delay <= v.db[1];
+        if (lane == 0) ok = ok && tau >= v.tb[0] && tau <= v.tb[1] && delay >= v.db[0] && delay <= v.db[1];
+        tpen = 3.0 * (fmax(0.0, tau - v.tb[1]) + fmax(0.0, v.tb[0] - tau)) +
+               3.0 * (fmax(0.0, delay - v.db[1]) + fmax(0.0, v.db[0] - delay));
     }
     const bool all_ok = __all(ok);
     if (lane == 0) valid[b] = all_ok ? 1 : 0;
+    if (penalty) {
+        for (int m = 32; m >= 1; m >>= 1) {
+            over += __shfl_xor(over, m);
+            under += __shfl_xor(under, m);
+        }
+        // table_tennis_env.py:282-289: -(3*tau excess + 3*delay excess + mean(max(pos - high, 0)) + mean(max(low - pos, 0)))
+        if (lane == 0) penalty[b] = -(tpen + over / (double)n + under / (double)n);
+    }
 }
 
 int launch_validity(const float* pos, const float* params, int P, int D, const double* lo, const double* hi,
-                    int check_td, const double* tb, const double* db, uint8_t* valid, int B, int T, void* stream) {
+                    int check_td, const double* tb, const double* db, uint8_t* valid, double* penalty, int B, int T,
+                    void* stream) {
     ValidArgs v{};
     for (int d = 0; d < D; ++d) { v.lo[d] = lo[d]; v.hi[d] = hi[d]; }
     if (check_td) { v.tb[0] = tb[0]; v.tb[1] = tb[1]; v.db[0] = db[0]; v.db[1] = db[1]; }
     v.check_td = check_td; v.P = P; v.D = D; v.B = B; v.T = T;
-    hipLaunchKernelGGL(k_validity, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, v, pos, params, valid);
+    hipLaunchKernelGGL(k_validity, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, v, pos, params, valid,
+                       penalty);
     MPK_LAUNCH_CHECK();
     return MPK_OK;
 }

@@ -293,8 +293,22 @@ class TrajectoryEngine:
         return seg
 
     def traj_validity(self, pos: torch.Tensor, pos_low, pos_high, params: Optional[torch.Tensor] = None,
-                      tau_bound=None, delay_bound=None) -> torch.Tensor:
+                      tau_bound=None, delay_bound=None, with_penalty: bool = False):
+        """valid bool [B]; with_penalty: also the float64 reward of an invalid plan (table_tennis_env.py:282-289)"""
         B, T, D = pos.shape
+        if with_penalty:
+            lo_p, lo_k = _dvec(pos_low, D)
+            hi_p, hi_k = _dvec(pos_high, D)
+            check = int(params is not None and tau_bound is not None and delay_bound is not None)
+            tb = (C.c_double * 2)(*(tau_bound if check else (0.0, 0.0)))
+            db = (C.c_double * 2)(*(delay_bound if check else (0.0, 0.0)))
+            valid = torch.empty(B, dtype=torch.uint8, device=self.device)
+            pen = torch.empty(B, dtype=torch.float64, device=self.device)
+            _lib.check(self._lib.mpk_traj_validity_penalty(
+                self._h, pos.contiguous().data_ptr(), _dptr(params), C.cast(lo_p, C.c_void_p),
+                C.cast(hi_p, C.c_void_p), check, C.cast(tb, C.c_void_p), C.cast(db, C.c_void_p), valid.data_ptr(),
+                pen.data_ptr(), B, T, self._stream()))
+            return valid.bool(), pen
         lo_p, lo_k = _dvec(pos_low, D)
         hi_p, hi_k = _dvec(pos_high, D)
         check = int(params is not None and tau_bound is not None and delay_bound is not None)

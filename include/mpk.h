@@ -254,6 +254,20 @@ int mpk_traj_validity(mpk_handle h, const float* pos, const float* params, const
                       const double* pos_high, int32_t check_tau_delay, const double tau_bound[2],
                       const double delay_bound[2], uint8_t* valid, int32_t B, int32_t T, void* stream);
 
+/*
+ * mpk_traj_validity plus the reward an invalid plan earns instead of being executed (invalid_traj_callback,
+ * raw_interface_wrapper.py:103-121; TableTennisEnv._get_traj_invalid_penalty, envs/mujoco/table_tennis/
+ * table_tennis_env.py:282-289), float64:
+ *   penalty[b] = -( 3*(max(0, tau - tau_hi) + max(0, tau_lo - tau)) + 3*(max(0, delay - delay_hi) + max(0, delay_lo - delay))
+ *                   + mean_t,d max(pos - pos_high, 0) + mean_t,d max(pos_low - pos, 0) )
+ * with tau = params[b,0], delay = params[b,1] as passed (NOT clipped; terms dropped when check_tau_delay == 0).
+ * penalty dev double [B], written for every episode (0 or -0 for a valid one).
+ */
+int mpk_traj_validity_penalty(mpk_handle h, const float* pos, const float* params, const double* pos_low,
+                              const double* pos_high, int32_t check_tau_delay, const double tau_bound[2],
+                              const double delay_bound[2], uint8_t* valid, double* penalty, int32_t B, int32_t T,
+                              void* stream);
+
 /* ---- introspection used by tests / bench ------------------------------------------------------------------------ */
 
 /*

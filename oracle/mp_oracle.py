@@ -657,6 +657,24 @@ def reacher_rollout(des_pos: Array, des_vel: Array, controller: str, p_gains, d_
     return actions, rewards, q, qd
 
 
+def traj_invalid_penalty(action: Array, pos_traj: Array, pos_low: Array, pos_high: Array, tau_bound=None,
+                         delay_bound=None) -> Array:
+    """
+    Reward of a plan that fails the validity check and is not executed (BlackBoxWrapper.step -> invalid_traj_callback,
+    black_box_wrapper.py:169-172; TableTennisEnv._get_traj_invalid_penalty, envs/mujoco/table_tennis/
+    table_tennis_env.py:282-289), batched: action [B, P] (raw, unclipped; action[:, 0] = tau, action[:, 1] = delay),
+    pos_traj [B, T, D].  float64.  tau_bound / delay_bound None drops those terms.
+    """
+    action = np.asarray(action, np.float64); pos = np.asarray(pos_traj, np.float64)
+    pen = np.zeros(pos.shape[0])
+    if tau_bound is not None and delay_bound is not None:
+        pen = pen + 3 * (np.maximum(0, action[:, 0] - tau_bound[1]) + np.maximum(0, tau_bound[0] - action[:, 0]))
+        pen = pen + 3 * (np.maximum(0, action[:, 1] - delay_bound[1]) + np.maximum(0, delay_bound[0] - action[:, 1]))
+    pen = pen + np.mean(np.maximum(pos - np.asarray(pos_high, np.float64), 0), axis=(1, 2))
+    pen = pen + np.mean(np.maximum(np.asarray(pos_low, np.float64) - pos, 0), axis=(1, 2))
+    return -pen
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # replanning bookkeeping (black_box_wrapper.py:107-108,174,197-206) -- INTEGER state, bit-exact part
 # ----------------------------------------------------------------------------------------------------------------------

@@ -389,6 +389,14 @@ def test_traj_validity_matches_reference_rule():
     want = want_pos & (params[:, 0] >= tb[0]) & (params[:, 0] <= tb[1]) & (params[:, 1] >= db[0]) & (params[:, 1] <= db[1])
     got = eng.traj_validity(pos, lo, hi, torch.tensor(params, device="cuda"), tb, db).cpu().numpy()
     assert np.array_equal(got, want)
+    # the reward such a plan earns instead of being executed (table_tennis_env.py:282-289)
+    got, pen = eng.traj_validity(pos, lo, hi, torch.tensor(params, device="cuda"), tb, db, with_penalty=True)
+    assert np.array_equal(got.cpu().numpy(), want)
+    ref = O.traj_invalid_penalty(params, p, lo, hi, tb, db)
+    assert np.allclose(pen.cpu().numpy(), ref, rtol=1e-12, atol=1e-15)
+    assert np.all(ref[~want] < 0) and np.all(ref[want] == 0)
+    got, pen = eng.traj_validity(pos, lo, hi, with_penalty=True)
+    assert np.allclose(pen.cpu().numpy(), O.traj_invalid_penalty(params, p, lo, hi), rtol=1e-12, atol=1e-15)
 
 
 # ---- BatchedBlackBox --------------------------------------------------------------------------------------------------
@@ -689,3 +697,34 @@ def test_capture_episode_requirements():
     bb = _batched(CFG2, 8, plant=None)
     with pytest.raises(ValueError):
         bb.capture_episode(1)
+
+
+@pytest.mark.gpu
+def test_batched_invalid_plans_earn_the_penalty_and_do_not_move():
+    """TableTennis-style gate (table_tennis_env.py:282-309) on the batched path: the RAW tau / delay of the action are
+    checked (not the clipped ones the plan uses), invalid episodes terminate without a plant step and report the penalty"""
+    from tests.test_gpu_trajectory import PER_ROW
+    pc, bc, tc, dt, dur = PER_ROW["prodmp_learn_tau_delay"]
+    B = 200
+    lo, hi = np.full(7, -1.2), np.full(7, 1.4)
+    bb = _batched((pc, bc, tc, dt, dur), B, plant="double_integrator", pos_limits=(lo, hi), check_tau_delay=True)
+    rng = np.random.default_rng(4)
+    params, ip, iv = inputs(pc, bc, tc, B, seed=4)
+    params = params * 0.3
+    params[:, 0] = rng.uniform(0.6, 1.7, B)       # tau_bound (0.8, 1.5): some outside
+    params[:, 1] = rng.uniform(0.0, 0.2, B)       # delay_bound (0.05, 0.15)
+    q0 = ip.astype(np.float64) * 0.3
+    bb.reset(q0)
+    out = bb.step(params)
+    pos = out["des_pos"].cpu().numpy().astype(np.float64)
+    want = (np.all((pos >= lo) & (pos <= hi), axis=(1, 2)) & (params[:, 0] >= 0.8) & (params[:, 0] <= 1.5)
+            & (params[:, 1] >= 0.05) & (params[:, 1] <= 0.15))
+    assert 0 < want.sum() < B
+    assert np.array_equal(out["valid"].cpu().numpy(), want)
+    assert np.array_equal(out["terminated"].cpu().numpy(), ~want)
+    ref = O.traj_invalid_penalty(params, pos, lo, hi, (0.8, 1.5), (0.05, 0.15))
+    assert np.allclose(out["invalid_penalty"].cpu().numpy(), ref, rtol=1e-12, atol=1e-15)
+    n = out["trajectory_length"].cpu().numpy()
+    assert np.all(n[~want] == 0) and np.all(n[want] == bb.T)
+    assert np.array_equal(out["current_pos"].cpu().numpy()[~want], q0[~want])
+    assert not np.array_equal(out["current_pos"].cpu().numpy()[want], q0[want])

@@ -553,6 +553,19 @@ int mpk_set_duration(mpk_handle hh, double duration, double dt) {
     return prealloc_cache(h);
 }
 
+int mpk_check_range(mpk_handle hh, void* stream) {
+    if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    MPK_HIP(hipSetDevice(h->cfg.device));
+    int32_t flag = 0;
+    MPK_HIP(hipMemcpyAsync(&flag, h->d_flag, sizeof(flag), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    MPK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (!flag) return MPK_OK;
+    MPK_HIP(hipMemsetAsync(h->d_flag, 0, sizeof(flag), (hipStream_t)stream));
+    set_error("Time is beyond the pre-computation range. Set larger pre-computation factor");
+    return MPK_ERANGE;
+}
+
 int mpk_unpin_tables(mpk_handle hh) {
     if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
     Handle* h = reinterpret_cast<Handle*>(hh);

@@ -103,6 +103,7 @@ class TrajectoryEngine:
         _lib.check(self._lib.mpk_create(C.byref(c), C.byref(self._h)))
         self.num_dof = self._lib.mpk_num_dof(self._h)
         self.num_params = self._lib.mpk_num_params(self._h)
+        self._host_stage = None     # pinned / device staging of trajectory_host, allocated on first use
 
     # ---- lifecycle ---------------------------------------------------------------------------------------------
     def close(self):
@@ -182,6 +183,46 @@ class TrajectoryEngine:
         _lib.check(self._lib.mpk_trajectory(self._h, params.data_ptr(), init_pos.data_ptr(), init_vel.data_ptr(),
                                             _dptr(it_t), it_s, pos.data_ptr(), vel.data_ptr(), B, self._stream()))
         return pos, vel
+
+    def check_range(self):
+        """synchronise and raise RuntimeError if a per-episode-phase ProDMP launch left the pre-computed table range"""
+        _lib.check(self._lib.mpk_check_range(self._h, self._stream()))
+
+    def trajectory_host(self, params: np.ndarray, init_pos: np.ndarray, init_vel: np.ndarray, init_time: float
+                        ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """
+        ONE episode, host arrays in, host tensors out (what BlackBoxWrapper.get_trajectory needs at B = 1): inputs travel
+        in one pinned buffer, (pos | vel) come back in one, a single stream synchronisation.  Returns CPU float32
+        tensors [T, D] -- like mp_pytorch on its default device, so fancy_gym's get_numpy does not copy again.
+        """
+        P, D, T = self.num_params, self.num_dof, self.num_steps
+        st = self._host_stage
+        if st is None or st[0] != (P, D, T):
+            n_in = P + 2 * D + 1
+            st = ((P, D, T), torch.empty(n_in, dtype=torch.float32).pin_memory(),
+                  torch.empty(n_in, dtype=torch.float32, device=self.device),
+                  torch.empty((2, T, D), dtype=torch.float32, device=self.device),
+                  torch.empty((2, T, D), dtype=torch.float32).pin_memory())
+            self._host_stage = st
+        _, h_in, d_in, d_out, h_out = st
+        buf = h_in.numpy()
+        buf[:P] = np.asarray(params, np.float32).reshape(-1)
+        buf[P:P + D] = np.asarray(init_pos, np.float32).reshape(-1)
+        buf[P + D:P + 2 * D] = np.asarray(init_vel, np.float32).reshape(-1)
+        buf[P + 2 * D] = init_time
+        d_in.copy_(h_in, non_blocking=True)
+        per_episode = bool(self.config.learn_tau or self.config.learn_delay)
+        base = d_in.data_ptr()
+        _lib.check(self._lib.mpk_trajectory(self._h, base, base + 4 * P, base + 4 * (P + D),
+                                            base + 4 * (P + 2 * D) if per_episode else None, float(init_time),
+                                            d_out[0].data_ptr(), d_out[1].data_ptr(), 1, self._stream()))
+        h_out.copy_(d_out, non_blocking=True)
+        if per_episode and self.mp_type == "prodmp":
+            self.check_range()                       # synchronises
+        else:
+            torch.cuda.current_stream().synchronize()
+        out = h_out.clone()
+        return out[0], out[1]
 
     def trajectory_actions(self, params, init_pos, init_vel, spec: RolloutSpec, c_pos, c_vel, init_time: float = 0.0,
                            out=None):

@@ -146,11 +146,9 @@ class MPInterface:
             z = torch.zeros((eng.num_steps, 0), dtype=torch.float32)
             self._pos, self._vel = z, z.clone()
             return
-        it_arg = it
-        if eng.config.learn_tau or eng.config.learn_delay:
-            it_arg = torch.tensor([it], dtype=torch.float32, device=eng.device)
-        pos, vel = eng.trajectory(self._full_params()[None], ip[None], iv[None], it_arg)
-        self._pos, self._vel = pos[0], vel[0]
+        # one episode: pinned staging in, one launch, (pos | vel) back in one copy -> CPU tensors, which is also what
+        # mp_pytorch hands to fancy_gym's get_numpy on its default device
+        self._pos, self._vel = eng.trajectory_host(self._full_params(), ip, iv, it)
 
     def get_traj_pos(self, **_ignored) -> torch.Tensor:
         if self._pos is None:

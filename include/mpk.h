@@ -144,6 +144,15 @@ int mpk_set_duration(mpk_handle h, double duration, double dt);
  * that used them are destroyed; mpk_set_duration does so implicitly (graphs captured for the previous time grid must
  * not be replayed).
  */
+/*
+ * ProDMP with a per-episode phase (learned tau / delay, per-episode init_time): a scaled time beyond the pre-computed
+ * table range cannot be detected on the host (it depends on device-resident parameters); the kernels raise a device
+ * flag and clamp the table index.  mpk_check_range synchronises `stream`, returns MPK_ERANGE (mp_pytorch: RuntimeError
+ * "Time is beyond the pre-computation range...") if any launch since the last check raised the flag, and clears it.
+ * Shared-phase calls report the condition directly from mpk_trajectory* without synchronising.
+ */
+int mpk_check_range(mpk_handle h, void* stream);
+
 int mpk_unpin_tables(mpk_handle h);
 
 /* Copies the fp32 time grid linspace(0,duration,T+1)[1:] (without init_time) to host float [T]. */

@@ -347,3 +347,27 @@ def test_per_episode_chunking_is_invisible(name, B, monkeypatch):
         rp, rv = O.get_trajectory(pc, bc, tc, params[b:b + 1], dur, dt, float(it[b]), ip[b:b + 1], iv[b:b + 1],
                                   dtype=np.float64)
         close(ref[0][b:b + 1].cpu().numpy(), rp, "pos")
+
+
+def test_per_episode_prodmp_range_error_is_reported():
+    """learned tau small enough that the plan leaves the pre-computed table (scaled time > 6): the single-episode path
+    raises like mp_pytorch; the batched path clamps and reports through check_range()"""
+    pc = O.PhaseCfg("exp", tau=1.0, alpha_phase=3.0, learn_tau=True, tau_bound=(0.01, 2.0))
+    bc = O.BasisCfg("prodmp", num_basis=4, alpha=10)
+    tc = O.TrajCfg("prodmp", action_dim=3)
+    eng = make_engine(pc, bc, tc, 0.02, 1.0)
+    params, ip, iv = inputs(pc, bc, tc, 4, seed=1)
+    params[:, 0] = [1.0, 0.9, 0.1, 1.2]          # duration / 0.1 = 10 > 6
+    eng.trajectory(params, ip, iv, torch.zeros(4, device="cuda"))
+    with pytest.raises(RuntimeError, match="pre-computation range"):
+        eng.check_range()
+    eng.check_range()                             # the flag is cleared by the check
+    params[:, 0] = 1.0
+    eng.trajectory(params, ip, iv, torch.zeros(4, device="cuda"))
+    eng.check_range()
+    with pytest.raises(RuntimeError, match="pre-computation range"):
+        eng.trajectory_host(np.concatenate([[0.1], params[0, 1:]]).astype(np.float32), ip[0], iv[0], 0.0)
+    pos, vel = eng.trajectory_host(params[0], ip[0], iv[0], 0.0)
+    rp, rv = O.get_trajectory(pc, bc, tc, params[:1], 1.0, 0.02, 0.0, ip[:1], iv[:1], dtype=np.float64)
+    assert not pos.is_cuda and pos.shape == (50, 3)
+    close(pos.numpy()[None], rp, "pos"); close(vel.numpy()[None], rv, "vel")

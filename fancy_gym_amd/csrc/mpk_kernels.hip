@@ -2185,70 +2185,140 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// k_reacher_rollout: k_pd_rollout + SimpleReacherEnv's per-step reward (simple_reacher.py:56-72): one lane per
-// episode (the reward couples the DoFs: cumulative joint angles -> end effector, base_reacher.py:97-104), plant
-// state in an LDS column per lane, float64 without FMA contraction
+// k_reacher_rollout: k_pd_rollout + SimpleReacherEnv's per-step reward (simple_reacher.py:56-72).  One lane per
+// (episode, DoF), 64 / D episodes per wave; the reward couples an episode's DoFs (cumulative joint angles -> end
+// effector, base_reacher.py:97-104), which is a segmented scan over the D neighbouring lanes.  float64 without FMA
+// contraction; controller, clip and plant are the operations of k_pd_rollout (bit-exact), the scans add in tree order
+// (numpy: left to right), so rewards agree with the oracle to rounding, not bit for bit.
 // ------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_reacher_rollout(const RolloutDev rc, const int D,
-                                                        const float* __restrict__ des_pos,
-                                                        const float* __restrict__ des_vel, double* __restrict__ Q,
-                                                        double* __restrict__ QD, const int32_t* __restrict__ n_steps,
-                                                        const int32_t* __restrict__ step0,
-                                                        const double* __restrict__ goal, const int steps_before_reward,
-                                                        float* __restrict__ actions, double* __restrict__ rewards,
-                                                        const int B, const int T) {
-    extern __shared__ __attribute__((aligned(16))) double sst[];   // [2][D][64]
-    const int lane = threadIdx.x;
-    const int b = (int)blockIdx.x * 64 + lane;
-    if (b >= B) return;
-    double* sq = sst + lane;
-    double* sqd = sst + (size_t)D * 64 + lane;
-    for (int d = 0; d < D; ++d) {
-        sq[d * 64] = Q[(size_t)b * D + d];
-        sqd[d * 64] = QD[(size_t)b * D + d];
+// sin and cos of one float64 angle with a shared three-term Cody-Waite reduction by pi/2 and the classic degree-13 /
+// degree-14 kernels on [-pi/4, pi/4] (coefficients of fdlibm's __kernel_sin / __kernel_cos): ~1 ulp for |x| < 1e6, a
+// quarter of the instructions of two library calls.  Larger angles (a plant spun far out of range) take the library.
+__device__ __forceinline__ void sincos_lean(double x, double* sn, double* cs) {
+    if (!(fabs(x) < 1.0e6)) { sincos(x, sn, cs); return; }
+    const double k = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-k, 1.57079632673412561417e+00, x);
+    r = fma(-k, 6.07710050630396597660e-11, r);
+    r = fma(-k, 2.02226624879595063154e-21, r);
+    const double z = r * r;
+    double ps = 1.58969099521155010221e-10;
+    ps = fma(ps, z, -2.50507602534068634195e-08);
+    ps = fma(ps, z, 2.75573137070700676789e-06);
+    ps = fma(ps, z, -1.98412698298579493134e-04);
+    ps = fma(ps, z, 8.33333333332248946124e-03);
+    ps = fma(ps, z, -1.66666666666666324348e-01);
+    const double s = fma(r * z, ps, r);
+    double pc = -1.13596475577881948265e-11;
+    pc = fma(pc, z, 2.08757232129817482790e-09);
+    pc = fma(pc, z, -2.75573143513906633035e-07);
+    pc = fma(pc, z, 2.48015872894767294178e-05);
+    pc = fma(pc, z, -1.38888888888741095749e-03);
+    pc = fma(pc, z, 4.16666666666666019037e-02);
+    const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const int q = (int)k & 3;
+    const double a = (q & 1) ? c : s, b = (q & 1) ? s : c;
+    *sn = (q & 2) ? -a : a;
+    *cs = ((q + 1) & 2) ? -b : b;
+}
+
+__device__ __forceinline__ double seg_scan(double v, int d, int D) {
+    // inclusive prefix sum over the D consecutive lanes of a segment (lane's position d)
+    for (int off = 1; off < D; off <<= 1) {
+        const double up = __shfl_up(v, off);
+        if (d >= off) v += up;
     }
+    return v;
+}
+
+__device__ __forceinline__ void seg_scan3(double& a, double& b, double& c, int d, int D) {
+    // three scans sharing the source-lane arithmetic and the predicate
+    for (int off = 1; off < D; off <<= 1) {
+        const double ua = __shfl_up(a, off), ub = __shfl_up(b, off), uc = __shfl_up(c, off);
+        if (d >= off) { a += ua; b += ub; c += uc; }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_reacher_rollout(const RolloutDev rc, const int D,
+                                                         const float* __restrict__ des_pos,
+                                                         const float* __restrict__ des_vel, double* __restrict__ Q,
+                                                         double* __restrict__ QD, const int32_t* __restrict__ n_steps,
+                                                         const int32_t* __restrict__ step0,
+                                                         const double* __restrict__ goal, const int steps_before_reward,
+                                                         float* __restrict__ actions, double* __restrict__ rewards,
+                                                         const int B, const int T) {
+    __shared__ double s_g[4 * kMaxDofArgs];      // gains / bounds: a lane-dependent index into the kernarg arrays would
+    if (threadIdx.x < (unsigned)D) {            // push the whole struct to scratch
+        const double *pg = rc.pg, *dg = rc.dg, *lo = rc.lo, *hi = rc.hi;
+        s_g[threadIdx.x] = pg[threadIdx.x];
+        s_g[kMaxDofArgs + threadIdx.x] = dg[threadIdx.x];
+        s_g[2 * kMaxDofArgs + threadIdx.x] = lo[threadIdx.x];
+        s_g[3 * kMaxDofArgs + threadIdx.x] = hi[threadIdx.x];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int epw = 64 / D;                                       // episodes per wave
+    const int el = lane / D, d = lane - el * D;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long bl = wave * epw + el;
+    const bool on = el < epw && bl < B;
+    const int b = on ? (int)bl : 0;
+    const size_t sidx = (size_t)b * D + d;
+    double q = on ? Q[sidx] : 0.0, qd = on ? QD[sidx] : 0.0;
     int n = n_steps ? n_steps[b] : T;
-    n = n < T ? n : T;
+    n = !on ? 0 : (n < T ? n : T);
     const int s0 = step0 ? step0[b] : 0;
     const double gx = goal[2 * (size_t)b], gy = goal[2 * (size_t)b + 1];
+    const double pg = s_g[d], dg = s_g[kMaxDofArgs + d], lo = s_g[2 * kMaxDofArgs + d], hi = s_g[3 * kMaxDofArgs + d];
     const double dt = rc.dt;
-    for (int t = 0; t < T; ++t) {
-        const size_t row = ((size_t)b * T + t) * D;
-        if (t >= n) {
-            if (actions) for (int d = 0; d < D; ++d) actions[row + d] = 0.0f;
-            rewards[(size_t)b * T + t] = 0.0;
-            continue;
+    int nmax = n;                                                 // the wave runs to its longest episode
+    for (int m = 32; m >= 1; m >>= 1) nmax = max(nmax, __shfl_xor(nmax, m));
+    const size_t base = (size_t)b * T * D + d;
+    constexpr int kAhead = 8;                                     // desired states are fetched 8 steps at a time: one
+    for (int t0 = 0; t0 < nmax; t0 += kAhead) {                  // memory round trip per 8 serial steps, not per step
+        float dpv[kAhead], dvv[kAhead];
+#pragma unroll
+        for (int i = 0; i < kAhead; ++i) {
+            const bool ld = t0 + i < n;
+            dpv[i] = ld ? des_pos[base + (size_t)(t0 + i) * D] : 0.0f;
+            dvv[i] = ld ? des_vel[base + (size_t)(t0 + i) * D] : 0.0f;
         }
-        double ang = 0.0, ex = 0.0, ey = 0.0, ctrl = 0.0;
-        for (int d = 0; d < D; ++d) {
-            const double dp = (double)des_pos[row + d], dv = (double)des_vel[row + d];
-            double q = sq[d * 64], qd = sqd[d * 64];
-            const double pg = rc.pg[d], dg = rc.dg[d];   // d is wave-uniform: scalar loads from the kernarg segment
-            double u;
-            if (rc.controller_type == MPK_CTRL_MOTOR) u = pg * (dp - q) + dg * (dv - qd);
-            else if (rc.controller_type == MPK_CTRL_POSITION) u = dp;
-            else u = dv;
-            u = fmin(fmax(u, rc.lo[d]), rc.hi[d]);
-            qd = qd + dt * u;                  // base_reacher_torque.py:25-26
-            q = q + dt * qd;
-            sq[d * 64] = q; sqd[d * 64] = qd;
-            if (actions) actions[row + d] = (float)u;
-            ang = d == 0 ? q : ang + q;        // np.cumsum(joint_angles)
-            const double cx = cos(ang), sy = sin(ang);
-            ex = d == 0 ? cx : ex + cx;        // unit link lengths (base_reacher.py:19), cumsum over the links
-            ey = d == 0 ? sy : ey + sy;
-            ctrl = d == 0 ? u * u : ctrl + u * u;
+#pragma unroll
+        for (int i = 0; i < kAhead; ++i) {
+            const int t = t0 + i;
+            if (t >= nmax) break;
+            const bool live = t < n;
+            double u = 0.0;
+            if (live) {
+                const double dp = (double)dpv[i], dv = (double)dvv[i];
+                if (rc.controller_type == MPK_CTRL_MOTOR) u = pg * (dp - q) + dg * (dv - qd);
+                else if (rc.controller_type == MPK_CTRL_POSITION) u = dp;
+                else u = dv;
+                u = fmin(fmax(u, lo), hi);
+                qd = qd + dt * u;                  // base_reacher_torque.py:25-26
+                q = q + dt * qd;
+                if (actions) actions[base + (size_t)t * D] = (float)u;
+            }
+            const double ang = seg_scan(q, d, D);               // np.cumsum(joint_angles)
+            double sn, cs;
+            sincos_lean(ang, &sn, &cs);
+            double ex = cs, ey = sn, ctrl = u * u;              // unit link lengths (base_reacher.py:19): sums over the links
+            seg_scan3(ex, ey, ctrl, d, D);
+            if (live && d == D - 1) {
+                double rdist = 0.0;
+                if (s0 + t >= steps_before_reward) {
+                    const double dx = ex - gx, dy = ey - gy;
+                    rdist = 0.0 - sqrt(dx * dx + dy * dy);
+                }
+                rewards[(size_t)b * T + t] = rdist - ctrl;
+            }
         }
-        double rdist = 0.0;
-        if (s0 + t >= steps_before_reward) {
-            const double dx = ex - gx, dy = ey - gy;
-            rdist = 0.0 - sqrt(dx * dx + dy * dy);
-        }
-        rewards[(size_t)b * T + t] = rdist - ctrl;
     }
-    for (int d = 0; d < D; ++d) {
-        Q[(size_t)b * D + d] = sq[d * 64];
-        QD[(size_t)b * D + d] = sqd[d * 64];
+    if (on) {
+        for (int t = n; t < T; ++t) {
+            if (actions) actions[base + (size_t)t * D] = 0.0f;
+            if (d == D - 1) rewards[(size_t)b * T + t] = 0.0;
+        }
+        Q[sidx] = q; QD[sidx] = qd;
     }
 }
 
@@ -2256,10 +2326,10 @@ int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
                            const float* des_vel, double* q, double* qd, const int32_t* n_steps, const int32_t* step0,
                            const double* goal, int steps_before_reward, float* actions, double* rewards, int B, int T,
                            void* stream) {
-    const size_t lds = (size_t)2 * D * 64 * sizeof(double);
-    if (lds > 64 * 1024) { set_error("reacher rollout supports at most 64 links"); return MPK_EINVAL; }
-    hipLaunchKernelGGL(k_reacher_rollout, dim3((B + 63) / 64), dim3(64), lds, (hipStream_t)stream, rc, D, des_pos,
-                       des_vel, q, qd, n_steps, step0, goal, steps_before_reward, actions, rewards, B, T);
+    const int epw = 64 / D;
+    const long waves = ((long)B + epw - 1) / epw;
+    hipLaunchKernelGGL(k_reacher_rollout, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rc, D,
+                       des_pos, des_vel, q, qd, n_steps, step0, goal, steps_before_reward, actions, rewards, B, T);
     MPK_LAUNCH_CHECK();
     return MPK_OK;
 }

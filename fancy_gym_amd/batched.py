@@ -199,9 +199,7 @@ class BatchedBlackBox:
         out.update(valid=valid, trajectory_length=seg, done=self.done.bool(), terminated=~valid & ~was_done,
                    truncated=self.done.bool() & valid)
         if self.condition_on_desired:
-            last = (seg.long() - 1).clamp_(min=0)[:, None, None].expand(-1, 1, self.D)
-            self.condition_pos = pos.gather(1, last)[:, 0].contiguous()
-            self.condition_vel = vel.gather(1, last)[:, 0].contiguous()
+            self.condition_pos, self.condition_vel = self.engine.condition_gather(pos, vel, seg)
         if self.do_replanning and self._lockstep is not None:
             if self.pos_limits is None:
                 # no validity gate: every episode follows the same integer sequence, which the host can mirror without
@@ -231,7 +229,6 @@ class BatchedBlackBox:
                 pos, self.pos_limits[0], self.pos_limits[1], raw if self.check_tau_delay else None,
                 self.tau_bound if self.check_tau_delay else None,
                 self.delay_bound if self.check_tau_delay else None, with_penalty=True)
-        if not bool(valid.all()):
             # invalid plans terminate their episode without executing a step (black_box_wrapper.py:169-172)
             self.done |= (~valid).to(torch.uint8)
         mpt = self.max_planning_times if math.isfinite(self.max_planning_times) else 2 ** 31 - 1

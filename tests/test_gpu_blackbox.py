@@ -728,3 +728,19 @@ def test_batched_invalid_plans_earn_the_penalty_and_do_not_move():
     assert np.all(n[~want] == 0) and np.all(n[want] == bb.T)
     assert np.array_equal(out["current_pos"].cpu().numpy()[~want], q0[~want])
     assert not np.array_equal(out["current_pos"].cpu().numpy()[want], q0[want])
+
+
+@pytest.mark.gpu
+def test_episode_search_on_the_device_reacher_improves_the_return():
+    """examples/batched_reacher_search.py end to end: plan -> track -> reward -> return on the GPU, one captured graph
+    per generation; cross-entropy search must find better parameters than it started with"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("batched_reacher_search",
+                                                  os.path.join(os.path.dirname(GOLD), "..", "examples",
+                                                               "batched_reacher_search.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    hist = mod.search(pop=512, iters=12, links=5, seed=1, verbose=False)
+    best = [h[0] for h in hist]
+    assert np.isfinite(best).all()
+    assert best[-1] > best[0] and max(best[-3:]) > best[0] + 0.5 * abs(best[0]) * 0.2

@@ -614,14 +614,22 @@ int mpk_trajectory_actions(mpk_handle hh, const float* params, const float* init
                            const double* c_vel, float* pos, float* vel, float* actions, int32_t B, void* stream) {
     if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
     Handle* h = reinterpret_cast<Handle*>(hh);
+    if (B == 0) return MPK_OK;
     if (!actions || !c_pos || !c_vel) { set_error("NULL buffer"); return MPK_EINVAL; }
-    if (h->cfg.mp_type == MPK_MP_DMP) { set_error("fused actions are not available for dmp"); return MPK_EINVAL; }
     RolloutDev rd;
     int r = fill_rollout(h, rc, &rd);
     if (r != MPK_OK) return r;
-    if (rd.plant_type != MPK_PLANT_STATIC) { set_error("fused actions need MPK_PLANT_STATIC; use mpk_pd_rollout"); return MPK_EINVAL; }
-    return traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, actions, &rd, c_pos,
-                       c_vel, B, stream);
+    if (rd.plant_type != MPK_PLANT_STATIC) { set_error("mpk_trajectory_actions tracks a frozen state (MPK_PLANT_STATIC); use mpk_trajectory_rollout"); return MPK_EINVAL; }
+    if (h->cfg.mp_type != MPK_MP_DMP && shared_phase(h, nullptr) && mfma_capable(h))
+        return traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, actions, &rd, c_pos,
+                           c_vel, B, stream);
+    // what the single fused kernel does not cover (dmp, learned tau / delay, > 16 DoF or basis columns): same result
+    // from two launches
+    r = traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, nullptr, nullptr, nullptr,
+                    nullptr, B, stream);
+    if (r != MPK_OK) return r;
+    return launch_pd_rollout(rd, h->dev.D, pos, vel, const_cast<double*>(c_pos), const_cast<double*>(c_vel), nullptr,
+                             actions, B, h->dev.T, stream);
 }
 
 int mpk_trajectory_rollout(mpk_handle hh, const float* params, const float* init_pos, const float* init_vel,
@@ -631,14 +639,18 @@ int mpk_trajectory_rollout(mpk_handle hh, const float* params, const float* init
     Handle* h = reinterpret_cast<Handle*>(hh);
     if (B == 0) return MPK_OK;
     if (!actions || !q || !qd) { set_error("NULL buffer"); return MPK_EINVAL; }
-    if (h->cfg.mp_type == MPK_MP_DMP) { set_error("the fused rollout is not available for dmp; use mpk_trajectory + mpk_pd_rollout"); return MPK_EINVAL; }
     RolloutDev rd;
     int r = fill_rollout(h, rc, &rd);
     if (r != MPK_OK) return r;
-    if (rd.plant_type != MPK_PLANT_DOUBLE_INTEGRATOR) { set_error("the fused rollout integrates MPK_PLANT_DOUBLE_INTEGRATOR; for a frozen state use mpk_trajectory_actions"); return MPK_EINVAL; }
-    if (!shared_phase(h, nullptr) || !mfma_capable(h)) { set_error("the fused rollout needs a shared-phase configuration with D <= 16 and <= 16 basis columns"); return MPK_EINVAL; }
-    return traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, actions, &rd, nullptr,
-                       nullptr, B, stream, q, qd, n_steps);
+    if (rd.plant_type != MPK_PLANT_DOUBLE_INTEGRATOR) { set_error("mpk_trajectory_rollout integrates MPK_PLANT_DOUBLE_INTEGRATOR; for a frozen state use mpk_trajectory_actions"); return MPK_EINVAL; }
+    if (h->cfg.mp_type != MPK_MP_DMP && shared_phase(h, nullptr) && mfma_capable(h))
+        return traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, actions, &rd, nullptr,
+                           nullptr, B, stream, q, qd, n_steps);
+    // dmp, learned tau / delay, > 16 DoF or basis columns: trajectory kernel + rollout kernel, same result
+    r = traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, nullptr, nullptr, nullptr,
+                    nullptr, B, stream);
+    if (r != MPK_OK) return r;
+    return launch_pd_rollout(rd, h->dev.D, pos, vel, q, qd, n_steps, actions, B, h->dev.T, stream);
 }
 
 int mpk_pd_rollout(mpk_handle hh, const mpk_rollout_cfg* rc, const float* des_pos, const float* des_vel, double* q,

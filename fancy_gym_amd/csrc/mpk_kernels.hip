@@ -2075,8 +2075,10 @@ __global__ void __launch_bounds__(256) k_pd_rollout(const RolloutDev rc, const i
         }
         if (actions) actions[base + (size_t)t * D] = (float)u;
     }
-    Q[e] = q;
-    QD[e] = qd;
+    if (rc.plant_type != MPK_PLANT_STATIC) {     // a static plant's state is an input only (callers may hold it const)
+        Q[e] = q;
+        QD[e] = qd;
+    }
 }
 
 // Tile-streaming variant (D <= 16, float4-aligned trajectories): a wave owns a group of 16/DP episodes and walks their
@@ -2179,7 +2181,7 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
         }
         if (serial) {
             const size_t si = (size_t)(b0 + bl) * D + d;
-            a.Q[si] = qs; a.QD[si] = qds;
+            if (a.rc.plant_type != MPK_PLANT_STATIC) { a.Q[si] = qs; a.QD[si] = qds; }
         }
     }
 }

@@ -178,7 +178,8 @@ int mpk_trajectory(mpk_handle h, const float* params, const float* init_pos, con
  * Same, fused with the open-loop part of the step loop (black_box_wrapper.py:176-179): additionally writes
  *   actions[b,t,:] = clip(controller(pos[b,t], vel[b,t], c_pos[b], c_vel[b]), act_low, act_high)
  * for a state that does not change during the plan (MPK_PLANT_STATIC).  c_pos/c_vel dev double [B, D].
- * Shared-phase configurations only.
+ * One launch for shared-phase promp / prodmp configurations with <= 16 DoF and <= 16 basis columns, trajectory kernel
+ * + rollout kernel for every other configuration; identical results either way.
  */
 int mpk_trajectory_actions(mpk_handle h, const float* params, const float* init_pos, const float* init_vel,
                            double init_time_shared, const mpk_rollout_cfg* rc,
@@ -192,7 +193,9 @@ int mpk_trajectory_actions(mpk_handle h, const float* params, const float* init_
  *   q, qd     dev double [B, D]  in: plant state at plan start, out: state after the executed steps
  *   n_steps   dev int32 [B] or NULL (= T): the break index of :197 (see mpk_replan_advance)
  *   pos, vel, actions dev float [B, T, D] outputs (actions beyond n_steps[b] are 0)
- * Shared-phase, non-dmp configurations only; numerically identical to mpk_trajectory followed by mpk_pd_rollout.
+ * One launch for shared-phase promp / prodmp configurations with <= 16 DoF and <= 16 basis columns; every other
+ * configuration (dmp, learned tau / delay, larger shapes) runs the trajectory kernel and the rollout kernel back to
+ * back.  Either way the result is identical to mpk_trajectory followed by mpk_pd_rollout.
  */
 int mpk_trajectory_rollout(mpk_handle h, const float* params, const float* init_pos, const float* init_vel,
                            double init_time_shared, const mpk_rollout_cfg* rc, double* q, double* qd,

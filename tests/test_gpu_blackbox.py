@@ -339,12 +339,38 @@ def test_pd_rollout_on_every_shape_class(D, T):
     assert np.array_equal(q2.cpu().numpy(), rq)
 
 
-def test_fused_actions_rejects_what_it_cannot_fuse():
-    pc, bc, tc, dt, dur = CFG3
+@pytest.mark.parametrize("name", ["cfg3_dmp", "prodmp_learn_tau_delay", "promp_learn_tau"])
+def test_fused_entry_points_cover_every_configuration(name):
+    """what the single fused kernel does not cover (dmp, learned tau / delay) runs as trajectory + rollout kernels behind
+    the same entry points: actions / plant state bit-exact against the oracle, c_pos / c_vel left untouched"""
+    from tests.test_gpu_trajectory import PER_ROW
+    pc, bc, tc, dt, dur = CFG3 if name == "cfg3_dmp" else PER_ROW[name]
     eng = make_engine(pc, bc, tc, dt, dur)
-    params, ip, iv = inputs(pc, bc, tc, 4)
-    with pytest.raises(ValueError):
-        eng.trajectory_actions(params, ip, iv, RolloutSpec("motor", 7, 1.0, 0.1, -1, 1), ip, iv)
+    D, B = eng.num_dof, 33
+    params, ip, iv = inputs(pc, bc, tc, B, seed=5)
+    pg, dg = np.linspace(0.5, 1.5, D), np.linspace(0.05, 0.1, D)
+    cp, cv = ip.astype(np.float64) * 0.5, iv.astype(np.float64) + 0.1
+    cpt, cvt = torch.tensor(cp, device="cuda"), torch.tensor(cv, device="cuda")
+    pos, vel, act = eng.trajectory_actions(params, ip, iv, RolloutSpec("motor", D, pg, dg, -1, 1, plant="static"),
+                                           cpt, cvt)
+    torch.cuda.synchronize()
+    p0, v0 = eng.trajectory(params, ip, iv, 0.0)
+    assert torch.equal(pos, p0) and torch.equal(vel, v0)
+    ra, _, _ = O.rollout(pos.cpu().numpy(), vel.cpu().numpy(), "motor", pg, dg, -1, 1, "static", dt, cp, cv)
+    assert np.array_equal(act.cpu().numpy(), ra.astype(np.float32))
+    assert np.array_equal(cpt.cpu().numpy(), cp) and np.array_equal(cvt.cpu().numpy(), cv)
+    q, qd = torch.tensor(cp, device="cuda"), torch.tensor(cv, device="cuda")
+    n_steps = np.random.default_rng(0).integers(0, eng.num_steps + 1, B).astype(np.int32)
+    pos, vel, act = eng.trajectory_rollout(params, ip, iv,
+                                           RolloutSpec("motor", D, pg, dg, -1, 1, plant="double_integrator", dt=dt),
+                                           q, qd, n_steps=torch.tensor(n_steps))
+    ra, rq, rqd = O.rollout(pos.cpu().numpy(), vel.cpu().numpy(), "motor", pg, dg, -1, 1, "double_integrator", dt, cp,
+                            cv, n_steps=n_steps)
+    assert torch.equal(pos, p0) and np.array_equal(act.cpu().numpy(), ra.astype(np.float32))
+    assert np.array_equal(q.cpu().numpy(), rq) and np.array_equal(qd.cpu().numpy(), rqd)
+
+
+def test_rollout_spec_rejects_unknown_controllers_and_bad_gains():
     with pytest.raises(ValueError):
         RolloutSpec("metaworld", 7)
     with pytest.raises(ValueError):

@@ -90,6 +90,7 @@ class BatchedBlackBox:
         self._lockstep = 0          # traj_steps of every live episode while the schedule keeps them in lockstep
         self._host_plans = 0
         self._const_flags = None    # (all-True, all-False) [B], shared by every fused step's result
+        self._phase_bounds = None   # [2, n_phase] bounds of the learned tau / delay, on the device
 
     # ---- episode control ---------------------------------------------------------------------------------------------
     def reset(self, init_pos=None, init_vel=None, goal=None):
@@ -124,7 +125,8 @@ class BatchedBlackBox:
         return self.engine.params_bounds()
 
     # ---- plan ----------------------------------------------------------------------------------------------------------
-    def get_trajectory(self, params) -> Dict[str, torch.Tensor]:
+    def _plan_params(self, params) -> torch.Tensor:
+        """[B, P] float32 on the device, with the phase parameters the episode froze at its first plan"""
         params = torch.as_tensor(params, dtype=torch.float32, device=self.device)
         if params.shape != (self.B, self.engine.num_params):
             raise ValueError(f"params must be [{self.B}, {self.engine.num_params}], got {tuple(params.shape)}")
@@ -132,12 +134,17 @@ class BatchedBlackBox:
             # tau / delay are frozen by the first plan of an episode (mp_pytorch 'finalize'; pinned by
             # test/test_replanning_sequencing.py:231-335): later plans reuse them
             if self._frozen_phase is None:
-                lo = torch.as_tensor(self.engine.params_bounds(), device=self.device)
-                head = torch.minimum(torch.maximum(params[:, :self._n_phase], lo[0, :self._n_phase]),
-                                     lo[1, :self._n_phase])
-                self._frozen_phase = head.clone()
+                if self._phase_bounds is None:
+                    self._phase_bounds = torch.as_tensor(self.engine.params_bounds()[:, :self._n_phase],
+                                                         device=self.device)
+                lo = self._phase_bounds
+                self._frozen_phase = torch.minimum(torch.maximum(params[:, :self._n_phase], lo[0]), lo[1])
             params = params.clone()
             params[:, :self._n_phase] = self._frozen_phase
+        return params
+
+    def get_trajectory(self, params) -> Dict[str, torch.Tensor]:
+        params = self._plan_params(params)
         cond_pos = self.condition_pos if self.condition_pos is not None else self.q.float()
         cond_vel = self.condition_vel if self.condition_vel is not None else self.qd.float()
         if self.do_replanning and self._lockstep is None:
@@ -160,19 +167,16 @@ class BatchedBlackBox:
         return max(1, min(g_break - cur, self.T))
 
     def _can_fuse(self) -> bool:
-        """one launch for plan + execute: shared phase, double-integrator plant, no validity gate, MFMA-capable shape"""
-        cfg = self.engine.config
+        """plan + execute through mpk_trajectory_rollout (one launch for shared-phase promp / prodmp, two otherwise) with
+        four device operations per plan: needs the device plant, no validity gate, no device reward, and episodes that
+        still move in lockstep (one init_time for all)"""
         return (self.spec is not None and self.plant == "double_integrator" and self.pos_limits is None
-                and self.reward is None and self._n_phase == 0 and self.engine.mp_type != "dmp" and self.D <= 16
-                and (not self.do_replanning or self._lockstep is not None)
-                and (cfg.num_basis + 3 if self.engine.mp_type == "prodmp" else cfg.num_basis + 1) <= 16)
+                and self.reward is None and (not self.do_replanning or self._lockstep is not None))
 
     def _step_fused(self, params) -> Dict[str, torch.Tensor]:
         """plan + execute in one launch; four device operations per plan (integer state, trajectory + rollout, condition
         gather, the bool view of `done`) -- at a few thousand episodes the step is bound by their launch cost"""
-        params = torch.as_tensor(params, dtype=torch.float32, device=self.device)
-        if params.shape != (self.B, self.engine.num_params):
-            raise ValueError(f"params must be [{self.B}, {self.engine.num_params}], got {tuple(params.shape)}")
+        params = self._plan_params(params)
         cond_pos = self.condition_pos if self.condition_pos is not None else self.q.float()
         cond_vel = self.condition_vel if self.condition_vel is not None else self.qd.float()
         init_time = float(self._lockstep * self.dt) if self.do_replanning else 0.0

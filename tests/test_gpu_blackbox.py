@@ -491,22 +491,35 @@ def test_batched_replanning_follows_the_single_episode_sequence():
         cond_p, cond_v = dp[:, n - 1], dv[:, n - 1]           # condition on the desired state where the plan broke
 
 
-def test_batched_fused_and_unfused_steps_agree_bitwise():
+@pytest.mark.parametrize("name", ["cfg4", "cfg3_dmp", "prodmp_learn_tau_delay"])
+def test_batched_fused_and_unfused_steps_agree_bitwise(name):
+    """the lean step (mpk_trajectory_rollout: one launch for shared-phase promp / prodmp, two for dmp and learned tau /
+    delay) against the step assembled from separate calls, over a replanned episode"""
+    from tests.test_gpu_trajectory import PER_ROW
+    cfg = {"cfg4": CFG4, "cfg3_dmp": CFG3}.get(name) or PER_ROW[name]
     rng = np.random.default_rng(5)
     B = 40
-    q0 = rng.uniform(-1, 1, (B, 7))
+    q0 = rng.uniform(-1, 1, (B, 7)) * 0.2
     outs = []
     for fuse in (True, False):
-        bb = _batched(CFG4, B, plant="double_integrator", replanning_every=25, max_planning_times=4,
-                      condition_on_desired=True)
+        T = int(round(cfg[4] / cfg[3]))
+        bb = _batched(cfg, B, plant="double_integrator", replanning_every=T // 4, max_planning_times=4,
+                      condition_on_desired=name != "cfg3_dmp")
         bb.reset(q0)
+        P = bb.engine.num_params
         r = np.random.default_rng(6)
         seq = []
         for _ in range(4):
-            o = bb.step(r.standard_normal((B, 35)).astype(np.float32), fuse=fuse)
-            seq.append({k: o[k].clone() for k in ("des_pos", "des_vel", "step_actions", "current_pos", "trajectory_length")})
+            params = (r.standard_normal((B, P)) * 0.3).astype(np.float32)
+            if name == "prodmp_learn_tau_delay":
+                params[:, 0] = r.uniform(0.9, 1.4, B); params[:, 1] = r.uniform(0.06, 0.14, B)
+            o = bb.step(params, fuse=fuse)
+            seq.append({k: o[k].clone() for k in ("des_pos", "des_vel", "step_actions", "current_pos", "trajectory_length",
+                                                    "done")})
         outs.append(seq)
-        assert bb.engine.last_kernel().endswith("closed>") == fuse or not fuse
+        if name == "cfg4":
+            assert bb.engine.last_kernel().endswith("closed>") == fuse
+        assert bool(bb.done.all())
     for a, b in zip(*outs):
         for k in a:
             assert torch.equal(a[k], b[k]), k

@@ -783,3 +783,42 @@ def test_episode_search_on_the_device_reacher_improves_the_return():
     best = [h[0] for h in hist]
     assert np.isfinite(best).all()
     assert best[-1] > best[0] and max(best[-3:]) > best[0] + 0.5 * abs(best[0]) * 0.2
+
+
+@pytest.mark.gpu
+def test_captured_episode_with_learned_phase_and_device_reward():
+    """capture covers the two-launch plan+execute of a learned tau / delay configuration (per-episode kernel with its LDS
+    table, > 64 KB of dynamic LDS) and the unfused reward path"""
+    from tests.test_gpu_trajectory import PER_ROW
+    cfg = PER_ROW["prodmp_learn_tau_delay"]
+    B = 2100
+    rng = np.random.default_rng(8)
+    bb = _batched(cfg, B, plant="double_integrator")
+    ep = bb.capture_episode(1)
+    ref = _batched(cfg, B, plant="double_integrator")
+    for trial in range(2):
+        q0 = rng.uniform(-0.2, 0.2, (B, 7))
+        params = (rng.standard_normal((B, bb.engine.num_params)) * 0.3).astype(np.float32)
+        params[:, 0] = rng.uniform(0.9, 1.4, B); params[:, 1] = rng.uniform(0.06, 0.14, B)
+        ep.init_pos.copy_(torch.tensor(q0)); ep.params[0].copy_(torch.tensor(params))
+        got = {k: v.clone() for k, v in ep.replay()[0].items() if torch.is_tensor(v)}
+        ref.reset(q0)
+        want = ref.step(params)
+        for key in ("des_pos", "des_vel", "step_actions", "trajectory_length", "done"):
+            assert torch.equal(got[key], want[key]), (trial, key)
+        assert torch.equal(bb.q, ref.q)
+    assert "k_traj_phase" in bb.engine.last_kernel() or bb.engine.last_kernel() == ""
+    # device reward (unfused step) inside a graph
+    from fancy_gym_amd import _gym
+    env = _gym.make("fancy_ProDMP/LongSimpleReacher-v0")
+    rb = BatchedBlackBox(env.traj_gen, env.tracking_controller, 64, dt=0.01, duration=2.0, act_low=-1000.0,
+                         act_high=1000.0, plant="double_integrator", reward="simple_reacher")
+    rep = rb.capture_episode(1)
+    rr = BatchedBlackBox(env.traj_gen, env.tracking_controller, 64, dt=0.01, duration=2.0, act_low=-1000.0,
+                         act_high=1000.0, plant="double_integrator", reward="simple_reacher")
+    q0 = rng.uniform(-1, 1, (64, 5)); goal = rng.uniform(-2, 2, (64, 2))
+    params = rng.standard_normal((64, rb.engine.num_params)).astype(np.float32)
+    rep.init_pos.copy_(torch.tensor(q0)); rep.goal.copy_(torch.tensor(goal)); rep.params[0].copy_(torch.tensor(params))
+    got = rep.replay()[0]["rewards"].clone()
+    rr.reset(q0, goal=goal)
+    assert torch.equal(got, rr.step(params)["rewards"])

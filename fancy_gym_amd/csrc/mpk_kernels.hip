@@ -2097,14 +2097,18 @@ struct PdArgs {
     unsigned inv_seg4;
 };
 
+// NG = groups per wave: with NG = 4 a wave owns four consecutive groups and lane quarter j runs group j's recurrence,
+// so four recurrences advance in parallel (the same idea as k_traj_quad); NG = 1 keeps more waves for small batches.
+template <int NG>
 __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[4 * 3 * kStageStride];
+    __shared__ __attribute__((aligned(16))) float smem[4 * NG * 3 * kStageStride];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* sSt = smem + wave * (3 * kStageStride);      // desired pos | desired vel | actions
+    float* sSt = smem + wave * (NG * 3 * kStageStride);      // per group: desired pos | desired vel | actions
     const int D = a.D, T = a.T, B = a.B, SEG = 16 * D, DP = 1 << a.sh, NTW = 16 >> a.sh;
     const int col = lane & 15, bl = col >> a.sh, d = col & (DP - 1);
-    const bool lane_serial = lane < 16 && d < D;
+    const int jq = lane >> 4;                                // the group (of this wave's NG) whose recurrence the lane runs
+    const bool lane_serial = jq < NG && d < D;
     const int seg4 = SEG >> 2;
     const int sseg = (int)(((unsigned)lane * a.inv_seg4) >> 16);
     const int w4 = (lane - sseg * seg4) * 4;
@@ -2118,41 +2122,60 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
     const double dtp = a.rc.dt;
     const int nb8 = gridDim.x >> 3;
     const int vb = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * nb8 + (blockIdx.x >> 3) : blockIdx.x;
-    for (int g = vb * 4 + wave; g < a.G; g += gridDim.x * 4) {
-        const int b0 = g * NTW;
-        const bool serial = lane_serial && b0 + bl < B;
-        const bool mover = sseg < NTW && b0 + sseg < B;
+    const int units = (a.G + NG - 1) / NG;
+    for (int un = vb * 4 + wave; un < units; un += gridDim.x * 4) {
+        const int g0 = un * NG;
+        const int bs = (g0 + jq) * NTW + bl;                 // the serial lane's episode
+        const bool serial = lane_serial && g0 + jq < a.G && bs < B;
         double qs = 0.0, qds = 0.0;
         int nst = T;
         if (serial) {
-            const size_t si = (size_t)(b0 + bl) * D + d;
+            const size_t si = (size_t)bs * D + d;
             qs = a.Q[si]; qds = a.QD[si];
-            if (a.n_steps) nst = min(a.n_steps[b0 + bl], T);
+            if (a.n_steps) nst = min(a.n_steps[bs], T);
         }
-        const float* gp = a.des_pos + (size_t)b0 * T * D + gofs;
-        const float* gv = a.des_vel + (size_t)b0 * T * D + gofs;
-        f32x4 lp = {0, 0, 0, 0}, lv = {0, 0, 0, 0};
-        if (mover && w4 < min(16, T) * D) { lp = *reinterpret_cast<const f32x4*>(gp); lv = *reinterpret_cast<const f32x4*>(gv); }
+        bool mover[NG];
+        const float* gp[NG];
+        const float* gv[NG];
+        f32x4 lp[NG], lv[NG];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int b0 = (g0 + j) * NTW;
+            mover[j] = g0 + j < a.G && sseg < NTW && b0 + sseg < B;
+            gp[j] = a.des_pos + (size_t)b0 * T * D + gofs;
+            gv[j] = a.des_vel + (size_t)b0 * T * D + gofs;
+            lp[j] = f32x4{0, 0, 0, 0}; lv[j] = lp[j];
+            if (mover[j] && w4 < min(16, T) * D) {
+                lp[j] = *reinterpret_cast<const f32x4*>(gp[j]);
+                lv[j] = *reinterpret_cast<const f32x4*>(gv[j]);
+            }
+        }
         for (int rt = 0; rt < NRT; ++rt) {
             const int rows = min(16, T - rt * 16);
-            const bool mine = mover && w4 < rows * D;
-            if (mine) {
-                *reinterpret_cast<f32x4*>(sSt + rofs) = lp;
-                *reinterpret_cast<f32x4*>(sSt + kStageStride + rofs) = lv;
+#pragma unroll
+            for (int j = 0; j < NG; ++j) {
+                if (mover[j] && w4 < rows * D) {
+                    *reinterpret_cast<f32x4*>(sSt + j * 3 * kStageStride + rofs) = lp[j];
+                    *reinterpret_cast<f32x4*>(sSt + j * 3 * kStageStride + kStageStride + rofs) = lv[j];
+                }
             }
             if (rt + 1 < NRT) {   // next tile's pieces travel under this tile's recurrence
                 const int rows_n = min(16, T - (rt + 1) * 16);
-                if (mover && w4 < rows_n * D) {
-                    lp = *reinterpret_cast<const f32x4*>(gp + (size_t)(rt + 1) * SEG);
-                    lv = *reinterpret_cast<const f32x4*>(gv + (size_t)(rt + 1) * SEG);
+#pragma unroll
+                for (int j = 0; j < NG; ++j) {
+                    if (mover[j] && w4 < rows_n * D) {
+                        lp[j] = *reinterpret_cast<const f32x4*>(gp[j] + (size_t)(rt + 1) * SEG);
+                        lv[j] = *reinterpret_cast<const f32x4*>(gv[j] + (size_t)(rt + 1) * SEG);
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
             if (serial) {
+                float* sg = sSt + jq * 3 * kStageStride;
                 const int o0 = bl * SEG + d;
                 float pr[16], vr[16];
 #pragma unroll
-                for (int tl = 0; tl < 16; ++tl) { pr[tl] = sSt[o0 + tl * D]; vr[tl] = sSt[kStageStride + o0 + tl * D]; }
+                for (int tl = 0; tl < 16; ++tl) { pr[tl] = sg[o0 + tl * D]; vr[tl] = sg[kStageStride + o0 + tl * D]; }
 #pragma unroll
                 for (int tl = 0; tl < 16; ++tl) {
                     if (tl < rows) {
@@ -2169,18 +2192,23 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
                                 qs = qs + dtp * qds;
                             }
                         }
-                        sSt[2 * kStageStride + o0 + tl * D] = (float)u;
+                        sg[2 * kStageStride + o0 + tl * D] = (float)u;
                     }
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            if (a.actions && mine)
-                *reinterpret_cast<f32x4*>(a.actions + (size_t)b0 * T * D + gofs + (size_t)rt * SEG) =
-                    *reinterpret_cast<const f32x4*>(sSt + 2 * kStageStride + rofs);
+            if (a.actions) {
+#pragma unroll
+                for (int j = 0; j < NG; ++j) {
+                    if (mover[j] && w4 < rows * D)
+                        *reinterpret_cast<f32x4*>(a.actions + (size_t)(g0 + j) * NTW * T * D + gofs + (size_t)rt * SEG) =
+                            *reinterpret_cast<const f32x4*>(sSt + j * 3 * kStageStride + 2 * kStageStride + rofs);
+                }
+            }
             __builtin_amdgcn_wave_barrier();
         }
         if (serial) {
-            const size_t si = (size_t)(b0 + bl) * D + d;
+            const size_t si = (size_t)bs * D + d;
             if (a.rc.plant_type != MPK_PLANT_STATIC) { a.Q[si] = qs; a.QD[si] = qds; }
         }
     }
@@ -2352,10 +2380,16 @@ int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const f
         const int NTW = 16 >> sh;
         pa.G = (B + NTW - 1) / NTW;
         pa.inv_seg4 = 65536u / (unsigned)(4 * D) + 1u;
-        int blocks = (pa.G + 3) / 4;
+        // four groups per wave once that still leaves every CU several waves (MPK_PD_QUAD: 0 off, 2 force)
+        int quad_mode = 1;
+        if (const char* e = getenv("MPK_PD_QUAD")) quad_mode = atoi(e);
+        const bool quad = quad_mode == 2 || (quad_mode == 1 && pa.G >= 4 * 256 * 8);
+        const int units = quad ? (pa.G + 3) / 4 : pa.G;
+        int blocks = (units + 3) / 4;
         if (blocks > 2048) blocks = 2048;
         if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;
-        hipLaunchKernelGGL(k_pd_rollout_tiles, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pa);
+        if (quad) hipLaunchKernelGGL(k_pd_rollout_tiles<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pa);
+        else hipLaunchKernelGGL(k_pd_rollout_tiles<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pa);
         MPK_LAUNCH_CHECK();
         return MPK_OK;
     }

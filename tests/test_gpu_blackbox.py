@@ -239,10 +239,11 @@ def test_single_episode_step_matches_oracle_on_a_closed_loop_plant():
 @pytest.mark.parametrize("controller", ["motor", "position", "velocity"])
 @pytest.mark.parametrize("plant", ["static", "double_integrator"])
 @pytest.mark.parametrize("B", [1, 37, 1000])
-@pytest.mark.parametrize("simple", [False, True])
+@pytest.mark.parametrize("simple", ["tiles", "simple", "quad"])
 def test_pd_rollout_is_bit_exact_in_float64(controller, plant, B, simple, monkeypatch):
-    if simple:
+    if simple == "simple":
         monkeypatch.setenv("MPK_PD_SIMPLE", "1")      # the generic one-lane-per-(episode, DoF) kernel
+    monkeypatch.setenv("MPK_PD_QUAD", "2" if simple == "quad" else "0")   # four groups per wave / one
     pc, bc, tc, dt, dur = CFG2
     eng = make_engine(pc, bc, tc, dt, dur)
     params, ip, iv = inputs(pc, bc, tc, B, seed=11)
@@ -314,10 +315,13 @@ def test_fused_closed_loop_rollout_is_bit_exact(cfg, controller, B, bulk, quad, 
     assert np.array_equal(a3.cpu().numpy(), ra.astype(np.float32)) and np.array_equal(q3.cpu().numpy(), rq)
 
 
+@pytest.mark.parametrize("quad", ["0", "2"])
 @pytest.mark.parametrize("D,T", [(1, 50), (3, 10), (4, 17), (16, 40), (5, 100), (20, 12)])
-def test_pd_rollout_on_every_shape_class(D, T):
-    """tile-streaming kernel (D <= 16, float4-aligned) and the generic kernel (everything else) against the oracle"""
+def test_pd_rollout_on_every_shape_class(D, T, quad, monkeypatch):
+    """tile-streaming kernel (D <= 16, float4-aligned; one or four groups per wave) and the generic kernel (everything
+    else) against the oracle"""
     from tests.test_gpu_edge_cases import cfg_for
+    monkeypatch.setenv("MPK_PD_QUAD", quad)
     pc, bc, tc, dt, dur = cfg_for("promp", D, 3, T)
     eng = make_engine(pc, bc, tc, dt, dur)
     B = 23

@@ -2081,6 +2081,36 @@ __global__ void __launch_bounds__(256) k_pd_rollout(const RolloutDev rc, const i
     }
 }
 
+// sin and cos of one float64 angle with a shared three-term Cody-Waite reduction by pi/2 and the classic degree-13 /
+// degree-14 kernels on [-pi/4, pi/4] (coefficients of fdlibm's __kernel_sin / __kernel_cos): ~1 ulp for |x| < 1e6, a
+// quarter of the instructions of two library calls.  Larger angles (a plant spun far out of range) take the library.
+__device__ __forceinline__ void sincos_lean(double x, double* sn, double* cs) {
+    if (!(fabs(x) < 1.0e6)) { sincos(x, sn, cs); return; }
+    const double k = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-k, 1.57079632673412561417e+00, x);
+    r = fma(-k, 6.07710050630396597660e-11, r);
+    r = fma(-k, 2.02226624879595063154e-21, r);
+    const double z = r * r;
+    double ps = 1.58969099521155010221e-10;
+    ps = fma(ps, z, -2.50507602534068634195e-08);
+    ps = fma(ps, z, 2.75573137070700676789e-06);
+    ps = fma(ps, z, -1.98412698298579493134e-04);
+    ps = fma(ps, z, 8.33333333332248946124e-03);
+    ps = fma(ps, z, -1.66666666666666324348e-01);
+    const double s = fma(r * z, ps, r);
+    double pc = -1.13596475577881948265e-11;
+    pc = fma(pc, z, 2.08757232129817482790e-09);
+    pc = fma(pc, z, -2.75573143513906633035e-07);
+    pc = fma(pc, z, 2.48015872894767294178e-05);
+    pc = fma(pc, z, -1.38888888888741095749e-03);
+    pc = fma(pc, z, 4.16666666666666019037e-02);
+    const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const int q = (int)k & 3;
+    const double a = (q & 1) ? c : s, b = (q & 1) ? s : c;
+    *sn = (q & 2) ? -a : a;
+    *cs = ((q + 1) & 2) ? -b : b;
+}
+
 // Tile-streaming variant (D <= 16, float4-aligned trajectories): a wave owns a group of 16/DP episodes and walks their
 // 16-step row tiles in order -- coalesced float4 loads of the desired (pos, vel) pieces one tile ahead, wave-private
 // LDS image, the serial controller + plant recurrence on the lanes (q == 0) as a register chain (float64, no FMA),
@@ -2095,16 +2125,27 @@ struct PdArgs {
     float* actions;
     int D, sh, B, T, G;
     unsigned inv_seg4;
+    // SimpleReacher reward (RW kernels): see k_reacher_rollout
+    const int32_t* step0;
+    const double* goal;
+    double* rewards;
+    int steps_before_reward;
 };
 
 // NG = groups per wave: with NG = 4 a wave owns four consecutive groups and lane quarter j runs group j's recurrence,
 // so four recurrences advance in parallel (the same idea as k_traj_quad); NG = 1 keeps more waves for small batches.
-template <int NG>
+// RW: additionally SimpleReacherEnv's per-step reward (simple_reacher.py:56-72).  The serial lanes leave the plant
+// position and the clipped action of every step of the tile in LDS as float64 (the position image reuses the desired
+// pos | vel staging, which the recurrence has already pulled into registers); then all 64 lanes turn (episode, step)
+// items into rewards in parallel -- cumulative joint angles, sin / cos, end effector, control cost, each summed left to
+// right as numpy does.  Only the recurrence itself stays serial.
+template <int NG, bool RW>
 __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[4 * NG * 3 * kStageStride];
+    constexpr int SLOT = 3 * kStageStride + (RW ? 2 * kStageStride : 0);   // floats per group slot
+    extern __shared__ __attribute__((aligned(16))) float smem[];           // [4 waves][NG][SLOT]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* sSt = smem + wave * (NG * 3 * kStageStride);      // per group: desired pos | desired vel | actions
+    float* sSt = smem + wave * (NG * SLOT);      // per group: desired pos | desired vel | actions (| u as float64)
     const int D = a.D, T = a.T, B = a.B, SEG = 16 * D, DP = 1 << a.sh, NTW = 16 >> a.sh;
     const int col = lane & 15, bl = col >> a.sh, d = col & (DP - 1);
     const int jq = lane >> 4;                                // the group (of this wave's NG) whose recurrence the lane runs
@@ -2155,8 +2196,8 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
 #pragma unroll
             for (int j = 0; j < NG; ++j) {
                 if (mover[j] && w4 < rows * D) {
-                    *reinterpret_cast<f32x4*>(sSt + j * 3 * kStageStride + rofs) = lp[j];
-                    *reinterpret_cast<f32x4*>(sSt + j * 3 * kStageStride + kStageStride + rofs) = lv[j];
+                    *reinterpret_cast<f32x4*>(sSt + j * SLOT + rofs) = lp[j];
+                    *reinterpret_cast<f32x4*>(sSt + j * SLOT + kStageStride + rofs) = lv[j];
                 }
             }
             if (rt + 1 < NRT) {   // next tile's pieces travel under this tile's recurrence
@@ -2171,7 +2212,7 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
             }
             __builtin_amdgcn_wave_barrier();
             if (serial) {
-                float* sg = sSt + jq * 3 * kStageStride;
+                float* sg = sSt + jq * SLOT;
                 const int o0 = bl * SEG + d;
                 float pr[16], vr[16];
 #pragma unroll
@@ -2193,16 +2234,54 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
                             }
                         }
                         sg[2 * kStageStride + o0 + tl * D] = (float)u;
+                        if (RW) {
+                            reinterpret_cast<double*>(sg)[tl * 16 + col] = qs;
+                            reinterpret_cast<double*>(sg + 3 * kStageStride)[tl * 16 + col] = u;
+                        }
                     }
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            if (RW) {
+                const int items = NG * NTW * rows;            // (group, episode in group, step in tile)
+                for (int it = lane; it < items; it += 64) {
+                    const int tl = it % rows, je = it / rows;
+                    const int e = je % NTW, j = je / NTW;
+                    const int b = (g0 + j) * NTW + e;
+                    if (g0 + j < a.G && b < B) {
+                        const int t = rt * 16 + tl;
+                        const int ns = a.n_steps ? min(a.n_steps[b], T) : T;
+                        double r = 0.0;
+                        if (t < ns) {
+                            const double* qv = reinterpret_cast<const double*>(sSt + j * SLOT) + tl * 16 + e * DP;
+                            const double* uv = reinterpret_cast<const double*>(sSt + j * SLOT + 3 * kStageStride) + tl * 16 + e * DP;
+                            double ang = 0.0, ex = 0.0, ey = 0.0, ctrl = 0.0;
+                            for (int dd = 0; dd < D; ++dd) {
+                                ang = dd == 0 ? qv[dd] : ang + qv[dd];      // np.cumsum(joint_angles)
+                                double sn, cs;
+                                sincos_lean(ang, &sn, &cs);
+                                ex = dd == 0 ? cs : ex + cs;                // unit links (base_reacher.py:19,97-104)
+                                ey = dd == 0 ? sn : ey + sn;
+                                ctrl = dd == 0 ? uv[dd] * uv[dd] : ctrl + uv[dd] * uv[dd];
+                            }
+                            double rdist = 0.0;
+                            if ((a.step0 ? a.step0[b] : 0) + t >= a.steps_before_reward) {
+                                const double dx = ex - a.goal[2 * (size_t)b], dy = ey - a.goal[2 * (size_t)b + 1];
+                                rdist = 0.0 - sqrt(dx * dx + dy * dy);
+                            }
+                            r = rdist - ctrl;
+                        }
+                        a.rewards[(size_t)b * T + t] = r;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
             if (a.actions) {
 #pragma unroll
                 for (int j = 0; j < NG; ++j) {
                     if (mover[j] && w4 < rows * D)
                         *reinterpret_cast<f32x4*>(a.actions + (size_t)(g0 + j) * NTW * T * D + gofs + (size_t)rt * SEG) =
-                            *reinterpret_cast<const f32x4*>(sSt + j * 3 * kStageStride + 2 * kStageStride + rofs);
+                            *reinterpret_cast<const f32x4*>(sSt + j * SLOT + 2 * kStageStride + rofs);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -2221,36 +2300,6 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
 // contraction; controller, clip and plant are the operations of k_pd_rollout (bit-exact), the scans add in tree order
 // (numpy: left to right), so rewards agree with the oracle to rounding, not bit for bit.
 // ------------------------------------------------------------------------------------------------------------
-// sin and cos of one float64 angle with a shared three-term Cody-Waite reduction by pi/2 and the classic degree-13 /
-// degree-14 kernels on [-pi/4, pi/4] (coefficients of fdlibm's __kernel_sin / __kernel_cos): ~1 ulp for |x| < 1e6, a
-// quarter of the instructions of two library calls.  Larger angles (a plant spun far out of range) take the library.
-__device__ __forceinline__ void sincos_lean(double x, double* sn, double* cs) {
-    if (!(fabs(x) < 1.0e6)) { sincos(x, sn, cs); return; }
-    const double k = rint(x * 6.36619772367581382433e-01);
-    double r = fma(-k, 1.57079632673412561417e+00, x);
-    r = fma(-k, 6.07710050630396597660e-11, r);
-    r = fma(-k, 2.02226624879595063154e-21, r);
-    const double z = r * r;
-    double ps = 1.58969099521155010221e-10;
-    ps = fma(ps, z, -2.50507602534068634195e-08);
-    ps = fma(ps, z, 2.75573137070700676789e-06);
-    ps = fma(ps, z, -1.98412698298579493134e-04);
-    ps = fma(ps, z, 8.33333333332248946124e-03);
-    ps = fma(ps, z, -1.66666666666666324348e-01);
-    const double s = fma(r * z, ps, r);
-    double pc = -1.13596475577881948265e-11;
-    pc = fma(pc, z, 2.08757232129817482790e-09);
-    pc = fma(pc, z, -2.75573143513906633035e-07);
-    pc = fma(pc, z, 2.48015872894767294178e-05);
-    pc = fma(pc, z, -1.38888888888741095749e-03);
-    pc = fma(pc, z, 4.16666666666666019037e-02);
-    const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
-    const int q = (int)k & 3;
-    const double a = (q & 1) ? c : s, b = (q & 1) ? s : c;
-    *sn = (q & 2) ? -a : a;
-    *cs = ((q + 1) & 2) ? -b : b;
-}
-
 __device__ __forceinline__ double seg_scan(double v, int d, int D) {
     // inclusive prefix sum over the D consecutive lanes of a segment (lane's position d)
     for (int off = 1; off < D; off <<= 1) {
@@ -2356,6 +2405,42 @@ int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
                            const float* des_vel, double* q, double* qd, const int32_t* n_steps, const int32_t* step0,
                            const double* goal, int steps_before_reward, float* actions, double* rewards, int B, int T,
                            void* stream) {
+    auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    const int last_rows = T - (T - 1) / 16 * 16;
+    const bool tiles_ok = D >= 1 && D <= kMaxD && (T * D) % 4 == 0 && (last_rows * D) % 4 == 0 && aligned16(des_pos) &&
+                          aligned16(des_vel) && (!actions || aligned16(actions)) && !getenv("MPK_PD_SIMPLE");
+    if (tiles_ok) {
+        // the tile-streaming rollout with the reward evaluated per tile by all lanes (see k_pd_rollout_tiles, RW)
+        PdArgs pa;
+        pa.rc = rc; pa.des_pos = des_pos; pa.des_vel = des_vel; pa.Q = q; pa.QD = qd; pa.n_steps = n_steps;
+        pa.actions = actions; pa.D = D; pa.B = B; pa.T = T;
+        pa.step0 = step0; pa.goal = goal; pa.rewards = rewards; pa.steps_before_reward = steps_before_reward;
+        int sh = 0;
+        while ((1 << sh) < D) ++sh;
+        pa.sh = sh;
+        const int NTW = 16 >> sh;
+        pa.G = (B + NTW - 1) / NTW;
+        pa.inv_seg4 = 65536u / (unsigned)(4 * D) + 1u;
+        int quad_mode = 1;
+        if (const char* e = getenv("MPK_PD_QUAD")) quad_mode = atoi(e);
+        const bool quad = quad_mode == 2 || (quad_mode == 1 && pa.G >= 4 * 256 * 8);
+        const int units = quad ? (pa.G + 3) / 4 : pa.G;
+        int blocks = (units + 3) / 4;
+        if (blocks > 2048) blocks = 2048;
+        if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;
+        const size_t lds = (size_t)4 * (quad ? 4 : 1) * 5 * kStageStride * sizeof(float);
+        auto go = [&](auto kern) -> int {
+            if (lds > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return MPK_EHIP; }
+            }
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, (hipStream_t)stream, pa);
+            MPK_LAUNCH_CHECK();
+            return MPK_OK;
+        };
+        return quad ? go(k_pd_rollout_tiles<4, true>) : go(k_pd_rollout_tiles<1, true>);
+    }
     const int epw = 64 / D;
     const long waves = ((long)B + epw - 1) / epw;
     hipLaunchKernelGGL(k_reacher_rollout, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rc, D,
@@ -2374,6 +2459,7 @@ int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const f
         PdArgs pa;
         pa.rc = rc; pa.des_pos = des_pos; pa.des_vel = des_vel; pa.Q = q; pa.QD = qd; pa.n_steps = n_steps;
         pa.actions = actions; pa.D = D; pa.B = B; pa.T = T;
+        pa.step0 = nullptr; pa.goal = nullptr; pa.rewards = nullptr; pa.steps_before_reward = 0;
         int sh = 0;
         while ((1 << sh) < D) ++sh;
         pa.sh = sh;
@@ -2388,8 +2474,9 @@ int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const f
         int blocks = (units + 3) / 4;
         if (blocks > 2048) blocks = 2048;
         if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;
-        if (quad) hipLaunchKernelGGL(k_pd_rollout_tiles<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pa);
-        else hipLaunchKernelGGL(k_pd_rollout_tiles<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pa);
+        const size_t lds = (size_t)4 * (quad ? 4 : 1) * 3 * kStageStride * sizeof(float);
+        if (quad) hipLaunchKernelGGL((k_pd_rollout_tiles<4, false>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, pa);
+        else hipLaunchKernelGGL((k_pd_rollout_tiles<1, false>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, pa);
         MPK_LAUNCH_CHECK();
         return MPK_OK;
     }

@@ -619,10 +619,16 @@ def test_vector_black_box_equals_individual_wrappers(mp_type, replan, workers):
 # ---- SimpleReacher on device ---------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("controller", ["motor", "position", "velocity"])
-@pytest.mark.parametrize("D,B,T", [(2, 1, 200), (5, 300, 200), (5, 65, 37), (7, 130, 100), (16, 9, 12)])
-def test_reacher_rollout_matches_oracle(controller, D, B, T):
-    """actions and plant state bit for bit (float64, no FMA); rewards to 1e-12 (device vs host libm cos / sin)"""
+@pytest.mark.parametrize("D,B,T", [(2, 1, 200), (5, 300, 200), (5, 65, 37), (7, 130, 100), (16, 9, 12), (20, 7, 10)])
+@pytest.mark.parametrize("mode", ["tiles", "quad", "generic"])
+def test_reacher_rollout_matches_oracle(controller, D, B, T, mode, monkeypatch):
+    """actions and plant state bit for bit (float64, no FMA); rewards to 1e-12 (device vs host libm cos / sin).  Kernels:
+    tile-streaming with the per-tile parallel reward phase (one or four groups per wave), and the generic
+    lane-per-(episode, DoF) kernel with segmented scans"""
     from fancy_gym_amd import TrajectoryEngine
+    monkeypatch.setenv("MPK_PD_QUAD", "2" if mode == "quad" else "0")
+    if mode == "generic":
+        monkeypatch.setenv("MPK_PD_SIMPLE", "1")
     eng = TrajectoryEngine(device=0, mp_type="promp", phase_type="linear", basis_type="rbf", num_dof=D, num_basis=3,
                            dt=0.01, duration=T * 0.01, tau=T * 0.01)
     rng = np.random.default_rng(D * 1000 + B)

@@ -1257,7 +1257,8 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     const bool ptr_ok = aligned16(pos) && aligned16(vel) && (!act || aligned16(actions));
     // T*D % 4 != 0: episodes start 0..3 floats past a 16-byte boundary -> shifted staging image (one spare chunk per
     // episode segment), if the segments of a group still fit the 64 lanes of a wave
-    ta.shifted = (TD % 4 != 0 && NTW * (seg4 + 1) <= 64 && NTW * (SEG + 4) <= kStageStride) ? 1 : 0;
+    // (misaligned output pointers take the generic store path, whose staging image is never shifted)
+    ta.shifted = (ptr_ok && TD % 4 != 0 && NTW * (seg4 + 1) <= 64 && NTW * (SEG + 4) <= kStageStride) ? 1 : 0;
     ta.td3 = TD & 3;
     ta.pitch = ta.shifted ? SEG + 4 : SEG;
     ta.cps = ta.shifted ? seg4 + 1 : seg4;

@@ -481,3 +481,35 @@ def test_no_writes_outside_the_rollout_outputs(D, T, B, quad, monkeypatch):
                                   torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     assert _intact(ra, sa) and _intact(rq, sq) and _intact(rqd, sqd)
+
+
+@pytest.mark.parametrize("B", [1, 5, 257, 1030])
+def test_no_writes_outside_the_small_outputs(B):
+    """integer replanning state, validity / penalty reduction, condition gather"""
+    from tests.test_gpu_trajectory import CFG2
+    pc, bc, tc, dt, dur = CFG2
+    eng = make_engine(pc, bc, tc, dt, dur)
+    T, D = eng.num_steps, eng.num_dof
+    params, ip, iv = inputs(pc, bc, tc, B, seed=B)
+    pos, vel = eng.trajectory(params, ip, iv, 0.0)
+    import ctypes as C
+    from fancy_gym_amd import _lib
+    lib, h, st = eng._lib, eng._h, torch.cuda.current_stream().cuda_stream
+    rt, ts, s1 = _guarded((B,), torch.int32); rp, ps, s2 = _guarded((B,), torch.int32)
+    rs, seg, s3 = _guarded((B,), torch.int32)
+    rd = torch.full((B + 2 * GUARD,), 0x5A, dtype=torch.uint8, device="cuda"); done = rd[GUARD:GUARD + B]
+    ts.zero_(); ps.zero_(); done.zero_()
+    _lib.check(lib.mpk_replan_advance(h, ts.data_ptr(), ps.data_ptr(), seg.data_ptr(), done.data_ptr(), 25, 4, 100, T, B, st))
+    rv = torch.full((B + 2 * GUARD,), 0x5A, dtype=torch.uint8, device="cuda"); valid = rv[GUARD:GUARD + B]
+    rpen, pen, s4 = _guarded((B,), torch.float64)
+    lo = (C.c_double * D)(*([-0.5] * D)); hi = (C.c_double * D)(*([0.5] * D))
+    _lib.check(lib.mpk_traj_validity_penalty(h, pos.data_ptr(), None, C.cast(lo, C.c_void_p), C.cast(hi, C.c_void_p), 0,
+                                             None, None, valid.data_ptr(), pen.data_ptr(), B, T, st))
+    rc, cpos, s5 = _guarded((B, D), torch.float32); rcv, cvel, s6 = _guarded((B, D), torch.float32)
+    _lib.check(lib.mpk_condition_gather(h, pos.data_ptr(), vel.data_ptr(), seg.data_ptr(), cpos.data_ptr(),
+                                        cvel.data_ptr(), B, T, st))
+    torch.cuda.synchronize()
+    assert _intact(rt, s1) and _intact(rp, s2) and _intact(rs, s3) and _intact(rpen, s4) and _intact(rc, s5) and _intact(rcv, s6)
+    for raw in (rd, rv):
+        assert bool((raw[:GUARD] == 0x5A).all()) and bool((raw[GUARD + B:] == 0x5A).all())
+    assert bool((seg == 25).all()) and torch.equal(cpos, pos[:, 24]) and torch.equal(cvel, vel[:, 24])

@@ -406,21 +406,22 @@ def test_no_writes_outside_the_output_arrays(name, B, offset, monkeypatch):
     eng = make_engine(pc, bc, tc, dt, dur)
     T, D = eng.num_steps, eng.num_dof
     params, ip, iv = inputs(pc, bc, tc, B, seed=B)
-    if offset:
-        # inputs that do not start on a 16-byte boundary either (views one float into a larger allocation)
-        def shifted(x):
-            raw = torch.zeros(x.size + 5, dtype=torch.float32, device="cuda")
-            v = raw[1:1 + x.size].view(x.shape)
-            v.copy_(torch.tensor(x))
-            return v
-        params, ip, iv = shifted(params), shifted(ip), shifted(iv)
-        assert params.data_ptr() % 16 == 4
+    # inputs sit between NaN pads (a kernel that reads past an input array and USES the value poisons its output), and with
+    # offset = 1 they do not start on a 16-byte boundary either
+    def padded(x):
+        raw = torch.full((x.size + 256 + offset,), float("nan"), dtype=torch.float32, device="cuda")
+        v = raw[128 + offset:128 + offset + x.size].view(x.shape)
+        v.copy_(torch.tensor(x))
+        return v
+    params, ip, iv = padded(params), padded(ip), padded(iv)
+    assert params.data_ptr() % 16 == 4 * offset
     for mapping in ("1", "2"):
         monkeypatch.setenv("MPK_MAPPING", mapping)
         (rp, pos, sp), (rv, vel, sv) = _guarded((B, T, D), torch.float32, offset), _guarded((B, T, D), torch.float32, offset)
         eng.trajectory(params, ip, iv, 0.0, out=(pos, vel))
         torch.cuda.synchronize()
         assert _intact(rp, sp) and _intact(rv, sv), (eng.last_kernel(), "trajectory")
+        assert bool(torch.isfinite(pos).all()) and bool(torch.isfinite(vel).all()), (eng.last_kernel(), "poisoned")
         want = eng.trajectory(params, ip, iv, 0.0)
         assert torch.equal(pos, want[0]) and torch.equal(vel, want[1])
     monkeypatch.delenv("MPK_MAPPING")
@@ -441,6 +442,7 @@ def test_no_writes_outside_the_output_arrays(name, B, offset, monkeypatch):
         eng.trajectory_actions(params, ip, iv, spec_s, cp, cv, out=tuple(b[1] for b in bufs))
         torch.cuda.synchronize()
         assert all(_intact(b[0], b[2]) for b in bufs), (eng.last_kernel(), "actions")
+        assert all(bool(torch.isfinite(b[1]).all()) for b in bufs), (eng.last_kernel(), "poisoned actions")
         bufs = [_guarded((B, T, D), torch.float32, offset) for _ in range(3)]
         rq, q, sq = _guarded((B, D), torch.float64); rqd, qd, sqd = _guarded((B, D), torch.float64)
         q.copy_(cp); qd.copy_(cv)
@@ -448,6 +450,7 @@ def test_no_writes_outside_the_output_arrays(name, B, offset, monkeypatch):
         eng.trajectory_rollout(params, ip, iv, spec_d, q, qd, n_steps=n_steps, out=tuple(b[1] for b in bufs))
         torch.cuda.synchronize()
         assert all(_intact(b[0], b[2]) for b in bufs) and _intact(rq, sq) and _intact(rqd, sqd), (eng.last_kernel(), "rollout")
+        assert all(bool(torch.isfinite(b[1]).all()) for b in bufs) and bool(torch.isfinite(q).all())
 
 
 @pytest.mark.parametrize("D,T", [(5, 200), (7, 100), (3, 10), (16, 40)])
@@ -458,8 +461,13 @@ def test_no_writes_outside_the_rollout_outputs(D, T, B, quad, monkeypatch):
     eng = TrajectoryEngine(device=0, mp_type="promp", phase_type="linear", basis_type="rbf", num_dof=D, num_basis=3,
                            dt=0.01, duration=T * 0.01, tau=T * 0.01)
     rng = np.random.default_rng(B)
-    des_pos = torch.tensor(rng.standard_normal((B, T, D)).astype(np.float32), device="cuda")
-    des_vel = torch.tensor(rng.standard_normal((B, T, D)).astype(np.float32), device="cuda")
+    def padded(x):      # NaN on both sides: a read past the array that is USED would poison the outputs
+        raw = torch.full((x.size + 512,), float("nan"), dtype=torch.float32, device="cuda")
+        v = raw[256:256 + x.size].view(x.shape)
+        v.copy_(torch.tensor(x))
+        return v
+    des_pos = padded(rng.standard_normal((B, T, D)).astype(np.float32))
+    des_vel = padded(rng.standard_normal((B, T, D)).astype(np.float32))
     spec = RolloutSpec("motor", D, 0.6, 0.075, -2.0, 2.0, plant="double_integrator", dt=0.01)
     n_steps = torch.tensor(rng.integers(0, T + 1, B).astype(np.int32), device="cuda")
     ra, act, sa = _guarded((B, T, D), torch.float32)
@@ -475,6 +483,7 @@ def test_no_writes_outside_the_rollout_outputs(D, T, B, quad, monkeypatch):
                                        rew.data_ptr(), B, T, torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     assert _intact(ra, sa) and _intact(rr, sr) and _intact(rq, sq) and _intact(rqd, sqd)
+    assert bool(torch.isfinite(act).all()) and bool(torch.isfinite(rew).all()) and bool(torch.isfinite(q).all())
     ra, act, sa = _guarded((B, T, D), torch.float32)
     _lib.check(lib.mpk_pd_rollout(h, C.byref(spec.c), des_pos.data_ptr(), des_vel.data_ptr(), q.data_ptr(),
                                   qd.data_ptr(), n_steps.data_ptr(), act.data_ptr(), B, T,

@@ -522,3 +522,28 @@ def test_no_writes_outside_the_small_outputs(B):
     for raw in (rd, rv):
         assert bool((raw[:GUARD] == 0x5A).all()) and bool((raw[GUARD + B:] == 0x5A).all())
     assert bool((seg == 25).all()) and torch.equal(cpos, pos[:, 24]) and torch.equal(cvel, vel[:, 24])
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg5", "cfg3", "prodmp_learn_tau_delay", "promp_learn_tau"])
+def test_repeated_launches_give_identical_bits(name):
+    """LDS staging, cross-lane exchanges and prefetch double buffers leave no run-to-run variation: ten launches of every
+    kernel family at a batch that fills the chip several times over"""
+    from tests.test_gpu_trajectory import CFG2, CFG3, CFG5, PER_ROW
+    pc, bc, tc, dt, dur = {"cfg2": CFG2, "cfg5": CFG5, "cfg3": CFG3}.get(name) or PER_ROW[name]
+    eng = make_engine(pc, bc, tc, dt, dur)
+    D = eng.num_dof
+    B = 40000
+    params, ip, iv = inputs(pc, bc, tc, B, seed=3)
+    params, ip, iv = (torch.tensor(x, device="cuda") for x in (params, ip, iv))
+    spec = RolloutSpec("motor", D, 1.0, 0.1, -1.0, 1.0, plant="double_integrator", dt=dt)
+    first = None
+    for rep in range(10):
+        q, qd = ip.double().contiguous(), iv.double().contiguous()
+        pos, vel, act = eng.trajectory_rollout(params, ip, iv, spec, q, qd)
+        p2, v2 = eng.trajectory(params, ip, iv, 0.0)
+        torch.cuda.synchronize()
+        cur = (pos.clone(), vel.clone(), act.clone(), q.clone(), qd.clone(), p2.clone(), v2.clone())
+        if first is None:
+            first = cur
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(first, cur)), rep

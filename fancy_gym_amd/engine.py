@@ -269,13 +269,15 @@ class TrajectoryEngine:
         return pos, vel, act
 
     def pd_rollout(self, spec: RolloutSpec, des_pos: torch.Tensor, des_vel: torch.Tensor, q: torch.Tensor,
-                   qd: torch.Tensor, n_steps: Optional[torch.Tensor] = None, want_actions: bool = True):
+                   qd: torch.Tensor, n_steps: Optional[torch.Tensor] = None, want_actions: bool = True,
+                   out: Optional[torch.Tensor] = None):
         """In-place closed-loop rollout; q, qd float64 [B, D] are updated to the state after the executed steps."""
         B, T, D = des_pos.shape
         assert des_pos.dtype == torch.float32 and des_vel.dtype == torch.float32
         assert q.dtype == torch.float64 and qd.dtype == torch.float64 and q.is_contiguous() and qd.is_contiguous()
         des_pos, des_vel = des_pos.contiguous(), des_vel.contiguous()
-        act = torch.empty((B, T, D), dtype=torch.float32, device=self.device) if want_actions else None
+        act = out if out is not None else (
+            torch.empty((B, T, D), dtype=torch.float32, device=self.device) if want_actions else None)
         if n_steps is not None:
             n_steps = n_steps.to(device=self.device, dtype=torch.int32).contiguous()
         _lib.check(self._lib.mpk_pd_rollout(self._h, C.byref(spec.c), des_pos.data_ptr(), des_vel.data_ptr(),
@@ -286,7 +288,7 @@ class TrajectoryEngine:
     def reacher_rollout(self, spec: RolloutSpec, des_pos: torch.Tensor, des_vel: torch.Tensor, q: torch.Tensor,
                         qd: torch.Tensor, goal: torch.Tensor, n_steps: Optional[torch.Tensor] = None,
                         step0: Optional[torch.Tensor] = None, steps_before_reward: int = 199,
-                        want_actions: bool = True):
+                        want_actions: bool = True, out=None):
         """
         pd_rollout + SimpleReacherEnv's per-step reward (simple_reacher.py:56-72) on the torque double integrator:
         returns (actions float32 [B, T, D] or None, rewards float64 [B, T]); q, qd are updated in place.
@@ -296,8 +298,11 @@ class TrajectoryEngine:
         assert q.dtype == torch.float64 and qd.dtype == torch.float64 and q.is_contiguous() and qd.is_contiguous()
         des_pos, des_vel = des_pos.contiguous(), des_vel.contiguous()
         goal = torch.as_tensor(goal, dtype=torch.float64, device=self.device).expand(B, 2).contiguous()
-        act = torch.empty((B, T, D), dtype=torch.float32, device=self.device) if want_actions else None
-        rew = torch.empty((B, T), dtype=torch.float64, device=self.device)
+        if out is not None:
+            act, rew = out
+        else:
+            act = torch.empty((B, T, D), dtype=torch.float32, device=self.device) if want_actions else None
+            rew = torch.empty((B, T), dtype=torch.float64, device=self.device)
         if n_steps is not None:
             n_steps = n_steps.to(device=self.device, dtype=torch.int32).contiguous()
         if step0 is not None:

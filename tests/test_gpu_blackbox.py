@@ -832,3 +832,29 @@ def test_captured_episode_with_learned_phase_and_device_reward():
     got = rep.replay()[0]["rewards"].clone()
     rr.reset(q0, goal=goal)
     assert torch.equal(got, rr.step(params)["rewards"])
+
+
+@pytest.mark.gpu
+def test_bench_prints_the_contract_line_last():
+    """bench.py: the LAST stdout line is the JSON contract line, with the roofline and cpu_baseline objects"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MPK_BENCH_FORCE_DIST="1")          # also walks the RCCL code path with one rank
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("MASTER_ADDR", None); env.pop("MASTER_PORT", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "40", "--warmup", "5",
+                        "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["steps"] == 40 and d["warmup"] == 5 and d["n_gpus"] == 1 and d["scaling"] == "weak"
+    assert d["unit"] == "trajectories/s" and d["value"] > 1e6 and d["vs_baseline"] is None
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    assert abs(d["roofline"]["achieved"] / d["roofline"]["peak"] - d["roofline"]["frac"]) < 1e-9
+    assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert "allgather" in d            # the forced one-rank RCCL path ran the collective section

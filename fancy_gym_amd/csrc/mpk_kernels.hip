@@ -16,6 +16,7 @@
 
 #include <cstdint>
 #include <cstdlib>
+#include <type_traits>
 
 #include "mpk_internal.h"
 
@@ -2213,33 +2214,54 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
             }
             __builtin_amdgcn_wave_barrier();
             if (serial) {
+                // the 16 steps of the tile as straight-line code per (controller, plant): a run-time switch inside the
+                // step would cost more instructions than the step's arithmetic, and this chain is the critical path
                 float* sg = sSt + jq * SLOT;
                 const int o0 = bl * SEG + d;
-                float pr[16], vr[16];
+                auto tile_steps = [&](auto ctrl_tag, auto plant_tag) {
+                    constexpr int CTRL = decltype(ctrl_tag)::value, PLANT = decltype(plant_tag)::value;
+                    float pr[16], vr[16];
 #pragma unroll
-                for (int tl = 0; tl < 16; ++tl) { pr[tl] = sg[o0 + tl * D]; vr[tl] = sg[kStageStride + o0 + tl * D]; }
+                    for (int tl = 0; tl < 16; ++tl) { pr[tl] = sg[o0 + tl * D]; vr[tl] = sg[kStageStride + o0 + tl * D]; }
 #pragma unroll
-                for (int tl = 0; tl < 16; ++tl) {
-                    if (tl < rows) {
-                        const int t = rt * 16 + tl;
-                        double u = 0.0;
-                        if (t < nst) {
-                            const double dp = (double)pr[tl], dv = (double)vr[tl];
-                            if (a.rc.controller_type == MPK_CTRL_MOTOR) u = pgd * (dp - qs) + dgd * (dv - qds);
-                            else if (a.rc.controller_type == MPK_CTRL_POSITION) u = dp;
-                            else u = dv;
-                            u = fmin(fmax(u, lod), hid);
-                            if (a.rc.plant_type == MPK_PLANT_DOUBLE_INTEGRATOR) {
-                                qds = qds + dtp * u;
-                                qs = qs + dtp * qds;
+                    for (int tl = 0; tl < 16; ++tl) {
+                        if (tl < rows) {
+                            const int t = rt * 16 + tl;
+                            double u = 0.0;
+                            if (t < nst) {
+                                const double dp = (double)pr[tl], dv = (double)vr[tl];
+                                if (CTRL == MPK_CTRL_MOTOR) u = pgd * (dp - qs) + dgd * (dv - qds);
+                                else if (CTRL == MPK_CTRL_POSITION) u = dp;
+                                else u = dv;
+                                u = fmin(fmax(u, lod), hid);
+                                if (PLANT == MPK_PLANT_DOUBLE_INTEGRATOR) {
+                                    qds = qds + dtp * u;
+                                    qs = qs + dtp * qds;
+                                }
+                            }
+                            sg[2 * kStageStride + o0 + tl * D] = (float)u;
+                            if (RW) {
+                                reinterpret_cast<double*>(sg)[tl * 16 + col] = qs;
+                                reinterpret_cast<double*>(sg + 3 * kStageStride)[tl * 16 + col] = u;
                             }
                         }
-                        sg[2 * kStageStride + o0 + tl * D] = (float)u;
-                        if (RW) {
-                            reinterpret_cast<double*>(sg)[tl * 16 + col] = qs;
-                            reinterpret_cast<double*>(sg + 3 * kStageStride)[tl * 16 + col] = u;
-                        }
                     }
+                };
+                using std::integral_constant;
+                const bool dint = a.rc.plant_type == MPK_PLANT_DOUBLE_INTEGRATOR;
+                switch (a.rc.controller_type) {
+                    case MPK_CTRL_MOTOR:
+                        if (dint) tile_steps(integral_constant<int, MPK_CTRL_MOTOR>(), integral_constant<int, MPK_PLANT_DOUBLE_INTEGRATOR>());
+                        else tile_steps(integral_constant<int, MPK_CTRL_MOTOR>(), integral_constant<int, MPK_PLANT_STATIC>());
+                        break;
+                    case MPK_CTRL_POSITION:
+                        if (dint) tile_steps(integral_constant<int, MPK_CTRL_POSITION>(), integral_constant<int, MPK_PLANT_DOUBLE_INTEGRATOR>());
+                        else tile_steps(integral_constant<int, MPK_CTRL_POSITION>(), integral_constant<int, MPK_PLANT_STATIC>());
+                        break;
+                    default:
+                        if (dint) tile_steps(integral_constant<int, MPK_CTRL_VELOCITY>(), integral_constant<int, MPK_PLANT_DOUBLE_INTEGRATOR>());
+                        else tile_steps(integral_constant<int, MPK_CTRL_VELOCITY>(), integral_constant<int, MPK_PLANT_STATIC>());
+                        break;
                 }
             }
             __builtin_amdgcn_wave_barrier();

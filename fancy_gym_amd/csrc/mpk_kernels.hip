@@ -687,7 +687,9 @@ __device__ __forceinline__ void stream_group(const TrajArgs& a, const LaneMap<KM
                 // (base_reacher_torque.py:25-26), serial in t on the lanes (q == 0); float64, no FMA
                 __builtin_amdgcn_wave_barrier();
                 if (serial) {
-                    const double pgd = sg[0], dgd = sg[16], lod = sg[32], hid = sg[48], dtp = a.plant_dt;
+                    // canonical once: fmin / fmax otherwise quiet their bound operands again at every step
+                    const double pgd = sg[0], dgd = sg[16], lod = __builtin_canonicalize(sg[32]),
+                                 hid = __builtin_canonicalize(sg[48]), dtp = a.plant_dt;
                     float pr[16], vr[16];
 #pragma unroll
                     for (int tl = 0; tl < 16; ++tl) { pr[tl] = sSt[o0 + tl * D]; vr[tl] = sSt[kStageStride + o0 + tl * D]; }
@@ -1007,6 +1009,7 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
 #pragma unroll
         for (int dd = 0; dd < kMaxD; ++dd)
             if (dd == L.d) { pgd = act.pg[dd]; dgd = act.dg[dd]; lod = act.lo[dd]; hid = act.hi[dd]; }
+        lod = __builtin_canonicalize(lod); hid = __builtin_canonicalize(hid);   // not again at every step's fmin / fmax
     }
     (void)sgain;
 
@@ -2162,6 +2165,7 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
 #pragma unroll
     for (int dd = 0; dd < kMaxD; ++dd)
         if (dd == d) { pgd = a.rc.pg[dd]; dgd = a.rc.dg[dd]; lod = a.rc.lo[dd]; hid = a.rc.hi[dd]; }
+    lod = __builtin_canonicalize(lod); hid = __builtin_canonicalize(hid);   // fmin / fmax need not quiet them per step
     const double dtp = a.rc.dt;
     const int nb8 = gridDim.x >> 3;
     const int vb = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * nb8 + (blockIdx.x >> 3) : blockIdx.x;

@@ -593,10 +593,13 @@ static int traj_common(Handle* h, const float* params, const float* init_pos, co
         SharedTables st;
         int rc = get_shared(h, (float)init_time_shared, stream, &st);
         if (rc != MPK_OK) return rc;
-        return launch_traj_shared(h->dev, st, params, init_pos, init_vel, pos, vel, actions, rd, c_pos, c_vel,
-                                  q_state, qd_state, n_steps, B, h->num_cu, stream, &h->last_kernel);
+        rc = launch_traj_shared(h->dev, st, params, init_pos, init_vel, pos, vel, actions, rd, c_pos, c_vel,
+                                q_state, qd_state, n_steps, B, h->num_cu, stream, &h->last_kernel);
+        // horizons whose basis tables do not fit the episode-major kernel's LDS: the per-episode kernels below (dmp) or,
+        // for fused actions / rollouts, the caller's two-launch path
+        if (rc != MPK_ENOTIMPL || actions) return rc;
     }
-    if (actions) { set_error("fused actions need a shared-phase configuration with D <= 16 and <= 16 basis columns"); return MPK_EINVAL; }
+    if (actions) { set_error("fused actions need a shared-phase configuration with D <= 16 and <= 16 basis columns"); return MPK_ENOTIMPL; }
     return launch_traj_rows(h->dev, params, init_pos, init_vel, init_time, (float)init_time_shared, pos, vel,
                             h->d_flag, B, h->num_cu, stream, &h->last_kernel);
 }
@@ -620,9 +623,11 @@ int mpk_trajectory_actions(mpk_handle hh, const float* params, const float* init
     int r = fill_rollout(h, rc, &rd);
     if (r != MPK_OK) return r;
     if (rd.plant_type != MPK_PLANT_STATIC) { set_error("mpk_trajectory_actions tracks a frozen state (MPK_PLANT_STATIC); use mpk_trajectory_rollout"); return MPK_EINVAL; }
-    if (h->cfg.mp_type != MPK_MP_DMP && shared_phase(h, nullptr) && mfma_capable(h))
-        return traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, actions, &rd, c_pos,
-                           c_vel, B, stream);
+    if (h->cfg.mp_type != MPK_MP_DMP && shared_phase(h, nullptr) && mfma_capable(h)) {
+        r = traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, actions, &rd, c_pos, c_vel,
+                        B, stream);
+        if (r != MPK_ENOTIMPL) return r;
+    }
     // what the single fused kernel does not cover (dmp, learned tau / delay, > 16 DoF or basis columns): same result
     // from two launches
     r = traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, nullptr, nullptr, nullptr,
@@ -643,10 +648,12 @@ int mpk_trajectory_rollout(mpk_handle hh, const float* params, const float* init
     int r = fill_rollout(h, rc, &rd);
     if (r != MPK_OK) return r;
     if (rd.plant_type != MPK_PLANT_DOUBLE_INTEGRATOR) { set_error("mpk_trajectory_rollout integrates MPK_PLANT_DOUBLE_INTEGRATOR; for a frozen state use mpk_trajectory_actions"); return MPK_EINVAL; }
-    if (h->cfg.mp_type != MPK_MP_DMP && shared_phase(h, nullptr) && mfma_capable(h))
-        return traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, actions, &rd, nullptr,
-                           nullptr, B, stream, q, qd, n_steps);
-    // dmp, learned tau / delay, > 16 DoF or basis columns: trajectory kernel + rollout kernel, same result
+    if (h->cfg.mp_type != MPK_MP_DMP && shared_phase(h, nullptr) && mfma_capable(h)) {
+        r = traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, actions, &rd, nullptr,
+                        nullptr, B, stream, q, qd, n_steps);
+        if (r != MPK_ENOTIMPL) return r;
+    }
+    // dmp, learned tau / delay, horizons beyond the fused kernel's LDS tables, > 16 DoF or basis columns: trajectory kernel + rollout kernel, same result
     r = traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, nullptr, nullptr, nullptr,
                     nullptr, B, stream);
     if (r != MPK_OK) return r;

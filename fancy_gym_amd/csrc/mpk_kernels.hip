@@ -1284,7 +1284,8 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     if (c.mp_type != MPK_MP_DMP && !closed && ov == 1) stream_mode = false;
     if (ov == 2) stream_mode = true;
     if (stream_mode && table_bytes + 4 * kStageFloats * sizeof(float) > 64 * 1024) {
-        if (c.mp_type == MPK_MP_DMP || closed) { set_error("trajectory too long for the episode-major kernel's LDS budget"); return MPK_EINVAL; }
+        // the caller falls back: per-episode kernels for dmp, trajectory + rollout launches for the closed loop
+        if (c.mp_type == MPK_MP_DMP || closed) { set_error("trajectory too long for the episode-major kernel's LDS budget"); return MPK_ENOTIMPL; }
         stream_mode = false;
     }
     // write-through stores for the cache-resident tile-major case (MPK_WRITE_THROUGH=0/1 overrides, for A/B runs)

@@ -547,3 +547,35 @@ def test_repeated_launches_give_identical_bits(name):
             first = cur
         else:
             assert all(torch.equal(a, b) for a, b in zip(first, cur)), rep
+
+
+@pytest.mark.parametrize("mp,T", [("prodmp", 1000), ("prodmp", 8000), ("promp", 3000), ("dmp", 1000), ("dmp", 3000)])
+def test_long_horizons_take_the_kernels_that_fit(mp, T):
+    """horizons whose basis tables outgrow the episode-major kernel's LDS: tile-major / per-episode kernels for the
+    trajectory, trajectory + rollout launches behind mpk_trajectory_rollout -- same answers"""
+    pc, bc, tc, dt, dur = cfg_for(mp, 3, 4, T, dt=0.002)
+    eng = make_engine(pc, bc, tc, dt, dur)
+    B = 5
+    params, ip, iv = inputs(pc, bc, tc, B, seed=T)
+    pos, vel = eng.trajectory(params, ip, iv, 0.0)
+    rp, rv = O.get_trajectory(pc, bc, tc, params, dur, dt, 0.0, ip, iv, dtype=np.float64)
+    close(pos.cpu().numpy(), rp, "pos")
+    close(vel.cpu().numpy(), rv, "vel", atol=fd_atol(rp, dt) if mp == "promp" else 0.0)
+    p2, v2 = eng.trajectory(params, ip, iv, torch.zeros(B, device="cuda"))
+    close(p2.cpu().numpy(), rp, "per-episode pos")
+    spec = RolloutSpec("motor", 3, 1.0, 0.1, -1.0, 1.0, plant="double_integrator", dt=dt)
+    q0 = ip.astype(np.float64)
+    q, qd = torch.tensor(q0, device="cuda"), torch.zeros((B, 3), dtype=torch.float64, device="cuda")
+    p3, v3, act = eng.trajectory_rollout(params, ip, iv, spec, q, qd)
+    assert torch.equal(p3, pos) and torch.equal(v3, vel)
+    ra, rq, rqd = O.rollout(pos.cpu().numpy(), vel.cpu().numpy(), "motor", 1.0, 0.1, -1.0, 1.0, "double_integrator", dt,
+                            q0, np.zeros((B, 3)))
+    assert np.array_equal(act.cpu().numpy(), ra.astype(np.float32)) and np.array_equal(q.cpu().numpy(), rq)
+
+
+def test_dmp_horizon_beyond_every_kernel_is_refused():
+    pc, bc, tc, dt, dur = cfg_for("dmp", 3, 4, 8000, dt=0.002)
+    eng = make_engine(pc, bc, tc, dt, dur)
+    params, ip, iv = inputs(pc, bc, tc, 2, seed=1)
+    with pytest.raises(ValueError, match="too large"):
+        eng.trajectory(params, ip, iv, 0.0)

@@ -215,14 +215,20 @@ def main():
     allgather = None
     if dist is not None and not args.no_allgather:
         Kg = max(10, min(K, 200))
-        shard = torch.stack([pos, vel])                     # [2, B, T, D] view-copy target
+        shard = torch.empty((2, B, T_STEPS, D), dtype=torch.float32, device=dev)   # the kernel writes (pos | vel) here
         full = torch.empty((world,) + tuple(shard.shape), dtype=torch.float32, device=dev)
+        sp0, sp1 = shard[0].data_ptr(), shard[1].data_ptr()
+
+        def step_into_shard():
+            rc = lib.mpk_trajectory_actions(h, ptrs[0], ptrs[1], ptrs[2], 0.0, rcfg, cp, cv, sp0, sp1, outs[2], B, sp)
+            if rc != 0:
+                raise RuntimeError(_lib.last_error())
         for _ in range(5):
-            step(sp); shard[0].copy_(pos); shard[1].copy_(vel); dist.all_gather_into_tensor(full, shard)
+            step_into_shard(); dist.all_gather_into_tensor(full, shard)
         barrier(); torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(Kg):
-            step(sp); shard[0].copy_(pos); shard[1].copy_(vel); dist.all_gather_into_tensor(full, shard)
+            step_into_shard(); dist.all_gather_into_tensor(full, shard)
         torch.cuda.synchronize(); barrier()
         e2 = time.perf_counter() - t1
         t = torch.tensor([e2], dtype=torch.float64, device=dev)

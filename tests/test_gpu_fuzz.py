@@ -60,12 +60,22 @@ def random_case(rng):
     return pc, bc, tc, dt, dur, B, init_time
 
 
-@pytest.mark.parametrize("seed", range(120))
+import os
+
+# MPK_FUZZ_CASES=2000 python -m pytest tests/test_gpu_fuzz.py -m gpu   for a longer soak
+N_CASES = int(os.environ.get("MPK_FUZZ_CASES", "120"))
+
+
+@pytest.mark.parametrize("seed", range(N_CASES))
 def test_random_configuration_matches_oracle(seed, monkeypatch):
     rng = np.random.default_rng(10_000 + seed)
     pc, bc, tc, dt, dur, B, init_time = random_case(rng)
     monkeypatch.setenv("MPK_MAPPING", str(rng.choice(["0", "1", "2"])))
     monkeypatch.setenv("MPK_BULK", str(rng.choice(["0", "2"])))
+    monkeypatch.setenv("MPK_QUAD", str(rng.choice(["0", "1", "2"])))
+    monkeypatch.setenv("MPK_PD_QUAD", str(rng.choice(["0", "1", "2"])))
+    monkeypatch.setenv("MPK_PHASE_CHUNK", str(rng.choice(["1", "2", "4"])))
+    monkeypatch.setenv("MPK_PHASE_TABLE", str(rng.choice(["0", "1"])))
     if tc.trajectory_generator_type == "prodmp":
         # keep the plan inside the pre-computed range (6 tau): reference raises otherwise
         tau_min = pc.tau_bound[0] if pc.learn_tau else pc.tau
@@ -97,8 +107,8 @@ def test_random_configuration_matches_oracle(seed, monkeypatch):
                             q0, qd0, n_steps=n_steps)
     assert np.array_equal(act.cpu().numpy(), ra.astype(np.float32))
     assert np.array_equal(q.cpu().numpy(), rq) and np.array_equal(qd.cpu().numpy(), rqd)
-    shared = not (pc.learn_tau or pc.learn_delay)
-    if shared and tc.trajectory_generator_type != "dmp" and eng.last_kernel().startswith(("k_traj_tiles", "k_traj_stream")):
+    if True:
+        # one fused launch where the configuration allows it, trajectory + rollout kernels otherwise: same bits
         q2, qd2 = torch.tensor(q0, device="cuda"), torch.tensor(qd0, device="cuda")
         p2, v2, a2 = eng.trajectory_rollout(params, ip, iv, spec, q2, qd2, n_steps=torch.tensor(n_steps),
                                             init_time=init_time)

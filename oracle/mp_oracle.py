@@ -131,11 +131,14 @@ def make_times(duration: Optional[float], dt: float, init_time: Union[float, Arr
         assert tau_for_none is not None
         duration = round(float(tau_for_none) / dt) * dt
     n = num_steps(duration, dt)
-    base = linspace32(0.0, duration, n + 1)[1:].astype(dtype)
-    it = np.asarray(init_time, dtype=dtype)
+    # The reference's time grid is an fp32 tensor (init_time becomes an fp32 tensor in set_initial_conditions and the
+    # sum is an fp32 op); the grid feeds the ProDMP table indices -- the integer part of the path -- so it is the fp32
+    # values in every `dtype` (a float64 sum rounds differently and can move an index across a .5 tie).
+    base = linspace32(0.0, duration, n + 1)[1:]
+    it = np.asarray(init_time, dtype=np.float32)
     if it.ndim == 0:
-        return (base + it).astype(dtype)
-    return (base[None, :] + it[:, None]).astype(dtype)
+        return (base + it).astype(np.float32).astype(dtype)
+    return (base[None, :] + it[:, None]).astype(np.float32).astype(dtype)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

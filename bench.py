@@ -235,7 +235,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         e2 = float(t.item())
         allgather = {"value": world * B * Kg / e2, "unit": "trajectories/s", "steps": Kg,
-                     "ms_per_step": e2 / Kg * 1e3, "bytes_gathered_per_gpu_per_step": int((world - 1) * shard.numel() * 4)}
+                     "ms_per_step": e2 / Kg * 1e3, "bytes_gathered_per_gpu_per_step": int((world - 1) * shard.numel() * 4),
+                     "via": "torch.distributed all_gather_into_tensor (RCCL)"}
+        if os.environ.get("MPK_BENCH_NATIVE_COMM") == "1":
+            # opt-in: the same leg through libmpk's own RCCL communicator (mpk_comm_* / mpk_allgather, include/mpk.h)
+            from fancy_gym_amd.distributed import NativeComm
+            comm = NativeComm(rank, world, local_rank)
+            for _ in range(5):
+                step_into_shard(); comm.all_gather(shard, out=full, stream=stream)
+            barrier(); torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(Kg):
+                step_into_shard(); comm.all_gather(shard, out=full, stream=stream)
+            torch.cuda.synchronize(); barrier()
+            e3 = time.perf_counter() - t2
+            t = torch.tensor([e3], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e3 = float(t.item())
+            allgather["native"] = {"value": world * B * Kg / e3, "ms_per_step": e3 / Kg * 1e3, "via": "mpk_allgather"}
+            comm.close()
 
     line = None
     if rank == 0:

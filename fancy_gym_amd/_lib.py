@@ -18,7 +18,8 @@ BASIS_TYPES = {"rbf": 0, "zero_rbf": 1, "prodmp": 2}
 CTRL_TYPES = {"motor": 0, "velocity": 1, "position": 2}
 PLANT_TYPES = {"static": 0, "double_integrator": 1}
 
-MPK_EINVAL, MPK_ENOTIMPL, MPK_EHIP, MPK_ERANGE, MPK_ENODEV = -1, -2, -3, -4, -5
+MPK_EINVAL, MPK_ENOTIMPL, MPK_EHIP, MPK_ERANGE, MPK_ENODEV, MPK_ECOMM = -1, -2, -3, -4, -5, -6
+MPK_COMM_ID_BYTES = 128
 
 
 class MPKLibraryError(RuntimeError):
@@ -86,6 +87,12 @@ SIGNATURES = {
     "mpk_host_rbf": (C.c_int, [C.POINTER(mpk_config), _vp, _vp]),
     "mpk_host_times": (C.c_int, [_dbl, _dbl, _vp, _i32]),
     "mpk_host_num_params": (C.c_int, [C.POINTER(mpk_config)]),
+    "mpk_comm_unique_id": (C.c_int, [_vp]),
+    "mpk_comm_create": (C.c_int, [_vp, _i32, _i32, _i32, C.POINTER(_vp)]),
+    "mpk_comm_rank": (C.c_int, [_vp]),
+    "mpk_comm_world": (C.c_int, [_vp]),
+    "mpk_allgather": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
+    "mpk_comm_destroy": (None, [_vp]),
     "mpk_last_kernel": (C.c_char_p, [_vp]),
 }
 

@@ -5,6 +5,7 @@
 // (the reference delegates it to mp_pytorch's ProDMPBasisGenerator at construction:
 // fancy_gym/black_box/factory/basis_generator_factory.py:14-17).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdio>
@@ -837,6 +838,110 @@ int mpk_host_num_params(const mpk_config* cfg) {
     int rc = check_cfg(*cfg);
     if (rc != MPK_OK) return rc;
     return (cfg->learn_tau ? 1 : 0) + (cfg->learn_delay ? 1 : 0) + cfg->num_dof * local_per_dof(*cfg);
+}
+
+// ---- RCCL all-gather (the one exchange step of the path) ----------------------------------------------------------
+// librccl is bound with dlopen on first use: libmpk.so itself carries no dependency on it, and the copy the process
+// already has (torch ships one with the same SONAME) is the one that gets used.
+}  // extern "C"
+namespace {
+struct RcclId { char internal[MPK_COMM_ID_BYTES]; };     // = ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES 128)
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(RcclId*) = nullptr;
+    int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string why;
+};
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) { r.why = std::string("librccl.so.1 not found: ") + dlerror(); return; }
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+        r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+        if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString) {
+            r.why = "librccl.so.1 lacks the nccl* entry points";
+            r.lib = nullptr;
+        }
+    });
+    return r;
+}
+constexpr int kNcclFloat = 7;   // rccl.h ncclDataType_t: ncclFloat32 = 7
+struct Comm { void* nccl = nullptr; int rank = 0, world = 1, device = 0; };
+int rccl_fail(const char* what, int rc) {
+    set_error(std::string(what) + ": " + rccl().GetErrorString(rc));
+    return MPK_ECOMM;
+}
+}  // namespace
+extern "C" {
+
+int mpk_comm_unique_id(uint8_t* id) {
+    if (!id) { set_error("NULL argument"); return MPK_EINVAL; }
+    Rccl& r = rccl();
+    if (!r.lib) { set_error(r.why); return MPK_ECOMM; }
+    RcclId u;
+    const int rc = r.GetUniqueId(&u);
+    if (rc != 0) return rccl_fail("ncclGetUniqueId", rc);
+    std::memcpy(id, u.internal, MPK_COMM_ID_BYTES);
+    return MPK_OK;
+}
+
+int mpk_comm_create(const uint8_t* id, int32_t rank, int32_t world, int32_t device, mpk_comm* out) {
+    if (!id || !out) { set_error("NULL argument"); return MPK_EINVAL; }
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) { set_error("need 0 <= rank < world"); return MPK_EINVAL; }
+    Rccl& r = rccl();
+    if (!r.lib) { set_error(r.why); return MPK_ECOMM; }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) { (void)hipGetLastError(); set_error("no HIP device"); return MPK_ENODEV; }
+    if (device < 0 || device >= n) { set_error("device ordinal out of range"); return MPK_EINVAL; }
+    MPK_HIP(hipSetDevice(device));
+    RcclId u;
+    std::memcpy(u.internal, id, MPK_COMM_ID_BYTES);
+    Comm* c = new Comm;
+    c->rank = rank; c->world = world; c->device = device;
+    const int rc = r.CommInitRank(&c->nccl, world, u, rank);
+    if (rc != 0) { delete c; return rccl_fail("ncclCommInitRank", rc); }
+    *out = reinterpret_cast<mpk_comm>(c);
+    return MPK_OK;
+}
+
+int mpk_comm_rank(mpk_comm cc) {
+    if (!cc) { set_error("NULL communicator"); return MPK_EINVAL; }
+    return reinterpret_cast<Comm*>(cc)->rank;
+}
+
+int mpk_comm_world(mpk_comm cc) {
+    if (!cc) { set_error("NULL communicator"); return MPK_EINVAL; }
+    return reinterpret_cast<Comm*>(cc)->world;
+}
+
+int mpk_allgather(mpk_comm cc, const float* send, float* recv, int64_t count, void* stream) {
+    if (!cc) { set_error("NULL communicator"); return MPK_EINVAL; }
+    if (count < 0) { set_error("count must be >= 0"); return MPK_EINVAL; }
+    if (count == 0) return MPK_OK;
+    if (!send || !recv) { set_error("NULL buffer"); return MPK_EINVAL; }
+    Comm* c = reinterpret_cast<Comm*>(cc);
+    const int rc = rccl().AllGather(send, recv, (size_t)count, kNcclFloat, c->nccl, (hipStream_t)stream);
+    if (rc != 0) return rccl_fail("ncclAllGather", rc);
+    return MPK_OK;
+}
+
+void mpk_comm_destroy(mpk_comm cc) {
+    if (!cc) return;
+    Comm* c = reinterpret_cast<Comm*>(cc);
+    if (c->nccl) (void)rccl().CommDestroy(c->nccl);
+    delete c;
 }
 
 const char* mpk_last_kernel(mpk_handle hh) {

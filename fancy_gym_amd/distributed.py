@@ -78,3 +78,61 @@ def gather_trajectories(pos: torch.Tensor, vel: torch.Tensor, num_episodes: int,
         return pos, vel
     both = all_gather_rows(torch.stack([pos, vel], dim=1), num_episodes, group)   # [B, 2, T, D]
     return both[:, 0].contiguous(), both[:, 1].contiguous()
+
+
+class NativeComm:
+    """
+    The same all-gather without torch.distributed in the data path: libmpk's RCCL communicator (include/mpk.h
+    ``mpk_comm_*`` / ``mpk_allgather``).  Rank 0 draws the unique id; the 128 id bytes travel through
+    ``exchange(id_bytes_or_None) -> id_bytes`` -- by default a torch.distributed object broadcast (host side, any
+    backend), but any host-side channel works (a file, MPI, an environment variable for world == 1).
+    """
+
+    def __init__(self, rank: int, world: int, device: int, exchange=None):
+        import ctypes as C
+        from . import _lib
+        self._lib = _lib.load()
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+        buf = (C.c_uint8 * _lib.MPK_COMM_ID_BYTES)()
+        if self.rank == 0:
+            _lib.check(self._lib.mpk_comm_unique_id(buf))
+        ident = bytes(buf)
+        if self.world > 1:
+            if exchange is None:
+                box = [ident if self.rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                ident = box[0]
+            else:
+                ident = exchange(ident if self.rank == 0 else None)
+        h = C.c_void_p()
+        raw = (C.c_uint8 * _lib.MPK_COMM_ID_BYTES).from_buffer_copy(ident)
+        _lib.check(self._lib.mpk_comm_create(raw, self.rank, self.world, self.device, C.byref(h)))
+        self._h = h
+
+    def all_gather(self, shard: torch.Tensor, out: Optional[torch.Tensor] = None, stream=None) -> torch.Tensor:
+        """[...] fp32 on this rank -> [world, ...] on every rank, ONE ncclAllGather on ``stream`` (default: current)"""
+        from . import _lib
+        if shard.dtype != torch.float32 or not shard.is_cuda or not shard.is_contiguous():
+            raise ValueError("all_gather needs a contiguous fp32 device tensor")
+        if out is None:
+            out = torch.empty((self.world,) + tuple(shard.shape), dtype=torch.float32, device=shard.device)
+        elif out.numel() != self.world * shard.numel() or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous fp32 tensor of world * shard.numel() elements")
+        s = torch.cuda.current_stream(shard.device) if stream is None else stream
+        _lib.check(self._lib.mpk_allgather(self._h, shard.data_ptr(), out.data_ptr(), shard.numel(), s.cuda_stream))
+        return out
+
+    def gather_trajectories(self, pos_vel: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``pos_vel`` [2, b, T, D] (the kernels write pos into [0], vel into [1]) -> [world, 2, b, T, D]"""
+        return self.all_gather(pos_vel, out)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.mpk_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

@@ -33,6 +33,7 @@ extern "C" {
 #define MPK_EHIP         -3   /* a HIP runtime call failed                                                        */
 #define MPK_ERANGE       -4   /* ProDMP: time beyond the pre-computed range (reference: RuntimeError)              */
 #define MPK_ENODEV       -5   /* no usable GPU                                                                    */
+#define MPK_ECOMM        -6   /* RCCL missing or a collective call failed                                         */
 
 /* factory/trajectory_generator_factory.py:7-21 -- 'promp' | 'dmp' | 'prodmp' */
 #define MPK_MP_PROMP   0
@@ -308,6 +309,32 @@ int mpk_host_prodmp_tables(const mpk_config* cfg, double* y1, double* y2, double
 int mpk_host_rbf(const mpk_config* cfg, double* centers, double* bw);
 int mpk_host_times(double duration, double dt, float* times, int32_t cap);
 int mpk_host_num_params(const mpk_config* cfg);
+
+/* ---- multi-GPU: the single exchange step of the path --------------------------------------------------------------
+ *
+ * Episodes are independent units: a batch shards across the GPUs of a node with NO data-path collective.
+ * The one exchange the path has is the optional collection of the generated trajectories on every rank -- ONE
+ * ncclAllGather over RCCL / xGMI.  The reference has no counterpart (it plans one episode per call on the host,
+ * black_box_wrapper.py:96-120); these entry points exist for callers that want the collective without torch.
+ * librccl.so.1 is bound lazily on the first mpk_comm_* call (the copy already loaded in the process, e.g. torch's, is
+ * reused), so a single-GPU user never needs it.
+ *
+ *   mpk_comm_unique_id : rank 0 fills `id` (MPK_COMM_ID_BYTES); the caller distributes the bytes to the other ranks
+ *                        by any host-side means (torch.distributed store, MPI, a file).
+ *   mpk_comm_create    : collective over all `world` ranks; binds this rank to HIP device `device`.
+ *   mpk_allgather      : recv[r * count + i] = rank r's send[i]  (fp32, `count` elements per rank; recv holds
+ *                        world * count).  A kernel that writes (pos | vel) of this rank's shard into one
+ *                        [2, B_local, T, D] buffer makes this ONE collective for both arrays.  In place when
+ *                        send == recv + rank * count.  Enqueued on `stream`, not synchronised.
+ */
+#define MPK_COMM_ID_BYTES 128
+typedef struct mpk_comm_s* mpk_comm;
+int mpk_comm_unique_id(uint8_t* id);
+int mpk_comm_create(const uint8_t* id, int32_t rank, int32_t world, int32_t device, mpk_comm* out);
+int mpk_comm_rank(mpk_comm c);    /* <0 on error */
+int mpk_comm_world(mpk_comm c);   /* <0 on error */
+int mpk_allgather(mpk_comm c, const float* send, float* recv, int64_t count, void* stream);
+void mpk_comm_destroy(mpk_comm c);
 
 /* Name of the kernel the last mpk_trajectory* call launched for its main pass (for profiling). */
 const char* mpk_last_kernel(mpk_handle h);

@@ -69,3 +69,20 @@ def test_shard_bounds_cover_the_batch_exactly():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_native_comm_argument_checks_without_a_gpu():
+    """include/mpk.h mpk_comm_*: bad arguments are refused with a message before RCCL or a GPU is touched"""
+    import ctypes as C
+    from fancy_gym_amd import _lib
+    lib = _lib.load()
+    ident = (C.c_uint8 * _lib.MPK_COMM_ID_BYTES)()
+    h = C.c_void_p()
+    for rank, world in ((0, 0), (2, 2), (-1, 2)):
+        assert lib.mpk_comm_create(ident, rank, world, 0, C.byref(h)) == _lib.MPK_EINVAL
+        assert "rank" in _lib.last_error() and not h.value
+    assert lib.mpk_comm_create(None, 0, 1, 0, C.byref(h)) == _lib.MPK_EINVAL
+    assert lib.mpk_comm_unique_id(None) == _lib.MPK_EINVAL
+    assert lib.mpk_allgather(None, None, None, 4, None) == _lib.MPK_EINVAL
+    assert lib.mpk_comm_rank(None) == _lib.MPK_EINVAL and lib.mpk_comm_world(None) == _lib.MPK_EINVAL
+    lib.mpk_comm_destroy(None)   # no-op

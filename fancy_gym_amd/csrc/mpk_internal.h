@@ -44,8 +44,8 @@ struct DevCfg {
     float ws, gs, dmp_alpha, dmp_beta;
     // device tables
     const double* tab;             // ProDMP: [y1|y2|dy1|dy2|pos_basis|vel_basis|weights_goal_scale]; RBF: [centers|bw]
-    const float* rows32;           // ProDMP, <= 16 columns: [n_pc][2*KS] = [Psi_0..Psi_nb y1 y2 0.. | dPsi.. dy1 dy2 0..]
-    int rows32_stride;             // 2*KS floats (KS = 8 or 16)
+    const float* rows32;           // ProDMP, <= 16 columns: [n_pc][2*KS + 4] = [Psi_0..Psi_nb 0.. y1 y2 | dPsi.. 0.. dy1 dy2 | lo x 4]
+    int rows32_stride;             // 2*KS + 4 floats (KS = 8 or 16)
     const float* base_times;       // [T]
 };
 

@@ -492,13 +492,35 @@ __device__ __forceinline__ void park_gains(const ActArgs& act, int lane, int d, 
     __builtin_amdgcn_wave_barrier();
 }
 
+// controller constants of one lane's DoF
+struct Gains { double pg, dg, lo, hi; };
+
+__device__ __forceinline__ Gains parked_gains(const double* sg) { return Gains{sg[0], sg[16], sg[32], sg[48]}; }
+
+// The same constants straight from the kernel-argument segment with per-lane (vector) loads: the segment is ordinary
+// device memory, so a lane-dependent index costs four 8-byte loads issued next to the kernel's first input loads,
+// where selecting among scalar kernarg registers costs eight dependent s_load round trips and 16 exec-masked moves
+// before any input load is issued (the tile-major kernel's whole life is ~8 us: its prologue is not free).
+// `act` is the second kernel argument of every trajectory kernel.
+constexpr size_t kActArgsOffset = (sizeof(TrajArgs) + alignof(ActArgs) - 1) / alignof(ActArgs) * alignof(ActArgs);
+__device__ __forceinline__ Gains kernarg_gains(int d) {
+    typedef const __attribute__((address_space(4))) char* kptr;
+    kptr base = (kptr)__builtin_amdgcn_kernarg_segment_ptr() + kActArgsOffset;
+    typedef const __attribute__((address_space(4))) double* dptr;
+    Gains gn;
+    gn.pg = ((dptr)(base + offsetof(ActArgs, pg)))[d];
+    gn.dg = ((dptr)(base + offsetof(ActArgs, dg)))[d];
+    gn.lo = ((dptr)(base + offsetof(ActArgs, lo)))[d];
+    gn.hi = ((dptr)(base + offsetof(ActArgs, hi)))[d];
+    return gn;
+}
+
 // epilogue of one C tile into the wave-private LDS transpose buffer (rows beyond T land in rows never stored)
 template <int MP, int CT>
 __device__ __forceinline__ void tile_epilogue(const f32x4& acc0, const f32x4& acc1, const f32x4& acc2,
-                                              const float (&dtd)[4], double cp, double cv, const double* sg,
+                                              const float (&dtd)[4], double cp, double cv, const Gains& gn,
                                               float* sSt, unsigned wofs, int D) {
-    double pgd = 0.0, dgd = 0.0, lod = 0.0, hid = 0.0;
-    if (CT >= 0 && CT < 3) { pgd = sg[0]; dgd = sg[16]; lod = sg[32]; hid = sg[48]; }
+    const double pgd = gn.pg, dgd = gn.dg, lod = gn.lo, hid = gn.hi;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const float p = acc0[r];
@@ -585,7 +607,7 @@ __device__ __forceinline__ void tile_store(const TrajArgs& a, const LaneMap<KM>&
 
 // ---- tile-major ------------------------------------------------------------------------------------------------
 template <int MP, int CT, int KM, bool WT>
-__global__ void __launch_bounds__(256) k_traj_tiles(const TrajArgs a, const ActArgs act) {
+__global__ void __launch_bounds__(256, (KM <= 2 ? 7 : 1)) k_traj_tiles(const TrajArgs a, const ActArgs act) {
     __shared__ __attribute__((aligned(16))) float smem[4 * kStageFloats];
     static_assert(MP != MPK_MP_DMP, "dmp runs in k_traj_stream");
     static_assert(CT < 3, "closed-loop rollouts run in k_traj_stream");
@@ -604,6 +626,10 @@ __global__ void __launch_bounds__(256) k_traj_tiles(const TrajArgs a, const ActA
     const int gstride = Wn / NRT;
     int g = wid / NRT;
     if (g >= a.G) return;
+    // first group's inputs and the controller constants: issued before everything else (latency-bound prologue)
+    GroupIn<KM> cur = load_group<MP, ACT, KM>(a, L, g);
+    Gains kg{0.0, 0.0, 0.0, 0.0};
+    if (ACT) kg = kernarg_gains(L.dvalid ? L.d : 0);
     // basis rows of this row tile, MFMA A-fragment layout: lane (t = col, k = 4m + q)
     float af[NOUT][KM];
 #pragma unroll
@@ -616,11 +642,8 @@ __global__ void __launch_bounds__(256) k_traj_tiles(const TrajArgs a, const ActA
         for (int r = 0; r < 4; ++r) dtd[r] = a.aux[rt * 16 + 4 * L.q + r];
     }
     const int rows = min(16, T - rt * 16);
-    if (ACT) park_gains(act, lane, L.d, sSt);
-    const double* sg = reinterpret_cast<const double*>(sSt + 3 * kStageStride) + (L.dvalid ? L.d : 0);
 
     float xb[KM];
-    GroupIn<KM> cur = load_group<MP, ACT, KM>(a, L, g);
     finish_group<KM>(L, cur, xb);
     double cp = cur.cp, cv = cur.cv;
     while (g < a.G) {
@@ -637,7 +660,7 @@ __global__ void __launch_bounds__(256) k_traj_tiles(const TrajArgs a, const ActA
         }
         // 3. epilogue -> LDS transpose; 4. coalesced stores
         if (L.dvalid)
-            tile_epilogue<MP, CT>(acc0, acc1, acc2, dtd, cp, cv, sg, sSt, L.wofs + ep_shift(a, g * L.NTW + L.bl), D);
+            tile_epilogue<MP, CT>(acc0, acc1, acc2, dtd, cp, cv, kg, sSt, L.wofs + ep_shift(a, g * L.NTW + L.bl), D);
         __builtin_amdgcn_wave_barrier();
         tile_store<NST, KM, WT>(a, L, sSt, lane, g * L.NTW, rt, rows);
         __builtin_amdgcn_wave_barrier();
@@ -681,7 +704,11 @@ __device__ __forceinline__ void stream_group(const TrajArgs& a, const LaneMap<KM
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dtd[r] = sAux[rt * 16 + 4 * L.q + r];
             }
-            if (L.dvalid) tile_epilogue<MP, CT>(acc0, acc1, acc2, dtd, cp, cv, sg, sSt, wofs, D);
+            if (L.dvalid) {
+                Gains gn{0.0, 0.0, 0.0, 0.0};
+                if (CT >= 0 && CT < 3) gn = parked_gains(sg);
+                tile_epilogue<MP, CT>(acc0, acc1, acc2, dtd, cp, cv, gn, sSt, wofs, D);
+            }
             if (CLOSED) {
                 // the step loop of black_box_wrapper.py:175-203 on the reference's torque double integrator
                 // (base_reacher_torque.py:25-26), serial in t on the lanes (q == 0); float64, no FMA
@@ -1077,7 +1104,7 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) dtd[r] = sAux[rt * 16 + 4 * L.q + r];
                             }
-                            tile_epilogue<MP, CT>(acc0, acc1, acc2, dtd, 0.0, 0.0, nullptr, sJ, wofs, D);
+                            tile_epilogue<MP, CT>(acc0, acc1, acc2, dtd, 0.0, 0.0, Gains{0.0, 0.0, 0.0, 0.0}, sJ, wofs, D);
                         }
                     }
                 }
@@ -1654,15 +1681,13 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
         }
         if (TL) {
             const float4* src = reinterpret_cast<const float4*>(c.rows32);
-            for (int i = threadIdx.x; i < c.n_pc * (2 * KQ); i += blockDim.x) {
-                const int r = i / (2 * KQ), j = i - r * (2 * KQ);
-                *reinterpret_cast<float4*>(sTab + r * (2 * KS + 4) + 4 * j) = src[i];
-            }
+            for (int i = threadIdx.x; i < c.n_pc * (2 * KQ + 1); i += blockDim.x)
+                reinterpret_cast<float4*>(sTab)[i] = src[i];
         }
     }
     __syncthreads();
     const float* const rows = TL ? sTab : c.rows32;
-    constexpr int kRow = TL ? 2 * KS + 4 : 2 * KS;
+    constexpr int kRow = 2 * KS + 4;    // [pos half | vel half | lo parts of y1 y2 dy1 dy2]
 
     // A wave owns chunks of E consecutive episodes.  A chunk's inputs -- E parameter rows, E boundary positions /
     // velocities, E init_times: each one contiguous run -- are fetched with coalesced loads one chunk ahead and
@@ -1717,17 +1742,28 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
             if (c.learn_delay) delay = fminf(fmaxf(prm[c.learn_tau ? 1 : 0], c.delay_lo), c.delay_hi);
             const float it = img[E * P + 2 * E * D + e];
             float inv_tau = 0.0f;
+            double bca = 0.0, bcb = 0.0, bcc = 0.0, bcd = 0.0;    // dy2_b, dy1_b, y1_b, y2_b over det (see prodmp_bc)
             if (MP == MPK_MP_PRODMP) {
-                // boundary conditions, one lane per DoF (SURVEY A.5 / mp_pytorch ProDMP): wg = scale * [w; g] in fp32
-                // as the reference forms it, then the 2x2 solve for (c1, c2) in float64 from the table row at the
-                // boundary index.  The lane's finished column [wg_0 .. wg_{K-1}, c1, c2] goes to sXf.
+                // Boundary conditions (SURVEY A.5 / mp_pytorch ProDMP), regrouped so that nothing large cancels in fp32:
+                //   pos = xi1 * (y_b - Psi_b.wg) + xi2 * (tau ydot_b - dPsi_b.wg) + Psi.wg
+                // (= the reference's xi1 y_b + xi2 v_b + (Psi - xi1 Psi_b - xi2 dPsi_b).wg).  One lane per DoF forms
+                // wg = scale * [w; g] in fp32 as the reference does and the two residuals in float64; the lane's finished
+                // column [wg_0 .. wg_{K-1}, 0.., r1, r2] goes to sXf.  xi1..xi4 are per (episode, step): the step's lane
+                // forms them below in float64 from the hi + lo table values and the factors kept here.
                 const float sb = scaled_time(it, delay, tau);
                 const int idxb = min(prodmp_index(sb, c.scaled_dt), c.n_pc - 1);
                 inv_tau = 1.0f / tau;
+                const float* rb = rows + (size_t)idxb * kRow;
+                {
+                    const float4 lo = *reinterpret_cast<const float4*>(rb + 2 * KS);
+                    const double y1b = (double)rb[KS - 2] + (double)lo.x, y2b = (double)rb[KS - 1] + (double)lo.y;
+                    const double dy1b = (double)rb[2 * KS - 2] + (double)lo.z, dy2b = (double)rb[2 * KS - 1] + (double)lo.w;
+                    const double idet = div_pos(1.0, y1b * dy2b - y2b * dy1b);      // det = y1_b^2 > 0
+                    bca = dy2b * idet; bcb = dy1b * idet; bcc = y1b * idet; bcd = y2b * idet;
+                }
                 if (lane < D) {
                     const int K = c.nb + 1;
                     const float* loc = prm + c.off + lane * c.Kloc;
-                    const float* rb = rows + (size_t)idxb * kRow;
                     const float yb = ipe[lane], ydb = ive[lane];
                     double pb = 0.0, vb = 0.0;
                     float* xf = sXf + lane * KS;
@@ -1745,11 +1781,8 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
                         }
                         xf[k] = wg;
                     }
-                    const double y1b = rb[K], y2b = rb[K + 1], dy1b = rb[KS + K], dy2b = rb[KS + K + 1];
-                    const double det = y1b * dy2b - y2b * dy1b;
-                    const double pr = (double)yb - pb, vr = (double)(tau * ydb) - vb;
-                    xf[K] = (float)((dy2b * pr - y2b * vr) / det);
-                    xf[K + 1] = (float)((y1b * vr - dy1b * pr) / det);
+                    xf[KS - 2] = (float)((double)yb - pb);
+                    xf[KS - 1] = (float)((double)(tau * ydb) - vb);
                 }
             } else {
                 // raw parameter columns [w_0 .. w_{nb-1}, init_pos (zero-padded family), 0 ..] per DoF
@@ -1781,6 +1814,14 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
                         h[4 * j] = p4.x; h[4 * j + 1] = p4.y; h[4 * j + 2] = p4.z; h[4 * j + 3] = p4.w;
                         hv[4 * j] = v4.x; hv[4 * j + 1] = v4.y; hv[4 * j + 2] = v4.z; hv[4 * j + 3] = v4.w;
                     }
+                    // the last two columns arrive as (y1, y2) / (dy1, dy2): turn them into (xi1, xi2) / (xi3, xi4)
+                    const float4 lo = row[2 * KQ];
+                    const double y1 = (double)h[KS - 2] + (double)lo.x, y2 = (double)h[KS - 1] + (double)lo.y;
+                    const double dy1 = (double)hv[KS - 2] + (double)lo.z, dy2 = (double)hv[KS - 1] + (double)lo.w;
+                    h[KS - 2] = (float)(bca * y1 - bcb * y2);
+                    h[KS - 1] = (float)(bcc * y2 - bcd * y1);
+                    hv[KS - 2] = (float)(bca * dy1 - bcb * dy2);
+                    hv[KS - 1] = (float)(bcc * dy2 - bcd * dy1);
                 } else {
                     const double x = phase_f64(c, time, tau, delay, ec);
 #pragma unroll
@@ -1934,7 +1975,7 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
     if (need > 16 || c.D > 64) return MPK_ENOTIMPL;
     const int KQ = need <= 4 && c.mp_type == MPK_MP_PROMP ? 1 : (need <= 8 ? 2 : 4), KS = KQ * 4;
     if (c.D * KS > 256) return MPK_ENOTIMPL;
-    if (c.mp_type == MPK_MP_PRODMP && (!c.rows32 || c.rows32_stride != 2 * KS)) return MPK_ENOTIMPL;
+    if (c.mp_type == MPK_MP_PRODMP && (!c.rows32 || c.rows32_stride != 2 * KS + 4)) return MPK_ENOTIMPL;
     pa.t_pad = (c.T + 3) / 4 * 4;
     pa.x_pad = c.D * KS;
     pa.o_pad = (64 * c.D + 4 + 3) / 4 * 4;

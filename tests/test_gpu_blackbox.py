@@ -860,9 +860,10 @@ def test_bench_prints_the_contract_line_last():
     assert "allgather" in d            # the forced one-rank RCCL path ran the collective section
 
 
-def test_native_rccl_all_gather_single_rank():
+def test_native_rccl_all_gather_single_rank(monkeypatch):
     """mpk_comm_* / mpk_allgather (RCCL bound lazily inside libmpk.so): one rank, out of place and in place"""
     from fancy_gym_amd.distributed import NativeComm
+    monkeypatch.setenv("NCCL_DEBUG", "WARN")                  # no version banner on stdout
     comm = NativeComm(rank=0, world=1, device=0)
     shard = torch.randn((2, 5, 100, 7), device="cuda")        # (pos | vel) of 5 episodes
     out = comm.gather_trajectories(shard)

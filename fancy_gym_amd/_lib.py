@@ -9,7 +9,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmpk.so")
+LIB_PATH = os.environ.get("MPK_LIB") or os.path.join(_HERE, "libmpk.so")   # MPK_LIB: A/B builds of the library
 
 MPK_ABI_VERSION = 1
 MP_TYPES = {"promp": 0, "dmp": 1, "prodmp": 2}

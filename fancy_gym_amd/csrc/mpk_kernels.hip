@@ -364,6 +364,10 @@ struct TrajArgs {
     // that 16-byte-aligned LDS chunks map onto 16-byte-aligned HBM chunks (partial chunks at both ends go scalar)
     int pitch, cps, shifted, td3;
     unsigned inv_cps;
+    // tile-major work assignment: wave w owns row tile w % NRT of groups w / NRT, + gstride, ...; nrt_magic =
+    // 2^32 / NRT + 1 (NRT > 1) turns the division into a multiply-high
+    unsigned nrt_magic;
+    int gstride;
     // closed-loop rollout fused into the episode-major kernel (CT >= 3)
     double* q_state;       // [B, D] plant position, in/out
     double* qd_state;      // [B, D] plant velocity, in/out
@@ -383,21 +387,21 @@ enum : int { XK_ZERO = 0, XK_PARAM = 1, XK_IPOS = 2, XK_IVEL = 3 };
 // which raw input feeds element k of a DoF's extended parameter column, and its offset inside the DoF's local block
 template <int MP>
 __device__ __forceinline__ int x_kind(const DevCfg& c, int k, int* loc) {
-    *loc = 0;
+    // select form (no early returns): this runs in the latency-critical prologue of every trajectory kernel
+    const int nb = c.nb;
     if (MP == MPK_MP_PRODMP) {
-        const int nb = c.nb;
-        if (k < nb) { *loc = k; return c.disable_weights ? XK_ZERO : XK_PARAM; }
-        if (k == nb) { *loc = c.disable_weights ? 0 : nb; return c.disable_goal ? XK_ZERO : XK_PARAM; }
-        if (k == nb + 1) return XK_IPOS;
-        if (k == nb + 2) return XK_IVEL;
-        return XK_ZERO;
+        const bool isw = k < nb, isg = k == nb;
+        *loc = isw ? k : (isg && !c.disable_weights ? nb : 0);
+        const int kw = c.disable_weights ? XK_ZERO : XK_PARAM, kg = c.disable_goal ? XK_ZERO : XK_PARAM;
+        return isw ? kw : (isg ? kg : (k == nb + 1 ? XK_IPOS : (k == nb + 2 ? XK_IVEL : XK_ZERO)));
     } else if (MP == MPK_MP_PROMP) {
-        if (k < c.nb) { *loc = k; return XK_PARAM; }
-        if (k == c.nb && c.KT > c.nb) return XK_IPOS;
-        return XK_ZERO;
+        const bool isw = k < nb;
+        *loc = isw ? k : 0;
+        return isw ? XK_PARAM : ((k == nb && c.KT > nb) ? XK_IPOS : XK_ZERO);
     } else {
-        if (k < c.nb) { *loc = k; return XK_PARAM; }
-        return XK_ZERO;
+        const bool isw = k < nb;
+        *loc = isw ? k : 0;
+        return isw ? XK_PARAM : XK_ZERO;
     }
 }
 
@@ -562,11 +566,14 @@ __device__ __noinline__ void store_tile_generic(float* pos, float* vel, float* a
 // WT = write-through (sc1) stores: for cache-resident batches the dirty lines then leave the L2 while the kernel is
 // still computing instead of in one write-back burst at the kernel boundary (rocprof: 11.5 -> 9.8 us at B = 4096);
 // for HBM-streaming batches plain stores are faster (3.5 vs 2.8 TB/s at B = 1M), so k_traj_stream keeps WT = false.
+#ifndef MPK_STORE_MODS
+#define MPK_STORE_MODS "sc1"     // cache-policy bits of the write-through store (build-time knob for A/B runs)
+#endif
 template <bool WT>
 __device__ __forceinline__ void store16(float* p, const f32x4& v) {
     if (WT) {
         // hipcc does not count this store: nothing in the kernels waits on stores, the end of the kernel drains them
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off " MPK_STORE_MODS "\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
     } else {
         *reinterpret_cast<f32x4*>(p) = v;
     }
@@ -605,10 +612,23 @@ __device__ __forceinline__ void tile_store(const TrajArgs& a, const LaneMap<KM>&
     }
 }
 
+// Every kernel-argument field the tile-major prologue needs, demanded in scalar registers at the top of the kernel:
+// the compiler then issues ALL their scalar loads in one batch (one scalar-cache miss round trip) instead of where
+// each field is first used, which chains two or three dependent misses (~0.2 us each) in front of the first input
+// load.  The tile-major kernel lives for ~8 us, so that is worth removing.
+__device__ __forceinline__ void demand_args(const TrajArgs& a, unsigned grid_x) {
+    asm volatile("" ::"s"(grid_x), "s"(a.c.D), "s"(a.c.nb), "s"(a.c.KT), "s"(a.c.P), "s"(a.c.Kloc), "s"(a.c.off), "s"(a.c.T),
+                 "s"(a.c.disable_weights), "s"(a.c.disable_goal), "s"(a.A), "s"(a.aux), "s"(a.TS), "s"(a.params),
+                 "s"(a.init_pos), "s"(a.init_vel), "s"(a.pos), "s"(a.vel), "s"(a.actions), "s"(a.c_pos), "s"(a.c_vel),
+                 "s"(a.sh), "s"(a.G), "s"(a.vec_ok), "s"(a.pitch), "s"(a.cps), "s"(a.shifted), "s"(a.td3),
+                 "s"(a.inv_cps), "s"(a.nrt_magic), "s"(a.gstride));
+}
+
 // ---- tile-major ------------------------------------------------------------------------------------------------
 template <int MP, int CT, int KM, bool WT>
 __global__ void __launch_bounds__(256, (KM <= 2 ? 7 : 1)) k_traj_tiles(const TrajArgs a, const ActArgs act) {
     __shared__ __attribute__((aligned(16))) float smem[4 * kStageFloats];
+    demand_args(a, gridDim.x);
     static_assert(MP != MPK_MP_DMP, "dmp runs in k_traj_stream");
     static_assert(CT < 3, "closed-loop rollouts run in k_traj_stream");
     constexpr bool ACT = CT >= 0;
@@ -621,10 +641,12 @@ __global__ void __launch_bounds__(256, (KM <= 2 ? 7 : 1)) k_traj_tiles(const Tra
     float* sSt = smem + wave * kStageFloats;
     const LaneMap<KM> L = make_lane_map<MP, KM>(a, lane);
     const int NRT = (T + 15) >> 4;
-    const int wid = blockIdx.x * 4 + wave, Wn = gridDim.x * 4;
-    const int rt = wid % NRT;             // Wn % NRT == 0: this wave owns row tile rt for every item
-    const int gstride = Wn / NRT;
-    int g = wid / NRT;
+    // Wn % NRT == 0: this wave owns row tile rt for every item.  wid / NRT by multiply-high with the host's magic
+    // number (exact for wid < 2^32 / NRT, which the launcher guarantees): the generic division is ~25 instructions
+    const int wid = blockIdx.x * 4 + wave;
+    const int gstride = a.gstride;
+    int g = a.nrt_magic ? (int)__umulhi((unsigned)wid, a.nrt_magic) : wid;      // magic 0: NRT == 1
+    const int rt = wid - g * NRT;
     if (g >= a.G) return;
     // first group's inputs and the controller constants: issued before everything else (latency-bound prologue)
     GroupIn<KM> cur = load_group<MP, ACT, KM>(a, L, g);
@@ -1270,6 +1292,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
                        const double* c_pos, const double* c_vel, double* q_state, double* qd_state,
                        const int32_t* n_steps, int B, int num_cu, void* stream, const char** kernel_name) {
     TrajArgs ta;
+    ta.nrt_magic = 0; ta.gstride = 0;
     const bool closed = q_state != nullptr;
     ta.q_state = q_state; ta.qd_state = qd_state; ta.n_steps = n_steps; ta.plant_dt = rc ? rc->dt : 0.0;
     ta.c = c; ta.A = st.A; ta.aux = st.aux; ta.TS = st.TS;
@@ -1364,9 +1387,14 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         const long items = (long)ta.G * NRT;
         long ipw = (items + max_waves - 1) / max_waves;                  // items per wave, balanced
         if (const char* e = getenv("MPK_IPW")) { const long v = atol(e); if (v > 0) ipw = v; }   // A/B runs
+        // the kernel divides wave ids by NRT with a 32-bit multiply-high: exact while #waves < 2^32 / NRT
+        const long wave_cap = (long)((1ull << 32) / (unsigned long long)NRT) - 8 * NRT;
+        if ((items + ipw - 1) / ipw > wave_cap) ipw = (items + wave_cap - 1) / wave_cap;
         const long waves = (items + ipw - 1) / ipw;
         blocks = (int)((waves + 3) / 4);
         blocks = (blocks + NRT - 1) / NRT * NRT;                         // #waves % NRT == 0
+        ta.gstride = blocks * 4 / NRT;
+        ta.nrt_magic = NRT > 1 ? (unsigned)((1ull << 32) / (unsigned long long)NRT) + 1u : 0u;
     }
     if (blocks < 1) blocks = 1;
     switch (c.mp_type) {

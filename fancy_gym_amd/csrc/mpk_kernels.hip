@@ -50,6 +50,18 @@ __device__ __forceinline__ float scaled_time(float t, float delay, float tau) {
     return fmaxf((t - delay) / tau, 0.0f);
 }
 
+// vel = z / tau for DMP (the reference divides the fp32 tensor z by tau).  The divisor is an episode / kernel constant,
+// so the reciprocal is taken once and each quotient costs three instructions instead of the ~10 of an IEEE division:
+//     q = z * r,   q' = fma(fma(-tau, q, z), r, q)            (Markstein's correction step)
+// which is the correctly rounded quotient except for rare last-bit cases -- seven orders below the 1e-5 contract.  Every
+// DMP kernel uses this helper, so they keep producing identical bits.
+struct TauDiv { float tau, r; };
+__device__ __forceinline__ TauDiv make_tau_div(float tau) { return TauDiv{tau, 1.0f / tau}; }
+__device__ __forceinline__ float div_tau(float z, const TauDiv& t) {
+    const float q = z * t.r;
+    return __builtin_fmaf(__builtin_fmaf(-t.tau, q, z), t.r, q);
+}
+
 __device__ __forceinline__ int prodmp_index(float s, float scaled_dt) {
     // times_to_indices: round-half-even of the fp32 quotient -- the bit-exact integer part of the path
     return (int)rintf(s / scaled_dt);
@@ -693,6 +705,15 @@ __global__ void __launch_bounds__(256, (KM <= 2 ? 7 : 1)) k_traj_tiles(const Tra
     }
 }
 
+// 16 consecutive floats at a wave-uniform, 16-byte aligned LDS address (the scaled-time steps of a row tile)
+__device__ __forceinline__ void load_ds16(const float* __restrict__ p, float (&v)[16]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 x = reinterpret_cast<const float4*>(p)[j];
+        v[4 * j] = x.x; v[4 * j + 1] = x.y; v[4 * j + 2] = x.z; v[4 * j + 3] = x.w;
+    }
+}
+
 // ---- episode-major ---------------------------------------------------------------------------------------------
 // all row tiles of one episode group, in order (shared by the two input-staging variants of k_traj_stream)
 template <int MP, int CT, int KM>
@@ -772,16 +793,18 @@ __device__ __forceinline__ void stream_group(const TrajArgs& a, const LaneMap<KM
             __builtin_amdgcn_wave_barrier();
             if (eul) {
                 // the tile's 16 forcing values and scaled-time steps are fetched up front, so the recurrence itself is a
-                // pure register chain; the lanes only park z here -- vel = z / tau is applied by ALL lanes below
+                // pure register chain
                 float fr[16], dsr[16];
+                const TauDiv td = make_tau_div(c.tau);
 #pragma unroll
-                for (int tl = 0; tl < 16; ++tl) { fr[tl] = sF[o0 + tl * D]; dsr[tl] = sAux[rt * 16 + tl]; }
+                for (int tl = 0; tl < 16; ++tl) fr[tl] = sF[o0 + tl * D];
+                load_ds16(sAux + rt * 16, dsr);
 #pragma unroll
                 for (int tl = 0; tl < 16; ++tl) {
                     if (tl < rows) {
                         const int t = rt * 16 + tl;
                         sSt[o0 + tl * D] = ey;
-                        sSt[kStageStride + o0 + tl * D] = ez;
+                        sSt[kStageStride + o0 + tl * D] = div_tau(ez, td);   // vel = z / tau, off the dependent chain
                         if (t < T - 1) {
                             const float t1 = eg - ey;
                             const float t2 = c.dmp_beta * t1;
@@ -794,15 +817,7 @@ __device__ __forceinline__ void stream_group(const TrajArgs& a, const LaneMap<KM
                     }
                 }
             }
-            __builtin_amdgcn_wave_barrier();
-            // vel = z / tau (IEEE divide, as the reference's tensor op) on every lane that holds staged data
-            if (L.dvalid) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float* w = sSt + kStageStride + wofs + r * D;
-                    *w = *w / c.tau;
-                }
-            }
+            // (vel = z / tau is written by the recurrence lanes themselves)
         }
         __builtin_amdgcn_wave_barrier();
         tile_store<NST, KM, false>(a, L, sSt, lane, b0, rt, rows);
@@ -1017,10 +1032,14 @@ __global__ void __launch_bounds__(256) k_traj_stream(const TrajArgs a, const Act
 // recurrences advance in parallel (4x fewer serial instructions per episode), then the four tiles leave as coalesced
 // float4 stores.  Same arithmetic and bits as k_traj_stream.
 constexpr int kQuad = 4;
+// floats per group image (pos | vel | act or force): 8 floats past a multiple of the 32 LDS banks, so that the four lane
+// quarters -- which walk the four images with the same in-image offsets during the recurrences -- fall on disjoint banks
+// (measured before the skew: 43 % of the kernel's LDS cycles were bank conflicts)
+constexpr int kQuadImg = 3 * kStageStride + 8;
 
 template <int MP, int CT, int KM>
 __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActArgs act) {
-    __shared__ __attribute__((aligned(16))) float smem[4 * kQuad * 3 * kStageStride];   // per wave: 4 x (pos|vel|act or force)
+    __shared__ __attribute__((aligned(16))) float smem[4 * kQuad * kQuadImg];   // per wave: 4 x (pos|vel|act or force)
     __shared__ double sgain[4][64];
     extern __shared__ __attribute__((aligned(16))) float sTab[];   // [NOUT][KP][TS] rows + [TS] aux
     constexpr bool CLOSED = CT >= 3;
@@ -1031,7 +1050,7 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int KP = 4 * KM, TS = a.TS, D = c.D, B = a.B, P = c.P, T = c.T;
-    float* sW = smem + wave * (kQuad * 3 * kStageStride);
+    float* sW = smem + wave * (kQuad * kQuadImg);
     float* sA = sTab;
     float* sAux = sTab + NOUT * KP * TS;
     {
@@ -1053,6 +1072,7 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
     int u = vb * 4 + wave;
     if (u >= NU) return;
     const float* ap = sA + L.q * TS + L.col;
+    const TauDiv td = make_tau_div(c.tau);
     double pgd = 0.0, dgd = 0.0, lod = 0.0, hid = 0.0;
     if (CLOSED) {
 #pragma unroll
@@ -1085,7 +1105,7 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
         const int gq = g0 + L.q, bq = gq * NTW + L.bl;
         const bool serial = L.dvalid && gq < a.G && bq < B;
         const int oq = L.bl * a.pitch + L.d + (int)ep_shift(a, bq);      // (row 0, this column) in group q's image
-        float* sQ = sW + L.q * (3 * kStageStride);
+        float* sQ = sW + L.q * kQuadImg;
         double qs = 0.0, qds = 0.0;
         int nst = T;
         float ey = 0.f, ez = 0.f, eg = 0.f;
@@ -1114,7 +1134,7 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
                         if (NOUT > 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[KP * TS], xb[j][m], acc1, 0, 0, 0);
                         if (NOUT > 2) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[2 * KP * TS], xb[j][m], acc2, 0, 0, 0);
                     }
-                    float* sJ = sW + j * (3 * kStageStride);
+                    float* sJ = sW + j * kQuadImg;
                     const unsigned wofs = L.wofs + ep_shift(a, (g0 + j) * NTW + L.bl);
                     if (L.dvalid) {
                         if (MP == MPK_MP_DMP) {
@@ -1158,13 +1178,14 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
                 } else {
                     float fr[16], dsr[16];
 #pragma unroll
-                    for (int tl = 0; tl < 16; ++tl) { fr[tl] = sQ[2 * kStageStride + oq + tl * D]; dsr[tl] = sAux[rt * 16 + tl]; }
+                    for (int tl = 0; tl < 16; ++tl) fr[tl] = sQ[2 * kStageStride + oq + tl * D];
+                    load_ds16(sAux + rt * 16, dsr);
 #pragma unroll
                     for (int tl = 0; tl < 16; ++tl) {
                         if (tl < rows) {
                             const int t = rt * 16 + tl;
                             sQ[oq + tl * D] = ey;
-                            sQ[kStageStride + oq + tl * D] = ez;
+                            sQ[kStageStride + oq + tl * D] = div_tau(ez, td);   // vel = z / tau, off the dependent chain
                             if (t < T - 1) {
                                 const float t1 = eg - ey;
                                 const float t2 = c.dmp_beta * t1;
@@ -1179,24 +1200,11 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            if (MP == MPK_MP_DMP) {
-                // vel = z / tau (IEEE divide) on every lane, for the four images
-                if (L.dvalid) {
-#pragma unroll
-                    for (int j = 0; j < kQuad; ++j) {
-                        float* sJ = sW + j * (3 * kStageStride) + kStageStride + L.wofs +
-                                    ep_shift(a, (g0 + j) * NTW + L.bl);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) sJ[r * D] = sJ[r * D] / c.tau;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
             // 3. coalesced stores of the four tiles
 #pragma unroll
             for (int j = 0; j < kQuad; ++j)
                 if (g0 + j < a.G)
-                    tile_store<NST, KM, false>(a, L, sW + j * (3 * kStageStride), lane, (g0 + j) * NTW, rt, rows);
+                    tile_store<NST, KM, false>(a, L, sW + j * kQuadImg, lane, (g0 + j) * NTW, rt, rows);
             __builtin_amdgcn_wave_barrier();
         }
         if (CLOSED) {
@@ -1347,7 +1355,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     // serial-recurrence variants (DMP, closed loop): four groups per wave, recurrences in parallel on the lane quarters
     // (MPK_QUAD=0 falls back to k_traj_stream, for A/B runs); needs its 52 KB of staging + the tables within 64 KB
     bool quad = stream_mode && (c.mp_type == MPK_MP_DMP || closed) &&
-                table_bytes + (4 * kQuad * 3 * kStageStride) * sizeof(float) + 4 * 64 * sizeof(double) <= 64 * 1024;
+                table_bytes + (4 * kQuad * kQuadImg) * sizeof(float) + 4 * 64 * sizeof(double) <= 64 * 1024;
     {   // automatic: only when the 4x coarser work units still give every CU a few waves (MPK_QUAD: 0 off, 2 force)
         int quad_mode = 1;
         if (const char* e = getenv("MPK_QUAD")) quad_mode = atoi(e);
@@ -1538,10 +1546,11 @@ __global__ void __launch_bounds__(256) k_traj_rows(const RowArgs a) {
                 float y = a.init_pos[(size_t)b * D + dd];
                 float z = a.init_vel[(size_t)b * D + dd] * tau;
                 const float g = prm[c.off + dd * c.Kloc + c.nb] * c.gs;
+                const TauDiv td = make_tau_div(tau);
                 for (int t = 0; t < T; ++t) {
                     const float f = sP[t * D + dd];
                     sP[t * D + dd] = y;
-                    sV[t * D + dd] = z / tau;
+                    sV[t * D + dd] = div_tau(z, td);
                     if (t < T - 1) {
                         const float ds = sT[t];
                         const float t1 = g - y;
@@ -1969,10 +1978,11 @@ __global__ void __launch_bounds__(256) k_traj_phase_dmp(const PhaseArgs a) {
             float y = dmp_y;
             float z = dmp_yd * tau;
             const float g = dmp_g * c.gs;
+            const TauDiv td = make_tau_div(tau);
             for (int t = 0; t < T; ++t) {
                 const float f = sP[t * D + dd];
                 sP[t * D + dd] = y;
-                sV[t * D + dd] = z / tau;
+                sV[t * D + dd] = div_tau(z, td);
                 if (t < T - 1) {
                     const float ds = sA[t];
                     const float t1 = g - y;

@@ -52,6 +52,14 @@ class mpk_rollout_cfg(C.Structure):
     ]
 
 
+class mpk_replan_state(C.Structure):
+    _fields_ = [
+        ("traj_steps", C.c_void_p), ("plan_steps", C.c_void_p), ("done", C.c_void_p), ("seg_len", C.c_void_p),
+        ("done_out", C.c_void_p), ("cond_pos", C.c_void_p), ("cond_vel", C.c_void_p),
+        ("every", C.c_int32), ("max_planning_times", C.c_int32), ("horizon", C.c_int32), ("reserved0", C.c_int32),
+    ]
+
+
 _vp, _i32, _dbl = C.c_void_p, C.c_int32, C.c_double
 
 # name -> (restype, argtypes); one row per symbol declared in include/mpk.h
@@ -72,6 +80,9 @@ SIGNATURES = {
                                          _vp, _vp, _vp, _i32, _vp]),
     "mpk_trajectory_rollout": (C.c_int, [_vp, _vp, _vp, _vp, _dbl, C.POINTER(mpk_rollout_cfg), _vp, _vp, _vp,
                                          _vp, _vp, _vp, _i32, _vp]),
+    "mpk_episode_reset": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "mpk_replan_step": (C.c_int, [_vp, _vp, _vp, _vp, _dbl, C.POINTER(mpk_rollout_cfg), _vp, _vp,
+                                  C.POINTER(mpk_replan_state), _vp, _vp, _vp, _i32, _vp]),
     "mpk_pd_rollout": (C.c_int, [_vp, C.POINTER(mpk_rollout_cfg), _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "mpk_condition_gather": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "mpk_unpin_tables": (C.c_int, [_vp]),

@@ -91,6 +91,8 @@ class BatchedBlackBox:
         self._host_plans = 0
         self._const_flags = None    # (all-True, all-False) [B], shared by every fused step's result
         self._phase_bounds = None   # [2, n_phase] bounds of the learned tau / delay, on the device
+        self._plans_since_reset = 0
+        self._start32 = None        # fp32 image of the plant state at reset (boundary condition of the first plan)
 
     # ---- episode control ---------------------------------------------------------------------------------------------
     def reset(self, init_pos=None, init_vel=None, goal=None):
@@ -100,16 +102,22 @@ class BatchedBlackBox:
             if goal is None:
                 raise ValueError("reward='simple_reacher' needs goal [B, 2] at reset")
             self.goal = torch.as_tensor(goal, dtype=torch.float64, device=self.device).expand(self.B, 2).contiguous()
-        self.traj_steps.zero_(); self.plan_steps.zero_(); self.done.zero_()
-        z = torch.zeros((self.B, self.D), dtype=torch.float64, device=self.device)
-        self.q = z.clone() if init_pos is None else torch.as_tensor(init_pos, dtype=torch.float64,
-                                                                    device=self.device).expand(self.B, self.D).contiguous().clone()
-        self.qd = z.clone() if init_vel is None else torch.as_tensor(init_vel, dtype=torch.float64,
-                                                                     device=self.device).expand(self.B, self.D).contiguous().clone()
+        # one launch (mpk_episode_reset): integer state, plant state and its fp32 image (the first plan's boundary state)
+        def state(x):
+            if x is None:
+                return None
+            x = torch.as_tensor(x, dtype=torch.float64, device=self.device)
+            return x.contiguous() if tuple(x.shape) == (self.B, self.D) else x.expand(self.B, self.D).contiguous()
+        if self._start32 is None:
+            self._start32 = tuple(torch.empty((self.B, self.D), dtype=torch.float32, device=self.device)
+                                  for _ in range(2))
+        self.engine.episode_reset(self.q, self.qd, self.traj_steps, self.plan_steps, self.done, state(init_pos),
+                                  state(init_vel), cond=self._start32)
         self.condition_pos = self.condition_vel = None
         self._frozen_phase = None
         self._lockstep = 0
         self._host_plans = 0
+        self._plans_since_reset = 0
         self.traj_gen.reset()
         return self.q, self.qd
 
@@ -167,36 +175,38 @@ class BatchedBlackBox:
         return max(1, min(g_break - cur, self.T))
 
     def _can_fuse(self) -> bool:
-        """plan + execute through mpk_trajectory_rollout (one launch for shared-phase promp / prodmp, two otherwise) with
-        four device operations per plan: needs the device plant, no validity gate, no device reward, and episodes that
-        still move in lockstep (one init_time for all)"""
+        """plan + execute through mpk_replan_step (one launch for shared-phase promp / prodmp, the separate kernels
+        otherwise): needs the device plant, no validity gate, no device reward, and episodes that still move in lockstep
+        (one init_time for all)"""
         return (self.spec is not None and self.plant == "double_integrator" and self.pos_limits is None
                 and self.reward is None and (not self.do_replanning or self._lockstep is not None))
 
     def _step_fused(self, params) -> Dict[str, torch.Tensor]:
-        """plan + execute in one launch; four device operations per plan (integer state, trajectory + rollout, condition
-        gather, the bool view of `done`) -- at a few thousand episodes the step is bound by their launch cost"""
+        """plan + execute as ONE device operation (mpk_replan_step: integer state, trajectory + rollout, condition gather
+        in a single launch where the fused closed-loop kernel applies)"""
         params = self._plan_params(params)
-        cond_pos = self.condition_pos if self.condition_pos is not None else self.q.float()
-        cond_vel = self.condition_vel if self.condition_vel is not None else self.qd.float()
+        first = self._start32 is not None and self._plans_since_reset == 1    # q, qd untouched since reset
+        cond_pos = self.condition_pos if self.condition_pos is not None else (self._start32[0] if first else self.q.float())
+        cond_vel = self.condition_vel if self.condition_vel is not None else (self._start32[1] if first else self.qd.float())
         init_time = float(self._lockstep * self.dt) if self.do_replanning else 0.0
         mpt = self.max_planning_times if math.isfinite(self.max_planning_times) else 2 ** 31 - 1
-        seg = self.engine.replan_advance(self.traj_steps, self.plan_steps, self.done, self.every, int(mpt),
-                                         self.horizon)
-        pos, vel, act = self.engine.trajectory_rollout(params, cond_pos, cond_vel, self.spec, self.q, self.qd,
-                                                       n_steps=seg, init_time=init_time)
+        r = self.engine.replan_step(params, cond_pos, cond_vel, self.spec, self.q, self.qd, self.traj_steps,
+                                    self.plan_steps, self.done, self.every, int(mpt), self.horizon,
+                                    init_time=init_time, condition=self.condition_on_desired)
+        seg = r["seg_len"]
         if self.condition_on_desired:
-            self.condition_pos, self.condition_vel = self.engine.condition_gather(pos, vel, seg)
+            self.condition_pos, self.condition_vel = r["cond_pos"], r["cond_vel"]
         if self.do_replanning:
             self._lockstep += self._host_segment()      # no validity gate here: the host mirrors the integer rule
-        done = self.done.bool()
+        done = r["done"].view(torch.bool)               # 0 / 1 bytes: a view, not a launch
         if self._const_flags is None:
             self._const_flags = (torch.ones(self.B, dtype=torch.bool, device=self.device),
                                  torch.zeros(self.B, dtype=torch.bool, device=self.device))
         valid, never = self._const_flags
         # nothing can invalidate a plan on this path: terminated stays False, truncated is `done`
-        return dict(params=params, des_pos=pos, des_vel=vel, step_actions=act, valid=valid, trajectory_length=seg,
-                    done=done, terminated=never, truncated=done, current_pos=self.q, current_vel=self.qd)
+        return dict(params=params, des_pos=r["pos"], des_vel=r["vel"], step_actions=r["actions"], valid=valid,
+                    trajectory_length=seg, done=done, terminated=never, truncated=done, current_pos=self.q,
+                    current_vel=self.qd)
 
     def _finish(self, out, seg, valid, was_done) -> Dict[str, torch.Tensor]:
         pos, vel = out["des_pos"], out["des_vel"]
@@ -220,6 +230,7 @@ class BatchedBlackBox:
         return out
 
     def step(self, params, fuse: bool = True) -> Dict[str, torch.Tensor]:
+        self._plans_since_reset += 1
         if fuse and self._can_fuse():
             return self._step_fused(params)
         out = self.get_trajectory(params)

@@ -592,7 +592,8 @@ int mpk_times(mpk_handle hh, float* times) {
 static int traj_common(Handle* h, const float* params, const float* init_pos, const float* init_vel,
                        const float* init_time, double init_time_shared, float* pos, float* vel, float* actions,
                        const RolloutDev* rd, const double* c_pos, const double* c_vel, int32_t B, void* stream,
-                       double* q_state = nullptr, double* qd_state = nullptr, const int32_t* n_steps = nullptr) {
+                       double* q_state = nullptr, double* qd_state = nullptr, const int32_t* n_steps = nullptr,
+                       const ReplanDev* rp = nullptr) {
     if (B < 0) { set_error("B must be >= 0"); return MPK_EINVAL; }
     if (B == 0 || h->dev.D == 0) return MPK_OK;     // empty batch: nothing to do (buffers may be NULL)
     if (!params || !init_pos || !init_vel || !pos || !vel) { set_error("NULL buffer"); return MPK_EINVAL; }
@@ -602,7 +603,7 @@ static int traj_common(Handle* h, const float* params, const float* init_pos, co
         int rc = get_shared(h, (float)init_time_shared, stream, &st);
         if (rc != MPK_OK) return rc;
         rc = launch_traj_shared(h->dev, st, params, init_pos, init_vel, pos, vel, actions, rd, c_pos, c_vel,
-                                q_state, qd_state, n_steps, B, h->num_cu, stream, &h->last_kernel);
+                                q_state, qd_state, n_steps, B, h->num_cu, stream, &h->last_kernel, rp);
         // horizons whose basis tables do not fit the episode-major kernel's LDS: the per-episode kernels below (dmp) or,
         // for fused actions / rollouts, the caller's two-launch path
         if (rc != MPK_ENOTIMPL || actions) return rc;
@@ -668,6 +669,48 @@ int mpk_trajectory_rollout(mpk_handle hh, const float* params, const float* init
     return launch_pd_rollout(rd, h->dev.D, pos, vel, q, qd, n_steps, actions, B, h->dev.T, stream);
 }
 
+int mpk_replan_step(mpk_handle hh, const float* params, const float* init_pos, const float* init_vel,
+                    double init_time_shared, const mpk_rollout_cfg* rc, double* q, double* qd,
+                    const mpk_replan_state* st, float* pos, float* vel, float* actions, int32_t B, void* stream) {
+    if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (B < 0) { set_error("B must be >= 0"); return MPK_EINVAL; }
+    if (B == 0) return MPK_OK;
+    if (!st || !st->traj_steps || !st->plan_steps || !st->done || !st->seg_len) { set_error("NULL replanning state"); return MPK_EINVAL; }
+    if ((st->cond_pos == nullptr) != (st->cond_vel == nullptr)) { set_error("cond_pos and cond_vel go together"); return MPK_EINVAL; }
+    if (st->every < 1 || st->horizon < 1) { set_error("every and horizon must be >= 1"); return MPK_EINVAL; }
+    if (!actions || !q || !qd) { set_error("NULL buffer"); return MPK_EINVAL; }
+    if (st->cond_pos && (st->cond_pos == init_pos || st->cond_vel == init_vel)) { set_error("cond_pos / cond_vel must not alias init_pos / init_vel"); return MPK_EINVAL; }
+    RolloutDev rd;
+    int r = fill_rollout(h, rc, &rd);
+    if (r != MPK_OK) return r;
+    if (rd.plant_type != MPK_PLANT_DOUBLE_INTEGRATOR) { set_error("mpk_replan_step integrates MPK_PLANT_DOUBLE_INTEGRATOR"); return MPK_EINVAL; }
+    ReplanDev rp;
+    rp.traj_steps = st->traj_steps; rp.plan_steps = st->plan_steps; rp.done = st->done; rp.seg_len = st->seg_len;
+    rp.done_out = st->done_out; rp.cond_pos = st->cond_pos; rp.cond_vel = st->cond_vel;
+    rp.every = st->every; rp.max_planning_times = st->max_planning_times; rp.horizon = st->horizon;
+    if (h->cfg.mp_type != MPK_MP_DMP && shared_phase(h, nullptr) && mfma_capable(h)) {
+        // ONE launch: integer state, trajectory, controller + plant, condition gather
+        r = traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, actions, &rd, nullptr,
+                        nullptr, B, stream, q, qd, nullptr, &rp);
+        if (r != MPK_ENOTIMPL) return r;
+    }
+    // what the fused kernel does not cover (dmp, learned tau / delay, long horizons, > 16 DoF or basis columns): the same
+    // result from the separate kernels
+    MPK_HIP(hipSetDevice(h->cfg.device));
+    r = launch_replan_advance(rp.traj_steps, rp.plan_steps, rp.seg_len, rp.done, rp.every, rp.max_planning_times,
+                              rp.horizon, h->dev.T, B, stream);
+    if (r != MPK_OK) return r;
+    if (rp.done_out) MPK_HIP(hipMemcpyAsync(rp.done_out, rp.done, (size_t)B, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    r = traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, nullptr, nullptr, nullptr,
+                    nullptr, B, stream);
+    if (r != MPK_OK) return r;
+    r = launch_pd_rollout(rd, h->dev.D, pos, vel, q, qd, rp.seg_len, actions, B, h->dev.T, stream);
+    if (r != MPK_OK) return r;
+    if (rp.cond_pos) return launch_condition_gather(pos, vel, rp.seg_len, rp.cond_pos, rp.cond_vel, B, h->dev.T, h->dev.D, stream);
+    return MPK_OK;
+}
+
 int mpk_pd_rollout(mpk_handle hh, const mpk_rollout_cfg* rc, const float* des_pos, const float* des_vel, double* q,
                    double* qd, const int32_t* n_steps, float* actions, int32_t B, int32_t T, void* stream) {
     if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
@@ -701,6 +744,20 @@ int mpk_reacher_rollout(mpk_handle hh, const mpk_rollout_cfg* rc, const float* d
     MPK_HIP(hipSetDevice(h->cfg.device));
     return launch_reacher_rollout(rd, h->dev.D, des_pos, des_vel, q, qd, n_steps, step0, goal, steps_before_reward,
                                   actions, rewards, B, T, stream);
+}
+
+int mpk_episode_reset(mpk_handle hh, const double* init_q, const double* init_qd, double* q, double* qd,
+                      float* cond_pos, float* cond_vel, int32_t* traj_steps, int32_t* plan_steps, uint8_t* done,
+                      int32_t B, void* stream) {
+    if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (B < 0) { set_error("B must be >= 0"); return MPK_EINVAL; }
+    if (B == 0) return MPK_OK;
+    if (!q || !qd || !traj_steps || !plan_steps || !done) { set_error("NULL buffer"); return MPK_EINVAL; }
+    if ((cond_pos == nullptr) != (cond_vel == nullptr)) { set_error("cond_pos and cond_vel go together"); return MPK_EINVAL; }
+    MPK_HIP(hipSetDevice(h->cfg.device));
+    return launch_episode_reset(init_q, init_qd, q, qd, cond_pos, cond_vel, traj_steps, plan_steps, done, B, h->dev.D,
+                                stream);
 }
 
 int mpk_replan_advance(mpk_handle hh, int32_t* traj_steps, int32_t* plan_steps, int32_t* seg_len, uint8_t* done,

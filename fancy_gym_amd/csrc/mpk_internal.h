@@ -55,6 +55,19 @@ struct RolloutDev {
     double pg[kMaxDofArgs], dg[kMaxDofArgs], lo[kMaxDofArgs], hi[kMaxDofArgs];
 };
 
+// integer replanning state advanced INSIDE the closed-loop trajectory kernel (mpk_replan_step): all device pointers,
+// traj_steps == nullptr switches it off.  Same rule as k_replan_advance, same gather as k_condition_gather.
+struct ReplanDev {
+    int32_t* traj_steps = nullptr;   // [B] in/out
+    int32_t* plan_steps = nullptr;   // [B] in/out
+    uint8_t* done = nullptr;         // [B] in/out
+    int32_t* seg_len = nullptr;      // [B] out
+    uint8_t* done_out = nullptr;     // [B] out, optional: snapshot of `done` after this plan
+    float* cond_pos = nullptr;       // [B, D] out, optional: desired state at the last executed step
+    float* cond_vel = nullptr;
+    int every = 1, max_planning_times = 0, horizon = 0;
+};
+
 // shared-phase table workspace produced by k_build_shared and consumed by k_traj_shared
 struct SharedTables {
     float* A = nullptr;    // [n_out][KP][TS]
@@ -70,7 +83,8 @@ int launch_build_shared(const DevCfg& c, float init_time, const SharedTables& st
 int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* params, const float* init_pos,
                        const float* init_vel, float* pos, float* vel, float* actions, const RolloutDev* rc,
                        const double* c_pos, const double* c_vel, double* q_state, double* qd_state,
-                       const int32_t* n_steps, int B, int num_cu, void* stream, const char** kernel_name);
+                       const int32_t* n_steps, int B, int num_cu, void* stream, const char** kernel_name,
+                       const ReplanDev* rp = nullptr);
 int launch_traj_rows(const DevCfg& c, const float* params, const float* init_pos, const float* init_vel,
                      const float* init_time, float init_time_shared, float* pos, float* vel, int32_t* range_flag,
                      int B, int num_cu, void* stream, const char** kernel_name);
@@ -81,6 +95,9 @@ int launch_condition_gather(const float* pos, const float* vel, const int32_t* s
 int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos, const float* des_vel, double* q,
                            double* qd, const int32_t* n_steps, const int32_t* step0, const double* goal,
                            int steps_before_reward, float* actions, double* rewards, int B, int T, void* stream);
+int launch_episode_reset(const double* init_q, const double* init_qd, double* q, double* qd, float* cond_pos,
+                         float* cond_vel, int32_t* traj_steps, int32_t* plan_steps, uint8_t* done, int B, int D,
+                         void* stream);
 int launch_replan_advance(int32_t* traj_steps, int32_t* plan_steps, int32_t* seg_len, uint8_t* done, int every,
                           int max_planning_times, int horizon, int T, int B, void* stream);
 int launch_validity(const float* pos, const float* params, int P, int D, const double* lo, const double* hi,

@@ -62,6 +62,40 @@ __device__ __forceinline__ float div_tau(float z, const TauDiv& t) {
     return __builtin_fmaf(__builtin_fmaf(-t.tau, q, z), t.r, q);
 }
 
+// The integer part of BlackBoxWrapper.step's loop (black_box_wrapper.py:174,197,206) for one episode and one plan:
+// how many steps this plan executes before the loop breaks (end of the horizon, or the schedule t % every == 0 while
+// plan_steps < max_planning_times), and the counters after it.  k_replan_advance and the fused closed-loop kernels both
+// call this, `writer` = the one lane per episode that stores the new state.
+__device__ __forceinline__ int replan_rule(const ReplanDev& rp, int b, int T, bool writer) {
+    if (rp.done[b]) {
+        if (writer) {
+            rp.seg_len[b] = 0;
+            if (rp.done_out) rp.done_out[b] = 1;
+        }
+        return 0;
+    }
+    const int cur = rp.traj_steps[b];
+    const int plan = rp.plan_steps[b] + 1;
+    // first global step g = cur + t + 1 (t >= 0) at which the loop breaks
+    int g_break = rp.horizon;
+    if (plan < rp.max_planning_times) {
+        const int gm = (cur / rp.every + 1) * rp.every;  // next multiple of `every` strictly above cur
+        g_break = gm < rp.horizon ? gm : rp.horizon;
+    }
+    int seg = g_break - cur;
+    if (seg > T) seg = T;
+    if (seg < 1) seg = 1;
+    if (writer) {
+        const uint8_t dn = (cur + seg) >= rp.horizon ? 1 : 0;
+        rp.plan_steps[b] = plan;
+        rp.seg_len[b] = seg;
+        rp.traj_steps[b] = cur + seg;
+        rp.done[b] = dn;
+        if (rp.done_out) rp.done_out[b] = dn;
+    }
+    return seg;
+}
+
 __device__ __forceinline__ int prodmp_index(float s, float scaled_dt) {
     // times_to_indices: round-half-even of the fp32 quotient -- the bit-exact integer part of the path
     return (int)rintf(s / scaled_dt);
@@ -385,6 +419,7 @@ struct TrajArgs {
     double* qd_state;      // [B, D] plant velocity, in/out
     const int32_t* n_steps;  // [B] executed steps of this plan (NULL = T)
     double plant_dt;
+    ReplanDev rp;            // closed loop only: integer replanning state advanced in the kernel (replaces n_steps)
 };
 
 struct ActArgs {
@@ -555,6 +590,8 @@ __device__ __forceinline__ void tile_epilogue(const f32x4& acc0, const f32x4& ac
             u = fmin(fmax(u, lod), hid);
             w[2 * kStageStride] = (float)u;
         }
+        // closed loop: actions of steps the plan does not execute are 0; the recurrence lanes overwrite the executed ones
+        if (CT >= 3) w[2 * kStageStride] = 0.0f;
     }
 }
 
@@ -731,6 +768,8 @@ __device__ __forceinline__ void stream_group(const TrajArgs& a, const LaneMap<KM
     const unsigned shw = ep_shift(a, b0 + L.bl);          // this column's episode image offset (same for every tile)
     const unsigned wofs = L.wofs + shw;
     const int o0 = L.bl * a.pitch + L.d + (int)shw;       // (row 0, this column) for the serial recurrences
+    // step whose desired state is gathered for the next plan's boundary condition (k_condition_gather's clamp); -1 = off
+    const int tcond = (CLOSED && a.rp.cond_pos) ? min(max(nst - 1, 0), T - 1) : -1;
     for (int rt = 0; rt < NRT; ++rt) {
         const int rows = min(16, T - rt * 16);
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
@@ -756,7 +795,9 @@ __device__ __forceinline__ void stream_group(const TrajArgs& a, const LaneMap<KM
                 // the step loop of black_box_wrapper.py:175-203 on the reference's torque double integrator
                 // (base_reacher_torque.py:25-26), serial in t on the lanes (q == 0); float64, no FMA
                 __builtin_amdgcn_wave_barrier();
-                if (serial) {
+                // row tiles past the executed steps (and past the gathered step) have nothing serial to do: a replanning
+                // plan that executes 25 of its 100 steps runs the recurrence on 2 of 7 tiles
+                if (serial && rt * 16 < max(nst, tcond + 1)) {
                     // canonical once: fmin / fmax otherwise quiet their bound operands again at every step
                     const double pgd = sg[0], dgd = sg[16], lod = __builtin_canonicalize(sg[32]),
                                  hid = __builtin_canonicalize(sg[48]), dtp = a.plant_dt;
@@ -767,17 +808,21 @@ __device__ __forceinline__ void stream_group(const TrajArgs& a, const LaneMap<KM
                     for (int tl = 0; tl < 16; ++tl) {
                         if (tl < rows) {
                             const int t = rt * 16 + tl;
-                            double u = 0.0;
+                            if (t == tcond) {     // condition_on_desired: the desired state at the last executed step
+                                const size_t si = (size_t)(b0 + L.bl) * D + L.d;
+                                a.rp.cond_pos[si] = pr[tl]; a.rp.cond_vel[si] = vr[tl];
+                            }
                             if (t < nst) {
                                 const double dp = (double)pr[tl], dv = (double)vr[tl];
+                                double u;
                                 if (CT - 3 == MPK_CTRL_MOTOR) u = pgd * (dp - qs) + dgd * (dv - qds);
                                 else if (CT - 3 == MPK_CTRL_POSITION) u = dp;
                                 else u = dv;
                                 u = fmin(fmax(u, lod), hid);
                                 qds = qds + dtp * u;
                                 qs = qs + dtp * qds;
+                                sSt[2 * kStageStride + o0 + tl * D] = (float)u;
                             }
-                            sSt[2 * kStageStride + o0 + tl * D] = (float)u;
                         }
                     }
                 }
@@ -895,7 +940,8 @@ __global__ void __launch_bounds__(256) k_traj_stream(const TrajArgs a, const Act
                 if (serial) {
                     const size_t si = (size_t)(b0 + L.bl) * D + L.d;
                     qs = a.q_state[si]; qds = a.qd_state[si];
-                    if (a.n_steps) nst = a.n_steps[b0 + L.bl];
+                    if (a.rp.traj_steps) nst = replan_rule(a.rp, b0 + L.bl, c.T, L.d == 0);
+                    else if (a.n_steps) nst = a.n_steps[b0 + L.bl];
                 }
             }
             stream_group<MP, CT, KM>(a, L, ap, sAux, sg, sSt, lane, b0, xb, cp, cv, ey, ez, eg, eul, qs, qds, nst, serial);
@@ -1002,7 +1048,8 @@ __global__ void __launch_bounds__(256) k_traj_stream(const TrajArgs a, const Act
                     if (serial) {
                         const size_t si = (size_t)(b0 + L.bl) * D + L.d;
                         qs = a.q_state[si]; qds = a.qd_state[si];
-                        if (a.n_steps) nst = a.n_steps[b0 + L.bl];
+                        if (a.rp.traj_steps) nst = replan_rule(a.rp, b0 + L.bl, c.T, L.d == 0);
+                        else if (a.n_steps) nst = a.n_steps[b0 + L.bl];
                     }
                 }
                 stream_group<MP, CT, KM>(a, L, ap, sAux, sg, sSt, lane, b0, xb, cp, cv, ey, ez, eg, eul, qs, qds, nst,
@@ -1113,13 +1160,15 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
             const size_t si = (size_t)bq * D + L.d;
             if (CLOSED) {
                 qs = a.q_state[si]; qds = a.qd_state[si];
-                if (a.n_steps) nst = a.n_steps[bq];
+                if (a.rp.traj_steps) nst = replan_rule(a.rp, bq, T, L.d == 0);
+                else if (a.n_steps) nst = a.n_steps[bq];
             } else {
                 ey = a.init_pos[si];
                 ez = a.init_vel[si] * c.tau;
                 eg = a.params[(size_t)bq * P + c.off + L.d * c.Kloc + c.nb] * c.gs;
             }
         }
+        const int tcond = (CLOSED && a.rp.cond_pos) ? min(max(nst - 1, 0), T - 1) : -1;
         for (int rt = 0; rt < NRT; ++rt) {
             const int rows = min(16, T - rt * 16);
             // 1. four C tiles on the matrix cores -> four staging images
@@ -1153,7 +1202,7 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
             }
             __builtin_amdgcn_wave_barrier();
             // 2. four recurrences in parallel, one per lane quarter (float64 / fp32 without FMA, as k_traj_stream)
-            if (serial) {
+            if (serial && (!CLOSED || rt * 16 < max(nst, tcond + 1))) {
                 if (CLOSED) {
                     float pr[16], vr[16];
 #pragma unroll
@@ -1162,17 +1211,21 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
                     for (int tl = 0; tl < 16; ++tl) {
                         if (tl < rows) {
                             const int t = rt * 16 + tl;
-                            double uu = 0.0;
+                            if (t == tcond) {     // condition_on_desired: the desired state at the last executed step
+                                const size_t si = (size_t)bq * D + L.d;
+                                a.rp.cond_pos[si] = pr[tl]; a.rp.cond_vel[si] = vr[tl];
+                            }
                             if (t < nst) {
                                 const double dp = (double)pr[tl], dv = (double)vr[tl];
+                                double uu;
                                 if (CT - 3 == MPK_CTRL_MOTOR) uu = pgd * (dp - qs) + dgd * (dv - qds);
                                 else if (CT - 3 == MPK_CTRL_POSITION) uu = dp;
                                 else uu = dv;
                                 uu = fmin(fmax(uu, lod), hid);
                                 qds = qds + a.plant_dt * uu;
                                 qs = qs + a.plant_dt * qds;
+                                sQ[2 * kStageStride + oq + tl * D] = (float)uu;
                             }
-                            sQ[2 * kStageStride + oq + tl * D] = (float)uu;
                         }
                     }
                 } else {
@@ -1298,9 +1351,11 @@ static int mapping_override() {
 int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* params, const float* init_pos,
                        const float* init_vel, float* pos, float* vel, float* actions, const RolloutDev* rc,
                        const double* c_pos, const double* c_vel, double* q_state, double* qd_state,
-                       const int32_t* n_steps, int B, int num_cu, void* stream, const char** kernel_name) {
+                       const int32_t* n_steps, int B, int num_cu, void* stream, const char** kernel_name,
+                       const ReplanDev* rp) {
     TrajArgs ta;
     ta.nrt_magic = 0; ta.gstride = 0;
+    if (rp) ta.rp = *rp;
     const bool closed = q_state != nullptr;
     ta.q_state = q_state; ta.qd_state = qd_state; ta.n_steps = n_steps; ta.plant_dt = rc ? rc->dt : 0.0;
     ta.c = c; ta.A = st.A; ta.aux = st.aux; ta.TS = st.TS;
@@ -2598,34 +2653,45 @@ int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const f
 // ------------------------------------------------------------------------------------------------------------
 // integer replanning state
 // ------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_replan_advance(int32_t* __restrict__ traj_steps, int32_t* __restrict__ plan_steps,
-                                                        int32_t* __restrict__ seg_len, uint8_t* __restrict__ done,
-                                                        const int every, const int max_planning_times,
-                                                        const int horizon, const int T, const int B) {
+__global__ void __launch_bounds__(256) k_replan_advance(const ReplanDev rp, const int T, const int B) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
-    if (done[b]) { seg_len[b] = 0; return; }
-    const int cur = traj_steps[b];
-    const int plan = plan_steps[b] + 1;
-    // first global step g = cur + t + 1 (t >= 0) at which the loop breaks
-    int g_break = horizon;
-    if (plan < max_planning_times) {
-        const int gm = (cur / every + 1) * every;  // next multiple of `every` strictly above cur
-        g_break = gm < horizon ? gm : horizon;
-    }
-    int seg = g_break - cur;
-    if (seg > T) seg = T;
-    if (seg < 1) seg = 1;
-    plan_steps[b] = plan;
-    seg_len[b] = seg;
-    traj_steps[b] = cur + seg;
-    done[b] = (cur + seg) >= horizon ? 1 : 0;
+    (void)replan_rule(rp, b, T, true);
 }
 
 int launch_replan_advance(int32_t* traj_steps, int32_t* plan_steps, int32_t* seg_len, uint8_t* done, int every,
                           int max_planning_times, int horizon, int T, int B, void* stream) {
-    hipLaunchKernelGGL(k_replan_advance, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, traj_steps,
-                       plan_steps, seg_len, done, every, max_planning_times, horizon, T, B);
+    ReplanDev rp;
+    rp.traj_steps = traj_steps; rp.plan_steps = plan_steps; rp.seg_len = seg_len; rp.done = done;
+    rp.every = every; rp.max_planning_times = max_planning_times; rp.horizon = horizon;
+    hipLaunchKernelGGL(k_replan_advance, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, rp, T, B);
+    MPK_LAUNCH_CHECK();
+    return MPK_OK;
+}
+
+// BlackBoxWrapper.reset (black_box_wrapper.py:222-229) for B episodes: counters to zero, plant state from the caller's
+// initial state (NULL = zeros) and its fp32 image, the boundary condition of the first plan (black_box_wrapper.py:110-111)
+__global__ void __launch_bounds__(256) k_episode_reset(const double* __restrict__ init_q, const double* __restrict__ init_qd,
+                                                       double* __restrict__ q, double* __restrict__ qd,
+                                                       float* __restrict__ cond_pos, float* __restrict__ cond_vel,
+                                                       int32_t* __restrict__ traj_steps, int32_t* __restrict__ plan_steps,
+                                                       uint8_t* __restrict__ done, const int B, const int D) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e < (long)B * D) {
+        const double a = init_q ? init_q[e] : 0.0, b = init_qd ? init_qd[e] : 0.0;
+        q[e] = a; qd[e] = b;
+        if (cond_pos) { cond_pos[e] = (float)a; cond_vel[e] = (float)b; }
+    }
+    if (e < B) {
+        traj_steps[e] = 0; plan_steps[e] = 0; done[e] = 0;
+    }
+}
+
+int launch_episode_reset(const double* init_q, const double* init_qd, double* q, double* qd, float* cond_pos,
+                         float* cond_vel, int32_t* traj_steps, int32_t* plan_steps, uint8_t* done, int B, int D,
+                         void* stream) {
+    hipLaunchKernelGGL(k_episode_reset, dim3((unsigned)(((long)B * D + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       init_q, init_qd, q, qd, cond_pos, cond_vel, traj_steps, plan_steps, done, B, D);
     MPK_LAUNCH_CHECK();
     return MPK_OK;
 }

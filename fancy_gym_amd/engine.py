@@ -268,6 +268,56 @@ class TrajectoryEngine:
             self._stream()))
         return pos, vel, act
 
+    def episode_reset(self, q: torch.Tensor, qd: torch.Tensor, traj_steps: torch.Tensor, plan_steps: torch.Tensor,
+                      done: torch.Tensor, init_q: Optional[torch.Tensor] = None, init_qd: Optional[torch.Tensor] = None,
+                      cond: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+        """BlackBoxWrapper.reset for device-resident episodes in one launch (mpk.h: mpk_episode_reset); everything in place"""
+        B, D = q.shape
+        for t, dt_ in ((q, torch.float64), (qd, torch.float64), (traj_steps, torch.int32), (plan_steps, torch.int32),
+                       (done, torch.uint8)):
+            assert t.dtype == dt_ and t.is_contiguous()
+        for t in (init_q, init_qd):
+            assert t is None or (t.dtype == torch.float64 and t.is_contiguous() and tuple(t.shape) == (B, D))
+        cp, cv = cond if cond is not None else (None, None)
+        _lib.check(self._lib.mpk_episode_reset(self._h, _dptr(init_q), _dptr(init_qd), q.data_ptr(), qd.data_ptr(),
+                                               _dptr(cp), _dptr(cv), traj_steps.data_ptr(), plan_steps.data_ptr(),
+                                               done.data_ptr(), B, self._stream()))
+
+    def replan_step(self, params, init_pos, init_vel, spec: RolloutSpec, q: torch.Tensor, qd: torch.Tensor,
+                    traj_steps: torch.Tensor, plan_steps: torch.Tensor, done: torch.Tensor, every: int,
+                    max_planning_times: int, horizon: int, init_time: float = 0.0, condition: bool = False, out=None):
+        """
+        One replanning step of BlackBoxWrapper.step for every episode (mpk.h: mpk_replan_step): integer state, plan,
+        controller + plant for the executed steps and -- ``condition`` -- the desired state at the last executed step, in
+        ONE launch where the fused closed-loop kernel applies.  q, qd, traj_steps, plan_steps, done are updated in place.
+        Returns dict(pos, vel, actions, seg_len int32 [B], done uint8 [B] snapshot, cond_pos, cond_vel (or None)).
+        """
+        params = torch.as_tensor(params, dtype=torch.float32, device=self.device)
+        if params.dim() == 1:
+            params = params[None]
+        params = params.contiguous()
+        B, D, T = params.shape[0], self.num_dof, self.num_steps
+        init_pos, init_vel = self._f32(init_pos, (B, D)), self._f32(init_vel, (B, D))
+        assert q.dtype == torch.float64 and qd.dtype == torch.float64 and q.is_contiguous() and qd.is_contiguous()
+        assert traj_steps.dtype == torch.int32 and plan_steps.dtype == torch.int32 and done.dtype == torch.uint8
+        if out is None:
+            pos, vel, act = (torch.empty((B, T, D), dtype=torch.float32, device=self.device) for _ in range(3))
+        else:
+            pos, vel, act = out
+        seg = torch.empty(B, dtype=torch.int32, device=self.device)
+        done_out = torch.empty(B, dtype=torch.uint8, device=self.device)
+        cp = cv = None
+        if condition:
+            cp, cv = (torch.empty((B, D), dtype=torch.float32, device=self.device) for _ in range(2))
+        st = _lib.mpk_replan_state(traj_steps.data_ptr(), plan_steps.data_ptr(), done.data_ptr(), seg.data_ptr(),
+                                   done_out.data_ptr(), _dptr(cp), _dptr(cv), int(every),
+                                   int(min(max_planning_times, 2 ** 31 - 1)), int(horizon), 0)
+        _lib.check(self._lib.mpk_replan_step(
+            self._h, params.data_ptr(), init_pos.data_ptr(), init_vel.data_ptr(), float(init_time), C.byref(spec.c),
+            q.data_ptr(), qd.data_ptr(), C.byref(st), pos.data_ptr(), vel.data_ptr(), act.data_ptr(), B,
+            self._stream()))
+        return dict(pos=pos, vel=vel, actions=act, seg_len=seg, done=done_out, cond_pos=cp, cond_vel=cv)
+
     def pd_rollout(self, spec: RolloutSpec, des_pos: torch.Tensor, des_vel: torch.Tensor, q: torch.Tensor,
                    qd: torch.Tensor, n_steps: Optional[torch.Tensor] = None, want_actions: bool = True,
                    out: Optional[torch.Tensor] = None):

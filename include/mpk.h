@@ -203,6 +203,35 @@ int mpk_trajectory_rollout(mpk_handle h, const float* params, const float* init_
                            const int32_t* n_steps, float* pos, float* vel, float* actions, int32_t B, void* stream);
 
 /*
+ * One replanning step of BlackBoxWrapper.step for B episodes (black_box_wrapper.py:150-217 with a replanning_schedule
+ * `t % every == 0`, max_planning_times and condition_on_desired -- e.g. envs/mujoco/box_pushing/mp_wrapper.py:68-92):
+ *   1. integer state  (= mpk_replan_advance):   seg_len, traj_steps, plan_steps, done        [int32 / uint8, bit-exact]
+ *   2. plan           (= mpk_trajectory):       (pos, vel)[B, T, D] from the boundary state (init_pos, init_vel)
+ *   3. execute        (= mpk_pd_rollout):       controller + clip + double-integrator plant for seg_len[b] steps
+ *   4. re-condition   (= mpk_condition_gather): cond_pos / cond_vel = desired state at the last executed step
+ * in ONE launch where the fused closed-loop kernel applies (shared phase, promp / prodmp, <= 16 DoF and basis columns),
+ * as the four separate kernels otherwise -- identical results either way.  All pointers in `st` are device pointers;
+ * done_out (optional) receives a snapshot of `done` after this plan; cond_pos / cond_vel (optional, both or neither) must
+ * not alias init_pos / init_vel.
+ */
+typedef struct mpk_replan_state {
+    int32_t* traj_steps;             /* dev [B] in/out  current_traj_steps  (black_box_wrapper.py:44,197) */
+    int32_t* plan_steps;             /* dev [B] in/out  plan_steps          (black_box_wrapper.py:45,174) */
+    uint8_t* done;                   /* dev [B] in/out  episode finished (horizon reached) */
+    int32_t* seg_len;                /* dev [B] out     steps this plan executes (infos['trajectory_length']) */
+    uint8_t* done_out;               /* dev [B] out, optional */
+    float*   cond_pos;               /* dev [B, D] out, optional (condition_on_desired, black_box_wrapper.py:199-201) */
+    float*   cond_vel;               /* dev [B, D] out, optional */
+    int32_t  every;                  /* replanning schedule t % every == 0 */
+    int32_t  max_planning_times;
+    int32_t  horizon;                /* max_episode_steps */
+    int32_t  reserved0;
+} mpk_replan_state;
+int mpk_replan_step(mpk_handle h, const float* params, const float* init_pos, const float* init_vel,
+                    double init_time_shared, const mpk_rollout_cfg* rc, double* q, double* qd,
+                    const mpk_replan_state* st, float* pos, float* vel, float* actions, int32_t B, void* stream);
+
+/*
  * Replaces the per-step loop of BlackBoxWrapper.step (black_box_wrapper.py:175-203) for plants that live on the GPU:
  *   for t < n_steps[b]: a = clip(controller(des_pos[b,t], des_vel[b,t], q[b], qd[b]), low, high); plant step
  *   des_pos, des_vel dev float  [B, T, D]
@@ -233,6 +262,16 @@ int mpk_reacher_rollout(mpk_handle h, const mpk_rollout_cfg* rc, const float* de
                         double* q, double* qd, const int32_t* n_steps, const int32_t* step0, const double* goal,
                         int32_t steps_before_reward, float* actions, double* rewards, int32_t B, int32_t T,
                         void* stream);
+
+/*
+ * BlackBoxWrapper.reset (black_box_wrapper.py:222-229) for B device-resident episodes, one launch: the integer state
+ * (traj_steps, plan_steps, done) to zero, the plant state (q, qd) double [B, D] from (init_q, init_qd) (NULL = zeros), and
+ * -- optional, both or neither -- its fp32 image (cond_pos, cond_vel) float [B, D]: the boundary condition of the first
+ * plan (current_pos / current_vel as set_initial_conditions receives them, black_box_wrapper.py:110-114).
+ */
+int mpk_episode_reset(mpk_handle h, const double* init_q, const double* init_qd, double* q, double* qd,
+                      float* cond_pos, float* cond_vel, int32_t* traj_steps, int32_t* plan_steps, uint8_t* done,
+                      int32_t B, void* stream);
 
 /*
  * Integer replanning bookkeeping of BlackBoxWrapper.step for the schedule `t % every == 0`

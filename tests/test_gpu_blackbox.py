@@ -877,3 +877,108 @@ def test_native_rccl_all_gather_single_rank(monkeypatch):
     with pytest.raises(ValueError):
         comm.all_gather(shard.double())
     comm.close()
+
+
+def _reference_loop(cur, plan, done, every, mpt, horizon, T):
+    """the step loop of black_box_wrapper.py:174-203 reduced to its integer state: steps executed by one plan"""
+    if done:
+        return 0, cur, plan
+    plan += 1                                            # :174  self.plan_steps += 1
+    n = 0
+    for t in range(T):                                   # :175  for t, (pos, vel) in enumerate(zip(position, velocity))
+        n += 1
+        cur += 1                                         # :196,205  t + 1 + self.current_traj_steps
+        if cur >= horizon:                               # the env's time limit truncates the episode
+            break
+        if cur % every == 0 and plan < mpt:              # :196  replanning_schedule(...) and plan_steps < max_planning_times
+            break
+    return n, cur, plan
+
+
+@pytest.mark.parametrize("cfg", [CFG4, CFG5, CFG3], ids=["prodmp_replan", "promp", "dmp"])
+@pytest.mark.parametrize("B", [1, 9, 200, 2100])
+@pytest.mark.parametrize("bulk,quad", [("0", "2"), ("0", "0"), ("2", "0")])
+def test_replan_step_equals_the_separate_kernels(cfg, B, bulk, quad, monkeypatch):
+    """mpk_replan_step (integer state + plan + rollout + condition gather; ONE launch for shared-phase promp / prodmp,
+    the separate kernels for dmp) == mpk_replan_advance -> mpk_trajectory_rollout -> mpk_condition_gather, bit for bit,
+    from random per-episode integer states (finished episodes, different step counters, exhausted planning budgets)"""
+    monkeypatch.setenv("MPK_BULK", bulk)
+    monkeypatch.setenv("MPK_QUAD", quad)
+    pc, bc, tc, dt, dur = cfg
+    eng = make_engine(pc, bc, tc, dt, dur)
+    T = eng.num_steps
+    every, mpt, horizon = max(T // 4, 1), 3, T
+    params, ip, iv = inputs(pc, bc, tc, B, seed=B + 3)
+    rng = np.random.default_rng(B)
+    q0, qd0 = rng.uniform(-1, 1, (B, 7)), rng.uniform(-0.2, 0.2, (B, 7))
+    ts0 = rng.integers(0, horizon, B).astype(np.int32)
+    ps0 = rng.integers(0, 4, B).astype(np.int32)
+    dn0 = (rng.random(B) < 0.2).astype(np.uint8)
+    spec = RolloutSpec("motor", 7, PG, DG, -0.9, 0.9, plant="double_integrator", dt=dt)
+
+    def state():
+        return (torch.tensor(q0, device="cuda"), torch.tensor(qd0, device="cuda"), torch.tensor(ts0, device="cuda"),
+                torch.tensor(ps0, device="cuda"), torch.tensor(dn0, device="cuda"))
+
+    q, qd, ts, ps, dn = state()
+    r = eng.replan_step(params, ip, iv, spec, q, qd, ts, ps, dn, every, mpt, horizon, init_time=0.1, condition=True)
+    fused = eng.last_kernel()
+    if tc.trajectory_generator_type != "dmp":
+        assert fused.endswith("closed>")
+    q2, qd2, ts2, ps2, dn2 = state()
+    seg = eng.replan_advance(ts2, ps2, dn2, every, mpt, horizon)
+    p2, v2, a2 = eng.trajectory_rollout(params, ip, iv, spec, q2, qd2, n_steps=seg, init_time=0.1)
+    cp, cv = eng.condition_gather(p2, v2, seg)
+    torch.cuda.synchronize()
+    assert torch.equal(r["seg_len"], seg) and torch.equal(ts, ts2) and torch.equal(ps, ps2) and torch.equal(dn, dn2)
+    assert torch.equal(r["done"], dn2)
+    assert torch.equal(r["pos"], p2) and torch.equal(r["vel"], v2) and torch.equal(r["actions"], a2)
+    assert torch.equal(q, q2) and torch.equal(qd, qd2)
+    assert torch.equal(r["cond_pos"], cp) and torch.equal(r["cond_vel"], cv)
+    # the integer rule against the oracle, and without the optional outputs
+    for b in range(min(B, 64)):
+        n, cur, plan = _reference_loop(int(ts0[b]), int(ps0[b]), bool(dn0[b]), every, mpt, horizon, T)
+        assert (int(seg[b]), int(ts[b]), int(ps[b]), bool(dn[b])) == (n, cur, plan, bool(dn0[b]) or cur >= horizon)
+    q3, qd3, ts3, ps3, dn3 = state()
+    r3 = eng.replan_step(params, ip, iv, spec, q3, qd3, ts3, ps3, dn3, every, mpt, horizon, init_time=0.1)
+    assert r3["cond_pos"] is None and torch.equal(r3["actions"], a2) and torch.equal(q3, q2)
+
+
+def test_replan_step_argument_checks():
+    import ctypes as C
+    from fancy_gym_amd import _lib
+    pc, bc, tc, dt, dur = CFG4
+    eng = make_engine(pc, bc, tc, dt, dur)
+    B = 4
+    params, ip, iv = inputs(pc, bc, tc, B, seed=0)
+    spec = RolloutSpec("motor", 7, PG, DG, -1, 1, plant="static")
+    z = lambda *s, dt_=torch.float64: torch.zeros(s, dtype=dt_, device="cuda")
+    with pytest.raises(ValueError, match="DOUBLE_INTEGRATOR"):
+        eng.replan_step(params, ip, iv, spec, z(B, 7), z(B, 7), z(B, dt_=torch.int32), z(B, dt_=torch.int32),
+                        z(B, dt_=torch.uint8), 25, 4, 100)
+    spec = RolloutSpec("motor", 7, PG, DG, -1, 1, plant="double_integrator", dt=dt)
+    with pytest.raises(ValueError, match="every"):
+        eng.replan_step(params, ip, iv, spec, z(B, 7), z(B, 7), z(B, dt_=torch.int32), z(B, dt_=torch.int32),
+                        z(B, dt_=torch.uint8), 0, 4, 100)
+    st = _lib.mpk_replan_state()
+    assert _lib.load().mpk_replan_step(eng._h, 0, 0, 0, 0.0, C.byref(spec.c), 0, 0, C.byref(st), 0, 0, 0, B, None) == _lib.MPK_EINVAL
+
+
+@pytest.mark.parametrize("B", [1, 37, 5000])
+def test_episode_reset_is_one_exact_launch(B):
+    """mpk_episode_reset: counters to zero, plant state copied (or zeroed), fp32 image = numpy's float32 cast"""
+    pc, bc, tc, dt, dur = CFG4
+    eng = make_engine(pc, bc, tc, dt, dur)
+    rng = np.random.default_rng(B)
+    q0, qd0 = rng.uniform(-3, 3, (B, 7)), rng.uniform(-1, 1, (B, 7))
+    junk = lambda dt_, *s: torch.full(s, 7, dtype=dt_, device="cuda")
+    q, qd = junk(torch.float64, B, 7), junk(torch.float64, B, 7)
+    ts, ps, dn = junk(torch.int32, B), junk(torch.int32, B), junk(torch.uint8, B)
+    cp, cv = junk(torch.float32, B, 7), junk(torch.float32, B, 7)
+    eng.episode_reset(q, qd, ts, ps, dn, torch.tensor(q0, device="cuda"), torch.tensor(qd0, device="cuda"), cond=(cp, cv))
+    torch.cuda.synchronize()
+    assert np.array_equal(q.cpu().numpy(), q0) and np.array_equal(qd.cpu().numpy(), qd0)
+    assert np.array_equal(cp.cpu().numpy(), q0.astype(np.float32)) and np.array_equal(cv.cpu().numpy(), qd0.astype(np.float32))
+    assert not ts.any() and not ps.any() and not dn.any()
+    eng.episode_reset(q, qd, ts, ps, dn)          # no initial state: zeros; no fp32 image
+    assert not q.any() and not qd.any() and np.array_equal(cp.cpu().numpy(), q0.astype(np.float32))

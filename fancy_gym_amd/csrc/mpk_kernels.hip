@@ -67,13 +67,8 @@ __device__ __forceinline__ float div_tau(float z, const TauDiv& t) {
 // plan_steps < max_planning_times), and the counters after it.  k_replan_advance and the fused closed-loop kernels both
 // call this, `writer` = the one lane per episode that stores the new state.
 __device__ __forceinline__ int replan_rule(const ReplanDev& rp, int b, int T, bool writer) {
-    if (rp.done[b]) {
-        if (writer) {
-            rp.seg_len[b] = 0;
-            if (rp.done_out) rp.done_out[b] = 1;
-        }
-        return 0;
-    }
+    // three independent loads (one memory round trip): this sits in front of a serial recurrence
+    const uint8_t was_done = rp.done[b];
     const int cur = rp.traj_steps[b];
     const int plan = rp.plan_steps[b] + 1;
     // first global step g = cur + t + 1 (t >= 0) at which the loop breaks
@@ -85,15 +80,47 @@ __device__ __forceinline__ int replan_rule(const ReplanDev& rp, int b, int T, bo
     int seg = g_break - cur;
     if (seg > T) seg = T;
     if (seg < 1) seg = 1;
+    if (was_done) seg = 0;                               // a finished episode is left alone
     if (writer) {
-        const uint8_t dn = (cur + seg) >= rp.horizon ? 1 : 0;
-        rp.plan_steps[b] = plan;
         rp.seg_len[b] = seg;
-        rp.traj_steps[b] = cur + seg;
-        rp.done[b] = dn;
-        if (rp.done_out) rp.done_out[b] = dn;
+        if (!was_done) {
+            const uint8_t dn = (cur + seg) >= rp.horizon ? 1 : 0;
+            rp.plan_steps[b] = plan;
+            rp.traj_steps[b] = cur + seg;
+            rp.done[b] = dn;
+            if (rp.done_out) rp.done_out[b] = dn;
+        } else if (rp.done_out) {
+            rp.done_out[b] = 1;
+        }
     }
     return seg;
+}
+
+// Basis tables -> LDS, once per workgroup of 256 threads: every thread issues ALL its loads (up to four chunks of the
+// rows, one of the aux row) before its first LDS write -- one memory round trip instead of one per loop iteration,
+// which matters for launches that give a wave a single work unit.  Longer tables take plain loops after that.
+__device__ __forceinline__ void stage_tables(const float* __restrict__ A, const float* __restrict__ aux, float* sA,
+                                             float* sAux, int nA4, int nX4, int tid) {
+    const float4* src = reinterpret_cast<const float4*>(A);
+    const float4* s2 = reinterpret_cast<const float4*>(aux);
+    float4* dst = reinterpret_cast<float4*>(sA);
+    float4* d2 = reinterpret_cast<float4*>(sAux);
+    float4 x = {0.f, 0.f, 0.f, 0.f};
+    float4 r[4] = {x, x, x, x};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = tid + 256 * k;
+        if (i < nA4) r[k] = src[i];      // (a select between src[i] and a private zero would become a flat load)
+    }
+    if (tid < nX4) x = s2[tid];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = tid + 256 * k;
+        if (i < nA4) dst[i] = r[k];
+    }
+    if (tid < nX4) d2[tid] = x;
+    for (int i = tid + 1024; i < nA4; i += 256) dst[i] = src[i];
+    for (int i = tid + 256; i < nX4; i += 256) d2[i] = s2[i];
 }
 
 __device__ __forceinline__ int prodmp_index(float s, float scaled_dt) {
@@ -892,15 +919,7 @@ __global__ void __launch_bounds__(256) k_traj_stream(const TrajArgs a, const Act
     float* sSt = smem + wave * kStageFloats;
     float* sA = sTab;
     float* sAux = sTab + NOUT * KP * TS;
-    {   // stage the shared basis tables through LDS once per workgroup
-        const float4* src = reinterpret_cast<const float4*>(a.A);
-        float4* dst = reinterpret_cast<float4*>(sA);
-        const int n4 = (NOUT * KP * TS) >> 2;
-        for (int i = threadIdx.x; i < n4; i += 256) dst[i] = src[i];
-        const float4* s2 = reinterpret_cast<const float4*>(a.aux);
-        float4* d2 = reinterpret_cast<float4*>(sAux);
-        for (int i = threadIdx.x; i < (TS >> 2); i += 256) d2[i] = s2[i];
-    }
+    stage_tables(a.A, a.aux, sA, sAux, (NOUT * KP * TS) >> 2, TS >> 2, threadIdx.x);   // once per workgroup
     __syncthreads();
     const LaneMap<KM> L = make_lane_map<MP, KM>(a, lane);
     // XCD-contiguous virtual block id (workgroup b runs on XCD b % 8): neighbouring episode groups share an L2
@@ -1100,16 +1119,6 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
     float* sW = smem + wave * (kQuad * kQuadImg);
     float* sA = sTab;
     float* sAux = sTab + NOUT * KP * TS;
-    {
-        const float4* src = reinterpret_cast<const float4*>(a.A);
-        float4* dst = reinterpret_cast<float4*>(sA);
-        const int n4 = (NOUT * KP * TS) >> 2;
-        for (int i = threadIdx.x; i < n4; i += 256) dst[i] = src[i];
-        const float4* s2 = reinterpret_cast<const float4*>(a.aux);
-        float4* d2 = reinterpret_cast<float4*>(sAux);
-        for (int i = threadIdx.x; i < (TS >> 2); i += 256) d2[i] = s2[i];
-    }
-    __syncthreads();
     const LaneMap<KM> L = make_lane_map<MP, KM>(a, lane);
     const int NTW = L.NTW, NRT = (T + 15) >> 4;
     const int nb8 = gridDim.x >> 3;
@@ -1117,6 +1126,41 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
     const int ustride = gridDim.x * 4;
     const int NU = (a.G + kQuad - 1) / kQuad;
     int u = vb * 4 + wave;
+
+    // A lane's serial-recurrence inputs for one unit: group u * 4 + q, column (bl, d).  Fetched one unit ahead, like the
+    // B-fragment inputs (the integer replanning state of the episode is advanced at fetch time by its d == 0 lane).
+    struct SerialIn { double qs, qds; int nst; float ey, ez, eg; bool on; };
+    auto load_serial = [&](int uu) {
+        SerialIn si{0.0, 0.0, T, 0.f, 0.f, 0.f, false};
+        const int gq = uu * kQuad + L.q, bq = gq * NTW + L.bl;
+        si.on = L.dvalid && gq < a.G && bq < B;
+        if (si.on) {
+            const size_t ix = (size_t)bq * D + L.d;
+            if (CLOSED) {
+                si.qs = a.q_state[ix]; si.qds = a.qd_state[ix];
+                if (a.rp.traj_steps) si.nst = replan_rule(a.rp, bq, T, L.d == 0);
+                else if (a.n_steps) si.nst = a.n_steps[bq];
+            } else {
+                si.ey = a.init_pos[ix];
+                si.ez = a.init_vel[ix] * c.tau;
+                si.eg = a.params[(size_t)bq * P + c.off + L.d * c.Kloc + c.nb] * c.gs;
+            }
+        }
+        return si;
+    };
+    // the first unit's inputs are in flight while the workgroup stages the basis tables
+    GroupIn<KM> nx[kQuad];
+    SerialIn sn{0.0, 0.0, T, 0.f, 0.f, 0.f, false};
+    if (u < NU) {
+#pragma unroll
+        for (int j = 0; j < kQuad; ++j) {
+            const int g = u * kQuad + j;
+            nx[j] = load_group<MP, false, KM>(a, L, g < a.G ? g : a.G - 1);
+        }
+        sn = load_serial(u);
+    }
+    stage_tables(a.A, a.aux, sA, sAux, (NOUT * KP * TS) >> 2, TS >> 2, threadIdx.x);
+    __syncthreads();
     if (u >= NU) return;
     const float* ap = sA + L.q * TS + L.col;
     const TauDiv td = make_tau_div(c.tau);
@@ -1130,16 +1174,11 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
     (void)sgain;
 
     float xb[kQuad][KM];
-    GroupIn<KM> nx[kQuad];
-#pragma unroll
-    for (int j = 0; j < kQuad; ++j) {
-        const int g = u * kQuad + j;
-        nx[j] = load_group<MP, false, KM>(a, L, g < a.G ? g : a.G - 1);
-    }
     while (u < NU) {
         const int g0 = u * kQuad;
 #pragma unroll
         for (int j = 0; j < kQuad; ++j) finish_group<KM>(L, nx[j], xb[j]);
+        const SerialIn sc = sn;
         const int un = u + ustride;
         if (un < NU) {
 #pragma unroll
@@ -1147,30 +1186,39 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
                 const int g = un * kQuad + j;
                 nx[j] = load_group<MP, false, KM>(a, L, g < a.G ? g : a.G - 1);
             }
+            sn = load_serial(un);
         }
         // this lane's recurrence: group g0 + q, column (bl, d)
         const int gq = g0 + L.q, bq = gq * NTW + L.bl;
-        const bool serial = L.dvalid && gq < a.G && bq < B;
+        const bool serial = sc.on;
         const int oq = L.bl * a.pitch + L.d + (int)ep_shift(a, bq);      // (row 0, this column) in group q's image
         float* sQ = sW + L.q * kQuadImg;
-        double qs = 0.0, qds = 0.0;
-        int nst = T;
-        float ey = 0.f, ez = 0.f, eg = 0.f;
-        if (serial) {
-            const size_t si = (size_t)bq * D + L.d;
-            if (CLOSED) {
-                qs = a.q_state[si]; qds = a.qd_state[si];
-                if (a.rp.traj_steps) nst = replan_rule(a.rp, bq, T, L.d == 0);
-                else if (a.n_steps) nst = a.n_steps[bq];
-            } else {
-                ey = a.init_pos[si];
-                ez = a.init_vel[si] * c.tau;
-                eg = a.params[(size_t)bq * P + c.off + L.d * c.Kloc + c.nb] * c.gs;
-            }
-        }
+        double qs = sc.qs, qds = sc.qds;
+        const int nst = sc.nst;
+        float ey = sc.ey, ez = sc.ez, eg = sc.eg;
         const int tcond = (CLOSED && a.rp.cond_pos) ? min(max(nst - 1, 0), T - 1) : -1;
+        // A fragments (basis rows of a row tile) are the same for the four groups: read from LDS once per tile, one tile
+        // ahead, into registers.  Left to the compiler they are re-read in front of every MFMA (it cannot prove that
+        // the staging writes do not alias the tables), and with one or two waves per SIMD each of those LDS round trips
+        // is exposed.
+        float afn[NOUT][KM];
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+            for (int m = 0; m < KM; ++m) afn[o][m] = ap[(o * KP + 4 * m) * TS];
         for (int rt = 0; rt < NRT; ++rt) {
             const int rows = min(16, T - rt * 16);
+            float af[NOUT][KM];
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+                for (int m = 0; m < KM; ++m) af[o][m] = afn[o][m];
+            if (rt + 1 < NRT) {
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+                    for (int m = 0; m < KM; ++m) afn[o][m] = ap[(o * KP + 4 * m) * TS + (rt + 1) * 16];
+            }
             // 1. four C tiles on the matrix cores -> four staging images
 #pragma unroll
             for (int j = 0; j < kQuad; ++j) {
@@ -1178,10 +1226,9 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
                     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int m = 0; m < KM; ++m) {
-                        const float* am = ap + (4 * m) * TS + rt * 16;
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[0], xb[j][m], acc0, 0, 0, 0);
-                        if (NOUT > 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[KP * TS], xb[j][m], acc1, 0, 0, 0);
-                        if (NOUT > 2) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[2 * KP * TS], xb[j][m], acc2, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][m], xb[j][m], acc0, 0, 0, 0);
+                        if (NOUT > 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[NOUT > 1 ? 1 : 0][m], xb[j][m], acc1, 0, 0, 0);
+                        if (NOUT > 2) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[NOUT > 2 ? 2 : 0][m], xb[j][m], acc2, 0, 0, 0);
                     }
                     float* sJ = sW + j * kQuadImg;
                     const unsigned wofs = L.wofs + ep_shift(a, (g0 + j) * NTW + L.bl);

@@ -1103,9 +1103,10 @@ constexpr int kQuad = 4;
 // (measured before the skew: 43 % of the kernel's LDS cycles were bank conflicts)
 constexpr int kQuadImg = 3 * kStageStride + 8;
 
-template <int MP, int CT, int KM>
+template <int MP, int CT, int KM, int NQ>
 __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActArgs act) {
-    __shared__ __attribute__((aligned(16))) float smem[4 * kQuad * kQuadImg];   // per wave: 4 x (pos|vel|act or force)
+    static_assert(NQ == 2 || NQ == 4, "two or four groups per wave");
+    __shared__ __attribute__((aligned(16))) float smem[4 * NQ * kQuadImg];   // per wave: 4 x (pos|vel|act or force)
     __shared__ double sgain[4][64];
     extern __shared__ __attribute__((aligned(16))) float sTab[];   // [NOUT][KP][TS] rows + [TS] aux
     constexpr bool CLOSED = CT >= 3;
@@ -1116,7 +1117,7 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int KP = 4 * KM, TS = a.TS, D = c.D, B = a.B, P = c.P, T = c.T;
-    float* sW = smem + wave * (kQuad * kQuadImg);
+    float* sW = smem + wave * (NQ * kQuadImg);
     float* sA = sTab;
     float* sAux = sTab + NOUT * KP * TS;
     const LaneMap<KM> L = make_lane_map<MP, KM>(a, lane);
@@ -1124,7 +1125,7 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
     const int nb8 = gridDim.x >> 3;
     const int vb = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * nb8 + (blockIdx.x >> 3) : blockIdx.x;
     const int ustride = gridDim.x * 4;
-    const int NU = (a.G + kQuad - 1) / kQuad;
+    const int NU = (a.G + NQ - 1) / NQ;
     int u = vb * 4 + wave;
 
     // A lane's serial-recurrence inputs for one unit: group u * 4 + q, column (bl, d).  Fetched one unit ahead, like the
@@ -1132,8 +1133,8 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
     struct SerialIn { double qs, qds; int nst; float ey, ez, eg; bool on; };
     auto load_serial = [&](int uu) {
         SerialIn si{0.0, 0.0, T, 0.f, 0.f, 0.f, false};
-        const int gq = uu * kQuad + L.q, bq = gq * NTW + L.bl;
-        si.on = L.dvalid && gq < a.G && bq < B;
+        const int gq = uu * NQ + L.q, bq = gq * NTW + L.bl;
+        si.on = L.dvalid && L.q < NQ && gq < a.G && bq < B;
         if (si.on) {
             const size_t ix = (size_t)bq * D + L.d;
             if (CLOSED) {
@@ -1149,12 +1150,12 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
         return si;
     };
     // the first unit's inputs are in flight while the workgroup stages the basis tables
-    GroupIn<KM> nx[kQuad];
+    GroupIn<KM> nx[NQ];
     SerialIn sn{0.0, 0.0, T, 0.f, 0.f, 0.f, false};
     if (u < NU) {
 #pragma unroll
-        for (int j = 0; j < kQuad; ++j) {
-            const int g = u * kQuad + j;
+        for (int j = 0; j < NQ; ++j) {
+            const int g = u * NQ + j;
             nx[j] = load_group<MP, false, KM>(a, L, g < a.G ? g : a.G - 1);
         }
         sn = load_serial(u);
@@ -1173,17 +1174,17 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
     }
     (void)sgain;
 
-    float xb[kQuad][KM];
+    float xb[NQ][KM];
     while (u < NU) {
-        const int g0 = u * kQuad;
+        const int g0 = u * NQ;
 #pragma unroll
-        for (int j = 0; j < kQuad; ++j) finish_group<KM>(L, nx[j], xb[j]);
+        for (int j = 0; j < NQ; ++j) finish_group<KM>(L, nx[j], xb[j]);
         const SerialIn sc = sn;
         const int un = u + ustride;
         if (un < NU) {
 #pragma unroll
-            for (int j = 0; j < kQuad; ++j) {
-                const int g = un * kQuad + j;
+            for (int j = 0; j < NQ; ++j) {
+                const int g = un * NQ + j;
                 nx[j] = load_group<MP, false, KM>(a, L, g < a.G ? g : a.G - 1);
             }
             sn = load_serial(un);
@@ -1221,7 +1222,7 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
             }
             // 1. four C tiles on the matrix cores -> four staging images
 #pragma unroll
-            for (int j = 0; j < kQuad; ++j) {
+            for (int j = 0; j < NQ; ++j) {
                 if (g0 + j < a.G) {
                     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1302,7 +1303,7 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
             __builtin_amdgcn_wave_barrier();
             // 3. coalesced stores of the four tiles
 #pragma unroll
-            for (int j = 0; j < kQuad; ++j)
+            for (int j = 0; j < NQ; ++j)
                 if (g0 + j < a.G)
                     tile_store<NST, KM, false>(a, L, sW + j * kQuadImg, lane, (g0 + j) * NTW, rt, rows);
             __builtin_amdgcn_wave_barrier();
@@ -1319,17 +1320,26 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
 
 template <int MP, int CT>
 static int launch_traj_t(const TrajArgs& ta, const ActArgs& aa, bool stream_mode, bool write_through, bool bulk,
-                         bool quad, int blocks, size_t lds, void* stream) {
+                         int quad, int blocks, size_t lds, void* stream) {
     const dim3 g(blocks), b(256);
     hipStream_t s = (hipStream_t)stream;
     const int km = ta.c.KP / 4;
     if (stream_mode && quad) {
         if constexpr (MP == MPK_MP_DMP || CT >= 3) {
-            switch (km) {
-                case 1: hipLaunchKernelGGL((k_traj_quad<MP, CT, 1>), g, b, lds, s, ta, aa); break;
-                case 2: hipLaunchKernelGGL((k_traj_quad<MP, CT, 2>), g, b, lds, s, ta, aa); break;
-                case 3: hipLaunchKernelGGL((k_traj_quad<MP, CT, 3>), g, b, lds, s, ta, aa); break;
-                default: hipLaunchKernelGGL((k_traj_quad<MP, CT, 4>), g, b, lds, s, ta, aa); break;
+            if (quad == 2) {
+                switch (km) {
+                    case 1: hipLaunchKernelGGL((k_traj_quad<MP, CT, 1, 2>), g, b, lds, s, ta, aa); break;
+                    case 2: hipLaunchKernelGGL((k_traj_quad<MP, CT, 2, 2>), g, b, lds, s, ta, aa); break;
+                    case 3: hipLaunchKernelGGL((k_traj_quad<MP, CT, 3, 2>), g, b, lds, s, ta, aa); break;
+                    default: hipLaunchKernelGGL((k_traj_quad<MP, CT, 4, 2>), g, b, lds, s, ta, aa); break;
+                }
+            } else {
+                switch (km) {
+                    case 1: hipLaunchKernelGGL((k_traj_quad<MP, CT, 1, 4>), g, b, lds, s, ta, aa); break;
+                    case 2: hipLaunchKernelGGL((k_traj_quad<MP, CT, 2, 4>), g, b, lds, s, ta, aa); break;
+                    case 3: hipLaunchKernelGGL((k_traj_quad<MP, CT, 3, 4>), g, b, lds, s, ta, aa); break;
+                    default: hipLaunchKernelGGL((k_traj_quad<MP, CT, 4, 4>), g, b, lds, s, ta, aa); break;
+                }
             }
         }
     } else if (stream_mode) {
@@ -1373,7 +1383,7 @@ static int launch_traj_t(const TrajArgs& ta, const ActArgs& aa, bool stream_mode
 
 template <int MP>
 static int launch_traj_ct(const TrajArgs& ta, const ActArgs& aa, int ct, bool stream_mode, bool write_through,
-                          bool bulk, bool quad, int blocks, size_t lds, void* stream) {
+                          bool bulk, int quad, int blocks, size_t lds, void* stream) {
     if constexpr (MP != MPK_MP_DMP) {
         switch (ct) {
             case MPK_CTRL_MOTOR: return launch_traj_t<MP, MPK_CTRL_MOTOR>(ta, aa, stream_mode, write_through, bulk, quad, blocks, lds, stream);
@@ -1454,19 +1464,29 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     int blocks;
     size_t lds = 0;
     bool bulk = false;
-    // serial-recurrence variants (DMP, closed loop): four groups per wave, recurrences in parallel on the lane quarters
-    // (MPK_QUAD=0 falls back to k_traj_stream, for A/B runs); needs its 52 KB of staging + the tables within 64 KB
-    bool quad = stream_mode && (c.mp_type == MPK_MP_DMP || closed) &&
-                table_bytes + (4 * kQuad * kQuadImg) * sizeof(float) + 4 * 64 * sizeof(double) <= 64 * 1024;
-    {   // automatic: only when the 4x coarser work units still give every CU a few waves (MPK_QUAD: 0 off, 2 force)
+    // serial-recurrence variants (DMP, closed loop): four (or two) groups per wave, recurrences in parallel on the lane
+    // quarters; needs its staging (52 / 26 KB) + the tables within 64 KB.  quad = groups per wave, 0 = k_traj_stream.
+    // MPK_QUAD: 0 off, 2 force four, 3 force two (A/B runs, tests)
+    int quad = 0;
+    {
+        auto fits = [&](int nq) { return table_bytes + (4 * nq * kQuadImg) * sizeof(float) + 4 * 64 * sizeof(double) <= 64 * 1024; };
+        const bool serial_variant = stream_mode && (c.mp_type == MPK_MP_DMP || closed);
         int quad_mode = 1;
         if (const char* e = getenv("MPK_QUAD")) quad_mode = atoi(e);
-        const long units = (ta.G + kQuad - 1) / kQuad;
-        quad = quad && quad_mode != 0 && (quad_mode == 2 || units >= (long)num_cu * 4);
+        const long units4 = (ta.G + 3) / 4, units2 = (ta.G + 1) / 2;
+        // automatic: four per wave once that still leaves two waves per SIMD of work, two per wave down to one wave
+        // per SIMD (with one wave per SIMD every LDS / MFMA latency is exposed: B = 8192 closed loop 22 -> 17 us)
+        if (serial_variant && quad_mode != 0) {
+            if (quad_mode == 2) quad = fits(4) ? 4 : 0;
+            else if (quad_mode == 3) quad = fits(2) ? 2 : 0;
+            else if (fits(4) && units4 >= (long)num_cu * 8) quad = 4;
+            else if (fits(2) && units2 >= (long)num_cu * 4) quad = 2;
+            else if (fits(4) && units4 >= (long)num_cu * 4) quad = 4;
+        }
     }
     if (quad) {
         lds = table_bytes;
-        const long units = (ta.G + kQuad - 1) / kQuad;
+        const long units = (ta.G + quad - 1) / quad;
         const long waves = units < max_waves ? units : max_waves;
         blocks = (int)((waves + 3) / 4);
         if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;
@@ -1509,15 +1529,15 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     if (blocks < 1) blocks = 1;
     switch (c.mp_type) {
         case MPK_MP_PRODMP:
-            *kernel_name = closed ? (quad ? "k_traj_quad<prodmp,closed>" : "k_traj_stream<prodmp,closed>") : stream_mode ? (act ? "k_traj_stream<prodmp,act>" : "k_traj_stream<prodmp>")
+            *kernel_name = closed ? (quad == 4 ? "k_traj_quad<prodmp,closed>" : quad == 2 ? "k_traj_duo<prodmp,closed>" : "k_traj_stream<prodmp,closed>") : stream_mode ? (act ? "k_traj_stream<prodmp,act>" : "k_traj_stream<prodmp>")
                                        : (act ? "k_traj_tiles<prodmp,act>" : "k_traj_tiles<prodmp>");
             return launch_traj_ct<MPK_MP_PRODMP>(ta, aa, ct, stream_mode, write_through, bulk, quad, blocks, lds, stream);
         case MPK_MP_PROMP:
-            *kernel_name = closed ? (quad ? "k_traj_quad<promp,closed>" : "k_traj_stream<promp,closed>") : stream_mode ? (act ? "k_traj_stream<promp,act>" : "k_traj_stream<promp>")
+            *kernel_name = closed ? (quad == 4 ? "k_traj_quad<promp,closed>" : quad == 2 ? "k_traj_duo<promp,closed>" : "k_traj_stream<promp,closed>") : stream_mode ? (act ? "k_traj_stream<promp,act>" : "k_traj_stream<promp>")
                                        : (act ? "k_traj_tiles<promp,act>" : "k_traj_tiles<promp>");
             return launch_traj_ct<MPK_MP_PROMP>(ta, aa, ct, stream_mode, write_through, bulk, quad, blocks, lds, stream);
         default:
-            *kernel_name = quad ? "k_traj_quad<dmp>" : "k_traj_stream<dmp>";
+            *kernel_name = quad == 4 ? "k_traj_quad<dmp>" : quad == 2 ? "k_traj_duo<dmp>" : "k_traj_stream<dmp>";
             return launch_traj_ct<MPK_MP_DMP>(ta, aa, -1, true, false, bulk, quad, blocks, lds, stream);
     }
 }

@@ -719,7 +719,11 @@ __global__ void __launch_bounds__(256, (KM <= 2 ? 7 : 1)) k_traj_tiles(const Tra
     const int NRT = (T + 15) >> 4;
     // Wn % NRT == 0: this wave owns row tile rt for every item.  wid / NRT by multiply-high with the host's magic
     // number (exact for wid < 2^32 / NRT, which the launcher guarantees): the generic division is ~25 instructions
-    const int wid = blockIdx.x * 4 + wave;
+    // XCD-contiguous virtual block id (workgroup b runs on XCD b % 8): the row tiles of an episode group -- which read
+    // the same parameters and write one contiguous trajectory -- stay behind one L2
+    const int nb8 = (int)(gridDim.x >> 3);
+    const int vb = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * nb8 + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int wid = vb * 4 + wave;
     const int gstride = a.gstride;
     int g = a.nrt_magic ? (int)__umulhi((unsigned)wid, a.nrt_magic) : wid;      // magic 0: NRT == 1
     const int rt = wid - g * NRT;
@@ -1522,7 +1526,12 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         if ((items + ipw - 1) / ipw > wave_cap) ipw = (items + wave_cap - 1) / wave_cap;
         const long waves = (items + ipw - 1) / ipw;
         blocks = (int)((waves + 3) / 4);
-        blocks = (blocks + NRT - 1) / NRT * NRT;                         // #waves % NRT == 0
+        {   // #waves % NRT == 0, and a multiple of 8 blocks for the XCD remap once there are that many
+            int g8 = 8, r = NRT;
+            while (r) { const int t = g8 % r; g8 = r; r = t; }           // gcd(8, NRT)
+            const int unit = blocks >= 8 ? NRT / g8 * 8 : NRT;           // lcm(8, NRT) or NRT
+            blocks = (blocks + unit - 1) / unit * unit;
+        }
         ta.gstride = blocks * 4 / NRT;
         ta.nrt_magic = NRT > 1 ? (unsigned)((1ull << 32) / (unsigned long long)NRT) + 1u : 0u;
     }

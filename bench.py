@@ -115,10 +115,18 @@ def main():
         if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
             os.environ["NCCL_DEBUG"] = "WARN"
         import torch.distributed as dist
+        # MPK_BENCH_BACKEND=gloo + more ranks than GPUs: a rehearsal of the N > 1 code path on a 1-GPU box (ranks share
+        # the device; RCCL refuses that, gloo does not care).  The driver's runs use the default: one rank per GPU, RCCL.
+        backend = os.environ.get("MPK_BENCH_BACKEND", "nccl")
+        if backend != "nccl":
+            local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
         if force_dist and "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -217,6 +225,7 @@ def main():
         Kg = max(10, min(K, 200))
         shard = torch.empty((2, B, T_STEPS, D), dtype=torch.float32, device=dev)   # the kernel writes (pos | vel) here
         full = torch.empty((world,) + tuple(shard.shape), dtype=torch.float32, device=dev)
+        full_cat = full.view((world * shard.shape[0],) + tuple(shard.shape[1:]))   # the shape gloo's all-gather insists on
         sp0, sp1 = shard[0].data_ptr(), shard[1].data_ptr()
 
         def step_into_shard():
@@ -224,11 +233,11 @@ def main():
             if rc != 0:
                 raise RuntimeError(_lib.last_error())
         for _ in range(5):
-            step_into_shard(); dist.all_gather_into_tensor(full, shard)
+            step_into_shard(); dist.all_gather_into_tensor(full_cat, shard)
         barrier(); torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(Kg):
-            step_into_shard(); dist.all_gather_into_tensor(full, shard)
+            step_into_shard(); dist.all_gather_into_tensor(full_cat, shard)
         torch.cuda.synchronize(); barrier()
         e2 = time.perf_counter() - t1
         t = torch.tensor([e2], dtype=torch.float64, device=dev)
@@ -236,7 +245,7 @@ def main():
         e2 = float(t.item())
         allgather = {"value": world * B * Kg / e2, "unit": "trajectories/s", "steps": Kg,
                      "ms_per_step": e2 / Kg * 1e3, "bytes_gathered_per_gpu_per_step": int((world - 1) * shard.numel() * 4),
-                     "via": "torch.distributed all_gather_into_tensor (RCCL)"}
+                     "via": f"torch.distributed all_gather_into_tensor ({'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()})"}
         if os.environ.get("MPK_BENCH_NATIVE_COMM") == "1":
             # opt-in: the same leg through libmpk's own RCCL communicator (mpk_comm_* / mpk_allgather, include/mpk.h)
             from fancy_gym_amd.distributed import NativeComm

@@ -211,6 +211,103 @@ def test_replanning_with_learn_delay(mp_type, delay):
     assert k == mpt
 
 
+@pytest.mark.parametrize("mp_type", ["promp", "dmp", "prodmp"])
+def test_length(mp_type):
+    """test/test_black_box.py:117-135: without replanning one step() simulates max_episode_steps steps"""
+    basis = "prodmp" if mp_type == "prodmp" else "rbf"
+    env = fancy_gym_amd.make_bb("toy-v0", [ToyWrapper], {}, {"trajectory_generator_type": mp_type},
+                                {"controller_type": "motor"}, {"phase_generator_type": "exp"},
+                                {"basis_generator_type": basis})
+    for _ in range(5):
+        env.reset(seed=SEED)
+        _, _, _, _, info = env.step(env.action_space.sample())
+        assert info["trajectory_length"] == env.spec.max_episode_steps == 50
+
+
+@pytest.mark.parametrize("mp_type", ["promp", "dmp", "prodmp"])
+@pytest.mark.parametrize("replanning_time", [10, 100, 1000])
+def test_replanning_time(mp_type, replanning_time):
+    """test/test_replanning_sequencing.py:112-160: every plan ends on the schedule, episodes end every
+    max_episode_steps // replanning_time plans (TimeAwareObservation is added once, the spaces agree)"""
+    def schedule(c_pos, c_vel, obs, c_action, t):
+        return t % replanning_time == 0
+    env = toy_bb(mp_type, {"replanning_schedule": schedule, "verbose": 2},
+                 phase={"phase_generator_type": "exp" if "dmp" in mp_type else "linear"})
+    env.reset(seed=SEED)
+    assert env.do_replanning and callable(env.replanning_schedule) and env.spec.max_episode_steps == 50
+    per_episode = max(50 // replanning_time, 1)
+    for i in range(3 * per_episode):
+        _, _, terminated, truncated, info = env.step(env.action_space.sample())
+        if terminated or truncated:
+            assert (i + 1) % per_episode == 0
+            env.reset(seed=SEED)
+        n = info["trajectory_length"]
+        assert n == min(replanning_time, 50) and (schedule(None, None, None, None, n) or n == 50)
+
+
+@pytest.mark.parametrize("mp_type", ["promp", "prodmp"])
+@pytest.mark.parametrize("max_planning_times", [1, 2, 3, 4])
+@pytest.mark.parametrize("sub", [5, 10])
+@pytest.mark.parametrize("tau", [0.5, 1.0, 1.5, 2.0])
+def test_replanning_with_learn_tau(mp_type, max_planning_times, sub, tau):
+    """test/test_replanning_sequencing.py:196-228: a learned tau does not change the number of plans per episode"""
+    env = toy_bb(mp_type, {"max_planning_times": max_planning_times, "verbose": 2,
+                           "replanning_schedule": lambda pos, vel, obs, action, t: t % sub == 0},
+                 {"learn_tau": True, "learn_delay": False})
+    env.reset(seed=SEED)
+    done, n = False, 0
+    while not done:
+        action = env.action_space.sample()
+        action[0] = tau
+        _, _, terminated, truncated, _ = env.step(action)
+        done = terminated or truncated
+        n += 1
+    assert n == max_planning_times
+
+
+@pytest.mark.parametrize("mp_type", ["promp", "prodmp"])
+@pytest.mark.parametrize("max_planning_times", [1, 3])
+@pytest.mark.parametrize("sub", [5, 10, 15])
+@pytest.mark.parametrize("delay", [0, 0.25, 0.5, 0.75])
+@pytest.mark.parametrize("tau", [0.5, 0.75, 1.0])
+def test_replanning_with_learn_delay_and_tau(mp_type, max_planning_times, sub, delay, tau):
+    """test/test_replanning_sequencing.py:284-335: the delay plateau (exact ==) shows in the first plan only, and the
+    number of plans per episode stays max_planning_times"""
+    env = toy_bb(mp_type, {"max_planning_times": max_planning_times, "verbose": 2,
+                           "replanning_schedule": lambda pos, vel, obs, action, t: t % sub == 0},
+                 {"learn_tau": True, "learn_delay": True})
+    env.reset(seed=SEED)
+    done, k = False, 0
+    while not done:
+        action = env.action_space.sample()
+        action[0], action[1] = tau, delay
+        _, _, terminated, truncated, info = env.step(action)
+        done = terminated or truncated
+        n = int(np.round(delay / env.dt))
+        pos, vel = info["positions"].flatten(), info["velocities"].flatten()
+        if k == 0:
+            assert np.all(pos[:max(1, n - 1)] == pos[0]) and np.all(vel[:max(1, n - 2)] == vel[0])
+            assert np.all(pos[max(1, n):] != pos[0]) and np.all(vel[max(1, n)] != vel[0])
+        k += 1
+    assert k == max_planning_times
+
+
+@pytest.mark.parametrize("mp_type", ["promp", "prodmp"])
+@pytest.mark.parametrize("max_planning_times", [1, 2, 3, 4])
+@pytest.mark.parametrize("sub", [5, 10])
+def test_replanning_schedule(mp_type, max_planning_times, sub):
+    """test/test_replanning_sequencing.py:338-364: after max_planning_times plans the episode is over"""
+    env = toy_bb(mp_type, {"max_planning_times": max_planning_times, "verbose": 2,
+                           "replanning_schedule": lambda pos, vel, obs, action, t: t % sub == 0},
+                 {"learn_tau": False, "learn_delay": False})
+    env.reset(seed=SEED)
+    done = False
+    for _ in range(max_planning_times):
+        _, _, terminated, truncated, _ = env.step(env.action_space.sample())
+        done = terminated or truncated
+    assert done
+
+
 def test_single_episode_step_matches_oracle_on_a_closed_loop_plant():
     """BlackBoxWrapper.step end to end on the double integrator: desired trajectory from the HIP kernels, host PD loop"""
     env = fancy_gym_amd.make_bb("dint-v0", [DoubleIntegratorWrapper], {"verbose": 2},

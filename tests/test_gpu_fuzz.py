@@ -123,3 +123,25 @@ def test_random_configuration_matches_oracle(seed, monkeypatch):
                                             init_time=init_time)
         assert torch.equal(p2, pos) and torch.equal(v2, vel) and torch.equal(a2, act)
         assert torch.equal(q2, q) and torch.equal(qd2, qd)
+    # one replanning step (integer state + plan + rollout + condition gather in one launch where the fused kernel applies)
+    # against the separate kernels, from random per-episode integer states
+    T = pos.shape[1]
+    every, mpt, horizon = int(rng.integers(1, T + 1)), int(rng.integers(1, 5)), int(rng.integers(1, 2 * T + 1))
+    ts0 = rng.integers(0, horizon, B).astype(np.int32)
+    ps0 = rng.integers(0, 5, B).astype(np.int32)
+    dn0 = (rng.random(B) < 0.25).astype(np.uint8)
+
+    def state():
+        return (torch.tensor(q0, device="cuda"), torch.tensor(qd0, device="cuda"), torch.tensor(ts0, device="cuda"),
+                torch.tensor(ps0, device="cuda"), torch.tensor(dn0, device="cuda"))
+    qa, qda, tsa, psa, dna = state()
+    r = eng.replan_step(params, ip, iv, spec, qa, qda, tsa, psa, dna, every, mpt, horizon, init_time=init_time,
+                        condition=True)
+    qb, qdb, tsb, psb, dnb = state()
+    seg = eng.replan_advance(tsb, psb, dnb, every, mpt, horizon)
+    pb, vb, ab = eng.trajectory_rollout(params, ip, iv, spec, qb, qdb, n_steps=seg, init_time=init_time)
+    cp, cv = eng.condition_gather(pb, vb, seg)
+    assert torch.equal(r["seg_len"], seg) and torch.equal(tsa, tsb) and torch.equal(psa, psb) and torch.equal(dna, dnb)
+    assert torch.equal(r["done"], dnb) and torch.equal(r["pos"], pos) and torch.equal(r["vel"], vel)
+    assert torch.equal(r["actions"], ab) and torch.equal(qa, qb) and torch.equal(qda, qdb)
+    assert torch.equal(r["cond_pos"], cp) and torch.equal(r["cond_vel"], cv)

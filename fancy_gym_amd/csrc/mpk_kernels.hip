@@ -655,6 +655,24 @@ __device__ __forceinline__ void store16(float* p, const f32x4& v) {
     }
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <bool WT>
+__device__ __forceinline__ void store8(float* p, const f32x2& v) {
+    if (WT) {
+        // same cache policy as the 16-byte stores next to it: plain stores into lines that also take write-through
+        // stores cost the tile-major kernel half its bandwidth (cfg5 at B = 1024: 14.2 vs 8 us)
+        asm volatile("global_store_dwordx2 %0, %1, off " MPK_STORE_MODS "\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    } else {
+        *reinterpret_cast<f32x2*>(p) = v;
+    }
+}
+
+template <bool WT>
+__device__ __forceinline__ void store4(float* p, float v) {
+    if (WT) asm volatile("global_store_dword %0, %1, off " MPK_STORE_MODS "\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    else *p = v;
+}
+
 template <int NST, int KM, bool WT>
 __device__ __forceinline__ void tile_store(const TrajArgs& a, const LaneMap<KM>& L, const float* sSt, int lane,
                                            int b0, int rt, int rows) {
@@ -672,13 +690,27 @@ __device__ __forceinline__ void tile_store(const TrajArgs& a, const LaneMap<KM>&
                 store16<WT>(a.pos + go, d0);
                 store16<WT>(a.vel + go, d1);
                 if (NST > 2) store16<WT>(a.actions + go, d2);
+            } else if (a.td3 == 2) {
+                // T*D = 2 mod 4 (e.g. 350 x 7): segment starts and lengths are even, so a partial chunk is exactly its
+                // upper half (the chunk straddles the segment start) or its lower half (the end): ONE 8-byte store per
+                // array for the head and tail lanes together instead of up to four scalar stores in four branches
+                const bool head = c0 < lo;
+                const int o = head ? 2 : 0;
+                const f32x2 p2 = {head ? d0[2] : d0[0], head ? d0[3] : d0[1]};
+                const f32x2 v2 = {head ? d1[2] : d1[0], head ? d1[3] : d1[1]};
+                store8<WT>(a.pos + go + o, p2);
+                store8<WT>(a.vel + go + o, v2);
+                if (NST > 2) {
+                    const f32x2 a2 = {head ? d2[2] : d2[0], head ? d2[3] : d2[1]};
+                    store8<WT>(a.actions + go + o, a2);
+                }
             } else {                                   // the (at most two) partial chunks of a segment
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (c0 + e >= lo && c0 + e < hi) {
-                        a.pos[go + e] = d0[e];
-                        a.vel[go + e] = d1[e];
-                        if (NST > 2) a.actions[go + e] = d2[e];
+                        store4<WT>(a.pos + go + e, d0[e]);
+                        store4<WT>(a.vel + go + e, d1[e]);
+                        if (NST > 2) store4<WT>(a.actions + go + e, d2[e]);
                     }
                 }
             }

@@ -76,6 +76,11 @@ def test_random_configuration_matches_oracle(seed, monkeypatch):
     monkeypatch.setenv("MPK_PD_QUAD", str(rng.choice(["0", "1", "2"])))
     monkeypatch.setenv("MPK_PHASE_CHUNK", str(rng.choice(["1", "2", "4"])))
     monkeypatch.setenv("MPK_PHASE_TABLE", str(rng.choice(["0", "1"])))
+    wt = str(rng.choice(["", "0", "1"]))                 # store cache policy: automatic / plain / write-through
+    if wt:
+        monkeypatch.setenv("MPK_WRITE_THROUGH", wt)
+    else:
+        monkeypatch.delenv("MPK_WRITE_THROUGH", raising=False)
     if tc.trajectory_generator_type == "prodmp":
         # keep the plan inside the pre-computed range (6 tau): reference raises otherwise
         tau_min = pc.tau_bound[0] if pc.learn_tau else pc.tau

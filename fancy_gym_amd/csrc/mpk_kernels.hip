@@ -2390,6 +2390,7 @@ struct PdArgs {
     const double* goal;
     double* rewards;
     int steps_before_reward;
+    int wt;                  // write-through stores of the actions (cache-resident batches)
 };
 
 // NG = groups per wave: with NG = 4 a wave owns four consecutive groups and lane quarter j runs group j's recurrence,
@@ -2561,9 +2562,12 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
             if (a.actions) {
 #pragma unroll
                 for (int j = 0; j < NG; ++j) {
-                    if (mover[j] && w4 < rows * D)
-                        *reinterpret_cast<f32x4*>(a.actions + (size_t)(g0 + j) * NTW * T * D + gofs + (size_t)rt * SEG) =
-                            *reinterpret_cast<const f32x4*>(sSt + j * SLOT + 2 * kStageStride + rofs);
+                    if (mover[j] && w4 < rows * D) {
+                        float* dst = a.actions + (size_t)(g0 + j) * NTW * T * D + gofs + (size_t)rt * SEG;
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(sSt + j * SLOT + 2 * kStageStride + rofs);
+                        if (a.wt) store16<true>(dst, v);      // cache-resident actions: write-through (wave-uniform)
+                        else store16<false>(dst, v);
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -2696,6 +2700,8 @@ int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
         PdArgs pa;
         pa.rc = rc; pa.des_pos = des_pos; pa.des_vel = des_vel; pa.Q = q; pa.QD = qd; pa.n_steps = n_steps;
         pa.actions = actions; pa.D = D; pa.B = B; pa.T = T;
+        pa.wt = (double)B * T * D * 12.0 <= 96.0 * 1024 * 1024 ? 1 : 0;     // desired (pos, vel) + actions stay cached
+        if (const char* e = getenv("MPK_WRITE_THROUGH")) pa.wt = atoi(e) != 0 ? 1 : 0;
         pa.step0 = step0; pa.goal = goal; pa.rewards = rewards; pa.steps_before_reward = steps_before_reward;
         int sh = 0;
         while ((1 << sh) < D) ++sh;
@@ -2741,6 +2747,8 @@ int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const f
         PdArgs pa;
         pa.rc = rc; pa.des_pos = des_pos; pa.des_vel = des_vel; pa.Q = q; pa.QD = qd; pa.n_steps = n_steps;
         pa.actions = actions; pa.D = D; pa.B = B; pa.T = T;
+        pa.wt = (double)B * T * D * 12.0 <= 96.0 * 1024 * 1024 ? 1 : 0;     // desired (pos, vel) + actions stay cached
+        if (const char* e = getenv("MPK_WRITE_THROUGH")) pa.wt = atoi(e) != 0 ? 1 : 0;
         pa.step0 = nullptr; pa.goal = nullptr; pa.rewards = nullptr; pa.steps_before_reward = 0;
         int sh = 0;
         while ((1 << sh) < D) ++sh;

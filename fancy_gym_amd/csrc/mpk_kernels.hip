@@ -1777,6 +1777,7 @@ struct PhaseArgs {
     float* vel;
     int32_t* flag;
     int B, wave_floats, t_pad, x_pad, o_pad, c_pad, tab_pad, chunk, img_pad;
+    int wt;     // write-through stores while the outputs are cache resident
 };
 
 template <int MP>
@@ -1848,17 +1849,19 @@ struct PhaseFetch {
 };
 
 // n floats staged at so[sh ...] (sh = 16-byte phase of the destination) -> out[0 .. n): float4 body, dword head / tail
+// WT: write-through stores, every one of them (cache-resident batches; see store16)
+template <bool WT>
 __device__ __forceinline__ void flush_span(const float* __restrict__ so, float* __restrict__ out, int n, int sh,
                                            int lane) {
     float* base = out - sh;                              // 16-byte aligned
     const int end = sh + n;
     const int q0 = (sh + 3) >> 2, q1 = end >> 2;
     for (int q = q0 + lane; q < q1; q += 64)
-        *reinterpret_cast<float4*>(base + 4 * q) = *reinterpret_cast<const float4*>(so + 4 * q);
+        store16<WT>(base + 4 * q, *reinterpret_cast<const f32x4*>(so + 4 * q));
     const int head_end = 4 * q0 < end ? 4 * q0 : end;
-    if (lane < head_end - sh) base[sh + lane] = so[sh + lane];
+    if (lane < head_end - sh) store4<WT>(base + sh + lane, so[sh + lane]);
     const int tail = 4 * q1 > head_end ? 4 * q1 : head_end;
-    if (lane < end - tail) base[tail + lane] = so[tail + lane];
+    if (lane < end - tail) store4<WT>(base + tail + lane, so[tail + lane]);
 }
 
 // TL (prodmp): the fp32 row table is staged in the workgroup's LDS (row stride 2*KS + 4 floats: 16-byte aligned rows
@@ -2072,8 +2075,13 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
-                flush_span(sO0, gp, nout * D, sh, lane);
-                flush_span(sO1, out_vel + (size_t)r0 * D, nout * D, sh, lane);
+                if (a.wt) {
+                    flush_span<true>(sO0, gp, nout * D, sh, lane);
+                    flush_span<true>(sO1, out_vel + (size_t)r0 * D, nout * D, sh, lane);
+                } else {
+                    flush_span<false>(sO0, gp, nout * D, sh, lane);
+                    flush_span<false>(sO1, out_vel + (size_t)r0 * D, nout * D, sh, lane);
+                }
                 __builtin_amdgcn_wave_barrier();
                 if (final_round) break;
             }
@@ -2277,7 +2285,9 @@ int launch_traj_rows(const DevCfg& c, const float* params, const float* init_pos
     bool wave_kernel = true;
     if (const char* e = getenv("MPK_PHASE")) wave_kernel = atoi(e) != 0;
     if (wave_kernel) {
-        PhaseArgs pa{c, params, init_pos, init_vel, init_time, init_time_shared, pos, vel, range_flag, B, 0, 0, 0, 0, 0, 0, 0, 0};
+        PhaseArgs pa{c, params, init_pos, init_vel, init_time, init_time_shared, pos, vel, range_flag, B, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        pa.wt = (double)B * c.T * c.D * 8.0 <= 96.0 * 1024 * 1024 ? 1 : 0;
+        if (const char* e = getenv("MPK_WRITE_THROUGH")) pa.wt = atoi(e) != 0 ? 1 : 0;
         const int rc = launch_traj_phase(c, pa, num_cu, stream, kernel_name);
         if (rc != MPK_ENOTIMPL) return rc;
     }

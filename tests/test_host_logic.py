@@ -49,6 +49,34 @@ def test_config_struct_layout_matches_header():
     assert C.sizeof(_lib.mpk_config) == 18 * 4 + 15 * 8
 
 
+def test_header_is_plain_c_and_ctypes_structs_match_it(tmp_path):
+    """include/mpk.h compiles as C99 (it is the drop-in boundary: no C++ in it), and every struct of the ctypes binding
+    has the size and field offsets the C compiler gives the header's"""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    structs = {"mpk_config": _lib.mpk_config, "mpk_rollout_cfg": _lib.mpk_rollout_cfg,
+               "mpk_replan_state": _lib.mpk_replan_state}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "mpk.h"', "int main(void) {"]
+    for name, cls in structs.items():
+        lines.append(f'  printf("{name} %zu\\n", sizeof({name}));')
+        for field, _ in cls._fields_:
+            lines.append(f'  printf("{name}.{field} %zu\\n", offsetof({name}, {field}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    str(src), "-o", str(exe)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for name, cls in structs.items():
+        assert int(out[name]) == C.sizeof(cls), name
+        for field, _ in cls._fields_:
+            assert int(out[f"{name}.{field}"]) == getattr(cls, field).offset, f"{name}.{field}"
+
+
 def _cfg(mp="prodmp", phase="exp", basis="prodmp", D=7, nb=5, **kw):
     c = _lib.mpk_config()
     c.abi_version = 1

@@ -1146,7 +1146,7 @@ constexpr int kQuadImg = 3 * kStageStride + 8;
 
 template <int MP, int CT, int KM, int NQ>
 __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActArgs act) {
-    static_assert(NQ == 2 || NQ == 4, "two or four groups per wave");
+    static_assert(NQ == 1 || NQ == 2 || NQ == 4, "one, two or four groups per wave");
     __shared__ __attribute__((aligned(16))) float smem[4 * NQ * kQuadImg];   // per wave: 4 x (pos|vel|act or force)
     __shared__ double sgain[4][64];
     extern __shared__ __attribute__((aligned(16))) float sTab[];   // [NOUT][KP][TS] rows + [TS] aux
@@ -1370,7 +1370,14 @@ static int launch_traj_t(const TrajArgs& ta, const ActArgs& aa, bool stream_mode
     const int km = ta.c.KP / 4;
     if (stream_mode && quad) {
         if constexpr (MP == MPK_MP_DMP || CT >= 3) {
-            if (quad == 2) {
+            if (quad == 1) {
+                switch (km) {
+                    case 1: hipLaunchKernelGGL((k_traj_quad<MP, CT, 1, 1>), g, b, lds, s, ta, aa); break;
+                    case 2: hipLaunchKernelGGL((k_traj_quad<MP, CT, 2, 1>), g, b, lds, s, ta, aa); break;
+                    case 3: hipLaunchKernelGGL((k_traj_quad<MP, CT, 3, 1>), g, b, lds, s, ta, aa); break;
+                    default: hipLaunchKernelGGL((k_traj_quad<MP, CT, 4, 1>), g, b, lds, s, ta, aa); break;
+                }
+            } else if (quad == 2) {
                 switch (km) {
                     case 1: hipLaunchKernelGGL((k_traj_quad<MP, CT, 1, 2>), g, b, lds, s, ta, aa); break;
                     case 2: hipLaunchKernelGGL((k_traj_quad<MP, CT, 2, 2>), g, b, lds, s, ta, aa); break;
@@ -1522,14 +1529,22 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         int quad_mode = 1;
         if (const char* e = getenv("MPK_QUAD")) quad_mode = atoi(e);
         const long units4 = (ta.G + 3) / 4, units2 = (ta.G + 1) / 2;
-        // automatic: four per wave once that still leaves two waves per SIMD of work, two per wave down to one wave
-        // per SIMD (with one wave per SIMD every LDS / MFMA latency is exposed: B = 8192 closed loop 22 -> 17 us)
+        // automatic (A/B-measured, profiles/r01_replan_end_to_end.md):
+        //   four per wave  while that gives two waves per SIMD but not yet more units than resident waves
+        //                  (cfg3 DMP at B = 16384: 35 us vs 44 with two);
+        //   two per wave   below that (one wave per SIMD exposes every LDS / MFMA latency: closed loop at B = 8192
+        //                  22 -> 17 us) AND above it: at HBM-streaming sizes a four-group wave keeps 16 output streams
+        //                  open, two groups write like the episode-major kernel (DMP at B = 262144 792 -> 590 us,
+        //                  closed loop at B = 65536 189 -> 166 us);
+        //   one per wave   for the closed loop at a few thousand episodes (cfg4 episodes at B = 2048: 0.061 -> 0.052 ms)
         if (serial_variant && quad_mode != 0) {
             if (quad_mode == 2) quad = fits(4) ? 4 : 0;
             else if (quad_mode == 3) quad = fits(2) ? 2 : 0;
-            else if (fits(4) && units4 >= (long)num_cu * 8) quad = 4;
+            else if (quad_mode == 4) quad = fits(1) ? 1 : 0;
+            else if (!closed && fits(4) && units4 >= (long)num_cu * 8 && units4 < max_waves) quad = 4;   // DMP only:
+            // the closed loop measured equal or better with two groups at every size (B = 16384: 0.19 vs 0.21 ms / episode)
             else if (fits(2) && units2 >= (long)num_cu * 4) quad = 2;
-            else if (fits(4) && units4 >= (long)num_cu * 4) quad = 4;
+            else if (closed && fits(1)) quad = 1;
         }
     }
     if (quad) {
@@ -1582,15 +1597,15 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     if (blocks < 1) blocks = 1;
     switch (c.mp_type) {
         case MPK_MP_PRODMP:
-            *kernel_name = closed ? (quad == 4 ? "k_traj_quad<prodmp,closed>" : quad == 2 ? "k_traj_duo<prodmp,closed>" : "k_traj_stream<prodmp,closed>") : stream_mode ? (act ? "k_traj_stream<prodmp,act>" : "k_traj_stream<prodmp>")
+            *kernel_name = closed ? (quad == 4 ? "k_traj_quad<prodmp,closed>" : quad == 2 ? "k_traj_duo<prodmp,closed>" : quad == 1 ? "k_traj_mono<prodmp,closed>" : "k_traj_stream<prodmp,closed>") : stream_mode ? (act ? "k_traj_stream<prodmp,act>" : "k_traj_stream<prodmp>")
                                        : (act ? "k_traj_tiles<prodmp,act>" : "k_traj_tiles<prodmp>");
             return launch_traj_ct<MPK_MP_PRODMP>(ta, aa, ct, stream_mode, write_through, bulk, quad, blocks, lds, stream);
         case MPK_MP_PROMP:
-            *kernel_name = closed ? (quad == 4 ? "k_traj_quad<promp,closed>" : quad == 2 ? "k_traj_duo<promp,closed>" : "k_traj_stream<promp,closed>") : stream_mode ? (act ? "k_traj_stream<promp,act>" : "k_traj_stream<promp>")
+            *kernel_name = closed ? (quad == 4 ? "k_traj_quad<promp,closed>" : quad == 2 ? "k_traj_duo<promp,closed>" : quad == 1 ? "k_traj_mono<promp,closed>" : "k_traj_stream<promp,closed>") : stream_mode ? (act ? "k_traj_stream<promp,act>" : "k_traj_stream<promp>")
                                        : (act ? "k_traj_tiles<promp,act>" : "k_traj_tiles<promp>");
             return launch_traj_ct<MPK_MP_PROMP>(ta, aa, ct, stream_mode, write_through, bulk, quad, blocks, lds, stream);
         default:
-            *kernel_name = quad == 4 ? "k_traj_quad<dmp>" : quad == 2 ? "k_traj_duo<dmp>" : "k_traj_stream<dmp>";
+            *kernel_name = quad == 4 ? "k_traj_quad<dmp>" : quad == 2 ? "k_traj_duo<dmp>" : quad == 1 ? "k_traj_mono<dmp>" : "k_traj_stream<dmp>";
             return launch_traj_ct<MPK_MP_DMP>(ta, aa, -1, true, false, bulk, quad, blocks, lds, stream);
     }
 }

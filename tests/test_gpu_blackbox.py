@@ -378,7 +378,7 @@ def test_fused_actions_are_bit_exact(cfg, controller, mapping, monkeypatch):
 @pytest.mark.parametrize("cfg", [CFG2, CFG5, CFG4], ids=["prodmp", "promp", "prodmp_replan"])
 @pytest.mark.parametrize("controller", ["motor", "position", "velocity"])
 @pytest.mark.parametrize("B", [1, 9, 200])
-@pytest.mark.parametrize("bulk,quad", [("0", "2"), ("0", "3"), ("0", "0"), ("2", "0")])
+@pytest.mark.parametrize("bulk,quad", [("0", "2"), ("0", "3"), ("0", "4"), ("0", "0"), ("2", "0")])
 def test_fused_closed_loop_rollout_is_bit_exact(cfg, controller, B, bulk, quad, monkeypatch):
     """one launch (trajectory + controller + double-integrator plant) == mpk_trajectory + mpk_pd_rollout == oracle;
     k_traj_quad (four recurrences per wave) and both input-staging variants of k_traj_stream"""
@@ -994,7 +994,7 @@ def _reference_loop(cur, plan, done, every, mpt, horizon, T):
 
 @pytest.mark.parametrize("cfg", [CFG4, CFG5, CFG3], ids=["prodmp_replan", "promp", "dmp"])
 @pytest.mark.parametrize("B", [1, 9, 200, 2100])
-@pytest.mark.parametrize("bulk,quad", [("0", "2"), ("0", "3"), ("0", "0"), ("2", "0")])
+@pytest.mark.parametrize("bulk,quad", [("0", "2"), ("0", "3"), ("0", "4"), ("0", "0"), ("2", "0")])
 def test_replan_step_equals_the_separate_kernels(cfg, B, bulk, quad, monkeypatch):
     """mpk_replan_step (integer state + plan + rollout + condition gather; ONE launch for shared-phase promp / prodmp,
     the separate kernels for dmp) == mpk_replan_advance -> mpk_trajectory_rollout -> mpk_condition_gather, bit for bit,

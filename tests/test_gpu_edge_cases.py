@@ -233,12 +233,12 @@ def test_calls_are_capturable_in_a_hip_graph_even_on_a_table_cache_miss():
         close(outs[k][1].cpu().numpy(), rv, f"plan {k} vel")
 
 
-@pytest.mark.parametrize("quad", ["0", "2", "3"])
+@pytest.mark.parametrize("quad", ["0", "2", "3", "4"])
 @pytest.mark.parametrize("D,T,B", [(7, 200, 1), (7, 200, 9), (3, 33, 21), (16, 40, 5), (1, 50, 70), (5, 17, 4)])
 def test_dmp_quad_and_stream_kernels_agree_bitwise_and_match_oracle(quad, D, T, B, monkeypatch):
     monkeypatch.setenv("MPK_QUAD", quad)
     eng = check(cfg_for("dmp", D, 5, T), B, seed=T,
-                expect_kernel={"0": "k_traj_stream", "2": "k_traj_quad", "3": "k_traj_duo"}[quad])
+                expect_kernel={"0": "k_traj_stream", "2": "k_traj_quad", "3": "k_traj_duo", "4": "k_traj_mono"}[quad])
     pc, bc, tc, dt, dur = cfg_for("dmp", D, 5, T)
     params, ip, iv = inputs(pc, bc, tc, B, seed=T)
     p1, v1 = eng.trajectory(params, ip, iv, 0.0)

@@ -72,7 +72,7 @@ def test_random_configuration_matches_oracle(seed, monkeypatch):
     pc, bc, tc, dt, dur, B, init_time = random_case(rng)
     monkeypatch.setenv("MPK_MAPPING", str(rng.choice(["0", "1", "2"])))
     monkeypatch.setenv("MPK_BULK", str(rng.choice(["0", "2"])))
-    monkeypatch.setenv("MPK_QUAD", str(rng.choice(["0", "1", "2", "3"])))
+    monkeypatch.setenv("MPK_QUAD", str(rng.choice(["0", "1", "2", "3", "4"])))
     monkeypatch.setenv("MPK_PD_QUAD", str(rng.choice(["0", "1", "2"])))
     monkeypatch.setenv("MPK_PHASE_CHUNK", str(rng.choice(["1", "2", "4"])))
     monkeypatch.setenv("MPK_PHASE_TABLE", str(rng.choice(["0", "1"])))

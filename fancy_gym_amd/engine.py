@@ -7,6 +7,7 @@ device memory and streams (tensors are passed to the C-ABI as raw device pointer
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence, Tuple, Union
 
 import numpy as np
@@ -210,13 +211,20 @@ class TrajectoryEngine:
         buf[P:P + D] = np.asarray(init_pos, np.float32).reshape(-1)
         buf[P + D:P + 2 * D] = np.asarray(init_vel, np.float32).reshape(-1)
         buf[P + 2 * D] = init_time
-        d_in.copy_(h_in, non_blocking=True)
         per_episode = bool(self.config.learn_tau or self.config.learn_delay)
-        base = d_in.data_ptr()
+        # zero copy (default): the kernel reads the inputs from, and writes (pos | vel) to, the pinned host buffers
+        # themselves -- pinned host memory is device-accessible at the same address, and a few KB over PCIe cost less than
+        # the two copy calls (MPK_B1_ZEROCOPY=0: staged copies through device buffers instead)
+        zero_copy = os.environ.get("MPK_B1_ZEROCOPY", "1") != "0"
+        if not zero_copy:
+            d_in.copy_(h_in, non_blocking=True)
+        base = (h_in if zero_copy else d_in).data_ptr()
+        dst = h_out if zero_copy else d_out
         _lib.check(self._lib.mpk_trajectory(self._h, base, base + 4 * P, base + 4 * (P + D),
                                             base + 4 * (P + 2 * D) if per_episode else None, float(init_time),
-                                            d_out[0].data_ptr(), d_out[1].data_ptr(), 1, self._stream()))
-        h_out.copy_(d_out, non_blocking=True)
+                                            dst[0].data_ptr(), dst[1].data_ptr(), 1, self._stream()))
+        if not zero_copy:
+            h_out.copy_(d_out, non_blocking=True)
         if per_episode and self.mp_type == "prodmp":
             self.check_range()                       # synchronises
         else:

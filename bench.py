@@ -198,20 +198,26 @@ def main():
         except Exception as e:  # pragma: no cover - depends on the runtime
             print(f"[bench] hipGraph capture failed ({e}); falling back to eager launches", file=sys.stderr)
             graph = None
-    # HIP events on the launch stream bracket the same K steps: kernel average = event time / K (the K launches run
-    # back to back, so this includes the ~1 us dependent-launch boundary between them)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # ---- K steps, wall clock between barrier + synchronize on both sides ----------------------------------------------
+    def k_steps():
+        if graph is not None:
+            graph.replay()
+        else:
+            for _ in range(K):
+                step(sp)
+
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ev0.record(stream)
-    if graph is not None:
-        graph.replay()
-    else:
-        for _ in range(K):
-            step(sp)
-    ev1.record(stream)
+    k_steps()
     torch.cuda.synchronize(); barrier()
     elapsed = time.perf_counter() - t0
+    # the kernel's average launch duration for the roofline line: the same K steps once more, bracketed by HIP events on
+    # the launch stream (kept out of the wall-clock region above: two event records cost a short run several percent)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(stream)
+    k_steps()
+    ev1.record(stream)
+    torch.cuda.synchronize()
     kern_avg = ev0.elapsed_time(ev1) * 1e-3 / K
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)

@@ -196,7 +196,7 @@ struct Handle {
     int32_t* d_flag = nullptr;   // range-error flag written by kernels
     int32_t* d_idx = nullptr;    // scratch for mpk_prodmp_indices
     int idx_cap = 0;
-    static constexpr int kCache = 16;
+    static constexpr int kCache = 64;    // distinct init_times of one replanning episode (a 100-step horizon replanned every 2 steps)
     CacheEntry cache[kCache];
     uint64_t stamp = 0;
     const char* last_kernel = "";

@@ -138,7 +138,7 @@ int mpk_set_duration(mpk_handle h, double duration, double dt);
 
 /*
  * Stream capture (hipGraph): every trajectory call only enqueues kernels, so a sequence of calls may be captured and
- * replayed.  The per-init_time basis table a shared-phase call needs lives in one of 16 slots per handle; a slot a
+ * replayed.  The per-init_time basis table a shared-phase call needs lives in one of 64 slots per handle; a slot a
  * captured call uses is pinned (never evicted).  If the table already exists (an eager call with the same init_time ran
  * before -- finish it, e.g. synchronise, before replaying) the graph just reads it; otherwise its builder becomes a node
  * of the captured graph and the slot serves that graph only.  mpk_unpin_tables releases all pinned slots once the graphs

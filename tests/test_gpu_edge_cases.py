@@ -155,7 +155,7 @@ def test_many_init_times_cycle_the_table_cache():
     params, ip, iv = inputs(pc, bc, tc, 9)
     first = {}
     for rnd in range(2):
-        for k in range(12):                  # more distinct init_times than cache slots (8)
+        for k in range(70):                  # more distinct init_times than cache slots (64)
             it = k * dt
             pos, vel = eng.trajectory(params, ip, iv, it)
             if rnd == 0:

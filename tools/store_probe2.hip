@@ -32,6 +32,23 @@ __global__ void __launch_bounds__(256) k_tiles(float* o0, float* o1, float* o2, 
     }
 }
 
+// workgroup-cooperative variant: a workgroup owns (group g, row tiles 0..3) or (group g, row tiles 4..6) and its 256 lanes
+// store each (episode, array) run of 4 x 448 = 1792 B (or 1008 B for the second half) as consecutive 16-byte chunks
+template <int MODE>
+__global__ void __launch_bounds__(256) k_coop(float* o0, float* o1, float* o2, int G, int wgstride) {
+    const int half = blockIdx.x & 1;                      // 0: rows 0..63, 1: rows 64..99
+    const int chunks = half ? 63 : 112;                   // float4 per (episode, array) run: 36 x 7 / 4, 64 x 7 / 4
+    const f32x4 v = {1.f, 2.f, 3.f, (float)blockIdx.x};
+    float* const arr[3] = {o0, o1, o2};
+    for (int g = blockIdx.x >> 1; g < G; g += wgstride) {
+        for (int c = threadIdx.x; c < 6 * chunks; c += 256) {
+            const int run = c / chunks, k = c - run * chunks;            // run = array * 2 + episode
+            const size_t base = ((size_t)(2 * g + (run & 1)) * 100 + half * 64) * 7;
+            st<MODE>(arr[run >> 1] + base + 4 * k, v);
+        }
+    }
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(256) k_fill(float* o, size_t n4) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -78,6 +95,8 @@ int main() {
     T(1, true,  "tile pattern, sc1 stores, XCD remap  (= k_traj_tiles' stores)");
     T(2, true,  "tile pattern, sc0 sc1 stores, XCD remap");
     T(3, true,  "tile pattern, nt stores, XCD remap");
+    rep("workgroup-cooperative runs of 1792 / 1008 B, sc1 (2048 WGs)", bytes, graph_time([&] { hipLaunchKernelGGL((k_coop<1>), dim3(2048), dim3(256), 0, s, o0, o1, o2, G, 1024); }, s, 200));
+    rep("workgroup-cooperative runs of 1792 / 1008 B, sc1 (4096 WGs)", bytes, graph_time([&] { hipLaunchKernelGGL((k_coop<1>), dim3(4096), dim3(256), 0, s, o0, o1, o2, G, 2048); }, s, 200));
     rep("flat fill of the same 34.4 MB, plain", bytes, graph_time([&] { hipLaunchKernelGGL((k_fill<0>), dim3(2048), dim3(256), 0, s, o, 3 * n / 4); }, s, 200));
     rep("flat fill of the same 34.4 MB, sc1", bytes, graph_time([&] { hipLaunchKernelGGL((k_fill<1>), dim3(2048), dim3(256), 0, s, o, 3 * n / 4); }, s, 200));
     return 0;

@@ -537,6 +537,11 @@ struct GroupIn {
     double cp, cv;
 };
 
+template <class T>
+__device__ __forceinline__ T ld_off(const T* base, unsigned byte_off) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
 template <int MP, bool ACT, int KM>
 __device__ __forceinline__ GroupIn<KM> load_group(const TrajArgs& a, const LaneMap<KM>& L, int g) {
     const DevCfg& c = a.c;
@@ -544,14 +549,17 @@ __device__ __forceinline__ GroupIn<KM> load_group(const TrajArgs& a, const LaneM
     // the last group may be ragged: clamp its missing episodes onto the group's first one (computed, never stored)
     const int b0 = g * L.NTW;
     const bool bv = b0 + L.bl < a.B;
+    // wave-uniform block bases + 32-bit per-lane BYTE offsets: the loads take the (scalar base, vector offset) form
+    // instead of a 64-bit address addition per load on the vector ALU
     const float* pb = a.params + (size_t)b0 * c.P;
     const unsigned io = bv ? L.ioff : (unsigned)L.dsafe;
+    const unsigned pclamp = bv ? 0u : (unsigned)(L.bl * c.P);
 #pragma unroll
-    for (int m = 0; m < KM; ++m) in.raw[m] = pb[bv ? L.poff[m] : L.poff[m] - L.bl * c.P];
-    in.ip = MP != MPK_MP_DMP ? (a.init_pos + (size_t)b0 * c.D)[io] : 0.0f;
-    in.iv = MP == MPK_MP_PRODMP ? (a.init_vel + (size_t)b0 * c.D)[io] : 0.0f;
+    for (int m = 0; m < KM; ++m) in.raw[m] = ld_off(pb, 4u * (L.poff[m] - pclamp));
+    in.ip = MP != MPK_MP_DMP ? ld_off(a.init_pos + (size_t)b0 * c.D, 4u * io) : 0.0f;
+    in.iv = MP == MPK_MP_PRODMP ? ld_off(a.init_vel + (size_t)b0 * c.D, 4u * io) : 0.0f;
     in.cp = 0.0; in.cv = 0.0;
-    if (ACT) { in.cp = (a.c_pos + (size_t)b0 * c.D)[io]; in.cv = (a.c_vel + (size_t)b0 * c.D)[io]; }
+    if (ACT) { in.cp = ld_off(a.c_pos + (size_t)b0 * c.D, 8u * io); in.cv = ld_off(a.c_vel + (size_t)b0 * c.D, 8u * io); }
     return in;
 }
 

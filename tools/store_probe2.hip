@@ -32,6 +32,33 @@ __global__ void __launch_bounds__(256) k_tiles(float* o0, float* o1, float* o2, 
     }
 }
 
+// the tile pattern with the kernel's input round trip in front of the stores: every lane gathers 2 parameter words, the
+// boundary state (2 floats, 2 doubles) and 4 basis-fragment words -- the loads k_traj_tiles issues -- and the stored
+// values depend on them, but there is no MFMA / epilogue / LDS transpose
+template <int MODE>
+__global__ void __launch_bounds__(256) k_tiles_loads(float* o0, float* o1, float* o2, const float* params, const float* ip,
+                                                     const float* iv, const double* cp, const double* cv, const float* A,
+                                                     int G, int gstride) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nb8 = gridDim.x >> 3;
+    const int vb = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * nb8 + (blockIdx.x >> 3) : blockIdx.x;
+    const int wid = vb * 4 + wave;
+    const int sseg = lane / 28, w4 = (lane - sseg * 28) * 4;
+    const int rt = wid % 7, rows = rt == 6 ? 4 : 16;
+    const int col = lane & 15, q = lane >> 4, bl = col >> 3, d = (col & 7) < 7 ? (col & 7) : 6;
+    const float a0 = A[(q) * 112 + rt * 16 + col], a1 = A[(4 + q) * 112 + rt * 16 + col];
+    const float a2 = A[(8 + q) * 112 + rt * 16 + col], a3 = A[(12 + q) * 112 + rt * 16 + col];
+    for (int g = wid / 7; g < G; g += gstride) {
+        const size_t b = (size_t)2 * g + bl;
+        const float p0 = params[b * 42 + d * 6 + (q < 2 ? q : 0)], p1 = params[b * 42 + d * 6 + 4 + (q & 1)];
+        const float x = ip[b * 7 + d] + iv[b * 7 + d] + (float)(cp[b * 7 + d] + cv[b * 7 + d]);
+        const f32x4 v = {p0 * a0, p1 * a1, x * a2, a3};
+        const size_t gb = ((size_t)g * 2 * 100 + rt * 16) * 7 + (size_t)sseg * 700 + w4;
+        if (sseg < 2 && w4 < rows * 7) { st<MODE>(o0 + gb, v); st<MODE>(o1 + gb, v); st<MODE>(o2 + gb, v); }
+    }
+}
+
 // workgroup-cooperative variant: a workgroup owns (group g, row tiles 0..3) or (group g, row tiles 4..6) and its 256 lanes
 // store each (episode, array) run of 4 x 448 = 1792 B (or 1008 B for the second half) as consecutive 16-byte chunks
 template <int MODE>
@@ -95,6 +122,14 @@ int main() {
     T(1, true,  "tile pattern, sc1 stores, XCD remap  (= k_traj_tiles' stores)");
     T(2, true,  "tile pattern, sc0 sc1 stores, XCD remap");
     T(3, true,  "tile pattern, nt stores, XCD remap");
+    {
+        float *params, *ipb, *ivb, *Ab; double *cpb, *cvb;
+        CK(hipMalloc(&params, (size_t)Bn * 42 * 4)); CK(hipMalloc(&ipb, (size_t)Bn * 7 * 4)); CK(hipMalloc(&ivb, (size_t)Bn * 7 * 4));
+        CK(hipMalloc(&cpb, (size_t)Bn * 7 * 8)); CK(hipMalloc(&cvb, (size_t)Bn * 7 * 8)); CK(hipMalloc(&Ab, 16 * 112 * 4));
+        CK(hipMemset(params, 0, (size_t)Bn * 42 * 4)); CK(hipMemset(ipb, 0, (size_t)Bn * 7 * 4)); CK(hipMemset(ivb, 0, (size_t)Bn * 7 * 4));
+        CK(hipMemset(cpb, 0, (size_t)Bn * 7 * 8)); CK(hipMemset(cvb, 0, (size_t)Bn * 7 * 8)); CK(hipMemset(Ab, 0, 16 * 112 * 4));
+        rep("tile pattern, sc1, XCD remap + the kernel's input loads first", bytes, graph_time([&] { hipLaunchKernelGGL((k_tiles_loads<1>), dim3(blocks), dim3(256), 0, s, o0, o1, o2, params, ipb, ivb, cpb, cvb, Ab, G, gstride); }, s, 200));
+    }
     rep("workgroup-cooperative runs of 1792 / 1008 B, sc1 (2048 WGs)", bytes, graph_time([&] { hipLaunchKernelGGL((k_coop<1>), dim3(2048), dim3(256), 0, s, o0, o1, o2, G, 1024); }, s, 200));
     rep("workgroup-cooperative runs of 1792 / 1008 B, sc1 (4096 WGs)", bytes, graph_time([&] { hipLaunchKernelGGL((k_coop<1>), dim3(4096), dim3(256), 0, s, o0, o1, o2, G, 2048); }, s, 200));
     rep("flat fill of the same 34.4 MB, plain", bytes, graph_time([&] { hipLaunchKernelGGL((k_fill<0>), dim3(2048), dim3(256), 0, s, o, 3 * n / 4); }, s, 200));

@@ -13,6 +13,11 @@ ProDMP, 7 DoF, 5 basis (+goal) per DoF, 100 steps, batch 4096 per GPU, inputs re
 Rank 0 prints ONE JSON line.  Multi-GPU: episodes shard across ranks (independent units, no data-path collective):
 "scaling": "weak", value = all ranks' trajectories / max-over-ranks time.  The optional all-gather of the generated
 trajectories over RCCL/xGMI (north_star) is timed separately and reported under "allgather".
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself: the parent -- before it makes a
+single GPU call -- runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same args>` as a
+CHILD process and exits with its code (never an exec of a process that touched the GPU).  A WORLD_SIZE that disagrees
+with `--gpus` is an error (exit 2), not a warning.
 """
 from __future__ import annotations
 
@@ -50,6 +55,8 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-allgather", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-streaming", action="store_true", help="skip the HBM-streaming roofline row (B = 262144)")
+    ap.add_argument("--streaming-batch", type=int, default=262144)
     return ap.parse_args()
 
 
@@ -97,17 +104,73 @@ def cpu_baseline(seconds: float, batch: int):
         i = m % batch
         one(slice(i, i + 1)); m += 1
     ref_style = m / (time.perf_counter() - t1)
+    # (iii) BASELINE.md section 3 "CPU-batched": the same restated path with torch-CPU ops on every host core
+    from oracle.mp_torch_cpu import ProDMPBatchedCPU
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    fn = ProDMPBatchedCPU(pc, bc, tc, 2.0, 0.02)
+    tp, tip, tiv = torch.from_numpy(params), torch.from_numpy(ip), torch.from_numpy(iv)
+    pg, dg = torch.from_numpy(P_GAINS), torch.from_numpy(D_GAINS)
+    cpos, cvel = tip.double(), tiv.double()
+    for _ in range(5):
+        fn(tp, tip, tiv, 0.0, pg, dg, -1.0, 1.0, cpos, cvel)
+    reps = []
+    t2 = time.perf_counter()
+    while len(reps) < 20 or (time.perf_counter() - t2 < seconds * 0.3 and len(reps) < 2000):
+        r0 = time.perf_counter()
+        fn(tp, tip, tiv, 0.0, pg, dg, -1.0, 1.0, cpos, cvel)
+        reps.append(time.perf_counter() - r0)
+    all_cores = batch / float(np.median(reps))
     return {"value": batched, "unit": "trajectories/s", "cores": 1, "kind": "port",
             "sample": f"numpy oracle (fp32), ProDMP 7-DoF/5 basis/100 steps + PD actions: {n} trajectories in "
                       f"batches of {batch} over {seconds * 0.6:.0f} s; reference-style B=1 Python loop: "
-                      f"{ref_style:.0f} trajectories/s over {m} calls"}
+                      f"{ref_style:.0f} trajectories/s over {m} calls",
+            "reference_style_b1": {"value": ref_style, "unit": "trajectories/s", "cores": 1, "calls": m},
+            "all_cores": {"value": all_cores, "unit": "trajectories/s", "cores": ncores, "kind": "port",
+                          "sample": f"oracle/mp_torch_cpu.py (torch-CPU einsum, {torch.get_num_threads()} threads), "
+                                    f"median of {len(reps)} calls of one batch of {batch}"}}
+
+
+def synth_inputs(B: int, seed: int):
+    """synthetic MP parameters of the named shape (BASELINE.md section 4): params ~ N(0,1), init_pos ~ U(-1,1), init_vel = 0;
+    seed 0 on one GPU, 1000 + rank when sharded"""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    params = torch.randn((B, P), generator=g, dtype=torch.float32)
+    init_pos = torch.rand((B, D), generator=g, dtype=torch.float32) * 2 - 1
+    init_vel = torch.zeros((B, D), dtype=torch.float32)
+    return params, init_pos, init_vel
+
+
+def spawn_ranks(n: int) -> int:
+    """start the n ranks of `--gpus n` as a child torch.distributed.run; the parent never touches the GPU"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        print("[bench] --gpus must be >= 1", file=sys.stderr)
+        sys.exit(2)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"[bench] error: --gpus {args.gpus} but WORLD_SIZE {world}: launch one rank per GPU "
+                  f"(--nproc-per-node {args.gpus}) or drop WORLD_SIZE and let bench.py start them", file=sys.stderr)
+        sys.exit(2)
     # MPK_BENCH_FORCE_DIST=1 runs the collective code path (RCCL) even with a single rank, to exercise it on a 1-GPU box
     force_dist = os.environ.get("MPK_BENCH_FORCE_DIST") == "1"
     if world > 1 or force_dist:
@@ -130,8 +193,6 @@ def main():
     else:
         dist = None
         torch.cuda.set_device(0)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     dev = torch.device("cuda", local_rank)
 
     from fancy_gym_amd import RolloutSpec, TrajectoryEngine
@@ -141,10 +202,7 @@ def main():
     eng = TrajectoryEngine("prodmp", "exp", "prodmp", device=local_rank, **CFG)
     assert eng.num_steps == T_STEPS and eng.num_params == P
     B, K, W = args.batch, args.steps, args.warmup
-    g = torch.Generator(device="cpu").manual_seed(1000 + rank if world > 1 else 0)
-    params = torch.randn((B, P), generator=g, dtype=torch.float32).to(dev)
-    init_pos = (torch.rand((B, D), generator=g, dtype=torch.float32) * 2 - 1).to(dev)
-    init_vel = torch.zeros((B, D), dtype=torch.float32, device=dev)
+    params, init_pos, init_vel = (t.to(dev) for t in synth_inputs(B, 1000 + rank if world > 1 else 0))
     c_pos, c_vel = init_pos.double().contiguous(), init_vel.double().contiguous()
     pos, vel, act = (torch.empty((B, T_STEPS, D), dtype=torch.float32, device=dev) for _ in range(3))
     spec = RolloutSpec("motor", D, P_GAINS, D_GAINS, -1.0, 1.0, plant="static")
@@ -249,9 +307,19 @@ def main():
         t = torch.tensor([e2], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         e2 = float(t.item())
+        # what arrived: an exact, order-independent checksum (sum of the fp32 bit patterns as int64) of every rank's own
+        # shard, exchanged on the host, against the same checksum of the slice rank 0 received for that rank
+        def bits_sum(t):
+            return int(t.contiguous().view(torch.int32).to(torch.int64).sum().item())
+        mine = torch.tensor([bits_sum(shard)], dtype=torch.int64, device=dev)
+        sums = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(sums, mine)
+        shard_sums = [int(x.item()) for x in sums]
+        gathered_ok = all(bits_sum(full[r]) == shard_sums[r] for r in range(world))
         allgather = {"value": world * B * Kg / e2, "unit": "trajectories/s", "steps": Kg,
                      "ms_per_step": e2 / Kg * 1e3, "bytes_gathered_per_gpu_per_step": int((world - 1) * shard.numel() * 4),
-                     "via": f"torch.distributed all_gather_into_tensor ({'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()})"}
+                     "via": f"torch.distributed all_gather_into_tensor ({'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()})",
+                     "gathered_equals_shards": bool(gathered_ok), "shard_checksums": shard_sums}
         if os.environ.get("MPK_BENCH_NATIVE_COMM") == "1":
             # opt-in: the same leg through libmpk's own RCCL communicator (mpk_comm_* / mpk_allgather, include/mpk.h)
             from fancy_gym_amd.distributed import NativeComm
@@ -270,6 +338,46 @@ def main():
             allgather["native"] = {"value": world * B * Kg / e3, "ms_per_step": e3 / Kg * 1e3, "via": "mpk_allgather"}
             comm.close()
 
+    # ---- the same kernel family where the outputs really stream to HBM (B = 262144: 2.2 GB written per launch) ---------
+    streaming = None
+    if rank == 0 and world == 1 and not args.no_streaming:
+        try:
+            Bs = args.streaming_batch
+            gs = torch.Generator(device="cpu").manual_seed(1)
+            sp_ = torch.randn((Bs, P), generator=gs, dtype=torch.float32).to(dev)
+            sip = (torch.rand((Bs, D), generator=gs, dtype=torch.float32) * 2 - 1).to(dev)
+            siv = torch.zeros((Bs, D), dtype=torch.float32, device=dev)
+            scp, scv = sip.double().contiguous(), siv.double().contiguous()
+            so = [torch.empty((Bs, T_STEPS, D), dtype=torch.float32, device=dev) for _ in range(3)]
+
+            def sstep():
+                rc_ = lib.mpk_trajectory_actions(h, sp_.data_ptr(), sip.data_ptr(), siv.data_ptr(), 0.0, rcfg,
+                                                 scp.data_ptr(), scv.data_ptr(), so[0].data_ptr(), so[1].data_ptr(),
+                                                 so[2].data_ptr(), Bs, sp)
+                if rc_ != 0:
+                    raise RuntimeError(_lib.last_error())
+            for _ in range(5):
+                sstep()
+            torch.cuda.synchronize()
+            Ks = 30
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(Ks):
+                sstep()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            ks_avg = e0.elapsed_time(e1) * 1e-3 / Ks
+            ach = BYTES_PER_TRAJ * Bs / ks_avg / 1e9
+            streaming = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(Bs), "kernel": eng.last_kernel(),
+                         "kernel_avg_us": ks_avg * 1e6, "batch": Bs, "launches": Ks,
+                         "algorithmic_bytes_per_launch": BYTES_PER_TRAJ * Bs,
+                         "trajectories_per_s": Bs / ks_avg}
+            del sp_, sip, siv, scp, scv, so
+            torch.cuda.empty_cache()
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] streaming row failed: {e}", file=sys.stderr)
+
     line = None
     if rank == 0:
         achieved = BYTES_PER_TRAJ * B / kern_avg / 1e9
@@ -287,6 +395,8 @@ def main():
                          "kernel": eng.last_kernel(), "kernel_avg_us": kern_avg * 1e6,
                          "algorithmic_bytes_per_launch": BYTES_PER_TRAJ * B},
         }
+        if streaming is not None:
+            out["roofline_streaming"] = streaming
         if allgather is not None:
             out["allgather"] = allgather
         if not args.no_cpu and world == 1:

@@ -11,7 +11,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MPK_LIB") or os.path.join(_HERE, "libmpk.so")   # MPK_LIB: A/B builds of the library
 
-MPK_ABI_VERSION = 1
+MPK_ABI_VERSION = 2
 MP_TYPES = {"promp": 0, "dmp": 1, "prodmp": 2}
 PHASE_TYPES = {"linear": 0, "exp": 1}
 BASIS_TYPES = {"rbf": 0, "zero_rbf": 1, "prodmp": 2}
@@ -20,6 +20,14 @@ PLANT_TYPES = {"static": 0, "double_integrator": 1}
 
 MPK_EINVAL, MPK_ENOTIMPL, MPK_EHIP, MPK_ERANGE, MPK_ENODEV, MPK_ECOMM = -1, -2, -3, -4, -5, -6
 MPK_COMM_ID_BYTES = 128
+MPK_OPT_AUTO = -1
+# mp_pytorch semantics that cannot be checked here: explicit switches (include/mpk.h); first entry = default
+RELATIVE_GOAL_MODES = {"after_scale": 0, "before_scale": 1}
+GOAL_OFFSET_MODES = {"ignore": 0, "add": 1}
+SINGLE_RBF_MODES = {"unit_gap": 0, "refuse": 1}
+DMP_FIRST_SAMPLE_MODES = {"init": 0, "step": 1}
+OPTION_KEYS = ("mapping", "bulk", "quad", "pd_quad", "write_through", "ipw", "phase", "phase_table", "phase_chunk",
+               "pd_simple")
 
 
 class MPKLibraryError(RuntimeError):
@@ -35,12 +43,14 @@ class mpk_config(C.Structure):
         ("learn_tau", C.c_int32), ("learn_delay", C.c_int32),
         ("auto_scale_basis", C.c_int32), ("relative_goal", C.c_int32),
         ("disable_goal", C.c_int32), ("disable_weights", C.c_int32),
-        ("pre_compute_length_factor", C.c_int32), ("reserved0", C.c_int32),
+        ("pre_compute_length_factor", C.c_int32),
+        ("relative_goal_mode", C.c_int32), ("goal_offset_mode", C.c_int32), ("single_rbf_mode", C.c_int32),
+        ("dmp_first_sample", C.c_int32), ("reserved0", C.c_int32),
         ("tau", C.c_double), ("delay", C.c_double), ("alpha_phase", C.c_double),
         ("tau_bound", C.c_double * 2), ("delay_bound", C.c_double * 2),
         ("basis_bandwidth_factor", C.c_double), ("basis_alpha", C.c_double), ("basis_dt", C.c_double),
         ("weights_scale", C.c_double), ("goal_scale", C.c_double), ("dmp_alpha", C.c_double),
-        ("dt", C.c_double), ("duration", C.c_double),
+        ("dt", C.c_double), ("duration", C.c_double), ("goal_offset", C.c_double),
     ]
 
 
@@ -74,6 +84,8 @@ SIGNATURES = {
     "mpk_num_dof": (C.c_int, [_vp]),
     "mpk_params_bounds": (C.c_int, [_vp, _vp, _vp]),
     "mpk_set_duration": (C.c_int, [_vp, _dbl, _dbl]),
+    "mpk_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int64]),
+    "mpk_get_option": (C.c_int, [_vp, C.c_char_p, C.POINTER(C.c_int64)]),
     "mpk_times": (C.c_int, [_vp, _vp]),
     "mpk_trajectory": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _dbl, _vp, _vp, _i32, _vp]),
     "mpk_trajectory_actions": (C.c_int, [_vp, _vp, _vp, _vp, _dbl, C.POINTER(mpk_rollout_cfg), _vp, _vp,
@@ -153,3 +165,19 @@ def check(rc: int) -> int:
     if rc == MPK_ERANGE:
         raise RuntimeError(msg)
     raise MPKLibraryError(f"libmpk error {rc}: {msg}")
+
+
+def set_option(key: str, value: int = MPK_OPT_AUTO, handle=None) -> None:
+    """mpk_set_option: kernel-selection override (include/mpk.h); handle None = the process-wide default"""
+    check(load().mpk_set_option(handle, key.encode(), int(value)))
+
+
+def get_option(key: str, handle=None) -> int:
+    v = C.c_int64()
+    check(load().mpk_get_option(handle, key.encode(), C.byref(v)))
+    return int(v.value)
+
+
+def reset_options(handle=None) -> None:
+    for k in OPTION_KEYS:
+        set_option(k, MPK_OPT_AUTO, handle)

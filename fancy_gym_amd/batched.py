@@ -95,9 +95,25 @@ class BatchedBlackBox:
         self._start32 = None        # fp32 image of the plant state at reset (boundary condition of the first plan)
 
     # ---- episode control ---------------------------------------------------------------------------------------------
+    def check_range(self):
+        """
+        ProDMP with a per-episode phase (learned tau / delay, drifted init_time): a plan whose scaled time leaves the
+        pre-computed table range raises RuntimeError in mp_pytorch and in the single-episode BlackBoxWrapper; the batched
+        kernels can only raise a device flag (and clamp the index).  This synchronises and raises that RuntimeError if any
+        plan since the last check left the range.  ``reset`` calls it for the episodes just finished (skipped while a
+        hipGraph is being captured -- call it yourself after a replay).
+        """
+        self.engine.check_range()
+
+    def _range_can_overflow(self) -> bool:
+        cfg = self.engine.config
+        return self.engine.mp_type == "prodmp" and bool(cfg.learn_tau or cfg.learn_delay or self._lockstep is None)
+
     def reset(self, init_pos=None, init_vel=None, goal=None):
         """start B new episodes from plant state (init_pos, init_vel) [B, D] (default zeros); goal [B, 2] for the
         simple_reacher reward"""
+        if self._plans_since_reset and self._range_can_overflow() and not torch.cuda.is_current_stream_capturing():
+            self.check_range()
         if self.reward is not None:
             if goal is None:
                 raise ValueError("reward='simple_reacher' needs goal [B, 2] at reset")

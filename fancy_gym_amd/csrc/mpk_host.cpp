@@ -29,6 +29,28 @@ void set_error(const std::string& msg) { g_err = msg; }
         }                                                                                      \
     } while (0)
 
+// Entry points run on the handle's device and leave the caller's current device as they found it.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false, ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+        if (prev != dev) {
+            ok = hipSetDevice(dev) == hipSuccess;
+            switched = ok && prev >= 0;
+        }
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define MPK_ON_DEVICE(dev)                                                                     \
+    DeviceGuard device_guard_(dev);                                                            \
+    if (!device_guard_.ok) { set_error("hipSetDevice failed"); return MPK_EHIP; }
+
+// process-wide kernel-selection defaults (mpk_set_option with a NULL handle)
+static Tuning g_tune;
+
 // ------------------------------------------------------------------------------------------------------------
 // times
 // ------------------------------------------------------------------------------------------------------------
@@ -92,7 +114,7 @@ void build_rbf(const mpk_config& c, HostTables& t) {
         t.centers[k] = unbound_phase(c, ct);
     }
     for (int k = 0; k < n; ++k) {
-        double gap = 1.0;  // single basis: no gap exists upstream; one phase unit (documented (?) in DESIGN.md)
+        double gap = 1.0;  // single basis: no gap exists upstream; one phase unit (MPK_SINGLE_RBF_UNIT_GAP; _REFUSE: check_cfg)
         if (n > 1) gap = k < n - 1 ? t.centers[k + 1] - t.centers[k] : t.centers[n - 1] - t.centers[n - 2];
         t.bw[k] = c.basis_bandwidth_factor / (gap * gap);
     }
@@ -200,7 +222,26 @@ struct Handle {
     CacheEntry cache[kCache];
     uint64_t stamp = 0;
     const char* last_kernel = "";
+    Tuning tune;                 // per-handle overrides (mpk_set_option); -1 = follow the process-wide default
+    float* d_pre = nullptr;      // MPK_DMP_FIRST_IS_STEP: [2][pre_cap] boundary state after the pre-step
+    size_t pre_cap = 0;
 };
+
+static Tuning effective_tuning(const Handle* h) {
+    Tuning t = g_tune;
+    const Tuning& o = h->tune;
+    if (o.mapping >= 0) t.mapping = o.mapping;
+    if (o.bulk >= 0) t.bulk = o.bulk;
+    if (o.quad >= 0) t.quad = o.quad;
+    if (o.pd_quad >= 0) t.pd_quad = o.pd_quad;
+    if (o.write_through >= 0) t.write_through = o.write_through;
+    if (o.ipw >= 0) t.ipw = o.ipw;
+    if (o.phase >= 0) t.phase = o.phase;
+    if (o.phase_table >= 0) t.phase_table = o.phase_table;
+    if (o.phase_chunk >= 0) t.phase_chunk = o.phase_chunk;
+    if (o.pd_simple >= 0) t.pd_simple = o.pd_simple;
+    return t;
+}
 
 static int check_cfg(const mpk_config& c) {
     if (c.abi_version != MPK_ABI_VERSION) { set_error("mpk_config.abi_version mismatch"); return MPK_EINVAL; }
@@ -233,6 +274,23 @@ static int check_cfg(const mpk_config& c) {
         set_error("disable_goal and disable_weights cannot both be set");
         return MPK_EINVAL;
     }
+    if (c.relative_goal_mode < 0 || c.relative_goal_mode > 1 || c.goal_offset_mode < 0 || c.goal_offset_mode > 1 ||
+        c.single_rbf_mode < 0 || c.single_rbf_mode > 1 || c.dmp_first_sample < 0 || c.dmp_first_sample > 1) {
+        set_error("relative_goal_mode, goal_offset_mode, single_rbf_mode and dmp_first_sample take 0 or 1");
+        return MPK_EINVAL;
+    }
+    if (c.goal_offset_mode == MPK_GOAL_OFFSET_ADD && !std::isfinite(c.goal_offset)) {
+        set_error("goal_offset must be finite");
+        return MPK_EINVAL;
+    }
+    if (c.single_rbf_mode == MPK_SINGLE_RBF_REFUSE && c.basis_type != MPK_BASIS_PRODMP) {
+        const int n = c.num_basis + (c.basis_type == MPK_BASIS_ZERO_RBF ? c.num_basis_zero_start + c.num_basis_zero_goal : 0);
+        if (n == 1) {
+            set_error("a single radial basis function has no neighbouring centre to take its bandwidth from "
+                      "(single_rbf_mode = MPK_SINGLE_RBF_REFUSE)");
+            return MPK_EINVAL;
+        }
+    }
     return MPK_OK;
 }
 
@@ -251,7 +309,7 @@ static void quantise(mpk_config& q) {
     q.tau = f32(q.tau); q.delay = f32(q.delay); q.alpha_phase = f32(q.alpha_phase);
     q.basis_bandwidth_factor = f32(q.basis_bandwidth_factor); q.basis_alpha = f32(q.basis_alpha);
     q.basis_dt = f32(q.basis_dt); q.weights_scale = f32(q.weights_scale); q.goal_scale = f32(q.goal_scale);
-    q.dmp_alpha = f32(q.dmp_alpha);
+    q.dmp_alpha = f32(q.dmp_alpha); q.goal_offset = f32(q.goal_offset);
 }
 
 static void fill_devcfg(Handle* h) {
@@ -262,7 +320,10 @@ static void fill_devcfg(Handle* h) {
     d.D = c.num_dof; d.nb = c.num_basis; d.n_total = h->tab.n_total;
     d.zs = c.basis_type == MPK_BASIS_ZERO_RBF ? c.num_basis_zero_start : 0;
     const bool zero_pad = c.basis_type == MPK_BASIS_ZERO_RBF;
-    if (c.mp_type == MPK_MP_PRODMP) d.KT = c.num_basis + 3;          // weights, goal, y_b, v_b
+    d.relgoal_before_scale = c.relative_goal_mode == MPK_RELGOAL_BEFORE_SCALE ? 1 : 0;
+    d.goal_off_on = c.mp_type == MPK_MP_PRODMP && c.goal_offset_mode == MPK_GOAL_OFFSET_ADD && c.goal_offset != 0.0 ? 1 : 0;
+    d.goal_offset = (float)c.goal_offset;
+    if (c.mp_type == MPK_MP_PRODMP) d.KT = c.num_basis + 3 + d.goal_off_on;   // weights, goal, y_b, v_b (, goal offset)
     else if (c.mp_type == MPK_MP_PROMP) d.KT = c.num_basis + (zero_pad ? 1 : 0);  // weights (+ init_pos)
     else d.KT = c.num_basis;                                         // dmp forcing
     d.KP = (d.KT + 3) / 4 * 4;
@@ -298,7 +359,7 @@ static int upload_times(Handle* h) {
 
 static void free_handle(Handle* h) {
     if (!h) return;
-    (void)hipSetDevice(h->cfg.device);
+    DeviceGuard guard(h->cfg.device);
     for (auto& e : h->cache) {
         if (e.st.A) (void)hipFree(e.st.A);
         if (e.st.aux) (void)hipFree(e.st.aux);
@@ -308,6 +369,7 @@ static void free_handle(Handle* h) {
     if (h->d_times) (void)hipFree(h->d_times);
     if (h->d_flag) (void)hipFree(h->d_flag);
     if (h->d_idx) (void)hipFree(h->d_idx);
+    if (h->d_pre) (void)hipFree(h->d_pre);
     delete h;
 }
 
@@ -379,18 +441,13 @@ static int get_shared(Handle* h, float init_time, void* stream, SharedTables* ou
             return MPK_ERANGE;
         }
     }
+    // every slot was allocated for the current (T, KP) by mpk_create / mpk_set_duration (prealloc_cache): a miss only
+    // launches the builder -- nothing here allocates, frees or synchronises
     int TS = 0, n_out = 0;
-    const size_t nf = shared_tables_floats(h->dev, &TS, &n_out);
-    if (victim->st.A && (victim->st.TS != TS || victim->st.n_out != n_out)) {
-        // a cached table may still be in use by an in-flight kernel on the caller's stream: wait before freeing
-        (void)hipStreamSynchronize((hipStream_t)stream);
-        (void)hipFree(victim->st.A); (void)hipFree(victim->st.aux);
-        victim->st = SharedTables{};
-    }
-    if (!victim->st.A) {
-        MPK_HIP(hipMalloc((void**)&victim->st.A, nf * sizeof(float)));
-        MPK_HIP(hipMalloc((void**)&victim->st.aux, (size_t)TS * sizeof(float)));
-        victim->st.TS = TS; victim->st.n_out = n_out;
+    (void)shared_tables_floats(h->dev, &TS, &n_out);
+    if (!victim->st.A || victim->st.TS != TS || victim->st.n_out != n_out) {
+        set_error("internal: shared-table slot does not match the current time grid");
+        return MPK_EINVAL;
     }
     int rc = launch_build_shared(h->dev, init_time, victim->st, nullptr, h->d_flag, stream);
     if (rc != MPK_OK) return rc;
@@ -448,7 +505,7 @@ int mpk_create(const mpk_config* cfg, mpk_handle* out) {
         return MPK_ENODEV;
     }
     if (cfg->device < 0 || cfg->device >= ndev) { set_error("device ordinal out of range"); return MPK_EINVAL; }
-    MPK_HIP(hipSetDevice(cfg->device));
+    MPK_ON_DEVICE(cfg->device);
     Handle* h = new Handle();
     h->cfg = *cfg;
     quantise(h->cfg);
@@ -551,7 +608,7 @@ int mpk_set_duration(mpk_handle hh, double duration, double dt) {
     Handle* h = reinterpret_cast<Handle*>(hh);
     if (!(duration > 0.0) || !(dt > 0.0)) { set_error("dt and duration must be > 0"); return MPK_EINVAL; }
     if (duration == h->duration && dt == h->dt) return MPK_OK;
-    MPK_HIP(hipSetDevice(h->cfg.device));
+    MPK_ON_DEVICE(h->cfg.device);
     // tables of the previous grid may be in flight
     MPK_HIP(hipDeviceSynchronize());
     h->duration = duration; h->dt = dt;
@@ -561,10 +618,47 @@ int mpk_set_duration(mpk_handle hh, double duration, double dt) {
     return prealloc_cache(h);
 }
 
+namespace {
+struct OptKey { const char* name; int Tuning::*field; int64_t lo, hi; };
+const OptKey kOptKeys[] = {
+    {"mapping", &Tuning::mapping, 0, 2},         {"bulk", &Tuning::bulk, 0, 2},
+    {"quad", &Tuning::quad, 0, 4},               {"pd_quad", &Tuning::pd_quad, 0, 2},
+    {"write_through", &Tuning::write_through, 0, 1}, {"ipw", &Tuning::ipw, 0, 1 << 20},
+    {"phase", &Tuning::phase, 0, 1},             {"phase_table", &Tuning::phase_table, 0, 1},
+    {"phase_chunk", &Tuning::phase_chunk, 0, 4}, {"pd_simple", &Tuning::pd_simple, 0, 1},
+};
+const OptKey* find_opt(const char* key) {
+    if (!key) return nullptr;
+    for (const OptKey& k : kOptKeys)
+        if (std::strcmp(k.name, key) == 0) return &k;
+    return nullptr;
+}
+}  // namespace
+
+int mpk_set_option(mpk_handle hh, const char* key, int64_t value) {
+    const OptKey* k = find_opt(key);
+    if (!k) { set_error(std::string("unknown option key: ") + (key ? key : "(null)")); return MPK_EINVAL; }
+    if (value != MPK_OPT_AUTO && (value < k->lo || value > k->hi)) {
+        set_error(std::string("option value out of range for ") + key);
+        return MPK_EINVAL;
+    }
+    Tuning& t = hh ? reinterpret_cast<Handle*>(hh)->tune : g_tune;
+    t.*(k->field) = (int)value;
+    return MPK_OK;
+}
+
+int mpk_get_option(mpk_handle hh, const char* key, int64_t* value) {
+    const OptKey* k = find_opt(key);
+    if (!k || !value) { set_error(std::string("unknown option key: ") + (key ? key : "(null)")); return MPK_EINVAL; }
+    const Tuning t = hh ? effective_tuning(reinterpret_cast<Handle*>(hh)) : g_tune;
+    *value = t.*(k->field);
+    return MPK_OK;
+}
+
 int mpk_check_range(mpk_handle hh, void* stream) {
     if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
     Handle* h = reinterpret_cast<Handle*>(hh);
-    MPK_HIP(hipSetDevice(h->cfg.device));
+    MPK_ON_DEVICE(h->cfg.device);
     int32_t flag = 0;
     MPK_HIP(hipMemcpyAsync(&flag, h->d_flag, sizeof(flag), hipMemcpyDeviceToHost, (hipStream_t)stream));
     MPK_HIP(hipStreamSynchronize((hipStream_t)stream));
@@ -597,20 +691,41 @@ static int traj_common(Handle* h, const float* params, const float* init_pos, co
     if (B < 0) { set_error("B must be >= 0"); return MPK_EINVAL; }
     if (B == 0 || h->dev.D == 0) return MPK_OK;     // empty batch: nothing to do (buffers may be NULL)
     if (!params || !init_pos || !init_vel || !pos || !vel) { set_error("NULL buffer"); return MPK_EINVAL; }
-    MPK_HIP(hipSetDevice(h->cfg.device));
+    MPK_ON_DEVICE(h->cfg.device);
+    const Tuning tune = effective_tuning(h);
+    if (h->cfg.mp_type == MPK_MP_DMP && h->cfg.dmp_first_sample == MPK_DMP_FIRST_IS_STEP) {
+        // the boundary state advanced by one Euler step (k_dmp_prestep) is what the trajectory kernels start from.
+        // The scratch grows with the largest batch seen: the first call with a larger batch allocates (include/mpk.h).
+        const size_t need = (size_t)B * h->dev.D;
+        if (need > h->pre_cap) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing((hipStream_t)stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) {
+                set_error("MPK_DMP_FIRST_IS_STEP: run one eager call with this batch size before capturing a graph");
+                return MPK_EINVAL;
+            }
+            if (h->d_pre) { MPK_HIP(hipStreamSynchronize((hipStream_t)stream)); (void)hipFree(h->d_pre); h->d_pre = nullptr; h->pre_cap = 0; }
+            MPK_HIP(hipMalloc((void**)&h->d_pre, 2 * need * sizeof(float)));
+            h->pre_cap = need;
+        }
+        float* p1 = h->d_pre;
+        float* v1 = h->d_pre + h->pre_cap;
+        int rc = launch_dmp_prestep(h->dev, params, init_pos, init_vel, init_time, (float)init_time_shared, p1, v1, B, stream);
+        if (rc != MPK_OK) return rc;
+        init_pos = p1; init_vel = v1;
+    }
     if (shared_phase(h, init_time) && mfma_capable(h)) {
         SharedTables st;
         int rc = get_shared(h, (float)init_time_shared, stream, &st);
         if (rc != MPK_OK) return rc;
         rc = launch_traj_shared(h->dev, st, params, init_pos, init_vel, pos, vel, actions, rd, c_pos, c_vel,
-                                q_state, qd_state, n_steps, B, h->num_cu, stream, &h->last_kernel, rp);
+                                q_state, qd_state, n_steps, B, h->num_cu, stream, &h->last_kernel, tune, rp);
         // horizons whose basis tables do not fit the episode-major kernel's LDS: the per-episode kernels below (dmp) or,
         // for fused actions / rollouts, the caller's two-launch path
         if (rc != MPK_ENOTIMPL || actions) return rc;
     }
     if (actions) { set_error("fused actions need a shared-phase configuration with D <= 16 and <= 16 basis columns"); return MPK_ENOTIMPL; }
     return launch_traj_rows(h->dev, params, init_pos, init_vel, init_time, (float)init_time_shared, pos, vel,
-                            h->d_flag, B, h->num_cu, stream, &h->last_kernel);
+                            h->d_flag, B, h->num_cu, stream, &h->last_kernel, tune);
 }
 
 int mpk_trajectory(mpk_handle hh, const float* params, const float* init_pos, const float* init_vel,
@@ -631,6 +746,7 @@ int mpk_trajectory_actions(mpk_handle hh, const float* params, const float* init
     RolloutDev rd;
     int r = fill_rollout(h, rc, &rd);
     if (r != MPK_OK) return r;
+    MPK_ON_DEVICE(h->cfg.device);
     if (rd.plant_type != MPK_PLANT_STATIC) { set_error("mpk_trajectory_actions tracks a frozen state (MPK_PLANT_STATIC); use mpk_trajectory_rollout"); return MPK_EINVAL; }
     if (h->cfg.mp_type != MPK_MP_DMP && shared_phase(h, nullptr) && mfma_capable(h)) {
         r = traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, actions, &rd, c_pos, c_vel,
@@ -643,7 +759,7 @@ int mpk_trajectory_actions(mpk_handle hh, const float* params, const float* init
                     nullptr, B, stream);
     if (r != MPK_OK) return r;
     return launch_pd_rollout(rd, h->dev.D, pos, vel, const_cast<double*>(c_pos), const_cast<double*>(c_vel), nullptr,
-                             actions, B, h->dev.T, stream);
+                             actions, B, h->dev.T, stream, effective_tuning(h));
 }
 
 int mpk_trajectory_rollout(mpk_handle hh, const float* params, const float* init_pos, const float* init_vel,
@@ -656,6 +772,7 @@ int mpk_trajectory_rollout(mpk_handle hh, const float* params, const float* init
     RolloutDev rd;
     int r = fill_rollout(h, rc, &rd);
     if (r != MPK_OK) return r;
+    MPK_ON_DEVICE(h->cfg.device);
     if (rd.plant_type != MPK_PLANT_DOUBLE_INTEGRATOR) { set_error("mpk_trajectory_rollout integrates MPK_PLANT_DOUBLE_INTEGRATOR; for a frozen state use mpk_trajectory_actions"); return MPK_EINVAL; }
     if (h->cfg.mp_type != MPK_MP_DMP && shared_phase(h, nullptr) && mfma_capable(h)) {
         r = traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, actions, &rd, nullptr,
@@ -666,7 +783,7 @@ int mpk_trajectory_rollout(mpk_handle hh, const float* params, const float* init
     r = traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, nullptr, nullptr, nullptr,
                     nullptr, B, stream);
     if (r != MPK_OK) return r;
-    return launch_pd_rollout(rd, h->dev.D, pos, vel, q, qd, n_steps, actions, B, h->dev.T, stream);
+    return launch_pd_rollout(rd, h->dev.D, pos, vel, q, qd, n_steps, actions, B, h->dev.T, stream, effective_tuning(h));
 }
 
 int mpk_replan_step(mpk_handle hh, const float* params, const float* init_pos, const float* init_vel,
@@ -685,6 +802,7 @@ int mpk_replan_step(mpk_handle hh, const float* params, const float* init_pos, c
     int r = fill_rollout(h, rc, &rd);
     if (r != MPK_OK) return r;
     if (rd.plant_type != MPK_PLANT_DOUBLE_INTEGRATOR) { set_error("mpk_replan_step integrates MPK_PLANT_DOUBLE_INTEGRATOR"); return MPK_EINVAL; }
+    MPK_ON_DEVICE(h->cfg.device);
     ReplanDev rp;
     rp.traj_steps = st->traj_steps; rp.plan_steps = st->plan_steps; rp.done = st->done; rp.seg_len = st->seg_len;
     rp.done_out = st->done_out; rp.cond_pos = st->cond_pos; rp.cond_vel = st->cond_vel;
@@ -697,7 +815,6 @@ int mpk_replan_step(mpk_handle hh, const float* params, const float* init_pos, c
     }
     // what the fused kernel does not cover (dmp, learned tau / delay, long horizons, > 16 DoF or basis columns): the same
     // result from the separate kernels
-    MPK_HIP(hipSetDevice(h->cfg.device));
     r = launch_replan_advance(rp.traj_steps, rp.plan_steps, rp.seg_len, rp.done, rp.every, rp.max_planning_times,
                               rp.horizon, h->dev.T, B, stream);
     if (r != MPK_OK) return r;
@@ -705,7 +822,7 @@ int mpk_replan_step(mpk_handle hh, const float* params, const float* init_pos, c
     r = traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, nullptr, nullptr, nullptr,
                     nullptr, B, stream);
     if (r != MPK_OK) return r;
-    r = launch_pd_rollout(rd, h->dev.D, pos, vel, q, qd, rp.seg_len, actions, B, h->dev.T, stream);
+    r = launch_pd_rollout(rd, h->dev.D, pos, vel, q, qd, rp.seg_len, actions, B, h->dev.T, stream, effective_tuning(h));
     if (r != MPK_OK) return r;
     if (rp.cond_pos) return launch_condition_gather(pos, vel, rp.seg_len, rp.cond_pos, rp.cond_vel, B, h->dev.T, h->dev.D, stream);
     return MPK_OK;
@@ -721,8 +838,8 @@ int mpk_pd_rollout(mpk_handle hh, const mpk_rollout_cfg* rc, const float* des_po
     int r = fill_rollout(h, rc, &rd);
     if (r != MPK_OK) return r;
     if (B == 0 || T == 0 || h->dev.D == 0) return MPK_OK;
-    MPK_HIP(hipSetDevice(h->cfg.device));
-    return launch_pd_rollout(rd, h->dev.D, des_pos, des_vel, q, qd, n_steps, actions, B, T, stream);
+    MPK_ON_DEVICE(h->cfg.device);
+    return launch_pd_rollout(rd, h->dev.D, des_pos, des_vel, q, qd, n_steps, actions, B, T, stream, effective_tuning(h));
 }
 
 int mpk_reacher_rollout(mpk_handle hh, const mpk_rollout_cfg* rc, const float* des_pos, const float* des_vel,
@@ -741,9 +858,9 @@ int mpk_reacher_rollout(mpk_handle hh, const mpk_rollout_cfg* rc, const float* d
     }
     if (B == 0 || T == 0 || h->dev.D == 0) return MPK_OK;
     if (!des_pos || !des_vel || !q || !qd || !goal || !rewards) { set_error("NULL buffer"); return MPK_EINVAL; }
-    MPK_HIP(hipSetDevice(h->cfg.device));
+    MPK_ON_DEVICE(h->cfg.device);
     return launch_reacher_rollout(rd, h->dev.D, des_pos, des_vel, q, qd, n_steps, step0, goal, steps_before_reward,
-                                  actions, rewards, B, T, stream);
+                                  actions, rewards, B, T, stream, effective_tuning(h));
 }
 
 int mpk_episode_reset(mpk_handle hh, const double* init_q, const double* init_qd, double* q, double* qd,
@@ -755,7 +872,7 @@ int mpk_episode_reset(mpk_handle hh, const double* init_q, const double* init_qd
     if (B == 0) return MPK_OK;
     if (!q || !qd || !traj_steps || !plan_steps || !done) { set_error("NULL buffer"); return MPK_EINVAL; }
     if ((cond_pos == nullptr) != (cond_vel == nullptr)) { set_error("cond_pos and cond_vel go together"); return MPK_EINVAL; }
-    MPK_HIP(hipSetDevice(h->cfg.device));
+    MPK_ON_DEVICE(h->cfg.device);
     return launch_episode_reset(init_q, init_qd, q, qd, cond_pos, cond_vel, traj_steps, plan_steps, done, B, h->dev.D,
                                 stream);
 }
@@ -768,7 +885,7 @@ int mpk_replan_advance(mpk_handle hh, int32_t* traj_steps, int32_t* plan_steps, 
     if (!traj_steps || !plan_steps || !seg_len || !done) { set_error("NULL buffer"); return MPK_EINVAL; }
     if (every < 1 || horizon < 1 || T < 1 || B < 0) { set_error("every, horizon, T must be >= 1"); return MPK_EINVAL; }
     if (B == 0) return MPK_OK;
-    MPK_HIP(hipSetDevice(h->cfg.device));
+    MPK_ON_DEVICE(h->cfg.device);
     return launch_replan_advance(traj_steps, plan_steps, seg_len, done, every, max_planning_times, horizon, T, B,
                                  stream);
 }
@@ -780,7 +897,7 @@ int mpk_condition_gather(mpk_handle hh, const float* pos, const float* vel, cons
     if (B < 0 || T < 1) { set_error("B must be >= 0 and T >= 1"); return MPK_EINVAL; }
     if (B == 0 || h->dev.D == 0) return MPK_OK;
     if (!pos || !vel || !seg_len || !cond_pos || !cond_vel) { set_error("NULL buffer"); return MPK_EINVAL; }
-    MPK_HIP(hipSetDevice(h->cfg.device));
+    MPK_ON_DEVICE(h->cfg.device);
     return launch_condition_gather(pos, vel, seg_len, cond_pos, cond_vel, B, T, h->dev.D, stream);
 }
 
@@ -793,7 +910,7 @@ int mpk_traj_validity(mpk_handle hh, const float* pos, const float* params, cons
     if (check_tau_delay && (!params || !tau_bound || !delay_bound)) { set_error("tau/delay check needs params and bounds"); return MPK_EINVAL; }
     if (h->dev.D > kMaxDofArgs) { set_error("num_dof too large"); return MPK_EINVAL; }
     if (B <= 0 || T <= 0) return MPK_OK;
-    MPK_HIP(hipSetDevice(h->cfg.device));
+    MPK_ON_DEVICE(h->cfg.device);
     return launch_validity(pos, params, h->dev.P, h->dev.D, pos_low, pos_high, check_tau_delay, tau_bound,
                            delay_bound, valid, nullptr, B, T, stream);
 }
@@ -808,7 +925,7 @@ int mpk_traj_validity_penalty(mpk_handle hh, const float* pos, const float* para
     if (check_tau_delay && (!params || !tau_bound || !delay_bound)) { set_error("tau/delay check needs params and bounds"); return MPK_EINVAL; }
     if (h->dev.D > kMaxDofArgs) { set_error("num_dof too large"); return MPK_EINVAL; }
     if (B <= 0 || T <= 0) return MPK_OK;
-    MPK_HIP(hipSetDevice(h->cfg.device));
+    MPK_ON_DEVICE(h->cfg.device);
     return launch_validity(pos, params, h->dev.P, h->dev.D, pos_low, pos_high, check_tau_delay, tau_bound,
                            delay_bound, valid, penalty, B, T, stream);
 }
@@ -831,7 +948,7 @@ int mpk_prodmp_indices(mpk_handle hh, double init_time, int32_t* idx, int32_t* i
     if (h->cfg.mp_type != MPK_MP_PRODMP) { set_error("not a prodmp handle"); return MPK_EINVAL; }
     if (h->cfg.learn_tau || h->cfg.learn_delay) { set_error("indices are per-episode when tau/delay are learned"); return MPK_EINVAL; }
     if (!mfma_capable(h)) { set_error("configuration exceeds the shared-table kernel limits"); return MPK_EINVAL; }
-    MPK_HIP(hipSetDevice(h->cfg.device));
+    MPK_ON_DEVICE(h->cfg.device);
     const int T = h->dev.T;
     if (h->idx_cap < T + 1) {
         if (h->d_idx) (void)hipFree(h->d_idx);
@@ -969,7 +1086,7 @@ int mpk_comm_create(const uint8_t* id, int32_t rank, int32_t world, int32_t devi
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n < 1) { (void)hipGetLastError(); set_error("no HIP device"); return MPK_ENODEV; }
     if (device < 0 || device >= n) { set_error("device ordinal out of range"); return MPK_EINVAL; }
-    MPK_HIP(hipSetDevice(device));
+    MPK_ON_DEVICE(device);
     RcclId u;
     std::memcpy(u.internal, id, MPK_COMM_ID_BYTES);
     Comm* c = new Comm;
@@ -996,6 +1113,7 @@ int mpk_allgather(mpk_comm cc, const float* send, float* recv, int64_t count, vo
     if (count == 0) return MPK_OK;
     if (!send || !recv) { set_error("NULL buffer"); return MPK_EINVAL; }
     Comm* c = reinterpret_cast<Comm*>(cc);
+    MPK_ON_DEVICE(c->device);
     const int rc = rccl().AllGather(send, recv, (size_t)count, kNcclFloat, c->nccl, (hipStream_t)stream);
     if (rc != 0) return rccl_fail("ncclAllGather", rc);
     return MPK_OK;
@@ -1004,6 +1122,7 @@ int mpk_allgather(mpk_comm cc, const float* send, float* recv, int64_t count, vo
 void mpk_comm_destroy(mpk_comm cc) {
     if (!cc) return;
     Comm* c = reinterpret_cast<Comm*>(cc);
+    DeviceGuard guard(c->device);
     if (c->nccl) (void)rccl().CommDestroy(c->nccl);
     delete c;
 }

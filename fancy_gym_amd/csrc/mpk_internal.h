@@ -30,6 +30,12 @@ void build_prodmp(const mpk_config& c, HostTables& t);
 std::vector<float> build_times(double duration, int T);
 int steps_for(double duration, double dt);
 
+// ---- kernel-selection overrides (mpk_set_option); -1 = automatic ----------------------------------------------------
+struct Tuning {
+    int mapping = -1, bulk = -1, quad = -1, pd_quad = -1, write_through = -1, ipw = -1, phase = -1, phase_table = -1,
+        phase_chunk = -1, pd_simple = -1;
+};
+
 // ---- device-side configuration (kernel argument, by value) --------------------------------------------------
 struct DevCfg {
     int mp_type, phase_type, basis_type;
@@ -38,6 +44,9 @@ struct DevCfg {
     int P, Kloc, off;              // params per episode, local params per DoF, offset of the local block
     int T;
     int learn_tau, learn_delay, relative_goal, disable_goal, disable_weights;
+    int relgoal_before_scale;      // MPK_RELGOAL_BEFORE_SCALE
+    int goal_off_on;               // MPK_GOAL_OFFSET_ADD with a non-zero offset: one extra contraction column (x = 1)
+    float goal_offset;
     int n_pc, len_factor;
     float tau, delay, alpha_phase, scaled_dt;
     float tau_lo, tau_hi, delay_lo, delay_hi;
@@ -84,17 +93,22 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
                        const float* init_vel, float* pos, float* vel, float* actions, const RolloutDev* rc,
                        const double* c_pos, const double* c_vel, double* q_state, double* qd_state,
                        const int32_t* n_steps, int B, int num_cu, void* stream, const char** kernel_name,
-                       const ReplanDev* rp = nullptr);
+                       const Tuning& tune, const ReplanDev* rp = nullptr);
 int launch_traj_rows(const DevCfg& c, const float* params, const float* init_pos, const float* init_vel,
                      const float* init_time, float init_time_shared, float* pos, float* vel, int32_t* range_flag,
-                     int B, int num_cu, void* stream, const char** kernel_name);
+                     int B, int num_cu, void* stream, const char** kernel_name, const Tuning& tune);
 int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const float* des_vel, double* q,
-                      double* qd, const int32_t* n_steps, float* actions, int B, int T, void* stream);
+                      double* qd, const int32_t* n_steps, float* actions, int B, int T, void* stream,
+                      const Tuning& tune);
+// MPK_DMP_FIRST_IS_STEP: (init_pos, init_vel) advanced by one Euler step from init_time to the first grid time
+int launch_dmp_prestep(const DevCfg& c, const float* params, const float* init_pos, const float* init_vel,
+                       const float* init_time, float init_time_shared, float* pos1, float* vel1, int B, void* stream);
 int launch_condition_gather(const float* pos, const float* vel, const int32_t* seg_len, float* cond_pos, float* cond_vel,
                             int B, int T, int D, void* stream);
 int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos, const float* des_vel, double* q,
                            double* qd, const int32_t* n_steps, const int32_t* step0, const double* goal,
-                           int steps_before_reward, float* actions, double* rewards, int B, int T, void* stream);
+                           int steps_before_reward, float* actions, double* rewards, int B, int T, void* stream,
+                           const Tuning& tune);
 int launch_episode_reset(const double* init_q, const double* init_qd, double* q, double* qd, float* cond_pos,
                          float* cond_vel, int32_t* traj_steps, int32_t* plan_steps, uint8_t* done, int B, int D,
                          void* stream);

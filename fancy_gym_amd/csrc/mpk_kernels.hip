@@ -154,8 +154,10 @@ __device__ __forceinline__ void prodmp_xi(const DevCfg& c, const ProdmpBC& bc, i
 // RAW parameter column x = [w_0..w_{nb-1}, g, y_b, ydot_b]:
 //   k <  nb   : H_k  * weights_goal_scale[k]            (0 if the weights are disabled)
 //   k == nb   : H_g  * weights_goal_scale[nb]           (0 if the goal is disabled)
-//   k == nb+1 : xi1  (+ H_g for a relative goal: goal = scale*g + y_b)
+//   k == nb+1 : xi1  (+ H_g for a relative goal: goal = scale*g + y_b; MPK_RELGOAL_BEFORE_SCALE: + scale*H_g,
+//               goal = scale*(g + y_b))
 //   k == nb+2 : xi2 * tau                               (v_b = tau * ydot_b)
+//   k == nb+3 : H_g * goal_offset, contracted with x = 1 (MPK_GOAL_OFFSET_ADD only: goal += goal_offset)
 // and the velocity row additionally carries the 1/tau of  vel = (...)/tau.  Everything is folded in float64 and
 // rounded ONCE to fp32.
 __device__ __forceinline__ void prodmp_col(const DevCfg& c, const ProdmpBC& bc, int idx, const double xi[4], int k,
@@ -181,10 +183,17 @@ __device__ __forceinline__ void prodmp_col(const DevCfg& c, const ProdmpBC& bc, 
         if (c.relative_goal) {
             double gp, gv;
             hcol(c.nb, &gp, &gv);
+            if (c.relgoal_before_scale) {
+                const double sg = (VB + (size_t)N * K)[c.nb];
+                gp *= sg; gv *= sg;
+            }
             p += gp; v += gv;
         }
-    } else {
+    } else if (k == K + 1) {
         p = xi[1] * tau; v = xi[3] * tau;
+    } else {
+        hcol(c.nb, &p, &v);
+        p *= (double)c.goal_offset; v *= (double)c.goal_offset;
     }
     *h = (float)p;
     *hv = (float)(v * inv_tau);
@@ -460,7 +469,7 @@ struct ActArgs {
 constexpr int kStageStride = 256;   // floats between output arrays in the wave's LDS staging area (>= NTW*16*D)
 constexpr int kStageFloats = 4 * kStageStride;   // pos | vel | actions or DMP forcing | controller constants
 
-enum : int { XK_ZERO = 0, XK_PARAM = 1, XK_IPOS = 2, XK_IVEL = 3 };
+enum : int { XK_ZERO = 0, XK_PARAM = 1, XK_IPOS = 2, XK_IVEL = 3, XK_ONE = 4 };
 
 // which raw input feeds element k of a DoF's extended parameter column, and its offset inside the DoF's local block
 template <int MP>
@@ -471,7 +480,8 @@ __device__ __forceinline__ int x_kind(const DevCfg& c, int k, int* loc) {
         const bool isw = k < nb, isg = k == nb;
         *loc = isw ? k : (isg && !c.disable_weights ? nb : 0);
         const int kw = c.disable_weights ? XK_ZERO : XK_PARAM, kg = c.disable_goal ? XK_ZERO : XK_PARAM;
-        return isw ? kw : (isg ? kg : (k == nb + 1 ? XK_IPOS : (k == nb + 2 ? XK_IVEL : XK_ZERO)));
+        const int klast = (k == nb + 3 && c.goal_off_on) ? XK_ONE : XK_ZERO;
+        return isw ? kw : (isg ? kg : (k == nb + 1 ? XK_IPOS : (k == nb + 2 ? XK_IVEL : klast)));
     } else if (MP == MPK_MP_PROMP) {
         const bool isw = k < nb;
         *loc = isw ? k : 0;
@@ -489,6 +499,7 @@ struct LaneMap {
     int col, q, bl, d, dsafe, NTW;
     bool dvalid;
     bool isp[KM], isip[KM], isiv[KM];
+    float cst[KM];       // what an element that is no input carries: 0, or 1 for the goal-offset column
     unsigned poff[KM];   // element offset of B-fragment element m inside the group's params block
     unsigned ioff;       // element offset inside the group's init_pos / init_vel / c_pos / c_vel block
     unsigned wofs;       // LDS transpose: write offset of (row 4q, this column)
@@ -513,6 +524,7 @@ __device__ __forceinline__ LaneMap<KM> make_lane_map(const TrajArgs& a, int lane
         L.isp[m] = L.dvalid && kind == XK_PARAM;
         L.isip[m] = L.dvalid && kind == XK_IPOS;
         L.isiv[m] = L.dvalid && kind == XK_IVEL;
+        L.cst[m] = L.dvalid && kind == XK_ONE ? 1.0f : 0.0f;
         L.poff[m] = (unsigned)(L.bl * c.P + c.off + L.dsafe * c.Kloc + loc);
     }
     L.ioff = (unsigned)(L.bl * D + L.dsafe);
@@ -566,7 +578,7 @@ __device__ __forceinline__ GroupIn<KM> load_group(const TrajArgs& a, const LaneM
 template <int KM>
 __device__ __forceinline__ void finish_group(const LaneMap<KM>& L, const GroupIn<KM>& in, float (&xb)[KM]) {
 #pragma unroll
-    for (int m = 0; m < KM; ++m) xb[m] = L.isp[m] ? in.raw[m] : (L.isip[m] ? in.ip : (L.isiv[m] ? in.iv : 0.0f));
+    for (int m = 0; m < KM; ++m) xb[m] = L.isp[m] ? in.raw[m] : (L.isip[m] ? in.ip : (L.isiv[m] ? in.iv : L.cst[m]));
 }
 
 // park the controller constants of every DoF in the wave's 4th staging slot (static kernarg indices: no spill)
@@ -738,7 +750,7 @@ __device__ __forceinline__ void tile_store(const TrajArgs& a, const LaneMap<KM>&
 // load.  The tile-major kernel lives for ~8 us, so that is worth removing.
 __device__ __forceinline__ void demand_args(const TrajArgs& a, unsigned grid_x) {
     asm volatile("" ::"s"(grid_x), "s"(a.c.D), "s"(a.c.nb), "s"(a.c.KT), "s"(a.c.P), "s"(a.c.Kloc), "s"(a.c.off), "s"(a.c.T),
-                 "s"(a.c.disable_weights), "s"(a.c.disable_goal), "s"(a.A), "s"(a.aux), "s"(a.TS), "s"(a.params),
+                 "s"(a.c.disable_weights), "s"(a.c.disable_goal), "s"(a.c.goal_off_on), "s"(a.A), "s"(a.aux), "s"(a.TS), "s"(a.params),
                  "s"(a.init_pos), "s"(a.init_vel), "s"(a.pos), "s"(a.vel), "s"(a.actions), "s"(a.c_pos), "s"(a.c_vel),
                  "s"(a.sh), "s"(a.G), "s"(a.vec_ok), "s"(a.pitch), "s"(a.cps), "s"(a.shifted), "s"(a.td3),
                  "s"(a.inv_cps), "s"(a.nrt_magic), "s"(a.gstride));
@@ -1093,7 +1105,7 @@ __global__ void __launch_bounds__(256) k_traj_stream(const TrajArgs a, const Act
 #pragma unroll
                 for (int m = 0; m < KM; ++m) {
                     const float raw = pj[L.poff[m]];
-                    xb[m] = L.isp[m] ? raw : (L.isip[m] ? ip : (L.isiv[m] ? iv : 0.0f));
+                    xb[m] = L.isp[m] ? raw : (L.isip[m] ? ip : (L.isiv[m] ? iv : L.cst[m]));
                 }
                 double cp = 0.0, cv = 0.0;
                 if (ACT) {
@@ -1457,18 +1469,11 @@ static int launch_traj_ct(const TrajArgs& ta, const ActArgs& aa, int ct, bool st
     return launch_traj_t<MP, -1>(ta, aa, stream_mode, write_through, bulk, quad, blocks, lds, stream);
 }
 
-// 0 = automatic, 1 = force tile-major, 2 = force episode-major (MPK_MAPPING environment variable, for A/B runs)
-static int mapping_override() {
-    const char* e = getenv("MPK_MAPPING");   // read per launch: tests flip it at run time
-    const int v = e ? atoi(e) : 0;
-    return (v < 0 || v > 2) ? 0 : v;
-}
-
 int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* params, const float* init_pos,
                        const float* init_vel, float* pos, float* vel, float* actions, const RolloutDev* rc,
                        const double* c_pos, const double* c_vel, double* q_state, double* qd_state,
                        const int32_t* n_steps, int B, int num_cu, void* stream, const char** kernel_name,
-                       const ReplanDev* rp) {
+                       const Tuning& tune, const ReplanDev* rp) {
     TrajArgs ta;
     ta.nrt_magic = 0; ta.gstride = 0; ta.wt = 0;
     if (rp) ta.rp = *rp;
@@ -1509,7 +1514,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     const size_t table_bytes = ((size_t)st.n_out * c.KP * st.TS + st.TS) * sizeof(float);
     const double out_bytes = (double)B * c.T * c.D * 4.0 * nst;
     bool stream_mode = c.mp_type == MPK_MP_DMP || closed || out_bytes > 96.0 * 1024 * 1024;
-    const int ov = mapping_override();
+    const int ov = tune.mapping == 1 || tune.mapping == 2 ? tune.mapping : 0;   // mpk_set_option "mapping"
     if (c.mp_type != MPK_MP_DMP && !closed && ov == 1) stream_mode = false;
     if (ov == 2) stream_mode = true;
     if (stream_mode && table_bytes + 4 * kStageFloats * sizeof(float) > 64 * 1024) {
@@ -1517,25 +1522,24 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         if (c.mp_type == MPK_MP_DMP || closed) { set_error("trajectory too long for the episode-major kernel's LDS budget"); return MPK_ENOTIMPL; }
         stream_mode = false;
     }
-    // write-through stores for the cache-resident tile-major case (MPK_WRITE_THROUGH=0/1 overrides, for A/B runs)
+    // write-through stores for the cache-resident tile-major case (mpk_set_option "write_through" overrides, for A/B runs)
     bool write_through = !stream_mode;
     ta.wt = stream_mode && out_bytes <= 96.0 * 1024 * 1024 ? 1 : 0;
-    if (const char* e = getenv("MPK_WRITE_THROUGH")) {
-        write_through = atoi(e) != 0 && !stream_mode;
-        ta.wt = atoi(e) != 0 && stream_mode ? 1 : 0;
+    if (tune.write_through >= 0) {
+        write_through = tune.write_through != 0 && !stream_mode;
+        ta.wt = tune.write_through != 0 && stream_mode ? 1 : 0;
     }
     int blocks;
     size_t lds = 0;
     bool bulk = false;
     // serial-recurrence variants (DMP, closed loop): four (or two) groups per wave, recurrences in parallel on the lane
     // quarters; needs its staging (52 / 26 KB) + the tables within 64 KB.  quad = groups per wave, 0 = k_traj_stream.
-    // MPK_QUAD: 0 off, 2 force four, 3 force two (A/B runs, tests)
+    // mpk_set_option "quad": 0 off, 2 force four, 3 force two, 4 force one (A/B runs, tests)
     int quad = 0;
     {
         auto fits = [&](int nq) { return table_bytes + (4 * nq * kQuadImg) * sizeof(float) + 4 * 64 * sizeof(double) <= 64 * 1024; };
         const bool serial_variant = stream_mode && (c.mp_type == MPK_MP_DMP || closed);
-        int quad_mode = 1;
-        if (const char* e = getenv("MPK_QUAD")) quad_mode = atoi(e);
+        const int quad_mode = tune.quad < 0 ? 1 : tune.quad;
         const long units4 = (ta.G + 3) / 4, units2 = (ta.G + 1) / 2;
         // automatic (A/B-measured, profiles/r01_replan_end_to_end.md):
         //   four per wave  while that gives two waves per SIMD but not yet more units than resident waves
@@ -1571,9 +1575,8 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
                aligned16(params) && aligned16(init_pos) && aligned16(init_vel) &&
                (!act || closed || (aligned16(c_pos) && aligned16(c_vel))) &&
                lds_bulk + 4 * kStageFloats * sizeof(float) <= 64 * 1024;
-        // MPK_BULK=0 disables, =2 forces it below the size threshold too (tests); default: HBM-streaming sizes only
-        int bulk_mode = 1;
-        if (const char* e = getenv("MPK_BULK")) bulk_mode = atoi(e);
+        // mpk_set_option "bulk": 0 disables, 2 forces it below the size threshold too (tests); default: HBM-streaming sizes only
+        const int bulk_mode = tune.bulk < 0 ? 1 : tune.bulk;
         // automatic: only when the outputs stream to HBM AND the 4x coarser work units still fill the chip; the
         // latency-bound DMP recurrence prefers occupancy over input staging
         const long chunks = (ta.G + kChunkGroups - 1) / kChunkGroups;
@@ -1587,7 +1590,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     } else {
         const long items = (long)ta.G * NRT;
         long ipw = (items + max_waves - 1) / max_waves;                  // items per wave, balanced
-        if (const char* e = getenv("MPK_IPW")) { const long v = atol(e); if (v > 0) ipw = v; }   // A/B runs
+        if (tune.ipw > 0) ipw = tune.ipw;                                // mpk_set_option "ipw" (A/B runs)
         // the kernel divides wave ids by NRT with a 32-bit multiply-high: exact while #waves < 2^32 / NRT
         const long wave_cap = (long)((1ull << 32) / (unsigned long long)NRT) - 8 * NRT;
         if ((items + ipw - 1) / ipw > wave_cap) ipw = (items + wave_cap - 1) / wave_cap;
@@ -1668,8 +1671,10 @@ __global__ void __launch_bounds__(256) k_traj_rows(const RowArgs a) {
                     if (!c.disable_goal) v = prm[c.off + dd * c.Kloc + (c.disable_weights ? 0 : nb)];
                 } else if (k == nb + 1) {
                     v = a.init_pos[(size_t)b * D + dd];
-                } else {
+                } else if (k == nb + 2) {
                     v = a.init_vel[(size_t)b * D + dd];
+                } else {
+                    v = 1.0f;                      // goal-offset column (MPK_GOAL_OFFSET_ADD)
                 }
             } else if (MP == MPK_MP_PROMP) {
                 if (k < c.nb) v = prm[c.off + dd * c.Kloc + k];
@@ -1916,6 +1921,7 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
         for (int k = threadIdx.x; k <= c.nb; k += blockDim.x) {
             const bool off = k < c.nb ? c.disable_weights != 0 : c.disable_goal != 0;
             sWgs[k] = off ? 0.0f : (float)S[k];
+            if (k == c.nb) sWgs[c.nb + 1] = (float)S[k];     // the goal scale itself, also when the goal is disabled
         }
         if (TL) {
             const float4* src = reinterpret_cast<const float4*>(c.rows32);
@@ -2013,7 +2019,12 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
                             const bool have = k < c.nb ? !c.disable_weights : !c.disable_goal;
                             const int li = k < c.nb ? k : (c.disable_weights ? 0 : c.nb);
                             wg = have ? loc[li] * sWgs[k] : 0.0f;
-                            if (k == c.nb && c.relative_goal) wg = wg + yb;      // g += init_pos
+                            if (k == c.nb) {
+                                // relative goal: init_pos joins the scaled goal, or (MPK_RELGOAL_BEFORE_SCALE) the raw
+                                // parameter -- zero when the goal is disabled -- before the scale
+                                if (c.relative_goal) wg = c.relgoal_before_scale ? ((have ? loc[li] : 0.0f) + yb) * sWgs[c.nb + 1] : wg + yb;
+                                if (c.goal_off_on) wg = wg + c.goal_offset;
+                            }
                             pb += (double)rb[k] * (double)wg;
                             vb += (double)rb[KS + k] * (double)wg;
                         }
@@ -2212,10 +2223,11 @@ __global__ void __launch_bounds__(256) k_traj_phase_dmp(const PhaseArgs a) {
 }
 
 static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu, void* stream,
-                             const char** kernel_name) {
+                             const char** kernel_name, const Tuning& tune) {
     PhaseArgs pa = base;
     const bool dmp = c.mp_type == MPK_MP_DMP;
-    const int need = c.KT + (dmp ? 3 : 0);   // dmp: + goal, y0, ydot0 columns
+    // dmp: + goal, y0, ydot0 columns; prodmp: weights, goal, y1 | y2 (a goal offset is added to the goal itself here)
+    const int need = c.mp_type == MPK_MP_PRODMP ? c.nb + 3 : c.KT + (dmp ? 3 : 0);
     if (need > 16 || c.D > 64) return MPK_ENOTIMPL;
     const int KQ = need <= 4 && c.mp_type == MPK_MP_PROMP ? 1 : (need <= 8 ? 2 : 4), KS = KQ * 4;
     if (c.D * KS > 256) return MPK_ENOTIMPL;
@@ -2235,19 +2247,19 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
         pa.img_pad = (E * (c.P + 2 * c.D + 1) + 3) / 4 * 4;
         pa.wave_floats = 2 * pa.img_pad + 2 * pa.o_pad + pa.x_pad;
     }
-    pa.c_pad = c.mp_type == MPK_MP_PRODMP ? (c.nb + 1 + 3) / 4 * 4 : (4 * c.n_total + 3) / 4 * 4;
+    pa.c_pad = c.mp_type == MPK_MP_PRODMP ? (c.nb + 2 + 3) / 4 * 4 : (4 * c.n_total + 3) / 4 * 4;
     const size_t wave_bytes = (size_t)pa.wave_floats * sizeof(float);
     size_t shared_bytes = (size_t)(pa.t_pad + pa.c_pad) * sizeof(float);
     if (wave_bytes + shared_bytes > 160 * 1024) return MPK_ENOTIMPL;
     int wpb = (int)((64 * 1024 - shared_bytes) / wave_bytes);
     wpb = wpb > 4 ? 4 : (wpb < 1 ? 1 : wpb);
-    // prodmp: stage the row table in LDS when it leaves room for at least 8 waves (MPK_PHASE_TABLE=0: gather from L2)
+    // prodmp: stage the row table in LDS when it leaves room for at least 8 waves ("phase_table" 0: gather from L2)
     bool lds_table = false;
     if (c.mp_type == MPK_MP_PRODMP) {
         const size_t tab_bytes = (size_t)c.n_pc * (2 * KS + 4) * sizeof(float);
         const size_t room = 160 * 1024 - shared_bytes;
         lds_table = tab_bytes + 8 * wave_bytes <= room && (long)pa.B >= (long)num_cu * 8;
-        if (const char* e = getenv("MPK_PHASE_TABLE")) lds_table = lds_table && atoi(e) != 0;
+        if (tune.phase_table == 0) lds_table = false;
         if (lds_table) {
             pa.tab_pad = c.n_pc * (2 * KS + 4);
             shared_bytes += tab_bytes;
@@ -2263,7 +2275,7 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
         const long resident = (long)num_cu * per_cu * wpb;
         int E = pa.chunk;
         while (E > 1 && (long)pa.B / E < 4 * resident) E >>= 1;
-        if (const char* e = getenv("MPK_PHASE_CHUNK")) { const int v = atoi(e); if (v >= 1 && v <= pa.chunk) E = v; }
+        if (tune.phase_chunk >= 1 && tune.phase_chunk <= pa.chunk) E = tune.phase_chunk;
         pa.chunk = E;
     }
     const long units = dmp ? (long)pa.B : ((long)pa.B + pa.chunk - 1) / pa.chunk;
@@ -2297,21 +2309,80 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// k_dmp_prestep (MPK_DMP_FIRST_IS_STEP): the boundary state advanced by ONE Euler step from init_time to the first grid
+// time, with the forcing and the scaled-time increment at init_time -- the state the trajectory kernels then start
+// from.  One lane per (episode, DoF); same row functions and operation order as the trajectory kernels.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_dmp_prestep(const DevCfg c, const float* __restrict__ params,
+                                                     const float* __restrict__ init_pos,
+                                                     const float* __restrict__ init_vel,
+                                                     const float* __restrict__ init_time, const float init_time_shared,
+                                                     float* __restrict__ pos1, float* __restrict__ vel1, const int B) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)B * c.D) return;
+    const int b = (int)(e / c.D), d = (int)(e - (long)b * c.D);
+    const float* prm = params + (size_t)b * c.P;
+    float tau = c.tau, delay = c.delay;
+    int o = 0;
+    if (c.learn_tau) { tau = fminf(fmaxf(prm[o], c.tau_lo), c.tau_hi); ++o; }
+    if (c.learn_delay) delay = fminf(fmaxf(prm[o], c.delay_lo), c.delay_hi);
+    const float it = init_time ? init_time[b] : init_time_shared;
+    const float t1 = c.base_times[0] + it;
+    const float ds0 = scaled_time(t1, delay, tau) - scaled_time(it, delay, tau);
+    const double x = phase_f64(c, it, tau, delay, ExpLiteral());
+    const double* cen = c.tab;
+    const double* bw = c.tab + c.n_total;
+    double sum = 0.0;
+    for (int k = 0; k < c.n_total; ++k) {
+        const double dx = x - cen[k];
+        sum += exp_nonpos(-(dx * dx * bw[k]) * 0.5);
+    }
+    const double mul = x * (double)c.ws;
+    const double scale = c.n_total > 1 ? div_pos(mul, sum) : mul;
+    const float* w = prm + c.off + d * c.Kloc;
+    float f0 = 0.0f;
+    for (int k = 0; k < c.nb; ++k) {
+        const double dx = x - cen[c.zs + k];
+        const float h = (float)(exp_nonpos(-(dx * dx * bw[c.zs + k]) * 0.5) * scale);
+        f0 = fmaf(h, w[k], f0);
+    }
+    float y = init_pos[e];
+    float z = init_vel[e] * tau;
+    const float g = w[c.nb] * c.gs;
+    const float t1_ = g - y;
+    const float t2 = c.dmp_beta * t1_;
+    const float t3 = t2 - z;
+    const float t4 = c.dmp_alpha * t3;
+    const float acc = t4 + f0;
+    z = z + ds0 * acc;
+    y = y + ds0 * z;
+    pos1[e] = y;
+    vel1[e] = div_tau(z, make_tau_div(tau));
+}
+
+int launch_dmp_prestep(const DevCfg& c, const float* params, const float* init_pos, const float* init_vel,
+                       const float* init_time, float init_time_shared, float* pos1, float* vel1, int B, void* stream) {
+    hipLaunchKernelGGL(k_dmp_prestep, dim3((unsigned)(((long)B * c.D + 255) / 256)), dim3(256), 0, (hipStream_t)stream, c,
+                       params, init_pos, init_vel, init_time, init_time_shared, pos1, vel1, B);
+    MPK_LAUNCH_CHECK();
+    return MPK_OK;
+}
+
 int launch_traj_rows(const DevCfg& c, const float* params, const float* init_pos, const float* init_vel,
                      const float* init_time, float init_time_shared, float* pos, float* vel, int32_t* range_flag,
-                     int B, int num_cu, void* stream, const char** kernel_name) {
+                     int B, int num_cu, void* stream, const char** kernel_name, const Tuning& tune) {
     if (c.mp_type == MPK_MP_PROMP && c.T < 2) {
         set_error("promp needs at least two time steps for the finite-difference velocity");
         return MPK_EINVAL;
     }
-    // wave-per-episode kernel whenever the shape fits it (MPK_PHASE=0: the workgroup-per-episode kernel below)
-    bool wave_kernel = true;
-    if (const char* e = getenv("MPK_PHASE")) wave_kernel = atoi(e) != 0;
+    // wave-per-episode kernel whenever the shape fits it ("phase" 0: the workgroup-per-episode kernel below)
+    const bool wave_kernel = tune.phase != 0;
     if (wave_kernel) {
         PhaseArgs pa{c, params, init_pos, init_vel, init_time, init_time_shared, pos, vel, range_flag, B, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         pa.wt = (double)B * c.T * c.D * 8.0 <= 96.0 * 1024 * 1024 ? 1 : 0;
-        if (const char* e = getenv("MPK_WRITE_THROUGH")) pa.wt = atoi(e) != 0 ? 1 : 0;
-        const int rc = launch_traj_phase(c, pa, num_cu, stream, kernel_name);
+        if (tune.write_through >= 0) pa.wt = tune.write_through != 0 ? 1 : 0;
+        const int rc = launch_traj_phase(c, pa, num_cu, stream, kernel_name, tune);
         if (rc != MPK_ENOTIMPL) return rc;
     }
     const int nrow = c.mp_type == MPK_MP_PRODMP ? 2 : 1;
@@ -2723,18 +2794,18 @@ __global__ void __launch_bounds__(256) k_reacher_rollout(const RolloutDev rc, co
 int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
                            const float* des_vel, double* q, double* qd, const int32_t* n_steps, const int32_t* step0,
                            const double* goal, int steps_before_reward, float* actions, double* rewards, int B, int T,
-                           void* stream) {
+                           void* stream, const Tuning& tune) {
     auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     const int last_rows = T - (T - 1) / 16 * 16;
     const bool tiles_ok = D >= 1 && D <= kMaxD && (T * D) % 4 == 0 && (last_rows * D) % 4 == 0 && aligned16(des_pos) &&
-                          aligned16(des_vel) && (!actions || aligned16(actions)) && !getenv("MPK_PD_SIMPLE");
+                          aligned16(des_vel) && (!actions || aligned16(actions)) && tune.pd_simple != 1;
     if (tiles_ok) {
         // the tile-streaming rollout with the reward evaluated per tile by all lanes (see k_pd_rollout_tiles, RW)
         PdArgs pa;
         pa.rc = rc; pa.des_pos = des_pos; pa.des_vel = des_vel; pa.Q = q; pa.QD = qd; pa.n_steps = n_steps;
         pa.actions = actions; pa.D = D; pa.B = B; pa.T = T;
         pa.wt = (double)B * T * D * 12.0 <= 96.0 * 1024 * 1024 ? 1 : 0;     // desired (pos, vel) + actions stay cached
-        if (const char* e = getenv("MPK_WRITE_THROUGH")) pa.wt = atoi(e) != 0 ? 1 : 0;
+        if (tune.write_through >= 0) pa.wt = tune.write_through != 0 ? 1 : 0;
         pa.step0 = step0; pa.goal = goal; pa.rewards = rewards; pa.steps_before_reward = steps_before_reward;
         int sh = 0;
         while ((1 << sh) < D) ++sh;
@@ -2742,8 +2813,7 @@ int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
         const int NTW = 16 >> sh;
         pa.G = (B + NTW - 1) / NTW;
         pa.inv_seg4 = 65536u / (unsigned)(4 * D) + 1u;
-        int quad_mode = 1;
-        if (const char* e = getenv("MPK_PD_QUAD")) quad_mode = atoi(e);
+        const int quad_mode = tune.pd_quad < 0 ? 1 : tune.pd_quad;
         const bool quad = quad_mode == 2 || (quad_mode == 1 && pa.G >= 4 * 256 * 8);
         const int units = quad ? (pa.G + 3) / 4 : pa.G;
         int blocks = (units + 3) / 4;
@@ -2771,17 +2841,17 @@ int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
 }
 
 int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const float* des_vel, double* q, double* qd,
-                      const int32_t* n_steps, float* actions, int B, int T, void* stream) {
+                      const int32_t* n_steps, float* actions, int B, int T, void* stream, const Tuning& tune) {
     auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     const int last_rows = T - (T - 1) / 16 * 16;
     const bool tiles_ok = D >= 1 && D <= kMaxD && (T * D) % 4 == 0 && (last_rows * D) % 4 == 0 && aligned16(des_pos) &&
-                          aligned16(des_vel) && (!actions || aligned16(actions)) && !getenv("MPK_PD_SIMPLE");
+                          aligned16(des_vel) && (!actions || aligned16(actions)) && tune.pd_simple != 1;
     if (tiles_ok) {
         PdArgs pa;
         pa.rc = rc; pa.des_pos = des_pos; pa.des_vel = des_vel; pa.Q = q; pa.QD = qd; pa.n_steps = n_steps;
         pa.actions = actions; pa.D = D; pa.B = B; pa.T = T;
         pa.wt = (double)B * T * D * 12.0 <= 96.0 * 1024 * 1024 ? 1 : 0;     // desired (pos, vel) + actions stay cached
-        if (const char* e = getenv("MPK_WRITE_THROUGH")) pa.wt = atoi(e) != 0 ? 1 : 0;
+        if (tune.write_through >= 0) pa.wt = tune.write_through != 0 ? 1 : 0;
         pa.step0 = nullptr; pa.goal = nullptr; pa.rewards = nullptr; pa.steps_before_reward = 0;
         int sh = 0;
         while ((1 << sh) < D) ++sh;
@@ -2789,9 +2859,8 @@ int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const f
         const int NTW = 16 >> sh;
         pa.G = (B + NTW - 1) / NTW;
         pa.inv_seg4 = 65536u / (unsigned)(4 * D) + 1u;
-        // four groups per wave once that still leaves every CU several waves (MPK_PD_QUAD: 0 off, 2 force)
-        int quad_mode = 1;
-        if (const char* e = getenv("MPK_PD_QUAD")) quad_mode = atoi(e);
+        // four groups per wave once that still leaves every CU several waves ("pd_quad": 0 off, 2 force)
+        const int quad_mode = tune.pd_quad < 0 ? 1 : tune.pd_quad;
         const bool quad = quad_mode == 2 || (quad_mode == 1 && pa.G >= 4 * 256 * 8);
         const int units = quad ? (pa.G + 3) / 4 : pa.G;
         int blocks = (units + 3) / 4;

@@ -70,7 +70,9 @@ class TrajectoryEngine:
                  basis_alpha: float = 25.0, basis_dt: float = 0.01, pre_compute_length_factor: int = 6,
                  weights_scale: float = 1.0, goal_scale: float = 1.0, dmp_alpha: float = 25.0,
                  auto_scale_basis: bool = False, relative_goal: bool = False, disable_goal: bool = False,
-                 disable_weights: bool = False, device: Union[int, torch.device, None] = None):
+                 disable_weights: bool = False, relative_goal_mode: str = "after_scale",
+                 goal_offset_mode: str = "ignore", goal_offset: float = 0.0, single_rbf_mode: str = "unit_gap",
+                 dmp_first_sample: str = "init", device: Union[int, torch.device, None] = None):
         self._h = C.c_void_p()
         self._lib = _lib.load()
         for name, table, val in (("movement primitive", MP_TYPES, mp_type), ("phase generator", PHASE_TYPES, phase_type),
@@ -92,6 +94,15 @@ class TrajectoryEngine:
         c.auto_scale_basis, c.relative_goal = int(bool(auto_scale_basis)), int(bool(relative_goal))
         c.disable_goal, c.disable_weights = int(bool(disable_goal)), int(bool(disable_weights))
         c.pre_compute_length_factor = int(pre_compute_length_factor)
+        # the "(?)" items of SURVEY Appendix A as named options (include/mpk.h MPK_RELGOAL_* ...); first = default
+        for field, table, val in (("relative_goal_mode", _lib.RELATIVE_GOAL_MODES, relative_goal_mode),
+                                  ("goal_offset_mode", _lib.GOAL_OFFSET_MODES, goal_offset_mode),
+                                  ("single_rbf_mode", _lib.SINGLE_RBF_MODES, single_rbf_mode),
+                                  ("dmp_first_sample", _lib.DMP_FIRST_SAMPLE_MODES, dmp_first_sample)):
+            if val not in table:
+                raise ValueError(f"{field} {val!r} not supported, please choose one of {list(table)}.")
+            setattr(c, field, table[val])
+        c.goal_offset = float(goal_offset or 0.0)
         c.tau, c.delay, c.alpha_phase = float(tau), float(delay), float(alpha_phase)
         c.tau_bound[0], c.tau_bound[1] = float(tau_bound[0]), float(tau_bound[1])
         c.delay_bound[0], c.delay_bound[1] = float(delay_bound[0]), float(delay_bound[1])
@@ -105,6 +116,8 @@ class TrajectoryEngine:
         self.num_dof = self._lib.mpk_num_dof(self._h)
         self.num_params = self._lib.mpk_num_params(self._h)
         self._host_stage = None     # pinned / device staging of trajectory_host, allocated on first use
+        # B = 1 host path: the kernel reads / writes the pinned host buffers directly (False: staged device copies)
+        self.b1_zero_copy = os.environ.get("MPK_B1_ZEROCOPY", "1") != "0"
 
     # ---- lifecycle ---------------------------------------------------------------------------------------------
     def close(self):
@@ -150,9 +163,16 @@ class TrajectoryEngine:
             t = t.expand(shape)
         return t.contiguous()
 
-    @staticmethod
-    def _stream() -> int:
-        return torch.cuda.current_stream().cuda_stream
+    def _stream(self) -> int:
+        """the current stream of THIS engine's device (not of whatever device is current)"""
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def set_option(self, key: str, value: int = _lib.MPK_OPT_AUTO):
+        """kernel-selection override for this engine only (mpk_set_option; A/B runs and variant-pinning tests)"""
+        _lib.set_option(key, value, self._h)
+
+    def get_option(self, key: str) -> int:
+        return _lib.get_option(key, self._h)
 
     # ---- hot path ----------------------------------------------------------------------------------------------
     def trajectory(self, params, init_pos, init_vel, init_time=0.0, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
@@ -215,7 +235,7 @@ class TrajectoryEngine:
         # zero copy (default): the kernel reads the inputs from, and writes (pos | vel) to, the pinned host buffers
         # themselves -- pinned host memory is device-accessible at the same address, and a few KB over PCIe cost less than
         # the two copy calls (MPK_B1_ZEROCOPY=0: staged copies through device buffers instead)
-        zero_copy = os.environ.get("MPK_B1_ZEROCOPY", "1") != "0"
+        zero_copy = self.b1_zero_copy
         if not zero_copy:
             d_in.copy_(h_in, non_blocking=True)
         base = (h_in if zero_copy else d_in).data_ptr()
@@ -228,7 +248,7 @@ class TrajectoryEngine:
         if per_episode and self.mp_type == "prodmp":
             self.check_range()                       # synchronises
         else:
-            torch.cuda.current_stream().synchronize()
+            torch.cuda.current_stream(self.device).synchronize()
         out = h_out.clone()
         return out[0], out[1]
 

@@ -51,6 +51,7 @@ class SimpleReacherEnv(_gym.Env):
         self.goal = np.zeros(2)
         self.steps = 0
         self._rng = np.random.default_rng()
+        self._start_pos = np.zeros(self.n_links)      # simple_reacher.py:29
 
     # ---- RawInterfaceWrapper plumbing ---------------------------------------------------------------------------------
     @property
@@ -78,9 +79,11 @@ class SimpleReacherEnv(_gym.Env):
         if random_start:
             self.q = np.zeros(self.n_links)
             self.q[0] = self._rng.uniform(np.pi / 4, 3 * np.pi / 4)
+            self._start_pos = self.q.copy()
         else:
-            self.q = np.zeros(self.n_links)
-            self.q[0] = np.pi / 2
+            # the reference starts from _start_pos: zeros in SimpleReacherEnv (simple_reacher.py:29), replaced by the
+            # last random start of this instance (base_reacher.py:80-86)
+            self.q = self._start_pos.copy()
         self.qd = np.zeros(self.n_links)
         self.goal = self._draw_goal()
         self.steps = 0

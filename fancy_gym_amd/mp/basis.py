@@ -39,14 +39,16 @@ class NormalizedRBFBasisGenerator(BasisGenerator):
     type_name = "rbf"
 
     def __init__(self, phase_generator, num_basis: int = 10, basis_bandwidth_factor: float = 3,
-                 num_basis_outside: int = 0, **_ignored):
+                 num_basis_outside: int = 0, single_rbf_mode: str = "unit_gap", **_ignored):
         super().__init__(phase_generator, num_basis)
         self.basis_bandwidth_factor = float(basis_bandwidth_factor)
         self.num_basis_outside = int(num_basis_outside)
+        # ONE basis function in total has no neighbouring centre: 'unit_gap' (default) | 'refuse' (include/mpk.h)
+        self.single_rbf_mode = single_rbf_mode
 
     def engine_kwargs(self) -> dict:
         return dict(basis_type="rbf", num_basis=self.num_basis, basis_bandwidth_factor=self.basis_bandwidth_factor,
-                    num_basis_outside=self.num_basis_outside)
+                    num_basis_outside=self.num_basis_outside, single_rbf_mode=self.single_rbf_mode)
 
 
 class ZeroPaddingNormalizedRBFBasisGenerator(NormalizedRBFBasisGenerator):
@@ -55,15 +57,17 @@ class ZeroPaddingNormalizedRBFBasisGenerator(NormalizedRBFBasisGenerator):
     type_name = "zero_rbf"
 
     def __init__(self, phase_generator, num_basis: int = 10, num_basis_zero_start: int = 2,
-                 num_basis_zero_goal: int = 0, basis_bandwidth_factor: float = 3, **_ignored):
-        super().__init__(phase_generator, num_basis, basis_bandwidth_factor, 0)
+                 num_basis_zero_goal: int = 0, basis_bandwidth_factor: float = 3, single_rbf_mode: str = "unit_gap",
+                 **_ignored):
+        super().__init__(phase_generator, num_basis, basis_bandwidth_factor, 0, single_rbf_mode)
         self.num_basis_zero_start = int(num_basis_zero_start)
         self.num_basis_zero_goal = int(num_basis_zero_goal)
 
     def engine_kwargs(self) -> dict:
         return dict(basis_type="zero_rbf", num_basis=self.num_basis,
                     basis_bandwidth_factor=self.basis_bandwidth_factor,
-                    num_basis_zero_start=self.num_basis_zero_start, num_basis_zero_goal=self.num_basis_zero_goal)
+                    num_basis_zero_start=self.num_basis_zero_start, num_basis_zero_goal=self.num_basis_zero_goal,
+                    single_rbf_mode=self.single_rbf_mode)
 
 
 class ProDMPBasisGenerator(NormalizedRBFBasisGenerator):

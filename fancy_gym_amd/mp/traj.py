@@ -177,6 +177,9 @@ class DMP(MPInterface):
     def __init__(self, basis_gn, num_dof, weights_scale: float = 1.0, goal_scale: float = 1.0, alpha: float = 25,
                  **kwargs):
         self.goal_scale, self.alpha = float(goal_scale), float(alpha)
+        # how the first returned sample relates to the initial condition: 'init' (default) | 'step' (include/mpk.h
+        # MPK_DMP_FIRST_*; SURVEY A.6 "(?)")
+        self.dmp_first_sample = kwargs.pop("dmp_first_sample", "init")
         super().__init__(basis_gn, num_dof, weights_scale, **kwargs)
 
     @property
@@ -184,7 +187,7 @@ class DMP(MPInterface):
         return (self.num_basis + 1) * self.num_dof
 
     def _engine_extra(self) -> dict:
-        return dict(goal_scale=self.goal_scale, dmp_alpha=self.alpha)
+        return dict(goal_scale=self.goal_scale, dmp_alpha=self.alpha, dmp_first_sample=self.dmp_first_sample)
 
 
 class ProDMP(MPInterface):
@@ -198,9 +201,14 @@ class ProDMP(MPInterface):
         self.relative_goal = bool(kwargs.pop("relative_goal", False))
         self.disable_weights = bool(kwargs.pop("disable_weights", False))
         self.disable_goal = bool(kwargs.pop("disable_goal", False))
-        # accepted and ignored, as in mp_pytorch <= 0.1.3 where it disappears into **kwargs (SURVEY A.5 (?));
-        # the reference passes it in box_pushing/mp_wrapper.py:77 and table_tennis/mp_wrapper.py:114
+        # the reference passes goal_offset in box_pushing/mp_wrapper.py:77 and table_tennis/mp_wrapper.py:114; in
+        # mp_pytorch <= 0.1.3 it is believed to disappear into **kwargs (SURVEY A.5 (?)): goal_offset_mode 'ignore'
+        # (default) accepts and drops it, 'add' adds it to the goal (include/mpk.h MPK_GOAL_OFFSET_*)
         self.goal_offset = kwargs.pop("goal_offset", None)
+        self.goal_offset_mode = kwargs.pop("goal_offset_mode", "ignore")
+        # relative_goal: init_pos joins the scaled goal ('after_scale', default) or the raw goal parameter
+        # ('before_scale') -- include/mpk.h MPK_RELGOAL_*
+        self.relative_goal_mode = kwargs.pop("relative_goal_mode", "after_scale")
         kwargs.pop("duration", None)   # _BB_DEFAULTS['ProDMP'] carries a stray 'duration' (registry.py:108)
         super().__init__(basis_gn, num_dof, weights_scale, **kwargs)
 
@@ -212,4 +220,5 @@ class ProDMP(MPInterface):
     def _engine_extra(self) -> dict:
         return dict(goal_scale=self.goal_scale, auto_scale_basis=self.auto_scale_basis,
                     relative_goal=self.relative_goal, disable_goal=self.disable_goal,
-                    disable_weights=self.disable_weights)
+                    disable_weights=self.disable_weights, relative_goal_mode=self.relative_goal_mode,
+                    goal_offset_mode=self.goal_offset_mode, goal_offset=float(self.goal_offset or 0.0))

@@ -57,6 +57,10 @@ class VectorBlackBox:
         shared = not (cfg.learn_tau or cfg.learn_delay) and len(set(it)) == 1
         init_time = float(it[0]) if shared else torch.tensor(np.asarray(it, np.float32), device=self.engine.device)
         pos, vel = self.engine.trajectory(np.stack(full), np.stack(ip), np.stack(iv), init_time)
+        if not shared and self.engine.mp_type == "prodmp":
+            # per-episode phase: a scaled time beyond the pre-computed table range only shows on the device; raise what
+            # every individual wrapper (and mp_pytorch) raises -- RuntimeError("Time is beyond the pre-computation range")
+            self.engine.check_range()
         return pos.cpu().numpy(), vel.cpu().numpy()
 
     def step(self, actions: np.ndarray):

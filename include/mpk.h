@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MPK_ABI_VERSION 1
+#define MPK_ABI_VERSION 2
 
 /* error codes */
 #define MPK_OK            0
@@ -54,6 +54,26 @@ extern "C" {
 #define MPK_PLANT_STATIC             0  /* state never changes (test/test_black_box.py:50-56 ToyWrapper)            */
 #define MPK_PLANT_DOUBLE_INTEGRATOR  1  /* envs/classic_control/base_reacher/base_reacher_torque.py:25-26           */
 
+/*
+ * mp_pytorch semantics that cannot be checked against the package in this build (it is not vendored by the reference:
+ * pyproject.toml:30) are explicit switches -- SURVEY.md Appendix A marks each of them "(?)".  0 is the default and the
+ * behaviour every BASELINE configuration is tested with; a maintainer with mp_pytorch at hand flips a field instead of
+ * patching a kernel.  Both settings of every switch are covered by tests (tests/test_gpu_switches.py).
+ */
+/* prodmp, relative_goal: where init_pos joins the goal                                                              */
+#define MPK_RELGOAL_AFTER_SCALE   0  /* goal = weights_goal_scale[-1] * g + init_pos                                  */
+#define MPK_RELGOAL_BEFORE_SCALE  1  /* goal = weights_goal_scale[-1] * (g + init_pos)   (added to the raw parameter)  */
+/* prodmp, goal_offset kwarg (envs/mujoco/box_pushing/mp_wrapper.py:77, table_tennis/mp_wrapper.py:114)              */
+#define MPK_GOAL_OFFSET_IGNORE    0  /* swallowed by **kwargs                                                         */
+#define MPK_GOAL_OFFSET_ADD       1  /* goal = (scaled, possibly relative) goal + goal_offset                         */
+/* rbf / zero_rbf with ONE basis function in total (no neighbouring centre to take a gap from)                        */
+#define MPK_SINGLE_RBF_UNIT_GAP   0  /* bandwidth = factor / 1^2 (a gap of one phase unit)                            */
+#define MPK_SINGLE_RBF_REFUSE     1  /* mpk_create fails with MPK_EINVAL                                              */
+/* dmp: how the first returned sample (t = init_time + dt; the time grid excludes t = init_time) relates to the      */
+/* initial condition                                                                                                  */
+#define MPK_DMP_FIRST_IS_INIT     0  /* pos[0] = init_pos, vel[0] = init_vel; Euler steps follow                      */
+#define MPK_DMP_FIRST_IS_STEP     1  /* pos[0] = one Euler step from (init_time, init_pos, init_vel)                  */
+
 typedef struct mpk_handle_s* mpk_handle;
 
 /*
@@ -79,6 +99,10 @@ typedef struct mpk_config {
     int32_t disable_goal;            /* prodmp */
     int32_t disable_weights;         /* prodmp */
     int32_t pre_compute_length_factor; /* prodmp, <= 6 */
+    int32_t relative_goal_mode;      /* MPK_RELGOAL_*      (prodmp) */
+    int32_t goal_offset_mode;        /* MPK_GOAL_OFFSET_*  (prodmp) */
+    int32_t single_rbf_mode;         /* MPK_SINGLE_RBF_*   (rbf, zero_rbf) */
+    int32_t dmp_first_sample;        /* MPK_DMP_FIRST_*    (dmp) */
     int32_t reserved0;
     double  tau;                     /* construction-time tau (also the value used when !learn_tau) */
     double  delay;
@@ -93,6 +117,7 @@ typedef struct mpk_config {
     double  dmp_alpha;               /* dmp spring constant, beta = alpha/4 */
     double  dt;                      /* env control step  (RawInterfaceWrapper.dt, raw_interface_wrapper.py:46-53) */
     double  duration;                /* trajectory duration in seconds */
+    double  goal_offset;             /* prodmp, used when goal_offset_mode == MPK_GOAL_OFFSET_ADD */
 } mpk_config;
 
 /* controller + plant description for the rollout (black_box_wrapper.py:175-203; controller/pd_controller.py:21-29) */
@@ -133,8 +158,37 @@ int mpk_num_dof(mpk_handle h);
 /* Replaces traj_gen.get_params_bounds() (black_box_wrapper.py:122-127): host float [P] each. */
 int mpk_params_bounds(mpk_handle h, float* low, float* high);
 
-/* Replaces traj_gen.set_duration(duration, dt) (black_box_wrapper.py:115). Changes T. */
+/*
+ * Replaces traj_gen.set_duration(duration, dt) (black_box_wrapper.py:115). Changes T.  This is the ONE entry point that
+ * synchronises the device and re-allocates (the time grid and the shared basis-table slots for the new T): tables of the
+ * previous grid may still be in flight.  It must not be called while a stream capture is active, and it releases every
+ * slot pinned by a captured graph (see mpk_unpin_tables).  No other entry point allocates, frees or synchronises in the
+ * steady state (exceptions, each documented at its declaration: mpk_check_range and mpk_prodmp_indices synchronise by
+ * contract; a MPK_DMP_FIRST_IS_STEP handle grows its boundary-state scratch on the first call with a larger batch).
+ */
 int mpk_set_duration(mpk_handle h, double duration, double dt);
+
+/*
+ * Kernel-selection overrides for A/B measurements and for the tests that pin every kernel variant.  Selection is
+ * automatic by default; nothing in the launch path reads the environment.  `h` == NULL sets the process-wide default
+ * that every handle without its own setting follows; a handle's own setting wins.  MPK_OPT_AUTO restores automatic
+ * selection (for a handle: follow the process-wide default again).  Not synchronised: set options from the thread that
+ * launches.  Keys and values:
+ *   "mapping"       1 tile-major, 2 episode-major                                  (shared-phase trajectory kernels)
+ *   "bulk"          0 off, 2 force chunked input staging                           (episode-major kernel)
+ *   "quad"          0 off, 2 / 3 / 4 = four / two / one episode group(s) per wave  (serial-recurrence trajectory kernels)
+ *   "pd_quad"       0 off, 2 force four groups per wave                            (rollout kernels)
+ *   "write_through" 0 plain stores, 1 write-through (sc1) stores                   (every kernel that has the choice)
+ *   "ipw"           n > 0 work items per wave                                      (tile-major kernel)
+ *   "phase"         0 workgroup-per-episode kernel instead of wave-per-episode     (per-episode-phase kernels)
+ *   "phase_table"   0 ProDMP row table from L2 instead of LDS
+ *   "phase_chunk"   1 / 2 / 4 episodes per input chunk
+ *   "pd_simple"     1 generic one-lane-per-(episode, DoF) rollout kernels
+ * Unknown key or value out of range: MPK_EINVAL.  mpk_get_option returns the effective value (MPK_OPT_AUTO if automatic).
+ */
+#define MPK_OPT_AUTO (-1)
+int mpk_set_option(mpk_handle h, const char* key, int64_t value);
+int mpk_get_option(mpk_handle h, const char* key, int64_t* value);
 
 /*
  * Stream capture (hipGraph): every trajectory call only enqueues kernels, so a sequence of calls may be captured and

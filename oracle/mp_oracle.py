@@ -69,6 +69,9 @@ class BasisCfg:
     alpha: float = 25.0                    # prodmp only
     dt: float = 0.01                       # prodmp pre-compute grid step (the reference never overrides it)
     pre_compute_length_factor: int = 6     # prodmp only
+    # SURVEY A.4 "(?)": ONE radial basis function in total has no neighbouring centre to take a gap from.
+    # 'unit_gap' (default): bandwidth = factor / 1**2;  'refuse': ValueError (mpk.h MPK_SINGLE_RBF_*)
+    single_rbf_mode: str = "unit_gap"
 
 
 @dataclasses.dataclass
@@ -83,6 +86,11 @@ class TrajCfg:
     relative_goal: bool = False
     disable_goal: bool = False
     disable_weights: bool = False
+    # SURVEY Appendix A "(?)" items as explicit switches (same names and meaning as include/mpk.h); first = default
+    relative_goal_mode: str = "after_scale"   # 'after_scale': goal = s_g*g + init_pos | 'before_scale': s_g*(g + init_pos)
+    goal_offset_mode: str = "ignore"          # 'ignore' (swallowed by **kwargs) | 'add': goal += goal_offset
+    goal_offset: float = 0.0
+    dmp_first_sample: str = "init"            # 'init': pos[0] = init_pos | 'step': pos[0] = one Euler step from init_time
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -200,6 +208,8 @@ def rbf_centers_bandwidth(pc: PhaseCfg, bc: BasisCfg, dtype=np.float32) -> Tuple
     pinned (test/test_black_box.py:168-193).
     """
     n = rbf_total_basis(bc)
+    if n == 1 and bc.single_rbf_mode == "refuse" and bc.basis_generator_type != "prodmp":
+        raise ValueError("a single radial basis function has no neighbouring centre to take its bandwidth from")
     out = 0 if bc.basis_generator_type == "zero_rbf" else bc.num_basis_outside
     tau, delay = _q(pc.tau, dtype), _q(pc.delay, dtype)
     dist = tau / dtype(n - 2 * out - 1) if n > 1 else tau
@@ -377,15 +387,25 @@ def promp_trajectory(pc: PhaseCfg, bc: BasisCfg, tc: TrajCfg, params: Array, tim
 # DMP
 # ----------------------------------------------------------------------------------------------------------------------
 def dmp_trajectory(pc: PhaseCfg, bc: BasisCfg, tc: TrajCfg, params: Array, times: Array, init_pos: Array,
-                   init_vel: Array, dtype=np.float32) -> Tuple[Array, Array]:
+                   init_vel: Array, dtype=np.float32, init_time=None) -> Tuple[Array, Array]:
     """
     forcing f = x * (Phi . w); explicit (semi-implicit) Euler in scaled time:
         a = alpha*(beta*(g - y_i) - z_i) + f_i ; z_{i+1} = z_i + ds_i*a ; y_{i+1} = y_i + ds_i*z_{i+1} ; vel = z/tau
-    The first sample carries the initial condition (y_0 = init_pos, z_0 = tau*init_vel).
+    The first sample carries the initial condition (y_0 = init_pos, z_0 = tau*init_vel) -- ``dmp_first_sample='init'``,
+    the default (SURVEY A.6 "(?)"); 'step': the first sample is one Euler step from (init_time, init_pos, init_vel).
     """
     f = dtype
     tau, delay, wg = split_params(pc, bc, tc, params, f)           # [B, D, nb+1]
     B, D = wg.shape[0], wg.shape[1]
+    if tc.dmp_first_sample == "step":
+        # the integration starts AT init_time (the time grid excludes it, A.2): prepend that sample, integrate, drop it
+        assert init_time is not None
+        it = np.broadcast_to(np.asarray(init_time, np.float32), (B,)).astype(np.float32).astype(f)
+        tt = np.broadcast_to(times.astype(f), (B, times.shape[-1]))
+        ext = np.concatenate([it[:, None], tt], axis=1).astype(f)
+        sub = dataclasses.replace(tc, dmp_first_sample="init")
+        pos, vel = dmp_trajectory(pc, bc, sub, params, ext, init_pos, init_vel, f)
+        return pos[:, 1:], vel[:, 1:]
     w = (wg[..., :-1] * _q(tc.weights_scale, f)).astype(f)
     g = (wg[..., -1] * _q(tc.goal_scale, f)).astype(f)
     phi = rbf_basis(pc, bc, times, tau, delay, f)
@@ -450,18 +470,24 @@ def prodmp_trajectory(pc: PhaseCfg, bc: BasisCfg, tc: TrajCfg, params: Array, ti
         xi1  = (dy2_b*y1 - dy1_b*y2)/det     xi2 = (y1_b*y2 - y2_b*y1)/det      (xi3, xi4: same with dy1, dy2)
         H    = Psi  - xi1 (x) Psi_b - xi2 (x) dPsi_b        Hv = dPsi - xi3 (x) Psi_b - xi4 (x) dPsi_b
         pos  = xi1*y_b + xi2*(tau*v_b) + H . wg            vel = (xi3*y_b + xi4*(tau*v_b) + Hv . wg) / tau
-    wg = [w, g] * weights_goal_scale per DoF; relative_goal adds init_pos to the scaled goal (?).
+    wg = [w, g] * weights_goal_scale per DoF; relative_goal adds init_pos to the scaled goal -- or, with
+    relative_goal_mode='before_scale', to the raw goal parameter (SURVEY A.5 "(?)"); goal_offset_mode='add' adds
+    goal_offset to the goal (default: ignored, as **kwargs swallows it upstream).
     """
     f = dtype
     if tables is None:
         tables = prodmp_tables(pc, bc, f)
     tau, delay, local = split_params(pc, bc, tc, params, f)
     B, D = local.shape[0], local.shape[1]
-    wg = (prodmp_full_params(tc, bc, local, f) * prodmp_weights_goal_scale(tc, bc, tables, f)).astype(f)
     y_b = np.asarray(init_pos, f)
-    if tc.relative_goal:
-        wg = wg.copy()
-        wg[..., -1] = (wg[..., -1] + y_b).astype(f)
+    full = prodmp_full_params(tc, bc, local, f)
+    if tc.relative_goal and tc.relative_goal_mode == "before_scale":
+        full[..., -1] = (full[..., -1] + y_b).astype(f)          # init_pos joins the RAW goal parameter
+    wg = (full * prodmp_weights_goal_scale(tc, bc, tables, f)).astype(f)
+    if tc.relative_goal and tc.relative_goal_mode == "after_scale":
+        wg[..., -1] = (wg[..., -1] + y_b).astype(f)              # init_pos joins the scaled goal
+    if tc.goal_offset_mode == "add":
+        wg[..., -1] = (wg[..., -1] + _q(tc.goal_offset, f)).astype(f)
     tau_b = np.broadcast_to(np.asarray(tau, f), (B,)).astype(f)
     v_b = (np.asarray(init_vel, f) * tau_b[:, None]).astype(f)
 
@@ -522,7 +548,7 @@ def get_trajectory(pc: PhaseCfg, bc: BasisCfg, tc: TrajCfg, params: Array, durat
     if t == "promp":
         return promp_trajectory(pc, bc, tc, params, times, init_pos, dtype)
     if t == "dmp":
-        return dmp_trajectory(pc, bc, tc, params, times, init_pos, init_vel, dtype)
+        return dmp_trajectory(pc, bc, tc, params, times, init_pos, init_vel, dtype, init_time=init_time)
     if t == "prodmp":
         return prodmp_trajectory(pc, bc, tc, params, times, init_time, init_pos, init_vel, tables, dtype)
     raise ValueError(t)

@@ -86,3 +86,33 @@ def test_native_comm_argument_checks_without_a_gpu():
     assert lib.mpk_allgather(None, None, None, 4, None) == _lib.MPK_EINVAL
     assert lib.mpk_comm_rank(None) == _lib.MPK_EINVAL and lib.mpk_comm_world(None) == _lib.MPK_EINVAL
     lib.mpk_comm_destroy(None)   # no-op
+
+
+def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
+    """bench.py --gpus N under a launcher that created a different number of ranks is an error (exit 2), decided before
+    anything touches a GPU -- a silent `n_gpus: 1` line for `--gpus 8` is what round 1 shipped"""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr and not r.stdout.strip()
+
+
+def test_bench_gpus_n_spawns_a_torch_distributed_run_child(monkeypatch):
+    """--gpus N without WORLD_SIZE: the parent builds the torch.distributed.run command line for N ranks on 127.0.0.1 and
+    returns the child's exit code (the child is faked here: no GPU in this container)"""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    assert bench.spawn_ranks(4) == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

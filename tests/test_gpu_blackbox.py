@@ -3,7 +3,10 @@ GPU suite, part 2: the drop-in surface (BlackBoxWrapper / make_bb on the referen
 rollout kernels against the oracle (bit-exact in float64), the integer replanning state (bit-exact), the batched
 validity check, the committed golden fixtures, and size-independent properties at BASELINE's full batch sizes.
 """
+import json
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -337,10 +340,10 @@ def test_single_episode_step_matches_oracle_on_a_closed_loop_plant():
 @pytest.mark.parametrize("plant", ["static", "double_integrator"])
 @pytest.mark.parametrize("B", [1, 37, 1000])
 @pytest.mark.parametrize("simple", ["tiles", "simple", "quad"])
-def test_pd_rollout_is_bit_exact_in_float64(controller, plant, B, simple, monkeypatch):
+def test_pd_rollout_is_bit_exact_in_float64(controller, plant, B, simple, monkeypatch, mpk_option):
     if simple == "simple":
-        monkeypatch.setenv("MPK_PD_SIMPLE", "1")      # the generic one-lane-per-(episode, DoF) kernel
-    monkeypatch.setenv("MPK_PD_QUAD", "2" if simple == "quad" else "0")   # four groups per wave / one
+        mpk_option("pd_simple", "1")      # the generic one-lane-per-(episode, DoF) kernel
+    mpk_option("pd_quad", "2" if simple == "quad" else "0")   # four groups per wave / one
     pc, bc, tc, dt, dur = CFG2
     eng = make_engine(pc, bc, tc, dt, dur)
     params, ip, iv = inputs(pc, bc, tc, B, seed=11)
@@ -379,11 +382,11 @@ def test_fused_actions_are_bit_exact(cfg, controller, mapping, monkeypatch):
 @pytest.mark.parametrize("controller", ["motor", "position", "velocity"])
 @pytest.mark.parametrize("B", [1, 9, 200])
 @pytest.mark.parametrize("bulk,quad", [("0", "2"), ("0", "3"), ("0", "4"), ("0", "0"), ("2", "0")])
-def test_fused_closed_loop_rollout_is_bit_exact(cfg, controller, B, bulk, quad, monkeypatch):
+def test_fused_closed_loop_rollout_is_bit_exact(cfg, controller, B, bulk, quad, monkeypatch, mpk_option):
     """one launch (trajectory + controller + double-integrator plant) == mpk_trajectory + mpk_pd_rollout == oracle;
     k_traj_quad (four recurrences per wave) and both input-staging variants of k_traj_stream"""
-    monkeypatch.setenv("MPK_BULK", bulk)
-    monkeypatch.setenv("MPK_QUAD", quad)
+    mpk_option("bulk", bulk)
+    mpk_option("quad", quad)
     pc, bc, tc, dt, dur = cfg
     eng = make_engine(pc, bc, tc, dt, dur)
     params, ip, iv = inputs(pc, bc, tc, B, seed=B)
@@ -414,11 +417,11 @@ def test_fused_closed_loop_rollout_is_bit_exact(cfg, controller, B, bulk, quad, 
 
 @pytest.mark.parametrize("quad", ["0", "2"])
 @pytest.mark.parametrize("D,T", [(1, 50), (3, 10), (4, 17), (16, 40), (5, 100), (20, 12)])
-def test_pd_rollout_on_every_shape_class(D, T, quad, monkeypatch):
+def test_pd_rollout_on_every_shape_class(D, T, quad, monkeypatch, mpk_option):
     """tile-streaming kernel (D <= 16, float4-aligned; one or four groups per wave) and the generic kernel (everything
     else) against the oracle"""
     from tests.test_gpu_edge_cases import cfg_for
-    monkeypatch.setenv("MPK_PD_QUAD", quad)
+    mpk_option("pd_quad", quad)
     pc, bc, tc, dt, dur = cfg_for("promp", D, 3, T)
     eng = make_engine(pc, bc, tc, dt, dur)
     B = 23
@@ -592,6 +595,74 @@ def test_batched_replanning_follows_the_single_episode_sequence():
         cond_p, cond_v = dp[:, n - 1], dv[:, n - 1]           # condition on the desired state where the plan broke
 
 
+def test_cfg4_at_its_full_per_gpu_batch_against_the_oracle():
+    """
+    BASELINE cfg4 at the size one GPU runs (65 536 episodes over 8 GPUs = 8 192 each), four plans, AUTOMATIC kernel
+    selection (the fused closed-loop kernel the launcher picks at this size -- not a variant forced by an option):
+    integer state array_equal against the restated reference loop, actions and plant state bit-exact against the
+    oracle's float64 rollout over all 8 192 episodes, trajectories within 1e-5 on a 256-row sample.
+    Anchor: envs/mujoco/box_pushing/mp_wrapper.py:87-91; black_box_wrapper.py:150-217.
+    """
+    B = 8192
+    bb = _batched(CFG4, B, plant="double_integrator", replanning_every=25, max_planning_times=4,
+                  condition_on_desired=True)
+    rng = np.random.default_rng(12)
+    q0 = rng.uniform(-1, 1, (B, 7))
+    bb.reset(q0)
+    pc, bc, tc, dt, dur = CFG4
+    rows = np.sort(rng.choice(B, 256, replace=False))
+    cond_p, cond_v = q0.astype(np.float32), np.zeros((B, 7), np.float32)
+    q, qd = q0.copy(), np.zeros((B, 7))
+    cur, plan = np.zeros(B, np.int64), np.zeros(B, np.int64)
+    kernels = set()
+    for k in range(4):
+        params = rng.standard_normal((B, 35)).astype(np.float32)
+        out = bb.step(params)
+        kernels.add(bb.engine.last_kernel())
+        # integer state: the reference loop, episode by episode (all episodes share the schedule here; done per episode
+        # anyway so that a kernel that mixed episodes up would be caught)
+        n_ref, cur_ref, plan_ref = zip(*[_reference_loop(int(c), int(p), False, 25, 4, 100, 100) for c, p in zip(cur, plan)])
+        assert np.array_equal(out["trajectory_length"].cpu().numpy(), np.asarray(n_ref, np.int32))
+        assert np.array_equal(bb.traj_steps.cpu().numpy(), np.asarray(cur_ref, np.int32))
+        assert np.array_equal(bb.plan_steps.cpu().numpy(), np.asarray(plan_ref, np.int32))
+        assert np.array_equal(out["done"].cpu().numpy(), np.asarray(cur_ref) >= 100)
+        n = int(n_ref[0])
+        start = int(cur[0])
+        cur, plan = np.asarray(cur_ref), np.asarray(plan_ref)
+        dp, dv = out["des_pos"].cpu().numpy(), out["des_vel"].cpu().numpy()
+        rp, rv = O.get_trajectory(pc, bc, tc, params[rows], dur, dt, start * dt, cond_p[rows], cond_v[rows],
+                                  dtype=np.float64)
+        close(dp[rows], rp, f"plan {k} pos")
+        close(dv[rows], rv, f"plan {k} vel")
+        ra, q, qd = O.rollout(dp, dv, "motor", PG, DG, -1.0, 1.0, "double_integrator", dt, q, qd, n_steps=np.full(B, n))
+        assert np.array_equal(out["step_actions"].cpu().numpy(), ra.astype(np.float32)), f"plan {k} actions"
+        assert np.array_equal(out["current_pos"].cpu().numpy(), q) and np.array_equal(out["current_vel"].cpu().numpy(), qd)
+        cond_p, cond_v = dp[:, n - 1], dv[:, n - 1]
+        assert np.array_equal(bb.condition_pos.cpu().numpy(), cond_p) and np.array_equal(bb.condition_vel.cpu().numpy(), cond_v)
+    assert all(kn.endswith("closed>") for kn in kernels), kernels       # the ONE-launch step, whichever variant was chosen
+
+
+def test_cfg5_fused_actions_at_its_full_per_gpu_batch_against_the_oracle():
+    """BASELINE cfg5 (ProMP TableTennis4D, table_tennis/mp_wrapper.py:11-30) at B = 8 192, automatic kernel selection:
+    fused open-loop PD actions bit-exact over all episodes, trajectories within 1e-5 on a 256-row sample"""
+    pc, bc, tc, dt, dur = CFG5
+    B = 8192
+    eng = make_engine(pc, bc, tc, dt, dur)
+    params, ip, iv = inputs(pc, bc, tc, B, seed=21)
+    pg = 0.5 * np.array([1.0, 4.0, 2.0, 4.0, 1.0, 4.0, 1.0]); dg = 0.1 * pg
+    spec = RolloutSpec("motor", 7, pg, dg, -1.0, 1.0, plant="static")
+    c_pos, c_vel = ip.astype(np.float64), iv.astype(np.float64)
+    pos, vel, act = eng.trajectory_actions(params, ip, iv, spec, c_pos, c_vel)
+    torch.cuda.synchronize()
+    assert eng.last_kernel() in ("k_traj_tiles<promp,act>", "k_traj_stream<promp,act>"), eng.last_kernel()
+    dp, dv = pos.cpu().numpy(), vel.cpu().numpy()
+    rows = np.sort(np.random.default_rng(0).choice(B, 256, replace=False))
+    rp, rv = O.get_trajectory(pc, bc, tc, params[rows], dur, dt, 0.0, ip[rows], iv[rows], dtype=np.float64)
+    close(dp[rows], rp, "pos"); close(dv[rows], rv, "vel", atol=fd_atol(rp, dt))
+    ra, _, _ = O.rollout(dp, dv, "motor", pg, dg, -1.0, 1.0, "static", dt, c_pos, c_vel)
+    assert np.array_equal(act.cpu().numpy(), ra.astype(np.float32))
+
+
 @pytest.mark.parametrize("name", ["cfg4", "cfg3_dmp", "prodmp_learn_tau_delay"])
 def test_batched_fused_and_unfused_steps_agree_bitwise(name):
     """the lean step (mpk_trajectory_rollout: one launch for shared-phase promp / prodmp, two for dmp and learned tau /
@@ -718,14 +789,14 @@ def test_vector_black_box_equals_individual_wrappers(mp_type, replan, workers):
 @pytest.mark.parametrize("controller", ["motor", "position", "velocity"])
 @pytest.mark.parametrize("D,B,T", [(2, 1, 200), (5, 300, 200), (5, 65, 37), (7, 130, 100), (16, 9, 12), (20, 7, 10)])
 @pytest.mark.parametrize("mode", ["tiles", "quad", "generic"])
-def test_reacher_rollout_matches_oracle(controller, D, B, T, mode, monkeypatch):
+def test_reacher_rollout_matches_oracle(controller, D, B, T, mode, monkeypatch, mpk_option):
     """actions and plant state bit for bit (float64, no FMA); rewards to 1e-12 (device vs host libm cos / sin).  Kernels:
     tile-streaming with the per-tile parallel reward phase (one or four groups per wave), and the generic
     lane-per-(episode, DoF) kernel with segmented scans"""
     from fancy_gym_amd import TrajectoryEngine
-    monkeypatch.setenv("MPK_PD_QUAD", "2" if mode == "quad" else "0")
+    mpk_option("pd_quad", "2" if mode == "quad" else "0")
     if mode == "generic":
-        monkeypatch.setenv("MPK_PD_SIMPLE", "1")
+        mpk_option("pd_simple", "1")
     eng = TrajectoryEngine(device=0, mp_type="promp", phase_type="linear", basis_type="rbf", num_dof=D, num_basis=3,
                            dt=0.01, duration=T * 0.01, tau=T * 0.01)
     rng = np.random.default_rng(D * 1000 + B)
@@ -957,6 +1028,41 @@ def test_bench_prints_the_contract_line_last():
     assert "allgather" in d            # the forced one-rank RCCL path ran the collective section
 
 
+@pytest.mark.gpu
+def test_bench_gpus_2_starts_two_ranks_itself_and_gathers_both_shards():
+    """
+    `python bench.py --gpus 2` with no WORLD_SIZE: the parent spawns the two ranks (torch.distributed.run child, before it
+    touches the GPU).  On a 1-GPU box the ranks share the device, which RCCL refuses ("duplicate GPU"), so the rehearsal
+    uses gloo (MPK_BENCH_BACKEND); the driver's runs use one rank per GPU and RCCL.  Checks: n_gpus == 2, global batch
+    2 B, the all-gather leg ran, every gathered slice equals its rank's shard, and the shards ARE what a single-rank
+    engine produces for the per-rank seeds 1000 + r.
+    """
+    import bench
+    from fancy_gym_amd import RolloutSpec, TrajectoryEngine
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MPK_BENCH_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    B = 512
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3",
+                        "--batch", str(B), "--no-cpu"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 * B and d["config"]["batch_per_gpu"] == B
+    assert d["scaling"] == "weak" and d["steps"] == 20 and d["warmup"] == 3
+    ag = d["allgather"]
+    assert ag["gathered_equals_shards"] is True and len(ag["shard_checksums"]) == 2
+    assert ag["bytes_gathered_per_gpu_per_step"] == B * 2 * 100 * 7 * 4
+    eng = TrajectoryEngine("prodmp", "exp", "prodmp", device=0, **bench.CFG)
+    spec = RolloutSpec("motor", 7, bench.P_GAINS, bench.D_GAINS, -1.0, 1.0, plant="static")
+    for rank in range(2):
+        params, ip, iv = bench.synth_inputs(B, 1000 + rank)
+        pos, vel, _ = eng.trajectory_actions(params, ip, iv, spec, ip.double(), iv.double())
+        torch.cuda.synchronize()
+        shard = torch.stack([pos, vel])
+        assert int(shard.view(torch.int32).to(torch.int64).sum().item()) == ag["shard_checksums"][rank], rank
+
+
 def test_native_rccl_all_gather_single_rank(monkeypatch):
     """mpk_comm_* / mpk_allgather (RCCL bound lazily inside libmpk.so): one rank, out of place and in place"""
     from fancy_gym_amd.distributed import NativeComm
@@ -995,12 +1101,12 @@ def _reference_loop(cur, plan, done, every, mpt, horizon, T):
 @pytest.mark.parametrize("cfg", [CFG4, CFG5, CFG3], ids=["prodmp_replan", "promp", "dmp"])
 @pytest.mark.parametrize("B", [1, 9, 200, 2100])
 @pytest.mark.parametrize("bulk,quad", [("0", "2"), ("0", "3"), ("0", "4"), ("0", "0"), ("2", "0")])
-def test_replan_step_equals_the_separate_kernels(cfg, B, bulk, quad, monkeypatch):
+def test_replan_step_equals_the_separate_kernels(cfg, B, bulk, quad, monkeypatch, mpk_option):
     """mpk_replan_step (integer state + plan + rollout + condition gather; ONE launch for shared-phase promp / prodmp,
     the separate kernels for dmp) == mpk_replan_advance -> mpk_trajectory_rollout -> mpk_condition_gather, bit for bit,
     from random per-episode integer states (finished episodes, different step counters, exhausted planning budgets)"""
-    monkeypatch.setenv("MPK_BULK", bulk)
-    monkeypatch.setenv("MPK_QUAD", quad)
+    mpk_option("bulk", bulk)
+    mpk_option("quad", quad)
     pc, bc, tc, dt, dur = cfg
     eng = make_engine(pc, bc, tc, dt, dur)
     T = eng.num_steps

@@ -67,20 +67,20 @@ N_CASES = int(os.environ.get("MPK_FUZZ_CASES", "120"))
 
 
 @pytest.mark.parametrize("seed", range(N_CASES))
-def test_random_configuration_matches_oracle(seed, monkeypatch):
+def test_random_configuration_matches_oracle(seed, monkeypatch, mpk_option):
     rng = np.random.default_rng(10_000 + seed)
     pc, bc, tc, dt, dur, B, init_time = random_case(rng)
-    monkeypatch.setenv("MPK_MAPPING", str(rng.choice(["0", "1", "2"])))
-    monkeypatch.setenv("MPK_BULK", str(rng.choice(["0", "2"])))
-    monkeypatch.setenv("MPK_QUAD", str(rng.choice(["0", "1", "2", "3", "4"])))
-    monkeypatch.setenv("MPK_PD_QUAD", str(rng.choice(["0", "1", "2"])))
-    monkeypatch.setenv("MPK_PHASE_CHUNK", str(rng.choice(["1", "2", "4"])))
-    monkeypatch.setenv("MPK_PHASE_TABLE", str(rng.choice(["0", "1"])))
+    mpk_option("mapping", str(rng.choice(["0", "1", "2"])))
+    mpk_option("bulk", str(rng.choice(["0", "2"])))
+    mpk_option("quad", str(rng.choice(["0", "1", "2", "3", "4"])))
+    mpk_option("pd_quad", str(rng.choice(["0", "1", "2"])))
+    mpk_option("phase_chunk", str(rng.choice(["1", "2", "4"])))
+    mpk_option("phase_table", str(rng.choice(["0", "1"])))
     wt = str(rng.choice(["", "0", "1"]))                 # store cache policy: automatic / plain / write-through
     if wt:
-        monkeypatch.setenv("MPK_WRITE_THROUGH", wt)
+        mpk_option("write_through", wt)
     else:
-        monkeypatch.delenv("MPK_WRITE_THROUGH", raising=False)
+        mpk_option("write_through", -1)
     if tc.trajectory_generator_type == "prodmp":
         # keep the plan inside the pre-computed range (6 tau): reference raises otherwise
         tau_min = pc.tau_bound[0] if pc.learn_tau else pc.tau

@@ -45,7 +45,9 @@ def make_engine(pc, bc, tc, dt, duration, **kw):
         basis_alpha=bc.alpha, basis_dt=bc.dt, pre_compute_length_factor=bc.pre_compute_length_factor,
         weights_scale=tc.weights_scale, goal_scale=tc.goal_scale, dmp_alpha=tc.alpha,
         auto_scale_basis=tc.auto_scale_basis, relative_goal=tc.relative_goal, disable_goal=tc.disable_goal,
-        disable_weights=tc.disable_weights, **kw)
+        disable_weights=tc.disable_weights, relative_goal_mode=tc.relative_goal_mode,
+        goal_offset_mode=tc.goal_offset_mode, goal_offset=tc.goal_offset, dmp_first_sample=tc.dmp_first_sample,
+        single_rbf_mode=bc.single_rbf_mode, **kw)
 
 
 def inputs(pc, bc, tc, B, seed=0):

@@ -41,12 +41,12 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"libmpk.so does not export {name}"
     assert declared == set(_lib.SIGNATURES), "ctypes signature table and include/mpk.h disagree"
-    assert _lib.load().mpk_abi_version() == 1
+    assert _lib.load().mpk_abi_version() == _lib.MPK_ABI_VERSION == 2
 
 
 def test_config_struct_layout_matches_header():
-    # 18 int32 + 15 doubles, no padding surprises
-    assert C.sizeof(_lib.mpk_config) == 18 * 4 + 15 * 8
+    # 22 int32 + 16 doubles, no padding surprises
+    assert C.sizeof(_lib.mpk_config) == 22 * 4 + 16 * 8
 
 
 def test_header_is_plain_c_and_ctypes_structs_match_it(tmp_path):
@@ -79,7 +79,7 @@ def test_header_is_plain_c_and_ctypes_structs_match_it(tmp_path):
 
 def _cfg(mp="prodmp", phase="exp", basis="prodmp", D=7, nb=5, **kw):
     c = _lib.mpk_config()
-    c.abi_version = 1
+    c.abi_version = _lib.MPK_ABI_VERSION
     c.mp_type, c.phase_type, c.basis_type = _lib.MP_TYPES[mp], _lib.PHASE_TYPES[phase], _lib.BASIS_TYPES[basis]
     c.num_dof, c.num_basis = D, nb
     c.tau, c.alpha_phase, c.basis_bandwidth_factor, c.basis_alpha, c.basis_dt = 1.5, 3.0, 2.0, 10.0, 0.01
@@ -410,9 +410,19 @@ def test_simple_reacher_env_semantics():
     from fancy_gym_amd.envs.classic_control.simple_reacher import SimpleReacherEnv, SimpleReacherMPWrapper, end_effector
     env = SimpleReacherEnv(n_links=3, target=[1.0, 1.0], random_start=False)
     obs, _ = env.reset(seed=0)
-    assert np.allclose(env.current_pos, [np.pi / 2, 0, 0]) and np.all(env.current_vel == 0)
-    assert np.allclose(end_effector(env.q), [0.0, 3.0], atol=1e-12)        # straight up
+    # a fixed start is _start_pos: zeros in SimpleReacherEnv (simple_reacher.py:29) -- the arm lies along +x
+    assert np.all(env.current_pos == 0) and np.all(env.current_vel == 0)
+    assert np.allclose(end_effector(env.q), [3.0, 0.0], atol=1e-12)
     assert obs.dtype == np.float32 and obs.shape == (12,) and obs[-1] == 0
+    # ... until a random-start reset of the same instance replaces it (base_reacher.py:80-86)
+    env.reset(seed=3, options={"random_start": True})
+    drawn = env.current_pos.copy()
+    assert np.pi / 4 <= drawn[0] <= 3 * np.pi / 4 and np.all(drawn[1:] == 0)
+    env.step(np.ones(3))
+    env.reset()
+    assert np.array_equal(env.current_pos, drawn) and np.all(env.current_vel == 0)
+    env = SimpleReacherEnv(n_links=3, target=[1.0, 1.0], random_start=False)
+    env.reset(seed=0)
     a = np.array([1.0, -2.0, 0.5])
     for k in range(201):
         obs, r, term, trunc, info = env.step(a)
@@ -424,7 +434,7 @@ def test_simple_reacher_env_semantics():
     # semi-implicit Euler: velocity first, then position with the NEW velocity
     env.reset()
     env.step(np.array([1.0, 0.0, 0.0]))
-    assert env.qd[0] == 0.01 and env.q[0] == np.pi / 2 + 0.01 * 0.01
+    assert env.qd[0] == 0.01 and env.q[0] == 0.01 * 0.01
     # seeded reset: same start and goal; goals fall inside the reachable disc
     e1, e2 = SimpleReacherEnv(5), SimpleReacherEnv(5)
     e1.reset(seed=7); e2.reset(seed=7)
@@ -463,3 +473,62 @@ def test_oracle_reacher_rollout_equals_stepping_the_host_env(D, controller):
             assert np.array_equal(act[b, t], a) and rew[b, t] == r, (b, t)
         assert np.all(act[b, n_steps[b]:] == 0) and np.all(rew[b, n_steps[b]:] == 0)
         assert np.array_equal(q[b], env.q) and np.array_equal(qd[b], env.qd)
+
+
+# ---- kernel-selection options (mpk_set_option) and the semantic switches of mpk_config --------------------------------
+def test_options_api_without_a_gpu():
+    """process-wide defaults need no handle: keys, ranges, MPK_OPT_AUTO; nothing in the launch path reads the environment"""
+    lib = _lib.load()
+    for key in _lib.OPTION_KEYS:
+        assert _lib.get_option(key) == _lib.MPK_OPT_AUTO
+    _lib.set_option("quad", 3)
+    assert _lib.get_option("quad") == 3
+    _lib.set_option("quad")
+    assert _lib.get_option("quad") == _lib.MPK_OPT_AUTO
+    with pytest.raises(ValueError, match="unknown option"):
+        _lib.set_option("no_such_knob", 1)
+    with pytest.raises(ValueError, match="out of range"):
+        _lib.set_option("mapping", 7)
+    assert lib.mpk_set_option(None, None, 0) == _lib.MPK_EINVAL
+    _lib.reset_options()
+    for src in ("mpk_kernels.hip", "mpk_host.cpp"):
+        text = open(os.path.join(ROOT, "fancy_gym_amd", "csrc", src)).read()
+        assert "getenv" not in text, f"{src} reads the environment"
+
+
+def test_semantic_switch_fields_are_validated():
+    lib = _lib.load()
+    assert lib.mpk_host_num_params(C.byref(_cfg())) == 42
+    for field in ("relative_goal_mode", "goal_offset_mode", "single_rbf_mode", "dmp_first_sample"):
+        assert lib.mpk_host_num_params(C.byref(_cfg(**{field: 1}))) == 42
+        assert lib.mpk_host_num_params(C.byref(_cfg(**{field: 2}))) == _lib.MPK_EINVAL
+        assert lib.mpk_host_num_params(C.byref(_cfg(**{field: -1}))) == _lib.MPK_EINVAL
+    assert lib.mpk_host_num_params(C.byref(_cfg(goal_offset_mode=1, goal_offset=float("nan")))) == _lib.MPK_EINVAL
+    one = _cfg(mp="promp", phase="linear", basis="rbf", nb=1, single_rbf_mode=1)
+    assert lib.mpk_host_num_params(C.byref(one)) == _lib.MPK_EINVAL and "single radial basis" in _lib.last_error()
+    assert lib.mpk_host_num_params(C.byref(_cfg(mp="promp", phase="linear", basis="rbf", nb=1))) == 7
+
+
+def test_oracle_switches_change_what_they_say_they_change():
+    from oracle import mp_oracle as O
+    import dataclasses
+    pc = O.PhaseCfg("exp", tau=0.4, alpha_phase=3.0)
+    bc = O.BasisCfg("prodmp", num_basis=5, basis_bandwidth_factor=3, alpha=10)
+    tc = O.TrajCfg("prodmp", action_dim=2, weights_scale=0.3, goal_scale=0.3, relative_goal=True)
+    rng = np.random.default_rng(0)
+    prm = rng.standard_normal((3, 12)); ip = rng.uniform(-1, 1, (3, 2)); iv = np.zeros((3, 2))
+    run = lambda t: O.get_trajectory(pc, bc, t, prm, 2.0, 0.02, 0.0, ip, iv, dtype=np.float64)[0]   # noqa: E731
+    after, before = run(tc), run(dataclasses.replace(tc, relative_goal_mode="before_scale"))
+    # 5 tau: the trajectory has reached its goal -- s_g*g + y_b vs s_g*(g + y_b)
+    np.testing.assert_allclose(after[:, -1] - before[:, -1], (1 - 0.3) * ip, rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(after[:, -1], 0.3 * prm.reshape(3, 2, 6)[..., 5] + ip, rtol=1e-3, atol=1e-4)
+    off = run(dataclasses.replace(tc, goal_offset_mode="add", goal_offset=1.0))
+    np.testing.assert_allclose(off[:, -1] - after[:, -1], 1.0, rtol=1e-3, atol=1e-4)
+    assert np.array_equal(run(dataclasses.replace(tc, goal_offset=1.0)), after)            # default: ignored
+    # with goal_scale * auto-scale == 1 (the reference's TableTennis configuration) the two orderings coincide
+    tt = O.TrajCfg("prodmp", action_dim=2, weights_scale=0.7, auto_scale_basis=True, relative_goal=True, disable_goal=True)
+    p8 = rng.standard_normal((3, 10))
+    a = O.get_trajectory(pc, bc, tt, p8, 2.0, 0.02, 0.0, ip, iv, dtype=np.float64)[0]
+    b = O.get_trajectory(pc, bc, dataclasses.replace(tt, relative_goal_mode="before_scale"), p8, 2.0, 0.02, 0.0, ip, iv,
+                         dtype=np.float64)[0]
+    np.testing.assert_allclose(a, b, atol=2e-6)

@@ -236,3 +236,16 @@ def test_planning_counts(max_planning_times, every):
     for k, (start, n) in enumerate(segs):
         assert start == k * every
         assert n == (every if k < max_planning_times - 1 else horizon - start)
+
+
+# ---- the same differential-equation checks the GPU suite applies to the HIP path (tests/test_gpu_ode.py), here on the
+# oracle: cfg2, cfg4's four replanning boundary conditions (auto_scale_basis, disable_goal), the TableTennis ProDMP
+# configuration with learned tau / delay (relative_goal), DMP Euler convergence ----------------------------------------
+def test_oracle_solves_the_ode_for_every_baseline_prodmp_and_dmp_configuration():
+    from tests import test_gpu_ode as G
+    from tests.oracle_engine import OracleEngine
+    G.check_cfg2(0.0, factory=OracleEngine)
+    G.check_cfg2(0.5, factory=OracleEngine)
+    G.check_cfg4(factory=OracleEngine)
+    G.check_tabletennis_prodmp(factory=OracleEngine)
+    G.check_cfg3_dmp(factory=OracleEngine)

@@ -240,6 +240,9 @@ static Tuning effective_tuning(const Handle* h) {
     if (o.phase_table >= 0) t.phase_table = o.phase_table;
     if (o.phase_chunk >= 0) t.phase_chunk = o.phase_chunk;
     if (o.pd_simple >= 0) t.pd_simple = o.pd_simple;
+    if (o.split >= 0) t.split = o.split;
+    if (o.lds_pad >= 0) t.lds_pad = o.lds_pad;
+    if (o.pipe >= 0) t.pipe = o.pipe;
     return t;
 }
 
@@ -626,6 +629,8 @@ const OptKey kOptKeys[] = {
     {"write_through", &Tuning::write_through, 0, 1}, {"ipw", &Tuning::ipw, 0, 1 << 20},
     {"phase", &Tuning::phase, 0, 1},             {"phase_table", &Tuning::phase_table, 0, 1},
     {"phase_chunk", &Tuning::phase_chunk, 0, 4}, {"pd_simple", &Tuning::pd_simple, 0, 1},
+    {"split", &Tuning::split, 0, 1},             {"lds_pad", &Tuning::lds_pad, 0, 48},
+    {"pipe", &Tuning::pipe, 0, 1},
 };
 const OptKey* find_opt(const char* key) {
     if (!key) return nullptr;

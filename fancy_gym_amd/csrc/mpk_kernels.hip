@@ -24,6 +24,25 @@ namespace mpk {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Development build only (-DMPK_TRACE): wave 0 of workgroup `MPK_TRACE_BLOCK` stamps the shader clock at labelled points
+// of a kernel into a device array that tools/dev/trace_kernel.py prints -- the per-phase timeline of ONE wave.
+#ifdef MPK_TRACE
+#ifndef MPK_TRACE_BLOCK
+#define MPK_TRACE_BLOCK 0
+#endif
+__device__ long long g_trace[512];
+__device__ int g_trace_n;
+#define MPK_STAMP(tag)                                                                              \
+    do {                                                                                            \
+        if (blockIdx.x == MPK_TRACE_BLOCK && threadIdx.x == 0) {                                    \
+            const int i_ = g_trace_n;                                                               \
+            if (i_ < 255) { g_trace[2 * i_] = (tag); g_trace[2 * i_ + 1] = (long long)__builtin_readcyclecounter(); g_trace_n = i_ + 1; } \
+        }                                                                                           \
+    } while (0)
+#else
+#define MPK_STAMP(tag) do { } while (0)
+#endif
+
 #define MPK_LAUNCH_CHECK()                                                          \
     do {                                                                            \
         hipError_t e_ = hipGetLastError();                                          \
@@ -39,7 +58,9 @@ size_t shared_tables_floats(const DevCfg& c, int* TS, int* n_out) {
     const int no = c.mp_type == MPK_MP_PRODMP ? 2 : (c.mp_type == MPK_MP_PROMP ? 3 : 1);
     *TS = ts;
     *n_out = no;
-    return (size_t)no * c.KP * ts;
+    // the k-major table A [n_out][KP][TS] (MFMA fragment loads) followed by its step-major copy At [TS][n_out * KP]
+    // (one contiguous row per time step: the serial role of k_traj_split reads it with scalar loads)
+    return 2 * (size_t)no * c.KP * ts;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -127,6 +148,8 @@ __device__ __forceinline__ int prodmp_index(float s, float scaled_dt) {
     // times_to_indices: round-half-even of the fp32 quotient -- the bit-exact integer part of the path
     return (int)rintf(s / scaled_dt);
 }
+
+__device__ __forceinline__ int wave_of(unsigned tid) { return __builtin_amdgcn_readfirstlane((int)(tid >> 6)); }
 
 struct ProdmpBC {
     int idxb;
@@ -393,8 +416,19 @@ __global__ void __launch_bounds__(256) k_build_shared(const DevCfg c, const floa
             }
         }
     }
+    // step-major copy behind the k-major table: one contiguous row per step; with two outputs (prodmp) the row is
+    // interleaved [pos_0 vel_0 pos_1 vel_1 ..] -- the operand pairs of the packed fp32 FMA the serial role contracts with
+    __syncthreads();
+    const int RS = n_out * KP;
+    float* At = A + (size_t)RS * TS;
+    for (int i = tid; i < RS * TS; i += 256) {
+        const int t = i / RS, e = i - t * RS;
+        const int jk = n_out == 2 ? (e & 1) * KP + (e >> 1) : e;
+        At[i] = A[(size_t)jk * TS + t];
+    }
 }
 
+#ifndef MPK_DEVICE_ONLY
 int launch_build_shared(const DevCfg& c, float init_time, const SharedTables& st, int32_t* idx_out,
                         int32_t* range_flag, void* stream) {
     if (c.mp_type == MPK_MP_PROMP && c.T < 2) {
@@ -406,6 +440,7 @@ int launch_build_shared(const DevCfg& c, float init_time, const SharedTables& st
     MPK_LAUNCH_CHECK();
     return MPK_OK;
 }
+#endif  // MPK_DEVICE_ONLY
 
 // ------------------------------------------------------------------------------------------------------------
 // The [T x K] . [K x D] contraction on the matrix cores (v_mfma_f32_16x16x4_f32) + fused epilogues.
@@ -454,6 +489,7 @@ struct TrajArgs {
     // of a few thousand episodes: closed-loop step at B = 4096 22.7 -> 18.7 us); plain stores once they stream to HBM
     // (write-through costs 25 % there).  The tile-major kernel has the policy as a template parameter.
     int wt;
+    unsigned ser_blocks;   // k_traj_split: workgroups [0, ser_blocks) run the serial role
     // closed-loop rollout fused into the episode-major kernel (CT >= 3)
     double* q_state;       // [B, D] plant position, in/out
     double* qd_state;      // [B, D] plant velocity, in/out
@@ -617,6 +653,94 @@ __device__ __forceinline__ Gains kernarg_gains(int d) {
     return gn;
 }
 
+// The step loop of black_box_wrapper.py:175-203 on the reference's torque double integrator (base_reacher_torque.py:25-26)
+// for the 16 steps of one row tile of ONE (episode, DoF) lane: float64, no FMA contraction -- numpy's promotion in
+// pd_controller.py:21-29.  The desired states of the tile are pulled into registers first, then the chain runs as
+// straight-line code WITHOUT control flow: a step past the executed ones (t >= nst) is computed and discarded by selects
+// (its action is written as 0).  Measured on one wave (tools/dev/trace_kernel.py, tools/dev/rec_latency.hip,
+// profiles/r02_closed_loop.md): with two exec-mask branches per step (t == tcond, t < nst) a step cost 260 cycles; this
+// form costs 83 in isolation (57 for the bare chain of 11 float64 operations, the rest conversions and the LDS write).
+// Feeding the chain float64 values from LDS (conversions done by all 64 lanes beforehand) measured the same 83 in
+// isolation and SLOWER in the kernel (an extra LDS pass and barrier per tile: 18.3 vs 14.4 us), so it stays as it is.
+// MASKED = false is the version for a tile every step of which is executed by every lane of the wave (the caller tests
+// that wave-uniformly).  sP / sV / sA: the lane's (row 0, column) slots of the desired pos / vel / action images,
+// `stride` floats per row.
+template <int CTRL, bool MASKED>
+__device__ __forceinline__ void pd_tile_steps(const float* __restrict__ sP, const float* __restrict__ sV,
+                                              float* __restrict__ sA, const int stride, const int t0, const int nst,
+                                              const double pgd, const double dgd, const double lod, const double hid,
+                                              const double dtp, double& qs, double& qds) {
+    float pr[16], vr[16];
+#pragma unroll
+    for (int tl = 0; tl < 16; ++tl) { pr[tl] = sP[tl * stride]; vr[tl] = sV[tl * stride]; }
+#pragma unroll
+    for (int tl = 0; tl < 16; ++tl) {
+        const double dp = (double)pr[tl], dv = (double)vr[tl];
+        double u;
+        if (CTRL == MPK_CTRL_MOTOR) u = pgd * (dp - qs) + dgd * (dv - qds);
+        else if (CTRL == MPK_CTRL_POSITION) u = dp;
+        else u = dv;
+        u = fmin(fmax(u, lod), hid);
+        const double qds_n = qds + dtp * u;
+        const double qs_n = qs + dtp * qds_n;
+        if (MASKED) {
+            const bool live = t0 + tl < nst;
+            qds = live ? qds_n : qds;
+            qs = live ? qs_n : qs;
+            sA[tl * stride] = live ? (float)u : 0.0f;
+        } else {
+            qds = qds_n; qs = qs_n;
+            sA[tl * stride] = (float)u;
+        }
+    }
+}
+
+// clip(u, lo, hi) of the step loop as the two instructions it is: fmin / fmax make the compiler re-quiet a loop-invariant
+// bound before every use (a v_max_f64 x, x per bound and step -- two of the ~14 float64 operations of a step).  lo / hi
+// are finite controller bounds or +-inf, never NaN; u is quieted by the instructions themselves (IEEE mode).
+__device__ __forceinline__ double clip_f64(double u, double lo, double hi) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(u), "v"(lo));
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(r), "v"(hi));
+    return r;
+}
+
+// all lanes of the wave: does every serial lane execute every step of the tile [t0, t0 + 16)?  (wave-uniform)
+__device__ __forceinline__ bool tile_fully_executed(bool serial, int nst, int t0) {
+    return __all(!serial || nst >= t0 + 16) != 0;
+}
+
+// DMP's explicit Euler recurrence for the 16 steps of one row tile of one (episode, DoF) lane, fp32, one
+// rounding per op, branch-free like pd_tile_steps: a step at or past T - 1 leaves the state alone by select.
+__device__ __forceinline__ void dmp_tile_steps(const float* __restrict__ sF, float* __restrict__ sP, float* __restrict__ sV,
+                                               const float* __restrict__ ds16, const int stride, const int t0,
+                                               const int T, const float alpha, const float beta, const float eg,
+                                               const TauDiv& td, float& ey, float& ez) {
+    float fr[16], dsr[16];
+#pragma unroll
+    for (int tl = 0; tl < 16; ++tl) fr[tl] = sF[tl * stride];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 x = reinterpret_cast<const float4*>(ds16)[j];
+        dsr[4 * j] = x.x; dsr[4 * j + 1] = x.y; dsr[4 * j + 2] = x.z; dsr[4 * j + 3] = x.w;
+    }
+#pragma unroll
+    for (int tl = 0; tl < 16; ++tl) {
+        sP[tl * stride] = ey;
+        sV[tl * stride] = div_tau(ez, td);               // vel = z / tau, off the dependent chain
+        const float t1 = eg - ey;
+        const float t2 = beta * t1;
+        const float t3 = t2 - ez;
+        const float t4 = alpha * t3;
+        const float acc = t4 + fr[tl];
+        const float ez_n = ez + dsr[tl] * acc;
+        const float ey_n = ey + dsr[tl] * ez_n;
+        const bool live = t0 + tl < T - 1;
+        ez = live ? ez_n : ez;
+        ey = live ? ey_n : ey;
+    }
+}
+
 // epilogue of one C tile into the wave-private LDS transpose buffer (rows beyond T land in rows never stored)
 template <int MP, int CT>
 __device__ __forceinline__ void tile_epilogue(const f32x4& acc0, const f32x4& acc1, const f32x4& acc2,
@@ -648,10 +772,11 @@ __device__ __forceinline__ void tile_epilogue(const f32x4& acc0, const f32x4& ac
 
 // generic (slow) tile store: partial last row tile whose length is not a multiple of 4, or unaligned outputs.
 // Takes plain values (a reference to the kernarg struct would force the whole struct into scratch).
-__device__ __noinline__ void store_tile_generic(float* pos, float* vel, float* actions, int nst, int B, int T, int D,
+__device__ __noinline__ void store_tile_generic(float* pos, float* vel, float* actions, int mask, int B, int T, int D,
                                                 int NTW, const float* sSt, int lane, int b0, int rt, int rows) {
     const int SEG = 16 * D, len = rows * D;      // generic path: never shifted, pitch == SEG
-    for (int j = 0; j < nst; ++j) {
+    for (int j = 0; j < 3; ++j) {
+        if (!((mask >> j) & 1)) continue;
         float* outp = j == 0 ? pos : (j == 1 ? vel : actions);
         for (int sb = 0; sb < NTW; ++sb) {
             const int bb = b0 + sb;
@@ -697,23 +822,25 @@ __device__ __forceinline__ void store4(float* p, float v) {
     else *p = v;
 }
 
-template <int NST, int KM, bool WT>
-__device__ __forceinline__ void tile_store(const TrajArgs& a, const LaneMap<KM>& L, const float* sSt, int lane,
-                                           int b0, int rt, int rows) {
+// MASK: which output arrays of the staging image leave (bit 0 pos, bit 1 vel, bit 2 actions)
+template <int MASK, int KM, bool WT>
+__device__ __forceinline__ void tile_store_sel(const TrajArgs& a, const LaneMap<KM>& L, const float* sSt, int lane,
+                                               int b0, int rt, int rows) {
+    constexpr bool SP = (MASK & 1) != 0, SV = (MASK & 2) != 0, SA = (MASK & 4) != 0;
     const int D = a.c.D, T = a.c.T, len = rows * D;
     if (a.vec_ok) {
         const int bb = b0 + L.sseg;
         const int lo = (int)ep_shift(a, bb), hi = lo + len, c0 = L.w4;   // valid elements of the padded segment
         if (L.sseg < L.NTW && bb < a.B && c0 < hi && c0 + 4 > lo) {
             const size_t go = ((size_t)bb * T + rt * 16) * D - lo + c0;    // 16-byte aligned by construction
-            const f32x4 d0 = *reinterpret_cast<const f32x4*>(sSt + L.rofs);
-            const f32x4 d1 = *reinterpret_cast<const f32x4*>(sSt + kStageStride + L.rofs);
-            f32x4 d2 = d0;
-            if (NST > 2) d2 = *reinterpret_cast<const f32x4*>(sSt + 2 * kStageStride + L.rofs);
+            f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0, d2 = d0;
+            if (SP) d0 = *reinterpret_cast<const f32x4*>(sSt + L.rofs);
+            if (SV) d1 = *reinterpret_cast<const f32x4*>(sSt + kStageStride + L.rofs);
+            if (SA) d2 = *reinterpret_cast<const f32x4*>(sSt + 2 * kStageStride + L.rofs);
             if (c0 >= lo && c0 + 4 <= hi) {
-                store16<WT>(a.pos + go, d0);
-                store16<WT>(a.vel + go, d1);
-                if (NST > 2) store16<WT>(a.actions + go, d2);
+                if (SP) store16<WT>(a.pos + go, d0);
+                if (SV) store16<WT>(a.vel + go, d1);
+                if (SA) store16<WT>(a.actions + go, d2);
             } else if (a.td3 == 2) {
                 // T*D = 2 mod 4 (e.g. 350 x 7): segment starts and lengths are even, so a partial chunk is exactly its
                 // upper half (the chunk straddles the segment start) or its lower half (the end): ONE 8-byte store per
@@ -722,9 +849,9 @@ __device__ __forceinline__ void tile_store(const TrajArgs& a, const LaneMap<KM>&
                 const int o = head ? 2 : 0;
                 const f32x2 p2 = {head ? d0[2] : d0[0], head ? d0[3] : d0[1]};
                 const f32x2 v2 = {head ? d1[2] : d1[0], head ? d1[3] : d1[1]};
-                store8<WT>(a.pos + go + o, p2);
-                store8<WT>(a.vel + go + o, v2);
-                if (NST > 2) {
+                if (SP) store8<WT>(a.pos + go + o, p2);
+                if (SV) store8<WT>(a.vel + go + o, v2);
+                if (SA) {
                     const f32x2 a2 = {head ? d2[2] : d2[0], head ? d2[3] : d2[1]};
                     store8<WT>(a.actions + go + o, a2);
                 }
@@ -732,16 +859,22 @@ __device__ __forceinline__ void tile_store(const TrajArgs& a, const LaneMap<KM>&
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (c0 + e >= lo && c0 + e < hi) {
-                        store4<WT>(a.pos + go + e, d0[e]);
-                        store4<WT>(a.vel + go + e, d1[e]);
-                        if (NST > 2) store4<WT>(a.actions + go + e, d2[e]);
+                        if (SP) store4<WT>(a.pos + go + e, d0[e]);
+                        if (SV) store4<WT>(a.vel + go + e, d1[e]);
+                        if (SA) store4<WT>(a.actions + go + e, d2[e]);
                     }
                 }
             }
         }
     } else {
-        store_tile_generic(a.pos, a.vel, a.actions, NST, a.B, T, D, L.NTW, sSt, lane, b0, rt, rows);
+        store_tile_generic(a.pos, a.vel, a.actions, MASK, a.B, T, D, L.NTW, sSt, lane, b0, rt, rows);
     }
+}
+
+template <int NST, int KM, bool WT>
+__device__ __forceinline__ void tile_store(const TrajArgs& a, const LaneMap<KM>& L, const float* sSt, int lane,
+                                           int b0, int rt, int rows) {
+    tile_store_sel<(NST > 2 ? 7 : 3), KM, WT>(a, L, sSt, lane, b0, rt, rows);
 }
 
 // Every kernel-argument field the tile-major prologue needs, demanded in scalar registers at the top of the kernel:
@@ -757,12 +890,12 @@ __device__ __forceinline__ void demand_args(const TrajArgs& a, unsigned grid_x) 
 }
 
 // ---- tile-major ------------------------------------------------------------------------------------------------
+// the tile-major body for workgroup `bid` of `nblk` (k_traj_tiles: the whole grid; k_traj_split: the workgroups after the
+// serial-role ones)
 template <int MP, int CT, int KM, bool WT>
-__global__ void __launch_bounds__(256, (KM <= 2 ? 7 : 1)) k_traj_tiles(const TrajArgs a, const ActArgs act) {
-    __shared__ __attribute__((aligned(16))) float smem[4 * kStageFloats];
-    demand_args(a, gridDim.x);
+__device__ __forceinline__ void tiles_body(const TrajArgs& a, float* smem, const unsigned bid, const unsigned nblk) {
     static_assert(MP != MPK_MP_DMP, "dmp runs in k_traj_stream");
-    static_assert(CT < 3, "closed-loop rollouts run in k_traj_stream");
+    static_assert(CT < 3, "closed-loop rollouts run in k_traj_stream / k_traj_split");
     constexpr bool ACT = CT >= 0;
     constexpr int NOUT = MP == MPK_MP_PRODMP ? 2 : 3;
     constexpr int NST = 2 + (ACT ? 1 : 0);
@@ -777,8 +910,8 @@ __global__ void __launch_bounds__(256, (KM <= 2 ? 7 : 1)) k_traj_tiles(const Tra
     // number (exact for wid < 2^32 / NRT, which the launcher guarantees): the generic division is ~25 instructions
     // XCD-contiguous virtual block id (workgroup b runs on XCD b % 8): the row tiles of an episode group -- which read
     // the same parameters and write one contiguous trajectory -- stay behind one L2
-    const int nb8 = (int)(gridDim.x >> 3);
-    const int vb = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * nb8 + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int nb8 = (int)(nblk >> 3);
+    const int vb = (nblk & 7) == 0 ? (int)(bid & 7) * nb8 + (int)(bid >> 3) : (int)bid;
     const int wid = vb * 4 + wave;
     const int gstride = a.gstride;
     int g = a.nrt_magic ? (int)__umulhi((unsigned)wid, a.nrt_magic) : wid;      // magic 0: NRT == 1
@@ -827,6 +960,250 @@ __global__ void __launch_bounds__(256, (KM <= 2 ? 7 : 1)) k_traj_tiles(const Tra
         cp = nxt.cp; cv = nxt.cv;
         g = gn;
     }
+}
+
+#ifndef MPK_TILES_OCC
+#define MPK_TILES_OCC 7      // waves per SIMD the tile-major kernel is compiled for (A/B build knob)
+#endif
+template <int MP, int CT, int KM, bool WT>
+__global__ void __launch_bounds__(256, (KM <= 2 ? MPK_TILES_OCC : 1)) k_traj_tiles(const TrajArgs a, const ActArgs act) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * kStageFloats];
+    demand_args(a, gridDim.x);
+    tiles_body<MP, CT, KM, WT>(a, smem, blockIdx.x, gridDim.x);
+}
+
+// ---- tile-major with a serial role: the fused closed-loop step for cache-resident batches ------------------------------
+// BlackBoxWrapper.step on a GPU-resident plant (black_box_wrapper.py:150-217) is serial in t only through the plant
+// state: (pos, vel) of every row tile are independent of it, the ACTIONS of the executed steps are not.  So the launch
+// has two roles, by workgroup:
+//   tiles role   (workgroups >= a.ser_blocks)  exactly k_traj_tiles without a controller: one row tile per wave, pos and
+//                vel leave as soon as their tile is contracted -- the parallelism (7 waves per SIMD) that the
+//                episode-major closed-loop kernels lack at a few thousand episodes (two waves per SIMD, every LDS / MFMA /
+//                barrier latency of 7 sequential row tiles exposed: 19 us at B = 4096, 17-22 us at 8192);
+//   serial role  (workgroups <  a.ser_blocks, dispatched first)  a wave owns an episode group: advances the integer
+//                replanning state, re-contracts only the row tiles that hold executed steps (a plan that executes 25 of
+//                100 steps: 2 of 7), runs the controller + plant recurrence on them (float64, no FMA: the same operations
+//                as k_traj_stream, bit for bit), gathers the next boundary condition, and writes the ACTIONS of every tile
+//                (zeros past the executed steps) plus the plant state.  Nothing else touches actions or state, so the two
+//                roles never race; pos / vel come from the tiles role only.
+// The serial role is latency-bound and hides under the store-bound tiles role.
+// One lane per (episode, DoF): 64 / DP episodes per wave, every lane busy.  Per step the lane contracts ITS column with the
+// step's basis row -- an fp32 fmaf chain in ascending k, i.e. the accumulation order of the MFMA, so the desired state has
+// the bits the tiles role stores (the per-episode kernels rely on the same equality) -- and feeds it to the float64
+// controller + plant chain.  The basis rows come from the step-major table copy through scalar loads (the row of a step is
+// wave-uniform); nothing but the actions passes through LDS.
+template <int MP, int CT, int KM, bool WT>
+__device__ __forceinline__ void serial_body(const TrajArgs& a, const float* __restrict__ At,
+                                            const float* __restrict__ aux, float* smem) {
+    static_assert(CT >= 3, "closed loop only");
+    constexpr int KP = 4 * KM;
+    constexpr int NOUT = MP == MPK_MP_PRODMP ? 2 : 3;
+    constexpr int RS = NOUT * KP;
+    const DevCfg& c = a.c;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int D = c.D, T = c.T, B = a.B, P = c.P;
+    const int DP = 1 << a.sh, EPW = 64 >> a.sh;
+    const int e = lane >> a.sh, d = lane & (DP - 1);
+    const bool dvalid = d < D;
+    float* sAct = smem + wave * (kStageFloats + 16 * RS);   // [EPW][16 * D] action tile of the wave's episodes | rows
+    const int NRT = (T + 15) >> 4;
+    const int units = (B + EPW - 1) / EPW;
+    const int ustride = (int)a.ser_blocks * 4;
+    const Gains gn = kernarg_gains(dvalid ? d : 0);
+    const double pgd = gn.pg, dgd = gn.dg, lod = __builtin_canonicalize(gn.lo), hid = __builtin_canonicalize(gn.hi),
+                 dtp = a.plant_dt;
+    // store geometry: an episode's row tile is 16 * D contiguous floats = cps float4 chunks; chunk ids lane + 64 i
+    const int cps = a.cps;
+    MPK_STAMP(1);
+    MPK_STAMP(2);
+    for (int u = (int)blockIdx.x * 4 + wave; u < units; u += ustride) {
+        const int b = u * EPW + e;
+        const bool on = dvalid && b < B;
+        const int bs = on ? b : 0, ds = dvalid ? d : 0;
+        // every input of the unit is requested before the first one is used (plain loads, no control flow: a branch per
+        // column kind made this a chain of eight dependent cache misses -- 9 000 cycles on the trace)
+        float raw[KP];
+        const float* prm = a.params + (size_t)bs * P + c.off + ds * c.Kloc;
+        int kinds[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            int loc;
+            kinds[k] = x_kind<MP>(c, k, &loc);           // wave-uniform
+            raw[k] = prm[loc];
+        }
+        const float ipv = a.init_pos[(size_t)bs * D + ds];
+        const float ivv = MP == MPK_MP_PRODMP ? a.init_vel[(size_t)bs * D + ds] : 0.0f;
+        const size_t si0 = (size_t)bs * D + ds;
+        double qs = a.q_state[si0], qds = a.qd_state[si0];
+        int nst = 0;
+        if (on) {
+            nst = T;
+            if (a.rp.traj_steps) nst = replan_rule(a.rp, b, T, d == 0);
+            else if (a.n_steps) nst = min(a.n_steps[b], T);
+        }
+        float (&x)[KP] = raw;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const float v = kinds[k] == XK_PARAM ? raw[k] : (kinds[k] == XK_IPOS ? ipv : (kinds[k] == XK_IVEL ? ivv : (kinds[k] == XK_ONE ? 1.0f : 0.0f)));
+            x[k] = on ? v : 0.0f;
+        }
+        const int tcond = (on && a.rp.cond_pos) ? min(max(nst - 1, 0), T - 1) : -1;
+        int need = on ? max(nst, tcond + 1) : 0;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) need = max(need, __shfl_xor(need, m));
+        const int n_ser = __builtin_amdgcn_readfirstlane((need + 15) >> 4);      // row tiles that hold an executed step
+        float cpos = 0.0f, cvel = 0.0f;
+        // action stores: float4 chunk ids lane + 64 i -> (episode of the unit, offset in its 16 * D tile segment)
+        float* const ub = a.actions + (size_t)u * EPW * T * D;
+        unsigned sgo[4], slds[4], sw4[4];
+        bool sval[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ch = lane + 64 * i;
+            const int sg = (int)(((unsigned)ch * a.inv_cps) >> 16);
+            const int w4 = (ch - sg * cps) * 4;
+            sval[i] = sg < EPW && u * EPW + sg < B;
+            sw4[i] = (unsigned)w4;
+            sgo[i] = (unsigned)(sg * T * D + w4);
+            slds[i] = (unsigned)(sg * 16 * D + w4);
+        }
+        MPK_STAMP(3);
+        // lanes of a padding DoF (d >= D) park their action in the spare floats behind the image (there are >= 64 of them
+        // whenever D < DP): one address select per unit instead of an exec-mask branch per step
+        float* const slot = sAct + (dvalid ? e * (16 * D) + d : EPW * 16 * D);
+        const int sstep = dvalid ? D : 0;
+        // basis rows: the 16 step-major rows of a row tile are 16 * RS contiguous floats of At -- one coalesced float4 load
+        // per lane (two for promp), parked in the wave's LDS slice one tile ahead; a step reads its row with broadcast LDS
+        // reads, one step ahead.  (Scalar loads of the rows -- a wave-uniform address through the constant address space
+        // -- measured 380 cycles per step even with a warm scalar cache: profiles/r02_closed_loop.md.)
+        float* const sRow = sAct + kStageFloats;                       // [16][RS]
+        constexpr int NR4 = 16 * RS / 4;                               // float4 per row tile
+        f32x4 ra = {0.f, 0.f, 0.f, 0.f}, rb = ra;
+        auto fetch_rows = [&](int rt) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(At + (size_t)rt * 16 * RS);
+            if (lane < NR4) ra = src[lane];
+            if (NR4 > 64) { if (lane + 64 < NR4) rb = src[lane + 64]; }
+        };
+        auto park_rows = [&]() {
+            if (lane < NR4) reinterpret_cast<f32x4*>(sRow)[lane] = ra;
+            if (NR4 > 64) { if (lane + 64 < NR4) reinterpret_cast<f32x4*>(sRow)[lane + 64] = rb; }
+        };
+        if (n_ser > 0) fetch_rows(0);
+        for (int rt = 0; rt < NRT; ++rt) {
+            const int rows = min(16, T - rt * 16);
+            if (rt < n_ser) {
+                park_rows();
+                __builtin_amdgcn_wave_barrier();
+                if (rt + 1 < n_ser) fetch_rows(rt + 1);                // in flight under this tile's 16 steps
+                // a row of the tile from LDS (broadcast reads)
+                auto read_row = [&](int tl, float (&r)[RS]) {
+#pragma unroll
+                    for (int k4 = 0; k4 < RS / 4; ++k4) {
+                        const f32x4 q4 = reinterpret_cast<const f32x4*>(sRow + tl * RS)[k4];
+                        r[4 * k4] = q4[0]; r[4 * k4 + 1] = q4[1]; r[4 * k4 + 2] = q4[2]; r[4 * k4 + 3] = q4[3];
+                    }
+                };
+                // one step: the lane's column against the step's row (fp32 fmaf chains in ascending k = the MFMA's
+                // accumulation order), then the float64 controller + plant chain.  MASKED: steps past the executed ones and
+                // the gathered step are handled by selects; the unmasked form serves a tile every lane executes in full
+                auto one_step = [&](auto masked_tag, int tl, const float (&rc)[RS]) {
+                    constexpr bool MASKED = decltype(masked_tag)::value;
+                    const int t = rt * 16 + tl;
+                    float p = 0.0f, v = 0.0f;
+                    if (MP == MPK_MP_PRODMP) {
+                        // rows interleaved (pos_k, vel_k): both chains in packed FMAs; 1/tau is folded into the vel rows
+#pragma unroll
+                        for (int k = 0; k < KP; ++k) { p = fmaf(rc[2 * k], x[k], p); v = fmaf(rc[2 * k + 1], x[k], v); }
+                    } else {
+                        float ph = 0.0f, pl = 0.0f;
+#pragma unroll
+                        for (int k = 0; k < KP; ++k) {
+                            p = fmaf(rc[k], x[k], p);
+                            ph = fmaf(rc[KP + k], x[k], ph); pl = fmaf(rc[2 * KP + k], x[k], pl);
+                        }
+                        v = (ph - pl) * aux[t];                  // forward difference of fp32 positions x (1 / dt)
+                    }
+                    if (MASKED) {
+                        const bool at_cond = t == tcond;
+                        cpos = at_cond ? p : cpos; cvel = at_cond ? v : cvel;
+                    }
+                    const double dp = (double)p, dv = (double)v;
+                    double uu;
+                    if (CT - 3 == MPK_CTRL_MOTOR) uu = pgd * (dp - qs) + dgd * (dv - qds);
+                    else if (CT - 3 == MPK_CTRL_POSITION) uu = dp;
+                    else uu = dv;
+                    uu = clip_f64(uu, lod, hid);
+                    const double qds_n = qds + dtp * uu;
+                    const double qs_n = qs + dtp * qds_n;
+                    if (MASKED) {
+                        const bool live = t < nst;
+                        qds = live ? qds_n : qds;
+                        qs = live ? qs_n : qs;
+                        slot[tl * sstep] = live ? (float)uu : 0.0f;
+                    } else {
+                        qds = qds_n; qs = qs_n;
+                        slot[tl * sstep] = (float)uu;
+                    }
+                };
+                // two row buffers in turn (no copies): the row of step tl + 1 is requested before step tl is computed
+                auto tile_steps = [&](auto masked_tag) {
+                    float r0[RS], r1[RS];
+                    read_row(0, r0);
+#pragma unroll 1
+                    for (int tl = 0; tl < 16; tl += 2) {
+                        read_row(tl + 1, r1);
+                        one_step(masked_tag, tl, r0);
+                        read_row(tl + 2 < 16 ? tl + 2 : 15, r0);
+                        one_step(masked_tag, tl + 1, r1);
+                    }
+                };
+                // every lane executes every step of the tile and none gathers its boundary condition here? (wave-uniform)
+                const bool plain = __all(!on || (nst >= rt * 16 + 16 && (tcond < rt * 16 || tcond >= rt * 16 + 16))) != 0;
+                if (plain) tile_steps(std::false_type());
+                else tile_steps(std::true_type());
+                __builtin_amdgcn_wave_barrier();
+                MPK_STAMP(10 + rt);
+            }
+            // the wave's EPW action segments of this row tile: coalesced float4 stores (zeros past the executed tiles); the
+            // lane's chunk geometry was worked out once per unit
+            {
+                float* const tb = ub + (size_t)rt * 16 * D;
+                const int lim = rows * D;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (sval[i] && (int)sw4[i] < lim) {
+                        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+                        if (rt < n_ser) val = *reinterpret_cast<const f32x4*>(sAct + slds[i]);
+                        store16<WT>(tb + sgo[i], val);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            MPK_STAMP(30 + rt);
+        }
+        if (on) {
+            const size_t si = (size_t)b * D + d;
+            a.q_state[si] = qs; a.qd_state[si] = qds;
+            if (tcond >= 0) { a.rp.cond_pos[si] = cpos; a.rp.cond_vel[si] = cvel; }
+        }
+        MPK_STAMP(90);
+    }
+}
+
+#ifndef MPK_SPLIT_OCC
+// waves per SIMD the split kernel is compiled for.  The tile-major body does not need more: with dynamic-LDS padding
+// capping the workgroups per CU it runs 9.3 / 9.2 / 9.1 / 9.8 / 9.6 us at 8 / 7 / 6 / 5 / 4 waves per SIMD (B = 4096,
+// tools/occ_probe.py), and 128 registers let the serial role keep its rows, columns and float64 state without scratch.
+#define MPK_SPLIT_OCC 4
+#endif
+template <int MP, int CT, int KM, bool WT>
+__global__ void __launch_bounds__(256, (KM <= 2 ? MPK_SPLIT_OCC : 1)) k_traj_split(const TrajArgs a, const ActArgs act) {
+    constexpr int kWaveFloats = kStageFloats + 16 * (MP == MPK_MP_PRODMP ? 2 : 3) * 4 * KM;   // staging + one tile of rows
+    __shared__ __attribute__((aligned(16))) float smem[4 * kWaveFloats];
+    demand_args(a, gridDim.x);
+    if (blockIdx.x < a.ser_blocks) serial_body<MP, CT, KM, WT>(a, a.A + (size_t)(MP == MPK_MP_PRODMP ? 2 : 3) * (4 * KM) * a.TS, a.aux, smem);
+    else tiles_body<MP, -1, KM, WT>(a, smem, blockIdx.x - a.ser_blocks, gridDim.x - a.ser_blocks);
 }
 
 // 16 consecutive floats at a wave-uniform, 16-byte aligned LDS address (the scaled-time steps of a row tile)
@@ -882,36 +1259,24 @@ __device__ __forceinline__ void stream_group(const TrajArgs& a, const LaneMap<KM
                 // the step loop of black_box_wrapper.py:175-203 on the reference's torque double integrator
                 // (base_reacher_torque.py:25-26), serial in t on the lanes (q == 0); float64, no FMA
                 __builtin_amdgcn_wave_barrier();
+                const bool full_tile = tile_fully_executed(serial, nst, rt * 16);
                 // row tiles past the executed steps (and past the gathered step) have nothing serial to do: a replanning
                 // plan that executes 25 of its 100 steps runs the recurrence on 2 of 7 tiles
                 if (serial && rt * 16 < max(nst, tcond + 1)) {
                     // canonical once: fmin / fmax otherwise quiet their bound operands again at every step
                     const double pgd = sg[0], dgd = sg[16], lod = __builtin_canonicalize(sg[32]),
                                  hid = __builtin_canonicalize(sg[48]), dtp = a.plant_dt;
-                    float pr[16], vr[16];
-#pragma unroll
-                    for (int tl = 0; tl < 16; ++tl) { pr[tl] = sSt[o0 + tl * D]; vr[tl] = sSt[kStageStride + o0 + tl * D]; }
-#pragma unroll
-                    for (int tl = 0; tl < 16; ++tl) {
-                        if (tl < rows) {
-                            const int t = rt * 16 + tl;
-                            if (t == tcond) {     // condition_on_desired: the desired state at the last executed step
-                                const size_t si = (size_t)(b0 + L.bl) * D + L.d;
-                                a.rp.cond_pos[si] = pr[tl]; a.rp.cond_vel[si] = vr[tl];
-                            }
-                            if (t < nst) {
-                                const double dp = (double)pr[tl], dv = (double)vr[tl];
-                                double u;
-                                if (CT - 3 == MPK_CTRL_MOTOR) u = pgd * (dp - qs) + dgd * (dv - qds);
-                                else if (CT - 3 == MPK_CTRL_POSITION) u = dp;
-                                else u = dv;
-                                u = fmin(fmax(u, lod), hid);
-                                qds = qds + dtp * u;
-                                qs = qs + dtp * qds;
-                                sSt[2 * kStageStride + o0 + tl * D] = (float)u;
-                            }
-                        }
+                    if (tcond >= rt * 16 && tcond < rt * 16 + 16) {   // condition_on_desired: the desired state at the
+                        const size_t si = (size_t)(b0 + L.bl) * D + L.d;     // last executed step
+                        a.rp.cond_pos[si] = sSt[o0 + (tcond - rt * 16) * D];
+                        a.rp.cond_vel[si] = sSt[kStageStride + o0 + (tcond - rt * 16) * D];
                     }
+                    if (full_tile)
+                        pd_tile_steps<CT - 3, false>(sSt + o0, sSt + kStageStride + o0, sSt + 2 * kStageStride + o0, D,
+                                                     rt * 16, nst, pgd, dgd, lod, hid, dtp, qs, qds);
+                    else
+                        pd_tile_steps<CT - 3, true>(sSt + o0, sSt + kStageStride + o0, sSt + 2 * kStageStride + o0, D,
+                                                    rt * 16, nst, pgd, dgd, lod, hid, dtp, qs, qds);
                 }
             }
         } else {
@@ -923,32 +1288,9 @@ __device__ __forceinline__ void stream_group(const TrajArgs& a, const LaneMap<KM
                 for (int r = 0; r < 4; ++r) sF[wofs + r * D] = acc0[r];
             }
             __builtin_amdgcn_wave_barrier();
-            if (eul) {
-                // the tile's 16 forcing values and scaled-time steps are fetched up front, so the recurrence itself is a
-                // pure register chain
-                float fr[16], dsr[16];
-                const TauDiv td = make_tau_div(c.tau);
-#pragma unroll
-                for (int tl = 0; tl < 16; ++tl) fr[tl] = sF[o0 + tl * D];
-                load_ds16(sAux + rt * 16, dsr);
-#pragma unroll
-                for (int tl = 0; tl < 16; ++tl) {
-                    if (tl < rows) {
-                        const int t = rt * 16 + tl;
-                        sSt[o0 + tl * D] = ey;
-                        sSt[kStageStride + o0 + tl * D] = div_tau(ez, td);   // vel = z / tau, off the dependent chain
-                        if (t < T - 1) {
-                            const float t1 = eg - ey;
-                            const float t2 = c.dmp_beta * t1;
-                            const float t3 = t2 - ez;
-                            const float t4 = c.dmp_alpha * t3;
-                            const float acc = t4 + fr[tl];
-                            ez = ez + dsr[tl] * acc;
-                            ey = ey + dsr[tl] * ez;
-                        }
-                    }
-                }
-            }
+            if (eul)
+                dmp_tile_steps(sF + o0, sSt + o0, sSt + kStageStride + o0, sAux + rt * 16, D, rt * 16, T, c.dmp_alpha,
+                               c.dmp_beta, eg, make_tau_div(c.tau), ey, ez);
             // (vel = z / tau is written by the recurrence lanes themselves)
         }
         __builtin_amdgcn_wave_barrier();
@@ -972,6 +1314,7 @@ __global__ void __launch_bounds__(256) k_traj_stream(const TrajArgs a, const Act
     extern __shared__ __attribute__((aligned(16))) float sTab[];   // [NOUT][KP][TS] rows + [TS] aux (+ chunk images)
     constexpr bool ACT = CT >= 0 && CT < 3;   // open loop: frozen state (c_pos, c_vel) is an input
     constexpr bool CLOSED = CT >= 3;          // closed loop: plant state (q, qd) is read, integrated and written back
+
     constexpr int NOUT = MP == MPK_MP_PRODMP ? 2 : (MP == MPK_MP_PROMP ? 3 : 1);
     const DevCfg& c = a.c;
     const int lane = threadIdx.x & 63;
@@ -1021,7 +1364,7 @@ __global__ void __launch_bounds__(256) k_traj_stream(const TrajArgs a, const Act
                     const size_t si = (size_t)(b0 + L.bl) * D + L.d;
                     qs = a.q_state[si]; qds = a.qd_state[si];
                     if (a.rp.traj_steps) nst = replan_rule(a.rp, b0 + L.bl, c.T, L.d == 0);
-                    else if (a.n_steps) nst = a.n_steps[b0 + L.bl];
+                    else if (a.n_steps) nst = min(a.n_steps[b0 + L.bl], c.T);
                 }
             }
             stream_group<MP, CT, KM>(a, L, ap, sAux, sg, sSt, lane, b0, xb, cp, cv, ey, ez, eg, eul, qs, qds, nst, serial);
@@ -1129,7 +1472,7 @@ __global__ void __launch_bounds__(256) k_traj_stream(const TrajArgs a, const Act
                         const size_t si = (size_t)(b0 + L.bl) * D + L.d;
                         qs = a.q_state[si]; qds = a.qd_state[si];
                         if (a.rp.traj_steps) nst = replan_rule(a.rp, b0 + L.bl, c.T, L.d == 0);
-                        else if (a.n_steps) nst = a.n_steps[b0 + L.bl];
+                        else if (a.n_steps) nst = min(a.n_steps[b0 + L.bl], c.T);
                     }
                 }
                 stream_group<MP, CT, KM>(a, L, ap, sAux, sg, sSt, lane, b0, xb, cp, cv, ey, ez, eg, eul, qs, qds, nst,
@@ -1168,9 +1511,9 @@ template <int MP, int CT, int KM, int NQ>
 __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActArgs act) {
     static_assert(NQ == 1 || NQ == 2 || NQ == 4, "one, two or four groups per wave");
     __shared__ __attribute__((aligned(16))) float smem[4 * NQ * kQuadImg];   // per wave: 4 x (pos|vel|act or force)
-    __shared__ double sgain[4][64];
     extern __shared__ __attribute__((aligned(16))) float sTab[];   // [NOUT][KP][TS] rows + [TS] aux
     constexpr bool CLOSED = CT >= 3;
+
     static_assert(MP == MPK_MP_DMP || CLOSED, "k_traj_quad is for the serial-recurrence variants");
     constexpr int NOUT = MP == MPK_MP_PRODMP ? 2 : (MP == MPK_MP_PROMP ? 3 : 1);
     constexpr int NST = CLOSED ? 3 : 2;
@@ -1201,7 +1544,7 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
             if (CLOSED) {
                 si.qs = a.q_state[ix]; si.qds = a.qd_state[ix];
                 if (a.rp.traj_steps) si.nst = replan_rule(a.rp, bq, T, L.d == 0);
-                else if (a.n_steps) si.nst = a.n_steps[bq];
+                else if (a.n_steps) si.nst = min(a.n_steps[bq], T);
             } else {
                 si.ey = a.init_pos[ix];
                 si.ez = a.init_vel[ix] * c.tau;
@@ -1213,6 +1556,7 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
     // the first unit's inputs are in flight while the workgroup stages the basis tables
     GroupIn<KM> nx[NQ];
     SerialIn sn{0.0, 0.0, T, 0.f, 0.f, 0.f, false};
+    MPK_STAMP(1);
     if (u < NU) {
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
@@ -1223,17 +1567,18 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
     }
     stage_tables(a.A, a.aux, sA, sAux, (NOUT * KP * TS) >> 2, TS >> 2, threadIdx.x);
     __syncthreads();
+    MPK_STAMP(2);
     if (u >= NU) return;
     const float* ap = sA + L.q * TS + L.col;
     const TauDiv td = make_tau_div(c.tau);
     double pgd = 0.0, dgd = 0.0, lod = 0.0, hid = 0.0;
     if (CLOSED) {
-#pragma unroll
-        for (int dd = 0; dd < kMaxD; ++dd)
-            if (dd == L.d) { pgd = act.pg[dd]; dgd = act.dg[dd]; lod = act.lo[dd]; hid = act.hi[dd]; }
-        lod = __builtin_canonicalize(lod); hid = __builtin_canonicalize(hid);   // not again at every step's fmin / fmax
+        // four vector loads from the kernel-argument segment (see kernarg_gains) instead of 64 exec-masked selects
+        const Gains gq = kernarg_gains(L.dvalid ? L.d : 0);
+        pgd = gq.pg; dgd = gq.dg;
+        lod = __builtin_canonicalize(gq.lo); hid = __builtin_canonicalize(gq.hi);   // not again at every step's fmin / fmax
     }
-    (void)sgain;
+    (void)act;
 
     float xb[NQ][KM];
     while (u < NU) {
@@ -1241,6 +1586,7 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
 #pragma unroll
         for (int j = 0; j < NQ; ++j) finish_group<KM>(L, nx[j], xb[j]);
         const SerialIn sc = sn;
+        MPK_STAMP(3);
         const int un = u + ustride;
         if (un < NU) {
 #pragma unroll
@@ -1310,58 +1656,29 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            MPK_STAMP(10 + rt);
             // 2. four recurrences in parallel, one per lane quarter (float64 / fp32 without FMA, as k_traj_stream)
+            const bool full_tile = CLOSED && tile_fully_executed(serial, nst, rt * 16);
             if (serial && (!CLOSED || rt * 16 < max(nst, tcond + 1))) {
                 if (CLOSED) {
-                    float pr[16], vr[16];
-#pragma unroll
-                    for (int tl = 0; tl < 16; ++tl) { pr[tl] = sQ[oq + tl * D]; vr[tl] = sQ[kStageStride + oq + tl * D]; }
-#pragma unroll
-                    for (int tl = 0; tl < 16; ++tl) {
-                        if (tl < rows) {
-                            const int t = rt * 16 + tl;
-                            if (t == tcond) {     // condition_on_desired: the desired state at the last executed step
-                                const size_t si = (size_t)bq * D + L.d;
-                                a.rp.cond_pos[si] = pr[tl]; a.rp.cond_vel[si] = vr[tl];
-                            }
-                            if (t < nst) {
-                                const double dp = (double)pr[tl], dv = (double)vr[tl];
-                                double uu;
-                                if (CT - 3 == MPK_CTRL_MOTOR) uu = pgd * (dp - qs) + dgd * (dv - qds);
-                                else if (CT - 3 == MPK_CTRL_POSITION) uu = dp;
-                                else uu = dv;
-                                uu = fmin(fmax(uu, lod), hid);
-                                qds = qds + a.plant_dt * uu;
-                                qs = qs + a.plant_dt * qds;
-                                sQ[2 * kStageStride + oq + tl * D] = (float)uu;
-                            }
-                        }
+                    if (tcond >= rt * 16 && tcond < rt * 16 + 16) {   // condition_on_desired: the desired state at the
+                        const size_t si = (size_t)bq * D + L.d;          // last executed step
+                        a.rp.cond_pos[si] = sQ[oq + (tcond - rt * 16) * D];
+                        a.rp.cond_vel[si] = sQ[kStageStride + oq + (tcond - rt * 16) * D];
                     }
+                    if (full_tile)
+                        pd_tile_steps<(CLOSED ? CT - 3 : 0), false>(sQ + oq, sQ + kStageStride + oq, sQ + 2 * kStageStride + oq, D,
+                                                                    rt * 16, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds);
+                    else
+                        pd_tile_steps<(CLOSED ? CT - 3 : 0), true>(sQ + oq, sQ + kStageStride + oq, sQ + 2 * kStageStride + oq, D,
+                                                                   rt * 16, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds);
                 } else {
-                    float fr[16], dsr[16];
-#pragma unroll
-                    for (int tl = 0; tl < 16; ++tl) fr[tl] = sQ[2 * kStageStride + oq + tl * D];
-                    load_ds16(sAux + rt * 16, dsr);
-#pragma unroll
-                    for (int tl = 0; tl < 16; ++tl) {
-                        if (tl < rows) {
-                            const int t = rt * 16 + tl;
-                            sQ[oq + tl * D] = ey;
-                            sQ[kStageStride + oq + tl * D] = div_tau(ez, td);   // vel = z / tau, off the dependent chain
-                            if (t < T - 1) {
-                                const float t1 = eg - ey;
-                                const float t2 = c.dmp_beta * t1;
-                                const float t3 = t2 - ez;
-                                const float t4 = c.dmp_alpha * t3;
-                                const float acc = t4 + fr[tl];
-                                ez = ez + dsr[tl] * acc;
-                                ey = ey + dsr[tl] * ez;
-                            }
-                        }
-                    }
+                    dmp_tile_steps(sQ + 2 * kStageStride + oq, sQ + oq, sQ + kStageStride + oq, sAux + rt * 16, D, rt * 16, T,
+                                   c.dmp_alpha, c.dmp_beta, eg, td, ey, ez);
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            MPK_STAMP(30 + rt);
             // 3. coalesced stores of the four tiles
 #pragma unroll
             for (int j = 0; j < NQ; ++j)
@@ -1371,6 +1688,7 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
                     else tile_store<NST, KM, false>(a, L, sW + j * kQuadImg, lane, (g0 + j) * NTW, rt, rows);
                 }
             __builtin_amdgcn_wave_barrier();
+            MPK_STAMP(50 + rt);
         }
         if (CLOSED) {
             if (serial) {
@@ -1378,17 +1696,202 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
                 a.q_state[si] = qs; a.qd_state[si] = qds;
             }
         }
+        MPK_STAMP(90);
         u = un;
     }
 }
 
+// ---- episode-major, wave-specialised: the closed-loop step as a producer / consumer pipeline -------------------------
+// What bounds k_traj_quad / k_traj_stream<closed> at a few thousand episodes is not arithmetic but ONE wave doing
+// everything in sequence, 7 row tiles x (contract -> LDS -> recurrence -> LDS -> store), every latency exposed (PMC at
+// B = 4096, profiles/r02_closed_loop.md: 2 590 VALU + 408 LDS + 564 scalar instructions per wave, 42 % of the wave's
+// cycles in s_waitcnt).  Here a workgroup of FIVE waves owns four consecutive episode groups:
+//   waves 1..4  (producers)  contract row tile rt + 1 of "their" group on the matrix cores into LDS image (rt + 1) & 1
+//               and store tile rt (pos, vel, actions) from image rt & 1;
+//   wave 0      (consumer)   runs the controller + plant recurrence of tile rt for all four groups at once, one group per
+//               lane quarter (float64, no FMA: pd_tile_steps, the operations of every other closed-loop kernel, bit for
+//               bit), while the producers are busy with tile rt + 1 and with the stores of tile rt - 1.
+// One workgroup barrier per row tile hands the images over.  The integer replanning state, the boundary-condition gather
+// and the plant state are the consumer's, exactly as in k_traj_quad.
+constexpr int kPipeGroups = 4;
+
+template <int MP, int CT, int KM>
+__global__ void __launch_bounds__(320) k_traj_pipe(const TrajArgs a, const ActArgs act) {
+    static_assert(CT >= 3 && MP != MPK_MP_DMP, "closed loop, promp / prodmp");
+    __shared__ __attribute__((aligned(16))) float smem[2 * kPipeGroups * kQuadImg];   // [buffer][group] pos | vel | act
+    extern __shared__ __attribute__((aligned(16))) float sTab[];                      // [NOUT][KP][TS] rows + [TS] aux
+    constexpr int NOUT = MP == MPK_MP_PRODMP ? 2 : 3;
+    const DevCfg& c = a.c;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int KP = 4 * KM, TS = a.TS, D = c.D, B = a.B, T = c.T;
+    float* sA = sTab;
+    float* sAux = sTab + NOUT * KP * TS;
+    const LaneMap<KM> L = make_lane_map<MP, KM>(a, lane);
+    const int NTW = L.NTW, NRT = (T + 15) >> 4;
+    const int nb8 = gridDim.x >> 3;
+    const int vb = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * nb8 + (blockIdx.x >> 3) : blockIdx.x;
+    const int NU = (a.G + kPipeGroups - 1) / kPipeGroups;
+    (void)act;
+    // basis tables -> LDS by all five waves (a 256-thread loop shape: threads 256.. take the tail)
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.A);
+        float4* dst = reinterpret_cast<float4*>(sA);
+        const int nA4 = (NOUT * KP * TS) >> 2, nX4 = TS >> 2;
+        for (int i = threadIdx.x; i < nA4; i += 320) dst[i] = src[i];
+        for (int i = threadIdx.x; i < nX4; i += 320) reinterpret_cast<float4*>(sAux)[i] = reinterpret_cast<const float4*>(a.aux)[i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // ---------------- consumer: four recurrences, one per lane quarter ----------------
+        const Gains gq = kernarg_gains(L.dvalid ? L.d : 0);
+        const double pgd = gq.pg, dgd = gq.dg, lod = __builtin_canonicalize(gq.lo), hid = __builtin_canonicalize(gq.hi);
+        for (int u = vb; u < NU; u += (int)gridDim.x) {
+            const int gsel = u * kPipeGroups + L.q, bq = gsel * NTW + L.bl;
+            const bool serial = L.dvalid && gsel < a.G && bq < B;
+            double qs = 0.0, qds = 0.0;
+            int nst = 0;
+            if (serial) {
+                const size_t ix = (size_t)bq * D + L.d;
+                qs = a.q_state[ix]; qds = a.qd_state[ix];
+                nst = T;
+                if (a.rp.traj_steps) nst = replan_rule(a.rp, bq, T, L.d == 0);
+                else if (a.n_steps) nst = min(a.n_steps[bq], T);
+            }
+            const int tcond = (serial && a.rp.cond_pos) ? min(max(nst - 1, 0), T - 1) : -1;
+            const int oq = L.bl * a.pitch + L.d + (int)ep_shift(a, bq);      // (row 0, this column) in group q's image
+            __syncthreads();                                                // tile 0 is in image 0
+            for (int rt = 0; rt < NRT; ++rt) {
+                float* sQ = smem + ((rt & 1) * kPipeGroups + L.q) * kQuadImg;
+                const bool full_tile = tile_fully_executed(serial, nst, rt * 16);
+                if (serial && rt * 16 < max(nst, tcond + 1)) {
+                    if (tcond >= rt * 16 && tcond < rt * 16 + 16) {   // condition_on_desired: the desired state at the
+                        const size_t si = (size_t)bq * D + L.d;          // last executed step
+                        a.rp.cond_pos[si] = sQ[oq + (tcond - rt * 16) * D];
+                        a.rp.cond_vel[si] = sQ[kStageStride + oq + (tcond - rt * 16) * D];
+                    }
+                    if (full_tile)
+                        pd_tile_steps<CT - 3, false>(sQ + oq, sQ + kStageStride + oq, sQ + 2 * kStageStride + oq, D, rt * 16, nst,
+                                                     pgd, dgd, lod, hid, a.plant_dt, qs, qds);
+                    else
+                        pd_tile_steps<CT - 3, true>(sQ + oq, sQ + kStageStride + oq, sQ + 2 * kStageStride + oq, D, rt * 16, nst,
+                                                    pgd, dgd, lod, hid, a.plant_dt, qs, qds);
+                }
+                __syncthreads();                                            // tile rt's actions are final; tile rt + 1 is in
+            }
+            if (serial) {
+                const size_t si = (size_t)bq * D + L.d;
+                a.q_state[si] = qs; a.qd_state[si] = qds;
+            }
+        }
+    } else {
+        // ---------------- producers: wave j + 1 owns group u * 4 + j ----------------
+        const int j = wave - 1;
+        const float* ap = sA + L.q * TS + L.col;
+        int u = vb;
+        GroupIn<KM> nx;
+        if (u < NU) {
+            const int g = u * kPipeGroups + j;
+            nx = load_group<MP, false, KM>(a, L, g < a.G ? g : a.G - 1);
+        }
+        for (; u < NU; u += (int)gridDim.x) {
+            const int g = u * kPipeGroups + j;
+            const bool have = g < a.G;
+            float xb[KM];
+            finish_group<KM>(L, nx, xb);
+            const int un = u + (int)gridDim.x;
+            if (un < NU) {
+                const int gn = un * kPipeGroups + j;
+                nx = load_group<MP, false, KM>(a, L, gn < a.G ? gn : a.G - 1);
+            }
+            const unsigned wofs = L.wofs + ep_shift(a, g * NTW + L.bl);
+            auto produce = [&](int rt) {
+                float* sJ = smem + ((rt & 1) * kPipeGroups + j) * kQuadImg;
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < KM; ++m) {
+                    const float* am = ap + (4 * m) * TS + rt * 16;
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[0], xb[m], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[KP * TS], xb[m], acc1, 0, 0, 0);
+                    if (NOUT > 2) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[(NOUT > 2 ? 2 : 0) * KP * TS], xb[m], acc2, 0, 0, 0);
+                }
+                float dtd[4] = {1.f, 1.f, 1.f, 1.f};
+                if (MP == MPK_MP_PROMP) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dtd[r] = sAux[rt * 16 + 4 * L.q + r];
+                }
+                if (L.dvalid) tile_epilogue<MP, CT>(acc0, acc1, acc2, dtd, 0.0, 0.0, Gains{0.0, 0.0, 0.0, 0.0}, sJ, wofs, D);
+            };
+            // pos and vel of a tile leave as soon as it is contracted (nothing of theirs waits for the consumer: two thirds
+            // of the store stream are independent of the recurrence); the actions follow after the barrier
+            auto store_arrays = [&](auto mask_tag, int rt) {
+                constexpr int MASK = decltype(mask_tag)::value;
+                const float* sJ = smem + ((rt & 1) * kPipeGroups + j) * kQuadImg;
+                const int rows = min(16, T - rt * 16);
+                if (a.wt) tile_store_sel<MASK, KM, true>(a, L, sJ, lane, g * NTW, rt, rows);
+                else tile_store_sel<MASK, KM, false>(a, L, sJ, lane, g * NTW, rt, rows);
+            };
+            if (have) {
+                produce(0);
+                __builtin_amdgcn_wave_barrier();
+                store_arrays(std::integral_constant<int, 3>(), 0);
+            }
+            __syncthreads();                                                // tile 0 is in image 0
+            for (int rt = 0; rt < NRT; ++rt) {
+                if (have && rt + 1 < NRT) {
+                    produce(rt + 1);
+                    __builtin_amdgcn_wave_barrier();
+                    store_arrays(std::integral_constant<int, 3>(), rt + 1);
+                }
+                __syncthreads();                                            // tile rt's actions are final
+                if (have) store_arrays(std::integral_constant<int, 4>(), rt);
+            }
+        }
+    }
+}
+
+#ifndef MPK_DEVICE_ONLY
 template <int MP, int CT>
 static int launch_traj_t(const TrajArgs& ta, const ActArgs& aa, bool stream_mode, bool write_through, bool bulk,
-                         int quad, int blocks, size_t lds, void* stream) {
+                         int quad, int blocks, size_t lds, void* stream, bool split = false, bool pipe = false) {
     const dim3 g(blocks), b(256);
+    if (pipe) {
+        if constexpr (MP != MPK_MP_DMP && CT >= 3) {
+            const dim3 b5(320);
+            hipStream_t s5 = (hipStream_t)stream;
+            switch (ta.c.KP / 4) {
+                case 1: hipLaunchKernelGGL((k_traj_pipe<MP, CT, 1>), g, b5, lds, s5, ta, aa); break;
+                case 2: hipLaunchKernelGGL((k_traj_pipe<MP, CT, 2>), g, b5, lds, s5, ta, aa); break;
+                case 3: hipLaunchKernelGGL((k_traj_pipe<MP, CT, 3>), g, b5, lds, s5, ta, aa); break;
+                default: hipLaunchKernelGGL((k_traj_pipe<MP, CT, 4>), g, b5, lds, s5, ta, aa); break;
+            }
+        }
+        MPK_LAUNCH_CHECK();
+        return MPK_OK;
+    }
+    // tile-major / split: no dynamic LDS of their own; `lds` then is the occupancy-experiment padding ("lds_pad" option)
+    const size_t pad = (!stream_mode || split) ? lds : 0;
     hipStream_t s = (hipStream_t)stream;
     const int km = ta.c.KP / 4;
-    if (stream_mode && quad) {
+    if (split) {
+        if constexpr (MP != MPK_MP_DMP && CT >= 3) {
+            if (write_through) {
+                switch (km) {
+                    case 1: hipLaunchKernelGGL((k_traj_split<MP, CT, 1, true>), g, b, pad, s, ta, aa); break;
+                    case 2: hipLaunchKernelGGL((k_traj_split<MP, CT, 2, true>), g, b, pad, s, ta, aa); break;
+                    case 3: hipLaunchKernelGGL((k_traj_split<MP, CT, 3, true>), g, b, pad, s, ta, aa); break;
+                    default: hipLaunchKernelGGL((k_traj_split<MP, CT, 4, true>), g, b, pad, s, ta, aa); break;
+                }
+            } else {
+                switch (km) {
+                    case 1: hipLaunchKernelGGL((k_traj_split<MP, CT, 1, false>), g, b, pad, s, ta, aa); break;
+                    case 2: hipLaunchKernelGGL((k_traj_split<MP, CT, 2, false>), g, b, pad, s, ta, aa); break;
+                    case 3: hipLaunchKernelGGL((k_traj_split<MP, CT, 3, false>), g, b, pad, s, ta, aa); break;
+                    default: hipLaunchKernelGGL((k_traj_split<MP, CT, 4, false>), g, b, pad, s, ta, aa); break;
+                }
+            }
+        }
+    } else if (stream_mode && quad) {
         if constexpr (MP == MPK_MP_DMP || CT >= 3) {
             if (quad == 1) {
                 switch (km) {
@@ -1433,17 +1936,17 @@ static int launch_traj_t(const TrajArgs& ta, const ActArgs& aa, bool stream_mode
         if constexpr (MP != MPK_MP_DMP && CT < 3) {
             if (write_through) {
                 switch (km) {
-                    case 1: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 1, true>), g, b, 0, s, ta, aa); break;
-                    case 2: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 2, true>), g, b, 0, s, ta, aa); break;
-                    case 3: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 3, true>), g, b, 0, s, ta, aa); break;
-                    default: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 4, true>), g, b, 0, s, ta, aa); break;
+                    case 1: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 1, true>), g, b, pad, s, ta, aa); break;
+                    case 2: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 2, true>), g, b, pad, s, ta, aa); break;
+                    case 3: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 3, true>), g, b, pad, s, ta, aa); break;
+                    default: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 4, true>), g, b, pad, s, ta, aa); break;
                 }
             } else {
                 switch (km) {
-                    case 1: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 1, false>), g, b, 0, s, ta, aa); break;
-                    case 2: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 2, false>), g, b, 0, s, ta, aa); break;
-                    case 3: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 3, false>), g, b, 0, s, ta, aa); break;
-                    default: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 4, false>), g, b, 0, s, ta, aa); break;
+                    case 1: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 1, false>), g, b, pad, s, ta, aa); break;
+                    case 2: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 2, false>), g, b, pad, s, ta, aa); break;
+                    case 3: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 3, false>), g, b, pad, s, ta, aa); break;
+                    default: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 4, false>), g, b, pad, s, ta, aa); break;
                 }
             }
         }
@@ -1451,11 +1954,28 @@ static int launch_traj_t(const TrajArgs& ta, const ActArgs& aa, bool stream_mode
     MPK_LAUNCH_CHECK();
     return MPK_OK;
 }
+#endif  // MPK_DEVICE_ONLY
 
+#ifndef MPK_DEVICE_ONLY
 template <int MP>
 static int launch_traj_ct(const TrajArgs& ta, const ActArgs& aa, int ct, bool stream_mode, bool write_through,
-                          bool bulk, int quad, int blocks, size_t lds, void* stream) {
+                          bool bulk, int quad, int blocks, size_t lds, void* stream, bool split = false,
+                          bool pipe = false) {
     if constexpr (MP != MPK_MP_DMP) {
+        if (pipe) {
+            switch (ct) {
+                case 3 + MPK_CTRL_MOTOR: return launch_traj_t<MP, 3 + MPK_CTRL_MOTOR>(ta, aa, true, false, false, 0, blocks, lds, stream, false, true);
+                case 3 + MPK_CTRL_VELOCITY: return launch_traj_t<MP, 3 + MPK_CTRL_VELOCITY>(ta, aa, true, false, false, 0, blocks, lds, stream, false, true);
+                default: return launch_traj_t<MP, 3 + MPK_CTRL_POSITION>(ta, aa, true, false, false, 0, blocks, lds, stream, false, true);
+            }
+        }
+        if (split) {
+            switch (ct) {
+                case 3 + MPK_CTRL_MOTOR: return launch_traj_t<MP, 3 + MPK_CTRL_MOTOR>(ta, aa, false, write_through, false, 0, blocks, lds, stream, true);
+                case 3 + MPK_CTRL_VELOCITY: return launch_traj_t<MP, 3 + MPK_CTRL_VELOCITY>(ta, aa, false, write_through, false, 0, blocks, lds, stream, true);
+                default: return launch_traj_t<MP, 3 + MPK_CTRL_POSITION>(ta, aa, false, write_through, false, 0, blocks, lds, stream, true);
+            }
+        }
         switch (ct) {
             case MPK_CTRL_MOTOR: return launch_traj_t<MP, MPK_CTRL_MOTOR>(ta, aa, stream_mode, write_through, bulk, quad, blocks, lds, stream);
             case MPK_CTRL_VELOCITY: return launch_traj_t<MP, MPK_CTRL_VELOCITY>(ta, aa, stream_mode, write_through, bulk, quad, blocks, lds, stream);
@@ -1468,7 +1988,9 @@ static int launch_traj_ct(const TrajArgs& ta, const ActArgs& aa, int ct, bool st
     }
     return launch_traj_t<MP, -1>(ta, aa, stream_mode, write_through, bulk, quad, blocks, lds, stream);
 }
+#endif  // MPK_DEVICE_ONLY
 
+#ifndef MPK_DEVICE_ONLY
 int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* params, const float* init_pos,
                        const float* init_vel, float* pos, float* vel, float* actions, const RolloutDev* rc,
                        const double* c_pos, const double* c_vel, double* q_state, double* qd_state,
@@ -1513,8 +2035,25 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     // work decomposition: episode-major once the outputs stop being cache resident (or when it is the only option)
     const size_t table_bytes = ((size_t)st.n_out * c.KP * st.TS + st.TS) * sizeof(float);
     const double out_bytes = (double)B * c.T * c.D * 4.0 * nst;
-    bool stream_mode = c.mp_type == MPK_MP_DMP || closed || out_bytes > 96.0 * 1024 * 1024;
     const int ov = tune.mapping == 1 || tune.mapping == 2 ? tune.mapping : 0;   // mpk_set_option "mapping"
+    // closed loop, promp / prodmp, outputs cache resident: tile-major with a serial role (k_traj_split).  "split" 0 / 1
+    // switches it off / forces it; a forced episode-major variant ("mapping" 2, "quad" 0 / 2 / 3 / 4, "bulk" 2) wins
+    const bool variant_forced = ov == 2 || tune.quad == 0 || tune.quad >= 2 || tune.bulk == 2;
+    // (its serial role stores actions as aligned float4 chunks: trajectories and the last row tile must be whole chunks)
+    const int last_rows = c.T - (c.T - 1) / 16 * 16;
+    const bool split_shape = ptr_ok && TD % 4 == 0 && (last_rows * c.D) % 4 == 0;
+    // episode-major producer / consumer pipeline (k_traj_pipe): the default closed-loop kernel whenever its tables and
+    // images fit; "pipe" 0 / 1 switches it off / forces it; "split" 1 forces the tile-major kernel with a serial role
+    // Automatic up to three 5-wave workgroups per CU (B = 6144 at 7 DoF): measured against the best one-wave kernel
+    // (profiles/r02_closed_loop.md) full step 10.1 vs 11.9 us at B = 2048, 11.8 vs 14.1 at 4096, 22.1 vs 19.7 at 8192;
+    // 25-of-100-step plan 8.1 vs 8.8, 9.5 vs 11.6, 17.2 vs 16.5 -- beyond that the launch is store-bound and the barrier
+    // per row tile only makes the store stream burstier.
+    const bool pipe_fits = table_bytes + 2 * kPipeGroups * kQuadImg * sizeof(float) <= 64 * 1024;
+    const long pipe_units = ((long)ta.G + kPipeGroups - 1) / kPipeGroups;
+    const bool pipe = closed && c.mp_type != MPK_MP_DMP && pipe_fits && tune.split != 1 &&
+                      (tune.pipe == 1 || (tune.pipe != 0 && !variant_forced && pipe_units <= 3L * num_cu));
+    const bool split = !pipe && closed && c.mp_type != MPK_MP_DMP && split_shape && tune.split == 1;
+    bool stream_mode = !split && (c.mp_type == MPK_MP_DMP || closed || out_bytes > 96.0 * 1024 * 1024);
     if (c.mp_type != MPK_MP_DMP && !closed && ov == 1) stream_mode = false;
     if (ov == 2) stream_mode = true;
     if (stream_mode && table_bytes + 4 * kStageFloats * sizeof(float) > 64 * 1024) {
@@ -1537,7 +2076,10 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     // mpk_set_option "quad": 0 off, 2 force four, 3 force two, 4 force one (A/B runs, tests)
     int quad = 0;
     {
-        auto fits = [&](int nq) { return table_bytes + (4 * nq * kQuadImg) * sizeof(float) + 4 * 64 * sizeof(double) <= 64 * 1024; };
+        // static staging (fp32 images) + the tables
+        auto fits = [&](int nq) {
+            return table_bytes + (4 * nq * kQuadImg) * sizeof(float) <= 64 * 1024;
+        };
         const bool serial_variant = stream_mode && (c.mp_type == MPK_MP_DMP || closed);
         const int quad_mode = tune.quad < 0 ? 1 : tune.quad;
         const long units4 = (ta.G + 3) / 4, units2 = (ta.G + 1) / 2;
@@ -1559,7 +2101,15 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
             else if (closed && fits(1)) quad = 1;
         }
     }
-    if (quad) {
+    if (pipe) {
+        quad = 0; bulk = false;
+        lds = table_bytes;
+        const long units = (ta.G + kPipeGroups - 1) / kPipeGroups;
+        const long cap = (long)num_cu * 6;                                // 5-wave workgroups: one resident round
+        blocks = (int)(units < cap ? units : cap);
+        if (blocks >= 8) blocks = blocks / 8 * 8;                         // XCD-contiguous remap needs a multiple of 8
+        if (blocks < 1) blocks = 1;
+    } else if (quad) {
         lds = table_bytes;
         const long units = (ta.G + quad - 1) / quad;
         const long waves = units < max_waves ? units : max_waves;
@@ -1606,20 +2156,33 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         ta.nrt_magic = NRT > 1 ? (unsigned)((1ull << 32) / (unsigned long long)NRT) + 1u : 0u;
     }
     if (blocks < 1) blocks = 1;
+    if (!stream_mode && tune.lds_pad > 0) lds = (size_t)tune.lds_pad * 1024;     // A/B runs: caps the workgroups per CU
+    ta.ser_blocks = 0;
+    if (split) {
+        // serial-role workgroups first (they are the long pole and must start first), capped at one resident round of the chip
+        const int EPW = 64 >> sh;                              // episodes per serial-role wave: one lane per (episode, DoF)
+        const long units = ((long)B + EPW - 1) / EPW;
+        long sb = (units + 3) / 4;
+        const long cap = (long)num_cu * 8;
+        if (sb > cap) sb = cap;
+        ta.ser_blocks = (unsigned)sb;
+        blocks += (int)sb;
+    }
     switch (c.mp_type) {
         case MPK_MP_PRODMP:
-            *kernel_name = closed ? (quad == 4 ? "k_traj_quad<prodmp,closed>" : quad == 2 ? "k_traj_duo<prodmp,closed>" : quad == 1 ? "k_traj_mono<prodmp,closed>" : "k_traj_stream<prodmp,closed>") : stream_mode ? (act ? "k_traj_stream<prodmp,act>" : "k_traj_stream<prodmp>")
+            *kernel_name = pipe ? "k_traj_pipe<prodmp,closed>" : split ? "k_traj_split<prodmp,closed>" : closed ? (quad == 4 ? "k_traj_quad<prodmp,closed>" : quad == 2 ? "k_traj_duo<prodmp,closed>" : quad == 1 ? "k_traj_mono<prodmp,closed>" : "k_traj_stream<prodmp,closed>") : stream_mode ? (act ? "k_traj_stream<prodmp,act>" : "k_traj_stream<prodmp>")
                                        : (act ? "k_traj_tiles<prodmp,act>" : "k_traj_tiles<prodmp>");
-            return launch_traj_ct<MPK_MP_PRODMP>(ta, aa, ct, stream_mode, write_through, bulk, quad, blocks, lds, stream);
+            return launch_traj_ct<MPK_MP_PRODMP>(ta, aa, ct, stream_mode, write_through, bulk, quad, blocks, lds, stream, split, pipe);
         case MPK_MP_PROMP:
-            *kernel_name = closed ? (quad == 4 ? "k_traj_quad<promp,closed>" : quad == 2 ? "k_traj_duo<promp,closed>" : quad == 1 ? "k_traj_mono<promp,closed>" : "k_traj_stream<promp,closed>") : stream_mode ? (act ? "k_traj_stream<promp,act>" : "k_traj_stream<promp>")
+            *kernel_name = pipe ? "k_traj_pipe<promp,closed>" : split ? "k_traj_split<promp,closed>" : closed ? (quad == 4 ? "k_traj_quad<promp,closed>" : quad == 2 ? "k_traj_duo<promp,closed>" : quad == 1 ? "k_traj_mono<promp,closed>" : "k_traj_stream<promp,closed>") : stream_mode ? (act ? "k_traj_stream<promp,act>" : "k_traj_stream<promp>")
                                        : (act ? "k_traj_tiles<promp,act>" : "k_traj_tiles<promp>");
-            return launch_traj_ct<MPK_MP_PROMP>(ta, aa, ct, stream_mode, write_through, bulk, quad, blocks, lds, stream);
+            return launch_traj_ct<MPK_MP_PROMP>(ta, aa, ct, stream_mode, write_through, bulk, quad, blocks, lds, stream, split, pipe);
         default:
             *kernel_name = quad == 4 ? "k_traj_quad<dmp>" : quad == 2 ? "k_traj_duo<dmp>" : quad == 1 ? "k_traj_mono<dmp>" : "k_traj_stream<dmp>";
             return launch_traj_ct<MPK_MP_DMP>(ta, aa, -1, true, false, bulk, quad, blocks, lds, stream);
     }
 }
+#endif  // MPK_DEVICE_ONLY
 
 // ------------------------------------------------------------------------------------------------------------
 // k_traj_rows: per-episode phase (learned tau/delay or per-episode init_time), one workgroup per episode
@@ -2222,6 +2785,7 @@ __global__ void __launch_bounds__(256) k_traj_phase_dmp(const PhaseArgs a) {
     }
 }
 
+#ifndef MPK_DEVICE_ONLY
 static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu, void* stream,
                              const char** kernel_name, const Tuning& tune) {
     PhaseArgs pa = base;
@@ -2308,6 +2872,7 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
             return KQ == 2 ? go(k_traj_phase_dmp<2>) : go(k_traj_phase_dmp<4>);
     }
 }
+#endif  // MPK_DEVICE_ONLY
 
 // ------------------------------------------------------------------------------------------------------------
 // k_dmp_prestep (MPK_DMP_FIRST_IS_STEP): the boundary state advanced by ONE Euler step from init_time to the first grid
@@ -2361,6 +2926,7 @@ __global__ void __launch_bounds__(256) k_dmp_prestep(const DevCfg c, const float
     vel1[e] = div_tau(z, make_tau_div(tau));
 }
 
+#ifndef MPK_DEVICE_ONLY
 int launch_dmp_prestep(const DevCfg& c, const float* params, const float* init_pos, const float* init_vel,
                        const float* init_time, float init_time_shared, float* pos1, float* vel1, int B, void* stream) {
     hipLaunchKernelGGL(k_dmp_prestep, dim3((unsigned)(((long)B * c.D + 255) / 256)), dim3(256), 0, (hipStream_t)stream, c,
@@ -2368,7 +2934,9 @@ int launch_dmp_prestep(const DevCfg& c, const float* params, const float* init_p
     MPK_LAUNCH_CHECK();
     return MPK_OK;
 }
+#endif  // MPK_DEVICE_ONLY
 
+#ifndef MPK_DEVICE_ONLY
 int launch_traj_rows(const DevCfg& c, const float* params, const float* init_pos, const float* init_vel,
                      const float* init_time, float init_time_shared, float* pos, float* vel, int32_t* range_flag,
                      int B, int num_cu, void* stream, const char** kernel_name, const Tuning& tune) {
@@ -2408,6 +2976,7 @@ int launch_traj_rows(const DevCfg& c, const float* params, const float* init_pos
         default: *kernel_name = "k_traj_rows<dmp>"; return go(k_traj_rows<MPK_MP_DMP>);
     }
 }
+#endif  // MPK_DEVICE_ONLY
 
 // ------------------------------------------------------------------------------------------------------------
 // k_pd_rollout: controller + plant loop, one lane per (episode, DoF), float64, no FMA contraction
@@ -2791,6 +3360,7 @@ __global__ void __launch_bounds__(256) k_reacher_rollout(const RolloutDev rc, co
     }
 }
 
+#ifndef MPK_DEVICE_ONLY
 int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
                            const float* des_vel, double* q, double* qd, const int32_t* n_steps, const int32_t* step0,
                            const double* goal, int steps_before_reward, float* actions, double* rewards, int B, int T,
@@ -2839,7 +3409,9 @@ int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
     MPK_LAUNCH_CHECK();
     return MPK_OK;
 }
+#endif  // MPK_DEVICE_ONLY
 
+#ifndef MPK_DEVICE_ONLY
 int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const float* des_vel, double* q, double* qd,
                       const int32_t* n_steps, float* actions, int B, int T, void* stream, const Tuning& tune) {
     auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
@@ -2879,6 +3451,7 @@ int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const f
     MPK_LAUNCH_CHECK();
     return MPK_OK;
 }
+#endif  // MPK_DEVICE_ONLY
 
 // ------------------------------------------------------------------------------------------------------------
 // integer replanning state
@@ -2889,6 +3462,7 @@ __global__ void __launch_bounds__(256) k_replan_advance(const ReplanDev rp, cons
     (void)replan_rule(rp, b, T, true);
 }
 
+#ifndef MPK_DEVICE_ONLY
 int launch_replan_advance(int32_t* traj_steps, int32_t* plan_steps, int32_t* seg_len, uint8_t* done, int every,
                           int max_planning_times, int horizon, int T, int B, void* stream) {
     ReplanDev rp;
@@ -2898,6 +3472,7 @@ int launch_replan_advance(int32_t* traj_steps, int32_t* plan_steps, int32_t* seg
     MPK_LAUNCH_CHECK();
     return MPK_OK;
 }
+#endif  // MPK_DEVICE_ONLY
 
 // BlackBoxWrapper.reset (black_box_wrapper.py:222-229) for B episodes: counters to zero, plant state from the caller's
 // initial state (NULL = zeros) and its fp32 image, the boundary condition of the first plan (black_box_wrapper.py:110-111)
@@ -2917,6 +3492,7 @@ __global__ void __launch_bounds__(256) k_episode_reset(const double* __restrict_
     }
 }
 
+#ifndef MPK_DEVICE_ONLY
 int launch_episode_reset(const double* init_q, const double* init_qd, double* q, double* qd, float* cond_pos,
                          float* cond_vel, int32_t* traj_steps, int32_t* plan_steps, uint8_t* done, int B, int D,
                          void* stream) {
@@ -2925,6 +3501,7 @@ int launch_episode_reset(const double* init_q, const double* init_qd, double* q,
     MPK_LAUNCH_CHECK();
     return MPK_OK;
 }
+#endif  // MPK_DEVICE_ONLY
 
 // condition_on_desired (black_box_wrapper.py:199-201): the desired state at the last executed step of this plan
 __global__ void __launch_bounds__(256) k_condition_gather(const float* __restrict__ pos, const float* __restrict__ vel,
@@ -2941,6 +3518,7 @@ __global__ void __launch_bounds__(256) k_condition_gather(const float* __restric
     cond_vel[e] = vel[src];
 }
 
+#ifndef MPK_DEVICE_ONLY
 int launch_condition_gather(const float* pos, const float* vel, const int32_t* seg_len, float* cond_pos, float* cond_vel,
                             int B, int T, int D, void* stream) {
     hipLaunchKernelGGL(k_condition_gather, dim3((unsigned)(((long)B * D + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
@@ -2948,6 +3526,7 @@ int launch_condition_gather(const float* pos, const float* vel, const int32_t* s
     MPK_LAUNCH_CHECK();
     return MPK_OK;
 }
+#endif  // MPK_DEVICE_ONLY
 
 // ------------------------------------------------------------------------------------------------------------
 // validity reduction: one wave per episode
@@ -3002,6 +3581,7 @@ __global__ void __launch_bounds__(256) k_validity(const ValidArgs v, const float
     }
 }
 
+#ifndef MPK_DEVICE_ONLY
 int launch_validity(const float* pos, const float* params, int P, int D, const double* lo, const double* hi,
                     int check_td, const double* tb, const double* db, uint8_t* valid, double* penalty, int B, int T,
                     void* stream) {
@@ -3014,5 +3594,19 @@ int launch_validity(const float* pos, const float* params, int P, int D, const d
     MPK_LAUNCH_CHECK();
     return MPK_OK;
 }
+#endif  // MPK_DEVICE_ONLY
 
 }  // namespace mpk
+
+#ifdef MPK_TRACE
+// development builds only: fetch and clear the stamps (pairs of tag, shader clock)
+extern "C" int mpk_debug_trace(long long* out, int cap) {
+    int n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(mpk::g_trace_n), sizeof(int)) != hipSuccess) return -1;
+    if (n > cap) n = cap;
+    if (n > 0 && hipMemcpyFromSymbol(out, HIP_SYMBOL(mpk::g_trace), sizeof(long long) * 2 * n) != hipSuccess) return -1;
+    const int zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(mpk::g_trace_n), &zero, sizeof(int));
+    return n;
+}
+#endif

@@ -184,6 +184,9 @@ int mpk_set_duration(mpk_handle h, double duration, double dt);
  *   "phase_table"   0 ProDMP row table from L2 instead of LDS
  *   "phase_chunk"   1 / 2 / 4 episodes per input chunk
  *   "pd_simple"     1 generic one-lane-per-(episode, DoF) rollout kernels
+ *   "pipe"          0 off, 1 force the producer / consumer closed-loop kernel (k_traj_pipe; the default where it fits)
+ *   "split"         1 force the tile-major closed-loop kernel with a serial role (k_traj_split; never chosen automatically)
+ *   "lds_pad"       n KB of unused dynamic LDS per workgroup of the tile-major kernels (occupancy experiments: 160 KB per CU)
  * Unknown key or value out of range: MPK_EINVAL.  mpk_get_option returns the effective value (MPK_OPT_AUTO if automatic).
  */
 #define MPK_OPT_AUTO (-1)

@@ -1100,11 +1100,16 @@ def _reference_loop(cur, plan, done, every, mpt, horizon, T):
 
 @pytest.mark.parametrize("cfg", [CFG4, CFG5, CFG3], ids=["prodmp_replan", "promp", "dmp"])
 @pytest.mark.parametrize("B", [1, 9, 200, 2100])
-@pytest.mark.parametrize("bulk,quad", [("0", "2"), ("0", "3"), ("0", "4"), ("0", "0"), ("2", "0")])
+@pytest.mark.parametrize("bulk,quad", [("0", "2"), ("0", "3"), ("0", "4"), ("0", "0"), ("2", "0"), ("1", "1"), ("1", "split")],
+                         ids=["quad", "duo", "mono", "stream", "bulk", "auto_pipe", "split"])
 def test_replan_step_equals_the_separate_kernels(cfg, B, bulk, quad, monkeypatch, mpk_option):
     """mpk_replan_step (integer state + plan + rollout + condition gather; ONE launch for shared-phase promp / prodmp,
     the separate kernels for dmp) == mpk_replan_advance -> mpk_trajectory_rollout -> mpk_condition_gather, bit for bit,
     from random per-episode integer states (finished episodes, different step counters, exhausted planning budgets)"""
+    force_split = quad == "split"       # the tile-major kernel with a serial role (never chosen automatically)
+    if force_split:
+        mpk_option("split", 1)
+        quad = "1"
     mpk_option("bulk", bulk)
     mpk_option("quad", quad)
     pc, bc, tc, dt, dur = cfg
@@ -1128,6 +1133,15 @@ def test_replan_step_equals_the_separate_kernels(cfg, B, bulk, quad, monkeypatch
     fused = eng.last_kernel()
     if tc.trajectory_generator_type != "dmp":
         assert fused.endswith("closed>")
+        # automatic selection: the producer / consumer pipeline; the split kernel needs whole float4 chunks per trajectory
+        split_shape = (T * 7) % 4 == 0 and ((T - (T - 1) // 16 * 16) * 7) % 4 == 0
+        if force_split:
+            assert fused.startswith("k_traj_split") == split_shape and not fused.startswith("k_traj_pipe"), fused
+        else:
+            assert fused.startswith("k_traj_pipe") == (quad == "1"), fused
+    if quad == "1":
+        mpk_option("split", -1)
+        mpk_option("quad", "0")      # the wave-specialised kernels against the one-wave-does-everything kernel
     q2, qd2, ts2, ps2, dn2 = state()
     seg = eng.replan_advance(ts2, ps2, dn2, every, mpt, horizon)
     p2, v2, a2 = eng.trajectory_rollout(params, ip, iv, spec, q2, qd2, n_steps=seg, init_time=0.1)

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""
+The fused closed-loop step (BlackBoxWrapper.step on the GPU-resident double integrator) per kernel variant:
+  full   mpk_trajectory_rollout, cfg2 shape, all 100 steps executed
+  plan   mpk_replan_step, cfg4 shape (P = 35, 25 of 100 steps executed, condition gather, integer state)
+timed as a captured graph of 20 launches (HIP events), per batch size and per option set.
+    python tools/closed_bench.py [B ...]        (MPK_LIB=<other build> for A/B runs of two builds)
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from fancy_gym_amd import RolloutSpec, TrajectoryEngine, _lib  # noqa: E402
+
+PG = 0.01 * np.array([120., 120., 120., 120., 50., 30., 10.])
+DG = 0.01 * np.array([10., 10., 10., 10., 6., 5., 3.])
+CFG2 = dict(mp_type="prodmp", phase_type="exp", basis_type="prodmp", num_dof=7, num_basis=5, dt=0.02, duration=2.0,
+            tau=1.5, alpha_phase=3.0, basis_bandwidth_factor=2.0, basis_alpha=10.0)
+CFG4 = dict(CFG2, basis_bandwidth_factor=3.0, weights_scale=0.3, goal_scale=0.3, auto_scale_basis=True, disable_goal=True)
+
+
+def graph_time(fn, reps=20, rounds=7):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(reps):
+                fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for _ in range(5):
+        g.replay()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(rounds):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); g.replay(); b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) * 1e-3 / reps)
+    return float(np.median(ts))
+
+
+def main():
+    batches = [int(a) for a in sys.argv[1:] if a.isdigit()] or [2048, 4096, 8192, 16384]
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(0)
+    variants = [("auto", {}), ("pipe=0", {"pipe": 0}), ("split", {"split": 1}), ("duo", {"quad": 3}), ("mono", {"quad": 4})]
+    print(f"lib: {_lib.LIB_PATH}")
+    print("| step | batch | variant | kernel | us | episodes-or-plans/s | GB/s (alg.) | of 8 TB/s |")
+    print("|---|---|---|---|---|---|---|---|")
+    for B in batches:
+        for name, kw, P, nbytes in (("full", CFG2, 42, 224 + 3 * 2800), ("plan", CFG4, 35, 196 + 3 * 2800)):
+            eng = TrajectoryEngine(device=0, **kw)
+            params = torch.randn((B, P), generator=g).to(dev)
+            ip = (torch.rand((B, 7), generator=g) * 2 - 1).to(dev)
+            iv = torch.zeros((B, 7), device=dev)
+            spec = RolloutSpec("motor", 7, PG, DG, -1.0, 1.0, plant="double_integrator", dt=0.02)
+            q, qd = ip.double().contiguous(), iv.double().contiguous()
+            out = tuple(torch.empty((B, 100, 7), device=dev) for _ in range(3))
+            ts = torch.zeros(B, dtype=torch.int32, device=dev)
+            ps = torch.zeros(B, dtype=torch.int32, device=dev)
+            dn = torch.zeros(B, dtype=torch.uint8, device=dev)
+            if name == "full":
+                fn = lambda: eng.trajectory_rollout(params, ip, iv, spec, q, qd, out=out)      # noqa: E731
+            else:
+                # horizon / planning budget out of reach: every call executes the 25 steps up to the next multiple of 25,
+                # like each of cfg4's four plans, without memsets of the integer state inside the timed graph
+                def fn():
+                    eng.replan_step(params, ip, iv, spec, q, qd, ts, ps, dn, 25, 2 ** 30, 2 ** 30, condition=True, out=out)
+            for vn, opts in variants:
+                _lib.reset_options()
+                for k, v in opts.items():
+                    _lib.set_option(k, v)
+                try:
+                    t = graph_time(fn)
+                except Exception as e:  # noqa: BLE001
+                    print(f"| {name} | {B} | {vn} | failed: {e} |")
+                    continue
+                if name == "plan":
+                    # the three tiny memsets of the integer state ride in the graph: subtract nothing, report as is
+                    pass
+                print(f"| {name} | {B} | {vn} | `{eng.last_kernel()}` | {t * 1e6:.2f} | {B / t:.3e} | "
+                      f"{B * nbytes / t / 1e9:.0f} | {B * nbytes / t / 8e12 * 100:.1f} % |")
+            _lib.reset_options()
+            del eng, out
+
+
+if __name__ == "__main__":
+    main()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Run one BASELINE configuration N times (for rocprofv3):  python tools/run_cfg.py <cfg2|cfg2act|cfg2closed|cfg3|cfg4|cfg5|cfg5tau|cfg2tau> B N"""
+"""Run one BASELINE configuration N times (for rocprofv3):  python tools/run_cfg.py <cfg2|cfg2act|cfg2closed|cfg3|cfg4|cfg5|cfg5tau|cfg2tau> B N [option=value ...]"""
 import os
 import sys
 
@@ -36,6 +36,10 @@ KW = {
 
 def main():
     name, B, N = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    from fancy_gym_amd import _lib
+    for kv in sys.argv[4:]:                     # kernel-selection overrides: key=value (mpk_set_option)
+        k, v = kv.split("=")
+        _lib.set_option(k, int(v))
     base = name.replace("act", "").replace("closed", "")
     torch.cuda.set_device(0)
     eng = TrajectoryEngine(device=0, **KW[base])

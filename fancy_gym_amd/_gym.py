@@ -59,7 +59,32 @@ except Exception:  # noqa: BLE001
         def __repr__(self):
             return f"Box({self.low.min()}, {self.high.max()}, {self.shape}, {self.dtype})"
 
-    spaces = SimpleNamespace(Box=_Box)
+    class _Dict:
+        """the few features of gymnasium.spaces.Dict the path touches: ``.spaces`` (name -> space), contains, sample"""
+
+        def __init__(self, spaces=None, seed=None, **kw):
+            self.spaces = dict(spaces or {}, **kw)
+            self.dtype = None
+            self.shape = None
+
+        def sample(self):
+            return {k: sp.sample() for k, sp in self.spaces.items()}
+
+        def contains(self, x):
+            return isinstance(x, dict) and x.keys() == self.spaces.keys() and all(
+                self.spaces[k].contains(np.asarray(v, dtype=self.spaces[k].dtype).reshape(self.spaces[k].shape))
+                for k, v in x.items())
+
+        def __getitem__(self, k):
+            return self.spaces[k]
+
+        def __eq__(self, other):
+            return isinstance(other, _Dict) and self.spaces == other.spaces
+
+        def __repr__(self):
+            return "Dict(" + ", ".join(f"{k!r}: {v!r}" for k, v in self.spaces.items()) + ")"
+
+    spaces = SimpleNamespace(Box=_Box, Dict=_Dict)
 
     class Env:
         observation_space = None

@@ -106,6 +106,8 @@ SIGNATURES = {
     "mpk_traj_validity_penalty": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "mpk_prodmp_tables": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mpk_prodmp_indices": (C.c_int, [_vp, _dbl, _vp, _vp, _vp]),
+    "mpk_scaled_basis": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
+    "mpk_selftest_division": (C.c_int, [_vp, C.c_float, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), _vp]),
     "mpk_host_prodmp_tables": (C.c_int, [C.POINTER(mpk_config), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mpk_host_rbf": (C.c_int, [C.POINTER(mpk_config), _vp, _vp]),
     "mpk_host_times": (C.c_int, [_dbl, _dbl, _vp, _i32]),

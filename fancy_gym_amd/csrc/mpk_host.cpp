@@ -323,6 +323,22 @@ static void fill_devcfg(Handle* h) {
     d.D = c.num_dof; d.nb = c.num_basis; d.n_total = h->tab.n_total;
     d.zs = c.basis_type == MPK_BASIS_ZERO_RBF ? c.num_basis_zero_start : 0;
     const bool zero_pad = c.basis_type == MPK_BASIS_ZERO_RBF;
+    {   // linear phase: centres equally spaced in phase, one bandwidth -> Gaussians by product recurrence, unless the first
+        // one could underflow before the recurrence climbs back (bw (n - 1)^2 D^2 / 2 beyond the float64 exponent range)
+        const HostTables& t = h->tab;
+        bool uni = c.basis_type != MPK_BASIS_PRODMP && c.phase_type == MPK_PHASE_LINEAR && t.n_total >= 2;
+        if (uni) {
+            const int n = t.n_total;
+            const double D = (t.centers[n - 1] - t.centers[0]) / (double)(n - 1);
+            for (int k = 0; k < n && uni; ++k)
+                uni = std::fabs(t.centers[k] - (t.centers[0] + k * D)) <= 1e-12 * std::fabs(D) * n &&
+                      std::fabs(t.bw[k] - t.bw[0]) <= 1e-12 * t.bw[0];
+            // phase in [0, 1] against centres that may lie outside it
+            const double span = std::fmax(std::fabs(1.0 - t.centers[0]), std::fabs(0.0 - t.centers[0])) + std::fabs(D) * n;
+            uni = uni && 0.5 * t.bw[0] * span * span < 600.0;
+        }
+        d.rbf_uniform = uni ? 1 : 0;
+    }
     d.relgoal_before_scale = c.relative_goal_mode == MPK_RELGOAL_BEFORE_SCALE ? 1 : 0;
     d.goal_off_on = c.mp_type == MPK_MP_PRODMP && c.goal_offset_mode == MPK_GOAL_OFFSET_ADD && c.goal_offset != 0.0 ? 1 : 0;
     d.goal_offset = (float)c.goal_offset;
@@ -534,11 +550,13 @@ int mpk_create(const mpk_config* cfg, mpk_handle* out) {
             if (cfg->auto_scale_basis) sc = (float)t.scale[k] * sc;
             packed.push_back((double)sc);
         }
-        // fp32 row table for the per-episode-phase kernel, one table index per row of 2*KS + 4 floats (KS = 8 or 16):
-        // [Psi_0 .. Psi_nb, 0.., y1, y2 | dPsi_0 .. dPsi_nb, 0.., dy1, dy2 | lo(y1) lo(y2) lo(dy1) lo(dy2)]
-        // y1, y2, dy1, dy2 sit in the LAST two columns of their halves (compile-time positions in the kernel) and carry a
-        // second float each (value = hi + lo to ~48 bits): the kernel forms the boundary-condition factors xi1..xi4 from
-        // them in float64, where rounding y1, y2 to fp32 first would be amplified by the cancellation c1*y1 + c2*y2.
+        // row table for the per-episode-phase kernel, one table index per row of 2*KS + 4 floats (KS = 8 or 16):
+        //   [(Psi_0, dPsi_0) (Psi_1, dPsi_1) .. (Psi_{KS-3}, dPsi_{KS-3}) | y1 y2 dy1 dy2]
+        // the position / velocity basis values as fp32 PAIRS (columns past nb are 0) -- the operand pairs of the packed fp32
+        // FMA that advances the position and the velocity chain in one instruction --, then y1, y2, dy1, dy2 as FLOAT64
+        // (two float slots each, 16-byte aligned): the kernel forms the boundary-condition factors xi1..xi4 from them in
+        // float64, where rounding y1, y2 to fp32 first would be amplified by the cancellation c1*y1 + c2*y2.  (Round 1 kept
+        // separate halves and hi + lo float pairs: two FMAs per k and three instructions per value and step to rebuild.)
         const int K = cfg->num_basis + 1;
         if (K + 2 <= 16) {
             const int KS = K + 2 <= 8 ? 8 : 16, RS = 2 * KS + 4;
@@ -547,21 +565,25 @@ int mpk_create(const mpk_config* cfg, mpk_handle* out) {
             for (int i = 0; i < t.n_pc; ++i) {
                 float* r = h->rows32.data() + (size_t)i * RS;
                 for (int kk = 0; kk < K; ++kk) {
-                    r[kk] = (float)t.pos_basis[(size_t)i * K + kk];
-                    r[KS + kk] = (float)t.vel_basis[(size_t)i * K + kk];
+                    r[2 * kk] = (float)t.pos_basis[(size_t)i * K + kk];
+                    r[2 * kk + 1] = (float)t.vel_basis[(size_t)i * K + kk];
                 }
                 const double v[4] = {t.y1[i], t.y2[i], t.dy1[i], t.dy2[i]};
-                float* const hi[4] = {r + KS - 2, r + KS - 1, r + 2 * KS - 2, r + 2 * KS - 1};
-                for (int j = 0; j < 4; ++j) {
-                    *hi[j] = (float)v[j];
-                    r[2 * KS + j] = (float)(v[j] - (double)*hi[j]);
-                }
+                std::memcpy(r + 2 * KS - 4, v, sizeof(v));
             }
         }
     } else {
         build_rbf(*cfg, h->tab);
         packed.insert(packed.end(), h->tab.centers.begin(), h->tab.centers.end());
         packed.insert(packed.end(), h->tab.bw.begin(), h->tab.bw.end());
+        {   // constants of the product recurrence (mpk_kernels.hip RbfRecur), used when rbf_uniform
+            const int n = h->tab.n_total;
+            const double D = n > 1 ? (h->tab.centers[n - 1] - h->tab.centers[0]) / (double)(n - 1) : 0.0;
+            const double bw0 = h->tab.bw[0];
+            packed.push_back(bw0 * D);
+            packed.push_back(0.5 * bw0 * D * D);
+            packed.push_back(std::exp(-bw0 * D * D));
+        }
     }
     auto fail = [&](int code) { free_handle(h); return code; };
     if (hipMalloc((void**)&h->d_tab, packed.size() * sizeof(double)) != hipSuccess) { set_error("hipMalloc(tables) failed"); return fail(MPK_EHIP); }
@@ -974,6 +996,49 @@ int mpk_prodmp_indices(mpk_handle hh, double init_time, int32_t* idx, int32_t* i
         if (e != hipSuccess) { set_error(hipGetErrorString(e)); rc = MPK_EHIP; }
     }
     (void)hipFree(st.A); (void)hipFree(st.aux);
+    return rc;
+}
+
+int mpk_scaled_basis(mpk_handle hh, const float* times, int32_t n, float* basis, void* stream) {
+    if (!hh || !times || !basis) { set_error("NULL argument"); return MPK_EINVAL; }
+    if (n < 0) { set_error("n must be >= 0"); return MPK_EINVAL; }
+    if (n == 0) return MPK_OK;
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    MPK_ON_DEVICE(h->cfg.device);
+    const int K = h->cfg.mp_type == MPK_MP_PRODMP ? h->cfg.num_basis + 1 : h->cfg.num_basis;
+    float *d_t = nullptr, *d_o = nullptr;
+    MPK_HIP(hipMalloc((void**)&d_t, sizeof(float) * n));
+    if (hipMalloc((void**)&d_o, sizeof(float) * (size_t)n * K) != hipSuccess) { (void)hipFree(d_t); set_error("hipMalloc failed"); return MPK_EHIP; }
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemcpyAsync(d_t, times, sizeof(float) * n, hipMemcpyHostToDevice, s);
+    int rc = e == hipSuccess ? launch_scaled_basis(h->dev, d_t, n, d_o, stream) : MPK_EHIP;
+    if (rc == MPK_OK) {
+        e = hipMemcpyAsync(basis, d_o, sizeof(float) * (size_t)n * K, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { set_error(hipGetErrorString(e)); rc = MPK_EHIP; }
+    }
+    (void)hipFree(d_t); (void)hipFree(d_o);
+    return rc;
+}
+
+int mpk_selftest_division(mpk_handle hh, float divisor, uint32_t first_bits, uint64_t count, uint64_t* mismatches,
+                          void* stream) {
+    if (!hh || !mismatches) { set_error("NULL argument"); return MPK_EINVAL; }
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (!(divisor > 0.0f) || !std::isfinite(divisor)) { set_error("divisor must be positive and finite"); return MPK_EINVAL; }
+    MPK_ON_DEVICE(h->cfg.device);
+    unsigned long long* d_bad = nullptr;
+    MPK_HIP(hipMalloc((void**)&d_bad, sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d_bad, 0, sizeof(unsigned long long), (hipStream_t)stream);
+    int rc = e == hipSuccess ? launch_div_sweep(divisor, first_bits, count, d_bad, stream) : MPK_EHIP;
+    unsigned long long bad = 0;
+    if (rc == MPK_OK) {
+        e = hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, (hipStream_t)stream);
+        if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+        if (e != hipSuccess) { set_error(hipGetErrorString(e)); rc = MPK_EHIP; }
+    }
+    (void)hipFree(d_bad);
+    *mismatches = bad;
     return rc;
 }
 

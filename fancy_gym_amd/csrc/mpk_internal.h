@@ -44,6 +44,7 @@ struct DevCfg {
     int P, Kloc, off;              // params per episode, local params per DoF, offset of the local block
     int T;
     int learn_tau, learn_delay, relative_goal, disable_goal, disable_weights;
+    int rbf_uniform;               // equally spaced centres, one bandwidth: Gaussians by product recurrence (RbfRecur)
     int relgoal_before_scale;      // MPK_RELGOAL_BEFORE_SCALE
     int goal_off_on;               // MPK_GOAL_OFFSET_ADD with a non-zero offset: one extra contraction column (x = 1)
     float goal_offset;
@@ -117,6 +118,9 @@ int launch_replan_advance(int32_t* traj_steps, int32_t* plan_steps, int32_t* seg
 int launch_validity(const float* pos, const float* params, int P, int D, const double* lo, const double* hi,
                     int check_td, const double* tb, const double* db, uint8_t* valid, double* penalty, int B, int T,
                     void* stream);
+
+int launch_scaled_basis(const DevCfg& c, const float* times, int n, float* out, void* stream);
+int launch_div_sweep(float d, uint32_t first, uint64_t count, unsigned long long* mismatches, void* stream);
 
 size_t shared_tables_floats(const DevCfg& c, int* TS, int* n_out);
 

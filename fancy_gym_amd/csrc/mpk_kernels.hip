@@ -23,6 +23,7 @@
 namespace mpk {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Development build only (-DMPK_TRACE): wave 0 of workgroup `MPK_TRACE_BLOCK` stamps the shader clock at labelled points
 // of a kernel into a device array that tools/dev/trace_kernel.py prints -- the per-phase timeline of ONE wave.
@@ -81,6 +82,24 @@ __device__ __forceinline__ TauDiv make_tau_div(float tau) { return TauDiv{tau, 1
 __device__ __forceinline__ float div_tau(float z, const TauDiv& t) {
     const float q = z * t.r;
     return __builtin_fmaf(__builtin_fmaf(-t.tau, q, z), t.r, q);
+}
+
+// The CORRECTLY ROUNDED fp32 quotient z / d for a divisor that is reused (an episode's tau, the table's grid step): the
+// reciprocal r = RN(1 / d) is taken once with an IEEE division; then
+//     q = RN(z * r),   e = RN(z - d * q)  (exact: one fma),   q' = RN(q + e * r)
+// is RN(z / d) whenever the significand of d is not all ones and nothing over- or underflows (Markstein 1990; Muller et
+// al., Handbook of Floating-Point Arithmetic, section 4.7: a correctly rounded reciprocal and a quotient estimate within
+// one ulp make the correction step exact).  The one excluded divisor pattern takes the IEEE division.  This feeds the
+// ProDMP table indices -- the integer part of the path -- so tests/test_gpu_edge_cases.py sweeps every fp32 numerator a
+// BASELINE time grid can produce against the IEEE division for 64 divisors (identical, 3 x 10^9 quotients).
+struct ExactDiv { float d, r; bool plain; };
+__device__ __forceinline__ ExactDiv make_exact_div(float d) {
+    return ExactDiv{d, 1.0f / d, (__float_as_uint(d) & 0x7fffffu) == 0x7fffffu};
+}
+__device__ __forceinline__ float div_exact(float z, const ExactDiv& x) {
+    if (x.plain) return z / x.d;                               // wave-uniform for a per-episode divisor
+    const float q = z * x.r;
+    return __builtin_fmaf(__builtin_fmaf(-x.d, q, z), x.r, q);
 }
 
 // The integer part of BlackBoxWrapper.step's loop (black_box_wrapper.py:174,197,206) for one episode and one plan:
@@ -262,6 +281,7 @@ struct ExpRegs {
 template <class CF>
 __device__ __forceinline__ double exp_nonpos(double x, const CF& cf) {
     x = fmax(x, -700.0);                                        // exp(-700) ~ 1e-304: still normal, rounds to 0.0f
+    // (arguments are <= 0 everywhere but in RbfRecur's ratio, which stays far below the overflow threshold)
     const double n = rint(x * cf[0]);
     double r = fma(n, cf[1], x);
     r = fma(n, cf[2], r);
@@ -291,10 +311,44 @@ __device__ __forceinline__ double phase_f64(const DevCfg& c, float time, float t
 
 
 
+// Equally spaced centres with one bandwidth (every linear-phase configuration: the centres are equally spaced in time,
+// SURVEY A.4): the Gaussians e_k = exp(-bw (x - c_k)^2 / 2), c_k = c_0 + k D, obey
+//     e_{k+1} = e_k r_k,   r_k = exp(bw D (x - c_k) - bw D^2 / 2),   r_{k+1} = r_k exp(-bw D^2)
+// -- TWO exponentials per row and two float64 multiplications per further basis function instead of one exponential
+// each (a row of cfg5's five RBFs: 60 % of its instructions were exponentials).  The products carry ~k 1e-16 relative
+// error, nine orders below the single rounding to fp32 that follows; every row builder on the device goes through the
+// same code, so the shared-phase and per-episode kernels keep producing identical bits.  The host enables it
+// (DevCfg::rbf_uniform) only where e_0 cannot underflow; constants behind the bandwidths in the device table:
+// [bw D, bw D^2 / 2, exp(-bw D^2)].
+struct RbfRecur {
+    double e, r, q;
+    template <class CF>
+    __device__ __forceinline__ RbfRecur(const double* cen, const double* bw, int n_total, double x, const CF& cf) {
+        const double* k3 = bw + n_total;
+        const double dx0 = x - cen[0];
+        e = exp_nonpos(-(dx0 * dx0 * bw[0]) * 0.5, cf);
+        r = exp_nonpos(k3[0] * dx0 - k3[1], cf);
+        q = k3[2];
+    }
+    __device__ __forceinline__ double next() { const double v = e; e *= r; r *= q; return v; }
+};
+
 // normalised RBF row: writes nb learnable columns scaled by `mul` (column zs.. of the zero-padded family)
 __device__ __forceinline__ void rbf_cols(const DevCfg& c, double x, double mul, float* out, int stride) {
     const double* cen = c.tab;
     const double* bw = c.tab + c.n_total;
+    if (c.rbf_uniform) {
+        RbfRecur s1(cen, bw, c.n_total, x, ExpLiteral());
+        double sum = 0.0;
+        for (int k = 0; k < c.n_total; ++k) sum += s1.next();
+        const double scale = div_pos(mul, sum);
+        RbfRecur s2(cen, bw, c.n_total, x, ExpLiteral());
+        for (int k = 0; k < c.zs + c.nb; ++k) {
+            const double ek = s2.next();
+            if (k >= c.zs) out[(size_t)(k - c.zs) * stride] = (float)(ek * scale);
+        }
+        return;
+    }
     double sum = 0.0;
     for (int k = 0; k < c.n_total; ++k) {
         const double dx = x - cen[k];
@@ -317,6 +371,14 @@ __device__ __forceinline__ void rbf_row(const DevCfg& c, const double* cen, cons
     if (c.zs <= 2 && c.n_total <= NE) {
         // every RBF once: the learnable columns are e[zs .. zs + nb)
         double e[NE], sum = 0.0;
+        if (c.rbf_uniform) {
+            RbfRecur rr(cen, bw, c.n_total, x, cf);          // the same operations as rbf_cols: same bits
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                e[k] = 0.0;
+                if (k < c.n_total) { e[k] = rr.next(); sum += e[k]; }
+            }
+        } else {
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
             e[k] = 0.0;
@@ -325,6 +387,7 @@ __device__ __forceinline__ void rbf_row(const DevCfg& c, const double* cen, cons
                 e[k] = exp_nonpos(-(dx * dx * bw[k]) * 0.5, cf);
                 sum += e[k];
             }
+        }
         }
         const double scale = c.n_total > 1 ? div_pos(mul, sum) : mul;
 #pragma unroll
@@ -335,6 +398,20 @@ __device__ __forceinline__ void rbf_row(const DevCfg& c, const double* cen, cons
             } else if (k == c.nb && c.KT > c.nb) {
                 h[k] = 1.0f;
             }
+        }
+        return;
+    }
+    if (c.rbf_uniform) {
+        RbfRecur s1(cen, bw, c.n_total, x, cf);
+        double sum = 0.0;
+        for (int k = 0; k < c.n_total; ++k) sum += s1.next();
+        const double scale = div_pos(mul, sum);
+        RbfRecur s2(cen, bw, c.n_total, x, cf);
+        for (int k = 0; k < c.zs; ++k) (void)s2.next();
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            if (k < c.nb) h[k] = (float)(s2.next() * scale);
+            else if (k == c.nb && c.KT > c.nb) h[k] = 1.0f;
         }
         return;
     }
@@ -804,7 +881,6 @@ __device__ __forceinline__ void store16(float* p, const f32x4& v) {
     }
 }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <bool WT>
 __device__ __forceinline__ void store8(float* p, const f32x2& v) {
     if (WT) {
@@ -917,6 +993,7 @@ __device__ __forceinline__ void tiles_body(const TrajArgs& a, float* smem, const
     int g = a.nrt_magic ? (int)__umulhi((unsigned)wid, a.nrt_magic) : wid;      // magic 0: NRT == 1
     const int rt = wid - g * NRT;
     if (g >= a.G) return;
+    MPK_STAMP(1);
     // first group's inputs and the controller constants: issued before everything else (latency-bound prologue)
     GroupIn<KM> cur = load_group<MP, ACT, KM>(a, L, g);
     Gains kg{0.0, 0.0, 0.0, 0.0};
@@ -937,6 +1014,7 @@ __device__ __forceinline__ void tiles_body(const TrajArgs& a, float* smem, const
     float xb[KM];
     finish_group<KM>(L, cur, xb);
     double cp = cur.cp, cv = cur.cv;
+    MPK_STAMP(2);
     while (g < a.G) {
         // 1. issue the NEXT group's loads (consumed at the bottom of this iteration)
         const int gn = g + gstride;
@@ -953,13 +1031,20 @@ __device__ __forceinline__ void tiles_body(const TrajArgs& a, float* smem, const
         if (L.dvalid)
             tile_epilogue<MP, CT>(acc0, acc1, acc2, dtd, cp, cv, kg, sSt, L.wofs + ep_shift(a, g * L.NTW + L.bl), D);
         __builtin_amdgcn_wave_barrier();
+        MPK_STAMP(10);
         tile_store<NST, KM, WT>(a, L, sSt, lane, g * L.NTW, rt, rows);
         __builtin_amdgcn_wave_barrier();
+        MPK_STAMP(11);
         // 5. finish the prefetched fragments for the next iteration
         finish_group<KM>(L, nxt, xb);
         cp = nxt.cp; cv = nxt.cv;
         g = gn;
     }
+#ifdef MPK_TRACE
+    MPK_STAMP(20);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every store of this wave acknowledged
+    MPK_STAMP(21);
+#endif
 }
 
 #ifndef MPK_TILES_OCC
@@ -2478,7 +2563,7 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
     float* sWgs = smem;                                 // prodmp: weights_goal_scale[nb + 1] (in place of sCen)
     for (int t = threadIdx.x; t < T; t += blockDim.x) sBT[t] = c.base_times[t];
     if (MP != MPK_MP_PRODMP) {
-        for (int k = threadIdx.x; k < 2 * c.n_total; k += blockDim.x) sCen[k] = c.tab[k];
+        for (int k = threadIdx.x; k < 2 * c.n_total + 3; k += blockDim.x) sCen[k] = c.tab[k];
     } else {
         const double* S = c.tab + 4 * (size_t)c.n_pc + 2 * (size_t)c.n_pc * (c.nb + 1);
         for (int k = threadIdx.x; k <= c.nb; k += blockDim.x) {
@@ -2494,7 +2579,8 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
     }
     __syncthreads();
     const float* const rows = TL ? sTab : c.rows32;
-    constexpr int kRow = 2 * KS + 4;    // [pos half | vel half | lo parts of y1 y2 dy1 dy2]
+    constexpr int kRow = 2 * KS + 4;    // [pos half .. y1 (f64) | vel half .. y2 (f64) | dy1 dy2 (f64)]
+    const ExactDiv dsdt = make_exact_div(c.scaled_dt);
 
     // A wave owns chunks of E consecutive episodes.  A chunk's inputs -- E parameter rows, E boundary positions /
     // velocities, E init_times: each one contiguous run -- are fetched with coalesced loads one chunk ahead and
@@ -2550,6 +2636,9 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
             const float it = img[E * P + 2 * E * D + e];
             float inv_tau = 0.0f;
             double bca = 0.0, bcb = 0.0, bcc = 0.0, bcd = 0.0;    // dy2_b, dy1_b, y1_b, y2_b over det (see prodmp_bc)
+            // table index = round(max((t - delay) / tau, 0) / scaled_dt): both quotients correctly rounded (div_exact), the
+            // reciprocals taken once per episode / kernel instead of two IEEE divisions per step
+            const ExactDiv dtau = make_exact_div(tau);
             if (MP == MPK_MP_PRODMP) {
                 // Boundary conditions (SURVEY A.5 / mp_pytorch ProDMP), regrouped so that nothing large cancels in fp32:
                 //   pos = xi1 * (y_b - Psi_b.wg) + xi2 * (tau ydot_b - dPsi_b.wg) + Psi.wg
@@ -2557,14 +2646,14 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
                 // wg = scale * [w; g] in fp32 as the reference does and the two residuals in float64; the lane's finished
                 // column [wg_0 .. wg_{K-1}, 0.., r1, r2] goes to sXf.  xi1..xi4 are per (episode, step): the step's lane
                 // forms them below in float64 from the hi + lo table values and the factors kept here.
-                const float sb = scaled_time(it, delay, tau);
-                const int idxb = min(prodmp_index(sb, c.scaled_dt), c.n_pc - 1);
-                inv_tau = 1.0f / tau;
+                const float sb = fmaxf(div_exact(it - delay, dtau), 0.0f);
+                const int idxb = min((int)rintf(div_exact(sb, dsdt)), c.n_pc - 1);
+                inv_tau = dtau.r;
                 const float* rb = rows + (size_t)idxb * kRow;
                 {
-                    const float4 lo = *reinterpret_cast<const float4*>(rb + 2 * KS);
-                    const double y1b = (double)rb[KS - 2] + (double)lo.x, y2b = (double)rb[KS - 1] + (double)lo.y;
-                    const double dy1b = (double)rb[2 * KS - 2] + (double)lo.z, dy2b = (double)rb[2 * KS - 1] + (double)lo.w;
+                    // y1, y2, dy1, dy2 sit behind the (Psi_k, dPsi_k) pairs as float64 (see mpk_create)
+                    const double* yb4 = reinterpret_cast<const double*>(rb + 2 * KS - 4);
+                    const double y1b = yb4[0], y2b = yb4[1], dy1b = yb4[2], dy2b = yb4[3];
                     const double idet = div_pos(1.0, y1b * dy2b - y2b * dy1b);      // det = y1_b^2 > 0
                     bca = dy2b * idet; bcb = dy1b * idet; bcc = y1b * idet; bcd = y2b * idet;
                 }
@@ -2588,8 +2677,8 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
                                 if (c.relative_goal) wg = c.relgoal_before_scale ? ((have ? loc[li] : 0.0f) + yb) * sWgs[c.nb + 1] : wg + yb;
                                 if (c.goal_off_on) wg = wg + c.goal_offset;
                             }
-                            pb += (double)rb[k] * (double)wg;
-                            vb += (double)rb[KS + k] * (double)wg;
+                            pb += (double)rb[2 * k] * (double)wg;
+                            vb += (double)rb[2 * k + 1] * (double)wg;
                         }
                         xf[k] = wg;
                     }
@@ -2613,27 +2702,28 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
                 const bool final_round = T - r0 <= 64;
                 const int nout = final_round ? T - r0 : kStep;
                 const int t = r0 + lane < T ? r0 + lane : T - 1;
-                float h[KS], hv[KS], rdt = 0.0f;
+                // prodmp: hq = (Psi_k, dPsi_k) pairs, as the table row holds them -- the position and velocity chains then are
+                // ONE packed fp32 FMA per k (v_pk_fma_f32) instead of two; promp: h = the lane's RBF row
+                float h[KS], hq[MP == MPK_MP_PRODMP ? 2 * KS : 2], rdt = 0.0f;
                 const float time = sBT[t] + it;
                 if (MP == MPK_MP_PRODMP) {
-                    const float s = scaled_time(time, delay, tau);
+                    const float s = fmaxf(div_exact(time - delay, dtau), 0.0f);
                     if (s > (float)c.len_factor) atomicOr(a.flag, 1);
-                    const int idx = min(prodmp_index(s, c.scaled_dt), c.n_pc - 1);
+                    const int idx = min((int)rintf(div_exact(s, dsdt)), c.n_pc - 1);
                     const float4* row = reinterpret_cast<const float4*>(rows + (size_t)idx * kRow);
 #pragma unroll
-                    for (int j = 0; j < KQ; ++j) {
-                        const float4 p4 = row[j], v4 = row[KQ + j];
-                        h[4 * j] = p4.x; h[4 * j + 1] = p4.y; h[4 * j + 2] = p4.z; h[4 * j + 3] = p4.w;
-                        hv[4 * j] = v4.x; hv[4 * j + 1] = v4.y; hv[4 * j + 2] = v4.z; hv[4 * j + 3] = v4.w;
+                    for (int j = 0; j < (2 * KS - 4) / 4; ++j) {
+                        const float4 q4 = row[j];
+                        hq[4 * j] = q4.x; hq[4 * j + 1] = q4.y; hq[4 * j + 2] = q4.z; hq[4 * j + 3] = q4.w;
                     }
-                    // the last two columns arrive as (y1, y2) / (dy1, dy2): turn them into (xi1, xi2) / (xi3, xi4)
-                    const float4 lo = row[2 * KQ];
-                    const double y1 = (double)h[KS - 2] + (double)lo.x, y2 = (double)h[KS - 1] + (double)lo.y;
-                    const double dy1 = (double)hv[KS - 2] + (double)lo.z, dy2 = (double)hv[KS - 1] + (double)lo.w;
-                    h[KS - 2] = (float)(bca * y1 - bcb * y2);
-                    h[KS - 1] = (float)(bcc * y2 - bcd * y1);
-                    hv[KS - 2] = (float)(bca * dy1 - bcb * dy2);
-                    hv[KS - 1] = (float)(bcc * dy2 - bcd * dy1);
+                    // y1, y2, dy1, dy2 as float64 behind the pairs: turn them into (xi1, xi3) and (xi2, xi4), the pairs of
+                    // the two boundary-condition columns
+                    const double* y4 = reinterpret_cast<const double*>(row + (2 * KS - 4) / 4);
+                    const double y1 = y4[0], y2 = y4[1], dy1 = y4[2], dy2 = y4[3];
+                    hq[2 * KS - 4] = (float)(bca * y1 - bcb * y2);
+                    hq[2 * KS - 3] = (float)(bca * dy1 - bcb * dy2);
+                    hq[2 * KS - 2] = (float)(bcc * y2 - bcd * y1);
+                    hq[2 * KS - 1] = (float)(bcc * dy2 - bcd * dy1);
                 } else {
                     const double x = phase_f64(c, time, tau, delay, ec);
 #pragma unroll
@@ -2645,7 +2735,6 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
                 if (more && e == ne - 1 && r0 == 0) park_chunk(sImg + (slot ^ 1) * img_floats);
                 float* const gp = out_pos + (size_t)r0 * D;
                 const int sh = (int)((reinterpret_cast<uintptr_t>(gp) >> 2) & 3);
-                const bool keep = lane < nout;
                 for (int d = 0; d < D; ++d) {
                     float x[KS];
 #pragma unroll
@@ -2654,22 +2743,23 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
                         x[4 * j + 0] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
                     }
                     float p = 0.0f, v = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < KS; ++k) p = fmaf(h[k], x[k], p);
                     if (MP == MPK_MP_PRODMP) {
+                        f32x2 pv = {0.0f, 0.0f};        // (pos, vel) chains, ascending k: one v_pk_fma_f32 per k
 #pragma unroll
-                        for (int k = 0; k < KS; ++k) v = fmaf(hv[k], x[k], v);
-                        v = v * inv_tau;
+                        for (int k = 0; k < KS; ++k)
+                            pv = __builtin_elementwise_fma(f32x2{hq[2 * k], hq[2 * k + 1]}, f32x2{x[k], x[k]}, pv);
+                        p = pv[0];
+                        v = pv[1] * inv_tau;
                     } else {
+#pragma unroll
+                        for (int k = 0; k < KS; ++k) p = fmaf(h[k], x[k], p);
                         const float nx = __shfl_down(p, 1);
                         v = (nx - p) * rdt;
                         const float pv = __shfl_up(v, 1);      // last row repeats the difference before it
                         if (r0 + lane == T - 1) v = pv;
                     }
-                    if (keep) {
-                        sO0[sh + lane * D + d] = p;
-                        sO1[sh + lane * D + d] = v;
-                    }
+                    sO0[sh + lane * D + d] = p;        // every lane: the staging holds 64 rows, rows >= nout never leave
+                    sO1[sh + lane * D + d] = v;
                 }
                 __builtin_amdgcn_wave_barrier();
                 if (a.wt) {
@@ -2811,7 +2901,7 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
         pa.img_pad = (E * (c.P + 2 * c.D + 1) + 3) / 4 * 4;
         pa.wave_floats = 2 * pa.img_pad + 2 * pa.o_pad + pa.x_pad;
     }
-    pa.c_pad = c.mp_type == MPK_MP_PRODMP ? (c.nb + 2 + 3) / 4 * 4 : (4 * c.n_total + 3) / 4 * 4;
+    pa.c_pad = c.mp_type == MPK_MP_PRODMP ? (c.nb + 2 + 3) / 4 * 4 : (4 * c.n_total + 6 + 3) / 4 * 4;
     const size_t wave_bytes = (size_t)pa.wave_floats * sizeof(float);
     size_t shared_bytes = (size_t)(pa.t_pad + pa.c_pad) * sizeof(float);
     if (wave_bytes + shared_bytes > 160 * 1024) return MPK_ENOTIMPL;
@@ -3591,6 +3681,61 @@ int launch_validity(const float* pos, const float* params, int P, int D, const d
     v.check_td = check_td; v.P = P; v.D = D; v.B = B; v.T = T;
     hipLaunchKernelGGL(k_validity, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, v, pos, params, valid,
                        penalty);
+    MPK_LAUNCH_CHECK();
+    return MPK_OK;
+}
+#endif  // MPK_DEVICE_ONLY
+
+// ------------------------------------------------------------------------------------------------------------
+// k_scaled_basis: traj_gen.show_scaled_basis (examples/mp_params_tuning.py:7) -- the basis functions times their
+// parameter scale at arbitrary times, evaluated by the row functions the trajectory kernels use
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_scaled_basis(const DevCfg c, const float* __restrict__ times, const int n,
+                                                      float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float t = times[i];
+    if (c.mp_type == MPK_MP_PRODMP) {
+        const int N = c.n_pc, K = c.nb + 1;
+        const double* PB = c.tab + 4 * (size_t)N;
+        const double* S = PB + 2 * (size_t)N * K;
+        const float s = scaled_time(t, c.delay, c.tau);
+        const int idx = min(prodmp_index(s, c.scaled_dt), N - 1);
+        for (int k = 0; k < K; ++k) out[(size_t)i * K + k] = (float)PB[(size_t)idx * K + k] * (float)S[k];
+    } else {
+        const double x = phase_f64(c, t, c.tau, c.delay, ExpLiteral());
+        rbf_cols(c, x, (double)c.ws, out + (size_t)i * c.nb, 1);
+    }
+}
+
+#ifndef MPK_DEVICE_ONLY
+int launch_scaled_basis(const DevCfg& c, const float* times, int n, float* out, void* stream) {
+    hipLaunchKernelGGL(k_scaled_basis, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, c, times, n, out);
+    MPK_LAUNCH_CHECK();
+    return MPK_OK;
+}
+#endif  // MPK_DEVICE_ONLY
+
+// ------------------------------------------------------------------------------------------------------------
+// self-test of div_exact (the table-index arithmetic): every fp32 numerator bit pattern in [first, first + count) against
+// the IEEE division, for one divisor
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_div_sweep(const float d, const uint32_t first, const uint64_t count,
+                                                   unsigned long long* __restrict__ mismatches) {
+    const ExactDiv x = make_exact_div(d);
+    unsigned long long bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256) {
+        const float z = __uint_as_float(first + (uint32_t)i);
+        const float q0 = z / d, q1 = div_exact(z, x);
+        // identical bits, or both NaN (numerators that are NaN / inf are outside any time grid but harmless)
+        if (__float_as_uint(q0) != __float_as_uint(q1) && !(q0 != q0 && q1 != q1)) ++bad;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+#ifndef MPK_DEVICE_ONLY
+int launch_div_sweep(float d, uint32_t first, uint64_t count, unsigned long long* mismatches, void* stream) {
+    hipLaunchKernelGGL(k_div_sweep, dim3(4096), dim3(256), 0, (hipStream_t)stream, d, first, count, mismatches);
     MPK_LAUNCH_CHECK();
     return MPK_OK;
 }

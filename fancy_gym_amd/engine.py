@@ -463,5 +463,13 @@ class TrajectoryEngine:
                                                 self._stream()))
         return idx, int(ib[0])
 
+    def scaled_basis(self, times) -> np.ndarray:
+        """basis functions x their parameter scale at ``times`` [n] -> float32 [n, K] (mpk.h: mpk_scaled_basis)"""
+        t = np.ascontiguousarray(np.asarray(times, np.float32).reshape(-1))
+        K = self.config.num_basis + (1 if self.mp_type == "prodmp" else 0)
+        out = np.empty((t.shape[0], K), np.float32)
+        _lib.check(self._lib.mpk_scaled_basis(self._h, t.ctypes.data, int(t.shape[0]), out.ctypes.data, self._stream()))
+        return out
+
     def last_kernel(self) -> str:
         return self._lib.mpk_last_kernel(self._h).decode()

@@ -150,6 +150,29 @@ class MPInterface:
         # mp_pytorch hands to fancy_gym's get_numpy on its default device
         self._pos, self._vel = eng.trajectory_host(self._full_params(), ip, iv, it)
 
+    def show_scaled_basis(self, plot: bool = False):
+        """
+        mp_pytorch's inspection helper the reference's examples call (fancy_gym/examples/mp_params_tuning.py:7): the basis
+        functions times their parameter scale on 1000 times from ``delay - tau`` to ``delay + 2 tau``, evaluated by the
+        device row functions (mpk_scaled_basis).  Returns ``(times [1000], basis [1000, K])`` as numpy arrays; ``plot=True``
+        additionally draws them with matplotlib as upstream does.
+        """
+        tau, delay = float(self.phase_gn._tau0), float(self.phase_gn._delay0)
+        times = np.linspace(delay - tau, delay + 2 * tau, 1000, dtype=np.float32)
+        if self.duration is None:
+            self.set_duration(tau, 0.01)          # any grid: the basis is evaluated at `times`, not on the plan's grid
+        basis = self.engine().scaled_basis(times)
+        if plot:  # pragma: no cover - needs a display
+            import matplotlib.pyplot as plt
+            plt.figure()
+            for i in range(basis.shape[-1]):
+                plt.plot(times, basis[:, i], label=f"w_basis_{i}")
+            plt.grid(); plt.legend()
+            plt.axvline(x=delay, linestyle="--", color="k", alpha=0.3)
+            plt.axvline(x=delay + tau, linestyle="--", color="k", alpha=0.3)
+            plt.show()
+        return times, basis
+
     def get_traj_pos(self, **_ignored) -> torch.Tensor:
         if self._pos is None:
             self._compute()

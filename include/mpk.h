@@ -393,6 +393,26 @@ int mpk_prodmp_tables(mpk_handle h, double* y1, double* y2, double* dy1, double*
 int mpk_prodmp_indices(mpk_handle h, double init_time, int32_t* idx, int32_t* idx_init, void* stream);
 
 /*
+ * Replaces traj_gen.show_scaled_basis() (examples/mp_params_tuning.py:7; listed in the drop-in surface): the basis
+ * functions times their parameter scale at `n` arbitrary times, evaluated on the device by the row functions of the
+ * trajectory kernels with the construction-time tau / delay:
+ *   promp / dmp : basis [n, num_basis]      normalised RBFs (the learnable ones of a zero-padded family) x weights_scale
+ *   prodmp      : basis [n, num_basis + 1]  position basis at the table index of each time x weights_goal_scale
+ * times, basis: HOST float arrays.  A plotting / inspection helper: allocates, synchronises `stream`.
+ */
+int mpk_scaled_basis(mpk_handle h, const float* times, int32_t n, float* basis, void* stream);
+
+/*
+ * Self-test of the table-index arithmetic.  The per-episode-phase ProDMP kernel replaces the two IEEE divisions of
+ * times_to_indices -- (t - delay) / tau and scaled_time / scaled_dt -- by a reciprocal taken once and one correction step
+ * that yields the correctly rounded quotient (Markstein); the indices are the bit-exact part of the path, so the claim is
+ * checkable: for `divisor`, every numerator whose fp32 bit pattern lies in [first_bits, first_bits + count) is divided
+ * both ways on the device; *mismatches receives the number of quotients whose bits differ.  Synchronises `stream`.
+ */
+int mpk_selftest_division(mpk_handle h, float divisor, uint32_t first_bits, uint64_t count, uint64_t* mismatches,
+                          void* stream);
+
+/*
  * Device-free views of the construction-time host logic (no GPU needed; used by the CPU test-suite):
  *   mpk_host_prodmp_tables : the float64 ProDMP pre-compute for `cfg` (same outputs as mpk_prodmp_tables, plus the
  *                            fp32 grid step `scaled_dt`); pass all-NULL outputs to query N.  Returns N or <0.

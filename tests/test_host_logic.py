@@ -532,3 +532,43 @@ def test_oracle_switches_change_what_they_say_they_change():
     b = O.get_trajectory(pc, bc, dataclasses.replace(tt, relative_goal_mode="before_scale"), p8, 2.0, 0.02, 0.0, ip, iv,
                          dtype=np.float64)[0]
     np.testing.assert_allclose(a, b, atol=2e-6)
+
+
+def test_time_aware_observation_box_and_dict_branches():
+    """utils/wrappers.py:11-87: Box -> one more entry in [0, 1]; Dict -> the entry 'time_awareness' (float64 Box(0, 1));
+    enforce_dtype_float32 asserts the dtype"""
+    from types import SimpleNamespace
+    from fancy_gym_amd._gym import Env, spaces
+    from fancy_gym_amd.utils.wrappers import TimeAwareObservation
+
+    class _E(Env):
+        spec = SimpleNamespace(max_episode_steps=4)
+
+        def __init__(self, space, obs):
+            self.observation_space, self._obs = space, obs
+            self.action_space = spaces.Box(-1, 1, (1,))
+
+        def reset(self, *, seed=None, options=None):
+            return self._obs, {}
+
+        def step(self, action):
+            return self._obs, 1.0, False, False, {}
+
+    box = TimeAwareObservation(_E(spaces.Box(-2.0, 2.0, (3,), np.float32), np.zeros(3, np.float32)))
+    assert box.observation_space.shape == (4,) and box.observation_space.low[-1] == 0 and box.observation_space.high[-1] == 1
+    obs, _ = box.reset()
+    assert obs.shape == (4,) and obs[-1] == 0.0
+    assert box.step(np.zeros(1))[0][-1] == 0.25 and box.step(np.zeros(1))[0][-1] == 0.5
+    d = spaces.Dict({"a": spaces.Box(-1, 1, (2,), np.float32), "b": spaces.Box(0, 5, (1,), np.float64)})
+    raw = {"a": np.zeros(2, np.float32), "b": np.ones(1)}
+    dic = TimeAwareObservation(_E(d, raw))
+    assert set(dic.observation_space.spaces) == {"a", "b", "time_awareness"}
+    ta = dic.observation_space.spaces["time_awareness"]
+    assert ta.dtype == np.float64 and float(ta.low) == 0.0 and float(ta.high) == 1.0
+    obs, _ = dic.reset()
+    assert obs["time_awareness"] == 0.0 and obs is not raw and "time_awareness" not in raw
+    assert dic.step(np.zeros(1))[0]["time_awareness"] == 0.25
+    assert dic.observation_space.contains(dic.step(np.zeros(1))[0])
+    with pytest.raises(AssertionError, match="float32"):
+        TimeAwareObservation(_E(spaces.Box(-1, 1, (2,), np.float64), np.zeros(2)), enforce_dtype_float32=True)
+    TimeAwareObservation(_E(spaces.Box(-1, 1, (2,), np.float32), np.zeros(2, np.float32)), enforce_dtype_float32=True)

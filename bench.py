@@ -105,30 +105,43 @@ def cpu_baseline(seconds: float, batch: int):
         one(slice(i, i + 1)); m += 1
     ref_style = m / (time.perf_counter() - t1)
     # (iii) BASELINE.md section 3 "CPU-batched": the same restated path with torch-CPU ops on every host core
+    # A batch of 4096 is small for a 256-thread box (oversubscribed it runs slower than one core), so the thread count is
+    # scanned and the best one reported next to nproc.
     from oracle.mp_torch_cpu import ProDMPBatchedCPU
     ncores = os.cpu_count() or 1
-    torch.set_num_threads(ncores)
     fn = ProDMPBatchedCPU(pc, bc, tc, 2.0, 0.02)
     tp, tip, tiv = torch.from_numpy(params), torch.from_numpy(ip), torch.from_numpy(iv)
     pg, dg = torch.from_numpy(P_GAINS), torch.from_numpy(D_GAINS)
     cpos, cvel = tip.double(), tiv.double()
-    for _ in range(5):
-        fn(tp, tip, tiv, 0.0, pg, dg, -1.0, 1.0, cpos, cvel)
-    reps = []
-    t2 = time.perf_counter()
-    while len(reps) < 20 or (time.perf_counter() - t2 < seconds * 0.3 and len(reps) < 2000):
-        r0 = time.perf_counter()
-        fn(tp, tip, tiv, 0.0, pg, dg, -1.0, 1.0, cpos, cvel)
-        reps.append(time.perf_counter() - r0)
-    all_cores = batch / float(np.median(reps))
+    best = None
+    scan = {}
+    for nt in sorted({ncores, max(1, ncores // 2), max(1, ncores // 4), 32, 16, 8, 4, 1} & set(range(1, ncores + 1))):
+        torch.set_num_threads(nt)
+        for _ in range(3):
+            fn(tp, tip, tiv, 0.0, pg, dg, -1.0, 1.0, cpos, cvel)
+        reps = []
+        t2 = time.perf_counter()
+        while len(reps) < 20 or (time.perf_counter() - t2 < seconds * 0.04 and len(reps) < 2000):
+            r0 = time.perf_counter()
+            fn(tp, tip, tiv, 0.0, pg, dg, -1.0, 1.0, cpos, cvel)
+            reps.append(time.perf_counter() - r0)
+            if time.perf_counter() - t2 > seconds * 0.08:
+                break
+        rate = batch / float(np.median(reps))
+        scan[nt] = rate
+        if best is None or rate > best[1]:
+            best = (nt, rate, len(reps))
+    torch.set_num_threads(1)
+    all_cores = best[1]
     return {"value": batched, "unit": "trajectories/s", "cores": 1, "kind": "port",
             "sample": f"numpy oracle (fp32), ProDMP 7-DoF/5 basis/100 steps + PD actions: {n} trajectories in "
                       f"batches of {batch} over {seconds * 0.6:.0f} s; reference-style B=1 Python loop: "
                       f"{ref_style:.0f} trajectories/s over {m} calls",
             "reference_style_b1": {"value": ref_style, "unit": "trajectories/s", "cores": 1, "calls": m},
-            "all_cores": {"value": all_cores, "unit": "trajectories/s", "cores": ncores, "kind": "port",
-                          "sample": f"oracle/mp_torch_cpu.py (torch-CPU einsum, {torch.get_num_threads()} threads), "
-                                    f"median of {len(reps)} calls of one batch of {batch}"}}
+            "all_cores": {"value": all_cores, "unit": "trajectories/s", "cores": best[0], "nproc": ncores, "kind": "port",
+                          "sample": f"oracle/mp_torch_cpu.py (torch-CPU einsum), batch of {batch} per call, median of "
+                                    f"{best[2]} calls at the best of the scanned thread counts",
+                          "threads_scan": {str(k): v for k, v in scan.items()}}}
 
 
 def synth_inputs(B: int, seed: int):
@@ -357,9 +370,35 @@ def main():
                                                  so[2].data_ptr(), Bs, sp)
                 if rc_ != 0:
                     raise RuntimeError(_lib.last_error())
-            for _ in range(5):
-                sstep()
-            torch.cuda.synchronize()
+            # the shader clock needs ~20 ms of streaming load to settle under the package power cap (tools/clock_probe.py:
+            # 449 us for the first 40 launches, 422 after), so the row is warmed for ~0.3 s; one rocm-smi sample taken
+            # meanwhile records the clocks / power the number was measured at (boxes differ)
+            smi = {}
+
+            def sample_smi():
+                try:
+                    import subprocess
+                    r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True,
+                                       text=True, timeout=5)
+                    card = next(iter(json.loads(r.stdout).values()))
+                    for k, v in card.items():
+                        if "sclk clock speed" in k or "mclk clock speed" in k or "fclk clock speed" in k:
+                            smi[k.split()[0] + "_mhz"] = int("".join(ch for ch in v if ch.isdigit()))
+                        elif "Power" in k:
+                            smi["package_power_w"] = float(v)
+                except Exception:  # noqa: BLE001 - the sample is optional
+                    pass
+            import threading
+            th = threading.Thread(target=sample_smi)
+            t_w = time.perf_counter()
+            th.start()
+            while time.perf_counter() - t_w < 0.3 or th.is_alive():
+                for _ in range(10):
+                    sstep()
+                torch.cuda.synchronize()
+                if time.perf_counter() - t_w > 3.0:
+                    break
+            th.join(timeout=5)
             Ks = 30
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
@@ -373,7 +412,7 @@ def main():
                          "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(Bs), "kernel": eng.last_kernel(),
                          "kernel_avg_us": ks_avg * 1e6, "batch": Bs, "launches": Ks,
                          "algorithmic_bytes_per_launch": BYTES_PER_TRAJ * Bs,
-                         "trajectories_per_s": Bs / ks_avg}
+                         "trajectories_per_s": Bs / ks_avg, "gpu_state_during_warmup": smi or None}
             del sp_, sip, siv, scp, scv, so
             torch.cuda.empty_cache()
         except Exception as e:  # noqa: BLE001

@@ -32,6 +32,16 @@ torch.set_num_threads(1)
 F = torch.float32
 
 
+def _sha256(path):
+    import hashlib
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+GENERATOR_SHA256 = _sha256(os.path.abspath(__file__))
+ORACLE_SHA256 = _sha256(os.path.join(ROOT, "oracle", "mp_oracle.py"))
+
+
 # ======================================================================================================================
 # second formulation: torch CPU fp32, mp_pytorch-style objects
 # ======================================================================================================================
@@ -291,7 +301,10 @@ def main():
         params, ip, iv = make_inputs(pc, bc, tc, B, seed=abs(hash(name)) % 1000 if False else len(name))
         out = dict(params=params, init_pos=ip, init_vel=iv, init_times=np.array(cfg["init_times"], np.float64),
                    meta=np.array("generated by tests/golden/make_golden.py from the restatement in oracle/mp_oracle.py "
-                                 "and an independent torch-CPU fp32 formulation; NOT from mp_pytorch (unavailable)"))
+                                 "and an independent torch-CPU fp32 formulation; NOT from mp_pytorch (unavailable)"),
+                   # provenance: the library versions the vectors were produced with and the exact generator script
+                   versions=np.array(f"numpy {np.__version__}; torch {torch.__version__}; python {sys.version.split()[0]}"),
+                   generator_sha256=np.array(GENERATOR_SHA256), oracle_sha256=np.array(ORACLE_SHA256))
         for k, it in enumerate(cfg["init_times"]):
             p32, v32 = O.get_trajectory(pc, bc, tc, params, duration, dt, it, ip, iv, dtype=np.float32)
             p64, v64 = O.get_trajectory(pc, bc, tc, params, duration, dt, it, ip, iv, dtype=np.float64)

@@ -408,11 +408,23 @@ def main():
             torch.cuda.synchronize()
             ks_avg = e0.elapsed_time(e1) * 1e-3 / Ks
             ach = BYTES_PER_TRAJ * Bs / ks_avg / 1e9
+            # the box's own ceiling beside it: a plain fill of the same three output arrays (boxes differ by up to 30 %
+            # on HBM-streaming launches with identical clocks; a slow box shows here too, a slow kernel does not)
+            for o in so:
+                o.fill_(1.0)
+            e0.record(stream)
+            for _ in range(10):
+                for o in so:
+                    o.fill_(1.0)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            fill_gbs = 10 * sum(o.numel() * 4 for o in so) / (e0.elapsed_time(e1) * 1e-3) / 1e9
             streaming = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(Bs), "kernel": eng.last_kernel(),
                          "kernel_avg_us": ks_avg * 1e6, "batch": Bs, "launches": Ks,
                          "algorithmic_bytes_per_launch": BYTES_PER_TRAJ * Bs,
-                         "trajectories_per_s": Bs / ks_avg, "gpu_state_during_warmup": smi or None}
+                         "trajectories_per_s": Bs / ks_avg, "box_fill_GBps": fill_gbs,
+                         "gpu_state_during_warmup": smi or None}
             del sp_, sip, siv, scp, scv, so
             torch.cuda.empty_cache()
         except Exception as e:  # noqa: BLE001

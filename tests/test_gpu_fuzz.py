@@ -3,6 +3,8 @@ GPU suite, part 4: seeded random configurations (movement primitive, DoF, basis 
 ProDMP flags, batch size, init_time, work decomposition) against the float64 oracle -- every kernel variant gets hit
 with shapes nobody hand-picked.
 """
+import dataclasses
+
 import numpy as np
 import pytest
 import torch
@@ -81,6 +83,15 @@ def test_random_configuration_matches_oracle(seed, monkeypatch, mpk_option):
         mpk_option("write_through", wt)
     else:
         mpk_option("write_through", -1)
+    # the Appendix-A options and the round-2 kernel options, from a generator of their own (cases keep their shapes)
+    r2 = np.random.default_rng(77_000 + seed)
+    mpk_option("pipe", int(r2.choice([-1, 0, 1])))
+    mpk_option("split", int(r2.choice([-1, 0, 1])))
+    if tc.trajectory_generator_type == "prodmp":
+        tc = dataclasses.replace(tc, relative_goal_mode=str(r2.choice(["after_scale", "before_scale"])),
+                                 goal_offset_mode=str(r2.choice(["ignore", "add"])), goal_offset=float(r2.uniform(-0.5, 0.5)))
+    elif tc.trajectory_generator_type == "dmp":
+        tc = dataclasses.replace(tc, dmp_first_sample=str(r2.choice(["init", "step"])))
     if tc.trajectory_generator_type == "prodmp":
         # keep the plan inside the pre-computed range (6 tau): reference raises otherwise
         tau_min = pc.tau_bound[0] if pc.learn_tau else pc.tau

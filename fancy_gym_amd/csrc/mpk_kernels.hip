@@ -31,17 +31,19 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef MPK_TRACE_BLOCK
 #define MPK_TRACE_BLOCK 0
 #endif
-__device__ long long g_trace[512];
-__device__ int g_trace_n;
-#define MPK_STAMP(tag)                                                                              \
+// slot = tag (< 256): a stamp is one s_memtime and one fire-and-forget store -- no counter to fetch, nothing to wait for
+// but the clock itself (a version that appended through a counter in memory paid a memory round trip per stamp and
+// stretched the traced wave by half).  A tag stamped repeatedly keeps its last value.
+__device__ long long g_trace[256];
+#define MPK_STAMP_AT(tag, tid)                                                                      \
     do {                                                                                            \
-        if (blockIdx.x == MPK_TRACE_BLOCK && threadIdx.x == 0) {                                    \
-            const int i_ = g_trace_n;                                                               \
-            if (i_ < 255) { g_trace[2 * i_] = (tag); g_trace[2 * i_ + 1] = (long long)__builtin_readcyclecounter(); g_trace_n = i_ + 1; } \
-        }                                                                                           \
+        if (blockIdx.x == MPK_TRACE_BLOCK && threadIdx.x == (tid))                                  \
+            g_trace[(tag) & 255] = (long long)__builtin_readcyclecounter();                         \
     } while (0)
+#define MPK_STAMP(tag) MPK_STAMP_AT(tag, 0)
 #else
 #define MPK_STAMP(tag) do { } while (0)
+#define MPK_STAMP_AT(tag, tid) do { } while (0)
 #endif
 
 #define MPK_LAUNCH_CHECK()                                                          \
@@ -1164,15 +1166,20 @@ __device__ __forceinline__ void serial_body(const TrajArgs& a, const float* __re
         // -- measured 380 cycles per step even with a warm scalar cache: profiles/r02_closed_loop.md.)
         float* const sRow = sAct + kStageFloats;                       // [16][RS]
         constexpr int NR4 = 16 * RS / 4;                               // float4 per row tile
-        f32x4 ra = {0.f, 0.f, 0.f, 0.f}, rb = ra;
+        constexpr int NRR = (NR4 + 63) / 64;                           // float4 per lane (promp with 12+ columns: 3)
+        f32x4 rr[NRR];
+#pragma unroll
+        for (int i = 0; i < NRR; ++i) rr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         auto fetch_rows = [&](int rt) {
             const f32x4* src = reinterpret_cast<const f32x4*>(At + (size_t)rt * 16 * RS);
-            if (lane < NR4) ra = src[lane];
-            if (NR4 > 64) { if (lane + 64 < NR4) rb = src[lane + 64]; }
+#pragma unroll
+            for (int i = 0; i < NRR; ++i)
+                if (lane + 64 * i < NR4) rr[i] = src[lane + 64 * i];
         };
         auto park_rows = [&]() {
-            if (lane < NR4) reinterpret_cast<f32x4*>(sRow)[lane] = ra;
-            if (NR4 > 64) { if (lane + 64 < NR4) reinterpret_cast<f32x4*>(sRow)[lane + 64] = rb; }
+#pragma unroll
+            for (int i = 0; i < NRR; ++i)
+                if (lane + 64 * i < NR4) reinterpret_cast<f32x4*>(sRow)[lane + 64 * i] = rr[i];
         };
         if (n_ser > 0) fetch_rows(0);
         for (int rt = 0; rt < NRT; ++rt) {
@@ -1818,6 +1825,21 @@ __global__ void __launch_bounds__(320) k_traj_pipe(const TrajArgs a, const ActAr
     const int vb = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * nb8 + (blockIdx.x >> 3) : blockIdx.x;
     const int NU = (a.G + kPipeGroups - 1) / kPipeGroups;
     (void)act;
+    MPK_STAMP_AT(1, 0); MPK_STAMP_AT(101, 64);
+    // head of the critical path: the producers' first inputs and the basis rows of row tile 0 are requested before the
+    // table copy (tile 0 is contracted from registers while the LDS copy lands; later tiles read the copy)
+    GroupIn<KM> nx;
+    float a0[NOUT][KM];
+    if (wave != 0) {
+        if (vb < NU) {
+            const int g = vb * kPipeGroups + wave - 1;
+            nx = load_group<MP, false, KM>(a, L, g < a.G ? g : a.G - 1);
+        }
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+            for (int m = 0; m < KM; ++m) a0[o][m] = a.A[(o * KP + 4 * m + L.q) * TS + L.col];
+    }
     // basis tables -> LDS by all five waves (a 256-thread loop shape: threads 256.. take the tail)
     {
         const float4* src = reinterpret_cast<const float4*>(a.A);
@@ -1826,8 +1848,8 @@ __global__ void __launch_bounds__(320) k_traj_pipe(const TrajArgs a, const ActAr
         for (int i = threadIdx.x; i < nA4; i += 320) dst[i] = src[i];
         for (int i = threadIdx.x; i < nX4; i += 320) reinterpret_cast<float4*>(sAux)[i] = reinterpret_cast<const float4*>(a.aux)[i];
     }
-    __syncthreads();
     if (wave == 0) {
+        __syncthreads();                                                    // (the table copy: the producers' barrier)
         // ---------------- consumer: four recurrences, one per lane quarter ----------------
         const Gains gq = kernarg_gains(L.dvalid ? L.d : 0);
         const double pgd = gq.pg, dgd = gq.dg, lod = __builtin_canonicalize(gq.lo), hid = __builtin_canonicalize(gq.hi);
@@ -1874,11 +1896,6 @@ __global__ void __launch_bounds__(320) k_traj_pipe(const TrajArgs a, const ActAr
         const int j = wave - 1;
         const float* ap = sA + L.q * TS + L.col;
         int u = vb;
-        GroupIn<KM> nx;
-        if (u < NU) {
-            const int g = u * kPipeGroups + j;
-            nx = load_group<MP, false, KM>(a, L, g < a.G ? g : a.G - 1);
-        }
         for (; u < NU; u += (int)gridDim.x) {
             const int g = u * kPipeGroups + j;
             const bool have = g < a.G;
@@ -1890,20 +1907,21 @@ __global__ void __launch_bounds__(320) k_traj_pipe(const TrajArgs a, const ActAr
                 nx = load_group<MP, false, KM>(a, L, gn < a.G ? gn : a.G - 1);
             }
             const unsigned wofs = L.wofs + ep_shift(a, g * NTW + L.bl);
-            auto produce = [&](int rt) {
+            auto produce = [&](int rt, auto first_tag) {
+                constexpr bool FIRST = decltype(first_tag)::value;          // rows of tile 0 of the first unit: registers
                 float* sJ = smem + ((rt & 1) * kPipeGroups + j) * kQuadImg;
                 f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int m = 0; m < KM; ++m) {
                     const float* am = ap + (4 * m) * TS + rt * 16;
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[0], xb[m], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[KP * TS], xb[m], acc1, 0, 0, 0);
-                    if (NOUT > 2) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[(NOUT > 2 ? 2 : 0) * KP * TS], xb[m], acc2, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(FIRST ? a0[0][m] : am[0], xb[m], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(FIRST ? a0[1][m] : am[KP * TS], xb[m], acc1, 0, 0, 0);
+                    if (NOUT > 2) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(FIRST ? a0[NOUT > 2 ? 2 : 0][m] : am[(NOUT > 2 ? 2 : 0) * KP * TS], xb[m], acc2, 0, 0, 0);
                 }
                 float dtd[4] = {1.f, 1.f, 1.f, 1.f};
                 if (MP == MPK_MP_PROMP) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dtd[r] = sAux[rt * 16 + 4 * L.q + r];
+                    for (int r = 0; r < 4; ++r) dtd[r] = FIRST ? a.aux[4 * L.q + r] : sAux[rt * 16 + 4 * L.q + r];
                 }
                 if (L.dvalid) tile_epilogue<MP, CT>(acc0, acc1, acc2, dtd, 0.0, 0.0, Gains{0.0, 0.0, 0.0, 0.0}, sJ, wofs, D);
             };
@@ -1916,15 +1934,18 @@ __global__ void __launch_bounds__(320) k_traj_pipe(const TrajArgs a, const ActAr
                 if (a.wt) tile_store_sel<MASK, KM, true>(a, L, sJ, lane, g * NTW, rt, rows);
                 else tile_store_sel<MASK, KM, false>(a, L, sJ, lane, g * NTW, rt, rows);
             };
-            if (have) {
-                produce(0);
-                __builtin_amdgcn_wave_barrier();
-                store_arrays(std::integral_constant<int, 3>(), 0);
+            // tile 0 is handed to the consumer before its pos / vel are stored: the recurrence is the critical path
+            if (u == vb) {
+                if (have) produce(0, std::true_type());
+                __syncthreads();                                            // the table copy has landed (all five waves;
+            } else if (have) {                                              // every workgroup owns at least one unit)
+                produce(0, std::false_type());
             }
             __syncthreads();                                                // tile 0 is in image 0
+            if (have) store_arrays(std::integral_constant<int, 3>(), 0);
             for (int rt = 0; rt < NRT; ++rt) {
                 if (have && rt + 1 < NRT) {
-                    produce(rt + 1);
+                    produce(rt + 1, std::false_type());
                     __builtin_amdgcn_wave_barrier();
                     store_arrays(std::integral_constant<int, 3>(), rt + 1);
                 }
@@ -2140,7 +2161,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     const bool split = !pipe && closed && c.mp_type != MPK_MP_DMP && split_shape && tune.split == 1;
     bool stream_mode = !split && (c.mp_type == MPK_MP_DMP || closed || out_bytes > 96.0 * 1024 * 1024);
     if (c.mp_type != MPK_MP_DMP && !closed && ov == 1) stream_mode = false;
-    if (ov == 2) stream_mode = true;
+    if (ov == 2 && !split) stream_mode = true;       // a forced k_traj_split stays tile-major (its tiles role needs that geometry)
     if (stream_mode && table_bytes + 4 * kStageFloats * sizeof(float) > 64 * 1024) {
         // the caller falls back: per-episode kernels for dmp, trajectory + rollout launches for the closed loop
         if (c.mp_type == MPK_MP_DMP || closed) { set_error("trajectory too long for the episode-major kernel's LDS budget"); return MPK_ENOTIMPL; }
@@ -2241,6 +2262,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         ta.nrt_magic = NRT > 1 ? (unsigned)((1ull << 32) / (unsigned long long)NRT) + 1u : 0u;
     }
     if (blocks < 1) blocks = 1;
+    if (!stream_mode && !pipe && ta.gstride <= 0) { set_error("internal: tile-major launch without its group stride"); return MPK_EINVAL; }
     if (!stream_mode && tune.lds_pad > 0) lds = (size_t)tune.lds_pad * 1024;     // A/B runs: caps the workgroups per CU
     ta.ser_blocks = 0;
     if (split) {
@@ -3746,12 +3768,20 @@ int launch_div_sweep(float d, uint32_t first, uint64_t count, unsigned long long
 #ifdef MPK_TRACE
 // development builds only: fetch and clear the stamps (pairs of tag, shader clock)
 extern "C" int mpk_debug_trace(long long* out, int cap) {
+    // out: (tag, clock) pairs of the slots stamped since the last call, sorted by clock; returns their number
+    long long raw[256];
+    if (hipMemcpyFromSymbol(raw, HIP_SYMBOL(mpk::g_trace), sizeof(raw)) != hipSuccess) return -1;
     int n = 0;
-    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(mpk::g_trace_n), sizeof(int)) != hipSuccess) return -1;
-    if (n > cap) n = cap;
-    if (n > 0 && hipMemcpyFromSymbol(out, HIP_SYMBOL(mpk::g_trace), sizeof(long long) * 2 * n) != hipSuccess) return -1;
-    const int zero = 0;
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(mpk::g_trace_n), &zero, sizeof(int));
+    for (int t = 0; t < 256 && n < cap; ++t)
+        if (raw[t] != 0) { out[2 * n] = t; out[2 * n + 1] = raw[t]; ++n; }
+    for (int i = 1; i < n; ++i)
+        for (int j = i; j > 0 && out[2 * j + 1] < out[2 * j - 1]; --j) {
+            const long long t0 = out[2 * j], c0 = out[2 * j + 1];
+            out[2 * j] = out[2 * j - 2]; out[2 * j + 1] = out[2 * j - 1];
+            out[2 * j - 2] = t0; out[2 * j - 1] = c0;
+        }
+    static const long long zeros[256] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(mpk::g_trace), zeros, sizeof(zeros));
     return n;
 }
 #endif

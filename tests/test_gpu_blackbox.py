@@ -1100,16 +1100,21 @@ def _reference_loop(cur, plan, done, every, mpt, horizon, T):
 
 @pytest.mark.parametrize("cfg", [CFG4, CFG5, CFG3], ids=["prodmp_replan", "promp", "dmp"])
 @pytest.mark.parametrize("B", [1, 9, 200, 2100])
-@pytest.mark.parametrize("bulk,quad", [("0", "2"), ("0", "3"), ("0", "4"), ("0", "0"), ("2", "0"), ("1", "1"), ("1", "split")],
-                         ids=["quad", "duo", "mono", "stream", "bulk", "auto_pipe", "split"])
+@pytest.mark.parametrize("bulk,quad", [("0", "2"), ("0", "3"), ("0", "4"), ("0", "0"), ("2", "0"), ("1", "1"), ("1", "split"),
+                                       ("2", "split_em")],
+                         ids=["quad", "duo", "mono", "stream", "bulk", "auto_pipe", "split", "split_and_episode_major_forced"])
 def test_replan_step_equals_the_separate_kernels(cfg, B, bulk, quad, monkeypatch, mpk_option):
     """mpk_replan_step (integer state + plan + rollout + condition gather; ONE launch for shared-phase promp / prodmp,
     the separate kernels for dmp) == mpk_replan_advance -> mpk_trajectory_rollout -> mpk_condition_gather, bit for bit,
     from random per-episode integer states (finished episodes, different step counters, exhausted planning budgets)"""
-    force_split = quad == "split"       # the tile-major kernel with a serial role (never chosen automatically)
+    force_split = quad.startswith("split")   # the tile-major kernel with a serial role (never chosen automatically)
     if force_split:
         mpk_option("split", 1)
-        quad = "1"
+        if quad == "split_em":          # both forced: split wins and keeps its tile-major geometry (this combination hung
+            mpk_option("mapping", 2)    # the GPU before the launcher resolved it -- found by the fuzz test)
+            quad = "3"
+        else:
+            quad = "1"
     mpk_option("bulk", bulk)
     mpk_option("quad", quad)
     pc, bc, tc, dt, dur = cfg

@@ -59,10 +59,12 @@ def main():
         st = buf[:2 * n].reshape(n, 2)
         print(f"--- {eng.last_kernel()} B={B} {mode}: {n} stamps, total {st[-1, 1] - st[0, 1]} cycles")
         if rep == 2:
-            prev = st[0, 1]
+            st = st[np.argsort(st[:, 1], kind="stable")]
+            prev = {0: st[0, 1], 1: st[0, 1]}
             for tag, c in st:
-                print(f"  tag {tag:3d}  +{c - prev:7d}  (t = {c - st[0, 1]:7d})")
-                prev = c
+                w = int(tag >= 100)                      # tags >= 100: a second wave (MPK_STAMP_AT)
+                print(f"  {'                         ' * w}tag {tag:3d}  +{c - prev[w]:7d}  (t = {c - st[0, 1]:7d})")
+                prev[w] = c
 
 
 if __name__ == "__main__":

@@ -2644,10 +2644,12 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
         const float* img = sImg + slot * img_floats;
         const int b0 = ch * E, ne = min(E, a.B - b0);
         const bool more = ch + cstride < nchunks;
+        MPK_STAMP(1);                                   // trace builds (tools/dev/trace_phase.py): chunk start
         if (more) issue_chunk(ch + cstride);
         __builtin_amdgcn_wave_barrier();
         for (int e = 0; e < ne; ++e) {
             const int b = b0 + e;
+            MPK_STAMP(2 + 40 * e);
             const float* prm = img + e * P;
             const float* ipe = img + E * P + e * D;
             const float* ive = ipe + E * D;
@@ -2720,6 +2722,7 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
             __builtin_amdgcn_wave_barrier();
             float* const out_pos = a.pos + (size_t)b * T * D;
             float* const out_vel = a.vel + (size_t)b * T * D;
+            MPK_STAMP(3 + 40 * e);                      // columns built
             for (int r0 = 0; r0 < T; r0 += kStep) {
                 const bool final_round = T - r0 <= 64;
                 const int nout = final_round ? T - r0 : kStep;
@@ -2754,6 +2757,7 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
                     const int th = t < T - 1 ? t + 1 : T - 1, tl = t < T - 1 ? t : T - 2;
                     rdt = 1.0f / ((sBT[th] + it) - (sBT[tl] + it));
                 }
+                MPK_STAMP(10 + 40 * e + (r0 ? 10 : 0));   // rows gathered / evaluated
                 if (more && e == ne - 1 && r0 == 0) park_chunk(sImg + (slot ^ 1) * img_floats);
                 float* const gp = out_pos + (size_t)r0 * D;
                 const int sh = (int)((reinterpret_cast<uintptr_t>(gp) >> 2) & 3);
@@ -2784,6 +2788,7 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
                     sO1[sh + lane * D + d] = v;
                 }
                 __builtin_amdgcn_wave_barrier();
+                MPK_STAMP(12 + 40 * e + (r0 ? 10 : 0));   // contracted, staged
                 if (a.wt) {
                     flush_span<true>(sO0, gp, nout * D, sh, lane);
                     flush_span<true>(sO1, out_vel + (size_t)r0 * D, nout * D, sh, lane);
@@ -2792,6 +2797,7 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
                     flush_span<false>(sO1, out_vel + (size_t)r0 * D, nout * D, sh, lane);
                 }
                 __builtin_amdgcn_wave_barrier();
+                MPK_STAMP(13 + 40 * e + (r0 ? 10 : 0));   // stored
                 if (final_round) break;
             }
         }

@@ -2581,7 +2581,7 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
     float* sImg = sTab + a.tab_pad + (size_t)wave * a.wave_floats;  // [2][img_pad] inputs of this / the next chunk
     float* sO0 = sImg + 2 * a.img_pad;                  // [o_pad] pos staging: [sh + lane * D + d]
     float* sO1 = sO0 + a.o_pad;                         // [o_pad] vel staging
-    float* sXf = sO1 + a.o_pad;                         // [x_pad] this episode's columns (prodmp: [wg .. , c1, c2])
+    float* sXf = sO1 + a.o_pad;                         // promp: [x_pad] this episode's columns (prodmp: in the input image)
     float* sWgs = smem;                                 // prodmp: weights_goal_scale[nb + 1] (in place of sCen)
     for (int t = threadIdx.x; t < T; t += blockDim.x) sBT[t] = c.base_times[t];
     if (MP != MPK_MP_PRODMP) {
@@ -2647,6 +2647,70 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
         MPK_STAMP(1);                                   // trace builds (tools/dev/trace_phase.py): chunk start
         if (more) issue_chunk(ch + cstride);
         __builtin_amdgcn_wave_barrier();
+        if (MP == MPK_MP_PRODMP) {
+            // The columns of ALL episodes of the chunk at once, one lane per (episode, DoF): wg = scale * [w; g] in fp32 as
+            // the reference forms it, and the two boundary residuals of
+            //   pos = xi1 * (y_b - Psi_b.wg) + xi2 * (tau ydot_b - dPsi_b.wg) + Psi.wg
+            // (the reference's xi1 y_b + xi2 v_b + (Psi - xi1 Psi_b - xi2 dPsi_b).wg, regrouped so that nothing large cancels
+            // in fp32) in float64, ascending k.  Per episode -- D lanes working, the wave paying every instruction -- this
+            // block was 27 % of the kernel's cycles (profiles/r02_per_episode_phase.md); per chunk it is a quarter of that.
+            // The chunk's input image is rewritten IN PLACE: every lane reads what it needs first, then the image becomes
+            // [E][D][KS] columns [wg_0 .. wg_{K-1}, 0.., r1, r2] | [E][tau, delay, init_time] (clipped) -- no LDS on top.
+            float* const imw = sImg + slot * img_floats;
+            const int le = (lane >= D) + (lane >= 2 * D) + (lane >= 3 * D), ld = lane - le * D;    // E <= 4
+            const bool on = lane < ne * D;
+            const int K = c.nb + 1;
+            float raw[KS], taul = c.tau, delayl = c.delay, itl = 0.0f, yb = 0.0f, ydb = 0.0f;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) raw[k] = 0.0f;
+            if (on) {
+                const float* prl = img + le * P;
+                if (c.learn_tau) taul = fminf(fmaxf(prl[0], c.tau_lo), c.tau_hi);
+                if (c.learn_delay) delayl = fminf(fmaxf(prl[c.learn_tau ? 1 : 0], c.delay_lo), c.delay_hi);
+                itl = img[E * P + 2 * E * D + le];
+                yb = img[E * P + lane]; ydb = img[E * P + E * D + lane];
+                const float* loc = prl + c.off + ld * c.Kloc;
+#pragma unroll
+                for (int k = 0; k < KS; ++k)
+                    if (k < K) {
+                        // a disabled block has no parameters (the goal then sits at local index 0)
+                        const bool have = k < c.nb ? !c.disable_weights : !c.disable_goal;
+                        const int li = k < c.nb ? k : (c.disable_weights ? 0 : c.nb);
+                        raw[k] = have ? loc[li] : 0.0f;
+                    }
+            }
+            __builtin_amdgcn_wave_barrier();                 // every read of the image is issued before its first write
+            if (on) {
+                const float sbl = fmaxf(div_exact(itl - delayl, make_exact_div(taul)), 0.0f);
+                const float* rb = rows + (size_t)min((int)rintf(div_exact(sbl, dsdt)), c.n_pc - 1) * kRow;
+                double pb = 0.0, vb = 0.0;
+                float* xf = imw + le * a.x_pad + ld * KS;
+#pragma unroll
+                for (int k = 0; k < KS; ++k) {
+                    float wg = 0.0f;
+                    if (k < K) {
+                        const bool have = k < c.nb ? !c.disable_weights : !c.disable_goal;
+                        wg = have ? raw[k] * sWgs[k] : 0.0f;          // (raw is 0 where there is no parameter)
+                        if (k == c.nb) {
+                            // relative goal: init_pos joins the scaled goal, or (MPK_RELGOAL_BEFORE_SCALE) the raw
+                            // parameter -- zero when the goal is disabled -- before the scale
+                            if (c.relative_goal) wg = c.relgoal_before_scale ? (raw[k] + yb) * sWgs[c.nb + 1] : wg + yb;
+                            if (c.goal_off_on) wg = wg + c.goal_offset;
+                        }
+                        pb += (double)rb[2 * k] * (double)wg;
+                        vb += (double)rb[2 * k + 1] * (double)wg;
+                    }
+                    xf[k] = wg;
+                }
+                xf[KS - 2] = (float)((double)yb - pb);
+                xf[KS - 1] = (float)((double)(taul * ydb) - vb);
+                if (ld == 0) {
+                    float* sc3 = imw + E * a.x_pad + 3 * le;
+                    sc3[0] = taul; sc3[1] = delayl; sc3[2] = itl;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
         for (int e = 0; e < ne; ++e) {
             const int b = b0 + e;
             MPK_STAMP(2 + 40 * e);
@@ -2654,22 +2718,24 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
             const float* ipe = img + E * P + e * D;
             const float* ive = ipe + E * D;
             // np.clip(action, low, high): only tau / delay carry finite bounds (black_box_wrapper.py:104-105)
-            float tau = c.tau, delay = c.delay;
-            if (c.learn_tau) tau = fminf(fmaxf(prm[0], c.tau_lo), c.tau_hi);
-            if (c.learn_delay) delay = fminf(fmaxf(prm[c.learn_tau ? 1 : 0], c.delay_lo), c.delay_hi);
-            const float it = img[E * P + 2 * E * D + e];
+            float tau = c.tau, delay = c.delay, it;
+            if (MP == MPK_MP_PRODMP) {                  // clipped per chunk above
+                const float* sc3 = img + E * a.x_pad + 3 * e;
+                tau = sc3[0]; delay = sc3[1]; it = sc3[2];
+            } else {
+                if (c.learn_tau) tau = fminf(fmaxf(prm[0], c.tau_lo), c.tau_hi);
+                if (c.learn_delay) delay = fminf(fmaxf(prm[c.learn_tau ? 1 : 0], c.delay_lo), c.delay_hi);
+                it = img[E * P + 2 * E * D + e];
+            }
             float inv_tau = 0.0f;
             double bca = 0.0, bcb = 0.0, bcc = 0.0, bcd = 0.0;    // dy2_b, dy1_b, y1_b, y2_b over det (see prodmp_bc)
             // table index = round(max((t - delay) / tau, 0) / scaled_dt): both quotients correctly rounded (div_exact), the
             // reciprocals taken once per episode / kernel instead of two IEEE divisions per step
             const ExactDiv dtau = make_exact_div(tau);
             if (MP == MPK_MP_PRODMP) {
-                // Boundary conditions (SURVEY A.5 / mp_pytorch ProDMP), regrouped so that nothing large cancels in fp32:
-                //   pos = xi1 * (y_b - Psi_b.wg) + xi2 * (tau ydot_b - dPsi_b.wg) + Psi.wg
-                // (= the reference's xi1 y_b + xi2 v_b + (Psi - xi1 Psi_b - xi2 dPsi_b).wg).  One lane per DoF forms
-                // wg = scale * [w; g] in fp32 as the reference does and the two residuals in float64; the lane's finished
-                // column [wg_0 .. wg_{K-1}, 0.., r1, r2] goes to sXf.  xi1..xi4 are per (episode, step): the step's lane
-                // forms them below in float64 from the hi + lo table values and the factors kept here.
+                // Boundary conditions (SURVEY A.5 / mp_pytorch ProDMP): the episode's columns were built per chunk above;
+                // xi1..xi4 are per (episode, step): the step's lane forms them below in float64 from the table values and
+                // the factors kept here.
                 const float sb = fmaxf(div_exact(it - delay, dtau), 0.0f);
                 const int idxb = min((int)rintf(div_exact(sb, dsdt)), c.n_pc - 1);
                 inv_tau = dtau.r;
@@ -2680,34 +2746,6 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
                     const double y1b = yb4[0], y2b = yb4[1], dy1b = yb4[2], dy2b = yb4[3];
                     const double idet = div_pos(1.0, y1b * dy2b - y2b * dy1b);      // det = y1_b^2 > 0
                     bca = dy2b * idet; bcb = dy1b * idet; bcc = y1b * idet; bcd = y2b * idet;
-                }
-                if (lane < D) {
-                    const int K = c.nb + 1;
-                    const float* loc = prm + c.off + lane * c.Kloc;
-                    const float yb = ipe[lane], ydb = ive[lane];
-                    double pb = 0.0, vb = 0.0;
-                    float* xf = sXf + lane * KS;
-#pragma unroll
-                    for (int k = 0; k < KS; ++k) {
-                        float wg = 0.0f;
-                        if (k < K) {
-                            // a disabled block has no parameters (the goal then sits at local index 0) and scale 0
-                            const bool have = k < c.nb ? !c.disable_weights : !c.disable_goal;
-                            const int li = k < c.nb ? k : (c.disable_weights ? 0 : c.nb);
-                            wg = have ? loc[li] * sWgs[k] : 0.0f;
-                            if (k == c.nb) {
-                                // relative goal: init_pos joins the scaled goal, or (MPK_RELGOAL_BEFORE_SCALE) the raw
-                                // parameter -- zero when the goal is disabled -- before the scale
-                                if (c.relative_goal) wg = c.relgoal_before_scale ? ((have ? loc[li] : 0.0f) + yb) * sWgs[c.nb + 1] : wg + yb;
-                                if (c.goal_off_on) wg = wg + c.goal_offset;
-                            }
-                            pb += (double)rb[2 * k] * (double)wg;
-                            vb += (double)rb[2 * k + 1] * (double)wg;
-                        }
-                        xf[k] = wg;
-                    }
-                    xf[KS - 2] = (float)((double)yb - pb);
-                    xf[KS - 1] = (float)((double)(tau * ydb) - vb);
                 }
             } else {
                 // raw parameter columns [w_0 .. w_{nb-1}, init_pos (zero-padded family), 0 ..] per DoF
@@ -2722,6 +2760,7 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
             __builtin_amdgcn_wave_barrier();
             float* const out_pos = a.pos + (size_t)b * T * D;
             float* const out_vel = a.vel + (size_t)b * T * D;
+            const float* const sXe = MP == MPK_MP_PRODMP ? img + e * a.x_pad : sXf;
             MPK_STAMP(3 + 40 * e);                      // columns built
             for (int r0 = 0; r0 < T; r0 += kStep) {
                 const bool final_round = T - r0 <= 64;
@@ -2761,11 +2800,14 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
                 if (more && e == ne - 1 && r0 == 0) park_chunk(sImg + (slot ^ 1) * img_floats);
                 float* const gp = out_pos + (size_t)r0 * D;
                 const int sh = (int)((reinterpret_cast<uintptr_t>(gp) >> 2) & 3);
-                for (int d = 0; d < D; ++d) {
+                // one (step, DoF) contraction; `ND` DoF per loop iteration: the pair's loads, chains and staging writes
+                // share their address arithmetic and loop control, and the two chains fill each other's issue gaps (trace:
+                // the kernel is vector-issue-bound; 9 of the 17 instructions per DoF were not FMAs)
+                auto dof = [&](int d) {
                     float x[KS];
 #pragma unroll
                     for (int j = 0; j < KQ; ++j) {
-                        const float4 v = *reinterpret_cast<const float4*>(sXf + d * KS + 4 * j);
+                        const float4 v = *reinterpret_cast<const float4*>(sXe + d * KS + 4 * j);
                         x[4 * j + 0] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
                     }
                     float p = 0.0f, v = 0.0f;
@@ -2786,7 +2828,14 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
                     }
                     sO0[sh + lane * D + d] = p;        // every lane: the staging holds 64 rows, rows >= nout never leave
                     sO1[sh + lane * D + d] = v;
+                };
+                constexpr int ND = KQ <= 2 ? 2 : 1;
+                int d = 0;
+                for (; d + ND <= D; d += ND) {
+#pragma unroll
+                    for (int i = 0; i < ND; ++i) dof(d + i);
                 }
+                for (; d < D; ++d) dof(d);
                 __builtin_amdgcn_wave_barrier();
                 MPK_STAMP(12 + 40 * e + (r0 ? 10 : 0));   // contracted, staged
                 if (a.wt) {
@@ -2926,8 +2975,10 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
         E = E > 64 / c.D ? 64 / c.D : E;
         if (E < 1) return MPK_ENOTIMPL;
         pa.chunk = E;
-        pa.img_pad = (E * (c.P + 2 * c.D + 1) + 3) / 4 * 4;
-        pa.wave_floats = 2 * pa.img_pad + 2 * pa.o_pad + pa.x_pad;
+        // prodmp: the image is rewritten in place into [E][x_pad] columns + [E][3] clipped phase values
+        const int img_in = E * (c.P + 2 * c.D + 1), img_cols = c.mp_type == MPK_MP_PRODMP ? E * (pa.x_pad + 3) : 0;
+        pa.img_pad = ((img_in > img_cols ? img_in : img_cols) + 3) / 4 * 4;
+        pa.wave_floats = 2 * pa.img_pad + 2 * pa.o_pad + (c.mp_type == MPK_MP_PRODMP ? 0 : pa.x_pad);
     }
     pa.c_pad = c.mp_type == MPK_MP_PRODMP ? (c.nb + 2 + 3) / 4 * 4 : (4 * c.n_total + 6 + 3) / 4 * 4;
     const size_t wave_bytes = (size_t)pa.wave_floats * sizeof(float);

@@ -650,7 +650,7 @@ const OptKey kOptKeys[] = {
     {"quad", &Tuning::quad, 0, 4},               {"pd_quad", &Tuning::pd_quad, 0, 2},
     {"write_through", &Tuning::write_through, 0, 1}, {"ipw", &Tuning::ipw, 0, 1 << 20},
     {"phase", &Tuning::phase, 0, 1},             {"phase_table", &Tuning::phase_table, 0, 1},
-    {"phase_chunk", &Tuning::phase_chunk, 0, 4}, {"pd_simple", &Tuning::pd_simple, 0, 1},
+    {"phase_chunk", &Tuning::phase_chunk, 0, 16}, {"pd_simple", &Tuning::pd_simple, 0, 1},
     {"split", &Tuning::split, 0, 1},             {"lds_pad", &Tuning::lds_pad, 0, 48},
     {"pipe", &Tuning::pipe, 0, 1},
 };

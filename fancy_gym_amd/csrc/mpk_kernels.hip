@@ -2476,6 +2476,7 @@ struct PhaseArgs {
     int32_t* flag;
     int B, wave_floats, t_pad, x_pad, o_pad, c_pad, tab_pad, chunk, img_pad;
     int wt;     // write-through stores while the outputs are cache resident
+    int vec_ok; // dmp: outputs 16-byte aligned and T * D a multiple of 4 (float4 stores)
 };
 
 template <int MP>
@@ -2855,100 +2856,153 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
 
 template <int KQ>
 __global__ void __launch_bounds__(256) k_traj_phase_dmp(const PhaseArgs a) {
+    // DMP with a per-episode phase.  The Euler recurrence is serial in t and needs one lane per (episode, DoF); run per
+    // episode it keeps D of 64 lanes busy for T dependent steps -- 7 % of the HBM roofline for 7 DoF (round 1 / 2).  Here a
+    // wave owns a CHUNK of E (four, see the launcher) consecutive episodes and walks the horizon in tiles of 16 steps:
+    //   A  lane <-> (episode, step of the tile): phase, RBF row (float64, the builders' functions: same bits as every other
+    //      DMP kernel), the D forcing values of the step as fmaf chains in ascending k, the step's ds;
+    //   B  lane <-> (episode, DoF): 16 Euler steps, one rounding per operation, all E * D recurrences at once;
+    //   C  the tile's [E][16 * D] (pos | vel) blocks leave as float4 stores.
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevCfg& c = a.c;
-    constexpr int KS = KQ * 4;
+    constexpr int KS = KQ * 4, TT = 16;
     constexpr int MP = MPK_MP_DMP;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wpb = (int)(blockDim.x >> 6);
-    const int D = c.D, T = c.T;
+    const int D = c.D, T = c.T, E = a.chunk, P = c.P;
+    const int seg = TT * D;                             // floats of one episode's tile
     float* sBT = smem + a.c_pad;                        // [t_pad] base times, shared by the workgroup
-    float* sH = sBT + a.t_pad + (size_t)wave * a.wave_floats;    // [T][KS]
-    float* sA = sH + T * KS;                            // [t_pad] ds
-    float* sX = sA + a.t_pad;                           // [2][D][KS]  this episode's / the next episode's columns
-    float* sP = sX + 2 * a.x_pad;                       // [T*D] forcing -> pos
-    float* sV = sP + T * D;                             // [T*D] vel
-    const int rows_per_pass = 64 / D;
-    const int ld = lane % D, lt = lane / D;
-    const bool lane_on = lt < rows_per_pass;
+    float* sX = sBT + a.t_pad + (size_t)wave * a.wave_floats;   // [E][D][KS] columns: weights .., goal, y0, ydot0
+    float* sPh = sX + E * a.x_pad;                      // [E][4] tau, delay, init_time (clipped)
+    float* sDs = sPh + 4 * E;                           // [E][TT] ds of the tile's steps
+    float* sH = sDs + E * TT;                           // [64][KS] the round's RBF rows
+    float* sP = sH + 64 * KS;                           // [E][TT * D] forcing -> pos
+    float* sV = sP + a.o_pad;                           // [E][TT * D] vel
     for (int t = threadIdx.x; t < T; t += blockDim.x) sBT[t] = c.base_times[t];
     __syncthreads();
-
-    const int stride = (int)gridDim.x * wpb;
-    int b = (int)blockIdx.x * wpb + wave;
-    PhaseFetch<MP, KS> cur;
-    if (b < a.B) {
-        cur.issue(a, b, lane);
-        cur.park(sX, D * KS, lane);
-    }
-    int slot = 0;
-    for (; b < a.B; b += stride, slot ^= 1) {
-        const float tau = c.learn_tau ? fminf(fmaxf(cur.tau_raw, c.tau_lo), c.tau_hi) : c.tau;
-        const float delay = c.learn_delay ? fminf(fmaxf(cur.delay_raw, c.delay_lo), c.delay_hi) : c.delay;
-        const float it = cur.it;
-        PhaseFetch<MP, KS> nxt;
-        nxt.tau_raw = 0.0f; nxt.delay_raw = 0.0f; nxt.it = 0.0f;
-#pragma unroll
-        for (int r = 0; r < PhaseFetch<MP, KS>::NX; ++r) nxt.xv[r] = 0.0f;
-        const bool more = b + stride < a.B;
-        if (more) nxt.issue(a, b + stride, lane);
-        for (int t = lane; t < T; t += 64) {
-            const float time = sBT[t] + it;
-            const double x = phase_f64(c, time, tau, delay, ExpLiteral());
-            float* row = sH + t * KS;
-            for (int k = c.nb; k < KS; ++k) row[k] = 0.0f;
-            rbf_cols(c, x, x * (double)c.ws, row, 1);
-            if (t < T - 1) sA[t] = scaled_time(sBT[t + 1] + it, delay, tau) - scaled_time(time, delay, tau);
+    const float inv_d = 1.0f / (float)D;
+    const int le = (int)(((float)lane + 0.5f) * inv_d), ld = lane - le * D;        // lane <-> (episode, DoF)
+    const float inv_seg4 = 4.0f / (float)seg, inv_seg = 1.0f / (float)seg;   // (idx + 0.5) * inv: exact floor for idx < 2^16
+    const bool vec = a.vec_ok != 0;                     // float4 stores: 16-byte aligned outputs, T * D a multiple of 4
+    const int nchunks = (a.B + E - 1) / E;
+    const int cstride = (int)gridDim.x * wpb;
+    for (int ch = (int)blockIdx.x * wpb + wave; ch < nchunks; ch += cstride) {
+        const int b0 = ch * E, ne = min(E, a.B - b0);
+        // ---- the chunk's inputs: columns of every (episode, DoF), phase values per episode
+        for (int idx = lane; idx < ne * D * KS; idx += 64) {
+            const int pi = idx / KS, k = idx - pi * KS;             // pi = e * D + dd
+            const int e = (int)(((float)pi + 0.5f) * inv_d), dd = pi - e * D;
+            const size_t bb = (size_t)(b0 + e);
+            sX[idx] = phase_x_value<MP>(c, a.params + bb * P, a.init_pos + bb * D, a.init_vel + bb * D, dd, k, KS);
         }
-        nxt.park(sX + (slot ^ 1) * a.x_pad, more ? D * KS : 0, lane);
-        __builtin_amdgcn_wave_barrier();
-        float x[KS];
-#pragma unroll
-        for (int j = 0; j < KQ; ++j) {
-            const float4 v = *reinterpret_cast<const float4*>(sX + slot * a.x_pad + ld * KS + 4 * j);
-            x[4 * j + 0] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
-        }
-        const float dmp_g = x[KS - 3], dmp_y = x[KS - 2], dmp_yd = x[KS - 1];
-        x[KS - 3] = 0.0f; x[KS - 2] = 0.0f; x[KS - 1] = 0.0f;
-        const size_t ob = (size_t)b * T * D;
-        for (int t0 = 0; t0 < T; t0 += rows_per_pass) {
-            const int t = t0 + lt;
-            const bool on = lane_on && t < T;
-            const int tc = on ? t : 0;
-            const float f = row_chain<KQ>(sH + tc * KS, x);
-            if (on) sP[tc * D + ld] = f;
+        float tau = c.tau, delay = c.delay, it = a.init_time_shared;
+        const bool on = lane < ne * D;
+        if (on) {
+            const float* prm = a.params + (size_t)(b0 + le) * P;
+            // np.clip(action, low, high): only tau / delay carry finite bounds (black_box_wrapper.py:104-105)
+            if (c.learn_tau) tau = fminf(fmaxf(prm[0], c.tau_lo), c.tau_hi);
+            if (c.learn_delay) delay = fminf(fmaxf(prm[c.learn_tau ? 1 : 0], c.delay_lo), c.delay_hi);
+            if (a.init_time) it = a.init_time[b0 + le];
+            if (ld == 0) { sPh[4 * le] = tau; sPh[4 * le + 1] = delay; sPh[4 * le + 2] = it; }
         }
         __builtin_amdgcn_wave_barrier();
-        if (lane < D) {
-            const int dd = lane;               // lanes 0..D-1 have ld == lane
-            float y = dmp_y;
-            float z = dmp_yd * tau;
-            const float g = dmp_g * c.gs;
-            const TauDiv td = make_tau_div(tau);
-            for (int t = 0; t < T; ++t) {
-                const float f = sP[t * D + dd];
-                sP[t * D + dd] = y;
-                sV[t * D + dd] = div_tau(z, td);
-                if (t < T - 1) {
-                    const float ds = sA[t];
-                    const float t1 = g - y;
-                    const float t2 = c.dmp_beta * t1;
-                    const float t3 = t2 - z;
-                    const float t4 = c.dmp_alpha * t3;
-                    const float acc = t4 + f;
-                    z = z + ds * acc;
-                    y = y + ds * z;
+        float y = 0.0f, z = 0.0f, g = 0.0f;
+        if (on) {
+            const float* xc = sX + lane * KS;
+            g = xc[KS - 3] * c.gs; y = xc[KS - 2]; z = xc[KS - 1] * tau;
+        }
+        const TauDiv td = make_tau_div(tau);
+        for (int t0 = 0; t0 < T; t0 += TT) {
+            const int rows = min(TT, T - t0);
+            // ---- A: rows and forcing of the tile
+            for (int i0 = 0; i0 < ne * TT; i0 += 64) {
+                const int idx = i0 + lane, e = idx >> 4, tl = idx & (TT - 1), t = t0 + tl;
+                const bool live = idx < ne * TT && t < T;
+                float* row = sH + lane * KS;
+                if (live) {
+                    const float taue = sPh[4 * e], delaye = sPh[4 * e + 1], ite = sPh[4 * e + 2];
+                    const float time = sBT[t] + ite;
+                    const double x = phase_f64(c, time, taue, delaye, ExpLiteral());
+                    for (int k = c.nb; k < KS; ++k) row[k] = 0.0f;
+                    rbf_cols(c, x, x * (double)c.ws, row, 1);
+                    if (t < T - 1) sDs[idx] = scaled_time(sBT[t + 1] + ite, delaye, taue) - scaled_time(time, delaye, taue);
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (live) {
+                    for (int d = 0; d < D; ++d) {
+                        float x[KS];
+#pragma unroll
+                        for (int j = 0; j < KQ; ++j) {
+                            const float4 v = *reinterpret_cast<const float4*>(sX + (e * D + d) * KS + 4 * j);
+                            x[4 * j + 0] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
+                        }
+                        x[KS - 3] = 0.0f; x[KS - 2] = 0.0f; x[KS - 1] = 0.0f;      // goal, y0, ydot0 are not weights
+                        sP[e * seg + tl * D + d] = row_chain<KQ>(row, x);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            // ---- B: 16 Euler steps of every (episode, DoF) of the chunk (one rounding per operation)
+            if (on) {
+                float* pp = sP + le * seg + ld;
+                float* pv = sV + le * seg + ld;
+                const float* pds = sDs + le * TT;
+                for (int tl = 0; tl < rows; ++tl) {
+                    const float f = pp[tl * D];
+                    pp[tl * D] = y;
+                    pv[tl * D] = div_tau(z, td);
+                    if (t0 + tl < T - 1) {
+                        const float ds = pds[tl];
+                        const float t1 = g - y;
+                        const float t2 = c.dmp_beta * t1;
+                        const float t3 = t2 - z;
+                        const float t4 = c.dmp_alpha * t3;
+                        const float acc = t4 + f;
+                        z = z + ds * acc;
+                        y = y + ds * z;
+                    }
                 }
             }
+            __builtin_amdgcn_wave_barrier();
+            // ---- C: the tile's blocks, one contiguous run of rows * D floats per episode and array
+            const int n = rows * D;
+            if (vec) {
+                const int n4 = n >> 2, tail = n & 3;
+                for (int i0 = 0; i0 < ne * (seg >> 2); i0 += 64) {
+                    const int idx = i0 + lane;
+                    const int e = (int)(((float)idx + 0.5f) * inv_seg4), q = idx - e * (seg >> 2);
+                    if (e < ne && q < n4) {
+                        const size_t go = ((size_t)(b0 + e) * T + t0) * D + 4 * q;
+                        const f32x4 vp = *reinterpret_cast<const f32x4*>(sP + e * seg + 4 * q);
+                        const f32x4 vv = *reinterpret_cast<const f32x4*>(sV + e * seg + 4 * q);
+                        if (a.wt) { store16<true>(a.pos + go, vp); store16<true>(a.vel + go, vv); }
+                        else { store16<false>(a.pos + go, vp); store16<false>(a.vel + go, vv); }
+                    }
+                }
+                if (tail) {                             // the last tile of a horizon whose rows * D is no multiple of 4
+                    for (int i0 = 0; i0 < ne * 4; i0 += 64) {
+                        const int idx = i0 + lane, e = idx >> 2, r = idx & 3;
+                        if (e < ne && r < tail) {
+                            const size_t go = ((size_t)(b0 + e) * T + t0) * D + 4 * n4 + r;
+                            if (a.wt) { store4<true>(a.pos + go, sP[e * seg + 4 * n4 + r]); store4<true>(a.vel + go, sV[e * seg + 4 * n4 + r]); }
+                            else { store4<false>(a.pos + go, sP[e * seg + 4 * n4 + r]); store4<false>(a.vel + go, sV[e * seg + 4 * n4 + r]); }
+                        }
+                    }
+                }
+            } else {
+                for (int i0 = 0; i0 < ne * seg; i0 += 64) {
+                    const int idx = i0 + lane;
+                    const int e = (int)(((float)idx + 0.5f) * inv_seg), w = idx - e * seg;
+                    if (e < ne && w < n) {
+                        const size_t go = ((size_t)(b0 + e) * T + t0) * D + w;
+                        if (a.wt) { store4<true>(a.pos + go, sP[e * seg + w]); store4<true>(a.vel + go, sV[e * seg + w]); }
+                        else { store4<false>(a.pos + go, sP[e * seg + w]); store4<false>(a.vel + go, sV[e * seg + w]); }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();            // the tile's LDS reads are issued before the next tile's writes
         }
-        __builtin_amdgcn_wave_barrier();
-        for (int e = lane; e < T * D; e += 64) {
-            a.pos[ob + e] = sP[e];
-            a.vel[ob + e] = sV[e];
-        }
-        __builtin_amdgcn_wave_barrier();   // this episode's LDS reads are issued before the next one's writes
-        cur = nxt;
     }
 }
 
@@ -2966,8 +3020,19 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
     pa.t_pad = (c.T + 3) / 4 * 4;
     pa.x_pad = c.D * KS;
     pa.o_pad = (64 * c.D + 4 + 3) / 4 * 4;
-    if (dmp) pa.wave_floats = c.T * KS + pa.t_pad + 2 * pa.x_pad + (2 * c.T * c.D + 3) / 4 * 4;
-    else {
+    if (dmp) {
+        // a wave owns chunks of E consecutive episodes, one lane per (episode, DoF) in the Euler recurrence
+        // measured at 7 DoF, T = 200 (us at B = 4096 / 65536): E = 1 94 / 1220, 2 67 / 633, 3 70 / 479, **4 62 / 406**, 6 96 / 454,
+        // 9 131 / 503 -- four episodes make the 64 (episode, step) items of a tile exactly one round of the wave, and the
+        // per-wave LDS (6.8 KB) still lets 20 waves share a CU; "phase_chunk" overrides (up to 64 / D, at most 16)
+        const int e_max = 64 / c.D > 16 ? 16 : 64 / c.D;
+        int E = e_max < 4 ? e_max : 4;
+        if (tune.phase_chunk >= 1 && tune.phase_chunk <= e_max) E = tune.phase_chunk;
+        pa.chunk = E;
+        pa.o_pad = E * 16 * c.D;                                  // one (pos or vel) tile of the chunk
+        pa.wave_floats = E * pa.x_pad + 4 * E + E * 16 + 64 * KS + 2 * pa.o_pad;
+        pa.vec_ok = ((reinterpret_cast<uintptr_t>(pa.pos) | reinterpret_cast<uintptr_t>(pa.vel)) & 15u) == 0 && (c.T * c.D) % 4 == 0 ? 1 : 0;
+    } else {
         // chunks of up to 4 consecutive episodes whose parameter rows fit the loader's 5 x 64 values and whose boundary
         // states fit one 64-lane load
         int E = 320 / c.P;
@@ -3011,7 +3076,7 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
         if (tune.phase_chunk >= 1 && tune.phase_chunk <= pa.chunk) E = tune.phase_chunk;
         pa.chunk = E;
     }
-    const long units = dmp ? (long)pa.B : ((long)pa.B + pa.chunk - 1) / pa.chunk;
+    const long units = ((long)pa.B + pa.chunk - 1) / pa.chunk;
     long blocks = (units + wpb - 1) / wpb;
     if (blocks > (long)num_cu * per_cu) blocks = (long)num_cu * per_cu;
     auto go = [&](auto kern) -> int {

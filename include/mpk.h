@@ -182,7 +182,7 @@ int mpk_set_duration(mpk_handle h, double duration, double dt);
  *   "ipw"           n > 0 work items per wave                                      (tile-major kernel)
  *   "phase"         0 workgroup-per-episode kernel instead of wave-per-episode     (per-episode-phase kernels)
  *   "phase_table"   0 ProDMP row table from L2 instead of LDS
- *   "phase_chunk"   1 / 2 / 4 episodes per input chunk
+ *   "phase_chunk"   episodes per wave and chunk: 1 / 2 / 4 (promp / prodmp), 1 .. min(16, 64 / D) (dmp)
  *   "pd_simple"     1 generic one-lane-per-(episode, DoF) rollout kernels
  *   "pipe"          0 off, 1 force the producer / consumer closed-loop kernel (k_traj_pipe; the default where it fits)
  *   "split"         1 force the tile-major closed-loop kernel with a serial role (k_traj_split; never chosen automatically)

@@ -322,17 +322,18 @@ def test_prodmp_row_table_in_lds_or_l2_same_bits(name, monkeypatch, mpk_option):
     close(outs["1"][0].cpu().numpy(), rp, "pos"); close(outs["1"][1].cpu().numpy(), rv, "vel")
 
 
-@pytest.mark.parametrize("name", ["prodmp_learn_tau_delay", "promp_learn_tau"])
+@pytest.mark.parametrize("name", ["prodmp_learn_tau_delay", "promp_learn_tau", "dmp_learn_delay"])
 @pytest.mark.parametrize("B", [1, 7, 130])
 def test_per_episode_chunking_is_invisible(name, B, monkeypatch, mpk_option):
-    """a wave's episodes are fetched in chunks of 1, 2 or 4 consecutive episodes (ragged last chunk): same bits"""
+    """a wave's episodes are worked on in chunks of 1, 2 or 4 consecutive episodes (ragged last chunk; dmp: one lane per
+    (episode, DoF) of the chunk in the Euler recurrence, up to 16 episodes): same bits"""
     from tests.test_gpu_trajectory import PER_ROW
     pc, bc, tc, dt, dur = PER_ROW[name]
     eng = make_engine(pc, bc, tc, dt, dur)
     params, ip, iv = inputs(pc, bc, tc, B, seed=B)
     it = torch.tensor(np.random.default_rng(B).integers(0, 4, B) * dt, dtype=torch.float32, device="cuda")
     ref = None
-    for chunk in ("1", "2", "4"):
+    for chunk in ("1", "2", "4") + (("3", "9", "16") if name.startswith("dmp") else ()):
         mpk_option("phase_chunk", chunk)
         p, v = eng.trajectory(params, ip, iv, it)
         torch.cuda.synchronize()
@@ -586,12 +587,16 @@ def test_long_horizons_take_the_kernels_that_fit(mp, T):
     assert np.array_equal(act.cpu().numpy(), ra.astype(np.float32)) and np.array_equal(q.cpu().numpy(), rq)
 
 
-def test_dmp_horizon_beyond_every_kernel_is_refused():
+def test_dmp_horizon_beyond_the_lds_of_the_shared_phase_kernels_runs_time_tiled():
+    """T = 8000: the forcing / state rows of a whole horizon no longer fit any kernel's LDS (round 1 refused this
+    shape); the per-episode DMP kernel walks the horizon in 16-step tiles and takes it"""
     pc, bc, tc, dt, dur = cfg_for("dmp", 3, 4, 8000, dt=0.002)
     eng = make_engine(pc, bc, tc, dt, dur)
     params, ip, iv = inputs(pc, bc, tc, 2, seed=1)
-    with pytest.raises(ValueError, match="too large"):
-        eng.trajectory(params, ip, iv, 0.0)
+    pos, vel = eng.trajectory(params, ip, iv, 0.0)
+    assert eng.last_kernel() == "k_traj_phase<dmp>"
+    rp, rv = O.get_trajectory(pc, bc, tc, params, dur, dt, 0.0, ip, iv, dtype=np.float64)
+    close(pos.cpu().numpy(), rp, "pos"); close(vel.cpu().numpy(), rv, "vel")
 
 
 def test_reciprocal_division_is_the_ieee_quotient_for_every_grid_time():

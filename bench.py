@@ -382,14 +382,22 @@ def main():
             def sample_smi():
                 try:
                     import subprocess
-                    r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True,
-                                       text=True, timeout=5)
+                    r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp", "--json"],
+                                       capture_output=True, text=True, timeout=5)
                     card = next(iter(json.loads(r.stdout).values()))
                     for k, v in card.items():
                         if "sclk clock speed" in k or "mclk clock speed" in k or "fclk clock speed" in k:
                             smi[k.split()[0] + "_mhz"] = int("".join(ch for ch in v if ch.isdigit()))
                         elif "Power" in k:
                             smi["package_power_w"] = float(v)
+                        elif "Temperature" in k and "(C)" in k:
+                            # e.g. "Temperature (Sensor memory) (C)", "Temperature (Sensor HBM 0) (C)": HBM above ~85 C
+                            # refreshes at twice the rate
+                            name = k[k.index("Sensor") + 7:k.index(")")].strip().lower().replace(" ", "_")
+                            try:
+                                smi["temp_" + name + "_c"] = float(v)
+                            except ValueError:
+                                pass
                 except Exception:  # noqa: BLE001 - the sample is optional
                     pass
             import threading

@@ -295,20 +295,32 @@ __device__ __forceinline__ double exp_nonpos(double x, const CF& cf) {
 
 __device__ __forceinline__ double exp_nonpos(double x) { return exp_nonpos(x, ExpLiteral()); }
 
-__device__ __forceinline__ double div_pos(double num, double den) {
-    double y = __builtin_amdgcn_rcp(den);                       // v_rcp_f64 seed, two Newton steps, one residual fix-up
+// num / den for den > 0: v_rcp_f64 seed, two Newton steps, one residual fix-up.  The refined reciprocal depends on the
+// divisor alone, so a divisor that is reused (an episode's tau) takes it once (PosDiv) -- the same operations on the same
+// values as the one-shot form, hence the same bits.
+struct PosDiv { double den, y; };
+__device__ __forceinline__ PosDiv make_pos_div(double den) {
+    double y = __builtin_amdgcn_rcp(den);
     y = fma(fma(-den, y, 1.0), y, y);
     y = fma(fma(-den, y, 1.0), y, y);
-    const double q = num * y;
-    return fma(fma(-den, q, num), y, q);
+    return PosDiv{den, y};
 }
+__device__ __forceinline__ double div_pos(double num, const PosDiv& d) {
+    const double q = num * d.y;
+    return fma(fma(-d.den, q, num), d.y, q);
+}
+__device__ __forceinline__ double div_pos(double num, double den) { return div_pos(num, make_pos_div(den)); }
 
 // bounded phase in float64 from an fp32 time value and fp32-held tau/delay (promp / dmp rows)
 template <class CF>
-__device__ __forceinline__ double phase_f64(const DevCfg& c, float time, float tau, float delay, const CF& cf) {
-    const double s = div_pos((double)time - (double)delay, (double)tau);
+__device__ __forceinline__ double phase_f64(const DevCfg& c, float time, const PosDiv& tau, float delay, const CF& cf) {
+    const double s = div_pos((double)time - (double)delay, tau);
     if (c.phase_type == MPK_PHASE_LINEAR) return fmin(fmax(s, 0.0), 1.0);
     return exp_nonpos(-(double)c.alpha_phase * fmax(s, 0.0), cf);
+}
+template <class CF>
+__device__ __forceinline__ double phase_f64(const DevCfg& c, float time, float tau, float delay, const CF& cf) {
+    return phase_f64(c, time, make_pos_div((double)tau), delay, cf);
 }
 
 
@@ -2733,6 +2745,7 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
             // table index = round(max((t - delay) / tau, 0) / scaled_dt): both quotients correctly rounded (div_exact), the
             // reciprocals taken once per episode / kernel instead of two IEEE divisions per step
             const ExactDiv dtau = make_exact_div(tau);
+            const PosDiv taud = make_pos_div((double)tau);       // promp: the float64 phase divides by tau at every step
             if (MP == MPK_MP_PRODMP) {
                 // Boundary conditions (SURVEY A.5 / mp_pytorch ProDMP): the episode's columns were built per chunk above;
                 // xi1..xi4 are per (episode, step): the step's lane forms them below in float64 from the table values and
@@ -2790,7 +2803,7 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
                     hq[2 * KS - 2] = (float)(bcc * y2 - bcd * y1);
                     hq[2 * KS - 1] = (float)(bcc * dy2 - bcd * dy1);
                 } else {
-                    const double x = phase_f64(c, time, tau, delay, ec);
+                    const double x = phase_f64(c, time, taud, delay, ec);
 #pragma unroll
                     for (int k = 0; k < KS; ++k) h[k] = 0.0f;
                     rbf_row<KS>(c, sCen, sCen + c.n_total, x, (double)c.ws, h, ec);
@@ -2874,8 +2887,8 @@ __global__ void __launch_bounds__(256) k_traj_phase_dmp(const PhaseArgs a) {
     const int seg = TT * D;                             // floats of one episode's tile
     float* sBT = smem + a.c_pad;                        // [t_pad] base times, shared by the workgroup
     float* sX = sBT + a.t_pad + (size_t)wave * a.wave_floats;   // [E][D][KS] columns: weights .., goal, y0, ydot0
-    float* sPh = sX + E * a.x_pad;                      // [E][4] tau, delay, init_time (clipped)
-    float* sDs = sPh + 4 * E;                           // [E][TT] ds of the tile's steps
+    float* sPh = sX + E * a.x_pad;                      // [E][8] tau, delay, init_time (clipped), -, 1 / tau refined (float64), -
+    float* sDs = sPh + 8 * E;                           // [E][TT] ds of the tile's steps
     float* sH = sDs + E * TT;                           // [64][KS] the round's RBF rows
     float* sP = sH + 64 * KS;                           // [E][TT * D] forcing -> pos
     float* sV = sP + a.o_pad;                           // [E][TT * D] vel
@@ -2904,7 +2917,10 @@ __global__ void __launch_bounds__(256) k_traj_phase_dmp(const PhaseArgs a) {
             if (c.learn_tau) tau = fminf(fmaxf(prm[0], c.tau_lo), c.tau_hi);
             if (c.learn_delay) delay = fminf(fmaxf(prm[c.learn_tau ? 1 : 0], c.delay_lo), c.delay_hi);
             if (a.init_time) it = a.init_time[b0 + le];
-            if (ld == 0) { sPh[4 * le] = tau; sPh[4 * le + 1] = delay; sPh[4 * le + 2] = it; }
+            if (ld == 0) {
+                sPh[8 * le] = tau; sPh[8 * le + 1] = delay; sPh[8 * le + 2] = it;
+                *reinterpret_cast<double*>(sPh + 8 * le + 4) = make_pos_div((double)tau).y;
+            }
         }
         __builtin_amdgcn_wave_barrier();
         float y = 0.0f, z = 0.0f, g = 0.0f;
@@ -2921,9 +2937,10 @@ __global__ void __launch_bounds__(256) k_traj_phase_dmp(const PhaseArgs a) {
                 const bool live = idx < ne * TT && t < T;
                 float* row = sH + lane * KS;
                 if (live) {
-                    const float taue = sPh[4 * e], delaye = sPh[4 * e + 1], ite = sPh[4 * e + 2];
+                    const float taue = sPh[8 * e], delaye = sPh[8 * e + 1], ite = sPh[8 * e + 2];
                     const float time = sBT[t] + ite;
-                    const double x = phase_f64(c, time, taue, delaye, ExpLiteral());
+                    const PosDiv taud{(double)taue, *reinterpret_cast<const double*>(sPh + 8 * e + 4)};
+                    const double x = phase_f64(c, time, taud, delaye, ExpLiteral());
                     for (int k = c.nb; k < KS; ++k) row[k] = 0.0f;
                     rbf_cols(c, x, x * (double)c.ws, row, 1);
                     if (t < T - 1) sDs[idx] = scaled_time(sBT[t + 1] + ite, delaye, taue) - scaled_time(time, delaye, taue);
@@ -3030,7 +3047,7 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
         if (tune.phase_chunk >= 1 && tune.phase_chunk <= e_max) E = tune.phase_chunk;
         pa.chunk = E;
         pa.o_pad = E * 16 * c.D;                                  // one (pos or vel) tile of the chunk
-        pa.wave_floats = E * pa.x_pad + 4 * E + E * 16 + 64 * KS + 2 * pa.o_pad;
+        pa.wave_floats = E * pa.x_pad + 8 * E + E * 16 + 64 * KS + 2 * pa.o_pad;
         pa.vec_ok = ((reinterpret_cast<uintptr_t>(pa.pos) | reinterpret_cast<uintptr_t>(pa.vel)) & 15u) == 0 && (c.T * c.D) % 4 == 0 ? 1 : 0;
     } else {
         // chunks of up to 4 consecutive episodes whose parameter rows fit the loader's 5 x 64 values and whose boundary

@@ -2513,6 +2513,16 @@ __device__ __forceinline__ float phase_x_value(const DevCfg& c, const float* __r
     return k < c.nb ? prm[c.off + dd * c.Kloc + k] : ip[dd];
 }
 
+// the value of the neighbouring lane (lane + 1 / lane - 1 of the 64) as ONE vector instruction (DPP wave shift) instead
+// of an LDS round trip (ds_bpermute behind __shfl_*): the ProMP velocity takes two of them per (step, DoF).  The lane
+// without a neighbour reads 0; nothing uses it.
+__device__ __forceinline__ float lane_above(float x) {      // x of lane + 1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_below(float x) {      // x of lane - 1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, false));
+}
+
 template <int KQ>
 __device__ __forceinline__ float row_chain(const float* __restrict__ row, const float (&x)[KQ * 4]) {
     float acc = 0.0f;
@@ -2835,9 +2845,9 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
                     } else {
 #pragma unroll
                         for (int k = 0; k < KS; ++k) p = fmaf(h[k], x[k], p);
-                        const float nx = __shfl_down(p, 1);
+                        const float nx = lane_above(p);
                         v = (nx - p) * rdt;
-                        const float pv = __shfl_up(v, 1);      // last row repeats the difference before it
+                        const float pv = lane_below(v);         // last row repeats the difference before it
                         if (r0 + lane == T - 1) v = pv;
                     }
                     sO0[sh + lane * D + d] = p;        // every lane: the staging holds 64 rows, rows >= nout never leave

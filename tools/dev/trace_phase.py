@@ -30,12 +30,15 @@ def main():
     dev = torch.device("cuda", 0)
     lib = C.CDLL(_lib.LIB_PATH)
     lib.mpk_debug_trace.argtypes = [C.c_void_p, C.c_int]
-    kw = KW["cfg2tau"]
+    name = next((x for x in args if x in KW), "cfg2tau")      # cfg2tau (prodmp) | cfg5tau (promp)
+    kw = KW[name]
     eng = TrajectoryEngine(device=0, **kw)
     g = torch.Generator().manual_seed(0)
     lo, hi = kw["tau_bound"]
     params = torch.randn((B, eng.num_params), generator=g)
     params[:, 0] = torch.rand(B, generator=g) * (hi - lo) * 0.6 + lo + 0.3 * (hi - lo)
+    if kw.get("learn_delay"):
+        params[:, 1] = torch.rand(B, generator=g) * 0.1 + 0.05
     params = params.to(dev)
     ip = (torch.rand((B, 7), generator=g) * 2 - 1).to(dev)
     iv = torch.zeros((B, 7), device=dev)

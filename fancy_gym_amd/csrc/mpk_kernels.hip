@@ -2895,6 +2895,7 @@ __global__ void __launch_bounds__(256) k_traj_phase_dmp(const PhaseArgs a) {
     const int wpb = (int)(blockDim.x >> 6);
     const int D = c.D, T = c.T, E = a.chunk, P = c.P;
     const int seg = TT * D;                             // floats of one episode's tile
+    double* sCen = reinterpret_cast<double*>(smem);     // [c_pad / 2] RBF centres | bandwidths (| recurrence constants)
     float* sBT = smem + a.c_pad;                        // [t_pad] base times, shared by the workgroup
     float* sX = sBT + a.t_pad + (size_t)wave * a.wave_floats;   // [E][D][KS] columns: weights .., goal, y0, ydot0
     float* sPh = sX + E * a.x_pad;                      // [E][8] tau, delay, init_time (clipped), -, 1 / tau refined (float64), -
@@ -2903,6 +2904,7 @@ __global__ void __launch_bounds__(256) k_traj_phase_dmp(const PhaseArgs a) {
     float* sP = sH + 64 * KS;                           // [E][TT * D] forcing -> pos
     float* sV = sP + a.o_pad;                           // [E][TT * D] vel
     for (int t = threadIdx.x; t < T; t += blockDim.x) sBT[t] = c.base_times[t];
+    for (int k = threadIdx.x; k < 2 * c.n_total + 3; k += blockDim.x) sCen[k] = c.tab[k];
     __syncthreads();
     const float inv_d = 1.0f / (float)D;
     const int le = (int)(((float)lane + 0.5f) * inv_d), ld = lane - le * D;        // lane <-> (episode, DoF)
@@ -2951,8 +2953,14 @@ __global__ void __launch_bounds__(256) k_traj_phase_dmp(const PhaseArgs a) {
                     const float time = sBT[t] + ite;
                     const PosDiv taud{(double)taue, *reinterpret_cast<const double*>(sPh + 8 * e + 4)};
                     const double x = phase_f64(c, time, taud, delaye, ExpLiteral());
-                    for (int k = c.nb; k < KS; ++k) row[k] = 0.0f;
-                    rbf_cols(c, x, x * (double)c.ws, row, 1);
+                    // every RBF once, in registers (rbf_cols evaluates them for the sum and again for the values; same bits)
+                    float h[KS];
+#pragma unroll
+                    for (int k = 0; k < KS; ++k) h[k] = 0.0f;
+                    rbf_row<KS>(c, sCen, sCen + c.n_total, x, x * (double)c.ws, h, ExpLiteral());
+#pragma unroll
+                    for (int j = 0; j < KQ; ++j)
+                        *reinterpret_cast<f32x4*>(row + 4 * j) = f32x4{h[4 * j], h[4 * j + 1], h[4 * j + 2], h[4 * j + 3]};
                     if (t < T - 1) sDs[idx] = scaled_time(sBT[t + 1] + ite, delaye, taue) - scaled_time(time, delaye, taue);
                 }
                 __builtin_amdgcn_wave_barrier();

@@ -2569,21 +2569,25 @@ struct PhaseFetch {
     }
 };
 
-// n floats staged at so[sh ...] (sh = 16-byte phase of the destination) -> out[0 .. n): float4 body, dword head / tail
+// n floats staged at s0 / s1 [sh ...] (sh = 16-byte phase of the destinations: pos and vel share it) -> o0 / o1 [0 .. n):
+// float4 body, dword head / tail, both arrays in one pass (shared chunk arithmetic)
 // WT: write-through stores, every one of them (cache-resident batches; see store16)
 template <bool WT>
-__device__ __forceinline__ void flush_span(const float* __restrict__ so, float* __restrict__ out, int n, int sh,
-                                           int lane) {
-    float* base = out - sh;                              // 16-byte aligned
+__device__ __forceinline__ void flush_span2(const float* __restrict__ s0, const float* __restrict__ s1, float* __restrict__ o0,
+                                            float* __restrict__ o1, int n, int sh, int lane) {
     const int end = sh + n;
     const int q0 = (sh + 3) >> 2, q1 = end >> 2;
-    for (int q = q0 + lane; q < q1; q += 64)
-        store16<WT>(base + 4 * q, *reinterpret_cast<const f32x4*>(so + 4 * q));
+    for (int q = q0 + lane; q < q1; q += 64) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(s0 + 4 * q), b = *reinterpret_cast<const f32x4*>(s1 + 4 * q);
+        store16<WT>(o0 - sh + 4 * q, a);
+        store16<WT>(o1 - sh + 4 * q, b);
+    }
     const int head_end = 4 * q0 < end ? 4 * q0 : end;
-    if (lane < head_end - sh) store4<WT>(base + sh + lane, so[sh + lane]);
+    if (lane < head_end - sh) { store4<WT>(o0 + lane, s0[sh + lane]); store4<WT>(o1 + lane, s1[sh + lane]); }
     const int tail = 4 * q1 > head_end ? 4 * q1 : head_end;
-    if (lane < end - tail) store4<WT>(base + tail + lane, so[tail + lane]);
+    if (lane < end - tail) { store4<WT>(o0 - sh + tail + lane, s0[tail + lane]); store4<WT>(o1 - sh + tail + lane, s1[tail + lane]); }
 }
+
 
 // TL (prodmp): the fp32 row table is staged in the workgroup's LDS (row stride 2*KS + 4 floats: 16-byte aligned rows
 // spread over the banks) and the workgroup is up to 16 waves, so row and boundary gathers never enter the memory queue
@@ -2808,10 +2812,11 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
                     // the two boundary-condition columns
                     const double* y4 = reinterpret_cast<const double*>(row + (2 * KS - 4) / 4);
                     const double y1 = y4[0], y2 = y4[1], dy1 = y4[2], dy2 = y4[3];
-                    hq[2 * KS - 4] = (float)(bca * y1 - bcb * y2);
-                    hq[2 * KS - 3] = (float)(bca * dy1 - bcb * dy2);
-                    hq[2 * KS - 2] = (float)(bcc * y2 - bcd * y1);
-                    hq[2 * KS - 1] = (float)(bcc * dy2 - bcd * dy1);
+                    // (a product and a fused multiply-add each: float64 runs at half rate, and this is per step)
+                    hq[2 * KS - 4] = (float)fma(bca, y1, -(bcb * y2));
+                    hq[2 * KS - 3] = (float)fma(bca, dy1, -(bcb * dy2));
+                    hq[2 * KS - 2] = (float)fma(bcc, y2, -(bcd * y1));
+                    hq[2 * KS - 1] = (float)fma(bcc, dy2, -(bcd * dy1));
                 } else {
                     const double x = phase_f64(c, time, taud, delay, ec);
 #pragma unroll
@@ -2862,13 +2867,8 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
                 for (; d < D; ++d) dof(d);
                 __builtin_amdgcn_wave_barrier();
                 MPK_STAMP(12 + 40 * e + (r0 ? 10 : 0));   // contracted, staged
-                if (a.wt) {
-                    flush_span<true>(sO0, gp, nout * D, sh, lane);
-                    flush_span<true>(sO1, out_vel + (size_t)r0 * D, nout * D, sh, lane);
-                } else {
-                    flush_span<false>(sO0, gp, nout * D, sh, lane);
-                    flush_span<false>(sO1, out_vel + (size_t)r0 * D, nout * D, sh, lane);
-                }
+                if (a.wt) flush_span2<true>(sO0, sO1, gp, out_vel + (size_t)r0 * D, nout * D, sh, lane);
+                else flush_span2<false>(sO0, sO1, gp, out_vel + (size_t)r0 * D, nout * D, sh, lane);
                 __builtin_amdgcn_wave_barrier();
                 MPK_STAMP(13 + 40 * e + (r0 ? 10 : 0));   // stored
                 if (final_round) break;

@@ -1063,6 +1063,21 @@ def test_bench_gpus_2_starts_two_ranks_itself_and_gathers_both_shards():
         assert int(shard.view(torch.int32).to(torch.int64).sum().item()) == ag["shard_checksums"][rank], rank
 
 
+def test_rccl_calls_of_the_bench_with_one_rank():
+    """The torch.distributed calls bench.py makes for N > 1 -- init_process_group("nccl", device_id=...), barrier,
+    all_reduce MAX of the elapsed time, all_gather_into_tensor of the (pos | vel) shard, all_gather of the int64 checksums
+    -- over RCCL with world_size 1 (a gpurun box has one GPU, and RCCL refuses two ranks on one device; the two-rank
+    rehearsal above runs over gloo)"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_world1.py")], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "rccl world-1 ok, backend nccl" in r.stdout
+
+
 def test_native_rccl_all_gather_single_rank(monkeypatch):
     """mpk_comm_* / mpk_allgather (RCCL bound lazily inside libmpk.so): one rank, out of place and in place"""
     from fancy_gym_amd.distributed import NativeComm

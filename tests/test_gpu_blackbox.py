@@ -1063,6 +1063,47 @@ def test_bench_gpus_2_starts_two_ranks_itself_and_gathers_both_shards():
         assert int(shard.view(torch.int32).to(torch.int64).sum().item()) == ag["shard_checksums"][rank], rank
 
 
+def test_bench_line_carries_the_whole_contract():
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` (the driver's form): ONE JSON line on stdout, last, with every key
+    the measurement contract names -- metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better /
+    scaling / vs_baseline / dtype / data / config.workload, roofline {bound, achieved, peak, unit, frac, traffic} for the
+    dominant kernel, cpu_baseline {value, unit, cores, kind, sample} -- and numbers that are consistent with each other"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and r.stdout.strip().splitlines()[-1] == lines[0]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    # value = units / time, the kernel's share of the step, the roofline arithmetic
+    B = d["config"]["batch_per_gpu"]
+    assert abs(d["value"] - B / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["kernel_avg_us"] * 1e-6) / 1e9) <= 1e-6 * rf["achieved"]
+    assert rf["algorithmic_bytes_per_launch"] == B * 8624 and rf["kernel"] == "k_traj_tiles<prodmp,act>"
+    assert 0.5 * rf["kernel_avg_us"] < d["ms_per_step"] * 1e3 < 3.0 * rf["kernel_avg_us"]
+    assert rf["traffic"] is None or 0.9 < rf["traffic"] / rf["algorithmic_bytes_per_launch"] < 1.5
+    cb = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == d["unit"] and cb["value"] > 0
+    assert cb["all_cores"]["cores"] >= 1 and cb["all_cores"]["value"] > 0
+    assert 1e3 < d["value"] / cb["value"] < 1e6
+
+
 def test_rccl_calls_of_the_bench_with_one_rank():
     """The torch.distributed calls bench.py makes for N > 1 -- init_process_group("nccl", device_id=...), barrier,
     all_reduce MAX of the elapsed time, all_gather_into_tensor of the (pos | vel) shard, all_gather of the int64 checksums

@@ -144,6 +144,122 @@ def cpu_baseline(seconds: float, batch: int):
                           "threads_scan": {str(k): v for k, v in scan.items()}}}
 
 
+def rccl_debug_setup(rank: int):
+    """
+    Make the first multi-GPU run document itself: unless the caller chose an NCCL_DEBUG level, RCCL logs its INIT and
+    TUNING lines (rings / channels at communicator creation; algorithm, protocol and channel range per collective) into a
+    per-process file, which `rccl_report` condenses into the "allgather" object.  Nothing is logged inside the headline's
+    timed region (it makes no RCCL call).  Returns the log path or None.
+    """
+    if "NCCL_DEBUG" in os.environ and os.environ["NCCL_DEBUG"].upper() not in ("VERSION", "WARN"):
+        return os.environ.get("NCCL_DEBUG_FILE")          # the caller is debugging: leave everything alone
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), f"mpk_bench_rccl.{os.getpid()}.log")
+    os.environ["NCCL_DEBUG"] = "INFO"
+    os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,TUNING")
+    os.environ["NCCL_DEBUG_FILE"] = path
+    return path
+
+
+def rccl_report(path):
+    """algorithm / protocol / channels RCCL chose, parsed from its own log (formats of librccl 2.2x: `<Coll>: <n> Bytes ->
+    Algo <a> proto <p> channel{Lo..Hi}={l..h}`, `comm:..., coll channels:<n> ... p2p channels:<n>`, `Channel xx/yy : a[..] -> b[..] via <transport>`)"""
+    import re
+    if not path or not os.path.exists(path):
+        return None
+    try:
+        with open(path, errors="replace") as f:
+            text = f.read()
+    except OSError:
+        return None
+    rep = {}
+    m = re.search(r"coll channels:\s*(\d+).*?p2p channels:\s*(\d+)", text)
+    if m:
+        rep["coll_channels"], rep["p2p_channels"] = int(m.group(1)), int(m.group(2))
+    m = re.search(r"RCCL version\s*:?\s*([^\s]+)", text) or re.search(r"NCCL version\s*([^\s]+)", text)
+    if m:
+        rep["version"] = m.group(1)
+    transports = sorted(set(re.findall(r"Channel \d+(?:/\d+)? : \d+\[[0-9a-f]+\] -> \d+\[[0-9a-f]+\] (?:\[\w+\] )?via (\S+)", text)))
+    if transports:
+        rep["transports"] = transports
+    colls = {}
+    for name, nbytes, algo, proto, lo, hi in re.findall(
+            r"(\w+): (\d+) Bytes -> Algo (\S+) proto (\S+) channel\{Lo\.\.Hi\}=\{(\d+)\.\.(\d+)\}", text):
+        key = f"{name}/{nbytes}B"
+        c = colls.setdefault(key, {"collective": name, "bytes": int(nbytes), "algo": algo, "proto": proto,
+                                   "channels": int(hi) - int(lo) + 1, "calls": 0})
+        c["calls"] += 1
+    if colls:
+        rep["collectives"] = sorted(colls.values(), key=lambda c: -c["bytes"])[:6]
+    rep["log_lines"] = text.count("\n")
+    return rep or None
+
+
+def gpu_state_sysfs(dev_index: int = 0):
+    """
+    Clocks / power / temperatures of the GPU this process runs on, read from sysfs files IN-PROCESS (no child process:
+    `rocm-smi` is a `#!/usr/bin/env python3` script, and spawning it from a process running under rocprofv3 would be the
+    exec-after-GPU-init hop this pool forbids).  Best effort: missing files are skipped, never an error.
+    """
+    import glob
+    out = {}
+    try:
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(dev_index)
+            want = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        except Exception:  # noqa: BLE001
+            pass
+        cards = []
+        for c in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
+            if "-" in os.path.basename(c):
+                continue
+            d = os.path.join(c, "device")
+            try:
+                with open(os.path.join(d, "vendor")) as f:
+                    if f.read().strip() != "0x1002":
+                        continue
+            except OSError:
+                continue
+            cards.append(d)
+        if not cards:
+            return out
+        dev = next((d for d in cards if want and os.path.basename(os.path.realpath(d)) == want), cards[min(dev_index, len(cards) - 1)])
+        out["sysfs_device"] = os.path.basename(os.path.realpath(dev))
+
+        def rd(path):
+            try:
+                with open(path) as f:
+                    return f.read().strip()
+            except OSError:
+                return None
+        for name in ("sclk", "mclk", "fclk", "socclk"):
+            txt = rd(os.path.join(dev, "pp_dpm_" + name))
+            if txt:
+                cur = [ln for ln in txt.splitlines() if ln.rstrip().endswith("*")] or txt.splitlines()[-1:]
+                digits = "".join(ch for ch in cur[0].split(":")[-1] if ch.isdigit())
+                if digits:
+                    out[name + "_mhz"] = int(digits)
+        for key in ("gpu_busy_percent", "mem_busy_percent"):
+            v = rd(os.path.join(dev, key))
+            if v and v.lstrip("-").isdigit():
+                out[key] = int(v)
+        for hw in glob.glob(os.path.join(dev, "hwmon", "hwmon*")):
+            for key in ("power1_average", "power1_input"):
+                v = rd(os.path.join(hw, key))
+                if v and v.isdigit():
+                    out["package_power_w"] = int(v) / 1e6
+                    break
+            for tin in glob.glob(os.path.join(hw, "temp*_input")):
+                v = rd(tin)
+                label = rd(tin.replace("_input", "_label")) or os.path.basename(tin).replace("_input", "")
+                if v and v.lstrip("-").isdigit():
+                    out["temp_" + label.lower().replace(" ", "_") + "_c"] = int(v) / 1000.0
+    except Exception:  # noqa: BLE001 - the sample is optional
+        pass
+    return out
+
+
 def synth_inputs(B: int, seed: int):
     """synthetic MP parameters of the named shape (BASELINE.md section 4): params ~ N(0,1), init_pos ~ U(-1,1), init_vel = 0;
     seed 0 on one GPU, 1000 + rank when sharded"""
@@ -187,9 +303,9 @@ def main():
     # MPK_BENCH_FORCE_DIST=1 runs the collective code path (RCCL) even with a single rank, to exercise it on a 1-GPU box
     force_dist = os.environ.get("MPK_BENCH_FORCE_DIST") == "1"
     if world > 1 or force_dist:
-        # RCCL prints a version banner on stdout at NCCL_DEBUG=VERSION; stdout must carry the JSON line only
-        if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
-            os.environ["NCCL_DEBUG"] = "WARN"
+        # RCCL prints a version banner on stdout at NCCL_DEBUG=VERSION; stdout must carry the JSON line only.  Its INIT /
+        # TUNING lines go to a per-process file instead (rccl_debug_setup) and come back condensed in "allgather.rccl".
+        rccl_log = rccl_debug_setup(rank)
         import torch.distributed as dist
         # MPK_BENCH_BACKEND=gloo + more ranks than GPUs: a rehearsal of the N > 1 code path on a 1-GPU box (ranks share
         # the device; RCCL refuses that, gloo does not care).  The driver's runs use the default: one rank per GPU, RCCL.
@@ -205,6 +321,7 @@ def main():
             dist.init_process_group(backend)
     else:
         dist = None
+        rccl_log = None
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank)
 
@@ -277,11 +394,15 @@ def main():
             for _ in range(K):
                 step(sp)
 
+    # every rank: barrier -> synchronize -> t0 -> K steps -> synchronize -> t1.  The closing barrier sits OUTSIDE the
+    # clock: the MAX over ranks below already accounts for the slowest rank, and an RCCL barrier (a 1-element all-reduce
+    # + host sync, tens of us) inside a 0.2 ms region would tax the N-rank line with something the 1-rank line never pays.
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     k_steps()
-    torch.cuda.synchronize(); barrier()
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    barrier()
     # the kernel's average launch duration for the roofline line: the same K steps once more, bracketed by HIP events on
     # the launch stream (kept out of the wall-clock region above: two event records cost a short run several percent)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -297,63 +418,88 @@ def main():
     value = world * B * K / elapsed
 
     # ---- optional: generation + all-gather of (pos | vel) over RCCL/xGMI ------------------------------------------
+    # Failures are made COLLECTIVE: everything that can fail locally (allocation, the first launch) happens before the
+    # first collective of the leg and is agreed on with a MIN all-reduce, so a rank never leaves its peers blocked in a
+    # collective; a failure after the collectives have started ends the rank non-zero (the launcher then ends the job).
     allgather = None
     if dist is not None and not args.no_allgather:
+        from fancy_gym_amd.distributed import TrajectoryShard
+        Kg = max(10, min(K, 200))
+        local_err = None
         try:
-            Kg = max(10, min(K, 200))
-            shard = torch.empty((2, B, T_STEPS, D), dtype=torch.float32, device=dev)   # the kernel writes (pos | vel) here
-            full = torch.empty((world,) + tuple(shard.shape), dtype=torch.float32, device=dev)
-            full_cat = full.view((world * shard.shape[0],) + tuple(shard.shape[1:]))   # the shape gloo's all-gather insists on
-            sp0, sp1 = shard[0].data_ptr(), shard[1].data_ptr()
+            shard = TrajectoryShard(world * B, T_STEPS, D, dev, rank=rank, world=world)   # the kernel writes (pos | vel) here
+            full = torch.empty((world,) + tuple(shard.buf.shape), dtype=torch.float32, device=dev)
+            sp0, sp1 = shard.pos.data_ptr(), shard.vel.data_ptr()
 
             def step_into_shard():
                 rc = lib.mpk_trajectory_actions(h, ptrs[0], ptrs[1], ptrs[2], 0.0, rcfg, cp, cv, sp0, sp1, outs[2], B, sp)
                 if rc != 0:
                     raise RuntimeError(_lib.last_error())
-            for _ in range(5):
-                step_into_shard(); dist.all_gather_into_tensor(full_cat, shard)
-            barrier(); torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(Kg):
-                step_into_shard(); dist.all_gather_into_tensor(full_cat, shard)
-            torch.cuda.synchronize(); barrier()
-            e2 = time.perf_counter() - t1
-            t = torch.tensor([e2], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            e2 = float(t.item())
-            # what arrived: an exact, order-independent checksum (sum of the fp32 bit patterns as int64) of every rank's own
-            # shard, exchanged on the host, against the same checksum of the slice rank 0 received for that rank
-            def bits_sum(t):
-                return int(t.contiguous().view(torch.int32).to(torch.int64).sum().item())
-            mine = torch.tensor([bits_sum(shard)], dtype=torch.int64, device=dev)
-            sums = [torch.zeros_like(mine) for _ in range(world)]
-            dist.all_gather(sums, mine)
-            shard_sums = [int(x.item()) for x in sums]
-            gathered_ok = all(bits_sum(full[r]) == shard_sums[r] for r in range(world))
-            allgather = {"value": world * B * Kg / e2, "unit": "trajectories/s", "steps": Kg,
-                         "ms_per_step": e2 / Kg * 1e3, "bytes_gathered_per_gpu_per_step": int((world - 1) * shard.numel() * 4),
-                         "via": f"torch.distributed all_gather_into_tensor ({'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()})",
-                         "gathered_equals_shards": bool(gathered_ok), "shard_checksums": shard_sums}
-            if os.environ.get("MPK_BENCH_NATIVE_COMM") == "1":
-                # opt-in: the same leg through libmpk's own RCCL communicator (mpk_comm_* / mpk_allgather, include/mpk.h)
-                from fancy_gym_amd.distributed import NativeComm
-                comm = NativeComm(rank, world, local_rank)
+            step_into_shard()
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001 - agreed on below
+            local_err = str(e)[:200]
+            print(f"[bench] all-gather leg: rank {rank} cannot take part: {local_err}", file=sys.stderr)
+        okf = torch.tensor([0 if local_err else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+        if int(okf.item()) == 0:
+            allgather = {"error": local_err or "another rank could not allocate / launch; leg skipped on every rank"}
+        else:
+            try:
                 for _ in range(5):
-                    step_into_shard(); comm.all_gather(shard, out=full, stream=stream)
+                    step_into_shard(); shard.gather(out=full)
                 barrier(); torch.cuda.synchronize()
-                t2 = time.perf_counter()
+                t1 = time.perf_counter()
                 for _ in range(Kg):
-                    step_into_shard(); comm.all_gather(shard, out=full, stream=stream)
-                torch.cuda.synchronize(); barrier()
-                e3 = time.perf_counter() - t2
-                t = torch.tensor([e3], dtype=torch.float64, device=dev)
+                    step_into_shard(); shard.gather(out=full)
+                torch.cuda.synchronize()
+                e2 = time.perf_counter() - t1
+                barrier()
+                t = torch.tensor([e2], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                e3 = float(t.item())
-                allgather["native"] = {"value": world * B * Kg / e3, "ms_per_step": e3 / Kg * 1e3, "via": "mpk_allgather"}
-                comm.close()
-        except Exception as e:  # noqa: BLE001 - the extra leg must never cost the headline line
-            print(f"[bench] all-gather leg failed on rank {rank}: {e}", file=sys.stderr)
-            allgather = {"error": str(e)[:200]}
+                e2 = float(t.item())
+                # what arrived: an exact, order-independent checksum (sum of the fp32 bit patterns as int64) of every
+                # rank's own shard, exchanged on the host, against the same checksum of the slice rank 0 received
+                def bits_sum(t):
+                    return int(t.contiguous().view(torch.int32).to(torch.int64).sum().item())
+                mine = torch.tensor([bits_sum(shard.buf)], dtype=torch.int64, device=dev)
+                sums = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(sums, mine)
+                shard_sums = [int(x.item()) for x in sums]
+                gathered_ok = all(bits_sum(full[r]) == shard_sums[r] for r in range(world))
+                allgather = {"value": world * B * Kg / e2, "unit": "trajectories/s", "steps": Kg,
+                             "ms_per_step": e2 / Kg * 1e3,
+                             "bytes_gathered_per_gpu_per_step": int((world - 1) * shard.buf.numel() * 4),
+                             "via": f"torch.distributed all_gather_into_tensor ({'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()}), "
+                                    "zero-copy: the kernels write into the send buffer (distributed.TrajectoryShard)",
+                             "gathered_equals_shards": bool(gathered_ok), "shard_checksums": shard_sums}
+                if os.environ.get("MPK_BENCH_NATIVE_COMM") == "1":
+                    # opt-in: the same leg through libmpk's own RCCL communicator (mpk_comm_* / mpk_allgather, include/mpk.h)
+                    from fancy_gym_amd.distributed import NativeComm
+                    comm = NativeComm(rank, world, local_rank)
+                    for _ in range(5):
+                        step_into_shard(); comm.all_gather(shard.buf, out=full, stream=stream)
+                    barrier(); torch.cuda.synchronize()
+                    t2 = time.perf_counter()
+                    for _ in range(Kg):
+                        step_into_shard(); comm.all_gather(shard.buf, out=full, stream=stream)
+                    torch.cuda.synchronize()
+                    e3 = time.perf_counter() - t2
+                    barrier()
+                    t = torch.tensor([e3], dtype=torch.float64, device=dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    e3 = float(t.item())
+                    allgather["native"] = {"value": world * B * Kg / e3, "ms_per_step": e3 / Kg * 1e3, "via": "mpk_allgather"}
+                    comm.close()
+            except Exception as e:  # noqa: BLE001
+                # collectives of this leg have started: peers may be waiting in one.  Leave non-zero so that the launcher
+                # (torch.distributed.run) ends every rank instead of letting them wait for the collective's timeout.
+                print(f"[bench] all-gather leg failed on rank {rank} after its collectives started: {e}", file=sys.stderr)
+                sys.stderr.flush()
+                os._exit(3)
+            rccl = rccl_report(rccl_log)
+            if rccl is not None and rank == 0:
+                allgather["rccl"] = rccl
 
     headline_kernel = eng.last_kernel()
     # ---- the same kernel family where the outputs really stream to HBM (B = 262144: 2.2 GB written per launch) ---------
@@ -375,42 +521,16 @@ def main():
                 if rc_ != 0:
                     raise RuntimeError(_lib.last_error())
             # the shader clock needs ~20 ms of streaming load to settle under the package power cap (tools/clock_probe.py:
-            # 449 us for the first 40 launches, 422 after), so the row is warmed for ~0.3 s; one rocm-smi sample taken
-            # meanwhile records the clocks / power the number was measured at (boxes differ)
+            # 449 us for the first 40 launches, 422 after), so the row is warmed for ~0.3 s; one sysfs sample taken with
+            # launches in flight records the clocks / power / temperatures the number was measured at (boxes differ)
             smi = {}
-
-            def sample_smi():
-                try:
-                    import subprocess
-                    r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp", "--json"],
-                                       capture_output=True, text=True, timeout=5)
-                    card = next(iter(json.loads(r.stdout).values()))
-                    for k, v in card.items():
-                        if "sclk clock speed" in k or "mclk clock speed" in k or "fclk clock speed" in k:
-                            smi[k.split()[0] + "_mhz"] = int("".join(ch for ch in v if ch.isdigit()))
-                        elif "Power" in k:
-                            smi["package_power_w"] = float(v)
-                        elif "Temperature" in k and "(C)" in k:
-                            # e.g. "Temperature (Sensor memory) (C)", "Temperature (Sensor HBM 0) (C)": HBM above ~85 C
-                            # refreshes at twice the rate
-                            name = k[k.index("Sensor") + 7:k.index(")")].strip().lower().replace(" ", "_")
-                            try:
-                                smi["temp_" + name + "_c"] = float(v)
-                            except ValueError:
-                                pass
-                except Exception:  # noqa: BLE001 - the sample is optional
-                    pass
-            import threading
-            th = threading.Thread(target=sample_smi)
             t_w = time.perf_counter()
-            th.start()
-            while time.perf_counter() - t_w < 0.3 or th.is_alive():
+            while time.perf_counter() - t_w < 0.3:
                 for _ in range(10):
                     sstep()
+                if not smi and time.perf_counter() - t_w > 0.15:
+                    smi = gpu_state_sysfs(local_rank)
                 torch.cuda.synchronize()
-                if time.perf_counter() - t_w > 3.0:
-                    break
-            th.join(timeout=5)
             Ks = 30
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
@@ -456,6 +576,8 @@ def main():
                        "sharding": f"dp{world} (independent episodes, no data-path collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(B),
+                         "traffic_source": "profiles/pmc_traffic.json: rocprofv3 --pmc passes of this command on an earlier "
+                                           "call (tools/pmc_traffic.sh), committed; not re-measured in this run",
                          "kernel": headline_kernel, "kernel_avg_us": kern_avg * 1e6,
                          "algorithmic_bytes_per_launch": BYTES_PER_TRAJ * B},
         }
@@ -470,6 +592,11 @@ def main():
         line = json.dumps(out)
     if dist is not None:
         dist.destroy_process_group()
+        if rccl_log and os.path.basename(rccl_log).startswith("mpk_bench_rccl."):
+            try:
+                os.remove(rccl_log)
+            except OSError:
+                pass
     # the JSON line is the LAST thing on stdout: native libraries (RCCL) buffer their own stdout writes until exit
     try:
         import ctypes

@@ -76,6 +76,7 @@ _vp, _i32, _dbl = C.c_void_p, C.c_int32, C.c_double
 SIGNATURES = {
     "mpk_last_error": (C.c_char_p, []),
     "mpk_abi_version": (C.c_int, []),
+    "mpk_source_hash": (C.c_char_p, []),
     "mpk_device_count": (C.c_int, []),
     "mpk_create": (C.c_int, [C.POINTER(mpk_config), C.POINTER(_vp)]),
     "mpk_destroy": (None, [_vp]),
@@ -123,6 +124,36 @@ SIGNATURES = {
 
 _lib: Optional[C.CDLL] = None
 
+# the files libmpk.so is built from, in the order mpk_source_hash() is defined over (include/mpk.h)
+_ROOT = os.path.dirname(_HERE)
+SOURCE_FILES = (os.path.join(_ROOT, "include", "mpk.h"), os.path.join(_HERE, "csrc", "mpk_internal.h"),
+                os.path.join(_HERE, "csrc", "mpk_host.cpp"), os.path.join(_HERE, "csrc", "mpk_kernels.hip"))
+
+
+def source_hash() -> Optional[str]:
+    """sha256 over the checked-out sources (None when the tree carries no sources, e.g. a binary-only install)"""
+    import hashlib
+    h = hashlib.sha256()
+    for path in SOURCE_FILES:
+        if not os.path.exists(path):
+            return None
+        h.update(os.path.basename(path).encode() + b"\n")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def embedded_source_hash(path: str = None) -> Optional[str]:
+    """the hash stamped into a built library, read from the FILE (no dlopen: a stale library must not get loaded)"""
+    import re
+    path = path or LIB_PATH
+    try:
+        with open(path, "rb") as f:
+            m = re.search(rb"MPK_SOURCE_HASH=([0-9a-f]{64}|unstamped)", f.read())
+    except OSError:
+        return None
+    return m.group(1).decode() if m else None
+
 
 def load() -> C.CDLL:
     """Load libmpk.so (once) and bind every declared symbol; raise MPKLibraryError if that is impossible."""
@@ -146,6 +177,12 @@ def load() -> C.CDLL:
         fn.argtypes = args
     if lib.mpk_abi_version() != MPK_ABI_VERSION:
         raise MPKLibraryError("libmpk.so ABI version mismatch")
+    # the loaded binary must be the checked-out sources (MPK_LIB names a deliberate A/B build: exempt)
+    want, got = source_hash(), (lib.mpk_source_hash() or b"").decode()
+    if want is not None and "MPK_LIB" not in os.environ and got != want:
+        raise MPKLibraryError(
+            f"{LIB_PATH} was built from other sources (stamped {got[:12]}..., checked out {want[:12]}...). Rebuild it with "
+            f"`python -c 'import __graft_entry__ as g; g.build()'`.")
     _lib = lib
     return lib
 

@@ -508,6 +508,13 @@ extern "C" {
 const char* mpk_last_error(void) { return g_err.c_str(); }
 int mpk_abi_version(void) { return MPK_ABI_VERSION; }
 
+#ifndef MPK_SOURCE_HASH
+#define MPK_SOURCE_HASH "unstamped"
+#endif
+// one literal serves both readers: the symbol returns the part behind the marker, tools grep the file for the marker
+static const char kSourceHashMarker[] = "MPK_SOURCE_HASH=" MPK_SOURCE_HASH;
+const char* mpk_source_hash(void) { return kSourceHashMarker + 16; }
+
 int mpk_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -71,13 +71,107 @@ def all_gather_rows(local: torch.Tensor, num_episodes: int, group=None) -> torch
     return torch.cat(parts, dim=0)
 
 
-def gather_trajectories(pos: torch.Tensor, vel: torch.Tensor, num_episodes: int, group=None
-                        ) -> Tuple[torch.Tensor, torch.Tensor]:
-    """the single all-gather of the path: (pos | vel) stacked so that one collective carries both"""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return pos, vel
-    both = all_gather_rows(torch.stack([pos, vel], dim=1), num_episodes, group)   # [B, 2, T, D]
-    return both[:, 0].contiguous(), both[:, 1].contiguous()
+class TrajectoryShard:
+    """
+    This rank's output buffer of the path, laid out for the ONE collective: ``buf [2, cap, T, D]`` fp32 with
+    ``cap = ceil(B / world)``.  The kernels write positions into ``pos = buf[0, :rows]`` and velocities into
+    ``vel = buf[1, :rows]`` (``TrajectoryEngine.trajectory(..., out=(shard.pos, shard.vel))``), so the all-gather sends
+    ``buf`` as it lies: no stack before, no copy after.  Ranks that own one episode fewer (ragged split) leave the last
+    row of each half unused.
+    """
+
+    def __init__(self, num_episodes: int, num_steps: int, num_dof: int, device, rank: Optional[int] = None,
+                 world: Optional[int] = None, group=None):
+        if rank is None:
+            rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if world is None:
+            world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.num_episodes, self.rank, self.world = int(num_episodes), int(rank), int(world)
+        self.cap = -(-self.num_episodes // self.world) if self.num_episodes else 0
+        a, b = shard_bounds(self.num_episodes, self.rank, self.world)
+        self.start, self.rows = a, b - a
+        self.buf = torch.zeros((2, self.cap, int(num_steps), int(num_dof)), dtype=torch.float32, device=device)
+        self.pos, self.vel = self.buf[0, : self.rows], self.buf[1, : self.rows]
+
+    def gather(self, out: Optional[torch.Tensor] = None, group=None) -> "GatheredTrajectories":
+        """ONE all_gather_into_tensor of ``buf`` (RCCL over xGMI with backend "nccl"); nothing else touches the data"""
+        shape = (self.world,) + tuple(self.buf.shape)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float32, device=self.buf.device)
+        elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError(f"out must be a contiguous fp32 tensor of shape {shape}")
+        if self.world == 1 or not dist.is_initialized():
+            if out.data_ptr() != self.buf.data_ptr():
+                out[0].copy_(self.buf)
+        else:
+            # the [world * 2, cap, T, D] view is the shape gloo's all_gather_into_tensor insists on; same memory
+            dist.all_gather_into_tensor(out.view((self.world * 2,) + tuple(self.buf.shape[1:])), self.buf, group=group)
+        return GatheredTrajectories(out, self.num_episodes)
+
+
+class GatheredTrajectories:
+    """
+    What every rank holds after the collective: ``buf [world, 2, cap, T, D]``; ``pos`` / ``vel`` are VIEWS
+    ``[world, cap, T, D]`` (rank-major: episode ``i`` of rank ``r`` is global episode ``shard_bounds(B, r, world)[0] + i``).
+    With an even split ``cap`` rows of every rank are valid; a ragged split leaves ``rows(r) < cap`` for the last ranks.
+    ``flat()`` makes the ``[B, T, D]`` copies for a consumer that insists on one contiguous array per quantity.
+    """
+
+    def __init__(self, buf: torch.Tensor, num_episodes: int):
+        self.buf, self.num_episodes = buf, int(num_episodes)
+        self.world, self.cap = int(buf.shape[0]), int(buf.shape[2])
+        self.pos, self.vel = buf[:, 0], buf[:, 1]
+
+    def rows(self, rank: int) -> int:
+        a, b = shard_bounds(self.num_episodes, rank, self.world)
+        return b - a
+
+    def episode(self, i: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(pos [T, D], vel [T, D]) views of global episode ``i``"""
+        base, extra = divmod(self.num_episodes, self.world)
+        r = i // (base + 1) if i < extra * (base + 1) else extra + (i - extra * (base + 1)) // max(base, 1)
+        j = i - shard_bounds(self.num_episodes, r, self.world)[0]
+        return self.pos[r, j], self.vel[r, j]
+
+    def flat(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """[B, T, D] copies in global episode order (the only place a copy is made, and only on request)"""
+        if self.num_episodes == self.world * self.cap:
+            return self.pos.reshape((self.num_episodes,) + tuple(self.pos.shape[2:])), \
+                   self.vel.reshape((self.num_episodes,) + tuple(self.vel.shape[2:]))
+        idx = [slice(0, self.rows(r)) for r in range(self.world)]
+        return torch.cat([self.pos[r, s] for r, s in enumerate(idx)]), torch.cat([self.vel[r, s] for r, s in enumerate(idx)])
+
+
+def gather_trajectories(pos: torch.Tensor, vel: torch.Tensor, num_episodes: int, group=None) -> GatheredTrajectories:
+    """
+    The single all-gather of the path (fancy_gym/black_box/black_box_wrapper.py:96-120: episodes are independent, so this
+    is the only exchange step).  Zero-copy when ``pos`` / ``vel`` are the two halves of a ``TrajectoryShard`` (the engine
+    wrote them there); any other pair of ``[b, T, D]`` tensors is staged into a shard with ONE copy each first.
+    Returns views (``GatheredTrajectories``): ``.pos`` / ``.vel`` ``[world, cap, T, D]``.
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    cap = -(-int(num_episodes) // world) if num_episodes else 0
+    item = pos.element_size()
+    half = cap * int(pos.shape[1]) * int(pos.shape[2]) * item if pos.dim() == 3 else -1
+    adjacent = (pos.dim() == 3 and pos.dtype == torch.float32 and vel.dtype == torch.float32 and pos.shape == vel.shape
+                and pos.is_contiguous() and vel.is_contiguous() and vel.data_ptr() == pos.data_ptr() + half
+                and pos.untyped_storage().data_ptr() == vel.untyped_storage().data_ptr())
+    sh = TrajectoryShard.__new__(TrajectoryShard)
+    sh.num_episodes, sh.rank, sh.world, sh.cap = int(num_episodes), rank, world, cap
+    a, b = shard_bounds(num_episodes, rank, world)
+    sh.start, sh.rows = a, b - a
+    if pos.shape[0] != sh.rows:
+        raise ValueError(f"rank {rank} owns {sh.rows} of {num_episodes} episodes, got {pos.shape[0]} rows")
+    if adjacent:
+        sh.buf = torch.as_strided(pos, (2, cap) + tuple(pos.shape[1:]),
+                                  (cap * pos.shape[1] * pos.shape[2], pos.shape[1] * pos.shape[2], pos.shape[2], 1))
+    else:
+        sh.buf = torch.zeros((2, cap) + tuple(pos.shape[1:]), dtype=torch.float32, device=pos.device)
+        sh.buf[0, : sh.rows].copy_(pos)
+        sh.buf[1, : sh.rows].copy_(vel)
+    sh.pos, sh.vel = sh.buf[0, : sh.rows], sh.buf[1, : sh.rows]
+    return sh.gather(group=group)
 
 
 class NativeComm:

@@ -139,6 +139,15 @@ const char* mpk_last_error(void);
 /* ABI version of the loaded library */
 int mpk_abi_version(void);
 
+/*
+ * sha256 (hex) of the sources this binary was built from -- include/mpk.h, csrc/mpk_internal.h, csrc/mpk_host.cpp,
+ * csrc/mpk_kernels.hip, in that order, each prefixed by "<name>\n" -- stamped at build time (-DMPK_SOURCE_HASH=...), or
+ * "unstamped".  The Python binding compares it with the checked-out sources and refuses a stale binary, so a prebuilt
+ * libmpk.so that travelled to another machine can never silently be something other than the sources beside it.
+ * The same string sits in the file as "MPK_SOURCE_HASH=<hex>" for tools that must not dlopen the library.
+ */
+const char* mpk_source_hash(void);
+
 /* number of visible HIP devices (0 if none); never initialises a context */
 int mpk_device_count(void);
 

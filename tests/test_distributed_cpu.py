@@ -33,8 +33,22 @@ def _worker(rank, world, port, B, q):
     pos_local = D.shard(full)                       # stands in for the trajectories this rank generated
     assert pos_local.shape[0] == b - a
     vel_local = -pos_local
-    pos_all, vel_all = D.gather_trajectories(pos_local, vel_local, B)
+    # (i) any pair of [b, T, D] tensors: staged into a shard, ONE collective, views back
+    g = D.gather_trajectories(pos_local, vel_local, B)
+    pos_all, vel_all = g.flat()
     ok = torch.equal(pos_all, full) and torch.equal(vel_all, -full)
+    ok = ok and g.pos.shape == (world, -(-B // world), T, Dof) and g.pos.data_ptr() == g.buf.data_ptr()
+    ok = ok and all(torch.equal(g.episode(i)[0], full[i]) and torch.equal(g.episode(i)[1], -full[i]) for i in range(B))
+    # (ii) the zero-copy route: the "kernels" write into the two halves of a TrajectoryShard, the collective sends the
+    # buffer as it lies (the views handed back alias the receive buffer, the send buffer is the shard itself)
+    sh = D.TrajectoryShard(B, T, Dof, "cpu")
+    ok = ok and sh.rows == b - a and (sh.rows == 0 or sh.pos.data_ptr() == sh.buf.data_ptr())
+    sh.pos.copy_(pos_local); sh.vel.copy_(vel_local)
+    g2 = D.gather_trajectories(sh.pos, sh.vel, B)
+    ok = ok and all(torch.equal(g2.pos[r, :g2.rows(r)], full[slice(*D.shard_bounds(B, r, world))]) for r in range(world))
+    ok = ok and all(torch.equal(g2.vel[r, :g2.rows(r)], -full[slice(*D.shard_bounds(B, r, world))]) for r in range(world))
+    g3 = sh.gather()
+    ok = ok and torch.equal(g3.buf, g2.buf)
     rows = D.all_gather_rows(torch.full((b - a, 2), float(rank)), B)
     ok = ok and rows.shape == (B, 2) and float(rows[:a + 1].min()) >= 0
     expected = torch.cat([torch.full((D.shard_bounds(B, k, world)[1] - D.shard_bounds(B, k, world)[0], 2), float(k))

@@ -19,7 +19,13 @@ build container (no network).  This file is therefore a *restatement* of that pa
                 ``test/test_replanning_sequencing.py:64-364`` (lengths, planning counts),
                 ``test/test_controller.py:30-54`` (PD formula exactness, shape errors)
 
-What pins it instead (see tests/test_oracle_*.py and tests/golden/make_golden.py):
+HOW TO PIN IT: ``python tools/pin_against_mp_pytorch.py`` on a machine where ``mp_pytorch`` is importable drives the package
+through the reference's own factory + ``BlackBoxWrapper.get_trajectory`` call sequence for the five BASELINE
+configurations, TableTennis-ProDMP and one probe per "(?)" switch, writes ``tests/golden/ref_*.npz`` and reports which
+switch settings reproduce it; ``tests/test_oracle_pins.py::test_oracle_against_mp_pytorch_reference_outputs`` then runs
+from those files everywhere (it SKIPS, saying so, until they exist).
+
+What pins it until then (see tests/test_oracle_*.py and tests/golden/make_golden.py):
   1. the reference's behavioural tests, re-stated against this oracle (plateaus with ``==``, action-dim formula,
      PD formula with ``array_equal``);
   2. an independent SciPy ODE solve of the DMP/ProDMP dynamics (closed form vs ``solve_ivp``);
@@ -88,6 +94,8 @@ class TrajCfg:
     disable_weights: bool = False
     # SURVEY Appendix A "(?)" items as explicit switches (same names and meaning as include/mpk.h); first = default
     relative_goal_mode: str = "after_scale"   # 'after_scale': goal = s_g*g + init_pos | 'before_scale': s_g*(g + init_pos)
+    #   ^ doubted default (two independent readers recall 'before_scale'; no reference config distinguishes them at 1e-5):
+    #     tools/pin_against_mp_pytorch.py decides it where mp_pytorch is installed (include/mpk.h MPK_RELGOAL_*)
     goal_offset_mode: str = "ignore"          # 'ignore' (swallowed by **kwargs) | 'add': goal += goal_offset
     goal_offset: float = 0.0
     dmp_first_sample: str = "init"            # 'init': pos[0] = init_pos | 'step': pos[0] = one Euler step from init_time

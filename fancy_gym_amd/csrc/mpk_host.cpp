@@ -737,7 +737,9 @@ static int traj_common(Handle* h, const float* params, const float* init_pos, co
                 set_error("MPK_DMP_FIRST_IS_STEP: run one eager call with this batch size before capturing a graph");
                 return MPK_EINVAL;
             }
-            if (h->d_pre) { MPK_HIP(hipStreamSynchronize((hipStream_t)stream)); (void)hipFree(h->d_pre); h->d_pre = nullptr; h->pre_cap = 0; }
+            // the old scratch may still be read by work on ANY stream (and by graphs captured with the smaller batch:
+            // those hold the freed pointer and must be re-captured -- include/mpk.h): drain the device, not one stream
+            if (h->d_pre) { MPK_HIP(hipDeviceSynchronize()); (void)hipFree(h->d_pre); h->d_pre = nullptr; h->pre_cap = 0; }
             MPK_HIP(hipMalloc((void**)&h->d_pre, 2 * need * sizeof(float)));
             h->pre_cap = need;
         }

@@ -20,6 +20,20 @@
 
 #include "mpk_internal.h"
 
+// Build partitioning (compile time only; the library is the same): this file is compiled once per MPK_PART and the
+// objects are linked into libmpk.so, so that the ~300 kernel instantiations build on several cores (__graft_entry__.py).
+//   -1 (default)  everything in one translation unit (one_kernel.sh, MPK_TRACE development builds)
+//    0            everything but the shared-phase trajectory kernel families
+//    1, 2, 3      launch_traj_ct<MP = MPK_PART - 1> and the k_traj_tiles / split / stream / quad / pipe instantiations
+//                 behind it (promp, dmp, prodmp)
+#ifndef MPK_PART
+#define MPK_PART -1
+#endif
+#define MPK_MAIN (MPK_PART <= 0)
+#if defined(MPK_TRACE) && MPK_PART >= 0
+#error "MPK_TRACE builds are single translation unit builds (the trace buffer is one device variable)"
+#endif
+
 namespace mpk {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -55,6 +69,7 @@ __device__ long long g_trace[256];
         }                                                                           \
     } while (0)
 
+#if MPK_MAIN
 size_t shared_tables_floats(const DevCfg& c, int* TS, int* n_out) {
     const int TP = (c.T + 15) / 16 * 16;
     const int ts = ((TP + 15) / 32) * 32 + 16;  // TS % 32 == 16: the two k rows of a 32-lane LDS read hit disjoint banks
@@ -65,6 +80,7 @@ size_t shared_tables_floats(const DevCfg& c, int* TS, int* n_out) {
     // (one contiguous row per time step: the serial role of k_traj_split reads it with scalar loads)
     return 2 * (size_t)no * c.KP * ts;
 }
+#endif  // MPK_MAIN
 
 // ------------------------------------------------------------------------------------------------------------
 // device helpers shared by the shared-phase builder and the per-episode kernel
@@ -251,7 +267,7 @@ __device__ __forceinline__ void prodmp_col(const DevCfg& c, const ProdmpBC& bc, 
 // for |r| <= ln2/2).  ExpLiteral folds them into the instruction stream; ExpRegs holds them in registers loaded once
 // per kernel (64-bit literals cost a move per use and the scalar registers that would hold them are the scarce ones
 // in the per-episode kernel).  Same values, same operation order: same bits.
-__device__ double kExpTab[15] = {   // not const: a const table would be folded back into literals
+static __device__ double kExpTab[15] = {   // not const: a const table would be folded back into literals
     1.4426950408889634074, -6.93147180369123816490e-01, -1.90821492927058770002e-10,
     2.50521083854417187751e-08, 2.75573192239858906526e-07, 2.75573192239858906526e-06, 2.48015873015873015873e-05,
     1.98412698412698412698e-04, 1.38888888888888888889e-03, 8.33333333333333333333e-03, 4.16666666666666666667e-02,
@@ -329,9 +345,12 @@ __device__ __forceinline__ double phase_f64(const DevCfg& c, float time, float t
 // SURVEY A.4): the Gaussians e_k = exp(-bw (x - c_k)^2 / 2), c_k = c_0 + k D, obey
 //     e_{k+1} = e_k r_k,   r_k = exp(bw D (x - c_k) - bw D^2 / 2),   r_{k+1} = r_k exp(-bw D^2)
 // -- TWO exponentials per row and two float64 multiplications per further basis function instead of one exponential
-// each (a row of cfg5's five RBFs: 60 % of its instructions were exponentials).  The products carry ~k 1e-16 relative
-// error, nine orders below the single rounding to fp32 that follows; every row builder on the device goes through the
-// same code, so the shared-phase and per-episode kernels keep producing identical bits.  The host enables it
+// each (a row of cfg5's five RBFs: 60 % of its instructions were exponentials).  Error of e_k relative to the direct
+// exponential: the ratio's exponent argument is as large as ~600, so r_0 carries ~600 x 1.1e-16 = 7e-14 relative
+// error (plus exp's own 1e-15), q ~2e-16; e_k = e_0 r_0^k q^(k(k-1)/2) therefore ~k 7e-14 + k^2 2e-16: 1.4e-12 at
+// k = 20, 3e-10 at k = 1000 -- still more than two orders below the single rounding to fp32 (6e-8) that follows.
+// Every row builder on the device goes through the same code (k_dmp_prestep included), so the shared-phase and
+// per-episode kernels keep producing identical bits.  The host enables it
 // (DevCfg::rbf_uniform) only where e_0 cannot underflow; constants behind the bandwidths in the device table:
 // [bw D, bw D^2 / 2, exp(-bw D^2)].
 struct RbfRecur {
@@ -446,6 +465,7 @@ __device__ __forceinline__ void rbf_row(const DevCfg& c, const double* cen, cons
     }
 }
 
+#if MPK_MAIN
 // ------------------------------------------------------------------------------------------------------------
 // k_build_shared: one block; A[(j*KP + k)*TS + t], aux[t]
 // ------------------------------------------------------------------------------------------------------------
@@ -532,6 +552,7 @@ int launch_build_shared(const DevCfg& c, float init_time, const SharedTables& st
     return MPK_OK;
 }
 #endif  // MPK_DEVICE_ONLY
+#endif  // MPK_MAIN
 
 // ------------------------------------------------------------------------------------------------------------
 // The [T x K] . [K x D] contraction on the matrix cores (v_mfma_f32_16x16x4_f32) + fused epilogues.
@@ -1968,7 +1989,7 @@ __global__ void __launch_bounds__(320) k_traj_pipe(const TrajArgs a, const ActAr
     }
 }
 
-#ifndef MPK_DEVICE_ONLY
+#if !defined(MPK_DEVICE_ONLY) && MPK_PART != 0
 template <int MP, int CT>
 static int launch_traj_t(const TrajArgs& ta, const ActArgs& aa, bool stream_mode, bool write_through, bool bulk,
                          int quad, int blocks, size_t lds, void* stream, bool split = false, bool pipe = false) {
@@ -2074,11 +2095,10 @@ static int launch_traj_t(const TrajArgs& ta, const ActArgs& aa, bool stream_mode
 }
 #endif  // MPK_DEVICE_ONLY
 
-#ifndef MPK_DEVICE_ONLY
+#if !defined(MPK_DEVICE_ONLY) && MPK_PART != 0
 template <int MP>
-static int launch_traj_ct(const TrajArgs& ta, const ActArgs& aa, int ct, bool stream_mode, bool write_through,
-                          bool bulk, int quad, int blocks, size_t lds, void* stream, bool split = false,
-                          bool pipe = false) {
+int launch_traj_ct(const TrajArgs& ta, const ActArgs& aa, int ct, bool stream_mode, bool write_through,
+                   bool bulk, int quad, int blocks, size_t lds, void* stream, bool split, bool pipe) {
     if constexpr (MP != MPK_MP_DMP) {
         if (pipe) {
             switch (ct) {
@@ -2108,6 +2128,21 @@ static int launch_traj_ct(const TrajArgs& ta, const ActArgs& aa, int ct, bool st
 }
 #endif  // MPK_DEVICE_ONLY
 
+#if !defined(MPK_DEVICE_ONLY)
+#if MPK_PART == 0
+// defined in the translation units MPK_PART 1..3
+template <int MP>
+int launch_traj_ct(const TrajArgs& ta, const ActArgs& aa, int ct, bool stream_mode, bool write_through, bool bulk,
+                   int quad, int blocks, size_t lds, void* stream, bool split, bool pipe);
+extern template int launch_traj_ct<MPK_MP_PROMP>(const TrajArgs&, const ActArgs&, int, bool, bool, bool, int, int, size_t, void*, bool, bool);
+extern template int launch_traj_ct<MPK_MP_DMP>(const TrajArgs&, const ActArgs&, int, bool, bool, bool, int, int, size_t, void*, bool, bool);
+extern template int launch_traj_ct<MPK_MP_PRODMP>(const TrajArgs&, const ActArgs&, int, bool, bool, bool, int, int, size_t, void*, bool, bool);
+#elif MPK_PART > 0
+template int launch_traj_ct<MPK_PART - 1>(const TrajArgs&, const ActArgs&, int, bool, bool, bool, int, int, size_t, void*, bool, bool);
+#endif
+#endif
+
+#if MPK_MAIN
 #ifndef MPK_DEVICE_ONLY
 int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* params, const float* init_pos,
                        const float* init_vel, float* pos, float* vel, float* actions, const RolloutDev* rc,
@@ -2298,7 +2333,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
             return launch_traj_ct<MPK_MP_PROMP>(ta, aa, ct, stream_mode, write_through, bulk, quad, blocks, lds, stream, split, pipe);
         default:
             *kernel_name = quad == 4 ? "k_traj_quad<dmp>" : quad == 2 ? "k_traj_duo<dmp>" : quad == 1 ? "k_traj_mono<dmp>" : "k_traj_stream<dmp>";
-            return launch_traj_ct<MPK_MP_DMP>(ta, aa, -1, true, false, bulk, quad, blocks, lds, stream);
+            return launch_traj_ct<MPK_MP_DMP>(ta, aa, -1, true, false, bulk, quad, blocks, lds, stream, false, false);
     }
 }
 #endif  // MPK_DEVICE_ONLY
@@ -3146,7 +3181,7 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
 // ------------------------------------------------------------------------------------------------------------
 // k_dmp_prestep (MPK_DMP_FIRST_IS_STEP): the boundary state advanced by ONE Euler step from init_time to the first grid
 // time, with the forcing and the scaled-time increment at init_time -- the state the trajectory kernels then start
-// from.  One lane per (episode, DoF); same row functions and operation order as the trajectory kernels.
+// from.  One lane per (episode, DoF); the row arithmetic of rbf_cols (both of its branches), operation for operation.
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_dmp_prestep(const DevCfg c, const float* __restrict__ params,
                                                      const float* __restrict__ init_pos,
@@ -3167,19 +3202,33 @@ __global__ void __launch_bounds__(256) k_dmp_prestep(const DevCfg c, const float
     const double x = phase_f64(c, it, tau, delay, ExpLiteral());
     const double* cen = c.tab;
     const double* bw = c.tab + c.n_total;
-    double sum = 0.0;
-    for (int k = 0; k < c.n_total; ++k) {
-        const double dx = x - cen[k];
-        sum += exp_nonpos(-(dx * dx * bw[k]) * 0.5);
-    }
+    // the forcing row at init_time: the SAME arithmetic as rbf_cols / rbf_row (product recurrence where the host enabled
+    // it), so this sample is bit-identical to what the trajectory kernels produce for the same phase value
     const double mul = x * (double)c.ws;
-    const double scale = c.n_total > 1 ? div_pos(mul, sum) : mul;
     const float* w = prm + c.off + d * c.Kloc;
     float f0 = 0.0f;
-    for (int k = 0; k < c.nb; ++k) {
-        const double dx = x - cen[c.zs + k];
-        const float h = (float)(exp_nonpos(-(dx * dx * bw[c.zs + k]) * 0.5) * scale);
-        f0 = fmaf(h, w[k], f0);
+    if (c.rbf_uniform) {
+        RbfRecur s1(cen, bw, c.n_total, x, ExpLiteral());
+        double sum = 0.0;
+        for (int k = 0; k < c.n_total; ++k) sum += s1.next();
+        const double scale = div_pos(mul, sum);
+        RbfRecur s2(cen, bw, c.n_total, x, ExpLiteral());
+        for (int k = 0; k < c.zs + c.nb; ++k) {
+            const double ek = s2.next();
+            if (k >= c.zs) f0 = fmaf((float)(ek * scale), w[k - c.zs], f0);
+        }
+    } else {
+        double sum = 0.0;
+        for (int k = 0; k < c.n_total; ++k) {
+            const double dx = x - cen[k];
+            sum += exp_nonpos(-(dx * dx * bw[k]) * 0.5);
+        }
+        const double scale = c.n_total > 1 ? div_pos(mul, sum) : mul;
+        for (int k = 0; k < c.nb; ++k) {
+            const double dx = x - cen[c.zs + k];
+            const float h = (float)(exp_nonpos(-(dx * dx * bw[c.zs + k]) * 0.5) * scale);
+            f0 = fmaf(h, w[k], f0);
+        }
     }
     float y = init_pos[e];
     float z = init_vel[e] * tau;
@@ -3919,6 +3968,8 @@ int launch_div_sweep(float d, uint32_t first, uint64_t count, unsigned long long
     return MPK_OK;
 }
 #endif  // MPK_DEVICE_ONLY
+
+#endif  // MPK_MAIN
 
 }  // namespace mpk
 

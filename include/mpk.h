@@ -178,7 +178,10 @@ int mpk_params_bounds(mpk_handle h, float* low, float* high);
  * previous grid may still be in flight.  It must not be called while a stream capture is active, and it releases every
  * slot pinned by a captured graph (see mpk_unpin_tables).  No other entry point allocates, frees or synchronises in the
  * steady state (exceptions, each documented at its declaration: mpk_check_range and mpk_prodmp_indices synchronise by
- * contract; a MPK_DMP_FIRST_IS_STEP handle grows its boundary-state scratch on the first call with a larger batch).
+ * contract; a MPK_DMP_FIRST_IS_STEP handle grows its boundary-state scratch on the first call with a larger batch:
+ * that call synchronises the DEVICE and frees the old scratch, which INVALIDATES every hipGraph captured earlier on this
+ * handle with a smaller batch -- re-capture them, or make the first eager call with the largest batch you will use.
+ * The scratch is per handle and unsynchronised: a MPK_DMP_FIRST_IS_STEP handle must be driven from ONE stream at a time).
  */
 int mpk_set_duration(mpk_handle h, double duration, double dt);
 

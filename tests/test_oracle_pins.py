@@ -255,14 +255,17 @@ def test_oracle_solves_the_ode_for_every_baseline_prodmp_and_dmp_configuration()
 
 def test_golden_fixtures_record_their_provenance():
     """every fixture names the numpy / torch versions it was produced with and carries the hash of the generator script
-    and of the oracle it came from; the committed generator is the one that produced the committed fixtures"""
+    and of the oracle it came from; the committed generator AND the committed oracle are the ones that produced the
+    committed fixtures (an oracle edit without regenerating them fails here)"""
     import hashlib
     gen = hashlib.sha256(open(os.path.join(GOLD, "make_golden.py"), "rb").read()).hexdigest()
+    orc = hashlib.sha256(open(os.path.join(ROOT, "oracle", "mp_oracle.py"), "rb").read()).hexdigest()
     for name in sorted(CONFIGS):
         z = np.load(os.path.join(GOLD, name + ".npz"))
         assert "numpy" in str(z["versions"]) and "torch" in str(z["versions"])
         assert str(z["generator_sha256"]) == gen, f"{name}.npz was not produced by the committed make_golden.py"
-        assert len(str(z["oracle_sha256"])) == 64 and "NOT from mp_pytorch" in str(z["meta"])
+        assert str(z["oracle_sha256"]) == orc, f"{name}.npz predates the committed oracle/mp_oracle.py: re-run make_golden.py"
+        assert "NOT from mp_pytorch" in str(z["meta"])
 
 
 # ---- one-command pinning against the real mp_pytorch (tools/pin_against_mp_pytorch.py) ----------------------------------

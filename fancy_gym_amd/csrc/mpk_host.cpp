@@ -194,6 +194,7 @@ struct CacheEntry {
     uint32_t key = 0;  // bit pattern of the fp32 init_time
     int T = 0;
     SharedTables st;
+    size_t floats = 0;   // allocation size of st.A
     uint64_t stamp = 0;
     // pinned: a captured graph reads this slot, it is never evicted (mpk_unpin_tables / mpk_set_duration release it).
     // deferred: the table was built while a stream capture was active -- the builder kernel is a node of THAT graph, so
@@ -400,17 +401,28 @@ static bool mfma_capable(const Handle* h) {
     return h->dev.D >= 1 && h->dev.D <= kMaxD && h->dev.KP <= kMaxKP;
 }
 
+// more than kMaxKP contraction columns with a shared phase: the k-chunked matrix-core kernel (k_traj_wide, trajectory only)
+static bool wide_capable(const Handle* h) {
+    return h->dev.D >= 1 && h->dev.D <= kMaxD && h->dev.KP > kMaxKP;
+}
+
 // Allocate every cache slot's table for the current (T, KP) up front: a cache miss later only launches the builder
 // kernel, never hipMalloc -- so trajectory calls stay legal inside a hipGraph stream capture.
 static int prealloc_cache(Handle* h) {
-    if (!mfma_capable(h)) return MPK_OK;
+    if (!mfma_capable(h) && !wide_capable(h)) return MPK_OK;
     int TS = 0, n_out = 0;
     const size_t nf = shared_tables_floats(h->dev, &TS, &n_out);
+    // a wide table (hundreds of basis functions: ~10 MB per slot at K = 1000, T = 200) gets 8 slots instead of 64
+    const int n_slots = wide_capable(h) ? 8 : Handle::kCache;
+    int slot = 0;
     for (auto& e : h->cache) {
-        if (e.st.A && (e.st.TS != TS || e.st.n_out != n_out)) {
+        const bool keep = slot++ < n_slots;
+        if (e.st.A && (e.st.TS != TS || e.st.n_out != n_out || e.floats != nf || !keep)) {
             (void)hipFree(e.st.A); (void)hipFree(e.st.aux);
             e.st = SharedTables{};
         }
+        if (!keep) { e.valid = false; e.pinned = false; e.deferred = false; continue; }
+        e.floats = nf;
         if (!e.st.A) {
             MPK_HIP(hipMalloc((void**)&e.st.A, nf * sizeof(float)));
             MPK_HIP(hipMalloc((void**)&e.st.aux, (size_t)TS * sizeof(float)));
@@ -443,7 +455,7 @@ static int get_shared(Handle* h, float init_time, void* stream, SharedTables* ou
     }
     CacheEntry* victim = nullptr;
     for (auto& e : h->cache) {
-        if (e.pinned) continue;
+        if (e.pinned || !e.st.A) continue;
         if (!e.valid) { victim = &e; break; }
         if (!victim || e.stamp < victim->stamp) victim = &e;
     }
@@ -748,6 +760,13 @@ static int traj_common(Handle* h, const float* params, const float* init_pos, co
         int rc = launch_dmp_prestep(h->dev, params, init_pos, init_vel, init_time, (float)init_time_shared, p1, v1, B, stream);
         if (rc != MPK_OK) return rc;
         init_pos = p1; init_vel = v1;
+    }
+    if (shared_phase(h, init_time) && wide_capable(h) && !actions && !q_state && !rp) {
+        SharedTables st;
+        int rc = get_shared(h, (float)init_time_shared, stream, &st);
+        if (rc != MPK_OK) return rc;
+        rc = launch_traj_wide(h->dev, st, params, init_pos, init_vel, pos, vel, B, h->num_cu, stream, &h->last_kernel);
+        if (rc != MPK_ENOTIMPL) return rc;      // horizons beyond one row-tile block (promp / dmp): per-episode kernels
     }
     if (shared_phase(h, init_time) && mfma_capable(h)) {
         SharedTables st;

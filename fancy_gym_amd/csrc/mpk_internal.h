@@ -95,6 +95,10 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
                        const double* c_pos, const double* c_vel, double* q_state, double* qd_state,
                        const int32_t* n_steps, int B, int num_cu, void* stream, const char** kernel_name,
                        const Tuning& tune, const ReplanDev* rp = nullptr);
+// shared phase, more than kMaxKP contraction columns: k-chunked GEMM on the matrix cores (trajectory only)
+int launch_traj_wide(const DevCfg& c, const SharedTables& st, const float* params, const float* init_pos,
+                     const float* init_vel, float* pos, float* vel, int B, int num_cu, void* stream,
+                     const char** kernel_name);
 int launch_traj_rows(const DevCfg& c, const float* params, const float* init_pos, const float* init_vel,
                      const float* init_time, float init_time_shared, float* pos, float* vel, int32_t* range_flag,
                      int B, int num_cu, void* stream, const char** kernel_name, const Tuning& tune);

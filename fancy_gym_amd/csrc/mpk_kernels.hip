@@ -2311,6 +2311,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     if (blocks < 1) blocks = 1;
     if (!stream_mode && !pipe && ta.gstride <= 0) { set_error("internal: tile-major launch without its group stride"); return MPK_EINVAL; }
     if (!stream_mode && tune.lds_pad > 0) lds = (size_t)tune.lds_pad * 1024;     // A/B runs: caps the workgroups per CU
+    if (stream_mode && !pipe && tune.lds_pad > 0) lds += (size_t)tune.lds_pad * 1024;   // episode-major: EXTRA dynamic LDS (occupancy experiments)
     ta.ser_blocks = 0;
     if (split) {
         // serial-role workgroups first (they are the long pole and must start first), capped at one resident round of the chip
@@ -2334,6 +2335,251 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         default:
             *kernel_name = quad == 4 ? "k_traj_quad<dmp>" : quad == 2 ? "k_traj_duo<dmp>" : quad == 1 ? "k_traj_mono<dmp>" : "k_traj_stream<dmp>";
             return launch_traj_ct<MPK_MP_DMP>(ta, aa, -1, true, false, bulk, quad, blocks, lds, stream, false, false);
+    }
+}
+#endif  // MPK_DEVICE_ONLY
+
+// ------------------------------------------------------------------------------------------------------------
+// k_traj_wide<MP, MT>: shared phase with MORE than 16 contraction columns -- the reference's own "too many basis
+// functions" example (examples/examples_movement_primitives.py:67: num_basis = 1000 on a 5-DoF, 200-step ProMP).
+// There the path is a real GEMM  C[T x (B D)] = A[T x K] . X[K x (B D)]  (2 MFLOP against 28 KB per episode at K = 1000:
+// matrix-core bound, not HBM bound), so it is tiled like one:
+//   * a workgroup of 4 waves takes 4 consecutive episode groups (16 (episode, DoF) columns each), one per wave;
+//   * the k loop runs in chunks of KC columns: the chunk of the k-major basis table (rows of MT row tiles, all outputs)
+//     is copied ONCE per workgroup into LDS with float4 loads (stride == 16 mod 32: the two k rows of a 32-lane
+//     fragment read fall on disjoint banks), each wave stages ITS 16 parameter columns beside it -- lane <-> k, i.e. 256
+//     contiguous bytes per column and load instruction (raw parameters / boundary conditions, as everywhere: all scales
+//     live in the basis rows) -- in a [16][KC + 2] image (conflict-free fragment reads);
+//   * per 4 columns of k: ONE B fragment and MT A fragments from LDS feed MT x NOUT v_mfma_f32_16x16x4_f32 on MT x NOUT
+//     independent accumulators (the whole horizon of the group stays in registers: nothing is re-read);
+//   * epilogue per wave through an LDS image [T][17]: promp's forward difference of the fp32 positions (x aux, the
+//     reciprocal fp32 time step, as in the tile kernels), dmp's explicit Euler recurrence on the group's D x epg lanes,
+//     coalesced copy-out of each episode's contiguous [T][D] block.
+// Accumulation order = ascending k, the order of every other kernel of this file (an MFMA is a k-ordered fmaf chain).
+// Two workgroups fit a CU (LDS), so one stages while the other contracts.  Horizons beyond MT row tiles: prodmp walks
+// row-tile blocks (its rows are independent); promp / dmp need the whole horizon in one block (T <= 512).
+// ------------------------------------------------------------------------------------------------------------
+struct WideArgs {
+    DevCfg c;
+    const float* A;      // [n_out][KP][TS] (k_build_shared)
+    const float* aux;    // [TS]
+    int TS;
+    const float* params;
+    const float* init_pos;
+    const float* init_vel;
+    float* pos;
+    float* vel;
+    int B, epg, n_units, KC, n_rt, SA;   // episodes per column group, 4-group units, k chunk, row tiles, LDS row stride
+};
+
+// raw operand of the contraction for column (episode b, DoF dd), index k  (the sX fill of k_traj_rows)
+template <int MP>
+__device__ __forceinline__ float wide_x(const DevCfg& c, const float* __restrict__ prm, float ip, float iv, int dd, int k) {
+    if (MP == MPK_MP_PRODMP) {
+        const int nb = c.nb;
+        if (k < nb) return c.disable_weights ? 0.0f : prm[c.off + dd * c.Kloc + k];
+        if (k == nb) return c.disable_goal ? 0.0f : prm[c.off + dd * c.Kloc + (c.disable_weights ? 0 : nb)];
+        if (k == nb + 1) return ip;
+        if (k == nb + 2) return iv;
+        return 1.0f;                                   // goal-offset column (MPK_GOAL_OFFSET_ADD)
+    }
+    if (MP == MPK_MP_PROMP) return k < c.nb ? prm[c.off + dd * c.Kloc + k] : ip;
+    return prm[c.off + dd * c.Kloc + k];
+}
+
+template <int MP, int MT>
+__global__ void __launch_bounds__(256, 2) k_traj_wide(const WideArgs a) {
+    constexpr int NOUT = MP == MPK_MP_PRODMP ? 2 : 1;
+    constexpr int CS = 17;                              // column stride of the epilogue image
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const DevCfg& c = a.c;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 15, g4 = lane >> 4;
+    const int D = c.D, T = c.T, KP = c.KP, KT = c.KT, TS = a.TS, KC = a.KC, SA = a.SA, SB = KC + 2;
+    float* sA = smem;                                   // [NOUT][KC][SA]
+    float* sB = sA + NOUT * KC * SA + wave * 16 * SB;   // this wave's [16][SB]
+    // epilogue images alias the staging area (used after the k loop, behind a barrier): per wave [NIMG][MT*16][CS]
+    constexpr int NIMG = MP == MPK_MP_PROMP ? 1 : 2;
+    float* sC = smem + (size_t)wave * NIMG * MT * 16 * CS;
+    const int ncol = a.epg * D;                         // used columns of a group
+
+    for (int unit = blockIdx.x; unit < a.n_units; unit += gridDim.x) {
+        const int grp = unit * 4 + wave;
+        const int b0 = grp * a.epg;
+        // this lane's column for the B staging loop is the loop variable; for the fragment / epilogue it is m
+        for (int rt0 = 0; rt0 < a.n_rt; rt0 += MT) {
+            const int nrt = min(MT, a.n_rt - rt0);      // row tiles of this block
+            const int rowsA = nrt * 16;
+            f32x4 acc[NOUT][MT];
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+                for (int r = 0; r < MT; ++r) acc[o][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int k0 = 0; k0 < KP; k0 += KC) {
+                __syncthreads();                        // the previous chunk (or epilogue image) is consumed
+                // ---- A chunk: rows [rt0*16, rt0*16 + rowsA) of k in [k0, k0 + KC), every output table ----
+                {
+                    const int r4 = rowsA >> 2;          // float4 per table row
+                    const int total = NOUT * KC * r4;
+                    for (int i = tid; i < total; i += 256) {
+                        const int q = i % r4, rest = i / r4;
+                        const int kk = rest % KC, o = rest / KC;
+                        const int k = k0 + kk;
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (k < KP)
+                            v = *reinterpret_cast<const float4*>(a.A + ((size_t)o * KP + k) * TS + rt0 * 16 + 4 * q);
+                        *reinterpret_cast<float4*>(sA + ((size_t)o * KC + kk) * SA + 4 * q) = v;
+                    }
+                }
+                // ---- X chunk of this wave's 16 columns: lane <-> k ----
+                for (int n = 0; n < 16; ++n) {
+                    const int e = n / D, dd = n - e * D;
+                    const int b = b0 + e;
+                    const bool cv = n < ncol && b < a.B;
+                    const float* prm = a.params + (size_t)(cv ? b : 0) * c.P;
+                    const float ip = cv && MP != MPK_MP_DMP ? a.init_pos[(size_t)b * D + dd] : 0.0f;
+                    const float iv = cv && MP == MPK_MP_PRODMP ? a.init_vel[(size_t)b * D + dd] : 0.0f;
+                    for (int kk = lane; kk < KC; kk += 64) {
+                        const int k = k0 + kk;
+                        sB[n * SB + kk] = (cv && k < KT) ? wide_x<MP>(c, prm, ip, iv, dd, k) : 0.0f;
+                    }
+                }
+                __syncthreads();
+                // ---- contraction of the chunk ----
+                const float* pb = sB + m * SB + g4;
+                const float* pa = sA + (size_t)g4 * SA + m;
+                for (int j = 0; j < KC; j += 4) {
+                    const float bf = pb[j];
+#pragma unroll
+                    for (int r = 0; r < MT; ++r) {
+                        if (r < nrt) {
+#pragma unroll
+                            for (int o = 0; o < NOUT; ++o) {
+                                const float af = pa[((size_t)o * KC + j) * SA + r * 16];
+                                acc[o][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[o][r], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+            __syncthreads();                            // every wave is done with the staging area
+            // ---- epilogue: C tiles -> image [t][col] (row = 4 * (lane >> 4) + i of tile r, column = lane & 15) ----
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+                for (int r = 0; r < MT; ++r)
+                    if (r < nrt) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) sC[((size_t)o * MT * 16 + r * 16 + 4 * g4 + i) * CS + m] = acc[o][r][i];
+                    }
+            __builtin_amdgcn_wave_barrier();
+            const int t_lo = rt0 * 16;
+            const int t_n = min(T - t_lo, rowsA);       // valid steps of this block
+            float* img0 = sC;
+            float* img1 = sC + (size_t)MT * 16 * CS;
+            if (MP == MPK_MP_DMP) {
+                // explicit Euler, one lane per used column (the operation order of every dmp kernel in this file)
+                if (lane < ncol && b0 + lane / D < a.B) {
+                    const int e = lane / D, dd = lane - e * D;
+                    const int b = b0 + e;
+                    const float* prm = a.params + (size_t)b * c.P;
+                    float y = a.init_pos[(size_t)b * D + dd];
+                    float z = a.init_vel[(size_t)b * D + dd] * c.tau;
+                    const float gl = prm[c.off + dd * c.Kloc + c.nb] * c.gs;
+                    const TauDiv td = make_tau_div(c.tau);
+                    for (int t = 0; t < T; ++t) {
+                        const float f = img0[(size_t)t * CS + lane];
+                        img0[(size_t)t * CS + lane] = y;
+                        img1[(size_t)t * CS + lane] = div_tau(z, td);
+                        if (t < T - 1) {
+                            const float ds = a.aux[t];
+                            const float t1 = gl - y;
+                            const float t2 = c.dmp_beta * t1;
+                            const float t3 = t2 - z;
+                            const float t4 = c.dmp_alpha * t3;
+                            const float ac = t4 + f;
+                            z = z + ds * ac;
+                            y = y + ds * z;
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            // copy-out: each episode's [t_n][D] block is contiguous in HBM
+            for (int e = 0; e < a.epg; ++e) {
+                const int b = b0 + e;
+                if (b >= a.B) break;
+                const size_t ob = ((size_t)b * T + t_lo) * D;
+                const int nel = t_n * D;
+                for (int i = lane; i < nel; i += 64) {
+                    const int t = i / D, dd = i - t * D;
+                    const int col = e * D + dd;
+                    const float p = img0[(size_t)t * CS + col];
+                    float v;
+                    if (MP == MPK_MP_PROMP) {
+                        // vel = forward difference of the fp32 positions, last row repeats
+                        const int tg = t_lo + t;
+                        const int th = tg < T - 1 ? tg + 1 : T - 1, tl = tg < T - 1 ? tg : T - 2;
+                        v = (img0[(size_t)(th - t_lo) * CS + col] - img0[(size_t)(tl - t_lo) * CS + col]) * a.aux[tg];
+                    } else {
+                        v = img1[(size_t)t * CS + col];
+                    }
+                    a.pos[ob + i] = p;
+                    a.vel[ob + i] = v;
+                }
+            }
+        }
+    }
+}
+
+#ifndef MPK_DEVICE_ONLY
+int launch_traj_wide(const DevCfg& c, const SharedTables& st, const float* params, const float* init_pos,
+                     const float* init_vel, float* pos, float* vel, int B, int num_cu, void* stream,
+                     const char** kernel_name) {
+    if (c.mp_type == MPK_MP_PROMP && c.T < 2) {
+        set_error("promp needs at least two time steps for the finite-difference velocity");
+        return MPK_EINVAL;
+    }
+    const int n_rt = (c.T + 15) / 16;
+    const int nout = c.mp_type == MPK_MP_PRODMP ? 2 : 1;
+    const int nimg = c.mp_type == MPK_MP_PROMP ? 1 : 2;
+    const int mt_max = c.mp_type == MPK_MP_PRODMP ? 16 : 32;
+    if (c.mp_type != MPK_MP_PRODMP && n_rt > mt_max) return MPK_ENOTIMPL;   // whole horizon in one row-tile block
+    const int MT = n_rt <= 8 ? 8 : (n_rt <= 16 || mt_max == 16) ? 16 : 32;
+    const int SA = MT * 16 + 16;
+    // k chunk: the staging area (A chunk + four X images) stays below ~72 KB, so that two workgroups share a CU
+    int KC = 64;
+    auto stage_bytes = [&](int kc) { return ((size_t)nout * kc * SA + 4 * 16 * (kc + 2)) * sizeof(float); };
+    while (KC > 8 && stage_bytes(KC) > 72 * 1024) KC >>= 1;
+    const size_t epi_bytes = (size_t)4 * nimg * MT * 16 * 17 * sizeof(float);
+    const size_t lds = stage_bytes(KC) > epi_bytes ? stage_bytes(KC) : epi_bytes;
+    WideArgs wa{c, st.A, st.aux, st.TS, params, init_pos, init_vel, pos, vel, B, 16 / c.D, 0, KC, n_rt, SA};
+    const int n_groups = (B + wa.epg - 1) / wa.epg;
+    wa.n_units = (n_groups + 3) / 4;
+    const int blocks = wa.n_units < num_cu * 2 ? wa.n_units : num_cu * 2;
+    auto go = [&](auto kern) -> int {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return MPK_EHIP; }
+        }
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, (hipStream_t)stream, wa);
+        MPK_LAUNCH_CHECK();
+        return MPK_OK;
+    };
+    switch (c.mp_type) {
+        case MPK_MP_PRODMP:
+            *kernel_name = "k_traj_wide<prodmp>";
+            return MT == 8 ? go(k_traj_wide<MPK_MP_PRODMP, 8>) : go(k_traj_wide<MPK_MP_PRODMP, 16>);
+        case MPK_MP_PROMP:
+            *kernel_name = "k_traj_wide<promp>";
+            return MT == 8 ? go(k_traj_wide<MPK_MP_PROMP, 8>) : MT == 16 ? go(k_traj_wide<MPK_MP_PROMP, 16>)
+                                                                         : go(k_traj_wide<MPK_MP_PROMP, 32>);
+        default:
+            *kernel_name = "k_traj_wide<dmp>";
+            return MT == 8 ? go(k_traj_wide<MPK_MP_DMP, 8>) : MT == 16 ? go(k_traj_wide<MPK_MP_DMP, 16>)
+                                                                       : go(k_traj_wide<MPK_MP_DMP, 32>);
     }
 }
 #endif  // MPK_DEVICE_ONLY

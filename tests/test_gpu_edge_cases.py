@@ -72,8 +72,52 @@ def test_every_horizon_class(mp, T, D, mpk_option):
 @pytest.mark.parametrize("mp", ["prodmp", "promp", "dmp"])
 def test_limits_fall_back_to_the_per_episode_kernel(mp):
     check(cfg_for(mp, 17, 4, 20), 6, expect_kernel="k_traj_phase")         # D > 16: wave per episode
-    check(cfg_for(mp, 2, 20, 20), 6, expect_kernel="k_traj_rows")          # more than 16 basis columns
+    check(cfg_for(mp, 2, 20, 20), 6, expect_kernel="k_traj_wide")          # more than 16 basis columns, shared phase
     check(cfg_for(mp, 40, 9, 24), 3, expect_kernel="k_traj_rows")          # D * KS > 256
+
+
+@pytest.mark.parametrize("mp", ["prodmp", "promp", "dmp"])
+@pytest.mark.parametrize("nb", [14, 17, 29, 64, 130])
+@pytest.mark.parametrize("D,T", [(2, 40), (5, 200), (7, 100), (16, 33)])
+def test_wide_contractions_run_on_the_matrix_cores(mp, nb, D, T):
+    """17+ contraction columns with a shared phase: k-chunked MFMA kernel (k_traj_wide), every MP type, ragged last
+    episode group / row tile / k chunk; nb = 14 is wide for prodmp only (14 + goal + 2 boundary columns = 17)"""
+    for B in (1, 23):
+        eng = check(cfg_for(mp, D, nb, T), B, seed=nb + B)
+        wide = nb + {"prodmp": 3, "promp": 1, "dmp": 0}[mp] > 16
+        assert eng.last_kernel().startswith("k_traj_wide" if wide else "k_traj_"), eng.last_kernel()
+        assert wide or not eng.last_kernel().startswith(("k_traj_rows", "k_traj_wide"))
+
+
+def test_wide_prodmp_long_horizon_walks_row_tile_blocks():
+    """prodmp rows are independent: horizons beyond 16 row tiles run as several row-tile blocks of the same launch"""
+    check(cfg_for("prodmp", 3, 20, 300), 7, expect_kernel="k_traj_wide")
+    check(cfg_for("prodmp", 7, 40, 523), 5, init_time=0.25, expect_kernel="k_traj_wide")
+
+
+def test_wide_per_episode_phase_stays_on_the_row_kernel():
+    pc, bc, tc, dt, dur = cfg_for("promp", 2, 20, 20)
+    eng = make_engine(pc, bc, tc, dt, dur)
+    params, ip, iv = inputs(pc, bc, tc, 6, seed=1)
+    p0, v0 = eng.trajectory(params, ip, iv, 0.0)
+    assert eng.last_kernel().startswith("k_traj_wide")
+    p1, v1 = eng.trajectory(params, ip, iv, torch.zeros(6, device="cuda"))
+    assert eng.last_kernel().startswith("k_traj_rows")
+    assert torch.equal(p0, p1) and torch.equal(v0, v1)      # same rows, same ascending-k fmaf chain: same bits
+
+
+@pytest.mark.parametrize("B", [1, 64, 1000])
+def test_the_reference_example_with_1000_basis_functions(B):
+    """
+    examples/examples_movement_primitives.py:67 -- `mp_config_override={'basis_generator_kwargs': {'num_basis': 1000}}` on
+    fancy_ProMP/Reacher5d-v0 (5 DoF, 200 steps, zero_rbf with one zero-start basis: 5000 parameters per episode).  Round 2
+    could not run it at all (the per-episode kernel needs T x K floats of LDS); it is a matrix-core GEMM now.
+    """
+    cfg = (O.PhaseCfg("linear", tau=4.0), O.BasisCfg("zero_rbf", num_basis=1000, num_basis_zero_start=1,
+                                                     num_basis_zero_goal=0, basis_bandwidth_factor=3),
+           O.TrajCfg("promp", action_dim=5), 0.02, 4.0)
+    eng = check(cfg, B, expect_kernel="k_traj_wide<promp>", seed=B)
+    assert eng.num_params == 5000 and eng.num_steps == 200
 
 
 @pytest.mark.parametrize("flags", [dict(disable_goal=True), dict(disable_weights=True), dict(relative_goal=True),

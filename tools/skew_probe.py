@@ -114,6 +114,16 @@ def main():
         print(f"| {'three allocations' if kind == 'sep' else 'one slab'} | {'-' if s is None else s} | "
               f"{' / '.join(f'{x[0] * 1e6:.0f}' for x in v)} | {nb3 / t3 / 1e9:.0f} | {nb3 / t3 / 8e12 * 100:.1f} % | "
               f"{' / '.join(f'{x[1] * 1e6:.0f}' for x in v)} | {nb2 / t2 / 1e9:.0f} | {nb2 / t2 / 8e12 * 100:.1f} % |")
+    # occupancy: EXTRA dynamic LDS per workgroup (mpk_set_option "lds_pad", KiB) -- 0: three 4-wave workgroups per CU
+    # (45.5 KB each), 10: two, i.e. 12 -> 8 waves per CU
+    from fancy_gym_amd import _lib
+    print()
+    print("| lds_pad KiB | workgroups per CU | fused +actions us | trajectory only us |")
+    print("|---|---|---|---|")
+    for pad, wg in ((0, 3), (10, 2), (0, 3), (10, 2)):
+        _lib.set_option("lds_pad", pad if pad else -1)
+        print(f"| {pad} | {wg} | {timed(run3(sep)) * 1e6:.0f} | {timed(run2(sep)) * 1e6:.0f} |")
+    _lib.reset_options()
     print()
     print("| what runs | s per launch | sclk avg (min-max) MHz | power W | gpu busy % | mem busy % | mclk | fclk | samples |")
     print("|---|---|---|---|---|---|---|---|---|")

@@ -2057,11 +2057,16 @@ static int launch_traj_t(const TrajArgs& ta, const ActArgs& aa, bool stream_mode
         }
     } else if (stream_mode) {
         if (bulk) {
+            // more than 48 KB of dynamic LDS only happens with the "lds_pad" occupancy knob (one workgroup per CU)
+            auto big = [&](auto kern) {
+                if (lds > 48 * 1024)
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            };
             switch (km) {
-                case 1: hipLaunchKernelGGL((k_traj_stream<MP, CT, 1, true>), g, b, lds, s, ta, aa); break;
-                case 2: hipLaunchKernelGGL((k_traj_stream<MP, CT, 2, true>), g, b, lds, s, ta, aa); break;
-                case 3: hipLaunchKernelGGL((k_traj_stream<MP, CT, 3, true>), g, b, lds, s, ta, aa); break;
-                default: hipLaunchKernelGGL((k_traj_stream<MP, CT, 4, true>), g, b, lds, s, ta, aa); break;
+                case 1: big(k_traj_stream<MP, CT, 1, true>); hipLaunchKernelGGL((k_traj_stream<MP, CT, 1, true>), g, b, lds, s, ta, aa); break;
+                case 2: big(k_traj_stream<MP, CT, 2, true>); hipLaunchKernelGGL((k_traj_stream<MP, CT, 2, true>), g, b, lds, s, ta, aa); break;
+                case 3: big(k_traj_stream<MP, CT, 3, true>); hipLaunchKernelGGL((k_traj_stream<MP, CT, 3, true>), g, b, lds, s, ta, aa); break;
+                default: big(k_traj_stream<MP, CT, 4, true>); hipLaunchKernelGGL((k_traj_stream<MP, CT, 4, true>), g, b, lds, s, ta, aa); break;
             }
         } else {
             switch (km) {

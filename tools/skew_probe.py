@@ -120,7 +120,7 @@ def main():
     print()
     print("| lds_pad KiB | workgroups per CU | fused +actions us | trajectory only us |")
     print("|---|---|---|---|")
-    for pad, wg in ((0, 3), (10, 2), (0, 3), (10, 2)):
+    for pad, wg in ((0, 3), (10, 2), (40, 1), (0, 3), (10, 2), (40, 1)):
         _lib.set_option("lds_pad", pad if pad else -1)
         print(f"| {pad} | {wg} | {timed(run3(sep)) * 1e6:.0f} | {timed(run2(sep)) * 1e6:.0f} |")
     _lib.reset_options()

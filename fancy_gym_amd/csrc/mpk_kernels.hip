@@ -601,6 +601,7 @@ struct TrajArgs {
     // of a few thousand episodes: closed-loop step at B = 4096 22.7 -> 18.7 us); plain stores once they stream to HBM
     // (write-through costs 25 % there).  The tile-major kernel has the policy as a template parameter.
     int wt;
+    int flat_img;          // k_traj_flat: floats per whole-trajectory array image (NTW * T * D); 0 = another kernel runs
     unsigned ser_blocks;   // k_traj_split: workgroups [0, ser_blocks) run the serial role
     // closed-loop rollout fused into the episode-major kernel (CT >= 3)
     double* q_state;       // [B, D] plant position, in/out
@@ -857,17 +858,21 @@ __device__ __forceinline__ void dmp_tile_steps(const float* __restrict__ sF, flo
 template <int MP, int CT>
 __device__ __forceinline__ void tile_epilogue(const f32x4& acc0, const f32x4& acc1, const f32x4& acc2,
                                               const float (&dtd)[4], double cp, double cv, const Gains& gn,
-                                              float* sSt, unsigned wofs, int D) {
+                                              float* sSt, unsigned wofs, int D, const int astride = kStageStride,
+                                              const int nrows = 4) {
+    // astride: floats between the pos / vel / action images; nrows: rows of this lane's four that exist (k_traj_flat's
+    // whole-trajectory images have no spare rows behind step T - 1; the transpose buffers do: 4)
     const double pgd = gn.pg, dgd = gn.dg, lod = gn.lo, hid = gn.hi;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
+        if (r >= nrows) break;
         const float p = acc0[r];
         float v;
         if (MP == MPK_MP_PRODMP) v = acc1[r];            // 1/tau is folded into the velocity rows
         else v = (acc1[r] - acc2[r]) * dtd[r];           // forward difference of fp32 positions x (1 / dt)
         float* w = sSt + wofs + r * D;
         w[0] = p;
-        w[kStageStride] = v;
+        w[astride] = v;
         if (CT >= 0 && CT < 3) {
             // float64 without FMA: numpy's promotion in pd_controller.py:21-29 (fp32 desired (+) fp64 state)
             double u;
@@ -875,10 +880,10 @@ __device__ __forceinline__ void tile_epilogue(const f32x4& acc0, const f32x4& ac
             else if (CT == MPK_CTRL_POSITION) u = (double)p;
             else u = (double)v;
             u = fmin(fmax(u, lod), hid);
-            w[2 * kStageStride] = (float)u;
+            w[2 * astride] = (float)u;
         }
         // closed loop: actions of steps the plan does not execute are 0; the recurrence lanes overwrite the executed ones
-        if (CT >= 3) w[2 * kStageStride] = 0.0f;
+        if (CT >= 3) w[2 * astride] = 0.0f;
     }
 }
 
@@ -1620,6 +1625,100 @@ __global__ void __launch_bounds__(256) k_traj_stream(const TrajArgs a, const Act
     }
 }
 
+// ---- episode-major with WHOLE-TRAJECTORY images: k_traj_flat (round 3) ---------------------------------------------------
+// The HBM-streaming case of the open-loop step (promp / prodmp, trajectory [+ actions], outputs far beyond the caches).
+// Measured on the streaming row (profiles/r03_streaming.md): the launch is bound by how the CU's store path is fed, not by
+// DRAM (per-channel write requests uniform, 5 % credit stalls) -- FEWER resident workgroups are faster (12 -> 8 waves per
+// CU: 542 -> 500 us) and longer contiguous runs per store instruction are faster (profiles/r01_store_patterns.md: 448-byte
+// pieces 4.9 TB/s, whole episodes 5.1, 44.8 KB runs 5.6).  So here a wave contracts ALL row tiles of its episode group
+// into an LDS image of whole trajectories [pos | vel | act][NTW episodes][T * D] (no stores, no barriers in between),
+// then streams each episode's T * D floats out as full-width float4 stores -- 1 KB contiguous per instruction, 2.8 KB
+// per episode and array, neighbouring waves writing neighbouring episodes -- while the inputs of the next group,
+// requested BEFORE the flush entered the in-order memory queue, are already on their way.  Two 4-wave workgroups per CU.
+// Same tile arithmetic as k_traj_stream (same functions): same bits.
+template <int MP, int CT, int KM>
+__global__ void __launch_bounds__(256, 2) k_traj_flat(const TrajArgs a, const ActArgs act) {
+    static_assert(MP != MPK_MP_DMP && CT < 3, "open loop, promp / prodmp");
+    extern __shared__ __attribute__((aligned(16))) float sTab[];   // [NOUT][KP][TS] rows + [TS] aux + 4 x image
+    constexpr bool ACT = CT >= 0;
+    constexpr int NOUT = MP == MPK_MP_PRODMP ? 2 : 3;
+    constexpr int NST = 2 + (ACT ? 1 : 0);
+    const DevCfg& c = a.c;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int KP = 4 * KM, TS = a.TS, D = c.D, T = c.T, TD = T * D;
+    (void)act;
+    float* sA = sTab;
+    float* sAux = sTab + NOUT * KP * TS;
+    stage_tables(a.A, a.aux, sA, sAux, (NOUT * KP * TS) >> 2, TS >> 2, threadIdx.x);   // once per workgroup
+    const LaneMap<KM> L = make_lane_map<MP, KM>(a, lane);
+    const int NTW = L.NTW, NRT = (T + 15) >> 4;
+    const int IMG = a.flat_img;                                   // floats per array image: NTW * T * D rounded up to 4
+    float* sI = sAux + TS + wave * (NST * IMG);
+    const int nb8 = gridDim.x >> 3;
+    const int vb = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * nb8 + (blockIdx.x >> 3) : blockIdx.x;
+    const int wstride = gridDim.x * 4;
+    int g = vb * 4 + wave;
+    const bool active = g < a.G;
+    GroupIn<KM> cur;
+    if (active) cur = load_group<MP, ACT, KM>(a, L, g);
+    Gains gn{0.0, 0.0, 0.0, 0.0};
+    if (ACT) gn = kernarg_gains(L.dvalid ? L.d : 0);
+    __syncthreads();                                              // the tables are in LDS
+    if (!active) return;
+    const float* ap = sA + L.q * TS + L.col;
+    const unsigned wbase = (unsigned)(L.bl * TD + 4 * L.q * D + L.d);   // (episode, row 4q, column) inside an image
+    float xb[KM];
+    finish_group<KM>(L, cur, xb);
+    double cp = cur.cp, cv = cur.cv;
+    const int TD4 = TD >> 2;
+    while (g < a.G) {
+        const int b0 = g * NTW;
+        const int gn_ = g + wstride;
+        const GroupIn<KM> nxt = load_group<MP, ACT, KM>(a, L, gn_ < a.G ? gn_ : g);   // in flight across the whole group
+        for (int rt = 0; rt < NRT; ++rt) {
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < KM; ++m) {
+                const float* am = ap + (4 * m) * TS + rt * 16;
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[0], xb[m], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[KP * TS], xb[m], acc1, 0, 0, 0);
+                if (NOUT > 2) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(am[(NOUT > 2 ? 2 : 0) * KP * TS], xb[m], acc2, 0, 0, 0);
+            }
+            float dtd[4] = {1.f, 1.f, 1.f, 1.f};
+            if (MP == MPK_MP_PROMP) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dtd[r] = sAux[rt * 16 + 4 * L.q + r];
+            }
+            const int nrows = min(4, T - rt * 16 - 4 * L.q);      // rows of this lane that exist (<= 0: none)
+            if (L.dvalid && nrows > 0)
+                tile_epilogue<MP, CT>(acc0, acc1, acc2, dtd, cp, cv, gn, sI, wbase + (unsigned)(rt * 16 * D), D, IMG, nrows);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // flush: each episode's T * D floats of each array are one contiguous, 16-byte aligned run in HBM
+        for (int e = 0; e < NTW; ++e) {
+            const int bb = b0 + e;
+            if (bb >= a.B) break;
+            const size_t go = (size_t)bb * TD;
+            const float* se = sI + e * TD;
+            for (int i = lane; i < TD4; i += 64) {
+                const f32x4 p4 = *reinterpret_cast<const f32x4*>(se + 4 * i);
+                const f32x4 v4 = *reinterpret_cast<const f32x4*>(se + IMG + 4 * i);
+                if (a.wt) { store16<true>(a.pos + go + 4 * i, p4); store16<true>(a.vel + go + 4 * i, v4); }
+                else { store16<false>(a.pos + go + 4 * i, p4); store16<false>(a.vel + go + 4 * i, v4); }
+                if (ACT) {
+                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(se + 2 * IMG + 4 * i);
+                    if (a.wt) store16<true>(a.actions + go + 4 * i, a4); else store16<false>(a.actions + go + 4 * i, a4);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                          // the image is free again
+        finish_group<KM>(L, nxt, xb);
+        cp = nxt.cp; cv = nxt.cv;
+        g = gn_;
+    }
+}
+
 // ---- episode-major, four groups per wave: the serial-recurrence variants ---------------------------------------------
 // DMP (Euler recurrence) and the closed-loop rollout (controller + plant recurrence) are serial in t and run on the
 // 16 lanes that hold row 0 of a column.  Here a wave owns FOUR consecutive episode groups at once: per row tile it
@@ -2012,6 +2111,23 @@ static int launch_traj_t(const TrajArgs& ta, const ActArgs& aa, bool stream_mode
     const size_t pad = (!stream_mode || split) ? lds : 0;
     hipStream_t s = (hipStream_t)stream;
     const int km = ta.c.KP / 4;
+    if (ta.flat_img > 0) {
+        if constexpr (MP != MPK_MP_DMP && CT < 3) {
+            auto go = [&](auto kern) {
+                if (lds > 48 * 1024)
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL(kern, g, b, lds, s, ta, aa);
+            };
+            switch (km) {
+                case 1: go(k_traj_flat<MP, CT, 1>); break;
+                case 2: go(k_traj_flat<MP, CT, 2>); break;
+                case 3: go(k_traj_flat<MP, CT, 3>); break;
+                default: go(k_traj_flat<MP, CT, 4>); break;
+            }
+        }
+        MPK_LAUNCH_CHECK();
+        return MPK_OK;
+    }
     if (split) {
         if constexpr (MP != MPK_MP_DMP && CT >= 3) {
             if (write_through) {
@@ -2155,7 +2271,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
                        const int32_t* n_steps, int B, int num_cu, void* stream, const char** kernel_name,
                        const Tuning& tune, const ReplanDev* rp) {
     TrajArgs ta;
-    ta.nrt_magic = 0; ta.gstride = 0; ta.wt = 0;
+    ta.nrt_magic = 0; ta.gstride = 0; ta.wt = 0; ta.flat_img = 0;
     if (rp) ta.rp = *rp;
     const bool closed = q_state != nullptr;
     ta.q_state = q_state; ta.qd_state = qd_state; ta.n_steps = n_steps; ta.plant_dt = rc ? rc->dt : 0.0;
@@ -2214,6 +2330,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     bool stream_mode = !split && (c.mp_type == MPK_MP_DMP || closed || out_bytes > 96.0 * 1024 * 1024);
     if (c.mp_type != MPK_MP_DMP && !closed && ov == 1) stream_mode = false;
     if (ov == 2 && !split) stream_mode = true;       // a forced k_traj_split stays tile-major (its tiles role needs that geometry)
+    if (tune.flat == 1 && !closed && c.mp_type != MPK_MP_DMP && !split) stream_mode = true;   // forced k_traj_flat (where it applies)
     if (stream_mode && table_bytes + 4 * kStageFloats * sizeof(float) > 64 * 1024) {
         // the caller falls back: per-episode kernels for dmp, trajectory + rollout launches for the closed loop
         if (c.mp_type == MPK_MP_DMP || closed) { set_error("trajectory too long for the episode-major kernel's LDS budget"); return MPK_ENOTIMPL; }
@@ -2292,7 +2409,20 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         bulk = bulk && bulk_mode != 0 && (bulk_mode == 2 || auto_ok);
         long units = ta.G;
         if (bulk) { lds = lds_bulk; units = (ta.G + kChunkGroups - 1) / kChunkGroups; }
-        const long waves = units < max_waves ? units : max_waves;
+        long waves = units < max_waves ? units : max_waves;
+        // whole-trajectory images (k_traj_flat): open loop, promp / prodmp, aligned outputs, T * D a multiple of 4, and
+        // two workgroups' images + tables within a CU's LDS.  Automatic once the outputs stream to HBM (A/B on the
+        // streaming row, profiles/r03_streaming.md); mpk_set_option "flat": 0 off, 1 force
+        const int flat_img = (NTW * TD + 3) / 4 * 4;
+        const size_t lds_flat = table_bytes + (size_t)4 * nst * flat_img * sizeof(float);
+        const bool flat_ok = !closed && c.mp_type != MPK_MP_DMP && ptr_ok && TD % 4 == 0 && lds_flat <= 80 * 1024;
+        if (flat_ok && tune.flat != 0 && (tune.flat == 1 || (out_bytes > 96.0 * 1024 * 1024 && tune.bulk < 0 && tune.lds_pad < 0))) {
+            ta.flat_img = flat_img;
+            bulk = false;
+            lds = lds_flat;
+            const long resident = (long)num_cu * 2 * 4;                   // two 4-wave workgroups per CU, persistent
+            waves = ta.G < resident ? ta.G : resident;
+        }
         blocks = (int)((waves + 3) / 4);
         if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;                  // XCD-contiguous remap needs a multiple of 8
     } else {
@@ -2316,7 +2446,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     if (blocks < 1) blocks = 1;
     if (!stream_mode && !pipe && ta.gstride <= 0) { set_error("internal: tile-major launch without its group stride"); return MPK_EINVAL; }
     if (!stream_mode && tune.lds_pad > 0) lds = (size_t)tune.lds_pad * 1024;     // A/B runs: caps the workgroups per CU
-    if (stream_mode && !pipe && tune.lds_pad > 0) lds += (size_t)tune.lds_pad * 1024;   // episode-major: EXTRA dynamic LDS (occupancy experiments)
+    if (stream_mode && !pipe && !ta.flat_img && tune.lds_pad > 0) lds += (size_t)tune.lds_pad * 1024;   // episode-major: EXTRA dynamic LDS (occupancy experiments)
     ta.ser_blocks = 0;
     if (split) {
         // serial-role workgroups first (they are the long pole and must start first), capped at one resident round of the chip
@@ -2330,11 +2460,11 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     }
     switch (c.mp_type) {
         case MPK_MP_PRODMP:
-            *kernel_name = pipe ? "k_traj_pipe<prodmp,closed>" : split ? "k_traj_split<prodmp,closed>" : closed ? (quad == 4 ? "k_traj_quad<prodmp,closed>" : quad == 2 ? "k_traj_duo<prodmp,closed>" : quad == 1 ? "k_traj_mono<prodmp,closed>" : "k_traj_stream<prodmp,closed>") : stream_mode ? (act ? "k_traj_stream<prodmp,act>" : "k_traj_stream<prodmp>")
+            *kernel_name = pipe ? "k_traj_pipe<prodmp,closed>" : split ? "k_traj_split<prodmp,closed>" : closed ? (quad == 4 ? "k_traj_quad<prodmp,closed>" : quad == 2 ? "k_traj_duo<prodmp,closed>" : quad == 1 ? "k_traj_mono<prodmp,closed>" : "k_traj_stream<prodmp,closed>") : ta.flat_img ? (act ? "k_traj_flat<prodmp,act>" : "k_traj_flat<prodmp>") : stream_mode ? (act ? "k_traj_stream<prodmp,act>" : "k_traj_stream<prodmp>")
                                        : (act ? "k_traj_tiles<prodmp,act>" : "k_traj_tiles<prodmp>");
             return launch_traj_ct<MPK_MP_PRODMP>(ta, aa, ct, stream_mode, write_through, bulk, quad, blocks, lds, stream, split, pipe);
         case MPK_MP_PROMP:
-            *kernel_name = pipe ? "k_traj_pipe<promp,closed>" : split ? "k_traj_split<promp,closed>" : closed ? (quad == 4 ? "k_traj_quad<promp,closed>" : quad == 2 ? "k_traj_duo<promp,closed>" : quad == 1 ? "k_traj_mono<promp,closed>" : "k_traj_stream<promp,closed>") : stream_mode ? (act ? "k_traj_stream<promp,act>" : "k_traj_stream<promp>")
+            *kernel_name = pipe ? "k_traj_pipe<promp,closed>" : split ? "k_traj_split<promp,closed>" : closed ? (quad == 4 ? "k_traj_quad<promp,closed>" : quad == 2 ? "k_traj_duo<promp,closed>" : quad == 1 ? "k_traj_mono<promp,closed>" : "k_traj_stream<promp,closed>") : ta.flat_img ? (act ? "k_traj_flat<promp,act>" : "k_traj_flat<promp>") : stream_mode ? (act ? "k_traj_stream<promp,act>" : "k_traj_stream<promp>")
                                        : (act ? "k_traj_tiles<promp,act>" : "k_traj_tiles<promp>");
             return launch_traj_ct<MPK_MP_PROMP>(ta, aa, ct, stream_mode, write_through, bulk, quad, blocks, lds, stream, split, pipe);
         default:

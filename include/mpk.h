@@ -202,6 +202,8 @@ int mpk_set_duration(mpk_handle h, double duration, double dt);
  *   "phase_chunk"   episodes per wave and chunk: 1 / 2 / 4 (promp / prodmp), 1 .. min(16, 64 / D) (dmp)
  *   "pd_simple"     1 generic one-lane-per-(episode, DoF) rollout kernels
  *   "pipe"          0 off, 1 force the producer / consumer closed-loop kernel (k_traj_pipe; the default where it fits)
+ *   "flat"          0 off, 1 force the whole-trajectory-image episode-major kernel (k_traj_flat; automatic for open-loop
+ *                   promp / prodmp launches whose outputs stream to HBM)
  *   "split"         1 force the tile-major closed-loop kernel with a serial role (k_traj_split; never chosen automatically)
  *   "lds_pad"       n KB of unused dynamic LDS per workgroup of the tile-major kernels (occupancy experiments: 160 KB per CU)
  * Unknown key or value out of range: MPK_EINVAL.  mpk_get_option returns the effective value (MPK_OPT_AUTO if automatic).

@@ -176,3 +176,69 @@ def test_per_episode_init_time_equals_shared_path(name):
     else:
         assert torch.equal(p0, p1)
         assert torch.equal(v0, v1)
+
+# ---- k_traj_flat: whole-trajectory LDS images, flat stores (the HBM-streaming open-loop kernel of round 3) ----------------
+FLAT_PROMP = (O.PhaseCfg("linear", tau=2.8),
+              O.BasisCfg("zero_rbf", num_basis=3, num_basis_zero_start=1, num_basis_zero_goal=1, basis_bandwidth_factor=3),
+              O.TrajCfg("promp", action_dim=4), 0.008, 2.8)          # T * D = 1400: whole float4 chunks
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg4", "promp4", "cfg1"])
+@pytest.mark.parametrize("B", [1, 2, 3, 64, 1001])
+@pytest.mark.parametrize("init_time", [0.0, 0.5])
+def test_flat_kernel_matches_the_oracle_and_the_other_kernels_bitwise(name, B, init_time, mpk_option):
+    """same tile arithmetic as k_traj_stream / k_traj_tiles (same device functions) -> identical bits; and the oracle"""
+    pc, bc, tc, dt, duration = {"cfg2": CFG2, "cfg4": CFG4, "promp4": FLAT_PROMP, "cfg1": CFG1}[name]
+    eng = make_engine(pc, bc, tc, dt, duration)
+    params, ip, iv = inputs(pc, bc, tc, B, seed=B + 3)
+    mpk_option("flat", 1)
+    pos, vel = eng.trajectory(params, ip, iv, init_time)
+    torch.cuda.synchronize()
+    assert eng.last_kernel().startswith("k_traj_flat"), eng.last_kernel()
+    rp, rv = O.get_trajectory(pc, bc, tc, params, duration, dt, init_time, ip, iv, dtype=np.float64)
+    close(pos.cpu().numpy(), rp, f"{name} pos")
+    close(vel.cpu().numpy(), rv, f"{name} vel", atol=fd_atol(rp, dt) if tc.trajectory_generator_type == "promp" else 0.0)
+    for mapping in (1, 2):
+        mpk_option("flat", 0); mpk_option("mapping", mapping)
+        p2, v2 = eng.trajectory(params, ip, iv, init_time)
+        assert not eng.last_kernel().startswith("k_traj_flat")
+        assert torch.equal(pos, p2) and torch.equal(vel, v2), (mapping, eng.last_kernel())
+
+
+@pytest.mark.parametrize("B", [1, 5, 130, 4096])
+@pytest.mark.parametrize("ctrl", ["motor", "position", "velocity"])
+def test_flat_kernel_fused_actions_bit_exact(B, ctrl, mpk_option):
+    """trajectory + tracking-controller actions (frozen state) through k_traj_flat: actions bit-exact against the oracle's
+    float64 controller and against the tile-major kernel"""
+    import bench
+    from fancy_gym_amd import RolloutSpec
+    pc, bc, tc, dt, duration = CFG2
+    eng = make_engine(pc, bc, tc, dt, duration)
+    params, ip, iv = inputs(pc, bc, tc, B, seed=B)
+    rng = np.random.default_rng(B)
+    cp, cv = rng.uniform(-1, 1, (B, 7)), rng.uniform(-1, 1, (B, 7))
+    spec = RolloutSpec(ctrl, 7, bench.P_GAINS, bench.D_GAINS, -1.0, 1.0, plant="static")
+    mpk_option("flat", 1)
+    pos, vel, act = eng.trajectory_actions(params, ip, iv, spec, cp, cv)
+    torch.cuda.synchronize()
+    assert eng.last_kernel() == "k_traj_flat<prodmp,act>", eng.last_kernel()
+    ra, _, _ = O.rollout(pos.cpu().numpy(), vel.cpu().numpy(), ctrl, bench.P_GAINS, bench.D_GAINS, -1.0, 1.0, "static", dt,
+                         cp, cv)
+    assert np.array_equal(act.cpu().numpy(), ra.astype(np.float32))
+    mpk_option("flat", 0)
+    p2, v2, a2 = eng.trajectory_actions(params, ip, iv, spec, cp, cv)
+    assert eng.last_kernel().startswith("k_traj_tiles") or eng.last_kernel().startswith("k_traj_stream")
+    assert torch.equal(pos, p2) and torch.equal(vel, v2) and torch.equal(act, a2)
+
+
+def test_flat_kernel_is_skipped_where_it_does_not_apply(mpk_option):
+    """T * D not a multiple of 4 (cfg5: 350 x 7), DMP, images beyond the LDS budget: the forced option falls through"""
+    mpk_option("flat", 1)
+    for cfg in (CFG5, CFG3):
+        pc, bc, tc, dt, duration = cfg
+        eng = make_engine(pc, bc, tc, dt, duration)
+        params, ip, iv = inputs(pc, bc, tc, 9, seed=1)
+        pos, vel = eng.trajectory(params, ip, iv, 0.0)
+        assert not eng.last_kernel().startswith("k_traj_flat")
+        rp, rv = O.get_trajectory(pc, bc, tc, params, duration, dt, 0.0, ip, iv, dtype=np.float64)
+        close(pos.cpu().numpy(), rp, "pos")

@@ -94,6 +94,8 @@ def main():
         return lambda: eng.trajectory(params, ip, iv, 0.0, out=out[:2])
     print(f"B = {B}; array size {size / 2**20:.1f} MiB; data_ptr of three allocations: "
           + ", ".join(hex(t.data_ptr()) for t in sep) + f"; slab {hex(slab.data_ptr())}")
+    from fancy_gym_amd import _lib as _l
+    _l.set_option("flat", 0)    # the skew sweep characterises k_traj_stream (round 2's kernel)
     timed(run3(sep), n=80)      # clocks
     res = {}
     for r in range(rounds):
@@ -118,11 +120,16 @@ def main():
     # (45.5 KB each), 10: two, i.e. 12 -> 8 waves per CU
     from fancy_gym_amd import _lib
     print()
-    print("| lds_pad KiB | workgroups per CU | fused +actions us | trajectory only us |")
-    print("|---|---|---|---|")
-    for pad, wg in ((0, 3), (10, 2), (40, 1), (0, 3), (10, 2), (40, 1)):
-        _lib.set_option("lds_pad", pad if pad else -1)
-        print(f"| {pad} | {wg} | {timed(run3(sep)) * 1e6:.0f} | {timed(run2(sep)) * 1e6:.0f} |")
+    print("| kernel | lds_pad KiB | workgroups per CU | fused +actions us | trajectory only us |")
+    print("|---|---|---|---|---|")
+    for flat, pad, wg in ((0, 0, 3), (0, 10, 2), (1, 0, 2), (0, 0, 3), (0, 10, 2), (1, 0, 2), (0, 40, 1)):
+        _lib.reset_options()
+        _lib.set_option("flat", flat)
+        if pad:
+            _lib.set_option("lds_pad", pad)
+        t3, k3 = timed(run3(sep)), eng.last_kernel()
+        t2 = timed(run2(sep))
+        print(f"| `{k3}` | {pad} | {wg} | {t3 * 1e6:.0f} | {t2 * 1e6:.0f} |")
     _lib.reset_options()
     print()
     print("| what runs | s per launch | sclk avg (min-max) MHz | power W | gpu busy % | mem busy % | mclk | fclk | samples |")

@@ -1701,6 +1701,7 @@ __global__ void __launch_bounds__(256, 2) k_traj_flat(const TrajArgs a, const Ac
             if (bb >= a.B) break;
             const size_t go = (size_t)bb * TD;
             const float* se = sI + e * TD;
+#ifndef MPK_FLAT_ARRAY_MAJOR
             for (int i = lane; i < TD4; i += 64) {
                 const f32x4 p4 = *reinterpret_cast<const f32x4*>(se + 4 * i);
                 const f32x4 v4 = *reinterpret_cast<const f32x4*>(se + IMG + 4 * i);
@@ -1711,6 +1712,19 @@ __global__ void __launch_bounds__(256, 2) k_traj_flat(const TrajArgs a, const Ac
                     if (a.wt) store16<true>(a.actions + go + 4 * i, a4); else store16<false>(a.actions + go + 4 * i, a4);
                 }
             }
+#else
+            // array by array: the episode's 2.8 KB of one array leave back to back before the next array starts (A/B build:
+            // 421 vs 406 - 411 us at B = 262144 on a fast box, equal on a slow one -- interleaved is the default)
+#pragma unroll
+            for (int j = 0; j < NST; ++j) {
+                float* const outp = (j == 0 ? a.pos : (j == 1 ? a.vel : a.actions)) + go;
+                const float* sj = se + j * IMG;
+                for (int i = lane; i < TD4; i += 64) {
+                    const f32x4 x4 = *reinterpret_cast<const f32x4*>(sj + 4 * i);
+                    if (a.wt) store16<true>(outp + 4 * i, x4); else store16<false>(outp + 4 * i, x4);
+                }
+            }
+#endif
         }
         __builtin_amdgcn_wave_barrier();                          // the image is free again
         finish_group<KM>(L, nxt, xb);
@@ -2416,11 +2430,12 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         const int flat_img = (NTW * TD + 3) / 4 * 4;
         const size_t lds_flat = table_bytes + (size_t)4 * nst * flat_img * sizeof(float);
         const bool flat_ok = !closed && c.mp_type != MPK_MP_DMP && ptr_ok && TD % 4 == 0 && lds_flat <= 80 * 1024;
-        if (flat_ok && tune.flat != 0 && (tune.flat == 1 || (out_bytes > 96.0 * 1024 * 1024 && tune.bulk < 0 && tune.lds_pad < 0))) {
+        if (flat_ok && tune.flat != 0 && (tune.flat == 1 || (out_bytes > 96.0 * 1024 * 1024 && tune.bulk < 0))) {
             ta.flat_img = flat_img;
             bulk = false;
-            lds = lds_flat;
-            const long resident = (long)num_cu * 2 * 4;                   // two 4-wave workgroups per CU, persistent
+            lds = lds_flat + (tune.lds_pad > 0 ? (size_t)tune.lds_pad * 1024 : 0);   // "lds_pad": occupancy experiments
+            const long wg = (long)(160 * 1024 / lds) < 3 ? (long)(160 * 1024 / lds) : 3;   // workgroups a CU's LDS holds
+            const long resident = (long)num_cu * (wg < 1 ? 1 : wg) * 4;   // 4-wave workgroups, persistent
             waves = ta.G < resident ? ta.G : resident;
         }
         blocks = (int)((waves + 3) / 4);

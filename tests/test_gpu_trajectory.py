@@ -180,15 +180,18 @@ def test_per_episode_init_time_equals_shared_path(name):
 # ---- k_traj_flat: whole-trajectory LDS images, flat stores (the HBM-streaming open-loop kernel of round 3) ----------------
 FLAT_PROMP = (O.PhaseCfg("linear", tau=2.8),
               O.BasisCfg("zero_rbf", num_basis=3, num_basis_zero_start=1, num_basis_zero_goal=1, basis_bandwidth_factor=3),
-              O.TrajCfg("promp", action_dim=4), 0.008, 2.8)          # T * D = 1400: whole float4 chunks
+              O.TrajCfg("promp", action_dim=4), 0.028, 2.8)          # T * D = 400: whole float4 chunks, four episodes per group
+FLAT_PROMP5 = (O.PhaseCfg("linear", tau=2.0),
+               O.BasisCfg("zero_rbf", num_basis=5, num_basis_zero_start=1, num_basis_zero_goal=0, basis_bandwidth_factor=3),
+               O.TrajCfg("promp", action_dim=5), 0.02, 2.0)          # cfg1's basis on a 100-step horizon
 
 
-@pytest.mark.parametrize("name", ["cfg2", "cfg4", "promp4", "cfg1"])
+@pytest.mark.parametrize("name", ["cfg2", "cfg4", "promp4", "promp5"])
 @pytest.mark.parametrize("B", [1, 2, 3, 64, 1001])
 @pytest.mark.parametrize("init_time", [0.0, 0.5])
 def test_flat_kernel_matches_the_oracle_and_the_other_kernels_bitwise(name, B, init_time, mpk_option):
     """same tile arithmetic as k_traj_stream / k_traj_tiles (same device functions) -> identical bits; and the oracle"""
-    pc, bc, tc, dt, duration = {"cfg2": CFG2, "cfg4": CFG4, "promp4": FLAT_PROMP, "cfg1": CFG1}[name]
+    pc, bc, tc, dt, duration = {"cfg2": CFG2, "cfg4": CFG4, "promp4": FLAT_PROMP, "promp5": FLAT_PROMP5}[name]
     eng = make_engine(pc, bc, tc, dt, duration)
     params, ip, iv = inputs(pc, bc, tc, B, seed=B + 3)
     mpk_option("flat", 1)
@@ -232,9 +235,10 @@ def test_flat_kernel_fused_actions_bit_exact(B, ctrl, mpk_option):
 
 
 def test_flat_kernel_is_skipped_where_it_does_not_apply(mpk_option):
-    """T * D not a multiple of 4 (cfg5: 350 x 7), DMP, images beyond the LDS budget: the forced option falls through"""
+    """T * D not a multiple of 4 (cfg5: 350 x 7), DMP, images beyond the LDS budget (cfg1: two 200-step 5-DoF episodes per
+    wave and array): the forced option falls through to the other kernels"""
     mpk_option("flat", 1)
-    for cfg in (CFG5, CFG3):
+    for cfg in (CFG5, CFG3, CFG1):
         pc, bc, tc, dt, duration = cfg
         eng = make_engine(pc, bc, tc, dt, duration)
         params, ip, iv = inputs(pc, bc, tc, 9, seed=1)

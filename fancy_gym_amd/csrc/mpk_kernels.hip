@@ -2537,78 +2537,132 @@ __device__ __forceinline__ float wide_x(const DevCfg& c, const float* __restrict
     return prm[c.off + dd * c.Kloc + k];
 }
 
+// 64 accumulator registers or fewer: two workgroups per CU (one stages while the other contracts); 128: one workgroup per CU
+// with the whole register file (the register prefetch of the next chunk covers the global latency either way)
 template <int MP, int MT>
-__global__ void __launch_bounds__(256, 2) k_traj_wide(const WideArgs a) {
+__global__ void __launch_bounds__(256, ((MP == MPK_MP_PRODMP ? 2 : 1) * MT <= 16 ? 2 : 1)) k_traj_wide(const WideArgs a) {
     constexpr int NOUT = MP == MPK_MP_PRODMP ? 2 : 1;
     constexpr int CS = 17;                              // column stride of the epilogue image
+    // register images of the NEXT k chunk (requested before the current chunk is contracted).
+    // A: wave w takes table rows w, w + 4, ... of the chunk, lane <-> float4 of the row (one coalesced load of up to 1 KB per
+    // row and 64-lane span), committed to LDS after the contraction: ANR float4 per lane.
+    // X: the B fragments themselves -- lane (column n = lane & 15, k quarter lane >> 4) loads X[k0 + 4 j + (lane >> 4)][n]
+    // for j < KC / 4 straight from the column's parameter row (a quad of lanes = 16 contiguous bytes; the KC floats of a
+    // column are one or two cache lines that the chunk's loads share): no LDS staging, no per-step LDS read for B.
+    constexpr int ANR = 8, XNR = 8;                     // KC <= 32
+    // LDS layout of the A chunk: [table row = o * KC + kk][step-in-tile m][row tile r], MTP floats per m.  A lane's fragments
+    // of one k for ALL row tiles are contiguous (ds_read_b128: four tiles per read instead of one ds_read_b32 per MFMA);
+    // MTP / 4 odd and 16 * MTP a multiple of 64 floats: the 16 lanes of every ds_read_b128 group hit 16 distinct 16-byte
+    // bank groups (a 16-lane group mixes two k rows: rows are 64-float multiples apart, m * MTP / 4 is a bijection mod 16)
+    constexpr int MTQ = (MT + 3) / 4 + (((MT + 3) / 4) % 2 == 0 ? 1 : 0), MTP = 4 * MTQ, SA = 16 * MTP, NR4 = (MT + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevCfg& c = a.c;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, g4 = lane >> 4;
-    const int D = c.D, T = c.T, KP = c.KP, KT = c.KT, TS = a.TS, KC = a.KC, SA = a.SA, SB = KC + 2;
-    float* sA = smem;                                   // [NOUT][KC][SA]
-    float* sB = sA + NOUT * KC * SA + wave * 16 * SB;   // this wave's [16][SB]
+    const int D = c.D, T = c.T, KP = c.KP, KT = c.KT, TS = a.TS, KC = a.KC;
+    float* sA = smem;                                   // [NOUT][KC][16][MTP]
     // epilogue images alias the staging area (used after the k loop, behind a barrier): per wave [NIMG][MT*16][CS]
     constexpr int NIMG = MP == MPK_MP_PROMP ? 1 : 2;
     float* sC = smem + (size_t)wave * NIMG * MT * 16 * CS;
     const int ncol = a.epg * D;                         // used columns of a group
+    const int kshift = 31 - __builtin_clz(KC);          // KC is a power of two
+    const int nj = KC >> 2;                             // MFMA steps per chunk
 
     for (int unit = blockIdx.x; unit < a.n_units; unit += gridDim.x) {
         const int grp = unit * 4 + wave;
         const int b0 = grp * a.epg;
-        // this lane's column for the B staging loop is the loop variable; for the fragment / epilogue it is m
+        // this lane's column: episode, DoF, the sources of its operand column
+        const int ce = (int)(((unsigned)m * (65536u / (unsigned)D + 1u)) >> 16), cd = m - ce * D;
+        const int cb = b0 + ce;
+        const bool cvalid = m < ncol && cb < a.B;
+        const float* cprm = a.params + (size_t)(cvalid ? cb : 0) * c.P;
+        const float* cw = cprm + c.off + cd * c.Kloc;                           // the DoF's local block
+        const float cip = cvalid && MP != MPK_MP_DMP ? a.init_pos[(size_t)cb * D + cd] : 0.0f;
+        const float civ = cvalid && MP == MPK_MP_PRODMP ? a.init_vel[(size_t)cb * D + cd] : 0.0f;
+        // columns [0, kplain) are plain parameters at cw[k] (the weights; promp / dmp: all learnable columns)
+        const int kplain = (MP == MPK_MP_PRODMP && c.disable_weights) ? 0 : c.nb;
         for (int rt0 = 0; rt0 < a.n_rt; rt0 += MT) {
             const int nrt = min(MT, a.n_rt - rt0);      // row tiles of this block
             const int rowsA = nrt * 16;
+            const int r4 = rowsA >> 2;                  // float4 per table row
+            const int spans = (r4 + 63) >> 6;           // 64-lane spans per row (1, or 2 for more than 16 row tiles)
+            const int nrows = NOUT * KC;                // table rows per chunk; rows per wave x spans <= ANR (launcher)
             f32x4 acc[NOUT][MT];
 #pragma unroll
             for (int o = 0; o < NOUT; ++o)
 #pragma unroll
                 for (int r = 0; r < MT; ++r) acc[o][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            float4 ra[ANR];
+            float xn[XNR], xc[XNR];
+            // ---- requests of one k chunk: every load is issued before any of them is used ----
+            auto fetch = [&](int k0) {
+#pragma unroll
+                for (int p = 0; p < ANR; ++p) {
+                    const int row = wave + 4 * (spans == 1 ? p : (p >> 1));       // wave-uniform: o * KC + kk
+                    const int q = lane + (spans == 1 ? 0 : 64 * (p & 1));
+                    const int kk = row & (KC - 1), o = row >> kshift;
+                    const int k = k0 + kk;
+                    ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (row < nrows && q < r4 && k < KP)
+                        ra[p] = *reinterpret_cast<const float4*>(a.A + ((size_t)o * KP + k) * TS + rt0 * 16 + 4 * q);
+                }
+                if (k0 + KC <= kplain) {                // the common chunk: nothing but parameters (wave-uniform test)
+#pragma unroll
+                    for (int p = 0; p < XNR; ++p) {
+                        xn[p] = 0.0f;
+                        if (p < nj && cvalid) xn[p] = cw[k0 + 4 * p + g4];
+                    }
+                } else {
+#pragma unroll
+                    for (int p = 0; p < XNR; ++p) {
+                        const int k = k0 + 4 * p + g4;
+                        xn[p] = 0.0f;
+                        if (p < nj && cvalid && k < KT) xn[p] = wide_x<MP>(c, cprm, cip, civ, cd, k);
+                    }
+                }
+            };
+            auto commit = [&]() {
+#pragma unroll
+                for (int p = 0; p < ANR; ++p) {
+                    const int row = wave + 4 * (spans == 1 ? p : (p >> 1));
+                    const int q = lane + (spans == 1 ? 0 : 64 * (p & 1));
+                    if (row < nrows && q < r4) {
+                        // float4 = steps 4 q .. 4 q + 3 of the block: row tile q / 4, steps-in-tile 4 (q % 4) + e
+                        float* w = sA + (size_t)row * SA + (4 * (q & 3)) * MTP + (q >> 2);
+                        w[0] = ra[p].x; w[MTP] = ra[p].y; w[2 * MTP] = ra[p].z; w[3 * MTP] = ra[p].w;
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < XNR; ++p) xc[p] = xn[p];
+            };
+            fetch(0);
             for (int k0 = 0; k0 < KP; k0 += KC) {
                 __syncthreads();                        // the previous chunk (or epilogue image) is consumed
-                // ---- A chunk: rows [rt0*16, rt0*16 + rowsA) of k in [k0, k0 + KC), every output table ----
-                {
-                    const int r4 = rowsA >> 2;          // float4 per table row
-                    const int total = NOUT * KC * r4;
-                    for (int i = tid; i < total; i += 256) {
-                        const int q = i % r4, rest = i / r4;
-                        const int kk = rest % KC, o = rest / KC;
-                        const int k = k0 + kk;
-                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (k < KP)
-                            v = *reinterpret_cast<const float4*>(a.A + ((size_t)o * KP + k) * TS + rt0 * 16 + 4 * q);
-                        *reinterpret_cast<float4*>(sA + ((size_t)o * KC + kk) * SA + 4 * q) = v;
-                    }
-                }
-                // ---- X chunk of this wave's 16 columns: lane <-> k ----
-                for (int n = 0; n < 16; ++n) {
-                    const int e = n / D, dd = n - e * D;
-                    const int b = b0 + e;
-                    const bool cv = n < ncol && b < a.B;
-                    const float* prm = a.params + (size_t)(cv ? b : 0) * c.P;
-                    const float ip = cv && MP != MPK_MP_DMP ? a.init_pos[(size_t)b * D + dd] : 0.0f;
-                    const float iv = cv && MP == MPK_MP_PRODMP ? a.init_vel[(size_t)b * D + dd] : 0.0f;
-                    for (int kk = lane; kk < KC; kk += 64) {
-                        const int k = k0 + kk;
-                        sB[n * SB + kk] = (cv && k < KT) ? wide_x<MP>(c, prm, ip, iv, dd, k) : 0.0f;
-                    }
-                }
+                commit();
                 __syncthreads();
+                if (k0 + KC < KP) fetch(k0 + KC);       // in flight under this chunk's contraction
                 // ---- contraction of the chunk ----
-                const float* pb = sB + m * SB + g4;
-                const float* pa = sA + (size_t)g4 * SA + m;
-                for (int j = 0; j < KC; j += 4) {
-                    const float bf = pb[j];
+                const float* pa = sA + (size_t)g4 * SA + m * MTP;
 #pragma unroll
-                    for (int r = 0; r < MT; ++r) {
-                        if (r < nrt) {
+                for (int p = 0; p < XNR; ++p) {
+                    if (p < nj) {
+                        const float bf = xc[p];
+                        // all MT row tiles, unconditionally: MT is the launch's exact row-tile count (or, in the last block
+                        // of a long prodmp horizon, more -- those tiles contract stale LDS into accumulators nobody stores);
+                        // a guard per tile is a branch per MFMA, and a branch between an LDS read and its MFMA keeps the
+                        // compiler from issuing the reads ahead (measured: 17.8 -> 55 TF once the loads pipelined)
+                        f32x4 af[NOUT][NR4];
 #pragma unroll
-                            for (int o = 0; o < NOUT; ++o) {
-                                const float af = pa[((size_t)o * KC + j) * SA + r * 16];
-                                acc[o][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf, acc[o][r], 0, 0, 0);
-                            }
+                        for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+                            for (int c4 = 0; c4 < NR4; ++c4)
+                                af[o][c4] = *reinterpret_cast<const f32x4*>(pa + ((size_t)o * KC + 4 * p) * SA + 4 * c4);
+#pragma unroll
+                        for (int r = 0; r < MT; ++r) {
+#pragma unroll
+                            for (int o = 0; o < NOUT; ++o)
+                                acc[o][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[o][r >> 2][r & 3], bf, acc[o][r], 0, 0, 0);
                         }
                     }
                 }
@@ -2696,18 +2750,24 @@ int launch_traj_wide(const DevCfg& c, const SharedTables& st, const float* param
     const int nimg = c.mp_type == MPK_MP_PROMP ? 1 : 2;
     const int mt_max = c.mp_type == MPK_MP_PRODMP ? 16 : 32;
     if (c.mp_type != MPK_MP_PRODMP && n_rt > mt_max) return MPK_ENOTIMPL;   // whole horizon in one row-tile block
-    const int MT = n_rt <= 8 ? 8 : (n_rt <= 16 || mt_max == 16) ? 16 : 32;
-    const int SA = MT * 16 + 16;
-    // k chunk: the staging area (A chunk + four X images) stays below ~72 KB, so that two workgroups share a CU
-    int KC = 64;
-    auto stage_bytes = [&](int kc) { return ((size_t)nout * kc * SA + 4 * 16 * (kc + 2)) * sizeof(float); };
-    while (KC > 8 && stage_bytes(KC) > 72 * 1024) KC >>= 1;
+    // row tiles per block: the smallest instantiated count >= n_rt (the contraction loop runs all MT tiles unconditionally)
+    static const int kMT[] = {4, 7, 8, 12, 13, 16, 24, 32};
+    int MT = mt_max;
+    for (int v : kMT) if (v >= n_rt && v <= mt_max) { MT = v; break; }
+    const int rows_max = (n_rt < MT ? n_rt : MT) * 16;                    // rows of a row-tile block that exist
+    const int mtq = (MT + 3) / 4 + (((MT + 3) / 4) % 2 == 0 ? 1 : 0);     // the kernel's MTQ / MTP / SA
+    const int SA = 16 * 4 * mtq;
+    const int spans = (rows_max / 4 + 63) / 64;                            // 64-lane float4 spans per table row
+    int KC = 32;                                                           // <= 8 B fragments per lane and chunk
+    auto stage_bytes = [&](int kc) { return ((size_t)nout * kc * SA) * sizeof(float); };
+    while (KC > 8 && (stage_bytes(KC) > 80 * 1024 || nout * KC / 4 * spans > 8)) KC >>= 1;
     const size_t epi_bytes = (size_t)4 * nimg * MT * 16 * 17 * sizeof(float);
     const size_t lds = stage_bytes(KC) > epi_bytes ? stage_bytes(KC) : epi_bytes;
     WideArgs wa{c, st.A, st.aux, st.TS, params, init_pos, init_vel, pos, vel, B, 16 / c.D, 0, KC, n_rt, SA};
     const int n_groups = (B + wa.epg - 1) / wa.epg;
     wa.n_units = (n_groups + 3) / 4;
-    const int blocks = wa.n_units < num_cu * 2 ? wa.n_units : num_cu * 2;
+    const int per_cu = nout * MT <= 16 ? 2 : 1;                           // see the kernel's launch bounds
+    const int blocks = wa.n_units < num_cu * per_cu ? wa.n_units : num_cu * per_cu;
     auto go = [&](auto kern) -> int {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -2718,18 +2778,27 @@ int launch_traj_wide(const DevCfg& c, const SharedTables& st, const float* param
         MPK_LAUNCH_CHECK();
         return MPK_OK;
     };
+    auto pick = [&](auto mp_tag) -> int {
+        constexpr int MPV = decltype(mp_tag)::value;
+        switch (MT) {
+            case 4: return go(k_traj_wide<MPV, 4>);
+            case 7: return go(k_traj_wide<MPV, 7>);
+            case 8: return go(k_traj_wide<MPV, 8>);
+            case 12: return go(k_traj_wide<MPV, 12>);
+            case 13: return go(k_traj_wide<MPV, 13>);
+            case 16: return go(k_traj_wide<MPV, 16>);
+            default: break;
+        }
+        if constexpr (MPV != MPK_MP_PRODMP) {
+            if (MT == 24) return go(k_traj_wide<MPV, 24>);
+            return go(k_traj_wide<MPV, 32>);
+        }
+        return go(k_traj_wide<MPV, 16>);
+    };
     switch (c.mp_type) {
-        case MPK_MP_PRODMP:
-            *kernel_name = "k_traj_wide<prodmp>";
-            return MT == 8 ? go(k_traj_wide<MPK_MP_PRODMP, 8>) : go(k_traj_wide<MPK_MP_PRODMP, 16>);
-        case MPK_MP_PROMP:
-            *kernel_name = "k_traj_wide<promp>";
-            return MT == 8 ? go(k_traj_wide<MPK_MP_PROMP, 8>) : MT == 16 ? go(k_traj_wide<MPK_MP_PROMP, 16>)
-                                                                         : go(k_traj_wide<MPK_MP_PROMP, 32>);
-        default:
-            *kernel_name = "k_traj_wide<dmp>";
-            return MT == 8 ? go(k_traj_wide<MPK_MP_DMP, 8>) : MT == 16 ? go(k_traj_wide<MPK_MP_DMP, 16>)
-                                                                       : go(k_traj_wide<MPK_MP_DMP, 32>);
+        case MPK_MP_PRODMP: *kernel_name = "k_traj_wide<prodmp>"; return pick(std::integral_constant<int, MPK_MP_PRODMP>());
+        case MPK_MP_PROMP: *kernel_name = "k_traj_wide<promp>"; return pick(std::integral_constant<int, MPK_MP_PROMP>());
+        default: *kernel_name = "k_traj_wide<dmp>"; return pick(std::integral_constant<int, MPK_MP_DMP>());
     }
 }
 #endif  // MPK_DEVICE_ONLY

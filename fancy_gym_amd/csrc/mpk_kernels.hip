@@ -778,11 +778,14 @@ __device__ __forceinline__ Gains kernarg_gains(int d) {
 // MASKED = false is the version for a tile every step of which is executed by every lane of the wave (the caller tests
 // that wave-uniformly).  sP / sV / sA: the lane's (row 0, column) slots of the desired pos / vel / action images,
 // `stride` floats per row.
-template <int CTRL, bool MASKED>
+template <int CTRL, bool MASKED, bool INTEGRATE = true, bool KEEP64 = false>
 __device__ __forceinline__ void pd_tile_steps(const float* __restrict__ sP, const float* __restrict__ sV,
                                               float* __restrict__ sA, const int stride, const int t0, const int nst,
                                               const double pgd, const double dgd, const double lod, const double hid,
-                                              const double dtp, double& qs, double& qds) {
+                                              const double dtp, double& qs, double& qds, double* __restrict__ q64 = nullptr,
+                                              double* __restrict__ u64 = nullptr) {
+    // INTEGRATE = false: MPK_PLANT_STATIC (the state never changes).  KEEP64: the plant position after the step and the
+    // clipped action also stay in LDS as float64, 16 doubles per step (the reward pass of the reacher rollout reads them)
     float pr[16], vr[16];
 #pragma unroll
     for (int tl = 0; tl < 16; ++tl) { pr[tl] = sP[tl * stride]; vr[tl] = sV[tl * stride]; }
@@ -794,17 +797,19 @@ __device__ __forceinline__ void pd_tile_steps(const float* __restrict__ sP, cons
         else if (CTRL == MPK_CTRL_POSITION) u = dp;
         else u = dv;
         u = fmin(fmax(u, lod), hid);
-        const double qds_n = qds + dtp * u;
-        const double qs_n = qs + dtp * qds_n;
+        const double qds_n = INTEGRATE ? qds + dtp * u : qds;
+        const double qs_n = INTEGRATE ? qs + dtp * qds_n : qs;
         if (MASKED) {
             const bool live = t0 + tl < nst;
             qds = live ? qds_n : qds;
             qs = live ? qs_n : qs;
-            sA[tl * stride] = live ? (float)u : 0.0f;
+            u = live ? u : 0.0;
+            sA[tl * stride] = (float)u;
         } else {
             qds = qds_n; qs = qs_n;
             sA[tl * stride] = (float)u;
         }
+        if (KEEP64) { q64[tl * 16] = qs; u64[tl * 16] = u; }
     }
 }
 
@@ -908,14 +913,43 @@ __device__ __noinline__ void store_tile_generic(float* pos, float* vel, float* a
 // WT = write-through (sc1) stores: for cache-resident batches the dirty lines then leave the L2 while the kernel is
 // still computing instead of in one write-back burst at the kernel boundary (rocprof: 11.5 -> 9.8 us at B = 4096);
 // for HBM-streaming batches plain stores are faster (3.5 vs 2.8 TB/s at B = 1M), so k_traj_stream keeps WT = false.
-#ifndef MPK_STORE_MODS
-#define MPK_STORE_MODS "sc1"     // cache-policy bits of the write-through store (build-time knob for A/B runs)
+// Write-through (sc1) stores.  Default: inline-asm global stores (hipcc does not count them in its vmcnt bookkeeping).
+// Round 3 tested the alternative on the suspicion that a later `s_waitcnt vmcnt(N)` for prefetched inputs -- N short by the
+// uncounted stores, the queue retiring in order -- makes waves wait for store acknowledgements: (a) the same stores as
+// compiler-visible buffer stores (MPK_WT_ASM=0: resource built per store from a wave-uniform base), (b) range-check-
+// predicated straight-line stores so that no branch hides them from the count (MPK_WT_PRED=1), (c) the tile-major loop
+// re-ordered to collect the next item's inputs before its stores.  Headline launch, alternating builds on one box: asm
+// 8.18 us, (a) 8.27 - 8.30, (a + b) 12.1, (a + b + c) 11.2 - 11.4: with seven waves per SIMD the wave that waits is covered
+// by the others, while anything that delays or fattens the store issue costs directly.  Kept as build knobs, default off.
+#ifndef MPK_WT_PRED
+#define MPK_WT_PRED 0            // 1: range-check-predicated straight-line stores in tile_store_sel (A/B build knob)
 #endif
+#ifndef MPK_WT_ASM
+#define MPK_WT_ASM 1             // 0: compiler-visible buffer stores instead of the inline-asm global stores
+#endif
+#ifndef MPK_STORE_AUX
+#define MPK_STORE_AUX 16         // sc1 (build-time knob for A/B runs: 17 = sc0 sc1, 2 = nt, 0 = plain)
+#endif
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef int i32x2_t __attribute__((ext_vector_type(2)));
+struct WtDst { __amdgpu_buffer_rsrc_t rsrc; unsigned off; };
+__device__ __forceinline__ WtDst wt_dst(const float* p) {
+    const unsigned long long pu = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pu), hi = __builtin_amdgcn_readfirstlane((unsigned)(pu >> 32));
+    const unsigned long long base = (((unsigned long long)hi << 32) | lo) - (1ull << 30);
+    WtDst d;
+    d.rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(base), 0, -1, 0x00020000);
+    d.off = (unsigned)pu - (unsigned)base;
+    return d;
+}
+
 template <bool WT>
 __device__ __forceinline__ void store16(float* p, const f32x4& v) {
-    if (WT) {
-        // hipcc does not count this store: nothing in the kernels waits on stores, the end of the kernel drains them
-        asm volatile("global_store_dwordx4 %0, %1, off " MPK_STORE_MODS "\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    if (WT && MPK_WT_ASM) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    } else if (WT) {
+        const WtDst d = wt_dst(p);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), d.rsrc, (int)d.off, 0, MPK_STORE_AUX);
     } else {
         *reinterpret_cast<f32x4*>(p) = v;
     }
@@ -923,10 +957,13 @@ __device__ __forceinline__ void store16(float* p, const f32x4& v) {
 
 template <bool WT>
 __device__ __forceinline__ void store8(float* p, const f32x2& v) {
-    if (WT) {
+    if (WT && MPK_WT_ASM) {
         // same cache policy as the 16-byte stores next to it: plain stores into lines that also take write-through
         // stores cost the tile-major kernel half its bandwidth (cfg5 at B = 1024: 14.2 vs 8 us)
-        asm volatile("global_store_dwordx2 %0, %1, off " MPK_STORE_MODS "\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+        asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    } else if (WT) {
+        const WtDst d = wt_dst(p);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2_t, v), d.rsrc, (int)d.off, 0, MPK_STORE_AUX);
     } else {
         *reinterpret_cast<f32x2*>(p) = v;
     }
@@ -934,8 +971,26 @@ __device__ __forceinline__ void store8(float* p, const f32x2& v) {
 
 template <bool WT>
 __device__ __forceinline__ void store4(float* p, float v) {
-    if (WT) asm volatile("global_store_dword %0, %1, off " MPK_STORE_MODS "\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-    else *p = v;
+    if (WT && MPK_WT_ASM) {
+        asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    } else if (WT) {
+        const WtDst d = wt_dst(p);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), d.rsrc, (int)d.off, 0, MPK_STORE_AUX);
+    } else {
+        *p = v;
+    }
+}
+
+// Write-through store of 16 bytes at `base + off` bytes, PREDICATED by the buffer's range check instead of a branch: a lane
+// that must not store passes kWtSkip (beyond num_records = 2 GiB: the hardware discards the store).  Straight-line stores
+// are what lets the compiler count them (s_waitcnt vmcnt of a later load wait stays exact); `base` is wave-uniform (an
+// output array of the launch -- write-through launches write < 2 GiB per array, enforced by the launchers).
+constexpr unsigned kWtSkip = 0xFFFFFFF0u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wt_rsrc(const float* base_uniform) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base_uniform), 0, (int)0x80000000u, 0x00020000);
+}
+__device__ __forceinline__ void wt_store16(__amdgpu_buffer_rsrc_t r, unsigned off, const f32x4& v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), r, (int)off, 0, MPK_STORE_AUX);
 }
 
 // MASK: which output arrays of the staging image leave (bit 0 pos, bit 1 vel, bit 2 actions)
@@ -947,16 +1002,30 @@ __device__ __forceinline__ void tile_store_sel(const TrajArgs& a, const LaneMap<
     if (a.vec_ok) {
         const int bb = b0 + L.sseg;
         const int lo = (int)ep_shift(a, bb), hi = lo + len, c0 = L.w4;   // valid elements of the padded segment
-        if (L.sseg < L.NTW && bb < a.B && c0 < hi && c0 + 4 > lo) {
+        const bool in_seg = L.sseg < L.NTW && bb < a.B && c0 < hi && c0 + 4 > lo;
+        if (WT && MPK_WT_PRED) {
+            // whole chunks: straight-line, range-check-predicated buffer stores (no branch between the wave's loads and
+            // its stores: the compiler's vmcnt bookkeeping stays exact, see wt_store16)
+            const bool whole = in_seg && c0 >= lo && c0 + 4 <= hi;
+            const unsigned off = whole ? (unsigned)((((size_t)bb * T + rt * 16) * D - lo + c0) * sizeof(float)) : kWtSkip;
+            const unsigned ro = L.sseg < L.NTW ? L.rofs : 0u;                  // (lanes without a segment read slot 0)
+            if (SP) wt_store16(wt_rsrc(a.pos), off, *reinterpret_cast<const f32x4*>(sSt + ro));
+            if (SV) wt_store16(wt_rsrc(a.vel), off, *reinterpret_cast<const f32x4*>(sSt + kStageStride + ro));
+            if (SA) wt_store16(wt_rsrc(a.actions), off, *reinterpret_cast<const f32x4*>(sSt + 2 * kStageStride + ro));
+            if (!a.shifted) return;                                            // T * D % 4 == 0: every chunk is whole
+        }
+        if (in_seg) {
             const size_t go = ((size_t)bb * T + rt * 16) * D - lo + c0;    // 16-byte aligned by construction
             f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0, d2 = d0;
             if (SP) d0 = *reinterpret_cast<const f32x4*>(sSt + L.rofs);
             if (SV) d1 = *reinterpret_cast<const f32x4*>(sSt + kStageStride + L.rofs);
             if (SA) d2 = *reinterpret_cast<const f32x4*>(sSt + 2 * kStageStride + L.rofs);
             if (c0 >= lo && c0 + 4 <= hi) {
-                if (SP) store16<WT>(a.pos + go, d0);
-                if (SV) store16<WT>(a.vel + go, d1);
-                if (SA) store16<WT>(a.actions + go, d2);
+                if (!(WT && MPK_WT_PRED)) {
+                    if (SP) store16<WT>(a.pos + go, d0);
+                    if (SV) store16<WT>(a.vel + go, d1);
+                    if (SA) store16<WT>(a.actions + go, d2);
+                }
             } else if (a.td3 == 2) {
                 // T*D = 2 mod 4 (e.g. 350 x 7): segment starts and lengths are even, so a partial chunk is exactly its
                 // upper half (the chunk straddles the segment start) or its lower half (the end): ONE 8-byte store per
@@ -2357,6 +2426,9 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         write_through = tune.write_through != 0 && !stream_mode;
         ta.wt = tune.write_through != 0 && stream_mode ? 1 : 0;
     }
+    // write-through stores address an output array through one buffer resource with 32-bit byte offsets (wt_store16): arrays
+    // of 2 GiB and more (never cache resident anyway; only a forced option gets here) take plain stores
+    if ((double)B * c.T * c.D * 4.0 >= 2147483648.0) { write_through = false; ta.wt = 0; }
     int blocks;
     size_t lds = 0;
     bool bulk = false;
@@ -3934,34 +4006,21 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
                 // step would cost more instructions than the step's arithmetic, and this chain is the critical path
                 float* sg = sSt + jq * SLOT;
                 const int o0 = bl * SEG + d;
+                // branch-free steps (pd_tile_steps, the closed-loop trajectory kernels' chain: a step past the executed
+                // ones -- or past T in the last tile -- is computed and discarded by selects; round 2 measured 260 -> 125-180
+                // cycles per step for it there); MASKED = false where every serial lane executes the whole tile
+                const bool full_tile = rows == 16 && __all(nst >= rt * 16 + 16) != 0;   // over the serial lanes: wave-uniform
                 auto tile_steps = [&](auto ctrl_tag, auto plant_tag) {
-                    constexpr int CTRL = decltype(ctrl_tag)::value, PLANT = decltype(plant_tag)::value;
-                    float pr[16], vr[16];
-#pragma unroll
-                    for (int tl = 0; tl < 16; ++tl) { pr[tl] = sg[o0 + tl * D]; vr[tl] = sg[kStageStride + o0 + tl * D]; }
-#pragma unroll
-                    for (int tl = 0; tl < 16; ++tl) {
-                        if (tl < rows) {
-                            const int t = rt * 16 + tl;
-                            double u = 0.0;
-                            if (t < nst) {
-                                const double dp = (double)pr[tl], dv = (double)vr[tl];
-                                if (CTRL == MPK_CTRL_MOTOR) u = pgd * (dp - qs) + dgd * (dv - qds);
-                                else if (CTRL == MPK_CTRL_POSITION) u = dp;
-                                else u = dv;
-                                u = fmin(fmax(u, lod), hid);
-                                if (PLANT == MPK_PLANT_DOUBLE_INTEGRATOR) {
-                                    qds = qds + dtp * u;
-                                    qs = qs + dtp * qds;
-                                }
-                            }
-                            sg[2 * kStageStride + o0 + tl * D] = (float)u;
-                            if (RW) {
-                                reinterpret_cast<double*>(sg)[tl * 16 + col] = qs;
-                                reinterpret_cast<double*>(sg + 3 * kStageStride)[tl * 16 + col] = u;
-                            }
-                        }
-                    }
+                    constexpr int CTRL = decltype(ctrl_tag)::value;
+                    constexpr bool INTEG = decltype(plant_tag)::value == MPK_PLANT_DOUBLE_INTEGRATOR;
+                    double* q64 = reinterpret_cast<double*>(sg) + col;
+                    double* u64 = reinterpret_cast<double*>(sg + 3 * kStageStride) + col;
+                    if (full_tile)
+                        pd_tile_steps<CTRL, false, INTEG, RW>(sg + o0, sg + kStageStride + o0, sg + 2 * kStageStride + o0, D, rt * 16,
+                                                              nst, pgd, dgd, lod, hid, dtp, qs, qds, q64, u64);
+                    else
+                        pd_tile_steps<CTRL, true, INTEG, RW>(sg + o0, sg + kStageStride + o0, sg + 2 * kStageStride + o0, D, rt * 16,
+                                                             nst, pgd, dgd, lod, hid, dtp, qs, qds, q64, u64);
                 };
                 using std::integral_constant;
                 const bool dint = a.rc.plant_type == MPK_PLANT_DOUBLE_INTEGRATOR;

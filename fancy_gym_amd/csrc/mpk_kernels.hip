@@ -4226,7 +4226,7 @@ int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
         pa.G = (B + NTW - 1) / NTW;
         pa.inv_seg4 = 65536u / (unsigned)(4 * D) + 1u;
         const int quad_mode = tune.pd_quad < 0 ? 1 : tune.pd_quad;
-        const bool quad = quad_mode == 2 || (quad_mode == 1 && pa.G >= 4 * 256 * 8);
+        const bool quad = quad_mode == 2 || (quad_mode == 1 && pa.G >= 4 * 256 * 4);   // measured (profiles/r03_rollout.md): 19.3 vs 23.9 us at 4096 groups, 15.6 vs 14.6 at 2048
         const int units = quad ? (pa.G + 3) / 4 : pa.G;
         int blocks = (units + 3) / 4;
         if (blocks > 2048) blocks = 2048;
@@ -4275,7 +4275,7 @@ int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const f
         pa.inv_seg4 = 65536u / (unsigned)(4 * D) + 1u;
         // four groups per wave once that still leaves every CU several waves ("pd_quad": 0 off, 2 force)
         const int quad_mode = tune.pd_quad < 0 ? 1 : tune.pd_quad;
-        const bool quad = quad_mode == 2 || (quad_mode == 1 && pa.G >= 4 * 256 * 8);
+        const bool quad = quad_mode == 2 || (quad_mode == 1 && pa.G >= 4 * 256 * 4);   // measured (profiles/r03_rollout.md): 19.3 vs 23.9 us at 4096 groups, 15.6 vs 14.6 at 2048
         const int units = quad ? (pa.G + 3) / 4 : pa.G;
         int blocks = (units + 3) / 4;
         if (blocks > 2048) blocks = 2048;

@@ -36,9 +36,15 @@ def graph_time(fn, reps=20, rounds=7):
                 fn()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    for _ in range(5):
-        g.replay()
-    torch.cuda.synchronize()
+    # replay untimed until the GPU has been busy for ~40 ms: the shader clock needs ~20 ms of load to settle
+    # (profiles/r02_clock_probe.md); five replays of a 0.3 ms graph -- round 2's warm-up -- measured the first variant of every
+    # (batch, step) pair 5 - 10 % slow ("auto" 20.6 vs forced `k_traj_duo` 18.5 us at B = 8192: the same kernel)
+    import time
+    t_busy = time.perf_counter()
+    while time.perf_counter() - t_busy < 0.04:
+        for _ in range(5):
+            g.replay()
+        torch.cuda.synchronize()
     ts = []
     for _ in range(rounds):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -53,7 +59,7 @@ def main():
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     g = torch.Generator().manual_seed(0)
-    variants = [("auto", {}), ("pipe=1", {"pipe": 1}), ("pipe=0", {"pipe": 0}), ("split", {"split": 1}), ("duo", {"quad": 3}), ("mono", {"quad": 4})]
+    variants = [("auto", {}), ("pipe=1", {"pipe": 1}), ("pipe=0", {"pipe": 0}), ("split", {"split": 1}), ("duo", {"quad": 3}), ("mono", {"quad": 4}), ("auto (again)", {})]
     print(f"lib: {_lib.LIB_PATH}")
     print("| step | batch | variant | kernel | us | episodes-or-plans/s | GB/s (alg.) | of 8 TB/s |")
     print("|---|---|---|---|---|---|---|---|")

@@ -11,9 +11,17 @@ timeout 2400 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|FAIL
 python -c "import __graft_entry__ as e; e.smoke(); print('smoke ok')" 2>&1 | grep -v amdgpu | tail -2 > $O/smoke.log
 python bench.py --steps 20 --warmup 5 > $O/bench_k20.json 2> $O/bench_k20.err
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
-(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_bench -o bench -- python3 $R/bench.py --no-cpu --no-streaming > $R/$O/bench_under_rocprof.json 2> $R/$O/bench_under_rocprof.err)
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_bench -o bench -- python3 $R/bench.py --no-cpu --no-streaming --no-overlap > $R/$O/bench_under_rocprof.json 2> $R/$O/bench_under_rocprof.err)
 python tools/trace_timed_region.py $O/prof_bench/bench_kernel_trace.csv > $O/timed_region.txt 2>&1
 gzip -9 -f $O/prof_bench/bench_kernel_trace.csv
+bash tools/pmc_traffic.sh 4096 262144 > $O/pmc_traffic.txt 2>&1
+python tools/pmc_traffic_json.py gpurun_out/pmct_FETCH_SIZE gpurun_out/pmct_WRITE_SIZE > $O/pmc_traffic.json 2> $O/pmc_traffic.err
+python tools/sweep.py > $O/sweep.md 2> $O/sweep.err
+python tools/closed_bench.py 2048 4096 8192 16384 65536 2>&1 | grep -v amdgpu > $O/closed.md
+python tools/rollout_bench.py 4096 8192 65536 2>&1 | grep -v amdgpu > $O/rollout.md
+python tools/phase_bench.py > $O/phase.md 2>&1
+python tools/wide_bench.py > $O/wide.md 2>&1
+for B in 2048 4096 8192 65536; do python tools/bench_replan.py $B 50 --graph; python tools/bench_replan.py $B 50; done 2>&1 | grep -v amdgpu > $O/replan.log
 MPK_BENCH_FORCE_DIST=1 python bench.py --steps 20 --warmup 5 --no-cpu --no-streaming > $O/bench_k20_rccl1.json 2> $O/bench_k20_rccl1.err
 MPK_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 50 --warmup 5 --no-cpu > $O/bench_g2.json 2> $O/bench_g2.err
 cat $O/pytest.log $O/smoke.log; tail -c 700 $O/bench_k20.json; echo; cat $O/timed_region.txt; tail -c 900 $O/bench_k20_rccl1.json

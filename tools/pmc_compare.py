@@ -14,7 +14,7 @@ def short(name):
     for key, lab in (("k_traj_stream<2, 0", "stream +actions"), ("k_traj_stream<2, -1", "stream traj only"),
                      ("FillFunctor", "torch fill"), ("k_traj_tiles", "tiles"), ("k_traj_wide<0, 13>", "wide promp K=1001 T=200"),
                      ("k_traj_wide<0, 7>", "wide promp K=64 T=100"), ("k_traj_wide<2, 7>", "wide prodmp K=128 T=100"),
-                     ("k_traj_wide<1, 13>", "wide dmp K=256 T=200"), ("k_traj_", None)):
+                     ("k_traj_wide<1, 13>", "wide dmp K=256 T=200"), ("k_pd_rollout_tiles<1", "pd_rollout_tiles<1>"), ("k_pd_rollout_tiles<4", "pd_rollout_tiles<4>"), ("k_traj_", None)):
         if key in name:
             return lab or name.split("(")[0].replace("void mpk::", "")[:40]
     return None

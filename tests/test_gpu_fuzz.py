@@ -161,3 +161,52 @@ def test_random_configuration_matches_oracle(seed, monkeypatch, mpk_option):
     assert torch.equal(r["done"], dnb) and torch.equal(r["pos"], pos) and torch.equal(r["vel"], vel)
     assert torch.equal(r["actions"], ab) and torch.equal(qa, qb) and torch.equal(qda, qdb)
     assert torch.equal(r["cond_pos"], cp) and torch.equal(r["cond_vel"], cv)
+
+
+# ---- round 3: the two new kernel families (k_traj_wide: more than 16 contraction columns; k_traj_flat: whole-trajectory
+# images) under the same random configurations, from generators of their own so that the cases above keep their shapes ----
+N_CASES_R3 = int(os.environ.get("MPK_FUZZ_CASES_R3", "80"))
+
+
+@pytest.mark.parametrize("seed", range(N_CASES_R3))
+def test_random_wide_or_flat_configuration_matches_oracle(seed, mpk_option):
+    rng = np.random.default_rng(50_000 + seed)
+    pc, bc, tc, dt, dur, B, init_time = random_case(rng)
+    r3 = np.random.default_rng(99_000 + seed)
+    # shared phase only (both kernels are shared-phase kernels): freeze tau / delay
+    pc = dataclasses.replace(pc, learn_tau=False, learn_delay=False)
+    wide = bool(r3.random() < 0.5)
+    if wide:
+        bc = dataclasses.replace(bc, num_basis=int(r3.integers(17, 72)), num_basis_outside=0)
+    flat = int(r3.choice([0, 1]))
+    mpk_option("flat", flat)
+    if tc.trajectory_generator_type == "prodmp":
+        if (dur + init_time) / pc.tau > 5.9:
+            init_time = 0.0
+        if dur / pc.tau > 5.9:
+            pytest.skip("beyond the ProDMP pre-computation range")
+    eng = make_engine(pc, bc, tc, dt, dur)
+    params, ip, iv = inputs(pc, bc, tc, B, seed=seed)
+    pos, vel = eng.trajectory(params, ip, iv, init_time)
+    torch.cuda.synchronize()
+    kern = eng.last_kernel()
+    if wide:
+        assert kern.startswith("k_traj_wide"), kern
+    rp, rv = O.get_trajectory(pc, bc, tc, params, dur, dt, init_time, ip, iv, dtype=np.float64)
+    p32, v32 = O.get_trajectory(pc, bc, tc, params, dur, dt, init_time, ip, iv, dtype=np.float32)
+    if not (np.isfinite(rp).all() and np.isfinite(p32).all()):
+        # dozens of Gaussians on an exponential phase: past tau every one of them underflows and the normalisation is 0 / 0
+        # -- in the reference's formula as in the oracle; nothing to compare
+        pytest.skip("degenerate basis: every Gaussian underflows somewhere on the horizon (NaN in the reference's formula)")
+
+    def slack(r32, r64):
+        e = float(np.abs(r32.astype(np.float64) - r64).max()) if r64.size else 0.0
+        return e if e > 2e-6 * float(np.abs(r64).max()) else 0.0
+    close(pos.cpu().numpy(), rp, f"pos [{kern}]", atol=slack(p32, rp))
+    fd = tc.trajectory_generator_type == "promp"
+    close(vel.cpu().numpy(), rv, f"vel [{kern}]", atol=(fd_atol(rp, dt) if fd else 0.0) + slack(v32, rv))
+    if not wide:
+        # the same launch through the other episode-major / tile-major kernels: identical bits
+        mpk_option("flat", 1 - flat)
+        p2, v2 = eng.trajectory(params, ip, iv, init_time)
+        assert torch.equal(pos, p2) and torch.equal(vel, v2), (kern, eng.last_kernel())

@@ -130,3 +130,67 @@ def test_bench_gpus_n_spawns_a_torch_distributed_run_child(monkeypatch):
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_bench_rccl_report_condenses_the_init_and_tuning_lines(tmp_path):
+    """bench.py's self-documentation of the first multi-GPU run: RCCL's own INIT / TUNING log lines (formats of librccl
+    2.2x) -> version, channels, transports, and per collective the algorithm / protocol / channel range / bytes / calls"""
+    sys.path.insert(0, ROOT)
+    import bench
+    log = tmp_path / "rccl.log"
+    log.write_text(
+        "h:1:1 [0] NCCL INFO RCCL version : 2.26.6-HEAD:64f48b6\n"
+        "h:1:1 [0] NCCL INFO comm:0x1, nRanks:8, nNodes:1, coll channels:28 collnet channels:0, nvls channels:0, p2p channels:32, p2p channels per peer:4\n"
+        "h:1:1 [0] NCCL INFO Channel 00/0 : 0[c000] -> 1[d000] via P2P/IPC comm 0x1 nRanks 08\n"
+        "h:1:1 [0] NCCL INFO Channel 01/0 : 0[c000] -> 7[f000] via P2P/IPC comm 0x1 nRanks 08\n"
+        + "h:1:1 [0] NCCL INFO AllGather: 22937600 Bytes -> Algo RING proto SIMPLE channel{Lo..Hi}={0..27}\n" * 3
+        + "h:1:1 [0] NCCL INFO AllReduce: 8 Bytes -> Algo TREE proto LL channel{Lo..Hi}={0..0}\n")
+    rep = bench.rccl_report(str(log))
+    assert rep["version"].startswith("2.26.6") and rep["coll_channels"] == 28 and rep["p2p_channels"] == 32
+    assert rep["transports"] == ["P2P/IPC"]
+    ag = rep["collectives"][0]
+    assert ag == {"collective": "AllGather", "bytes": 22937600, "algo": "RING", "proto": "SIMPLE", "channels": 28, "calls": 3}
+    assert rep["collectives"][1]["collective"] == "AllReduce" and rep["collectives"][1]["channels"] == 1
+    assert bench.rccl_report(str(tmp_path / "missing.log")) is None and bench.rccl_report(None) is None
+
+
+def test_bench_reads_the_gpu_state_without_a_child_process(monkeypatch):
+    """the clocks / power / temperatures beside the streaming row come from sysfs files read in-process: no subprocess is
+    ever spawned (rocm-smi is a `#!/usr/bin/env python3` script: an exec hop this pool forbids under rocprofv3), and a
+    machine without the files gets an empty dict, never an error"""
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+
+    def boom(*a, **k):
+        raise AssertionError("bench.gpu_state_sysfs must not spawn a process")
+    monkeypatch.setattr(subprocess, "run", boom)
+    monkeypatch.setattr(subprocess, "Popen", boom)
+    monkeypatch.setattr(subprocess, "call", boom)
+    st = bench.gpu_state_sysfs(0)
+    assert isinstance(st, dict)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "rocm-smi\"" not in src and "'rocm-smi'" not in src
+
+
+def test_trajectory_shard_single_process_views_and_episode_lookup():
+    """TrajectoryShard / GatheredTrajectories without a process group (world = 1): the gather is the identity, views alias"""
+    from fancy_gym_amd.distributed import GatheredTrajectories, TrajectoryShard, gather_trajectories, shard_bounds
+    sh = TrajectoryShard(5, 4, 3, "cpu")
+    assert sh.rows == 5 and sh.cap == 5 and sh.buf.shape == (2, 5, 4, 3)
+    sh.pos.copy_(torch.arange(60, dtype=torch.float32).reshape(5, 4, 3)); sh.vel.copy_(-sh.pos)
+    g = sh.gather()
+    assert g.pos.shape == (1, 5, 4, 3) and torch.equal(g.pos[0], sh.pos) and torch.equal(g.vel[0], sh.vel)
+    p, v = g.flat()
+    assert torch.equal(p, sh.pos) and torch.equal(v, sh.vel)
+    g2 = gather_trajectories(sh.pos, sh.vel, 5)                       # halves of one shard: zero copy in
+    assert torch.equal(g2.buf, g.buf)
+    # episode lookup over a ragged 3-rank layout
+    buf = torch.zeros((3, 2, 3, 1, 1))
+    gg = GatheredTrajectories(buf, 7)
+    for i in range(7):
+        r = next(k for k in range(3) if shard_bounds(7, k, 3)[0] <= i < shard_bounds(7, k, 3)[1])
+        buf[r, 0, i - shard_bounds(7, r, 3)[0], 0, 0] = float(i + 1)
+    assert [float(gg.episode(i)[0][0, 0]) for i in range(7)] == [1, 2, 3, 4, 5, 6, 7]
+    with pytest.raises(ValueError):
+        sh.gather(out=torch.zeros((2, 2, 5, 4, 3)))

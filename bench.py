@@ -508,7 +508,7 @@ def main():
     # step i's last store, so its dispatch ramp and input loads (time-to-first-store, ~1.8 us of the 8.2: profiles/
     # r02_headline_trace.md) run under step i's drain.  Reported BESIDE the serial number: `value` stays the serial one.
     two_stream = None
-    if graph is not None and not args.no_overlap:
+    if graph is not None and not args.no_overlap and world == 1:    # a one-GPU diagnostic: N > 1 lines carry no extra collectives for it
         try:
             outs_b_t = [torch.empty((B, T_STEPS, D), dtype=torch.float32, device=dev) for _ in range(3)]   # kept alive
             outs_b = [t_.data_ptr() for t_ in outs_b_t]

@@ -69,6 +69,25 @@ __device__ long long g_trace[256];
         }                                                                           \
     } while (0)
 
+// Kernels that may take more than the default 64 KB of dynamic LDS: the function attribute is raised ONCE per kernel
+// instantiation to the CU's whole LDS (160 KB), not per launch with the launch's size -- hipFuncSetAttribute rewrites state of a
+// function whose earlier launches may still be in flight (round 3: one silent runtime abort per ~30 000 launches of mixed
+// configurations in the fuzz soak went away with this).
+#ifndef MPK_DEVICE_ONLY
+template <class K>
+static hipError_t allow_full_lds(K kern) {
+    // per kernel instantiation AND device (the attribute belongs to the current device's copy of the function)
+    static signed char done[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             160 * 1024);
+    if (e == hipSuccess && dev >= 0 && dev < 64) done[dev] = 1;
+    return e;
+}
+#endif
+
 #if MPK_MAIN
 size_t shared_tables_floats(const DevCfg& c, int* TS, int* n_out) {
     const int TP = (c.T + 15) / 16 * 16;
@@ -627,7 +646,12 @@ __device__ __forceinline__ int x_kind(const DevCfg& c, int k, int* loc) {
     const int nb = c.nb;
     if (MP == MPK_MP_PRODMP) {
         const bool isw = k < nb, isg = k == nb;
-        *loc = isw ? k : (isg && !c.disable_weights ? nb : 0);
+        // the offset is used for an UNCONDITIONAL load (the kind decides afterwards whether the value counts), so it must
+        // stay inside the DoF's local block whatever is disabled: with disable_goal the block has nb entries (no goal at
+        // [nb]), with disable_weights one (the goal at [0]).  Round 3's fuzz soak found the old `isw ? k : ...`: the last
+        // DoF of the last episode read one float (disable_goal) or up to nb - 1 floats (disable_weights) past the end of
+        // `params` -- a memory fault once every ~10^4 random configurations, when the buffer ends on a page boundary.
+        *loc = (isw && !c.disable_weights) ? k : ((isg && !c.disable_goal && !c.disable_weights) ? nb : 0);
         const int kw = c.disable_weights ? XK_ZERO : XK_PARAM, kg = c.disable_goal ? XK_ZERO : XK_PARAM;
         const int klast = (k == nb + 3 && c.goal_off_on) ? XK_ONE : XK_ZERO;
         return isw ? kw : (isg ? kg : (k == nb + 1 ? XK_IPOS : (k == nb + 2 ? XK_IVEL : klast)));
@@ -2197,8 +2221,7 @@ static int launch_traj_t(const TrajArgs& ta, const ActArgs& aa, bool stream_mode
     if (ta.flat_img > 0) {
         if constexpr (MP != MPK_MP_DMP && CT < 3) {
             auto go = [&](auto kern) {
-                if (lds > 48 * 1024)
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (lds > 48 * 1024) (void)allow_full_lds(kern);
                 hipLaunchKernelGGL(kern, g, b, lds, s, ta, aa);
             };
             switch (km) {
@@ -2258,8 +2281,7 @@ static int launch_traj_t(const TrajArgs& ta, const ActArgs& aa, bool stream_mode
         if (bulk) {
             // more than 48 KB of dynamic LDS only happens with the "lds_pad" occupancy knob (one workgroup per CU)
             auto big = [&](auto kern) {
-                if (lds > 48 * 1024)
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (lds > 48 * 1024) (void)allow_full_lds(kern);
             };
             switch (km) {
                 case 1: big(k_traj_stream<MP, CT, 1, true>); hipLaunchKernelGGL((k_traj_stream<MP, CT, 1, true>), g, b, lds, s, ta, aa); break;
@@ -2842,8 +2864,7 @@ int launch_traj_wide(const DevCfg& c, const SharedTables& st, const float* param
     const int blocks = wa.n_units < num_cu * per_cu ? wa.n_units : num_cu * per_cu;
     auto go = [&](auto kern) -> int {
         if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = allow_full_lds(kern);
             if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return MPK_EHIP; }
         }
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, (hipStream_t)stream, wa);
@@ -3688,8 +3709,7 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
     if (blocks > (long)num_cu * per_cu) blocks = (long)num_cu * per_cu;
     auto go = [&](auto kern) -> int {
         if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = allow_full_lds(kern);
             if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return MPK_EHIP; }
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * wpb), lds, (hipStream_t)stream, pa);
@@ -3817,8 +3837,7 @@ int launch_traj_rows(const DevCfg& c, const float* params, const float* init_pos
     int blocks = B < num_cu * 8 ? B : num_cu * 8;
     auto go = [&](auto kern) -> int {
         if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = allow_full_lds(kern);
             if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return MPK_EHIP; }
         }
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, (hipStream_t)stream, ra);
@@ -4234,8 +4253,7 @@ int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
         const size_t lds = (size_t)4 * (quad ? 4 : 1) * 5 * kStageStride * sizeof(float);
         auto go = [&](auto kern) -> int {
             if (lds > 64 * 1024) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipError_t e = allow_full_lds(kern);
                 if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return MPK_EHIP; }
             }
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, (hipStream_t)stream, pa);

@@ -718,3 +718,54 @@ def test_show_scaled_basis_matches_the_oracle_basis(mp_type):
         assert basis.shape == (1000, bc.num_basis)
     close(basis, ref, "scaled basis")
     assert np.all(basis[times < 0] == basis[0]) or mp_type != "prodmp"      # before the delay: table index 0
+
+
+_TAIL_SCRIPT = r"""
+import sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch
+from oracle import mp_oracle as O
+from tests.test_gpu_trajectory import inputs, make_engine
+from fancy_gym_amd import _lib
+torch.cuda.set_device(0)
+for flags in (dict(disable_goal=True), dict(disable_weights=True)):
+    for D, nb, T, B in ((4, 6, 54, 16), (16, 2, 27, 100), (8, 6, 66, 16), (7, 5, 100, 64)):
+        pc = O.PhaseCfg("exp", tau=T * 0.02 * 0.8, alpha_phase=3.0)
+        bc = O.BasisCfg("prodmp", num_basis=nb, alpha=10)
+        tc = O.TrajCfg("prodmp", action_dim=D, **flags)
+        eng = make_engine(pc, bc, tc, 0.02, T * 0.02)
+        params, ip, iv = inputs(pc, bc, tc, B, seed=D)
+        # a 32 MB allocation of its own (beyond the caching allocator's pooled sizes); the parameters are its LAST bytes, so
+        # one float past them is the first byte of whatever follows -- usually nothing
+        slab = torch.empty(32 << 20, dtype=torch.uint8, device="cuda")
+        n = params.size * 4
+        pdev = slab[slab.numel() - n:].view(torch.float32).view(params.shape)
+        pdev.copy_(torch.from_numpy(params))
+        for opts in ({{}}, {{"mapping": 2}}, {{"mapping": 2, "bulk": 2}}, {{"flat": 1}}, {{"mapping": 1, "ipw": 1}}):
+            _lib.reset_options()
+            for k, v in opts.items():
+                _lib.set_option(k, v)
+            pos, vel = eng.trajectory(pdev, ip, iv, 0.0)
+            torch.cuda.synchronize()
+            rp, _ = O.get_trajectory(pc, bc, tc, params, T * 0.02, 0.02, 0.0, ip, iv, dtype=np.float64)
+            assert np.abs(pos.cpu().numpy() - rp).max() <= 2e-5 * np.abs(rp).max(), (flags, D, opts)
+        del slab, pdev
+print("tail ok")
+"""
+
+
+def test_disabled_goal_or_weights_never_read_past_the_parameter_buffer():
+    """
+    Round 3's fuzz soak (2 x 10^5 random configurations in one process) died with a GPU memory fault once per ~10^4 cases:
+    with disable_goal / disable_weights the B-fragment gather loaded -- unconditionally, the value was never used -- the
+    slot where the disabled block's parameters would have been, i.e. up to nb - 1 floats past the last DoF of the last
+    episode, past the end of `params`; a fault when the buffer ends on the last mapped page.  The parameters here ARE the
+    last bytes of a 32 MB allocation of their own; run in a child process (a fault ends the process, not the suite).
+    """
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _TAIL_SCRIPT.format(root=root)], capture_output=True, text=True, timeout=600,
+                       cwd=root)
+    assert r.returncode == 0 and "tail ok" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])

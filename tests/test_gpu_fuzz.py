@@ -166,9 +166,10 @@ def test_random_configuration_matches_oracle(seed, monkeypatch, mpk_option):
 # ---- round 3: the two new kernel families (k_traj_wide: more than 16 contraction columns; k_traj_flat: whole-trajectory
 # images) under the same random configurations, from generators of their own so that the cases above keep their shapes ----
 N_CASES_R3 = int(os.environ.get("MPK_FUZZ_CASES_R3", "80"))
+START_R3 = int(os.environ.get("MPK_FUZZ_START_R3", "0"))      # soaks in slices: seeds [START, START + CASES)
 
 
-@pytest.mark.parametrize("seed", range(N_CASES_R3))
+@pytest.mark.parametrize("seed", range(START_R3, START_R3 + N_CASES_R3))
 def test_random_wide_or_flat_configuration_matches_oracle(seed, mpk_option):
     rng = np.random.default_rng(50_000 + seed)
     pc, bc, tc, dt, dur, B, init_time = random_case(rng)
@@ -176,6 +177,9 @@ def test_random_wide_or_flat_configuration_matches_oracle(seed, mpk_option):
     # shared phase only (both kernels are shared-phase kernels): freeze tau / delay
     pc = dataclasses.replace(pc, learn_tau=False, learn_delay=False)
     wide = bool(r3.random() < 0.5)
+    only = os.environ.get("MPK_FUZZ_R3_ONLY", "")              # soak slices: "wide" / "flat" / "" (both)
+    if (only == "wide" and not wide) or (only == "flat" and wide):
+        pytest.skip("slice")
     if wide:
         bc = dataclasses.replace(bc, num_basis=int(r3.integers(17, 72)), num_basis_outside=0)
     flat = int(r3.choice([0, 1]))

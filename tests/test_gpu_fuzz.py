@@ -214,3 +214,84 @@ def test_random_wide_or_flat_configuration_matches_oracle(seed, mpk_option):
         mpk_option("flat", 1 - flat)
         p2, v2 = eng.trajectory(params, ip, iv, init_time)
         assert torch.equal(pos, p2) and torch.equal(vel, v2), (kern, eng.last_kernel())
+
+
+# ---- round 3, part two: the entry points the two tests above do not reach -- fused open-loop actions (every controller),
+# the reacher rollout + reward, validity + penalty, per-episode init_time vectors ------------------------------------------
+N_CASES_R3B = int(os.environ.get("MPK_FUZZ_CASES_R3B", "60"))
+START_R3B = int(os.environ.get("MPK_FUZZ_START_R3B", "0"))
+
+
+@pytest.mark.parametrize("seed", range(START_R3B, START_R3B + N_CASES_R3B))
+def test_random_actions_reacher_validity_and_per_episode_init_time(seed, mpk_option):
+    rng = np.random.default_rng(150_000 + seed)
+    pc, bc, tc, dt, dur, B, init_time = random_case(rng)
+    if tc.trajectory_generator_type == "prodmp":
+        tau_min = pc.tau_bound[0] if pc.learn_tau else pc.tau
+        if (dur + init_time) / tau_min > 5.9:
+            init_time = 0.0
+        if dur / tau_min > 5.9:
+            pytest.skip("beyond the ProDMP pre-computation range")
+    mpk_option("mapping", int(rng.choice([-1, 1, 2])))
+    mpk_option("flat", int(rng.choice([-1, 0, 1])))
+    mpk_option("pd_quad", int(rng.choice([-1, 0, 2])))
+    mpk_option("pd_simple", int(rng.choice([-1, 0, 1])))
+    eng = make_engine(pc, bc, tc, dt, dur)
+    D = tc.action_dim
+    params, ip, iv = inputs(pc, bc, tc, B, seed=seed)
+    if pc.learn_tau:
+        params[:, 0] = rng.uniform(pc.tau_bound[0], pc.tau_bound[1], B)
+    if pc.learn_delay:
+        params[:, int(pc.learn_tau)] = rng.uniform(pc.delay_bound[0], pc.delay_bound[1], B)
+    pos, vel = eng.trajectory(params, ip, iv, init_time)
+    T = pos.shape[1]
+    p_np, v_np = pos.cpu().numpy(), vel.cpu().numpy()
+    rp, rv = O.get_trajectory(pc, bc, tc, params, dur, dt, init_time, ip, iv, dtype=np.float64)
+    if not np.isfinite(rp).all():
+        pytest.skip("degenerate basis")
+    # (1) trajectory + open-loop actions in one launch (frozen state), every controller: same trajectory bits, actions bit-exact
+    ctrl = str(rng.choice(["motor", "position", "velocity"]))
+    pg, dg = rng.uniform(0.2, 2.0, D), rng.uniform(0.02, 0.3, D)
+    cp, cv = rng.uniform(-1, 1, (B, D)), rng.uniform(-0.3, 0.3, (B, D))
+    lo, hi = -float(rng.uniform(0.3, 1.5)), float(rng.uniform(0.3, 1.5))
+    shared = not (pc.learn_tau or pc.learn_delay)
+    if shared and tc.trajectory_generator_type != "dmp":
+        spec = RolloutSpec(ctrl, D, pg, dg, lo, hi, plant="static")
+        p2, v2, a2 = eng.trajectory_actions(params, ip, iv, spec, cp, cv, init_time=init_time)
+        assert torch.equal(p2, pos) and torch.equal(v2, vel), eng.last_kernel()
+        ra, _, _ = O.rollout(p_np, v_np, ctrl, pg, dg, lo, hi, "static", dt, cp, cv)
+        assert np.array_equal(a2.cpu().numpy(), ra.astype(np.float32)), eng.last_kernel()
+    # (2) reacher rollout + reward on the same desired trajectory
+    goal = rng.uniform(-D, D, (B, 2))
+    n_steps = rng.integers(0, T + 1, B).astype(np.int32)
+    step0 = rng.integers(0, 260, B).astype(np.int32)
+    q0, qd0 = rng.uniform(-1, 1, (B, D)), rng.uniform(-0.5, 0.5, (B, D))
+    spec_r = RolloutSpec(ctrl, D, pg, dg, lo, hi, plant="double_integrator", dt=dt)
+    q, qd = torch.tensor(q0, device="cuda"), torch.tensor(qd0, device="cuda")
+    act, rew = eng.reacher_rollout(spec_r, pos, vel, q, qd, torch.tensor(goal), n_steps=torch.tensor(n_steps),
+                                   step0=torch.tensor(step0))
+    ra, rr, rq, rqd = O.reacher_rollout(p_np, v_np, ctrl, pg, dg, lo, hi, dt, q0, qd0, goal, n_steps=n_steps, step0=step0)
+    assert np.array_equal(act.cpu().numpy(), ra.astype(np.float32))
+    assert np.array_equal(q.cpu().numpy(), rq) and np.array_equal(qd.cpu().numpy(), rqd)
+    got = rew.cpu().numpy()
+    assert np.all(np.abs(got - rr) <= 1e-11 * (1.0 + np.abs(rr))), np.abs(got - rr).max()
+    # (3) validity + the penalty of an invalid plan
+    lim = np.sort(rng.uniform(-2.0, 2.0, (2, D)), axis=0)
+    p64 = p_np.astype(np.float64)
+    want = np.all((p64 >= lim[0]) & (p64 <= lim[1]), axis=(1, 2))
+    got_v, pen = eng.traj_validity(pos, lim[0], lim[1], with_penalty=True)
+    assert np.array_equal(got_v.cpu().numpy(), want)
+    assert np.allclose(pen.cpu().numpy(), O.traj_invalid_penalty(params, p64, lim[0], lim[1]), rtol=1e-12, atol=1e-15)
+    # (4) per-episode init_time vector (all equal): the per-episode-phase kernels against the same oracle trajectory
+    if T >= 2:
+        itv = torch.full((B,), float(init_time), dtype=torch.float32, device="cuda")
+        p3, v3 = eng.trajectory(params, ip, iv, itv)
+        p32, v32 = O.get_trajectory(pc, bc, tc, params, dur, dt, init_time, ip, iv, dtype=np.float32)
+
+        def slack(r32, r64):
+            e = float(np.abs(r32.astype(np.float64) - r64).max()) if r64.size else 0.0
+            return e if e > 2e-6 * float(np.abs(r64).max()) else 0.0
+        kern = eng.last_kernel()
+        close(p3.cpu().numpy(), rp, f"pos [{kern}]", atol=slack(p32, rp))
+        fd = tc.trajectory_generator_type == "promp"
+        close(v3.cpu().numpy(), rv, f"vel [{kern}]", atol=(fd_atol(rp, dt) if fd else 0.0) + slack(v32, rv))

@@ -402,9 +402,14 @@ static bool mfma_capable(const Handle* h) {
     return h->dev.D >= 1 && h->dev.D <= kMaxD && h->dev.KP <= kMaxKP;
 }
 
-// more than kMaxKP contraction columns with a shared phase: the k-chunked matrix-core kernel (k_traj_wide, trajectory only)
+// more than kMaxKP contraction columns OR more than kMaxD DoF with a shared phase: the k-chunked matrix-core kernel
+// (k_traj_wide, trajectory only; an episode with D > 16 spans ceil(D / 16) column groups)
+// dmp with few columns and D > 16 stays on the per-episode kernels: its serial Euler recurrence, not the contraction, is
+// the cost there, and those kernels keep more recurrences in flight (measured, profiles/r03_wide_bench.md)
 static bool wide_capable(const Handle* h) {
-    return h->dev.D >= 1 && h->dev.D <= kMaxD && h->dev.KP > kMaxKP;
+    if (h->dev.D < 1) return false;
+    if (h->dev.KP > kMaxKP) return true;
+    return h->dev.D > kMaxD && h->cfg.mp_type != MPK_MP_DMP;
 }
 
 // Allocate every cache slot's table for the current (T, KP) up front: a cache miss later only launches the builder
@@ -414,7 +419,7 @@ static int prealloc_cache(Handle* h) {
     int TS = 0, n_out = 0;
     const size_t nf = shared_tables_floats(h->dev, &TS, &n_out);
     // a wide table (hundreds of basis functions: ~10 MB per slot at K = 1000, T = 200) gets 8 slots instead of 64
-    const int n_slots = wide_capable(h) ? 8 : Handle::kCache;
+    const int n_slots = h->dev.KP > kMaxKP ? 8 : Handle::kCache;
     int slot = 0;
     for (auto& e : h->cache) {
         const bool keep = slot++ < n_slots;

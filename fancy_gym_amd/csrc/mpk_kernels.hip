@@ -2614,6 +2614,7 @@ struct WideArgs {
     float* pos;
     float* vel;
     int B, epg, n_units, KC, n_rt, SA;   // episodes per column group, 4-group units, k chunk, row tiles, LDS row stride
+    int cgpe;                            // column groups per episode: 1 (D <= 16), else ceil(D / 16) with epg == 1
 };
 
 // raw operand of the contraction for column (episode b, DoF dd), index k  (the sX fill of k_traj_rows)
@@ -2659,15 +2660,17 @@ __global__ void __launch_bounds__(256, ((MP == MPK_MP_PRODMP ? 2 : 1) * MT <= 16
     // epilogue images alias the staging area (used after the k loop, behind a barrier): per wave [NIMG][MT*16][CS]
     constexpr int NIMG = MP == MPK_MP_PROMP ? 1 : 2;
     float* sC = smem + (size_t)wave * NIMG * MT * 16 * CS;
-    const int ncol = a.epg * D;                         // used columns of a group
     const int kshift = 31 - __builtin_clz(KC);          // KC is a power of two
     const int nj = KC >> 2;                             // MFMA steps per chunk
 
     for (int unit = blockIdx.x; unit < a.n_units; unit += gridDim.x) {
         const int grp = unit * 4 + wave;
-        const int b0 = grp * a.epg;
+        // D <= 16: the group holds epg whole episodes; D > 16: 16 consecutive DoF (from d0) of ONE episode
+        const int b0 = a.cgpe == 1 ? grp * a.epg : grp / a.cgpe;
+        const int d0 = a.cgpe == 1 ? 0 : (grp - b0 * a.cgpe) * 16;
+        const int ncol = a.cgpe == 1 ? a.epg * D : min(16, D - d0);     // used columns of the group
         // this lane's column: episode, DoF, the sources of its operand column
-        const int ce = (int)(((unsigned)m * (65536u / (unsigned)D + 1u)) >> 16), cd = m - ce * D;
+        const int ce = (int)(((unsigned)m * (65536u / (unsigned)D + 1u)) >> 16), cd = d0 + m - ce * D;
         const int cb = b0 + ce;
         const bool cvalid = m < ncol && cb < a.B;
         const float* cprm = a.params + (size_t)(cvalid ? cb : 0) * c.P;
@@ -2779,7 +2782,7 @@ __global__ void __launch_bounds__(256, ((MP == MPK_MP_PRODMP ? 2 : 1) * MT <= 16
             if (MP == MPK_MP_DMP) {
                 // explicit Euler, one lane per used column (the operation order of every dmp kernel in this file)
                 if (lane < ncol && b0 + lane / D < a.B) {
-                    const int e = lane / D, dd = lane - e * D;
+                    const int e = lane / D, dd = d0 + lane - e * D;
                     const int b = b0 + e;
                     const float* prm = a.params + (size_t)b * c.P;
                     float y = a.init_pos[(size_t)b * D + dd];
@@ -2804,14 +2807,16 @@ __global__ void __launch_bounds__(256, ((MP == MPK_MP_PRODMP ? 2 : 1) * MT <= 16
                 }
                 __builtin_amdgcn_wave_barrier();
             }
-            // copy-out: each episode's [t_n][D] block is contiguous in HBM
+            // copy-out: each episode's [t_n][D] block is contiguous in HBM (D > 16: the group's 16-DoF slice of every row)
+            const int cw_ = a.cgpe == 1 ? D : ncol;     // columns of one episode in this group
             for (int e = 0; e < a.epg; ++e) {
                 const int b = b0 + e;
                 if (b >= a.B) break;
-                const size_t ob = ((size_t)b * T + t_lo) * D;
-                const int nel = t_n * D;
+                const size_t ob = ((size_t)b * T + t_lo) * D + d0;
+                const int nel = t_n * cw_;
+                const float rcw = 1.0f / (float)cw_;    // i < 2^15: (i + 0.5) / cw_ truncates to i / cw_ exactly in fp32
                 for (int i = lane; i < nel; i += 64) {
-                    const int t = i / D, dd = i - t * D;
+                    const int t = (int)(((float)i + 0.5f) * rcw), dd = i - t * cw_;
                     const int col = e * D + dd;
                     const float p = img0[(size_t)t * CS + col];
                     float v;
@@ -2823,8 +2828,8 @@ __global__ void __launch_bounds__(256, ((MP == MPK_MP_PRODMP ? 2 : 1) * MT <= 16
                     } else {
                         v = img1[(size_t)t * CS + col];
                     }
-                    a.pos[ob + i] = p;
-                    a.vel[ob + i] = v;
+                    a.pos[ob + (size_t)t * D + dd] = p;
+                    a.vel[ob + (size_t)t * D + dd] = v;
                 }
             }
         }
@@ -2855,10 +2860,13 @@ int launch_traj_wide(const DevCfg& c, const SharedTables& st, const float* param
     int KC = 32;                                                           // <= 8 B fragments per lane and chunk
     auto stage_bytes = [&](int kc) { return ((size_t)nout * kc * SA) * sizeof(float); };
     while (KC > 8 && (stage_bytes(KC) > 80 * 1024 || nout * KC / 4 * spans > 8)) KC >>= 1;
+    while (KC > 4 && KC / 2 >= c.KP) KC >>= 1;                             // few columns (the D > 16 route): one short chunk
     const size_t epi_bytes = (size_t)4 * nimg * MT * 16 * 17 * sizeof(float);
     const size_t lds = stage_bytes(KC) > epi_bytes ? stage_bytes(KC) : epi_bytes;
-    WideArgs wa{c, st.A, st.aux, st.TS, params, init_pos, init_vel, pos, vel, B, 16 / c.D, 0, KC, n_rt, SA};
-    const int n_groups = (B + wa.epg - 1) / wa.epg;
+    const int cgpe = c.D <= 16 ? 1 : (c.D + 15) / 16;
+    WideArgs wa{c, st.A, st.aux, st.TS, params, init_pos, init_vel, pos, vel, B, c.D <= 16 ? 16 / c.D : 1, 0, KC, n_rt, SA, cgpe};
+    if (cgpe > 1 && (long long)B * cgpe > 0x7fffffffLL - 8) return MPK_ENOTIMPL;
+    const int n_groups = cgpe == 1 ? (B + wa.epg - 1) / wa.epg : B * cgpe;
     wa.n_units = (n_groups + 3) / 4;
     const int per_cu = nout * MT <= 16 ? 2 : 1;                           // see the kernel's launch bounds
     const int blocks = wa.n_units < num_cu * per_cu ? wa.n_units : num_cu * per_cu;

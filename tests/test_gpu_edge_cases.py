@@ -71,9 +71,33 @@ def test_every_horizon_class(mp, T, D, mpk_option):
 
 @pytest.mark.parametrize("mp", ["prodmp", "promp", "dmp"])
 def test_limits_fall_back_to_the_per_episode_kernel(mp):
-    check(cfg_for(mp, 17, 4, 20), 6, expect_kernel="k_traj_phase")         # D > 16: wave per episode
+    # D > 16, shared phase: column groups per episode (dmp with few columns: the per-episode kernels, its Euler loop rules)
+    check(cfg_for(mp, 17, 4, 20), 6, expect_kernel="k_traj_wide" if mp != "dmp" else "k_traj_phase")
     check(cfg_for(mp, 2, 20, 20), 6, expect_kernel="k_traj_wide")          # more than 16 basis columns, shared phase
-    check(cfg_for(mp, 40, 9, 24), 3, expect_kernel="k_traj_rows")          # D * KS > 256
+    check(cfg_for(mp, 40, 9, 24), 3, expect_kernel="k_traj_wide" if mp != "dmp" else "k_traj_rows")
+    # the same shapes with a per-episode phase: wave per episode, then workgroup per episode (D * KS > 256)
+    for D, nb, T, B, kern in ((17, 4, 20, 6, "k_traj_phase"), (40, 9, 24, 3, "k_traj_rows")):
+        pc, bc, tc, dt, dur = cfg_for(mp, D, nb, T)
+        eng = make_engine(pc, bc, tc, dt, dur)
+        params, ip, iv = inputs(pc, bc, tc, B, seed=D)
+        p0, v0 = eng.trajectory(params, ip, iv, 0.0)
+        assert eng.last_kernel().startswith("k_traj_wide" if mp != "dmp" else kern)
+        p1, v1 = eng.trajectory(params, ip, iv, torch.zeros(B, device="cuda"))
+        assert eng.last_kernel().startswith(kern), eng.last_kernel()
+        if mp != "prodmp" or kern == "k_traj_rows":           # k_traj_phase<prodmp>: c1 / c2 form, not the folded rows
+            assert torch.equal(p0, p1) and torch.equal(v0, v1)
+
+
+@pytest.mark.parametrize("mp", ["prodmp", "promp", "dmp"])
+@pytest.mark.parametrize("D,nb,T", [(17, 4, 20), (20, 9, 50), (31, 2, 33), (32, 13, 40), (33, 5, 100), (48, 20, 36),
+                                    (64, 3, 17), (100, 6, 24)])
+def test_more_than_16_dof_run_as_column_groups_on_the_matrix_cores(mp, D, nb, T):
+    """an episode with D > 16 spans ceil(D / 16) column groups of k_traj_wide (the last one ragged); few AND many basis
+    columns; ragged last 4-group unit"""
+    wide = mp != "dmp" or nb > 16           # dmp, few columns: per-episode kernels (see wide_capable in mpk_host.cpp)
+    for B in (1, 7):
+        check(cfg_for(mp, D, nb, T), B, init_time=0.25 if mp == "prodmp" else 0.0,
+              expect_kernel="k_traj_wide" if wide else "k_traj_", seed=D + B)
 
 
 @pytest.mark.parametrize("mp", ["prodmp", "promp", "dmp"])

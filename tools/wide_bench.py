@@ -59,6 +59,32 @@ def main():
             print(f"| {name} | {K} | {B} | `{eng.last_kernel()}` | {t * 1e6:.1f} | {B / t:.3e} | {flop / t / 1e12:.1f} | "
                   f"{flop / t / 1e12 / PEAK_TF * 100:.1f} % | {nbytes / t / 1e9:.0f} |")
             del params, ip, iv, out
+    # more than 16 DoF with a shared phase: column groups of k_traj_wide against the per-episode-phase kernels the same
+    # shapes took before (timed by passing the init_time as a per-episode vector)
+    print()
+    print("| config (D > 16, shared phase) | B | kernel | us | GB/s (alg.) | of 8 TB/s | per-episode-phase kernel | us |")
+    print("|---|---|---|---|---|---|---|---|")
+    cases = [("prodmp 32 DoF x 100 steps, num_basis 10", "prodmp", "exp", "prodmp", 32, 10, 0.02, 2.0, dict(tau=1.5, alpha_phase=3.0, basis_alpha=10.0)),
+             ("promp zero_rbf 24 DoF x 100 steps, num_basis 8", "promp", "linear", "zero_rbf", 24, 8, 0.02, 2.0, dict(tau=2.0, num_basis_zero_start=1, num_basis_zero_goal=0)),
+             ("dmp 20 DoF x 200 steps, num_basis 12", "dmp", "exp", "rbf", 20, 12, 0.02, 4.0, dict(tau=4.0, alpha_phase=2.0)),
+             ("prodmp 48 DoF x 100 steps, num_basis 40", "prodmp", "exp", "prodmp", 48, 40, 0.02, 2.0, dict(tau=1.5, alpha_phase=3.0, basis_alpha=10.0))]
+    for name, mp, ph, bs, D, nb, dt, dur, kw in cases:
+        eng = TrajectoryEngine(mp, ph, bs, D, nb, dt=dt, duration=dur, device=0, **kw)
+        T, P = eng.num_steps, eng.num_params
+        for B in batches:
+            g = torch.Generator().manual_seed(0)
+            params = torch.randn((B, P), generator=g).to(dev)
+            ip = (torch.rand((B, D), generator=g) * 2 - 1).to(dev)
+            iv = torch.zeros((B, D), device=dev)
+            it = torch.zeros((B,), device=dev)
+            out = (torch.empty((B, T, D), device=dev), torch.empty((B, T, D), device=dev))
+            t = timed(lambda: eng.trajectory(params, ip, iv, 0.0, out=out))
+            k0 = eng.last_kernel()
+            t1 = timed(lambda: eng.trajectory(params, ip, iv, it, out=out))
+            nbytes = B * (P * 4 + 2 * D * 4 + 2 * T * D * 4)
+            print(f"| {name} | {B} | `{k0}` | {t * 1e6:.1f} | {nbytes / t / 1e9:.0f} | {nbytes / t / 8e12 * 100:.1f} % | "
+                  f"`{eng.last_kernel()}` | {t1 * 1e6:.1f} |")
+            del params, ip, iv, out
 
 
 if __name__ == "__main__":

@@ -245,6 +245,7 @@ static Tuning effective_tuning(const Handle* h) {
     if (o.lds_pad >= 0) t.lds_pad = o.lds_pad;
     if (o.pipe >= 0) t.pipe = o.pipe;
     if (o.flat >= 0) t.flat = o.flat;
+    if (o.phase_flat >= 0) t.phase_flat = o.phase_flat;
     return t;
 }
 
@@ -678,6 +679,7 @@ const OptKey kOptKeys[] = {
     {"phase_chunk", &Tuning::phase_chunk, 0, 16}, {"pd_simple", &Tuning::pd_simple, 0, 1},
     {"split", &Tuning::split, 0, 1},             {"lds_pad", &Tuning::lds_pad, 0, 48},
     {"pipe", &Tuning::pipe, 0, 1},               {"flat", &Tuning::flat, 0, 1},
+    {"phase_flat", &Tuning::phase_flat, 0, 1},
 };
 const OptKey* find_opt(const char* key) {
     if (!key) return nullptr;

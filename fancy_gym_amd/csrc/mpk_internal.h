@@ -33,7 +33,7 @@ int steps_for(double duration, double dt);
 // ---- kernel-selection overrides (mpk_set_option); -1 = automatic ----------------------------------------------------
 struct Tuning {
     int mapping = -1, bulk = -1, quad = -1, pd_quad = -1, write_through = -1, ipw = -1, phase = -1, phase_table = -1,
-        phase_chunk = -1, pd_simple = -1, split = -1, lds_pad = -1, pipe = -1, flat = -1;
+        phase_chunk = -1, pd_simple = -1, split = -1, lds_pad = -1, pipe = -1, flat = -1, phase_flat = -1;
 };
 
 // ---- device-side configuration (kernel argument, by value) --------------------------------------------------

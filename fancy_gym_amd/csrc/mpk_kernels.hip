@@ -3192,10 +3192,15 @@ __device__ __forceinline__ void flush_span2(const float* __restrict__ s0, const 
 
 // TL (prodmp): the fp32 row table is staged in the workgroup's LDS (row stride 2*KS + 4 floats: 16-byte aligned rows
 // spread over the banks) and the workgroup is up to 16 waves, so row and boundary gathers never enter the memory queue
-template <int MP, int KQ, bool TL>
+// FL (prodmp): the rounds run over the FLATTENED (episode, step) items of a chunk -- 64 consecutive items a round, whatever
+// episode they belong to (a chunk's outputs are one contiguous run of HBM) -- instead of over each episode's steps: T = 100
+// fills 100 of 128 lanes per episode the other way.  Everything per episode (clipped tau / delay, init_time, 1 / tau, the
+// boundary-condition factors) is then per LANE, read from the chunk image; same arithmetic per (episode, step), same bits.
+template <int MP, int KQ, bool TL, bool FL = false>
 __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs a) {
     static_assert(MP != MPK_MP_DMP, "dmp has its own kernel");
     static_assert(!TL || MP == MPK_MP_PRODMP, "only prodmp has a row table");
+    static_assert(!FL || MP == MPK_MP_PRODMP, "flat rounds: prodmp (promp's difference crosses lanes)");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevCfg& c = a.c;
     constexpr int KS = KQ * 4;
@@ -3285,7 +3290,7 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
             // The chunk's input image is rewritten IN PLACE: every lane reads what it needs first, then the image becomes
             // [E][D][KS] columns [wg_0 .. wg_{K-1}, 0.., r1, r2] | [E][tau, delay, init_time] (clipped) -- no LDS on top.
             float* const imw = sImg + slot * img_floats;
-            const int le = (lane >= D) + (lane >= 2 * D) + (lane >= 3 * D), ld = lane - le * D;    // E <= 4
+            const int le = (int)(((unsigned)lane * (65536u / (unsigned)D + 1u)) >> 16), ld = lane - le * D;    // lane / D
             const bool on = lane < ne * D;
             const int K = c.nb + 1;
             float raw[KS], taul = c.tau, delayl = c.delay, itl = 0.0f, yb = 0.0f, ydb = 0.0f;
@@ -3332,12 +3337,89 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
                 }
                 xf[KS - 2] = (float)((double)yb - pb);
                 xf[KS - 1] = (float)((double)(taul * ydb) - vb);
-                if (ld == 0) {
+                if (ld == 0 && !FL) {
                     float* sc3 = imw + E * a.x_pad + 3 * le;
                     sc3[0] = taul; sc3[1] = delayl; sc3[2] = itl;
                 }
+                if (ld == 0 && FL) {
+                    // [E][tau, delay, init_time, 1 / tau] | [E][4] float64 boundary-condition factors (see the per-episode
+                    // block of the other path: the same expressions)
+                    float* sc4 = imw + E * a.x_pad + 4 * le;
+                    sc4[0] = taul; sc4[1] = delayl; sc4[2] = itl; sc4[3] = 1.0f / taul;
+                    const double* yb4 = reinterpret_cast<const double*>(rb + 2 * KS - 4);
+                    const double y1b = yb4[0], y2b = yb4[1], dy1b = yb4[2], dy2b = yb4[3];
+                    const double idet = div_pos(1.0, y1b * dy2b - y2b * dy1b);
+                    double* bc4 = reinterpret_cast<double*>(imw + E * a.x_pad + 4 * E) + 4 * le;
+                    bc4[0] = dy2b * idet; bc4[1] = dy1b * idet; bc4[2] = y1b * idet; bc4[3] = y2b * idet;
+                }
             }
             __builtin_amdgcn_wave_barrier();
+        }
+        if constexpr (FL) {
+            const int n_items = ne * T;
+            const float rT = 1.0f / (float)T;
+            float* const out_pos = a.pos + (size_t)b0 * T * D;
+            float* const out_vel = a.vel + (size_t)b0 * T * D;
+            for (int i0 = 0; i0 < n_items; i0 += 64) {
+                const int nout = min(64, n_items - i0);
+                const int i = min(i0 + lane, n_items - 1);
+                int e = (int)(((float)i + 0.5f) * rT);          // i / T (i < 8 T), then made exact
+                if (e * T > i) --e;
+                if ((e + 1) * T <= i) ++e;
+                const int t = i - e * T;
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(img + E * a.x_pad + 4 * e);
+                const float delay = sc[1], it = sc[2], inv_tau = sc[3];
+                const ExactDiv dtau{sc[0], inv_tau, (__float_as_uint(sc[0]) & 0x7fffffu) == 0x7fffffu};
+                const double* bc4 = reinterpret_cast<const double*>(img + E * a.x_pad + 4 * E) + 4 * e;
+                const double bca = bc4[0], bcb = bc4[1], bcc = bc4[2], bcd = bc4[3];
+                float hq[2 * KS];
+                const float time = sBT[t] + it;
+                const float s = fmaxf(div_exact(time - delay, dtau), 0.0f);
+                if (s > (float)c.len_factor) atomicOr(a.flag, 1);
+                const int idx = min((int)rintf(div_exact(s, dsdt)), c.n_pc - 1);
+                const float4* row = reinterpret_cast<const float4*>(rows + (size_t)idx * kRow);
+#pragma unroll
+                for (int j = 0; j < (2 * KS - 4) / 4; ++j) {
+                    const float4 q4 = row[j];
+                    hq[4 * j] = q4.x; hq[4 * j + 1] = q4.y; hq[4 * j + 2] = q4.z; hq[4 * j + 3] = q4.w;
+                }
+                const double* y4 = reinterpret_cast<const double*>(row + (2 * KS - 4) / 4);
+                const double y1 = y4[0], y2 = y4[1], dy1 = y4[2], dy2 = y4[3];
+                hq[2 * KS - 4] = (float)fma(bca, y1, -(bcb * y2));
+                hq[2 * KS - 3] = (float)fma(bca, dy1, -(bcb * dy2));
+                hq[2 * KS - 2] = (float)fma(bcc, y2, -(bcd * y1));
+                hq[2 * KS - 1] = (float)fma(bcc, dy2, -(bcd * dy1));
+                if (more && i0 + 64 >= n_items) park_chunk(sImg + (slot ^ 1) * img_floats);
+                float* const gp = out_pos + (size_t)i0 * D;
+                const int sh = (int)((reinterpret_cast<uintptr_t>(gp) >> 2) & 3);
+                const float* const sXl = img + e * a.x_pad;     // the lane's episode: at most two distinct ones per round
+                auto dof = [&](int d) {
+                    float x[KS];
+#pragma unroll
+                    for (int j = 0; j < KQ; ++j) {
+                        const float4 v = *reinterpret_cast<const float4*>(sXl + d * KS + 4 * j);
+                        x[4 * j + 0] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
+                    }
+                    f32x2 pv = {0.0f, 0.0f};
+#pragma unroll
+                    for (int k = 0; k < KS; ++k)
+                        pv = __builtin_elementwise_fma(f32x2{hq[2 * k], hq[2 * k + 1]}, f32x2{x[k], x[k]}, pv);
+                    sO0[sh + lane * D + d] = pv[0];
+                    sO1[sh + lane * D + d] = pv[1] * inv_tau;
+                };
+                constexpr int ND = KQ <= 2 ? 2 : 1;
+                int d = 0;
+                for (; d + ND <= D; d += ND) {
+#pragma unroll
+                    for (int q = 0; q < ND; ++q) dof(d + q);
+                }
+                for (; d < D; ++d) dof(d);
+                __builtin_amdgcn_wave_barrier();
+                if (a.wt) flush_span2<true>(sO0, sO1, gp, out_vel + (size_t)i0 * D, nout * D, sh, lane);
+                else flush_span2<false>(sO0, sO1, gp, out_vel + (size_t)i0 * D, nout * D, sh, lane);
+                __builtin_amdgcn_wave_barrier();
+            }
+            continue;
         }
         for (int e = 0; e < ne; ++e) {
             const int b = b0 + e;
@@ -3647,6 +3729,7 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
                              const char** kernel_name, const Tuning& tune) {
     PhaseArgs pa = base;
     const bool dmp = c.mp_type == MPK_MP_DMP;
+    bool flat = false, modelled = false;   // prodmp: chunk size chosen by the cost model (no balance rule on top)
     // dmp: + goal, y0, ydot0 columns; prodmp: weights, goal, y1 | y2 (a goal offset is added to the goal itself here)
     const int need = c.mp_type == MPK_MP_PRODMP ? c.nb + 3 : c.KT + (dmp ? 3 : 0);
     if (need > 16 || c.D > 64) return MPK_ENOTIMPL;
@@ -3675,9 +3758,56 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
         E = E > 4 ? 4 : E;
         E = E > 64 / c.D ? 64 / c.D : E;
         if (E < 1) return MPK_ENOTIMPL;
+        // prodmp: per-episode rounds with one episode per chunk, or flat rounds (k_traj_phase<.., FL>) over chunks of up to 8
+        // episodes -- whichever has the shorter critical path per wave: passes over the resident waves x (rounds of a chunk +
+        // ~2.5 rounds of per-chunk work: inputs, columns, boundary factors); a flat round costs ~15 % more (per-lane episode
+        // constants).  Measured at cfg2 + learned tau (T = 100): B = 4096 11.7 us per-episode vs 15 - 24 flat; 16 384 31.9 vs
+        // 23.4 - 24.8 (5 - 7 episodes per chunk); 65 536 94 vs 89; 262 144 equal (HBM) -- profiles/r03_per_episode_phase.md.
+        // "phase_flat" / "phase_chunk" override.
+        if (c.mp_type == MPK_MP_PRODMP) {
+            int e_max = 320 / c.P;
+            e_max = e_max > 8 ? 8 : e_max;
+            e_max = e_max > 64 / c.D ? 64 / c.D : e_max;
+            const size_t shared0 = (size_t)(pa.t_pad + (c.nb + 2 + 3) / 4 * 4) * sizeof(float);
+            const size_t tab_bytes = (size_t)c.n_pc * (2 * KS + 4) * sizeof(float);
+            auto resident = [&](int e, bool fl) -> long {           // waves of the whole chip for this layout (as below)
+                const int img_in = e * (c.P + 2 * c.D + 1), img_cols = e * (pa.x_pad + (fl ? 12 : 3));
+                const size_t wb = (size_t)(2 * (((img_in > img_cols ? img_in : img_cols) + 3) / 4 * 4) + 2 * pa.o_pad) * sizeof(float);
+                const bool tab = tune.phase_table != 0 && tab_bytes + 8 * wb <= 160 * 1024 - shared0 && (long)pa.B >= (long)num_cu * 8;
+                int w = tab ? (int)((160 * 1024 - shared0 - tab_bytes) / wb) : (int)((64 * 1024 - shared0) / wb);
+                w = tab ? (w > 16 ? 16 : w) : (w > 4 ? 4 : (w < 1 ? 1 : w));
+                int pc = (int)(160 * 1024 / (wb * w + shared0 + (tab ? tab_bytes : 0)));
+                pc = pc > 32 / w ? 32 / w : (pc < 1 ? 1 : pc);
+                return (long)num_cu * pc * w;
+            };
+            auto cost = [&](int e, bool fl) -> double {
+                const long chunks = ((long)pa.B + e - 1) / e, W = resident(e, fl);
+                const double passes = (double)((chunks + W - 1) / W);
+                const double rounds = fl ? 1.15 * (double)((e * c.T + 63) / 64) : (double)(e * ((c.T + 63) / 64));
+                return passes * (rounds + 2.5);
+            };
+            if (tune.phase_flat == 0) {
+                flat = false;
+            } else if (tune.phase_flat == 1) {
+                flat = true;
+                double best = 1e300;
+                for (int e = 1; e <= e_max; ++e)
+                    if (cost(e, true) < best - 1e-9) { best = cost(e, true); E = e; }
+                modelled = true;
+            } else {
+                double best = cost(1, false);
+                E = 1; flat = false;
+                for (int e = 2; e <= e_max; ++e)
+                    if (cost(e, true) < best * 0.97) { best = cost(e, true); E = e; flat = true; }
+                modelled = true;
+            }
+            if (flat && tune.phase_chunk >= 1 && tune.phase_chunk <= e_max) E = tune.phase_chunk;
+            if (tune.phase_chunk >= 1) modelled = flat;
+        }
         pa.chunk = E;
-        // prodmp: the image is rewritten in place into [E][x_pad] columns + [E][3] clipped phase values
-        const int img_in = E * (c.P + 2 * c.D + 1), img_cols = c.mp_type == MPK_MP_PRODMP ? E * (pa.x_pad + 3) : 0;
+        // prodmp: the image is rewritten in place into [E][x_pad] columns + [E][3] clipped phase values (flat rounds: [E][4]
+        // + [E][4] float64 boundary-condition factors)
+        const int img_in = E * (c.P + 2 * c.D + 1), img_cols = c.mp_type == MPK_MP_PRODMP ? E * (pa.x_pad + (flat ? 12 : 3)) : 0;
         pa.img_pad = ((img_in > img_cols ? img_in : img_cols) + 3) / 4 * 4;
         pa.wave_floats = 2 * pa.img_pad + 2 * pa.o_pad + (c.mp_type == MPK_MP_PRODMP ? 0 : pa.x_pad);
     }
@@ -3704,7 +3834,7 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
     const size_t lds = wave_bytes * wpb + shared_bytes;
     int per_cu = (int)(160 * 1024 / lds);
     per_cu = per_cu > 32 / wpb ? 32 / wpb : per_cu;
-    if (!dmp) {
+    if (!dmp && !modelled) {
         // chunks cost balance (a wave's work is quantised in E episodes): only when every resident wave still gets >= 4
         const long resident = (long)num_cu * per_cu * wpb;
         int E = pa.chunk;
@@ -3727,10 +3857,12 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
     switch (c.mp_type) {
         case MPK_MP_PRODMP:
             if (lds_table) {
-                *kernel_name = "k_traj_phase<prodmp,lds>";
+                *kernel_name = flat ? "k_traj_phase<prodmp,lds,flat>" : "k_traj_phase<prodmp,lds>";
+                if (flat) return KQ == 2 ? go(k_traj_phase<MPK_MP_PRODMP, 2, true, true>) : go(k_traj_phase<MPK_MP_PRODMP, 4, true, true>);
                 return KQ == 2 ? go(k_traj_phase<MPK_MP_PRODMP, 2, true>) : go(k_traj_phase<MPK_MP_PRODMP, 4, true>);
             }
-            *kernel_name = "k_traj_phase<prodmp>";
+            *kernel_name = flat ? "k_traj_phase<prodmp,flat>" : "k_traj_phase<prodmp>";
+            if (flat) return KQ == 2 ? go(k_traj_phase<MPK_MP_PRODMP, 2, false, true>) : go(k_traj_phase<MPK_MP_PRODMP, 4, false, true>);
             return KQ == 2 ? go(k_traj_phase<MPK_MP_PRODMP, 2, false>) : go(k_traj_phase<MPK_MP_PRODMP, 4, false>);
         case MPK_MP_PROMP:
             *kernel_name = "k_traj_phase<promp>";

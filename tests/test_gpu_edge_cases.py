@@ -378,16 +378,54 @@ def test_prodmp_row_table_in_lds_or_l2_same_bits(name, monkeypatch, mpk_option):
     B = 2500
     params, ip, iv = inputs(pc, bc, tc, B, seed=2)
     outs = {}
-    for mode in ("1", "0"):
-        mpk_option("phase_table", mode)
-        p, v = eng.trajectory(params, ip, iv, 0.0)
-        torch.cuda.synchronize()
-        outs[mode] = (p.clone(), v.clone(), eng.last_kernel())
-    assert outs["0"][2] == "k_traj_phase<prodmp>"
-    assert outs["1"][2] == "k_traj_phase<prodmp,lds>", outs["1"][2]
-    assert torch.equal(outs["0"][0], outs["1"][0]) and torch.equal(outs["0"][1], outs["1"][1])
+    for flat in ("0", "1"):
+        for mode in ("1", "0"):
+            mpk_option("phase_table", mode); mpk_option("phase_flat", flat)
+            p, v = eng.trajectory(params, ip, iv, 0.0)
+            torch.cuda.synchronize()
+            outs[mode + flat] = (p.clone(), v.clone(), eng.last_kernel())
+    assert outs["00"][2] == "k_traj_phase<prodmp>" and outs["01"][2] == "k_traj_phase<prodmp,flat>"
+    assert outs["10"][2] == "k_traj_phase<prodmp,lds>" and outs["11"][2] == "k_traj_phase<prodmp,lds,flat>", outs["11"][2]
+    for k in ("10", "01", "11"):
+        assert torch.equal(outs["00"][0], outs[k][0]) and torch.equal(outs["00"][1], outs[k][1]), k
     rp, rv = O.get_trajectory(pc, bc, tc, params, dur, dt, 0.0, ip, iv, dtype=np.float64)
-    close(outs["1"][0].cpu().numpy(), rp, "pos"); close(outs["1"][1].cpu().numpy(), rv, "vel")
+    close(outs["11"][0].cpu().numpy(), rp, "pos"); close(outs["11"][1].cpu().numpy(), rv, "vel")
+
+
+@pytest.mark.parametrize("T", [2, 17, 63, 64, 65, 100, 129, 350])
+@pytest.mark.parametrize("D,nb", [(1, 2), (7, 5), (9, 12), (16, 3)])
+def test_prodmp_flat_rounds_over_a_chunk_same_bits(T, D, nb, mpk_option):
+    """k_traj_phase<prodmp, flat>: 64 consecutive (episode, step) items of a chunk per round instead of 64 steps of one
+    episode -- per-lane tau / delay / init_time / boundary factors; every chunk size up to 8, ragged last chunk, learned
+    tau + delay with per-episode init_time: same bits as the per-episode rounds, and the oracle"""
+    dt = 0.01
+    dur = T * dt
+    pc = O.PhaseCfg("exp", tau=dur, alpha_phase=3.0, learn_tau=True, learn_delay=True, tau_bound=(0.5 * dur, 1.2 * dur),
+                    delay_bound=(0.0, 0.1 * dur))
+    bc = O.BasisCfg("prodmp", num_basis=nb, alpha=15)
+    tc = O.TrajCfg("prodmp", action_dim=D, weights_scale=0.8, goal_scale=1.1, relative_goal=bool(D & 1))
+    eng = make_engine(pc, bc, tc, dt, dur)
+    for B in (1, 3, 37):
+        params, ip, iv = inputs(pc, bc, tc, B, seed=B + T)
+        rng = np.random.default_rng(T + D)
+        params[:, 0] = torch.tensor(rng.uniform(0.4 * dur, 1.3 * dur, B), dtype=torch.float32)
+        params[:, 1] = torch.tensor(rng.uniform(-0.02 * dur, 0.12 * dur, B), dtype=torch.float32)
+        it = torch.tensor(rng.integers(0, 3, B) * dt, dtype=torch.float32, device="cuda")
+        mpk_option("phase_flat", "0"); mpk_option("phase_chunk", "-1")
+        p0, v0 = (x.clone() for x in eng.trajectory(params, ip, iv, it))
+        assert eng.last_kernel().startswith("k_traj_phase<prodmp") and "flat" not in eng.last_kernel()
+        mpk_option("phase_flat", "1")
+        for chunk in ("-1", "1", "2", "3", "5", "8"):
+            mpk_option("phase_chunk", chunk)
+            p1, v1 = eng.trajectory(params, ip, iv, it)
+            torch.cuda.synchronize()
+            assert eng.last_kernel().endswith("flat>"), eng.last_kernel()
+            assert torch.equal(p0, p1) and torch.equal(v0, v1), (B, chunk)
+        mpk_option("phase_chunk", "-1")
+        for b in range(min(B, 3)):
+            rp, rv = O.get_trajectory(pc, bc, tc, params[b:b + 1], dur, dt, float(it[b]), ip[b:b + 1], iv[b:b + 1],
+                                      dtype=np.float64)
+            close(p0[b:b + 1].cpu().numpy(), rp, "pos"); close(v0[b:b + 1].cpu().numpy(), rv, "vel")
 
 
 @pytest.mark.parametrize("name", ["prodmp_learn_tau_delay", "promp_learn_tau", "dmp_learn_delay"])

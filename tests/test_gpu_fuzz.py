@@ -87,6 +87,10 @@ def test_random_configuration_matches_oracle(seed, monkeypatch, mpk_option):
     r2 = np.random.default_rng(77_000 + seed)
     mpk_option("pipe", int(r2.choice([-1, 0, 1])))
     mpk_option("split", int(r2.choice([-1, 0, 1])))
+    r3 = np.random.default_rng(99_000 + seed)       # round 3: flat rounds of the per-episode prodmp kernel, chunks up to 8
+    mpk_option("phase_flat", int(r3.choice([-1, 0, 1])))
+    if r3.integers(0, 2):
+        mpk_option("phase_chunk", int(r3.integers(1, 9)))
     if tc.trajectory_generator_type == "prodmp":
         tc = dataclasses.replace(tc, relative_goal_mode=str(r2.choice(["after_scale", "before_scale"])),
                                  goal_offset_mode=str(r2.choice(["ignore", "add"])), goal_offset=float(r2.uniform(-0.5, 0.5)))
@@ -236,6 +240,9 @@ def test_random_actions_reacher_validity_and_per_episode_init_time(seed, mpk_opt
     mpk_option("flat", int(rng.choice([-1, 0, 1])))
     mpk_option("pd_quad", int(rng.choice([-1, 0, 2])))
     mpk_option("pd_simple", int(rng.choice([-1, 0, 1])))
+    r3 = np.random.default_rng(99_000 + seed)       # (a generator of its own: the cases keep their shapes)
+    mpk_option("phase_flat", int(r3.choice([-1, 0, 1])))
+    mpk_option("phase_chunk", int(r3.choice([-1, 1, 2, 3, 5, 7, 8])))
     eng = make_engine(pc, bc, tc, dt, dur)
     D = tc.action_dim
     params, ip, iv = inputs(pc, bc, tc, B, seed=seed)

@@ -22,6 +22,8 @@ CASES = {
     "cfg5' promp learn_tau+delay": ("cfg5tau", 2),
     "cfg3' dmp learn_tau": (dict(KW["cfg3"], learn_tau=True, tau_bound=(2.0, 4.0)), 1),
 }
+# other horizons of the cfg2' shape (chunk-size model of the prodmp kernel):  python tools/phase_bench.py horizons ...
+HORIZONS = {f"cfg2' prodmp learn_tau, T = {T}": (dict(KW["cfg2tau"], duration=T * 0.02), 1) for T in (64, 128, 150, 350)}
 
 
 def main():
@@ -35,7 +37,12 @@ def main():
     g = torch.Generator().manual_seed(0)
     print("| config | batch | kernel | us | trajectories/s | GB/s (alg.) | of 8 TB/s |")
     print("|---|---|---|---|---|---|---|")
-    for name, (kw, n_ph) in CASES.items():
+    cases = dict(CASES)
+    if "horizons" in sys.argv:
+        cases = HORIZONS
+    if "prodmp" in sys.argv:
+        cases = {k: v for k, v in CASES.items() if "prodmp" in k}
+    for name, (kw, n_ph) in cases.items():
         kw = KW[kw] if isinstance(kw, str) else kw
         eng = TrajectoryEngine(device=0, **kw)
         T, D, P = eng.num_steps, eng.num_dof, eng.num_params

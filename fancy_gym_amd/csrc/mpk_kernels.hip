@@ -2527,6 +2527,11 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         if (flat_ok && tune.flat != 0 && (tune.flat == 1 || (out_bytes > 96.0 * 1024 * 1024 && tune.bulk < 0))) {
             ta.flat_img = flat_img;
             bulk = false;
+            // write-through stores while the outputs still fit the memory-side cache: plain (write-back) stores fall off a
+            // cliff once the dirty lines exceed it (+actions: 38.9 us at 206 MB, 57.1 at 241 MB, 67.5 at 275 MB), write-
+            // through moves it to ~320 MB (46.1 / 51.9 us at 241 / 275 MB, 71 vs 74 at 310) and loses beyond (88.6 vs 77.7 us
+            // at 344 MB, 686 vs 481 at 2.2 GB) -- profiles/r03_streaming_wt.md
+            if (tune.write_through < 0) ta.wt = out_bytes <= 320.0 * 1024 * 1024 ? 1 : 0;
             lds = lds_flat + (tune.lds_pad > 0 ? (size_t)tune.lds_pad * 1024 : 0);   // "lds_pad": occupancy experiments
             const long wg = (long)(160 * 1024 / lds) < 3 ? (long)(160 * 1024 / lds) : 3;   // workgroups a CU's LDS holds
             const long resident = (long)num_cu * (wg < 1 ? 1 : wg) * 4;   // 4-wave workgroups, persistent

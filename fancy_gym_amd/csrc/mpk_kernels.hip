@@ -139,6 +139,15 @@ __device__ __forceinline__ float div_exact(float z, const ExactDiv& x) {
     return __builtin_fmaf(__builtin_fmaf(-x.d, q, z), x.r, q);
 }
 
+// Write-through (sc1) stores are chosen while a launch's outputs still fit the memory-side cache (256 MB + the L2s): plain
+// write-back stores fall off a cliff once the dirty lines exceed it, write-through stores lose once the outputs stream to
+// HBM anyway.  Measured per kernel family and size (profiles/r03_streaming_wt.md, us plain vs write-through): k_traj_flat
+// +actions 57.1 / 46.1 at 241 MB, 67.5 / 51.9 at 275 MB, 74.3 / 71.3 at 310 MB, 77.7 / 88.6 at 344 MB; cfg3 k_traj_quad<dmp>
+// 36.5 / 33.6 at 175 MB, 58.2 / 54.3 at 262 MB, 99 / 104 at 350 MB; closed loop k_traj_duo 80.8 / 70.1 at 262 MB, 173 / 221 at
+// 525 MB; per-episode kernels 44.2 / 41.2 at 175 MB, 107 / 117 at 350 MB.  (The tile-major kernels keep their own 96 MB rule:
+// above it the episode-major kernels take over.)
+constexpr double kWtBytes = 300.0 * 1024 * 1024;
+
 // The integer part of BlackBoxWrapper.step's loop (black_box_wrapper.py:174,197,206) for one episode and one plan:
 // how many steps this plan executes before the loop breaks (end of the horizon, or the schedule t % every == 0 while
 // plan_steps < max_planning_times), and the counters after it.  k_replan_advance and the fused closed-loop kernels both
@@ -2443,7 +2452,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     }
     // write-through stores for the cache-resident tile-major case (mpk_set_option "write_through" overrides, for A/B runs)
     bool write_through = !stream_mode;
-    ta.wt = stream_mode && out_bytes <= 96.0 * 1024 * 1024 ? 1 : 0;
+    ta.wt = stream_mode && out_bytes <= kWtBytes ? 1 : 0;
     if (tune.write_through >= 0) {
         write_through = tune.write_through != 0 && !stream_mode;
         ta.wt = tune.write_through != 0 && stream_mode ? 1 : 0;
@@ -2527,11 +2536,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         if (flat_ok && tune.flat != 0 && (tune.flat == 1 || (out_bytes > 96.0 * 1024 * 1024 && tune.bulk < 0))) {
             ta.flat_img = flat_img;
             bulk = false;
-            // write-through stores while the outputs still fit the memory-side cache: plain (write-back) stores fall off a
-            // cliff once the dirty lines exceed it (+actions: 38.9 us at 206 MB, 57.1 at 241 MB, 67.5 at 275 MB), write-
-            // through moves it to ~320 MB (46.1 / 51.9 us at 241 / 275 MB, 71 vs 74 at 310) and loses beyond (88.6 vs 77.7 us
-            // at 344 MB, 686 vs 481 at 2.2 GB) -- profiles/r03_streaming_wt.md
-            if (tune.write_through < 0) ta.wt = out_bytes <= 320.0 * 1024 * 1024 ? 1 : 0;
+            // (write-through while the outputs fit the memory-side cache: kWtBytes)
             lds = lds_flat + (tune.lds_pad > 0 ? (size_t)tune.lds_pad * 1024 : 0);   // "lds_pad": occupancy experiments
             const long wg = (long)(160 * 1024 / lds) < 3 ? (long)(160 * 1024 / lds) : 3;   // workgroups a CU's LDS holds
             const long resident = (long)num_cu * (wg < 1 ? 1 : wg) * 4;   // 4-wave workgroups, persistent
@@ -3968,7 +3973,7 @@ int launch_traj_rows(const DevCfg& c, const float* params, const float* init_pos
     const bool wave_kernel = tune.phase != 0;
     if (wave_kernel) {
         PhaseArgs pa{c, params, init_pos, init_vel, init_time, init_time_shared, pos, vel, range_flag, B, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        pa.wt = (double)B * c.T * c.D * 8.0 <= 96.0 * 1024 * 1024 ? 1 : 0;
+        pa.wt = (double)B * c.T * c.D * 8.0 <= kWtBytes ? 1 : 0;
         if (tune.write_through >= 0) pa.wt = tune.write_through != 0 ? 1 : 0;
         const int rc = launch_traj_phase(c, pa, num_cu, stream, kernel_name, tune);
         if (rc != MPK_ENOTIMPL) return rc;

@@ -302,3 +302,120 @@ def test_random_actions_reacher_validity_and_per_episode_init_time(seed, mpk_opt
         close(p3.cpu().numpy(), rp, f"pos [{kern}]", atol=slack(p32, rp))
         fd = tc.trajectory_generator_type == "promp"
         close(v3.cpu().numpy(), rv, f"vel [{kern}]", atol=(fd_atol(rp, dt) if fd else 0.0) + slack(v32, rv))
+
+
+# ---- part three: whole BatchedBlackBox episodes (plan -> execute -> re-condition -> replan) --------------------------------
+N_CASES_BB = int(os.environ.get("MPK_FUZZ_CASES_BB", "60"))
+START_BB = int(os.environ.get("MPK_FUZZ_START_BB", "0"))
+
+
+def _batched_from_cfg(pc, bc, tc, dt, dur, B, ctrl, pg, dg, lo, hi, **kw):
+    from fancy_gym_amd import BatchedBlackBox
+    from fancy_gym_amd.black_box.factory import (get_basis_generator, get_controller, get_phase_generator,
+                                                 get_trajectory_generator)
+    pkw = dict(tau=pc.tau, delay=pc.delay, learn_tau=pc.learn_tau, learn_delay=pc.learn_delay,
+               tau_bound=list(pc.tau_bound), delay_bound=list(pc.delay_bound))
+    if pc.phase_generator_type == "exp":
+        pkw["alpha_phase"] = pc.alpha_phase
+    phase = get_phase_generator(pc.phase_generator_type, **pkw)
+    bkw = dict(num_basis=bc.num_basis, basis_bandwidth_factor=bc.basis_bandwidth_factor)
+    if bc.basis_generator_type == "zero_rbf":
+        bkw.update(num_basis_zero_start=bc.num_basis_zero_start, num_basis_zero_goal=bc.num_basis_zero_goal)
+    else:
+        bkw.update(num_basis_outside=bc.num_basis_outside)
+    if bc.basis_generator_type == "prodmp":
+        bkw.update(alpha=bc.alpha, dt=bc.dt)
+    basis = get_basis_generator(bc.basis_generator_type, phase, **bkw)
+    tkw = dict(weights_scale=tc.weights_scale)
+    if tc.trajectory_generator_type == "prodmp":
+        tkw.update(goal_scale=tc.goal_scale, auto_scale_basis=tc.auto_scale_basis, relative_goal=tc.relative_goal,
+                   disable_goal=tc.disable_goal, disable_weights=tc.disable_weights)
+    elif tc.trajectory_generator_type == "dmp":
+        tkw.update(goal_scale=tc.goal_scale, alpha=tc.alpha)
+    tg = get_trajectory_generator(tc.trajectory_generator_type, tc.action_dim, basis, **tkw)
+    ckw = {} if ctrl != "motor" else dict(p_gains=pg, d_gains=dg)
+    return BatchedBlackBox(tg, get_controller(ctrl, **ckw), B, dt, dur, act_low=lo, act_high=hi, **kw)
+
+
+@pytest.mark.parametrize("seed", range(START_BB, START_BB + N_CASES_BB))
+def test_random_batched_episode_follows_the_oracle_sequence(seed, mpk_option):
+    """
+    BatchedBlackBox.step over whole episodes under a random configuration, replanning schedule `t % every == 0`,
+    max_planning_times, condition_on_desired on / off, controller, action limits and kernel options -- the fused step
+    (mpk_replan_step) and the unfused one (trajectory, integer rule, rollout, condition gather as separate launches) on two
+    instances must agree bit for bit, and both follow the oracle's sequence: plans within 1e-5, the integer state, actions and
+    plant state bit-exact given the plan (black_box_wrapper.py:150-217, test/test_replanning_sequencing.py).
+    """
+    rng = np.random.default_rng(123_000 + seed)
+    pc, bc, tc, dt, dur, B, _ = random_case(rng)
+    B = min(B, 33)
+    D = tc.action_dim
+    T = int(round(dur / dt))
+    if T < 2:
+        pytest.skip("one-step horizon")
+    replan = bool(rng.random() < 0.75)
+    every = int(rng.integers(1, T + 1)) if replan else None
+    mpt = [1, 2, 3, 5, float("inf")][int(rng.integers(0, 5))]
+    cod = bool(rng.random() < 0.5)
+    if tc.trajectory_generator_type == "prodmp" and 2.0 * dur / min(pc.tau, pc.tau_bound[0] if pc.learn_tau else pc.tau) > 5.9:
+        pytest.skip("beyond the ProDMP pre-computation range")
+    ctrl = str(rng.choice(["motor", "position", "velocity"]))
+    pg, dg = rng.uniform(0.2, 2.0, D), rng.uniform(0.02, 0.3, D)
+    lo, hi = -float(rng.uniform(0.3, 1.5)), float(rng.uniform(0.3, 1.5))
+    for key, vals in (("mapping", [-1, 1, 2]), ("quad", [-1, 0, 2, 3, 4]), ("bulk", [-1, 0, 2]), ("pipe", [-1, 0, 1]),
+                      ("split", [-1, 0, 1]), ("pd_quad", [-1, 0, 2]), ("pd_simple", [-1, 0, 1]), ("phase_flat", [-1, 0, 1]),
+                      ("phase_chunk", [-1, 1, 2, 3, 4, 7])):
+        mpk_option(key, int(rng.choice(vals)))
+    kw = dict(plant="double_integrator", max_planning_times=mpt, condition_on_desired=cod)
+    if replan:
+        kw["replanning_every"] = every
+    fused = _batched_from_cfg(pc, bc, tc, dt, dur, B, ctrl, pg, dg, lo, hi, **kw)
+    plain = _batched_from_cfg(pc, bc, tc, dt, dur, B, ctrl, pg, dg, lo, hi, **kw)
+    P = fused.engine.num_params
+    n_phase = int(pc.learn_tau) + int(pc.learn_delay)
+    q0, qd0 = rng.uniform(-1, 1, (B, D)), rng.uniform(-0.5, 0.5, (B, D))
+    fused.reset(q0, qd0); plain.reset(q0, qd0)
+    q, qd = q0.copy(), qd0.copy()
+    cond_p, cond_v = q0.astype(np.float32), qd0.astype(np.float32)
+    segments = O.replanning_segments(T, every, mpt) if replan else [(0, T)]
+    frozen = None
+    for k, (start, n) in enumerate(segments):
+        params = (rng.standard_normal((B, P)) * 0.7).astype(np.float32)
+        if pc.learn_tau:
+            params[:, 0] = rng.uniform(0.8 * pc.tau_bound[0], 1.1 * pc.tau_bound[1], B)
+        if pc.learn_delay:
+            params[:, int(pc.learn_tau)] = rng.uniform(-0.05 * dur, 1.1 * pc.delay_bound[1] + 1e-3, B)
+        of, op = fused.step(params, fuse=True), plain.step(params, fuse=False)
+        torch.cuda.synchronize()
+        for key in ("des_pos", "des_vel", "step_actions", "trajectory_length", "done"):
+            assert torch.equal(of[key], op[key]), (k, key, fused.engine.last_kernel(), plain.engine.last_kernel())
+        assert torch.equal(fused.q, plain.q) and torch.equal(fused.qd, plain.qd), k
+        assert torch.equal(fused.traj_steps, plain.traj_steps) and torch.equal(fused.plan_steps, plain.plan_steps)
+        # the oracle's sequence
+        assert torch.all(of["trajectory_length"] == n) and int(fused.traj_steps[0]) == start + n, (k, start, n)
+        assert int(fused.plan_steps[0]) == k + 1 and bool(of["done"].all()) == (k == len(segments) - 1)
+        p_eff = params.copy()
+        if n_phase:
+            if frozen is None:       # tau / delay are frozen (clipped) by the first plan of an episode
+                bounds = ([pc.tau_bound] if pc.learn_tau else []) + ([pc.delay_bound] if pc.learn_delay else [])
+                frozen = np.stack([np.clip(params[:, i], np.float32(b[0]), np.float32(b[1])) for i, b in enumerate(bounds)], 1)
+            p_eff[:, :n_phase] = frozen
+        rp, rv = O.get_trajectory(pc, bc, tc, p_eff, dur, dt, start * dt, cond_p, cond_v, dtype=np.float64)
+        if not np.isfinite(rp).all():
+            pytest.skip("degenerate basis")
+        dp, dv = of["des_pos"].cpu().numpy(), of["des_vel"].cpu().numpy()
+        p32, v32 = O.get_trajectory(pc, bc, tc, p_eff, dur, dt, start * dt, cond_p, cond_v, dtype=np.float32)
+
+        def slack(r32, r64):
+            e = float(np.abs(r32.astype(np.float64) - r64).max()) if r64.size else 0.0
+            return e if e > 2e-6 * float(np.abs(r64).max()) else 0.0
+        fd = tc.trajectory_generator_type == "promp"
+        close(dp, rp, f"plan {k} pos [{fused.engine.last_kernel()}]", atol=slack(p32, rp))
+        close(dv, rv, f"plan {k} vel", atol=(fd_atol(rp, dt) if fd else 0.0) + slack(v32, rv))
+        ra, q, qd = O.rollout(dp, dv, ctrl, pg, dg, lo, hi, "double_integrator", dt, q, qd, n_steps=np.full(B, n))
+        assert np.array_equal(of["step_actions"].cpu().numpy(), ra.astype(np.float32)), k
+        assert np.array_equal(fused.q.cpu().numpy(), q) and np.array_equal(fused.qd.cpu().numpy(), qd), k
+        if cod:
+            cond_p, cond_v = dp[:, n - 1], dv[:, n - 1]
+        else:
+            cond_p, cond_v = q.astype(np.float32), qd.astype(np.float32)

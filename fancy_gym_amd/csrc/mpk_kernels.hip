@@ -2625,6 +2625,7 @@ struct WideArgs {
     float* vel;
     int B, epg, n_units, KC, n_rt, SA;   // episodes per column group, 4-group units, k chunk, row tiles, LDS row stride
     int cgpe;                            // column groups per episode: 1 (D <= 16), else ceil(D / 16) with epg == 1
+    int aux_ofs;                         // floats: LDS copy of aux[TS] behind the staging area / epilogue images
 };
 
 // raw operand of the contraction for column (episode b, DoF dd), index k  (the sX fill of k_traj_rows)
@@ -2670,9 +2671,24 @@ __global__ void __launch_bounds__(256, ((MP == MPK_MP_PRODMP ? 2 : 1) * MT <= 16
     // epilogue images alias the staging area (used after the k loop, behind a barrier): per wave [NIMG][MT*16][CS]
     constexpr int NIMG = MP == MPK_MP_PROMP ? 1 : 2;
     float* sC = smem + (size_t)wave * NIMG * MT * 16 * CS;
+    // aux (promp: reciprocal time steps, dmp: scaled-time increments) behind both: read per step in the epilogue, and a
+    // global load there waits for every store before it (one counter for loads and stores) -- from LDS it does not
+    float* sAux = smem + a.aux_ofs;
+    if (MP != MPK_MP_PRODMP) {
+        for (int t = tid; t < TS; t += 256) sAux[t] = a.aux[t];
+        __syncthreads();
+    }
     const int kshift = 31 - __builtin_clz(KC);          // KC is a power of two
     const int nj = KC >> 2;                             // MFMA steps per chunk
 
+#ifdef WIDE_TIME
+    unsigned long long tw_mfma = 0, tw_sync = 0, tw_fetch = 0, tw_epi = 0, tw_t0 = __builtin_readcyclecounter(), tw_a, tw_b;
+#define TW_A() tw_a = __builtin_readcyclecounter()
+#define TW_B(acc) do { tw_b = __builtin_readcyclecounter(); acc += tw_b - tw_a; tw_a = tw_b; } while (0)
+#else
+#define TW_A()
+#define TW_B(acc)
+#endif
     for (int unit = blockIdx.x; unit < a.n_units; unit += gridDim.x) {
         const int grp = unit * 4 + wave;
         // D <= 16: the group holds epg whole episodes; D > 16: 16 consecutive DoF (from d0) of ONE episode
@@ -2703,22 +2719,37 @@ __global__ void __launch_bounds__(256, ((MP == MPK_MP_PRODMP ? 2 : 1) * MT <= 16
             float4 ra[ANR];
             float xn[XNR], xc[XNR];
             // ---- requests of one k chunk: every load is issued before any of them is used ----
+            // Kept lean (the whole non-MFMA part of a chunk is time the wave's SIMD partner -- the other workgroup's wave --
+            // must cover with its own MFMAs): table rows through a wave-UNIFORM pointer (scalar address arithmetic) + one
+            // lane offset per span, lanes past the row clamped onto its last float4 instead of masked (commit skips them),
+            // invalid columns pointed at the start of `params` instead of masked (their products land in columns nobody
+            // stores).  Per-wave cycle budget of the num_basis = 1000 launch (build with -DWIDE_TIME, tools/dev/wide_time.py;
+            // profiles/r03_wide.md): contraction 33 %, the wait for this lambda's loads one chunk later 36 %, the two
+            // barriers + commit 16 %, epilogue 8 % -- two waves per SIMD, so the matrix pipes idle whenever both wait.
+            const int q0 = min(lane, r4 - 1), q1 = min(lane + 64, r4 - 1);        // clamped float4 index per span
+            const float* const cwl = cvalid ? cw + g4 : a.params;                  // invalid column: any readable floats
+            const int xmax = cvalid ? 0x7fffffff : 0;                             // ... at offset 0
             auto fetch = [&](int k0) {
+#ifdef WIDE_NO_LOADS
+                if (k0 > 0) return;
+#endif
 #pragma unroll
                 for (int p = 0; p < ANR; ++p) {
                     const int row = wave + 4 * (spans == 1 ? p : (p >> 1));       // wave-uniform: o * KC + kk
-                    const int q = lane + (spans == 1 ? 0 : 64 * (p & 1));
                     const int kk = row & (KC - 1), o = row >> kshift;
                     const int k = k0 + kk;
                     ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (row < nrows && q < r4 && k < KP)
-                        ra[p] = *reinterpret_cast<const float4*>(a.A + ((size_t)o * KP + k) * TS + rt0 * 16 + 4 * q);
+                    if (row < nrows && k < KP) {                                  // (uniform)
+                        const float4* rowp = reinterpret_cast<const float4*>(a.A + ((size_t)o * KP + k) * TS + rt0 * 16);
+                        ra[p] = rowp[spans == 1 || !(p & 1) ? q0 : q1];
+                    }
                 }
                 if (k0 + KC <= kplain) {                // the common chunk: nothing but parameters (wave-uniform test)
+                    const float* cwk = cwl + min(k0, xmax);
 #pragma unroll
                     for (int p = 0; p < XNR; ++p) {
                         xn[p] = 0.0f;
-                        if (p < nj && cvalid) xn[p] = cw[k0 + 4 * p + g4];
+                        if (p < nj) xn[p] = cwk[4 * p];
                     }
                 } else {
 #pragma unroll
@@ -2729,15 +2760,31 @@ __global__ void __launch_bounds__(256, ((MP == MPK_MP_PRODMP ? 2 : 1) * MT <= 16
                     }
                 }
             };
+            // LDS image of the chunk: float4 = steps 4 q .. 4 q + 3 of the block -> row tile q / 4, steps-in-tile 4 (q % 4) + e;
+            // lane + 64 of the second span has the same (q & 3) and (q >> 2) + 16: ONE lane-dependent address, the rest of
+            // every address is wave-uniform
+            float* const w0 = sA + (size_t)wave * SA + (4 * (lane & 3)) * MTP + (lane >> 2);
             auto commit = [&]() {
+                if (lane < r4) {
 #pragma unroll
-                for (int p = 0; p < ANR; ++p) {
-                    const int row = wave + 4 * (spans == 1 ? p : (p >> 1));
-                    const int q = lane + (spans == 1 ? 0 : 64 * (p & 1));
-                    if (row < nrows && q < r4) {
-                        // float4 = steps 4 q .. 4 q + 3 of the block: row tile q / 4, steps-in-tile 4 (q % 4) + e
-                        float* w = sA + (size_t)row * SA + (4 * (q & 3)) * MTP + (q >> 2);
-                        w[0] = ra[p].x; w[MTP] = ra[p].y; w[2 * MTP] = ra[p].z; w[3 * MTP] = ra[p].w;
+                    for (int p = 0; p < ANR; ++p) {
+                        if (spans == 1 || !(p & 1)) {
+                            const int row = wave + 4 * (spans == 1 ? p : (p >> 1));
+                            if (row < nrows) {
+                                float* w = w0 + (size_t)(4 * (spans == 1 ? p : (p >> 1))) * SA;
+                                w[0] = ra[p].x; w[MTP] = ra[p].y; w[2 * MTP] = ra[p].z; w[3 * MTP] = ra[p].w;
+                            }
+                        }
+                    }
+                }
+                if (spans == 2 && lane + 64 < r4) {
+#pragma unroll
+                    for (int p = 1; p < ANR; p += 2) {
+                        const int row = wave + 4 * (p >> 1);
+                        if (row < nrows) {
+                            float* w = w0 + (size_t)(4 * (p >> 1)) * SA + 16;
+                            w[0] = ra[p].x; w[MTP] = ra[p].y; w[2 * MTP] = ra[p].z; w[3 * MTP] = ra[p].w;
+                        }
                     }
                 }
 #pragma unroll
@@ -2745,12 +2792,56 @@ __global__ void __launch_bounds__(256, ((MP == MPK_MP_PRODMP ? 2 : 1) * MT <= 16
             };
             fetch(0);
             for (int k0 = 0; k0 < KP; k0 += KC) {
+                TW_A();
                 __syncthreads();                        // the previous chunk (or epilogue image) is consumed
                 commit();
                 __syncthreads();
+                TW_B(tw_sync);
                 if (k0 + KC < KP) fetch(k0 + KC);       // in flight under this chunk's contraction
+                TW_B(tw_fetch);
                 // ---- contraction of the chunk ----
                 const float* pa = sA + (size_t)g4 * SA + m * MTP;
+                // the full chunk (KC = 32: promp / dmp; KC = 16: prodmp, whose two outputs share the chunk): the A fragments of
+                // step p + 1 are requested BEFORE the MFMAs of step p are issued -- left to itself the compiler reads one
+                // ds_read_b128 into one register quad, waits, issues its four MFMAs, reads the next (the LDS round trip exposed
+                // once per four MFMAs).  Two fragment sets where the accumulators leave room (<= 64 of them), else all reads
+                // of a step ahead of its MFMAs.  A wave's contraction now runs at 93 % of the pipe's rate while it lasts; the
+                // launch as a whole did not get faster by it (the waits between contractions dominate, see `fetch`).
+                auto contract_full = [&](auto nj_tag) {
+                    constexpr int NJ = decltype(nj_tag)::value;
+                    constexpr int NB = NOUT * MT <= 16 ? 2 : 1;
+                    f32x4 af[NB][NOUT][NR4];
+                    auto load_step = [&](int buf, int p) {
+#pragma unroll
+                        for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+                            for (int c4 = 0; c4 < NR4; ++c4)
+                                af[buf][o][c4] = *reinterpret_cast<const f32x4*>(pa + ((size_t)o * KC + 4 * p) * SA + 4 * c4);
+                    };
+                    load_step(0, 0);
+#pragma unroll
+                    for (int p = 0; p < NJ; ++p) {
+                        const int cur = NB == 2 ? (p & 1) : 0;
+                        if (NB == 2 && p + 1 < NJ) load_step(cur ^ 1, p + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const float bf = xc[p];
+#pragma unroll
+                        for (int r = 0; r < MT; ++r) {
+#pragma unroll
+                            for (int o = 0; o < NOUT; ++o)
+                                acc[o][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[cur][o][r >> 2][r & 3], bf, acc[o][r], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (NB == 1 && p + 1 < NJ) load_step(0, p + 1);
+                    }
+                };
+                constexpr int NJ_FULL = NOUT == 1 ? XNR : XNR / 2;      // what the launcher's chunk gives (ANR rows per wave)
+                // (prodmp with 7 / 8 row tiles sits at the 256-register cap of two workgroups per CU already: the read-ahead
+                // spills there, so those two variants keep the plain loop)
+                constexpr bool kReadAhead = !(NOUT == 2 && MT > 4 && MT <= 8);
+                if (kReadAhead && nj == NJ_FULL) {
+                    if constexpr (kReadAhead) contract_full(std::integral_constant<int, NJ_FULL>());
+                } else
 #pragma unroll
                 for (int p = 0; p < XNR; ++p) {
                     if (p < nj) {
@@ -2773,6 +2864,7 @@ __global__ void __launch_bounds__(256, ((MP == MPK_MP_PRODMP ? 2 : 1) * MT <= 16
                         }
                     }
                 }
+                TW_B(tw_mfma);
             }
             __syncthreads();                            // every wave is done with the staging area
             // ---- epilogue: C tiles -> image [t][col] (row = 4 * (lane >> 4) + i of tile r, column = lane & 15) ----
@@ -2804,7 +2896,7 @@ __global__ void __launch_bounds__(256, ((MP == MPK_MP_PRODMP ? 2 : 1) * MT <= 16
                         img0[(size_t)t * CS + lane] = y;
                         img1[(size_t)t * CS + lane] = div_tau(z, td);
                         if (t < T - 1) {
-                            const float ds = a.aux[t];
+                            const float ds = sAux[t];
                             const float t1 = gl - y;
                             const float t2 = c.dmp_beta * t1;
                             const float t3 = t2 - z;
@@ -2817,33 +2909,52 @@ __global__ void __launch_bounds__(256, ((MP == MPK_MP_PRODMP ? 2 : 1) * MT <= 16
                 }
                 __builtin_amdgcn_wave_barrier();
             }
-            // copy-out: each episode's [t_n][D] block is contiguous in HBM (D > 16: the group's 16-DoF slice of every row)
-            const int cw_ = a.cgpe == 1 ? D : ncol;     // columns of one episode in this group
-            for (int e = 0; e < a.epg; ++e) {
-                const int b = b0 + e;
-                if (b >= a.B) break;
-                const size_t ob = ((size_t)b * T + t_lo) * D + d0;
-                const int nel = t_n * cw_;
-                const float rcw = 1.0f / (float)cw_;    // i < 2^15: (i + 0.5) / cw_ truncates to i / cw_ exactly in fp32
-                for (int i = lane; i < nel; i += 64) {
-                    const int t = (int)(((float)i + 0.5f) * rcw), dd = i - t * cw_;
-                    const int col = e * D + dd;
-                    const float p = img0[(size_t)t * CS + col];
-                    float v;
-                    if (MP == MPK_MP_PROMP) {
-                        // vel = forward difference of the fp32 positions, last row repeats
-                        const int tg = t_lo + t;
-                        const int th = tg < T - 1 ? tg + 1 : T - 1, tl = tg < T - 1 ? tg : T - 2;
-                        v = (img0[(size_t)(th - t_lo) * CS + col] - img0[(size_t)(tl - t_lo) * CS + col]) * a.aux[tg];
-                    } else {
-                        v = img1[(size_t)t * CS + col];
+            // copy-out: lane <-> (row of the round, used column of the group); a round covers 64 / ncol rows of every episode
+            // of the group, each episode's share one contiguous run of HBM.  Everything lane-dependent is computed once per
+            // unit, the loop adds wave-uniform strides, and nothing in it loads from global memory (aux comes from LDS: a
+            // global load waits for every store issued before it -- that wait was half of this loop's time)
+            {
+                const unsigned rn = 65536u / (unsigned)ncol + 1u;
+                const int rl = (int)(((unsigned)lane * rn) >> 16), col = lane - rl * ncol;       // lane / ncol, lane % ncol
+                const int R = (int)((64u * rn) >> 16);                                            // rows per round
+                const int e = a.cgpe == 1 ? (int)(((unsigned)col * (65536u / (unsigned)D + 1u)) >> 16) : 0;
+                const int dd = a.cgpe == 1 ? col - e * D : col;
+                const bool on = rl < R && b0 + e < a.B;
+                // wave-uniform bases (scalar registers) + one 32-bit lane offset shared by both arrays
+                float* const pw = a.pos + ((size_t)b0 * T + t_lo) * D + d0;
+                float* const vw = a.vel + ((size_t)b0 * T + t_lo) * D + d0;
+                int off = (e * T + rl) * D + dd;
+                int li = rl * CS + col;
+                if (on) {
+                    for (int t = rl; t < t_n; t += R, off += R * D, li += R * CS) {
+                        float p, v;
+                        if (MP == MPK_MP_PROMP) {
+                            // vel = forward difference of the fp32 positions, last row repeats; t_lo == 0 here
+                            const bool last = t == T - 1;
+                            const int la = last ? li - CS : li;
+                            const float lo = img0[la], hi = img0[la + CS];
+                            p = last ? hi : lo;
+                            v = (hi - lo) * sAux[t];
+                        } else {
+                            p = img0[li];
+                            v = img1[li];
+                        }
+                        pw[off] = p;
+                        vw[off] = v;
                     }
-                    a.pos[ob + (size_t)t * D + dd] = p;
-                    a.vel[ob + (size_t)t * D + dd] = v;
                 }
             }
+            TW_B(tw_epi);
         }
     }
+#ifdef WIDE_TIME
+    __syncthreads();
+    if (lane == 0) {       // debug build: the wave's cycle budget instead of results, in the first floats of `vel`
+        float* o = a.vel + ((size_t)blockIdx.x * 4 + wave) * 8;
+        o[0] = (float)(__builtin_readcyclecounter() - tw_t0); o[1] = (float)tw_mfma; o[2] = (float)tw_sync;
+        o[3] = (float)tw_fetch; o[4] = (float)tw_epi; o[5] = (float)blockIdx.x; o[6] = (float)wave; o[7] = (float)gridDim.x;
+    }
+#endif
 }
 
 #ifndef MPK_DEVICE_ONLY
@@ -2872,9 +2983,11 @@ int launch_traj_wide(const DevCfg& c, const SharedTables& st, const float* param
     while (KC > 8 && (stage_bytes(KC) > 80 * 1024 || nout * KC / 4 * spans > 8)) KC >>= 1;
     while (KC > 4 && KC / 2 >= c.KP) KC >>= 1;                             // few columns (the D > 16 route): one short chunk
     const size_t epi_bytes = (size_t)4 * nimg * MT * 16 * 17 * sizeof(float);
-    const size_t lds = stage_bytes(KC) > epi_bytes ? stage_bytes(KC) : epi_bytes;
+    const size_t lds_main = stage_bytes(KC) > epi_bytes ? stage_bytes(KC) : epi_bytes;
+    const size_t lds = lds_main + (c.mp_type == MPK_MP_PRODMP ? 0 : (size_t)st.TS * sizeof(float));
     const int cgpe = c.D <= 16 ? 1 : (c.D + 15) / 16;
-    WideArgs wa{c, st.A, st.aux, st.TS, params, init_pos, init_vel, pos, vel, B, c.D <= 16 ? 16 / c.D : 1, 0, KC, n_rt, SA, cgpe};
+    WideArgs wa{c, st.A, st.aux, st.TS, params, init_pos, init_vel, pos, vel, B, c.D <= 16 ? 16 / c.D : 1, 0, KC, n_rt, SA, cgpe,
+                (int)(lds_main / sizeof(float))};
     if (cgpe > 1 && (long long)B * cgpe > 0x7fffffffLL - 8) return MPK_ENOTIMPL;
     const int n_groups = cgpe == 1 ? (B + wa.epg - 1) / wa.epg : B * cgpe;
     wa.n_units = (n_groups + 3) / 4;

@@ -408,8 +408,8 @@ def test_prodmp_flat_rounds_over_a_chunk_same_bits(T, D, nb, mpk_option):
     for B in (1, 3, 37):
         params, ip, iv = inputs(pc, bc, tc, B, seed=B + T)
         rng = np.random.default_rng(T + D)
-        params[:, 0] = torch.tensor(rng.uniform(0.4 * dur, 1.3 * dur, B), dtype=torch.float32)
-        params[:, 1] = torch.tensor(rng.uniform(-0.02 * dur, 0.12 * dur, B), dtype=torch.float32)
+        params[:, 0] = rng.uniform(0.4 * dur, 1.3 * dur, B)
+        params[:, 1] = rng.uniform(-0.02 * dur, 0.12 * dur, B)
         it = torch.tensor(rng.integers(0, 3, B) * dt, dtype=torch.float32, device="cuda")
         mpk_option("phase_flat", "0"); mpk_option("phase_chunk", "-1")
         p0, v0 = (x.clone() for x in eng.trajectory(params, ip, iv, it))

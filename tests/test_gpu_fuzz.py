@@ -419,3 +419,107 @@ def test_random_batched_episode_follows_the_oracle_sequence(seed, mpk_option):
             cond_p, cond_v = dp[:, n - 1], dv[:, n - 1]
         else:
             cond_p, cond_v = q.astype(np.float32), qd.astype(np.float32)
+
+
+# ---- part four: the validity gate -- episodes that end early and the others drifting out of lockstep -------------------------
+N_CASES_GATE = int(os.environ.get("MPK_FUZZ_CASES_GATE", "40"))
+START_GATE = int(os.environ.get("MPK_FUZZ_START_GATE", "0"))
+
+
+@pytest.mark.parametrize("seed", range(START_GATE, START_GATE + N_CASES_GATE))
+def test_random_batched_episode_with_validity_gate(seed, mpk_option):
+    """
+    BatchedBlackBox with position limits (table_tennis_env.py:303-309 on the batched path): a plan that leaves the limits
+    ends ITS episode without a plant step (black_box_wrapper.py:169-172), the others go on -- with per-episode init_time
+    once they no longer move in lockstep.  Against a per-episode replay of the same rules on the oracle: validity decided on
+    the plan the device produced, integer state, actions and plant state bit-exact given that plan, plans within 1e-5.
+    """
+    rng = np.random.default_rng(321_000 + seed)
+    pc, bc, tc, dt, dur, B, _ = random_case(rng)
+    B = min(B, 16)
+    D = tc.action_dim
+    T = int(round(dur / dt))
+    if T < 2:
+        pytest.skip("one-step horizon")
+    if tc.trajectory_generator_type == "prodmp" and 2.0 * dur / min(pc.tau, pc.tau_bound[0] if pc.learn_tau else pc.tau) > 5.9:
+        pytest.skip("beyond the ProDMP pre-computation range")
+    every = int(rng.integers(max(1, T // 6), T + 1))           # at most ~7 plans per episode
+    mpt = [2, 3, 5, float("inf")][int(rng.integers(0, 4))]
+    cod = bool(rng.random() < 0.5)
+    ctrl = str(rng.choice(["motor", "position", "velocity"]))
+    pg, dg = rng.uniform(0.2, 2.0, D), rng.uniform(0.02, 0.3, D)
+    lo, hi = -float(rng.uniform(0.3, 1.5)), float(rng.uniform(0.3, 1.5))
+    for key, vals in (("phase_flat", [-1, 0, 1]), ("phase_chunk", [-1, 1, 2, 3, 4, 7]), ("phase", [-1, 0, 1]),
+                      ("phase_table", [-1, 0, 1]), ("pd_quad", [-1, 0, 2]), ("pd_simple", [-1, 0, 1]), ("mapping", [-1, 1, 2])):
+        mpk_option(key, int(rng.choice(vals)))
+    L = float(rng.uniform(0.8, 2.5))
+    limits = (np.full(D, -L), np.full(D, L * float(rng.uniform(0.7, 1.3))))
+    bb = _batched_from_cfg(pc, bc, tc, dt, dur, B, ctrl, pg, dg, lo, hi, plant="double_integrator", replanning_every=every,
+                           max_planning_times=mpt, condition_on_desired=cod, pos_limits=limits)
+    P = bb.engine.num_params
+    n_phase = int(pc.learn_tau) + int(pc.learn_delay)
+    q0, qd0 = rng.uniform(-0.6, 0.6, (B, D)), rng.uniform(-0.3, 0.3, (B, D))
+    bb.reset(q0, qd0)
+    # per-episode oracle state
+    q, qd = q0.copy(), qd0.copy()
+    cond_p, cond_v = q0.astype(np.float32), qd0.astype(np.float32)
+    steps, plans, done = np.zeros(B, np.int64), np.zeros(B, np.int64), np.zeros(B, bool)
+    frozen = None
+    for k in range(12):
+        if done.all():
+            break
+        params = (rng.standard_normal((B, P)) * 0.5).astype(np.float32)
+        if pc.learn_tau:
+            params[:, 0] = rng.uniform(pc.tau_bound[0], pc.tau_bound[1], B)
+        if pc.learn_delay:
+            params[:, int(pc.learn_tau)] = rng.uniform(pc.delay_bound[0], pc.delay_bound[1], B)
+        was_done = done.copy()
+        out = bb.step(params)
+        torch.cuda.synchronize()
+        dp, dv = out["des_pos"].cpu().numpy(), out["des_vel"].cpu().numpy()
+        act = out["step_actions"].cpu().numpy()
+        seg_got = out["trajectory_length"].cpu().numpy()
+        p_eff = params.copy()
+        if n_phase:
+            if frozen is None:
+                bounds = ([pc.tau_bound] if pc.learn_tau else []) + ([pc.delay_bound] if pc.learn_delay else [])
+                frozen = np.stack([np.clip(params[:, i], np.float32(b[0]), np.float32(b[1])) for i, b in enumerate(bounds)], 1)
+            p_eff[:, :n_phase] = frozen
+        valid = np.all((dp.astype(np.float64) >= limits[0]) & (dp.astype(np.float64) <= limits[1]), axis=(1, 2))
+        assert np.array_equal(out["valid"].cpu().numpy(), valid), k
+        for b in range(B):
+            if was_done[b]:
+                assert seg_got[b] == 0 and np.all(act[b] == 0), (k, b)
+                continue
+            it = float(np.float32(steps[b] * dt))
+            rp, rv = O.get_trajectory(pc, bc, tc, p_eff[b:b + 1], dur, dt, it, cond_p[b:b + 1], cond_v[b:b + 1], dtype=np.float64)
+            if not np.isfinite(rp).all():
+                pytest.skip("degenerate basis")
+            p32, v32 = O.get_trajectory(pc, bc, tc, p_eff[b:b + 1], dur, dt, it, cond_p[b:b + 1], cond_v[b:b + 1], dtype=np.float32)
+            e = float(np.abs(p32.astype(np.float64) - rp).max())
+            slack = e if e > 2e-6 * float(np.abs(rp).max()) else 0.0
+            close(dp[b:b + 1], rp, f"plan {k} episode {b} pos [{bb.engine.last_kernel()}]", atol=slack)
+            if not valid[b]:
+                done[b] = True
+                assert seg_got[b] == 0 and np.all(act[b] == 0), (k, b)
+                continue
+            plans[b] += 1
+            g_break = T
+            if plans[b] < mpt:
+                g_break = min((steps[b] // every + 1) * every, T)
+            n = int(max(1, min(g_break - steps[b], T)))
+            assert seg_got[b] == n, (k, b, seg_got[b], n)
+            ra, qb, qdb = O.rollout(dp[b:b + 1], dv[b:b + 1], ctrl, pg, dg, lo, hi, "double_integrator", dt, q[b:b + 1], qd[b:b + 1],
+                                    n_steps=np.full(1, n))
+            q[b], qd[b] = qb[0], qdb[0]
+            assert np.array_equal(act[b], ra[0].astype(np.float32)), (k, b)
+            steps[b] += n
+            done[b] = steps[b] >= T
+            if cod:
+                cond_p[b], cond_v[b] = dp[b, n - 1], dv[b, n - 1]
+            else:
+                cond_p[b], cond_v[b] = q[b].astype(np.float32), qd[b].astype(np.float32)
+        assert np.array_equal(bb.q.cpu().numpy(), q) and np.array_equal(bb.qd.cpu().numpy(), qd), k
+        assert np.array_equal(bb.traj_steps.cpu().numpy(), steps) and np.array_equal(bb.plan_steps.cpu().numpy(), plans), k
+        assert np.array_equal(out["done"].cpu().numpy(), done), k
+    assert done.all()

@@ -497,7 +497,11 @@ def test_random_batched_episode_with_validity_gate(seed, mpk_option):
                 pytest.skip("degenerate basis")
             p32, v32 = O.get_trajectory(pc, bc, tc, p_eff[b:b + 1], dur, dt, it, cond_p[b:b + 1], cond_v[b:b + 1], dtype=np.float32)
             e = float(np.abs(p32.astype(np.float64) - rp).max())
-            slack = e if e > 2e-6 * float(np.abs(rp).max()) else 0.0
+            # a plan whose terms cancel (seed 83806: two weights of ~0.3 summing to 5e-4 over a saturated phase) carries the
+            # fp32 rounding of its TERMS, not of its result: both fp32 evaluations are then ~one ulp of a term off the float64
+            # one, each in its own direction
+            terms = float(np.abs(p_eff[b]).max()) * max(tc.weights_scale, tc.goal_scale, 1.0) + float(np.abs(cond_p[b]).max())
+            slack = (2.0 * e if e > 2e-6 * float(np.abs(rp).max()) else 0.0) + 2.0 * float(np.finfo(np.float32).eps) * terms
             close(dp[b:b + 1], rp, f"plan {k} episode {b} pos [{bb.engine.last_kernel()}]", atol=slack)
             if not valid[b]:
                 done[b] = True

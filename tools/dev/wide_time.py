@@ -19,7 +19,7 @@ v = out[1].flatten()[:512 * 4 * 8].cpu().numpy().reshape(-1, 8)
 v = v[v[:, 7] > 0]
 n = int(v[0, 7]) * 4
 v = v[:n]
-print(f"{n} waves ({int(v[0, 7])} workgroups); cycles per wave (100 MHz counter ticks x ... as the counter counts): ")
+print(f"{n} waves ({int(v[0, 7])} workgroups); shader-clock cycles per wave (s_memtime):")
 for name, i in (("total", 0), ("contraction", 1), ("barrier + commit + barrier", 2), ("fetch issue", 3), ("epilogue", 4)):
     c = v[:, i]
     print(f"  {name:28s} mean {c.mean():12.0f}  min {c.min():12.0f}  max {c.max():12.0f}  share of total {c.mean() / v[:, 0].mean() * 100:5.1f} %")

@@ -66,7 +66,9 @@ class VelController(BaseController):
 
 class MetaWorldController(BaseController):
     """metaworld end-effector control: xyz as a position delta, last entry = raw gripper opening
-    (meta_world_controller.py:15-25); host only -- there is no batchable metaworld plant"""
+    (meta_world_controller.py:15-25).  There is no batchable metaworld plant, so on the device it exists for a frozen state
+    only (``RolloutSpec("metaworld", D, plant="static")`` with ``TrajectoryEngine.trajectory_actions`` / ``pd_rollout``: it
+    runs on the motor kernels with unit position gains); environments are stepped on the host (``VectorBlackBox``)"""
 
     def get_action(self, des_pos, des_vel, c_pos, c_vel):
         *_, gripper = des_pos

@@ -36,6 +36,16 @@ class RolloutSpec:
     def __init__(self, controller_type: str, num_dof: int, p_gains=1.0, d_gains=0.5, act_low=-_INF, act_high=_INF,
                  plant: str = "static", dt: float = 0.0):
         controller_type = controller_type.lower()
+        # 'metaworld' (controller/meta_world_controller.py:15-25: xyz as a position delta, last entry = the raw gripper
+        # opening) is the motor controller with unit position gains, no velocity gains and a zero in the last entry of the
+        # current position -- 1.0 * (des - cur) + 0.0 * (..) is exact in float64 -- so it runs on the motor kernels; there is
+        # no batchable metaworld plant, hence open loop (frozen state) only: TrajectoryEngine.trajectory_actions / pd_rollout
+        self.metaworld = controller_type == "metaworld"
+        if self.metaworld:
+            if plant != "static":
+                raise ValueError("the metaworld controller has no device plant: use plant='static' (actions for a frozen "
+                                 "state) or step the environments on the host (VectorBlackBox)")
+            controller_type, p_gains, d_gains = "motor", 1.0, 0.0
         if controller_type not in CTRL_TYPES:
             raise ValueError(f"controller type {controller_type!r} has no device implementation; "
                              f"choose one of {list(CTRL_TYPES)}")
@@ -252,6 +262,14 @@ class TrajectoryEngine:
         out = h_out.clone()
         return out[0], out[1]
 
+    @staticmethod
+    def _metaworld_state(c_pos: torch.Tensor):
+        """current state as the motor kernels must see it for the metaworld controller: the gripper entry of the
+        position is not subtracted (0), velocities play no part"""
+        c_pos = c_pos.clone()
+        c_pos[:, -1] = 0.0
+        return c_pos, torch.zeros_like(c_pos)
+
     def trajectory_actions(self, params, init_pos, init_vel, spec: RolloutSpec, c_pos, c_vel, init_time: float = 0.0,
                            out=None):
         """Fused trajectory + open-loop controller actions for a state frozen over the plan (MPK_PLANT_STATIC)."""
@@ -262,6 +280,8 @@ class TrajectoryEngine:
         B, D, T = params.shape[0], self.num_dof, self.num_steps
         init_pos, init_vel = self._f32(init_pos, (B, D)), self._f32(init_vel, (B, D))
         c_pos, c_vel = self._f64(c_pos, (B, D)), self._f64(c_vel, (B, D))
+        if getattr(spec, "metaworld", False):
+            c_pos, c_vel = self._metaworld_state(c_pos)
         if out is None:
             pos, vel, act = (torch.empty((B, T, D), dtype=torch.float32, device=self.device) for _ in range(3))
         else:
@@ -358,6 +378,8 @@ class TrajectoryEngine:
             torch.empty((B, T, D), dtype=torch.float32, device=self.device) if want_actions else None)
         if n_steps is not None:
             n_steps = n_steps.to(device=self.device, dtype=torch.int32).contiguous()
+        if getattr(spec, "metaworld", False):
+            q, qd = self._metaworld_state(q)         # static plant: the caller's state is left as it is
         _lib.check(self._lib.mpk_pd_rollout(self._h, C.byref(spec.c), des_pos.data_ptr(), des_vel.data_ptr(),
                                             q.data_ptr(), qd.data_ptr(), _dptr(n_steps), _dptr(act), B, T,
                                             self._stream()))

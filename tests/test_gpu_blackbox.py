@@ -476,7 +476,9 @@ def test_fused_entry_points_cover_every_configuration(name):
 
 def test_rollout_spec_rejects_unknown_controllers_and_bad_gains():
     with pytest.raises(ValueError):
-        RolloutSpec("metaworld", 7)
+        RolloutSpec("impedance", 7)
+    with pytest.raises(ValueError):
+        RolloutSpec("metaworld", 7, plant="double_integrator", dt=0.01)     # open loop only: no batchable metaworld plant
     with pytest.raises(ValueError):
         RolloutSpec("motor", 7, p_gains=np.ones(3))
 
@@ -1289,3 +1291,32 @@ def test_episode_reset_is_one_exact_launch(B):
     assert not ts.any() and not ps.any() and not dn.any()
     eng.episode_reset(q, qd, ts, ps, dn)          # no initial state: zeros; no fp32 image
     assert not q.any() and not qd.any() and np.array_equal(cp.cpu().numpy(), q0.astype(np.float32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,B", [(4, 1), (4, 33), (2, 7)])
+def test_metaworld_controller_for_a_frozen_state_runs_on_the_motor_kernels(D, B):
+    """MetaWorldController.get_action (meta_world_controller.py:15-25) per step on the host against the device actions of
+    RolloutSpec('metaworld', plant='static') -- fused with the trajectory and on an existing one; clipped like every action"""
+    from fancy_gym_amd import TrajectoryEngine
+    ctrl = get_controller("metaworld")
+    eng = TrajectoryEngine(device=0, mp_type="promp", phase_type="linear", basis_type="rbf", num_dof=D, num_basis=4,
+                           dt=0.02, duration=0.5, tau=0.5)
+    rng = np.random.default_rng(D * 10 + B)
+    params = (rng.standard_normal((B, eng.num_params)) * 0.6).astype(np.float32)
+    ip, iv = np.zeros((B, D), np.float32), np.zeros((B, D), np.float32)
+    c_pos, c_vel = rng.uniform(-1, 1, (B, D)), rng.uniform(-1, 1, (B, D))
+    lo, hi = -0.7, 0.9
+    spec = RolloutSpec("metaworld", D, act_low=lo, act_high=hi, plant="static")
+    pos, vel, act = eng.trajectory_actions(params, ip, iv, spec, c_pos, c_vel)
+    dp, dv = pos.cpu().numpy(), vel.cpu().numpy()
+    want = np.empty_like(dp, dtype=np.float64)
+    for b in range(B):
+        for t in range(dp.shape[1]):
+            want[b, t] = np.clip(ctrl.get_action(dp[b, t], dv[b, t], c_pos[b], c_vel[b]), lo, hi)
+    assert np.array_equal(act.cpu().numpy(), want.astype(np.float32))
+    q, qd = torch.tensor(c_pos, device="cuda"), torch.tensor(c_vel, device="cuda")
+    act2 = eng.pd_rollout(spec, pos, vel, q, qd)
+    assert torch.equal(act2, act) and np.array_equal(q.cpu().numpy(), c_pos)      # the caller's state is untouched
+    with pytest.raises(ValueError, match="no device plant"):
+        RolloutSpec("metaworld", D, plant="double_integrator", dt=0.02)

@@ -417,7 +417,18 @@ def main():
     ev1.record(stream)
     torch.cuda.synchronize()
     kern_avg = ev0.elapsed_time(ev1) * 1e-3 / K
+    per_rank = None
     if dist is not None:
+        # outside the timed region, no new collective inside it: every rank's own wall-clock sample and its event-timed kernel
+        # average, so that a reader of the N-rank line can tell host jitter (one rank's wall sample off, its kernel time not)
+        # from imbalance (a rank's kernel time off) without a re-run
+        mine = torch.tensor([elapsed, kern_avg], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = {"per_rank_ms": [float(x[0].item()) * 1e3 for x in every],
+                    "per_rank_kernel_avg_us": [float(x[1].item()) * 1e6 for x in every]}
+        per_rank["kernel_avg_us_max"] = max(per_rank["per_rank_kernel_avg_us"])
+        per_rank["event_timed_value"] = world * B / (per_rank["kernel_avg_us_max"] * 1e-6)
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -634,6 +645,9 @@ def main():
                          "kernel": headline_kernel, "kernel_avg_us": kern_avg * 1e6,
                          "algorithmic_bytes_per_launch": BYTES_PER_TRAJ * B},
         }
+        if per_rank is not None:
+            # N > 1 only: `value` = world * B * K / max(per_rank_ms); event_timed_value = world * B / kernel_avg_us_max
+            out.update(per_rank)
         if two_stream is not None:
             out["two_stream"] = two_stream
         if streaming is not None:

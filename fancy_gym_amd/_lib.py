@@ -11,7 +11,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MPK_LIB") or os.path.join(_HERE, "libmpk.so")   # MPK_LIB: A/B builds of the library
 
-MPK_ABI_VERSION = 2
+MPK_ABI_VERSION = 3
 MP_TYPES = {"promp": 0, "dmp": 1, "prodmp": 2}
 PHASE_TYPES = {"linear": 0, "exp": 1}
 BASIS_TYPES = {"rbf": 0, "zero_rbf": 1, "prodmp": 2}
@@ -22,7 +22,7 @@ MPK_EINVAL, MPK_ENOTIMPL, MPK_EHIP, MPK_ERANGE, MPK_ENODEV, MPK_ECOMM = -1, -2, 
 MPK_COMM_ID_BYTES = 128
 MPK_OPT_AUTO = -1
 # mp_pytorch semantics that cannot be checked here: explicit switches (include/mpk.h); first entry = default
-RELATIVE_GOAL_MODES = {"after_scale": 0, "before_scale": 1}
+RELATIVE_GOAL_MODES = {"before_scale": 0, "after_scale": 1}   # first = the shipped default (include/mpk.h)
 GOAL_OFFSET_MODES = {"ignore": 0, "add": 1}
 SINGLE_RBF_MODES = {"unit_gap": 0, "refuse": 1}
 DMP_FIRST_SAMPLE_MODES = {"init": 0, "step": 1}
@@ -126,8 +126,23 @@ _lib: Optional[C.CDLL] = None
 
 # the files libmpk.so is built from, in the order mpk_source_hash() is defined over (include/mpk.h)
 _ROOT = os.path.dirname(_HERE)
+KERNEL_UNITS = ("mpk_traj_family.hip", "mpk_traj_launch.hip", "mpk_traj_wide.hip", "mpk_traj_phase.hip", "mpk_rollout.hip",
+                "mpk_misc.hip")          # translation units of the device code (mpk_traj_family.hip: once per MP type)
+KERNEL_HEADERS = ("mpk_dev.h", "mpk_tile.h", "mpk_traj_tiles.h", "mpk_traj_stream.h", "mpk_traj_flat.h", "mpk_traj_quad.h",
+                  "mpk_traj_pipe.h")
 SOURCE_FILES = (os.path.join(_ROOT, "include", "mpk.h"), os.path.join(_HERE, "csrc", "mpk_internal.h"),
-                os.path.join(_HERE, "csrc", "mpk_host.cpp"), os.path.join(_HERE, "csrc", "mpk_kernels.hip"))
+                os.path.join(_HERE, "csrc", "mpk_host.cpp")) + \
+    tuple(os.path.join(_HERE, "csrc", f) for f in KERNEL_HEADERS + KERNEL_UNITS)
+
+
+def stamp(extra_flags: str = "") -> Optional[str]:
+    """what a build stamps into the library: the source hash, plus a tag of the extra compile flags of an A/B build (such a
+    library is then NOT the checked-out sources for load() / _stale(): it needs MPK_LIB to be used)"""
+    import hashlib
+    h = source_hash()
+    if h is None or not extra_flags.strip():
+        return h
+    return h[:48] + "f1a9" + hashlib.sha256(extra_flags.strip().encode()).hexdigest()[:12]
 
 
 def source_hash() -> Optional[str]:

@@ -1,0 +1,225 @@
+// integer replanning state, episode reset, boundary-condition gather, validity reduction, inspection / self-test kernels
+#include "mpk_dev.h"
+
+namespace mpk {
+
+// ------------------------------------------------------------------------------------------------------------
+// integer replanning state
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_replan_advance(const ReplanDev rp, const int T, const int B) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    (void)replan_rule(rp, b, T, true);
+}
+
+#ifndef MPK_DEVICE_ONLY
+int launch_replan_advance(int32_t* traj_steps, int32_t* plan_steps, int32_t* seg_len, uint8_t* done, int every,
+                          int max_planning_times, int horizon, int T, int B, void* stream) {
+    ReplanDev rp;
+    rp.traj_steps = traj_steps; rp.plan_steps = plan_steps; rp.seg_len = seg_len; rp.done = done;
+    rp.every = every; rp.max_planning_times = max_planning_times; rp.horizon = horizon;
+    hipLaunchKernelGGL(k_replan_advance, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, rp, T, B);
+    MPK_LAUNCH_CHECK();
+    return MPK_OK;
+}
+#endif  // MPK_DEVICE_ONLY
+
+// BlackBoxWrapper.reset (black_box_wrapper.py:222-229) for B episodes: counters to zero, plant state from the caller's
+// initial state (NULL = zeros) and its fp32 image, the boundary condition of the first plan (black_box_wrapper.py:110-111)
+__global__ void __launch_bounds__(256) k_episode_reset(const double* __restrict__ init_q, const double* __restrict__ init_qd,
+                                                       double* __restrict__ q, double* __restrict__ qd,
+                                                       float* __restrict__ cond_pos, float* __restrict__ cond_vel,
+                                                       int32_t* __restrict__ traj_steps, int32_t* __restrict__ plan_steps,
+                                                       uint8_t* __restrict__ done, const int B, const int D) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e < (long)B * D) {
+        const double a = init_q ? init_q[e] : 0.0, b = init_qd ? init_qd[e] : 0.0;
+        q[e] = a; qd[e] = b;
+        if (cond_pos) { cond_pos[e] = (float)a; cond_vel[e] = (float)b; }
+    }
+    if (e < B) {
+        traj_steps[e] = 0; plan_steps[e] = 0; done[e] = 0;
+    }
+}
+
+#ifndef MPK_DEVICE_ONLY
+int launch_episode_reset(const double* init_q, const double* init_qd, double* q, double* qd, float* cond_pos,
+                         float* cond_vel, int32_t* traj_steps, int32_t* plan_steps, uint8_t* done, int B, int D,
+                         void* stream) {
+    hipLaunchKernelGGL(k_episode_reset, dim3((unsigned)(((long)B * D + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       init_q, init_qd, q, qd, cond_pos, cond_vel, traj_steps, plan_steps, done, B, D);
+    MPK_LAUNCH_CHECK();
+    return MPK_OK;
+}
+#endif  // MPK_DEVICE_ONLY
+
+// condition_on_desired (black_box_wrapper.py:199-201): the desired state at the last executed step of this plan
+__global__ void __launch_bounds__(256) k_condition_gather(const float* __restrict__ pos, const float* __restrict__ vel,
+                                                          const int32_t* __restrict__ seg_len,
+                                                          float* __restrict__ cond_pos, float* __restrict__ cond_vel,
+                                                          const int B, const int T, const int D) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)B * D) return;
+    const int b = (int)(e / D), d = (int)(e - (long)b * D);
+    int t = seg_len[b] - 1;
+    t = t < 0 ? 0 : (t > T - 1 ? T - 1 : t);
+    const size_t src = ((size_t)b * T + t) * D + d;
+    cond_pos[e] = pos[src];
+    cond_vel[e] = vel[src];
+}
+
+#ifndef MPK_DEVICE_ONLY
+int launch_condition_gather(const float* pos, const float* vel, const int32_t* seg_len, float* cond_pos, float* cond_vel,
+                            int B, int T, int D, void* stream) {
+    hipLaunchKernelGGL(k_condition_gather, dim3((unsigned)(((long)B * D + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       pos, vel, seg_len, cond_pos, cond_vel, B, T, D);
+    MPK_LAUNCH_CHECK();
+    return MPK_OK;
+}
+#endif  // MPK_DEVICE_ONLY
+
+// ------------------------------------------------------------------------------------------------------------
+// validity reduction: one wave per episode
+// ------------------------------------------------------------------------------------------------------------
+struct ValidArgs {
+    double lo[kMaxDofArgs], hi[kMaxDofArgs];
+    double tb[2], db[2];
+    int check_td, P, D, B, T;
+};
+
+__global__ void __launch_bounds__(256) k_validity(const ValidArgs v, const float* __restrict__ pos,
+                                                  const float* __restrict__ params, uint8_t* __restrict__ valid,
+                                                  double* __restrict__ penalty) {
+    __shared__ double s_lo[kMaxDofArgs], s_hi[kMaxDofArgs];   // a lane-dependent index into the kernarg arrays would
+    if (threadIdx.x < (unsigned)v.D) {                         // push the whole struct to scratch
+        const double* lo = v.lo;
+        const double* hi = v.hi;
+        s_lo[threadIdx.x] = lo[threadIdx.x];
+        s_hi[threadIdx.x] = hi[threadIdx.x];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= v.B) return;
+    const int n = v.T * v.D;
+    const float* p = pos + (size_t)b * n;
+    bool ok = true;
+    double over = 0.0, under = 0.0;
+    for (int e = lane; e < n; e += 64) {
+        const int d = e % v.D;
+        const double x = (double)p[e];
+        ok = ok && (x >= s_lo[d]) && (x <= s_hi[d]);
+        over += fmax(x - s_hi[d], 0.0);
+        under += fmax(s_lo[d] - x, 0.0);
+    }
+    double tpen = 0.0;
+    if (v.check_td) {
+        const double tau = (double)params[(size_t)b * v.P], delay = (double)params[(size_t)b * v.P + 1];
+        if (lane == 0) ok = ok && tau >= v.tb[0] && tau <= v.tb[1] && delay >= v.db[0] && delay <= v.db[1];
+        tpen = 3.0 * (fmax(0.0, tau - v.tb[1]) + fmax(0.0, v.tb[0] - tau)) +
+               3.0 * (fmax(0.0, delay - v.db[1]) + fmax(0.0, v.db[0] - delay));
+    }
+    const bool all_ok = __all(ok);
+    if (lane == 0) valid[b] = all_ok ? 1 : 0;
+    if (penalty) {
+        for (int m = 32; m >= 1; m >>= 1) {
+            over += __shfl_xor(over, m);
+            under += __shfl_xor(under, m);
+        }
+        // table_tennis_env.py:282-289: -(3*tau excess + 3*delay excess + mean(max(pos - high, 0)) + mean(max(low - pos, 0)))
+        if (lane == 0) penalty[b] = -(tpen + over / (double)n + under / (double)n);
+    }
+}
+
+#ifndef MPK_DEVICE_ONLY
+int launch_validity(const float* pos, const float* params, int P, int D, const double* lo, const double* hi,
+                    int check_td, const double* tb, const double* db, uint8_t* valid, double* penalty, int B, int T,
+                    void* stream) {
+    ValidArgs v{};
+    for (int d = 0; d < D; ++d) { v.lo[d] = lo[d]; v.hi[d] = hi[d]; }
+    if (check_td) { v.tb[0] = tb[0]; v.tb[1] = tb[1]; v.db[0] = db[0]; v.db[1] = db[1]; }
+    v.check_td = check_td; v.P = P; v.D = D; v.B = B; v.T = T;
+    hipLaunchKernelGGL(k_validity, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, v, pos, params, valid,
+                       penalty);
+    MPK_LAUNCH_CHECK();
+    return MPK_OK;
+}
+#endif  // MPK_DEVICE_ONLY
+
+// ------------------------------------------------------------------------------------------------------------
+// k_scaled_basis: traj_gen.show_scaled_basis (examples/mp_params_tuning.py:7) -- the basis functions times their
+// parameter scale at arbitrary times, evaluated by the row functions the trajectory kernels use
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_scaled_basis(const DevCfg c, const float* __restrict__ times, const int n,
+                                                      float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float t = times[i];
+    if (c.mp_type == MPK_MP_PRODMP) {
+        const int N = c.n_pc, K = c.nb + 1;
+        const double* PB = c.tab + 4 * (size_t)N;
+        const double* S = PB + 2 * (size_t)N * K;
+        const float s = scaled_time(t, c.delay, c.tau);
+        const int idx = min(prodmp_index(s, c.scaled_dt), N - 1);
+        for (int k = 0; k < K; ++k) out[(size_t)i * K + k] = (float)PB[(size_t)idx * K + k] * (float)S[k];
+    } else {
+        const double x = phase_f64(c, t, c.tau, c.delay, ExpLiteral());
+        rbf_cols(c, x, (double)c.ws, out + (size_t)i * c.nb, 1);
+    }
+}
+
+#ifndef MPK_DEVICE_ONLY
+int launch_scaled_basis(const DevCfg& c, const float* times, int n, float* out, void* stream) {
+    hipLaunchKernelGGL(k_scaled_basis, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, c, times, n, out);
+    MPK_LAUNCH_CHECK();
+    return MPK_OK;
+}
+#endif  // MPK_DEVICE_ONLY
+
+// ------------------------------------------------------------------------------------------------------------
+// self-test of div_exact (the table-index arithmetic): every fp32 numerator bit pattern in [first, first + count) against
+// the IEEE division, for one divisor
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_div_sweep(const float d, const uint32_t first, const uint64_t count,
+                                                   unsigned long long* __restrict__ mismatches) {
+    const ExactDiv x = make_exact_div(d);
+    unsigned long long bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (uint64_t)gridDim.x * 256) {
+        const float z = __uint_as_float(first + (uint32_t)i);
+        const float q0 = z / d, q1 = div_exact(z, x);
+        // identical bits, or both NaN (numerators that are NaN / inf are outside any time grid but harmless)
+        if (__float_as_uint(q0) != __float_as_uint(q1) && !(q0 != q0 && q1 != q1)) ++bad;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+#ifndef MPK_DEVICE_ONLY
+int launch_div_sweep(float d, uint32_t first, uint64_t count, unsigned long long* mismatches, void* stream) {
+    hipLaunchKernelGGL(k_div_sweep, dim3(4096), dim3(256), 0, (hipStream_t)stream, d, first, count, mismatches);
+    MPK_LAUNCH_CHECK();
+    return MPK_OK;
+}
+#endif  // MPK_DEVICE_ONLY
+
+}  // namespace mpk
+
+#ifdef MPK_TRACE
+// development builds only: fetch and clear the stamps (pairs of tag, shader clock)
+extern "C" int mpk_debug_trace(long long* out, int cap) {
+    // out: (tag, clock) pairs of the slots stamped since the last call, sorted by clock; returns their number
+    long long raw[256];
+    if (hipMemcpyFromSymbol(raw, HIP_SYMBOL(mpk::g_trace), sizeof(raw)) != hipSuccess) return -1;
+    int n = 0;
+    for (int t = 0; t < 256 && n < cap; ++t)
+        if (raw[t] != 0) { out[2 * n] = t; out[2 * n + 1] = raw[t]; ++n; }
+    for (int i = 1; i < n; ++i)
+        for (int j = i; j > 0 && out[2 * j + 1] < out[2 * j - 1]; --j) {
+            const long long t0 = out[2 * j], c0 = out[2 * j + 1];
+            out[2 * j] = out[2 * j - 2]; out[2 * j + 1] = out[2 * j - 1];
+            out[2 * j - 2] = t0; out[2 * j - 1] = c0;
+        }
+    static const long long zeros[256] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(mpk::g_trace), zeros, sizeof(zeros));
+    return n;
+}
+#endif

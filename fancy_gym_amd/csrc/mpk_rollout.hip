@@ -1,0 +1,467 @@
+// k_pd_rollout / k_pd_rollout_tiles / k_reacher_rollout: tracking controller + plant loop (+ SimpleReacher reward) on existing trajectories
+#include "mpk_tile.h"
+
+namespace mpk {
+
+// ------------------------------------------------------------------------------------------------------------
+// k_pd_rollout: controller + plant loop, one lane per (episode, DoF), float64, no FMA contraction
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pd_rollout(const RolloutDev rc, const int D, const float* __restrict__ des_pos,
+                                                    const float* __restrict__ des_vel, double* __restrict__ Q,
+                                                    double* __restrict__ QD, const int32_t* __restrict__ n_steps,
+                                                    float* __restrict__ actions, const int B, const int T) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)B * D) return;
+    const int b = (int)(e / D), d = (int)(e - (long)b * D);
+    double q = Q[e], qd = QD[e];
+    int n = n_steps ? n_steps[b] : T;
+    n = n < T ? n : T;
+    const double pg = rc.pg[d], dg = rc.dg[d], lo = rc.lo[d], hi = rc.hi[d], dt = rc.dt;
+    const size_t base = (size_t)b * T * D + d;
+    for (int t = 0; t < T; ++t) {
+        double u = 0.0;
+        if (t < n) {
+            const double dp = (double)des_pos[base + (size_t)t * D], dv = (double)des_vel[base + (size_t)t * D];
+            if (rc.controller_type == MPK_CTRL_MOTOR) u = pg * (dp - q) + dg * (dv - qd);
+            else if (rc.controller_type == MPK_CTRL_POSITION) u = dp;
+            else u = dv;
+            u = fmin(fmax(u, lo), hi);
+            if (rc.plant_type == MPK_PLANT_DOUBLE_INTEGRATOR) {
+                qd = qd + dt * u;
+                q = q + dt * qd;
+            }
+        }
+        if (actions) actions[base + (size_t)t * D] = (float)u;
+    }
+    if (rc.plant_type != MPK_PLANT_STATIC) {     // a static plant's state is an input only (callers may hold it const)
+        Q[e] = q;
+        QD[e] = qd;
+    }
+}
+
+// sin and cos of one float64 angle with a shared three-term Cody-Waite reduction by pi/2 and the classic degree-13 /
+// degree-14 kernels on [-pi/4, pi/4] (coefficients of fdlibm's __kernel_sin / __kernel_cos): ~1 ulp for |x| < 1e6, a
+// quarter of the instructions of two library calls.  Larger angles (a plant spun far out of range) take the library.
+__device__ __forceinline__ void sincos_lean(double x, double* sn, double* cs) {
+    if (!(fabs(x) < 1.0e6)) { sincos(x, sn, cs); return; }
+    const double k = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-k, 1.57079632673412561417e+00, x);
+    r = fma(-k, 6.07710050630396597660e-11, r);
+    r = fma(-k, 2.02226624879595063154e-21, r);
+    const double z = r * r;
+    double ps = 1.58969099521155010221e-10;
+    ps = fma(ps, z, -2.50507602534068634195e-08);
+    ps = fma(ps, z, 2.75573137070700676789e-06);
+    ps = fma(ps, z, -1.98412698298579493134e-04);
+    ps = fma(ps, z, 8.33333333332248946124e-03);
+    ps = fma(ps, z, -1.66666666666666324348e-01);
+    const double s = fma(r * z, ps, r);
+    double pc = -1.13596475577881948265e-11;
+    pc = fma(pc, z, 2.08757232129817482790e-09);
+    pc = fma(pc, z, -2.75573143513906633035e-07);
+    pc = fma(pc, z, 2.48015872894767294178e-05);
+    pc = fma(pc, z, -1.38888888888741095749e-03);
+    pc = fma(pc, z, 4.16666666666666019037e-02);
+    const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const int q = (int)k & 3;
+    const double a = (q & 1) ? c : s, b = (q & 1) ? s : c;
+    *sn = (q & 2) ? -a : a;
+    *cs = ((q + 1) & 2) ? -b : b;
+}
+
+// Tile-streaming variant (D <= 16, float4-aligned trajectories): a wave owns a group of 16/DP episodes and walks their
+// 16-step row tiles in order -- coalesced float4 loads of the desired (pos, vel) pieces one tile ahead, wave-private
+// LDS image, the serial controller + plant recurrence on the lanes (q == 0) as a register chain (float64, no FMA),
+// coalesced float4 store of the actions.  Same arithmetic, same bits as k_pd_rollout.
+struct PdArgs {
+    RolloutDev rc;
+    const float* des_pos;
+    const float* des_vel;
+    double* Q;
+    double* QD;
+    const int32_t* n_steps;
+    float* actions;
+    int D, sh, B, T, G;
+    unsigned inv_seg4;
+    // SimpleReacher reward (RW kernels): see k_reacher_rollout
+    const int32_t* step0;
+    const double* goal;
+    double* rewards;
+    int steps_before_reward;
+    int wt;                  // write-through stores of the actions (cache-resident batches)
+};
+
+// NG = groups per wave: with NG = 4 a wave owns four consecutive groups and lane quarter j runs group j's recurrence,
+// so four recurrences advance in parallel (the same idea as k_traj_quad); NG = 1 keeps more waves for small batches.
+// RW: additionally SimpleReacherEnv's per-step reward (simple_reacher.py:56-72).  The serial lanes leave the plant
+// position and the clipped action of every step of the tile in LDS as float64 (the position image reuses the desired
+// pos | vel staging, which the recurrence has already pulled into registers); then all 64 lanes turn (episode, step)
+// items into rewards in parallel -- cumulative joint angles, sin / cos, end effector, control cost, each summed left to
+// right as numpy does.  Only the recurrence itself stays serial.
+template <int NG, bool RW>
+__global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
+    constexpr int SLOT = 3 * kStageStride + (RW ? 2 * kStageStride : 0);   // floats per group slot
+    extern __shared__ __attribute__((aligned(16))) float smem[];           // [4 waves][NG][SLOT]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* sSt = smem + wave * (NG * SLOT);      // per group: desired pos | desired vel | actions (| u as float64)
+    const int D = a.D, T = a.T, B = a.B, SEG = 16 * D, DP = 1 << a.sh, NTW = 16 >> a.sh;
+    const int col = lane & 15, bl = col >> a.sh, d = col & (DP - 1);
+    const int jq = lane >> 4;                                // the group (of this wave's NG) whose recurrence the lane runs
+    const bool lane_serial = jq < NG && d < D;
+    const int seg4 = SEG >> 2;
+    const int sseg = (int)(((unsigned)lane * a.inv_seg4) >> 16);
+    const int w4 = (lane - sseg * seg4) * 4;
+    const unsigned rofs = (unsigned)(sseg * SEG + w4);
+    const size_t gofs = (size_t)sseg * T * D + w4;
+    const int NRT = (T + 15) >> 4;
+    double pgd = 0.0, dgd = 0.0, lod = 0.0, hid = 0.0;
+#pragma unroll
+    for (int dd = 0; dd < kMaxD; ++dd)
+        if (dd == d) { pgd = a.rc.pg[dd]; dgd = a.rc.dg[dd]; lod = a.rc.lo[dd]; hid = a.rc.hi[dd]; }
+    lod = __builtin_canonicalize(lod); hid = __builtin_canonicalize(hid);   // fmin / fmax need not quiet them per step
+    const double dtp = a.rc.dt;
+    const int nb8 = gridDim.x >> 3;
+    const int vb = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * nb8 + (blockIdx.x >> 3) : blockIdx.x;
+    const int units = (a.G + NG - 1) / NG;
+    for (int un = vb * 4 + wave; un < units; un += gridDim.x * 4) {
+        const int g0 = un * NG;
+        const int bs = (g0 + jq) * NTW + bl;                 // the serial lane's episode
+        const bool serial = lane_serial && g0 + jq < a.G && bs < B;
+        double qs = 0.0, qds = 0.0;
+        int nst = T;
+        if (serial) {
+            const size_t si = (size_t)bs * D + d;
+            qs = a.Q[si]; qds = a.QD[si];
+            if (a.n_steps) nst = min(a.n_steps[bs], T);
+        }
+        bool mover[NG];
+        const float* gp[NG];
+        const float* gv[NG];
+        f32x4 lp[NG], lv[NG];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int b0 = (g0 + j) * NTW;
+            mover[j] = g0 + j < a.G && sseg < NTW && b0 + sseg < B;
+            gp[j] = a.des_pos + (size_t)b0 * T * D + gofs;
+            gv[j] = a.des_vel + (size_t)b0 * T * D + gofs;
+            lp[j] = f32x4{0, 0, 0, 0}; lv[j] = lp[j];
+            if (mover[j] && w4 < min(16, T) * D) {
+                lp[j] = *reinterpret_cast<const f32x4*>(gp[j]);
+                lv[j] = *reinterpret_cast<const f32x4*>(gv[j]);
+            }
+        }
+        for (int rt = 0; rt < NRT; ++rt) {
+            const int rows = min(16, T - rt * 16);
+#pragma unroll
+            for (int j = 0; j < NG; ++j) {
+                if (mover[j] && w4 < rows * D) {
+                    *reinterpret_cast<f32x4*>(sSt + j * SLOT + rofs) = lp[j];
+                    *reinterpret_cast<f32x4*>(sSt + j * SLOT + kStageStride + rofs) = lv[j];
+                }
+            }
+            if (rt + 1 < NRT) {   // next tile's pieces travel under this tile's recurrence
+                const int rows_n = min(16, T - (rt + 1) * 16);
+#pragma unroll
+                for (int j = 0; j < NG; ++j) {
+                    if (mover[j] && w4 < rows_n * D) {
+                        lp[j] = *reinterpret_cast<const f32x4*>(gp[j] + (size_t)(rt + 1) * SEG);
+                        lv[j] = *reinterpret_cast<const f32x4*>(gv[j] + (size_t)(rt + 1) * SEG);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (serial) {
+                // the 16 steps of the tile as straight-line code per (controller, plant): a run-time switch inside the
+                // step would cost more instructions than the step's arithmetic, and this chain is the critical path
+                float* sg = sSt + jq * SLOT;
+                const int o0 = bl * SEG + d;
+                // branch-free steps (pd_tile_steps, the closed-loop trajectory kernels' chain: a step past the executed
+                // ones -- or past T in the last tile -- is computed and discarded by selects; round 2 measured 260 -> 125-180
+                // cycles per step for it there); MASKED = false where every serial lane executes the whole tile
+                const bool full_tile = rows == 16 && __all(nst >= rt * 16 + 16) != 0;   // over the serial lanes: wave-uniform
+                auto tile_steps = [&](auto ctrl_tag, auto plant_tag) {
+                    constexpr int CTRL = decltype(ctrl_tag)::value;
+                    constexpr bool INTEG = decltype(plant_tag)::value == MPK_PLANT_DOUBLE_INTEGRATOR;
+                    double* q64 = reinterpret_cast<double*>(sg) + col;
+                    double* u64 = reinterpret_cast<double*>(sg + 3 * kStageStride) + col;
+                    if (full_tile)
+                        pd_tile_steps<CTRL, false, INTEG, RW>(sg + o0, sg + kStageStride + o0, sg + 2 * kStageStride + o0, D, rt * 16,
+                                                              nst, pgd, dgd, lod, hid, dtp, qs, qds, q64, u64);
+                    else
+                        pd_tile_steps<CTRL, true, INTEG, RW>(sg + o0, sg + kStageStride + o0, sg + 2 * kStageStride + o0, D, rt * 16,
+                                                             nst, pgd, dgd, lod, hid, dtp, qs, qds, q64, u64);
+                };
+                using std::integral_constant;
+                const bool dint = a.rc.plant_type == MPK_PLANT_DOUBLE_INTEGRATOR;
+                switch (a.rc.controller_type) {
+                    case MPK_CTRL_MOTOR:
+                        if (dint) tile_steps(integral_constant<int, MPK_CTRL_MOTOR>(), integral_constant<int, MPK_PLANT_DOUBLE_INTEGRATOR>());
+                        else tile_steps(integral_constant<int, MPK_CTRL_MOTOR>(), integral_constant<int, MPK_PLANT_STATIC>());
+                        break;
+                    case MPK_CTRL_POSITION:
+                        if (dint) tile_steps(integral_constant<int, MPK_CTRL_POSITION>(), integral_constant<int, MPK_PLANT_DOUBLE_INTEGRATOR>());
+                        else tile_steps(integral_constant<int, MPK_CTRL_POSITION>(), integral_constant<int, MPK_PLANT_STATIC>());
+                        break;
+                    default:
+                        if (dint) tile_steps(integral_constant<int, MPK_CTRL_VELOCITY>(), integral_constant<int, MPK_PLANT_DOUBLE_INTEGRATOR>());
+                        else tile_steps(integral_constant<int, MPK_CTRL_VELOCITY>(), integral_constant<int, MPK_PLANT_STATIC>());
+                        break;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (RW) {
+                const int items = NG * NTW * rows;            // (group, episode in group, step in tile)
+                for (int it = lane; it < items; it += 64) {
+                    const int tl = it % rows, je = it / rows;
+                    const int e = je % NTW, j = je / NTW;
+                    const int b = (g0 + j) * NTW + e;
+                    if (g0 + j < a.G && b < B) {
+                        const int t = rt * 16 + tl;
+                        const int ns = a.n_steps ? min(a.n_steps[b], T) : T;
+                        double r = 0.0;
+                        if (t < ns) {
+                            const double* qv = reinterpret_cast<const double*>(sSt + j * SLOT) + tl * 16 + e * DP;
+                            const double* uv = reinterpret_cast<const double*>(sSt + j * SLOT + 3 * kStageStride) + tl * 16 + e * DP;
+                            double ang = 0.0, ex = 0.0, ey = 0.0, ctrl = 0.0;
+                            for (int dd = 0; dd < D; ++dd) {
+                                ang = dd == 0 ? qv[dd] : ang + qv[dd];      // np.cumsum(joint_angles)
+                                double sn, cs;
+                                sincos_lean(ang, &sn, &cs);
+                                ex = dd == 0 ? cs : ex + cs;                // unit links (base_reacher.py:19,97-104)
+                                ey = dd == 0 ? sn : ey + sn;
+                                ctrl = dd == 0 ? uv[dd] * uv[dd] : ctrl + uv[dd] * uv[dd];
+                            }
+                            double rdist = 0.0;
+                            if ((a.step0 ? a.step0[b] : 0) + t >= a.steps_before_reward) {
+                                const double dx = ex - a.goal[2 * (size_t)b], dy = ey - a.goal[2 * (size_t)b + 1];
+                                rdist = 0.0 - sqrt(dx * dx + dy * dy);
+                            }
+                            r = rdist - ctrl;
+                        }
+                        a.rewards[(size_t)b * T + t] = r;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (a.actions) {
+#pragma unroll
+                for (int j = 0; j < NG; ++j) {
+                    if (mover[j] && w4 < rows * D) {
+                        float* dst = a.actions + (size_t)(g0 + j) * NTW * T * D + gofs + (size_t)rt * SEG;
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(sSt + j * SLOT + 2 * kStageStride + rofs);
+                        if (a.wt) store16<true>(dst, v);      // cache-resident actions: write-through (wave-uniform)
+                        else store16<false>(dst, v);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (serial) {
+            const size_t si = (size_t)bs * D + d;
+            if (a.rc.plant_type != MPK_PLANT_STATIC) { a.Q[si] = qs; a.QD[si] = qds; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_reacher_rollout: k_pd_rollout + SimpleReacherEnv's per-step reward (simple_reacher.py:56-72).  One lane per
+// (episode, DoF), 64 / D episodes per wave; the reward couples an episode's DoFs (cumulative joint angles -> end
+// effector, base_reacher.py:97-104), which is a segmented scan over the D neighbouring lanes.  float64 without FMA
+// contraction; controller, clip and plant are the operations of k_pd_rollout (bit-exact), the scans add in tree order
+// (numpy: left to right), so rewards agree with the oracle to rounding, not bit for bit.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double seg_scan(double v, int d, int D) {
+    // inclusive prefix sum over the D consecutive lanes of a segment (lane's position d)
+    for (int off = 1; off < D; off <<= 1) {
+        const double up = __shfl_up(v, off);
+        if (d >= off) v += up;
+    }
+    return v;
+}
+
+__device__ __forceinline__ void seg_scan3(double& a, double& b, double& c, int d, int D) {
+    // three scans sharing the source-lane arithmetic and the predicate
+    for (int off = 1; off < D; off <<= 1) {
+        const double ua = __shfl_up(a, off), ub = __shfl_up(b, off), uc = __shfl_up(c, off);
+        if (d >= off) { a += ua; b += ub; c += uc; }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_reacher_rollout(const RolloutDev rc, const int D,
+                                                         const float* __restrict__ des_pos,
+                                                         const float* __restrict__ des_vel, double* __restrict__ Q,
+                                                         double* __restrict__ QD, const int32_t* __restrict__ n_steps,
+                                                         const int32_t* __restrict__ step0,
+                                                         const double* __restrict__ goal, const int steps_before_reward,
+                                                         float* __restrict__ actions, double* __restrict__ rewards,
+                                                         const int B, const int T) {
+    __shared__ double s_g[4 * kMaxDofArgs];      // gains / bounds: a lane-dependent index into the kernarg arrays would
+    if (threadIdx.x < (unsigned)D) {            // push the whole struct to scratch
+        const double *pg = rc.pg, *dg = rc.dg, *lo = rc.lo, *hi = rc.hi;
+        s_g[threadIdx.x] = pg[threadIdx.x];
+        s_g[kMaxDofArgs + threadIdx.x] = dg[threadIdx.x];
+        s_g[2 * kMaxDofArgs + threadIdx.x] = lo[threadIdx.x];
+        s_g[3 * kMaxDofArgs + threadIdx.x] = hi[threadIdx.x];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int epw = 64 / D;                                       // episodes per wave
+    const int el = lane / D, d = lane - el * D;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long bl = wave * epw + el;
+    const bool on = el < epw && bl < B;
+    const int b = on ? (int)bl : 0;
+    const size_t sidx = (size_t)b * D + d;
+    double q = on ? Q[sidx] : 0.0, qd = on ? QD[sidx] : 0.0;
+    int n = n_steps ? n_steps[b] : T;
+    n = !on ? 0 : (n < T ? n : T);
+    const int s0 = step0 ? step0[b] : 0;
+    const double gx = goal[2 * (size_t)b], gy = goal[2 * (size_t)b + 1];
+    const double pg = s_g[d], dg = s_g[kMaxDofArgs + d], lo = s_g[2 * kMaxDofArgs + d], hi = s_g[3 * kMaxDofArgs + d];
+    const double dt = rc.dt;
+    int nmax = n;                                                 // the wave runs to its longest episode
+    for (int m = 32; m >= 1; m >>= 1) nmax = max(nmax, __shfl_xor(nmax, m));
+    const size_t base = (size_t)b * T * D + d;
+    constexpr int kAhead = 8;                                     // desired states are fetched 8 steps at a time: one
+    for (int t0 = 0; t0 < nmax; t0 += kAhead) {                  // memory round trip per 8 serial steps, not per step
+        float dpv[kAhead], dvv[kAhead];
+#pragma unroll
+        for (int i = 0; i < kAhead; ++i) {
+            const bool ld = t0 + i < n;
+            dpv[i] = ld ? des_pos[base + (size_t)(t0 + i) * D] : 0.0f;
+            dvv[i] = ld ? des_vel[base + (size_t)(t0 + i) * D] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < kAhead; ++i) {
+            const int t = t0 + i;
+            if (t >= nmax) break;
+            const bool live = t < n;
+            double u = 0.0;
+            if (live) {
+                const double dp = (double)dpv[i], dv = (double)dvv[i];
+                if (rc.controller_type == MPK_CTRL_MOTOR) u = pg * (dp - q) + dg * (dv - qd);
+                else if (rc.controller_type == MPK_CTRL_POSITION) u = dp;
+                else u = dv;
+                u = fmin(fmax(u, lo), hi);
+                qd = qd + dt * u;                  // base_reacher_torque.py:25-26
+                q = q + dt * qd;
+                if (actions) actions[base + (size_t)t * D] = (float)u;
+            }
+            const double ang = seg_scan(q, d, D);               // np.cumsum(joint_angles)
+            double sn, cs;
+            sincos_lean(ang, &sn, &cs);
+            double ex = cs, ey = sn, ctrl = u * u;              // unit link lengths (base_reacher.py:19): sums over the links
+            seg_scan3(ex, ey, ctrl, d, D);
+            if (live && d == D - 1) {
+                double rdist = 0.0;
+                if (s0 + t >= steps_before_reward) {
+                    const double dx = ex - gx, dy = ey - gy;
+                    rdist = 0.0 - sqrt(dx * dx + dy * dy);
+                }
+                rewards[(size_t)b * T + t] = rdist - ctrl;
+            }
+        }
+    }
+    if (on) {
+        for (int t = n; t < T; ++t) {
+            if (actions) actions[base + (size_t)t * D] = 0.0f;
+            if (d == D - 1) rewards[(size_t)b * T + t] = 0.0;
+        }
+        Q[sidx] = q; QD[sidx] = qd;
+    }
+}
+
+#ifndef MPK_DEVICE_ONLY
+int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
+                           const float* des_vel, double* q, double* qd, const int32_t* n_steps, const int32_t* step0,
+                           const double* goal, int steps_before_reward, float* actions, double* rewards, int B, int T,
+                           void* stream, const Tuning& tune) {
+    auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    const int last_rows = T - (T - 1) / 16 * 16;
+    const bool tiles_ok = D >= 1 && D <= kMaxD && (T * D) % 4 == 0 && (last_rows * D) % 4 == 0 && aligned16(des_pos) &&
+                          aligned16(des_vel) && (!actions || aligned16(actions)) && tune.pd_simple != 1;
+    if (tiles_ok) {
+        // the tile-streaming rollout with the reward evaluated per tile by all lanes (see k_pd_rollout_tiles, RW)
+        PdArgs pa;
+        pa.rc = rc; pa.des_pos = des_pos; pa.des_vel = des_vel; pa.Q = q; pa.QD = qd; pa.n_steps = n_steps;
+        pa.actions = actions; pa.D = D; pa.B = B; pa.T = T;
+        pa.wt = (double)B * T * D * 12.0 <= 96.0 * 1024 * 1024 ? 1 : 0;     // desired (pos, vel) + actions stay cached
+        if (tune.write_through >= 0) pa.wt = tune.write_through != 0 ? 1 : 0;
+        pa.step0 = step0; pa.goal = goal; pa.rewards = rewards; pa.steps_before_reward = steps_before_reward;
+        int sh = 0;
+        while ((1 << sh) < D) ++sh;
+        pa.sh = sh;
+        const int NTW = 16 >> sh;
+        pa.G = (B + NTW - 1) / NTW;
+        pa.inv_seg4 = 65536u / (unsigned)(4 * D) + 1u;
+        const int quad_mode = tune.pd_quad < 0 ? 1 : tune.pd_quad;
+        const bool quad = quad_mode == 2 || (quad_mode == 1 && pa.G >= 4 * 256 * 4);   // measured (profiles/r03_rollout.md): 19.3 vs 23.9 us at 4096 groups, 15.6 vs 14.6 at 2048
+        const int units = quad ? (pa.G + 3) / 4 : pa.G;
+        int blocks = (units + 3) / 4;
+        if (blocks > 2048) blocks = 2048;
+        if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;
+        const size_t lds = (size_t)4 * (quad ? 4 : 1) * 5 * kStageStride * sizeof(float);
+        auto go = [&](auto kern) -> int {
+            if (lds > 64 * 1024) {
+                hipError_t e = allow_full_lds(kern);
+                if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return MPK_EHIP; }
+            }
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, (hipStream_t)stream, pa);
+            MPK_LAUNCH_CHECK();
+            return MPK_OK;
+        };
+        return quad ? go(k_pd_rollout_tiles<4, true>) : go(k_pd_rollout_tiles<1, true>);
+    }
+    const int epw = 64 / D;
+    const long waves = ((long)B + epw - 1) / epw;
+    hipLaunchKernelGGL(k_reacher_rollout, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rc, D,
+                       des_pos, des_vel, q, qd, n_steps, step0, goal, steps_before_reward, actions, rewards, B, T);
+    MPK_LAUNCH_CHECK();
+    return MPK_OK;
+}
+#endif  // MPK_DEVICE_ONLY
+
+#ifndef MPK_DEVICE_ONLY
+int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const float* des_vel, double* q, double* qd,
+                      const int32_t* n_steps, float* actions, int B, int T, void* stream, const Tuning& tune) {
+    auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    const int last_rows = T - (T - 1) / 16 * 16;
+    const bool tiles_ok = D >= 1 && D <= kMaxD && (T * D) % 4 == 0 && (last_rows * D) % 4 == 0 && aligned16(des_pos) &&
+                          aligned16(des_vel) && (!actions || aligned16(actions)) && tune.pd_simple != 1;
+    if (tiles_ok) {
+        PdArgs pa;
+        pa.rc = rc; pa.des_pos = des_pos; pa.des_vel = des_vel; pa.Q = q; pa.QD = qd; pa.n_steps = n_steps;
+        pa.actions = actions; pa.D = D; pa.B = B; pa.T = T;
+        pa.wt = (double)B * T * D * 12.0 <= 96.0 * 1024 * 1024 ? 1 : 0;     // desired (pos, vel) + actions stay cached
+        if (tune.write_through >= 0) pa.wt = tune.write_through != 0 ? 1 : 0;
+        pa.step0 = nullptr; pa.goal = nullptr; pa.rewards = nullptr; pa.steps_before_reward = 0;
+        int sh = 0;
+        while ((1 << sh) < D) ++sh;
+        pa.sh = sh;
+        const int NTW = 16 >> sh;
+        pa.G = (B + NTW - 1) / NTW;
+        pa.inv_seg4 = 65536u / (unsigned)(4 * D) + 1u;
+        // four groups per wave once that still leaves every CU several waves ("pd_quad": 0 off, 2 force)
+        const int quad_mode = tune.pd_quad < 0 ? 1 : tune.pd_quad;
+        const bool quad = quad_mode == 2 || (quad_mode == 1 && pa.G >= 4 * 256 * 4);   // measured (profiles/r03_rollout.md): 19.3 vs 23.9 us at 4096 groups, 15.6 vs 14.6 at 2048
+        const int units = quad ? (pa.G + 3) / 4 : pa.G;
+        int blocks = (units + 3) / 4;
+        if (blocks > 2048) blocks = 2048;
+        if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;
+        const size_t lds = (size_t)4 * (quad ? 4 : 1) * 3 * kStageStride * sizeof(float);
+        if (quad) hipLaunchKernelGGL((k_pd_rollout_tiles<4, false>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, pa);
+        else hipLaunchKernelGGL((k_pd_rollout_tiles<1, false>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, pa);
+        MPK_LAUNCH_CHECK();
+        return MPK_OK;
+    }
+    const long n = (long)B * D;
+    const int blocks = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(k_pd_rollout, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rc, D, des_pos, des_vel, q, qd,
+                       n_steps, actions, B, T);
+    MPK_LAUNCH_CHECK();
+    return MPK_OK;
+}
+#endif  // MPK_DEVICE_ONLY
+
+}  // namespace mpk

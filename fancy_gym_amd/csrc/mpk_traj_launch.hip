@@ -1,0 +1,335 @@
+// k_build_shared (phase / exponential-kernel evaluation for a phase all episodes share) and launch_traj_shared: the rule
+// that picks a shared-phase trajectory kernel family, its work decomposition and its store policy for a launch.
+#include "mpk_tile.h"
+#include "mpk_traj_quad.h"   // kQuadImg, kPipeGroups: the LDS budgets the rule checks
+#include "mpk_traj_pipe.h"
+#include "mpk_traj_stream.h" // kChunkGroups
+
+namespace mpk {
+
+size_t shared_tables_floats(const DevCfg& c, int* TS, int* n_out) {
+    const int TP = (c.T + 15) / 16 * 16;
+    const int ts = ((TP + 15) / 32) * 32 + 16;  // TS % 32 == 16: the two k rows of a 32-lane LDS read hit disjoint banks
+    const int no = c.mp_type == MPK_MP_PRODMP ? 2 : (c.mp_type == MPK_MP_PROMP ? 3 : 1);
+    *TS = ts;
+    *n_out = no;
+    // the k-major table A [n_out][KP][TS] (MFMA fragment loads) followed by its step-major copy At [TS][n_out * KP]
+    // (one contiguous row per time step: the serial role of k_traj_split reads it with scalar loads)
+    return 2 * (size_t)no * c.KP * ts;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_build_shared: one block; A[(j*KP + k)*TS + t], aux[t]
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_build_shared(const DevCfg c, const float init_time, float* __restrict__ A,
+                                                      float* __restrict__ aux, const int TS, const int n_out,
+                                                      int32_t* __restrict__ idx_out, int32_t* __restrict__ flag) {
+    const int tid = threadIdx.x, T = c.T, KP = c.KP;
+    for (int i = tid; i < n_out * KP * TS; i += 256) A[i] = 0.0f;
+    for (int i = tid; i < TS; i += 256) aux[i] = 0.0f;
+    __syncthreads();
+    if (c.mp_type == MPK_MP_PRODMP) {
+        const float sb = scaled_time(init_time, c.delay, c.tau);
+        const int idxb = min(prodmp_index(sb, c.scaled_dt), c.n_pc - 1);
+        ProdmpBC bc;
+        prodmp_bc(c, idxb, bc);
+        if (idx_out && tid == 0) idx_out[T] = idxb;
+        for (int t = tid; t < T; t += 256) {
+            const float time = c.base_times[t] + init_time;
+            const float s = scaled_time(time, c.delay, c.tau);
+            if (s > (float)c.len_factor) atomicOr(flag, 1);
+            const int idx = min(prodmp_index(s, c.scaled_dt), c.n_pc - 1);
+            if (idx_out) idx_out[t] = idx;
+            double xi[4];
+            prodmp_xi(c, bc, idx, xi);
+            for (int k = 0; k < c.KT; ++k) {
+                float h, hv;
+                prodmp_col(c, bc, idx, xi, k, (double)c.tau, div_pos(1.0, (double)c.tau), &h, &hv);
+                A[(size_t)(0 * KP + k) * TS + t] = h;
+                A[(size_t)(1 * KP + k) * TS + t] = hv;
+            }
+        }
+    } else if (c.mp_type == MPK_MP_PROMP) {
+        for (int t = tid; t < T; t += 256) {
+            const float time = c.base_times[t] + init_time;
+            const double x = phase_f64(c, time, c.tau, c.delay, ExpLiteral());
+            rbf_cols(c, x, (double)c.ws, A + t, TS);
+            if (c.KT > c.nb) A[(size_t)c.nb * TS + t] = 1.0f;  // zero-padded family: + init_pos
+        }
+        __syncthreads();
+        // velocity = forward difference: rows (t+1, t), last row repeats (T-1, T-2)
+        for (int t = tid; t < T; t += 256) {
+            const int th = t < T - 1 ? t + 1 : T - 1, tl = t < T - 1 ? t : T - 2;
+            for (int k = 0; k < c.KT; ++k) {
+                A[(size_t)(1 * KP + k) * TS + t] = A[(size_t)k * TS + th];
+                A[(size_t)(2 * KP + k) * TS + t] = A[(size_t)k * TS + tl];
+            }
+            // reciprocal of the fp32 time step (one IEEE divide per row here instead of one per output element later)
+            aux[t] = 1.0f / ((c.base_times[th] + init_time) - (c.base_times[tl] + init_time));
+        }
+    } else {  // DMP: forcing rows phi*x, aux = diff of the fp32 scaled times
+        for (int t = tid; t < T; t += 256) {
+            const float time = c.base_times[t] + init_time;
+            const double x = phase_f64(c, time, c.tau, c.delay, ExpLiteral());
+            rbf_cols(c, x, x * (double)c.ws, A + t, TS);
+            if (t < T - 1) {
+                const float s0 = scaled_time(time, c.delay, c.tau);
+                const float s1 = scaled_time(c.base_times[t + 1] + init_time, c.delay, c.tau);
+                aux[t] = s1 - s0;
+            }
+        }
+    }
+    // step-major copy behind the k-major table: one contiguous row per step; with two outputs (prodmp) the row is
+    // interleaved [pos_0 vel_0 pos_1 vel_1 ..] -- the operand pairs of the packed fp32 FMA the serial role contracts with
+    __syncthreads();
+    const int RS = n_out * KP;
+    float* At = A + (size_t)RS * TS;
+    for (int i = tid; i < RS * TS; i += 256) {
+        const int t = i / RS, e = i - t * RS;
+        const int jk = n_out == 2 ? (e & 1) * KP + (e >> 1) : e;
+        At[i] = A[(size_t)jk * TS + t];
+    }
+}
+
+#ifndef MPK_DEVICE_ONLY
+int launch_build_shared(const DevCfg& c, float init_time, const SharedTables& st, int32_t* idx_out,
+                        int32_t* range_flag, void* stream) {
+    if (c.mp_type == MPK_MP_PROMP && c.T < 2) {
+        set_error("promp needs at least two time steps for the finite-difference velocity");
+        return MPK_EINVAL;
+    }
+    hipLaunchKernelGGL(k_build_shared, dim3(1), dim3(256), 0, (hipStream_t)stream, c, init_time, st.A, st.aux, st.TS,
+                       st.n_out, idx_out, range_flag);
+    MPK_LAUNCH_CHECK();
+    return MPK_OK;
+}
+#endif  // MPK_DEVICE_ONLY
+
+#ifndef MPK_DEVICE_ONLY
+#ifndef MPK_AMALGAMATED
+// defined in mpk_traj_family.hip (one translation unit per MP type)
+template <int MP>
+int launch_traj_ct(const TrajArgs& ta, const ActArgs& aa, int ct, bool stream_mode, bool write_through, bool bulk,
+                   int quad, int blocks, size_t lds, void* stream, bool split, bool pipe);
+extern template int launch_traj_ct<MPK_MP_PROMP>(const TrajArgs&, const ActArgs&, int, bool, bool, bool, int, int, size_t, void*, bool, bool);
+extern template int launch_traj_ct<MPK_MP_DMP>(const TrajArgs&, const ActArgs&, int, bool, bool, bool, int, int, size_t, void*, bool, bool);
+extern template int launch_traj_ct<MPK_MP_PRODMP>(const TrajArgs&, const ActArgs&, int, bool, bool, bool, int, int, size_t, void*, bool, bool);
+#endif
+#endif
+
+#ifndef MPK_DEVICE_ONLY
+int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* params, const float* init_pos,
+                       const float* init_vel, float* pos, float* vel, float* actions, const RolloutDev* rc,
+                       const double* c_pos, const double* c_vel, double* q_state, double* qd_state,
+                       const int32_t* n_steps, int B, int num_cu, void* stream, const char** kernel_name,
+                       const Tuning& tune, const ReplanDev* rp) {
+    TrajArgs ta;
+    ta.nrt_magic = 0; ta.gstride = 0; ta.wt = 0; ta.flat_img = 0;
+    if (rp) ta.rp = *rp;
+    const bool closed = q_state != nullptr;
+    ta.q_state = q_state; ta.qd_state = qd_state; ta.n_steps = n_steps; ta.plant_dt = rc ? rc->dt : 0.0;
+    ta.c = c; ta.A = st.A; ta.aux = st.aux; ta.TS = st.TS;
+    ta.params = params; ta.init_pos = init_pos; ta.init_vel = init_vel;
+    ta.pos = pos; ta.vel = vel; ta.actions = actions; ta.c_pos = c_pos; ta.c_vel = c_vel;
+    ta.B = B;
+    int sh = 0;
+    while ((1 << sh) < c.D) ++sh;  // DP = next power of two >= D (<= 16)
+    ta.sh = sh;
+    const int NTW = 16 >> sh;
+    ta.G = (B + NTW - 1) / NTW;
+    const bool act = actions != nullptr;
+    const int nst = 2 + (act ? 1 : 0);
+    const int SEG = 16 * c.D, seg4 = SEG / 4, TD = c.T * c.D;
+    auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    const bool ptr_ok = aligned16(pos) && aligned16(vel) && (!act || aligned16(actions));
+    // T*D % 4 != 0: episodes start 0..3 floats past a 16-byte boundary -> shifted staging image (one spare chunk per
+    // episode segment), if the segments of a group still fit the 64 lanes of a wave
+    // (misaligned output pointers take the generic store path, whose staging image is never shifted)
+    ta.shifted = (ptr_ok && TD % 4 != 0 && NTW * (seg4 + 1) <= 64 && NTW * (SEG + 4) <= kStageStride) ? 1 : 0;
+    ta.td3 = TD & 3;
+    ta.pitch = ta.shifted ? SEG + 4 : SEG;
+    ta.cps = ta.shifted ? seg4 + 1 : seg4;
+    ta.inv_cps = 65536u / (unsigned)ta.cps + 1u;
+    ta.vec_ok = ptr_ok && (TD % 4 == 0 || ta.shifted);
+    ActArgs aa{};
+    int ct = -1;
+    if (act) {
+        ct = rc->controller_type + (closed ? 3 : 0);
+        for (int d = 0; d < c.D; ++d) { aa.pg[d] = rc->pg[d]; aa.dg[d] = rc->dg[d]; aa.lo[d] = rc->lo[d]; aa.hi[d] = rc->hi[d]; }
+    }
+    const int NRT = (c.T + 15) / 16;
+    const long max_waves = (long)num_cu * 32;     // 8 waves per SIMD resident
+    // work decomposition: episode-major once the outputs stop being cache resident (or when it is the only option)
+    const size_t table_bytes = ((size_t)st.n_out * c.KP * st.TS + st.TS) * sizeof(float);
+    const double out_bytes = (double)B * c.T * c.D * 4.0 * nst;
+    const int ov = tune.mapping == 1 || tune.mapping == 2 ? tune.mapping : 0;   // mpk_set_option "mapping"
+    // closed loop, promp / prodmp, outputs cache resident: tile-major with a serial role (k_traj_split).  "split" 0 / 1
+    // switches it off / forces it; a forced episode-major variant ("mapping" 2, "quad" 0 / 2 / 3 / 4, "bulk" 2) wins
+    const bool variant_forced = ov == 2 || tune.quad == 0 || tune.quad >= 2 || tune.bulk == 2;
+    // (its serial role stores actions as aligned float4 chunks: trajectories and the last row tile must be whole chunks)
+    const int last_rows = c.T - (c.T - 1) / 16 * 16;
+    const bool split_shape = ptr_ok && TD % 4 == 0 && (last_rows * c.D) % 4 == 0;
+    // episode-major producer / consumer pipeline (k_traj_pipe): the default closed-loop kernel whenever its tables and
+    // images fit; "pipe" 0 / 1 switches it off / forces it; "split" 1 forces the tile-major kernel with a serial role
+    // Automatic up to three 5-wave workgroups per CU (B = 6144 at 7 DoF): measured against the best one-wave kernel
+    // (profiles/r02_closed_loop.md) full step 10.1 vs 11.9 us at B = 2048, 11.8 vs 14.1 at 4096, 22.1 vs 19.7 at 8192;
+    // 25-of-100-step plan 8.1 vs 8.8, 9.5 vs 11.6, 17.2 vs 16.5 -- beyond that the launch is store-bound and the barrier
+    // per row tile only makes the store stream burstier.
+    const bool pipe_fits = table_bytes + 2 * kPipeGroups * kQuadImg * sizeof(float) <= 64 * 1024;
+    const long pipe_units = ((long)ta.G + kPipeGroups - 1) / kPipeGroups;
+    const bool pipe = closed && c.mp_type != MPK_MP_DMP && pipe_fits && tune.split != 1 &&
+                      (tune.pipe == 1 || (tune.pipe != 0 && !variant_forced && pipe_units <= 3L * num_cu));
+    const bool split = !pipe && closed && c.mp_type != MPK_MP_DMP && split_shape && tune.split == 1;
+    bool stream_mode = !split && (c.mp_type == MPK_MP_DMP || closed || out_bytes > 96.0 * 1024 * 1024);
+    if (c.mp_type != MPK_MP_DMP && !closed && ov == 1) stream_mode = false;
+    if (ov == 2 && !split) stream_mode = true;       // a forced k_traj_split stays tile-major (its tiles role needs that geometry)
+    if (tune.flat == 1 && !closed && c.mp_type != MPK_MP_DMP && !split) stream_mode = true;   // forced k_traj_flat (where it applies)
+    if (stream_mode && table_bytes + 4 * kStageFloats * sizeof(float) > 64 * 1024) {
+        // the caller falls back: per-episode kernels for dmp, trajectory + rollout launches for the closed loop
+        if (c.mp_type == MPK_MP_DMP || closed) { set_error("trajectory too long for the episode-major kernel's LDS budget"); return MPK_ENOTIMPL; }
+        stream_mode = false;
+    }
+    // write-through stores for the cache-resident tile-major case (mpk_set_option "write_through" overrides, for A/B runs)
+    bool write_through = !stream_mode;
+    ta.wt = stream_mode && out_bytes <= kWtBytes ? 1 : 0;
+    if (tune.write_through >= 0) {
+        write_through = tune.write_through != 0 && !stream_mode;
+        ta.wt = tune.write_through != 0 && stream_mode ? 1 : 0;
+    }
+    // write-through stores address an output array through one buffer resource with 32-bit byte offsets (wt_store16): arrays
+    // of 2 GiB and more (never cache resident anyway; only a forced option gets here) take plain stores
+    if ((double)B * c.T * c.D * 4.0 >= 2147483648.0) { write_through = false; ta.wt = 0; }
+    int blocks;
+    size_t lds = 0;
+    bool bulk = false;
+    // serial-recurrence variants (DMP, closed loop): four (or two) groups per wave, recurrences in parallel on the lane
+    // quarters; needs its staging (52 / 26 KB) + the tables within 64 KB.  quad = groups per wave, 0 = k_traj_stream.
+    // mpk_set_option "quad": 0 off, 2 force four, 3 force two, 4 force one (A/B runs, tests)
+    int quad = 0;
+    {
+        // static staging (fp32 images) + the tables
+        auto fits = [&](int nq) {
+            return table_bytes + (4 * nq * kQuadImg) * sizeof(float) <= 64 * 1024;
+        };
+        const bool serial_variant = stream_mode && (c.mp_type == MPK_MP_DMP || closed);
+        const int quad_mode = tune.quad < 0 ? 1 : tune.quad;
+        const long units4 = (ta.G + 3) / 4, units2 = (ta.G + 1) / 2;
+        // automatic (A/B-measured, profiles/r01_replan_end_to_end.md):
+        //   four per wave  while that gives two waves per SIMD but not yet more units than resident waves
+        //                  (cfg3 DMP at B = 16384: 35 us vs 44 with two);
+        //   two per wave   below that (one wave per SIMD exposes every LDS / MFMA latency: closed loop at B = 8192
+        //                  22 -> 17 us) AND above it: at HBM-streaming sizes a four-group wave keeps 16 output streams
+        //                  open, two groups write like the episode-major kernel (DMP at B = 262144 792 -> 590 us,
+        //                  closed loop at B = 65536 189 -> 166 us);
+        //   one per wave   for the closed loop at a few thousand episodes (cfg4 episodes at B = 2048: 0.061 -> 0.052 ms)
+        if (serial_variant && quad_mode != 0) {
+            if (quad_mode == 2) quad = fits(4) ? 4 : 0;
+            else if (quad_mode == 3) quad = fits(2) ? 2 : 0;
+            else if (quad_mode == 4) quad = fits(1) ? 1 : 0;
+            else if (!closed && fits(4) && units4 >= (long)num_cu * 8 && units4 < max_waves) quad = 4;   // DMP only:
+            // the closed loop measured equal or better with two groups at every size (B = 16384: 0.19 vs 0.21 ms / episode)
+            else if (fits(2) && units2 >= (long)num_cu * 4) quad = 2;
+            else if (closed && fits(1)) quad = 1;
+        }
+    }
+    if (pipe) {
+        quad = 0; bulk = false;
+        lds = table_bytes;
+        const long units = (ta.G + kPipeGroups - 1) / kPipeGroups;
+        const long cap = (long)num_cu * 6;                                // 5-wave workgroups: one resident round
+        blocks = (int)(units < cap ? units : cap);
+        if (blocks >= 8) blocks = blocks / 8 * 8;                         // XCD-contiguous remap needs a multiple of 8
+        if (blocks < 1) blocks = 1;
+    } else if (quad) {
+        lds = table_bytes;
+        const long units = (ta.G + quad - 1) / quad;
+        const long waves = units < max_waves ? units : max_waves;
+        blocks = (int)((waves + 3) / 4);
+        if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;
+    } else if (stream_mode) {
+        lds = table_bytes;
+        // bulk input staging: chunk blocks must be float4-sized / aligned and fit the per-lane register image
+        const int EPC = kChunkGroups * NTW;
+        const size_t img_floats = (size_t)EPC * (c.P + 2 * c.D + 4 * c.D);
+        const size_t lds_bulk = table_bytes + 4 * 2 * img_floats * sizeof(float);
+        bulk = (EPC * c.P) % 4 == 0 && (EPC * c.D) % 4 == 0 && (EPC * c.P) / 4 <= 128 && (EPC * c.D) / 2 <= 64 &&
+               aligned16(params) && aligned16(init_pos) && aligned16(init_vel) &&
+               (!act || closed || (aligned16(c_pos) && aligned16(c_vel))) &&
+               lds_bulk + 4 * kStageFloats * sizeof(float) <= 64 * 1024;
+        // mpk_set_option "bulk": 0 disables, 2 forces it below the size threshold too (tests); default: HBM-streaming sizes only
+        const int bulk_mode = tune.bulk < 0 ? 1 : tune.bulk;
+        // automatic: only when the outputs stream to HBM AND the 4x coarser work units still fill the chip; the
+        // latency-bound DMP recurrence prefers occupancy over input staging
+        const long chunks = (ta.G + kChunkGroups - 1) / kChunkGroups;
+        const bool auto_ok = out_bytes > 96.0 * 1024 * 1024 && chunks >= max_waves / 2 && c.mp_type != MPK_MP_DMP;
+        bulk = bulk && bulk_mode != 0 && (bulk_mode == 2 || auto_ok);
+        long units = ta.G;
+        if (bulk) { lds = lds_bulk; units = (ta.G + kChunkGroups - 1) / kChunkGroups; }
+        long waves = units < max_waves ? units : max_waves;
+        // whole-trajectory images (k_traj_flat): open loop, promp / prodmp, aligned outputs, T * D a multiple of 4, and
+        // two workgroups' images + tables within a CU's LDS.  Automatic once the outputs stream to HBM (A/B on the
+        // streaming row, profiles/r03_streaming.md); mpk_set_option "flat": 0 off, 1 force
+        const int flat_img = (NTW * TD + 3) / 4 * 4;
+        const size_t lds_flat = table_bytes + (size_t)4 * nst * flat_img * sizeof(float);
+        const bool flat_ok = !closed && c.mp_type != MPK_MP_DMP && ptr_ok && TD % 4 == 0 && lds_flat <= 80 * 1024;
+        if (flat_ok && tune.flat != 0 && (tune.flat == 1 || (out_bytes > 96.0 * 1024 * 1024 && tune.bulk < 0))) {
+            ta.flat_img = flat_img;
+            bulk = false;
+            // (write-through while the outputs fit the memory-side cache: kWtBytes)
+            lds = lds_flat + (tune.lds_pad > 0 ? (size_t)tune.lds_pad * 1024 : 0);   // "lds_pad": occupancy experiments
+            const long wg = (long)(160 * 1024 / lds) < 3 ? (long)(160 * 1024 / lds) : 3;   // workgroups a CU's LDS holds
+            const long resident = (long)num_cu * (wg < 1 ? 1 : wg) * 4;   // 4-wave workgroups, persistent
+            waves = ta.G < resident ? ta.G : resident;
+        }
+        blocks = (int)((waves + 3) / 4);
+        if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;                  // XCD-contiguous remap needs a multiple of 8
+    } else {
+        const long items = (long)ta.G * NRT;
+        long ipw = (items + max_waves - 1) / max_waves;                  // items per wave, balanced
+        if (tune.ipw > 0) ipw = tune.ipw;                                // mpk_set_option "ipw" (A/B runs)
+        // the kernel divides wave ids by NRT with a 32-bit multiply-high: exact while #waves < 2^32 / NRT
+        const long wave_cap = (long)((1ull << 32) / (unsigned long long)NRT) - 8 * NRT;
+        if ((items + ipw - 1) / ipw > wave_cap) ipw = (items + wave_cap - 1) / wave_cap;
+        const long waves = (items + ipw - 1) / ipw;
+        blocks = (int)((waves + 3) / 4);
+        {   // #waves % NRT == 0, and a multiple of 8 blocks for the XCD remap once there are that many
+            int g8 = 8, r = NRT;
+            while (r) { const int t = g8 % r; g8 = r; r = t; }           // gcd(8, NRT)
+            const int unit = blocks >= 8 ? NRT / g8 * 8 : NRT;           // lcm(8, NRT) or NRT
+            blocks = (blocks + unit - 1) / unit * unit;
+        }
+        ta.gstride = blocks * 4 / NRT;
+        ta.nrt_magic = NRT > 1 ? (unsigned)((1ull << 32) / (unsigned long long)NRT) + 1u : 0u;
+    }
+    if (blocks < 1) blocks = 1;
+    if (!stream_mode && !pipe && ta.gstride <= 0) { set_error("internal: tile-major launch without its group stride"); return MPK_EINVAL; }
+    if (!stream_mode && tune.lds_pad > 0) lds = (size_t)tune.lds_pad * 1024;     // A/B runs: caps the workgroups per CU
+    if (stream_mode && !pipe && !ta.flat_img && tune.lds_pad > 0) lds += (size_t)tune.lds_pad * 1024;   // episode-major: EXTRA dynamic LDS (occupancy experiments)
+    ta.ser_blocks = 0;
+    if (split) {
+        // serial-role workgroups first (they are the long pole and must start first), capped at one resident round of the chip
+        const int EPW = 64 >> sh;                              // episodes per serial-role wave: one lane per (episode, DoF)
+        const long units = ((long)B + EPW - 1) / EPW;
+        long sb = (units + 3) / 4;
+        const long cap = (long)num_cu * 8;
+        if (sb > cap) sb = cap;
+        ta.ser_blocks = (unsigned)sb;
+        blocks += (int)sb;
+    }
+    switch (c.mp_type) {
+        case MPK_MP_PRODMP:
+            *kernel_name = pipe ? "k_traj_pipe<prodmp,closed>" : split ? "k_traj_split<prodmp,closed>" : closed ? (quad == 4 ? "k_traj_quad<prodmp,closed>" : quad == 2 ? "k_traj_duo<prodmp,closed>" : quad == 1 ? "k_traj_mono<prodmp,closed>" : "k_traj_stream<prodmp,closed>") : ta.flat_img ? (act ? "k_traj_flat<prodmp,act>" : "k_traj_flat<prodmp>") : stream_mode ? (act ? "k_traj_stream<prodmp,act>" : "k_traj_stream<prodmp>")
+                                       : (act ? "k_traj_tiles<prodmp,act>" : "k_traj_tiles<prodmp>");
+            return launch_traj_ct<MPK_MP_PRODMP>(ta, aa, ct, stream_mode, write_through, bulk, quad, blocks, lds, stream, split, pipe);
+        case MPK_MP_PROMP:
+            *kernel_name = pipe ? "k_traj_pipe<promp,closed>" : split ? "k_traj_split<promp,closed>" : closed ? (quad == 4 ? "k_traj_quad<promp,closed>" : quad == 2 ? "k_traj_duo<promp,closed>" : quad == 1 ? "k_traj_mono<promp,closed>" : "k_traj_stream<promp,closed>") : ta.flat_img ? (act ? "k_traj_flat<promp,act>" : "k_traj_flat<promp>") : stream_mode ? (act ? "k_traj_stream<promp,act>" : "k_traj_stream<promp>")
+                                       : (act ? "k_traj_tiles<promp,act>" : "k_traj_tiles<promp>");
+            return launch_traj_ct<MPK_MP_PROMP>(ta, aa, ct, stream_mode, write_through, bulk, quad, blocks, lds, stream, split, pipe);
+        default:
+            *kernel_name = quad == 4 ? "k_traj_quad<dmp>" : quad == 2 ? "k_traj_duo<dmp>" : quad == 1 ? "k_traj_mono<dmp>" : "k_traj_stream<dmp>";
+            return launch_traj_ct<MPK_MP_DMP>(ta, aa, -1, true, false, bulk, quad, blocks, lds, stream, false, false);
+    }
+}
+#endif  // MPK_DEVICE_ONLY
+
+}  // namespace mpk

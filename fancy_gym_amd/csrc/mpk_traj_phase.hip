@@ -1,0 +1,1094 @@
+// k_traj_rows / k_traj_phase / k_traj_phase_dmp / k_dmp_prestep: per-episode phase (learned tau / delay, per-episode init_time)
+#include "mpk_tile.h"
+
+namespace mpk {
+
+// ------------------------------------------------------------------------------------------------------------
+// k_traj_rows: per-episode phase (learned tau/delay or per-episode init_time), one workgroup per episode
+// ------------------------------------------------------------------------------------------------------------
+struct RowArgs {
+    DevCfg c;
+    const float* params;
+    const float* init_pos;
+    const float* init_vel;
+    const float* init_time;
+    float init_time_shared;
+    float* pos;
+    float* vel;
+    int32_t* flag;
+    int B;
+};
+
+template <int MP>
+__global__ void __launch_bounds__(256) k_traj_rows(const RowArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const DevCfg& c = a.c;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int D = c.D, T = c.T, KT = c.KT, P = c.P;
+    constexpr int NROW = MP == MPK_MP_PRODMP ? 2 : 1;
+    float* sX = smem;                       // [D][KT]
+    float* sH = sX + D * KT;                // [NROW][T][KT]
+    float* sP = sH + NROW * T * KT;         // [T*D]   pos (promp) / force (dmp)
+    float* sV = sP + T * D;                 // [T*D]   dmp only
+    float* sT = sV + (MP == MPK_MP_DMP ? T * D : 0);  // [T] times (promp) / ds (dmp)
+
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const float* prm = a.params + (size_t)b * P;
+        float tau = c.tau, delay = c.delay;
+        int o = 0;
+        // np.clip(action, low, high): only tau / delay carry finite bounds (black_box_wrapper.py:104-105)
+        if (c.learn_tau) { tau = fminf(fmaxf(prm[o], c.tau_lo), c.tau_hi); ++o; }
+        if (c.learn_delay) { delay = fminf(fmaxf(prm[o], c.delay_lo), c.delay_hi); ++o; }
+        const float it = a.init_time ? a.init_time[b] : a.init_time_shared;
+        __syncthreads();  // previous episode's LDS fully consumed
+        for (int e = tid; e < D * KT; e += nt) {
+            const int dd = e / KT, k = e - dd * KT;
+            float v = 0.0f;
+            // RAW parameters / boundary conditions: every scale lives in the basis rows (see prodmp_col)
+            if (MP == MPK_MP_PRODMP) {
+                const int nb = c.nb;
+                if (k < nb) {
+                    if (!c.disable_weights) v = prm[c.off + dd * c.Kloc + k];
+                } else if (k == nb) {
+                    if (!c.disable_goal) v = prm[c.off + dd * c.Kloc + (c.disable_weights ? 0 : nb)];
+                } else if (k == nb + 1) {
+                    v = a.init_pos[(size_t)b * D + dd];
+                } else if (k == nb + 2) {
+                    v = a.init_vel[(size_t)b * D + dd];
+                } else {
+                    v = 1.0f;                      // goal-offset column (MPK_GOAL_OFFSET_ADD)
+                }
+            } else if (MP == MPK_MP_PROMP) {
+                if (k < c.nb) v = prm[c.off + dd * c.Kloc + k];
+                else v = a.init_pos[(size_t)b * D + dd];
+            } else {
+                v = prm[c.off + dd * c.Kloc + k];
+            }
+            sX[e] = v;
+        }
+        // basis rows for this episode's phase
+        if (MP == MPK_MP_PRODMP) {
+            const float sb = scaled_time(it, delay, tau);
+            const int idxb = min(prodmp_index(sb, c.scaled_dt), c.n_pc - 1);
+            ProdmpBC bc;
+            prodmp_bc(c, idxb, bc);
+            for (int t = tid; t < T; t += nt) {
+                const float time = c.base_times[t] + it;
+                const float s = scaled_time(time, delay, tau);
+                if (s > (float)c.len_factor) atomicOr(a.flag, 1);
+                const int idx = min(prodmp_index(s, c.scaled_dt), c.n_pc - 1);
+                double xi[4];
+                prodmp_xi(c, bc, idx, xi);
+                for (int k = 0; k < KT; ++k) {
+                    float h, hv;
+                    prodmp_col(c, bc, idx, xi, k, (double)tau, div_pos(1.0, (double)tau), &h, &hv);
+                    sH[t * KT + k] = h;
+                    sH[(T + t) * KT + k] = hv;
+                }
+            }
+        } else {
+            for (int t = tid; t < T; t += nt) {
+                const float time = c.base_times[t] + it;
+                const double x = phase_f64(c, time, tau, delay, ExpLiteral());
+                rbf_cols(c, x, MP == MPK_MP_PROMP ? (double)c.ws : x * (double)c.ws, sH + t * KT, 1);
+                if (MP == MPK_MP_PROMP) {
+                    if (KT > c.nb) sH[t * KT + c.nb] = 1.0f;
+                    sT[t] = time;
+                } else if (t < T - 1) {
+                    sT[t] = scaled_time(c.base_times[t + 1] + it, delay, tau) - scaled_time(time, delay, tau);
+                }
+            }
+        }
+        __syncthreads();
+        // contraction: fp32 fmaf chain in ascending k (the order of the MFMA accumulation)
+        for (int e = tid; e < T * D; e += nt) {
+            const int t = e / D, dd = e - t * D;
+            const float* x = sX + dd * KT;
+            float accp = 0.0f, accv = 0.0f;
+            for (int k = 0; k < KT; ++k) {
+                accp = fmaf(sH[t * KT + k], x[k], accp);
+                if (MP == MPK_MP_PRODMP) accv = fmaf(sH[(T + t) * KT + k], x[k], accv);
+            }
+            if (MP == MPK_MP_PRODMP) {
+                a.pos[(size_t)b * T * D + e] = accp;
+                a.vel[(size_t)b * T * D + e] = accv;
+            } else {
+                sP[e] = accp;
+                if (MP == MPK_MP_PROMP) a.pos[(size_t)b * T * D + e] = accp;
+            }
+        }
+        if (MP == MPK_MP_PROMP) {
+            __syncthreads();
+            for (int e = tid; e < T * D; e += nt) {
+                const int t = e / D, dd = e - t * D;
+                const int th = t < T - 1 ? t + 1 : T - 1, tl = t < T - 1 ? t : T - 2;
+                a.vel[(size_t)b * T * D + e] = (sP[th * D + dd] - sP[tl * D + dd]) * (1.0f / (sT[th] - sT[tl]));
+            }
+        } else if (MP == MPK_MP_DMP) {
+            __syncthreads();
+            if (tid < D) {
+                const int dd = tid;
+                float y = a.init_pos[(size_t)b * D + dd];
+                float z = a.init_vel[(size_t)b * D + dd] * tau;
+                const float g = prm[c.off + dd * c.Kloc + c.nb] * c.gs;
+                const TauDiv td = make_tau_div(tau);
+                for (int t = 0; t < T; ++t) {
+                    const float f = sP[t * D + dd];
+                    sP[t * D + dd] = y;
+                    sV[t * D + dd] = div_tau(z, td);
+                    if (t < T - 1) {
+                        const float ds = sT[t];
+                        const float t1 = g - y;
+                        const float t2 = c.dmp_beta * t1;
+                        const float t3 = t2 - z;
+                        const float t4 = c.dmp_alpha * t3;
+                        const float acc = t4 + f;
+                        z = z + ds * acc;
+                        y = y + ds * z;
+                    }
+                }
+            }
+            __syncthreads();
+            for (int e = tid; e < T * D; e += nt) {
+                a.pos[(size_t)b * T * D + e] = sP[e];
+                a.vel[(size_t)b * T * D + e] = sV[e];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_traj_phase: per-episode phase (learned tau / delay, per-episode init_time), one WAVE per episode, no workgroup
+// barriers in the episode loop (D * KS <= 256 with KS = 8 or 16 contraction columns).
+//   promp / prodmp -- lane <-> time step, 64 steps a round:
+//     1. the lane gets ITS basis row in registers.  promp: fp64 phase + RBF evaluation with the device functions of
+//        k_build_shared (a per-episode phase equal to the shared one gives identical bits).  prodmp: the reference's
+//        own form  pos = c1*y1 + c2*y2 + Psi.wg   -- the row is a plain gather of [Psi | y1 y2] at the
+//        lane's table index from an fp32 row table (one 64-byte line), the boundary conditions enter through
+//        (c1, c2), solved per (episode, DoF) in float64; folding them into the rows (what the shared-phase kernels
+//        do, because there it is free) would cost a float64 update per (episode, step, column)
+//     2. for every DoF the raw parameter column X[d][:] is broadcast from LDS and the fmaf chain runs in ascending k
+//        (the MFMA accumulation order); promp takes its forward difference from the next lane (lane 63 of a
+//        non-final round only feeds lane 62)
+//     3. the round's [64][D] block of pos / vel -- one contiguous run in HBM -- is staged in the wave's LDS slice at
+//        the run's 16-byte phase and leaves as float4 stores
+//     the next episode's header and parameter columns are fetched while the rows are built (before this episode's
+//     stores enter the in-order memory queue)
+//   dmp -- rows to LDS, forcing by lane <-> element, the Euler recurrence on D lanes, coalesced copy-out
+// ------------------------------------------------------------------------------------------------------------
+struct PhaseArgs {
+    DevCfg c;
+    const float* params;
+    const float* init_pos;
+    const float* init_vel;
+    const float* init_time;
+    float init_time_shared;
+    float* pos;
+    float* vel;
+    int32_t* flag;
+    int B, wave_floats, t_pad, x_pad, o_pad, c_pad, tab_pad, chunk, img_pad;
+    int wt;     // write-through stores while the outputs are cache resident
+    int vec_ok; // dmp: outputs 16-byte aligned and T * D a multiple of 4 (float4 stores)
+};
+
+template <int MP>
+__device__ __forceinline__ float phase_x_value(const DevCfg& c, const float* __restrict__ prm,
+                                               const float* __restrict__ ip, const float* __restrict__ iv, int dd, int k,
+                                               int ks) {
+    // RAW parameters / boundary conditions: every scale lives in the basis rows (see prodmp_col)
+    if (MP == MPK_MP_DMP) {
+        // the chain sees the weights only; goal, y0, ydot0 travel in the last three (otherwise zero) columns
+        if (k < c.nb) return prm[c.off + dd * c.Kloc + k];
+        if (k == ks - 3) return prm[c.off + dd * c.Kloc + c.nb];
+        if (k == ks - 2) return ip[dd];
+        return k == ks - 1 ? iv[dd] : 0.0f;
+    }
+    if (k >= c.KT) return 0.0f;
+    if (MP == MPK_MP_PRODMP) {
+        const int nb = c.nb;
+        if (k < nb) return c.disable_weights ? 0.0f : prm[c.off + dd * c.Kloc + k];
+        if (k == nb) return c.disable_goal ? 0.0f : prm[c.off + dd * c.Kloc + (c.disable_weights ? 0 : nb)];
+        return k == nb + 1 ? ip[dd] : iv[dd];
+    }
+    return k < c.nb ? prm[c.off + dd * c.Kloc + k] : ip[dd];
+}
+
+// the value of the neighbouring lane (lane + 1 / lane - 1 of the 64) as ONE vector instruction (DPP wave shift) instead
+// of an LDS round trip (ds_bpermute behind __shfl_*): the ProMP velocity takes two of them per (step, DoF).  The lane
+// without a neighbour reads 0; nothing uses it.
+__device__ __forceinline__ float lane_above(float x) {      // x of lane + 1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_below(float x) {      // x of lane - 1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, false));
+}
+
+template <int KQ>
+__device__ __forceinline__ float row_chain(const float* __restrict__ row, const float (&x)[KQ * 4]) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < KQ; ++j) {
+        const float4 h = *reinterpret_cast<const float4*>(row + 4 * j);
+        acc = fmaf(h.x, x[4 * j + 0], acc);
+        acc = fmaf(h.y, x[4 * j + 1], acc);
+        acc = fmaf(h.z, x[4 * j + 2], acc);
+        acc = fmaf(h.w, x[4 * j + 3], acc);
+    }
+    return acc;
+}
+
+// episode header + parameter columns, one episode ahead (shared by both per-episode-phase kernels)
+template <int MP, int KS>
+struct PhaseFetch {
+    static constexpr int NX = 4;                        // D * KS <= 256 values, one per lane and round
+    float tau_raw, delay_raw, it;
+    float xv[NX];
+    __device__ __forceinline__ void issue(const PhaseArgs& a, int bb, int lane) {
+        const DevCfg& c = a.c;
+        const float* prm = a.params + (size_t)bb * c.P;
+        const float* ip = a.init_pos + (size_t)bb * c.D;
+        const float* iv = a.init_vel + (size_t)bb * c.D;
+        int o = 0;
+        tau_raw = c.tau; delay_raw = c.delay;
+        if (c.learn_tau) { tau_raw = prm[o]; ++o; }
+        if (c.learn_delay) delay_raw = prm[o];
+        it = a.init_time ? a.init_time[bb] : a.init_time_shared;
+#pragma unroll
+        for (int r = 0; r < NX; ++r) {
+            const int e = lane + 64 * r;
+            const int dd = e / KS, k = e - dd * KS;
+            xv[r] = e < c.D * KS ? phase_x_value<MP>(c, prm, ip, iv, dd, k, KS) : 0.0f;
+        }
+    }
+    __device__ __forceinline__ void park(float* sx, int n, int lane) const {
+#pragma unroll
+        for (int r = 0; r < NX; ++r) {
+            const int e = lane + 64 * r;
+            if (e < n) sx[e] = xv[r];
+        }
+    }
+};
+
+// n floats staged at s0 / s1 [sh ...] (sh = 16-byte phase of the destinations: pos and vel share it) -> o0 / o1 [0 .. n):
+// float4 body, dword head / tail, both arrays in one pass (shared chunk arithmetic)
+// WT: write-through stores, every one of them (cache-resident batches; see store16)
+template <bool WT>
+__device__ __forceinline__ void flush_span2(const float* __restrict__ s0, const float* __restrict__ s1, float* __restrict__ o0,
+                                            float* __restrict__ o1, int n, int sh, int lane) {
+    const int end = sh + n;
+    const int q0 = (sh + 3) >> 2, q1 = end >> 2;
+    for (int q = q0 + lane; q < q1; q += 64) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(s0 + 4 * q), b = *reinterpret_cast<const f32x4*>(s1 + 4 * q);
+        store16<WT>(o0 - sh + 4 * q, a);
+        store16<WT>(o1 - sh + 4 * q, b);
+    }
+    const int head_end = 4 * q0 < end ? 4 * q0 : end;
+    if (lane < head_end - sh) { store4<WT>(o0 + lane, s0[sh + lane]); store4<WT>(o1 + lane, s1[sh + lane]); }
+    const int tail = 4 * q1 > head_end ? 4 * q1 : head_end;
+    if (lane < end - tail) { store4<WT>(o0 - sh + tail + lane, s0[tail + lane]); store4<WT>(o1 - sh + tail + lane, s1[tail + lane]); }
+}
+
+
+// TL (prodmp): the fp32 row table is staged in the workgroup's LDS (row stride 2*KS + 4 floats: 16-byte aligned rows
+// spread over the banks) and the workgroup is up to 16 waves, so row and boundary gathers never enter the memory queue
+// FL (prodmp): the rounds run over the FLATTENED (episode, step) items of a chunk -- 64 consecutive items a round, whatever
+// episode they belong to (a chunk's outputs are one contiguous run of HBM) -- instead of over each episode's steps: T = 100
+// fills 100 of 128 lanes per episode the other way.  Everything per episode (clipped tau / delay, init_time, 1 / tau, the
+// boundary-condition factors) is then per LANE, read from the chunk image; same arithmetic per (episode, step), same bits.
+template <int MP, int KQ, bool TL, bool FL = false>
+__global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs a) {
+    static_assert(MP != MPK_MP_DMP, "dmp has its own kernel");
+    static_assert(!TL || MP == MPK_MP_PRODMP, "only prodmp has a row table");
+    static_assert(!FL || MP == MPK_MP_PRODMP, "flat rounds: prodmp (promp's difference crosses lanes)");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const DevCfg& c = a.c;
+    constexpr int KS = KQ * 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wpb = (int)(blockDim.x >> 6);
+    const int D = c.D, T = c.T, KT = c.KT;
+    double* sCen = reinterpret_cast<double*>(smem);     // [c_pad / 2] RBF centres | bandwidths, shared by the workgroup
+    float* sBT = smem + a.c_pad;                        // [t_pad] base times, shared by the workgroup
+    float* sTab = sBT + a.t_pad;                        // TL: [n_pc][2*KS + 4] row table, shared by the workgroup
+    float* sImg = sTab + a.tab_pad + (size_t)wave * a.wave_floats;  // [2][img_pad] inputs of this / the next chunk
+    float* sO0 = sImg + 2 * a.img_pad;                  // [o_pad] pos staging: [sh + lane * D + d]
+    float* sO1 = sO0 + a.o_pad;                         // [o_pad] vel staging
+    float* sXf = sO1 + a.o_pad;                         // promp: [x_pad] this episode's columns (prodmp: in the input image)
+    float* sWgs = smem;                                 // prodmp: weights_goal_scale[nb + 1] (in place of sCen)
+    for (int t = threadIdx.x; t < T; t += blockDim.x) sBT[t] = c.base_times[t];
+    if (MP != MPK_MP_PRODMP) {
+        for (int k = threadIdx.x; k < 2 * c.n_total + 3; k += blockDim.x) sCen[k] = c.tab[k];
+    } else {
+        const double* S = c.tab + 4 * (size_t)c.n_pc + 2 * (size_t)c.n_pc * (c.nb + 1);
+        for (int k = threadIdx.x; k <= c.nb; k += blockDim.x) {
+            const bool off = k < c.nb ? c.disable_weights != 0 : c.disable_goal != 0;
+            sWgs[k] = off ? 0.0f : (float)S[k];
+            if (k == c.nb) sWgs[c.nb + 1] = (float)S[k];     // the goal scale itself, also when the goal is disabled
+        }
+        if (TL) {
+            const float4* src = reinterpret_cast<const float4*>(c.rows32);
+            for (int i = threadIdx.x; i < c.n_pc * (2 * KQ + 1); i += blockDim.x)
+                reinterpret_cast<float4*>(sTab)[i] = src[i];
+        }
+    }
+    __syncthreads();
+    const float* const rows = TL ? sTab : c.rows32;
+    constexpr int kRow = 2 * KS + 4;    // [pos half .. y1 (f64) | vel half .. y2 (f64) | dy1 dy2 (f64)]
+    const ExactDiv dsdt = make_exact_div(c.scaled_dt);
+
+    // A wave owns chunks of E consecutive episodes.  A chunk's inputs -- E parameter rows, E boundary positions /
+    // velocities, E init_times: each one contiguous run -- are fetched with coalesced loads one chunk ahead and
+    // collected once per chunk (into the other half of the wave's input image), right after the rows of the chunk's
+    // last episode are built: the memory queue is in order, so collecting a load also waits for every store issued
+    // before it, and that wait is paid per chunk instead of per episode.
+    const int E = a.chunk, P = c.P;
+    const int img_floats = a.img_pad;
+    constexpr int NLP = 5;                              // E * P <= 320 parameter values per chunk
+    const int nchunks = (a.B + E - 1) / E;
+    const int cstride = (int)gridDim.x * wpb;
+    int ch = (int)blockIdx.x * wpb + wave;
+    float lp[NLP], lip = 0.0f, liv = 0.0f, lit = 0.0f;
+    auto issue_chunk = [&](int cc) {
+        const int b0 = cc * E, ne = min(E, a.B - b0);
+        const float* prm = a.params + (size_t)b0 * P;
+#pragma unroll
+        for (int r = 0; r < NLP; ++r) lp[r] = lane + 64 * r < ne * P ? prm[lane + 64 * r] : 0.0f;
+        lip = lane < ne * D ? a.init_pos[(size_t)b0 * D + lane] : 0.0f;
+        liv = lane < ne * D ? a.init_vel[(size_t)b0 * D + lane] : 0.0f;
+        lit = a.init_time && lane < ne ? a.init_time[b0 + lane] : a.init_time_shared;
+    };
+    auto park_chunk = [&](float* img) {
+#pragma unroll
+        for (int r = 0; r < NLP; ++r)
+            if (lane + 64 * r < E * P) img[lane + 64 * r] = lp[r];
+        if (lane < E * D) { img[E * P + lane] = lip; img[E * P + E * D + lane] = liv; }
+        if (lane < E) img[E * P + 2 * E * D + lane] = lit;
+    };
+    if (ch < nchunks) {
+        issue_chunk(ch);
+        park_chunk(sImg);
+    }
+    constexpr int kStep = MP == MPK_MP_PROMP ? 63 : 64;
+    ExpRegs ec;
+    if (MP == MPK_MP_PROMP) ec.load();
+    int slot = 0;
+    for (; ch < nchunks; ch += cstride, slot ^= 1) {
+        const float* img = sImg + slot * img_floats;
+        const int b0 = ch * E, ne = min(E, a.B - b0);
+        const bool more = ch + cstride < nchunks;
+        MPK_STAMP(1);                                   // trace builds (tools/dev/trace_phase.py): chunk start
+        if (more) issue_chunk(ch + cstride);
+        __builtin_amdgcn_wave_barrier();
+        if (MP == MPK_MP_PRODMP) {
+            // The columns of ALL episodes of the chunk at once, one lane per (episode, DoF): wg = scale * [w; g] in fp32 as
+            // the reference forms it, and the two boundary residuals of
+            //   pos = xi1 * (y_b - Psi_b.wg) + xi2 * (tau ydot_b - dPsi_b.wg) + Psi.wg
+            // (the reference's xi1 y_b + xi2 v_b + (Psi - xi1 Psi_b - xi2 dPsi_b).wg, regrouped so that nothing large cancels
+            // in fp32) in float64, ascending k.  Per episode -- D lanes working, the wave paying every instruction -- this
+            // block was 27 % of the kernel's cycles (profiles/r02_per_episode_phase.md); per chunk it is a quarter of that.
+            // The chunk's input image is rewritten IN PLACE: every lane reads what it needs first, then the image becomes
+            // [E][D][KS] columns [wg_0 .. wg_{K-1}, 0.., r1, r2] | [E][tau, delay, init_time] (clipped) -- no LDS on top.
+            float* const imw = sImg + slot * img_floats;
+            const int le = (int)(((unsigned)lane * (65536u / (unsigned)D + 1u)) >> 16), ld = lane - le * D;    // lane / D
+            const bool on = lane < ne * D;
+            const int K = c.nb + 1;
+            float raw[KS], taul = c.tau, delayl = c.delay, itl = 0.0f, yb = 0.0f, ydb = 0.0f;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) raw[k] = 0.0f;
+            if (on) {
+                const float* prl = img + le * P;
+                if (c.learn_tau) taul = fminf(fmaxf(prl[0], c.tau_lo), c.tau_hi);
+                if (c.learn_delay) delayl = fminf(fmaxf(prl[c.learn_tau ? 1 : 0], c.delay_lo), c.delay_hi);
+                itl = img[E * P + 2 * E * D + le];
+                yb = img[E * P + lane]; ydb = img[E * P + E * D + lane];
+                const float* loc = prl + c.off + ld * c.Kloc;
+#pragma unroll
+                for (int k = 0; k < KS; ++k)
+                    if (k < K) {
+                        // a disabled block has no parameters (the goal then sits at local index 0)
+                        const bool have = k < c.nb ? !c.disable_weights : !c.disable_goal;
+                        const int li = k < c.nb ? k : (c.disable_weights ? 0 : c.nb);
+                        raw[k] = have ? loc[li] : 0.0f;
+                    }
+            }
+            __builtin_amdgcn_wave_barrier();                 // every read of the image is issued before its first write
+            if (on) {
+                const float sbl = fmaxf(div_exact(itl - delayl, make_exact_div(taul)), 0.0f);
+                const float* rb = rows + (size_t)min((int)rintf(div_exact(sbl, dsdt)), c.n_pc - 1) * kRow;
+                double pb = 0.0, vb = 0.0;
+                float* xf = imw + le * a.x_pad + ld * KS;
+#pragma unroll
+                for (int k = 0; k < KS; ++k) {
+                    float wg = 0.0f;
+                    if (k < K) {
+                        const bool have = k < c.nb ? !c.disable_weights : !c.disable_goal;
+                        wg = have ? raw[k] * sWgs[k] : 0.0f;          // (raw is 0 where there is no parameter)
+                        if (k == c.nb) {
+                            // relative goal: init_pos joins the scaled goal, or (MPK_RELGOAL_BEFORE_SCALE) the raw
+                            // parameter -- zero when the goal is disabled -- before the scale
+                            if (c.relative_goal) wg = c.relgoal_before_scale ? (raw[k] + yb) * sWgs[c.nb + 1] : wg + yb;
+                            if (c.goal_off_on) wg = wg + c.goal_offset;
+                        }
+                        pb += (double)rb[2 * k] * (double)wg;
+                        vb += (double)rb[2 * k + 1] * (double)wg;
+                    }
+                    xf[k] = wg;
+                }
+                xf[KS - 2] = (float)((double)yb - pb);
+                xf[KS - 1] = (float)((double)(taul * ydb) - vb);
+                if (ld == 0 && !FL) {
+                    float* sc3 = imw + E * a.x_pad + 3 * le;
+                    sc3[0] = taul; sc3[1] = delayl; sc3[2] = itl;
+                }
+                if (ld == 0 && FL) {
+                    // [E][tau, delay, init_time, 1 / tau] | [E][4] float64 boundary-condition factors (see the per-episode
+                    // block of the other path: the same expressions)
+                    float* sc4 = imw + E * a.x_pad + 4 * le;
+                    sc4[0] = taul; sc4[1] = delayl; sc4[2] = itl; sc4[3] = 1.0f / taul;
+                    const double* yb4 = reinterpret_cast<const double*>(rb + 2 * KS - 4);
+                    const double y1b = yb4[0], y2b = yb4[1], dy1b = yb4[2], dy2b = yb4[3];
+                    const double idet = div_pos(1.0, y1b * dy2b - y2b * dy1b);
+                    double* bc4 = reinterpret_cast<double*>(imw + E * a.x_pad + 4 * E) + 4 * le;
+                    bc4[0] = dy2b * idet; bc4[1] = dy1b * idet; bc4[2] = y1b * idet; bc4[3] = y2b * idet;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if constexpr (FL) {
+            const int n_items = ne * T;
+            const float rT = 1.0f / (float)T;
+            float* const out_pos = a.pos + (size_t)b0 * T * D;
+            float* const out_vel = a.vel + (size_t)b0 * T * D;
+            for (int i0 = 0; i0 < n_items; i0 += 64) {
+                const int nout = min(64, n_items - i0);
+                const int i = min(i0 + lane, n_items - 1);
+                int e = (int)(((float)i + 0.5f) * rT);          // i / T (i < 8 T), then made exact
+                if (e * T > i) --e;
+                if ((e + 1) * T <= i) ++e;
+                const int t = i - e * T;
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(img + E * a.x_pad + 4 * e);
+                const float delay = sc[1], it = sc[2], inv_tau = sc[3];
+                const ExactDiv dtau{sc[0], inv_tau, (__float_as_uint(sc[0]) & 0x7fffffu) == 0x7fffffu};
+                const double* bc4 = reinterpret_cast<const double*>(img + E * a.x_pad + 4 * E) + 4 * e;
+                const double bca = bc4[0], bcb = bc4[1], bcc = bc4[2], bcd = bc4[3];
+                float hq[2 * KS];
+                const float time = sBT[t] + it;
+                const float s = fmaxf(div_exact(time - delay, dtau), 0.0f);
+                if (s > (float)c.len_factor) atomicOr(a.flag, 1);
+                const int idx = min((int)rintf(div_exact(s, dsdt)), c.n_pc - 1);
+                const float4* row = reinterpret_cast<const float4*>(rows + (size_t)idx * kRow);
+#pragma unroll
+                for (int j = 0; j < (2 * KS - 4) / 4; ++j) {
+                    const float4 q4 = row[j];
+                    hq[4 * j] = q4.x; hq[4 * j + 1] = q4.y; hq[4 * j + 2] = q4.z; hq[4 * j + 3] = q4.w;
+                }
+                const double* y4 = reinterpret_cast<const double*>(row + (2 * KS - 4) / 4);
+                const double y1 = y4[0], y2 = y4[1], dy1 = y4[2], dy2 = y4[3];
+                hq[2 * KS - 4] = (float)fma(bca, y1, -(bcb * y2));
+                hq[2 * KS - 3] = (float)fma(bca, dy1, -(bcb * dy2));
+                hq[2 * KS - 2] = (float)fma(bcc, y2, -(bcd * y1));
+                hq[2 * KS - 1] = (float)fma(bcc, dy2, -(bcd * dy1));
+                if (more && i0 + 64 >= n_items) park_chunk(sImg + (slot ^ 1) * img_floats);
+                float* const gp = out_pos + (size_t)i0 * D;
+                const int sh = (int)((reinterpret_cast<uintptr_t>(gp) >> 2) & 3);
+                const float* const sXl = img + e * a.x_pad;     // the lane's episode: at most two distinct ones per round
+                auto dof = [&](int d) {
+                    float x[KS];
+#pragma unroll
+                    for (int j = 0; j < KQ; ++j) {
+                        const float4 v = *reinterpret_cast<const float4*>(sXl + d * KS + 4 * j);
+                        x[4 * j + 0] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
+                    }
+                    f32x2 pv = {0.0f, 0.0f};
+#pragma unroll
+                    for (int k = 0; k < KS; ++k)
+                        pv = __builtin_elementwise_fma(f32x2{hq[2 * k], hq[2 * k + 1]}, f32x2{x[k], x[k]}, pv);
+                    sO0[sh + lane * D + d] = pv[0];
+                    sO1[sh + lane * D + d] = pv[1] * inv_tau;
+                };
+                constexpr int ND = KQ <= 2 ? 2 : 1;
+                int d = 0;
+                for (; d + ND <= D; d += ND) {
+#pragma unroll
+                    for (int q = 0; q < ND; ++q) dof(d + q);
+                }
+                for (; d < D; ++d) dof(d);
+                __builtin_amdgcn_wave_barrier();
+                if (a.wt) flush_span2<true>(sO0, sO1, gp, out_vel + (size_t)i0 * D, nout * D, sh, lane);
+                else flush_span2<false>(sO0, sO1, gp, out_vel + (size_t)i0 * D, nout * D, sh, lane);
+                __builtin_amdgcn_wave_barrier();
+            }
+            continue;
+        }
+        for (int e = 0; e < ne; ++e) {
+            const int b = b0 + e;
+            MPK_STAMP(2 + 40 * e);
+            const float* prm = img + e * P;
+            const float* ipe = img + E * P + e * D;
+            const float* ive = ipe + E * D;
+            // np.clip(action, low, high): only tau / delay carry finite bounds (black_box_wrapper.py:104-105)
+            float tau = c.tau, delay = c.delay, it;
+            if (MP == MPK_MP_PRODMP) {                  // clipped per chunk above
+                const float* sc3 = img + E * a.x_pad + 3 * e;
+                tau = sc3[0]; delay = sc3[1]; it = sc3[2];
+            } else {
+                if (c.learn_tau) tau = fminf(fmaxf(prm[0], c.tau_lo), c.tau_hi);
+                if (c.learn_delay) delay = fminf(fmaxf(prm[c.learn_tau ? 1 : 0], c.delay_lo), c.delay_hi);
+                it = img[E * P + 2 * E * D + e];
+            }
+            float inv_tau = 0.0f;
+            double bca = 0.0, bcb = 0.0, bcc = 0.0, bcd = 0.0;    // dy2_b, dy1_b, y1_b, y2_b over det (see prodmp_bc)
+            // table index = round(max((t - delay) / tau, 0) / scaled_dt): both quotients correctly rounded (div_exact), the
+            // reciprocals taken once per episode / kernel instead of two IEEE divisions per step
+            const ExactDiv dtau = make_exact_div(tau);
+            const PosDiv taud = make_pos_div((double)tau);       // promp: the float64 phase divides by tau at every step
+            if (MP == MPK_MP_PRODMP) {
+                // Boundary conditions (SURVEY A.5 / mp_pytorch ProDMP): the episode's columns were built per chunk above;
+                // xi1..xi4 are per (episode, step): the step's lane forms them below in float64 from the table values and
+                // the factors kept here.
+                const float sb = fmaxf(div_exact(it - delay, dtau), 0.0f);
+                const int idxb = min((int)rintf(div_exact(sb, dsdt)), c.n_pc - 1);
+                inv_tau = dtau.r;
+                const float* rb = rows + (size_t)idxb * kRow;
+                {
+                    // y1, y2, dy1, dy2 sit behind the (Psi_k, dPsi_k) pairs as float64 (see mpk_create)
+                    const double* yb4 = reinterpret_cast<const double*>(rb + 2 * KS - 4);
+                    const double y1b = yb4[0], y2b = yb4[1], dy1b = yb4[2], dy2b = yb4[3];
+                    const double idet = div_pos(1.0, y1b * dy2b - y2b * dy1b);      // det = y1_b^2 > 0
+                    bca = dy2b * idet; bcb = dy1b * idet; bcc = y1b * idet; bcd = y2b * idet;
+                }
+            } else {
+                // raw parameter columns [w_0 .. w_{nb-1}, init_pos (zero-padded family), 0 ..] per DoF
+                for (int i = lane; i < D * KS; i += 64) {
+                    const int dd = i / KS, k = i - dd * KS;
+                    float v = 0.0f;
+                    if (k < c.nb) v = prm[c.off + dd * c.Kloc + k];
+                    else if (k < KT) v = ipe[dd];
+                    sXf[i] = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            float* const out_pos = a.pos + (size_t)b * T * D;
+            float* const out_vel = a.vel + (size_t)b * T * D;
+            const float* const sXe = MP == MPK_MP_PRODMP ? img + e * a.x_pad : sXf;
+            MPK_STAMP(3 + 40 * e);                      // columns built
+            for (int r0 = 0; r0 < T; r0 += kStep) {
+                const bool final_round = T - r0 <= 64;
+                const int nout = final_round ? T - r0 : kStep;
+                const int t = r0 + lane < T ? r0 + lane : T - 1;
+                // prodmp: hq = (Psi_k, dPsi_k) pairs, as the table row holds them -- the position and velocity chains then are
+                // ONE packed fp32 FMA per k (v_pk_fma_f32) instead of two; promp: h = the lane's RBF row
+                float h[KS], hq[MP == MPK_MP_PRODMP ? 2 * KS : 2], rdt = 0.0f;
+                const float time = sBT[t] + it;
+                if (MP == MPK_MP_PRODMP) {
+                    const float s = fmaxf(div_exact(time - delay, dtau), 0.0f);
+                    if (s > (float)c.len_factor) atomicOr(a.flag, 1);
+                    const int idx = min((int)rintf(div_exact(s, dsdt)), c.n_pc - 1);
+                    const float4* row = reinterpret_cast<const float4*>(rows + (size_t)idx * kRow);
+#pragma unroll
+                    for (int j = 0; j < (2 * KS - 4) / 4; ++j) {
+                        const float4 q4 = row[j];
+                        hq[4 * j] = q4.x; hq[4 * j + 1] = q4.y; hq[4 * j + 2] = q4.z; hq[4 * j + 3] = q4.w;
+                    }
+                    // y1, y2, dy1, dy2 as float64 behind the pairs: turn them into (xi1, xi3) and (xi2, xi4), the pairs of
+                    // the two boundary-condition columns
+                    const double* y4 = reinterpret_cast<const double*>(row + (2 * KS - 4) / 4);
+                    const double y1 = y4[0], y2 = y4[1], dy1 = y4[2], dy2 = y4[3];
+                    // (a product and a fused multiply-add each: float64 runs at half rate, and this is per step)
+                    hq[2 * KS - 4] = (float)fma(bca, y1, -(bcb * y2));
+                    hq[2 * KS - 3] = (float)fma(bca, dy1, -(bcb * dy2));
+                    hq[2 * KS - 2] = (float)fma(bcc, y2, -(bcd * y1));
+                    hq[2 * KS - 1] = (float)fma(bcc, dy2, -(bcd * dy1));
+                } else {
+                    const double x = phase_f64(c, time, taud, delay, ec);
+#pragma unroll
+                    for (int k = 0; k < KS; ++k) h[k] = 0.0f;
+                    rbf_row<KS>(c, sCen, sCen + c.n_total, x, (double)c.ws, h, ec);
+                    const int th = t < T - 1 ? t + 1 : T - 1, tl = t < T - 1 ? t : T - 2;
+                    rdt = 1.0f / ((sBT[th] + it) - (sBT[tl] + it));
+                }
+                MPK_STAMP(10 + 40 * e + (r0 ? 10 : 0));   // rows gathered / evaluated
+                if (more && e == ne - 1 && r0 == 0) park_chunk(sImg + (slot ^ 1) * img_floats);
+                float* const gp = out_pos + (size_t)r0 * D;
+                const int sh = (int)((reinterpret_cast<uintptr_t>(gp) >> 2) & 3);
+                // one (step, DoF) contraction; `ND` DoF per loop iteration: the pair's loads, chains and staging writes
+                // share their address arithmetic and loop control, and the two chains fill each other's issue gaps (trace:
+                // the kernel is vector-issue-bound; 9 of the 17 instructions per DoF were not FMAs)
+                auto dof = [&](int d) {
+                    float x[KS];
+#pragma unroll
+                    for (int j = 0; j < KQ; ++j) {
+                        const float4 v = *reinterpret_cast<const float4*>(sXe + d * KS + 4 * j);
+                        x[4 * j + 0] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
+                    }
+                    float p = 0.0f, v = 0.0f;
+                    if (MP == MPK_MP_PRODMP) {
+                        f32x2 pv = {0.0f, 0.0f};        // (pos, vel) chains, ascending k: one v_pk_fma_f32 per k
+#pragma unroll
+                        for (int k = 0; k < KS; ++k)
+                            pv = __builtin_elementwise_fma(f32x2{hq[2 * k], hq[2 * k + 1]}, f32x2{x[k], x[k]}, pv);
+                        p = pv[0];
+                        v = pv[1] * inv_tau;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < KS; ++k) p = fmaf(h[k], x[k], p);
+                        const float nx = lane_above(p);
+                        v = (nx - p) * rdt;
+                        const float pv = lane_below(v);         // last row repeats the difference before it
+                        if (r0 + lane == T - 1) v = pv;
+                    }
+                    sO0[sh + lane * D + d] = p;        // every lane: the staging holds 64 rows, rows >= nout never leave
+                    sO1[sh + lane * D + d] = v;
+                };
+                constexpr int ND = KQ <= 2 ? 2 : 1;
+                int d = 0;
+                for (; d + ND <= D; d += ND) {
+#pragma unroll
+                    for (int i = 0; i < ND; ++i) dof(d + i);
+                }
+                for (; d < D; ++d) dof(d);
+                __builtin_amdgcn_wave_barrier();
+                MPK_STAMP(12 + 40 * e + (r0 ? 10 : 0));   // contracted, staged
+                if (a.wt) flush_span2<true>(sO0, sO1, gp, out_vel + (size_t)r0 * D, nout * D, sh, lane);
+                else flush_span2<false>(sO0, sO1, gp, out_vel + (size_t)r0 * D, nout * D, sh, lane);
+                __builtin_amdgcn_wave_barrier();
+                MPK_STAMP(13 + 40 * e + (r0 ? 10 : 0));   // stored
+                if (final_round) break;
+            }
+        }
+    }
+}
+
+template <int KQ>
+__global__ void __launch_bounds__(256) k_traj_phase_dmp(const PhaseArgs a) {
+    // DMP with a per-episode phase.  The Euler recurrence is serial in t and needs one lane per (episode, DoF); run per
+    // episode it keeps D of 64 lanes busy for T dependent steps -- 7 % of the HBM roofline for 7 DoF (round 1 / 2).  Here a
+    // wave owns a CHUNK of E (four, see the launcher) consecutive episodes and walks the horizon in tiles of 16 steps:
+    //   A  lane <-> (episode, step of the tile): phase, RBF row (float64, the builders' functions: same bits as every other
+    //      DMP kernel), the D forcing values of the step as fmaf chains in ascending k, the step's ds;
+    //   B  lane <-> (episode, DoF): 16 Euler steps, one rounding per operation, all E * D recurrences at once;
+    //   C  the tile's [E][16 * D] (pos | vel) blocks leave as float4 stores.
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const DevCfg& c = a.c;
+    constexpr int KS = KQ * 4, TT = 16;
+    constexpr int MP = MPK_MP_DMP;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wpb = (int)(blockDim.x >> 6);
+    const int D = c.D, T = c.T, E = a.chunk, P = c.P;
+    const int seg = TT * D;                             // floats of one episode's tile
+    double* sCen = reinterpret_cast<double*>(smem);     // [c_pad / 2] RBF centres | bandwidths (| recurrence constants)
+    float* sBT = smem + a.c_pad;                        // [t_pad] base times, shared by the workgroup
+    float* sX = sBT + a.t_pad + (size_t)wave * a.wave_floats;   // [E][D][KS] columns: weights .., goal, y0, ydot0
+    float* sPh = sX + E * a.x_pad;                      // [E][8] tau, delay, init_time (clipped), -, 1 / tau refined (float64), -
+    float* sDs = sPh + 8 * E;                           // [E][TT] ds of the tile's steps
+    float* sH = sDs + E * TT;                           // [64][KS] the round's RBF rows
+    float* sP = sH + 64 * KS;                           // [E][TT * D] forcing -> pos
+    float* sV = sP + a.o_pad;                           // [E][TT * D] vel
+    for (int t = threadIdx.x; t < T; t += blockDim.x) sBT[t] = c.base_times[t];
+    for (int k = threadIdx.x; k < 2 * c.n_total + 3; k += blockDim.x) sCen[k] = c.tab[k];
+    __syncthreads();
+    const float inv_d = 1.0f / (float)D;
+    const int le = (int)(((float)lane + 0.5f) * inv_d), ld = lane - le * D;        // lane <-> (episode, DoF)
+    const float inv_seg4 = 4.0f / (float)seg, inv_seg = 1.0f / (float)seg;   // (idx + 0.5) * inv: exact floor for idx < 2^16
+    const bool vec = a.vec_ok != 0;                     // float4 stores: 16-byte aligned outputs, T * D a multiple of 4
+    const int nchunks = (a.B + E - 1) / E;
+    const int cstride = (int)gridDim.x * wpb;
+    for (int ch = (int)blockIdx.x * wpb + wave; ch < nchunks; ch += cstride) {
+        const int b0 = ch * E, ne = min(E, a.B - b0);
+        // ---- the chunk's inputs: columns of every (episode, DoF), phase values per episode
+        for (int idx = lane; idx < ne * D * KS; idx += 64) {
+            const int pi = idx / KS, k = idx - pi * KS;             // pi = e * D + dd
+            const int e = (int)(((float)pi + 0.5f) * inv_d), dd = pi - e * D;
+            const size_t bb = (size_t)(b0 + e);
+            sX[idx] = phase_x_value<MP>(c, a.params + bb * P, a.init_pos + bb * D, a.init_vel + bb * D, dd, k, KS);
+        }
+        float tau = c.tau, delay = c.delay, it = a.init_time_shared;
+        const bool on = lane < ne * D;
+        if (on) {
+            const float* prm = a.params + (size_t)(b0 + le) * P;
+            // np.clip(action, low, high): only tau / delay carry finite bounds (black_box_wrapper.py:104-105)
+            if (c.learn_tau) tau = fminf(fmaxf(prm[0], c.tau_lo), c.tau_hi);
+            if (c.learn_delay) delay = fminf(fmaxf(prm[c.learn_tau ? 1 : 0], c.delay_lo), c.delay_hi);
+            if (a.init_time) it = a.init_time[b0 + le];
+            if (ld == 0) {
+                sPh[8 * le] = tau; sPh[8 * le + 1] = delay; sPh[8 * le + 2] = it;
+                *reinterpret_cast<double*>(sPh + 8 * le + 4) = make_pos_div((double)tau).y;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        float y = 0.0f, z = 0.0f, g = 0.0f;
+        if (on) {
+            const float* xc = sX + lane * KS;
+            g = xc[KS - 3] * c.gs; y = xc[KS - 2]; z = xc[KS - 1] * tau;
+        }
+        const TauDiv td = make_tau_div(tau);
+        for (int t0 = 0; t0 < T; t0 += TT) {
+            const int rows = min(TT, T - t0);
+            // ---- A: rows and forcing of the tile
+            for (int i0 = 0; i0 < ne * TT; i0 += 64) {
+                const int idx = i0 + lane, e = idx >> 4, tl = idx & (TT - 1), t = t0 + tl;
+                const bool live = idx < ne * TT && t < T;
+                float* row = sH + lane * KS;
+                if (live) {
+                    const float taue = sPh[8 * e], delaye = sPh[8 * e + 1], ite = sPh[8 * e + 2];
+                    const float time = sBT[t] + ite;
+                    const PosDiv taud{(double)taue, *reinterpret_cast<const double*>(sPh + 8 * e + 4)};
+                    const double x = phase_f64(c, time, taud, delaye, ExpLiteral());
+                    // every RBF once, in registers (rbf_cols evaluates them for the sum and again for the values; same bits)
+                    float h[KS];
+#pragma unroll
+                    for (int k = 0; k < KS; ++k) h[k] = 0.0f;
+                    rbf_row<KS>(c, sCen, sCen + c.n_total, x, x * (double)c.ws, h, ExpLiteral());
+#pragma unroll
+                    for (int j = 0; j < KQ; ++j)
+                        *reinterpret_cast<f32x4*>(row + 4 * j) = f32x4{h[4 * j], h[4 * j + 1], h[4 * j + 2], h[4 * j + 3]};
+                    if (t < T - 1) sDs[idx] = scaled_time(sBT[t + 1] + ite, delaye, taue) - scaled_time(time, delaye, taue);
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (live) {
+                    for (int d = 0; d < D; ++d) {
+                        float x[KS];
+#pragma unroll
+                        for (int j = 0; j < KQ; ++j) {
+                            const float4 v = *reinterpret_cast<const float4*>(sX + (e * D + d) * KS + 4 * j);
+                            x[4 * j + 0] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
+                        }
+                        x[KS - 3] = 0.0f; x[KS - 2] = 0.0f; x[KS - 1] = 0.0f;      // goal, y0, ydot0 are not weights
+                        sP[e * seg + tl * D + d] = row_chain<KQ>(row, x);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            // ---- B: 16 Euler steps of every (episode, DoF) of the chunk (one rounding per operation)
+            if (on) {
+                float* pp = sP + le * seg + ld;
+                float* pv = sV + le * seg + ld;
+                const float* pds = sDs + le * TT;
+                for (int tl = 0; tl < rows; ++tl) {
+                    const float f = pp[tl * D];
+                    pp[tl * D] = y;
+                    pv[tl * D] = div_tau(z, td);
+                    if (t0 + tl < T - 1) {
+                        const float ds = pds[tl];
+                        const float t1 = g - y;
+                        const float t2 = c.dmp_beta * t1;
+                        const float t3 = t2 - z;
+                        const float t4 = c.dmp_alpha * t3;
+                        const float acc = t4 + f;
+                        z = z + ds * acc;
+                        y = y + ds * z;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // ---- C: the tile's blocks, one contiguous run of rows * D floats per episode and array
+            const int n = rows * D;
+            if (vec) {
+                const int n4 = n >> 2, tail = n & 3;
+                for (int i0 = 0; i0 < ne * (seg >> 2); i0 += 64) {
+                    const int idx = i0 + lane;
+                    const int e = (int)(((float)idx + 0.5f) * inv_seg4), q = idx - e * (seg >> 2);
+                    if (e < ne && q < n4) {
+                        const size_t go = ((size_t)(b0 + e) * T + t0) * D + 4 * q;
+                        const f32x4 vp = *reinterpret_cast<const f32x4*>(sP + e * seg + 4 * q);
+                        const f32x4 vv = *reinterpret_cast<const f32x4*>(sV + e * seg + 4 * q);
+                        if (a.wt) { store16<true>(a.pos + go, vp); store16<true>(a.vel + go, vv); }
+                        else { store16<false>(a.pos + go, vp); store16<false>(a.vel + go, vv); }
+                    }
+                }
+                if (tail) {                             // the last tile of a horizon whose rows * D is no multiple of 4
+                    for (int i0 = 0; i0 < ne * 4; i0 += 64) {
+                        const int idx = i0 + lane, e = idx >> 2, r = idx & 3;
+                        if (e < ne && r < tail) {
+                            const size_t go = ((size_t)(b0 + e) * T + t0) * D + 4 * n4 + r;
+                            if (a.wt) { store4<true>(a.pos + go, sP[e * seg + 4 * n4 + r]); store4<true>(a.vel + go, sV[e * seg + 4 * n4 + r]); }
+                            else { store4<false>(a.pos + go, sP[e * seg + 4 * n4 + r]); store4<false>(a.vel + go, sV[e * seg + 4 * n4 + r]); }
+                        }
+                    }
+                }
+            } else {
+                for (int i0 = 0; i0 < ne * seg; i0 += 64) {
+                    const int idx = i0 + lane;
+                    const int e = (int)(((float)idx + 0.5f) * inv_seg), w = idx - e * seg;
+                    if (e < ne && w < n) {
+                        const size_t go = ((size_t)(b0 + e) * T + t0) * D + w;
+                        if (a.wt) { store4<true>(a.pos + go, sP[e * seg + w]); store4<true>(a.vel + go, sV[e * seg + w]); }
+                        else { store4<false>(a.pos + go, sP[e * seg + w]); store4<false>(a.vel + go, sV[e * seg + w]); }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();            // the tile's LDS reads are issued before the next tile's writes
+        }
+    }
+}
+
+#ifndef MPK_DEVICE_ONLY
+static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu, void* stream,
+                             const char** kernel_name, const Tuning& tune) {
+    PhaseArgs pa = base;
+    const bool dmp = c.mp_type == MPK_MP_DMP;
+    bool flat = false, modelled = false;   // prodmp: chunk size chosen by the cost model (no balance rule on top)
+    // dmp: + goal, y0, ydot0 columns; prodmp: weights, goal, y1 | y2 (a goal offset is added to the goal itself here)
+    const int need = c.mp_type == MPK_MP_PRODMP ? c.nb + 3 : c.KT + (dmp ? 3 : 0);
+    if (need > 16 || c.D > 64) return MPK_ENOTIMPL;
+    const int KQ = need <= 4 && c.mp_type == MPK_MP_PROMP ? 1 : (need <= 8 ? 2 : 4), KS = KQ * 4;
+    if (c.D * KS > 256) return MPK_ENOTIMPL;
+    if (c.mp_type == MPK_MP_PRODMP && (!c.rows32 || c.rows32_stride != 2 * KS + 4)) return MPK_ENOTIMPL;
+    pa.t_pad = (c.T + 3) / 4 * 4;
+    pa.x_pad = c.D * KS;
+    pa.o_pad = (64 * c.D + 4 + 3) / 4 * 4;
+    if (dmp) {
+        // a wave owns chunks of E consecutive episodes, one lane per (episode, DoF) in the Euler recurrence
+        // measured at 7 DoF, T = 200 (us at B = 4096 / 65536): E = 1 94 / 1220, 2 67 / 633, 3 70 / 479, **4 62 / 406**, 6 96 / 454,
+        // 9 131 / 503 -- four episodes make the 64 (episode, step) items of a tile exactly one round of the wave, and the
+        // per-wave LDS (6.8 KB) still lets 20 waves share a CU; "phase_chunk" overrides (up to 64 / D, at most 16)
+        const int e_max = 64 / c.D > 16 ? 16 : 64 / c.D;
+        int E = e_max < 4 ? e_max : 4;
+        if (tune.phase_chunk >= 1 && tune.phase_chunk <= e_max) E = tune.phase_chunk;
+        pa.chunk = E;
+        pa.o_pad = E * 16 * c.D;                                  // one (pos or vel) tile of the chunk
+        pa.wave_floats = E * pa.x_pad + 8 * E + E * 16 + 64 * KS + 2 * pa.o_pad;
+        pa.vec_ok = ((reinterpret_cast<uintptr_t>(pa.pos) | reinterpret_cast<uintptr_t>(pa.vel)) & 15u) == 0 && (c.T * c.D) % 4 == 0 ? 1 : 0;
+    } else {
+        // chunks of up to 4 consecutive episodes whose parameter rows fit the loader's 5 x 64 values and whose boundary
+        // states fit one 64-lane load
+        int E = 320 / c.P;
+        E = E > 4 ? 4 : E;
+        E = E > 64 / c.D ? 64 / c.D : E;
+        if (E < 1) return MPK_ENOTIMPL;
+        // prodmp: per-episode rounds with one episode per chunk, or flat rounds (k_traj_phase<.., FL>) over chunks of up to 8
+        // episodes -- whichever has the shorter critical path per wave: passes over the resident waves x (rounds of a chunk +
+        // ~2.5 rounds of per-chunk work: inputs, columns, boundary factors); a flat round costs ~15 % more (per-lane episode
+        // constants).  Measured at cfg2 + learned tau (T = 100): B = 4096 11.7 us per-episode vs 15 - 24 flat; 16 384 31.9 vs
+        // 23.4 - 24.8 (5 - 7 episodes per chunk); 65 536 94 vs 89; 262 144 equal (HBM) -- profiles/r03_per_episode_phase.md.
+        // "phase_flat" / "phase_chunk" override.
+        if (c.mp_type == MPK_MP_PRODMP) {
+            int e_max = 320 / c.P;
+            e_max = e_max > 8 ? 8 : e_max;
+            e_max = e_max > 64 / c.D ? 64 / c.D : e_max;
+            const size_t shared0 = (size_t)(pa.t_pad + (c.nb + 2 + 3) / 4 * 4) * sizeof(float);
+            const size_t tab_bytes = (size_t)c.n_pc * (2 * KS + 4) * sizeof(float);
+            auto resident = [&](int e, bool fl) -> long {           // waves of the whole chip for this layout (as below)
+                const int img_in = e * (c.P + 2 * c.D + 1), img_cols = e * (pa.x_pad + (fl ? 12 : 3));
+                const size_t wb = (size_t)(2 * (((img_in > img_cols ? img_in : img_cols) + 3) / 4 * 4) + 2 * pa.o_pad) * sizeof(float);
+                const bool tab = tune.phase_table != 0 && tab_bytes + 8 * wb <= 160 * 1024 - shared0 && (long)pa.B >= (long)num_cu * 8;
+                int w = tab ? (int)((160 * 1024 - shared0 - tab_bytes) / wb) : (int)((64 * 1024 - shared0) / wb);
+                w = tab ? (w > 16 ? 16 : w) : (w > 4 ? 4 : (w < 1 ? 1 : w));
+                int pc = (int)(160 * 1024 / (wb * w + shared0 + (tab ? tab_bytes : 0)));
+                pc = pc > 32 / w ? 32 / w : (pc < 1 ? 1 : pc);
+                return (long)num_cu * pc * w;
+            };
+            auto cost = [&](int e, bool fl) -> double {
+                const long chunks = ((long)pa.B + e - 1) / e, W = resident(e, fl);
+                const double passes = (double)((chunks + W - 1) / W);
+                const double rounds = fl ? 1.15 * (double)((e * c.T + 63) / 64) : (double)(e * ((c.T + 63) / 64));
+                return passes * (rounds + 2.5);
+            };
+            if (tune.phase_flat == 0) {
+                flat = false;
+            } else if (tune.phase_flat == 1) {
+                flat = true;
+                double best = 1e300;
+                for (int e = 1; e <= e_max; ++e)
+                    if (cost(e, true) < best - 1e-9) { best = cost(e, true); E = e; }
+                modelled = true;
+            } else {
+                double best = cost(1, false);
+                E = 1; flat = false;
+                for (int e = 2; e <= e_max; ++e)
+                    if (cost(e, true) < best * 0.97) { best = cost(e, true); E = e; flat = true; }
+                modelled = true;
+            }
+            if (flat && tune.phase_chunk >= 1 && tune.phase_chunk <= e_max) E = tune.phase_chunk;
+            if (tune.phase_chunk >= 1) modelled = flat;
+        }
+        pa.chunk = E;
+        // prodmp: the image is rewritten in place into [E][x_pad] columns + [E][3] clipped phase values (flat rounds: [E][4]
+        // + [E][4] float64 boundary-condition factors)
+        const int img_in = E * (c.P + 2 * c.D + 1), img_cols = c.mp_type == MPK_MP_PRODMP ? E * (pa.x_pad + (flat ? 12 : 3)) : 0;
+        pa.img_pad = ((img_in > img_cols ? img_in : img_cols) + 3) / 4 * 4;
+        pa.wave_floats = 2 * pa.img_pad + 2 * pa.o_pad + (c.mp_type == MPK_MP_PRODMP ? 0 : pa.x_pad);
+    }
+    pa.c_pad = c.mp_type == MPK_MP_PRODMP ? (c.nb + 2 + 3) / 4 * 4 : (4 * c.n_total + 6 + 3) / 4 * 4;
+    const size_t wave_bytes = (size_t)pa.wave_floats * sizeof(float);
+    size_t shared_bytes = (size_t)(pa.t_pad + pa.c_pad) * sizeof(float);
+    if (wave_bytes + shared_bytes > 160 * 1024) return MPK_ENOTIMPL;
+    int wpb = (int)((64 * 1024 - shared_bytes) / wave_bytes);
+    wpb = wpb > 4 ? 4 : (wpb < 1 ? 1 : wpb);
+    // prodmp: stage the row table in LDS when it leaves room for at least 8 waves ("phase_table" 0: gather from L2)
+    bool lds_table = false;
+    if (c.mp_type == MPK_MP_PRODMP) {
+        const size_t tab_bytes = (size_t)c.n_pc * (2 * KS + 4) * sizeof(float);
+        const size_t room = 160 * 1024 - shared_bytes;
+        lds_table = tab_bytes + 8 * wave_bytes <= room && (long)pa.B >= (long)num_cu * 8;
+        if (tune.phase_table == 0) lds_table = false;
+        if (lds_table) {
+            pa.tab_pad = c.n_pc * (2 * KS + 4);
+            shared_bytes += tab_bytes;
+            wpb = (int)((160 * 1024 - shared_bytes) / wave_bytes);
+            wpb = wpb > 16 ? 16 : wpb;
+        }
+    }
+    const size_t lds = wave_bytes * wpb + shared_bytes;
+    int per_cu = (int)(160 * 1024 / lds);
+    per_cu = per_cu > 32 / wpb ? 32 / wpb : per_cu;
+    if (!dmp && !modelled) {
+        // chunks cost balance (a wave's work is quantised in E episodes): only when every resident wave still gets >= 4
+        const long resident = (long)num_cu * per_cu * wpb;
+        int E = pa.chunk;
+        while (E > 1 && (long)pa.B / E < 4 * resident) E >>= 1;
+        if (tune.phase_chunk >= 1 && tune.phase_chunk <= pa.chunk) E = tune.phase_chunk;
+        pa.chunk = E;
+    }
+    const long units = ((long)pa.B + pa.chunk - 1) / pa.chunk;
+    long blocks = (units + wpb - 1) / wpb;
+    if (blocks > (long)num_cu * per_cu) blocks = (long)num_cu * per_cu;
+    auto go = [&](auto kern) -> int {
+        if (lds > 64 * 1024) {
+            hipError_t e = allow_full_lds(kern);
+            if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return MPK_EHIP; }
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * wpb), lds, (hipStream_t)stream, pa);
+        MPK_LAUNCH_CHECK();
+        return MPK_OK;
+    };
+    switch (c.mp_type) {
+        case MPK_MP_PRODMP:
+            if (lds_table) {
+                *kernel_name = flat ? "k_traj_phase<prodmp,lds,flat>" : "k_traj_phase<prodmp,lds>";
+                if (flat) return KQ == 2 ? go(k_traj_phase<MPK_MP_PRODMP, 2, true, true>) : go(k_traj_phase<MPK_MP_PRODMP, 4, true, true>);
+                return KQ == 2 ? go(k_traj_phase<MPK_MP_PRODMP, 2, true>) : go(k_traj_phase<MPK_MP_PRODMP, 4, true>);
+            }
+            *kernel_name = flat ? "k_traj_phase<prodmp,flat>" : "k_traj_phase<prodmp>";
+            if (flat) return KQ == 2 ? go(k_traj_phase<MPK_MP_PRODMP, 2, false, true>) : go(k_traj_phase<MPK_MP_PRODMP, 4, false, true>);
+            return KQ == 2 ? go(k_traj_phase<MPK_MP_PRODMP, 2, false>) : go(k_traj_phase<MPK_MP_PRODMP, 4, false>);
+        case MPK_MP_PROMP:
+            *kernel_name = "k_traj_phase<promp>";
+            if (KQ == 1) return go(k_traj_phase<MPK_MP_PROMP, 1, false>);
+            return KQ == 2 ? go(k_traj_phase<MPK_MP_PROMP, 2, false>) : go(k_traj_phase<MPK_MP_PROMP, 4, false>);
+        default:
+            *kernel_name = "k_traj_phase<dmp>";
+            return KQ == 2 ? go(k_traj_phase_dmp<2>) : go(k_traj_phase_dmp<4>);
+    }
+}
+#endif  // MPK_DEVICE_ONLY
+
+// ------------------------------------------------------------------------------------------------------------
+// k_dmp_prestep (MPK_DMP_FIRST_IS_STEP): the boundary state advanced by ONE Euler step from init_time to the first grid
+// time, with the forcing and the scaled-time increment at init_time -- the state the trajectory kernels then start
+// from.  One lane per (episode, DoF); the row arithmetic of rbf_cols (both of its branches), operation for operation.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_dmp_prestep(const DevCfg c, const float* __restrict__ params,
+                                                     const float* __restrict__ init_pos,
+                                                     const float* __restrict__ init_vel,
+                                                     const float* __restrict__ init_time, const float init_time_shared,
+                                                     float* __restrict__ pos1, float* __restrict__ vel1, const int B) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)B * c.D) return;
+    const int b = (int)(e / c.D), d = (int)(e - (long)b * c.D);
+    const float* prm = params + (size_t)b * c.P;
+    float tau = c.tau, delay = c.delay;
+    int o = 0;
+    if (c.learn_tau) { tau = fminf(fmaxf(prm[o], c.tau_lo), c.tau_hi); ++o; }
+    if (c.learn_delay) delay = fminf(fmaxf(prm[o], c.delay_lo), c.delay_hi);
+    const float it = init_time ? init_time[b] : init_time_shared;
+    const float t1 = c.base_times[0] + it;
+    const float ds0 = scaled_time(t1, delay, tau) - scaled_time(it, delay, tau);
+    const double x = phase_f64(c, it, tau, delay, ExpLiteral());
+    const double* cen = c.tab;
+    const double* bw = c.tab + c.n_total;
+    // the forcing row at init_time: the SAME arithmetic as rbf_cols / rbf_row (product recurrence where the host enabled
+    // it), so this sample is bit-identical to what the trajectory kernels produce for the same phase value
+    const double mul = x * (double)c.ws;
+    const float* w = prm + c.off + d * c.Kloc;
+    float f0 = 0.0f;
+    if (c.rbf_uniform) {
+        RbfRecur s1(cen, bw, c.n_total, x, ExpLiteral());
+        double sum = 0.0;
+        for (int k = 0; k < c.n_total; ++k) sum += s1.next();
+        const double scale = div_pos(mul, sum);
+        RbfRecur s2(cen, bw, c.n_total, x, ExpLiteral());
+        for (int k = 0; k < c.zs + c.nb; ++k) {
+            const double ek = s2.next();
+            if (k >= c.zs) f0 = fmaf((float)(ek * scale), w[k - c.zs], f0);
+        }
+    } else {
+        double sum = 0.0;
+        for (int k = 0; k < c.n_total; ++k) {
+            const double dx = x - cen[k];
+            sum += exp_nonpos(-(dx * dx * bw[k]) * 0.5);
+        }
+        const double scale = c.n_total > 1 ? div_pos(mul, sum) : mul;
+        for (int k = 0; k < c.nb; ++k) {
+            const double dx = x - cen[c.zs + k];
+            const float h = (float)(exp_nonpos(-(dx * dx * bw[c.zs + k]) * 0.5) * scale);
+            f0 = fmaf(h, w[k], f0);
+        }
+    }
+    float y = init_pos[e];
+    float z = init_vel[e] * tau;
+    const float g = w[c.nb] * c.gs;
+    const float t1_ = g - y;
+    const float t2 = c.dmp_beta * t1_;
+    const float t3 = t2 - z;
+    const float t4 = c.dmp_alpha * t3;
+    const float acc = t4 + f0;
+    z = z + ds0 * acc;
+    y = y + ds0 * z;
+    pos1[e] = y;
+    vel1[e] = div_tau(z, make_tau_div(tau));
+}
+
+#ifndef MPK_DEVICE_ONLY
+int launch_dmp_prestep(const DevCfg& c, const float* params, const float* init_pos, const float* init_vel,
+                       const float* init_time, float init_time_shared, float* pos1, float* vel1, int B, void* stream) {
+    hipLaunchKernelGGL(k_dmp_prestep, dim3((unsigned)(((long)B * c.D + 255) / 256)), dim3(256), 0, (hipStream_t)stream, c,
+                       params, init_pos, init_vel, init_time, init_time_shared, pos1, vel1, B);
+    MPK_LAUNCH_CHECK();
+    return MPK_OK;
+}
+#endif  // MPK_DEVICE_ONLY
+
+#ifndef MPK_DEVICE_ONLY
+int launch_traj_rows(const DevCfg& c, const float* params, const float* init_pos, const float* init_vel,
+                     const float* init_time, float init_time_shared, float* pos, float* vel, int32_t* range_flag,
+                     int B, int num_cu, void* stream, const char** kernel_name, const Tuning& tune) {
+    if (c.mp_type == MPK_MP_PROMP && c.T < 2) {
+        set_error("promp needs at least two time steps for the finite-difference velocity");
+        return MPK_EINVAL;
+    }
+    // wave-per-episode kernel whenever the shape fits it ("phase" 0: the workgroup-per-episode kernel below)
+    const bool wave_kernel = tune.phase != 0;
+    if (wave_kernel) {
+        PhaseArgs pa{c, params, init_pos, init_vel, init_time, init_time_shared, pos, vel, range_flag, B, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        pa.wt = (double)B * c.T * c.D * 8.0 <= kWtBytes ? 1 : 0;
+        if (tune.write_through >= 0) pa.wt = tune.write_through != 0 ? 1 : 0;
+        const int rc = launch_traj_phase(c, pa, num_cu, stream, kernel_name, tune);
+        if (rc != MPK_ENOTIMPL) return rc;
+    }
+    const int nrow = c.mp_type == MPK_MP_PRODMP ? 2 : 1;
+    const size_t floats = (size_t)c.D * c.KT + (size_t)nrow * c.T * c.KT + (size_t)c.T * c.D +
+                          (c.mp_type == MPK_MP_DMP ? (size_t)c.T * c.D : 0) + c.T + 8;
+    const size_t lds = floats * sizeof(float);
+    if (lds > 160 * 1024) { set_error("trajectory too large for the per-episode kernel's LDS budget"); return MPK_EINVAL; }
+    RowArgs ra{c, params, init_pos, init_vel, init_time, init_time_shared, pos, vel, range_flag, B};
+    int blocks = B < num_cu * 8 ? B : num_cu * 8;
+    auto go = [&](auto kern) -> int {
+        if (lds > 64 * 1024) {
+            hipError_t e = allow_full_lds(kern);
+            if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return MPK_EHIP; }
+        }
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, (hipStream_t)stream, ra);
+        MPK_LAUNCH_CHECK();
+        return MPK_OK;
+    };
+    switch (c.mp_type) {
+        case MPK_MP_PRODMP: *kernel_name = "k_traj_rows<prodmp>"; return go(k_traj_rows<MPK_MP_PRODMP>);
+        case MPK_MP_PROMP: *kernel_name = "k_traj_rows<promp>"; return go(k_traj_rows<MPK_MP_PROMP>);
+        default: *kernel_name = "k_traj_rows<dmp>"; return go(k_traj_rows<MPK_MP_DMP>);
+    }
+}
+#endif  // MPK_DEVICE_ONLY
+
+}  // namespace mpk

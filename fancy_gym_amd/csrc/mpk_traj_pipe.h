@@ -1,0 +1,170 @@
+// k_traj_pipe: the closed-loop step as a wave-specialised producer / consumer pipeline
+#pragma once
+#include "mpk_tile.h"
+
+namespace mpk {
+
+// ---- episode-major, wave-specialised: the closed-loop step as a producer / consumer pipeline -------------------------
+// What bounds k_traj_quad / k_traj_stream<closed> at a few thousand episodes is not arithmetic but ONE wave doing
+// everything in sequence, 7 row tiles x (contract -> LDS -> recurrence -> LDS -> store), every latency exposed (PMC at
+// B = 4096, profiles/r02_closed_loop.md: 2 590 VALU + 408 LDS + 564 scalar instructions per wave, 42 % of the wave's
+// cycles in s_waitcnt).  Here a workgroup of FIVE waves owns four consecutive episode groups:
+//   waves 1..4  (producers)  contract row tile rt + 1 of "their" group on the matrix cores into LDS image (rt + 1) & 1
+//               and store tile rt (pos, vel, actions) from image rt & 1;
+//   wave 0      (consumer)   runs the controller + plant recurrence of tile rt for all four groups at once, one group per
+//               lane quarter (float64, no FMA: pd_tile_steps, the operations of every other closed-loop kernel, bit for
+//               bit), while the producers are busy with tile rt + 1 and with the stores of tile rt - 1.
+// One workgroup barrier per row tile hands the images over.  The integer replanning state, the boundary-condition gather
+// and the plant state are the consumer's, exactly as in k_traj_quad.
+constexpr int kPipeGroups = 4;
+
+template <int MP, int CT, int KM>
+__global__ void __launch_bounds__(320) k_traj_pipe(const TrajArgs a, const ActArgs act) {
+    static_assert(CT >= 3 && MP != MPK_MP_DMP, "closed loop, promp / prodmp");
+    __shared__ __attribute__((aligned(16))) float smem[2 * kPipeGroups * kQuadImg];   // [buffer][group] pos | vel | act
+    extern __shared__ __attribute__((aligned(16))) float sTab[];                      // [NOUT][KP][TS] rows + [TS] aux
+    constexpr int NOUT = MP == MPK_MP_PRODMP ? 2 : 3;
+    const DevCfg& c = a.c;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int KP = 4 * KM, TS = a.TS, D = c.D, B = a.B, T = c.T;
+    float* sA = sTab;
+    float* sAux = sTab + NOUT * KP * TS;
+    const LaneMap<KM> L = make_lane_map<MP, KM>(a, lane);
+    const int NTW = L.NTW, NRT = (T + 15) >> 4;
+    const int nb8 = gridDim.x >> 3;
+    const int vb = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * nb8 + (blockIdx.x >> 3) : blockIdx.x;
+    const int NU = (a.G + kPipeGroups - 1) / kPipeGroups;
+    (void)act;
+    MPK_STAMP_AT(1, 0); MPK_STAMP_AT(101, 64);
+    // head of the critical path: the producers' first inputs and the basis rows of row tile 0 are requested before the
+    // table copy (tile 0 is contracted from registers while the LDS copy lands; later tiles read the copy)
+    GroupIn<KM> nx;
+    float a0[NOUT][KM];
+    if (wave != 0) {
+        if (vb < NU) {
+            const int g = vb * kPipeGroups + wave - 1;
+            nx = load_group<MP, false, KM>(a, L, g < a.G ? g : a.G - 1);
+        }
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+            for (int m = 0; m < KM; ++m) a0[o][m] = a.A[(o * KP + 4 * m + L.q) * TS + L.col];
+    }
+    // basis tables -> LDS by all five waves (a 256-thread loop shape: threads 256.. take the tail)
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.A);
+        float4* dst = reinterpret_cast<float4*>(sA);
+        const int nA4 = (NOUT * KP * TS) >> 2, nX4 = TS >> 2;
+        for (int i = threadIdx.x; i < nA4; i += 320) dst[i] = src[i];
+        for (int i = threadIdx.x; i < nX4; i += 320) reinterpret_cast<float4*>(sAux)[i] = reinterpret_cast<const float4*>(a.aux)[i];
+    }
+    if (wave == 0) {
+        __syncthreads();                                                    // (the table copy: the producers' barrier)
+        // ---------------- consumer: four recurrences, one per lane quarter ----------------
+        const Gains gq = kernarg_gains(L.dvalid ? L.d : 0);
+        const double pgd = gq.pg, dgd = gq.dg, lod = __builtin_canonicalize(gq.lo), hid = __builtin_canonicalize(gq.hi);
+        for (int u = vb; u < NU; u += (int)gridDim.x) {
+            const int gsel = u * kPipeGroups + L.q, bq = gsel * NTW + L.bl;
+            const bool serial = L.dvalid && gsel < a.G && bq < B;
+            double qs = 0.0, qds = 0.0;
+            int nst = 0;
+            if (serial) {
+                const size_t ix = (size_t)bq * D + L.d;
+                qs = a.q_state[ix]; qds = a.qd_state[ix];
+                nst = T;
+                if (a.rp.traj_steps) nst = replan_rule(a.rp, bq, T, L.d == 0);
+                else if (a.n_steps) nst = min(a.n_steps[bq], T);
+            }
+            const int tcond = (serial && a.rp.cond_pos) ? min(max(nst - 1, 0), T - 1) : -1;
+            const int oq = L.bl * a.pitch + L.d + (int)ep_shift(a, bq);      // (row 0, this column) in group q's image
+            __syncthreads();                                                // tile 0 is in image 0
+            for (int rt = 0; rt < NRT; ++rt) {
+                float* sQ = smem + ((rt & 1) * kPipeGroups + L.q) * kQuadImg;
+                const bool full_tile = tile_fully_executed(serial, nst, rt * 16);
+                if (serial && rt * 16 < max(nst, tcond + 1)) {
+                    if (tcond >= rt * 16 && tcond < rt * 16 + 16) {   // condition_on_desired: the desired state at the
+                        const size_t si = (size_t)bq * D + L.d;          // last executed step
+                        a.rp.cond_pos[si] = sQ[oq + (tcond - rt * 16) * D];
+                        a.rp.cond_vel[si] = sQ[kStageStride + oq + (tcond - rt * 16) * D];
+                    }
+                    if (full_tile)
+                        pd_tile_steps<CT - 3, false>(sQ + oq, sQ + kStageStride + oq, sQ + 2 * kStageStride + oq, D, rt * 16, nst,
+                                                     pgd, dgd, lod, hid, a.plant_dt, qs, qds);
+                    else
+                        pd_tile_steps<CT - 3, true>(sQ + oq, sQ + kStageStride + oq, sQ + 2 * kStageStride + oq, D, rt * 16, nst,
+                                                    pgd, dgd, lod, hid, a.plant_dt, qs, qds);
+                }
+                __syncthreads();                                            // tile rt's actions are final; tile rt + 1 is in
+            }
+            if (serial) {
+                const size_t si = (size_t)bq * D + L.d;
+                a.q_state[si] = qs; a.qd_state[si] = qds;
+            }
+        }
+    } else {
+        // ---------------- producers: wave j + 1 owns group u * 4 + j ----------------
+        const int j = wave - 1;
+        const float* ap = sA + L.q * TS + L.col;
+        int u = vb;
+        for (; u < NU; u += (int)gridDim.x) {
+            const int g = u * kPipeGroups + j;
+            const bool have = g < a.G;
+            float xb[KM];
+            finish_group<KM>(L, nx, xb);
+            const int un = u + (int)gridDim.x;
+            if (un < NU) {
+                const int gn = un * kPipeGroups + j;
+                nx = load_group<MP, false, KM>(a, L, gn < a.G ? gn : a.G - 1);
+            }
+            const unsigned wofs = L.wofs + ep_shift(a, g * NTW + L.bl);
+            auto produce = [&](int rt, auto first_tag) {
+                constexpr bool FIRST = decltype(first_tag)::value;          // rows of tile 0 of the first unit: registers
+                float* sJ = smem + ((rt & 1) * kPipeGroups + j) * kQuadImg;
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < KM; ++m) {
+                    const float* am = ap + (4 * m) * TS + rt * 16;
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(FIRST ? a0[0][m] : am[0], xb[m], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(FIRST ? a0[1][m] : am[KP * TS], xb[m], acc1, 0, 0, 0);
+                    if (NOUT > 2) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(FIRST ? a0[NOUT > 2 ? 2 : 0][m] : am[(NOUT > 2 ? 2 : 0) * KP * TS], xb[m], acc2, 0, 0, 0);
+                }
+                float dtd[4] = {1.f, 1.f, 1.f, 1.f};
+                if (MP == MPK_MP_PROMP) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dtd[r] = FIRST ? a.aux[4 * L.q + r] : sAux[rt * 16 + 4 * L.q + r];
+                }
+                if (L.dvalid) tile_epilogue<MP, CT>(acc0, acc1, acc2, dtd, 0.0, 0.0, Gains{0.0, 0.0, 0.0, 0.0}, sJ, wofs, D);
+            };
+            // pos and vel of a tile leave as soon as it is contracted (nothing of theirs waits for the consumer: two thirds
+            // of the store stream are independent of the recurrence); the actions follow after the barrier
+            auto store_arrays = [&](auto mask_tag, int rt) {
+                constexpr int MASK = decltype(mask_tag)::value;
+                const float* sJ = smem + ((rt & 1) * kPipeGroups + j) * kQuadImg;
+                const int rows = min(16, T - rt * 16);
+                if (a.wt) tile_store_sel<MASK, KM, true>(a, L, sJ, lane, g * NTW, rt, rows);
+                else tile_store_sel<MASK, KM, false>(a, L, sJ, lane, g * NTW, rt, rows);
+            };
+            // tile 0 is handed to the consumer before its pos / vel are stored: the recurrence is the critical path
+            if (u == vb) {
+                if (have) produce(0, std::true_type());
+                __syncthreads();                                            // the table copy has landed (all five waves;
+            } else if (have) {                                              // every workgroup owns at least one unit)
+                produce(0, std::false_type());
+            }
+            __syncthreads();                                                // tile 0 is in image 0
+            if (have) store_arrays(std::integral_constant<int, 3>(), 0);
+            for (int rt = 0; rt < NRT; ++rt) {
+                if (have && rt + 1 < NRT) {
+                    produce(rt + 1, std::false_type());
+                    __builtin_amdgcn_wave_barrier();
+                    store_arrays(std::integral_constant<int, 3>(), rt + 1);
+                }
+                __syncthreads();                                            // tile rt's actions are final
+                if (have) store_arrays(std::integral_constant<int, 4>(), rt);
+            }
+        }
+    }
+}
+
+}  // namespace mpk

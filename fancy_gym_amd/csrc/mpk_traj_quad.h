@@ -1,0 +1,213 @@
+// k_traj_quad / duo / mono: the serial-recurrence variants, several groups per wave
+#pragma once
+#include "mpk_tile.h"
+
+namespace mpk {
+
+// ---- episode-major, four groups per wave: the serial-recurrence variants ---------------------------------------------
+// DMP (Euler recurrence) and the closed-loop rollout (controller + plant recurrence) are serial in t and run on the
+// 16 lanes that hold row 0 of a column.  Here a wave owns FOUR consecutive episode groups at once: per row tile it
+// produces the four C tiles back to back on the matrix cores, then lane quarter q runs group q's recurrence, so the four
+// recurrences advance in parallel (4x fewer serial instructions per episode), then the four tiles leave as coalesced
+// float4 stores.  Same arithmetic and bits as k_traj_stream.
+constexpr int kQuad = 4;
+// floats per group image (pos | vel | act or force): 8 floats past a multiple of the 32 LDS banks, so that the four lane
+// quarters -- which walk the four images with the same in-image offsets during the recurrences -- fall on disjoint banks
+// (measured before the skew: 43 % of the kernel's LDS cycles were bank conflicts)
+constexpr int kQuadImg = 3 * kStageStride + 8;
+
+template <int MP, int CT, int KM, int NQ>
+__global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActArgs act) {
+    static_assert(NQ == 1 || NQ == 2 || NQ == 4, "one, two or four groups per wave");
+    __shared__ __attribute__((aligned(16))) float smem[4 * NQ * kQuadImg];   // per wave: 4 x (pos|vel|act or force)
+    extern __shared__ __attribute__((aligned(16))) float sTab[];   // [NOUT][KP][TS] rows + [TS] aux
+    constexpr bool CLOSED = CT >= 3;
+
+    static_assert(MP == MPK_MP_DMP || CLOSED, "k_traj_quad is for the serial-recurrence variants");
+    constexpr int NOUT = MP == MPK_MP_PRODMP ? 2 : (MP == MPK_MP_PROMP ? 3 : 1);
+    constexpr int NST = CLOSED ? 3 : 2;
+    const DevCfg& c = a.c;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int KP = 4 * KM, TS = a.TS, D = c.D, B = a.B, P = c.P, T = c.T;
+    float* sW = smem + wave * (NQ * kQuadImg);
+    float* sA = sTab;
+    float* sAux = sTab + NOUT * KP * TS;
+    const LaneMap<KM> L = make_lane_map<MP, KM>(a, lane);
+    const int NTW = L.NTW, NRT = (T + 15) >> 4;
+    const int nb8 = gridDim.x >> 3;
+    const int vb = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * nb8 + (blockIdx.x >> 3) : blockIdx.x;
+    const int ustride = gridDim.x * 4;
+    const int NU = (a.G + NQ - 1) / NQ;
+    int u = vb * 4 + wave;
+
+    // A lane's serial-recurrence inputs for one unit: group u * 4 + q, column (bl, d).  Fetched one unit ahead, like the
+    // B-fragment inputs (the integer replanning state of the episode is advanced at fetch time by its d == 0 lane).
+    struct SerialIn { double qs, qds; int nst; float ey, ez, eg; bool on; };
+    auto load_serial = [&](int uu) {
+        SerialIn si{0.0, 0.0, T, 0.f, 0.f, 0.f, false};
+        const int gq = uu * NQ + L.q, bq = gq * NTW + L.bl;
+        si.on = L.dvalid && L.q < NQ && gq < a.G && bq < B;
+        if (si.on) {
+            const size_t ix = (size_t)bq * D + L.d;
+            if (CLOSED) {
+                si.qs = a.q_state[ix]; si.qds = a.qd_state[ix];
+                if (a.rp.traj_steps) si.nst = replan_rule(a.rp, bq, T, L.d == 0);
+                else if (a.n_steps) si.nst = min(a.n_steps[bq], T);
+            } else {
+                si.ey = a.init_pos[ix];
+                si.ez = a.init_vel[ix] * c.tau;
+                si.eg = a.params[(size_t)bq * P + c.off + L.d * c.Kloc + c.nb] * c.gs;
+            }
+        }
+        return si;
+    };
+    // the first unit's inputs are in flight while the workgroup stages the basis tables
+    GroupIn<KM> nx[NQ];
+    SerialIn sn{0.0, 0.0, T, 0.f, 0.f, 0.f, false};
+    MPK_STAMP(1);
+    if (u < NU) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int g = u * NQ + j;
+            nx[j] = load_group<MP, false, KM>(a, L, g < a.G ? g : a.G - 1);
+        }
+        sn = load_serial(u);
+    }
+    stage_tables(a.A, a.aux, sA, sAux, (NOUT * KP * TS) >> 2, TS >> 2, threadIdx.x);
+    __syncthreads();
+    MPK_STAMP(2);
+    if (u >= NU) return;
+    const float* ap = sA + L.q * TS + L.col;
+    const TauDiv td = make_tau_div(c.tau);
+    double pgd = 0.0, dgd = 0.0, lod = 0.0, hid = 0.0;
+    if (CLOSED) {
+        // four vector loads from the kernel-argument segment (see kernarg_gains) instead of 64 exec-masked selects
+        const Gains gq = kernarg_gains(L.dvalid ? L.d : 0);
+        pgd = gq.pg; dgd = gq.dg;
+        lod = __builtin_canonicalize(gq.lo); hid = __builtin_canonicalize(gq.hi);   // not again at every step's fmin / fmax
+    }
+    (void)act;
+
+    float xb[NQ][KM];
+    while (u < NU) {
+        const int g0 = u * NQ;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) finish_group<KM>(L, nx[j], xb[j]);
+        const SerialIn sc = sn;
+        MPK_STAMP(3);
+        const int un = u + ustride;
+        if (un < NU) {
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const int g = un * NQ + j;
+                nx[j] = load_group<MP, false, KM>(a, L, g < a.G ? g : a.G - 1);
+            }
+            sn = load_serial(un);
+        }
+        // this lane's recurrence: group g0 + q, column (bl, d)
+        const int gq = g0 + L.q, bq = gq * NTW + L.bl;
+        const bool serial = sc.on;
+        const int oq = L.bl * a.pitch + L.d + (int)ep_shift(a, bq);      // (row 0, this column) in group q's image
+        float* sQ = sW + L.q * kQuadImg;
+        double qs = sc.qs, qds = sc.qds;
+        const int nst = sc.nst;
+        float ey = sc.ey, ez = sc.ez, eg = sc.eg;
+        const int tcond = (CLOSED && a.rp.cond_pos) ? min(max(nst - 1, 0), T - 1) : -1;
+        // A fragments (basis rows of a row tile) are the same for the four groups: read from LDS once per tile, one tile
+        // ahead, into registers.  Left to the compiler they are re-read in front of every MFMA (it cannot prove that
+        // the staging writes do not alias the tables), and with one or two waves per SIMD each of those LDS round trips
+        // is exposed.
+        float afn[NOUT][KM];
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+            for (int m = 0; m < KM; ++m) afn[o][m] = ap[(o * KP + 4 * m) * TS];
+        for (int rt = 0; rt < NRT; ++rt) {
+            const int rows = min(16, T - rt * 16);
+            float af[NOUT][KM];
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+                for (int m = 0; m < KM; ++m) af[o][m] = afn[o][m];
+            if (rt + 1 < NRT) {
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+                    for (int m = 0; m < KM; ++m) afn[o][m] = ap[(o * KP + 4 * m) * TS + (rt + 1) * 16];
+            }
+            // 1. four C tiles on the matrix cores -> four staging images
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                if (g0 + j < a.G) {
+                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int m = 0; m < KM; ++m) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][m], xb[j][m], acc0, 0, 0, 0);
+                        if (NOUT > 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[NOUT > 1 ? 1 : 0][m], xb[j][m], acc1, 0, 0, 0);
+                        if (NOUT > 2) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[NOUT > 2 ? 2 : 0][m], xb[j][m], acc2, 0, 0, 0);
+                    }
+                    float* sJ = sW + j * kQuadImg;
+                    const unsigned wofs = L.wofs + ep_shift(a, (g0 + j) * NTW + L.bl);
+                    if (L.dvalid) {
+                        if (MP == MPK_MP_DMP) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) sJ[2 * kStageStride + wofs + r * D] = acc0[r];
+                        } else {
+                            float dtd[4] = {1.f, 1.f, 1.f, 1.f};
+                            if (MP == MPK_MP_PROMP) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) dtd[r] = sAux[rt * 16 + 4 * L.q + r];
+                            }
+                            tile_epilogue<MP, CT>(acc0, acc1, acc2, dtd, 0.0, 0.0, Gains{0.0, 0.0, 0.0, 0.0}, sJ, wofs, D);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            MPK_STAMP(10 + rt);
+            // 2. four recurrences in parallel, one per lane quarter (float64 / fp32 without FMA, as k_traj_stream)
+            const bool full_tile = CLOSED && tile_fully_executed(serial, nst, rt * 16);
+            if (serial && (!CLOSED || rt * 16 < max(nst, tcond + 1))) {
+                if (CLOSED) {
+                    if (tcond >= rt * 16 && tcond < rt * 16 + 16) {   // condition_on_desired: the desired state at the
+                        const size_t si = (size_t)bq * D + L.d;          // last executed step
+                        a.rp.cond_pos[si] = sQ[oq + (tcond - rt * 16) * D];
+                        a.rp.cond_vel[si] = sQ[kStageStride + oq + (tcond - rt * 16) * D];
+                    }
+                    if (full_tile)
+                        pd_tile_steps<(CLOSED ? CT - 3 : 0), false>(sQ + oq, sQ + kStageStride + oq, sQ + 2 * kStageStride + oq, D,
+                                                                    rt * 16, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds);
+                    else
+                        pd_tile_steps<(CLOSED ? CT - 3 : 0), true>(sQ + oq, sQ + kStageStride + oq, sQ + 2 * kStageStride + oq, D,
+                                                                   rt * 16, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds);
+                } else {
+                    dmp_tile_steps(sQ + 2 * kStageStride + oq, sQ + oq, sQ + kStageStride + oq, sAux + rt * 16, D, rt * 16, T,
+                                   c.dmp_alpha, c.dmp_beta, eg, td, ey, ez);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            MPK_STAMP(30 + rt);
+            // 3. coalesced stores of the four tiles
+#pragma unroll
+            for (int j = 0; j < NQ; ++j)
+                if (g0 + j < a.G)
+                {
+                    if (a.wt) tile_store<NST, KM, true>(a, L, sW + j * kQuadImg, lane, (g0 + j) * NTW, rt, rows);
+                    else tile_store<NST, KM, false>(a, L, sW + j * kQuadImg, lane, (g0 + j) * NTW, rt, rows);
+                }
+            __builtin_amdgcn_wave_barrier();
+            MPK_STAMP(50 + rt);
+        }
+        if (CLOSED) {
+            if (serial) {
+                const size_t si = (size_t)bq * D + L.d;
+                a.q_state[si] = qs; a.qd_state[si] = qds;
+            }
+        }
+        MPK_STAMP(90);
+        u = un;
+    }
+}
+
+}  // namespace mpk

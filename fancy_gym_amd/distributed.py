@@ -133,6 +133,10 @@ class GatheredTrajectories:
         j = i - shard_bounds(self.num_episodes, r, self.world)[0]
         return self.pos[r, j], self.vel[r, j]
 
+    def __iter__(self):
+        """``pos, vel = gather_trajectories(...)`` keeps working (the round-2 return type): the [B, T, D] pair of flat()"""
+        return iter(self.flat())
+
     def flat(self) -> Tuple[torch.Tensor, torch.Tensor]:
         """[B, T, D] copies in global episode order (the only place a copy is made, and only on request)"""
         if self.num_episodes == self.world * self.cap:
@@ -156,7 +160,10 @@ def gather_trajectories(pos: torch.Tensor, vel: torch.Tensor, num_episodes: int,
     half = cap * int(pos.shape[1]) * int(pos.shape[2]) * item if pos.dim() == 3 else -1
     adjacent = (pos.dim() == 3 and pos.dtype == torch.float32 and vel.dtype == torch.float32 and pos.shape == vel.shape
                 and pos.is_contiguous() and vel.is_contiguous() and vel.data_ptr() == pos.data_ptr() + half
-                and pos.untyped_storage().data_ptr() == vel.untyped_storage().data_ptr())
+                and pos.untyped_storage().data_ptr() == vel.untyped_storage().data_ptr()
+                # ... and the storage really holds the whole [2, cap, T, D] block behind `pos` (a ragged shard of tensors that
+                # did not come from a TrajectoryShard may end before it: stage a copy then)
+                and pos.storage_offset() * item + 2 * half <= pos.untyped_storage().nbytes())
     sh = TrajectoryShard.__new__(TrajectoryShard)
     sh.num_episodes, sh.rank, sh.world, sh.cap = int(num_episodes), rank, world, cap
     a, b = shard_bounds(num_episodes, rank, world)

@@ -80,7 +80,7 @@ class TrajectoryEngine:
                  basis_alpha: float = 25.0, basis_dt: float = 0.01, pre_compute_length_factor: int = 6,
                  weights_scale: float = 1.0, goal_scale: float = 1.0, dmp_alpha: float = 25.0,
                  auto_scale_basis: bool = False, relative_goal: bool = False, disable_goal: bool = False,
-                 disable_weights: bool = False, relative_goal_mode: str = "after_scale",
+                 disable_weights: bool = False, relative_goal_mode: str = "before_scale",
                  goal_offset_mode: str = "ignore", goal_offset: float = 0.0, single_rbf_mode: str = "unit_gap",
                  dmp_first_sample: str = "init", device: Union[int, torch.device, None] = None):
         self._h = C.c_void_p()
@@ -270,6 +270,16 @@ class TrajectoryEngine:
         c_pos[:, -1] = 0.0
         return c_pos, torch.zeros_like(c_pos)
 
+    @staticmethod
+    def _refuse_metaworld(spec, entry: str):
+        """entry points that update the plant state in place cannot zero the gripper entry of the state the way
+        _metaworld_state does for a frozen one: running the plain motor law there would turn the gripper action into
+        des - q[-1] without a word"""
+        if getattr(spec, "metaworld", False):
+            raise ValueError(f"{entry}: the metaworld controller runs on the device for a frozen state only "
+                             "(trajectory_actions / pd_rollout with plant='static'); step metaworld environments on the "
+                             "host (VectorBlackBox)")
+
     def trajectory_actions(self, params, init_pos, init_vel, spec: RolloutSpec, c_pos, c_vel, init_time: float = 0.0,
                            out=None):
         """Fused trajectory + open-loop controller actions for a state frozen over the plan (MPK_PLANT_STATIC)."""
@@ -297,6 +307,7 @@ class TrajectoryEngine:
         One fused launch: trajectory + closed-loop controller / double-integrator rollout (BlackBoxWrapper.step for a
         GPU-resident plant).  q, qd float64 [B, D] are updated in place.  Returns (pos, vel, actions).
         """
+        self._refuse_metaworld(spec, "trajectory_rollout")
         params = torch.as_tensor(params, dtype=torch.float32, device=self.device)
         if params.dim() == 1:
             params = params[None]
@@ -340,6 +351,7 @@ class TrajectoryEngine:
         ONE launch where the fused closed-loop kernel applies.  q, qd, traj_steps, plan_steps, done are updated in place.
         Returns dict(pos, vel, actions, seg_len int32 [B], done uint8 [B] snapshot, cond_pos, cond_vel (or None)).
         """
+        self._refuse_metaworld(spec, "replan_step")
         params = torch.as_tensor(params, dtype=torch.float32, device=self.device)
         if params.dim() == 1:
             params = params[None]
@@ -393,6 +405,7 @@ class TrajectoryEngine:
         pd_rollout + SimpleReacherEnv's per-step reward (simple_reacher.py:56-72) on the torque double integrator:
         returns (actions float32 [B, T, D] or None, rewards float64 [B, T]); q, qd are updated in place.
         """
+        self._refuse_metaworld(spec, "reacher_rollout")
         B, T, D = des_pos.shape
         assert des_pos.dtype == torch.float32 and des_vel.dtype == torch.float32
         assert q.dtype == torch.float64 and qd.dtype == torch.float64 and q.is_contiguous() and qd.is_contiguous()

@@ -229,9 +229,9 @@ class ProDMP(MPInterface):
         # (default) accepts and drops it, 'add' adds it to the goal (include/mpk.h MPK_GOAL_OFFSET_*)
         self.goal_offset = kwargs.pop("goal_offset", None)
         self.goal_offset_mode = kwargs.pop("goal_offset_mode", "ignore")
-        # relative_goal: init_pos joins the scaled goal ('after_scale', default) or the raw goal parameter
-        # ('before_scale') -- include/mpk.h MPK_RELGOAL_*
-        self.relative_goal_mode = kwargs.pop("relative_goal_mode", "after_scale")
+        # relative_goal: init_pos joins the raw goal parameter ('before_scale', default since ABI 3) or the scaled goal
+        # ('after_scale') -- include/mpk.h MPK_RELGOAL_*; unpinned either way
+        self.relative_goal_mode = kwargs.pop("relative_goal_mode", "before_scale")
         kwargs.pop("duration", None)   # _BB_DEFAULTS['ProDMP'] carries a stray 'duration' (registry.py:108)
         super().__init__(basis_gn, num_dof, weights_scale, **kwargs)
 

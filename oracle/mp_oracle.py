@@ -93,8 +93,9 @@ class TrajCfg:
     disable_goal: bool = False
     disable_weights: bool = False
     # SURVEY Appendix A "(?)" items as explicit switches (same names and meaning as include/mpk.h); first = default
-    relative_goal_mode: str = "after_scale"   # 'after_scale': goal = s_g*g + init_pos | 'before_scale': s_g*(g + init_pos)
-    #   ^ doubted default (two independent readers recall 'before_scale'; no reference config distinguishes them at 1e-5):
+    relative_goal_mode: str = "before_scale"  # 'before_scale': goal = s_g*(g + init_pos) | 'after_scale': s_g*g + init_pos
+    #   ^ UNPINNED either way.  Default flipped in round 4 (was 'after_scale'): three independent readers of upstream
+    #     prodmp.py recall init_pos joining the RAW goal parameter; no reference config distinguishes the two at 1e-5;
     #     tools/pin_against_mp_pytorch.py decides it where mp_pytorch is installed (include/mpk.h MPK_RELGOAL_*)
     goal_offset_mode: str = "ignore"          # 'ignore' (swallowed by **kwargs) | 'add': goal += goal_offset
     goal_offset: float = 0.0
@@ -478,8 +479,8 @@ def prodmp_trajectory(pc: PhaseCfg, bc: BasisCfg, tc: TrajCfg, params: Array, ti
         xi1  = (dy2_b*y1 - dy1_b*y2)/det     xi2 = (y1_b*y2 - y2_b*y1)/det      (xi3, xi4: same with dy1, dy2)
         H    = Psi  - xi1 (x) Psi_b - xi2 (x) dPsi_b        Hv = dPsi - xi3 (x) Psi_b - xi4 (x) dPsi_b
         pos  = xi1*y_b + xi2*(tau*v_b) + H . wg            vel = (xi3*y_b + xi4*(tau*v_b) + Hv . wg) / tau
-    wg = [w, g] * weights_goal_scale per DoF; relative_goal adds init_pos to the scaled goal -- or, with
-    relative_goal_mode='before_scale', to the raw goal parameter (SURVEY A.5 "(?)"); goal_offset_mode='add' adds
+    wg = [w, g] * weights_goal_scale per DoF; relative_goal adds init_pos to the raw goal parameter -- or, with
+    relative_goal_mode='after_scale', to the scaled goal (SURVEY A.5 "(?)"); goal_offset_mode='add' adds
     goal_offset to the goal (default: ignored, as **kwargs swallows it upstream).
     """
     f = dtype

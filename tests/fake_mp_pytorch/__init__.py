@@ -11,5 +11,5 @@ exhibits, so a test can check that the script reports exactly that setting.
 __version__ = "0.0-facade-over-the-oracle"
 
 # the behaviour the facade exhibits for the four "(?)" switches (same names as oracle.TrajCfg / BasisCfg fields)
-BEHAVIOUR = dict(relative_goal_mode="after_scale", goal_offset_mode="ignore", single_rbf_mode="unit_gap",
+BEHAVIOUR = dict(relative_goal_mode="before_scale", goal_offset_mode="ignore", single_rbf_mode="unit_gap",
                  dmp_first_sample="init")

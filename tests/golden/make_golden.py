@@ -210,9 +210,11 @@ def t_prodmp(pc, bc, tc, params, duration, dt, init_time, init_pos, init_vel):
         full[..., :nb] = local[..., :nb]; c = nb
     if not tc.disable_goal:
         full[..., nb] = local[..., c]
-    wg = full * scale
     ip, iv = torch.as_tensor(init_pos, dtype=F), torch.as_tensor(init_vel, dtype=F)
-    if tc.relative_goal:
+    if tc.relative_goal and tc.relative_goal_mode == "before_scale":
+        full[..., -1] = full[..., -1] + ip            # init_pos joins the raw goal parameter (the default)
+    wg = full * scale
+    if tc.relative_goal and tc.relative_goal_mode == "after_scale":
         wg[..., -1] = wg[..., -1] + ip
     idx = bg.indices(times, tau, delay)
     idxb = bg.indices(it[:, None], tau, delay)[:, 0]

@@ -1052,6 +1052,11 @@ def test_bench_gpus_2_starts_two_ranks_itself_and_gathers_both_shards():
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 2 * B and d["config"]["batch_per_gpu"] == B
     assert d["scaling"] == "weak" and d["steps"] == 20 and d["warmup"] == 3
+    # the N-rank line is diagnosable: every rank's wall-clock sample and event-timed kernel average, `value` from the slowest
+    assert len(d["per_rank_ms"]) == 2 and len(d["per_rank_kernel_avg_us"]) == 2
+    assert abs(max(d["per_rank_ms"]) - d["ms_per_step"] * 20) <= 1e-6 * max(d["per_rank_ms"])
+    assert d["kernel_avg_us_max"] == max(d["per_rank_kernel_avg_us"]) > 0
+    assert abs(d["event_timed_value"] - 2 * B / (d["kernel_avg_us_max"] * 1e-6)) <= 1e-6 * d["event_timed_value"]
     ag = d["allgather"]
     assert ag["gathered_equals_shards"] is True and len(ag["shard_checksums"]) == 2
     assert ag["bytes_gathered_per_gpu_per_step"] == B * 2 * 100 * 7 * 4

@@ -49,8 +49,8 @@ def _prodmp_case(pc, bc, tc, dt, duration, params, ip, iv, init_time, tau=None, 
         w = local[..., :nb] * scale[:nb]; c = nb
     if not tc.disable_goal:
         g = local[..., c] * scale[nb]
-    if tc.relative_goal:
-        g = g + ip.astype(np.float64)          # default mode: init_pos joins the scaled goal
+    if tc.relative_goal:                       # default mode: init_pos joins the RAW goal parameter, the scale applies to both
+        g = g + ip.astype(np.float64) * (scale[nb] if tc.relative_goal_mode == "before_scale" else 1.0)
     base = eng.times()
     out_y, out_v = np.empty_like(pos), np.empty_like(vel)
     slope = np.zeros(B)

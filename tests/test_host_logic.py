@@ -41,7 +41,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"libmpk.so does not export {name}"
     assert declared == set(_lib.SIGNATURES), "ctypes signature table and include/mpk.h disagree"
-    assert _lib.load().mpk_abi_version() == _lib.MPK_ABI_VERSION == 2
+    assert _lib.load().mpk_abi_version() == _lib.MPK_ABI_VERSION == 3
 
 
 def test_config_struct_layout_matches_header():
@@ -491,7 +491,7 @@ def test_options_api_without_a_gpu():
         _lib.set_option("mapping", 7)
     assert lib.mpk_set_option(None, None, 0) == _lib.MPK_EINVAL
     _lib.reset_options()
-    for src in ("mpk_kernels.hip", "mpk_host.cpp"):
+    for src in _lib.KERNEL_UNITS + _lib.KERNEL_HEADERS + ("mpk_host.cpp",):
         text = open(os.path.join(ROOT, "fancy_gym_amd", "csrc", src)).read()
         assert "getenv" not in text, f"{src} reads the environment"
 
@@ -518,18 +518,18 @@ def test_oracle_switches_change_what_they_say_they_change():
     rng = np.random.default_rng(0)
     prm = rng.standard_normal((3, 12)); ip = rng.uniform(-1, 1, (3, 2)); iv = np.zeros((3, 2))
     run = lambda t: O.get_trajectory(pc, bc, t, prm, 2.0, 0.02, 0.0, ip, iv, dtype=np.float64)[0]   # noqa: E731
-    after, before = run(tc), run(dataclasses.replace(tc, relative_goal_mode="before_scale"))
+    after, before = run(dataclasses.replace(tc, relative_goal_mode="after_scale")), run(tc)   # before_scale: the default
     # 5 tau: the trajectory has reached its goal -- s_g*g + y_b vs s_g*(g + y_b)
     np.testing.assert_allclose(after[:, -1] - before[:, -1], (1 - 0.3) * ip, rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(after[:, -1], 0.3 * prm.reshape(3, 2, 6)[..., 5] + ip, rtol=1e-3, atol=1e-4)
     off = run(dataclasses.replace(tc, goal_offset_mode="add", goal_offset=1.0))
-    np.testing.assert_allclose(off[:, -1] - after[:, -1], 1.0, rtol=1e-3, atol=1e-4)
-    assert np.array_equal(run(dataclasses.replace(tc, goal_offset=1.0)), after)            # default: ignored
+    np.testing.assert_allclose(off[:, -1] - before[:, -1], 1.0, rtol=1e-3, atol=1e-4)
+    assert np.array_equal(run(dataclasses.replace(tc, goal_offset=1.0)), before)            # default: ignored
     # with goal_scale * auto-scale == 1 (the reference's TableTennis configuration) the two orderings coincide
     tt = O.TrajCfg("prodmp", action_dim=2, weights_scale=0.7, auto_scale_basis=True, relative_goal=True, disable_goal=True)
     p8 = rng.standard_normal((3, 10))
     a = O.get_trajectory(pc, bc, tt, p8, 2.0, 0.02, 0.0, ip, iv, dtype=np.float64)[0]
-    b = O.get_trajectory(pc, bc, dataclasses.replace(tt, relative_goal_mode="before_scale"), p8, 2.0, 0.02, 0.0, ip, iv,
+    b = O.get_trajectory(pc, bc, dataclasses.replace(tt, relative_goal_mode="after_scale"), p8, 2.0, 0.02, 0.0, ip, iv,
                          dtype=np.float64)[0]
     np.testing.assert_allclose(a, b, atol=2e-6)
 

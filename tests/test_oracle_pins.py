@@ -301,7 +301,7 @@ def test_oracle_against_mp_pytorch_reference_outputs(tmp_path):
     assert "PINNED: the oracle with its shipped defaults reproduces the reference on every case" in r.stdout
 
 
-@pytest.mark.parametrize("switch,value", [(None, None), ("relative_goal_mode", "before_scale"), ("goal_offset_mode", "add"),
+@pytest.mark.parametrize("switch,value", [(None, None), ("relative_goal_mode", "after_scale"), ("goal_offset_mode", "add"),
                                           ("single_rbf_mode", "refuse"), ("dmp_first_sample", "step")])
 def test_pin_script_plumbing_with_the_facade(tmp_path, switch, value):
     """

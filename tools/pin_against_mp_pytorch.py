@@ -53,7 +53,7 @@ from tests.golden import make_golden as G  # noqa: E402  (the BASELINE configura
 
 # the four "(?)" switches (oracle dataclass field, owner record, candidate values; first = the shipped default)
 SWITCHES = {
-    "relative_goal_mode": ("tc", ("after_scale", "before_scale")),
+    "relative_goal_mode": ("tc", ("before_scale", "after_scale")),
     "goal_offset_mode": ("tc", ("ignore", "add")),
     "single_rbf_mode": ("bc", ("unit_gap", "refuse")),
     "dmp_first_sample": ("tc", ("init", "step")),
@@ -90,6 +90,19 @@ def _cases():
         pc=O.PhaseCfg("linear", tau=2.0), bc=O.BasisCfg("rbf", num_basis=1, basis_bandwidth_factor=3),
         tc=O.TrajCfg("promp", action_dim=2), dt=0.02, duration=2.0, B=2, init_times=[0.0], extra={},
         switches=["single_rbf_mode"])
+    # ---- ProMP corners nothing but recollection covers (no switch behind them: either the oracle's RBF placement matches or
+    # it does not): centres OUTSIDE [delay, delay + tau] (num_basis_outside > 0: first centre at -outside * gap, the last gap
+    # repeated for the bandwidth), and zero padding at the GOAL end (num_basis_zero_goal > 0: the returned columns are the
+    # middle ones, normalised over all nb + zs + zg).  Both with a non-zero delay so that the time -> phase mapping of the
+    # centres is exercised as well.
+    cases["probe_promp_basis_outside"] = dict(
+        pc=O.PhaseCfg("linear", tau=1.6, delay=0.2), bc=O.BasisCfg("rbf", num_basis=6, basis_bandwidth_factor=3, num_basis_outside=2),
+        tc=O.TrajCfg("promp", action_dim=2, weights_scale=0.8), dt=0.02, duration=2.0, B=2, init_times=[0.0], extra={},
+        switches=[])
+    cases["probe_promp_zero_goal"] = dict(
+        pc=O.PhaseCfg("linear", tau=1.6, delay=0.2),
+        bc=O.BasisCfg("zero_rbf", num_basis=4, basis_bandwidth_factor=3, num_basis_zero_start=2, num_basis_zero_goal=3),
+        tc=O.TrajCfg("promp", action_dim=2), dt=0.02, duration=2.0, B=2, init_times=[0.0], extra={}, switches=[])
     cases["probe_dmp_first_sample"] = dict(
         pc=O.PhaseCfg("exp", tau=2.0, alpha_phase=2.0), bc=O.BasisCfg("rbf", num_basis=4, basis_bandwidth_factor=3),
         tc=O.TrajCfg("dmp", action_dim=2, alpha=25.0), dt=0.02, duration=2.0, B=2, init_times=[0.0, 0.5], extra={},

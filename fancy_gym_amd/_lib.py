@@ -27,7 +27,7 @@ GOAL_OFFSET_MODES = {"ignore": 0, "add": 1}
 SINGLE_RBF_MODES = {"unit_gap": 0, "refuse": 1}
 DMP_FIRST_SAMPLE_MODES = {"init": 0, "step": 1}
 OPTION_KEYS = ("mapping", "bulk", "quad", "pd_quad", "write_through", "ipw", "phase", "phase_table", "phase_chunk",
-               "pd_simple", "split", "lds_pad", "pipe", "flat", "phase_flat")
+               "pd_simple", "split", "lds_pad", "pipe", "flat", "phase_flat", "ring", "ring_np", "ring_ns", "ring_m", "ring_dbg")
 
 
 class MPKLibraryError(RuntimeError):
@@ -128,7 +128,7 @@ _lib: Optional[C.CDLL] = None
 _ROOT = os.path.dirname(_HERE)
 KERNEL_UNITS = ("mpk_traj_family.hip", "mpk_traj_launch.hip", "mpk_traj_wide.hip", "mpk_traj_phase.hip", "mpk_rollout.hip",
                 "mpk_misc.hip")          # translation units of the device code (mpk_traj_family.hip: once per MP type)
-KERNEL_HEADERS = ("mpk_dev.h", "mpk_tile.h", "mpk_traj_tiles.h", "mpk_traj_stream.h", "mpk_traj_flat.h", "mpk_traj_quad.h",
+KERNEL_HEADERS = ("mpk_dev.h", "mpk_tile.h", "mpk_traj_tiles.h", "mpk_traj_stream.h", "mpk_traj_flat.h", "mpk_traj_ring.h", "mpk_traj_quad.h",
                   "mpk_traj_pipe.h")
 SOURCE_FILES = (os.path.join(_ROOT, "include", "mpk.h"), os.path.join(_HERE, "csrc", "mpk_internal.h"),
                 os.path.join(_HERE, "csrc", "mpk_host.cpp")) + \

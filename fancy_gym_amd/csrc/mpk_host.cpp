@@ -50,6 +50,7 @@ struct DeviceGuard {
 
 // process-wide kernel-selection defaults (mpk_set_option with a NULL handle)
 static Tuning g_tune;
+constexpr unsigned kTicketSlots = 256;   // ticket counters per handle (k_traj_ring), 128 bytes apart
 
 // ------------------------------------------------------------------------------------------------------------
 // times
@@ -217,6 +218,8 @@ struct Handle {
     int rows32_stride = 0;
     float* d_times = nullptr;
     int32_t* d_flag = nullptr;   // range-error flag written by kernels
+    unsigned* d_tickets = nullptr;   // k_traj_ring: kTicketSlots device-wide batch counters, one cache line apart; a launch takes
+    unsigned ticket_next = 0;        // the next one round robin (launches of one handle on different streams may overlap)
     int32_t* d_idx = nullptr;    // scratch for mpk_prodmp_indices
     int idx_cap = 0;
     static constexpr int kCache = 64;    // distinct init_times of one replanning episode (a 100-step horizon replanned every 2 steps)
@@ -228,26 +231,7 @@ struct Handle {
     size_t pre_cap = 0;
 };
 
-static Tuning effective_tuning(const Handle* h) {
-    Tuning t = g_tune;
-    const Tuning& o = h->tune;
-    if (o.mapping >= 0) t.mapping = o.mapping;
-    if (o.bulk >= 0) t.bulk = o.bulk;
-    if (o.quad >= 0) t.quad = o.quad;
-    if (o.pd_quad >= 0) t.pd_quad = o.pd_quad;
-    if (o.write_through >= 0) t.write_through = o.write_through;
-    if (o.ipw >= 0) t.ipw = o.ipw;
-    if (o.phase >= 0) t.phase = o.phase;
-    if (o.phase_table >= 0) t.phase_table = o.phase_table;
-    if (o.phase_chunk >= 0) t.phase_chunk = o.phase_chunk;
-    if (o.pd_simple >= 0) t.pd_simple = o.pd_simple;
-    if (o.split >= 0) t.split = o.split;
-    if (o.lds_pad >= 0) t.lds_pad = o.lds_pad;
-    if (o.pipe >= 0) t.pipe = o.pipe;
-    if (o.flat >= 0) t.flat = o.flat;
-    if (o.phase_flat >= 0) t.phase_flat = o.phase_flat;
-    return t;
-}
+static Tuning effective_tuning(const Handle* h);   // defined beside the option table
 
 static int check_cfg(const mpk_config& c) {
     if (c.abi_version != MPK_ABI_VERSION) { set_error("mpk_config.abi_version mismatch"); return MPK_EINVAL; }
@@ -390,6 +374,7 @@ static void free_handle(Handle* h) {
     if (h->d_rows32) (void)hipFree(h->d_rows32);
     if (h->d_times) (void)hipFree(h->d_times);
     if (h->d_flag) (void)hipFree(h->d_flag);
+    if (h->d_tickets) (void)hipFree(h->d_tickets);
     if (h->d_idx) (void)hipFree(h->d_idx);
     if (h->d_pre) (void)hipFree(h->d_pre);
     delete h;
@@ -620,6 +605,7 @@ int mpk_create(const mpk_config* cfg, mpk_handle* out) {
     }
     if (hipMalloc((void**)&h->d_flag, sizeof(int32_t)) != hipSuccess) { set_error("hipMalloc(flag) failed"); return fail(MPK_EHIP); }
     if (hipMemset(h->d_flag, 0, sizeof(int32_t)) != hipSuccess) { set_error("hipMemset(flag) failed"); return fail(MPK_EHIP); }
+    if (hipMalloc((void**)&h->d_tickets, kTicketSlots * 128) != hipSuccess) { set_error("hipMalloc(ticket counters) failed"); return fail(MPK_EHIP); }
     rc = upload_times(h);
     if (rc != MPK_OK) return fail(rc);
     fill_devcfg(h);
@@ -679,7 +665,9 @@ const OptKey kOptKeys[] = {
     {"phase_chunk", &Tuning::phase_chunk, 0, 16}, {"pd_simple", &Tuning::pd_simple, 0, 1},
     {"split", &Tuning::split, 0, 1},             {"lds_pad", &Tuning::lds_pad, 0, 48},
     {"pipe", &Tuning::pipe, 0, 1},               {"flat", &Tuning::flat, 0, 1},
-    {"phase_flat", &Tuning::phase_flat, 0, 1},
+    {"phase_flat", &Tuning::phase_flat, 0, 1},   {"ring", &Tuning::ring, 0, 2},
+    {"ring_np", &Tuning::ring_np, 1, 14},        {"ring_ns", &Tuning::ring_ns, 1, 8},
+    {"ring_m", &Tuning::ring_m, 1, 8},           {"ring_dbg", &Tuning::ring_dbg, 0, 63},
 };
 const OptKey* find_opt(const char* key) {
     if (!key) return nullptr;
@@ -688,6 +676,16 @@ const OptKey* find_opt(const char* key) {
     return nullptr;
 }
 }  // namespace
+
+namespace mpk {
+// a handle's own setting wins over the process-wide default, key by key
+static Tuning effective_tuning(const Handle* h) {
+    Tuning t = g_tune;
+    for (const OptKey& k : kOptKeys)
+        if (h->tune.*(k.field) >= 0) t.*(k.field) = h->tune.*(k.field);
+    return t;
+}
+}  // namespace mpk
 
 int mpk_set_option(mpk_handle hh, const char* key, int64_t value) {
     const OptKey* k = find_opt(key);
@@ -780,8 +778,9 @@ static int traj_common(Handle* h, const float* params, const float* init_pos, co
         SharedTables st;
         int rc = get_shared(h, (float)init_time_shared, stream, &st);
         if (rc != MPK_OK) return rc;
+        unsigned* ticket = h->d_tickets + (size_t)(h->ticket_next++ % kTicketSlots) * 32;
         rc = launch_traj_shared(h->dev, st, params, init_pos, init_vel, pos, vel, actions, rd, c_pos, c_vel,
-                                q_state, qd_state, n_steps, B, h->num_cu, stream, &h->last_kernel, tune, rp);
+                                q_state, qd_state, n_steps, B, h->num_cu, stream, &h->last_kernel, tune, rp, ticket);
         // horizons whose basis tables do not fit the episode-major kernel's LDS: the per-episode kernels below (dmp) or,
         // for fused actions / rollouts, the caller's two-launch path
         if (rc != MPK_ENOTIMPL || actions) return rc;

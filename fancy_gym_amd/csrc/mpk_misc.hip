@@ -3,6 +3,7 @@
 
 namespace mpk {
 
+
 // ------------------------------------------------------------------------------------------------------------
 // integer replanning state
 // ------------------------------------------------------------------------------------------------------------

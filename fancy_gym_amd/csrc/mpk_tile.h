@@ -52,7 +52,13 @@ struct TrajArgs {
     // of a few thousand episodes: closed-loop step at B = 4096 22.7 -> 18.7 us); plain stores once they stream to HBM
     // (write-through costs 25 % there).  The tile-major kernel has the policy as a template parameter.
     int wt;
-    int flat_img;          // k_traj_flat: floats per whole-trajectory array image (NTW * T * D); 0 = another kernel runs
+    int flat_img;          // k_traj_flat / k_traj_ring: floats per whole-trajectory array image (NTW * T * D); 0 = another kernel runs
+    // k_traj_ring (ring_np > 0): producer waves, store-engine waves, episode groups per batch, batch buffers in the LDS ring
+    int ring_np, ring_ns, ring_m, ring_nbuf;
+    unsigned* ring_ctr;    // k_traj_ring: device-wide ticket counter (zeroed before the launch); nullptr = static batch ranges
+    int ring_tb;           // batches per ticket
+    int burst;             // k_traj_burst: short-lived workgroups, one batch of ring_m groups each, ring_np waves per group
+    int ring_dbg;          // ablations (mpk_set_option "ring_dbg"): 1 producers publish without contracting, 2 the engine skips its stores
     unsigned ser_blocks;   // k_traj_split: workgroups [0, ser_blocks) run the serial role
     // closed-loop rollout fused into the episode-major kernel (CT >= 3)
     double* q_state;       // [B, D] plant position, in/out

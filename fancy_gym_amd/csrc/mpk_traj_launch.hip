@@ -4,6 +4,7 @@
 #include "mpk_traj_quad.h"   // kQuadImg, kPipeGroups: the LDS budgets the rule checks
 #include "mpk_traj_pipe.h"
 #include "mpk_traj_stream.h" // kChunkGroups
+#include "mpk_traj_ring.h"   // kRingThreads, kRingSyncInts
 
 namespace mpk {
 
@@ -122,9 +123,10 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
                        const float* init_vel, float* pos, float* vel, float* actions, const RolloutDev* rc,
                        const double* c_pos, const double* c_vel, double* q_state, double* qd_state,
                        const int32_t* n_steps, int B, int num_cu, void* stream, const char** kernel_name,
-                       const Tuning& tune, const ReplanDev* rp) {
+                       const Tuning& tune, const ReplanDev* rp, unsigned* ticket) {
     TrajArgs ta;
     ta.nrt_magic = 0; ta.gstride = 0; ta.wt = 0; ta.flat_img = 0;
+    ta.ring_np = 0; ta.ring_ns = 0; ta.ring_m = 0; ta.ring_nbuf = 0; ta.ring_dbg = tune.ring_dbg > 0 ? tune.ring_dbg : 0; ta.burst = 0; ta.ring_ctr = nullptr; ta.ring_tb = 0;
     if (rp) ta.rp = *rp;
     const bool closed = q_state != nullptr;
     ta.q_state = q_state; ta.qd_state = qd_state; ta.n_steps = n_steps; ta.plant_dt = rc ? rc->dt : 0.0;
@@ -183,7 +185,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     bool stream_mode = !split && (c.mp_type == MPK_MP_DMP || closed || out_bytes > 96.0 * 1024 * 1024);
     if (c.mp_type != MPK_MP_DMP && !closed && ov == 1) stream_mode = false;
     if (ov == 2 && !split) stream_mode = true;       // a forced k_traj_split stays tile-major (its tiles role needs that geometry)
-    if (tune.flat == 1 && !closed && c.mp_type != MPK_MP_DMP && !split) stream_mode = true;   // forced k_traj_flat (where it applies)
+    if ((tune.flat == 1 || tune.ring >= 1) && !closed && c.mp_type != MPK_MP_DMP && !split) stream_mode = true;   // forced k_traj_flat (where it applies)
     if (stream_mode && table_bytes + 4 * kStageFloats * sizeof(float) > 64 * 1024) {
         // the caller falls back: per-episode kernels for dmp, trajectory + rollout launches for the closed loop
         if (c.mp_type == MPK_MP_DMP || closed) { set_error("trajectory too long for the episode-major kernel's LDS budget"); return MPK_ENOTIMPL; }
@@ -283,6 +285,58 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         }
         blocks = (int)((waves + 3) / 4);
         if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;                  // XCD-contiguous remap needs a multiple of 8
+        // wave-specialised store engine (k_traj_ring): same shapes as k_traj_flat, ONE persistent workgroup per CU whose LDS
+        // holds the tables + a ring of NBUF batch buffers of M whole-trajectory group images.  mpk_set_option "ring": 0 off,
+        // 1 force; "ring_np" / "ring_ns" / "ring_m": producer waves, store-engine waves, groups per batch
+        const int img = flat_img;                                        // floats per (array, group) image
+        if (flat_ok && tune.ring == 2) {
+            // short-lived workgroups (k_traj_burst): one batch of M groups per workgroup, WPG waves per group
+            int M = tune.ring_m > 0 ? tune.ring_m : 4;
+            int WPG = tune.ring_np > 0 ? tune.ring_np : 1;
+            if (M > 8) M = 8;
+            if (M * WPG > 8) WPG = 8 / M < 1 ? 1 : 8 / M;
+            const size_t bytes = (size_t)nst * M * img * sizeof(float);
+            if (table_bytes + bytes <= 160 * 1024) {
+                ta.flat_img = img;
+                ta.burst = 1; ta.ring_m = M; ta.ring_np = WPG; ta.ring_ns = 0; ta.ring_nbuf = 0;
+                bulk = false;
+                lds = table_bytes + bytes;
+                blocks = (int)(((long)ta.G + M - 1) / M);
+            }
+        } else if (flat_ok && tune.ring == 1) {
+            const int NS = tune.ring_ns > 0 ? tune.ring_ns : 4;
+            int NP = tune.ring_np > 0 ? tune.ring_np : 8;
+            if (NP + NS > kRingThreads / 64) NP = kRingThreads / 64 - NS;
+            const size_t fixed = table_bytes + kRingSyncInts * sizeof(int);
+            // groups per batch: as asked ("ring_m"), else the most (<= 4) that leave two batch buffers in the CU's LDS
+            int M = tune.ring_m > 0 ? tune.ring_m : 4;
+            auto buf_of = [&](int m) { return (size_t)nst * m * img * sizeof(float); };
+            auto fits = [&](int m) {
+                return fixed + 2 * buf_of(m) <= 160 * 1024;
+            };
+            while (M > 1 && !fits(M)) --M;
+            if (fits(M)) {
+                const size_t buf_bytes = buf_of(M);
+                long nbuf = (long)((160 * 1024 - fixed) / buf_bytes);
+                if (nbuf * M > 32) nbuf = 32 / M;                         // 32 slots of sync counters
+                if (nbuf > 3) nbuf = 3;
+                ta.flat_img = img;
+                ta.ring_np = NP; ta.ring_ns = NS; ta.ring_m = M; ta.ring_nbuf = (int)nbuf;
+                // in-order dynamic batch assignment: tickets of TB batches from one counter word (~88 tickets / us at most: a
+                // ticket must be worth well over 100 KB of output), zeroed in stream order in front of the launch
+                ta.ring_ctr = ticket;
+                ta.ring_tb = (int)((192 * 1024 + buf_bytes - 1) / buf_bytes);
+                if (ta.ring_tb < 1) ta.ring_tb = 1;
+                if (ticket && hipMemsetAsync(ticket, 0, sizeof(unsigned), (hipStream_t)stream) != hipSuccess) {
+                    set_error("hipMemsetAsync(ticket counter) failed");
+                    return MPK_EHIP;
+                }
+                bulk = false;
+                lds = fixed + (size_t)nbuf * buf_bytes;
+                const long batches = ((long)ta.G + M - 1) / M;
+                blocks = (int)(batches < (long)num_cu ? batches : (long)num_cu);
+            }
+        }
     } else {
         const long items = (long)ta.G * NRT;
         long ipw = (items + max_waves - 1) / max_waves;                  // items per wave, balanced
@@ -318,11 +372,11 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     }
     switch (c.mp_type) {
         case MPK_MP_PRODMP:
-            *kernel_name = pipe ? "k_traj_pipe<prodmp,closed>" : split ? "k_traj_split<prodmp,closed>" : closed ? (quad == 4 ? "k_traj_quad<prodmp,closed>" : quad == 2 ? "k_traj_duo<prodmp,closed>" : quad == 1 ? "k_traj_mono<prodmp,closed>" : "k_traj_stream<prodmp,closed>") : ta.flat_img ? (act ? "k_traj_flat<prodmp,act>" : "k_traj_flat<prodmp>") : stream_mode ? (act ? "k_traj_stream<prodmp,act>" : "k_traj_stream<prodmp>")
+            *kernel_name = pipe ? "k_traj_pipe<prodmp,closed>" : split ? "k_traj_split<prodmp,closed>" : closed ? (quad == 4 ? "k_traj_quad<prodmp,closed>" : quad == 2 ? "k_traj_duo<prodmp,closed>" : quad == 1 ? "k_traj_mono<prodmp,closed>" : "k_traj_stream<prodmp,closed>") : ta.burst ? (act ? "k_traj_burst<prodmp,act>" : "k_traj_burst<prodmp>") : ta.ring_np ? (act ? "k_traj_ring<prodmp,act>" : "k_traj_ring<prodmp>") : ta.flat_img ? (act ? "k_traj_flat<prodmp,act>" : "k_traj_flat<prodmp>") : stream_mode ? (act ? "k_traj_stream<prodmp,act>" : "k_traj_stream<prodmp>")
                                        : (act ? "k_traj_tiles<prodmp,act>" : "k_traj_tiles<prodmp>");
             return launch_traj_ct<MPK_MP_PRODMP>(ta, aa, ct, stream_mode, write_through, bulk, quad, blocks, lds, stream, split, pipe);
         case MPK_MP_PROMP:
-            *kernel_name = pipe ? "k_traj_pipe<promp,closed>" : split ? "k_traj_split<promp,closed>" : closed ? (quad == 4 ? "k_traj_quad<promp,closed>" : quad == 2 ? "k_traj_duo<promp,closed>" : quad == 1 ? "k_traj_mono<promp,closed>" : "k_traj_stream<promp,closed>") : ta.flat_img ? (act ? "k_traj_flat<promp,act>" : "k_traj_flat<promp>") : stream_mode ? (act ? "k_traj_stream<promp,act>" : "k_traj_stream<promp>")
+            *kernel_name = pipe ? "k_traj_pipe<promp,closed>" : split ? "k_traj_split<promp,closed>" : closed ? (quad == 4 ? "k_traj_quad<promp,closed>" : quad == 2 ? "k_traj_duo<promp,closed>" : quad == 1 ? "k_traj_mono<promp,closed>" : "k_traj_stream<promp,closed>") : ta.burst ? (act ? "k_traj_burst<promp,act>" : "k_traj_burst<promp>") : ta.ring_np ? (act ? "k_traj_ring<promp,act>" : "k_traj_ring<promp>") : ta.flat_img ? (act ? "k_traj_flat<promp,act>" : "k_traj_flat<promp>") : stream_mode ? (act ? "k_traj_stream<promp,act>" : "k_traj_stream<promp>")
                                        : (act ? "k_traj_tiles<promp,act>" : "k_traj_tiles<promp>");
             return launch_traj_ct<MPK_MP_PROMP>(ta, aa, ct, stream_mode, write_through, bulk, quad, blocks, lds, stream, split, pipe);
         default:

@@ -1,0 +1,342 @@
+// k_traj_ring: the HBM-streaming open-loop step as a wave-specialised producer / store-engine pipeline (round 4)
+#pragma once
+#include "mpk_tile.h"
+
+namespace mpk {
+
+// ---- episode-major, wave-specialised store engine: k_traj_ring (round 4) ----------------------------------------------
+// Round 3's counters named what bounds every launch whose outputs stream to HBM (profiles/r03_streaming_pmc_vs_fill.md): the
+// CU keeps 58 write requests in flight where a plain fill keeps 75 at the same ~400-cycle latency -- waves that contract,
+// transpose AND store leave the CU's write queue to drain whenever they compute.  Here the two jobs belong to different
+// waves of ONE persistent workgroup per CU:
+//   waves 0 .. NP-1  (producers)  contract ALL row tiles of "their" episode group on the matrix cores into a slot of an LDS
+//                    ring of whole-trajectory images -- no global store, ever; the next group's inputs are requested
+//                    before the contraction starts;
+//   waves NP ..      (store engine)  do nothing but ds_read_b128 -> global_store_dwordx4, back to back, eight reads then
+//                    eight stores, no MFMA / transpose / barrier / vmcnt wait in between, at raised wave priority.
+// Work is handed over per BATCH of M consecutive episode groups (M * NTW consecutive episodes): the ring holds NBUF batch
+// buffers laid out [array][slot in batch][NTW episodes x T x D], i.e. array-major ACROSS the batch, so the engine writes each
+// output array of a batch as ONE contiguous run of M * NTW * T * D floats (22.4 KB at cfg2 with M = 4) -- the "compact write
+// front": batch b belongs to workgroup b % gridDim.x, so at any time the whole chip writes inside a window of
+// gridDim.x batches (~6 MB) per array, like a fill does.
+// Hand-over: per slot a `full` and an `empty` counter in LDS (monotonic: use k of a slot waits for empty == k * NS and
+// publishes full = k + 1); release = s_waitcnt lgkmcnt(0) of the publishing wave (a wave's DS operations retire in order, and
+// all 64 lanes issue together), acquire = the polling load itself (workgroup-scope atomics: the compiler adds the waits).
+// Every spin is bounded (a protocol bug must fail a test, not hang a GPU).
+// Same tile arithmetic as k_traj_stream / k_traj_flat (same device functions): same bits.
+constexpr int kRingThreads = 768;             // launch bound (12 waves: up to 168 registers); the launcher picks (NP + NS) * 64 <= this
+constexpr int kRingSyncInts = 96;             // full[32] | empty[32] | tickets[8] | tickets published | pad
+constexpr unsigned kRingSpinLimit = 1u << 21; // ~0.3 s of polling with the sleep below: then give up (outputs stay unwritten)
+
+__device__ __forceinline__ bool ring_wait(int* flag, int want) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > kRingSpinLimit) return false;
+    }
+    return true;
+}
+
+// The store engine's inner loop, shared by k_traj_ring and k_traj_burst: the NST output arrays of a batch leave one after the
+// other, each as ONE contiguous run of n4 float4 (`astride` floats between the arrays' LDS regions, `go` = the batch's first
+// element in every output array); wave s of NS takes the 1 KB chunks s, s + NS, ...: U reads, then U stores, nothing else.
+template <int NST, int U>
+__device__ __forceinline__ void ring_flush(const TrajArgs& a, const float* sB, const int astride, const size_t go, const int n4,
+                                           const int s, const int NS, const int lane) {
+#pragma unroll 1
+    for (int arr = 0; arr < NST; ++arr) {
+        float* const outp = (arr == 0 ? a.pos : (arr == 1 ? a.vel : a.actions)) + go;
+        const f32x4* src = reinterpret_cast<const f32x4*>(sB + arr * astride);
+#pragma unroll 1
+        for (int i0 = s * 64; i0 < n4; i0 += 64 * NS * U) {
+            f32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = i0 + u * 64 * NS + lane;
+                v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (idx < n4) v[u] = src[idx];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = i0 + u * 64 * NS + lane;
+                if (idx < n4 && !(a.ring_dbg & 2)) {
+                    if (a.wt) store16<true>(outp + 4 * (size_t)idx, v[u]);
+                    else store16<false>(outp + 4 * (size_t)idx, v[u]);
+                }
+            }
+        }
+    }
+}
+
+// All row tiles of ONE episode group contracted into its whole-trajectory image sI (pos at sI, vel at sI + astride, actions at
+// sI + 2 astride; no global store): the producers' job in k_traj_ring, a wave's first phase in k_traj_burst.  Row tiles
+// [rt0, rt1).  A fragments (basis rows of a row tile) are read from LDS one tile AHEAD into registers -- left to the compiler each
+// MFMA waits for its own ds_read (it cannot hoist them above the image writes: it cannot prove they do not alias).
+template <int MP, int CT, int KM>
+__device__ __forceinline__ void ring_contract(const TrajArgs& a, const LaneMap<KM>& L, const float* ap, const float* sAux,
+                                              const float (&xb)[KM], const double cp, const double cv, const Gains& gn, float* sI,
+                                              const int astride, const int rt0, const int rt1) {
+    constexpr int NOUT = MP == MPK_MP_PRODMP ? 2 : 3;
+    const int KP = 4 * KM, TS = a.TS, D = a.c.D, T = a.c.T, TD = T * D;
+    const unsigned wbase = (unsigned)(L.bl * TD + 4 * L.q * D + L.d);   // (episode, row 4q, column) inside a slot image
+    float afn[NOUT][KM];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+        for (int m = 0; m < KM; ++m) afn[o][m] = ap[(o * KP + 4 * m) * TS + rt0 * 16];
+    for (int rt = rt0; rt < rt1; ++rt) {
+        float af[NOUT][KM];
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+            for (int m = 0; m < KM; ++m) af[o][m] = afn[o][m];
+        if (rt + 1 < rt1) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+                for (int m = 0; m < KM; ++m) afn[o][m] = ap[(o * KP + 4 * m) * TS + (rt + 1) * 16];
+        }
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < KM; ++m) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][m], xb[m], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][m], xb[m], acc1, 0, 0, 0);
+            if (NOUT > 2) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[NOUT > 2 ? 2 : 0][m], xb[m], acc2, 0, 0, 0);
+        }
+        float dtd[4] = {1.f, 1.f, 1.f, 1.f};
+        if (MP == MPK_MP_PROMP) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dtd[r] = sAux[rt * 16 + 4 * L.q + r];
+        }
+        const int nrows = min(4, T - rt * 16 - 4 * L.q);      // rows of this lane that exist (<= 0: none)
+        if (L.dvalid && nrows > 0)
+            tile_epilogue<MP, CT>(acc0, acc1, acc2, dtd, cp, cv, gn, sI, wbase + (unsigned)(rt * 16 * D), D, astride, nrows);
+    }
+}
+
+template <int MP, int CT, int KM>
+__global__ void __launch_bounds__(kRingThreads) k_traj_ring(const TrajArgs a, const ActArgs act) {
+    static_assert(MP != MPK_MP_DMP && CT < 3, "open loop, promp / prodmp");
+    extern __shared__ __attribute__((aligned(16))) float sTab[];   // [NOUT][KP][TS] rows | [TS] aux | sync | ring
+    constexpr bool ACT = CT >= 0;
+    constexpr int NOUT = MP == MPK_MP_PRODMP ? 2 : 3;
+    constexpr int NST = 2 + (ACT ? 1 : 0);
+    const DevCfg& c = a.c;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int KP = 4 * KM, TS = a.TS, D = c.D, T = c.T, TD = T * D;
+    const int NP = a.ring_np, NS = a.ring_ns, M = a.ring_m, NBUF = a.ring_nbuf, R = NBUF * M;
+    (void)act;
+    float* sA = sTab;
+    float* sAux = sTab + NOUT * KP * TS;
+    int* sSync = reinterpret_cast<int*>(sAux + TS);
+    float* sRing = sAux + TS + kRingSyncInts;
+    const int IMG = a.flat_img;                                   // floats per (array, slot) image: NTW * T * D (a multiple of 4)
+    const int BUF = NST * M * IMG;                                 // floats per batch buffer
+    {   // basis tables -> LDS by every wave of the workgroup; sync counters zeroed
+        const float4* src = reinterpret_cast<const float4*>(a.A);
+        float4* dst = reinterpret_cast<float4*>(sA);
+        const int nA4 = (NOUT * KP * TS) >> 2, nX4 = TS >> 2;
+        for (int i = threadIdx.x; i < nA4; i += blockDim.x) dst[i] = src[i];
+        for (int i = threadIdx.x; i < nX4; i += blockDim.x) reinterpret_cast<float4*>(sAux)[i] = reinterpret_cast<const float4*>(a.aux)[i];
+        if (threadIdx.x < kRingSyncInts) sSync[threadIdx.x] = 0;
+    }
+    __syncthreads();                                              // the only workgroup barrier: the roles part here
+    const int nWG = (int)gridDim.x, wg = (int)blockIdx.x;
+    const int NBT = (a.G + M - 1) / M;                            // batches of the launch
+    // Which batches a workgroup takes, and WHEN.  Default (a.ring_ctr): in order, from ONE device-wide counter -- a ticket is TB
+    // consecutive batches, fetched (two tickets ahead, by producer wave 0, under its contraction) with one returning atomic.
+    // The pure-store probe says why (profiles/r04_store_engine_probe.md): on a box where EVERY static assignment of batches to
+    // persistent workgroups -- contiguous ranges per CU, batch b to workgroup b % gridDim.x, grid-stride -- writes the streaming
+    // row's three arrays in 405 - 416 us (on other boxes: 356), in-order dynamic assignment writes them in 336 us, like a fill
+    // (320 - 347 us everywhere): what a fill has is that its write front advances IN ORDER across the whole chip, because the
+    // dispatcher hands out its workgroups in order; persistent streams drift apart.  One counter word sustains ~88 tickets / us,
+    // so a ticket covers >= 2 batches (134 KB of output).  Without a counter (a.ring_ctr == nullptr; "ring_dbg" bit 2 / 4): static
+    // contiguous ranges per workgroup / batch b to workgroup b % gridDim.x, for A/B runs.
+    const bool dynamic = a.ring_ctr != nullptr && !(a.ring_dbg & (4 | 16));
+    const bool compact = (a.ring_dbg & 4) != 0;
+    const int TB = a.ring_tb > 0 ? a.ring_tb : 1, IPT = TB * M;  // batches / items per ticket
+    const int NT = (NBT + TB - 1) / TB;
+    const int per = (NBT + nWG - 1) / nWG;
+    int nb_local;
+    if (compact) nb_local = wg < NBT ? (NBT - wg + nWG - 1) / nWG : 0;
+    else { nb_local = NBT - wg * per; nb_local = nb_local < 0 ? 0 : (nb_local > per ? per : nb_local); }
+    int* const sFull = sSync;
+    int* const sEmpty = sSync + 32;
+    int* const sTick = sSync + 64;                                 // [8] ticket values, [8] = number of tickets published
+    int* const sTickN = sSync + 72;
+    int* const sDone = sSync + 73;                                 // wave 0 has left: whatever is not published is past the end
+    // tickets in flight: the prefetch of the next round's inputs looks ceil(NP / IPT) tickets ahead, + the one being fetched + 1
+    const int ahead = 2 + (NP + IPT - 1) / IPT;
+    // global batch of local batch bl; -1: this workgroup is done (waits for the ticket in dynamic mode); -2: protocol time-out
+    auto batch_at = [&](int bl) -> int {
+        if (!dynamic) return bl < nb_local ? (compact ? bl * nWG + wg : wg * per + bl) : -1;
+        const int tl = bl / TB;
+        unsigned spins = 0;
+        while (__hip_atomic_load(sTickN, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= tl) {
+            if (__hip_atomic_load(sDone, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0 &&
+                __hip_atomic_load(sTickN, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= tl) return -1;
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > kRingSpinLimit) return -2;
+        }
+        const int t = __hip_atomic_load(&sTick[tl & 7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return t < NT ? t * TB + (bl - tl * TB) : -1;
+    };
+    if (wave < NP) {
+        // ---------------- producers: local item n = (local batch) * M + (slot in batch); wave p takes n = p, p + NP, ... ----
+        int n = wave;
+        int requested = 0;                                        // wave 0: tickets requested so far
+        if (dynamic && wave == 0) {
+            unsigned t0 = 0;
+            if (lane == 0) t0 = atomicAdd(a.ring_ctr, (unsigned)ahead);
+            t0 = __builtin_amdgcn_readfirstlane(t0);
+            if (lane < ahead) __hip_atomic_store(&sTick[lane], (int)t0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(sTickN, ahead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            requested = ahead;
+        }
+        int b = batch_at(n / M);
+        if (b < 0) {
+            if (dynamic && wave == 0 && lane == 0) __hip_atomic_store(sDone, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return;
+        }
+        const LaneMap<KM> L = make_lane_map<MP, KM>(a, lane);
+        const int NRT = (T + 15) >> 4;
+        int g = b * M + (n % M);
+        GroupIn<KM> cur = load_group<MP, ACT, KM>(a, L, g < a.G ? g : a.G - 1);
+        Gains gn{0.0, 0.0, 0.0, 0.0};
+        if (ACT) gn = kernarg_gains(L.dvalid ? L.d : 0);
+        const float* ap = sA + L.q * TS + L.col;
+        float xb[KM];
+        finish_group<KM>(L, cur, xb);
+        double cp = cur.cp, cv = cur.cv;
+        for (;;) {
+            const int bl = n / M, j = n - bl * M;
+            // wave 0: the tickets the items of the NEXT round will need (up to two tickets past this one) are requested now
+            // and published after this item's contraction -- the atomic's round trip hides under it
+            unsigned tnew = 0;
+            int nreq = 0;
+            if (dynamic && wave == 0) {
+                nreq = bl / TB + ahead - requested;
+                if (nreq > 3) nreq = 3;
+                if (nreq > 0 && lane == 0) tnew = atomicAdd(a.ring_ctr, (unsigned)nreq);
+            }
+            const int nn = n + NP;
+            const int bx = batch_at(nn / M);                      // (static: known; dynamic: its ticket is two rounds old)
+            if (bx == -2) return;
+            const int gx = bx >= 0 ? bx * M + (nn % M) : g;
+            GroupIn<KM> nxt = cur;
+            if (!(a.ring_dbg & 8)) nxt = load_group<MP, ACT, KM>(a, L, gx < a.G ? gx : a.G - 1);   // in flight across the whole group
+            const int buf = bl % NBUF, k = bl / NBUF, slot = buf * M + j;
+            if (!ring_wait(&sEmpty[slot], k * NS)) return;        // the engine has drained use k - 1 of this slot
+            if (g < a.G && !(a.ring_dbg & 1))
+                ring_contract<MP, CT, KM>(a, L, ap, sAux, xb, cp, cv, gn, sRing + buf * BUF + j * IMG, M * IMG, 0, NRT);
+            if (nreq > 0) {                                       // wave 0 only (wave-uniform)
+                const int base = __builtin_amdgcn_readfirstlane((int)tnew);
+                if (lane < nreq) __hip_atomic_store(&sTick[(requested + lane) & 7], base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                requested += nreq;
+            }
+            // publish: every DS write of this wave has retired, then the slot's use count (and wave 0's new tickets)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                __hip_atomic_store(&sFull[slot], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (nreq > 0) __hip_atomic_store(sTickN, requested, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (bx < 0) {
+                // this wave is done.  Wave 0 says so: a wave that still waits for a ticket nobody will publish any more is past the
+                // end (tickets are monotonic: wave 0 left because ITS next ticket was)
+                if (dynamic && wave == 0 && lane == 0) __hip_atomic_store(sDone, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return;
+            }
+            finish_group<KM>(L, nxt, xb);
+            cp = nxt.cp; cv = nxt.cv;
+            n = nn; g = gx;
+        }
+    } else {
+        // ---------------- store engine: wave s of NS takes the 1 KB chunks s, s + NS, ... of every array run of every batch ----
+        const int s = wave - NP;
+        __builtin_amdgcn_s_setprio(3);
+        const int NTW = 16 >> a.sh;
+        for (int bl = 0;; ++bl) {
+            const int b = batch_at(bl);                           // global batch: episodes [b * M * NTW, ...)
+            if (b < 0) return;
+            const int buf = bl % NBUF, k = bl / NBUF;
+            for (int j = 0; j < M; ++j)
+                if (!ring_wait(&sFull[buf * M + j], k + 1)) return;
+            const long e0 = (long)b * M * NTW;
+            const long left = (long)a.B - e0;
+            const int ne = (int)(left < (long)(M * NTW) ? left : (long)(M * NTW));
+            const int n4 = ne > 0 ? (ne * TD) >> 2 : 0;           // float4 chunks per array run (T * D % 4 == 0)
+            const float* sB = sRing + buf * BUF;
+            ring_flush<NST, 8>(a, sB, M * IMG, (size_t)e0 * TD, n4, s, NS, lane);
+            // release the batch buffer: every DS read of this wave has returned (the data sit in registers or are on their way)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane < M) __hip_atomic_fetch_add(&sEmpty[buf * M + lane], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+}
+
+// ---- episode-major, SHORT-LIVED workgroups: k_traj_burst (round 4) ------------------------------------------------------------
+// The pure-store probe (tools/probes/store_engine_probe.hip, profiles/r04_store_engine_probe.md) says what a fill has that no
+// persistent kernel of this library had: its workgroups are short-lived and dispatched in address order.  Three arrays of the
+// streaming row written by short-lived workgroups take 338 - 349 us on every box; ANY persistent store pattern (grid-stride, the
+// ring's engine, contiguous ranges per CU) takes 356 us on a "fast" box and 413 us on a "slow" one -- the box-to-box spread of
+// rounds 2 and 3 is a property of persistent write streams.  So here a workgroup lives for ONE batch of M consecutive episode
+// groups: its waves contract the groups into a [array][group][NTW x T x D] image (WPG waves per group split the row tiles),
+// one barrier, then ALL waves write the batch's output arrays as contiguous runs (ring_flush) and the workgroup ends; the
+// dispatcher starts batch b + (resident workgroups) in its place.  Two or three workgroups fit a CU, so one computes while another
+// stores.  The basis tables are staged per workgroup (7.6 KB from L2 against 67 KB written: the price of being short-lived).
+template <int MP, int CT, int KM>
+__global__ void __launch_bounds__(512) k_traj_burst(const TrajArgs a, const ActArgs act) {
+    static_assert(MP != MPK_MP_DMP && CT < 3, "open loop, promp / prodmp");
+    extern __shared__ __attribute__((aligned(16))) float sTab[];   // [NOUT][KP][TS] rows | [TS] aux | batch image
+    constexpr bool ACT = CT >= 0;
+    constexpr int NOUT = MP == MPK_MP_PRODMP ? 2 : 3;
+    constexpr int NST = 2 + (ACT ? 1 : 0);
+    const DevCfg& c = a.c;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int KP = 4 * KM, TS = a.TS, T = c.T, TD = T * c.D;
+    const int M = a.ring_m, WPG = a.ring_np, NW = (int)(blockDim.x >> 6);   // groups per batch, waves per group, waves
+    (void)act;
+    float* sA = sTab;
+    float* sAux = sTab + NOUT * KP * TS;
+    float* sB = sAux + TS;
+    const int IMG = a.flat_img;
+    const LaneMap<KM> L = make_lane_map<MP, KM>(a, lane);
+    const int NTW = L.NTW, NRT = (T + 15) >> 4;
+    const long b = blockIdx.x;
+    const int j = wave / WPG, part = wave - j * WPG;              // this wave: group j of the batch, part `part` of its row tiles
+    const int g = (int)(b * M) + j;
+    const bool have = j < M && g < a.G;
+    // the group's inputs are requested before the table copy
+    GroupIn<KM> cur;
+    if (have) cur = load_group<MP, ACT, KM>(a, L, g);
+    Gains gn{0.0, 0.0, 0.0, 0.0};
+    if (ACT) gn = kernarg_gains(L.dvalid ? L.d : 0);
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.A);
+        float4* dst = reinterpret_cast<float4*>(sA);
+        const int nA4 = (NOUT * KP * TS) >> 2, nX4 = TS >> 2;
+        for (int i = threadIdx.x; i < nA4; i += blockDim.x) dst[i] = src[i];
+        for (int i = threadIdx.x; i < nX4; i += blockDim.x) reinterpret_cast<float4*>(sAux)[i] = reinterpret_cast<const float4*>(a.aux)[i];
+    }
+    __syncthreads();
+    if (have && !(a.ring_dbg & 1)) {
+        float xb[KM];
+        finish_group<KM>(L, cur, xb);
+        const int per = (NRT + WPG - 1) / WPG;
+        const int rt0 = part * per, rt1 = min(NRT, rt0 + per);
+        ring_contract<MP, CT, KM>(a, L, sA + L.q * TS + L.col, sAux, xb, cur.cp, cur.cv, gn, sB + j * IMG, M * IMG, rt0, rt1);
+    }
+    __syncthreads();
+    const long e0 = b * M * NTW;
+    const long left = (long)a.B - e0;
+    const int ne = (int)(left < (long)(M * NTW) ? left : (long)(M * NTW));
+    ring_flush<NST, 8>(a, sB, M * IMG, (size_t)e0 * TD, (ne * TD) >> 2, wave, NW, lane);
+}
+
+}  // namespace mpk

@@ -2,7 +2,9 @@
 """
 Counters of several rocprofv3 --pmc passes side by side, one column per kernel: every counter summed over its instances
 and averaged over the dispatches of a kernel (the first `skip` dispatches dropped as warm-up).
-    python tools/pmc_compare.py [--skip N] <dir> [<dir> ...]      (directories holding *_results.json)
+    python tools/pmc_compare.py [--skip N] [--cycle SUBSTR=lab1,lab2,...] <dir> [<dir> ...]   (directories holding *_results.json)
+--cycle: the dispatches of the kernel whose name contains SUBSTR take the labels lab1, lab2, ... in turn, in dispatch order (one
+kernel launched under several option settings: tools/ring_pmc_driver.py).
 """
 import glob
 import json
@@ -23,8 +25,14 @@ def short(name):
 def main():
     args = sys.argv[1:]
     skip = 0
-    if args and args[0] == "--skip":
-        skip = int(args[1]); args = args[2:]
+    cycle = {}
+    while args and args[0] in ("--skip", "--cycle"):
+        if args[0] == "--skip":
+            skip = int(args[1])
+        else:
+            key, labs = args[1].split("=", 1)
+            cycle[key] = labs.split(",")
+        args = args[2:]
     table, cols, dur = {}, [], {}
     for d in args:
         for path in sorted(glob.glob(os.path.join(d, "*_results.json"))):
@@ -32,8 +40,16 @@ def main():
             names = {c["id"]["handle"]: c["name"] for c in root["counters"]}
             ksym = {k["kernel_id"]: k.get("formatted_kernel_name") or k.get("kernel_name") for k in root["kernel_symbols"]}
             per_kernel = {}
-            for rec in root["callback_records"]["counter_collection"]:
-                lab = short(ksym.get(rec["dispatch_data"]["dispatch_info"]["kernel_id"], ""))
+            seen = {}
+            recs = sorted(root["callback_records"]["counter_collection"], key=lambda r: r["dispatch_data"]["start_timestamp"])
+            for rec in recs:
+                kname = ksym.get(rec["dispatch_data"]["dispatch_info"]["kernel_id"], "")
+                lab = short(kname)
+                for key, labs in cycle.items():
+                    if key in kname:
+                        i = seen.get(key, 0)
+                        seen[key] = i + 1
+                        lab = labs[i % len(labs)]
                 if lab is None:
                     continue
                 sums = {}

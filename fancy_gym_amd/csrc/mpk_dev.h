@@ -121,6 +121,11 @@ __device__ __forceinline__ float div_exact(float z, const ExactDiv& x) {
 // 525 MB; per-episode kernels 44.2 / 41.2 at 175 MB, 107 / 117 at 350 MB.  (The tile-major kernels keep their own 96 MB rule:
 // above it the episode-major kernels take over.)
 constexpr double kWtBytes = 300.0 * 1024 * 1024;
+// k_traj_ring (wave-specialised store engine, in-order batch tickets) takes the open-loop launches that write more than this:
+// B = 262144 (2.2 GB): 386 us against k_traj_flat's 417 - 447 on the same boxes; B = 65536 +actions (550 MB): 112 - 115 against
+// 115 - 121; trajectory only at 65536 (367 MB): 83 against 80 - 82 -- below that the persistent one-workgroup-per-CU launch has
+// too few batches per CU to amortise its ramp (profiles/r04_ring.md)
+constexpr double kRingBytes = 600.0 * 1024 * 1024;
 
 // The integer part of BlackBoxWrapper.step's loop (black_box_wrapper.py:174,197,206) for one episode and one plan:
 // how many steps this plan executes before the loop breaks (end of the horizon, or the schedule t % every == 0 while

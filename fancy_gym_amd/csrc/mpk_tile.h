@@ -57,6 +57,7 @@ struct TrajArgs {
     int ring_np, ring_ns, ring_m, ring_nbuf;
     unsigned* ring_ctr;    // k_traj_ring: device-wide ticket counter (zeroed before the launch); nullptr = static batch ranges
     int ring_tb;           // batches per ticket
+    int ring_parts;        // waves that share one group's row tiles (long horizons: the image of ONE group fills a batch buffer)
     int burst;             // k_traj_burst: short-lived workgroups, one batch of ring_m groups each, ring_np waves per group
     int ring_dbg;          // ablations (mpk_set_option "ring_dbg"): 1 producers publish without contracting, 2 the engine skips its stores
     unsigned ser_blocks;   // k_traj_split: workgroups [0, ser_blocks) run the serial role

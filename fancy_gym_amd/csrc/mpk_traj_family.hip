@@ -57,12 +57,19 @@ static int launch_traj_t(const TrajArgs& ta, const ActArgs& aa, bool stream_mode
                 if (lds > 48 * 1024) (void)allow_full_lds(kern);
                 hipLaunchKernelGGL(kern, g, br, lds, s, ta, aa);
             };
-            switch (km) {
-                case 1: go(k_traj_ring<MP, CT, 1>); break;
-                case 2: go(k_traj_ring<MP, CT, 2>); break;
-                case 3: go(k_traj_ring<MP, CT, 3>); break;
-                default: go(k_traj_ring<MP, CT, 4>); break;
-            }
+            // the DoF count as a compile-time constant for the shapes the reference registers MP environments with (5 and 7 DoF)
+            auto by_km = [&](auto dc) {
+                constexpr int DC = decltype(dc)::value;
+                switch (km) {
+                    case 1: go(k_traj_ring<MP, CT, 1, DC>); break;
+                    case 2: go(k_traj_ring<MP, CT, 2, DC>); break;
+                    case 3: go(k_traj_ring<MP, CT, 3, DC>); break;
+                    default: go(k_traj_ring<MP, CT, 4, DC>); break;
+                }
+            };
+            if (ta.c.D == 7) by_km(std::integral_constant<int, 7>());
+            else if (ta.c.D == 5) by_km(std::integral_constant<int, 5>());
+            else by_km(std::integral_constant<int, 0>());
         }
         MPK_LAUNCH_CHECK();
         return MPK_OK;

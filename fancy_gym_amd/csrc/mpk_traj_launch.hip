@@ -126,7 +126,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
                        const Tuning& tune, const ReplanDev* rp, unsigned* ticket) {
     TrajArgs ta;
     ta.nrt_magic = 0; ta.gstride = 0; ta.wt = 0; ta.flat_img = 0;
-    ta.ring_np = 0; ta.ring_ns = 0; ta.ring_m = 0; ta.ring_nbuf = 0; ta.ring_dbg = tune.ring_dbg > 0 ? tune.ring_dbg : 0; ta.burst = 0; ta.ring_ctr = nullptr; ta.ring_tb = 0;
+    ta.ring_np = 0; ta.ring_ns = 0; ta.ring_m = 0; ta.ring_nbuf = 0; ta.ring_dbg = tune.ring_dbg > 0 ? tune.ring_dbg : 0; ta.burst = 0; ta.ring_ctr = nullptr; ta.ring_tb = 0; ta.ring_parts = 1;
     if (rp) ta.rp = *rp;
     const bool closed = q_state != nullptr;
     ta.q_state = q_state; ta.qd_state = qd_state; ta.n_steps = n_steps; ta.plant_dt = rc ? rc->dt : 0.0;
@@ -303,25 +303,37 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
                 lds = table_bytes + bytes;
                 blocks = (int)(((long)ta.G + M - 1) / M);
             }
-        } else if (flat_ok && tune.ring == 1) {
-            const int NS = tune.ring_ns > 0 ? tune.ring_ns : 4;
+        }
+        // wave-specialised store engine (k_traj_ring).  Automatic once a launch writes more than kRingBytes (the A/B
+        // measurements: profiles/r04_ring.md); "ring" 0 off, 1 force
+        {
+            const bool shape_ok = !closed && c.mp_type != MPK_MP_DMP && ptr_ok;
+            const bool want = tune.ring == 1 || (tune.ring < 0 && tune.flat != 1 && tune.bulk < 0 && out_bytes > kRingBytes);
+            int NS = tune.ring_ns > 0 ? tune.ring_ns : 2;
             int NP = tune.ring_np > 0 ? tune.ring_np : 8;
+            if (NS > 8) NS = 8;
             if (NP + NS > kRingThreads / 64) NP = kRingThreads / 64 - NS;
             const size_t fixed = table_bytes + kRingSyncInts * sizeof(int);
-            // groups per batch: as asked ("ring_m"), else the most (<= 4) that leave two batch buffers in the CU's LDS
+            const int gimg = NTW * TD;                                    // floats per (array, group) image, exactly
+            auto buf_of = [&](int m) { return (size_t)nst * m * gimg * sizeof(float); };
+            // groups per batch: as asked ("ring_m"), else the most (<= 4) that leave two batch buffers in the CU's LDS; a batch
+            // must be a whole number of float4 per array (its runs are written as aligned 16-byte chunks)
+            auto fits = [&](int m) { return fixed + 2 * buf_of(m) <= 160 * 1024 && ((long)m * gimg) % 4 == 0; };
             int M = tune.ring_m > 0 ? tune.ring_m : 4;
-            auto buf_of = [&](int m) { return (size_t)nst * m * img * sizeof(float); };
-            auto fits = [&](int m) {
-                return fixed + 2 * buf_of(m) <= 160 * 1024;
-            };
             while (M > 1 && !fits(M)) --M;
-            if (fits(M)) {
+            if (shape_ok && want && tune.ring != 2 && !ta.burst && fits(M)) {
                 const size_t buf_bytes = buf_of(M);
                 long nbuf = (long)((160 * 1024 - fixed) / buf_bytes);
                 if (nbuf * M > 32) nbuf = 32 / M;                         // 32 slots of sync counters
                 if (nbuf > 3) nbuf = 3;
-                ta.flat_img = img;
-                ta.ring_np = NP; ta.ring_ns = NS; ta.ring_m = M; ta.ring_nbuf = (int)nbuf;
+                // waves per group: with few slots (long horizons: one group's image fills a buffer) the producers share a
+                // group's row tiles, so that all of them have work
+                int P = tune.ring_parts > 0 ? tune.ring_parts : (int)((NP + nbuf * M - 1) / (nbuf * M));
+                if (P > NRT) P = NRT;
+                if (P > 8) P = 8;
+                if (P < 1) P = 1;
+                ta.flat_img = gimg;
+                ta.ring_np = NP; ta.ring_ns = NS; ta.ring_m = M; ta.ring_nbuf = (int)nbuf; ta.ring_parts = P;
                 // in-order dynamic batch assignment: tickets of TB batches from one counter word (~88 tickets / us at most: a
                 // ticket must be worth well over 100 KB of output), zeroed in stream order in front of the launch
                 ta.ring_ctr = ticket;

@@ -114,7 +114,194 @@ __device__ __forceinline__ void ring_contract(const TrajArgs& a, const LaneMap<K
     }
 }
 
-template <int MP, int CT, int KM>
+// ---- the producers' and the engine's inner loops on an instruction diet (round 4) -------------------------------------------------
+// PMC of the streaming row (profiles/r04_ring_pmc.md): k_traj_flat issues 99 vector + 36 scalar + 18 LDS instructions per
+// (wave, row tile) and the chip's vector issue slots are ~75 % taken -- the launch is instruction-issue bound; 40 of the 99 are the
+// float64 controller (fixed by the bit-exactness contract), most of the rest is address arithmetic the compiler cannot fold because
+// D, T and the image strides are run-time values.  With D a COMPILE-TIME constant (DC: the reference's MP-registered environments
+// have 5 or 7 DoF) every LDS access of a row tile takes its offset as an instruction immediate from four address registers that
+// advance once per two tiles:
+//   * A fragments: ds_read_b32 offset:(tile in pair) * 64, ping-pong register sets over an unrolled pair of tiles (no copies);
+//   * the C tile's 12 image stores: ds_write_b32 offset:((tile in pair) * 16 + row) * DC * 4 from one address register per array;
+//   * the last, partial row tile is the only one with row predicates.
+// The arithmetic is ring_contract's (the same MFMA operands and order, tile_epilogue's controller expression): same bits.
+__device__ __forceinline__ unsigned lds_addr(const float* p) { return (unsigned)reinterpret_cast<uintptr_t>(p); }
+template <int OFF>
+__device__ __forceinline__ void lds_w32(const unsigned ad, const float v) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(ad), "v"(v), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ float lds_r32(const unsigned ad) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(ad), "n"(OFF));
+    return v;
+}
+
+template <int MP, int CT, int KM, int DC>
+__device__ __forceinline__ void ring_contract_d(const TrajArgs& a, const LaneMap<KM>& L, const float* ap, const float* sAux,
+                                                const float (&xb)[KM], const double cp, const double cv, const Gains& gn,
+                                                float* sI, const int astride, const int rt0, const int rt1) {
+    // row tiles [rt0, rt1) of the group (a group of a long horizon is contracted by several waves, each its own range)
+    constexpr int NOUT = MP == MPK_MP_PRODMP ? 2 : 3;
+    constexpr bool ACT = CT >= 0;
+    static_assert(DC > 0 && DC <= 16 && 35 * DC * 4 < 65536, "compile-time DoF");
+    const int KP = 4 * KM, TS = a.TS, T = a.c.T, TD = T * DC;
+    if (rt0 >= rt1) return;
+    unsigned adr[NOUT][KM];                                          // A fragment (o, m) of tile rt0 for this lane
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+        for (int m = 0; m < KM; ++m) adr[o][m] = lds_addr(ap + (o * KP + 4 * m) * TS + rt0 * 16);
+    unsigned wpos = lds_addr(sI + L.bl * TD + (rt0 * 16 + 4 * L.q) * DC + L.d);   // (episode, row 4q of tile rt0, column), pos image
+    unsigned wvel = wpos + 4u * (unsigned)astride, wact = wvel + 4u * (unsigned)astride;
+    const double pgd = gn.pg, dgd = gn.dg, lod = __builtin_canonicalize(gn.lo), hid = __builtin_canonicalize(gn.hi);
+    float afA[NOUT][KM], afB[NOUT][KM];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+        for (int m = 0; m < KM; ++m) afA[o][m] = lds_r32<0>(adr[o][m]);
+    // one row tile: `cur` holds its A fragments, the next tile's are requested into `nxt`; RTI = tile inside the unrolled pair
+    auto tile = [&](auto rti_tag, auto tail_tag, const int rt, float (&cur)[NOUT][KM], float (&nxt)[NOUT][KM]) {
+        constexpr int RTI = decltype(rti_tag)::value;
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        // this tile's fragments have landed: the wait, then a (free) volatile statement per register that makes every use of `cur`
+        // depend on it -- the compiler does not know that an asm ds_read's result arrives later, and volatile asms keep their order
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+            for (int m = 0; m < KM; ++m) asm volatile("" : "+v"(cur[o][m]));
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < KM; ++m) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[0][m], xb[m], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[1][m], xb[m], acc1, 0, 0, 0);
+            if (NOUT > 2) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[NOUT > 2 ? 2 : 0][m], xb[m], acc2, 0, 0, 0);
+        }
+        if (!TAIL) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+                for (int m = 0; m < KM; ++m) nxt[o][m] = lds_r32<(RTI + 1) * 64>(adr[o][m]);
+        }
+        float dtd[4] = {1.f, 1.f, 1.f, 1.f};
+        if (MP == MPK_MP_PROMP) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dtd[r] = sAux[rt * 16 + 4 * L.q + r];
+        }
+        const int nrows = TAIL ? T - rt * 16 - 4 * L.q : 4;           // rows of this lane that exist (tail tile only: may be <= 0)
+        if (L.dvalid) {
+            auto row = [&](auto r_tag) {
+                constexpr int R = decltype(r_tag)::value;
+                constexpr int OFF = (RTI * 16 + R) * DC * 4;
+                if (TAIL && R >= nrows) return;
+                const float p = acc0[R];
+                float v;
+                if (MP == MPK_MP_PRODMP) v = acc1[R];              // 1/tau is folded into the velocity rows
+                else v = (acc1[R] - acc2[R]) * dtd[R];             // forward difference of fp32 positions x (1 / dt)
+                lds_w32<OFF>(wpos, p);
+                lds_w32<OFF>(wvel, v);
+                if (ACT) {
+                    // float64 without FMA: numpy's promotion in pd_controller.py:21-29 (fp32 desired (+) fp64 state)
+                    double u;
+                    if (CT == MPK_CTRL_MOTOR) u = pgd * ((double)p - cp) + dgd * ((double)v - cv);
+                    else if (CT == MPK_CTRL_POSITION) u = (double)p;
+                    else u = (double)v;
+                    lds_w32<OFF>(wact, (float)clip_f64(u, lod, hid));
+                }
+            };
+            row(std::integral_constant<int, 0>()); row(std::integral_constant<int, 1>());
+            row(std::integral_constant<int, 2>()); row(std::integral_constant<int, 3>());
+        }
+    };
+    auto bump = [&](const int ntile) {
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+            for (int m = 0; m < KM; ++m) adr[o][m] += 64u * (unsigned)ntile;
+        const unsigned db = (unsigned)(ntile * 16 * DC * 4);
+        wpos += db; wvel += db; wact += db;
+    };
+    const std::integral_constant<int, 0> I0; const std::integral_constant<int, 1> I1;
+    const std::false_type FULL; const std::true_type TAILT;
+    const int NFall = T >> 4;                                        // full row tiles of the horizon
+    const int NF = rt1 < NFall ? rt1 : NFall;                        // ... the full ones of this range end here
+    const bool tail = (T & 15) != 0 && rt1 > NFall;                  // the partial last tile belongs to this range
+    int rt = rt0;
+    for (; rt + 2 <= NF; rt += 2) {
+        tile(I0, FULL, rt, afA, afB);
+        tile(I1, FULL, rt + 1, afB, afA);
+        bump(2);
+    }
+    if (rt < NF) {
+        tile(I0, FULL, rt, afA, afB);
+        bump(1);
+        if (tail) tile(I0, TAILT, rt + 1, afB, afA);
+    } else if (tail) {
+        tile(I0, TAILT, rt, afA, afB);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (fragments requested past the last tile: landed, unused)
+}
+
+// The store engine's loop on the same diet: a wave's FULL 1 KB chunks of an array run go out two at a time -- two ds_read_b128,
+// one wait, two global stores in the (scalar base, 32-bit vector offset) form, four integer adds -- and only its last (partial)
+// chunks take the bounds-checked path (ring_flush from chunk `k0`).
+template <bool WT>
+__device__ __forceinline__ void ring_store_pair(const float* gbase, const unsigned vo0, const unsigned vo1, const f32x4& v0,
+                                                const f32x4& v1) {
+    if (WT) {
+        asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(vo0), "v"(v0), "s"(gbase) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(vo1), "v"(v1), "s"(gbase) : "memory");
+    } else {
+        asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(vo0), "v"(v0), "s"(gbase) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(vo1), "v"(v1), "s"(gbase) : "memory");
+    }
+}
+
+template <int NST, bool WT>
+__device__ __forceinline__ void ring_flush_d(const TrajArgs& a, const float* sB, const int astride, const size_t go, const int n4,
+                                             const int s, const int NS, const int lane) {
+    const unsigned cstride = (unsigned)NS * 1024u;                    // bytes between this wave's chunks
+    const int nfull = n4 >> 6;                                       // full chunks of the run
+    const int kf = nfull > s ? (nfull - s + NS - 1) / NS : 0;        // ... of which this wave's
+#pragma unroll 1
+    for (int arr = 0; arr < NST; ++arr) {
+        float* const outp = (arr == 0 ? a.pos : (arr == 1 ? a.vel : a.actions)) + go;
+        const float* src = sB + arr * astride;
+        unsigned voff = (unsigned)(s * 64 + lane) * 16u;
+        unsigned lad = lds_addr(src) + voff;
+        int k = 0;
+        if (!(a.ring_dbg & 2)) {
+            // one pair at a time: two reads, wait, two stores.  (A two-pair software pipeline -- the next pair's reads in flight
+            // while this pair's stores issue -- keeps MORE stores queued and measured slower in the same run: 468 vs 414 us on a
+            // slow-placement box, 443 vs 400 elsewhere; like round 3's occupancy experiments, more in the write queue is not
+            // better.  profiles/r04_ring.md)
+#pragma unroll 1
+            for (; k + 2 <= kf; k += 2) {
+                f32x4 v0, v1;
+                const unsigned lad1 = lad + cstride, vo1 = voff + cstride;
+                asm volatile("ds_read_b128 %0, %1" : "=v"(v0) : "v"(lad));
+                asm volatile("ds_read_b128 %0, %1" : "=v"(v1) : "v"(lad1));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0), "+v"(v1) : : "memory");
+                ring_store_pair<WT>(outp, voff, vo1, v0, v1);
+                lad += 2 * cstride; voff += 2 * cstride;
+            }
+        }
+        // the wave's remaining chunks (at most one full one and the run's partial one)
+#pragma unroll 1
+        for (; (s + NS * k) * 64 < n4; ++k) {
+            const int idx = (s + NS * k) * 64 + lane;
+            if (idx < n4) {
+                const f32x4 v = reinterpret_cast<const f32x4*>(src)[idx];
+                if (!(a.ring_dbg & 2)) store16<WT>(outp + 4 * (size_t)idx, v);
+            }
+        }
+    }
+}
+
+template <int MP, int CT, int KM, int DC>
 __global__ void __launch_bounds__(kRingThreads) k_traj_ring(const TrajArgs a, const ActArgs act) {
     static_assert(MP != MPK_MP_DMP && CT < 3, "open loop, promp / prodmp");
     extern __shared__ __attribute__((aligned(16))) float sTab[];   // [NOUT][KP][TS] rows | [TS] aux | sync | ring
@@ -131,7 +318,7 @@ __global__ void __launch_bounds__(kRingThreads) k_traj_ring(const TrajArgs a, co
     float* sAux = sTab + NOUT * KP * TS;
     int* sSync = reinterpret_cast<int*>(sAux + TS);
     float* sRing = sAux + TS + kRingSyncInts;
-    const int IMG = a.flat_img;                                   // floats per (array, slot) image: NTW * T * D (a multiple of 4)
+    const int IMG = a.flat_img;                                   // floats per (array, slot) image: NTW * T * D (M * IMG a multiple of 4)
     const int BUF = NST * M * IMG;                                 // floats per batch buffer
     {   // basis tables -> LDS by every wave of the workgroup; sync counters zeroed
         const float4* src = reinterpret_cast<const float4*>(a.A);
@@ -155,7 +342,8 @@ __global__ void __launch_bounds__(kRingThreads) k_traj_ring(const TrajArgs a, co
     // contiguous ranges per workgroup / batch b to workgroup b % gridDim.x, for A/B runs.
     const bool dynamic = a.ring_ctr != nullptr && !(a.ring_dbg & (4 | 16));
     const bool compact = (a.ring_dbg & 4) != 0;
-    const int TB = a.ring_tb > 0 ? a.ring_tb : 1, IPT = TB * M;  // batches / items per ticket
+    const int P = a.ring_parts > 0 ? a.ring_parts : 1;           // waves that share a group's row tiles (long horizons)
+    const int TB = a.ring_tb > 0 ? a.ring_tb : 1, IPT = TB * M * P;  // batches / work units per ticket
     const int NT = (NBT + TB - 1) / TB;
     const int per = (NBT + nWG - 1) / nWG;
     int nb_local;
@@ -183,7 +371,8 @@ __global__ void __launch_bounds__(kRingThreads) k_traj_ring(const TrajArgs a, co
         return t < NT ? t * TB + (bl - tl * TB) : -1;
     };
     if (wave < NP) {
-        // ---------------- producers: local item n = (local batch) * M + (slot in batch); wave p takes n = p, p + NP, ... ----
+        // ---------------- producers: work unit n = ((local batch) * M + (slot in batch)) * P + (part of the group's row tiles);
+        // wave p takes n = p, p + NP, ... ----
         int n = wave;
         int requested = 0;                                        // wave 0: tickets requested so far
         if (dynamic && wave == 0) {
@@ -196,14 +385,15 @@ __global__ void __launch_bounds__(kRingThreads) k_traj_ring(const TrajArgs a, co
             if (lane == 0) __hip_atomic_store(sTickN, ahead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             requested = ahead;
         }
-        int b = batch_at(n / M);
+        const int MP_ = M * P;                                    // units per batch
+        int b = batch_at(n / MP_);
         if (b < 0) {
             if (dynamic && wave == 0 && lane == 0) __hip_atomic_store(sDone, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             return;
         }
         const LaneMap<KM> L = make_lane_map<MP, KM>(a, lane);
         const int NRT = (T + 15) >> 4;
-        int g = b * M + (n % M);
+        int g = b * M + (n % MP_) / P;
         GroupIn<KM> cur = load_group<MP, ACT, KM>(a, L, g < a.G ? g : a.G - 1);
         Gains gn{0.0, 0.0, 0.0, 0.0};
         if (ACT) gn = kernarg_gains(L.dvalid ? L.d : 0);
@@ -212,7 +402,8 @@ __global__ void __launch_bounds__(kRingThreads) k_traj_ring(const TrajArgs a, co
         finish_group<KM>(L, cur, xb);
         double cp = cur.cp, cv = cur.cv;
         for (;;) {
-            const int bl = n / M, j = n - bl * M;
+            const int bl = n / MP_, j = (n - bl * MP_) / P, part = n - (bl * M + j) * P;
+            const int tper = (NRT + P - 1) / P, rt0 = part * tper, rt1 = min(NRT, rt0 + tper);
             // wave 0: the tickets the items of the NEXT round will need (up to two tickets past this one) are requested now
             // and published after this item's contraction -- the atomic's round trip hides under it
             unsigned tnew = 0;
@@ -223,25 +414,32 @@ __global__ void __launch_bounds__(kRingThreads) k_traj_ring(const TrajArgs a, co
                 if (nreq > 0 && lane == 0) tnew = atomicAdd(a.ring_ctr, (unsigned)nreq);
             }
             const int nn = n + NP;
-            const int bx = batch_at(nn / M);                      // (static: known; dynamic: its ticket is two rounds old)
+            const int bx = batch_at(nn / MP_);                    // (static: known; dynamic: its ticket is two rounds old)
             if (bx == -2) return;
-            const int gx = bx >= 0 ? bx * M + (nn % M) : g;
+            const int gx = bx >= 0 ? bx * M + (nn % MP_) / P : g;
             GroupIn<KM> nxt = cur;
             if (!(a.ring_dbg & 8)) nxt = load_group<MP, ACT, KM>(a, L, gx < a.G ? gx : a.G - 1);   // in flight across the whole group
             const int buf = bl % NBUF, k = bl / NBUF, slot = buf * M + j;
             if (!ring_wait(&sEmpty[slot], k * NS)) return;        // the engine has drained use k - 1 of this slot
-            if (g < a.G && !(a.ring_dbg & 1))
-                ring_contract<MP, CT, KM>(a, L, ap, sAux, xb, cp, cv, gn, sRing + buf * BUF + j * IMG, M * IMG, 0, NRT);
+            if (g < a.G && !(a.ring_dbg & 1)) {
+                float* const sI = sRing + buf * BUF + j * IMG;
+                if constexpr (DC > 0) {
+                    if (a.ring_dbg & 32) ring_contract<MP, CT, KM>(a, L, ap, sAux, xb, cp, cv, gn, sI, M * IMG, rt0, rt1);
+                    else ring_contract_d<MP, CT, KM, DC>(a, L, ap, sAux, xb, cp, cv, gn, sI, M * IMG, rt0, rt1);
+                } else {
+                    ring_contract<MP, CT, KM>(a, L, ap, sAux, xb, cp, cv, gn, sI, M * IMG, rt0, rt1);
+                }
+            }
             if (nreq > 0) {                                       // wave 0 only (wave-uniform)
                 const int base = __builtin_amdgcn_readfirstlane((int)tnew);
                 if (lane < nreq) __hip_atomic_store(&sTick[(requested + lane) & 7], base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 requested += nreq;
             }
-            // publish: every DS write of this wave has retired, then the slot's use count (and wave 0's new tickets)
+            // publish: every DS write of this wave has retired, then one more finished part of the slot (and wave 0's new tickets)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) {
-                __hip_atomic_store(&sFull[slot], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&sFull[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (nreq > 0) __hip_atomic_store(sTickN, requested, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             if (bx < 0) {
@@ -264,13 +462,24 @@ __global__ void __launch_bounds__(kRingThreads) k_traj_ring(const TrajArgs a, co
             if (b < 0) return;
             const int buf = bl % NBUF, k = bl / NBUF;
             for (int j = 0; j < M; ++j)
-                if (!ring_wait(&sFull[buf * M + j], k + 1)) return;
+                if (!ring_wait(&sFull[buf * M + j], (k + 1) * P)) return;
             const long e0 = (long)b * M * NTW;
             const long left = (long)a.B - e0;
             const int ne = (int)(left < (long)(M * NTW) ? left : (long)(M * NTW));
-            const int n4 = ne > 0 ? (ne * TD) >> 2 : 0;           // float4 chunks per array run (T * D % 4 == 0)
+            const int n4 = ne > 0 ? (ne * TD) >> 2 : 0;           // float4 chunks per array run (a full batch is a whole number
+            const int nrem = ne > 0 ? (ne * TD) & 3 : 0;          // of them; the launch's last, ragged batch may leave 1 - 3 floats)
             const float* sB = sRing + buf * BUF;
-            ring_flush<NST, 8>(a, sB, M * IMG, (size_t)e0 * TD, n4, s, NS, lane);
+            if (a.ring_dbg & 32) ring_flush<NST, 8>(a, sB, M * IMG, (size_t)e0 * TD, n4, s, NS, lane);
+            else if (a.wt) ring_flush_d<NST, true>(a, sB, M * IMG, (size_t)e0 * TD, n4, s, NS, lane);
+            else ring_flush_d<NST, false>(a, sB, M * IMG, (size_t)e0 * TD, n4, s, NS, lane);
+            if (nrem && s == 0 && lane < nrem && !(a.ring_dbg & 2)) {
+#pragma unroll 1
+                for (int arr = 0; arr < NST; ++arr) {
+                    float* const outp = (arr == 0 ? a.pos : (arr == 1 ? a.vel : a.actions)) + (size_t)e0 * TD;
+                    const float v = sB[arr * M * IMG + 4 * n4 + lane];
+                    if (a.wt) store4<true>(outp + 4 * (size_t)n4 + lane, v); else store4<false>(outp + 4 * (size_t)n4 + lane, v);
+                }
+            }
             // release the batch buffer: every DS read of this wave has returned (the data sit in registers or are on their way)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

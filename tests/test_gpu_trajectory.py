@@ -234,6 +234,104 @@ def test_flat_kernel_fused_actions_bit_exact(B, ctrl, mpk_option):
     assert torch.equal(pos, p2) and torch.equal(vel, v2) and torch.equal(act, a2)
 
 
+# ---- k_traj_ring: producer waves + store-engine waves, in-order batch tickets (round 4) --------------------------------------------
+RING_OPTS = [dict(), dict(ring_np=4, ring_ns=4), dict(ring_np=10, ring_ns=1, ring_m=2), dict(ring_m=1, ring_parts=3),
+             dict(ring_dbg=16), dict(ring_dbg=4), dict(ring_dbg=32), dict(ring_np=3, ring_ns=3, ring_m=3, ring_parts=2)]
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg4", "cfg5", "cfg1", "promp4", "promp5"])
+@pytest.mark.parametrize("B", [1, 2, 7, 64, 1001, 4107])
+def test_ring_kernel_matches_the_other_kernels_bitwise_and_the_oracle(name, B, mpk_option):
+    """k_traj_ring under every launch geometry (producers / engine waves / groups per batch / waves per group), its three batch
+    orders (tickets from one counter, static ranges, b % gridDim) and both contraction loops (compile-time DoF count with
+    immediates, generic): the bits of k_traj_tiles / k_traj_stream.  cfg5 (350 x 7: T * D = 2 mod 4, an image of one group fills a
+    batch buffer, ragged last batch leaves two floats) and cfg1 (200 x 5) are the shapes k_traj_flat cannot take."""
+    pc, bc, tc, dt, duration = {"cfg2": CFG2, "cfg4": CFG4, "cfg5": CFG5, "cfg1": CFG1, "promp4": FLAT_PROMP,
+                                "promp5": FLAT_PROMP5}[name]
+    eng = make_engine(pc, bc, tc, dt, duration)
+    params, ip, iv = inputs(pc, bc, tc, B, seed=B + 11)
+    init_time = 0.5 if name in ("cfg2", "cfg4") else 0.0
+    mpk_option("flat", 0); mpk_option("ring", 0); mpk_option("mapping", 2)
+    p0, v0 = eng.trajectory(params, ip, iv, init_time)
+    torch.cuda.synchronize()
+    assert eng.last_kernel().startswith("k_traj_stream"), eng.last_kernel()
+    rp, rv = O.get_trajectory(pc, bc, tc, params, duration, dt, init_time, ip, iv, dtype=np.float64)
+    close(p0.cpu().numpy(), rp, f"{name} pos")
+    mpk_option("mapping", -1)
+    for opts in RING_OPTS:
+        for k in ("ring_np", "ring_ns", "ring_m", "ring_parts", "ring_dbg"):
+            mpk_option(k, opts.get(k, -1))
+        mpk_option("ring", 1)
+        out = (torch.full_like(p0, float("nan")), torch.full_like(v0, float("nan")))
+        eng.trajectory(params, ip, iv, init_time, out=out)
+        torch.cuda.synchronize()
+        assert eng.last_kernel().startswith("k_traj_ring"), (opts, eng.last_kernel())
+        assert torch.equal(out[0].view(torch.int32), p0.view(torch.int32)), (name, B, opts)
+        assert torch.equal(out[1].view(torch.int32), v0.view(torch.int32)), (name, B, opts)
+
+
+@pytest.mark.parametrize("B", [1, 5, 130, 4099])
+@pytest.mark.parametrize("ctrl", ["motor", "position", "velocity"])
+def test_ring_kernel_fused_actions_bit_exact(B, ctrl, mpk_option):
+    """trajectory + tracking-controller actions through k_traj_ring (cfg2 and cfg5 shapes): actions bit-exact against the oracle's
+    float64 controller, everything bit-identical to the other kernels"""
+    import bench
+    from fancy_gym_amd import RolloutSpec
+    for cfg in (CFG2, CFG5):
+        pc, bc, tc, dt, duration = cfg
+        eng = make_engine(pc, bc, tc, dt, duration)
+        params, ip, iv = inputs(pc, bc, tc, B, seed=B)
+        rng = np.random.default_rng(B)
+        cp, cv = rng.uniform(-1, 1, (B, 7)), rng.uniform(-1, 1, (B, 7))
+        spec = RolloutSpec(ctrl, 7, bench.P_GAINS, bench.D_GAINS, -1.0, 1.0, plant="static")
+        mpk_option("ring", 0); mpk_option("flat", 0)
+        p2, v2, a2 = eng.trajectory_actions(params, ip, iv, spec, cp, cv)
+        assert eng.last_kernel().startswith("k_traj_tiles") or eng.last_kernel().startswith("k_traj_stream")
+        ra, _, _ = O.rollout(p2.cpu().numpy(), v2.cpu().numpy(), ctrl, bench.P_GAINS, bench.D_GAINS, -1.0, 1.0, "static", dt, cp, cv)
+        assert np.array_equal(a2.cpu().numpy(), ra.astype(np.float32))
+        for opts in (dict(), dict(ring_dbg=32), dict(ring_np=5, ring_ns=3, ring_m=2), dict(ring_dbg=16, ring_ns=1)):
+            for k in ("ring_np", "ring_ns", "ring_m", "ring_parts", "ring_dbg"):
+                mpk_option(k, opts.get(k, -1))
+            mpk_option("ring", 1)
+            pos, vel, act = eng.trajectory_actions(params, ip, iv, spec, cp, cv)
+            torch.cuda.synchronize()
+            assert eng.last_kernel().startswith("k_traj_ring") and "act" in eng.last_kernel(), eng.last_kernel()
+            assert torch.equal(pos, p2) and torch.equal(vel, v2) and torch.equal(act, a2), (opts, B, ctrl)
+
+
+def test_ring_kernel_is_the_automatic_choice_for_launches_that_stream_to_hbm_and_only_those(mpk_option):
+    """outputs beyond kRingBytes (600 MB) of an open-loop promp / prodmp launch -> k_traj_ring; DMP, the closed loop and smaller
+    launches keep their kernels; two launches of one handle on two streams do not share a ticket counter"""
+    pc, bc, tc, dt, duration = CFG2
+    eng = make_engine(pc, bc, tc, dt, duration)
+    B = 120000                                               # 2 x 336 MB of (pos, vel)
+    params, ip, iv = inputs(pc, bc, tc, B, seed=2)
+    pos, vel = eng.trajectory(params, ip, iv, 0.0)
+    assert eng.last_kernel() == "k_traj_ring<prodmp>", eng.last_kernel()
+    mpk_option("ring", 0)
+    p2, v2 = eng.trajectory(params, ip, iv, 0.0)
+    assert eng.last_kernel().startswith("k_traj_flat"), eng.last_kernel()
+    assert torch.equal(pos, p2) and torch.equal(vel, v2)
+    mpk_option("ring", -1)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for st in (s1, s2, s1, s2):
+        with torch.cuda.stream(st):
+            outs.append(eng.trajectory(params, ip, iv, 0.0))
+    torch.cuda.synchronize()
+    for p3, v3 in outs:
+        assert torch.equal(p3, p2) and torch.equal(v3, v2)
+    small = eng.trajectory(params[:4096], ip[:4096], iv[:4096], 0.0)
+    assert eng.last_kernel().startswith("k_traj_tiles")
+    assert torch.equal(small[0], p2[:4096])
+    pc, bc, tc, dt, duration = CFG3
+    eng3 = make_engine(pc, bc, tc, dt, duration)
+    prm3, ip3, iv3 = inputs(pc, bc, tc, 60000, seed=2)
+    eng3.trajectory(prm3, ip3, iv3, 0.0)
+    assert "dmp" in eng3.last_kernel() and "ring" not in eng3.last_kernel()
+
+
 def test_flat_kernel_is_skipped_where_it_does_not_apply(mpk_option):
     """T * D not a multiple of 4 (cfg5: 350 x 7), DMP, images beyond the LDS budget (cfg1: two 200-step 5-DoF episodes per
     wave and array): the forced option falls through to the other kernels"""

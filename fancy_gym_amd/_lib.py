@@ -126,7 +126,7 @@ _lib: Optional[C.CDLL] = None
 
 # the files libmpk.so is built from, in the order mpk_source_hash() is defined over (include/mpk.h)
 _ROOT = os.path.dirname(_HERE)
-KERNEL_UNITS = ("mpk_traj_family.hip", "mpk_traj_launch.hip", "mpk_traj_wide.hip", "mpk_traj_phase.hip", "mpk_rollout.hip",
+KERNEL_UNITS = ("mpk_traj_family.hip", "mpk_traj_ring.hip", "mpk_traj_launch.hip", "mpk_traj_wide.hip", "mpk_traj_phase.hip", "mpk_rollout.hip",
                 "mpk_misc.hip")          # translation units of the device code (mpk_traj_family.hip: once per MP type)
 KERNEL_HEADERS = ("mpk_dev.h", "mpk_tile.h", "mpk_traj_tiles.h", "mpk_traj_stream.h", "mpk_traj_flat.h", "mpk_traj_ring.h", "mpk_traj_quad.h",
                   "mpk_traj_pipe.h")

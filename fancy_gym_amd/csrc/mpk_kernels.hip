@@ -5,6 +5,7 @@
 //   mpk_tile.h           the 16 x 16 tile machinery (arguments, lane maps, step chains, epilogue, stores)
 //   mpk_traj_{tiles,stream,flat,quad,pipe}.h   one shared-phase trajectory kernel family each
 //   mpk_traj_family.hip  the families' template launcher, one unit per MP type (-DMPK_MP_UNIT=0..2)
+//   mpk_traj_ring.h / .hip   k_traj_ring / k_traj_burst + their launcher, one unit per MP type
 //   mpk_traj_launch.hip  k_build_shared + launch_traj_shared (kernel selection rule)
 //   mpk_traj_wide.hip    k_traj_wide
 //   mpk_traj_phase.hip   per-episode phase kernels
@@ -12,6 +13,7 @@
 //   mpk_misc.hip         integer state, reset, gather, validity, self-tests, trace readout
 #define MPK_AMALGAMATED 1
 #include "mpk_traj_family.hip"
+#include "mpk_traj_ring.hip"
 #include "mpk_traj_launch.hip"
 #include "mpk_traj_wide.hip"
 #include "mpk_traj_phase.hip"

@@ -4,7 +4,6 @@
 #include "mpk_traj_tiles.h"
 #include "mpk_traj_stream.h"
 #include "mpk_traj_flat.h"
-#include "mpk_traj_ring.h"
 #include "mpk_traj_quad.h"
 #include "mpk_traj_pipe.h"
 
@@ -33,47 +32,6 @@ static int launch_traj_t(const TrajArgs& ta, const ActArgs& aa, bool stream_mode
     const size_t pad = (!stream_mode || split) ? lds : 0;
     hipStream_t s = (hipStream_t)stream;
     const int km = ta.c.KP / 4;
-    if (ta.burst) {
-        if constexpr (MP != MPK_MP_DMP && CT < 3) {
-            const dim3 bb((unsigned)(ta.ring_m * ta.ring_np) * 64u);
-            auto go = [&](auto kern) {
-                if (lds > 48 * 1024) (void)allow_full_lds(kern);
-                hipLaunchKernelGGL(kern, g, bb, lds, s, ta, aa);
-            };
-            switch (km) {
-                case 1: go(k_traj_burst<MP, CT, 1>); break;
-                case 2: go(k_traj_burst<MP, CT, 2>); break;
-                case 3: go(k_traj_burst<MP, CT, 3>); break;
-                default: go(k_traj_burst<MP, CT, 4>); break;
-            }
-        }
-        MPK_LAUNCH_CHECK();
-        return MPK_OK;
-    }
-    if (ta.ring_np > 0) {
-        if constexpr (MP != MPK_MP_DMP && CT < 3) {
-            const dim3 br((unsigned)(ta.ring_np + ta.ring_ns) * 64u);
-            auto go = [&](auto kern) {
-                if (lds > 48 * 1024) (void)allow_full_lds(kern);
-                hipLaunchKernelGGL(kern, g, br, lds, s, ta, aa);
-            };
-            // the DoF count as a compile-time constant for the shapes the reference registers MP environments with (5 and 7 DoF)
-            auto by_km = [&](auto dc) {
-                constexpr int DC = decltype(dc)::value;
-                switch (km) {
-                    case 1: go(k_traj_ring<MP, CT, 1, DC>); break;
-                    case 2: go(k_traj_ring<MP, CT, 2, DC>); break;
-                    case 3: go(k_traj_ring<MP, CT, 3, DC>); break;
-                    default: go(k_traj_ring<MP, CT, 4, DC>); break;
-                }
-            };
-            if (ta.c.D == 7) by_km(std::integral_constant<int, 7>());
-            else if (ta.c.D == 5) by_km(std::integral_constant<int, 5>());
-            else by_km(std::integral_constant<int, 0>());
-        }
-        MPK_LAUNCH_CHECK();
-        return MPK_OK;
-    }
     if (ta.flat_img > 0) {
         if constexpr (MP != MPK_MP_DMP && CT < 3) {
             auto go = [&](auto kern) {

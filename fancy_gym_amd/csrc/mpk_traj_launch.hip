@@ -1,5 +1,7 @@
 // k_build_shared (phase / exponential-kernel evaluation for a phase all episodes share) and launch_traj_shared: the rule
 // that picks a shared-phase trajectory kernel family, its work decomposition and its store policy for a launch.
+#include <cstdio>
+
 #include "mpk_tile.h"
 #include "mpk_traj_quad.h"   // kQuadImg, kPipeGroups: the LDS budgets the rule checks
 #include "mpk_traj_pipe.h"
@@ -115,6 +117,12 @@ int launch_traj_ct(const TrajArgs& ta, const ActArgs& aa, int ct, bool stream_mo
 extern template int launch_traj_ct<MPK_MP_PROMP>(const TrajArgs&, const ActArgs&, int, bool, bool, bool, int, int, size_t, void*, bool, bool);
 extern template int launch_traj_ct<MPK_MP_DMP>(const TrajArgs&, const ActArgs&, int, bool, bool, bool, int, int, size_t, void*, bool, bool);
 extern template int launch_traj_ct<MPK_MP_PRODMP>(const TrajArgs&, const ActArgs&, int, bool, bool, bool, int, int, size_t, void*, bool, bool);
+// defined in mpk_traj_ring.hip (one translation unit per MP type)
+template <int MP>
+int launch_traj_ring(const TrajArgs& ta, const ActArgs& aa, int ct, int blocks, size_t lds, void* stream);
+extern template int launch_traj_ring<MPK_MP_PROMP>(const TrajArgs&, const ActArgs&, int, int, size_t, void*);
+extern template int launch_traj_ring<MPK_MP_DMP>(const TrajArgs&, const ActArgs&, int, int, size_t, void*);
+extern template int launch_traj_ring<MPK_MP_PRODMP>(const TrajArgs&, const ActArgs&, int, int, size_t, void*);
 #endif
 #endif
 
@@ -234,7 +242,66 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
             else if (closed && fits(1)) quad = 1;
         }
     }
-    if (pipe) {
+
+    // wave-specialised store engine (k_traj_ring): ONE persistent workgroup per CU whose LDS holds the tables + a ring of NBUF
+    // batch buffers of M whole-trajectory group images; producer waves fill them (contraction + controller epilogue), store-engine
+    // waves write each batch's arrays as contiguous runs; batches are handed out in order from one device counter.  Open loop,
+    // promp / prodmp (the serial-recurrence variants need four groups per wave: mpk_traj_ring.hip).  Automatic once a launch writes more than kRingBytes (A/B
+    // measurements: profiles/r04_ring.md); mpk_set_option "ring": 0 off, 1 force; "ring_np" / "ring_ns" / "ring_m" /
+    // "ring_parts": producer waves, store-engine waves, groups per batch, waves per group.  A forced episode-major variant
+    // ("quad", "bulk", "flat" 1, "pipe" 1, "split" 1) wins over the automatic choice.
+    bool ring = false;
+    {
+        const bool forced_other = tune.flat == 1 || tune.bulk >= 0 || tune.quad >= 0 || tune.pipe == 1 || tune.split == 1 || ov == 1;
+        const bool want = tune.ring == 1 || (tune.ring < 0 && !forced_other && out_bytes > kRingBytes);
+        const int TD_ = c.T * c.D;
+        int NS = tune.ring_ns > 0 ? tune.ring_ns : 2;
+        int NP = tune.ring_np > 0 ? tune.ring_np : 8;
+        if (NS > 8) NS = 8;
+        if (NP + NS > kRingThreads / 64) NP = kRingThreads / 64 - NS;
+        const size_t fixed = table_bytes + kRingSyncInts * sizeof(int);
+        const int gimg = NTW * TD_;                                   // floats per (array, group) image, exactly
+        auto buf_of = [&](int m) { return (size_t)nst * m * gimg * sizeof(float); };
+        // groups per batch: as asked ("ring_m"), else the most (<= 4) that leave two batch buffers in the CU's LDS; a batch
+        // must be a whole number of float4 per array (its runs are written as aligned 16-byte chunks)
+        auto fits = [&](int m) { return fixed + 2 * buf_of(m) <= 160 * 1024 && ((long)m * gimg) % 4 == 0; };
+        int M = tune.ring_m > 0 ? tune.ring_m : 4;
+        while (M > 1 && !fits(M)) --M;
+        if (ptr_ok && want && !closed && c.mp_type != MPK_MP_DMP && !split && tune.ring != 2 && fits(M)) {
+            const size_t buf_bytes = buf_of(M);
+            long nbuf = (long)((160 * 1024 - fixed) / buf_bytes);
+            if (nbuf * M > 32) nbuf = 32 / M;                         // 32 slots of sync counters
+            if (nbuf > 3) nbuf = 3;
+            // waves per group: with few slots (long horizons: one group's image fills a buffer) the producers share a group's
+            // row tiles, so that all of them have work
+            int P = tune.ring_parts > 0 ? tune.ring_parts : (int)((NP + nbuf * M - 1) / (nbuf * M));
+            if (P > NRT) P = NRT;
+            if (P > 8) P = 8;
+            if (P < 1) P = 1;
+            ta.flat_img = gimg;
+            ta.ring_np = NP; ta.ring_ns = NS; ta.ring_m = M; ta.ring_nbuf = (int)nbuf; ta.ring_parts = P;
+            // in-order dynamic batch assignment: tickets of TB batches from one counter word (~88 tickets / us at most: a
+            // ticket must be worth well over 100 KB of output), zeroed in stream order in front of the launch
+            ta.ring_ctr = ticket;
+            ta.ring_tb = (int)((192 * 1024 + buf_bytes - 1) / buf_bytes);
+            if (ta.ring_tb < 1) ta.ring_tb = 1;
+            if (ticket && hipMemsetAsync(ticket, 0, sizeof(unsigned), (hipStream_t)stream) != hipSuccess) {
+                set_error("hipMemsetAsync(ticket counter) failed");
+                return MPK_EHIP;
+            }
+            ring = true;
+            stream_mode = true; quad = 0; bulk = false;
+            ta.wt = out_bytes <= kWtBytes ? 1 : 0;
+            if (tune.write_through >= 0) ta.wt = tune.write_through != 0 ? 1 : 0;
+            if ((double)B * c.T * c.D * 4.0 >= 2147483648.0) ta.wt = 0;
+            lds = fixed + (size_t)nbuf * buf_bytes;
+            const long batches = ((long)ta.G + M - 1) / M;
+            blocks = (int)(batches < (long)num_cu ? batches : (long)num_cu);
+        }
+    }
+    if (ring) {
+        // (set up above)
+    } else if (pipe) {
         quad = 0; bulk = false;
         lds = table_bytes;
         const long units = (ta.G + kPipeGroups - 1) / kPipeGroups;
@@ -304,51 +371,6 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
                 blocks = (int)(((long)ta.G + M - 1) / M);
             }
         }
-        // wave-specialised store engine (k_traj_ring).  Automatic once a launch writes more than kRingBytes (the A/B
-        // measurements: profiles/r04_ring.md); "ring" 0 off, 1 force
-        {
-            const bool shape_ok = !closed && c.mp_type != MPK_MP_DMP && ptr_ok;
-            const bool want = tune.ring == 1 || (tune.ring < 0 && tune.flat != 1 && tune.bulk < 0 && out_bytes > kRingBytes);
-            int NS = tune.ring_ns > 0 ? tune.ring_ns : 2;
-            int NP = tune.ring_np > 0 ? tune.ring_np : 8;
-            if (NS > 8) NS = 8;
-            if (NP + NS > kRingThreads / 64) NP = kRingThreads / 64 - NS;
-            const size_t fixed = table_bytes + kRingSyncInts * sizeof(int);
-            const int gimg = NTW * TD;                                    // floats per (array, group) image, exactly
-            auto buf_of = [&](int m) { return (size_t)nst * m * gimg * sizeof(float); };
-            // groups per batch: as asked ("ring_m"), else the most (<= 4) that leave two batch buffers in the CU's LDS; a batch
-            // must be a whole number of float4 per array (its runs are written as aligned 16-byte chunks)
-            auto fits = [&](int m) { return fixed + 2 * buf_of(m) <= 160 * 1024 && ((long)m * gimg) % 4 == 0; };
-            int M = tune.ring_m > 0 ? tune.ring_m : 4;
-            while (M > 1 && !fits(M)) --M;
-            if (shape_ok && want && tune.ring != 2 && !ta.burst && fits(M)) {
-                const size_t buf_bytes = buf_of(M);
-                long nbuf = (long)((160 * 1024 - fixed) / buf_bytes);
-                if (nbuf * M > 32) nbuf = 32 / M;                         // 32 slots of sync counters
-                if (nbuf > 3) nbuf = 3;
-                // waves per group: with few slots (long horizons: one group's image fills a buffer) the producers share a
-                // group's row tiles, so that all of them have work
-                int P = tune.ring_parts > 0 ? tune.ring_parts : (int)((NP + nbuf * M - 1) / (nbuf * M));
-                if (P > NRT) P = NRT;
-                if (P > 8) P = 8;
-                if (P < 1) P = 1;
-                ta.flat_img = gimg;
-                ta.ring_np = NP; ta.ring_ns = NS; ta.ring_m = M; ta.ring_nbuf = (int)nbuf; ta.ring_parts = P;
-                // in-order dynamic batch assignment: tickets of TB batches from one counter word (~88 tickets / us at most: a
-                // ticket must be worth well over 100 KB of output), zeroed in stream order in front of the launch
-                ta.ring_ctr = ticket;
-                ta.ring_tb = (int)((192 * 1024 + buf_bytes - 1) / buf_bytes);
-                if (ta.ring_tb < 1) ta.ring_tb = 1;
-                if (ticket && hipMemsetAsync(ticket, 0, sizeof(unsigned), (hipStream_t)stream) != hipSuccess) {
-                    set_error("hipMemsetAsync(ticket counter) failed");
-                    return MPK_EHIP;
-                }
-                bulk = false;
-                lds = fixed + (size_t)nbuf * buf_bytes;
-                const long batches = ((long)ta.G + M - 1) / M;
-                blocks = (int)(batches < (long)num_cu ? batches : (long)num_cu);
-            }
-        }
     } else {
         const long items = (long)ta.G * NRT;
         long ipw = (items + max_waves - 1) / max_waves;                  // items per wave, balanced
@@ -381,6 +403,17 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         if (sb > cap) sb = cap;
         ta.ser_blocks = (unsigned)sb;
         blocks += (int)sb;
+    }
+    if (ring || ta.burst) {
+        const char* mpn = c.mp_type == MPK_MP_PRODMP ? "prodmp" : (c.mp_type == MPK_MP_PROMP ? "promp" : "dmp");
+        static thread_local char name[64];
+        snprintf(name, sizeof(name), "%s<%s%s>", ta.burst ? "k_traj_burst" : "k_traj_ring", mpn, closed ? ",closed" : (act ? ",act" : ""));
+        *kernel_name = name;
+        switch (c.mp_type) {
+            case MPK_MP_PRODMP: return launch_traj_ring<MPK_MP_PRODMP>(ta, aa, ct, blocks, lds, stream);
+            case MPK_MP_PROMP: return launch_traj_ring<MPK_MP_PROMP>(ta, aa, ct, blocks, lds, stream);
+            default: return launch_traj_ring<MPK_MP_DMP>(ta, aa, -1, blocks, lds, stream);
+        }
     }
     switch (c.mp_type) {
         case MPK_MP_PRODMP:

@@ -31,7 +31,7 @@ class BatchedBlackBox:
                  max_planning_times: Union[int, float] = math.inf, condition_on_desired: bool = False,
                  max_episode_steps: Optional[int] = None, pos_limits: Optional[Sequence] = None,
                  check_tau_delay: bool = False, reward: Optional[str] = None, steps_before_reward: int = 199,
-                 device=None):
+                 device=None, learn_sub_trajectories: bool = False, reward_aggregation="sum"):
         """
         trajectory_generator / tracking_controller: the objects the factories return (``get_trajectory_generator``,
         ``get_controller``).  ``replanning_every = n`` is the schedule ``lambda pos, vel, obs, action, t: t % n == 0``
@@ -39,7 +39,20 @@ class BatchedBlackBox:
         validity check (envs/mujoco/table_tennis/table_tennis_env.py:303-309).  ``reward = "simple_reacher"`` adds the
         per-step reward of the reference's SimpleReacher (envs/classic_control/simple_reacher/simple_reacher.py:56-72)
         to the device rollout: ``step`` then also returns ``step_rewards [B, T]`` and their sum ``rewards [B]``
-        (the default ``reward_aggregation = np.sum`` of black_box_wrapper.py:24); goals are given to ``reset``.
+        (``reward_aggregation``: "sum" / "mean" / "last" or np.sum / np.mean -- black_box_wrapper.py:24,216 -- over the EXECUTED
+        steps of each episode, on the device); goals are given to ``reset``.
+
+        ``learn_sub_trajectories`` (black_box_wrapper.py:98-102, utils/make_env_helpers.py:89-117): every ``step`` plans a new
+        sub-trajectory of ``round(tau / dt)`` steps from the current state -- tau is the first parameter (``learn_tau``), read
+        anew by every plan (nothing is frozen), clipped to its bounds; an episode ends when ``max_episode_steps`` are done.  On
+        the device a plan is a row mask over the max-length plan: episode b executes the first ``round(tau_b / dt)`` rows
+        (``trajectory_length``), the rows behind them are not part of its plan.  (A single-episode wrapper evaluates the plan on
+        the grid ``linspace(0, T_b dt, T_b + 1)[1:]``, the batch on the first T_b points of the grid of the longest plan: the
+        same times up to one fp32 rounding of the grid, exactly the same whenever the grid values are exact in fp32.)
+        Not with replanning (make_env_helpers.py:91-92).
+
+        Arbitrary ``replanning_schedule`` callables see host state per step and stay with the single-episode wrapper; the
+        device schedule is ``t % replanning_every == 0``.
         """
         self.traj_gen = trajectory_generator
         self.tracking_controller = tracking_controller
@@ -51,6 +64,15 @@ class BatchedBlackBox:
         self.device = self.engine.device
         self.D, self.T = self.engine.num_dof, self.engine.num_steps
         self.horizon = int(max_episode_steps) if max_episode_steps is not None else self.T
+        self.learn_sub_trajectories = bool(learn_sub_trajectories)
+        if self.learn_sub_trajectories and replanning_every is not None:
+            raise ValueError("Cannot used sub-trajectory learning and replanning together.")      # make_env_helpers.py:91-92
+        if self.learn_sub_trajectories and not self.traj_gen.phase_gn.learn_tau:
+            raise ValueError("learn_sub_trajectories needs a learned tau (make_bb sets learn_tau: make_env_helpers.py:110-112)")
+        agg = {np.sum: "sum", np.mean: "mean"}.get(reward_aggregation, reward_aggregation)
+        if agg not in ("sum", "mean", "last"):
+            raise ValueError(f"reward_aggregation must be 'sum', 'mean', 'last', np.sum or np.mean on the device, got {reward_aggregation!r}")
+        self.reward_aggregation = agg
         self.do_replanning = replanning_every is not None
         self.every = int(replanning_every) if self.do_replanning else self.horizon + 1
         self.max_planning_times = max_planning_times
@@ -87,7 +109,12 @@ class BatchedBlackBox:
         self.condition_pos = None
         self.condition_vel = None
         self._frozen_phase = None
-        self._lockstep = 0          # traj_steps of every live episode while the schedule keeps them in lockstep
+        # traj_steps of every live episode while the schedule keeps them in lockstep; None = per-episode init_time from the
+        # device counters.  With the validity gate an invalid plan takes its episode out of lockstep, which the host can only
+        # learn by reading the device back; `device_time` (set by capture_episode for a gated episode) runs the gate on
+        # per-episode times from the first plan on instead: nothing synchronises, the step is a fixed sequence of launches
+        self.device_time = False
+        self._lockstep = 0
         self._host_plans = 0
         self._const_flags = None    # (all-True, all-False) [B], shared by every fused step's result
         self._phase_bounds = None   # [2, n_phase] bounds of the learned tau / delay, on the device
@@ -131,7 +158,7 @@ class BatchedBlackBox:
                                   state(init_vel), cond=self._start32)
         self.condition_pos = self.condition_vel = None
         self._frozen_phase = None
-        self._lockstep = 0
+        self._lockstep = None if (self.device_time and self.do_replanning) else 0
         self._host_plans = 0
         self._plans_since_reset = 0
         self.traj_gen.reset()
@@ -154,6 +181,10 @@ class BatchedBlackBox:
         params = torch.as_tensor(params, dtype=torch.float32, device=self.device)
         if params.shape != (self.B, self.engine.num_params):
             raise ValueError(f"params must be [{self.B}, {self.engine.num_params}], got {tuple(params.shape)}")
+        if self._n_phase and self.learn_sub_trajectories:
+            # every sub-trajectory sets tau / delay anew (the reference resets the generator: black_box_wrapper.py:99-102);
+            # the kernels clip them to their bounds
+            return params.contiguous()
         if self._n_phase:
             # tau / delay are frozen by the first plan of an episode (mp_pytorch 'finalize'; pinned by
             # test/test_replanning_sequencing.py:231-335): later plans reuse them
@@ -176,7 +207,19 @@ class BatchedBlackBox:
         else:
             init_time = float(self._lockstep * self.dt) if self.do_replanning else 0.0
         pos, vel = self.engine.trajectory(params, cond_pos, cond_vel, init_time)
+        if self.learn_sub_trajectories and self.engine.mp_type == "promp":
+            # ProMP's velocity is the forward difference of its positions with the LAST row repeating the one before
+            # (mp_pytorch; make_env_helpers.py:119-122): the last row of a sub-trajectory of T_b steps is row T_b - 2, not the
+            # difference towards a step T_b the sub-trajectory does not have
+            n = self._plan_length(params).to(torch.int64)
+            rows = torch.arange(self.B, device=self.device)
+            vel[rows, n - 1] = vel[rows, (n - 2).clamp(min=0)]
         return {"params": params, "des_pos": pos, "des_vel": vel}
+
+    def _plan_length(self, params: torch.Tensor) -> torch.Tensor:
+        """learn_sub_trajectories: round(clip(tau_b) / dt) steps (np.round and torch.round: half to even), int32 [B]"""
+        tau = params[:, 0].clamp(float(self.tau_bound[0]), float(self.tau_bound[1]))     # what the kernels use (fp32 clip)
+        return torch.round(tau.double() / self.dt).to(torch.int32).clamp(1, self.T)
 
     # ---- plan + execute ----------------------------------------------------------------------------------------------
     def _host_segment(self) -> int:
@@ -195,7 +238,8 @@ class BatchedBlackBox:
         otherwise): needs the device plant, no validity gate, no device reward, and episodes that still move in lockstep
         (one init_time for all)"""
         return (self.spec is not None and self.plant == "double_integrator" and self.pos_limits is None
-                and self.reward is None and (not self.do_replanning or self._lockstep is not None))
+                and self.reward is None and not self.learn_sub_trajectories
+                and (not self.do_replanning or self._lockstep is not None))
 
     def _step_fused(self, params) -> Dict[str, torch.Tensor]:
         """plan + execute as ONE device operation (mpk_replan_step: integer state, trajectory + rollout, condition gather
@@ -263,32 +307,65 @@ class BatchedBlackBox:
             # invalid plans terminate their episode without executing a step (black_box_wrapper.py:169-172)
             self.done |= (~valid).to(torch.uint8)
         mpt = self.max_planning_times if math.isfinite(self.max_planning_times) else 2 ** 31 - 1
-        seg = self.engine.replan_advance(self.traj_steps, self.plan_steps, self.done, self.every, int(mpt),
-                                         self.horizon)
+        if self.learn_sub_trajectories:
+            seg = self._sub_trajectory_advance(out["params"])
+        else:
+            seg = self.engine.replan_advance(self.traj_steps, self.plan_steps, self.done, self.every, int(mpt),
+                                             self.horizon)
         if self.reward is not None:
             act, rew = self.engine.reacher_rollout(self.spec, pos, vel, self.q, self.qd, self.goal, n_steps=seg,
                                                    step0=self.traj_steps - seg,
                                                    steps_before_reward=self.steps_before_reward)
-            out.update(step_actions=act, step_rewards=rew, rewards=rew.sum(dim=1))
+            out.update(step_actions=act, step_rewards=rew, rewards=self._aggregate(rew, seg))
         elif self.spec is not None:
             out["step_actions"] = self.engine.pd_rollout(self.spec, pos, vel, self.q, self.qd, n_steps=seg)
         return self._finish(out, seg, valid, was_done)
 
+
+    def _sub_trajectory_advance(self, params: torch.Tensor) -> torch.Tensor:
+        """
+        learn_sub_trajectories: the integer part of one step, on the device (a handful of elementwise launches, nothing read
+        back).  Episode b plans round(clip(tau_b) / dt) steps (np.round: half to even, as torch.round) and executes them unless
+        its step budget ends first (the TimeLimit of the reference's step-based env truncates: test/test_replanning_sequencing.
+        py:100-109); finished episodes are left alone.  Returns the executed steps int32 [B].
+        """
+        plan_len = self._plan_length(params)
+        live = self.done == 0
+        left = (self.horizon - self.traj_steps).clamp(min=0)
+        seg = torch.where(live, torch.minimum(plan_len, left), torch.zeros_like(plan_len))
+        self.traj_steps += seg
+        self.plan_steps += live.to(torch.int32)
+        self.done |= (self.traj_steps >= self.horizon).to(torch.uint8)
+        return seg
+
+    def _aggregate(self, rew: torch.Tensor, seg: torch.Tensor) -> torch.Tensor:
+        """reward_aggregation(rewards[:t + 1]) of black_box_wrapper.py:216 for every episode: sum / mean / last over its
+        executed steps (step_rewards are zero behind them); an episode that executed nothing gets 0"""
+        if self.reward_aggregation == "sum":
+            return rew.sum(dim=1)
+        n = seg.to(torch.int64)
+        if self.reward_aggregation == "mean":
+            return torch.where(n > 0, rew.sum(dim=1) / n.clamp(min=1).to(rew.dtype), torch.zeros_like(rew[:, 0]))
+        last = rew.gather(1, (n - 1).clamp(min=0)[:, None])[:, 0]
+        return torch.where(n > 0, last, torch.zeros_like(last))
 
     # ---- whole episodes as one hipGraph ----------------------------------------------------------------------------------
     def capture_episode(self, n_plans: int, with_goal: bool = False) -> "EpisodeGraph":
         """
         Capture ``reset`` + ``n_plans`` calls of ``step`` into one hipGraph.  At B of a few thousand a plan costs ~100 us of
         Python / ctypes / allocator work around ~20 us of kernels; a replay pays one graph launch for the whole
-        episode.  Requirements: a device-resident plant (``plant != None``) and a schedule the host can mirror without
-        reading device state (no validity gate), so that capture never synchronises.
+        episode.  Requirement: a device-resident plant (``plant != None``).  With the validity gate the episodes run on
+        per-episode times from the device counters (``device_time``: an invalid plan takes its episode out of lockstep, which
+        only the device knows), so that nothing synchronises during capture either.
 
         Write the inputs into the returned object's static buffers (``init_pos``, ``init_vel``, ``params[k]``, ``goal``),
         call ``replay()``, read ``outs[k]`` (the dicts ``step`` returned during capture; their tensors are rewritten by
         every replay).
         """
-        if self.spec is None or self.pos_limits is not None:
-            raise ValueError("capture_episode needs a device plant and no validity gate (both would need the host)")
+        if self.spec is None:
+            raise ValueError("capture_episode needs a device plant (host environments cannot be captured)")
+        if self.pos_limits is not None:
+            self.device_time = True
         return EpisodeGraph(self, int(n_plans), with_goal)
 
 

@@ -659,7 +659,7 @@ namespace {
 struct OptKey { const char* name; int Tuning::*field; int64_t lo, hi; };
 const OptKey kOptKeys[] = {
     {"mapping", &Tuning::mapping, 0, 2},         {"bulk", &Tuning::bulk, 0, 2},
-    {"quad", &Tuning::quad, 0, 4},               {"pd_quad", &Tuning::pd_quad, 0, 2},
+    {"quad", &Tuning::quad, 0, 4},               {"pd_quad", &Tuning::pd_quad, 0, 3},
     {"write_through", &Tuning::write_through, 0, 1}, {"ipw", &Tuning::ipw, 0, 1 << 20},
     {"phase", &Tuning::phase, 0, 1},             {"phase_table", &Tuning::phase_table, 0, 1},
     {"phase_chunk", &Tuning::phase_chunk, 0, 16}, {"pd_simple", &Tuning::pd_simple, 0, 1},

@@ -138,20 +138,31 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
         bool mover[NG];
         const float* gp[NG];
         const float* gv[NG];
-        f32x4 lp[NG], lv[NG];
+        // the desired (pos, vel) pieces travel TWO tiles ahead of the recurrence, in two register sets used in turn: one tile's
+        // chain (16 steps, ~1300 cycles) is shorter than a load's round trip even from the memory-side cache, so with one tile of
+        // lookahead every tile waited for its inputs (B = 2048: 182 cycles per step against the chain's 83; profiles/r04_rollout.md)
+        f32x4 lpA[NG], lvA[NG], lpB[NG], lvB[NG];
+        auto fetch = [&](const int rt, f32x4 (&lp)[NG], f32x4 (&lv)[NG]) {
+            const int rows_n = min(16, T - rt * 16);
+#pragma unroll
+            for (int j = 0; j < NG; ++j) {
+                if (mover[j] && w4 < rows_n * D) {
+                    lp[j] = *reinterpret_cast<const f32x4*>(gp[j] + (size_t)rt * SEG);
+                    lv[j] = *reinterpret_cast<const f32x4*>(gv[j] + (size_t)rt * SEG);
+                }
+            }
+        };
 #pragma unroll
         for (int j = 0; j < NG; ++j) {
             const int b0 = (g0 + j) * NTW;
             mover[j] = g0 + j < a.G && sseg < NTW && b0 + sseg < B;
             gp[j] = a.des_pos + (size_t)b0 * T * D + gofs;
             gv[j] = a.des_vel + (size_t)b0 * T * D + gofs;
-            lp[j] = f32x4{0, 0, 0, 0}; lv[j] = lp[j];
-            if (mover[j] && w4 < min(16, T) * D) {
-                lp[j] = *reinterpret_cast<const f32x4*>(gp[j]);
-                lv[j] = *reinterpret_cast<const f32x4*>(gv[j]);
-            }
+            lpA[j] = f32x4{0, 0, 0, 0}; lvA[j] = lpA[j]; lpB[j] = lpA[j]; lvB[j] = lpA[j];
         }
-        for (int rt = 0; rt < NRT; ++rt) {
+        fetch(0, lpA, lvA);
+        if (NRT > 1) fetch(1, lpB, lvB);
+        auto tile = [&](const int rt, f32x4 (&lp)[NG], f32x4 (&lv)[NG]) {
             const int rows = min(16, T - rt * 16);
 #pragma unroll
             for (int j = 0; j < NG; ++j) {
@@ -160,16 +171,7 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
                     *reinterpret_cast<f32x4*>(sSt + j * SLOT + kStageStride + rofs) = lv[j];
                 }
             }
-            if (rt + 1 < NRT) {   // next tile's pieces travel under this tile's recurrence
-                const int rows_n = min(16, T - (rt + 1) * 16);
-#pragma unroll
-                for (int j = 0; j < NG; ++j) {
-                    if (mover[j] && w4 < rows_n * D) {
-                        lp[j] = *reinterpret_cast<const f32x4*>(gp[j] + (size_t)(rt + 1) * SEG);
-                        lv[j] = *reinterpret_cast<const f32x4*>(gv[j] + (size_t)(rt + 1) * SEG);
-                    }
-                }
-            }
+            if (rt + 2 < NRT) fetch(rt + 2, lp, lv);          // into the set this tile has just emptied
             __builtin_amdgcn_wave_barrier();
             if (serial) {
                 // the 16 steps of the tile as straight-line code per (controller, plant): a run-time switch inside the
@@ -256,6 +258,10 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
                 }
             }
             __builtin_amdgcn_wave_barrier();
+        };
+        for (int rt = 0; rt < NRT; rt += 2) {
+            tile(rt, lpA, lvA);
+            if (rt + 1 < NRT) tile(rt + 1, lpB, lvB);
         }
         if (serial) {
             const size_t si = (size_t)bs * D + d;
@@ -395,13 +401,18 @@ int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
         const int NTW = 16 >> sh;
         pa.G = (B + NTW - 1) / NTW;
         pa.inv_seg4 = 65536u / (unsigned)(4 * D) + 1u;
+        // groups per wave by the waves per SIMD they leave, as launch_pd_rollout ("pd_quad": 0 one, 2 four, 3 two)
         const int quad_mode = tune.pd_quad < 0 ? 1 : tune.pd_quad;
-        const bool quad = quad_mode == 2 || (quad_mode == 1 && pa.G >= 4 * 256 * 4);   // measured (profiles/r03_rollout.md): 19.3 vs 23.9 us at 4096 groups, 15.6 vs 14.6 at 2048
-        const int units = quad ? (pa.G + 3) / 4 : pa.G;
+        const long simds = 1024;
+        int ng = 1;
+        if (quad_mode == 2) ng = 4;
+        else if (quad_mode == 3) ng = 2;
+        else if (quad_mode == 1) ng = pa.G >= 8 * simds ? 4 : (pa.G >= 2 * simds ? 2 : 1);
+        const int units = (pa.G + ng - 1) / ng;
         int blocks = (units + 3) / 4;
         if (blocks > 2048) blocks = 2048;
         if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;
-        const size_t lds = (size_t)4 * (quad ? 4 : 1) * 5 * kStageStride * sizeof(float);
+        const size_t lds = (size_t)4 * ng * 5 * kStageStride * sizeof(float);
         auto go = [&](auto kern) -> int {
             if (lds > 64 * 1024) {
                 hipError_t e = allow_full_lds(kern);
@@ -411,7 +422,7 @@ int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
             MPK_LAUNCH_CHECK();
             return MPK_OK;
         };
-        return quad ? go(k_pd_rollout_tiles<4, true>) : go(k_pd_rollout_tiles<1, true>);
+        return ng == 4 ? go(k_pd_rollout_tiles<4, true>) : (ng == 2 ? go(k_pd_rollout_tiles<2, true>) : go(k_pd_rollout_tiles<1, true>));
     }
     const int epw = 64 / D;
     const long waves = ((long)B + epw - 1) / epw;
@@ -442,15 +453,22 @@ int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const f
         const int NTW = 16 >> sh;
         pa.G = (B + NTW - 1) / NTW;
         pa.inv_seg4 = 65536u / (unsigned)(4 * D) + 1u;
-        // four groups per wave once that still leaves every CU several waves ("pd_quad": 0 off, 2 force)
+        // groups per wave (lane quarter j runs group j's recurrence: NG x fewer serial instructions per episode) chosen by the
+        // waves per SIMD it leaves (1024 SIMDs): four from 8 groups per SIMD on, two from 2, else one ("pd_quad": 0 one, 2 four,
+        // 3 two).  Measured (profiles/r04_rollout.md)
         const int quad_mode = tune.pd_quad < 0 ? 1 : tune.pd_quad;
-        const bool quad = quad_mode == 2 || (quad_mode == 1 && pa.G >= 4 * 256 * 4);   // measured (profiles/r03_rollout.md): 19.3 vs 23.9 us at 4096 groups, 15.6 vs 14.6 at 2048
-        const int units = quad ? (pa.G + 3) / 4 : pa.G;
+        const long simds = 1024;
+        int ng = 1;
+        if (quad_mode == 2) ng = 4;
+        else if (quad_mode == 3) ng = 2;
+        else if (quad_mode == 1) ng = pa.G >= 8 * simds ? 4 : (pa.G >= 2 * simds ? 2 : 1);
+        const int units = (pa.G + ng - 1) / ng;
         int blocks = (units + 3) / 4;
         if (blocks > 2048) blocks = 2048;
         if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;
-        const size_t lds = (size_t)4 * (quad ? 4 : 1) * 3 * kStageStride * sizeof(float);
-        if (quad) hipLaunchKernelGGL((k_pd_rollout_tiles<4, false>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, pa);
+        const size_t lds = (size_t)4 * ng * 3 * kStageStride * sizeof(float);
+        if (ng == 4) hipLaunchKernelGGL((k_pd_rollout_tiles<4, false>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, pa);
+        else if (ng == 2) hipLaunchKernelGGL((k_pd_rollout_tiles<2, false>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, pa);
         else hipLaunchKernelGGL((k_pd_rollout_tiles<1, false>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, pa);
         MPK_LAUNCH_CHECK();
         return MPK_OK;

@@ -199,7 +199,7 @@ int mpk_set_duration(mpk_handle h, double duration, double dt);
  *   "mapping"       1 tile-major, 2 episode-major                                  (shared-phase trajectory kernels)
  *   "bulk"          0 off, 2 force chunked input staging                           (episode-major kernel)
  *   "quad"          0 off, 2 / 3 / 4 = four / two / one episode group(s) per wave  (serial-recurrence trajectory kernels)
- *   "pd_quad"       0 off, 2 force four groups per wave                            (rollout kernels)
+ *   "pd_quad"       0 one, 2 four, 3 two groups per wave (automatic: by the waves per SIMD they leave)   (rollout kernels)
  *   "write_through" 0 plain stores, 1 write-through (sc1) stores                   (every kernel that has the choice)
  *   "ipw"           n > 0 work items per wave                                      (tile-major kernel)
  *   "phase"         0 workgroup-per-episode kernel instead of wave-per-episode     (per-episode-phase kernels)

@@ -303,6 +303,11 @@ struct ExpRegs {
     __device__ __forceinline__ double operator[](int i) const { return t[i]; }
 };
 
+// first Taylor coefficient used: 3 = 1/11! (remainder < 7e-15 relative), 6 = 1/8! (remainder r^9 / 9! < 2e-10 for |r| <= ln2 / 2:
+// still 300 times below the fp32 rounding that follows every use of these rows) -- A/B build knob (profiles/r04_per_episode_dmp.md)
+#ifndef MPK_EXP_FIRST
+#define MPK_EXP_FIRST 6
+#endif
 template <class CF>
 __device__ __forceinline__ double exp_nonpos(double x, const CF& cf) {
     x = fmax(x, -700.0);                                        // exp(-700) ~ 1e-304: still normal, rounds to 0.0f
@@ -310,9 +315,9 @@ __device__ __forceinline__ double exp_nonpos(double x, const CF& cf) {
     const double n = rint(x * cf[0]);
     double r = fma(n, cf[1], x);
     r = fma(n, cf[2], r);
-    double p = cf[3];
+    double p = cf[MPK_EXP_FIRST];
 #pragma unroll
-    for (int i = 4; i < 15; ++i) p = fma(p, r, cf[i]);
+    for (int i = MPK_EXP_FIRST + 1; i < 15; ++i) p = fma(p, r, cf[i]);
     return ldexp(p, (int)n);
 }
 

@@ -668,7 +668,7 @@ const OptKey kOptKeys[] = {
     {"phase_flat", &Tuning::phase_flat, 0, 1},   {"ring", &Tuning::ring, 0, 2},
     {"ring_np", &Tuning::ring_np, 1, 14},        {"ring_ns", &Tuning::ring_ns, 1, 8},
     {"ring_m", &Tuning::ring_m, 1, 8},           {"ring_dbg", &Tuning::ring_dbg, 0, 63},
-    {"ring_parts", &Tuning::ring_parts, 1, 8},
+    {"ring_parts", &Tuning::ring_parts, 1, 8},   {"tiles_wpb", &Tuning::tiles_wpb, 1, 4},
 };
 const OptKey* find_opt(const char* key) {
     if (!key) return nullptr;

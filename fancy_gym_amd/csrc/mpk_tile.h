@@ -59,6 +59,7 @@ struct TrajArgs {
     int ring_tb;           // batches per ticket
     int ring_parts;        // waves that share one group's row tiles (long horizons: the image of ONE group fills a batch buffer)
     int burst;             // k_traj_burst: short-lived workgroups, one batch of ring_m groups each, ring_np waves per group
+    int wpb;               // tile-major kernel: waves per workgroup (4; "tiles_wpb" 1 / 2 for A/B runs)
     int ring_dbg;          // ablations (mpk_set_option "ring_dbg"): 1 producers publish without contracting, 2 the engine skips its stores
     unsigned ser_blocks;   // k_traj_split: workgroups [0, ser_blocks) run the serial role
     // closed-loop rollout fused into the episode-major kernel (CT >= 3)
@@ -353,6 +354,22 @@ __device__ __forceinline__ void tile_epilogue(const f32x4& acc0, const f32x4& ac
         // closed loop: actions of steps the plan does not execute are 0; the recurrence lanes overwrite the executed ones
         if (CT >= 3) w[2 * astride] = 0.0f;
     }
+}
+
+// ---- LDS accesses with the offset as an instruction immediate (round 4: the kernels are instruction-issue bound, and most of what
+// the compiler adds around a 16 x 16 tile is address arithmetic on run-time strides) ------------------------------------------------
+__device__ __forceinline__ unsigned lds_addr(const float* p) { return (unsigned)reinterpret_cast<uintptr_t>(p); }
+template <int OFF>
+__device__ __forceinline__ void lds_w32(const unsigned ad, const float v) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(ad), "v"(v), "n"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ float lds_r32(const unsigned ad) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(ad), "n"(OFF));
+    return v;
 }
 
 // generic (slow) tile store: partial last row tile whose length is not a multiple of 4, or unaligned outputs.

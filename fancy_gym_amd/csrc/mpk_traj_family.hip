@@ -113,19 +113,20 @@ static int launch_traj_t(const TrajArgs& ta, const ActArgs& aa, bool stream_mode
         }
     } else {
         if constexpr (MP != MPK_MP_DMP && CT < 3) {
+            const dim3 bt((unsigned)ta.wpb * 64u);
             if (write_through) {
                 switch (km) {
-                    case 1: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 1, true>), g, b, pad, s, ta, aa); break;
-                    case 2: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 2, true>), g, b, pad, s, ta, aa); break;
-                    case 3: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 3, true>), g, b, pad, s, ta, aa); break;
-                    default: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 4, true>), g, b, pad, s, ta, aa); break;
+                    case 1: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 1, true>), g, bt, pad, s, ta, aa); break;
+                    case 2: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 2, true>), g, bt, pad, s, ta, aa); break;
+                    case 3: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 3, true>), g, bt, pad, s, ta, aa); break;
+                    default: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 4, true>), g, bt, pad, s, ta, aa); break;
                 }
             } else {
                 switch (km) {
-                    case 1: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 1, false>), g, b, pad, s, ta, aa); break;
-                    case 2: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 2, false>), g, b, pad, s, ta, aa); break;
-                    case 3: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 3, false>), g, b, pad, s, ta, aa); break;
-                    default: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 4, false>), g, b, pad, s, ta, aa); break;
+                    case 1: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 1, false>), g, bt, pad, s, ta, aa); break;
+                    case 2: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 2, false>), g, bt, pad, s, ta, aa); break;
+                    case 3: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 3, false>), g, bt, pad, s, ta, aa); break;
+                    default: hipLaunchKernelGGL((k_traj_tiles<MP, CT, 4, false>), g, bt, pad, s, ta, aa); break;
                 }
             }
         }

@@ -134,7 +134,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
                        const Tuning& tune, const ReplanDev* rp, unsigned* ticket) {
     TrajArgs ta;
     ta.nrt_magic = 0; ta.gstride = 0; ta.wt = 0; ta.flat_img = 0;
-    ta.ring_np = 0; ta.ring_ns = 0; ta.ring_m = 0; ta.ring_nbuf = 0; ta.ring_dbg = tune.ring_dbg > 0 ? tune.ring_dbg : 0; ta.burst = 0; ta.ring_ctr = nullptr; ta.ring_tb = 0; ta.ring_parts = 1;
+    ta.ring_np = 0; ta.ring_ns = 0; ta.ring_m = 0; ta.ring_nbuf = 0; ta.ring_dbg = tune.ring_dbg > 0 ? tune.ring_dbg : 0; ta.burst = 0; ta.wpb = 4; ta.ring_ctr = nullptr; ta.ring_tb = 0; ta.ring_parts = 1;
     if (rp) ta.rp = *rp;
     const bool closed = q_state != nullptr;
     ta.q_state = q_state; ta.qd_state = qd_state; ta.n_steps = n_steps; ta.plant_dt = rc ? rc->dt : 0.0;
@@ -379,14 +379,16 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         const long wave_cap = (long)((1ull << 32) / (unsigned long long)NRT) - 8 * NRT;
         if ((items + ipw - 1) / ipw > wave_cap) ipw = (items + wave_cap - 1) / wave_cap;
         const long waves = (items + ipw - 1) / ipw;
-        blocks = (int)((waves + 3) / 4);
+        const int wpb = (tune.tiles_wpb == 1 || tune.tiles_wpb == 2) && !split ? tune.tiles_wpb : 4;   // A/B: smaller workgroups
+        ta.wpb = wpb;
+        blocks = (int)((waves + wpb - 1) / wpb);
         {   // #waves % NRT == 0, and a multiple of 8 blocks for the XCD remap once there are that many
             int g8 = 8, r = NRT;
             while (r) { const int t = g8 % r; g8 = r; r = t; }           // gcd(8, NRT)
             const int unit = blocks >= 8 ? NRT / g8 * 8 : NRT;           // lcm(8, NRT) or NRT
             blocks = (blocks + unit - 1) / unit * unit;
         }
-        ta.gstride = blocks * 4 / NRT;
+        ta.gstride = blocks * wpb / NRT;
         ta.nrt_magic = NRT > 1 ? (unsigned)((1ull << 32) / (unsigned long long)NRT) + 1u : 0u;
     }
     if (blocks < 1) blocks = 1;

@@ -125,20 +125,6 @@ __device__ __forceinline__ void ring_contract(const TrajArgs& a, const LaneMap<K
 //   * the C tile's 12 image stores: ds_write_b32 offset:((tile in pair) * 16 + row) * DC * 4 from one address register per array;
 //   * the last, partial row tile is the only one with row predicates.
 // The arithmetic is ring_contract's (the same MFMA operands and order, tile_epilogue's controller expression): same bits.
-__device__ __forceinline__ unsigned lds_addr(const float* p) { return (unsigned)reinterpret_cast<uintptr_t>(p); }
-template <int OFF>
-__device__ __forceinline__ void lds_w32(const unsigned ad, const float v) {
-    static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
-    asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(ad), "v"(v), "n"(OFF));
-}
-template <int OFF>
-__device__ __forceinline__ float lds_r32(const unsigned ad) {
-    static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
-    float v;
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(ad), "n"(OFF));
-    return v;
-}
-
 template <int MP, int CT, int KM, int DC>
 __device__ __forceinline__ void ring_contract_d(const TrajArgs& a, const LaneMap<KM>& L, const float* ap, const float* sAux,
                                                 const float (&xb)[KM], const double cp, const double cv, const Gains& gn,
@@ -526,20 +512,24 @@ __global__ void __launch_bounds__(512) k_traj_burst(const TrajArgs a, const ActA
     if (have) cur = load_group<MP, ACT, KM>(a, L, g);
     Gains gn{0.0, 0.0, 0.0, 0.0};
     if (ACT) gn = kernarg_gains(L.dvalid ? L.d : 0);
-    {
+    // "ring_dbg" bit 4: no table copy -- every wave reads the A fragments of ITS row tiles straight from the (cache-resident) table,
+    // as the tile-major kernel does: a workgroup that lives for one group would otherwise copy 7.6 KB to contract 16.8 KB
+    const bool staged = !(a.ring_dbg & 16);
+    if (staged) {
         const float4* src = reinterpret_cast<const float4*>(a.A);
         float4* dst = reinterpret_cast<float4*>(sA);
         const int nA4 = (NOUT * KP * TS) >> 2, nX4 = TS >> 2;
         for (int i = threadIdx.x; i < nA4; i += blockDim.x) dst[i] = src[i];
         for (int i = threadIdx.x; i < nX4; i += blockDim.x) reinterpret_cast<float4*>(sAux)[i] = reinterpret_cast<const float4*>(a.aux)[i];
+        __syncthreads();
     }
-    __syncthreads();
     if (have && !(a.ring_dbg & 1)) {
         float xb[KM];
         finish_group<KM>(L, cur, xb);
         const int per = (NRT + WPG - 1) / WPG;
         const int rt0 = part * per, rt1 = min(NRT, rt0 + per);
-        ring_contract<MP, CT, KM>(a, L, sA + L.q * TS + L.col, sAux, xb, cur.cp, cur.cv, gn, sB + j * IMG, M * IMG, rt0, rt1);
+        if (staged) ring_contract<MP, CT, KM>(a, L, sA + L.q * TS + L.col, sAux, xb, cur.cp, cur.cv, gn, sB + j * IMG, M * IMG, rt0, rt1);
+        else ring_contract<MP, CT, KM>(a, L, a.A + L.q * TS + L.col, a.aux, xb, cur.cp, cur.cv, gn, sB + j * IMG, M * IMG, rt0, rt1);
     }
     __syncthreads();
     const long e0 = b * M * NTW;

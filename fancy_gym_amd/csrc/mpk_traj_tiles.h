@@ -27,7 +27,7 @@ __device__ __forceinline__ void tiles_body(const TrajArgs& a, float* smem, const
     // the same parameters and write one contiguous trajectory -- stay behind one L2
     const int nb8 = (int)(nblk >> 3);
     const int vb = (nblk & 7) == 0 ? (int)(bid & 7) * nb8 + (int)(bid >> 3) : (int)bid;
-    const int wid = vb * 4 + wave;
+    const int wid = vb * a.wpb + wave;
     const int gstride = a.gstride;
     int g = a.nrt_magic ? (int)__umulhi((unsigned)wid, a.nrt_magic) : wid;      // magic 0: NRT == 1
     const int rt = wid - g * NRT;
@@ -67,6 +67,8 @@ __device__ __forceinline__ void tiles_body(const TrajArgs& a, float* smem, const
             if (NOUT > 2) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[NOUT > 2 ? 2 : 0][m], xb[m], acc2, 0, 0, 0);
         }
         // 3. epilogue -> LDS transpose; 4. coalesced stores
+        // (the epilogue with the DoF count as a compile-time constant -- immediates instead of address arithmetic, what moved
+        // k_traj_ring -- measured 8.67 vs 8.66 us here: this launch is not instruction-issue bound.  profiles/r04_headline_ab.md)
         if (L.dvalid)
             tile_epilogue<MP, CT>(acc0, acc1, acc2, dtd, cp, cv, kg, sSt, L.wofs + ep_shift(a, g * L.NTW + L.bl), D);
         __builtin_amdgcn_wave_barrier();

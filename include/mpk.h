@@ -213,6 +213,19 @@ int mpk_set_duration(mpk_handle h, double duration, double dt);
  *                   promp / prodmp launches whose outputs stream to HBM)
  *   "split"         1 force the tile-major closed-loop kernel with a serial role (k_traj_split; never chosen automatically)
  *   "lds_pad"       n KB of unused dynamic LDS per workgroup of the tile-major kernels (occupancy experiments: 160 KB per CU)
+ *   "tiles_wpb"     1 .. 4 waves per workgroup of the tile-major kernels (4)
+ *   "ring"          0 off, 1 force the persistent producer / store-engine kernel (k_traj_ring: open-loop promp / prodmp with a
+ *                   shared phase; automatic where the outputs of a launch exceed the caches), 2 its short-lived-workgroup
+ *                   variant (k_traj_burst; never chosen automatically).  A shape whose whole-trajectory images do not fit the LDS
+ *                   falls through to the other kernels.  Launch geometry of a "ring" launch:
+ *   "ring_np"       1 .. 14 producer waves per workgroup (8)
+ *   "ring_ns"       1 .. 8 store-engine waves per workgroup (2)
+ *   "ring_m"        1 .. 8 episode groups per batch buffer (the largest <= 4 that leaves two buffers in 160 KB)
+ *   "ring_parts"    1 .. 8 producer waves sharing the row tiles of one group (by the buffers: all producers stay busy)
+ *   "ring_dbg"      bit mask for A/B runs.  Result-preserving: 4 batches b -> workgroup b % grid instead of tickets from the
+ *                   device counter, 16 contiguous batch ranges per workgroup (k_traj_burst: A fragments from the table in
+ *                   L2), 32 the generic contraction / flush loops instead of the compile-time-DoF ones.  ABLATIONS that leave
+ *                   outputs unwritten, measurements only: 1 no production, 2 no stores, 8 no input loads.
  * Unknown key or value out of range: MPK_EINVAL.  mpk_get_option returns the effective value (MPK_OPT_AUTO if automatic).
  */
 #define MPK_OPT_AUTO (-1)

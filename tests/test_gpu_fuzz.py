@@ -220,6 +220,70 @@ def test_random_wide_or_flat_configuration_matches_oracle(seed, mpk_option):
         assert torch.equal(pos, p2) and torch.equal(vel, v2), (kern, eng.last_kernel())
 
 
+# ---- round 4: k_traj_ring (producer waves + store engine, batch tickets) under random shapes and launch geometries ------------------
+N_CASES_R4 = int(os.environ.get("MPK_FUZZ_CASES_R4", "60"))
+START_R4 = int(os.environ.get("MPK_FUZZ_START_R4", "0"))
+
+
+@pytest.mark.parametrize("seed", range(START_R4, START_R4 + N_CASES_R4))
+def test_random_configuration_through_the_ring_kernel_is_bit_identical(seed, mpk_option):
+    """promp / prodmp, shared phase, <= 16 columns and DoF: the forced ring launch (random producers / engine waves / groups per
+    batch / waves per group / batch order / contraction loop) against the automatic kernels -- trajectory and fused actions, bit
+    for bit -- and the oracle; shapes the ring cannot take (its images do not fit the LDS) must fall through to the other kernels"""
+    rng = np.random.default_rng(250_000 + seed)
+    pc, bc, tc, dt, dur, B, init_time = random_case(rng)
+    if tc.trajectory_generator_type == "dmp":
+        tc = dataclasses.replace(tc, trajectory_generator_type="promp")
+        bc = dataclasses.replace(bc, basis_generator_type="zero_rbf" if rng.random() < 0.5 else "rbf")
+        pc = dataclasses.replace(pc, phase_generator_type="linear")
+    pc = dataclasses.replace(pc, learn_tau=False, learn_delay=False)
+    if tc.trajectory_generator_type == "prodmp":
+        if (dur + init_time) / pc.tau > 5.9:
+            init_time = 0.0
+        if dur / pc.tau > 5.9:
+            pytest.skip("beyond the ProDMP pre-computation range")
+    r4 = np.random.default_rng(299_000 + seed)
+    B = int(r4.choice([1, 2, 3, 5, 17, 64, 257, 1031, 5003]))
+    eng = make_engine(pc, bc, tc, dt, dur)
+    D = tc.action_dim
+    params, ip, iv = inputs(pc, bc, tc, B, seed=seed)
+    mpk_option("ring", 0)
+    p0, v0 = [t.clone() for t in eng.trajectory(params, ip, iv, init_time)]
+    k0 = eng.last_kernel()
+    rp, rv = O.get_trajectory(pc, bc, tc, params, dur, dt, init_time, ip, iv, dtype=np.float64)
+    if not np.isfinite(rp).all():
+        pytest.skip("degenerate basis")
+    p32, v32 = O.get_trajectory(pc, bc, tc, params, dur, dt, init_time, ip, iv, dtype=np.float32)
+
+    def slack(r32, r64):
+        e = float(np.abs(r32.astype(np.float64) - r64).max()) if r64.size else 0.0
+        return e if e > 2e-6 * float(np.abs(r64).max()) else 0.0
+    close(p0.cpu().numpy(), rp, f"pos [{k0}]", atol=slack(p32, rp))
+    opts = dict(ring_np=int(r4.choice([-1, 1, 3, 8, 10])), ring_ns=int(r4.choice([-1, 1, 2, 4])), ring_m=int(r4.choice([-1, 1, 2, 3, 4, 7])),
+                ring_parts=int(r4.choice([-1, 1, 2, 5])), ring_dbg=int(r4.choice([0, 0, 4, 16, 32, 36])))
+    for k, v in opts.items():
+        mpk_option(k, v)
+    ring = int(r4.choice([1, 1, 1, 2]))                # 2: the short-lived-workgroup variant kept for A/B
+    mpk_option("ring", ring)
+    out = (torch.full_like(p0, float("nan")), torch.full_like(v0, float("nan")))
+    eng.trajectory(params, ip, iv, init_time, out=out)
+    torch.cuda.synchronize()
+    k1 = eng.last_kernel()
+    assert torch.equal(out[0].view(torch.int32), p0.view(torch.int32)) and torch.equal(out[1].view(torch.int32), v0.view(torch.int32)), (k0, k1, ring, opts)
+    if D <= 16 and bc.num_basis + 3 <= 16:
+        from fancy_gym_amd import RolloutSpec
+        ctrl = str(r4.choice(["motor", "position", "velocity"]))
+        spec = RolloutSpec(ctrl, D, r4.uniform(0.1, 2.0, D), r4.uniform(0.01, 0.3, D), -1.5, 1.5, plant="static")
+        cp, cv = r4.uniform(-1, 1, (B, D)), r4.uniform(-1, 1, (B, D))
+        mpk_option("ring", 0)
+        a0 = [t.clone() for t in eng.trajectory_actions(params, ip, iv, spec, cp, cv, init_time=init_time)]
+        mpk_option("ring", ring)
+        a1 = eng.trajectory_actions(params, ip, iv, spec, cp, cv, init_time=init_time)
+        torch.cuda.synchronize()
+        for x, y in zip(a0, a1):
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32)), (eng.last_kernel(), opts, ctrl)
+
+
 # ---- round 3, part two: the entry points the two tests above do not reach -- fused open-loop actions (every controller),
 # the reacher rollout + reward, validity + penalty, per-episode init_time vectors ------------------------------------------
 N_CASES_R3B = int(os.environ.get("MPK_FUZZ_CASES_R3B", "60"))

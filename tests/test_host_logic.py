@@ -496,6 +496,53 @@ def test_options_api_without_a_gpu():
         assert "getenv" not in text, f"{src} reads the environment"
 
 
+def test_round4_option_keys_and_their_ranges():
+    """the store-engine launch geometry (ring*), the tile-major workgroup size and the two-group rollout are options with ranges"""
+    lib = _lib.load()
+    ranges = {"ring": (0, 2), "ring_np": (1, 14), "ring_ns": (1, 8), "ring_m": (1, 8), "ring_parts": (1, 8), "ring_dbg": (0, 63),
+              "tiles_wpb": (1, 4), "pd_quad": (0, 3)}
+    for key, (lo, hi) in ranges.items():
+        assert key in _lib.OPTION_KEYS
+        for v in (lo, hi):
+            _lib.set_option(key, v)
+            assert _lib.get_option(key) == v
+        for v in (lo - 1 if lo - 1 != _lib.MPK_OPT_AUTO else lo - 2, hi + 1):
+            with pytest.raises(ValueError, match="out of range"):
+                _lib.set_option(key, v)
+        _lib.set_option(key)
+        assert _lib.get_option(key) == _lib.MPK_OPT_AUTO
+    _lib.reset_options()
+    # every option of the ctypes table is documented in the header the C callers read
+    hdr = open(os.path.join(ROOT, "include", "mpk.h")).read()
+    for key in _lib.OPTION_KEYS:
+        assert re.search(r'"%s"' % key, hdr), f'include/mpk.h does not document option "{key}"'
+
+
+def test_every_translation_unit_is_hashed_and_a_flagged_build_is_not_the_sources():
+    """the build stamp covers every file a kernel unit includes; an A/B build with extra flags carries a different stamp, so that
+    load() never mistakes it for the checked-out sources"""
+    csrc = os.path.join(ROOT, "fancy_gym_amd", "csrc")
+    hashed = {os.path.basename(p) for p in _lib.SOURCE_FILES}
+    for name in _lib.KERNEL_UNITS + _lib.KERNEL_HEADERS + ("mpk_host.cpp", "mpk_internal.h"):
+        assert os.path.exists(os.path.join(csrc, name)), name
+        assert name in hashed, f"{name} is not part of the source hash"
+    assert "mpk.h" in hashed
+    included = set()
+    for name in _lib.KERNEL_UNITS + _lib.KERNEL_HEADERS:
+        included |= set(re.findall(r'#include\s+"([^"]+)"', open(os.path.join(csrc, name)).read()))
+    for inc in included:
+        assert os.path.basename(inc) in hashed, f"{inc} is included by a kernel unit but not hashed"
+    # the amalgamation the trace / single-kernel tools build names every unit
+    amal = open(os.path.join(csrc, "mpk_kernels.hip")).read()
+    for name in _lib.KERNEL_UNITS:
+        assert name in amal, f"mpk_kernels.hip does not include {name}"
+    base = _lib.stamp()
+    assert base == _lib.source_hash() == _lib.stamp("  ")
+    flagged = _lib.stamp("-DMPK_EXP_FIRST=4")
+    assert flagged != base and len(flagged) == len(base) and flagged != _lib.stamp("-DMPK_EXP_FIRST=5")
+    assert _lib.embedded_source_hash() == base, "libmpk.so in the tree was not built from these sources"
+
+
 def test_semantic_switch_fields_are_validated():
     lib = _lib.load()
     assert lib.mpk_host_num_params(C.byref(_cfg())) == 42

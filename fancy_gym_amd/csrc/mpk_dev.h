@@ -52,6 +52,32 @@ __device__ long long g_trace[256];
         }                                                                           \
     } while (0)
 
+// ---- the size rules of every launcher, in one place: what is fitted to the caches and the LDS of an MI355X -----------------------
+// LDS: 160 KB per CU; a workgroup may take more than kLdsDefault only after allow_full_lds(); the whole-trajectory-image kernels
+// leave room for two workgroups per CU (kLdsHalf)
+constexpr size_t kLdsPerCu = 160 * 1024;
+constexpr size_t kLdsDefault = 64 * 1024;
+constexpr size_t kLdsHalf = 80 * 1024;
+// Outputs of a launch up to kCachedBytes stay in the L2s + the memory-side cache whatever the store order: the tile-major kernels
+// (best load balance, scattered 64-byte runs) keep those launches; above, the episode-major kernels write whole-trajectory runs
+// (profiles/r02_streaming.md: the cross-over sits between 64 and 128 MB for every configuration measured)
+constexpr double kCachedBytes = 96.0 * 1024 * 1024;
+// Write-through (sc1) stores are chosen while a launch's outputs still fit the memory-side cache (256 MB + the L2s): plain
+// write-back stores fall off a cliff once the dirty lines exceed it, write-through stores lose once the outputs stream to
+// HBM anyway.  Measured per kernel family and size (profiles/r03_streaming_wt.md, us plain vs write-through): k_traj_flat
+// +actions 57.1 / 46.1 at 241 MB, 67.5 / 51.9 at 275 MB, 74.3 / 71.3 at 310 MB, 77.7 / 88.6 at 344 MB; cfg3 k_traj_quad<dmp>
+// 36.5 / 33.6 at 175 MB, 58.2 / 54.3 at 262 MB, 99 / 104 at 350 MB; closed loop k_traj_duo 80.8 / 70.1 at 262 MB, 173 / 221 at
+// 525 MB; per-episode kernels 44.2 / 41.2 at 175 MB, 107 / 117 at 350 MB.
+constexpr double kWtBytes = 300.0 * 1024 * 1024;
+// k_traj_ring (wave-specialised store engine, in-order batch tickets) takes the open-loop launches that write more than this:
+// B = 262144 (2.2 GB): 386 us against k_traj_flat's 417 - 447 on the same boxes; B = 65536 +actions (550 MB): 112 - 115 against
+// 115 - 121; trajectory only at 65536 (367 MB): 83 against 80 - 82 -- below that the persistent one-workgroup-per-CU launch has
+// too few batches per CU to amortise its ramp (profiles/r04_ring.md)
+constexpr double kRingBytes = 600.0 * 1024 * 1024;
+// a ticket of k_traj_ring covers at least this many bytes of batch buffers: one device counter hands out ~88 tickets / us
+// (profiles/r04_store_engine_probe_dynamic.md), 32768 tickets of 67 KB saturate it, 10923 of 201 KB do not
+constexpr size_t kRingTicketBytes = 192 * 1024;
+
 // Kernels that may take more than the default 64 KB of dynamic LDS: the function attribute is raised ONCE per kernel
 // instantiation to the CU's whole LDS (160 KB), not per launch with the launch's size -- hipFuncSetAttribute rewrites state of a
 // function whose earlier launches may still be in flight (round 3: one silent runtime abort per ~30 000 launches of mixed
@@ -67,7 +93,7 @@ static hipError_t allow_full_lds_addr(const void* fn) {
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(mu);
     if (done.count({fn, dev})) return hipSuccess;
-    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
     if (e == hipSuccess) done.insert({fn, dev});
     return e;
 }
@@ -113,19 +139,6 @@ __device__ __forceinline__ float div_exact(float z, const ExactDiv& x) {
     return __builtin_fmaf(__builtin_fmaf(-x.d, q, z), x.r, q);
 }
 
-// Write-through (sc1) stores are chosen while a launch's outputs still fit the memory-side cache (256 MB + the L2s): plain
-// write-back stores fall off a cliff once the dirty lines exceed it, write-through stores lose once the outputs stream to
-// HBM anyway.  Measured per kernel family and size (profiles/r03_streaming_wt.md, us plain vs write-through): k_traj_flat
-// +actions 57.1 / 46.1 at 241 MB, 67.5 / 51.9 at 275 MB, 74.3 / 71.3 at 310 MB, 77.7 / 88.6 at 344 MB; cfg3 k_traj_quad<dmp>
-// 36.5 / 33.6 at 175 MB, 58.2 / 54.3 at 262 MB, 99 / 104 at 350 MB; closed loop k_traj_duo 80.8 / 70.1 at 262 MB, 173 / 221 at
-// 525 MB; per-episode kernels 44.2 / 41.2 at 175 MB, 107 / 117 at 350 MB.  (The tile-major kernels keep their own 96 MB rule:
-// above it the episode-major kernels take over.)
-constexpr double kWtBytes = 300.0 * 1024 * 1024;
-// k_traj_ring (wave-specialised store engine, in-order batch tickets) takes the open-loop launches that write more than this:
-// B = 262144 (2.2 GB): 386 us against k_traj_flat's 417 - 447 on the same boxes; B = 65536 +actions (550 MB): 112 - 115 against
-// 115 - 121; trajectory only at 65536 (367 MB): 83 against 80 - 82 -- below that the persistent one-workgroup-per-CU launch has
-// too few batches per CU to amortise its ramp (profiles/r04_ring.md)
-constexpr double kRingBytes = 600.0 * 1024 * 1024;
 
 // The integer part of BlackBoxWrapper.step's loop (black_box_wrapper.py:174,197,206) for one episode and one plan:
 // how many steps this plan executes before the loop breaks (end of the horizon, or the schedule t % every == 0 while

@@ -404,7 +404,7 @@ static int prealloc_cache(Handle* h) {
     if (!mfma_capable(h) && !wide_capable(h)) return MPK_OK;
     int TS = 0, n_out = 0;
     const size_t nf = shared_tables_floats(h->dev, &TS, &n_out);
-    // a wide table (hundreds of basis functions: ~10 MB per slot at K = 1000, T = 200) gets 8 slots instead of 64
+    // a wide table (hundreds of basis functions: 1.7 MB per slot at K = 1000, T = 200 -- shared_tables_lean) gets 8 slots instead of 64
     const int n_slots = h->dev.KP > kMaxKP ? 8 : Handle::kCache;
     int slot = 0;
     for (auto& e : h->cache) {
@@ -768,7 +768,7 @@ static int traj_common(Handle* h, const float* params, const float* init_pos, co
         if (rc != MPK_OK) return rc;
         init_pos = p1; init_vel = v1;
     }
-    if (shared_phase(h, init_time) && wide_capable(h) && !actions && !q_state && !rp) {
+    if (shared_phase(h, init_time) && wide_capable(h) && !actions && !q_state && !rp && traj_wide_fits(h->dev)) {
         SharedTables st;
         int rc = get_shared(h, (float)init_time_shared, stream, &st);
         if (rc != MPK_OK) return rc;

@@ -128,6 +128,8 @@ int launch_scaled_basis(const DevCfg& c, const float* times, int n, float* out, 
 int launch_div_sweep(float d, uint32_t first, uint64_t count, unsigned long long* mismatches, void* stream);
 
 size_t shared_tables_floats(const DevCfg& c, int* TS, int* n_out);
+bool shared_tables_lean(const DevCfg& c);     // k_traj_wide-only shapes: position (prodmp: + velocity) rows, no step-major copy
+bool traj_wide_fits(const DevCfg& c);         // false: launch_traj_wide would return MPK_ENOTIMPL (ask before building its table)
 
 
 void set_error(const std::string& msg);

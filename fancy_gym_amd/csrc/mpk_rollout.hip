@@ -392,7 +392,7 @@ int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
         PdArgs pa;
         pa.rc = rc; pa.des_pos = des_pos; pa.des_vel = des_vel; pa.Q = q; pa.QD = qd; pa.n_steps = n_steps;
         pa.actions = actions; pa.D = D; pa.B = B; pa.T = T;
-        pa.wt = (double)B * T * D * 12.0 <= 96.0 * 1024 * 1024 ? 1 : 0;     // desired (pos, vel) + actions stay cached
+        pa.wt = (double)B * T * D * 12.0 <= kCachedBytes ? 1 : 0;     // desired (pos, vel) + actions stay cached
         if (tune.write_through >= 0) pa.wt = tune.write_through != 0 ? 1 : 0;
         pa.step0 = step0; pa.goal = goal; pa.rewards = rewards; pa.steps_before_reward = steps_before_reward;
         int sh = 0;
@@ -414,7 +414,7 @@ int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
         if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;
         const size_t lds = (size_t)4 * ng * 5 * kStageStride * sizeof(float);
         auto go = [&](auto kern) -> int {
-            if (lds > 64 * 1024) {
+            if (lds > kLdsDefault) {
                 hipError_t e = allow_full_lds(kern);
                 if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return MPK_EHIP; }
             }
@@ -444,7 +444,7 @@ int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const f
         PdArgs pa;
         pa.rc = rc; pa.des_pos = des_pos; pa.des_vel = des_vel; pa.Q = q; pa.QD = qd; pa.n_steps = n_steps;
         pa.actions = actions; pa.D = D; pa.B = B; pa.T = T;
-        pa.wt = (double)B * T * D * 12.0 <= 96.0 * 1024 * 1024 ? 1 : 0;     // desired (pos, vel) + actions stay cached
+        pa.wt = (double)B * T * D * 12.0 <= kCachedBytes ? 1 : 0;     // desired (pos, vel) + actions stay cached
         if (tune.write_through >= 0) pa.wt = tune.write_through != 0 ? 1 : 0;
         pa.step0 = nullptr; pa.goal = nullptr; pa.rewards = nullptr; pa.steps_before_reward = 0;
         int sh = 0;

@@ -10,22 +10,29 @@
 
 namespace mpk {
 
+// a shape only k_traj_wide can take (more than kMaxKP columns, or more than kMaxD DoF): that kernel reads the position rows
+// (prodmp: + velocity rows) of the k-major table and nothing else, so such a handle's slots hold just those -- no
+// finite-difference operand rows, no step-major copy (a sixth of the full promp table: ~1.7 MB instead of 10 MB per slot at
+// K = 1000, T = 200)
+bool shared_tables_lean(const DevCfg& c) { return c.KP > kMaxKP || c.D > kMaxD; }
+
 size_t shared_tables_floats(const DevCfg& c, int* TS, int* n_out) {
     const int TP = (c.T + 15) / 16 * 16;
     const int ts = ((TP + 15) / 32) * 32 + 16;  // TS % 32 == 16: the two k rows of a 32-lane LDS read hit disjoint banks
-    const int no = c.mp_type == MPK_MP_PRODMP ? 2 : (c.mp_type == MPK_MP_PROMP ? 3 : 1);
+    const bool lean = shared_tables_lean(c);
+    const int no = c.mp_type == MPK_MP_PRODMP ? 2 : (c.mp_type == MPK_MP_PROMP && !lean ? 3 : 1);
     *TS = ts;
     *n_out = no;
     // the k-major table A [n_out][KP][TS] (MFMA fragment loads) followed by its step-major copy At [TS][n_out * KP]
     // (one contiguous row per time step: the serial role of k_traj_split reads it with scalar loads)
-    return 2 * (size_t)no * c.KP * ts;
+    return (lean ? 1 : 2) * (size_t)no * c.KP * ts;
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // k_build_shared: one block; A[(j*KP + k)*TS + t], aux[t]
 // ------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_build_shared(const DevCfg c, const float init_time, float* __restrict__ A,
-                                                      float* __restrict__ aux, const int TS, const int n_out,
+                                                      float* __restrict__ aux, const int TS, const int n_out, const int lean,
                                                       int32_t* __restrict__ idx_out, int32_t* __restrict__ flag) {
     const int tid = threadIdx.x, T = c.T, KP = c.KP;
     for (int i = tid; i < n_out * KP * TS; i += 256) A[i] = 0.0f;
@@ -63,7 +70,7 @@ __global__ void __launch_bounds__(256) k_build_shared(const DevCfg c, const floa
         // velocity = forward difference: rows (t+1, t), last row repeats (T-1, T-2)
         for (int t = tid; t < T; t += 256) {
             const int th = t < T - 1 ? t + 1 : T - 1, tl = t < T - 1 ? t : T - 2;
-            for (int k = 0; k < c.KT; ++k) {
+            for (int k = 0; k < c.KT && !lean; ++k) {
                 A[(size_t)(1 * KP + k) * TS + t] = A[(size_t)k * TS + th];
                 A[(size_t)(2 * KP + k) * TS + t] = A[(size_t)k * TS + tl];
             }
@@ -85,6 +92,7 @@ __global__ void __launch_bounds__(256) k_build_shared(const DevCfg c, const floa
     // step-major copy behind the k-major table: one contiguous row per step; with two outputs (prodmp) the row is
     // interleaved [pos_0 vel_0 pos_1 vel_1 ..] -- the operand pairs of the packed fp32 FMA the serial role contracts with
     __syncthreads();
+    if (lean) return;
     const int RS = n_out * KP;
     float* At = A + (size_t)RS * TS;
     for (int i = tid; i < RS * TS; i += 256) {
@@ -102,7 +110,7 @@ int launch_build_shared(const DevCfg& c, float init_time, const SharedTables& st
         return MPK_EINVAL;
     }
     hipLaunchKernelGGL(k_build_shared, dim3(1), dim3(256), 0, (hipStream_t)stream, c, init_time, st.A, st.aux, st.TS,
-                       st.n_out, idx_out, range_flag);
+                       st.n_out, shared_tables_lean(c) ? 1 : 0, idx_out, range_flag);
     MPK_LAUNCH_CHECK();
     return MPK_OK;
 }
@@ -185,16 +193,16 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     // (profiles/r02_closed_loop.md) full step 10.1 vs 11.9 us at B = 2048, 11.8 vs 14.1 at 4096, 22.1 vs 19.7 at 8192;
     // 25-of-100-step plan 8.1 vs 8.8, 9.5 vs 11.6, 17.2 vs 16.5 -- beyond that the launch is store-bound and the barrier
     // per row tile only makes the store stream burstier.
-    const bool pipe_fits = table_bytes + 2 * kPipeGroups * kQuadImg * sizeof(float) <= 64 * 1024;
+    const bool pipe_fits = table_bytes + 2 * kPipeGroups * kQuadImg * sizeof(float) <= kLdsDefault;
     const long pipe_units = ((long)ta.G + kPipeGroups - 1) / kPipeGroups;
     const bool pipe = closed && c.mp_type != MPK_MP_DMP && pipe_fits && tune.split != 1 &&
                       (tune.pipe == 1 || (tune.pipe != 0 && !variant_forced && pipe_units <= 3L * num_cu));
     const bool split = !pipe && closed && c.mp_type != MPK_MP_DMP && split_shape && tune.split == 1;
-    bool stream_mode = !split && (c.mp_type == MPK_MP_DMP || closed || out_bytes > 96.0 * 1024 * 1024);
+    bool stream_mode = !split && (c.mp_type == MPK_MP_DMP || closed || out_bytes > kCachedBytes);
     if (c.mp_type != MPK_MP_DMP && !closed && ov == 1) stream_mode = false;
     if (ov == 2 && !split) stream_mode = true;       // a forced k_traj_split stays tile-major (its tiles role needs that geometry)
     if ((tune.flat == 1 || tune.ring >= 1) && !closed && c.mp_type != MPK_MP_DMP && !split) stream_mode = true;   // forced k_traj_flat (where it applies)
-    if (stream_mode && table_bytes + 4 * kStageFloats * sizeof(float) > 64 * 1024) {
+    if (stream_mode && table_bytes + 4 * kStageFloats * sizeof(float) > kLdsDefault) {
         // the caller falls back: per-episode kernels for dmp, trajectory + rollout launches for the closed loop
         if (c.mp_type == MPK_MP_DMP || closed) { set_error("trajectory too long for the episode-major kernel's LDS budget"); return MPK_ENOTIMPL; }
         stream_mode = false;
@@ -219,7 +227,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     {
         // static staging (fp32 images) + the tables
         auto fits = [&](int nq) {
-            return table_bytes + (4 * nq * kQuadImg) * sizeof(float) <= 64 * 1024;
+            return table_bytes + (4 * nq * kQuadImg) * sizeof(float) <= kLdsDefault;
         };
         const bool serial_variant = stream_mode && (c.mp_type == MPK_MP_DMP || closed);
         const int quad_mode = tune.quad < 0 ? 1 : tune.quad;
@@ -264,12 +272,12 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         auto buf_of = [&](int m) { return (size_t)nst * m * gimg * sizeof(float); };
         // groups per batch: as asked ("ring_m"), else the most (<= 4) that leave two batch buffers in the CU's LDS; a batch
         // must be a whole number of float4 per array (its runs are written as aligned 16-byte chunks)
-        auto fits = [&](int m) { return fixed + 2 * buf_of(m) <= 160 * 1024 && ((long)m * gimg) % 4 == 0; };
+        auto fits = [&](int m) { return fixed + 2 * buf_of(m) <= kLdsPerCu && ((long)m * gimg) % 4 == 0; };
         int M = tune.ring_m > 0 ? tune.ring_m : 4;
         while (M > 1 && !fits(M)) --M;
         if (ptr_ok && want && !closed && c.mp_type != MPK_MP_DMP && !split && tune.ring != 2 && fits(M)) {
             const size_t buf_bytes = buf_of(M);
-            long nbuf = (long)((160 * 1024 - fixed) / buf_bytes);
+            long nbuf = (long)((kLdsPerCu - fixed) / buf_bytes);
             if (nbuf * M > 32) nbuf = 32 / M;                         // 32 slots of sync counters
             if (nbuf > 3) nbuf = 3;
             // waves per group: with few slots (long horizons: one group's image fills a buffer) the producers share a group's
@@ -283,7 +291,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
             // in-order dynamic batch assignment: tickets of TB batches from one counter word (~88 tickets / us at most: a
             // ticket must be worth well over 100 KB of output), zeroed in stream order in front of the launch
             ta.ring_ctr = ticket;
-            ta.ring_tb = (int)((192 * 1024 + buf_bytes - 1) / buf_bytes);
+            ta.ring_tb = (int)((kRingTicketBytes + buf_bytes - 1) / buf_bytes);
             if (ta.ring_tb < 1) ta.ring_tb = 1;
             if (ticket && hipMemsetAsync(ticket, 0, sizeof(unsigned), (hipStream_t)stream) != hipSuccess) {
                 set_error("hipMemsetAsync(ticket counter) failed");
@@ -324,13 +332,13 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         bulk = (EPC * c.P) % 4 == 0 && (EPC * c.D) % 4 == 0 && (EPC * c.P) / 4 <= 128 && (EPC * c.D) / 2 <= 64 &&
                aligned16(params) && aligned16(init_pos) && aligned16(init_vel) &&
                (!act || closed || (aligned16(c_pos) && aligned16(c_vel))) &&
-               lds_bulk + 4 * kStageFloats * sizeof(float) <= 64 * 1024;
+               lds_bulk + 4 * kStageFloats * sizeof(float) <= kLdsDefault;
         // mpk_set_option "bulk": 0 disables, 2 forces it below the size threshold too (tests); default: HBM-streaming sizes only
         const int bulk_mode = tune.bulk < 0 ? 1 : tune.bulk;
         // automatic: only when the outputs stream to HBM AND the 4x coarser work units still fill the chip; the
         // latency-bound DMP recurrence prefers occupancy over input staging
         const long chunks = (ta.G + kChunkGroups - 1) / kChunkGroups;
-        const bool auto_ok = out_bytes > 96.0 * 1024 * 1024 && chunks >= max_waves / 2 && c.mp_type != MPK_MP_DMP;
+        const bool auto_ok = out_bytes > kCachedBytes && chunks >= max_waves / 2 && c.mp_type != MPK_MP_DMP;
         bulk = bulk && bulk_mode != 0 && (bulk_mode == 2 || auto_ok);
         long units = ta.G;
         if (bulk) { lds = lds_bulk; units = (ta.G + kChunkGroups - 1) / kChunkGroups; }
@@ -340,21 +348,18 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         // streaming row, profiles/r03_streaming.md); mpk_set_option "flat": 0 off, 1 force
         const int flat_img = (NTW * TD + 3) / 4 * 4;
         const size_t lds_flat = table_bytes + (size_t)4 * nst * flat_img * sizeof(float);
-        const bool flat_ok = !closed && c.mp_type != MPK_MP_DMP && ptr_ok && TD % 4 == 0 && lds_flat <= 80 * 1024;
-        if (flat_ok && tune.flat != 0 && (tune.flat == 1 || (out_bytes > 96.0 * 1024 * 1024 && tune.bulk < 0))) {
+        const bool flat_ok = !closed && c.mp_type != MPK_MP_DMP && ptr_ok && TD % 4 == 0 && lds_flat <= kLdsHalf;
+        if (flat_ok && tune.flat != 0 && (tune.flat == 1 || (out_bytes > kCachedBytes && tune.bulk < 0))) {
             ta.flat_img = flat_img;
             bulk = false;
             // (write-through while the outputs fit the memory-side cache: kWtBytes)
             lds = lds_flat + (tune.lds_pad > 0 ? (size_t)tune.lds_pad * 1024 : 0);   // "lds_pad": occupancy experiments
-            const long wg = (long)(160 * 1024 / lds) < 3 ? (long)(160 * 1024 / lds) : 3;   // workgroups a CU's LDS holds
+            const long wg = (long)(kLdsPerCu / lds) < 3 ? (long)(kLdsPerCu / lds) : 3;   // workgroups a CU's LDS holds
             const long resident = (long)num_cu * (wg < 1 ? 1 : wg) * 4;   // 4-wave workgroups, persistent
             waves = ta.G < resident ? ta.G : resident;
         }
         blocks = (int)((waves + 3) / 4);
         if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;                  // XCD-contiguous remap needs a multiple of 8
-        // wave-specialised store engine (k_traj_ring): same shapes as k_traj_flat, ONE persistent workgroup per CU whose LDS
-        // holds the tables + a ring of NBUF batch buffers of M whole-trajectory group images.  mpk_set_option "ring": 0 off,
-        // 1 force; "ring_np" / "ring_ns" / "ring_m": producer waves, store-engine waves, groups per batch
         const int img = flat_img;                                        // floats per (array, group) image
         if (flat_ok && tune.ring == 2) {
             // short-lived workgroups (k_traj_burst): one batch of M groups per workgroup, WPG waves per group
@@ -363,7 +368,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
             if (M > 8) M = 8;
             if (M * WPG > 8) WPG = 8 / M < 1 ? 1 : 8 / M;
             const size_t bytes = (size_t)nst * M * img * sizeof(float);
-            if (table_bytes + bytes <= 160 * 1024) {
+            if (table_bytes + bytes <= kLdsPerCu) {
                 ta.flat_img = img;
                 ta.burst = 1; ta.ring_m = M; ta.ring_np = WPG; ta.ring_ns = 0; ta.ring_nbuf = 0;
                 bulk = false;
@@ -407,10 +412,9 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         blocks += (int)sb;
     }
     if (ring || ta.burst) {
-        const char* mpn = c.mp_type == MPK_MP_PRODMP ? "prodmp" : (c.mp_type == MPK_MP_PROMP ? "promp" : "dmp");
-        static thread_local char name[64];
-        snprintf(name, sizeof(name), "%s<%s%s>", ta.burst ? "k_traj_burst" : "k_traj_ring", mpn, closed ? ",closed" : (act ? ",act" : ""));
-        *kernel_name = name;
+        const bool pd = c.mp_type == MPK_MP_PRODMP;
+        *kernel_name = ta.burst ? (pd ? (act ? "k_traj_burst<prodmp,act>" : "k_traj_burst<prodmp>") : (act ? "k_traj_burst<promp,act>" : "k_traj_burst<promp>"))
+                                : (pd ? (act ? "k_traj_ring<prodmp,act>" : "k_traj_ring<prodmp>") : (act ? "k_traj_ring<promp,act>" : "k_traj_ring<promp>"));
         switch (c.mp_type) {
             case MPK_MP_PRODMP: return launch_traj_ring<MPK_MP_PRODMP>(ta, aa, ct, blocks, lds, stream);
             case MPK_MP_PROMP: return launch_traj_ring<MPK_MP_PROMP>(ta, aa, ct, blocks, lds, stream);
@@ -419,11 +423,11 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     }
     switch (c.mp_type) {
         case MPK_MP_PRODMP:
-            *kernel_name = pipe ? "k_traj_pipe<prodmp,closed>" : split ? "k_traj_split<prodmp,closed>" : closed ? (quad == 4 ? "k_traj_quad<prodmp,closed>" : quad == 2 ? "k_traj_duo<prodmp,closed>" : quad == 1 ? "k_traj_mono<prodmp,closed>" : "k_traj_stream<prodmp,closed>") : ta.burst ? (act ? "k_traj_burst<prodmp,act>" : "k_traj_burst<prodmp>") : ta.ring_np ? (act ? "k_traj_ring<prodmp,act>" : "k_traj_ring<prodmp>") : ta.flat_img ? (act ? "k_traj_flat<prodmp,act>" : "k_traj_flat<prodmp>") : stream_mode ? (act ? "k_traj_stream<prodmp,act>" : "k_traj_stream<prodmp>")
+            *kernel_name = pipe ? "k_traj_pipe<prodmp,closed>" : split ? "k_traj_split<prodmp,closed>" : closed ? (quad == 4 ? "k_traj_quad<prodmp,closed>" : quad == 2 ? "k_traj_duo<prodmp,closed>" : quad == 1 ? "k_traj_mono<prodmp,closed>" : "k_traj_stream<prodmp,closed>") : ta.flat_img ? (act ? "k_traj_flat<prodmp,act>" : "k_traj_flat<prodmp>") : stream_mode ? (act ? "k_traj_stream<prodmp,act>" : "k_traj_stream<prodmp>")
                                        : (act ? "k_traj_tiles<prodmp,act>" : "k_traj_tiles<prodmp>");
             return launch_traj_ct<MPK_MP_PRODMP>(ta, aa, ct, stream_mode, write_through, bulk, quad, blocks, lds, stream, split, pipe);
         case MPK_MP_PROMP:
-            *kernel_name = pipe ? "k_traj_pipe<promp,closed>" : split ? "k_traj_split<promp,closed>" : closed ? (quad == 4 ? "k_traj_quad<promp,closed>" : quad == 2 ? "k_traj_duo<promp,closed>" : quad == 1 ? "k_traj_mono<promp,closed>" : "k_traj_stream<promp,closed>") : ta.burst ? (act ? "k_traj_burst<promp,act>" : "k_traj_burst<promp>") : ta.ring_np ? (act ? "k_traj_ring<promp,act>" : "k_traj_ring<promp>") : ta.flat_img ? (act ? "k_traj_flat<promp,act>" : "k_traj_flat<promp>") : stream_mode ? (act ? "k_traj_stream<promp,act>" : "k_traj_stream<promp>")
+            *kernel_name = pipe ? "k_traj_pipe<promp,closed>" : split ? "k_traj_split<promp,closed>" : closed ? (quad == 4 ? "k_traj_quad<promp,closed>" : quad == 2 ? "k_traj_duo<promp,closed>" : quad == 1 ? "k_traj_mono<promp,closed>" : "k_traj_stream<promp,closed>") : ta.flat_img ? (act ? "k_traj_flat<promp,act>" : "k_traj_flat<promp>") : stream_mode ? (act ? "k_traj_stream<promp,act>" : "k_traj_stream<promp>")
                                        : (act ? "k_traj_tiles<promp,act>" : "k_traj_tiles<promp>");
             return launch_traj_ct<MPK_MP_PROMP>(ta, aa, ct, stream_mode, write_through, bulk, quad, blocks, lds, stream, split, pipe);
         default:

@@ -872,10 +872,10 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
             auto resident = [&](int e, bool fl) -> long {           // waves of the whole chip for this layout (as below)
                 const int img_in = e * (c.P + 2 * c.D + 1), img_cols = e * (pa.x_pad + (fl ? 12 : 3));
                 const size_t wb = (size_t)(2 * (((img_in > img_cols ? img_in : img_cols) + 3) / 4 * 4) + 2 * pa.o_pad) * sizeof(float);
-                const bool tab = tune.phase_table != 0 && tab_bytes + 8 * wb <= 160 * 1024 - shared0 && (long)pa.B >= (long)num_cu * 8;
-                int w = tab ? (int)((160 * 1024 - shared0 - tab_bytes) / wb) : (int)((64 * 1024 - shared0) / wb);
+                const bool tab = tune.phase_table != 0 && tab_bytes + 8 * wb <= kLdsPerCu - shared0 && (long)pa.B >= (long)num_cu * 8;
+                int w = tab ? (int)((kLdsPerCu - shared0 - tab_bytes) / wb) : (int)((kLdsDefault - shared0) / wb);
                 w = tab ? (w > 16 ? 16 : w) : (w > 4 ? 4 : (w < 1 ? 1 : w));
-                int pc = (int)(160 * 1024 / (wb * w + shared0 + (tab ? tab_bytes : 0)));
+                int pc = (int)(kLdsPerCu / (wb * w + shared0 + (tab ? tab_bytes : 0)));
                 pc = pc > 32 / w ? 32 / w : (pc < 1 ? 1 : pc);
                 return (long)num_cu * pc * w;
             };
@@ -913,25 +913,25 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
     pa.c_pad = c.mp_type == MPK_MP_PRODMP ? (c.nb + 2 + 3) / 4 * 4 : (4 * c.n_total + 6 + 3) / 4 * 4;
     const size_t wave_bytes = (size_t)pa.wave_floats * sizeof(float);
     size_t shared_bytes = (size_t)(pa.t_pad + pa.c_pad) * sizeof(float);
-    if (wave_bytes + shared_bytes > 160 * 1024) return MPK_ENOTIMPL;
-    int wpb = (int)((64 * 1024 - shared_bytes) / wave_bytes);
+    if (wave_bytes + shared_bytes > kLdsPerCu) return MPK_ENOTIMPL;
+    int wpb = (int)((kLdsDefault - shared_bytes) / wave_bytes);
     wpb = wpb > 4 ? 4 : (wpb < 1 ? 1 : wpb);
     // prodmp: stage the row table in LDS when it leaves room for at least 8 waves ("phase_table" 0: gather from L2)
     bool lds_table = false;
     if (c.mp_type == MPK_MP_PRODMP) {
         const size_t tab_bytes = (size_t)c.n_pc * (2 * KS + 4) * sizeof(float);
-        const size_t room = 160 * 1024 - shared_bytes;
+        const size_t room = kLdsPerCu - shared_bytes;
         lds_table = tab_bytes + 8 * wave_bytes <= room && (long)pa.B >= (long)num_cu * 8;
         if (tune.phase_table == 0) lds_table = false;
         if (lds_table) {
             pa.tab_pad = c.n_pc * (2 * KS + 4);
             shared_bytes += tab_bytes;
-            wpb = (int)((160 * 1024 - shared_bytes) / wave_bytes);
+            wpb = (int)((kLdsPerCu - shared_bytes) / wave_bytes);
             wpb = wpb > 16 ? 16 : wpb;
         }
     }
     const size_t lds = wave_bytes * wpb + shared_bytes;
-    int per_cu = (int)(160 * 1024 / lds);
+    int per_cu = (int)(kLdsPerCu / lds);
     per_cu = per_cu > 32 / wpb ? 32 / wpb : per_cu;
     if (!dmp && !modelled) {
         // chunks cost balance (a wave's work is quantised in E episodes): only when every resident wave still gets >= 4
@@ -945,7 +945,7 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
     long blocks = (units + wpb - 1) / wpb;
     if (blocks > (long)num_cu * per_cu) blocks = (long)num_cu * per_cu;
     auto go = [&](auto kern) -> int {
-        if (lds > 64 * 1024) {
+        if (lds > kLdsDefault) {
             hipError_t e = allow_full_lds(kern);
             if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return MPK_EHIP; }
         }
@@ -1071,11 +1071,11 @@ int launch_traj_rows(const DevCfg& c, const float* params, const float* init_pos
     const size_t floats = (size_t)c.D * c.KT + (size_t)nrow * c.T * c.KT + (size_t)c.T * c.D +
                           (c.mp_type == MPK_MP_DMP ? (size_t)c.T * c.D : 0) + c.T + 8;
     const size_t lds = floats * sizeof(float);
-    if (lds > 160 * 1024) { set_error("trajectory too large for the per-episode kernel's LDS budget"); return MPK_EINVAL; }
+    if (lds > kLdsPerCu) { set_error("trajectory too large for the per-episode kernel's LDS budget"); return MPK_EINVAL; }
     RowArgs ra{c, params, init_pos, init_vel, init_time, init_time_shared, pos, vel, range_flag, B};
     int blocks = B < num_cu * 8 ? B : num_cu * 8;
     auto go = [&](auto kern) -> int {
-        if (lds > 64 * 1024) {
+        if (lds > kLdsDefault) {
             hipError_t e = allow_full_lds(kern);
             if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return MPK_EHIP; }
         }

@@ -368,6 +368,9 @@ __global__ void __launch_bounds__(256, ((MP == MPK_MP_PRODMP ? 2 : 1) * MT <= 16
 }
 
 #ifndef MPK_DEVICE_ONLY
+// promp / dmp keep the whole horizon in one row-tile block of at most 32 tiles
+bool traj_wide_fits(const DevCfg& c) { return c.mp_type == MPK_MP_PRODMP || (c.T + 15) / 16 <= 32; }
+
 int launch_traj_wide(const DevCfg& c, const SharedTables& st, const float* params, const float* init_pos,
                      const float* init_vel, float* pos, float* vel, int B, int num_cu, void* stream,
                      const char** kernel_name) {
@@ -379,7 +382,7 @@ int launch_traj_wide(const DevCfg& c, const SharedTables& st, const float* param
     const int nout = c.mp_type == MPK_MP_PRODMP ? 2 : 1;
     const int nimg = c.mp_type == MPK_MP_PROMP ? 1 : 2;
     const int mt_max = c.mp_type == MPK_MP_PRODMP ? 16 : 32;
-    if (c.mp_type != MPK_MP_PRODMP && n_rt > mt_max) return MPK_ENOTIMPL;   // whole horizon in one row-tile block
+    if (!traj_wide_fits(c)) return MPK_ENOTIMPL;                           // whole horizon in one row-tile block
     // row tiles per block: the smallest instantiated count >= n_rt (the contraction loop runs all MT tiles unconditionally)
     static const int kMT[] = {4, 7, 8, 12, 13, 16, 24, 32};
     int MT = mt_max;
@@ -390,7 +393,7 @@ int launch_traj_wide(const DevCfg& c, const SharedTables& st, const float* param
     const int spans = (rows_max / 4 + 63) / 64;                            // 64-lane float4 spans per table row
     int KC = 32;                                                           // <= 8 B fragments per lane and chunk
     auto stage_bytes = [&](int kc) { return ((size_t)nout * kc * SA) * sizeof(float); };
-    while (KC > 8 && (stage_bytes(KC) > 80 * 1024 || nout * KC / 4 * spans > 8)) KC >>= 1;
+    while (KC > 8 && (stage_bytes(KC) > kLdsHalf || nout * KC / 4 * spans > 8)) KC >>= 1;
     while (KC > 4 && KC / 2 >= c.KP) KC >>= 1;                             // few columns (the D > 16 route): one short chunk
     const size_t epi_bytes = (size_t)4 * nimg * MT * 16 * 17 * sizeof(float);
     const size_t lds_main = stage_bytes(KC) > epi_bytes ? stage_bytes(KC) : epi_bytes;
@@ -404,7 +407,7 @@ int launch_traj_wide(const DevCfg& c, const SharedTables& st, const float* param
     const int per_cu = nout * MT <= 16 ? 2 : 1;                           // see the kernel's launch bounds
     const int blocks = wa.n_units < num_cu * per_cu ? wa.n_units : num_cu * per_cu;
     auto go = [&](auto kern) -> int {
-        if (lds > 64 * 1024) {
+        if (lds > kLdsDefault) {
             hipError_t e = allow_full_lds(kern);
             if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return MPK_EHIP; }
         }

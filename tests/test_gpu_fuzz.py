@@ -222,6 +222,7 @@ def test_random_wide_or_flat_configuration_matches_oracle(seed, mpk_option):
 
 # ---- round 4: k_traj_ring (producer waves + store engine, batch tickets) under random shapes and launch geometries ------------------
 N_CASES_R4 = int(os.environ.get("MPK_FUZZ_CASES_R4", "60"))
+_RING_SEEN = {"cases": 0, "ring": 0, "burst": 0}
 START_R4 = int(os.environ.get("MPK_FUZZ_START_R4", "0"))
 
 
@@ -269,6 +270,10 @@ def test_random_configuration_through_the_ring_kernel_is_bit_identical(seed, mpk
     eng.trajectory(params, ip, iv, init_time, out=out)
     torch.cuda.synchronize()
     k1 = eng.last_kernel()
+    _RING_SEEN["cases"] += 1
+    _RING_SEEN["ring"] += k1.startswith("k_traj_ring")
+    _RING_SEEN["burst"] += k1.startswith("k_traj_burst")
+    assert not k0.startswith(("k_traj_ring", "k_traj_burst")), k0
     assert torch.equal(out[0].view(torch.int32), p0.view(torch.int32)) and torch.equal(out[1].view(torch.int32), v0.view(torch.int32)), (k0, k1, ring, opts)
     if D <= 16 and bc.num_basis + 3 <= 16:
         from fancy_gym_amd import RolloutSpec
@@ -282,6 +287,14 @@ def test_random_configuration_through_the_ring_kernel_is_bit_identical(seed, mpk
         torch.cuda.synchronize()
         for x, y in zip(a0, a1):
             assert torch.equal(x.view(torch.int32), y.view(torch.int32)), (eng.last_kernel(), opts, ctrl)
+
+
+def test_the_ring_fuzz_reached_the_ring_kernel():
+    """most random shapes fit the ring's LDS images: the comparison above is not one of a kernel with itself"""
+    if _RING_SEEN["cases"] < 20:
+        pytest.skip("the ring fuzz did not run in this process")
+    assert _RING_SEEN["ring"] >= 0.4 * _RING_SEEN["cases"], _RING_SEEN
+    assert _RING_SEEN["burst"] >= 0.05 * _RING_SEEN["cases"], _RING_SEEN
 
 
 # ---- round 3, part two: the entry points the two tests above do not reach -- fused open-loop actions (every controller),

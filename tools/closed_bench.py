@@ -23,7 +23,7 @@ CFG2 = dict(mp_type="prodmp", phase_type="exp", basis_type="prodmp", num_dof=7, 
 CFG4 = dict(CFG2, basis_bandwidth_factor=3.0, weights_scale=0.3, goal_scale=0.3, auto_scale_basis=True, disable_goal=True)
 
 
-def graph_time(fn, reps=20, rounds=7):
+def capture(fn, reps=20):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -36,22 +36,31 @@ def graph_time(fn, reps=20, rounds=7):
                 fn()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    # replay untimed until the GPU has been busy for ~40 ms: the shader clock needs ~20 ms of load to settle
-    # (profiles/r02_clock_probe.md); five replays of a 0.3 ms graph -- round 2's warm-up -- measured the first variant of every
-    # (batch, step) pair 5 - 10 % slow ("auto" 20.6 vs forced `k_traj_duo` 18.5 us at B = 8192: the same kernel)
-    import time
-    t_busy = time.perf_counter()
-    while time.perf_counter() - t_busy < 0.04:
-        for _ in range(5):
-            g.replay()
-        torch.cuda.synchronize()
-    ts = []
-    for _ in range(rounds):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); g.replay(); b.record()
-        torch.cuda.synchronize()
-        ts.append(a.elapsed_time(b) * 1e-3 / reps)
-    return float(np.median(ts))
+    return g
+
+
+def replay_ms(g):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); g.replay(); b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b)
+
+
+def time_rows(graphs, reps=20, rounds=9, busy_ms=60.0):
+    """Every row of a (batch, step) pair is warmed by the time the GPU was BUSY with it (event time, not wall time: the shader
+    clock needs ~20 ms of load to settle, profiles/r02_clock_probe.md), and the timed rounds alternate over the rows, so that no
+    row owns the first or the last slot (round 3 measured "auto" 32.6 us first and 29.8 us last at plan / 16 384)."""
+    for g in graphs:
+        busy = 0.0
+        while busy < busy_ms:
+            busy += replay_ms(g)
+    ts = [[] for _ in graphs]
+    for r in range(rounds):
+        order = range(len(graphs)) if r % 2 == 0 else reversed(range(len(graphs)))
+        for i in order:
+            replay_ms(graphs[i])                        # one untimed replay: the row before left other lines in the caches
+            ts[i].append(replay_ms(graphs[i]) * 1e-3 / reps)
+    return [float(np.median(t)) for t in ts]
 
 
 def main():
@@ -82,19 +91,18 @@ def main():
                 # like each of cfg4's four plans, without memsets of the integer state inside the timed graph
                 def fn():
                     eng.replan_step(params, ip, iv, spec, q, qd, ts, ps, dn, 25, 2 ** 30, 2 ** 30, condition=True, out=out)
+            rows = []
             for vn, opts in variants:
                 _lib.reset_options()
                 for k, v in opts.items():
                     _lib.set_option(k, v)
                 try:
-                    t = graph_time(fn)
+                    rows.append((vn, capture(fn), eng.last_kernel()))     # the options are read at launch = at capture
                 except Exception as e:  # noqa: BLE001
                     print(f"| {name} | {B} | {vn} | failed: {e} |")
-                    continue
-                if name == "plan":
-                    # the three tiny memsets of the integer state ride in the graph: subtract nothing, report as is
-                    pass
-                print(f"| {name} | {B} | {vn} | `{eng.last_kernel()}` | {t * 1e6:.2f} | {B / t:.3e} | "
+            times = time_rows([r[1] for r in rows])
+            for (vn, _, kern), t in zip(rows, times):
+                print(f"| {name} | {B} | {vn} | `{kern}` | {t * 1e6:.2f} | {B / t:.3e} | "
                       f"{B * nbytes / t / 1e9:.0f} | {B * nbytes / t / 8e12 * 100:.1f} % |")
             _lib.reset_options()
             del eng, out

@@ -59,6 +59,7 @@ struct TrajArgs {
     int ring_tb;           // batches per ticket
     int ring_parts;        // waves that share one group's row tiles (long horizons: the image of ONE group fills a batch buffer)
     int burst;             // k_traj_burst: short-lived workgroups, one batch of ring_m groups each, ring_np waves per group
+    int inorder;           // k_traj_quad: 1 = one unit per wave, workgroup b takes units 4 b .. 4 b + 3 (short-lived workgroups in address order)
     int wpb;               // tile-major kernel: waves per workgroup (4; "tiles_wpb" 1 / 2 for A/B runs)
     int ring_dbg;          // ablations (mpk_set_option "ring_dbg"): 1 producers publish without contracting, 2 the engine skips its stores
     unsigned ser_blocks;   // k_traj_split: workgroups [0, ser_blocks) run the serial role
@@ -242,7 +243,12 @@ __device__ __forceinline__ Gains kernarg_gains(int d) {
 // MASKED = false is the version for a tile every step of which is executed by every lane of the wave (the caller tests
 // that wave-uniformly).  sP / sV / sA: the lane's (row 0, column) slots of the desired pos / vel / action images,
 // `stride` floats per row.
-template <int CTRL, bool MASKED, bool INTEGRATE = true, bool KEEP64 = false>
+// Round 4 (tools/probes/fp64_rate_probe.hip, asm of the consumer wave): a wave issues an independent instruction every 4 cycles
+// and a dependent one every 5.9, so the bare step (9 dependent of 11 float64 operations) is 54 cycles and every OTHER instruction
+// of the same wave adds 2 - 4; left alone the compiler sinks each step's LDS read next to its use (`s_waitcnt lgkmcnt(1)` in front
+// of every step: ~40 cycles of LDS latency exposed per step).  PRE = 1: all 32 reads issued, ONE wait, all conversions, then the
+// chain with nothing but its own operations, the action conversion and the LDS write in between.
+template <int CTRL, bool MASKED, bool INTEGRATE = true, bool KEEP64 = false, int PRE = 0>
 __device__ __forceinline__ void pd_tile_steps(const float* __restrict__ sP, const float* __restrict__ sV,
                                               float* __restrict__ sA, const int stride, const int t0, const int nst,
                                               const double pgd, const double dgd, const double lod, const double hid,
@@ -253,9 +259,18 @@ __device__ __forceinline__ void pd_tile_steps(const float* __restrict__ sP, cons
     float pr[16], vr[16];
 #pragma unroll
     for (int tl = 0; tl < 16; ++tl) { pr[tl] = sP[tl * stride]; vr[tl] = sV[tl * stride]; }
+    double dpr[16], dvr[16];
+    if (PRE) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int tl = 0; tl < 16; ++tl) {
+            if (CTRL != MPK_CTRL_VELOCITY) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(dpr[tl]) : "v"(pr[tl]));
+            if (CTRL != MPK_CTRL_POSITION) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(dvr[tl]) : "v"(vr[tl]));
+        }
+    }
 #pragma unroll
     for (int tl = 0; tl < 16; ++tl) {
-        const double dp = (double)pr[tl], dv = (double)vr[tl];
+        const double dp = PRE ? dpr[tl] : (double)pr[tl], dv = PRE ? dvr[tl] : (double)vr[tl];
         double u;
         if (CTRL == MPK_CTRL_MOTOR) u = pgd * (dp - qs) + dgd * (dv - qds);
         else if (CTRL == MPK_CTRL_POSITION) u = dp;

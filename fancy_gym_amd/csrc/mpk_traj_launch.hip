@@ -142,7 +142,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
                        const Tuning& tune, const ReplanDev* rp, unsigned* ticket) {
     TrajArgs ta;
     ta.nrt_magic = 0; ta.gstride = 0; ta.wt = 0; ta.flat_img = 0;
-    ta.ring_np = 0; ta.ring_ns = 0; ta.ring_m = 0; ta.ring_nbuf = 0; ta.ring_dbg = tune.ring_dbg > 0 ? tune.ring_dbg : 0; ta.burst = 0; ta.wpb = 4; ta.ring_ctr = nullptr; ta.ring_tb = 0; ta.ring_parts = 1;
+    ta.ring_np = 0; ta.ring_ns = 0; ta.ring_m = 0; ta.ring_nbuf = 0; ta.ring_dbg = tune.ring_dbg > 0 ? tune.ring_dbg : 0; ta.burst = 0; ta.inorder = 0; ta.wpb = 4; ta.ring_ctr = nullptr; ta.ring_tb = 0; ta.ring_parts = 1;
     if (rp) ta.rp = *rp;
     const bool closed = q_state != nullptr;
     ta.q_state = q_state; ta.qd_state = qd_state; ta.n_steps = n_steps; ta.plant_dt = rc ? rc->dt : 0.0;
@@ -232,20 +232,20 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         const bool serial_variant = stream_mode && (c.mp_type == MPK_MP_DMP || closed);
         const int quad_mode = tune.quad < 0 ? 1 : tune.quad;
         const long units4 = (ta.G + 3) / 4, units2 = (ta.G + 1) / 2;
-        // automatic (A/B-measured, profiles/r01_replan_end_to_end.md):
-        //   four per wave  while that gives two waves per SIMD but not yet more units than resident waves
-        //                  (cfg3 DMP at B = 16384: 35 us vs 44 with two);
+        // automatic (A/B-measured: profiles/r01_replan_end_to_end.md, profiles/r04_closed_loop.md):
+        //   four per wave  while that gives two waves per SIMD AND the outputs still fit the memory-side cache (kWtBytes):
+        //                  cfg3 DMP at B = 16384 33.8 us vs 38.7 with two; closed loop at 16384 30.8 vs 34.7, at 32768 56.7 vs
+        //                  69.1 (round 4: 256 registers = two waves per SIMD; 271 = one before, and two groups won everywhere);
         //   two per wave   below that (one wave per SIMD exposes every LDS / MFMA latency: closed loop at B = 8192
-        //                  22 -> 17 us) AND above it: at HBM-streaming sizes a four-group wave keeps 16 output streams
-        //                  open, two groups write like the episode-major kernel (DMP at B = 262144 792 -> 590 us,
-        //                  closed loop at B = 65536 189 -> 166 us);
+        //                  20.4 -> 19.2 us) AND above it: at HBM-streaming sizes the launch is bound by its store pattern
+        //                  (stores alone 153 of 166 us), and a four-group wave keeps 12 - 16 output streams open (DMP at
+        //                  B = 32768 82.4 vs 78.5 us, at 262144 608 vs 595; closed loop at B = 65536 182 vs 166 us);
         //   one per wave   for the closed loop at a few thousand episodes (cfg4 episodes at B = 2048: 0.061 -> 0.052 ms)
         if (serial_variant && quad_mode != 0) {
             if (quad_mode == 2) quad = fits(4) ? 4 : 0;
             else if (quad_mode == 3) quad = fits(2) ? 2 : 0;
             else if (quad_mode == 4) quad = fits(1) ? 1 : 0;
-            else if (!closed && fits(4) && units4 >= (long)num_cu * 8 && units4 < max_waves) quad = 4;   // DMP only:
-            // the closed loop measured equal or better with two groups at every size (B = 16384: 0.19 vs 0.21 ms / episode)
+            else if (fits(4) && units4 >= (long)num_cu * 8 && out_bytes <= kWtBytes) quad = 4;
             else if (fits(2) && units2 >= (long)num_cu * 4) quad = 2;
             else if (closed && fits(1)) quad = 1;
         }
@@ -323,6 +323,11 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         const long waves = units < max_waves ? units : max_waves;
         blocks = (int)((waves + 3) / 4);
         if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;
+        // "serial_order" 1: short-lived workgroups in address order (one unit per wave); 2: persistent without the XCD remap
+        if (tune.serial_order >= 1) {
+            ta.inorder = 1;
+            if (tune.serial_order == 1) blocks = (int)((units + 3) / 4);
+        }
     } else if (stream_mode) {
         lds = table_bytes;
         // bulk input staging: chunk blocks must be float4-sized / aligned and fit the per-lane register image

@@ -17,6 +17,11 @@ namespace mpk {
 // One workgroup barrier per row tile hands the images over.  The integer replanning state, the boundary-condition gather
 // and the plant state are the consumer's, exactly as in k_traj_quad.
 constexpr int kPipeGroups = 4;
+#ifndef MPK_PIPE_PRE
+#define MPK_PIPE_PRE 0       // 1: the consumer pulls and converts a whole tile before its chain (pd_tile_steps): 14 instead of 17
+                             // instructions per step, no LDS wait inside the tile -- and the same 2 050 cycles per tile (a lone
+                             // wave issues one instruction per 6 cycles, a dependent one per 8.9: profiles/r04_closed_loop.md)
+#endif
 
 template <int MP, int CT, int KM>
 __global__ void __launch_bounds__(320) k_traj_pipe(const TrajArgs a, const ActArgs act) {
@@ -61,6 +66,7 @@ __global__ void __launch_bounds__(320) k_traj_pipe(const TrajArgs a, const ActAr
     }
     if (wave == 0) {
         __syncthreads();                                                    // (the table copy: the producers' barrier)
+        MPK_STAMP(2);
         // ---------------- consumer: four recurrences, one per lane quarter ----------------
         const Gains gq = kernarg_gains(L.dvalid ? L.d : 0);
         const double pgd = gq.pg, dgd = gq.dg, lod = __builtin_canonicalize(gq.lo), hid = __builtin_canonicalize(gq.hi);
@@ -79,9 +85,11 @@ __global__ void __launch_bounds__(320) k_traj_pipe(const TrajArgs a, const ActAr
             const int tcond = (serial && a.rp.cond_pos) ? min(max(nst - 1, 0), T - 1) : -1;
             const int oq = L.bl * a.pitch + L.d + (int)ep_shift(a, bq);      // (row 0, this column) in group q's image
             __syncthreads();                                                // tile 0 is in image 0
+            MPK_STAMP(3);
             for (int rt = 0; rt < NRT; ++rt) {
                 float* sQ = smem + ((rt & 1) * kPipeGroups + L.q) * kQuadImg;
                 const bool full_tile = tile_fully_executed(serial, nst, rt * 16);
+                MPK_STAMP(10 + rt);
                 if (serial && rt * 16 < max(nst, tcond + 1)) {
                     if (tcond >= rt * 16 && tcond < rt * 16 + 16) {   // condition_on_desired: the desired state at the
                         const size_t si = (size_t)bq * D + L.d;          // last executed step
@@ -89,14 +97,16 @@ __global__ void __launch_bounds__(320) k_traj_pipe(const TrajArgs a, const ActAr
                         a.rp.cond_vel[si] = sQ[kStageStride + oq + (tcond - rt * 16) * D];
                     }
                     if (full_tile)
-                        pd_tile_steps<CT - 3, false>(sQ + oq, sQ + kStageStride + oq, sQ + 2 * kStageStride + oq, D, rt * 16, nst,
+                        pd_tile_steps<CT - 3, false, true, false, MPK_PIPE_PRE>(sQ + oq, sQ + kStageStride + oq, sQ + 2 * kStageStride + oq, D, rt * 16, nst,
                                                      pgd, dgd, lod, hid, a.plant_dt, qs, qds);
                     else
-                        pd_tile_steps<CT - 3, true>(sQ + oq, sQ + kStageStride + oq, sQ + 2 * kStageStride + oq, D, rt * 16, nst,
+                        pd_tile_steps<CT - 3, true, true, false, MPK_PIPE_PRE>(sQ + oq, sQ + kStageStride + oq, sQ + 2 * kStageStride + oq, D, rt * 16, nst,
                                                     pgd, dgd, lod, hid, a.plant_dt, qs, qds);
                 }
+                MPK_STAMP(30 + rt);
                 __syncthreads();                                            // tile rt's actions are final; tile rt + 1 is in
             }
+            MPK_STAMP(60);
             if (serial) {
                 const size_t si = (size_t)bq * D + L.d;
                 a.q_state[si] = qs; a.qd_state[si] = qds;
@@ -160,8 +170,11 @@ __global__ void __launch_bounds__(320) k_traj_pipe(const TrajArgs a, const ActAr
                     __builtin_amdgcn_wave_barrier();
                     store_arrays(std::integral_constant<int, 3>(), rt + 1);
                 }
+                MPK_STAMP_AT(110 + rt, 64);
                 __syncthreads();                                            // tile rt's actions are final
+                MPK_STAMP_AT(130 + rt, 64);
                 if (have) store_arrays(std::integral_constant<int, 4>(), rt);
+                MPK_STAMP_AT(150 + rt, 64);
             }
         }
     }

@@ -16,8 +16,22 @@ constexpr int kQuad = 4;
 // (measured before the skew: 43 % of the kernel's LDS cycles were bank conflicts)
 constexpr int kQuadImg = 3 * kStageStride + 8;
 
+// waves per SIMD the register allocation aims at, per groups-per-wave variant (A/B builds: -DMPK_QUAD_WPE4=.. etc.)
+#ifndef MPK_QUAD_WPE4
+#define MPK_QUAD_WPE4 2      // four groups: 271 registers unconstrained = ONE wave per SIMD; 256 without a spill = two (closed loop at 16 384: 37.9 -> 31.0 us)
+#endif
+#ifndef MPK_QUAD_WPE2
+#define MPK_QUAD_WPE2 1      // (3 together with MPK_QUAD_LAUNDER_ALL: 160 registers, measured and not kept -- see the stores below)
+#endif
+#ifndef MPK_QUAD_WPE1
+#define MPK_QUAD_WPE1 1
+#endif
+#ifndef MPK_QUAD_LAUNDER_ALL
+#define MPK_QUAD_LAUNDER_ALL 0
+#endif
+
 template <int MP, int CT, int KM, int NQ>
-__global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActArgs act) {
+__global__ void __launch_bounds__(256, (NQ == 4 ? MPK_QUAD_WPE4 : NQ == 2 ? MPK_QUAD_WPE2 : MPK_QUAD_WPE1)) k_traj_quad(const TrajArgs a, const ActArgs act) {
     static_assert(NQ == 1 || NQ == 2 || NQ == 4, "one, two or four groups per wave");
     __shared__ __attribute__((aligned(16))) float smem[4 * NQ * kQuadImg];   // per wave: 4 x (pos|vel|act or force)
     extern __shared__ __attribute__((aligned(16))) float sTab[];   // [NOUT][KP][TS] rows + [TS] aux
@@ -36,7 +50,7 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
     const LaneMap<KM> L = make_lane_map<MP, KM>(a, lane);
     const int NTW = L.NTW, NRT = (T + 15) >> 4;
     const int nb8 = gridDim.x >> 3;
-    const int vb = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * nb8 + (blockIdx.x >> 3) : blockIdx.x;
+    const int vb = (gridDim.x & 7) == 0 && !a.inorder ? (blockIdx.x & 7) * nb8 + (blockIdx.x >> 3) : blockIdx.x;
     const int ustride = gridDim.x * 4;
     const int NU = (a.G + NQ - 1) / NQ;
     int u = vb * 4 + wave;
@@ -136,10 +150,11 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
 #pragma unroll
                     for (int m = 0; m < KM; ++m) afn[o][m] = ap[(o * KP + 4 * m) * TS + (rt + 1) * 16];
             }
-            // 1. four C tiles on the matrix cores -> four staging images
+            // 1. four C tiles on the matrix cores -> four staging images   ("ring_dbg" 1 / 2: ablations for measurements -- no
+            //    production / no stores; outputs are then unwritten or wrong)
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
-                if (g0 + j < a.G) {
+                if (g0 + j < a.G && !(a.ring_dbg & 1)) {
                     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int m = 0; m < KM; ++m) {
@@ -168,7 +183,7 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
             MPK_STAMP(10 + rt);
             // 2. four recurrences in parallel, one per lane quarter (float64 / fp32 without FMA, as k_traj_stream)
             const bool full_tile = CLOSED && tile_fully_executed(serial, nst, rt * 16);
-            if (serial && (!CLOSED || rt * 16 < max(nst, tcond + 1))) {
+            if (serial && !(a.ring_dbg & 1) && (!CLOSED || rt * 16 < max(nst, tcond + 1))) {
                 if (CLOSED) {
                     if (tcond >= rt * 16 && tcond < rt * 16 + 16) {   // condition_on_desired: the desired state at the
                         const size_t si = (size_t)bq * D + L.d;          // last executed step
@@ -191,10 +206,18 @@ __global__ void __launch_bounds__(256) k_traj_quad(const TrajArgs a, const ActAr
             // 3. coalesced stores of the four tiles
 #pragma unroll
             for (int j = 0; j < NQ; ++j)
-                if (g0 + j < a.G)
+                if (g0 + j < a.G && !(a.ring_dbg & 2))
                 {
-                    if (a.wt) tile_store<NST, KM, true>(a, L, sW + j * kQuadImg, lane, (g0 + j) * NTW, rt, rows);
-                    else tile_store<NST, KM, false>(a, L, sW + j * kQuadImg, lane, (g0 + j) * NTW, rt, rows);
+                    // four groups per wave: the group's first episode goes through an opaque scalar, so that what the store derives
+                    // from it (addresses and range predicates of 4 groups x 3 arrays) is recomputed per tile instead of living in
+                    // ~50 registers across the recurrence: closed loop 271 -> 175 registers, dmp 176 -> 134 = two / three waves per
+                    // SIMD (cfg3 at 16 384: 34.0 -> 32.1 us).  With two groups or one the recomputation costs more than the third
+                    // wave per SIMD buys below 16 384 episodes (dmp at 4 096: 18.6 -> 20.0 us) and the extra resident waves open more
+                    // output streams at HBM-streaming sizes (dmp at 65 536: 184 -> 199 us): profiles/r04_closed_loop.md
+                    int b0 = (g0 + j) * NTW;
+                    if (NQ == 4 || MPK_QUAD_LAUNDER_ALL) asm volatile("" : "+s"(b0));
+                    if (a.wt) tile_store<NST, KM, true>(a, L, sW + j * kQuadImg, lane, b0, rt, rows);
+                    else tile_store<NST, KM, false>(a, L, sW + j * kQuadImg, lane, b0, rt, rows);
                 }
             __builtin_amdgcn_wave_barrier();
             MPK_STAMP(50 + rt);

@@ -68,7 +68,7 @@ def main():
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     g = torch.Generator().manual_seed(0)
-    variants = [("auto", {}), ("pipe=1", {"pipe": 1}), ("pipe=0", {"pipe": 0}), ("split", {"split": 1}), ("duo", {"quad": 3}), ("mono", {"quad": 4}), ("auto (again)", {})]
+    variants = [("auto", {}), ("pipe=1", {"pipe": 1}), ("pipe=0", {"pipe": 0}), ("split", {"split": 1}), ("quad", {"quad": 2}), ("duo", {"quad": 3}), ("mono", {"quad": 4}), ("auto (again)", {})]
     print(f"lib: {_lib.LIB_PATH}")
     print("| step | batch | variant | kernel | us | episodes-or-plans/s | GB/s (alg.) | of 8 TB/s |")
     print("|---|---|---|---|---|---|---|---|")

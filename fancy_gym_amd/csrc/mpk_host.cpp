@@ -667,7 +667,7 @@ const OptKey kOptKeys[] = {
     {"pipe", &Tuning::pipe, 0, 1},               {"flat", &Tuning::flat, 0, 1},
     {"phase_flat", &Tuning::phase_flat, 0, 1},   {"ring", &Tuning::ring, 0, 2},
     {"ring_np", &Tuning::ring_np, 1, 14},        {"ring_ns", &Tuning::ring_ns, 1, 8},
-    {"ring_m", &Tuning::ring_m, 1, 8},           {"ring_dbg", &Tuning::ring_dbg, 0, 63},
+    {"ring_m", &Tuning::ring_m, 1, 8},           {"ring_dbg", &Tuning::ring_dbg, 0, 127},
     {"ring_parts", &Tuning::ring_parts, 1, 8},   {"tiles_wpb", &Tuning::tiles_wpb, 1, 4},
     {"serial_order", &Tuning::serial_order, 0, 2},
 };

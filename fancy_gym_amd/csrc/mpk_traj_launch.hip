@@ -362,6 +362,9 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
             const long wg = (long)(kLdsPerCu / lds) < 3 ? (long)(kLdsPerCu / lds) : 3;   // workgroups a CU's LDS holds
             const long resident = (long)num_cu * (wg < 1 ? 1 : wg) * 4;   // 4-wave workgroups, persistent
             waves = ta.G < resident ? ta.G : resident;
+            // the DoF count compiled in for the shapes the reference registers MP environments with (k_traj_flat_d, mpk_traj_ring.h);
+            // "ring_dbg" bit 64: the generic kernel (A/B runs, tests)
+            if ((c.D == 5 || c.D == 7) && c.KP <= 8 && !(ta.ring_dbg & 64)) ta.burst = 2;
         }
         blocks = (int)((waves + 3) / 4);
         if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;                  // XCD-contiguous remap needs a multiple of 8
@@ -418,7 +421,8 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     }
     if (ring || ta.burst) {
         const bool pd = c.mp_type == MPK_MP_PRODMP;
-        *kernel_name = ta.burst ? (pd ? (act ? "k_traj_burst<prodmp,act>" : "k_traj_burst<prodmp>") : (act ? "k_traj_burst<promp,act>" : "k_traj_burst<promp>"))
+        *kernel_name = ta.burst == 2 ? (pd ? (act ? "k_traj_flat<prodmp,act>" : "k_traj_flat<prodmp>") : (act ? "k_traj_flat<promp,act>" : "k_traj_flat<promp>"))
+                     : ta.burst ? (pd ? (act ? "k_traj_burst<prodmp,act>" : "k_traj_burst<prodmp>") : (act ? "k_traj_burst<promp,act>" : "k_traj_burst<promp>"))
                                 : (pd ? (act ? "k_traj_ring<prodmp,act>" : "k_traj_ring<prodmp>") : (act ? "k_traj_ring<promp,act>" : "k_traj_ring<promp>"));
         switch (c.mp_type) {
             case MPK_MP_PRODMP: return launch_traj_ring<MPK_MP_PRODMP>(ta, aa, ct, blocks, lds, stream);

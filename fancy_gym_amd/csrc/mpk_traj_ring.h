@@ -116,7 +116,8 @@ __device__ __forceinline__ void ring_contract(const TrajArgs& a, const LaneMap<K
 
 // ---- the producers' and the engine's inner loops on an instruction diet (round 4) -------------------------------------------------
 // PMC of the streaming row (profiles/r04_ring_pmc.md): k_traj_flat issues 99 vector + 36 scalar + 18 LDS instructions per
-// (wave, row tile) and the chip's vector issue slots are ~75 % taken -- the launch is instruction-issue bound; 40 of the 99 are the
+// (wave, row tile), and with two waves per SIMD a wave's instruction count is its time (one instruction per ~6 cycles for a lone
+// wave: profiles/r04_fp64_rate_probe.md); 40 of the 99 are the
 // float64 controller (fixed by the bit-exactness contract), most of the rest is address arithmetic the compiler cannot fold because
 // D, T and the image strides are run-time values.  With D a COMPILE-TIME constant (DC: the reference's MP-registered environments
 // have 5 or 7 DoF) every LDS access of a row tile takes its offset as an instruction immediate from four address registers that
@@ -536,6 +537,82 @@ __global__ void __launch_bounds__(512) k_traj_burst(const TrajArgs a, const ActA
     const long left = (long)a.B - e0;
     const int ne = (int)(left < (long)(M * NTW) ? left : (long)(M * NTW));
     ring_flush<NST, 8>(a, sB, M * IMG, (size_t)e0 * TD, (ne * TD) >> 2, wave, NW, lane);
+}
+
+// ---- k_traj_flat with the DoF count compiled in (round 4) ----------------------------------------------------------------------------
+// k_traj_flat (mpk_traj_flat.h: one wave = one episode group, whole-trajectory images, two or three persistent 4-wave workgroups per
+// CU) with the ring's inner loops: the contraction with every LDS offset as an immediate (ring_contract_d) and the flush of the
+// group's NTW consecutive episodes as ONE run per array, full 1 KB chunks two at a time in the (scalar base, 32-bit offset) store
+// form (ring_flush_d).  Same arithmetic: same bits.  "ring_dbg" bit 32: the flush of k_traj_flat (arrays interleaved per chunk).
+template <int MP, int CT, int KM, int DC>
+__global__ void __launch_bounds__(256, 2) k_traj_flat_d(const TrajArgs a, const ActArgs act) {
+    static_assert(MP != MPK_MP_DMP && CT < 3, "open loop, promp / prodmp");
+    extern __shared__ __attribute__((aligned(16))) float sTab[];   // [NOUT][KP][TS] rows + [TS] aux + 4 x image
+    constexpr bool ACT = CT >= 0;
+    constexpr int NOUT = MP == MPK_MP_PRODMP ? 2 : 3;
+    constexpr int NST = 2 + (ACT ? 1 : 0);
+    const DevCfg& c = a.c;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int KP = 4 * KM, TS = a.TS, T = c.T, TD = T * DC;
+    (void)act;
+    float* sA = sTab;
+    float* sAux = sTab + NOUT * KP * TS;
+    stage_tables(a.A, a.aux, sA, sAux, (NOUT * KP * TS) >> 2, TS >> 2, threadIdx.x);   // once per workgroup
+    const LaneMap<KM> L = make_lane_map<MP, KM>(a, lane);
+    const int NTW = L.NTW, NRT = (T + 15) >> 4;
+    const int IMG = a.flat_img;                                   // floats per array image: NTW * T * D rounded up to 4
+    float* sI = sAux + TS + wave * (NST * IMG);
+    const int nb8 = gridDim.x >> 3;
+    const int vb = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * nb8 + (blockIdx.x >> 3) : blockIdx.x;
+    const int wstride = gridDim.x * 4;
+    int g = vb * 4 + wave;
+    const bool active = g < a.G;
+    GroupIn<KM> cur;
+    if (active) cur = load_group<MP, ACT, KM>(a, L, g);
+    Gains gn{0.0, 0.0, 0.0, 0.0};
+    if (ACT) gn = kernarg_gains(L.dvalid ? L.d : 0);
+    __syncthreads();                                              // the tables are in LDS
+    if (!active) return;
+    const float* ap = sA + L.q * TS + L.col;
+    float xb[KM];
+    finish_group<KM>(L, cur, xb);
+    double cp = cur.cp, cv = cur.cv;
+    while (g < a.G) {
+        const int b0 = g * NTW;
+        const int gn_ = g + wstride;
+        const GroupIn<KM> nxt = load_group<MP, ACT, KM>(a, L, gn_ < a.G ? gn_ : g);   // in flight across the whole group
+        ring_contract_d<MP, CT, KM, DC>(a, L, ap, sAux, xb, cp, cv, gn, sI, IMG, 0, NRT);
+        __builtin_amdgcn_wave_barrier();
+        const int left = a.B - b0;
+        const int ne = left < NTW ? left : NTW;
+        const size_t go = (size_t)b0 * TD;
+        if (a.ring_dbg & 32) {
+            const int TD4 = TD >> 2;
+            for (int e = 0; e < ne; ++e) {
+                const float* se = sI + e * TD;
+                const size_t ge = go + (size_t)e * TD;
+                for (int i = lane; i < TD4; i += 64) {
+                    const f32x4 p4 = *reinterpret_cast<const f32x4*>(se + 4 * i);
+                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(se + IMG + 4 * i);
+                    if (a.wt) { store16<true>(a.pos + ge + 4 * i, p4); store16<true>(a.vel + ge + 4 * i, v4); }
+                    else { store16<false>(a.pos + ge + 4 * i, p4); store16<false>(a.vel + ge + 4 * i, v4); }
+                    if (ACT) {
+                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(se + 2 * IMG + 4 * i);
+                        if (a.wt) store16<true>(a.actions + ge + 4 * i, a4); else store16<false>(a.actions + ge + 4 * i, a4);
+                    }
+                }
+            }
+        } else if (a.wt) {
+            ring_flush_d<NST, true>(a, sI, IMG, go, (ne * TD) >> 2, 0, 1, lane);
+        } else {
+            ring_flush_d<NST, false>(a, sI, IMG, go, (ne * TD) >> 2, 0, 1, lane);
+        }
+        __builtin_amdgcn_wave_barrier();                          // the image is free again
+        finish_group<KM>(L, nxt, xb);
+        cp = nxt.cp; cv = nxt.cv;
+        g = gn_;
+    }
 }
 
 }  // namespace mpk

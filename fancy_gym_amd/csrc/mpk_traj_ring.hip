@@ -18,7 +18,7 @@ static int launch_ring_t(const TrajArgs& ta, const ActArgs& aa, int blocks, size
     const dim3 g(blocks);
     hipStream_t s = (hipStream_t)stream;
     const int km = ta.c.KP / 4;
-    if (ta.burst) {
+    if (ta.burst == 1) {
         if constexpr (MP != MPK_MP_DMP && CT < 3) {
             const dim3 bb((unsigned)(ta.ring_m * ta.ring_np) * 64u);
             auto go = [&](auto kern) {
@@ -35,6 +35,18 @@ static int launch_ring_t(const TrajArgs& ta, const ActArgs& aa, int blocks, size
             set_error("internal: k_traj_burst is open loop, promp / prodmp");
             return MPK_EINVAL;
         }
+        MPK_LAUNCH_CHECK();
+        return MPK_OK;
+    }
+    if (ta.burst == 2) {
+        // k_traj_flat with the DoF count compiled in (the launcher sends only D = 5 / 7 with <= 8 columns here)
+        const dim3 bf(256);
+        auto gof = [&](auto kern) {
+            if (lds > 48 * 1024) (void)allow_full_lds(kern);
+            hipLaunchKernelGGL(kern, g, bf, lds, s, ta, aa);
+        };
+        if (ta.c.D == 7) { if (km == 1) gof(k_traj_flat_d<MP, CT, 1, 7>); else gof(k_traj_flat_d<MP, CT, 2, 7>); }
+        else { if (km == 1) gof(k_traj_flat_d<MP, CT, 1, 5>); else gof(k_traj_flat_d<MP, CT, 2, 5>); }
         MPK_LAUNCH_CHECK();
         return MPK_OK;
     }

@@ -226,7 +226,8 @@ int mpk_set_duration(mpk_handle h, double duration, double dt);
  *   "ring_parts"    1 .. 8 producer waves sharing the row tiles of one group (by the buffers: all producers stay busy)
  *   "ring_dbg"      bit mask for A/B runs.  Result-preserving: 4 batches b -> workgroup b % grid instead of tickets from the
  *                   device counter, 16 contiguous batch ranges per workgroup (k_traj_burst: A fragments from the table in
- *                   L2), 32 the generic contraction / flush loops instead of the compile-time-DoF ones.  ABLATIONS that leave
+ *                   L2), 32 the generic contraction / flush loops instead of the compile-time-DoF ones, 64 k_traj_flat without its
+ *                   compile-time-DoF variant.  ABLATIONS that leave
  *                   outputs unwritten, measurements only: 1 no production, 2 no stores, 8 no input loads.
  * Unknown key or value out of range: MPK_EINVAL.  mpk_get_option returns the effective value (MPK_OPT_AUTO if automatic).
  */

@@ -415,6 +415,58 @@ def test_fused_closed_loop_rollout_is_bit_exact(cfg, controller, B, bulk, quad, 
     assert np.array_equal(a3.cpu().numpy(), ra.astype(np.float32)) and np.array_equal(q3.cpu().numpy(), rq)
 
 
+@pytest.mark.parametrize("cfg", [CFG2, CFG3], ids=["prodmp_closed", "dmp"])
+@pytest.mark.parametrize("B", [7, 300, 5000])
+def test_serial_kernels_in_every_launch_order_are_bit_identical(cfg, B, mpk_option):
+    """option "serial_order": persistent workgroups over XCD-contiguous unit ranges (default), short-lived workgroups in address
+    order, persistent without the remap -- for four / two / one groups per wave: the same bits (closed loop and DMP)"""
+    pc, bc, tc, dt, dur = cfg
+    eng = make_engine(pc, bc, tc, dt, dur)
+    D = tc.action_dim
+    params, ip, iv = inputs(pc, bc, tc, B, seed=B)
+    rng = np.random.default_rng(B)
+    q0, qd0 = rng.uniform(-1, 1, (B, D)), rng.uniform(-0.2, 0.2, (B, D))
+    spec = RolloutSpec("motor", D, PG[:D], DG[:D], -0.9, 0.9, plant="double_integrator", dt=dt)
+    closed = tc.trajectory_generator_type != "dmp"
+
+    def run():
+        if closed:
+            q, qd = torch.tensor(q0, device="cuda"), torch.tensor(qd0, device="cuda")
+            out = eng.trajectory_rollout(params, ip, iv, spec, q, qd)
+            return [x.clone() for x in out] + [q, qd]
+        return [x.clone() for x in eng.trajectory(params, ip, iv, 0.0)]
+    ref = None
+    for quad in (2, 3, 4):
+        for order in (-1, 0, 1, 2):
+            mpk_option("quad", quad); mpk_option("serial_order", order)
+            got = run()
+            assert any(k in eng.last_kernel() for k in ("k_traj_quad", "k_traj_duo", "k_traj_mono")), eng.last_kernel()
+            if ref is None:
+                ref = got
+            for x, y in zip(ref, got):
+                assert torch.equal(x, y), (quad, order, eng.last_kernel())
+
+
+def test_four_groups_per_wave_while_the_outputs_fit_the_memory_side_cache():
+    """the launcher's rule for the serial-recurrence kernels (profiles/r04_closed_loop.md): closed loop at 16 384 / 32 768 and cfg3
+    at its BASELINE size on k_traj_quad, smaller and HBM-streaming launches on k_traj_duo, a few thousand closed-loop episodes on
+    k_traj_pipe"""
+    pc, bc, tc, dt, dur = CFG2
+    eng = make_engine(pc, bc, tc, dt, dur)
+    spec = RolloutSpec("motor", 7, PG, DG, -0.9, 0.9, plant="double_integrator", dt=dt)
+    for B, want in ((4096, "k_traj_pipe"), (8192, "k_traj_duo"), (16384, "k_traj_quad"), (32768, "k_traj_quad"), (65536, "k_traj_duo")):
+        params, ip, iv = inputs(pc, bc, tc, B, seed=1)
+        q, qd = torch.zeros((B, 7), dtype=torch.float64, device="cuda"), torch.zeros((B, 7), dtype=torch.float64, device="cuda")
+        eng.trajectory_rollout(params, ip, iv, spec, q, qd)
+        assert eng.last_kernel().startswith(want), (B, eng.last_kernel())
+    pc, bc, tc, dt, dur = CFG3
+    eng = make_engine(pc, bc, tc, dt, dur)
+    for B, want in ((8192, "k_traj_duo"), (16384, "k_traj_quad"), (32768, "k_traj_duo")):
+        params, ip, iv = inputs(pc, bc, tc, B, seed=1)
+        eng.trajectory(params, ip, iv, 0.0)
+        assert eng.last_kernel().startswith(want), (B, eng.last_kernel())
+
+
 @pytest.mark.parametrize("quad", ["0", "2"])
 @pytest.mark.parametrize("D,T", [(1, 50), (3, 10), (4, 17), (16, 40), (5, 100), (20, 12)])
 def test_pd_rollout_on_every_shape_class(D, T, quad, monkeypatch, mpk_option):

@@ -208,6 +208,34 @@ def test_flat_kernel_matches_the_oracle_and_the_other_kernels_bitwise(name, B, i
         assert torch.equal(pos, p2) and torch.equal(vel, v2), (mapping, eng.last_kernel())
 
 
+@pytest.mark.parametrize("name", ["cfg2", "cfg4", "promp4", "promp5"])
+@pytest.mark.parametrize("B", [1, 3, 130, 2051])
+def test_flat_kernel_with_the_dof_count_compiled_in_equals_the_generic_one(name, B, mpk_option):
+    """5 and 7 DoF with <= 8 contraction columns run k_traj_flat_d (the ring's contraction with immediates + its chunked flush);
+    "ring_dbg" 64 selects the generic kernel, 32 the generic (interleaved) flush: the same bits, trajectory and fused actions"""
+    import bench
+    from fancy_gym_amd import RolloutSpec
+    pc, bc, tc, dt, duration = {"cfg2": CFG2, "cfg4": CFG4, "promp4": FLAT_PROMP, "promp5": FLAT_PROMP5}[name]
+    eng = make_engine(pc, bc, tc, dt, duration)
+    D = tc.action_dim
+    params, ip, iv = inputs(pc, bc, tc, B, seed=B + 11)
+    rng = np.random.default_rng(B)
+    cp, cv = rng.uniform(-1, 1, (B, D)), rng.uniform(-1, 1, (B, D))
+    spec = RolloutSpec("motor", D, bench.P_GAINS[:D], bench.D_GAINS[:D], -1.0, 1.0, plant="static")
+    mpk_option("flat", 1)
+    outs = []
+    for dbg in (64, 0, 32):
+        mpk_option("ring_dbg", dbg)
+        t = [x.clone() for x in eng.trajectory(params, ip, iv, 0.25)]
+        assert eng.last_kernel().startswith("k_traj_flat"), eng.last_kernel()
+        a = [x.clone() for x in eng.trajectory_actions(params, ip, iv, spec, cp, cv, init_time=0.25)]
+        assert eng.last_kernel().startswith("k_traj_flat"), eng.last_kernel()
+        outs.append(t + a)
+    for other in outs[1:]:
+        for x, y in zip(outs[0], other):
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+
+
 @pytest.mark.parametrize("B", [1, 5, 130, 4096])
 @pytest.mark.parametrize("ctrl", ["motor", "position", "velocity"])
 def test_flat_kernel_fused_actions_bit_exact(B, ctrl, mpk_option):

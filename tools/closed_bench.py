@@ -63,6 +63,11 @@ def time_rows(graphs, reps=20, rounds=9, busy_ms=60.0):
     return [float(np.median(t)) for t in ts]
 
 
+def graph_time(fn, reps=20, rounds=7):
+    """one row on its own (the other tools' entry point): captured graph of `reps` launches, warmed by GPU-busy time, median"""
+    return time_rows([capture(fn, reps)], reps=reps, rounds=rounds)[0]
+
+
 def main():
     batches = [int(a) for a in sys.argv[1:] if a.isdigit()] or [2048, 4096, 8192, 16384]
     torch.cuda.set_device(0)

@@ -229,7 +229,8 @@ def test_flat_kernel_with_the_dof_count_compiled_in_equals_the_generic_one(name,
         t = [x.clone() for x in eng.trajectory(params, ip, iv, 0.25)]
         assert eng.last_kernel().startswith("k_traj_flat"), eng.last_kernel()
         a = [x.clone() for x in eng.trajectory_actions(params, ip, iv, spec, cp, cv, init_time=0.25)]
-        assert eng.last_kernel().startswith("k_traj_flat"), eng.last_kernel()
+        # (three whole-trajectory images of promp4's 350-step episodes exceed the flat kernels' LDS budget: k_traj_stream there)
+        assert eng.last_kernel().startswith("k_traj_flat" if name != "promp4" else "k_traj_stream"), eng.last_kernel()
         outs.append(t + a)
     for other in outs[1:]:
         for x, y in zip(outs[0], other):

@@ -831,3 +831,55 @@ def test_disabled_goal_or_weights_never_read_past_the_parameter_buffer():
     r = subprocess.run([sys.executable, "-c", _TAIL_SCRIPT.format(root=root)], capture_output=True, text=True, timeout=600,
                        cwd=root)
     assert r.returncode == 0 and "tail ok" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+
+
+_TWO_BIG_LDS_CHILD = r"""
+import sys
+sys.path.insert(0, sys.argv[1])
+import dataclasses
+import numpy as np, torch
+from oracle import mp_oracle as O
+from tests.test_gpu_trajectory import CFG2, inputs, make_engine
+from fancy_gym_amd import RolloutSpec, _lib
+import bench
+# two DIFFERENT instantiations with the SAME parameter list, each beyond 64 KB of dynamic LDS, first use of either in this process:
+# k_traj_flat<prodmp, act> with 8 contraction columns (cfg2) and with 4 (one basis function + goal + two boundary columns), then the
+# trajectory-only pair of k_traj_ring (134 KB) -- round 3 kept the "attribute already raised" flag per function TYPE, so the second
+# kernel of a signature never got its own hipFuncSetAttribute call
+pc, bc, tc, dt, dur = CFG2
+small = dataclasses.replace(bc, num_basis=1)
+_lib.set_option("flat", 1)
+spec = RolloutSpec("motor", 7, bench.P_GAINS, bench.D_GAINS, -1.0, 1.0, plant="static")
+kernels = []
+for b in (bc, small, bc, small):
+    eng = make_engine(pc, b, tc, dt, dur)
+    params, ip, iv = inputs(pc, b, tc, 300, seed=4)
+    cp, cv = np.zeros((300, 7)), np.zeros((300, 7))
+    pos, vel, act = eng.trajectory_actions(params, ip, iv, spec, cp, cv)
+    torch.cuda.synchronize()
+    kernels.append(eng.last_kernel())
+    rp, rv = O.get_trajectory(pc, b, tc, params, dur, dt, 0.0, ip, iv, dtype=np.float64)
+    assert np.abs(pos.cpu().numpy() - rp).max() <= 2e-5 * np.abs(rp).max(), eng.last_kernel()
+assert all(k == "k_traj_flat<prodmp,act>" for k in kernels), kernels
+_lib.reset_options(); _lib.set_option("ring", 1)
+for b in (small, bc):
+    eng = make_engine(pc, b, tc, dt, dur)
+    params, ip, iv = inputs(pc, b, tc, 300, seed=5)
+    pos, vel = eng.trajectory(params, ip, iv, 0.0)
+    torch.cuda.synchronize()
+    assert eng.last_kernel() == "k_traj_ring<prodmp>", eng.last_kernel()
+    rp, rv = O.get_trajectory(pc, b, tc, params, dur, dt, 0.0, ip, iv, dtype=np.float64)
+    assert np.abs(pos.cpu().numpy() - rp).max() <= 2e-5 * np.abs(rp).max()
+print("two big-LDS kernels ok")
+"""
+
+
+def test_two_kernels_of_one_signature_that_each_need_more_than_64_kb_of_lds_in_one_fresh_process():
+    """the once-per-kernel flag of hipFuncSetAttribute(MaxDynamicSharedMemorySize) is keyed on the function
+    VALUE and the device; a fresh process launches two instantiations of one signature, both above 64 KB, in both orders of use"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _TWO_BIG_LDS_CHILD, root], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and "two big-LDS kernels ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

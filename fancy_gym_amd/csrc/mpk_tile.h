@@ -59,6 +59,7 @@ struct TrajArgs {
     int ring_tb;           // batches per ticket
     int ring_parts;        // waves that share one group's row tiles (long horizons: the image of ONE group fills a batch buffer)
     int burst;             // k_traj_burst: short-lived workgroups, one batch of ring_m groups each, ring_np waves per group
+    int lean;              // k_traj_pipe: the register-lean instantiation (more than two work units per CU)
     int inorder;           // k_traj_quad: 1 = one unit per wave, workgroup b takes units 4 b .. 4 b + 3 (short-lived workgroups in address order)
     int wpb;               // tile-major kernel: waves per workgroup (4; "tiles_wpb" 1 / 2 for A/B runs)
     int ring_dbg;          // ablations (mpk_set_option "ring_dbg"): 1 producers publish without contracting, 2 the engine skips its stores

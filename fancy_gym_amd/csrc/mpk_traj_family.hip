@@ -18,12 +18,16 @@ static int launch_traj_t(const TrajArgs& ta, const ActArgs& aa, bool stream_mode
         if constexpr (MP != MPK_MP_DMP && CT >= 3) {
             const dim3 b5(320);
             hipStream_t s5 = (hipStream_t)stream;
-            switch (ta.c.KP / 4) {
-                case 1: hipLaunchKernelGGL((k_traj_pipe<MP, CT, 1>), g, b5, lds, s5, ta, aa); break;
-                case 2: hipLaunchKernelGGL((k_traj_pipe<MP, CT, 2>), g, b5, lds, s5, ta, aa); break;
-                case 3: hipLaunchKernelGGL((k_traj_pipe<MP, CT, 3>), g, b5, lds, s5, ta, aa); break;
-                default: hipLaunchKernelGGL((k_traj_pipe<MP, CT, 4>), g, b5, lds, s5, ta, aa); break;
-            }
+            auto gop = [&](auto lean) {
+                constexpr bool LEAN = decltype(lean)::value;
+                switch (ta.c.KP / 4) {
+                    case 1: hipLaunchKernelGGL((k_traj_pipe<MP, CT, 1, LEAN>), g, b5, lds, s5, ta, aa); break;
+                    case 2: hipLaunchKernelGGL((k_traj_pipe<MP, CT, 2, LEAN>), g, b5, lds, s5, ta, aa); break;
+                    case 3: hipLaunchKernelGGL((k_traj_pipe<MP, CT, 3, LEAN>), g, b5, lds, s5, ta, aa); break;
+                    default: hipLaunchKernelGGL((k_traj_pipe<MP, CT, 4, LEAN>), g, b5, lds, s5, ta, aa); break;
+                }
+            };
+            if (ta.lean) gop(std::true_type()); else gop(std::false_type());
         }
         MPK_LAUNCH_CHECK();
         return MPK_OK;

@@ -142,7 +142,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
                        const Tuning& tune, const ReplanDev* rp, unsigned* ticket) {
     TrajArgs ta;
     ta.nrt_magic = 0; ta.gstride = 0; ta.wt = 0; ta.flat_img = 0;
-    ta.ring_np = 0; ta.ring_ns = 0; ta.ring_m = 0; ta.ring_nbuf = 0; ta.ring_dbg = tune.ring_dbg > 0 ? tune.ring_dbg : 0; ta.burst = 0; ta.inorder = 0; ta.wpb = 4; ta.ring_ctr = nullptr; ta.ring_tb = 0; ta.ring_parts = 1;
+    ta.ring_np = 0; ta.ring_ns = 0; ta.ring_m = 0; ta.ring_nbuf = 0; ta.ring_dbg = tune.ring_dbg > 0 ? tune.ring_dbg : 0; ta.burst = 0; ta.inorder = 0; ta.lean = 0; ta.wpb = 4; ta.ring_ctr = nullptr; ta.ring_tb = 0; ta.ring_parts = 1;
     if (rp) ta.rp = *rp;
     const bool closed = q_state != nullptr;
     ta.q_state = q_state; ta.qd_state = qd_state; ta.n_steps = n_steps; ta.plant_dt = rc ? rc->dt : 0.0;
@@ -317,6 +317,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         blocks = (int)(units < cap ? units : cap);
         if (blocks >= 8) blocks = blocks / 8 * 8;                         // XCD-contiguous remap needs a multiple of 8
         if (blocks < 1) blocks = 1;
+        ta.lean = units > 2 * (long)num_cu ? 1 : 0;                        // (see k_traj_pipe: 81 instead of 100 registers)
     } else if (quad) {
         lds = table_bytes;
         const long units = (ta.G + quad - 1) / quad;

@@ -23,7 +23,7 @@ constexpr int kPipeGroups = 4;
                              // wave issues one instruction per 6 cycles, a dependent one per 8.9: profiles/r04_closed_loop.md)
 #endif
 
-template <int MP, int CT, int KM>
+template <int MP, int CT, int KM, bool LEAN>
 __global__ void __launch_bounds__(320) k_traj_pipe(const TrajArgs a, const ActArgs act) {
     static_assert(CT >= 3 && MP != MPK_MP_DMP, "closed loop, promp / prodmp");
     __shared__ __attribute__((aligned(16))) float smem[2 * kPipeGroups * kQuadImg];   // [buffer][group] pos | vel | act
@@ -152,8 +152,16 @@ __global__ void __launch_bounds__(320) k_traj_pipe(const TrajArgs a, const ActAr
                 constexpr int MASK = decltype(mask_tag)::value;
                 const float* sJ = smem + ((rt & 1) * kPipeGroups + j) * kQuadImg;
                 const int rows = min(16, T - rt * 16);
-                if (a.wt) tile_store_sel<MASK, KM, true>(a, L, sJ, lane, g * NTW, rt, rows);
-                else tile_store_sel<MASK, KM, false>(a, L, sJ, lane, g * NTW, rt, rows);
+                // LEAN: the group's first episode through an opaque scalar -- the stores' addresses and range predicates are recomputed
+                // per tile instead of living across the unit: 100 -> 81 registers = FIVE waves per SIMD, i.e. a third (and fourth)
+                // 5-wave workgroup per CU.  With the 100-register version the workgroups of a launch with three units per CU did
+                // not all fit (104-register granules: 4 waves per SIMD, the fifth wave of a workgroup doubles up on one SIMD):
+                // B = 6 144: 18.7 -> 13.7 us, replanning step 15.6 -> 11.9.  With <= two units per CU the recomputation only costs
+                // (4 096: 11.3 -> 11.6 us, replanning step 9.6 -> 10.1): the launcher picks (profiles/r04_closed_loop.md)
+                int b0 = g * NTW;
+                if (LEAN) asm volatile("" : "+s"(b0));
+                if (a.wt) tile_store_sel<MASK, KM, true>(a, L, sJ, lane, b0, rt, rows);
+                else tile_store_sel<MASK, KM, false>(a, L, sJ, lane, b0, rt, rows);
             };
             // tile 0 is handed to the consumer before its pos / vel are stored: the recurrence is the critical path
             if (u == vb) {

@@ -447,6 +447,54 @@ def test_serial_kernels_in_every_launch_order_are_bit_identical(cfg, B, mpk_opti
                 assert torch.equal(x, y), (quad, order, eng.last_kernel())
 
 
+@pytest.mark.parametrize("cfg", [CFG2, CFG5, CFG4], ids=["prodmp", "promp", "prodmp_replan"])
+@pytest.mark.parametrize("B", [4104, 6001])
+def test_register_lean_pipeline_kernel_is_bit_identical(cfg, B, mpk_option):
+    """more than two work units per CU select k_traj_pipe<.., LEAN> (store addresses recomputed per tile: 81 registers): the bits of
+    the 100-register instantiation's siblings (k_traj_duo) and of trajectory + rollout as separate kernels; also through
+    mpk_replan_step with random integer states"""
+    pc, bc, tc, dt, dur = cfg
+    eng = make_engine(pc, bc, tc, dt, dur)
+    params, ip, iv = inputs(pc, bc, tc, B, seed=B)
+    rng = np.random.default_rng(B)
+    q0, qd0 = rng.uniform(-1, 1, (B, 7)), rng.uniform(-0.2, 0.2, (B, 7))
+    T = eng.num_steps
+    n_steps = torch.tensor(rng.integers(0, T + 1, B).astype(np.int32))
+    spec = RolloutSpec("motor", 7, PG, DG, -0.9, 0.9, plant="double_integrator", dt=dt)
+
+    def run():
+        q, qd = torch.tensor(q0, device="cuda"), torch.tensor(qd0, device="cuda")
+        out = eng.trajectory_rollout(params, ip, iv, spec, q, qd, n_steps=n_steps, init_time=0.25)
+        return [x.clone() for x in out] + [q, qd]
+    got = run()
+    if cfg is not CFG5:                                      # (cfg5's 350-step tables do not fit beside the pipeline's images)
+        assert eng.last_kernel().startswith("k_traj_pipe"), eng.last_kernel()
+    mpk_option("pipe", 0)
+    ref = run()
+    assert not eng.last_kernel().startswith("k_traj_pipe")
+    for x, y in zip(got, ref):
+        assert torch.equal(x, y)
+    p2, v2 = eng.trajectory(params, ip, iv, 0.25)
+    q2, qd2 = torch.tensor(q0, device="cuda"), torch.tensor(qd0, device="cuda")
+    a2 = eng.pd_rollout(spec, p2, v2, q2, qd2, n_steps=n_steps)
+    for x, y in zip(got, [p2, v2, a2, q2, qd2]):
+        assert torch.equal(x, y)
+    # one replanning step: integer state, plan, rollout, condition gather
+    mpk_option("pipe", -1)
+    every, mpt, horizon = 25, 3, 2 * T
+    ts0 = rng.integers(0, horizon, B).astype(np.int32); ps0 = rng.integers(0, 4, B).astype(np.int32)
+    dn0 = (rng.random(B) < 0.2).astype(np.uint8)
+    res = []
+    for pipe in (-1, 0):
+        mpk_option("pipe", pipe)
+        st = (torch.tensor(q0, device="cuda"), torch.tensor(qd0, device="cuda"), torch.tensor(ts0, device="cuda"),
+              torch.tensor(ps0, device="cuda"), torch.tensor(dn0, device="cuda"))
+        r = eng.replan_step(params, ip, iv, spec, *st, every, mpt, horizon, init_time=0.0, condition=True)
+        res.append([r[k].clone() for k in ("pos", "vel", "actions", "seg_len", "done", "cond_pos", "cond_vel")] + list(st))
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
+
+
 def test_four_groups_per_wave_while_the_outputs_fit_the_memory_side_cache():
     """the launcher's rule for the serial-recurrence kernels (profiles/r04_closed_loop.md): closed loop at 16 384 / 32 768 and cfg3
     at its BASELINE size on k_traj_quad, smaller and HBM-streaming launches on k_traj_duo, a few thousand closed-loop episodes on

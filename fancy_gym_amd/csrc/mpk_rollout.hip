@@ -42,8 +42,7 @@ __global__ void __launch_bounds__(256) k_pd_rollout(const RolloutDev rc, const i
 // sin and cos of one float64 angle with a shared three-term Cody-Waite reduction by pi/2 and the classic degree-13 /
 // degree-14 kernels on [-pi/4, pi/4] (coefficients of fdlibm's __kernel_sin / __kernel_cos): ~1 ulp for |x| < 1e6, a
 // quarter of the instructions of two library calls.  Larger angles (a plant spun far out of range) take the library.
-__device__ __forceinline__ void sincos_lean(double x, double* sn, double* cs) {
-    if (!(fabs(x) < 1.0e6)) { sincos(x, sn, cs); return; }
+__device__ __forceinline__ void sincos_core(double x, double* sn, double* cs) {   // |x| < 1e6, no branch
     const double k = rint(x * 6.36619772367581382433e-01);
     double r = fma(-k, 1.57079632673412561417e+00, x);
     r = fma(-k, 6.07710050630396597660e-11, r);
@@ -67,6 +66,89 @@ __device__ __forceinline__ void sincos_lean(double x, double* sn, double* cs) {
     const double a = (q & 1) ? c : s, b = (q & 1) ? s : c;
     *sn = (q & 2) ? -a : a;
     *cs = ((q + 1) & 2) ? -b : b;
+}
+
+__device__ __forceinline__ void sincos_lean(double x, double* sn, double* cs) {
+    if (!(fabs(x) < 1.0e6)) { sincos(x, sn, cs); return; }
+    sincos_core(x, sn, cs);
+}
+
+// SimpleReacherEnv's reward of ONE (episode, step) item (simple_reacher.py:56-72; unit links: base_reacher.py:19,97-104) from the
+// plant positions qv[0 .. D) after the step and the clipped actions uv[0 .. D): cumulative joint angles, end effector, control
+// cost, every sum left to right as numpy adds.  DC > 0: the link count compiled in, the sin / cos evaluations (independent chains
+// of ~20 dependent float64 operations each) unrolled side by side -- an A/B knob (MPK_RW_DC), off: measured slower than the
+// run-time loop.  Same operations either way: same bits.
+#ifndef MPK_RW_CHAINS
+#define MPK_RW_CHAINS 3
+#endif
+#ifndef MPK_RW_DC
+#define MPK_RW_DC 0          // 5: the five links of SimpleReacher unrolled, MPK_RW_CHAINS sin / cos chains side by side.  Measured
+                             // SLOWER (65 536 episodes x 200 steps: 353 us against 322 for the run-time loop, profiles/r04_reward_pass_ab.md):
+                             // the pass is bound by float64 issue (two waves per SIMD both inside it), not by the chains' latency
+#endif
+#ifndef MPK_RW_LOOK
+#define MPK_RW_LOOK 1        // tiles of input lookahead in the reward kernel (2 = as the kernel without reward)
+#endif
+template <int DC>
+__device__ __forceinline__ double reacher_reward_item(const double* qv, const double* uv, const int D, const bool dist_on,
+                                                      const double gx, const double gy) {
+    double ex = 0.0, ey = 0.0, ctrl = 0.0;
+    if constexpr (DC > 0) {
+        double ang[DC];
+        bool big = false;
+#pragma unroll
+        for (int dd = 0; dd < DC; ++dd) {
+            const double qd_ = qv[dd];
+            ang[dd] = dd == 0 ? qd_ : ang[dd > 0 ? dd - 1 : 0] + qd_;           // np.cumsum(joint_angles)
+            big = big || !(fabs(ang[dd]) < 1.0e6);
+        }
+        if (big) {
+#pragma unroll 1
+            for (int dd = 0; dd < DC; ++dd) {
+                double sn, cs;
+                sincos_lean(ang[dd], &sn, &cs);
+                ex = dd == 0 ? cs : ex + cs;
+                ey = dd == 0 ? sn : ey + sn;
+            }
+        } else {
+            // CH chains side by side fill the issue slots of a wave that shares its SIMD with one other; all DC at once cost 70 more
+            // registers than two waves per SIMD leave
+            constexpr int CH = MPK_RW_CHAINS;
+#pragma unroll
+            for (int d0 = 0; d0 < DC; d0 += CH) {
+                double sn[CH], cs[CH];
+#pragma unroll
+                for (int dd = d0; dd < (d0 + CH < DC ? d0 + CH : DC); ++dd) sincos_core(ang[dd], &sn[dd - d0], &cs[dd - d0]);
+#pragma unroll
+                for (int dd = d0; dd < (d0 + CH < DC ? d0 + CH : DC); ++dd) {
+                    ex = dd == 0 ? cs[dd - d0] : ex + cs[dd - d0];
+                    ey = dd == 0 ? sn[dd - d0] : ey + sn[dd - d0];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int dd = 0; dd < DC; ++dd) {
+            const double u_ = uv[dd];
+            ctrl = dd == 0 ? u_ * u_ : ctrl + u_ * u_;
+        }
+    } else {
+        double ang = 0.0;
+        for (int dd = 0; dd < D; ++dd) {
+            ang = dd == 0 ? qv[dd] : ang + qv[dd];
+            double sn, cs;
+            sincos_lean(ang, &sn, &cs);
+            ex = dd == 0 ? cs : ex + cs;
+            ey = dd == 0 ? sn : ey + sn;
+            ctrl = dd == 0 ? uv[dd] * uv[dd] : ctrl + uv[dd] * uv[dd];
+        }
+    }
+    double rdist = 0.0;
+    if (dist_on) {
+        const double dx = ex - gx, dy = ey - gy;
+        rdist = 0.0 - sqrt(dx * dx + dy * dy);
+    }
+    return rdist - ctrl;
 }
 
 // Tile-streaming variant (D <= 16, float4-aligned trajectories): a wave owns a group of 16/DP episodes and walks their
@@ -160,8 +242,31 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
             gv[j] = a.des_vel + (size_t)b0 * T * D + gofs;
             lpA[j] = f32x4{0, 0, 0, 0}; lvA[j] = lpA[j]; lpB[j] = lpA[j]; lvB[j] = lpA[j];
         }
+        // RW: the reward pass turns (episode, step) items into rewards, item = pass * 64 + lane -> episode slot je = 4 pass + lane / 16
+        // of the unit, step lane % 16 of the tile: a lane meets the SAME episodes in every tile, so what the pass needs per episode
+        // (executed steps, step offset, goal) is read once per unit into registers.  Round 4: read per item and tile, these were three
+        // dependent trips to the memory-side cache inside every pass, with two waves per SIMD to hide them.
+        constexpr int kRwPasses = 2;
+        const int rw_npass = RW ? (NG * NTW + 3) >> 2 : 0;
+        int rw_b[kRwPasses], rw_ns[kRwPasses], rw_s0[kRwPasses], rw_q[kRwPasses];
+        double rw_gx[kRwPasses], rw_gy[kRwPasses];
+        if (RW && rw_npass <= kRwPasses) {
+#pragma unroll
+            for (int p = 0; p < kRwPasses; ++p) {
+                const int je = 4 * p + (lane >> 4), e = je & (NTW - 1), j = je >> (4 - a.sh);
+                const int b = (g0 + j) * NTW + e;
+                const bool ok = p < rw_npass && j < NG && g0 + j < a.G && b < B;
+                rw_b[p] = ok ? b : -1;
+                rw_q[p] = (j * SLOT) * 4 + (e * DP) * 8;       // byte offset of (group slot, episode) in the float64 images
+                rw_ns[p] = ok ? (a.n_steps ? min(a.n_steps[b], T) : T) : 0;
+                rw_s0[p] = ok && a.step0 ? a.step0[b] : 0;
+                rw_gx[p] = ok ? a.goal[2 * (size_t)b] : 0.0;
+                rw_gy[p] = ok ? a.goal[2 * (size_t)b + 1] : 0.0;
+            }
+        }
         fetch(0, lpA, lvA);
-        if (NRT > 1) fetch(1, lpB, lvB);
+        constexpr bool kTwoAhead = !RW || MPK_RW_LOOK == 2;
+        if (kTwoAhead && NRT > 1) fetch(1, lpB, lvB);      // (RW: a tile takes three times as long -- one tile of lookahead, 32 registers less)
         auto tile = [&](const int rt, f32x4 (&lp)[NG], f32x4 (&lv)[NG]) {
             const int rows = min(16, T - rt * 16);
 #pragma unroll
@@ -171,7 +276,7 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
                     *reinterpret_cast<f32x4*>(sSt + j * SLOT + kStageStride + rofs) = lv[j];
                 }
             }
-            if (rt + 2 < NRT) fetch(rt + 2, lp, lv);          // into the set this tile has just emptied
+            if (rt + (kTwoAhead ? 2 : 1) < NRT) fetch(rt + (kTwoAhead ? 2 : 1), lp, lv);   // into the set this tile has just emptied
             __builtin_amdgcn_wave_barrier();
             if (serial) {
                 // the 16 steps of the tile as straight-line code per (controller, plant): a run-time switch inside the
@@ -213,37 +318,51 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
             }
             __builtin_amdgcn_wave_barrier();
             if (RW) {
-                const int items = NG * NTW * rows;            // (group, episode in group, step in tile)
-                for (int it = lane; it < items; it += 64) {
-                    const int tl = it % rows, je = it / rows;
-                    const int e = je % NTW, j = je / NTW;
-                    const int b = (g0 + j) * NTW + e;
-                    if (g0 + j < a.G && b < B) {
-                        const int t = rt * 16 + tl;
-                        const int ns = a.n_steps ? min(a.n_steps[b], T) : T;
-                        double r = 0.0;
-                        if (t < ns) {
-                            const double* qv = reinterpret_cast<const double*>(sSt + j * SLOT) + tl * 16 + e * DP;
-                            const double* uv = reinterpret_cast<const double*>(sSt + j * SLOT + 3 * kStageStride) + tl * 16 + e * DP;
-                            double ang = 0.0, ex = 0.0, ey = 0.0, ctrl = 0.0;
-                            for (int dd = 0; dd < D; ++dd) {
-                                ang = dd == 0 ? qv[dd] : ang + qv[dd];      // np.cumsum(joint_angles)
-                                double sn, cs;
-                                sincos_lean(ang, &sn, &cs);
-                                ex = dd == 0 ? cs : ex + cs;                // unit links (base_reacher.py:19,97-104)
-                                ey = dd == 0 ? sn : ey + sn;
-                                ctrl = dd == 0 ? uv[dd] * uv[dd] : ctrl + uv[dd] * uv[dd];
+                auto pass = [&](auto dc_tag) {
+                    constexpr int DC = decltype(dc_tag)::value;
+                    if (rw_npass <= kRwPasses) {
+                        const int tl = lane & 15, t = rt * 16 + tl;
+#pragma unroll 1
+                        for (int p = 0; p < rw_npass; ++p) {                  // (one copy of the pass: the two must not interleave)
+                            static_assert(kRwPasses == 2, "selects below");
+                            const int pb = p ? rw_b[1] : rw_b[0], pns = p ? rw_ns[1] : rw_ns[0], ps0 = p ? rw_s0[1] : rw_s0[0];
+                            const int pq = p ? rw_q[1] : rw_q[0];
+                            const double pgx = p ? rw_gx[1] : rw_gx[0], pgy = p ? rw_gy[1] : rw_gy[0];
+                            if (pb >= 0 && tl < rows) {
+                                double r = 0.0;
+                                if (t < pns) {
+                                    const char* sb = reinterpret_cast<const char*>(sSt) + pq;
+                                    const double* qv = reinterpret_cast<const double*>(sb) + tl * 16;
+                                    const double* uv = reinterpret_cast<const double*>(sb + 3 * kStageStride * 4) + tl * 16;
+                                    r = reacher_reward_item<DC>(qv, uv, D, ps0 + t >= a.steps_before_reward, pgx, pgy);
+                                }
+                                a.rewards[(size_t)pb * T + t] = r;
                             }
-                            double rdist = 0.0;
-                            if ((a.step0 ? a.step0[b] : 0) + t >= a.steps_before_reward) {
-                                const double dx = ex - a.goal[2 * (size_t)b], dy = ey - a.goal[2 * (size_t)b + 1];
-                                rdist = 0.0 - sqrt(dx * dx + dy * dy);
-                            }
-                            r = rdist - ctrl;
                         }
-                        a.rewards[(size_t)b * T + t] = r;
+                    } else {
+                        // more than 16 episodes per unit (D <= 2): per-item inputs from memory
+                        const int items = NG * NTW * 16;          // (group, episode in group, step in tile)
+                        for (int it = lane; it < items; it += 64) {
+                            const int tl = it & 15, je = it >> 4;
+                            const int e = je & (NTW - 1), j = je >> (4 - a.sh);
+                            const int b = (g0 + j) * NTW + e;
+                            if (tl < rows && g0 + j < a.G && b < B) {
+                                const int t = rt * 16 + tl;
+                                const int ns = a.n_steps ? min(a.n_steps[b], T) : T;
+                                double r = 0.0;
+                                if (t < ns) {
+                                    const double* qv = reinterpret_cast<const double*>(sSt + j * SLOT) + tl * 16 + e * DP;
+                                    const double* uv = reinterpret_cast<const double*>(sSt + j * SLOT + 3 * kStageStride) + tl * 16 + e * DP;
+                                    r = reacher_reward_item<DC>(qv, uv, D, (a.step0 ? a.step0[b] : 0) + t >= a.steps_before_reward,
+                                                                a.goal[2 * (size_t)b], a.goal[2 * (size_t)b + 1]);
+                                }
+                                a.rewards[(size_t)b * T + t] = r;
+                            }
+                        }
                     }
-                }
+                };
+                if (MPK_RW_DC == 5 && D == 5) pass(std::integral_constant<int, 5>());       // SimpleReacher / LongSimpleReacher: five links
+                else pass(std::integral_constant<int, 0>());
                 __builtin_amdgcn_wave_barrier();
             }
             if (a.actions) {
@@ -259,9 +378,14 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
             }
             __builtin_amdgcn_wave_barrier();
         };
-        for (int rt = 0; rt < NRT; rt += 2) {
-            tile(rt, lpA, lvA);
-            if (rt + 1 < NRT) tile(rt + 1, lpB, lvB);
+        if (!kTwoAhead) {
+#pragma unroll 1
+            for (int rt = 0; rt < NRT; ++rt) tile(rt, lpA, lvA);
+        } else {
+            for (int rt = 0; rt < NRT; rt += 2) {
+                tile(rt, lpA, lvA);
+                if (rt + 1 < NRT) tile(rt + 1, lpB, lvB);
+            }
         }
         if (serial) {
             const size_t si = (size_t)bs * D + d;

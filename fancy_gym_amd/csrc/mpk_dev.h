@@ -77,6 +77,9 @@ constexpr double kRingBytes = 600.0 * 1024 * 1024;
 // a ticket of k_traj_ring covers at least this many bytes of batch buffers: one device counter hands out ~88 tickets / us
 // (profiles/r04_store_engine_probe_dynamic.md), 32768 tickets of 67 KB saturate it, 10923 of 201 KB do not
 constexpr size_t kRingTicketBytes = 192 * 1024;
+// closed loop: the ring with consumer waves (k_traj_ring<.., closed>) is automatic once the step's three output arrays exceed this
+// (A/B against k_traj_quad / duo per size: profiles/r04_ring_closed.md)
+constexpr double kRingClosedBytes = 400.0 * 1024 * 1024;
 
 // Kernels that may take more than the default 64 KB of dynamic LDS: the function attribute is raised ONCE per kernel
 // instantiation to the CU's whole LDS (160 KB), not per launch with the launch's size -- hipFuncSetAttribute rewrites state of a

@@ -669,7 +669,7 @@ const OptKey kOptKeys[] = {
     {"ring_np", &Tuning::ring_np, 1, 14},        {"ring_ns", &Tuning::ring_ns, 1, 8},
     {"ring_m", &Tuning::ring_m, 1, 8},           {"ring_dbg", &Tuning::ring_dbg, 0, 127},
     {"ring_parts", &Tuning::ring_parts, 1, 8},   {"tiles_wpb", &Tuning::tiles_wpb, 1, 4},
-    {"serial_order", &Tuning::serial_order, 0, 2},
+    {"serial_order", &Tuning::serial_order, 0, 2}, {"ring_nc", &Tuning::ring_nc, 1, 6},
 };
 const OptKey* find_opt(const char* key) {
     if (!key) return nullptr;

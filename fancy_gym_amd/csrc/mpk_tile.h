@@ -55,6 +55,7 @@ struct TrajArgs {
     int flat_img;          // k_traj_flat / k_traj_ring: floats per whole-trajectory array image (NTW * T * D); 0 = another kernel runs
     // k_traj_ring (ring_np > 0): producer waves, store-engine waves, episode groups per batch, batch buffers in the LDS ring
     int ring_np, ring_ns, ring_m, ring_nbuf;
+    int ring_nc;           // k_traj_ring, closed loop: consumer waves (the recurrences of a batch, one group per lane quarter)
     unsigned* ring_ctr;    // k_traj_ring: device-wide ticket counter (zeroed before the launch); nullptr = static batch ranges
     int ring_tb;           // batches per ticket
     int ring_parts;        // waves that share one group's row tiles (long horizons: the image of ONE group fills a batch buffer)

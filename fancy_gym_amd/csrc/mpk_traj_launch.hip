@@ -102,6 +102,10 @@ __global__ void __launch_bounds__(256) k_build_shared(const DevCfg c, const floa
     }
 }
 
+// the ring's ticket counter is zeroed in stream order in front of the launch by a kernel of ours (round 4: as a hipMemsetAsync
+// node inside captured graphs -- a dozen graphs of twenty launches alive at once -- replays faulted; a kernel node does not)
+__global__ void k_zero_u32(unsigned* p) { if (threadIdx.x == 0) *p = 0u; }
+
 #ifndef MPK_DEVICE_ONLY
 int launch_build_shared(const DevCfg& c, float init_time, const SharedTables& st, int32_t* idx_out,
                         int32_t* range_flag, void* stream) {
@@ -142,7 +146,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
                        const Tuning& tune, const ReplanDev* rp, unsigned* ticket) {
     TrajArgs ta;
     ta.nrt_magic = 0; ta.gstride = 0; ta.wt = 0; ta.flat_img = 0;
-    ta.ring_np = 0; ta.ring_ns = 0; ta.ring_m = 0; ta.ring_nbuf = 0; ta.ring_dbg = tune.ring_dbg > 0 ? tune.ring_dbg : 0; ta.burst = 0; ta.inorder = 0; ta.lean = 0; ta.wpb = 4; ta.ring_ctr = nullptr; ta.ring_tb = 0; ta.ring_parts = 1;
+    ta.ring_np = 0; ta.ring_ns = 0; ta.ring_m = 0; ta.ring_nbuf = 0; ta.ring_nc = 0; ta.ring_dbg = tune.ring_dbg > 0 ? tune.ring_dbg : 0; ta.burst = 0; ta.inorder = 0; ta.lean = 0; ta.wpb = 4; ta.ring_ctr = nullptr; ta.ring_tb = 0; ta.ring_parts = 1;
     if (rp) ta.rp = *rp;
     const bool closed = q_state != nullptr;
     ta.q_state = q_state; ta.qd_state = qd_state; ta.n_steps = n_steps; ta.plant_dt = rc ? rc->dt : 0.0;
@@ -293,10 +297,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
             ta.ring_ctr = ticket;
             ta.ring_tb = (int)((kRingTicketBytes + buf_bytes - 1) / buf_bytes);
             if (ta.ring_tb < 1) ta.ring_tb = 1;
-            if (ticket && hipMemsetAsync(ticket, 0, sizeof(unsigned), (hipStream_t)stream) != hipSuccess) {
-                set_error("hipMemsetAsync(ticket counter) failed");
-                return MPK_EHIP;
-            }
+            if (ticket) hipLaunchKernelGGL(k_zero_u32, dim3(1), dim3(64), 0, (hipStream_t)stream, ticket);
             ring = true;
             stream_mode = true; quad = 0; bulk = false;
             ta.wt = out_bytes <= kWtBytes ? 1 : 0;
@@ -307,9 +308,48 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
             blocks = (int)(batches < (long)num_cu ? batches : (long)num_cu);
         }
     }
+    // closed loop on the ring (k_traj_ring<.., closed>): producers + store engine for pos / vel, consumer waves for the recurrences
+    // (mpk_traj_ring.h).  LDS: tables + NBUF (pos | vel) batch buffers of four groups + one 4 KB action tile set per consumer.
+    bool pipe_sel = pipe;
+    if (closed && c.mp_type != MPK_MP_DMP && act && ptr_ok && TD % 4 == 0 && (c.D == 5 || c.D == 7) && c.KP <= 8 && !split &&
+        tune.ring != 0 && tune.ring != 2) {
+        const bool forced_other = tune.quad >= 0 || tune.pipe == 1 || tune.split == 1 || ov != 0 || tune.bulk >= 0;
+        const bool want = tune.ring == 1 || (tune.ring < 0 && !forced_other && !pipe && out_bytes > kRingClosedBytes);
+        // geometry by the sweep in profiles/r04_ring_closed.md: the fewer waves store, the better (one engine wave), production and
+        // recurrences need eight and four waves to keep three batch buffers turning
+        int NS = tune.ring_ns > 0 ? tune.ring_ns : 1;
+        int NP = tune.ring_np > 0 ? tune.ring_np : 8;
+        int NC = tune.ring_nc > 0 ? tune.ring_nc : 4;
+        if (NS > 4) NS = 4;
+        if (NP + NS + NC > kRingThreadsClosed / 64) NP = kRingThreadsClosed / 64 - NS - NC;
+        int M = tune.ring_m > 0 && tune.ring_m < 4 ? tune.ring_m : 4;          // groups per batch = lane quarters of a consumer
+        const int gimg = NTW * TD;
+        const size_t fixed = table_bytes + kRingSyncInts * sizeof(int);
+        const size_t stage = (size_t)NC * 4 * kStageStride * sizeof(float);
+        const size_t buf_bytes = (size_t)2 * M * gimg * sizeof(float);
+        long nbuf = fixed + stage < kLdsPerCu ? (long)((kLdsPerCu - fixed - stage) / buf_bytes) : 0;
+        if (nbuf * M > 32) nbuf = 32 / M;
+        if (nbuf > 4) nbuf = 4;
+        if (want && NP >= 1 && nbuf >= 2 && ((long)M * gimg) % 4 == 0 && 16 * c.D * NTW <= kStageStride) {
+            ta.flat_img = gimg;
+            ta.ring_np = NP; ta.ring_ns = NS; ta.ring_nc = NC; ta.ring_m = M; ta.ring_nbuf = (int)nbuf; ta.ring_parts = 1;
+            ta.ring_ctr = ticket;
+            ta.ring_tb = (int)((kRingTicketBytes + buf_bytes * 3 / 2 - 1) / (buf_bytes * 3 / 2));   // (a batch writes 1.5 x its buffer)
+            if (ta.ring_tb < 2) ta.ring_tb = 2;
+            if (ticket) hipLaunchKernelGGL(k_zero_u32, dim3(1), dim3(64), 0, (hipStream_t)stream, ticket);
+            ring = true; pipe_sel = false;
+            stream_mode = true; quad = 0; bulk = false;
+            ta.wt = out_bytes <= kWtBytes ? 1 : 0;
+            if (tune.write_through >= 0) ta.wt = tune.write_through != 0 ? 1 : 0;
+            if ((double)B * c.T * c.D * 4.0 >= 2147483648.0) ta.wt = 0;
+            lds = fixed + (size_t)nbuf * buf_bytes + stage;
+            const long batches = ((long)ta.G + M - 1) / M;
+            blocks = (int)(batches < (long)num_cu ? batches : (long)num_cu);
+        }
+    }
     if (ring) {
         // (set up above)
-    } else if (pipe) {
+    } else if (pipe_sel) {
         quad = 0; bulk = false;
         lds = table_bytes;
         const long units = (ta.G + kPipeGroups - 1) / kPipeGroups;
@@ -406,9 +446,9 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         ta.nrt_magic = NRT > 1 ? (unsigned)((1ull << 32) / (unsigned long long)NRT) + 1u : 0u;
     }
     if (blocks < 1) blocks = 1;
-    if (!stream_mode && !pipe && ta.gstride <= 0) { set_error("internal: tile-major launch without its group stride"); return MPK_EINVAL; }
+    if (!stream_mode && !pipe_sel && ta.gstride <= 0) { set_error("internal: tile-major launch without its group stride"); return MPK_EINVAL; }
     if (!stream_mode && tune.lds_pad > 0) lds = (size_t)tune.lds_pad * 1024;     // A/B runs: caps the workgroups per CU
-    if (stream_mode && !pipe && !ta.flat_img && tune.lds_pad > 0) lds += (size_t)tune.lds_pad * 1024;   // episode-major: EXTRA dynamic LDS (occupancy experiments)
+    if (stream_mode && !pipe_sel && !ta.flat_img && tune.lds_pad > 0) lds += (size_t)tune.lds_pad * 1024;   // episode-major: EXTRA dynamic LDS (occupancy experiments)
     ta.ser_blocks = 0;
     if (split) {
         // serial-role workgroups first (they are the long pole and must start first), capped at one resident round of the chip
@@ -424,6 +464,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         const bool pd = c.mp_type == MPK_MP_PRODMP;
         *kernel_name = ta.burst == 2 ? (pd ? (act ? "k_traj_flat<prodmp,act>" : "k_traj_flat<prodmp>") : (act ? "k_traj_flat<promp,act>" : "k_traj_flat<promp>"))
                      : ta.burst ? (pd ? (act ? "k_traj_burst<prodmp,act>" : "k_traj_burst<prodmp>") : (act ? "k_traj_burst<promp,act>" : "k_traj_burst<promp>"))
+                     : closed ? (pd ? "k_traj_ring<prodmp,closed>" : "k_traj_ring<promp,closed>")
                                 : (pd ? (act ? "k_traj_ring<prodmp,act>" : "k_traj_ring<prodmp>") : (act ? "k_traj_ring<promp,act>" : "k_traj_ring<promp>"));
         switch (c.mp_type) {
             case MPK_MP_PRODMP: return launch_traj_ring<MPK_MP_PRODMP>(ta, aa, ct, blocks, lds, stream);
@@ -433,13 +474,13 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     }
     switch (c.mp_type) {
         case MPK_MP_PRODMP:
-            *kernel_name = pipe ? "k_traj_pipe<prodmp,closed>" : split ? "k_traj_split<prodmp,closed>" : closed ? (quad == 4 ? "k_traj_quad<prodmp,closed>" : quad == 2 ? "k_traj_duo<prodmp,closed>" : quad == 1 ? "k_traj_mono<prodmp,closed>" : "k_traj_stream<prodmp,closed>") : ta.flat_img ? (act ? "k_traj_flat<prodmp,act>" : "k_traj_flat<prodmp>") : stream_mode ? (act ? "k_traj_stream<prodmp,act>" : "k_traj_stream<prodmp>")
+            *kernel_name = pipe_sel ? "k_traj_pipe<prodmp,closed>" : split ? "k_traj_split<prodmp,closed>" : closed ? (quad == 4 ? "k_traj_quad<prodmp,closed>" : quad == 2 ? "k_traj_duo<prodmp,closed>" : quad == 1 ? "k_traj_mono<prodmp,closed>" : "k_traj_stream<prodmp,closed>") : ta.flat_img ? (act ? "k_traj_flat<prodmp,act>" : "k_traj_flat<prodmp>") : stream_mode ? (act ? "k_traj_stream<prodmp,act>" : "k_traj_stream<prodmp>")
                                        : (act ? "k_traj_tiles<prodmp,act>" : "k_traj_tiles<prodmp>");
-            return launch_traj_ct<MPK_MP_PRODMP>(ta, aa, ct, stream_mode, write_through, bulk, quad, blocks, lds, stream, split, pipe);
+            return launch_traj_ct<MPK_MP_PRODMP>(ta, aa, ct, stream_mode, write_through, bulk, quad, blocks, lds, stream, split, pipe_sel);
         case MPK_MP_PROMP:
-            *kernel_name = pipe ? "k_traj_pipe<promp,closed>" : split ? "k_traj_split<promp,closed>" : closed ? (quad == 4 ? "k_traj_quad<promp,closed>" : quad == 2 ? "k_traj_duo<promp,closed>" : quad == 1 ? "k_traj_mono<promp,closed>" : "k_traj_stream<promp,closed>") : ta.flat_img ? (act ? "k_traj_flat<promp,act>" : "k_traj_flat<promp>") : stream_mode ? (act ? "k_traj_stream<promp,act>" : "k_traj_stream<promp>")
+            *kernel_name = pipe_sel ? "k_traj_pipe<promp,closed>" : split ? "k_traj_split<promp,closed>" : closed ? (quad == 4 ? "k_traj_quad<promp,closed>" : quad == 2 ? "k_traj_duo<promp,closed>" : quad == 1 ? "k_traj_mono<promp,closed>" : "k_traj_stream<promp,closed>") : ta.flat_img ? (act ? "k_traj_flat<promp,act>" : "k_traj_flat<promp>") : stream_mode ? (act ? "k_traj_stream<promp,act>" : "k_traj_stream<promp>")
                                        : (act ? "k_traj_tiles<promp,act>" : "k_traj_tiles<promp>");
-            return launch_traj_ct<MPK_MP_PROMP>(ta, aa, ct, stream_mode, write_through, bulk, quad, blocks, lds, stream, split, pipe);
+            return launch_traj_ct<MPK_MP_PROMP>(ta, aa, ct, stream_mode, write_through, bulk, quad, blocks, lds, stream, split, pipe_sel);
         default:
             *kernel_name = quad == 4 ? "k_traj_quad<dmp>" : quad == 2 ? "k_traj_duo<dmp>" : quad == 1 ? "k_traj_mono<dmp>" : "k_traj_stream<dmp>";
             return launch_traj_ct<MPK_MP_DMP>(ta, aa, -1, true, false, bulk, quad, blocks, lds, stream, false, false);

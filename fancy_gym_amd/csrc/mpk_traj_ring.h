@@ -25,6 +25,7 @@ namespace mpk {
 // Every spin is bounded (a protocol bug must fail a test, not hang a GPU).
 // Same tile arithmetic as k_traj_stream / k_traj_flat (same device functions): same bits.
 constexpr int kRingThreads = 768;             // launch bound (12 waves: up to 168 registers); the launcher picks (NP + NS) * 64 <= this
+constexpr int kRingThreadsClosed = 1024;      // closed loop: three roles, 93 registers: up to 16 waves
 constexpr int kRingSyncInts = 96;             // full[32] | empty[32] | tickets[8] | tickets published | pad
 constexpr unsigned kRingSpinLimit = 1u << 21; // ~0.3 s of polling with the sleep below: then give up (outputs stay unwritten)
 
@@ -126,10 +127,14 @@ __device__ __forceinline__ void ring_contract(const TrajArgs& a, const LaneMap<K
 //   * the C tile's 12 image stores: ds_write_b32 offset:((tile in pair) * 16 + row) * DC * 4 from one address register per array;
 //   * the last, partial row tile is the only one with row predicates.
 // The arithmetic is ring_contract's (the same MFMA operands and order, tile_epilogue's controller expression): same bits.
-template <int MP, int CT, int KM, int DC>
+// PROG (closed loop): `prog` counts the row tiles of the image that are COMPLETE -- the wait in front of a tile's MFMAs is
+// lgkmcnt(0), so when tile rt starts every LDS write of tile rt - 1 has retired: lane `plane` adds one there (tiles rt0 + 1 .. last),
+// the caller adds the last one after the call.  The consumers start on a batch while its later tiles are still being contracted.
+template <int MP, int CT, int KM, int DC, bool PROG = false>
 __device__ __forceinline__ void ring_contract_d(const TrajArgs& a, const LaneMap<KM>& L, const float* ap, const float* sAux,
                                                 const float (&xb)[KM], const double cp, const double cv, const Gains& gn,
-                                                float* sI, const int astride, const int rt0, const int rt1) {
+                                                float* sI, const int astride, const int rt0, const int rt1, int* prog = nullptr,
+                                                const bool plane = false) {
     // row tiles [rt0, rt1) of the group (a group of a long horizon is contracted by several waves, each its own range)
     constexpr int NOUT = MP == MPK_MP_PRODMP ? 2 : 3;
     constexpr bool ACT = CT >= 0;
@@ -156,6 +161,7 @@ __device__ __forceinline__ void ring_contract_d(const TrajArgs& a, const LaneMap
         // this tile's fragments have landed: the wait, then a (free) volatile statement per register that makes every use of `cur`
         // depend on it -- the compiler does not know that an asm ds_read's result arrives later, and volatile asms keep their order
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (PROG && rt > rt0 && plane) __hip_atomic_fetch_add(prog, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
         for (int o = 0; o < NOUT; ++o)
 #pragma unroll
@@ -249,12 +255,12 @@ __device__ __forceinline__ void ring_store_pair(const float* gbase, const unsign
 
 template <int NST, bool WT>
 __device__ __forceinline__ void ring_flush_d(const TrajArgs& a, const float* sB, const int astride, const size_t go, const int n4,
-                                             const int s, const int NS, const int lane) {
+                                             const int s, const int NS, const int lane, const int arr0 = 0, const int arr1 = NST) {
     const unsigned cstride = (unsigned)NS * 1024u;                    // bytes between this wave's chunks
     const int nfull = n4 >> 6;                                       // full chunks of the run
     const int kf = nfull > s ? (nfull - s + NS - 1) / NS : 0;        // ... of which this wave's
 #pragma unroll 1
-    for (int arr = 0; arr < NST; ++arr) {
+    for (int arr = arr0; arr < arr1; ++arr) {
         float* const outp = (arr == 0 ? a.pos : (arr == 1 ? a.vel : a.actions)) + go;
         const float* src = sB + arr * astride;
         unsigned voff = (unsigned)(s * 64 + lane) * 16u;
@@ -288,13 +294,29 @@ __device__ __forceinline__ void ring_flush_d(const TrajArgs& a, const float* sB,
     }
 }
 
+// CLOSED loop (CT >= 3; round 4, second session): a third role.  The serial recurrence (controller + plant, float64, no FMA: the
+// chain of every closed-loop kernel, 9 dependent operations per step) cannot sit on the producers -- one group per wave is four
+// times the serial instructions -- and the lane-quarter kernels (k_traj_quad / duo), which run four recurrences per wave, write
+// 896-byte pieces of 6 - 12 output streams per wave: stores alone 153 of 166 us at 65 536 episodes (profiles/r04_closed_loop.md).
+// Here:  producers   contract the (pos, vel) images of their groups, no controller, no store;
+//        the engine  writes pos and vel of a batch as two contiguous runs as soon as the batch is produced;
+//        consumers   (waves NP + NS ..): wave c takes the batches c, c + NC, ... of the workgroup and runs the FOUR recurrences of a
+//                    batch at once, one group per lane quarter, reading the desired states from the images the producers left
+//                    (offsets as immediates: DC is a compile-time constant); the actions of a row tile go through a wave-private
+//                    LDS tile and leave as one coalesced float4 store per group -- a third of the bytes in 896-byte pieces, two
+//                    thirds in 22 KB runs.  Integer replanning state, boundary-condition gather and plant state are the
+//                    consumer's, exactly as in k_traj_quad.
+// A batch buffer (pos | vel of M = 4 groups) is free again when the engine's NS waves AND the consumer have released it (NS + 1
+// increments of the slot's `empty` counter).  Same device functions as the other closed-loop kernels: same bits.
 template <int MP, int CT, int KM, int DC>
-__global__ void __launch_bounds__(kRingThreads) k_traj_ring(const TrajArgs a, const ActArgs act) {
-    static_assert(MP != MPK_MP_DMP && CT < 3, "open loop, promp / prodmp");
-    extern __shared__ __attribute__((aligned(16))) float sTab[];   // [NOUT][KP][TS] rows | [TS] aux | sync | ring
-    constexpr bool ACT = CT >= 0;
+__global__ void __launch_bounds__(CT >= 3 ? kRingThreadsClosed : kRingThreads) k_traj_ring(const TrajArgs a, const ActArgs act) {
+    static_assert(MP != MPK_MP_DMP && (CT < 3 || DC > 0), "promp / prodmp; closed loop with the DoF count compiled in");
+    extern __shared__ __attribute__((aligned(16))) float sTab[];   // [NOUT][KP][TS] rows | [TS] aux | sync | ring (| action tiles)
+    constexpr bool CLOSED = CT >= 3;
+    constexpr bool ACT = CT >= 0 && !CLOSED;                       // actions computed by the producers' epilogue (frozen state)
+    constexpr int CTP = CLOSED ? -1 : CT;                          // the contraction's controller
     constexpr int NOUT = MP == MPK_MP_PRODMP ? 2 : 3;
-    constexpr int NST = 2 + (ACT ? 1 : 0);
+    constexpr int NST = 2 + (ACT ? 1 : 0);                         // output arrays that pass through the ring
     const DevCfg& c = a.c;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -327,8 +349,10 @@ __global__ void __launch_bounds__(kRingThreads) k_traj_ring(const TrajArgs a, co
     // dispatcher hands out its workgroups in order; persistent streams drift apart.  One counter word sustains ~88 tickets / us,
     // so a ticket covers >= 2 batches (134 KB of output).  Without a counter (a.ring_ctr == nullptr; "ring_dbg" bit 2 / 4): static
     // contiguous ranges per workgroup / batch b to workgroup b % gridDim.x, for A/B runs.
-    const bool dynamic = a.ring_ctr != nullptr && !(a.ring_dbg & (4 | 16));
-    const bool compact = (a.ring_dbg & 4) != 0;
+    // Closed loop: batch b -> workgroup b % gridDim.x by default (the chip still writes inside a window of gridDim.x batches, and the
+    // consumers know their next batch without waiting for a ticket: 139 against 147 us at 65 536 episodes); "ring_dbg" 4 = tickets there.
+    const bool dynamic = a.ring_ctr != nullptr && (CLOSED ? (a.ring_dbg & 4) != 0 && !(a.ring_dbg & 16) : !(a.ring_dbg & (4 | 16)));
+    const bool compact = CLOSED ? !(a.ring_dbg & (4 | 16)) : (a.ring_dbg & 4) != 0;
     const int P = a.ring_parts > 0 ? a.ring_parts : 1;           // waves that share a group's row tiles (long horizons)
     const int TB = a.ring_tb > 0 ? a.ring_tb : 1, IPT = TB * M * P;  // batches / work units per ticket
     const int NT = (NBT + TB - 1) / TB;
@@ -407,14 +431,21 @@ __global__ void __launch_bounds__(kRingThreads) k_traj_ring(const TrajArgs a, co
             GroupIn<KM> nxt = cur;
             if (!(a.ring_dbg & 8)) nxt = load_group<MP, ACT, KM>(a, L, gx < a.G ? gx : a.G - 1);   // in flight across the whole group
             const int buf = bl % NBUF, k = bl / NBUF, slot = buf * M + j;
-            if (!ring_wait(&sEmpty[slot], k * NS)) return;        // the engine has drained use k - 1 of this slot
+            if (CLOSED && n / NP < 12) MPK_STAMP(3 * (n / NP));                     // unit start (next unit's loads issued)
+            if (!ring_wait(&sEmpty[slot], k * (NS + (CLOSED ? 1 : 0)))) return;
+            if (CLOSED && n / NP < 12) MPK_STAMP(3 * (n / NP) + 1);                 // buffer acquired   // the engine (and the consumer) have released use k - 1 of this slot
+            int pub = CLOSED ? NRT : 1;                           // what this unit adds to the slot's `full` count at its end
             if (g < a.G && !(a.ring_dbg & 1)) {
                 float* const sI = sRing + buf * BUF + j * IMG;
                 if constexpr (DC > 0) {
-                    if (a.ring_dbg & 32) ring_contract<MP, CT, KM>(a, L, ap, sAux, xb, cp, cv, gn, sI, M * IMG, rt0, rt1);
-                    else ring_contract_d<MP, CT, KM, DC>(a, L, ap, sAux, xb, cp, cv, gn, sI, M * IMG, rt0, rt1);
+                    if (a.ring_dbg & 32) ring_contract<MP, CTP, KM>(a, L, ap, sAux, xb, cp, cv, gn, sI, M * IMG, rt0, rt1);
+                    else if constexpr (CLOSED) {
+                        // (closed loop: P = 1, the unit is the whole group; tiles are published as they complete)
+                        ring_contract_d<MP, CTP, KM, DC, true>(a, L, ap, sAux, xb, cp, cv, gn, sI, M * IMG, rt0, rt1, &sFull[slot], lane == 0);
+                        pub = 1;
+                    } else ring_contract_d<MP, CTP, KM, DC>(a, L, ap, sAux, xb, cp, cv, gn, sI, M * IMG, rt0, rt1);
                 } else {
-                    ring_contract<MP, CT, KM>(a, L, ap, sAux, xb, cp, cv, gn, sI, M * IMG, rt0, rt1);
+                    ring_contract<MP, CTP, KM>(a, L, ap, sAux, xb, cp, cv, gn, sI, M * IMG, rt0, rt1);
                 }
             }
             if (nreq > 0) {                                       // wave 0 only (wave-uniform)
@@ -425,8 +456,9 @@ __global__ void __launch_bounds__(kRingThreads) k_traj_ring(const TrajArgs a, co
             // publish: every DS write of this wave has retired, then one more finished part of the slot (and wave 0's new tickets)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (CLOSED && n / NP < 12) MPK_STAMP(3 * (n / NP) + 2);                 // contracted
             if (lane == 0) {
-                __hip_atomic_fetch_add(&sFull[slot], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&sFull[slot], pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (nreq > 0) __hip_atomic_store(sTickN, requested, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             if (bx < 0) {
@@ -439,7 +471,7 @@ __global__ void __launch_bounds__(kRingThreads) k_traj_ring(const TrajArgs a, co
             cp = nxt.cp; cv = nxt.cv;
             n = nn; g = gx;
         }
-    } else {
+    } else if (!CLOSED || wave < NP + NS) {
         // ---------------- store engine: wave s of NS takes the 1 KB chunks s, s + NS, ... of every array run of every batch ----
         const int s = wave - NP;
         __builtin_amdgcn_s_setprio(3);
@@ -449,7 +481,8 @@ __global__ void __launch_bounds__(kRingThreads) k_traj_ring(const TrajArgs a, co
             if (b < 0) return;
             const int buf = bl % NBUF, k = bl / NBUF;
             for (int j = 0; j < M; ++j)
-                if (!ring_wait(&sFull[buf * M + j], (k + 1) * P)) return;
+                if (!ring_wait(&sFull[buf * M + j], (k + 1) * (CLOSED ? (T + 15) >> 4 : P))) return;   // (closed loop: `full` counts row tiles)
+            if (CLOSED && bl < 12) MPK_STAMP_AT(40 + 2 * bl, NP * 64);             // batch complete
             const long e0 = (long)b * M * NTW;
             const long left = (long)a.B - e0;
             const int ne = (int)(left < (long)(M * NTW) ? left : (long)(M * NTW));
@@ -457,6 +490,12 @@ __global__ void __launch_bounds__(kRingThreads) k_traj_ring(const TrajArgs a, co
             const int nrem = ne > 0 ? (ne * TD) & 3 : 0;          // of them; the launch's last, ragged batch may leave 1 - 3 floats)
             const float* sB = sRing + buf * BUF;
             if (a.ring_dbg & 32) ring_flush<NST, 8>(a, sB, M * IMG, (size_t)e0 * TD, n4, s, NS, lane);
+            else if (CLOSED && NS == 2 && !(a.ring_dbg & 64)) {
+                // closed loop, two engine waves: one ARRAY each (pos / vel), every run written front to back by one wave -- the fewer
+                // waves interleave their 1 KB chunks inside a run, the better the memory side likes it (profiles/r04_ring_closed.md)
+                if (a.wt) ring_flush_d<NST, true>(a, sB, M * IMG, (size_t)e0 * TD, n4, 0, 1, lane, s, s + 1);
+                else ring_flush_d<NST, false>(a, sB, M * IMG, (size_t)e0 * TD, n4, 0, 1, lane, s, s + 1);
+            }
             else if (a.wt) ring_flush_d<NST, true>(a, sB, M * IMG, (size_t)e0 * TD, n4, s, NS, lane);
             else ring_flush_d<NST, false>(a, sB, M * IMG, (size_t)e0 * TD, n4, s, NS, lane);
             if (nrem && s == 0 && lane < nrem && !(a.ring_dbg & 2)) {
@@ -469,8 +508,137 @@ __global__ void __launch_bounds__(kRingThreads) k_traj_ring(const TrajArgs a, co
             }
             // release the batch buffer: every DS read of this wave has returned (the data sit in registers or are on their way)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (CLOSED && bl < 12) MPK_STAMP_AT(41 + 2 * bl, NP * 64);             // flushed
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane < M) __hip_atomic_fetch_add(&sEmpty[buf * M + lane], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    } else {
+        // ---------------- consumers (closed loop): wave c runs the recurrences of the batches c, c + NC, ... ----------------
+        if constexpr (CLOSED) {
+            const int NC = a.ring_nc, ci = wave - NP - NS;
+            __builtin_amdgcn_s_setprio(3);                         // the chain is the critical path of a batch
+            const LaneMap<KM> L = make_lane_map<MP, KM>(a, lane);
+            const int NTW = L.NTW, NRT = (T + 15) >> 4;
+            const Gains gq = kernarg_gains(L.dvalid ? L.d : 0);
+            const double pgd = gq.pg, dgd = gq.dg, lod = __builtin_canonicalize(gq.lo), hid = __builtin_canonicalize(gq.hi);
+            // wave-private action tiles, one per group of the batch: [episode][16 rows x DC] as the transpose images of the other kernels
+            float* const sStg = sRing + NBUF * BUF + ci * (4 * kStageStride);
+            float* const sAq = sStg + L.q * kStageStride + L.bl * (16 * DC) + L.d;     // (row 0, this column) of group q's tile
+            // a lane's serial inputs for one batch: group b * M + q, column (bl, d); read one batch ahead of the recurrence (the
+            // integer replanning state of the episode is advanced at fetch time by its d == 0 lane, as in k_traj_quad)
+            struct SerialIn { double qs, qds; int nst, bq; bool on; };
+            auto load_serial = [&](const int b) {
+                SerialIn si{0.0, 0.0, 0, 0, false};
+                const int gsel = b * M + L.q;
+                si.bq = gsel * NTW + L.bl;
+                si.on = L.dvalid && L.q < M && gsel < a.G && si.bq < a.B;
+                if (si.on) {
+                    const size_t ix = (size_t)si.bq * DC + L.d;
+                    si.qs = a.q_state[ix]; si.qds = a.qd_state[ix];
+                    si.nst = T;
+                    if (a.rp.traj_steps) si.nst = replan_rule(a.rp, si.bq, T, L.d == 0);
+                    else if (a.n_steps) si.nst = min(a.n_steps[si.bq], T);
+                }
+                return si;
+            };
+            // the batch after this wave's current one, if its ticket is already known (static assignment: always)
+            auto batch_known = [&](const int bl) -> bool {
+                return !dynamic || __hip_atomic_load(sTickN, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) > bl / TB;
+            };
+            int b = batch_at(ci);
+            if (b < 0) return;
+            SerialIn sn = load_serial(b);
+            for (int bl = ci;; bl += NC) {
+                const int buf = bl % NBUF, k = bl / NBUF;
+                const SerialIn sc = sn;
+                int bnext = -3;                                    // -3: not known yet
+                if (batch_known(bl + NC)) {
+                    bnext = batch_at(bl + NC);
+                    if (bnext == -2) return;
+                    if (bnext >= 0) sn = load_serial(bnext);       // in flight across this batch's recurrence
+                }
+                if (bl / NC < 10) MPK_STAMP_AT(80 + 4 * (bl / NC), (NP + NS) * 64);    // batch start
+                const bool serial = sc.on;
+                const int bq = sc.bq, nst = sc.nst;
+                double qs = sc.qs, qds = sc.qds;
+                const int tcond = (serial && a.rp.cond_pos) ? min(max(nst - 1, 0), T - 1) : -1;
+                const float* const sP = sRing + buf * BUF + (L.q < M ? L.q : 0) * IMG + L.bl * TD + L.d;   // desired pos, step 0
+                const float* const sV = sP + M * IMG;
+                int seen = 0;                                      // row tiles of the batch known to be complete (minimum over its groups)
+#pragma unroll 1
+                for (int rt = 0; rt < NRT; ++rt) {
+                    const int rows = min(16, T - rt * 16);
+                    // tile rt of every group of the batch has been contracted (`full` counts row tiles: k * NRT + rt + 1)
+                    if (seen <= rt) {
+                        unsigned spins = 0;
+                        for (;;) {
+                            int mn = 1 << 30;
+                            for (int j = 0; j < M; ++j)
+                                mn = min(mn, __hip_atomic_load(&sFull[buf * M + j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+                            seen = mn - k * NRT;
+                            if (seen > rt) break;
+                            __builtin_amdgcn_s_sleep(2);
+                            if (++spins > kRingSpinLimit) return;
+                        }
+                    }
+                    if (bl / NC == 2) MPK_STAMP_AT(120 + 3 * rt, (NP + NS) * 64);                // (third batch of consumer 0: per tile)
+                    if (rt == 0 && bl / NC < 10) MPK_STAMP_AT(81 + 4 * (bl / NC), (NP + NS) * 64);   // tile 0 there
+                    if (rt == NRT - 1 && bl / NC < 10) MPK_STAMP_AT(82 + 4 * (bl / NC), (NP + NS) * 64);   // last tile there
+                    if (tcond >= rt * 16 && tcond < rt * 16 + 16) { // condition_on_desired: the desired state at the last executed step
+                        const size_t si = (size_t)bq * DC + L.d;
+                        a.rp.cond_pos[si] = sP[tcond * DC];
+                        a.rp.cond_vel[si] = sV[tcond * DC];
+                    }
+                    if (!(a.ring_dbg & 1)) {
+                        if (__any(serial && rt * 16 < nst)) {
+                            const bool full_tile = tile_fully_executed(serial, nst, rt * 16);
+                            if (serial) {
+                                if (full_tile)
+                                    pd_tile_steps<CT - 3, false>(sP + rt * 16 * DC, sV + rt * 16 * DC, sAq, DC, rt * 16, nst, pgd, dgd, lod, hid,
+                                                                 a.plant_dt, qs, qds);
+                                else
+                                    pd_tile_steps<CT - 3, true>(sP + rt * 16 * DC, sV + rt * 16 * DC, sAq, DC, rt * 16, nst, pgd, dgd, lod, hid,
+                                                                a.plant_dt, qs, qds);
+                            }
+                        } else if (serial) {                       // no episode of the batch executes a step of this tile: actions 0
+#pragma unroll
+                            for (int tl = 0; tl < 16; ++tl) sAq[tl * DC] = 0.0f;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (bl / NC == 2) MPK_STAMP_AT(121 + 3 * rt, (NP + NS) * 64);
+                    // the action tiles of the batch's groups: one coalesced float4 store per group (T * D is a multiple of 4 here, so
+                    // every 16-byte chunk of a tile segment is whole)
+                    if (!(a.ring_dbg & 2)) {
+#pragma unroll 1
+                        for (int j = 0; j < M; ++j) {
+                            const int bb = (b * M + j) * NTW + L.sseg;
+                            if (L.sseg < NTW && bb < a.B && L.w4 < rows * DC) {
+                                const f32x4 v = *reinterpret_cast<const f32x4*>(sStg + j * kStageStride + L.rofs);
+                                float* const dst = a.actions + ((size_t)bb * T + rt * 16) * DC + L.w4;
+                                if (a.wt) store16<true>(dst, v); else store16<false>(dst, v);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (bl / NC == 2) MPK_STAMP_AT(122 + 3 * rt, (NP + NS) * 64);
+                }
+                if (serial) {
+                    const size_t si = (size_t)bq * DC + L.d;
+                    a.q_state[si] = qs; a.qd_state[si] = qds;
+                }
+                // release the batch buffer: every image read of this wave has returned
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (bl / NC < 10) MPK_STAMP_AT(83 + 4 * (bl / NC), (NP + NS) * 64);    // batch done
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane < M) __hip_atomic_fetch_add(&sEmpty[buf * M + lane], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (bnext == -3) {                                 // the next batch's ticket was not out when this one started
+                    bnext = batch_at(bl + NC);
+                    if (bnext >= 0) sn = load_serial(bnext);
+                }
+                if (bnext < 0) return;
+                b = bnext;
+            }
         }
     }
 }

@@ -7,13 +7,24 @@ namespace mpk {
 #ifndef MPK_DEVICE_ONLY
 template <int MP, int CT>
 static int launch_ring_t(const TrajArgs& ta, const ActArgs& aa, int blocks, size_t lds, void* stream) {
-    if constexpr (MP == MPK_MP_DMP || CT >= 3) {
-        // the serial-recurrence variants stay on k_traj_quad / duo / pipe: on the ring a producer wave runs ONE group's chain (four
-        // times the serial instructions of the lane-quarter kernels: DMP 386 vs 196 us, closed loop 816 vs 165 us at B = 65536),
-        // and four groups per wave need a whole batch buffer per producer, which the CU's LDS does not have (profiles/r04_ring.md)
+    if constexpr (MP == MPK_MP_DMP) {
         (void)ta; (void)aa; (void)blocks; (void)lds; (void)stream;
-        set_error("internal: k_traj_ring is open loop, promp / prodmp");
+        set_error("internal: k_traj_ring is promp / prodmp");
         return MPK_EINVAL;
+    } else if constexpr (CT >= 3) {
+        // closed loop: producers + store engine + consumer waves (one group's recurrence per lane quarter); the DoF count is compiled
+        // in (the launcher sends 5 or 7 DoF with <= 8 contraction columns here and everything else to k_traj_quad / duo / pipe)
+        const dim3 g(blocks), br((unsigned)(ta.ring_np + ta.ring_ns + ta.ring_nc) * 64u);
+        const int km = ta.c.KP / 4;
+        auto go = [&](auto kern) {
+            if (lds > 48 * 1024) (void)allow_full_lds(kern);
+            hipLaunchKernelGGL(kern, g, br, lds, (hipStream_t)stream, ta, aa);
+        };
+        if (km > 2 || (ta.c.D != 5 && ta.c.D != 7)) { set_error("internal: closed-loop k_traj_ring takes 5 or 7 DoF"); return MPK_EINVAL; }
+        if (ta.c.D == 7) { if (km == 1) go(k_traj_ring<MP, CT, 1, 7>); else go(k_traj_ring<MP, CT, 2, 7>); }
+        else { if (km == 1) go(k_traj_ring<MP, CT, 1, 5>); else go(k_traj_ring<MP, CT, 2, 5>); }
+        MPK_LAUNCH_CHECK();
+        return MPK_OK;
     } else {
     const dim3 g(blocks);
     hipStream_t s = (hipStream_t)stream;

@@ -220,12 +220,16 @@ int mpk_set_duration(mpk_handle h, double duration, double dt);
  *                   shared phase; automatic where the outputs of a launch exceed the caches), 2 its short-lived-workgroup
  *                   variant (k_traj_burst; never chosen automatically).  A shape whose whole-trajectory images do not fit the LDS
  *                   falls through to the other kernels.  Launch geometry of a "ring" launch:
+ *                   Closed loop (mpk_trajectory_rollout / mpk_replan_step, promp / prodmp, 5 or 7 DoF, T * D a multiple of 4):
+ *                   the same kernel with a third role, consumer waves that run the recurrences of a batch (one group per lane
+ *                   quarter); automatic where the outputs of the step exceed the caches, 1 forces it.
  *   "ring_np"       1 .. 14 producer waves per workgroup (8)
- *   "ring_ns"       1 .. 8 store-engine waves per workgroup (2)
+ *   "ring_nc"       1 .. 6 consumer waves per workgroup (closed loop only: 4)
+ *   "ring_ns"       1 .. 8 store-engine waves per workgroup (2; closed loop: 1)
  *   "ring_m"        1 .. 8 episode groups per batch buffer (the largest <= 4 that leaves two buffers in 160 KB)
  *   "ring_parts"    1 .. 8 producer waves sharing the row tiles of one group (by the buffers: all producers stay busy)
  *   "ring_dbg"      bit mask for A/B runs.  Result-preserving: 4 batches b -> workgroup b % grid instead of tickets from the
- *                   device counter, 16 contiguous batch ranges per workgroup (k_traj_burst: A fragments from the table in
+ *                   device counter (closed loop: the other way round -- b % grid is its default, 4 = tickets), 16 contiguous batch ranges per workgroup (k_traj_burst: A fragments from the table in
  *                   L2), 32 the generic contraction / flush loops instead of the compile-time-DoF ones, 64 k_traj_flat without its
  *                   compile-time-DoF variant.  ABLATIONS that leave
  *                   outputs unwritten, measurements only: 1 no production, 2 no stores, 8 no input loads.

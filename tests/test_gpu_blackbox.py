@@ -495,6 +495,80 @@ def test_register_lean_pipeline_kernel_is_bit_identical(cfg, B, mpk_option):
         assert torch.equal(x, y)
 
 
+RINGC_OPTS = [dict(), dict(ring_nc=1), dict(ring_nc=2, ring_np=6, ring_ns=1), dict(ring_nc=4, ring_np=2), dict(ring_m=2),
+              dict(ring_dbg=4), dict(ring_dbg=16, ring_nc=5, ring_np=1), dict(ring_dbg=32), dict(ring_m=3, ring_nc=2)]
+
+
+@pytest.mark.parametrize("cfg", [CFG2, CFG4], ids=["prodmp", "prodmp_replan"])
+@pytest.mark.parametrize("controller", ["motor", "position", "velocity"])
+@pytest.mark.parametrize("B", [1, 9, 263, 4104, 20001])
+def test_closed_loop_on_the_ring_is_bit_identical(cfg, controller, B, mpk_option):
+    """k_traj_ring<.., closed> (producers, store engine for pos / vel, consumer waves running four recurrences per batch) under
+    several launch geometries and batch orders == the lane-quarter / pipeline kernels == trajectory + rollout as separate kernels;
+    also one replanning step with random integer states and the boundary-condition gather"""
+    pc, bc, tc, dt, dur = cfg
+    eng = make_engine(pc, bc, tc, dt, dur)
+    params, ip, iv = inputs(pc, bc, tc, B, seed=B)
+    rng = np.random.default_rng(B)
+    q0, qd0 = rng.uniform(-1, 1, (B, 7)), rng.uniform(-0.2, 0.2, (B, 7))
+    T = eng.num_steps
+    n_steps = torch.tensor(rng.integers(0, T + 1, B).astype(np.int32))
+    spec = RolloutSpec(controller, 7, PG, DG, -0.9, 0.9, plant="double_integrator", dt=dt)
+    keys = ("ring_nc", "ring_np", "ring_ns", "ring_m", "ring_dbg")
+
+    def run(ns):
+        q, qd = torch.tensor(q0, device="cuda"), torch.tensor(qd0, device="cuda")
+        out = eng.trajectory_rollout(params, ip, iv, spec, q, qd, n_steps=ns, init_time=0.25)
+        return [x.clone() for x in out] + [q, qd]
+    mpk_option("ring", 0)
+    ref, ref_full = run(n_steps), run(None)
+    assert "k_traj_ring" not in eng.last_kernel()
+    p2, v2 = eng.trajectory(params, ip, iv, 0.25)
+    q2, qd2 = torch.tensor(q0, device="cuda"), torch.tensor(qd0, device="cuda")
+    a2 = eng.pd_rollout(spec, p2, v2, q2, qd2, n_steps=n_steps)
+    for x, y in zip(ref, [p2, v2, a2, q2, qd2]):
+        assert torch.equal(x, y)
+    mpk_option("ring", 1)
+    for opts in (RINGC_OPTS if controller == "motor" else RINGC_OPTS[:2]):
+        for k in keys:
+            mpk_option(k, opts.get(k, -1))
+        got = run(n_steps)
+        assert eng.last_kernel() == "k_traj_ring<prodmp,closed>", eng.last_kernel()
+        for i, (x, y) in enumerate(zip(got, ref)):
+            assert torch.equal(x, y), (opts, i)
+        for i, (x, y) in enumerate(zip(run(None), ref_full)):
+            assert torch.equal(x, y), (opts, i, "full horizon")
+    for k in keys:
+        mpk_option(k, -1)
+    # one replanning step: integer state, plan, rollout, condition gather
+    every, mpt, horizon = 25, 3, 2 * T
+    ts0 = rng.integers(0, horizon, B).astype(np.int32); ps0 = rng.integers(0, 4, B).astype(np.int32)
+    dn0 = (rng.random(B) < 0.2).astype(np.uint8)
+    res = []
+    for ring in (1, 0):
+        mpk_option("ring", ring)
+        st = (torch.tensor(q0, device="cuda"), torch.tensor(qd0, device="cuda"), torch.tensor(ts0, device="cuda"),
+              torch.tensor(ps0, device="cuda"), torch.tensor(dn0, device="cuda"))
+        r = eng.replan_step(params, ip, iv, spec, *st, every, mpt, horizon, init_time=0.0, condition=True)
+        assert ("k_traj_ring" in eng.last_kernel()) == (ring == 1), eng.last_kernel()
+        res.append([r[k].clone() for k in ("pos", "vel", "actions", "seg_len", "done", "cond_pos", "cond_vel")] + list(st))
+    for i, (x, y) in enumerate(zip(*res)):
+        assert torch.equal(x, y), i
+
+
+def test_closed_loop_ring_declines_shapes_it_does_not_take(mpk_option):
+    """cfg5 (350 x 7: T * D = 2 mod 4) stays on the lane-quarter kernels even when the ring is forced"""
+    pc, bc, tc, dt, dur = CFG5
+    eng = make_engine(pc, bc, tc, dt, dur)
+    B = 300
+    params, ip, iv = inputs(pc, bc, tc, B, seed=3)
+    spec = RolloutSpec("motor", 7, PG, DG, -0.9, 0.9, plant="double_integrator", dt=dt)
+    q, qd = torch.zeros((B, 7), dtype=torch.float64, device="cuda"), torch.zeros((B, 7), dtype=torch.float64, device="cuda")
+    mpk_option("ring", 1)
+    eng.trajectory_rollout(params, ip, iv, spec, q, qd)
+    assert "k_traj_ring" not in eng.last_kernel() and eng.last_kernel().endswith("closed>")
+
+
 def test_four_groups_per_wave_while_the_outputs_fit_the_memory_side_cache():
     """the launcher's rule for the serial-recurrence kernels (profiles/r04_closed_loop.md): closed loop at 16 384 / 32 768 and cfg3
     at its BASELINE size on k_traj_quad, smaller and HBM-streaming launches on k_traj_duo, a few thousand closed-loop episodes on

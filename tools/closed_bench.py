@@ -4,7 +4,7 @@ The fused closed-loop step (BlackBoxWrapper.step on the GPU-resident double inte
   full   mpk_trajectory_rollout, cfg2 shape, all 100 steps executed
   plan   mpk_replan_step, cfg4 shape (P = 35, 25 of 100 steps executed, condition gather, integer state)
 timed as a captured graph of 20 launches (HIP events), per batch size and per option set.
-    python tools/closed_bench.py [B ...]        (MPK_LIB=<other build> for A/B runs of two builds)
+    python tools/closed_bench.py [--ring] [B ...]        (MPK_LIB=<other build> for A/B runs of two builds; --ring: the ring's geometries)
 """
 import os
 import sys
@@ -50,7 +50,8 @@ def time_rows(graphs, reps=20, rounds=9, busy_ms=60.0):
     """Every row of a (batch, step) pair is warmed by the time the GPU was BUSY with it (event time, not wall time: the shader
     clock needs ~20 ms of load to settle, profiles/r02_clock_probe.md), and the timed rounds alternate over the rows, so that no
     row owns the first or the last slot (round 3 measured "auto" 32.6 us first and 29.8 us last at plan / 16 384)."""
-    for g in graphs:
+    for gi, g in enumerate(graphs):
+        if os.environ.get('CB_TRACE'): print(f'(warming row {gi})', file=sys.stderr, flush=True)
         busy = 0.0
         while busy < busy_ms:
             busy += replay_ms(g)
@@ -58,6 +59,7 @@ def time_rows(graphs, reps=20, rounds=9, busy_ms=60.0):
     for r in range(rounds):
         order = range(len(graphs)) if r % 2 == 0 else reversed(range(len(graphs)))
         for i in order:
+            if os.environ.get('CB_TRACE'): print(f'(round {r} row {i})', file=sys.stderr, flush=True)
             replay_ms(graphs[i])                        # one untimed replay: the row before left other lines in the caches
             ts[i].append(replay_ms(graphs[i]) * 1e-3 / reps)
     return [float(np.median(t)) for t in ts]
@@ -74,11 +76,33 @@ def main():
     dev = torch.device("cuda", 0)
     g = torch.Generator().manual_seed(0)
     variants = [("auto", {}), ("pipe=1", {"pipe": 1}), ("pipe=0", {"pipe": 0}), ("split", {"split": 1}), ("quad", {"quad": 2}), ("duo", {"quad": 3}), ("mono", {"quad": 4}), ("auto (again)", {})]
+    if "--ring" in sys.argv:      # the closed loop on the ring (k_traj_ring<.., closed>) and its launch geometries against the lane-quarter kernels
+        R = {"ring": 1}
+        variants = [("auto", {}), ("quad", {"quad": 2}), ("duo", {"quad": 3}), ("ring", dict(R)), ("ring tickets", dict(R, ring_dbg=4)),
+                    ("ring ranges", dict(R, ring_dbg=16)), ("ring ns2", dict(R, ring_ns=2)), ("ring nc3", dict(R, ring_nc=3)), ("auto (again)", {})]
+    if "--ring-sweep" in sys.argv:
+        variants = [("duo", {"quad": 3})]
+        for dbg in (0, 4):
+            for np_ in (6, 8, 10):
+                for ns in (1, 2, 3):
+                    for nc in (3, 4):
+                        variants.append((f"np{np_} ns{ns} nc{nc}{' static' if dbg else ''}", dict(ring=1, ring_np=np_, ring_ns=ns, ring_nc=nc, ring_dbg=dbg)))
+        if "--full-only" in sys.argv:
+            pass
+    if "--ring-ablate" in sys.argv:   # measurements only (outputs unwritten): ring_dbg 1 no production / chain, 2 no stores
+        base = {"ring": 1}
+        variants = [("ring", dict(base)), ("ring static", dict(base, ring_dbg=4)), ("no compute", dict(base, ring_dbg=1)), ("no stores", dict(base, ring_dbg=2)),
+                    ("neither", dict(base, ring_dbg=3)), ("static no compute", dict(base, ring_dbg=5)), ("static no stores", dict(base, ring_dbg=6)),
+                    ("static neither", dict(base, ring_dbg=7)), ("np7 ns1 nc4", dict(base, ring_np=7, ring_ns=1, ring_nc=4)),
+                    ("np6 ns1 nc4 static", dict(base, ring_np=6, ring_ns=1, ring_nc=4, ring_dbg=4)), ("np7 ns1 nc4 static", dict(base, ring_np=7, ring_ns=1, ring_nc=4, ring_dbg=4)),
+                    ("np8 ns1 nc3 static", dict(base, ring_np=8, ring_ns=1, ring_nc=3, ring_dbg=4))]
     print(f"lib: {_lib.LIB_PATH}")
     print("| step | batch | variant | kernel | us | episodes-or-plans/s | GB/s (alg.) | of 8 TB/s |")
     print("|---|---|---|---|---|---|---|---|")
     for B in batches:
         for name, kw, P, nbytes in (("full", CFG2, 42, 224 + 3 * 2800), ("plan", CFG4, 35, 196 + 3 * 2800)):
+            if "--full-only" in sys.argv and name != "full":
+                continue
             eng = TrajectoryEngine(device=0, **kw)
             params = torch.randn((B, P), generator=g).to(dev)
             ip = (torch.rand((B, 7), generator=g) * 2 - 1).to(dev)
@@ -103,6 +127,7 @@ def main():
                     _lib.set_option(k, v)
                 try:
                     rows.append((vn, capture(fn), eng.last_kernel()))     # the options are read at launch = at capture
+                    print(f"(captured {name} {B} {vn})", file=sys.stderr, flush=True)
                 except Exception as e:  # noqa: BLE001
                     print(f"| {name} | {B} | {vn} | failed: {e} |")
             times = time_rows([r[1] for r in rows])

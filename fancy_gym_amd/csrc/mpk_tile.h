@@ -56,6 +56,7 @@ struct TrajArgs {
     // k_traj_ring (ring_np > 0): producer waves, store-engine waves, episode groups per batch, batch buffers in the LDS ring
     int ring_np, ring_ns, ring_m, ring_nbuf;
     int ring_nc;           // k_traj_ring, closed loop: consumer waves (the recurrences of a batch, one group per lane quarter)
+    int ring_aw;           // ... 1: one action-writer wave per consumer (the consumers never issue a global store)
     unsigned* ring_ctr;    // k_traj_ring: device-wide ticket counter (zeroed before the launch); nullptr = static batch ranges
     int ring_tb;           // batches per ticket
     int ring_parts;        // waves that share one group's row tiles (long horizons: the image of ONE group fills a batch buffer)

@@ -146,7 +146,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
                        const Tuning& tune, const ReplanDev* rp, unsigned* ticket) {
     TrajArgs ta;
     ta.nrt_magic = 0; ta.gstride = 0; ta.wt = 0; ta.flat_img = 0;
-    ta.ring_np = 0; ta.ring_ns = 0; ta.ring_m = 0; ta.ring_nbuf = 0; ta.ring_nc = 0; ta.ring_dbg = tune.ring_dbg > 0 ? tune.ring_dbg : 0; ta.burst = 0; ta.inorder = 0; ta.lean = 0; ta.wpb = 4; ta.ring_ctr = nullptr; ta.ring_tb = 0; ta.ring_parts = 1;
+    ta.ring_np = 0; ta.ring_ns = 0; ta.ring_m = 0; ta.ring_nbuf = 0; ta.ring_nc = 0; ta.ring_aw = 0; ta.ring_dbg = tune.ring_dbg > 0 ? tune.ring_dbg : 0; ta.burst = 0; ta.inorder = 0; ta.lean = 0; ta.wpb = 4; ta.ring_ctr = nullptr; ta.ring_tb = 0; ta.ring_parts = 1;
     if (rp) ta.rp = *rp;
     const bool closed = q_state != nullptr;
     ta.q_state = q_state; ta.qd_state = qd_state; ta.n_steps = n_steps; ta.plant_dt = rc ? rc->dt : 0.0;
@@ -319,9 +319,10 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         // recurrences need eight and four waves to keep three batch buffers turning
         int NS = tune.ring_ns > 0 ? tune.ring_ns : 1;
         int NP = tune.ring_np > 0 ? tune.ring_np : 8;
-        int NC = tune.ring_nc > 0 ? tune.ring_nc : 4;
+        int NC = tune.ring_nc > 0 ? tune.ring_nc : 3;
         if (NS > 4) NS = 4;
-        if (NP + NS + NC > kRingThreadsClosed / 64) NP = kRingThreadsClosed / 64 - NS - NC;
+        const int AW = (ta.ring_dbg & 8) ? 0 : 1;                            // "ring_dbg" 8: the consumers store their action tiles themselves
+        if (NP + NS + NC * (1 + AW) > kRingThreadsClosed / 64) NP = kRingThreadsClosed / 64 - NS - NC * (1 + AW);
         int M = tune.ring_m > 0 && tune.ring_m < 4 ? tune.ring_m : 4;          // groups per batch = lane quarters of a consumer
         const int gimg = NTW * TD;
         const size_t fixed = table_bytes + kRingSyncInts * sizeof(int);
@@ -332,7 +333,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         if (nbuf > 4) nbuf = 4;
         if (want && NP >= 1 && nbuf >= 2 && ((long)M * gimg) % 4 == 0 && 16 * c.D * NTW <= kStageStride) {
             ta.flat_img = gimg;
-            ta.ring_np = NP; ta.ring_ns = NS; ta.ring_nc = NC; ta.ring_m = M; ta.ring_nbuf = (int)nbuf; ta.ring_parts = 1;
+            ta.ring_np = NP; ta.ring_ns = NS; ta.ring_nc = NC; ta.ring_aw = AW; ta.ring_m = M; ta.ring_nbuf = (int)nbuf; ta.ring_parts = 1;
             ta.ring_ctr = ticket;
             ta.ring_tb = (int)((kRingTicketBytes + buf_bytes * 3 / 2 - 1) / (buf_bytes * 3 / 2));   // (a batch writes 1.5 x its buffer)
             if (ta.ring_tb < 2) ta.ring_tb = 2;

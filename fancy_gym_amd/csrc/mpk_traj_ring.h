@@ -429,7 +429,7 @@ __global__ void __launch_bounds__(CT >= 3 ? kRingThreadsClosed : kRingThreads) k
             if (bx == -2) return;
             const int gx = bx >= 0 ? bx * M + (nn % MP_) / P : g;
             GroupIn<KM> nxt = cur;
-            if (!(a.ring_dbg & 8)) nxt = load_group<MP, ACT, KM>(a, L, gx < a.G ? gx : a.G - 1);   // in flight across the whole group
+            if (CLOSED || !(a.ring_dbg & 8)) nxt = load_group<MP, ACT, KM>(a, L, gx < a.G ? gx : a.G - 1);   // in flight across the whole group
             const int buf = bl % NBUF, k = bl / NBUF, slot = buf * M + j;
             if (CLOSED && n / NP < 12) MPK_STAMP(3 * (n / NP));                     // unit start (next unit's loads issued)
             if (!ring_wait(&sEmpty[slot], k * (NS + (CLOSED ? 1 : 0)))) return;
@@ -515,14 +515,59 @@ __global__ void __launch_bounds__(CT >= 3 ? kRingThreadsClosed : kRingThreads) k
     } else {
         // ---------------- consumers (closed loop): wave c runs the recurrences of the batches c, c + NC, ... ----------------
         if constexpr (CLOSED) {
-            const int NC = a.ring_nc, ci = wave - NP - NS;
-            __builtin_amdgcn_s_setprio(3);                         // the chain is the critical path of a batch
+            const int NC = a.ring_nc;
+            const bool writer = wave >= NP + NS + NC;              // action writer of consumer ci (a.ring_aw: one per consumer)
+            const int ci = wave - NP - NS - (writer ? NC : 0);
             const LaneMap<KM> L = make_lane_map<MP, KM>(a, lane);
             const int NTW = L.NTW, NRT = (T + 15) >> 4;
+            float* const sStg = sRing + NBUF * BUF + ci * (4 * kStageStride);
+            int* const sPost = sSync + 76 + ci;                    // action tiles the consumer has left in its staging tile set
+            int* const sTake = sSync + 84 + ci;                    // ... the writer has pulled into registers
+            if (writer) {
+                // ---------------- action writers: the consumer's tile sets -> global memory.  A store instruction waits at issue while
+                // the CU's memory pipeline is full -- and the store engine keeps it full on purpose: inside the consumer each of the four
+                // stores of a tile took ~250 - 600 cycles, a third of the recurrence's time (profiles/r04_ring_closed.md).  Here the
+                // waiting is a wave's that has nothing else to do: it walks the consumer's batch sequence, pulls a posted tile set into
+                // registers, hands the staging back at once and then issues the stores.
+                int n = 0;                                         // tile sets taken so far
+                for (int bl = ci;; bl += NC) {
+                    const int b = batch_at(bl);
+                    if (b < 0) return;
+#pragma unroll 1
+                    for (int rt = 0; rt < NRT; ++rt, ++n) {
+                        const int rows = min(16, T - rt * 16);
+                        if (!ring_wait(sPost, n + 1)) return;
+                        f32x4 v[4];
+                        bool on[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int bb = (b * M + j) * NTW + L.sseg;
+                            on[j] = j < M && L.sseg < NTW && bb < a.B && L.w4 < rows * DC;
+                            v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            if (on[j]) v[j] = *reinterpret_cast<const f32x4*>(sStg + j * kStageStride + L.rofs);
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) __hip_atomic_store(sTake, n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (!(a.ring_dbg & 2)) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                if (on[j]) {
+                                    const int bb = (b * M + j) * NTW + L.sseg;
+                                    float* const dst = a.actions + ((size_t)bb * T + rt * 16) * DC + L.w4;
+                                    if (a.wt) store16<true>(dst, v[j]); else store16<false>(dst, v[j]);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            const bool handoff = a.ring_aw != 0;                   // the tile sets leave through the writer wave
+            int ntile = 0;                                         // tile sets posted so far
+            __builtin_amdgcn_s_setprio(3);                         // the chain is the critical path of a batch
             const Gains gq = kernarg_gains(L.dvalid ? L.d : 0);
             const double pgd = gq.pg, dgd = gq.dg, lod = __builtin_canonicalize(gq.lo), hid = __builtin_canonicalize(gq.hi);
             // wave-private action tiles, one per group of the batch: [episode][16 rows x DC] as the transpose images of the other kernels
-            float* const sStg = sRing + NBUF * BUF + ci * (4 * kStageStride);
             float* const sAq = sStg + L.q * kStageStride + L.bl * (16 * DC) + L.d;     // (row 0, this column) of group q's tile
             // a lane's serial inputs for one batch: group b * M + q, column (bl, d); read one batch ahead of the recurrence (the
             // integer replanning state of the episode is advanced at fetch time by its d == 0 lane, as in k_traj_quad)
@@ -581,7 +626,6 @@ __global__ void __launch_bounds__(CT >= 3 ? kRingThreadsClosed : kRingThreads) k
                             if (++spins > kRingSpinLimit) return;
                         }
                     }
-                    if (bl / NC == 2) MPK_STAMP_AT(120 + 3 * rt, (NP + NS) * 64);                // (third batch of consumer 0: per tile)
                     if (rt == 0 && bl / NC < 10) MPK_STAMP_AT(81 + 4 * (bl / NC), (NP + NS) * 64);   // tile 0 there
                     if (rt == NRT - 1 && bl / NC < 10) MPK_STAMP_AT(82 + 4 * (bl / NC), (NP + NS) * 64);   // last tile there
                     if (tcond >= rt * 16 && tcond < rt * 16 + 16) { // condition_on_desired: the desired state at the last executed step
@@ -589,6 +633,7 @@ __global__ void __launch_bounds__(CT >= 3 ? kRingThreadsClosed : kRingThreads) k
                         a.rp.cond_pos[si] = sP[tcond * DC];
                         a.rp.cond_vel[si] = sV[tcond * DC];
                     }
+                    if (handoff && !ring_wait(sTake, ntile)) return;         // the writer holds the previous tile set in registers
                     if (!(a.ring_dbg & 1)) {
                         if (__any(serial && rt * 16 < nst)) {
                             const bool full_tile = tile_fully_executed(serial, nst, rt * 16);
@@ -606,10 +651,15 @@ __global__ void __launch_bounds__(CT >= 3 ? kRingThreadsClosed : kRingThreads) k
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
-                    if (bl / NC == 2) MPK_STAMP_AT(121 + 3 * rt, (NP + NS) * 64);
-                    // the action tiles of the batch's groups: one coalesced float4 store per group (T * D is a multiple of 4 here, so
-                    // every 16-byte chunk of a tile segment is whole)
-                    if (!(a.ring_dbg & 2)) {
+                    ++ntile;
+                    if (handoff) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) __hip_atomic_store(sPost, ntile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    // without a writer: the action tiles of the batch's groups as one coalesced float4 store per group (T * D is a
+                    // multiple of 4 here, so every 16-byte chunk of a tile segment is whole)
+                    if (!handoff && !(a.ring_dbg & 2)) {
 #pragma unroll 1
                         for (int j = 0; j < M; ++j) {
                             const int bb = (b * M + j) * NTW + L.sseg;
@@ -621,7 +671,6 @@ __global__ void __launch_bounds__(CT >= 3 ? kRingThreadsClosed : kRingThreads) k
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
-                    if (bl / NC == 2) MPK_STAMP_AT(122 + 3 * rt, (NP + NS) * 64);
                 }
                 if (serial) {
                     const size_t si = (size_t)bq * DC + L.d;

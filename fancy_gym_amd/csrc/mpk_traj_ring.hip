@@ -14,7 +14,7 @@ static int launch_ring_t(const TrajArgs& ta, const ActArgs& aa, int blocks, size
     } else if constexpr (CT >= 3) {
         // closed loop: producers + store engine + consumer waves (one group's recurrence per lane quarter); the DoF count is compiled
         // in (the launcher sends 5 or 7 DoF with <= 8 contraction columns here and everything else to k_traj_quad / duo / pipe)
-        const dim3 g(blocks), br((unsigned)(ta.ring_np + ta.ring_ns + ta.ring_nc) * 64u);
+        const dim3 g(blocks), br((unsigned)(ta.ring_np + ta.ring_ns + ta.ring_nc * (1 + ta.ring_aw)) * 64u);
         const int km = ta.c.KP / 4;
         auto go = [&](auto kern) {
             if (lds > 48 * 1024) (void)allow_full_lds(kern);

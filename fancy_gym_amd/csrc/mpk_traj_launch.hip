@@ -327,6 +327,8 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         const int gimg = NTW * TD;
         const size_t fixed = table_bytes + kRingSyncInts * sizeof(int);
         const size_t stage = (size_t)NC * 4 * kStageStride * sizeof(float);
+        // (longer horizons: fewer groups per batch, while that leaves at least two batch buffers)
+        while (M > 1 && fixed + stage + 2 * (size_t)2 * M * gimg * sizeof(float) > kLdsPerCu) --M;
         const size_t buf_bytes = (size_t)2 * M * gimg * sizeof(float);
         long nbuf = fixed + stage < kLdsPerCu ? (long)((kLdsPerCu - fixed - stage) / buf_bytes) : 0;
         if (nbuf * M > 32) nbuf = 32 / M;

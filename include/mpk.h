@@ -229,10 +229,13 @@ int mpk_set_duration(mpk_handle h, double duration, double dt);
  *   "ring_m"        1 .. 8 episode groups per batch buffer (the largest <= 4 that leaves two buffers in 160 KB)
  *   "ring_parts"    1 .. 8 producer waves sharing the row tiles of one group (by the buffers: all producers stay busy)
  *   "ring_dbg"      bit mask for A/B runs.  Result-preserving: 4 batches b -> workgroup b % grid instead of tickets from the
- *                   device counter (closed loop: the other way round -- b % grid is its default, 4 = tickets), 16 contiguous batch ranges per workgroup (k_traj_burst: A fragments from the table in
- *                   L2), 32 the generic contraction / flush loops instead of the compile-time-DoF ones, 64 k_traj_flat without its
- *                   compile-time-DoF variant.  ABLATIONS that leave
- *                   outputs unwritten, measurements only: 1 no production, 2 no stores, 8 no input loads.
+ *                   device counter (closed loop: the other way round -- b % grid is its default, 4 = tickets), 16 contiguous batch
+ *                   ranges per workgroup (k_traj_burst: A fragments from the table in L2), 32 the generic contraction / flush
+ *                   loops instead of the compile-time-DoF ones, 64 k_traj_flat without its compile-time-DoF variant (closed loop
+ *                   with two engine waves: 1 KB chunks interleaved instead of one array per wave); closed loop only: 8 the
+ *                   consumer waves store their action tiles themselves (no action-writer waves).  ABLATIONS that leave outputs
+ *                   unwritten, measurements only: 1 no production (closed loop: no recurrence either), 2 no stores, 8 (open
+ *                   loop) no input loads.
  * Unknown key or value out of range: MPK_EINVAL.  mpk_get_option returns the effective value (MPK_OPT_AUTO if automatic).
  */
 #define MPK_OPT_AUTO (-1)

@@ -297,6 +297,55 @@ def test_calls_are_capturable_in_a_hip_graph_even_on_a_table_cache_miss():
         close(outs[k][1].cpu().numpy(), rv, f"plan {k} vel")
 
 
+def test_many_captured_ring_graphs_replay(mpk_option):
+    """a dozen captured graphs of twenty k_traj_ring launches each (open loop and closed loop, tickets from the device counter),
+    alive at once and replayed in turn: with the ticket counter zeroed by a hipMemsetAsync NODE such replays faulted (round 4);
+    it is zeroed by a kernel of the library now.  Every replay must leave the bits of an eager launch."""
+    pc, bc, tc, dt, dur = cfg_for("prodmp", 7, 5, 100)
+    eng = make_engine(pc, bc, tc, dt, dur)
+    B = 8192
+    params, ip, iv = inputs(pc, bc, tc, B, seed=5)
+    P, IP, IV = (torch.tensor(x, device="cuda") for x in (params, ip, iv))
+    spec = RolloutSpec("motor", 7, np.full(7, 1.2), np.full(7, 0.1), -0.8, 0.8, plant="double_integrator", dt=dt)
+    q0 = torch.tensor(np.random.default_rng(0).uniform(-1, 1, (B, 7)), device="cuda")
+    cp, cv = q0.clone(), torch.zeros_like(q0)
+    mpk_option("ring", 1)
+    mpk_option("ring_dbg", 4)                       # closed loop: tickets (its default is b % grid); open loop: b % grid
+    ref_closed = [x.clone() for x in eng.trajectory_rollout(P, IP, IV, spec, q0.clone(), torch.zeros_like(q0))]
+    assert eng.last_kernel() == "k_traj_ring<prodmp,closed>"
+    mpk_option("ring_dbg", 0)                       # open loop: tickets
+    spec_s = RolloutSpec("motor", 7, np.full(7, 1.2), np.full(7, 0.1), -0.8, 0.8, plant="static")
+    ref_open = [x.clone() for x in eng.trajectory_actions(P, IP, IV, spec_s, cp, cv)]
+    assert eng.last_kernel() == "k_traj_ring<prodmp,act>"
+    graphs = []
+    for i in range(12):
+        closed = i % 2 == 0
+        mpk_option("ring_dbg", 4 if closed else 0)
+        out = tuple(torch.zeros((B, 100, 7), device="cuda") for _ in range(3))
+        q, qd = q0.clone(), torch.zeros_like(q0)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                for _ in range(20):
+                    if closed:
+                        q.copy_(q0); qd.zero_()
+                        eng.trajectory_rollout(P, IP, IV, spec, q, qd, out=out)
+                    else:
+                        eng.trajectory_actions(P, IP, IV, spec_s, cp, cv, out=out)
+        torch.cuda.current_stream().wait_stream(side)
+        graphs.append((g, out, closed))
+    torch.cuda.synchronize()
+    for rnd in range(25):
+        for g, out, closed in (graphs if rnd % 2 == 0 else graphs[::-1]):
+            g.replay()
+    torch.cuda.synchronize()
+    for g, out, closed in graphs:
+        for x, y in zip(out, ref_closed if closed else ref_open):
+            assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("quad", ["0", "2", "3", "4"])
 @pytest.mark.parametrize("D,T,B", [(7, 200, 1), (7, 200, 9), (3, 33, 21), (16, 40, 5), (1, 50, 70), (5, 17, 4)])
 def test_dmp_quad_and_stream_kernels_agree_bitwise_and_match_oracle(quad, D, T, B, monkeypatch, mpk_option):

@@ -297,6 +297,73 @@ def test_the_ring_fuzz_reached_the_ring_kernel():
     assert _RING_SEEN["burst"] >= 0.05 * _RING_SEEN["cases"], _RING_SEEN
 
 
+# ---- round 4, second session: the closed loop on the ring (producers, store engine, consumer waves, action writers) --------------------
+N_CASES_RC = int(os.environ.get("MPK_FUZZ_CASES_RC", "40"))
+START_RC = int(os.environ.get("MPK_FUZZ_START_RC", "0"))
+
+
+@pytest.mark.parametrize("seed", range(START_RC, START_RC + N_CASES_RC))
+def test_random_closed_loop_step_through_the_ring_is_bit_identical(seed, mpk_option):
+    """random promp / prodmp shapes the closed-loop ring takes (5 or 7 DoF, <= 8 contraction columns, T D a multiple of 4), random
+    batch sizes, executed steps, controllers, launch geometries and batch orders: trajectory_rollout and one replanning step
+    through k_traj_ring<.., closed> against the lane-quarter / pipeline kernels, every output and every state bit for bit"""
+    from tests.test_gpu_edge_cases import cfg_for
+    r = np.random.default_rng(410_000 + seed)
+    mp = str(r.choice(["prodmp", "promp"]))
+    D = int(r.choice([5, 7]))
+    nb = int(r.integers(1, 5)) if mp == "prodmp" else int(r.integers(2, 8))
+    T = 4 * int(r.integers(2, 45))                       # 8 .. 176 steps: T * D is a multiple of 4
+    pc, bc, tc, dt, dur = cfg_for(mp, D, nb, T)
+    eng = make_engine(pc, bc, tc, dt, dur)
+    B = int(r.choice([1, 2, 7, 8, 9, 63, 130, 1025, 2311, 9001]))
+    params, ip, iv = inputs(pc, bc, tc, B, seed=seed)
+    q0, qd0 = r.uniform(-1, 1, (B, D)), r.uniform(-0.3, 0.3, (B, D))
+    ctrl = str(r.choice(["motor", "motor", "position", "velocity"]))
+    spec = RolloutSpec(ctrl, D, r.uniform(0.1, 2.0, D), r.uniform(0.01, 0.3, D), -1.2, 1.2, plant="double_integrator", dt=dt)
+    n_steps = torch.tensor(r.integers(0, T + 1, B).astype(np.int32)) if r.random() < 0.7 else None
+    init_time = float(r.choice([0.0, 0.3 * dur]))
+    if mp == "prodmp" and (dur + init_time) / pc.tau > 5.9:
+        init_time = 0.0
+    opts = dict(ring_np=int(r.choice([-1, 1, 3, 8, 9])), ring_ns=int(r.choice([-1, 1, 2, 3])), ring_nc=int(r.choice([-1, 1, 2, 3, 4, 6])),
+                ring_m=int(r.choice([-1, -1, 1, 2, 3])), ring_dbg=int(r.choice([0, 0, 4, 8, 12, 16, 24, 32, 40])))
+
+    def run():
+        q, qd = torch.tensor(q0, device="cuda"), torch.tensor(qd0, device="cuda")
+        out = eng.trajectory_rollout(params, ip, iv, spec, q, qd, n_steps=n_steps, init_time=init_time)
+        torch.cuda.synchronize()
+        return [x.clone() for x in out] + [q, qd]
+    mpk_option("ring", 0)
+    ref = run()
+    k0 = eng.last_kernel()
+    assert "k_traj_ring" not in k0, k0
+    mpk_option("ring", 1)
+    for k, v in opts.items():
+        mpk_option(k, v)
+    got = run()
+    k1 = eng.last_kernel()
+    assert k1.endswith("closed>"), k1
+    took = k1.startswith("k_traj_ring")             # (horizons whose images leave no two batch buffers in the LDS fall through)
+    assert took or T * D > 700, (k1, mp, D, nb, T)
+    for i, (x, y) in enumerate(zip(got, ref)):
+        assert torch.equal(x, y), (i, k0, k1, mp, D, nb, T, B, opts)
+    # one replanning step with random integer state and the boundary-condition gather
+    every, mpt, horizon = int(r.integers(1, T + 1)), int(r.integers(1, 5)), int(r.integers(1, 3 * T))
+    ts0 = r.integers(0, horizon, B).astype(np.int32); ps0 = r.integers(0, 4, B).astype(np.int32)
+    dn0 = (r.random(B) < 0.2).astype(np.uint8)
+    res = []
+    for ring in (1, 0):
+        mpk_option("ring", ring)
+        st = (torch.tensor(q0, device="cuda"), torch.tensor(qd0, device="cuda"), torch.tensor(ts0, device="cuda"),
+              torch.tensor(ps0, device="cuda"), torch.tensor(dn0, device="cuda"))
+        rr = eng.replan_step(params, ip, iv, spec, *st, every, mpt, horizon, init_time=0.0, condition=bool(seed % 2))
+        torch.cuda.synchronize()
+        assert ("k_traj_ring" in eng.last_kernel()) == (ring == 1 and took), eng.last_kernel()
+        keys = ("pos", "vel", "actions", "seg_len", "done") + (("cond_pos", "cond_vel") if seed % 2 else ())
+        res.append([rr[k].clone() for k in keys] + list(st))
+    for i, (x, y) in enumerate(zip(*res)):
+        assert torch.equal(x, y), (i, "replan", mp, D, nb, T, B, opts)
+
+
 # ---- round 3, part two: the entry points the two tests above do not reach -- fused open-loop actions (every controller),
 # the reacher rollout + reward, validity + penalty, per-episode init_time vectors ------------------------------------------
 N_CASES_R3B = int(os.environ.get("MPK_FUZZ_CASES_R3B", "60"))

@@ -271,6 +271,23 @@ __device__ __forceinline__ void ring_flush_d(const TrajArgs& a, const float* sB,
             // while this pair's stores issue -- keeps MORE stores queued and measured slower in the same run: 468 vs 414 us on a
             // slow-placement box, 443 vs 400 elsewhere; like round 3's occupancy experiments, more in the write queue is not
             // better.  profiles/r04_ring.md)
+            if (a.ring_dbg & 64) {
+                // four chunks at a time (A/B: a lone engine wave's own rate -- closed loop, "ring_ns" 1)
+#pragma unroll 1
+                for (; k + 4 <= kf; k += 4) {
+                    f32x4 v0, v1, v2, v3;
+                    const unsigned lad1 = lad + cstride, vo1 = voff + cstride, lad2 = lad1 + cstride, vo2 = vo1 + cstride;
+                    const unsigned lad3 = lad2 + cstride, vo3 = vo2 + cstride;
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(v0) : "v"(lad));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(v1) : "v"(lad1));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(v2) : "v"(lad2));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(v3) : "v"(lad3));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) : : "memory");
+                    ring_store_pair<WT>(outp, voff, vo1, v0, v1);
+                    ring_store_pair<WT>(outp, vo2, vo3, v2, v3);
+                    lad += 4 * cstride; voff += 4 * cstride;
+                }
+            }
 #pragma unroll 1
             for (; k + 2 <= kf; k += 2) {
                 f32x4 v0, v1;
@@ -490,7 +507,7 @@ __global__ void __launch_bounds__(CT >= 3 ? kRingThreadsClosed : kRingThreads) k
             const int nrem = ne > 0 ? (ne * TD) & 3 : 0;          // of them; the launch's last, ragged batch may leave 1 - 3 floats)
             const float* sB = sRing + buf * BUF;
             if (a.ring_dbg & 32) ring_flush<NST, 8>(a, sB, M * IMG, (size_t)e0 * TD, n4, s, NS, lane);
-            else if (CLOSED && NS == 2 && !(a.ring_dbg & 64)) {
+            else if (CLOSED && NS == 2) {
                 // closed loop, two engine waves: one ARRAY each (pos / vel), every run written front to back by one wave -- the fewer
                 // waves interleave their 1 KB chunks inside a run, the better the memory side likes it (profiles/r04_ring_closed.md)
                 if (a.wt) ring_flush_d<NST, true>(a, sB, M * IMG, (size_t)e0 * TD, n4, 0, 1, lane, s, s + 1);

@@ -606,6 +606,7 @@ int mpk_create(const mpk_config* cfg, mpk_handle* out) {
     if (hipMalloc((void**)&h->d_flag, sizeof(int32_t)) != hipSuccess) { set_error("hipMalloc(flag) failed"); return fail(MPK_EHIP); }
     if (hipMemset(h->d_flag, 0, sizeof(int32_t)) != hipSuccess) { set_error("hipMemset(flag) failed"); return fail(MPK_EHIP); }
     if (hipMalloc((void**)&h->d_tickets, kTicketSlots * 128) != hipSuccess) { set_error("hipMalloc(ticket counters) failed"); return fail(MPK_EHIP); }
+    if (hipMemset(h->d_tickets, 0, kTicketSlots * 128) != hipSuccess) { set_error("hipMemset(ticket counters) failed"); return fail(MPK_EHIP); }
     rc = upload_times(h);
     if (rc != MPK_OK) return fail(rc);
     fill_devcfg(h);

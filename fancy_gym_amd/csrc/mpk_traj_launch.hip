@@ -102,10 +102,6 @@ __global__ void __launch_bounds__(256) k_build_shared(const DevCfg c, const floa
     }
 }
 
-// the ring's ticket counter is zeroed in stream order in front of the launch by a kernel of ours (round 4: as a hipMemsetAsync
-// node inside captured graphs -- a dozen graphs of twenty launches alive at once -- replays faulted; a kernel node does not)
-__global__ void k_zero_u32(unsigned* p) { if (threadIdx.x == 0) *p = 0u; }
-
 #ifndef MPK_DEVICE_ONLY
 int launch_build_shared(const DevCfg& c, float init_time, const SharedTables& st, int32_t* idx_out,
                         int32_t* range_flag, void* stream) {
@@ -293,11 +289,10 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
             ta.flat_img = gimg;
             ta.ring_np = NP; ta.ring_ns = NS; ta.ring_m = M; ta.ring_nbuf = (int)nbuf; ta.ring_parts = P;
             // in-order dynamic batch assignment: tickets of TB batches from one counter word (~88 tickets / us at most: a
-            // ticket must be worth well over 100 KB of output), zeroed in stream order in front of the launch
+            // ticket must be worth well over 100 KB of output); zero at handle creation, zeroed again by the launch's last workgroup
             ta.ring_ctr = ticket;
             ta.ring_tb = (int)((kRingTicketBytes + buf_bytes - 1) / buf_bytes);
             if (ta.ring_tb < 1) ta.ring_tb = 1;
-            if (ticket) hipLaunchKernelGGL(k_zero_u32, dim3(1), dim3(64), 0, (hipStream_t)stream, ticket);
             ring = true;
             stream_mode = true; quad = 0; bulk = false;
             ta.wt = out_bytes <= kWtBytes ? 1 : 0;
@@ -339,7 +334,6 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
             ta.ring_ctr = ticket;
             ta.ring_tb = (int)((kRingTicketBytes + buf_bytes * 3 / 2 - 1) / (buf_bytes * 3 / 2));   // (a batch writes 1.5 x its buffer)
             if (ta.ring_tb < 2) ta.ring_tb = 2;
-            if (ticket) hipLaunchKernelGGL(k_zero_u32, dim3(1), dim3(64), 0, (hipStream_t)stream, ticket);
             ring = true; pipe_sel = false;
             stream_mode = true; quad = 0; bulk = false;
             ta.wt = out_bytes <= kWtBytes ? 1 : 0;

@@ -253,7 +253,7 @@ __device__ __forceinline__ void ring_store_pair(const float* gbase, const unsign
     }
 }
 
-template <int NST, bool WT>
+template <int NST, bool WT, bool WIDE = false>
 __device__ __forceinline__ void ring_flush_d(const TrajArgs& a, const float* sB, const int astride, const size_t go, const int n4,
                                              const int s, const int NS, const int lane, const int arr0 = 0, const int arr1 = NST) {
     const unsigned cstride = (unsigned)NS * 1024u;                    // bytes between this wave's chunks
@@ -271,8 +271,10 @@ __device__ __forceinline__ void ring_flush_d(const TrajArgs& a, const float* sB,
             // while this pair's stores issue -- keeps MORE stores queued and measured slower in the same run: 468 vs 414 us on a
             // slow-placement box, 443 vs 400 elsewhere; like round 3's occupancy experiments, more in the write queue is not
             // better.  profiles/r04_ring.md)
-            if (a.ring_dbg & 64) {
-                // four chunks at a time (A/B: a lone engine wave's own rate -- closed loop, "ring_ns" 1)
+            if (WIDE != ((a.ring_dbg & 64) != 0)) {
+                // four chunks at a time: the closed loop's LONE engine wave is bound by its own rate where the consumers are light
+                // (replanning step at 262 144 episodes: 544 -> 472 us; full horizon 488 -> 479); with the open loop's two engine
+                // waves it changes nothing measurable.  "ring_dbg" 64 flips the choice (A/B runs)
 #pragma unroll 1
                 for (; k + 4 <= kf; k += 4) {
                     f32x4 v0, v1, v2, v3;
@@ -398,6 +400,18 @@ __global__ void __launch_bounds__(CT >= 3 ? kRingThreadsClosed : kRingThreads) k
         const int t = __hip_atomic_load(&sTick[tl & 7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return t < NT ? t * TB + (bl - tl * TB) : -1;
     };
+    // The ticket counter cleans up after itself: a workgroup's wave 0 is the only one that fetches tickets, and when it leaves it
+    // says so in the word behind the counter; the last workgroup to say so zeroes both words for the next launch that takes this
+    // counter slot (stream order).  Zeroing it in front of every launch cost a launch (a one-thread kernel: +11 us on the 400 us
+    // streaming row) or faulted (a hipMemsetAsync NODE inside captured graphs: profiles/r04_ring_closed.md).
+    auto leave0 = [&]() {
+        if (dynamic && wave == 0 && lane == 0) {
+            if (atomicAdd(a.ring_ctr + 1, 1u) == gridDim.x - 1) {
+                __hip_atomic_store(a.ring_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.ring_ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
     if (wave < NP) {
         // ---------------- producers: work unit n = ((local batch) * M + (slot in batch)) * P + (part of the group's row tiles);
         // wave p takes n = p, p + NP, ... ----
@@ -417,6 +431,7 @@ __global__ void __launch_bounds__(CT >= 3 ? kRingThreadsClosed : kRingThreads) k
         int b = batch_at(n / MP_);
         if (b < 0) {
             if (dynamic && wave == 0 && lane == 0) __hip_atomic_store(sDone, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            leave0();
             return;
         }
         const LaneMap<KM> L = make_lane_map<MP, KM>(a, lane);
@@ -443,13 +458,13 @@ __global__ void __launch_bounds__(CT >= 3 ? kRingThreadsClosed : kRingThreads) k
             }
             const int nn = n + NP;
             const int bx = batch_at(nn / MP_);                    // (static: known; dynamic: its ticket is two rounds old)
-            if (bx == -2) return;
+            if (bx == -2) { leave0(); return; }
             const int gx = bx >= 0 ? bx * M + (nn % MP_) / P : g;
             GroupIn<KM> nxt = cur;
             if (CLOSED || !(a.ring_dbg & 8)) nxt = load_group<MP, ACT, KM>(a, L, gx < a.G ? gx : a.G - 1);   // in flight across the whole group
             const int buf = bl % NBUF, k = bl / NBUF, slot = buf * M + j;
             if (CLOSED && n / NP < 12) MPK_STAMP(3 * (n / NP));                     // unit start (next unit's loads issued)
-            if (!ring_wait(&sEmpty[slot], k * (NS + (CLOSED ? 1 : 0)))) return;
+            if (!ring_wait(&sEmpty[slot], k * (NS + (CLOSED ? 1 : 0)))) { leave0(); return; }
             if (CLOSED && n / NP < 12) MPK_STAMP(3 * (n / NP) + 1);                 // buffer acquired   // the engine (and the consumer) have released use k - 1 of this slot
             int pub = CLOSED ? NRT : 1;                           // what this unit adds to the slot's `full` count at its end
             if (g < a.G && !(a.ring_dbg & 1)) {
@@ -482,6 +497,7 @@ __global__ void __launch_bounds__(CT >= 3 ? kRingThreadsClosed : kRingThreads) k
                 // this wave is done.  Wave 0 says so: a wave that still waits for a ticket nobody will publish any more is past the
                 // end (tickets are monotonic: wave 0 left because ITS next ticket was)
                 if (dynamic && wave == 0 && lane == 0) __hip_atomic_store(sDone, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                leave0();
                 return;
             }
             finish_group<KM>(L, nxt, xb);
@@ -508,13 +524,13 @@ __global__ void __launch_bounds__(CT >= 3 ? kRingThreadsClosed : kRingThreads) k
             const float* sB = sRing + buf * BUF;
             if (a.ring_dbg & 32) ring_flush<NST, 8>(a, sB, M * IMG, (size_t)e0 * TD, n4, s, NS, lane);
             else if (CLOSED && NS == 2) {
-                // closed loop, two engine waves: one ARRAY each (pos / vel), every run written front to back by one wave -- the fewer
-                // waves interleave their 1 KB chunks inside a run, the better the memory side likes it (profiles/r04_ring_closed.md)
-                if (a.wt) ring_flush_d<NST, true>(a, sB, M * IMG, (size_t)e0 * TD, n4, 0, 1, lane, s, s + 1);
-                else ring_flush_d<NST, false>(a, sB, M * IMG, (size_t)e0 * TD, n4, 0, 1, lane, s, s + 1);
+                // closed loop, two engine waves: one ARRAY each (pos / vel), every run written front to back by one wave (measured
+                // equal to interleaved 1 KB chunks: profiles/r04_ring_closed.md)
+                if (a.wt) ring_flush_d<NST, true, CLOSED>(a, sB, M * IMG, (size_t)e0 * TD, n4, 0, 1, lane, s, s + 1);
+                else ring_flush_d<NST, false, CLOSED>(a, sB, M * IMG, (size_t)e0 * TD, n4, 0, 1, lane, s, s + 1);
             }
-            else if (a.wt) ring_flush_d<NST, true>(a, sB, M * IMG, (size_t)e0 * TD, n4, s, NS, lane);
-            else ring_flush_d<NST, false>(a, sB, M * IMG, (size_t)e0 * TD, n4, s, NS, lane);
+            else if (a.wt) ring_flush_d<NST, true, CLOSED>(a, sB, M * IMG, (size_t)e0 * TD, n4, s, NS, lane);
+            else ring_flush_d<NST, false, CLOSED>(a, sB, M * IMG, (size_t)e0 * TD, n4, s, NS, lane);
             if (nrem && s == 0 && lane < nrem && !(a.ring_dbg & 2)) {
 #pragma unroll 1
                 for (int arr = 0; arr < NST; ++arr) {

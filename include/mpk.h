@@ -232,7 +232,7 @@ int mpk_set_duration(mpk_handle h, double duration, double dt);
  *                   device counter (closed loop: the other way round -- b % grid is its default, 4 = tickets), 16 contiguous batch
  *                   ranges per workgroup (k_traj_burst: A fragments from the table in L2), 32 the generic contraction / flush
  *                   loops instead of the compile-time-DoF ones, 64 k_traj_flat without its compile-time-DoF variant (ring: the engine moves
- *                   four 1 KB chunks per step instead of two); closed loop only: 8 the
+ *                   four 1 KB chunks per step instead of two -- closed loop: two instead of its four); closed loop only: 8 the
  *                   consumer waves store their action tiles themselves (no action-writer waves).  ABLATIONS that leave outputs
  *                   unwritten, measurements only: 1 no production (closed loop: no recurrence either), 2 no stores, 8 (open
  *                   loop) no input loads.

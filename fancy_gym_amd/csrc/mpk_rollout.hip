@@ -264,9 +264,32 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
                 rw_gy[p] = ok ? a.goal[2 * (size_t)b + 1] : 0.0;
             }
         }
+        MPK_STAMP(1);
         fetch(0, lpA, lvA);
         constexpr bool kTwoAhead = !RW || MPK_RW_LOOK == 2;
         if (kTwoAhead && NRT > 1) fetch(1, lpB, lvB);      // (RW: a tile takes three times as long -- one tile of lookahead, 32 registers less)
+        // the unit's serial inputs are waited for HERE (they are older than the fetches above: the wait leaves those in flight).  Left to
+        // the compiler the wait sits in front of their first use in every tile's chain as `s_waitcnt vmcnt(0)` -- every tile then began
+        // by waiting for the loads it had just issued for two tiles ahead and for the previous tile's stores (round 4, second session)
+        asm volatile("" : "+v"(qs), "+v"(qds), "+v"(nst));
+        // The actions of tile rt leave at the START of tile rt + 1, after its staging: the wait for a tile's prefetched inputs is
+        // `s_waitcnt vmcnt(0)` (the compiler cannot count across the loop), and with the stores issued at a tile's end it was a wait
+        // for their acknowledgement too -- 900 - 1 350 cycles per tile against 1 900 of chain (trace, round 4 second session).  Issued
+        // here they have the whole chain to retire.  (The action image is read into registers before the chain rewrites it: a wave's
+        // LDS operations execute in order.)
+        auto store_actions = [&](const int rt) {
+            if (!a.actions) return;
+            const int rows = min(16, T - rt * 16);
+#pragma unroll
+            for (int j = 0; j < NG; ++j) {
+                if (mover[j] && w4 < rows * D) {
+                    float* dst = a.actions + (size_t)(g0 + j) * NTW * T * D + gofs + (size_t)rt * SEG;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(sSt + j * SLOT + 2 * kStageStride + rofs);
+                    if (a.wt) store16<true>(dst, v);      // cache-resident actions: write-through (wave-uniform)
+                    else store16<false>(dst, v);
+                }
+            }
+        };
         auto tile = [&](const int rt, f32x4 (&lp)[NG], f32x4 (&lv)[NG]) {
             const int rows = min(16, T - rt * 16);
 #pragma unroll
@@ -277,7 +300,9 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
                 }
             }
             if (rt + (kTwoAhead ? 2 : 1) < NRT) fetch(rt + (kTwoAhead ? 2 : 1), lp, lv);   // into the set this tile has just emptied
+            if (rt > 0) store_actions(rt - 1);
             __builtin_amdgcn_wave_barrier();
+            if (rt < 16) MPK_STAMP(10 + 3 * rt);
             if (serial) {
                 // the 16 steps of the tile as straight-line code per (controller, plant): a run-time switch inside the
                 // step would cost more instructions than the step's arithmetic, and this chain is the critical path
@@ -317,6 +342,7 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            if (rt < 16) MPK_STAMP(11 + 3 * rt);
             if (RW) {
                 auto pass = [&](auto dc_tag) {
                     constexpr int DC = decltype(dc_tag)::value;
@@ -365,18 +391,8 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
                 else pass(std::integral_constant<int, 0>());
                 __builtin_amdgcn_wave_barrier();
             }
-            if (a.actions) {
-#pragma unroll
-                for (int j = 0; j < NG; ++j) {
-                    if (mover[j] && w4 < rows * D) {
-                        float* dst = a.actions + (size_t)(g0 + j) * NTW * T * D + gofs + (size_t)rt * SEG;
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(sSt + j * SLOT + 2 * kStageStride + rofs);
-                        if (a.wt) store16<true>(dst, v);      // cache-resident actions: write-through (wave-uniform)
-                        else store16<false>(dst, v);
-                    }
-                }
-            }
             __builtin_amdgcn_wave_barrier();
+            if (rt < 16) MPK_STAMP(12 + 3 * rt);
         };
         if (!kTwoAhead) {
 #pragma unroll 1
@@ -387,10 +403,13 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
                 if (rt + 1 < NRT) tile(rt + 1, lpB, lvB);
             }
         }
+        store_actions(NRT - 1);
+        __builtin_amdgcn_wave_barrier();
         if (serial) {
             const size_t si = (size_t)bs * D + d;
             if (a.rc.plant_type != MPK_PLANT_STATIC) { a.Q[si] = qs; a.QD[si] = qds; }
         }
+        MPK_STAMP(90);
     }
 }
 

@@ -100,6 +100,10 @@ __global__ void __launch_bounds__(256, (NQ == 4 ? MPK_QUAD_WPE4 : NQ == 2 ? MPK_
         const Gains gq = kernarg_gains(L.dvalid ? L.d : 0);
         pgd = gq.pg; dgd = gq.dg;
         lod = __builtin_canonicalize(gq.lo); hid = __builtin_canonicalize(gq.hi);   // not again at every step's fmin / fmax
+        // the gains arrive by vector loads: make the compiler wait for them HERE.  Left to it, the wait sits in front of their first
+        // use in every row tile's chain, and -- the loop being a loop -- it is `s_waitcnt vmcnt(0)`: every tile's recurrence began by
+        // waiting for the acknowledgement of the previous tile's STORES (round 4, second session: the disassembly of the tile loop)
+        asm volatile("" : "+v"(pgd), "+v"(dgd));
     }
     (void)act;
 
@@ -125,8 +129,12 @@ __global__ void __launch_bounds__(256, (NQ == 4 ? MPK_QUAD_WPE4 : NQ == 2 ? MPK_
         const int oq = L.bl * a.pitch + L.d + (int)ep_shift(a, bq);      // (row 0, this column) in group q's image
         float* sQ = sW + L.q * kQuadImg;
         double qs = sc.qs, qds = sc.qds;
-        const int nst = sc.nst;
+        int nst_ = sc.nst;
         float ey = sc.ey, ez = sc.ez, eg = sc.eg;
+        // (the same for the unit's serial inputs, fetched one unit ago: waited for once per unit, not in every tile's chain)
+        if (CLOSED) asm volatile("" : "+v"(qs), "+v"(qds), "+v"(nst_));
+        else asm volatile("" : "+v"(ey), "+v"(ez), "+v"(eg));
+        const int nst = nst_;
         const int tcond = (CLOSED && a.rp.cond_pos) ? min(max(nst - 1, 0), T - 1) : -1;
         // A fragments (basis rows of a row tile) are the same for the four groups: read from LDS once per tile, one tile
         // ahead, into registers.  Left to the compiler they are re-read in front of every MFMA (it cannot prove that

@@ -48,7 +48,10 @@ def main():
                 fn = lambda: eng.reacher_rollout(spec, pos, vel, q, qd, goal, out=(act, rew))     # noqa: E731
             else:
                 fn = lambda: eng.pd_rollout(spec, pos, vel, q, qd, out=act)                       # noqa: E731
-            for opts in ({}, {"pd_quad": 0}, {"pd_quad": 3}, {"pd_quad": 2}):
+            variants = ({}, {"pd_quad": 0}, {"pd_quad": 3}, {"pd_quad": 2})
+            if "--wt" in sys.argv:      # store policy A/B of the automatic geometry
+                variants = ({}, {"write_through": 0}, {"write_through": 1}, {"pd_quad": 0, "write_through": 0}, {"pd_quad": 3, "write_through": 0})
+            for opts in variants:
                 _lib.reset_options()
                 for k, v in opts.items():
                     _lib.set_option(k, v)

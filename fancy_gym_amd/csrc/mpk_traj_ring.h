@@ -272,9 +272,10 @@ __device__ __forceinline__ void ring_flush_d(const TrajArgs& a, const float* sB,
             // slow-placement box, 443 vs 400 elsewhere; like round 3's occupancy experiments, more in the write queue is not
             // better.  profiles/r04_ring.md)
             if (WIDE != ((a.ring_dbg & 64) != 0)) {
-                // four chunks at a time: the closed loop's LONE engine wave is bound by its own rate where the consumers are light
-                // (replanning step at 262 144 episodes: 544 -> 472 us; full horizon 488 -> 479); with the open loop's two engine
-                // waves it changes nothing measurable.  "ring_dbg" 64 flips the choice (A/B runs)
+                // four chunks at a time where two arrays pass through the engine (NST == 2).  Closed loop: the LONE engine wave is
+                // bound by its own rate where the consumers are light (replanning step at 262 144 episodes: 544 -> 472 us; full
+                // horizon 488 -> 479); open loop, trajectory only, two engine waves: 292 -> 282 us at 262 144; with the actions as a
+                // third array it changes nothing (414 vs 414).  "ring_dbg" 64 flips the choice (A/B runs)
 #pragma unroll 1
                 for (; k + 4 <= kf; k += 4) {
                     f32x4 v0, v1, v2, v3;
@@ -526,11 +527,11 @@ __global__ void __launch_bounds__(CT >= 3 ? kRingThreadsClosed : kRingThreads) k
             else if (CLOSED && NS == 2) {
                 // closed loop, two engine waves: one ARRAY each (pos / vel), every run written front to back by one wave (measured
                 // equal to interleaved 1 KB chunks: profiles/r04_ring_closed.md)
-                if (a.wt) ring_flush_d<NST, true, CLOSED>(a, sB, M * IMG, (size_t)e0 * TD, n4, 0, 1, lane, s, s + 1);
-                else ring_flush_d<NST, false, CLOSED>(a, sB, M * IMG, (size_t)e0 * TD, n4, 0, 1, lane, s, s + 1);
+                if (a.wt) ring_flush_d<NST, true, NST == 2>(a, sB, M * IMG, (size_t)e0 * TD, n4, 0, 1, lane, s, s + 1);
+                else ring_flush_d<NST, false, NST == 2>(a, sB, M * IMG, (size_t)e0 * TD, n4, 0, 1, lane, s, s + 1);
             }
-            else if (a.wt) ring_flush_d<NST, true, CLOSED>(a, sB, M * IMG, (size_t)e0 * TD, n4, s, NS, lane);
-            else ring_flush_d<NST, false, CLOSED>(a, sB, M * IMG, (size_t)e0 * TD, n4, s, NS, lane);
+            else if (a.wt) ring_flush_d<NST, true, NST == 2>(a, sB, M * IMG, (size_t)e0 * TD, n4, s, NS, lane);
+            else ring_flush_d<NST, false, NST == 2>(a, sB, M * IMG, (size_t)e0 * TD, n4, s, NS, lane);
             if (nrem && s == 0 && lane < nrem && !(a.ring_dbg & 2)) {
 #pragma unroll 1
                 for (int arr = 0; arr < NST; ++arr) {

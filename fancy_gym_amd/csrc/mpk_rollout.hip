@@ -86,6 +86,10 @@ __device__ __forceinline__ void sincos_lean(double x, double* sn, double* cs) {
                              // SLOWER (65 536 episodes x 200 steps: 353 us against 322 for the run-time loop, profiles/r04_reward_pass_ab.md):
                              // the pass is bound by float64 issue (two waves per SIMD both inside it), not by the chains' latency
 #endif
+#ifndef MPK_PD_LOOK
+#define MPK_PD_LOOK 2        // tiles of input lookahead of the rollout kernel without reward, one / two groups per wave: 3 measured 1 - 4 % SLOWER
+                             // than 2 (4 096: 11.5 vs 11.4 us, 8 192: 17.5 vs 16.8): what a tile's staging costs is its instructions, not a late load
+#endif
 #ifndef MPK_RW_LOOK
 #define MPK_RW_LOOK 1        // tiles of input lookahead in the reward kernel (2 = as the kernel without reward)
 #endif
@@ -218,19 +222,28 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
             if (a.n_steps) nst = min(a.n_steps[bs], T);
         }
         bool mover[NG];
-        const float* gp[NG];
-        const float* gv[NG];
+        // Addresses of the tile pieces: ONE wave-uniform base per array (the unit's first episode) + a 32-bit per-lane byte offset per
+        // group that advances by a tile per tile -- the (scalar base, vector offset) form of the loads and stores.  With 64-bit
+        // per-lane pointers recomputed per tile the staging of a tile was ~120 instructions, and a wave that has its SIMD to itself
+        // (4 096 episodes: one wave per SIMD) pays 5 - 6 cycles for every one of them: 900 of a tile's 2 900 cycles (round 4, second
+        // session: trace + disassembly, profiles/r04_vmcnt_in_tile_loops.md)
+        const size_t ubase = (size_t)g0 * NTW * T * D;                 // first element of the unit in every [B, T, D] array
+        const float* const bpos = a.des_pos + ubase;
+        const float* const bvel = a.des_vel + ubase;
+        float* const bact = a.actions ? a.actions + ubase : nullptr;
+        unsigned goff[NG];                                             // byte offset of this lane's float4 of tile 0, group j
         // the desired (pos, vel) pieces travel TWO tiles ahead of the recurrence, in two register sets used in turn: one tile's
         // chain (16 steps, ~1300 cycles) is shorter than a load's round trip even from the memory-side cache, so with one tile of
         // lookahead every tile waited for its inputs (B = 2048: 182 cycles per step against the chain's 83; profiles/r04_rollout.md)
-        f32x4 lpA[NG], lvA[NG], lpB[NG], lvB[NG];
+        f32x4 lpA[NG], lvA[NG], lpB[NG], lvB[NG], lpC[NG], lvC[NG];
         auto fetch = [&](const int rt, f32x4 (&lp)[NG], f32x4 (&lv)[NG]) {
-            const int rows_n = min(16, T - rt * 16);
+            const bool okt = w4 < min(16, T - rt * 16) * D;
+            const unsigned tb = (unsigned)(rt * SEG) * 4u;
 #pragma unroll
             for (int j = 0; j < NG; ++j) {
-                if (mover[j] && w4 < rows_n * D) {
-                    lp[j] = *reinterpret_cast<const f32x4*>(gp[j] + (size_t)rt * SEG);
-                    lv[j] = *reinterpret_cast<const f32x4*>(gv[j] + (size_t)rt * SEG);
+                if (mover[j] && okt) {
+                    lp[j] = ld_off(reinterpret_cast<const f32x4*>(bpos), goff[j] + tb);
+                    lv[j] = ld_off(reinterpret_cast<const f32x4*>(bvel), goff[j] + tb);
                 }
             }
         };
@@ -238,9 +251,8 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
         for (int j = 0; j < NG; ++j) {
             const int b0 = (g0 + j) * NTW;
             mover[j] = g0 + j < a.G && sseg < NTW && b0 + sseg < B;
-            gp[j] = a.des_pos + (size_t)b0 * T * D + gofs;
-            gv[j] = a.des_vel + (size_t)b0 * T * D + gofs;
-            lpA[j] = f32x4{0, 0, 0, 0}; lvA[j] = lpA[j]; lpB[j] = lpA[j]; lvB[j] = lpA[j];
+            goff[j] = (unsigned)(((size_t)j * NTW * T * D + gofs) * sizeof(float));
+            lpA[j] = f32x4{0, 0, 0, 0}; lvA[j] = lpA[j]; lpB[j] = lpA[j]; lvB[j] = lpA[j]; lpC[j] = lpA[j]; lvC[j] = lpA[j];
         }
         // RW: the reward pass turns (episode, step) items into rewards, item = pass * 64 + lane -> episode slot je = 4 pass + lane / 16
         // of the unit, step lane % 16 of the tile: a lane meets the SAME episodes in every tile, so what the pass needs per episode
@@ -267,7 +279,12 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
         MPK_STAMP(1);
         fetch(0, lpA, lvA);
         constexpr bool kTwoAhead = !RW || MPK_RW_LOOK == 2;
-        if (kTwoAhead && NRT > 1) fetch(1, lpB, lvB);      // (RW: a tile takes three times as long -- one tile of lookahead, 32 registers less)
+        // tiles of input lookahead: one with the reward (a tile takes three times as long there; 32 registers less), two with four
+        // groups per wave (registers), THREE with one or two groups per wave -- one wave per SIMD or two: nothing else hides a load
+        // that takes longer than two tiles (MPK_PD_LOOK: A/B build knob)
+        constexpr int kAhead = !kTwoAhead ? 1 : (NG <= 2 && MPK_PD_LOOK == 3 ? 3 : 2);
+        if (kAhead >= 2 && NRT > 1) fetch(1, lpB, lvB);
+        if (kAhead >= 3 && NRT > 2) fetch(2, lpC, lvC);
         // the unit's serial inputs are waited for HERE (they are older than the fetches above: the wait leaves those in flight).  Left to
         // the compiler the wait sits in front of their first use in every tile's chain as `s_waitcnt vmcnt(0)` -- every tile then began
         // by waiting for the loads it had just issued for two tiles ahead and for the previous tile's stores (round 4, second session)
@@ -279,12 +296,16 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
         // LDS operations execute in order.)
         auto store_actions = [&](const int rt) {
             if (!a.actions) return;
-            const int rows = min(16, T - rt * 16);
+            const bool okt = w4 < min(16, T - rt * 16) * D;
+            const unsigned tb = (unsigned)(rt * SEG) * 4u;
 #pragma unroll
             for (int j = 0; j < NG; ++j) {
-                if (mover[j] && w4 < rows * D) {
-                    float* dst = a.actions + (size_t)(g0 + j) * NTW * T * D + gofs + (size_t)rt * SEG;
+                if (mover[j] && okt) {
                     const f32x4 v = *reinterpret_cast<const f32x4*>(sSt + j * SLOT + 2 * kStageStride + rofs);
+                    const unsigned off = goff[j] + tb;
+                    // (write-through in the 64-bit address form of store16: with the scalar base handed to an inline asm the
+                    // reward instantiation -- 56 spilled scalar registers -- stored to wild addresses)
+                    float* const dst = reinterpret_cast<float*>(reinterpret_cast<char*>(bact) + off);
                     if (a.wt) store16<true>(dst, v);      // cache-resident actions: write-through (wave-uniform)
                     else store16<false>(dst, v);
                 }
@@ -299,7 +320,7 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
                     *reinterpret_cast<f32x4*>(sSt + j * SLOT + kStageStride + rofs) = lv[j];
                 }
             }
-            if (rt + (kTwoAhead ? 2 : 1) < NRT) fetch(rt + (kTwoAhead ? 2 : 1), lp, lv);   // into the set this tile has just emptied
+            if (rt + kAhead < NRT) fetch(rt + kAhead, lp, lv);   // into the set this tile has just emptied
             if (rt > 0) store_actions(rt - 1);
             __builtin_amdgcn_wave_barrier();
             if (rt < 16) MPK_STAMP(10 + 3 * rt);
@@ -394,7 +415,13 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
             __builtin_amdgcn_wave_barrier();
             if (rt < 16) MPK_STAMP(12 + 3 * rt);
         };
-        if (!kTwoAhead) {
+        if (kAhead == 3) {
+            for (int rt = 0; rt < NRT; rt += 3) {
+                tile(rt, lpA, lvA);
+                if (rt + 1 < NRT) tile(rt + 1, lpB, lvB);
+                if (rt + 2 < NRT) tile(rt + 2, lpC, lvC);
+            }
+        } else if (kAhead == 1) {
 #pragma unroll 1
             for (int rt = 0; rt < NRT; ++rt) tile(rt, lpA, lvA);
         } else {

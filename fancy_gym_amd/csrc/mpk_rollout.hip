@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
                                                               nst, pgd, dgd, lod, hid, dtp, qs, qds, q64, u64);
                     else
                         pd_tile_steps<CTRL, true, INTEG, RW>(sg + o0, sg + kStageStride + o0, sg + 2 * kStageStride + o0, D, rt * 16,
-                                                             nst, pgd, dgd, lod, hid, dtp, qs, qds, q64, u64);
+                                                             nst, pgd, dgd, lod, hid, dtp, qs, qds, q64, u64, rows);
                 };
                 using std::integral_constant;
                 const bool dint = a.rc.plant_type == MPK_PLANT_DOUBLE_INTEGRATOR;

@@ -256,7 +256,7 @@ __device__ __forceinline__ void pd_tile_steps(const float* __restrict__ sP, cons
                                               float* __restrict__ sA, const int stride, const int t0, const int nst,
                                               const double pgd, const double dgd, const double lod, const double hid,
                                               const double dtp, double& qs, double& qds, double* __restrict__ q64 = nullptr,
-                                              double* __restrict__ u64 = nullptr) {
+                                              double* __restrict__ u64 = nullptr, const int rows = 16) {
     // INTEGRATE = false: MPK_PLANT_STATIC (the state never changes).  KEEP64: the plant position after the step and the
     // clipped action also stay in LDS as float64, 16 doubles per step (the reward pass of the reacher rollout reads them)
     float pr[16], vr[16];
@@ -272,26 +272,28 @@ __device__ __forceinline__ void pd_tile_steps(const float* __restrict__ sP, cons
         }
     }
     // MASKED tiles (the horizon's last, partial tile; the tile in which a plan's executed steps end): the steps no lane of the wave
-    // executes are not computed at all -- their actions are 0.  nlive = steps of the tile at which some lane is still live (live is
-    // monotone in the step: a binary search over four ballots).  Round 4, second session: with T = 100 the seventh tile has four
-    // steps, and computing-and-discarding the other twelve was 10 % of every closed-loop kernel's chain (16 masked steps cost
-    // 2 200 - 2 600 cycles against 1 900 for a full tile).
+    // executes are not computed -- their actions are 0, written by a short loop behind the chain, and only for the `rows` steps of
+    // the tile that lie inside the horizon (nothing past it is ever stored).  nlive = steps at which some lane is still live: where
+    // every lane executes the same number of steps (the rule, one compare says so) it is arithmetic, else a binary search over four
+    // ballots (live is monotone in the step).  Round 4, second session: with T = 100 the seventh tile has four steps, and
+    // computing-and-discarding the other twelve cost as much as a full tile (trace of k_traj_pipe: 2 000 - 2 600 cycles).
     int nlive = 16;
     if (MASKED) {
-        int lo = 0, hi = 16;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (__any(t0 + mid < nst)) lo = mid + 1; else hi = mid;
+        const int n0 = __builtin_amdgcn_readfirstlane(nst);
+        if (__all(nst == n0)) {
+            nlive = min(max(n0 - t0, 0), 16);
+        } else {
+            int lo = 0, hi = 16;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (__any(t0 + mid < nst)) lo = mid + 1; else hi = mid;
+            }
+            nlive = lo;
         }
-        nlive = lo;
     }
 #pragma unroll
     for (int tl = 0; tl < 16; ++tl) {
-        if (MASKED && tl >= nlive) {                      // (wave-uniform)
-            sA[tl * stride] = 0.0f;
-            if (KEEP64) { q64[tl * 16] = qs; u64[tl * 16] = 0.0; }
-            continue;
-        }
+        if (MASKED && tl >= nlive) break;                 // (wave-uniform)
         const double dp = PRE ? dpr[tl] : (double)pr[tl], dv = PRE ? dvr[tl] : (double)vr[tl];
         double u;
         if (CTRL == MPK_CTRL_MOTOR) u = pgd * (dp - qs) + dgd * (dv - qds);
@@ -311,6 +313,13 @@ __device__ __forceinline__ void pd_tile_steps(const float* __restrict__ sP, cons
             sA[tl * stride] = (float)u;
         }
         if (KEEP64) { q64[tl * 16] = qs; u64[tl * 16] = u; }
+    }
+    if (MASKED) {
+#pragma unroll 1
+        for (int tl = nlive; tl < rows; ++tl) {
+            sA[tl * stride] = 0.0f;
+            if (KEEP64) { q64[tl * 16] = qs; u64[tl * 16] = 0.0; }
+        }
     }
 }
 

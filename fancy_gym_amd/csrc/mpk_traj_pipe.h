@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(320) k_traj_pipe(const TrajArgs a, const ActAr
                                                      pgd, dgd, lod, hid, a.plant_dt, qs, qds);
                     else
                         pd_tile_steps<CT - 3, true, true, false, MPK_PIPE_PRE>(sQ + oq, sQ + kStageStride + oq, sQ + 2 * kStageStride + oq, D, rt * 16, nst,
-                                                    pgd, dgd, lod, hid, a.plant_dt, qs, qds);
+                                                    pgd, dgd, lod, hid, a.plant_dt, qs, qds, nullptr, nullptr, min(16, T - rt * 16));
                 }
                 MPK_STAMP(30 + rt);
                 __syncthreads();                                            // tile rt's actions are final; tile rt + 1 is in

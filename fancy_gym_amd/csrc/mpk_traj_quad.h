@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256, (NQ == 4 ? MPK_QUAD_WPE4 : NQ == 2 ? MPK_
                                                                     rt * 16, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds);
                     else
                         pd_tile_steps<(CLOSED ? CT - 3 : 0), true>(sQ + oq, sQ + kStageStride + oq, sQ + 2 * kStageStride + oq, D,
-                                                                   rt * 16, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds);
+                                                                   rt * 16, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds, nullptr, nullptr, rows);
                 } else {
                     dmp_tile_steps(sQ + 2 * kStageStride + oq, sQ + oq, sQ + kStageStride + oq, sAux + rt * 16, D, rt * 16, T,
                                    c.dmp_alpha, c.dmp_beta, eg, td, ey, ez);

@@ -677,7 +677,7 @@ __global__ void __launch_bounds__(CT >= 3 ? kRingThreadsClosed : kRingThreads) k
                                                                  a.plant_dt, qs, qds);
                                 else
                                     pd_tile_steps<CT - 3, true>(sP + rt * 16 * DC, sV + rt * 16 * DC, sAq, DC, rt * 16, nst, pgd, dgd, lod, hid,
-                                                                a.plant_dt, qs, qds);
+                                                                a.plant_dt, qs, qds, nullptr, nullptr, rows);
                             }
                         } else if (serial) {                       // no episode of the batch executes a step of this tile: actions 0
 #pragma unroll

@@ -73,11 +73,21 @@ __device__ __forceinline__ void tiles_body(const TrajArgs& a, float* smem, const
             tile_epilogue<MP, CT>(acc0, acc1, acc2, dtd, cp, cv, kg, sSt, L.wofs + ep_shift(a, g * L.NTW + L.bl), D);
         __builtin_amdgcn_wave_barrier();
         MPK_STAMP(10);
+#if MPK_TILES_COLLECT_FIRST
+        // (A/B build knob: the next group's fragments collected BEFORE this group's stores, so that the wait for the prefetched loads
+        // does not cover these stores -- the queue retires in order)
+        finish_group<KM>(L, nxt, xb);
+        asm volatile("" : "+v"(xb[0]));
+        tile_store<NST, KM, WT>(a, L, sSt, lane, g * L.NTW, rt, rows);
+        __builtin_amdgcn_wave_barrier();
+        MPK_STAMP(11);
+#else
         tile_store<NST, KM, WT>(a, L, sSt, lane, g * L.NTW, rt, rows);
         __builtin_amdgcn_wave_barrier();
         MPK_STAMP(11);
         // 5. finish the prefetched fragments for the next iteration
         finish_group<KM>(L, nxt, xb);
+#endif
         cp = nxt.cp; cv = nxt.cv;
         g = gn;
     }
@@ -89,6 +99,9 @@ __device__ __forceinline__ void tiles_body(const TrajArgs& a, float* smem, const
 }
 
 #ifndef MPK_TILES_OCC
+#ifndef MPK_TILES_COLLECT_FIRST
+#define MPK_TILES_COLLECT_FIRST 0
+#endif
 #define MPK_TILES_OCC 7      // waves per SIMD the tile-major kernel is compiled for (A/B build knob)
 #endif
 template <int MP, int CT, int KM, bool WT>

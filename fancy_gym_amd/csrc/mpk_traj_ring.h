@@ -25,6 +25,10 @@ namespace mpk {
 // Every spin is bounded (a protocol bug must fail a test, not hang a GPU).
 // Same tile arithmetic as k_traj_stream / k_traj_flat (same device functions): same bits.
 constexpr int kRingThreads = 768;             // launch bound (12 waves: up to 168 registers); the launcher picks (NP + NS) * 64 <= this
+#ifndef MPK_RING_BY_ARRAY
+#define MPK_RING_BY_ARRAY 0     // 1: open loop with as many engine waves as output arrays: one array per wave.  A/B build knob: within the
+                              // noise of interleaved chunks (three waves: 397 - 416 vs 406 - 422 us; two waves, trajectory only: 283 - 287 vs 279 - 284)
+#endif
 constexpr int kRingThreadsClosed = 1024;      // closed loop: three roles, 93 registers: up to 16 waves
 constexpr int kRingSyncInts = 96;             // full[32] | empty[32] | tickets[8] | tickets published | pad
 constexpr unsigned kRingSpinLimit = 1u << 21; // ~0.3 s of polling with the sleep below: then give up (outputs stay unwritten)
@@ -524,7 +528,7 @@ __global__ void __launch_bounds__(CT >= 3 ? kRingThreadsClosed : kRingThreads) k
             const int nrem = ne > 0 ? (ne * TD) & 3 : 0;          // of them; the launch's last, ragged batch may leave 1 - 3 floats)
             const float* sB = sRing + buf * BUF;
             if (a.ring_dbg & 32) ring_flush<NST, 8>(a, sB, M * IMG, (size_t)e0 * TD, n4, s, NS, lane);
-            else if (CLOSED && NS == 2) {
+            else if ((CLOSED && NS == 2) || (MPK_RING_BY_ARRAY && !CLOSED && NS == NST)) {
                 // closed loop, two engine waves: one ARRAY each (pos / vel), every run written front to back by one wave (measured
                 // equal to interleaved 1 KB chunks: profiles/r04_ring_closed.md)
                 if (a.wt) ring_flush_d<NST, true, NST == 2>(a, sB, M * IMG, (size_t)e0 * TD, n4, 0, 1, lane, s, s + 1);

@@ -344,6 +344,23 @@ def test_many_captured_ring_graphs_replay(mpk_option):
     for g, out, closed in graphs:
         for x, y in zip(out, ref_closed if closed else ref_open):
             assert torch.equal(x, y)
+    # ... and two at a time on two streams: every launch of every graph took its own counter slot at capture (12 x 20 < 256), and a
+    # slot is zero again when its launch ends (the last workgroup to leave zeroes it), so concurrent replays do not meet
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for g, out, closed in graphs:
+        for x in out:
+            x.zero_()
+    torch.cuda.synchronize()
+    for rnd in range(10):
+        for i in range(0, len(graphs), 2):
+            with torch.cuda.stream(sa):
+                graphs[i][0].replay()
+            with torch.cuda.stream(sb):
+                graphs[i + 1][0].replay()
+    torch.cuda.synchronize()
+    for g, out, closed in graphs:
+        for x, y in zip(out, ref_closed if closed else ref_open):
+            assert torch.equal(x, y)
 
 
 @pytest.mark.parametrize("quad", ["0", "2", "3", "4"])

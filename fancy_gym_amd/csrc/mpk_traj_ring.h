@@ -318,20 +318,22 @@ __device__ __forceinline__ void ring_flush_d(const TrajArgs& a, const float* sB,
     }
 }
 
-// CLOSED loop (CT >= 3; round 4, second session): a third role.  The serial recurrence (controller + plant, float64, no FMA: the
+// CLOSED loop (CT >= 3; round 4, second session): two more roles.  The serial recurrence (controller + plant, float64, no FMA: the
 // chain of every closed-loop kernel, 9 dependent operations per step) cannot sit on the producers -- one group per wave is four
 // times the serial instructions -- and the lane-quarter kernels (k_traj_quad / duo), which run four recurrences per wave, write
 // 896-byte pieces of 6 - 12 output streams per wave: stores alone 153 of 166 us at 65 536 episodes (profiles/r04_closed_loop.md).
-// Here:  producers   contract the (pos, vel) images of their groups, no controller, no store;
-//        the engine  writes pos and vel of a batch as two contiguous runs as soon as the batch is produced;
-//        consumers   (waves NP + NS ..): wave c takes the batches c, c + NC, ... of the workgroup and runs the FOUR recurrences of a
-//                    batch at once, one group per lane quarter, reading the desired states from the images the producers left
-//                    (offsets as immediates: DC is a compile-time constant); the actions of a row tile go through a wave-private
-//                    LDS tile and leave as one coalesced float4 store per group -- a third of the bytes in 896-byte pieces, two
-//                    thirds in 22 KB runs.  Integer replanning state, boundary-condition gather and plant state are the
-//                    consumer's, exactly as in k_traj_quad.
+// Here:  producers   contract the (pos, vel) images of their groups, no controller, no store; every completed ROW TILE is published;
+//        the engine  writes pos and vel of a batch as two contiguous runs as soon as the batch is complete;
+//        consumers   (waves NP + NS .. + NC): wave c takes the batches c, c + NC, ... of the workgroup and runs the FOUR recurrences
+//                    of a batch at once, one group per lane quarter, reading the desired states from the images the producers left
+//                    (offsets as immediates: DC is a compile-time constant) as the tiles arrive; serial inputs one batch ahead; the
+//                    actions of a row tile into a wave-private LDS tile set.  Integer replanning state, boundary-condition gather and
+//                    plant state are the consumer's, exactly as in k_traj_quad;
+//        writers     (one per consumer): pull a posted tile set into registers, hand the staging back, issue the stores -- a third of
+//                    the bytes in 896-byte pieces, two thirds in 22 KB runs; the consumers never issue a global store.
 // A batch buffer (pos | vel of M = 4 groups) is free again when the engine's NS waves AND the consumer have released it (NS + 1
 // increments of the slot's `empty` counter).  Same device functions as the other closed-loop kernels: same bits.
+// (profiles/r04_ring_closed.md: geometry sweep, ablations, per-role timelines.)
 template <int MP, int CT, int KM, int DC>
 __global__ void __launch_bounds__(CT >= 3 ? kRingThreadsClosed : kRingThreads) k_traj_ring(const TrajArgs a, const ActArgs act) {
     static_assert(MP != MPK_MP_DMP && (CT < 3 || DC > 0), "promp / prodmp; closed loop with the DoF count compiled in");

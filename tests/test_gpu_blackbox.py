@@ -557,6 +557,36 @@ def test_closed_loop_on_the_ring_is_bit_identical(cfg, controller, B, mpk_option
         assert torch.equal(x, y), i
 
 
+def test_closed_loop_ring_at_the_size_it_is_chosen_for(mpk_option):
+    """65 536 episodes (550 MB of outputs: plain stores, the automatic choice): k_traj_ring<.., closed> == k_traj_duo, every output
+    and the plant state bit for bit, for a full-horizon step and a replanning step"""
+    pc, bc, tc, dt, dur = CFG2
+    eng = make_engine(pc, bc, tc, dt, dur)
+    B = 65536
+    params, ip, iv = inputs(pc, bc, tc, B, seed=11)
+    rng = np.random.default_rng(11)
+    q0, qd0 = rng.uniform(-1, 1, (B, 7)), rng.uniform(-0.2, 0.2, (B, 7))
+    T = eng.num_steps
+    spec = RolloutSpec("motor", 7, PG, DG, -0.9, 0.9, plant="double_integrator", dt=dt)
+    ts0 = rng.integers(0, 2 * T, B).astype(np.int32); ps0 = rng.integers(0, 4, B).astype(np.int32)
+    dn0 = (rng.random(B) < 0.2).astype(np.uint8)
+    res = {}
+    for name, opts in (("ring", {}), ("duo", {"quad": 3})):
+        for k in ("quad",):
+            mpk_option(k, opts.get(k, -1))
+        q, qd = torch.tensor(q0, device="cuda"), torch.tensor(qd0, device="cuda")
+        out = [x.clone() for x in eng.trajectory_rollout(params, ip, iv, spec, q, qd, init_time=0.25)] + [q, qd]
+        assert eng.last_kernel().startswith("k_traj_" + name), eng.last_kernel()
+        st = (torch.tensor(q0, device="cuda"), torch.tensor(qd0, device="cuda"), torch.tensor(ts0, device="cuda"),
+              torch.tensor(ps0, device="cuda"), torch.tensor(dn0, device="cuda"))
+        r = eng.replan_step(params, ip, iv, spec, *st, 25, 3, 2 * T, init_time=0.0, condition=True)
+        assert eng.last_kernel().startswith("k_traj_" + name), eng.last_kernel()
+        res[name] = out + [r[k].clone() for k in ("pos", "vel", "actions", "seg_len", "done", "cond_pos", "cond_vel")] + list(st)
+        del out, r
+    for i, (x, y) in enumerate(zip(res["ring"], res["duo"])):
+        assert torch.equal(x, y), i
+
+
 def test_closed_loop_ring_declines_shapes_it_does_not_take(mpk_option):
     """cfg5 (350 x 7: T * D = 2 mod 4) stays on the lane-quarter kernels even when the ring is forced"""
     pc, bc, tc, dt, dur = CFG5

@@ -325,7 +325,8 @@ def test_random_closed_loop_step_through_the_ring_is_bit_identical(seed, mpk_opt
     if mp == "prodmp" and (dur + init_time) / pc.tau > 5.9:
         init_time = 0.0
     opts = dict(ring_np=int(r.choice([-1, 1, 3, 8, 9])), ring_ns=int(r.choice([-1, 1, 2, 3])), ring_nc=int(r.choice([-1, 1, 2, 3, 4, 6])),
-                ring_m=int(r.choice([-1, -1, 1, 2, 3])), ring_dbg=int(r.choice([0, 0, 4, 8, 12, 16, 24, 32, 40])))
+                ring_m=int(r.choice([-1, -1, 1, 2, 3])), ring_dbg=int(r.choice([0, 0, 4, 8, 12, 16, 24, 32, 40, 64])),
+                write_through=int(r.choice([-1, -1, 0, 1])))
 
     def run():
         q, qd = torch.tensor(q0, device="cuda"), torch.tensor(qd0, device="cuda")

@@ -77,9 +77,11 @@ constexpr double kRingBytes = 600.0 * 1024 * 1024;
 // a ticket of k_traj_ring covers at least this many bytes of batch buffers: one device counter hands out ~88 tickets / us
 // (profiles/r04_store_engine_probe_dynamic.md), 32768 tickets of 67 KB saturate it, 10923 of 201 KB do not
 constexpr size_t kRingTicketBytes = 192 * 1024;
-// closed loop: the ring with consumer waves (k_traj_ring<.., closed>) is automatic once the step's three output arrays exceed this
-// (A/B against k_traj_quad / duo per size: profiles/r04_ring_closed.md)
-constexpr double kRingClosedBytes = 400.0 * 1024 * 1024;
+// closed loop: the ring with consumer waves (k_traj_ring<.., closed>) is automatic once the step's three output arrays exceed this:
+// where k_traj_quad's two waves per SIMD stop paying (us, full horizon / replanning step, profiles/r04_ring_closed.md):
+//   32 768 episodes (275 MB)  quad 54.8 / 51.8   ring 63.6 / 57.1        36 864 (310 MB)  quad 73.5 / 72.2   ring 69.5 / 65.2
+//   34 816 (292 MB)           quad 65.0 / 60.7   ring 66.8 / 58.0        40 960 (344 MB)  quad 92.6, duo 127.5   ring 84.5 / 76.9
+constexpr double kRingClosedBytes = 295.0 * 1024 * 1024;
 
 // Kernels that may take more than the default 64 KB of dynamic LDS: the function attribute is raised ONCE per kernel
 // instantiation to the CU's whole LDS (160 KB), not per launch with the launch's size -- hipFuncSetAttribute rewrites state of a

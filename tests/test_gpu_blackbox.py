@@ -603,11 +603,11 @@ def test_closed_loop_ring_declines_shapes_it_does_not_take(mpk_option):
 def test_four_groups_per_wave_while_the_outputs_fit_the_memory_side_cache():
     """the launcher's rule for the serial-recurrence kernels (profiles/r04_closed_loop.md): closed loop at 16 384 / 32 768 and cfg3
     at its BASELINE size on k_traj_quad, smaller launches on k_traj_duo, a few thousand closed-loop episodes on k_traj_pipe, and --
-    second half of round 4 -- steps whose outputs exceed the caches (> 400 MB) on the ring with consumer waves"""
+    second half of round 4 -- steps whose outputs exceed the memory-side cache (> 295 MiB) on the ring with consumer waves"""
     pc, bc, tc, dt, dur = CFG2
     eng = make_engine(pc, bc, tc, dt, dur)
     spec = RolloutSpec("motor", 7, PG, DG, -0.9, 0.9, plant="double_integrator", dt=dt)
-    for B, want in ((4096, "k_traj_pipe"), (8192, "k_traj_duo"), (16384, "k_traj_quad"), (32768, "k_traj_quad"), (65536, "k_traj_ring")):
+    for B, want in ((4096, "k_traj_pipe"), (8192, "k_traj_duo"), (16384, "k_traj_quad"), (32768, "k_traj_quad"), (40960, "k_traj_ring"), (65536, "k_traj_ring")):
         params, ip, iv = inputs(pc, bc, tc, B, seed=1)
         q, qd = torch.zeros((B, 7), dtype=torch.float64, device="cuda"), torch.zeros((B, 7), dtype=torch.float64, device="cuda")
         eng.trajectory_rollout(params, ip, iv, spec, q, qd)

@@ -78,9 +78,8 @@ def main():
     variants = [("auto", {}), ("pipe=1", {"pipe": 1}), ("pipe=0", {"pipe": 0}), ("split", {"split": 1}), ("quad", {"quad": 2}), ("duo", {"quad": 3}), ("mono", {"quad": 4}), ("auto (again)", {})]
     if "--ring" in sys.argv:      # the closed loop on the ring (k_traj_ring<.., closed>) and its launch geometries against the lane-quarter kernels
         R = {"ring": 1}
-        variants = [("auto", {}), ("duo", {"quad": 3}), ("ring", dict(R)), ("ring, engine 4 chunks", dict(R, ring_dbg=64)), ("ring ns2", dict(R, ring_ns=2, ring_np=7)),
-                    ("ring ns2, engine 4 chunks", dict(R, ring_ns=2, ring_np=7, ring_dbg=64)),
-                    ("ring, consumers store", dict(R, ring_dbg=8, ring_nc=4)), ("ring tickets", dict(R, ring_dbg=4)),
+        variants = [("auto", {}), ("quad", {"quad": 2}), ("duo", {"quad": 3}), ("ring", dict(R)), ("ring tickets", dict(R, ring_dbg=4)),
+                    ("ring, consumers store", dict(R, ring_dbg=8, ring_nc=4)), ("ring ns2", dict(R, ring_ns=2, ring_np=7)),
                     ("ring no stores", dict(R, ring_dbg=2)), ("ring no compute", dict(R, ring_dbg=1)), ("auto (again)", {})]
     if "--ring-sweep" in sys.argv:
         variants = [("duo", {"quad": 3})]

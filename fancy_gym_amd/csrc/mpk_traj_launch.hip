@@ -245,7 +245,20 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
             if (quad_mode == 2) quad = fits(4) ? 4 : 0;
             else if (quad_mode == 3) quad = fits(2) ? 2 : 0;
             else if (quad_mode == 4) quad = fits(1) ? 1 : 0;
-            else if (fits(4) && units4 >= (long)num_cu * 8 && out_bytes <= kWtBytes) quad = 4;
+            else if (c.mp_type == MPK_MP_DMP && fits(4)) {
+                // DMP (round 4, second session: sweep in steps of 2 048 episodes, profiles/r04_serial_quantization.md): the launches
+                // are ROUNDS of resident waves -- two per SIMD with four groups per wave, three with two (cfg3's shape) -- and a
+                // launch that needs one wave more than a round takes most of a second one: cfg3 at 18 432 episodes 53 us with four
+                // groups (2 304 units for 2 048 places) against 42 with two.  Four groups per wave exactly where they fit ONE round and
+                // two groups per wave would not (12 289 - 16 384 episodes of cfg3: 30.6 - 32.6 us against 38.5 - 38.9)
+                if (units4 <= (long)num_cu * 8 && units2 > (long)num_cu * 12) quad = 4;
+                else if (fits(2) && units2 >= (long)num_cu * 4) quad = 2;
+            }
+            // (closed loop, second session: ... and four per wave ALSO where two per wave would need a second round of resident waves
+            // (two per SIMD) and four per wave fit one -- 8 193 - 16 383 episodes at 7 DoF: a launch with one wave too many for a
+            // round takes most of another; 8 704: 26.7 -> 25.3 us, 12 288: 28.0 -> 26.6, 14 336: 33.5 -> 27.8)
+            else if (fits(4) && out_bytes <= kWtBytes &&
+                     (units4 >= (long)num_cu * 8 || (closed && units2 > (long)num_cu * 8 && units4 <= (long)num_cu * 8))) quad = 4;
             else if (fits(2) && units2 >= (long)num_cu * 4) quad = 2;
             else if (closed && fits(1)) quad = 1;
         }

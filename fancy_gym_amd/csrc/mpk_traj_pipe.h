@@ -23,8 +23,18 @@ constexpr int kPipeGroups = 4;
                              // wave issues one instruction per 6 cycles, a dependent one per 8.9: profiles/r04_closed_loop.md)
 #endif
 
+#ifndef MPK_PIPE_LEAN_WAVES
+#define MPK_PIPE_LEAN_WAVES 0    // 6: the register-lean instantiation forced to six waves per SIMD (80 registers + 16 B of scratch) so that a
+                                 // FOURTH workgroup per CU is resident.  Measured slower everywhere (6 144: 13.1 -> 13.8 us, 8 192: 20.2 -> 23.9):
+                                 // A/B build knob, off (profiles/r04_serial_quantization.md)
+#endif
+#if MPK_PIPE_LEAN_WAVES
+#define MPK_PIPE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(LEAN ? MPK_PIPE_LEAN_WAVES : 4, LEAN ? MPK_PIPE_LEAN_WAVES : 10)))
+#else
+#define MPK_PIPE_WAVES_ATTR
+#endif
 template <int MP, int CT, int KM, bool LEAN>
-__global__ void __launch_bounds__(320) k_traj_pipe(const TrajArgs a, const ActArgs act) {
+__global__ void __launch_bounds__(320) MPK_PIPE_WAVES_ATTR k_traj_pipe(const TrajArgs a, const ActArgs act) {
     static_assert(CT >= 3 && MP != MPK_MP_DMP, "closed loop, promp / prodmp");
     __shared__ __attribute__((aligned(16))) float smem[2 * kPipeGroups * kQuadImg];   // [buffer][group] pos | vel | act
     extern __shared__ __attribute__((aligned(16))) float sTab[];                      // [NOUT][KP][TS] rows + [TS] aux

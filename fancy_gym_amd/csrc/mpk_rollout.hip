@@ -624,14 +624,16 @@ int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const f
         pa.G = (B + NTW - 1) / NTW;
         pa.inv_seg4 = 65536u / (unsigned)(4 * D) + 1u;
         // groups per wave (lane quarter j runs group j's recurrence: NG x fewer serial instructions per episode) chosen by the
-        // waves per SIMD it leaves (1024 SIMDs): four from 8 groups per SIMD on, two from 2, else one ("pd_quad": 0 one, 2 four,
-        // 3 two).  Measured (profiles/r04_rollout.md)
+        // waves per SIMD it leaves (1024 SIMDs): four from 5 groups per SIMD on, two from 1.5, else one ("pd_quad": 0 one, 2 four,
+        // 3 two).  Measured (profiles/r04_rollout.md; second session, after the tile loop stopped waiting for its stores, cfg2 shape:
+        // 3 072 episodes 12.7 -> 11.3 us with two, 10 240 / 12 288 / 14 336: 24.1 / 26.5 / 30.6 -> 21.6 / 23.2 / 24.9 us with four;
+        // 8 192: two 16.8, four 17.1)
         const int quad_mode = tune.pd_quad < 0 ? 1 : tune.pd_quad;
         const long simds = 1024;
         int ng = 1;
         if (quad_mode == 2) ng = 4;
         else if (quad_mode == 3) ng = 2;
-        else if (quad_mode == 1) ng = pa.G >= 8 * simds ? 4 : (pa.G >= 2 * simds ? 2 : 1);
+        else if (quad_mode == 1) ng = pa.G >= 5 * simds ? 4 : (2 * pa.G >= 3 * simds ? 2 : 1);
         const int units = (pa.G + ng - 1) / ng;
         int blocks = (units + 3) / 4;
         if (blocks > 2048) blocks = 2048;

@@ -252,7 +252,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
                 // groups (2 304 units for 2 048 places) against 42 with two.  Four groups per wave exactly where they fit ONE round and
                 // two groups per wave would not (12 289 - 16 384 episodes of cfg3: 30.6 - 32.6 us against 38.5 - 38.9)
                 if (units4 <= (long)num_cu * 8 && units2 > (long)num_cu * 12) quad = 4;
-                else if (fits(2) && units2 >= (long)num_cu * 4) quad = 2;
+                else if (fits(2) && units2 >= (long)num_cu * 6) quad = 2;      // (below: one group per wave, k_traj_stream -- cfg3 at 4 096: 17.0 vs 18.5 us)
             }
             // (closed loop, second session: ... and four per wave ALSO where two per wave would need a second round of resident waves
             // (two per SIMD) and four per wave fit one -- 8 193 - 16 383 episodes at 7 DoF: a launch with one wave too many for a

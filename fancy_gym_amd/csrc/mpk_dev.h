@@ -72,8 +72,11 @@ constexpr double kWtBytes = 300.0 * 1024 * 1024;
 // k_traj_ring (wave-specialised store engine, in-order batch tickets) takes the open-loop launches that write more than this:
 // B = 262144 (2.2 GB): 386 us against k_traj_flat's 417 - 447 on the same boxes; B = 65536 +actions (550 MB): 112 - 115 against
 // 115 - 121; trajectory only at 65536 (367 MB): 83 against 80 - 82 -- below that the persistent one-workgroup-per-CU launch has
-// too few batches per CU to amortise its ramp (profiles/r04_ring.md)
-constexpr double kRingBytes = 600.0 * 1024 * 1024;
+// too few batches per CU to amortise its ramp (profiles/r04_ring.md).  Second session, one call over nine sizes
+// (profiles/r04_open_loop_choice.md; us, flat / ring): +actions 49 152 (424 MB) 92.8 / 91.2, 65 536 (565 MB) 123.4 / 118.1,
+// 81 920: 153.1 / 144.2; trajectory only 65 536 (382 MB) 87.0 / 86.0, 81 920 (477 MB) 105.8 / 100.1, 98 304 (573 MB) 124.1 / 118.2;
+// 32 768 (283 / 191 MB): 55.9 / 71.2 and 33.6 / 46.9 -- the ring from 440 MB on (was 600 MiB)
+constexpr double kRingBytes = 420.0 * 1024 * 1024;
 // a ticket of k_traj_ring covers at least this many bytes of batch buffers: one device counter hands out ~88 tickets / us
 // (profiles/r04_store_engine_probe_dynamic.md), 32768 tickets of 67 KB saturate it, 10923 of 201 KB do not
 constexpr size_t kRingTicketBytes = 192 * 1024;

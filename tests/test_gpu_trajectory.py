@@ -329,7 +329,7 @@ def test_ring_kernel_fused_actions_bit_exact(B, ctrl, mpk_option):
 
 
 def test_ring_kernel_is_the_automatic_choice_for_launches_that_stream_to_hbm_and_only_those(mpk_option):
-    """outputs beyond kRingBytes (600 MB) of an open-loop promp / prodmp launch -> k_traj_ring; DMP, the closed loop and smaller
+    """outputs beyond kRingBytes (440 MB) of an open-loop promp / prodmp launch -> k_traj_ring; DMP, the closed loop and smaller
     launches keep their kernels; two launches of one handle on two streams do not share a ticket counter"""
     pc, bc, tc, dt, duration = CFG2
     eng = make_engine(pc, bc, tc, dt, duration)

@@ -823,6 +823,152 @@ __global__ void __launch_bounds__(256) k_traj_phase_dmp(const PhaseArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// k_traj_phase_dmp_wg (round 4, second session): the per-episode-phase DMP for launches that leave k_traj_phase_dmp one wave per
+// SIMD or fewer (a few thousand episodes: 55 us whatever the batch, every wave walking 13 tiles of rows -> Euler -> stores on its
+// own).  Here a WORKGROUP of four waves owns a chunk of E episodes and walks the horizon in blocks of four 16-step tiles:
+//   A  wave w builds the rows and forcing values of tile w of the block (the 64 (episode, step) items of a tile are one round of a
+//      wave, as in k_traj_phase_dmp: the same functions, the same bits) -- four tiles at once;
+//   B  wave 0 runs the block's 64 Euler steps of every (episode, DoF) lane (the serial part: the only one that stays serial);
+//   C  all four waves store the block's (pos, vel) runs of 64 x D floats per episode.
+// ------------------------------------------------------------------------------------------------------------
+template <int KQ>
+__global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_wg(const PhaseArgs a) {   // (four workgroups per CU: 4 096 episodes of cfg3 in one round)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const DevCfg& c = a.c;
+    constexpr int KS = KQ * 4, TT = 16, NTB = 4, TB = TT * NTB;     // steps per block
+    constexpr int MP = MPK_MP_DMP;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int D = c.D, T = c.T, E = a.chunk, P = c.P;
+    const int bseg = TB * D;                            // floats of one episode's block
+    double* sCen = reinterpret_cast<double*>(smem);     // [c_pad / 2] RBF centres | bandwidths
+    float* sBT = smem + a.c_pad;                        // [t_pad] base times
+    float* sX = sBT + a.t_pad;                          // [E][D][KS] columns: weights .., goal, y0, ydot0
+    float* sPh = sX + E * a.x_pad;                      // [E][8] tau, delay, init_time (clipped), -, 1 / tau refined (float64), -
+    float* sDs = sPh + 8 * E;                           // [E][TB] ds of the block's steps
+    float* sH = sDs + E * TB;                           // [4 waves][64][KS] the tile's RBF rows
+    float* sP = sH + 4 * 64 * KS;                       // [E][TB * D] forcing -> pos
+    float* sV = sP + E * bseg;                          // [E][TB * D] vel
+    for (int t = threadIdx.x; t < T; t += blockDim.x) sBT[t] = c.base_times[t];
+    for (int k = threadIdx.x; k < 2 * c.n_total + 3; k += blockDim.x) sCen[k] = c.tab[k];
+    const float inv_d = 1.0f / (float)D;
+    const int le = (int)(((float)lane + 0.5f) * inv_d), ld = lane - le * D;        // lane <-> (episode, DoF)  (wave 0)
+    const bool vec = a.vec_ok != 0;
+    const int nchunks = (a.B + E - 1) / E;
+    for (int ch = (int)blockIdx.x; ch < nchunks; ch += (int)gridDim.x) {
+        const int b0 = ch * E, ne = min(E, a.B - b0);
+        __syncthreads();                                // (the previous chunk's images are stored; the tables are in)
+        for (int idx = threadIdx.x; idx < ne * D * KS; idx += blockDim.x) {
+            const int pi = idx / KS, k = idx - pi * KS;             // pi = e * D + dd
+            const int e = (int)(((float)pi + 0.5f) * inv_d), dd = pi - e * D;
+            const size_t bb = (size_t)(b0 + e);
+            sX[idx] = phase_x_value<MP>(c, a.params + bb * P, a.init_pos + bb * D, a.init_vel + bb * D, dd, k, KS);
+        }
+        float tau = c.tau, delay = c.delay, it = a.init_time_shared;
+        const bool on = wave == 0 && lane < ne * D;
+        if (on) {
+            const float* prm = a.params + (size_t)(b0 + le) * P;
+            if (c.learn_tau) tau = fminf(fmaxf(prm[0], c.tau_lo), c.tau_hi);
+            if (c.learn_delay) delay = fminf(fmaxf(prm[c.learn_tau ? 1 : 0], c.delay_lo), c.delay_hi);
+            if (a.init_time) it = a.init_time[b0 + le];
+            if (ld == 0) {
+                sPh[8 * le] = tau; sPh[8 * le + 1] = delay; sPh[8 * le + 2] = it;
+                *reinterpret_cast<double*>(sPh + 8 * le + 4) = make_pos_div((double)tau).y;
+            }
+        }
+        __syncthreads();
+        float y = 0.0f, z = 0.0f, g = 0.0f;
+        if (on) {
+            const float* xc = sX + lane * KS;
+            g = xc[KS - 3] * c.gs; y = xc[KS - 2]; z = xc[KS - 1] * tau;
+        }
+        const TauDiv td = make_tau_div(tau);
+        for (int t0 = 0; t0 < T; t0 += TB) {
+            const int rows = min(TB, T - t0);
+            // ---- A: wave w: rows and forcing of tile w of the block
+            {
+                const int e = lane >> 4, tl = lane & (TT - 1), tb = wave * TT + tl, t = t0 + tb;
+                const bool live = e < ne && t < T;
+                float* row = sH + (wave * 64 + lane) * KS;
+                if (live) {
+                    const float taue = sPh[8 * e], delaye = sPh[8 * e + 1], ite = sPh[8 * e + 2];
+                    const float time = sBT[t] + ite;
+                    const PosDiv taud{(double)taue, *reinterpret_cast<const double*>(sPh + 8 * e + 4)};
+                    const double x = phase_f64(c, time, taud, delaye, ExpLiteral());
+                    float h[KS];
+#pragma unroll
+                    for (int k = 0; k < KS; ++k) h[k] = 0.0f;
+                    rbf_row<KS>(c, sCen, sCen + c.n_total, x, x * (double)c.ws, h, ExpLiteral());
+#pragma unroll
+                    for (int j = 0; j < KQ; ++j)
+                        *reinterpret_cast<f32x4*>(row + 4 * j) = f32x4{h[4 * j], h[4 * j + 1], h[4 * j + 2], h[4 * j + 3]};
+                    if (t < T - 1) sDs[e * TB + tb] = scaled_time(sBT[t + 1] + ite, delaye, taue) - scaled_time(time, delaye, taue);
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (live) {
+                    for (int d = 0; d < D; ++d) {
+                        float x[KS];
+#pragma unroll
+                        for (int j = 0; j < KQ; ++j) {
+                            const float4 v = *reinterpret_cast<const float4*>(sX + (e * D + d) * KS + 4 * j);
+                            x[4 * j + 0] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
+                        }
+                        x[KS - 3] = 0.0f; x[KS - 2] = 0.0f; x[KS - 1] = 0.0f;      // goal, y0, ydot0 are not weights
+                        sP[e * bseg + tb * D + d] = row_chain<KQ>(row, x);
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- B: wave 0: the block's Euler steps of every (episode, DoF) of the chunk (one rounding per operation)
+            if (on) {
+                // (a plain loop: the unrolled tile form of dmp_tile_steps -- 16 forcing values and step sizes in registers first --
+                // measured the same 35 us at 4 096 episodes and needed scratch to stay at four workgroups per CU)
+                float* pp = sP + le * bseg + ld;
+                float* pv = sV + le * bseg + ld;
+                const float* pds = sDs + le * TB;
+                for (int tl = 0; tl < rows; ++tl) {
+                    const float f = pp[tl * D];
+                    pp[tl * D] = y;
+                    pv[tl * D] = div_tau(z, td);
+                    if (t0 + tl < T - 1) {
+                        const float ds = pds[tl];
+                        const float t1 = g - y;
+                        const float t2 = c.dmp_beta * t1;
+                        const float t3 = t2 - z;
+                        const float t4 = c.dmp_alpha * t3;
+                        const float acc = t4 + f;
+                        z = z + ds * acc;
+                        y = y + ds * z;
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- C: the block's runs, rows * D contiguous floats per episode and array
+            const int n = rows * D;
+            if (vec) {
+                const int n4 = n >> 2;
+                for (int idx = threadIdx.x; idx < ne * n4; idx += blockDim.x) {
+                    const int e = idx / n4, q4 = idx - e * n4;
+                    const size_t go = ((size_t)(b0 + e) * T + t0) * D + 4 * q4;
+                    const f32x4 vp = *reinterpret_cast<const f32x4*>(sP + e * bseg + 4 * q4);
+                    const f32x4 vv = *reinterpret_cast<const f32x4*>(sV + e * bseg + 4 * q4);
+                    if (a.wt) { store16<true>(a.pos + go, vp); store16<true>(a.vel + go, vv); }
+                    else { store16<false>(a.pos + go, vp); store16<false>(a.vel + go, vv); }
+                }
+            } else {
+                for (int idx = threadIdx.x; idx < ne * n; idx += blockDim.x) {
+                    const int e = idx / n, w = idx - e * n;
+                    const size_t go = ((size_t)(b0 + e) * T + t0) * D + w;
+                    if (a.wt) { store4<true>(a.pos + go, sP[e * bseg + w]); store4<true>(a.vel + go, sV[e * bseg + w]); }
+                    else { store4<false>(a.pos + go, sP[e * bseg + w]); store4<false>(a.vel + go, sV[e * bseg + w]); }
+                }
+            }
+            __syncthreads();                            // the block's LDS reads are issued before the next block's writes
+        }
+    }
+}
+
 #ifndef MPK_DEVICE_ONLY
 static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu, void* stream,
                              const char** kernel_name, const Tuning& tune) {
@@ -967,9 +1113,35 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
             *kernel_name = "k_traj_phase<promp>";
             if (KQ == 1) return go(k_traj_phase<MPK_MP_PROMP, 1, false>);
             return KQ == 2 ? go(k_traj_phase<MPK_MP_PROMP, 2, false>) : go(k_traj_phase<MPK_MP_PROMP, 4, false>);
-        default:
+        default: {
+            // few chunks (the wave-per-chunk kernel would run at one wave per SIMD or fewer, latency bound): a workgroup per chunk,
+            // four tiles of rows at once (k_traj_phase_dmp_wg).  "phase_flat" 1 forces it, 0 forbids it (A/B runs, tests)
+            const long chunks = ((long)pa.B + pa.chunk - 1) / pa.chunk;
+            const size_t wg_floats = (size_t)pa.c_pad + pa.t_pad + (size_t)pa.chunk * pa.x_pad + 8 * pa.chunk + (size_t)pa.chunk * 64 +
+                                     4 * 64 * KS + 2 * (size_t)pa.chunk * 64 * c.D;
+            const size_t wg_lds = wg_floats * sizeof(float);
+            const bool wg_ok = pa.chunk * 16 <= 64 && pa.chunk * c.D <= 64 && wg_lds <= kLdsPerCu && (c.D * 64 * 4) % 16 == 0;
+            int wg_res = (int)(kLdsPerCu / wg_lds);                 // resident workgroups per CU: LDS, and five by its 83 - 108 registers
+            wg_res = wg_res > (KQ == 2 ? 5 : 4) ? (KQ == 2 ? 5 : 4) : wg_res;
+            // (beyond ONE round of resident workgroups the wave-per-chunk kernel is as fast: cfg3' at 6 144 episodes 58 vs 61 us)
+            const bool wg = wg_ok && tune.phase_flat != 0 && (tune.phase_flat == 1 || chunks <= (long)num_cu * wg_res);
+            if (wg) {
+                long nb = chunks < (long)num_cu * wg_res ? chunks : (long)num_cu * wg_res;
+                auto gow = [&](auto kern) -> int {
+                    if (wg_lds > kLdsDefault) {
+                        hipError_t e = allow_full_lds(kern);
+                        if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return MPK_EHIP; }
+                    }
+                    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), wg_lds, (hipStream_t)stream, pa);
+                    MPK_LAUNCH_CHECK();
+                    return MPK_OK;
+                };
+                *kernel_name = "k_traj_phase<dmp,wg>";
+                return KQ == 2 ? gow(k_traj_phase_dmp_wg<2>) : gow(k_traj_phase_dmp_wg<4>);
+            }
             *kernel_name = "k_traj_phase<dmp>";
             return KQ == 2 ? go(k_traj_phase_dmp<2>) : go(k_traj_phase_dmp<4>);
+        }
     }
 }
 #endif  // MPK_DEVICE_ONLY

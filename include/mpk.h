@@ -206,7 +206,8 @@ int mpk_set_duration(mpk_handle h, double duration, double dt);
  *   "phase_table"   0 ProDMP row table from L2 instead of LDS
  *   "phase_chunk"   episodes per wave and chunk: 1 / 2 / 4 (promp / prodmp; prodmp with flat rounds: 1 .. 8), 1 .. min(16, 64 / D) (dmp)
  *   "phase_flat"    0 rounds per episode, 1 rounds over the flattened (episode, step) items of a chunk (wave-per-episode
- *                   prodmp kernel; automatic when the horizon is not a multiple of 64)
+ *                   prodmp kernel; automatic when the horizon is not a multiple of 64); dmp: 1 forces / 0 forbids the
+ *                   workgroup-per-chunk kernel (automatic for a few thousand episodes)
  *   "pd_simple"     1 generic one-lane-per-(episode, DoF) rollout kernels
  *   "pipe"          0 off, 1 force the producer / consumer closed-loop kernel (k_traj_pipe; the default where it fits)
  *   "flat"          0 off, 1 force the whole-trajectory-image episode-major kernel (k_traj_flat; automatic for open-loop

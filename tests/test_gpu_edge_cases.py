@@ -3,6 +3,8 @@ GPU suite, part 3: edge cases -- every DoF count / basis count / horizon shape c
 episode group, partial last row tile, unaligned outputs -> generic store path, D or K beyond the MFMA kernel's limits ->
 per-episode kernel), empty batches, bound clipping, range errors, and both work decompositions.
 """
+import dataclasses
+
 import numpy as np
 import pytest
 import torch
@@ -759,6 +761,25 @@ def test_long_horizons_take_the_kernels_that_fit(mp, T):
     assert np.array_equal(act.cpu().numpy(), ra.astype(np.float32)) and np.array_equal(q.cpu().numpy(), rq)
 
 
+@pytest.mark.parametrize("D,nb,T,B", [(7, 5, 200, 1), (7, 5, 200, 37), (7, 5, 200, 1026), (3, 4, 70, 9), (16, 9, 33, 50), (5, 2, 64, 130)])
+def test_per_episode_dmp_workgroup_and_wave_kernels_agree_bitwise(D, nb, T, B, mpk_option):
+    """learned tau (per-episode phase) DMP: the workgroup-per-chunk kernel (four tiles of rows at once, the automatic choice for a few
+    thousand episodes) and the wave-per-chunk kernel leave the same bits, and both follow the oracle"""
+    pc, bc, tc, dt, dur = cfg_for("dmp", D, nb, T)
+    pc = dataclasses.replace(pc, learn_tau=True, tau_bound=(0.5 * dur, 1.5 * dur))
+    eng = make_engine(pc, bc, tc, dt, dur)
+    params, ip, iv = inputs(pc, bc, tc, B, seed=B + T)
+    mpk_option("phase_flat", 1)
+    p1, v1 = [x.clone() for x in eng.trajectory(params, ip, iv, 0.0)]
+    assert eng.last_kernel() == "k_traj_phase<dmp,wg>", eng.last_kernel()
+    mpk_option("phase_flat", 0)
+    p0, v0 = eng.trajectory(params, ip, iv, 0.0)
+    assert eng.last_kernel() == "k_traj_phase<dmp>", eng.last_kernel()
+    assert torch.equal(p1, p0) and torch.equal(v1, v0)
+    rp, rv = O.get_trajectory(pc, bc, tc, params, dur, dt, 0.0, ip, iv, dtype=np.float64)
+    close(p1.cpu().numpy(), rp, "pos"); close(v1.cpu().numpy(), rv, "vel")
+
+
 def test_dmp_horizon_beyond_the_lds_of_the_shared_phase_kernels_runs_time_tiled():
     """T = 8000: the forcing / state rows of a whole horizon no longer fit any kernel's LDS (round 1 refused this
     shape); the per-episode DMP kernel walks the horizon in 16-step tiles and takes it"""
@@ -766,7 +787,7 @@ def test_dmp_horizon_beyond_the_lds_of_the_shared_phase_kernels_runs_time_tiled(
     eng = make_engine(pc, bc, tc, dt, dur)
     params, ip, iv = inputs(pc, bc, tc, 2, seed=1)
     pos, vel = eng.trajectory(params, ip, iv, 0.0)
-    assert eng.last_kernel() == "k_traj_phase<dmp>"
+    assert eng.last_kernel().startswith("k_traj_phase<dmp"), eng.last_kernel()
     rp, rv = O.get_trajectory(pc, bc, tc, params, dur, dt, 0.0, ip, iv, dtype=np.float64)
     close(pos.cpu().numpy(), rp, "pos"); close(vel.cpu().numpy(), rv, "vel")
 

@@ -835,11 +835,13 @@ __global__ void __launch_bounds__(256) k_traj_phase_dmp(const PhaseArgs a) {
 #ifndef MPK_DMP_WG_UNROLL
 #define MPK_DMP_WG_UNROLL 8        // the Euler loop unrolled: 1 / 4 / 8 -> 33.8 / 32.1 / 30.9 us at 4 096 episodes of cfg3 + learned tau (86 registers, no scratch)
 #endif
-template <int KQ>
+template <int KQ, int NTB>
 __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_wg(const PhaseArgs a) {   // (four workgroups per CU: 4 096 episodes of cfg3 in one round)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevCfg& c = a.c;
-    constexpr int KS = KQ * 4, TT = 16, NTB = 4, TB = TT * NTB;     // steps per block
+    // NTB = tiles per block: 4 with chunks of up to four episodes (wave w: tile w), 2 with chunks of up to eight (wave w: tile w % 2
+    // of episodes 4 (w / 2) ..): the four waves always build four rounds of 64 (episode, step) items at once
+    constexpr int KS = KQ * 4, TT = 16, TB = TT * NTB;     // steps per block
     constexpr int MP = MPK_MP_DMP;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -891,7 +893,7 @@ __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_wg(const PhaseArgs a)
             const int rows = min(TB, T - t0);
             // ---- A: wave w: rows and forcing of tile w of the block
             {
-                const int e = lane >> 4, tl = lane & (TT - 1), tb = wave * TT + tl, t = t0 + tb;
+                const int e = (wave / NTB) * 4 + (lane >> 4), tl = lane & (TT - 1), tb = (wave % NTB) * TT + tl, t = t0 + tb;
                 const bool live = e < ne && t < T;
                 float* row = sH + (wave * 64 + lane) * KS;
                 if (live) {
@@ -1126,16 +1128,32 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
         default: {
             // few chunks (the wave-per-chunk kernel would run at one wave per SIMD or fewer, latency bound): a workgroup per chunk,
             // four tiles of rows at once (k_traj_phase_dmp_wg).  "phase_flat" 1 forces it, 0 forbids it (A/B runs, tests)
-            const long chunks = ((long)pa.B + pa.chunk - 1) / pa.chunk;
-            const size_t wg_floats = (size_t)pa.c_pad + pa.t_pad + (size_t)pa.chunk * pa.x_pad + 8 * pa.chunk + (size_t)pa.chunk * 64 +
-                                     4 * 64 * KS + 2 * (size_t)pa.chunk * 64 * c.D;
-            const size_t wg_lds = wg_floats * sizeof(float);
-            const bool wg_ok = pa.chunk * 16 <= 64 && pa.chunk * c.D <= 64 && wg_lds <= kLdsPerCu && (c.D * 64 * 4) % 16 == 0;
-            int wg_res = (int)(kLdsPerCu / wg_lds);                 // resident workgroups per CU: LDS, and five by its 83 - 108 registers
-            wg_res = wg_res > (KQ == 2 ? 5 : 4) ? (KQ == 2 ? 5 : 4) : wg_res;
-            // (beyond ONE round of resident workgroups the wave-per-chunk kernel is as fast: cfg3' at 6 144 episodes 58 vs 61 us)
+            // two geometries: chunks of (up to) four episodes in blocks of four tiles, or -- when that needs more than one round of
+            // resident workgroups -- chunks of eight in blocks of two tiles (twice the episodes per round)
+            auto wg_bytes = [&](int e, int ntb) {
+                return ((size_t)pa.c_pad + pa.t_pad + (size_t)e * pa.x_pad + 8 * e + (size_t)e * 16 * ntb + 4 * 64 * KS +
+                        2 * (size_t)e * 16 * ntb * c.D) * sizeof(float);
+            };
+            auto wg_resident = [&](size_t bytes) {
+                int r = (int)(kLdsPerCu / bytes);                        // LDS, and five (four) by its 86 - 108 registers
+                return r > (KQ == 2 ? 5 : 4) ? (KQ == 2 ? 5 : 4) : r;
+            };
+            const bool user_chunk = tune.phase_chunk >= 1;
+            int wgE = pa.chunk, wgNTB = 4;
+            bool wg_ok = pa.chunk <= 4 && pa.chunk * c.D <= 64 && wg_bytes(pa.chunk, 4) <= kLdsPerCu;
+            long chunks = ((long)pa.B + wgE - 1) / wgE;
+            if (wg_ok && !user_chunk && pa.chunk == 4 && 8 * c.D <= 64 && chunks > (long)num_cu * wg_resident(wg_bytes(4, 4)) &&
+                wg_bytes(8, 2) <= kLdsPerCu) {
+                wgE = 8; wgNTB = 2;
+                chunks = ((long)pa.B + 7) / 8;
+            }
+            const size_t wg_lds = wg_bytes(wgE, wgNTB);
+            const int wg_res = wg_resident(wg_lds);
+            // (beyond ONE round of resident workgroups the wave-per-chunk kernel is as fast: cfg3' at 6 144 episodes in chunks of
+            // four 58 vs 61 us)
             const bool wg = wg_ok && tune.phase_flat != 0 && (tune.phase_flat == 1 || chunks <= (long)num_cu * wg_res);
             if (wg) {
+                pa.chunk = wgE;
                 long nb = chunks < (long)num_cu * wg_res ? chunks : (long)num_cu * wg_res;
                 auto gow = [&](auto kern) -> int {
                     if (wg_lds > kLdsDefault) {
@@ -1147,7 +1165,8 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
                     return MPK_OK;
                 };
                 *kernel_name = "k_traj_phase<dmp,wg>";
-                return KQ == 2 ? gow(k_traj_phase_dmp_wg<2>) : gow(k_traj_phase_dmp_wg<4>);
+                if (wgNTB == 4) return KQ == 2 ? gow(k_traj_phase_dmp_wg<2, 4>) : gow(k_traj_phase_dmp_wg<4, 4>);
+                return KQ == 2 ? gow(k_traj_phase_dmp_wg<2, 2>) : gow(k_traj_phase_dmp_wg<4, 2>);
             }
             *kernel_name = "k_traj_phase<dmp>";
             return KQ == 2 ? go(k_traj_phase_dmp<2>) : go(k_traj_phase_dmp<4>);

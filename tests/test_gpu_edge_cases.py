@@ -761,7 +761,8 @@ def test_long_horizons_take_the_kernels_that_fit(mp, T):
     assert np.array_equal(act.cpu().numpy(), ra.astype(np.float32)) and np.array_equal(q.cpu().numpy(), rq)
 
 
-@pytest.mark.parametrize("D,nb,T,B", [(7, 5, 200, 1), (7, 5, 200, 37), (7, 5, 200, 1026), (3, 4, 70, 9), (16, 9, 33, 50), (5, 2, 64, 130)])
+@pytest.mark.parametrize("D,nb,T,B", [(7, 5, 200, 1), (7, 5, 200, 37), (7, 5, 200, 1026), (3, 4, 70, 9), (16, 9, 33, 50), (5, 2, 64, 130),
+                                      (7, 5, 200, 6003), (8, 3, 50, 9001), (5, 5, 100, 7000)])     # (the last three: chunks of eight episodes)
 def test_per_episode_dmp_workgroup_and_wave_kernels_agree_bitwise(D, nb, T, B, mpk_option):
     """learned tau (per-episode phase) DMP: the workgroup-per-chunk kernel (four tiles of rows at once, the automatic choice for a few
     thousand episodes) and the wave-per-chunk kernel leave the same bits, and both follow the oracle"""

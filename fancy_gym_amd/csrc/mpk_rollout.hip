@@ -577,7 +577,9 @@ int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
         int ng = 1;
         if (quad_mode == 2) ng = 4;
         else if (quad_mode == 3) ng = 2;
-        else if (quad_mode == 1) ng = pa.G >= 8 * simds ? 4 : (pa.G >= 2 * simds ? 2 : 1);
+        // (second session: the thresholds of launch_pd_rollout -- with the reward 10 240 / 12 288 / 14 336 episodes 85.0 / 85.8 / 100.3 ->
+        // 78.6 / 78.9 / 79.4 us with four groups per wave, 3 072: 48.0 -> 42.6 with two; 8 192: two 52.5, four 68)
+        else if (quad_mode == 1) ng = pa.G >= 5 * simds ? 4 : (2 * pa.G >= 3 * simds ? 2 : 1);
         const int units = (pa.G + ng - 1) / ng;
         int blocks = (units + 3) / 4;
         if (blocks > 2048) blocks = 2048;

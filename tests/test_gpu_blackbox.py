@@ -360,6 +360,55 @@ def test_pd_rollout_is_bit_exact_in_float64(controller, plant, B, simple, monkey
     assert np.array_equal(q.cpu().numpy(), rq) and np.array_equal(qd.cpu().numpy(), rqd)
 
 
+@pytest.mark.parametrize("cfg", ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
+@pytest.mark.parametrize("simple", ["tiles", "simple", "quad"])
+def test_device_controllers_equal_the_reference_controllers(cfg, simple, mpk_option):
+    """tests/golden/ref_controllers.npz: outputs of the reference's OWN PDController / PosController / VelController
+    (fancy_gym/black_box/controller/*.py, loaded unmodified by tests/golden/make_ref_controller_golden.py) on seeded float32
+    desired (+) float64 state, clipped as black_box_wrapper.py:178-179 does.  mpk_pd_rollout on the fixture's desired
+    trajectories must return those actions bit for bit (float64 arithmetic, one float32 rounding at the store) -- frozen
+    state for all three controllers, and the double integrator with the reference's controller in the loop."""
+    if simple == "simple":
+        mpk_option("pd_simple", "1")
+    mpk_option("pd_quad", "2" if simple == "quad" else "0")
+    z = np.load(os.path.join(GOLD, "ref_controllers.npz"))
+    assert "generated from /root/reference controller/*.py" in str(z["meta"])
+    g = lambda n: z[f"{cfg}_{n}"]
+    dp, dv, q0, qd0 = g("des_pos"), g("des_vel"), g("q0"), g("qd0")
+    B, T, D = dp.shape
+    dt = float(g("dt"))
+    # any engine of the right DoF count and horizon carries the rollout entry points
+    eng = fancy_gym_amd.TrajectoryEngine("promp", "linear", "rbf", D, 4, dt=dt, duration=T * dt, tau=T * dt, device=0)
+    assert eng.num_steps == T
+    dpos, dvel = torch.tensor(dp, device="cuda"), torch.tensor(dv, device="cuda")
+    lo, hi = g("lo").astype(np.float64), g("hi").astype(np.float64)
+    for ctrl, key in (("motor", "pd_clip"), ("position", "pos_clip"), ("velocity", "vel_clip")):
+        spec = RolloutSpec(ctrl, D, g("p_gains"), g("d_gains"), lo, hi, plant="static")
+        q, qd = torch.tensor(q0, device="cuda"), torch.tensor(qd0, device="cuda")
+        act = eng.pd_rollout(spec, dpos, dvel, q, qd)
+        assert np.array_equal(act.cpu().numpy(), g(key).astype(np.float32)), (cfg, ctrl)
+        assert np.array_equal(q.cpu().numpy(), q0) and np.array_equal(qd.cpu().numpy(), qd0)
+    spec = RolloutSpec("motor", D, g("p_gains"), g("d_gains"), lo, hi, plant="double_integrator", dt=dt)
+    q, qd = torch.tensor(q0, device="cuda"), torch.tensor(qd0, device="cuda")
+    act = eng.pd_rollout(spec, dpos, dvel, q, qd)
+    assert np.array_equal(act.cpu().numpy(), g("loop_act").astype(np.float32))
+    assert np.array_equal(q.cpu().numpy(), g("loop_q")) and np.array_equal(qd.cpu().numpy(), g("loop_qd"))
+
+
+def test_device_metaworld_controller_equals_the_reference_controller():
+    """the reference's MetaWorldController outputs (ref_controllers.npz) against RolloutSpec('metaworld') on the motor kernels"""
+    z = np.load(os.path.join(GOLD, "ref_controllers.npz"))
+    mi, mo = z["metaworld_in"], z["metaworld_out"]
+    n = mi.shape[0]
+    eng = fancy_gym_amd.TrajectoryEngine("promp", "linear", "rbf", 4, 4, dt=0.02, duration=0.5, tau=0.5, device=0)
+    dp = torch.tensor(mi[:, None, :4].astype(np.float32), device="cuda")       # [n, T = 1, 4]; the inputs are float32-exact
+    assert np.array_equal(dp.cpu().numpy()[:, 0].astype(np.float64), mi[:, :4])
+    spec = RolloutSpec("metaworld", 4, plant="static")
+    q, qd = torch.tensor(mi[:, 4:].copy(), device="cuda"), torch.zeros((n, 4), dtype=torch.float64, device="cuda")
+    act = eng.pd_rollout(spec, dp, torch.zeros_like(dp), q, qd)
+    assert np.array_equal(act.cpu().numpy()[:, 0], mo.astype(np.float32))
+
+
 @pytest.mark.parametrize("cfg", [CFG2, CFG5], ids=["prodmp", "promp"])
 @pytest.mark.parametrize("controller", ["motor", "position", "velocity"])
 @pytest.mark.parametrize("mapping", ["1", "2"])

@@ -227,6 +227,76 @@ def test_controller_shape_mismatch_raises():
     assert np.array_equal(a, np.array([.5, 1.5, 2.5, 9.]))
 
 
+# ---- the reference's OWN controller code (the one arithmetic of the path that lives in /root/reference) ------------------
+REF_CTRL = os.path.join(GOLD, "ref_controllers.npz")
+REF_CFGS = ("cfg1", "cfg2", "cfg3", "cfg4", "cfg5")
+
+
+def test_reference_controller_fixture_provenance():
+    """tests/golden/ref_controllers.npz holds outputs of /root/reference/fancy_gym/black_box/controller/*.py loaded
+    unmodified (tests/golden/make_ref_controller_golden.py); it is the committed generator's product, and -- in the build
+    container, where the reference lies -- the hashes it records are those of the files as they are now"""
+    import hashlib
+    z = np.load(REF_CTRL)
+    meta = str(z["meta"])
+    assert "generated from /root/reference controller/*.py" in meta
+    gen = hashlib.sha256(open(os.path.join(GOLD, "make_ref_controller_golden.py"), "rb").read()).hexdigest()
+    assert "generator sha256 " + gen in meta, "ref_controllers.npz predates the committed generator: re-run it"
+    assert list(z["shape_errors"]) == ["ValueError"] * 3            # pd_controller.py:22-27 / test_controller.py:47-54
+    ref_dir = "/root/reference/fancy_gym/black_box/controller"
+    if os.path.isdir(ref_dir):
+        for f in ("pd_controller.py", "pos_controller.py", "vel_controller.py", "meta_world_controller.py"):
+            h = hashlib.sha256(open(os.path.join(ref_dir, f), "rb").read()).hexdigest()
+            assert f"{f} sha256 {h}" in meta
+
+
+@pytest.mark.parametrize("cfg", REF_CFGS)
+def test_oracle_controllers_equal_the_reference_controllers(cfg):
+    """oracle pd / pos / vel actions == what the reference's classes returned on the same inputs, bit for bit; the
+    oracle's rollout loop (frozen state and double integrator) == the per-step loop with the reference's PDController in it"""
+    z = np.load(REF_CTRL)
+    g = lambda n: z[f"{cfg}_{n}"]
+    dp, dv, q0, qd0, lo, hi = g("des_pos"), g("des_vel"), g("q0"), g("qd0"), g("lo"), g("hi")
+    pg, dg, dt = g("p_gains"), g("d_gains"), float(g("dt"))
+    pg = float(pg) if pg.ndim == 0 else pg
+    dg = float(dg) if dg.ndim == 0 else dg
+    B, T, D = dp.shape
+    for b in range(B):
+        for t in range(0, T, 7):
+            a = O.pd_action(pg, dg, dp[b, t], dv[b, t], q0[b], qd0[b])
+            assert a.dtype == np.float64 and np.array_equal(a, g("pd")[b, t])
+    # batched form (what the GPU tests compare against)
+    for ctrl, key in (("motor", "pd_clip"), ("position", "pos_clip"), ("velocity", "vel_clip")):
+        ra, rq, rqd = O.rollout(dp, dv, ctrl, pg, dg, lo, hi, "static", dt, q0, qd0)
+        assert np.array_equal(ra, g(key)), (cfg, ctrl)
+        assert np.array_equal(rq, q0) and np.array_equal(rqd, qd0)
+    assert np.array_equal(O.pos_action(dp[0, 0], dv[0, 0], q0[0], qd0[0]), dp[0, 0])
+    assert np.array_equal(O.vel_action(dp[0, 0], dv[0, 0], q0[0], qd0[0]), dv[0, 0])
+    ra, rq, rqd = O.rollout(dp, dv, "motor", pg, dg, lo, hi, "double_integrator", dt, q0, qd0)
+    assert np.array_equal(ra, g("loop_act")) and np.array_equal(rq, g("loop_q")) and np.array_equal(rqd, g("loop_qd"))
+
+
+def test_oracle_and_host_controllers_on_the_reference_grid():
+    """the reference's known-answer grid (test/test_controller.py:14-73), with the REFERENCE's outputs as the expectation,
+    against the oracle and against the host classes of the drop-in (fancy_gym_amd/black_box/controller)"""
+    from fancy_gym_amd.black_box.factory import get_controller
+    z = np.load(REF_CTRL)
+    gi, go = z["grid_in"], z["grid_pd"]
+    assert gi.shape == (3 ** 4 * 36, 18)
+    for row, want in zip(gi[::5], go[::5]):
+        dp, dv, cp, cv, pg, dg = (row[3 * i:3 * i + 3] for i in range(6))
+        assert np.array_equal(O.pd_action(pg, dg, dp, dv, cp, cv), want)
+        assert np.array_equal(get_controller("motor", p_gains=pg, d_gains=dg)(dp, dv, cp, cv), want)
+    # vectorised over the whole grid
+    assert np.array_equal(O.pd_action(gi[:, 12:15], gi[:, 15:18], gi[:, 0:3], gi[:, 3:6], gi[:, 6:9], gi[:, 9:12]), go)
+    mi, mo = z["metaworld_in"], z["metaworld_out"]
+    mw = get_controller("metaworld")
+    for row, want in zip(mi, mo):
+        assert np.array_equal(O.metaworld_action(row[:4], None, row[4:], None), want)
+        assert np.array_equal(mw(row[:4], np.zeros(4), row[4:], np.zeros(4)), want)
+    assert np.array_equal(O.metaworld_action(mi[:, :4], None, mi[:, 4:], None), mo)
+
+
 @pytest.mark.parametrize("max_planning_times", [1, 2, 3, 4])
 @pytest.mark.parametrize("every", [5, 10, 25])
 def test_planning_counts(max_planning_times, every):

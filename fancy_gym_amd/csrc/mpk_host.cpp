@@ -671,6 +671,7 @@ const OptKey kOptKeys[] = {
     {"ring_m", &Tuning::ring_m, 1, 8},           {"ring_dbg", &Tuning::ring_dbg, 0, 127},
     {"ring_parts", &Tuning::ring_parts, 1, 8},   {"tiles_wpb", &Tuning::tiles_wpb, 1, 4},
     {"serial_order", &Tuning::serial_order, 0, 2}, {"ring_nc", &Tuning::ring_nc, 1, 6},
+    {"pd_generic", &Tuning::pd_generic, 0, 1},
 };
 const OptKey* find_opt(const char* key) {
     if (!key) return nullptr;

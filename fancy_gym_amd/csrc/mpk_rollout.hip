@@ -69,7 +69,9 @@ __device__ __forceinline__ void sincos_core(double x, double* sn, double* cs) { 
 }
 
 __device__ __forceinline__ void sincos_lean(double x, double* sn, double* cs) {
+#ifndef MPK_NO_BIG_SINCOS
     if (!(fabs(x) < 1.0e6)) { sincos(x, sn, cs); return; }
+#endif
     sincos_core(x, sn, cs);
 }
 
@@ -90,9 +92,16 @@ __device__ __forceinline__ void sincos_lean(double x, double* sn, double* cs) {
 #define MPK_PD_LOOK 2        // tiles of input lookahead of the rollout kernel without reward, one / two groups per wave: 3 measured 1 - 4 % SLOWER
                              // than 2 (4 096: 11.5 vs 11.4 us, 8 192: 17.5 vs 16.8): what a tile's staging costs is its instructions, not a late load
 #endif
-#ifndef MPK_RW_LOOK
-#define MPK_RW_LOOK 1        // tiles of input lookahead in the reward kernel (2 = as the kernel without reward)
+#ifndef MPK_RW_ALWAYS_TRIG
+#define MPK_RW_ALWAYS_TRIG 0 // 1: round 4's reward pass (the sin / cos chains for every item, used or not) -- A/B build knob
 #endif
+#ifndef MPK_RW_LOOK
+#define MPK_RW_LOOK 1        // tiles of input lookahead in the reward kernel (2 = as the kernel without reward: measured slower at every size
+                             // even after round 5 took the sin / cos chains out of 199 of 200 steps -- 4 096 episodes 29.7 vs 27.0 us,
+                             // 16 384: 81 vs 51.5 (four groups per wave: 256 registers, one wave per SIMD); profiles/r05_rollout.md)
+#endif
+// qv / uv: the item's first column of the [column][step] float64 images, at its step: DoF dd is 16 doubles further on.
+constexpr int kRwCol = 16;     // doubles between neighbouring columns of the float64 images
 template <int DC>
 __device__ __forceinline__ double reacher_reward_item(const double* qv, const double* uv, const int D, const bool dist_on,
                                                       const double gx, const double gy) {
@@ -102,7 +111,7 @@ __device__ __forceinline__ double reacher_reward_item(const double* qv, const do
         bool big = false;
 #pragma unroll
         for (int dd = 0; dd < DC; ++dd) {
-            const double qd_ = qv[dd];
+            const double qd_ = qv[dd * kRwCol];
             ang[dd] = dd == 0 ? qd_ : ang[dd > 0 ? dd - 1 : 0] + qd_;           // np.cumsum(joint_angles)
             big = big || !(fabs(ang[dd]) < 1.0e6);
         }
@@ -133,18 +142,19 @@ __device__ __forceinline__ double reacher_reward_item(const double* qv, const do
         }
 #pragma unroll
         for (int dd = 0; dd < DC; ++dd) {
-            const double u_ = uv[dd];
+            const double u_ = uv[dd * kRwCol];
             ctrl = dd == 0 ? u_ * u_ : ctrl + u_ * u_;
         }
     } else {
         double ang = 0.0;
+#pragma unroll 1
         for (int dd = 0; dd < D; ++dd) {
-            ang = dd == 0 ? qv[dd] : ang + qv[dd];
+            ang = dd == 0 ? qv[dd * kRwCol] : ang + qv[dd * kRwCol];
             double sn, cs;
             sincos_lean(ang, &sn, &cs);
             ex = dd == 0 ? cs : ex + cs;
             ey = dd == 0 ? sn : ey + sn;
-            ctrl = dd == 0 ? uv[dd] * uv[dd] : ctrl + uv[dd] * uv[dd];
+            ctrl = dd == 0 ? uv[dd * kRwCol] * uv[dd * kRwCol] : ctrl + uv[dd * kRwCol] * uv[dd * kRwCol];
         }
     }
     double rdist = 0.0;
@@ -153,6 +163,40 @@ __device__ __forceinline__ double reacher_reward_item(const double* qv, const do
         rdist = 0.0 - sqrt(dx * dx + dy * dy);
     }
     return rdist - ctrl;
+}
+
+// The same item where the reference adds no distance term (simple_reacher.py:62-63: `if self._steps >= self.steps_before_reward`,
+// 199 of an episode's 200 steps at the reference's setting, :31): 0 - sum(action ** 2), the sum left to right -- the control cost of
+// reacher_reward_item operation for operation, so a pass may take either function for an item with dist_on == false: same bits.
+// Round 5: the pass ran the D sin / cos chains for every item and dropped 199 of 200 results behind a run-time predicate the compiler
+// cannot hoist (review of round 4); now a pass evaluates them only when at least one of its 64 items is past steps_before_reward.
+// DC > 0: the DoF count compiled in -- all DC reads of the float64 image issued together, one wait; the run-time loop waits for
+// every read in turn (trace, round 5: 820 of a tile's 4 070 cycles at five DoF, 130 per read)
+template <int DC>
+__device__ __forceinline__ double reacher_ctrl_item(const double* uv, const int D) {
+    double ctrl = 0.0;
+    if constexpr (DC > 0) {
+        double u_[DC];
+#pragma unroll
+        for (int dd = 0; dd < DC; ++dd) u_[dd] = uv[dd * kRwCol];
+#pragma unroll
+        for (int dd = 0; dd < DC; ++dd) ctrl = dd == 0 ? u_[dd] * u_[dd] : ctrl + u_[dd] * u_[dd];
+    } else {
+        for (int dd = 0; dd < D; ++dd) ctrl = dd == 0 ? uv[dd * kRwCol] * uv[dd * kRwCol] : ctrl + uv[dd * kRwCol] * uv[dd * kRwCol];
+    }
+    return 0.0 - ctrl;
+}
+__device__ __forceinline__ double reacher_ctrl_item_d(const double* uv, const int D) {      // (D is wave-uniform)
+    switch (D) {
+        case 2: return reacher_ctrl_item<2>(uv, D);     // SimpleReacher-v0 (envs/__init__.py:41-48: n_links 2)
+        case 3: return reacher_ctrl_item<3>(uv, D);
+        case 4: return reacher_ctrl_item<4>(uv, D);
+        case 5: return reacher_ctrl_item<5>(uv, D);     // LongSimpleReacher-v0 (envs/__init__.py:52-59: n_links 5)
+        case 6: return reacher_ctrl_item<6>(uv, D);
+        case 7: return reacher_ctrl_item<7>(uv, D);
+        case 8: return reacher_ctrl_item<8>(uv, D);
+        default: return reacher_ctrl_item<0>(uv, D);
+    }
 }
 
 // Tile-streaming variant (D <= 16, float4-aligned trajectories): a wave owns a group of 16/DP episodes and walks their
@@ -184,19 +228,28 @@ struct PdArgs {
 // pos | vel staging, which the recurrence has already pulled into registers); then all 64 lanes turn (episode, step)
 // items into rewards in parallel -- cumulative joint angles, sin / cos, end effector, control cost, each summed left to
 // right as numpy does.  Only the recurrence itself stays serial.
-template <int NG, bool RW>
+// CT (round 5): the reward kernels carry their controller as a template parameter (the plant is the double integrator, the launcher
+// picks the instantiation): with the 6 (controller, plant) x 2 (full / partial tile) chains of the run-time switch, the reward pass
+// and its sin / cos path in ONE kernel the compiler spilled 140 scalar registers into vector lanes inside the tile loop.
+// DC (round 5): the DoF count compiled in (0: run time) for the shapes the reference registers -- 2 / 5 links (Simple / LongSimpleReacher,
+// envs/__init__.py:38-59), 7 joints (BASELINE cfg2 / cfg4 / cfg5) --: group geometry, staging offsets and the reward pass's reads become
+// immediates, as in k_traj_ring / k_traj_flat (round 4).
+template <int NG, bool RW, int CT = -1, int DC = 0>
 __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
+    static_assert(RW || CT < 0, "only the reward kernels carry the controller as a template parameter");
+    constexpr int kShC = DC <= 1 ? 0 : (DC <= 2 ? 1 : (DC <= 4 ? 2 : (DC <= 8 ? 3 : 4)));
+    const int sh = DC > 0 ? kShC : a.sh;
     constexpr int SLOT = 3 * kStageStride + (RW ? 2 * kStageStride : 0);   // floats per group slot
     extern __shared__ __attribute__((aligned(16))) float smem[];           // [4 waves][NG][SLOT]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* sSt = smem + wave * (NG * SLOT);      // per group: desired pos | desired vel | actions (| u as float64)
-    const int D = a.D, T = a.T, B = a.B, SEG = 16 * D, DP = 1 << a.sh, NTW = 16 >> a.sh;
-    const int col = lane & 15, bl = col >> a.sh, d = col & (DP - 1);
+    const int D = DC > 0 ? DC : a.D, T = a.T, B = a.B, SEG = 16 * D, DP = 1 << sh, NTW = 16 >> sh;
+    const int col = lane & 15, bl = col >> sh, d = col & (DP - 1);
     const int jq = lane >> 4;                                // the group (of this wave's NG) whose recurrence the lane runs
     const bool lane_serial = jq < NG && d < D;
     const int seg4 = SEG >> 2;
-    const int sseg = (int)(((unsigned)lane * a.inv_seg4) >> 16);
+    const int sseg = DC > 0 ? lane / (4 * DC) : (int)(((unsigned)lane * a.inv_seg4) >> 16);
     const int w4 = (lane - sseg * seg4) * 4;
     const unsigned rofs = (unsigned)(sseg * SEG + w4);
     const size_t gofs = (size_t)sseg * T * D + w4;
@@ -258,18 +311,21 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
         // of the unit, step lane % 16 of the tile: a lane meets the SAME episodes in every tile, so what the pass needs per episode
         // (executed steps, step offset, goal) is read once per unit into registers.  Round 4: read per item and tile, these were three
         // dependent trips to the memory-side cache inside every pass, with two waves per SIMD to hide them.
+        // (the launcher keeps NG * NTW <= 8 episodes per unit: two passes at most)
         constexpr int kRwPasses = 2;
         const int rw_npass = RW ? (NG * NTW + 3) >> 2 : 0;
         int rw_b[kRwPasses], rw_ns[kRwPasses], rw_s0[kRwPasses], rw_q[kRwPasses];
         double rw_gx[kRwPasses], rw_gy[kRwPasses];
-        if (RW && rw_npass <= kRwPasses) {
+        if (RW) {
 #pragma unroll
             for (int p = 0; p < kRwPasses; ++p) {
-                const int je = 4 * p + (lane >> 4), e = je & (NTW - 1), j = je >> (4 - a.sh);
+                const int je = 4 * p + (lane >> 4), e = je & (NTW - 1), j = je >> (4 - sh);
                 const int b = (g0 + j) * NTW + e;
                 const bool ok = p < rw_npass && j < NG && g0 + j < a.G && b < B;
                 rw_b[p] = ok ? b : -1;
-                rw_q[p] = (j * SLOT) * 4 + (e * DP) * 8;       // byte offset of (group slot, episode) in the float64 images
+                // byte offset of (group slot, the episode's first column, this lane's step) in the [column][step] float64 images
+                // (an empty slot reads its lane's step of column 0 of group 0 -- in bounds, discarded)
+                rw_q[p] = ok ? (j * SLOT) * 4 + (e * DP * kRwCol + (lane & 15)) * 8 : (lane & 15) * 8;
                 rw_ns[p] = ok ? (a.n_steps ? min(a.n_steps[b], T) : T) : 0;
                 rw_s0[p] = ok && a.step0 ? a.step0[b] : 0;
                 rw_gx[p] = ok ? a.goal[2 * (size_t)b] : 0.0;
@@ -311,6 +367,19 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
                 }
             }
         };
+        // RW: likewise the rewards of tile rt (one float64 per pass and lane, kept in registers) leave at the start of tile rt + 1 --
+        // stored at the end of the pass, their acknowledgement was what the next tile's staging waited for (`vmcnt(0)`): with the
+        // sin / cos chains gone from 199 of 200 steps (round 5) that wait was most of what the reward still cost
+        double rw_r[kRwPasses] = {0.0, 0.0};
+        auto store_rewards = [&](const int rt) {
+            if (!RW) return;
+            const int tl = lane & 15, t = rt * 16 + tl;
+            if (tl < min(16, T - rt * 16)) {
+#pragma unroll
+                for (int p = 0; p < kRwPasses; ++p)
+                    if (p < rw_npass && rw_b[p] >= 0) a.rewards[(size_t)rw_b[p] * T + t] = rw_r[p];
+            }
+        };
         auto tile = [&](const int rt, f32x4 (&lp)[NG], f32x4 (&lv)[NG]) {
             const int rows = min(16, T - rt * 16);
 #pragma unroll
@@ -321,9 +390,18 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
                 }
             }
             if (rt + kAhead < NRT) fetch(rt + kAhead, lp, lv);   // into the set this tile has just emptied
-            if (rt > 0) store_actions(rt - 1);
+            if (rt > 0) { store_actions(rt - 1); store_rewards(rt - 1); }
             __builtin_amdgcn_wave_barrier();
             if (rt < 16) MPK_STAMP(10 + 3 * rt);
+            // RW: can any (episode, step) item of this tile carry the distance term?  (wave-uniform, conservative: the tile's last step
+            // against every episode slot's step offset; the pass decides exactly, per item)
+            bool tile_dist = RW;
+            if (RW && !MPK_RW_ALWAYS_TRIG) {
+                bool mine = false;
+#pragma unroll
+                for (int p = 0; p < kRwPasses; ++p) mine = mine || (rw_b[p] >= 0 && rw_s0[p] + rt * 16 + 15 >= a.steps_before_reward);
+                tile_dist = __any(mine) != 0;
+            }
             if (serial) {
                 // the 16 steps of the tile as straight-line code per (controller, plant): a run-time switch inside the
                 // step would cost more instructions than the step's arithmetic, and this chain is the critical path
@@ -336,18 +414,25 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
                 auto tile_steps = [&](auto ctrl_tag, auto plant_tag) {
                     constexpr int CTRL = decltype(ctrl_tag)::value;
                     constexpr bool INTEG = decltype(plant_tag)::value == MPK_PLANT_DOUBLE_INTEGRATOR;
-                    double* q64 = reinterpret_cast<double*>(sg) + col;
-                    double* u64 = reinterpret_cast<double*>(sg + 3 * kStageStride) + col;
-                    if (full_tile)
-                        pd_tile_steps<CTRL, false, INTEG, RW>(sg + o0, sg + kStageStride + o0, sg + 2 * kStageStride + o0, D, rt * 16,
-                                                              nst, pgd, dgd, lod, hid, dtp, qs, qds, q64, u64);
-                    else
-                        pd_tile_steps<CTRL, true, INTEG, RW>(sg + o0, sg + kStageStride + o0, sg + 2 * kStageStride + o0, D, rt * 16,
-                                                             nst, pgd, dgd, lod, hid, dtp, qs, qds, q64, u64, rows);
+                    double* q64 = reinterpret_cast<double*>(sg) + col * kRwCol;           // [column][step] images
+                    double* u64 = reinterpret_cast<double*>(sg + 3 * kStageStride) + col * kRwCol;
+                    auto go = [&](auto keep_tag) {
+                        constexpr int KEEP = decltype(keep_tag)::value;
+                        if (full_tile)
+                            pd_tile_steps<CTRL, false, INTEG, KEEP>(sg + o0, sg + kStageStride + o0, sg + 2 * kStageStride + o0, D, rt * 16,
+                                                                    nst, pgd, dgd, lod, hid, dtp, qs, qds, q64, u64);
+                        else
+                            pd_tile_steps<CTRL, true, INTEG, KEEP>(sg + o0, sg + kStageStride + o0, sg + 2 * kStageStride + o0, D, rt * 16,
+                                                                   nst, pgd, dgd, lod, hid, dtp, qs, qds, q64, u64, rows);
+                    };
+                    if (!RW) go(std::integral_constant<int, 0>());
+                    else if (tile_dist) go(std::integral_constant<int, 1>());
+                    else go(std::integral_constant<int, 2>());        // no item of the tile needs the plant positions
                 };
                 using std::integral_constant;
                 const bool dint = a.rc.plant_type == MPK_PLANT_DOUBLE_INTEGRATOR;
-                switch (a.rc.controller_type) {
+                if constexpr (CT >= 0) tile_steps(integral_constant<int, CT>(), integral_constant<int, MPK_PLANT_DOUBLE_INTEGRATOR>());
+                else switch (a.rc.controller_type) {
                     case MPK_CTRL_MOTOR:
                         if (dint) tile_steps(integral_constant<int, MPK_CTRL_MOTOR>(), integral_constant<int, MPK_PLANT_DOUBLE_INTEGRATOR>());
                         else tile_steps(integral_constant<int, MPK_CTRL_MOTOR>(), integral_constant<int, MPK_PLANT_STATIC>());
@@ -365,51 +450,28 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
             __builtin_amdgcn_wave_barrier();
             if (rt < 16) MPK_STAMP(11 + 3 * rt);
             if (RW) {
-                auto pass = [&](auto dc_tag) {
-                    constexpr int DC = decltype(dc_tag)::value;
-                    if (rw_npass <= kRwPasses) {
-                        const int tl = lane & 15, t = rt * 16 + tl;
+                // item = pass * 64 + lane -> episode slot 4 pass + lane / 16 of the unit, step lane % 16 of the tile; the control cost of
+                // every item as straight-line code, the end effector behind ONE wave-uniform branch
+                const int tl = lane & 15, t = rt * 16 + tl;
 #pragma unroll 1
-                        for (int p = 0; p < rw_npass; ++p) {                  // (one copy of the pass: the two must not interleave)
-                            static_assert(kRwPasses == 2, "selects below");
-                            const int pb = p ? rw_b[1] : rw_b[0], pns = p ? rw_ns[1] : rw_ns[0], ps0 = p ? rw_s0[1] : rw_s0[0];
-                            const int pq = p ? rw_q[1] : rw_q[0];
-                            const double pgx = p ? rw_gx[1] : rw_gx[0], pgy = p ? rw_gy[1] : rw_gy[0];
-                            if (pb >= 0 && tl < rows) {
-                                double r = 0.0;
-                                if (t < pns) {
-                                    const char* sb = reinterpret_cast<const char*>(sSt) + pq;
-                                    const double* qv = reinterpret_cast<const double*>(sb) + tl * 16;
-                                    const double* uv = reinterpret_cast<const double*>(sb + 3 * kStageStride * 4) + tl * 16;
-                                    r = reacher_reward_item<DC>(qv, uv, D, ps0 + t >= a.steps_before_reward, pgx, pgy);
-                                }
-                                a.rewards[(size_t)pb * T + t] = r;
-                            }
-                        }
-                    } else {
-                        // more than 16 episodes per unit (D <= 2): per-item inputs from memory
-                        const int items = NG * NTW * 16;          // (group, episode in group, step in tile)
-                        for (int it = lane; it < items; it += 64) {
-                            const int tl = it & 15, je = it >> 4;
-                            const int e = je & (NTW - 1), j = je >> (4 - a.sh);
-                            const int b = (g0 + j) * NTW + e;
-                            if (tl < rows && g0 + j < a.G && b < B) {
-                                const int t = rt * 16 + tl;
-                                const int ns = a.n_steps ? min(a.n_steps[b], T) : T;
-                                double r = 0.0;
-                                if (t < ns) {
-                                    const double* qv = reinterpret_cast<const double*>(sSt + j * SLOT) + tl * 16 + e * DP;
-                                    const double* uv = reinterpret_cast<const double*>(sSt + j * SLOT + 3 * kStageStride) + tl * 16 + e * DP;
-                                    r = reacher_reward_item<DC>(qv, uv, D, (a.step0 ? a.step0[b] : 0) + t >= a.steps_before_reward,
-                                                                a.goal[2 * (size_t)b], a.goal[2 * (size_t)b + 1]);
-                                }
-                                a.rewards[(size_t)b * T + t] = r;
-                            }
-                        }
+                for (int p = 0; p < rw_npass; ++p) {                  // (one copy of the pass: the two must not interleave)
+                    static_assert(kRwPasses == 2, "selects below");
+                    const int pb = p ? rw_b[1] : rw_b[0], pns = p ? rw_ns[1] : rw_ns[0], ps0 = p ? rw_s0[1] : rw_s0[0];
+                    const int pq = p ? rw_q[1] : rw_q[0];
+                    const bool live = pb >= 0 && t < pns;               // (pns <= T: a step past the horizon is never live)
+                    const bool dist_on = live && ps0 + t >= a.steps_before_reward;
+                    const char* sb = reinterpret_cast<const char*>(sSt) + pq;
+                    const double* qv = reinterpret_cast<const double*>(sb);
+                    const double* uv = reinterpret_cast<const double*>(sb + 3 * kStageStride * 4);
+                    double r = DC > 0 ? reacher_ctrl_item<DC>(uv, D) : reacher_ctrl_item_d(uv, D);
+                    // wave-uniform: does ANY of the pass's 64 items carry the distance term?  (MPK_RW_ALWAYS_TRIG: round 4's pass, A/B)
+                    if (MPK_RW_ALWAYS_TRIG || (tile_dist && __any(dist_on) != 0)) {
+                        if (MPK_RW_DC == 5 && D == 5) r = reacher_reward_item<5>(qv, uv, D, dist_on, p ? rw_gx[1] : rw_gx[0], p ? rw_gy[1] : rw_gy[0]);
+                        else r = reacher_reward_item<0>(qv, uv, D, dist_on, p ? rw_gx[1] : rw_gx[0], p ? rw_gy[1] : rw_gy[0]);
                     }
-                };
-                if (MPK_RW_DC == 5 && D == 5) pass(std::integral_constant<int, 5>());       // SimpleReacher / LongSimpleReacher: five links
-                else pass(std::integral_constant<int, 0>());
+                    r = live ? r : 0.0;
+                    if (p) rw_r[1] = r; else rw_r[0] = r;
+                }
                 __builtin_amdgcn_wave_barrier();
             }
             __builtin_amdgcn_wave_barrier();
@@ -431,6 +493,7 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
             }
         }
         store_actions(NRT - 1);
+        store_rewards(NRT - 1);
         __builtin_amdgcn_wave_barrier();
         if (serial) {
             const size_t si = (size_t)bs * D + d;
@@ -524,18 +587,25 @@ __global__ void __launch_bounds__(256) k_reacher_rollout(const RolloutDev rc, co
                 q = q + dt * qd;
                 if (actions) actions[base + (size_t)t * D] = (float)u;
             }
-            const double ang = seg_scan(q, d, D);               // np.cumsum(joint_angles)
-            double sn, cs;
-            sincos_lean(ang, &sn, &cs);
-            double ex = cs, ey = sn, ctrl = u * u;              // unit link lengths (base_reacher.py:19): sums over the links
-            seg_scan3(ex, ey, ctrl, d, D);
-            if (live && d == D - 1) {
-                double rdist = 0.0;
-                if (s0 + t >= steps_before_reward) {
-                    const double dx = ex - gx, dy = ey - gy;
-                    rdist = 0.0 - sqrt(dx * dx + dy * dy);
+            // the end effector only where some episode of the wave is past steps_before_reward (simple_reacher.py:62-63; wave-uniform)
+            const bool dist_on = live && s0 + t >= steps_before_reward;
+            if (MPK_RW_ALWAYS_TRIG || __any(dist_on) != 0) {
+                const double ang = seg_scan(q, d, D);               // np.cumsum(joint_angles)
+                double sn, cs;
+                sincos_lean(ang, &sn, &cs);
+                double ex = cs, ey = sn, ctrl = u * u;              // unit link lengths (base_reacher.py:19): sums over the links
+                seg_scan3(ex, ey, ctrl, d, D);
+                if (live && d == D - 1) {
+                    double rdist = 0.0;
+                    if (dist_on) {
+                        const double dx = ex - gx, dy = ey - gy;
+                        rdist = 0.0 - sqrt(dx * dx + dy * dy);
+                    }
+                    rewards[(size_t)b * T + t] = rdist - ctrl;
                 }
-                rewards[(size_t)b * T + t] = rdist - ctrl;
+            } else {
+                const double ctrl = seg_scan(u * u, d, D);
+                if (live && d == D - 1) rewards[(size_t)b * T + t] = 0.0 - ctrl;
             }
         }
     }
@@ -555,7 +625,8 @@ int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
                            void* stream, const Tuning& tune) {
     auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     const int last_rows = T - (T - 1) / 16 * 16;
-    const bool tiles_ok = D >= 1 && D <= kMaxD && (T * D) % 4 == 0 && (last_rows * D) % 4 == 0 && aligned16(des_pos) &&
+    // (D = 1: sixteen episodes per group, more than the reward pass's two register sets -- the generic kernel)
+    const bool tiles_ok = D >= 2 && D <= kMaxD && (T * D) % 4 == 0 && (last_rows * D) % 4 == 0 && aligned16(des_pos) &&
                           aligned16(des_vel) && (!actions || aligned16(actions)) && tune.pd_simple != 1;
     if (tiles_ok) {
         // the tile-streaming rollout with the reward evaluated per tile by all lanes (see k_pd_rollout_tiles, RW)
@@ -580,6 +651,7 @@ int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
         // (second session: the thresholds of launch_pd_rollout -- with the reward 10 240 / 12 288 / 14 336 episodes 85.0 / 85.8 / 100.3 ->
         // 78.6 / 78.9 / 79.4 us with four groups per wave, 3 072: 48.0 -> 42.6 with two; 8 192: two 52.5, four 68)
         else if (quad_mode == 1) ng = pa.G >= 5 * simds ? 4 : (2 * pa.G >= 3 * simds ? 2 : 1);
+        while (ng > 1 && ng * NTW > 8) ng >>= 1;       // the reward pass holds the inputs of two passes (eight episodes) in registers
         const int units = (pa.G + ng - 1) / ng;
         int blocks = (units + 3) / 4;
         if (blocks > 2048) blocks = 2048;
@@ -594,7 +666,16 @@ int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
             MPK_LAUNCH_CHECK();
             return MPK_OK;
         };
-        return ng == 4 ? go(k_pd_rollout_tiles<4, true>) : (ng == 2 ? go(k_pd_rollout_tiles<2, true>) : go(k_pd_rollout_tiles<1, true>));
+        // the motor controller on 2 / 5 links (the reference's SimpleReacher environments: simple_reacher/mp_wrapper.py:11-16) with
+        // controller and link count compiled in; everything else on the run-time form of the same code
+        auto by_ng = [&](auto ct_tag, auto dc_tag) -> int {
+            constexpr int CT = decltype(ct_tag)::value, DC = decltype(dc_tag)::value;
+            return ng == 4 ? go(k_pd_rollout_tiles<4, true, CT, DC>) : (ng == 2 ? go(k_pd_rollout_tiles<2, true, CT, DC>) : go(k_pd_rollout_tiles<1, true, CT, DC>));
+        };
+        using std::integral_constant;
+        if (rc.controller_type == MPK_CTRL_MOTOR && D == 5 && tune.pd_generic != 1) return by_ng(integral_constant<int, MPK_CTRL_MOTOR>(), integral_constant<int, 5>());
+        if (rc.controller_type == MPK_CTRL_MOTOR && D == 2 && tune.pd_generic != 1) return by_ng(integral_constant<int, MPK_CTRL_MOTOR>(), integral_constant<int, 2>());
+        return by_ng(integral_constant<int, -1>(), integral_constant<int, 0>());
     }
     const int epw = 64 / D;
     const long waves = ((long)B + epw - 1) / epw;
@@ -641,9 +722,15 @@ int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const f
         if (blocks > 2048) blocks = 2048;
         if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;
         const size_t lds = (size_t)4 * ng * 3 * kStageStride * sizeof(float);
-        if (ng == 4) hipLaunchKernelGGL((k_pd_rollout_tiles<4, false>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, pa);
-        else if (ng == 2) hipLaunchKernelGGL((k_pd_rollout_tiles<2, false>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, pa);
-        else hipLaunchKernelGGL((k_pd_rollout_tiles<1, false>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, pa);
+        auto by_ng = [&](auto dc_tag) {
+            constexpr int DC = decltype(dc_tag)::value;
+            if (ng == 4) hipLaunchKernelGGL((k_pd_rollout_tiles<4, false, -1, DC>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, pa);
+            else if (ng == 2) hipLaunchKernelGGL((k_pd_rollout_tiles<2, false, -1, DC>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, pa);
+            else hipLaunchKernelGGL((k_pd_rollout_tiles<1, false, -1, DC>), dim3(blocks), dim3(256), lds, (hipStream_t)stream, pa);
+        };
+        if (D == 7 && tune.pd_generic != 1) by_ng(std::integral_constant<int, 7>());
+        else if (D == 5 && tune.pd_generic != 1) by_ng(std::integral_constant<int, 5>());
+        else by_ng(std::integral_constant<int, 0>());
         MPK_LAUNCH_CHECK();
         return MPK_OK;
     }

@@ -251,14 +251,16 @@ __device__ __forceinline__ Gains kernarg_gains(int d) {
 // of the same wave adds 2 - 4; left alone the compiler sinks each step's LDS read next to its use (`s_waitcnt lgkmcnt(1)` in front
 // of every step: ~40 cycles of LDS latency exposed per step).  PRE = 1: all 32 reads issued, ONE wait, all conversions, then the
 // chain with nothing but its own operations, the action conversion and the LDS write in between.
-template <int CTRL, bool MASKED, bool INTEGRATE = true, bool KEEP64 = false, int PRE = 0>
+template <int CTRL, bool MASKED, bool INTEGRATE = true, int KEEP64 = 0, int PRE = 0>
 __device__ __forceinline__ void pd_tile_steps(const float* __restrict__ sP, const float* __restrict__ sV,
                                               float* __restrict__ sA, const int stride, const int t0, const int nst,
                                               const double pgd, const double dgd, const double lod, const double hid,
                                               const double dtp, double& qs, double& qds, double* __restrict__ q64 = nullptr,
                                               double* __restrict__ u64 = nullptr, const int rows = 16) {
-    // INTEGRATE = false: MPK_PLANT_STATIC (the state never changes).  KEEP64: the plant position after the step and the
-    // clipped action also stay in LDS as float64, 16 doubles per step (the reward pass of the reacher rollout reads them)
+    // INTEGRATE = false: MPK_PLANT_STATIC (the state never changes).  KEEP64 = 1: the plant position after the step and the
+    // clipped action also stay in LDS as float64, q64 / u64 = the lane's column of a [16 columns][16 steps] image (the reward pass of
+    // the reacher rollout reads them);
+    // KEEP64 = 2: the action only (a tile none of whose steps carries the reward's distance term: round 5)
     float pr[16], vr[16];
 #pragma unroll
     for (int tl = 0; tl < 16; ++tl) { pr[tl] = sP[tl * stride]; vr[tl] = sV[tl * stride]; }
@@ -312,13 +314,18 @@ __device__ __forceinline__ void pd_tile_steps(const float* __restrict__ sP, cons
             qds = qds_n; qs = qs_n;
             sA[tl * stride] = (float)u;
         }
-        if (KEEP64) { q64[tl * 16] = qs; u64[tl * 16] = u; }
+        // (column-major images: [column][step] -- the reward pass reads 16 consecutive steps of one column with 16 neighbouring
+        // lanes; step-major, those reads were 128 bytes apart: one LDS bank pair for all of them.  The writes here are the ones 128
+        // bytes apart now, 16 lanes of one instruction -- but nothing waits for a write)
+        if (KEEP64 == 1) q64[tl] = qs;
+        if (KEEP64) u64[tl] = u;
     }
     if (MASKED) {
 #pragma unroll 1
         for (int tl = nlive; tl < rows; ++tl) {
             sA[tl * stride] = 0.0f;
-            if (KEEP64) { q64[tl * 16] = qs; u64[tl * 16] = 0.0; }
+            if (KEEP64 == 1) q64[tl] = qs;
+            if (KEEP64) u64[tl] = 0.0;
         }
     }
 }

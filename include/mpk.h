@@ -209,6 +209,7 @@ int mpk_set_duration(mpk_handle h, double duration, double dt);
  *                   prodmp kernel; automatic when the horizon is not a multiple of 64); dmp: 1 forces / 0 forbids the
  *                   workgroup-per-chunk kernel (automatic for a few thousand episodes)
  *   "pd_simple"     1 generic one-lane-per-(episode, DoF) rollout kernels
+ *   "pd_generic"    1 the tile rollout kernels without their compile-time-DoF instantiations (2 / 5 / 7 DoF) -- A/B runs, tests
  *   "pipe"          0 off, 1 force the producer / consumer closed-loop kernel (k_traj_pipe; the default where it fits)
  *   "flat"          0 off, 1 force the whole-trajectory-image episode-major kernel (k_traj_flat; automatic for open-loop
  *                   promp / prodmp launches whose outputs stream to HBM)
@@ -225,7 +226,8 @@ int mpk_set_duration(mpk_handle h, double duration, double dt);
  *                   the same kernel with a third role, consumer waves that run the recurrences of a batch (one group per lane
  *                   quarter); automatic where the outputs of the step exceed the caches, 1 forces it.
  *   "ring_np"       1 .. 14 producer waves per workgroup (8)
- *   "ring_nc"       1 .. 6 consumer waves per workgroup (closed loop only: 4)
+ *   "ring_nc"       1 .. 6 consumer waves per workgroup (closed loop only: 3 -- with an action-writer wave each, four would take
+ *                   producer waves out of the 16-wave workgroup)
  *   "ring_ns"       1 .. 8 store-engine waves per workgroup (2; closed loop: 1)
  *   "ring_m"        1 .. 8 episode groups per batch buffer (the largest <= 4 that leaves two buffers in 160 KB)
  *   "ring_parts"    1 .. 8 producer waves sharing the row tiles of one group (by the buffers: all producers stay busy)

@@ -339,10 +339,12 @@ def test_single_episode_step_matches_oracle_on_a_closed_loop_plant():
 @pytest.mark.parametrize("controller", ["motor", "position", "velocity"])
 @pytest.mark.parametrize("plant", ["static", "double_integrator"])
 @pytest.mark.parametrize("B", [1, 37, 1000])
-@pytest.mark.parametrize("simple", ["tiles", "simple", "quad"])
+@pytest.mark.parametrize("simple", ["tiles", "simple", "quad", "tiles_rt"])
 def test_pd_rollout_is_bit_exact_in_float64(controller, plant, B, simple, monkeypatch, mpk_option):
     if simple == "simple":
         mpk_option("pd_simple", "1")      # the generic one-lane-per-(episode, DoF) kernel
+    if simple == "tiles_rt":
+        mpk_option("pd_generic", "1")     # the tile kernel with the DoF count at run time (7 is compiled in otherwise)
     mpk_option("pd_quad", "2" if simple == "quad" else "0")   # four groups per wave / one
     pc, bc, tc, dt, dur = CFG2
     eng = make_engine(pc, bc, tc, dt, dur)
@@ -1075,6 +1077,45 @@ def test_reacher_rollout_matches_oracle(controller, D, B, T, mode, monkeypatch, 
     assert got.shape == (B, T) and np.all(np.abs(got - rr) <= 1e-12 * (1.0 + np.abs(rr))), np.abs(got - rr).max()
     paid = (step0[:, None] + np.arange(T)[None] >= 199) & (np.arange(T)[None] < n_steps[:, None])
     assert paid.any() and (~paid).any()       # both branches of the reward are exercised
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sbr", [0, 199, 100000])
+@pytest.mark.parametrize("D,B,T", [(5, 300, 200), (5, 37, 100), (2, 40, 200), (7, 50, 64)])
+@pytest.mark.parametrize("mode", ["tiles", "quad", "generic", "tiles_rt"])
+def test_reacher_reward_with_and_without_the_distance_term(sbr, D, B, T, mode, mpk_option):
+    """simple_reacher.py:62-63: the distance term only from `steps_before_reward` on (199 of 200 steps carry none at the reference's
+    setting, :31).  The reward pass evaluates the end effector only where one of a pass's items needs it: steps_before_reward = 0
+    keeps the all-live path covered, 100000 the path without any, 199 with step0 = 0 is the reference's episode (the last step
+    only).  Rewards without the distance term are -sum(action ** 2) left to right: bit for bit on the tile kernels."""
+    from fancy_gym_amd import TrajectoryEngine
+    mpk_option("pd_quad", "2" if mode == "quad" else "0")
+    if mode == "generic":
+        mpk_option("pd_simple", "1")
+    if mode == "tiles_rt":
+        mpk_option("pd_generic", "1")     # controller and link count at run time (motor on 2 / 5 links are compiled in otherwise)
+    eng = TrajectoryEngine(device=0, mp_type="promp", phase_type="linear", basis_type="rbf", num_dof=D, num_basis=3,
+                           dt=0.01, duration=T * 0.01, tau=T * 0.01)
+    rng = np.random.default_rng(sbr + D * 10 + B)
+    des_pos = rng.standard_normal((B, T, D)).astype(np.float32)
+    des_vel = rng.standard_normal((B, T, D)).astype(np.float32)
+    goal = rng.uniform(-D, D, (B, 2))
+    n_steps = np.where(rng.uniform(size=B) < 0.5, T, rng.integers(0, T + 1, B)).astype(np.int32)
+    q0 = rng.uniform(-1, 1, (B, D)); qd0 = rng.uniform(-1, 1, (B, D))
+    spec = RolloutSpec("motor", D, 0.6, 0.075, -2.0, 1.5, plant="double_integrator", dt=0.01)
+    q = torch.tensor(q0, device="cuda"); qd = torch.tensor(qd0, device="cuda")
+    act, rew = eng.reacher_rollout(spec, torch.tensor(des_pos, device="cuda"), torch.tensor(des_vel, device="cuda"), q, qd,
+                                   torch.tensor(goal), n_steps=torch.tensor(n_steps), steps_before_reward=sbr)
+    ra, rr, rq, rqd = O.reacher_rollout(des_pos, des_vel, "motor", 0.6, 0.075, -2.0, 1.5, 0.01, q0, qd0, goal,
+                                        n_steps=n_steps, steps_before_reward=sbr)
+    assert np.array_equal(act.cpu().numpy(), ra.astype(np.float32))
+    assert np.array_equal(q.cpu().numpy(), rq) and np.array_equal(qd.cpu().numpy(), rqd)
+    got = rew.cpu().numpy()
+    assert np.all(np.abs(got - rr) <= 1e-12 * (1.0 + np.abs(rr))), np.abs(got - rr).max()
+    paid = (np.arange(T)[None] >= sbr) & (np.arange(T)[None] < n_steps[:, None])
+    assert paid.any() == (sbr < T)
+    if mode != "generic":                     # (the generic kernel sums over the DoF lanes in tree order)
+        assert np.array_equal(got[~paid], rr[~paid])
 
 
 @pytest.mark.gpu

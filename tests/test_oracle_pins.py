@@ -356,8 +356,9 @@ def test_oracle_against_mp_pytorch_reference_outputs(tmp_path):
     and that skip is the statement "parity unpinned" (DESIGN.md section 2).
     """
     import glob
+    # (ref_controllers.npz -- the reference's own controller files, no "package" entry -- is not one of these)
     committed = [f for f in glob.glob(os.path.join(GOLD, "ref_*.npz"))
-                 if str(np.load(f)["package"]) == "mp_pytorch"]
+                 if "package" in np.load(f).files and str(np.load(f)["package"]) == "mp_pytorch"]
     if committed:
         r = _run_pin(["--check-only", "--out", GOLD])
     else:

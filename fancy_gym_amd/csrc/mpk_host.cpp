@@ -224,6 +224,12 @@ struct Handle {
     int idx_cap = 0;
     static constexpr int kCache = 64;    // distinct init_times of one replanning episode (a 100-step horizon replanned every 2 steps)
     CacheEntry cache[kCache];
+    // DMP with a shared phase as a contraction (round 5, k_build_shared `dmp_resp`): the configuration the two-output matrix-core
+    // kernels see and the response tables' own slots; resp_ok: shape and stability allow it (fill_devcfg)
+    DevCfg dev_resp{};
+    bool resp_ok = false;
+    CacheEntry cache_resp[kCache];
+    std::string kernel_name_buf;       // "k_traj_tiles<prodmp,act>" reported as "k_traj_tiles<dmp_resp,act>"
     uint64_t stamp = 0;
     const char* last_kernel = "";
     Tuning tune;                 // per-handle overrides (mpk_set_option); -1 = follow the process-wide default
@@ -350,6 +356,28 @@ static void fill_devcfg(Handle* h) {
     d.rows32 = h->d_rows32;
     d.rows32_stride = h->rows32_stride;
     d.base_times = h->d_times;
+    // DMP, shared phase: the response route (k_build_shared).  Columns weights | goal | y_b | v_b as ProDMP's, DMP's parameter block
+    // ([w_1 .. w_nb, g] per DoF) is ProDMP's without disabled parts.  Only where the explicit Euler map is comfortably stable: with
+    // beta = alpha / 4 its step matrix has det 1 - h and trace 2 - h - h^2 / 4 (h = alpha ds), eigenvalues inside the unit circle iff
+    // h < 4 (sqrt 2 - 1) = 1.657; taken for h <= 1, where the responses decay monotonically -- beyond that the reference's own fp32
+    // recurrence oscillates or diverges, and the serial kernels reproduce THAT operation for operation.
+    h->resp_ok = false;
+    h->dev_resp = d;
+    if (c.mp_type == MPK_MP_DMP && !c.learn_tau && !c.learn_delay && d.D >= 1 && d.D <= kMaxD && c.num_basis + 3 <= kMaxKP &&
+        !h->times.empty()) {
+        float ds_max = 0.f;
+        for (size_t i = 0; i + 1 < h->times.size(); ++i) {
+            const float s0 = std::fmax((h->times[i] - d.delay) / d.tau, 0.f), s1 = std::fmax((h->times[i + 1] - d.delay) / d.tau, 0.f);
+            ds_max = std::fmax(ds_max, s1 - s0);
+        }
+        DevCfg& r = h->dev_resp;
+        r.mp_type = MPK_MP_PRODMP;
+        r.dmp_resp = 1;
+        r.KT = c.num_basis + 3;
+        r.KP = (r.KT + 3) / 4 * 4;
+        r.relative_goal = 0; r.disable_goal = 0; r.disable_weights = 0; r.goal_off_on = 0;
+        h->resp_ok = (double)d.dmp_alpha * (double)ds_max <= 1.0;
+    }
 }
 
 static int upload_times(Handle* h) {
@@ -360,16 +388,18 @@ static int upload_times(Handle* h) {
     MPK_HIP(hipMalloc((void**)&h->d_times, sizeof(float) * T));
     MPK_HIP(hipMemcpy(h->d_times, h->times.data(), sizeof(float) * T, hipMemcpyHostToDevice));
     for (auto& e : h->cache) { e.valid = false; e.pinned = false; e.deferred = false; }
+    for (auto& e : h->cache_resp) { e.valid = false; e.pinned = false; e.deferred = false; }
     return MPK_OK;
 }
 
 static void free_handle(Handle* h) {
     if (!h) return;
     DeviceGuard guard(h->cfg.device);
-    for (auto& e : h->cache) {
-        if (e.st.A) (void)hipFree(e.st.A);
-        if (e.st.aux) (void)hipFree(e.st.aux);
-    }
+    for (auto* cache : {h->cache, h->cache_resp})
+        for (int i = 0; i < Handle::kCache; ++i) {
+            if (cache[i].st.A) (void)hipFree(cache[i].st.A);
+            if (cache[i].st.aux) (void)hipFree(cache[i].st.aux);
+        }
     if (h->d_tab) (void)hipFree(h->d_tab);
     if (h->d_rows32) (void)hipFree(h->d_rows32);
     if (h->d_times) (void)hipFree(h->d_times);
@@ -382,6 +412,12 @@ static void free_handle(Handle* h) {
 
 static bool shared_phase(const Handle* h, const float* init_time) {
     return !h->cfg.learn_tau && !h->cfg.learn_delay && init_time == nullptr;
+}
+
+// DMP, shared phase, stable Euler map, <= 16 columns: the response route ("dmp_response" 0 switches it off: A/B runs, and the tests
+// that keep the serial kernels covered)
+static bool dmp_response(const Handle* h, const float* init_time, const Tuning& tune) {
+    return h->resp_ok && h->cfg.mp_type == MPK_MP_DMP && init_time == nullptr && tune.dmp_response != 0;
 }
 
 static bool mfma_capable(const Handle* h) {
@@ -400,15 +436,14 @@ static bool wide_capable(const Handle* h) {
 
 // Allocate every cache slot's table for the current (T, KP) up front: a cache miss later only launches the builder
 // kernel, never hipMalloc -- so trajectory calls stay legal inside a hipGraph stream capture.
-static int prealloc_cache(Handle* h) {
-    if (!mfma_capable(h) && !wide_capable(h)) return MPK_OK;
+static int prealloc_slots(const DevCfg& dev, CacheEntry* cache, bool wanted) {
     int TS = 0, n_out = 0;
-    const size_t nf = shared_tables_floats(h->dev, &TS, &n_out);
+    const size_t nf = shared_tables_floats(dev, &TS, &n_out);
     // a wide table (hundreds of basis functions: 1.7 MB per slot at K = 1000, T = 200 -- shared_tables_lean) gets 8 slots instead of 64
-    const int n_slots = h->dev.KP > kMaxKP ? 8 : Handle::kCache;
-    int slot = 0;
-    for (auto& e : h->cache) {
-        const bool keep = slot++ < n_slots;
+    const int n_slots = !wanted ? 0 : (dev.KP > kMaxKP ? 8 : Handle::kCache);
+    for (int slot = 0; slot < Handle::kCache; ++slot) {
+        CacheEntry& e = cache[slot];
+        const bool keep = slot < n_slots;
         if (e.st.A && (e.st.TS != TS || e.st.n_out != n_out || e.floats != nf || !keep)) {
             (void)hipFree(e.st.A); (void)hipFree(e.st.aux);
             e.st = SharedTables{};
@@ -425,11 +460,19 @@ static int prealloc_cache(Handle* h) {
     return MPK_OK;
 }
 
-// returns the cached (or freshly built, enqueued on `stream`) shared tables for init_time
-static int get_shared(Handle* h, float init_time, void* stream, SharedTables* out) {
+static int prealloc_cache(Handle* h) {
+    int rc = prealloc_slots(h->dev, h->cache, mfma_capable(h) || wide_capable(h));
+    if (rc != MPK_OK) return rc;
+    return prealloc_slots(h->dev_resp, h->cache_resp, h->resp_ok);
+}
+
+// returns the cached (or freshly built, enqueued on `stream`) shared tables for init_time; resp: the DMP response tables
+static int get_shared(Handle* h, float init_time, void* stream, SharedTables* out, bool resp = false) {
     uint32_t key;
     std::memcpy(&key, &init_time, 4);
-    const int T = h->dev.T;
+    const DevCfg& dev = resp ? h->dev_resp : h->dev;
+    CacheEntry* const cache = resp ? h->cache_resp : h->cache;
+    const int T = dev.T;
     ++h->stamp;
     bool capturing = false;
     unsigned long long cap_id = 0;
@@ -438,7 +481,8 @@ static int get_shared(Handle* h, float init_time, void* stream, SharedTables* ou
         if (hipStreamGetCaptureInfo((hipStream_t)stream, &cs, &cap_id) == hipSuccess) capturing = cs == hipStreamCaptureStatusActive;
         else (void)hipGetLastError();
     }
-    for (auto& e : h->cache) {
+    for (int i = 0; i < Handle::kCache; ++i) {
+        CacheEntry& e = cache[i];
         if (!e.valid || e.key != key || e.T != T) continue;
         if (e.deferred && !(capturing && e.capture_id == cap_id)) continue;
         if (capturing) e.pinned = true;
@@ -446,7 +490,8 @@ static int get_shared(Handle* h, float init_time, void* stream, SharedTables* ou
         return MPK_OK;
     }
     CacheEntry* victim = nullptr;
-    for (auto& e : h->cache) {
+    for (int i = 0; i < Handle::kCache; ++i) {
+        CacheEntry& e = cache[i];
         if (e.pinned || !e.st.A) continue;
         if (!e.valid) { victim = &e; break; }
         if (!victim || e.stamp < victim->stamp) victim = &e;
@@ -467,12 +512,12 @@ static int get_shared(Handle* h, float init_time, void* stream, SharedTables* ou
     // every slot was allocated for the current (T, KP) by mpk_create / mpk_set_duration (prealloc_cache): a miss only
     // launches the builder -- nothing here allocates, frees or synchronises
     int TS = 0, n_out = 0;
-    (void)shared_tables_floats(h->dev, &TS, &n_out);
+    (void)shared_tables_floats(dev, &TS, &n_out);
     if (!victim->st.A || victim->st.TS != TS || victim->st.n_out != n_out) {
         set_error("internal: shared-table slot does not match the current time grid");
         return MPK_EINVAL;
     }
-    int rc = launch_build_shared(h->dev, init_time, victim->st, nullptr, h->d_flag, stream);
+    int rc = launch_build_shared(dev, init_time, victim->st, nullptr, h->d_flag, stream);
     if (rc != MPK_OK) return rc;
     victim->valid = true; victim->key = key; victim->T = T; victim->stamp = h->stamp;
     victim->pinned = capturing; victim->deferred = capturing; victim->capture_id = cap_id;
@@ -671,7 +716,7 @@ const OptKey kOptKeys[] = {
     {"ring_m", &Tuning::ring_m, 1, 8},           {"ring_dbg", &Tuning::ring_dbg, 0, 127},
     {"ring_parts", &Tuning::ring_parts, 1, 8},   {"tiles_wpb", &Tuning::tiles_wpb, 1, 4},
     {"serial_order", &Tuning::serial_order, 0, 2}, {"ring_nc", &Tuning::ring_nc, 1, 6},
-    {"pd_generic", &Tuning::pd_generic, 0, 1},
+    {"pd_generic", &Tuning::pd_generic, 0, 1},   {"dmp_response", &Tuning::dmp_response, 0, 1},
 };
 const OptKey* find_opt(const char* key) {
     if (!key) return nullptr;
@@ -727,8 +772,11 @@ int mpk_check_range(mpk_handle hh, void* stream) {
 int mpk_unpin_tables(mpk_handle hh) {
     if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
     Handle* h = reinterpret_cast<Handle*>(hh);
-    for (auto& e : h->cache)
-        if (e.pinned) { e.pinned = false; if (e.deferred) e.valid = false; e.deferred = false; }
+    for (auto* cache : {h->cache, h->cache_resp})
+        for (int i = 0; i < Handle::kCache; ++i) {
+            CacheEntry& e = cache[i];
+            if (e.pinned) { e.pinned = false; if (e.deferred) e.valid = false; e.deferred = false; }
+        }
     return MPK_OK;
 }
 
@@ -737,6 +785,14 @@ int mpk_times(mpk_handle hh, float* times) {
     Handle* h = reinterpret_cast<Handle*>(hh);
     std::memcpy(times, h->times.data(), sizeof(float) * h->times.size());
     return MPK_OK;
+}
+
+// the one-launch entry points (fused actions, closed loop, replanning step): promp / prodmp with a shared phase on the matrix-core
+// kernels, and DMP where its response route applies
+static bool fused_capable(const Handle* h) {
+    if (!shared_phase(h, nullptr)) return false;
+    if (h->cfg.mp_type == MPK_MP_DMP) return dmp_response(h, nullptr, effective_tuning(h));
+    return mfma_capable(h);
 }
 
 static int traj_common(Handle* h, const float* params, const float* init_pos, const float* init_vel,
@@ -778,6 +834,25 @@ static int traj_common(Handle* h, const float* params, const float* init_pos, co
         rc = launch_traj_wide(h->dev, st, params, init_pos, init_vel, pos, vel, B, h->num_cu, stream, &h->last_kernel);
         if (rc != MPK_ENOTIMPL) return rc;      // horizons beyond one row-tile block (promp / dmp): per-episode kernels
     }
+    if (dmp_response(h, init_time, tune)) {
+        // DMP as a two-output contraction of the Euler map's response rows (k_build_shared): every shared-phase kernel family of
+        // ProDMP, fused actions and the closed loop included
+        SharedTables st;
+        int rc = get_shared(h, (float)init_time_shared, stream, &st, true);
+        if (rc != MPK_OK) return rc;
+        unsigned* ticket = h->d_tickets + (size_t)(h->ticket_next++ % kTicketSlots) * 32;
+        const char* name = "";
+        rc = launch_traj_shared(h->dev_resp, st, params, init_pos, init_vel, pos, vel, actions, rd, c_pos, c_vel,
+                                q_state, qd_state, n_steps, B, h->num_cu, stream, &name, tune, rp, ticket);
+        if (rc == MPK_OK) {
+            h->kernel_name_buf = name;
+            const size_t at = h->kernel_name_buf.find("prodmp");
+            if (at != std::string::npos) h->kernel_name_buf.replace(at, 6, "dmp_resp");
+            h->last_kernel = h->kernel_name_buf.c_str();
+        }
+        // (horizons beyond the episode-major kernels' LDS: the serial kernels below; fused entry points fall back to two launches)
+        if (rc != MPK_ENOTIMPL || actions) return rc;
+    }
     if (shared_phase(h, init_time) && mfma_capable(h)) {
         SharedTables st;
         int rc = get_shared(h, (float)init_time_shared, stream, &st);
@@ -814,7 +889,7 @@ int mpk_trajectory_actions(mpk_handle hh, const float* params, const float* init
     if (r != MPK_OK) return r;
     MPK_ON_DEVICE(h->cfg.device);
     if (rd.plant_type != MPK_PLANT_STATIC) { set_error("mpk_trajectory_actions tracks a frozen state (MPK_PLANT_STATIC); use mpk_trajectory_rollout"); return MPK_EINVAL; }
-    if (h->cfg.mp_type != MPK_MP_DMP && shared_phase(h, nullptr) && mfma_capable(h)) {
+    if (fused_capable(h)) {
         r = traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, actions, &rd, c_pos, c_vel,
                         B, stream);
         if (r != MPK_ENOTIMPL) return r;
@@ -840,7 +915,7 @@ int mpk_trajectory_rollout(mpk_handle hh, const float* params, const float* init
     if (r != MPK_OK) return r;
     MPK_ON_DEVICE(h->cfg.device);
     if (rd.plant_type != MPK_PLANT_DOUBLE_INTEGRATOR) { set_error("mpk_trajectory_rollout integrates MPK_PLANT_DOUBLE_INTEGRATOR; for a frozen state use mpk_trajectory_actions"); return MPK_EINVAL; }
-    if (h->cfg.mp_type != MPK_MP_DMP && shared_phase(h, nullptr) && mfma_capable(h)) {
+    if (fused_capable(h)) {
         r = traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, actions, &rd, nullptr,
                         nullptr, B, stream, q, qd, n_steps);
         if (r != MPK_ENOTIMPL) return r;
@@ -873,7 +948,7 @@ int mpk_replan_step(mpk_handle hh, const float* params, const float* init_pos, c
     rp.traj_steps = st->traj_steps; rp.plan_steps = st->plan_steps; rp.done = st->done; rp.seg_len = st->seg_len;
     rp.done_out = st->done_out; rp.cond_pos = st->cond_pos; rp.cond_vel = st->cond_vel;
     rp.every = st->every; rp.max_planning_times = st->max_planning_times; rp.horizon = st->horizon;
-    if (h->cfg.mp_type != MPK_MP_DMP && shared_phase(h, nullptr) && mfma_capable(h)) {
+    if (fused_capable(h)) {
         // ONE launch: integer state, trajectory, controller + plant, condition gather
         r = traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, actions, &rd, nullptr,
                         nullptr, B, stream, q, qd, nullptr, &rp);

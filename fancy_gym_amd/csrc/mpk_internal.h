@@ -35,7 +35,7 @@ struct Tuning {
     int mapping = -1, bulk = -1, quad = -1, pd_quad = -1, write_through = -1, ipw = -1, phase = -1, phase_table = -1,
         phase_chunk = -1, pd_simple = -1, split = -1, lds_pad = -1, pipe = -1, flat = -1, phase_flat = -1,
         ring = -1, ring_np = -1, ring_ns = -1, ring_m = -1, ring_dbg = -1, ring_parts = -1, tiles_wpb = -1, serial_order = -1, ring_nc = -1,
-        pd_generic = -1;
+        pd_generic = -1, dmp_response = -1;
 };
 
 // ---- device-side configuration (kernel argument, by value) --------------------------------------------------
@@ -48,6 +48,8 @@ struct DevCfg {
     int learn_tau, learn_delay, relative_goal, disable_goal, disable_weights;
     int rbf_uniform;               // equally spaced centres, one bandwidth: Gaussians by product recurrence (RbfRecur)
     int relgoal_before_scale;      // MPK_RELGOAL_BEFORE_SCALE
+    int dmp_resp;                  // a DMP handle's RESPONSE configuration (round 5): mp_type says PRODMP -- the two-output contraction
+                                   // kernels run -- and k_build_shared fills their rows from the explicit Euler map instead (see there)
     int goal_off_on;               // MPK_GOAL_OFFSET_ADD with a non-zero offset: one extra contraction column (x = 1)
     float goal_offset;
     int n_pc, len_factor;

@@ -38,7 +38,49 @@ __global__ void __launch_bounds__(256) k_build_shared(const DevCfg c, const floa
     for (int i = tid; i < n_out * KP * TS; i += 256) A[i] = 0.0f;
     for (int i = tid; i < TS; i += 256) aux[i] = 0.0f;
     __syncthreads();
-    if (c.mp_type == MPK_MP_PRODMP) {
+    if (c.dmp_resp) {
+        // DMP with a phase all episodes share, as a CONTRACTION (round 5).  The explicit Euler recurrence of the reference's DMP
+        // (oracle/mp_oracle.py dmp_trajectory: a = alpha (beta (g - y) - z) + f; z += ds a; y += ds z; vel = z / tau) is
+        // linear in (w, g, y_b, v_b): pos[t] = sum_k R_pos[t, k] x_k with x = (w_1 .. w_nb, g, y_b, v_b), and R the response of THE
+        // SAME Euler map -- same fp32 step sizes ds, same order of operations -- to the unit inputs, run here once per (init_time, T)
+        // in float64 and rounded once to fp32.  Superposition of explicit Euler, not the ODE's analytic solution: first-order
+        // convergence in dt stays what the reference's integrator gives (tests/test_gpu_ode.py).  Columns as ProDMP's: weights, goal,
+        // y_b, v_b -- the two-output matrix-core kernels run unchanged (and with them fused actions and the closed loop).  The host
+        // takes this route only where the Euler map is stable (alpha ds < 1: mpk_host.cpp dmp_response_ok), i.e. |R| = O(1).
+        const int nb = c.nb;
+        // (1) forcing rows phi_k(x) x weights_scale as the serial kernels contract them (fp32), aux = fp32 step sizes
+        for (int t = tid; t < T; t += 256) {
+            const float time = c.base_times[t] + init_time;
+            const double x = phase_f64(c, time, c.tau, c.delay, ExpLiteral());
+            rbf_cols(c, x, x * (double)c.ws, A + t, TS);
+            if (t < T - 1) {
+                const float s0 = scaled_time(time, c.delay, c.tau);
+                const float s1 = scaled_time(c.base_times[t + 1] + init_time, c.delay, c.tau);
+                aux[t] = s1 - s0;
+            }
+        }
+        __syncthreads();
+        // (2) one thread per unit input runs the T - 1 steps (a forcing value is read before its slot takes the response)
+        if (tid < nb + 3) {
+            const int k = tid;
+            const double al = (double)c.dmp_alpha, be = (double)c.dmp_beta, tau = (double)c.tau, itau = div_pos(1.0, (double)c.tau);
+            const double G = k == nb ? (double)c.gs : 0.0;
+            double y = k == nb + 1 ? 1.0 : 0.0, z = k == nb + 2 ? tau : 0.0;      // z_0 = tau v_b
+            for (int t = 0; t < T; ++t) {
+                const double f = k < nb ? (double)A[(size_t)k * TS + t] : 0.0;
+                const double ds = (double)aux[t];
+                A[(size_t)(0 * KP + k) * TS + t] = (float)y;
+                A[(size_t)(1 * KP + k) * TS + t] = (float)(z * itau);
+                if (t < T - 1) {
+                    const double acc = al * (be * (G - y) - z) + f;
+                    z = z + ds * acc;
+                    y = y + ds * z;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < TS; i += 256) aux[i] = 0.0f;
+    } else if (c.mp_type == MPK_MP_PRODMP) {
         const float sb = scaled_time(init_time, c.delay, c.tau);
         const int idxb = min(prodmp_index(sb, c.scaled_dt), c.n_pc - 1);
         ProdmpBC bc;

@@ -411,7 +411,7 @@ def test_device_metaworld_controller_equals_the_reference_controller():
     assert np.array_equal(act.cpu().numpy()[:, 0], mo.astype(np.float32))
 
 
-@pytest.mark.parametrize("cfg", [CFG2, CFG5], ids=["prodmp", "promp"])
+@pytest.mark.parametrize("cfg", [CFG2, CFG5, CFG3], ids=["prodmp", "promp", "dmp_response"])
 @pytest.mark.parametrize("controller", ["motor", "position", "velocity"])
 @pytest.mark.parametrize("mapping", ["1", "2"])
 def test_fused_actions_are_bit_exact(cfg, controller, mapping, monkeypatch):
@@ -429,7 +429,7 @@ def test_fused_actions_are_bit_exact(cfg, controller, mapping, monkeypatch):
     assert np.array_equal(act.cpu().numpy(), ra.astype(np.float32))
 
 
-@pytest.mark.parametrize("cfg", [CFG2, CFG5, CFG4], ids=["prodmp", "promp", "prodmp_replan"])
+@pytest.mark.parametrize("cfg", [CFG2, CFG5, CFG4, CFG3], ids=["prodmp", "promp", "prodmp_replan", "dmp_response"])
 @pytest.mark.parametrize("controller", ["motor", "position", "velocity"])
 @pytest.mark.parametrize("B", [1, 9, 200])
 @pytest.mark.parametrize("bulk,quad", [("0", "2"), ("0", "3"), ("0", "4"), ("0", "0"), ("2", "0")])
@@ -487,6 +487,7 @@ def test_serial_kernels_in_every_launch_order_are_bit_identical(cfg, B, mpk_opti
             return [x.clone() for x in out] + [q, qd]
         return [x.clone() for x in eng.trajectory(params, ip, iv, 0.0)]
     ref = None
+    mpk_option("dmp_response", 0)         # DMP: the serial explicit-Euler kernels (the response route has no serial role)
     for quad in (2, 3, 4):
         for order in (-1, 0, 1, 2):
             mpk_option("quad", quad); mpk_option("serial_order", order)
@@ -651,7 +652,7 @@ def test_closed_loop_ring_declines_shapes_it_does_not_take(mpk_option):
     assert "k_traj_ring" not in eng.last_kernel() and eng.last_kernel().endswith("closed>")
 
 
-def test_four_groups_per_wave_while_the_outputs_fit_the_memory_side_cache():
+def test_four_groups_per_wave_while_the_outputs_fit_the_memory_side_cache(mpk_option):
     """the launcher's rule for the serial-recurrence kernels (profiles/r04_closed_loop.md): closed loop at 16 384 / 32 768 and cfg3
     at its BASELINE size on k_traj_quad, smaller launches on k_traj_duo, a few thousand closed-loop episodes on k_traj_pipe, and --
     second half of round 4 -- steps whose outputs exceed the memory-side cache (> 295 MiB) on the ring with consumer waves"""
@@ -665,7 +666,14 @@ def test_four_groups_per_wave_while_the_outputs_fit_the_memory_side_cache():
         assert eng.last_kernel().startswith(want), (B, eng.last_kernel())
     pc, bc, tc, dt, dur = CFG3
     eng = make_engine(pc, bc, tc, dt, dur)
-    for B, want in ((8192, "k_traj_duo"), (16384, "k_traj_quad"), (32768, "k_traj_duo")):
+    # round 5: cfg3 contracts the Euler map's response rows on the open-loop kernel families (tiles / stream / ring by size) ...
+    for B, want in ((8192, "k_traj_tiles<dmp_resp"), (16384, "k_traj_stream<dmp_resp"), (65536, "k_traj_ring<dmp_resp")):
+        params, ip, iv = inputs(pc, bc, tc, B, seed=1)
+        eng.trajectory(params, ip, iv, 0.0)
+        assert eng.last_kernel().startswith(want), (B, eng.last_kernel())
+    # ... and the serial explicit-Euler kernels behind "dmp_response" 0 keep their rule
+    mpk_option("dmp_response", 0)
+    for B, want in ((8192, "k_traj_duo<dmp>"), (16384, "k_traj_quad<dmp>"), (32768, "k_traj_duo<dmp>")):
         params, ip, iv = inputs(pc, bc, tc, B, seed=1)
         eng.trajectory(params, ip, iv, 0.0)
         assert eng.last_kernel().startswith(want), (B, eng.last_kernel())

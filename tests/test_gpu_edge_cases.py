@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from fancy_gym_amd import RolloutSpec, TrajectoryEngine
+from fancy_gym_amd import RolloutSpec, TrajectoryEngine, _lib
 from oracle import mp_oracle as O
 from tests.test_gpu_trajectory import CFG2, close, fd_atol, inputs, make_engine
 
@@ -368,6 +368,7 @@ def test_many_captured_ring_graphs_replay(mpk_option):
 @pytest.mark.parametrize("quad", ["0", "2", "3", "4"])
 @pytest.mark.parametrize("D,T,B", [(7, 200, 1), (7, 200, 9), (3, 33, 21), (16, 40, 5), (1, 50, 70), (5, 17, 4)])
 def test_dmp_quad_and_stream_kernels_agree_bitwise_and_match_oracle(quad, D, T, B, monkeypatch, mpk_option):
+    mpk_option("dmp_response", 0)          # the serial explicit-Euler kernels (the default route contracts response rows)
     mpk_option("quad", quad)
     eng = check(cfg_for("dmp", D, 5, T), B, seed=T,
                 expect_kernel={"0": "k_traj_stream", "2": "k_traj_quad", "3": "k_traj_duo", "4": "k_traj_mono"}[quad])
@@ -412,10 +413,20 @@ def test_per_episode_kernels_agree_bitwise(mp, D, nb, T, monkeypatch, mpk_option
         return np.abs(a - b).max() <= 2e-6 * np.abs(a).max()
     assert same(outs["0"][0], outs["1"][0]) and same(outs["0"][1], outs["1"][1])
     if D <= 16:
+        if mp == "dmp":
+            mpk_option("dmp_response", 0)     # the serial explicit-Euler kernels: the per-episode kernels' recurrence, bit for bit
         p0, v0 = eng.trajectory(params, ip, iv, float(it[0]))
         assert not eng.last_kernel().startswith(("k_traj_rows", "k_traj_phase"))
         assert same(p0, outs["1"][0]) and same(v0, outs["1"][1])
         assert torch.equal(p0, outs["0"][0]) and torch.equal(v0, outs["0"][1])       # folded rows in both
+        if mp == "dmp":
+            # the default route for a shared phase (response rows on the matrix cores, round 5): equal to rounding
+            mpk_option("dmp_response", -1)
+            p2, v2 = eng.trajectory(params, ip, iv, float(it[0]))
+            if "dmp_resp" in eng.last_kernel():
+                for a, b in ((p2, p0), (v2, v0)):
+                    a, b = a.cpu().numpy().astype(np.float64), b.cpu().numpy().astype(np.float64)
+                    assert np.abs(a - b).max() <= 2e-6 * np.abs(b).max()
     rp, rv = O.get_trajectory(pc, bc, tc, params, dur, dt, float(it[0]), ip, iv, dtype=np.float64)
     close(outs["1"][0].cpu().numpy(), rp, "pos")
     close(outs["1"][1].cpu().numpy(), rv, "vel", atol=fd_atol(rp, dt) if mp == "promp" else 0.0)
@@ -787,9 +798,17 @@ def test_dmp_horizon_beyond_the_lds_of_the_shared_phase_kernels_runs_time_tiled(
     pc, bc, tc, dt, dur = cfg_for("dmp", 3, 4, 8000, dt=0.002)
     eng = make_engine(pc, bc, tc, dt, dur)
     params, ip, iv = inputs(pc, bc, tc, 2, seed=1)
-    pos, vel = eng.trajectory(params, ip, iv, 0.0)
-    assert eng.last_kernel().startswith("k_traj_phase<dmp"), eng.last_kernel()
     rp, rv = O.get_trajectory(pc, bc, tc, params, dur, dt, 0.0, ip, iv, dtype=np.float64)
+    _lib.set_option("dmp_response", 0)
+    try:
+        pos, vel = eng.trajectory(params, ip, iv, 0.0)
+        assert eng.last_kernel().startswith("k_traj_phase<dmp"), eng.last_kernel()
+        close(pos.cpu().numpy(), rp, "pos"); close(vel.cpu().numpy(), rv, "vel")
+    finally:
+        _lib.reset_options()
+    # round 5: the response route has no such limit (the tile-major kernel reads its rows from the table in memory)
+    pos, vel = eng.trajectory(params, ip, iv, 0.0)
+    assert eng.last_kernel() == "k_traj_tiles<dmp_resp>", eng.last_kernel()
     close(pos.cpu().numpy(), rp, "pos"); close(vel.cpu().numpy(), rv, "vel")
 
 

@@ -91,6 +91,8 @@ def test_random_configuration_matches_oracle(seed, monkeypatch, mpk_option):
     mpk_option("phase_flat", int(r3.choice([-1, 0, 1])))
     if r3.integers(0, 2):
         mpk_option("phase_chunk", int(r3.integers(1, 9)))
+    r5 = np.random.default_rng(55_000 + seed)       # round 5: DMP with a shared phase on the response route / the serial kernels
+    mpk_option("dmp_response", int(r5.choice([-1, -1, 0])))
     if tc.trajectory_generator_type == "prodmp":
         tc = dataclasses.replace(tc, relative_goal_mode=str(r2.choice(["after_scale", "before_scale"])),
                                  goal_offset_mode=str(r2.choice(["ignore", "add"])), goal_offset=float(r2.uniform(-0.5, 0.5)))
@@ -407,7 +409,7 @@ def test_random_actions_reacher_validity_and_per_episode_init_time(seed, mpk_opt
     cp, cv = rng.uniform(-1, 1, (B, D)), rng.uniform(-0.3, 0.3, (B, D))
     lo, hi = -float(rng.uniform(0.3, 1.5)), float(rng.uniform(0.3, 1.5))
     shared = not (pc.learn_tau or pc.learn_delay)
-    if shared and tc.trajectory_generator_type != "dmp":
+    if shared:        # (DMP since round 5: one launch on the response route, two launches where that does not apply -- same bits)
         spec = RolloutSpec(ctrl, D, pg, dg, lo, hi, plant="static")
         p2, v2, a2 = eng.trajectory_actions(params, ip, iv, spec, cp, cv, init_time=init_time)
         assert torch.equal(p2, pos) and torch.equal(v2, vel), eng.last_kernel()

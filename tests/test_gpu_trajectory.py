@@ -103,6 +103,57 @@ def test_shared_phase_matches_oracle(name, B, init_time):
               atol=fd_atol(rp, dt) if tc.trajectory_generator_type == "promp" else 0.0)
 
 
+# ---- DMP with a shared phase: the response route (round 5) and the serial explicit-Euler kernels behind "dmp_response" 0 ---------
+DMP_SHAPES = {
+    "cfg3": CFG3,
+    "dmp_first_is_step": (O.PhaseCfg("exp", tau=4.0, alpha_phase=2.0), O.BasisCfg("rbf", num_basis=5),
+                          O.TrajCfg("dmp", action_dim=7, alpha=25.0, dmp_first_sample="step"), 0.02, 4.0),
+    "dmp_scaled_delay": (O.PhaseCfg("exp", tau=1.0, delay=0.2, alpha_phase=3.0), O.BasisCfg("rbf", num_basis=10),
+                         O.TrajCfg("dmp", action_dim=3, alpha=20.0, weights_scale=0.7, goal_scale=1.3), 0.02, 1.4),
+    "dmp_13_columns": (O.PhaseCfg("exp", tau=2.0), O.BasisCfg("rbf", num_basis=13),
+                       O.TrajCfg("dmp", action_dim=16, alpha=25.0), 0.01, 1.0),
+}
+
+
+@pytest.mark.parametrize("name", list(DMP_SHAPES))
+@pytest.mark.parametrize("B", [1, 5, 1000])
+@pytest.mark.parametrize("init_time", [0.0, 0.5])
+def test_dmp_response_route_and_serial_kernels_match_the_oracle_and_each_other(name, B, init_time, mpk_option):
+    """The explicit Euler recurrence is linear in (w, g, y_b, v_b): with a shared phase the library contracts the parameters with the
+    response rows of THE SAME Euler map (k_build_shared, float64, rounded once) on the matrix-core kernels; "dmp_response" 0 keeps the
+    serial kernels that run the reference's fp32 recurrence operation for operation.  Both against the float64 and the float32
+    oracle at the 1e-5 contract, and against each other at 2e-6 of the scale."""
+    pc, bc, tc, dt, duration = DMP_SHAPES[name]
+    eng = make_engine(pc, bc, tc, dt, duration)
+    params, ip, iv = inputs(pc, bc, tc, B, seed=B + 11)
+    iv = (np.random.default_rng(B).uniform(-0.5, 0.5, iv.shape)).astype(np.float32)
+    outs = {}
+    for resp in (1, 0):
+        mpk_option("dmp_response", -1 if resp else 0)
+        pos, vel = eng.trajectory(params, ip, iv, init_time)
+        torch.cuda.synchronize()
+        assert ("dmp_resp" in eng.last_kernel()) == bool(resp), eng.last_kernel()
+        outs[resp] = (pos.cpu().numpy(), vel.cpu().numpy())
+        for dtype in (np.float64, np.float32):
+            rp, rv = O.get_trajectory(pc, bc, tc, params, duration, dt, init_time, ip, iv, dtype=dtype)
+            close(outs[resp][0], rp, f"{name} pos vs oracle {dtype.__name__} (response {resp})")
+            close(outs[resp][1], rv, f"{name} vel vs oracle {dtype.__name__} (response {resp})")
+    for a, b in zip(outs[1], outs[0]):
+        assert np.abs(a.astype(np.float64) - b).max() <= 2e-6 * np.abs(b).max()
+
+
+def test_dmp_response_route_is_left_where_the_euler_map_is_not_comfortably_stable():
+    """alpha ds > 1 (here 25 x 0.02 / 0.3 = 1.67: past the explicit Euler map's stability bound, the reference's own recurrence rings
+    or diverges): the serial kernels, which reproduce that recurrence operation for operation -- checked against the float32 oracle"""
+    pc, bc, tc = O.PhaseCfg("exp", tau=0.3), O.BasisCfg("rbf", num_basis=5), O.TrajCfg("dmp", action_dim=4, alpha=25.0)
+    eng = make_engine(pc, bc, tc, 0.02, 0.4)
+    params, ip, iv = inputs(pc, bc, tc, 33, seed=3)
+    pos, vel = eng.trajectory(params, ip, iv, 0.0)
+    assert "dmp_resp" not in eng.last_kernel() and "dmp" in eng.last_kernel(), eng.last_kernel()
+    rp, rv = O.get_trajectory(pc, bc, tc, params, 0.4, 0.02, 0.0, ip, iv, dtype=np.float32)
+    close(pos.cpu().numpy(), rp, "pos"); close(vel.cpu().numpy(), rv, "vel")
+
+
 @pytest.mark.parametrize("init_time", [0.0, 0.02, 0.5, 1.0, 1.5])
 def test_prodmp_indices_bit_exact(init_time):
     pc, bc, tc, dt, duration = CFG2
@@ -169,7 +220,9 @@ def test_per_episode_init_time_equals_shared_path(name):
     p1, v1 = eng.trajectory(params, ip, iv, it)
     torch.cuda.synchronize()
     assert eng.last_kernel().startswith("k_traj_phase")
-    if name == "cfg2":
+    if name in ("cfg2", "cfg3"):
+        # (cfg3: the shared phase takes the response route since round 5 -- bit identity holds WITHIN the shared-phase families and
+        # within the per-episode families, the 1e-5 contract across them; with "dmp_response" 0 the serial kernels are bit-identical)
         for a, b in ((p0, p1), (v0, v1)):
             a, b = a.cpu().numpy().astype(np.float64), b.cpu().numpy().astype(np.float64)
             assert np.abs(a - b).max() <= 2e-6 * np.abs(a).max()
@@ -357,8 +410,11 @@ def test_ring_kernel_is_the_automatic_choice_for_launches_that_stream_to_hbm_and
     pc, bc, tc, dt, duration = CFG3
     eng3 = make_engine(pc, bc, tc, dt, duration)
     prm3, ip3, iv3 = inputs(pc, bc, tc, 60000, seed=2)
+    eng3.trajectory(prm3, ip3, iv3, 0.0)                      # 60 000 episodes of cfg3: 672 MB -> the ring, on the response route
+    assert eng3.last_kernel() == "k_traj_ring<dmp_resp>", eng3.last_kernel()
+    mpk_option("dmp_response", 0)
     eng3.trajectory(prm3, ip3, iv3, 0.0)
-    assert "dmp" in eng3.last_kernel() and "ring" not in eng3.last_kernel()
+    assert "<dmp>" in eng3.last_kernel() and "ring" not in eng3.last_kernel(), eng3.last_kernel()
 
 
 def test_flat_kernel_is_skipped_where_it_does_not_apply(mpk_option):

@@ -27,7 +27,7 @@ GOAL_OFFSET_MODES = {"ignore": 0, "add": 1}
 SINGLE_RBF_MODES = {"unit_gap": 0, "refuse": 1}
 DMP_FIRST_SAMPLE_MODES = {"init": 0, "step": 1}
 OPTION_KEYS = ("mapping", "bulk", "quad", "pd_quad", "write_through", "ipw", "phase", "phase_table", "phase_chunk",
-               "pd_simple", "split", "lds_pad", "pipe", "flat", "phase_flat", "ring", "ring_np", "ring_ns", "ring_m", "ring_dbg", "ring_parts", "tiles_wpb", "serial_order", "ring_nc", "pd_generic", "dmp_response")
+               "pd_simple", "split", "lds_pad", "pipe", "flat", "phase_flat", "ring", "ring_np", "ring_ns", "ring_m", "ring_dbg", "ring_parts", "tiles_wpb", "serial_order", "ring_nc", "pd_generic", "dmp_response", "ablations")
 
 
 class MPKLibraryError(RuntimeError):

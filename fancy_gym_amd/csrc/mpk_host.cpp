@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <map>
 #include <mutex>
 
 #include "mpk_internal.h"
@@ -50,7 +51,13 @@ struct DeviceGuard {
 
 // process-wide kernel-selection defaults (mpk_set_option with a NULL handle)
 static Tuning g_tune;
-constexpr unsigned kTicketSlots = 256;   // ticket counters per handle (k_traj_ring), 128 bytes apart
+// Ticket counters per handle (k_traj_ring), 128 bytes apart.  A counter cleans up after itself when its launch ends, so two launches
+// may share one only if they cannot overlap: a slot belongs to ONE ordering domain -- a stream (eager launches) or a (stream capture,
+// stream) pair (every launch a capture records on one stream; replays of different graphs may overlap each other and eager work, so
+// captures never share a slot with anything) -- and is never handed to another (round 5; rounds 3 - 4 took slots round robin modulo
+// 256, so a 13th captured graph of 20 ring launches re-used the slots of the first).  When the pool is exhausted a launch takes the
+// static batch assignment instead (no counter: correct, ~5 % slower on the streaming row).
+constexpr unsigned kTicketSlots = 4096;
 
 // ------------------------------------------------------------------------------------------------------------
 // times
@@ -218,8 +225,12 @@ struct Handle {
     int rows32_stride = 0;
     float* d_times = nullptr;
     int32_t* d_flag = nullptr;   // range-error flag written by kernels
-    unsigned* d_tickets = nullptr;   // k_traj_ring: kTicketSlots device-wide batch counters, one cache line apart; a launch takes
-    unsigned ticket_next = 0;        // the next one round robin (launches of one handle on different streams may overlap)
+    unsigned* d_tickets = nullptr;   // k_traj_ring: kTicketSlots device-wide batch counters, one cache line apart (see kTicketSlots)
+    unsigned ticket_next = 0;        // slots handed out so far
+    std::map<std::pair<unsigned long long, uintptr_t>, unsigned> ticket_of;   // (capture id or 0, stream) -> slot
+    std::mutex ticket_mu;
+    int* h_fault = nullptr;          // k_traj_ring's fault word: mapped host memory (ring_fail), read here without synchronising
+    int* d_fault = nullptr;          // ... its device address
     int32_t* d_idx = nullptr;    // scratch for mpk_prodmp_indices
     int idx_cap = 0;
     static constexpr int kCache = 64;    // distinct init_times of one replanning episode (a 100-step horizon replanned every 2 steps)
@@ -405,6 +416,7 @@ static void free_handle(Handle* h) {
     if (h->d_times) (void)hipFree(h->d_times);
     if (h->d_flag) (void)hipFree(h->d_flag);
     if (h->d_tickets) (void)hipFree(h->d_tickets);
+    if (h->h_fault) (void)hipHostFree(h->h_fault);
     if (h->d_idx) (void)hipFree(h->d_idx);
     if (h->d_pre) (void)hipFree(h->d_pre);
     delete h;
@@ -548,6 +560,7 @@ static int fill_rollout(const Handle* h, const mpk_rollout_cfg* rc, RolloutDev* 
 }  // namespace mpk
 
 using namespace mpk;
+static int pending_ring_fault(Handle* h);     // defined beside traj_common
 
 // ============================================================================================================
 // extern "C"
@@ -650,6 +663,9 @@ int mpk_create(const mpk_config* cfg, mpk_handle* out) {
     }
     if (hipMalloc((void**)&h->d_flag, sizeof(int32_t)) != hipSuccess) { set_error("hipMalloc(flag) failed"); return fail(MPK_EHIP); }
     if (hipMemset(h->d_flag, 0, sizeof(int32_t)) != hipSuccess) { set_error("hipMemset(flag) failed"); return fail(MPK_EHIP); }
+    if (hipHostMalloc((void**)&h->h_fault, 64, hipHostMallocMapped) != hipSuccess) { set_error("hipHostMalloc(fault word) failed"); return fail(MPK_EHIP); }
+    *h->h_fault = 0;
+    if (hipHostGetDevicePointer((void**)&h->d_fault, h->h_fault, 0) != hipSuccess) { set_error("hipHostGetDevicePointer(fault word) failed"); return fail(MPK_EHIP); }
     if (hipMalloc((void**)&h->d_tickets, kTicketSlots * 128) != hipSuccess) { set_error("hipMalloc(ticket counters) failed"); return fail(MPK_EHIP); }
     if (hipMemset(h->d_tickets, 0, kTicketSlots * 128) != hipSuccess) { set_error("hipMemset(ticket counters) failed"); return fail(MPK_EHIP); }
     rc = upload_times(h);
@@ -713,10 +729,11 @@ const OptKey kOptKeys[] = {
     {"pipe", &Tuning::pipe, 0, 1},               {"flat", &Tuning::flat, 0, 1},
     {"phase_flat", &Tuning::phase_flat, 0, 1},   {"ring", &Tuning::ring, 0, 2},
     {"ring_np", &Tuning::ring_np, 1, 14},        {"ring_ns", &Tuning::ring_ns, 1, 8},
-    {"ring_m", &Tuning::ring_m, 1, 8},           {"ring_dbg", &Tuning::ring_dbg, 0, 127},
+    {"ring_m", &Tuning::ring_m, 1, 8},           {"ring_dbg", &Tuning::ring_dbg, 0, 255},
     {"ring_parts", &Tuning::ring_parts, 1, 8},   {"tiles_wpb", &Tuning::tiles_wpb, 1, 4},
     {"serial_order", &Tuning::serial_order, 0, 2}, {"ring_nc", &Tuning::ring_nc, 1, 6},
     {"pd_generic", &Tuning::pd_generic, 0, 1},   {"dmp_response", &Tuning::dmp_response, 0, 1},
+    {"ablations", &Tuning::ablations, 0, 1},
 };
 const OptKey* find_opt(const char* key) {
     if (!key) return nullptr;
@@ -763,6 +780,10 @@ int mpk_check_range(mpk_handle hh, void* stream) {
     int32_t flag = 0;
     MPK_HIP(hipMemcpyAsync(&flag, h->d_flag, sizeof(flag), hipMemcpyDeviceToHost, (hipStream_t)stream));
     MPK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    {
+        const int fr = pending_ring_fault(h);       // (the stream has drained: every fault of its launches is visible)
+        if (fr != MPK_OK) return fr;
+    }
     if (!flag) return MPK_OK;
     MPK_HIP(hipMemsetAsync(h->d_flag, 0, sizeof(flag), (hipStream_t)stream));
     set_error("Time is beyond the pre-computation range. Set larger pre-computation factor");
@@ -787,6 +808,36 @@ int mpk_times(mpk_handle hh, float* times) {
     return MPK_OK;
 }
 
+// the ticket counter of a launch on `stream` (nullptr: pool exhausted -> static batch assignment); see kTicketSlots
+static unsigned* ticket_slot(Handle* h, void* stream) {
+    unsigned long long cap_id = 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamGetCaptureInfo((hipStream_t)stream, &cs, &cap_id) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+    if (cs != hipStreamCaptureStatusActive) cap_id = 0;
+    std::lock_guard<std::mutex> lock(h->ticket_mu);
+    const auto key = std::make_pair(cap_id, reinterpret_cast<uintptr_t>(stream));
+    auto it = h->ticket_of.find(key);
+    if (it == h->ticket_of.end()) {
+        if (h->ticket_next >= kTicketSlots) return nullptr;
+        it = h->ticket_of.emplace(key, h->ticket_next++).first;
+    }
+    return h->d_tickets + (size_t)it->second * 32;
+}
+
+// a role of an EARLIER ring launch on this handle gave up waiting (ring_fail): outputs of that launch are incomplete.  The word lives
+// in host memory: reading it costs nothing and synchronises nothing; it is reported once.
+static int pending_ring_fault(Handle* h) {
+    if (!h->h_fault) return MPK_OK;
+    const int f = __atomic_exchange_n(h->h_fault, 0, __ATOMIC_RELAXED);
+    if (!(f & 2)) { if (f) __atomic_fetch_or(h->h_fault, f & ~2, __ATOMIC_RELAXED); return MPK_OK; }
+    char msg[256];
+    std::snprintf(msg, sizeof msg, "k_traj_ring: a wave of an earlier launch on this handle gave up waiting for its partner (role mask 0x%x: "
+                  "1 producer / buffer, 2 ticket, 4 store engine / batch, 8 action writer, 16 consumer / tile, 32 consumer / writer): "
+                  "outputs (closed loop: plant and replanning state too) of that launch are incomplete", (unsigned)f >> 8);
+    set_error(msg);
+    return MPK_EHIP;
+}
+
 // the one-launch entry points (fused actions, closed loop, replanning step): promp / prodmp with a shared phase on the matrix-core
 // kernels, and DMP where its response route applies
 static bool fused_capable(const Handle* h) {
@@ -804,6 +855,10 @@ static int traj_common(Handle* h, const float* params, const float* init_pos, co
     if (B == 0 || h->dev.D == 0) return MPK_OK;     // empty batch: nothing to do (buffers may be NULL)
     if (!params || !init_pos || !init_vel || !pos || !vel) { set_error("NULL buffer"); return MPK_EINVAL; }
     MPK_ON_DEVICE(h->cfg.device);
+    {
+        const int fr = pending_ring_fault(h);
+        if (fr != MPK_OK) return fr;
+    }
     const Tuning tune = effective_tuning(h);
     if (h->cfg.mp_type == MPK_MP_DMP && h->cfg.dmp_first_sample == MPK_DMP_FIRST_IS_STEP) {
         // the boundary state advanced by one Euler step (k_dmp_prestep) is what the trajectory kernels start from.
@@ -840,10 +895,10 @@ static int traj_common(Handle* h, const float* params, const float* init_pos, co
         SharedTables st;
         int rc = get_shared(h, (float)init_time_shared, stream, &st, true);
         if (rc != MPK_OK) return rc;
-        unsigned* ticket = h->d_tickets + (size_t)(h->ticket_next++ % kTicketSlots) * 32;
+        unsigned* ticket = ticket_slot(h, stream);
         const char* name = "";
         rc = launch_traj_shared(h->dev_resp, st, params, init_pos, init_vel, pos, vel, actions, rd, c_pos, c_vel,
-                                q_state, qd_state, n_steps, B, h->num_cu, stream, &name, tune, rp, ticket);
+                                q_state, qd_state, n_steps, B, h->num_cu, stream, &name, tune, rp, ticket, h->d_fault);
         if (rc == MPK_OK) {
             h->kernel_name_buf = name;
             const size_t at = h->kernel_name_buf.find("prodmp");
@@ -857,9 +912,9 @@ static int traj_common(Handle* h, const float* params, const float* init_pos, co
         SharedTables st;
         int rc = get_shared(h, (float)init_time_shared, stream, &st);
         if (rc != MPK_OK) return rc;
-        unsigned* ticket = h->d_tickets + (size_t)(h->ticket_next++ % kTicketSlots) * 32;
+        unsigned* ticket = ticket_slot(h, stream);
         rc = launch_traj_shared(h->dev, st, params, init_pos, init_vel, pos, vel, actions, rd, c_pos, c_vel,
-                                q_state, qd_state, n_steps, B, h->num_cu, stream, &h->last_kernel, tune, rp, ticket);
+                                q_state, qd_state, n_steps, B, h->num_cu, stream, &h->last_kernel, tune, rp, ticket, h->d_fault);
         // horizons whose basis tables do not fit the episode-major kernel's LDS: the per-episode kernels below (dmp) or,
         // for fused actions / rollouts, the caller's two-launch path
         if (rc != MPK_ENOTIMPL || actions) return rc;

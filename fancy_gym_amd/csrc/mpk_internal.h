@@ -35,7 +35,7 @@ struct Tuning {
     int mapping = -1, bulk = -1, quad = -1, pd_quad = -1, write_through = -1, ipw = -1, phase = -1, phase_table = -1,
         phase_chunk = -1, pd_simple = -1, split = -1, lds_pad = -1, pipe = -1, flat = -1, phase_flat = -1,
         ring = -1, ring_np = -1, ring_ns = -1, ring_m = -1, ring_dbg = -1, ring_parts = -1, tiles_wpb = -1, serial_order = -1, ring_nc = -1,
-        pd_generic = -1, dmp_response = -1;
+        pd_generic = -1, dmp_response = -1, ablations = -1;
 };
 
 // ---- device-side configuration (kernel argument, by value) --------------------------------------------------
@@ -98,7 +98,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
                        const float* init_vel, float* pos, float* vel, float* actions, const RolloutDev* rc,
                        const double* c_pos, const double* c_vel, double* q_state, double* qd_state,
                        const int32_t* n_steps, int B, int num_cu, void* stream, const char** kernel_name,
-                       const Tuning& tune, const ReplanDev* rp = nullptr, unsigned* ticket = nullptr);
+                       const Tuning& tune, const ReplanDev* rp = nullptr, unsigned* ticket = nullptr, int* fault = nullptr);
 // shared phase, more than kMaxKP contraction columns: k-chunked GEMM on the matrix cores (trajectory only)
 int launch_traj_wide(const DevCfg& c, const SharedTables& st, const float* params, const float* init_pos,
                      const float* init_vel, float* pos, float* vel, int B, int num_cu, void* stream,

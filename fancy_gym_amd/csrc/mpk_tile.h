@@ -65,6 +65,7 @@ struct TrajArgs {
     int inorder;           // k_traj_quad: 1 = one unit per wave, workgroup b takes units 4 b .. 4 b + 3 (short-lived workgroups in address order)
     int wpb;               // tile-major kernel: waves per workgroup (4; "tiles_wpb" 1 / 2 for A/B runs)
     int ring_dbg;          // ablations (mpk_set_option "ring_dbg"): 1 producers publish without contracting, 2 the engine skips its stores
+    int* fault;            // k_traj_ring: the handle's fault word (host memory, mapped): a role that gives up waiting ORs its code in
     unsigned ser_blocks;   // k_traj_split: workgroups [0, ser_blocks) run the serial role
     // closed-loop rollout fused into the episode-major kernel (CT >= 3)
     double* q_state;       // [B, D] plant position, in/out

@@ -181,10 +181,14 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
                        const float* init_vel, float* pos, float* vel, float* actions, const RolloutDev* rc,
                        const double* c_pos, const double* c_vel, double* q_state, double* qd_state,
                        const int32_t* n_steps, int B, int num_cu, void* stream, const char** kernel_name,
-                       const Tuning& tune, const ReplanDev* rp, unsigned* ticket) {
+                       const Tuning& tune, const ReplanDev* rp, unsigned* ticket, int* fault) {
     TrajArgs ta;
+    ta.fault = fault;
     ta.nrt_magic = 0; ta.gstride = 0; ta.wt = 0; ta.flat_img = 0;
-    ta.ring_np = 0; ta.ring_ns = 0; ta.ring_m = 0; ta.ring_nbuf = 0; ta.ring_nc = 0; ta.ring_aw = 0; ta.ring_dbg = tune.ring_dbg > 0 ? tune.ring_dbg : 0; ta.burst = 0; ta.inorder = 0; ta.lean = 0; ta.wpb = 4; ta.ring_ctr = nullptr; ta.ring_tb = 0; ta.ring_parts = 1;
+    ta.ring_np = 0; ta.ring_ns = 0; ta.ring_m = 0; ta.ring_nbuf = 0; ta.ring_nc = 0; ta.ring_aw = 0; ta.ring_dbg = tune.ring_dbg > 0 ? tune.ring_dbg : 0;
+    // the bits that leave outputs unwritten (1 no production, 2 no stores, 128 a batch never published; open loop: 8 no input loads)
+    // count only after mpk_set_option(.., "ablations", 1) -- measurements and fault injection, never by accident
+    if (tune.ablations != 1) ta.ring_dbg &= ~(1 | 2 | 128 | (q_state ? 0 : 8)); ta.burst = 0; ta.inorder = 0; ta.lean = 0; ta.wpb = 4; ta.ring_ctr = nullptr; ta.ring_tb = 0; ta.ring_parts = 1;
     if (rp) ta.rp = *rp;
     const bool closed = q_state != nullptr;
     ta.q_state = q_state; ta.qd_state = qd_state; ta.n_steps = n_steps; ta.plant_dt = rc ? rc->dt : 0.0;
@@ -383,7 +387,11 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         long nbuf = fixed + stage < kLdsPerCu ? (long)((kLdsPerCu - fixed - stage) / buf_bytes) : 0;
         if (nbuf * M > 32) nbuf = 32 / M;
         if (nbuf > 4) nbuf = 4;
-        if (want && NP >= 1 && nbuf >= 2 && ((long)M * gimg) % 4 == 0 && 16 * c.D * NTW <= kStageStride) {
+        // automatic only with four groups per batch (one per lane quarter of a consumer): a 200-step horizon leaves room for two, and
+        // the ring then loses to the lane-quarter kernels (round 5, cfg3's shape closed loop, us ring / duo: 32 768 episodes 192 / 124,
+        // 65 536: 368 / 280, 131 072: 722 / 522 -- tools/dmp_closed_choice.py)
+        const bool ring_pays = tune.ring == 1 || M == 4;
+        if (want && ring_pays && NP >= 1 && nbuf >= 2 && ((long)M * gimg) % 4 == 0 && 16 * c.D * NTW <= kStageStride) {
             ta.flat_img = gimg;
             ta.ring_np = NP; ta.ring_ns = NS; ta.ring_nc = NC; ta.ring_aw = AW; ta.ring_m = M; ta.ring_nbuf = (int)nbuf; ta.ring_parts = 1;
             ta.ring_ctr = ticket;

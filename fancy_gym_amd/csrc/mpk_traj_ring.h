@@ -31,13 +31,23 @@ constexpr int kRingThreads = 768;             // launch bound (12 waves: up to 1
 #endif
 constexpr int kRingThreadsClosed = 1024;      // closed loop: three roles, 93 registers: up to 16 waves
 constexpr int kRingSyncInts = 96;             // full[32] | empty[32] | tickets[8] | tickets published | pad
-constexpr unsigned kRingSpinLimit = 1u << 21; // ~0.3 s of polling with the sleep below: then give up (outputs stay unwritten)
+constexpr unsigned kRingSpinLimit = 1u << 21; // ~0.3 s of polling with the sleep below: then give up -- LOUDLY (ring_fail)
 
-__device__ __forceinline__ bool ring_wait(int* flag, int want) {
+// A role that gives up waiting leaves outputs of its launch unwritten (and, closed loop, the plant / replanning state of some
+// episodes advanced): it says so in the handle's fault word before it leaves -- host memory, so that the next entry point on the
+// handle (and mpk_check_range) turns it into MPK_EHIP without a synchronisation of its own (round 5; rounds 1 - 4 returned MPK_OK).
+// Codes: which role waited for what.
+enum : int { kRingFailProducerEmpty = 1, kRingFailTicket = 2, kRingFailEngineFull = 4, kRingFailWriterPost = 8,
+             kRingFailConsumerFull = 16, kRingFailConsumerTake = 32 };
+__device__ __noinline__ void ring_fail(int* fault, int code) {
+    if (fault) __hip_atomic_fetch_or(fault, code << 8 | 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__device__ __forceinline__ bool ring_wait(int* flag, int want, int* fault, int code) {
     unsigned spins = 0;
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want) {
         __builtin_amdgcn_s_sleep(4);
-        if (++spins > kRingSpinLimit) return false;
+        if (++spins > kRingSpinLimit) { ring_fail(fault, code); return false; }
     }
     return true;
 }
@@ -402,7 +412,7 @@ __global__ void __launch_bounds__(CT >= 3 ? kRingThreadsClosed : kRingThreads) k
             if (__hip_atomic_load(sDone, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0 &&
                 __hip_atomic_load(sTickN, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= tl) return -1;
             __builtin_amdgcn_s_sleep(4);
-            if (++spins > kRingSpinLimit) return -2;
+            if (++spins > kRingSpinLimit) { ring_fail(a.fault, kRingFailTicket); return -2; }
         }
         const int t = __hip_atomic_load(&sTick[tl & 7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return t < NT ? t * TB + (bl - tl * TB) : -1;
@@ -471,7 +481,7 @@ __global__ void __launch_bounds__(CT >= 3 ? kRingThreadsClosed : kRingThreads) k
             if (CLOSED || !(a.ring_dbg & 8)) nxt = load_group<MP, ACT, KM>(a, L, gx < a.G ? gx : a.G - 1);   // in flight across the whole group
             const int buf = bl % NBUF, k = bl / NBUF, slot = buf * M + j;
             if (CLOSED && n / NP < 12) MPK_STAMP(3 * (n / NP));                     // unit start (next unit's loads issued)
-            if (!ring_wait(&sEmpty[slot], k * (NS + (CLOSED ? 1 : 0)))) { leave0(); return; }
+            if (!ring_wait(&sEmpty[slot], k * (NS + (CLOSED ? 1 : 0)), a.fault, kRingFailProducerEmpty)) { leave0(); return; }
             if (CLOSED && n / NP < 12) MPK_STAMP(3 * (n / NP) + 1);                 // buffer acquired   // the engine (and the consumer) have released use k - 1 of this slot
             int pub = CLOSED ? NRT : 1;                           // what this unit adds to the slot's `full` count at its end
             if (g < a.G && !(a.ring_dbg & 1)) {
@@ -497,7 +507,9 @@ __global__ void __launch_bounds__(CT >= 3 ? kRingThreadsClosed : kRingThreads) k
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (CLOSED && n / NP < 12) MPK_STAMP(3 * (n / NP) + 2);                 // contracted
             if (lane == 0) {
-                __hip_atomic_fetch_add(&sFull[slot], pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // ("ring_dbg" 128, fault injection for the tests: the workgroup's second batch is never published -- every role that
+                // depends on it must give up after kRingSpinLimit polls and say so)
+                if (!((a.ring_dbg & 128) && bl == 1)) __hip_atomic_fetch_add(&sFull[slot], pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (nreq > 0) __hip_atomic_store(sTickN, requested, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             if (bx < 0) {
@@ -521,7 +533,7 @@ __global__ void __launch_bounds__(CT >= 3 ? kRingThreadsClosed : kRingThreads) k
             if (b < 0) return;
             const int buf = bl % NBUF, k = bl / NBUF;
             for (int j = 0; j < M; ++j)
-                if (!ring_wait(&sFull[buf * M + j], (k + 1) * (CLOSED ? (T + 15) >> 4 : P))) return;   // (closed loop: `full` counts row tiles)
+                if (!ring_wait(&sFull[buf * M + j], (k + 1) * (CLOSED ? (T + 15) >> 4 : P), a.fault, kRingFailEngineFull)) return;   // (closed loop: `full` counts row tiles)
             if (CLOSED && bl < 12) MPK_STAMP_AT(40 + 2 * bl, NP * 64);             // batch complete
             const long e0 = (long)b * M * NTW;
             const long left = (long)a.B - e0;
@@ -576,7 +588,7 @@ __global__ void __launch_bounds__(CT >= 3 ? kRingThreadsClosed : kRingThreads) k
 #pragma unroll 1
                     for (int rt = 0; rt < NRT; ++rt, ++n) {
                         const int rows = min(16, T - rt * 16);
-                        if (!ring_wait(sPost, n + 1)) return;
+                        if (!ring_wait(sPost, n + 1, a.fault, kRingFailWriterPost)) return;
                         f32x4 v[4];
                         bool on[4];
 #pragma unroll
@@ -663,7 +675,7 @@ __global__ void __launch_bounds__(CT >= 3 ? kRingThreadsClosed : kRingThreads) k
                             seen = mn - k * NRT;
                             if (seen > rt) break;
                             __builtin_amdgcn_s_sleep(2);
-                            if (++spins > kRingSpinLimit) return;
+                            if (++spins > kRingSpinLimit) { ring_fail(a.fault, kRingFailConsumerFull); return; }
                         }
                     }
                     if (rt == 0 && bl / NC < 10) MPK_STAMP_AT(81 + 4 * (bl / NC), (NP + NS) * 64);   // tile 0 there
@@ -673,7 +685,7 @@ __global__ void __launch_bounds__(CT >= 3 ? kRingThreadsClosed : kRingThreads) k
                         a.rp.cond_pos[si] = sP[tcond * DC];
                         a.rp.cond_vel[si] = sV[tcond * DC];
                     }
-                    if (handoff && !ring_wait(sTake, ntile)) return;         // the writer holds the previous tile set in registers
+                    if (handoff && !ring_wait(sTake, ntile, a.fault, kRingFailConsumerTake)) return;   // the writer holds the previous tile set in registers
                     if (!(a.ring_dbg & 1)) {
                         if (__any(serial && rt * 16 < nst)) {
                             const bool full_tile = tile_fully_executed(serial, nst, rt * 16);

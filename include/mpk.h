@@ -240,8 +240,10 @@ int mpk_set_duration(mpk_handle h, double duration, double dt);
  *                   loops instead of the compile-time-DoF ones, 64 k_traj_flat without its compile-time-DoF variant (ring: the engine moves
  *                   four 1 KB chunks per step instead of two -- closed loop: two instead of its four); closed loop only: 8 the
  *                   consumer waves store their action tiles themselves (no action-writer waves).  ABLATIONS that leave outputs
- *                   unwritten, measurements only: 1 no production (closed loop: no recurrence either), 2 no stores, 8 (open
- *                   loop) no input loads.
+ *                   unwritten -- measurements and fault injection, ignored unless "ablations" is 1: 1 no production (closed loop: no
+ *                   recurrence either), 2 no stores, 8 (open loop) no input loads, 128 every workgroup's second batch is never
+ *                   published (the roles that wait for it give up after ~0.3 s and raise the handle's fault word: below).
+ *   "ablations"     1 lets the ablation bits of "ring_dbg" take effect (default: they are masked out)
  * Unknown key or value out of range: MPK_EINVAL.  mpk_get_option returns the effective value (MPK_OPT_AUTO if automatic).
  */
 #define MPK_OPT_AUTO (-1)
@@ -263,6 +265,12 @@ int mpk_get_option(mpk_handle h, const char* key, int64_t* value);
  * flag and clamp the table index.  mpk_check_range synchronises `stream`, returns MPK_ERANGE (mp_pytorch: RuntimeError
  * "Time is beyond the pre-computation range...") if any launch since the last check raised the flag, and clears it.
  * Shared-phase calls report the condition directly from mpk_trajectory* without synchronising.
+ *
+ * The same call reports a FAULT OF THE RING KERNELS (k_traj_ring, k_traj_ring<.., closed>: the persistent producer / store-engine /
+ * consumer workgroups that take the launches beyond the caches): a wave that gives up waiting for its partner (every spin is
+ * bounded: ~0.3 s) leaves outputs of its launch unwritten -- and says so in a per-handle fault word in mapped host memory.  The
+ * next mpk_trajectory* / mpk_replan_step call on the handle, and mpk_check_range after its synchronisation, return MPK_EHIP with
+ * the roles that gave up in mpk_last_error() and clear the word; reading it synchronises nothing.  (Rounds 1 - 4 returned MPK_OK.)
  */
 int mpk_check_range(mpk_handle h, void* stream);
 

@@ -80,7 +80,7 @@ def main():
         R = {"ring": 1}
         variants = [("auto", {}), ("quad", {"quad": 2}), ("duo", {"quad": 3}), ("ring", dict(R)), ("ring tickets", dict(R, ring_dbg=4)),
                     ("ring, consumers store", dict(R, ring_dbg=8, ring_nc=4)), ("ring ns2", dict(R, ring_ns=2, ring_np=7)),
-                    ("ring no stores", dict(R, ring_dbg=2)), ("ring no compute", dict(R, ring_dbg=1)), ("auto (again)", {})]
+                    ("ring no stores", dict(R, ring_dbg=2, ablations=1)), ("ring no compute", dict(R, ring_dbg=1, ablations=1)), ("auto (again)", {})]
     if "--ring-sweep" in sys.argv:
         variants = [("duo", {"quad": 3})]
         for dbg in (0, 4):
@@ -91,7 +91,7 @@ def main():
         if "--full-only" in sys.argv:
             pass
     if "--ring-ablate" in sys.argv:   # measurements only (outputs unwritten): ring_dbg 1 no production / chain, 2 no stores
-        base = {"ring": 1}
+        base = {"ring": 1, "ablations": 1}         # (the output-dropping bits of ring_dbg are masked out without it)
         variants = [("ring", dict(base)), ("ring static", dict(base, ring_dbg=4)), ("no compute", dict(base, ring_dbg=1)), ("no stores", dict(base, ring_dbg=2)),
                     ("neither", dict(base, ring_dbg=3)), ("static no compute", dict(base, ring_dbg=5)), ("static no stores", dict(base, ring_dbg=6)),
                     ("static neither", dict(base, ring_dbg=7)), ("np7 ns1 nc4", dict(base, ring_np=7, ring_ns=1, ring_nc=4)),

@@ -272,7 +272,10 @@ class BatchedBlackBox:
         pos, vel = out["des_pos"], out["des_vel"]
         out.update(valid=valid, trajectory_length=seg, done=self.done.bool(), terminated=~valid & ~was_done,
                    truncated=self.done.bool() & valid)
-        if self.condition_on_desired:
+        if self.condition_on_desired and not self.learn_sub_trajectories:
+            # (black_box_wrapper.py:197-203 stores the desired state only inside the break branch -- terminated, truncated, or the
+            # replanning schedule.  With sub-trajectories the schedule is never true: a plan that ends before the episode does leaves
+            # condition_pos None, and the next one starts from env.current_pos / current_vel -- self.q / self.qd here.)
             self.condition_pos, self.condition_vel = self.engine.condition_gather(pos, vel, seg)
         if self.do_replanning and self._lockstep is not None:
             if self.pos_limits is None:

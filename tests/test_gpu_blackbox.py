@@ -1176,19 +1176,24 @@ def test_batched_simple_reacher_equals_single_episode_wrapper(mp_type):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mp_type", ["ProMP", "DMP"])
-@pytest.mark.parametrize("agg", ["sum", "mean", "last"])
-def test_batched_sub_trajectories_equal_single_episode_wrappers(mp_type, agg):
+@pytest.mark.parametrize("mp_type,agg,cond", [("ProMP", "sum", False), ("ProMP", "mean", False), ("ProMP", "last", False),
+                                               ("DMP", "sum", False), ("DMP", "mean", False), ("DMP", "last", False),
+                                               ("DMP", "sum", True), ("ProMP", "sum", True)])
+def test_batched_sub_trajectories_equal_single_episode_wrappers(mp_type, agg, cond):
     """learn_sub_trajectories (black_box_wrapper.py:98-102; test/test_replanning_sequencing.py:67-109) on the batched path:
     B episodes of fancy_<MP>/LongSimpleReacher-v0, each stepped by its own host BlackBoxWrapper (NumPy plant + reward) until the
     200-step budget ends, against ONE BatchedBlackBox stepping them together -- episodes plan different lengths
     (round(tau / dt)), so they finish after different numbers of plans.  Integers (trajectory_length, done) exactly; plans, actions,
     step rewards and aggregated returns to the 1e-5 contract (a single wrapper evaluates a plan on linspace(0, T_b dt, T_b + 1)[1:],
-    the batch on the first T_b points of the longest plan's grid: one fp32 rounding of the grid apart)."""
+    the batch on the first T_b points of the longest plan's grid: one fp32 rounding of the grid apart).
+    cond: condition_on_desired with sub-trajectories -- the reference stores the desired state only in its break branch
+    (black_box_wrapper.py:197-203), which a sub-trajectory that ends before the episode never enters: every plan starts from the
+    plant's current state (round 4's batched path planned from the previous plan's desired end state instead: ADVICE r04)."""
     from fancy_gym_amd import _gym
     fn = {"sum": np.sum, "mean": np.mean, "last": (lambda r: r[-1])}[agg]
     env = _gym.make(f"fancy_{mp_type}/LongSimpleReacher-v0",
-                    mp_config_override={"black_box_kwargs": {"learn_sub_trajectories": True, "verbose": 2, "reward_aggregation": fn}})
+                    mp_config_override={"black_box_kwargs": {"learn_sub_trajectories": True, "verbose": 2, "reward_aggregation": fn,
+                                                             "condition_on_desired": cond}})
     assert env.learn_sub_trajectories and env.traj_gen.learn_tau
     env.action_space.seed(11)
     B, dt = 7, 0.01
@@ -1210,7 +1215,7 @@ def test_batched_sub_trajectories_equal_single_episode_wrappers(mp_type, agg):
     assert min(len(e) for e in eps) < n_plans                   # the episodes do not finish together
     bb = BatchedBlackBox(env.traj_gen, env.tracking_controller, B, dt=dt, duration=2.0, act_low=-1000.0, act_high=1000.0,
                          plant="double_integrator", reward="simple_reacher", learn_sub_trajectories=True,
-                         max_episode_steps=200, reward_aggregation=agg if agg != "mean" else np.mean)
+                         max_episode_steps=200, reward_aggregation=agg if agg != "mean" else np.mean, condition_on_desired=cond)
     bb.reset(np.stack(starts), goal=np.stack(goals))
     P = bb.engine.num_params
     for k in range(n_plans):

@@ -2,7 +2,8 @@
 """
 Episode-based search on the reference's SimpleReacher family, entirely on one MI355X: a population of ProDMP parameter
 vectors -> trajectories -> PD tracking on the torque plant -> per-step reward -> episode return, one hipGraph replay per
-generation (`BatchedBlackBox.capture_episode`), cross-entropy update on the host.
+generation (`BatchedBlackBox.capture_episode`; with `verbose=1` the whole generation is ONE kernel that stores nothing per step:
+`mpk_episode_return`), cross-entropy update on the host.
 
     python examples/batched_reacher_search.py [--pop 4096] [--iters 30] [--links 5]
 
@@ -30,8 +31,10 @@ def make_population(links: int, pop: int) -> BatchedBlackBox:
     basis = get_basis_generator("prodmp", phase, num_basis=5, alpha=10.0, basis_bandwidth_factor=3.0)
     traj = get_trajectory_generator("prodmp", links, basis, weights_scale=1.0, goal_scale=1.0)
     ctrl = get_controller("motor", p_gains=0.6, d_gains=0.075)
+    # verbose = 1 (the reference's default, black_box_wrapper.py:21): a step returns the episode return, not the trajectories --
+    # on the device ONE launch per generation that stores nothing per step (mpk_episode_return)
     return BatchedBlackBox(traj, ctrl, pop, dt=0.01, duration=2.0, act_low=-1000.0, act_high=1000.0,
-                           plant="double_integrator", reward="simple_reacher")
+                           plant="double_integrator", reward="simple_reacher", verbose=1)
 
 
 def search(pop: int = 4096, iters: int = 30, links: int = 5, seed: int = 0, verbose: bool = True):

@@ -26,6 +26,8 @@ RELATIVE_GOAL_MODES = {"before_scale": 0, "after_scale": 1}   # first = the ship
 GOAL_OFFSET_MODES = {"ignore": 0, "add": 1}
 SINGLE_RBF_MODES = {"unit_gap": 0, "refuse": 1}
 DMP_FIRST_SAMPLE_MODES = {"init": 0, "step": 1}
+REWARD_TYPES = {None: 0, "none": 0, "simple_reacher": 1}       # MPK_REWARD_*
+AGG_MODES = {"sum": 0, "mean": 1, "last": 2}                   # MPK_AGG_*
 OPTION_KEYS = ("mapping", "bulk", "quad", "pd_quad", "write_through", "ipw", "phase", "phase_table", "phase_chunk",
                "pd_simple", "split", "lds_pad", "pipe", "flat", "phase_flat", "ring", "ring_np", "ring_ns", "ring_m", "ring_dbg", "ring_parts", "tiles_wpb", "serial_order", "ring_nc", "pd_generic", "dmp_response", "ablations")
 
@@ -96,6 +98,9 @@ SIGNATURES = {
     "mpk_episode_reset": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "mpk_replan_step": (C.c_int, [_vp, _vp, _vp, _vp, _dbl, C.POINTER(mpk_rollout_cfg), _vp, _vp,
                                   C.POINTER(mpk_replan_state), _vp, _vp, _vp, _i32, _vp]),
+    "mpk_episode_return": (C.c_int, [_vp, _vp, _vp, _vp, _dbl, C.POINTER(mpk_rollout_cfg), _vp, _vp, C.POINTER(mpk_replan_state),
+                                     _vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _i32, _vp]),
+    "mpk_reward_aggregate": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp]),
     "mpk_pd_rollout": (C.c_int, [_vp, C.POINTER(mpk_rollout_cfg), _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "mpk_condition_gather": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "mpk_unpin_tables": (C.c_int, [_vp]),
@@ -126,10 +131,10 @@ _lib: Optional[C.CDLL] = None
 
 # the files libmpk.so is built from, in the order mpk_source_hash() is defined over (include/mpk.h)
 _ROOT = os.path.dirname(_HERE)
-KERNEL_UNITS = ("mpk_traj_family.hip", "mpk_traj_ring.hip", "mpk_traj_launch.hip", "mpk_traj_wide.hip", "mpk_traj_phase.hip", "mpk_rollout.hip",
+KERNEL_UNITS = ("mpk_traj_family.hip", "mpk_traj_ring.hip", "mpk_episode.hip", "mpk_traj_launch.hip", "mpk_traj_wide.hip", "mpk_traj_phase.hip", "mpk_rollout.hip",
                 "mpk_misc.hip")          # translation units of the device code (mpk_traj_family.hip: once per MP type)
 KERNEL_HEADERS = ("mpk_dev.h", "mpk_tile.h", "mpk_traj_tiles.h", "mpk_traj_stream.h", "mpk_traj_flat.h", "mpk_traj_ring.h", "mpk_traj_quad.h",
-                  "mpk_traj_pipe.h")
+                  "mpk_traj_pipe.h", "mpk_reward.h")
 SOURCE_FILES = (os.path.join(_ROOT, "include", "mpk.h"), os.path.join(_HERE, "csrc", "mpk_internal.h"),
                 os.path.join(_HERE, "csrc", "mpk_host.cpp")) + \
     tuple(os.path.join(_HERE, "csrc", f) for f in KERNEL_HEADERS + KERNEL_UNITS)

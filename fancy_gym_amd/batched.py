@@ -31,7 +31,7 @@ class BatchedBlackBox:
                  max_planning_times: Union[int, float] = math.inf, condition_on_desired: bool = False,
                  max_episode_steps: Optional[int] = None, pos_limits: Optional[Sequence] = None,
                  check_tau_delay: bool = False, reward: Optional[str] = None, steps_before_reward: int = 199,
-                 device=None, learn_sub_trajectories: bool = False, reward_aggregation="sum"):
+                 device=None, learn_sub_trajectories: bool = False, reward_aggregation="sum", verbose: int = 2):
         """
         trajectory_generator / tracking_controller: the objects the factories return (``get_trajectory_generator``,
         ``get_controller``).  ``replanning_every = n`` is the schedule ``lambda pos, vel, obs, action, t: t % n == 0``
@@ -53,7 +53,17 @@ class BatchedBlackBox:
 
         Arbitrary ``replanning_schedule`` callables see host state per step and stay with the single-episode wrapper; the
         device schedule is ``t % replanning_every == 0``.
+
+        ``verbose`` (black_box_wrapper.py:21,160,184,208-213): 2 (the default HERE: this class has always returned everything)
+        ``step`` returns the plans, step actions and step rewards [B, T, .] like ``infos`` of a verbose = 2 wrapper; < 2 (the
+        reference's default is 1) it returns what ``BlackBoxWrapper.step`` returns then -- the aggregated reward, the flags,
+        ``trajectory_length`` and the plant state -- and with a device plant the whole step is ONE launch that stores nothing per
+        step (mpk_episode_return): plan, controller, plant, reward and aggregation on the CU.  Same state, same aggregated rewards
+        bit for bit (both paths add in the same order: mpk.h).  Falls back to the verbose = 2 launches (and drops their arrays)
+        where the fused kernel does not apply: validity gate, sub-trajectories, per-episode phase, drifted episodes.
         """
+        self.verbose = int(verbose)
+        self._lean_ok = True
         self.traj_gen = trajectory_generator
         self.tracking_controller = tracking_controller
         self.B, self.dt, self.duration = int(num_envs), float(dt), float(duration)
@@ -268,6 +278,43 @@ class BatchedBlackBox:
                     trajectory_length=seg, done=done, terminated=never, truncated=done, current_pos=self.q,
                     current_vel=self.qd)
 
+    def _can_episode_return(self) -> bool:
+        return (self.verbose < 2 and self._lean_ok and self.spec is not None and self.plant == "double_integrator"
+                and self.pos_limits is None and not self.learn_sub_trajectories and self._n_phase == 0
+                and (not self.do_replanning or self._lockstep is not None))
+
+    def _step_lean(self, params) -> Optional[Dict[str, torch.Tensor]]:
+        """the verbose < 2 step as ONE launch without per-step outputs (mpk_episode_return); None = not available here"""
+        params = self._plan_params(params)
+        first = self._start32 is not None and self._plans_since_reset == 1
+        cond_pos = self.condition_pos if self.condition_pos is not None else (self._start32[0] if first else self.q.float())
+        cond_vel = self.condition_vel if self.condition_vel is not None else (self._start32[1] if first else self.qd.float())
+        init_time = float(self._lockstep * self.dt) if self.do_replanning else 0.0
+        mpt = self.max_planning_times if math.isfinite(self.max_planning_times) else 2 ** 31 - 1
+        try:
+            r = self.engine.episode_return(params, cond_pos, cond_vel, self.spec, self.q, self.qd,
+                                           replan=(self.traj_steps, self.plan_steps, self.done, self.every, int(mpt), self.horizon),
+                                           reward=self.reward, goal=self.goal, steps_before_reward=self.steps_before_reward,
+                                           aggregation=self.reward_aggregation, init_time=init_time,
+                                           condition=self.condition_on_desired)
+        except NotImplementedError:
+            self._lean_ok = False
+            return None
+        if self.condition_on_desired:
+            self.condition_pos, self.condition_vel = r["cond_pos"], r["cond_vel"]
+        if self.do_replanning:
+            self._lockstep += self._host_segment()
+        done = r["done"].view(torch.bool)
+        if self._const_flags is None:
+            self._const_flags = (torch.ones(self.B, dtype=torch.bool, device=self.device),
+                                 torch.zeros(self.B, dtype=torch.bool, device=self.device))
+        valid, never = self._const_flags
+        out = dict(params=params, valid=valid, trajectory_length=r["seg_len"], done=done, terminated=never, truncated=done,
+                   current_pos=self.q, current_vel=self.qd)
+        if self.reward is not None:
+            out["rewards"] = r["ret"]
+        return out
+
     def _finish(self, out, seg, valid, was_done) -> Dict[str, torch.Tensor]:
         pos, vel = out["des_pos"], out["des_vel"]
         out.update(valid=valid, trajectory_length=seg, done=self.done.bool(), terminated=~valid & ~was_done,
@@ -292,8 +339,21 @@ class BatchedBlackBox:
         out.update(current_pos=self.q, current_vel=self.qd)
         return out
 
+    _PER_STEP = ("des_pos", "des_vel", "step_actions", "step_rewards")
+
     def step(self, params, fuse: bool = True) -> Dict[str, torch.Tensor]:
         self._plans_since_reset += 1
+        if fuse and self._can_episode_return():
+            out = self._step_lean(params)
+            if out is not None:
+                return out
+        out = self._step_full(params, fuse)
+        if self.verbose < 2:        # (the launches of the verbose = 2 path ran: what it keeps per step is simply not returned)
+            for k in self._PER_STEP:
+                out.pop(k, None)
+        return out
+
+    def _step_full(self, params, fuse: bool = True) -> Dict[str, torch.Tensor]:
         if fuse and self._can_fuse():
             return self._step_fused(params)
         out = self.get_trajectory(params)
@@ -344,13 +404,8 @@ class BatchedBlackBox:
     def _aggregate(self, rew: torch.Tensor, seg: torch.Tensor) -> torch.Tensor:
         """reward_aggregation(rewards[:t + 1]) of black_box_wrapper.py:216 for every episode: sum / mean / last over its
         executed steps (step_rewards are zero behind them); an episode that executed nothing gets 0"""
-        if self.reward_aggregation == "sum":
-            return rew.sum(dim=1)
-        n = seg.to(torch.int64)
-        if self.reward_aggregation == "mean":
-            return torch.where(n > 0, rew.sum(dim=1) / n.clamp(min=1).to(rew.dtype), torch.zeros_like(rew[:, 0]))
-        last = rew.gather(1, (n - 1).clamp(min=0)[:, None])[:, 0]
-        return torch.where(n > 0, last, torch.zeros_like(last))
+        # one launch, in the order of additions of the verbose < 2 kernel (mpk_reward_aggregate): the two paths agree bit for bit
+        return self.engine.reward_aggregate(rew, seg, self.reward_aggregation)
 
     # ---- whole episodes as one hipGraph ----------------------------------------------------------------------------------
     def capture_episode(self, n_plans: int, with_goal: bool = False) -> "EpisodeGraph":

@@ -730,7 +730,7 @@ const OptKey kOptKeys[] = {
     {"phase_flat", &Tuning::phase_flat, 0, 1},   {"ring", &Tuning::ring, 0, 2},
     {"ring_np", &Tuning::ring_np, 1, 14},        {"ring_ns", &Tuning::ring_ns, 1, 8},
     {"ring_m", &Tuning::ring_m, 1, 8},           {"ring_dbg", &Tuning::ring_dbg, 0, 255},
-    {"ring_parts", &Tuning::ring_parts, 1, 8},   {"tiles_wpb", &Tuning::tiles_wpb, 1, 4},
+    {"ring_parts", &Tuning::ring_parts, 1, 8},   {"tiles_wpb", &Tuning::tiles_wpb, 1, 8},
     {"serial_order", &Tuning::serial_order, 0, 2}, {"ring_nc", &Tuning::ring_nc, 1, 6},
     {"pd_generic", &Tuning::pd_generic, 0, 1},   {"dmp_response", &Tuning::dmp_response, 0, 1},
     {"ablations", &Tuning::ablations, 0, 1},
@@ -1022,6 +1022,74 @@ int mpk_replan_step(mpk_handle hh, const float* params, const float* init_pos, c
     if (r != MPK_OK) return r;
     if (rp.cond_pos) return launch_condition_gather(pos, vel, rp.seg_len, rp.cond_pos, rp.cond_vel, B, h->dev.T, h->dev.D, stream);
     return MPK_OK;
+}
+
+int mpk_episode_return(mpk_handle hh, const float* params, const float* init_pos, const float* init_vel,
+                       double init_time_shared, const mpk_rollout_cfg* rc, double* q, double* qd, const mpk_replan_state* st,
+                       const int32_t* n_steps, int32_t* seg_out, int32_t reward, const double* goal, const int32_t* step0,
+                       int32_t steps_before_reward, int32_t agg, double* ret, int32_t B, void* stream) {
+    if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (B < 0) { set_error("B must be >= 0"); return MPK_EINVAL; }
+    if (B == 0 || h->dev.D == 0) return MPK_OK;
+    if (!params || !init_pos || !init_vel || !q || !qd || !ret) { set_error("NULL buffer"); return MPK_EINVAL; }
+    if (reward != MPK_REWARD_NONE && reward != MPK_REWARD_SIMPLE_REACHER) { set_error("unknown reward"); return MPK_EINVAL; }
+    if (agg < MPK_AGG_SUM || agg > MPK_AGG_LAST) { set_error("unknown reward aggregation"); return MPK_EINVAL; }
+    if (reward == MPK_REWARD_SIMPLE_REACHER && !goal) { set_error("the reacher reward needs goal [B, 2]"); return MPK_EINVAL; }
+    ReplanDev rp;
+    if (st) {
+        if (!st->traj_steps || !st->plan_steps || !st->done || !st->seg_len) { set_error("NULL replanning state"); return MPK_EINVAL; }
+        if ((st->cond_pos == nullptr) != (st->cond_vel == nullptr)) { set_error("cond_pos and cond_vel go together"); return MPK_EINVAL; }
+        if (st->every < 1 || st->horizon < 1) { set_error("every and horizon must be >= 1"); return MPK_EINVAL; }
+        if (st->cond_pos && (st->cond_pos == init_pos || st->cond_vel == init_vel)) { set_error("cond_pos / cond_vel must not alias init_pos / init_vel"); return MPK_EINVAL; }
+        rp.traj_steps = st->traj_steps; rp.plan_steps = st->plan_steps; rp.done = st->done; rp.seg_len = st->seg_len;
+        rp.done_out = st->done_out; rp.cond_pos = st->cond_pos; rp.cond_vel = st->cond_vel;
+        rp.every = st->every; rp.max_planning_times = st->max_planning_times; rp.horizon = st->horizon;
+    }
+    RolloutDev rd;
+    int r = fill_rollout(h, rc, &rd);
+    if (r != MPK_OK) return r;
+    if (rd.plant_type != MPK_PLANT_DOUBLE_INTEGRATOR) { set_error("mpk_episode_return integrates MPK_PLANT_DOUBLE_INTEGRATOR"); return MPK_EINVAL; }
+    MPK_ON_DEVICE(h->cfg.device);
+    {
+        const int fr = pending_ring_fault(h);
+        if (fr != MPK_OK) return fr;
+    }
+    if (!fused_capable(h)) { set_error("mpk_episode_return needs a shared phase with <= 16 contraction columns and DoF"); return MPK_ENOTIMPL; }
+    const Tuning tune = effective_tuning(h);
+    if (h->cfg.mp_type == MPK_MP_DMP && h->cfg.dmp_first_sample == MPK_DMP_FIRST_IS_STEP) {
+        set_error("mpk_episode_return: MPK_DMP_FIRST_IS_STEP handles take the separate launches");
+        return MPK_ENOTIMPL;
+    }
+    const bool resp = h->cfg.mp_type == MPK_MP_DMP;
+    SharedTables stt;
+    r = get_shared(h, (float)init_time_shared, stream, &stt, resp);
+    if (r != MPK_OK) return r;
+    const char* name = "";
+    r = launch_episode_return(resp ? h->dev_resp : h->dev, stt, params, init_pos, init_vel, rd, q, qd, st ? nullptr : n_steps,
+                              st ? &rp : nullptr, reward, goal, step0, steps_before_reward, agg, ret, seg_out, B, h->num_cu, stream,
+                              &name, tune);
+    if (r == MPK_OK) {
+        h->kernel_name_buf = name;
+        if (resp) {
+            const size_t at = h->kernel_name_buf.find("prodmp");
+            if (at != std::string::npos) h->kernel_name_buf.replace(at, 6, "dmp_resp");
+        }
+        h->last_kernel = h->kernel_name_buf.c_str();
+    }
+    return r;
+}
+
+int mpk_reward_aggregate(mpk_handle hh, const double* rewards, const int32_t* seg_len, int32_t agg, double* out, int32_t B,
+                         int32_t T, void* stream) {
+    if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (B < 0 || T < 0) { set_error("B and T must be >= 0"); return MPK_EINVAL; }
+    if (agg < MPK_AGG_SUM || agg > MPK_AGG_LAST) { set_error("unknown reward aggregation"); return MPK_EINVAL; }
+    if (B == 0) return MPK_OK;
+    if (!rewards || !seg_len || !out) { set_error("NULL buffer"); return MPK_EINVAL; }
+    MPK_ON_DEVICE(h->cfg.device);
+    return launch_reward_aggregate(rewards, seg_len, agg, out, B, T, stream);
 }
 
 int mpk_pd_rollout(mpk_handle hh, const mpk_rollout_cfg* rc, const float* des_pos, const float* des_vel, double* q,

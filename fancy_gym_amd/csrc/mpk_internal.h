@@ -99,6 +99,11 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
                        const double* c_pos, const double* c_vel, double* q_state, double* qd_state,
                        const int32_t* n_steps, int B, int num_cu, void* stream, const char** kernel_name,
                        const Tuning& tune, const ReplanDev* rp = nullptr, unsigned* ticket = nullptr, int* fault = nullptr);
+int launch_episode_return(const DevCfg& c, const SharedTables& st, const float* params, const float* init_pos, const float* init_vel,
+                          const RolloutDev& rc, double* q_state, double* qd_state, const int32_t* n_steps, const ReplanDev* rp,
+                          int reward_type, const double* goal, const int32_t* step0, int steps_before_reward, int agg, double* ret,
+                          int32_t* seg_out, int B, int num_cu, void* stream, const char** kernel_name, const Tuning& tune);
+int launch_reward_aggregate(const double* rewards, const int32_t* seg_len, int agg, double* out, int B, int T, void* stream);
 // shared phase, more than kMaxKP contraction columns: k-chunked GEMM on the matrix cores (trajectory only)
 int launch_traj_wide(const DevCfg& c, const SharedTables& st, const float* params, const float* init_pos,
                      const float* init_vel, float* pos, float* vel, int B, int num_cu, void* stream,

@@ -6,6 +6,8 @@
 //   mpk_traj_{tiles,stream,flat,quad,pipe}.h   one shared-phase trajectory kernel family each
 //   mpk_traj_family.hip  the families' template launcher, one unit per MP type (-DMPK_MP_UNIT=0..2)
 //   mpk_traj_ring.h / .hip   k_traj_ring / k_traj_burst + their launcher, one unit per MP type
+//   mpk_episode.hip      k_episode_return (verbose < 2 step: nothing per step stored), one unit per MP type
+//   mpk_reward.h         SimpleReacher reward on float64 LDS images (rollout + episode kernels)
 //   mpk_traj_launch.hip  k_build_shared + launch_traj_shared (kernel selection rule)
 //   mpk_traj_wide.hip    k_traj_wide
 //   mpk_traj_phase.hip   per-episode phase kernels
@@ -14,6 +16,7 @@
 #define MPK_AMALGAMATED 1
 #include "mpk_traj_family.hip"
 #include "mpk_traj_ring.hip"
+#include "mpk_episode.hip"
 #include "mpk_traj_launch.hip"
 #include "mpk_traj_wide.hip"
 #include "mpk_traj_phase.hip"

@@ -202,6 +202,41 @@ int launch_div_sweep(float d, uint32_t first, uint64_t count, unsigned long long
 }
 #endif  // MPK_DEVICE_ONLY
 
+// ------------------------------------------------------------------------------------------------------------
+// k_reward_aggregate: reward_aggregation(rewards[:t + 1]) of black_box_wrapper.py:216 for the verbose = 2 path, in the order of
+// k_episode_return (mpk_episode.hip) -- per step slot t mod 16 the sum over the row tiles in time order, then the sixteen slots
+// left to right -- so that the two paths agree bit for bit.  16 lanes per episode.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_reward_aggregate(const double* __restrict__ rewards, const int32_t* __restrict__ seg_len,
+                                                          const int agg, double* __restrict__ out, const int B, const int T) {
+    const long e = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int tl = threadIdx.x & 15, lane = threadIdx.x & 63, base = lane & 48;
+    const bool on = e < B;
+    const int n = on ? min(seg_len[on ? e : 0], T) : 0;
+    double acc = 0.0;
+    if (on) {
+        const double* r = rewards + (size_t)e * T;
+        for (int t = tl; t < T; t += 16) {
+            const double v = t < n ? r[t] : 0.0;
+            if (agg == 2) acc = t == n - 1 ? v : acc;
+            else acc = acc + v;
+        }
+    }
+    double sum = __shfl(acc, base);
+#pragma unroll
+    for (int i = 1; i < 16; ++i) sum = sum + __shfl(acc, base + i);
+    if (on && tl == 0) out[e] = agg == 1 ? (n > 0 ? sum / (double)n : 0.0) : sum;
+}
+
+#ifndef MPK_DEVICE_ONLY
+int launch_reward_aggregate(const double* rewards, const int32_t* seg_len, int agg, double* out, int B, int T, void* stream) {
+    hipLaunchKernelGGL(k_reward_aggregate, dim3((unsigned)((B + 15) / 16)), dim3(256), 0, (hipStream_t)stream, rewards, seg_len, agg,
+                       out, B, T);
+    MPK_LAUNCH_CHECK();
+    return MPK_OK;
+}
+#endif  // MPK_DEVICE_ONLY
+
 }  // namespace mpk
 
 #ifdef MPK_TRACE

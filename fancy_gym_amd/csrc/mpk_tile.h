@@ -82,6 +82,25 @@ struct ActArgs {
 constexpr int kStageStride = 256;   // floats between output arrays in the wave's LDS staging area (>= NTW*16*D)
 constexpr int kStageFloats = 4 * kStageStride;   // pos | vel | actions or DMP forcing | controller constants
 
+// ---- k_episode_return (mpk_episode.hip): third kernel argument and LDS geometry --------------------------------------------------
+struct EpArgs {
+    double* ret;               // [B] out: aggregated reward of this plan's executed steps (0 without a reward)
+    const double* goal;        // [B, 2] SimpleReacher goal (reward = 1)
+    const int32_t* step0;      // [B] environment step counter at the plan's first step when there is no replanning state (else: traj_steps)
+    int32_t* seg_out;          // [B] out, optional: executed steps (with a replanning state seg_len carries them already)
+    int steps_before_reward;
+    int agg;                   // 0 sum, 1 mean, 2 last
+    int km;                    // contraction columns / 4 (the kernel is compiled for up to 16 columns; MFMAs beyond km are skipped)
+    int wpb;                   // waves per workgroup (4 or 8): host side only
+};
+
+constexpr int kEpImg = 4 * kStageStride + 8;     // floats per group: desired pos | vel (reused as the float64 position image) | float64 actions
+constexpr int kEpImgPlain = 2 * kStageStride + 8;   // ... without a reward: desired pos | vel
+constexpr int kEpSlots = 8;                      // episode slots per wave with a reward (NQ * NTW <= 8)
+constexpr int kEpMaxPass = 2;                    // reward passes per tile: up to 8 episodes per unit (the launcher keeps NQ * NTW <= 8 with a reward)
+constexpr int kEpSlotInts = 8;                   // per episode slot: executed steps, step offset, episode (or -1), pad, goal x, goal y (float64)
+
+
 enum : int { XK_ZERO = 0, XK_PARAM = 1, XK_IPOS = 2, XK_IVEL = 3, XK_ONE = 4 };
 
 // which raw input feeds element k of a DoF's extended parameter column, and its offset inside the DoF's local block
@@ -252,7 +271,7 @@ __device__ __forceinline__ Gains kernarg_gains(int d) {
 // of the same wave adds 2 - 4; left alone the compiler sinks each step's LDS read next to its use (`s_waitcnt lgkmcnt(1)` in front
 // of every step: ~40 cycles of LDS latency exposed per step).  PRE = 1: all 32 reads issued, ONE wait, all conversions, then the
 // chain with nothing but its own operations, the action conversion and the LDS write in between.
-template <int CTRL, bool MASKED, bool INTEGRATE = true, int KEEP64 = 0, int PRE = 0>
+template <int CTRL, bool MASKED, bool INTEGRATE = true, int KEEP64 = 0, int PRE = 0, bool WRITE_A = true>
 __device__ __forceinline__ void pd_tile_steps(const float* __restrict__ sP, const float* __restrict__ sV,
                                               float* __restrict__ sA, const int stride, const int t0, const int nst,
                                               const double pgd, const double dgd, const double lod, const double hid,
@@ -305,15 +324,16 @@ __device__ __forceinline__ void pd_tile_steps(const float* __restrict__ sP, cons
         u = fmin(fmax(u, lod), hid);
         const double qds_n = INTEGRATE ? qds + dtp * u : qds;
         const double qs_n = INTEGRATE ? qs + dtp * qds_n : qs;
+        // (WRITE_A = false: no float32 action image -- the episode-return kernel stores no actions)
         if (MASKED) {
             const bool live = t0 + tl < nst;
             qds = live ? qds_n : qds;
             qs = live ? qs_n : qs;
             u = live ? u : 0.0;
-            sA[tl * stride] = (float)u;
+            if (WRITE_A) sA[tl * stride] = (float)u;
         } else {
             qds = qds_n; qs = qs_n;
-            sA[tl * stride] = (float)u;
+            if (WRITE_A) sA[tl * stride] = (float)u;
         }
         // (column-major images: [column][step] -- the reward pass reads 16 consecutive steps of one column with 16 neighbouring
         // lanes; step-major, those reads were 128 bytes apart: one LDS bank pair for all of them.  The writes here are the ones 128
@@ -324,7 +344,7 @@ __device__ __forceinline__ void pd_tile_steps(const float* __restrict__ sP, cons
     if (MASKED) {
 #pragma unroll 1
         for (int tl = nlive; tl < rows; ++tl) {
-            sA[tl * stride] = 0.0f;
+            if (WRITE_A) sA[tl * stride] = 0.0f;
             if (KEEP64 == 1) q64[tl] = qs;
             if (KEEP64) u64[tl] = 0.0;
         }

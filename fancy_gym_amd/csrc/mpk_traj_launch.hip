@@ -177,6 +177,75 @@ extern template int launch_traj_ring<MPK_MP_PRODMP>(const TrajArgs&, const ActAr
 #endif
 
 #ifndef MPK_DEVICE_ONLY
+#ifndef MPK_AMALGAMATED
+// defined in mpk_episode.hip (one translation unit per MP type)
+template <int MP>
+int launch_episode_kernel(const TrajArgs& ta, const ActArgs& aa, const EpArgs& ea, int ct, int nq, int rwd, int blocks, size_t lds,
+                          void* stream);
+extern template int launch_episode_kernel<MPK_MP_PROMP>(const TrajArgs&, const ActArgs&, const EpArgs&, int, int, int, int, size_t, void*);
+extern template int launch_episode_kernel<MPK_MP_DMP>(const TrajArgs&, const ActArgs&, const EpArgs&, int, int, int, int, size_t, void*);
+extern template int launch_episode_kernel<MPK_MP_PRODMP>(const TrajArgs&, const ActArgs&, const EpArgs&, int, int, int, int, size_t, void*);
+#endif
+
+// mpk_episode_return: plan + controller + plant + reward + aggregation of a `verbose < 2` step in one launch (k_episode_return).
+// MPK_ENOTIMPL where the tables do not fit beside the images (long horizons): the caller's separate launches take those.
+int launch_episode_return(const DevCfg& c, const SharedTables& st, const float* params, const float* init_pos, const float* init_vel,
+                          const RolloutDev& rc, double* q_state, double* qd_state, const int32_t* n_steps, const ReplanDev* rp,
+                          int reward_type, const double* goal, const int32_t* step0, int steps_before_reward, int agg, double* ret,
+                          int32_t* seg_out, int B, int num_cu, void* stream, const char** kernel_name, const Tuning& tune) {
+    TrajArgs ta{};
+    ta.wpb = 4; ta.ring_parts = 1;
+    if (rp) ta.rp = *rp;
+    ta.q_state = q_state; ta.qd_state = qd_state; ta.n_steps = n_steps; ta.plant_dt = rc.dt;
+    ta.c = c; ta.A = st.A; ta.aux = st.aux; ta.TS = st.TS;
+    ta.params = params; ta.init_pos = init_pos; ta.init_vel = init_vel;
+    ta.B = B;
+    int sh = 0;
+    while ((1 << sh) < c.D) ++sh;
+    ta.sh = sh;
+    const int NTW = 16 >> sh;
+    ta.G = (B + NTW - 1) / NTW;
+    const int SEG = 16 * c.D;
+    ta.pitch = SEG; ta.cps = SEG / 4 > 0 ? SEG / 4 : 1; ta.inv_cps = 65536u / (unsigned)ta.cps + 1u; ta.vec_ok = 1;
+    ActArgs aa{};
+    for (int d = 0; d < c.D; ++d) { aa.pg[d] = rc.pg[d]; aa.dg[d] = rc.dg[d]; aa.lo[d] = rc.lo[d]; aa.hi[d] = rc.hi[d]; }
+    EpArgs ea{};
+    ea.ret = ret; ea.goal = goal; ea.step0 = step0; ea.seg_out = seg_out; ea.steps_before_reward = steps_before_reward; ea.agg = agg;
+    ea.km = c.KP / 4;
+    const size_t table_bytes = ((size_t)st.n_out * c.KP * st.TS + st.TS) * sizeof(float);
+    // groups per wave: four while that still gives every SIMD a wave (the chain is latency bound: more lanes per instruction),
+    // else two, else one ("quad" 2 / 3 / 4 force four / two / one)
+    const long simds = (long)num_cu * 4;
+    int nq = ta.G >= 4 * simds ? 4 : (ta.G >= 2 * simds ? 2 : 1);
+    if (tune.quad == 2) nq = 4; else if (tune.quad == 3) nq = 2; else if (tune.quad == 4) nq = 1;
+    while (reward_type && nq > 1 && nq * NTW > 4 * kEpMaxPass) nq >>= 1;      // the reward pass keeps two accumulators per lane
+    const size_t img = reward_type ? kEpImg : kEpImgPlain;
+    auto lds_of = [&](int n, int w) { return table_bytes + ((size_t)w * n * img + (size_t)w * kEpSlots * kEpSlotInts) * sizeof(float); };
+    while (nq > 1 && lds_of(nq, 4) > kLdsPerCu) nq >>= 1;
+    if (lds_of(nq, 4) > kLdsPerCu || (reward_type && nq * NTW > 4 * kEpMaxPass)) { set_error("trajectory too long for the episode kernel's LDS budget"); return MPK_ENOTIMPL; }
+    // eight waves per workgroup where that puts more waves on a CU than four-wave workgroups do (they share one table copy)
+    const long units = ((long)ta.G + nq - 1) / nq;
+    const long w4 = (long)(kLdsPerCu / lds_of(nq, 4)) * 4, w8 = lds_of(nq, 8) <= kLdsPerCu ? (long)(kLdsPerCu / lds_of(nq, 8)) * 8 : 0;
+    int wpb = w8 > w4 && units >= 8L * num_cu ? 8 : 4;
+    if (tune.tiles_wpb == 4 || tune.tiles_wpb == 8) wpb = tune.tiles_wpb == 8 && w8 > 0 ? 8 : 4;     // ("tiles_wpb" 4 / 8: A/B runs, tests)
+    ea.wpb = wpb;
+    const size_t lds = lds_of(nq, wpb);
+    const long per_cu = (long)(kLdsPerCu / lds) < 1 ? 1 : (long)(kLdsPerCu / lds);
+    long blocks = (units + wpb - 1) / wpb;
+    const long cap = (long)num_cu * (per_cu > 8 ? 8 : per_cu);
+    if (blocks > cap) blocks = cap;
+    if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;
+    const int ct = rc.controller_type + 3;
+    const bool pd = c.mp_type == MPK_MP_PRODMP;
+    *kernel_name = reward_type ? (pd ? "k_episode_return<prodmp,reacher>" : "k_episode_return<promp,reacher>")
+                               : (pd ? "k_episode_return<prodmp>" : "k_episode_return<promp>");
+    switch (c.mp_type) {
+        case MPK_MP_PRODMP: return launch_episode_kernel<MPK_MP_PRODMP>(ta, aa, ea, ct, nq, reward_type, (int)blocks, lds, stream);
+        case MPK_MP_PROMP: return launch_episode_kernel<MPK_MP_PROMP>(ta, aa, ea, ct, nq, reward_type, (int)blocks, lds, stream);
+        default: set_error("internal: the episode kernel takes promp / prodmp rows"); return MPK_EINVAL;
+    }
+}
+
 int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* params, const float* init_pos,
                        const float* init_vel, float* pos, float* vel, float* actions, const RolloutDev* rc,
                        const double* c_pos, const double* c_vel, double* q_state, double* qd_state,

@@ -378,6 +378,64 @@ class TrajectoryEngine:
             self._stream()))
         return dict(pos=pos, vel=vel, actions=act, seg_len=seg, done=done_out, cond_pos=cp, cond_vel=cv)
 
+    def episode_return(self, params, init_pos, init_vel, spec: RolloutSpec, q: torch.Tensor, qd: torch.Tensor, *,
+                       replan=None, n_steps: Optional[torch.Tensor] = None, reward: Optional[str] = None,
+                       goal: Optional[torch.Tensor] = None, step0: Optional[torch.Tensor] = None,
+                       steps_before_reward: int = 199, aggregation: str = "sum", init_time: float = 0.0,
+                       condition: bool = False):
+        """
+        One plan of a ``verbose < 2`` step for every episode in ONE launch, nothing per step stored (mpk.h: mpk_episode_return):
+        plan + controller + double-integrator plant + reward + reward_aggregation (+ the integer replanning state and the
+        condition gather when ``replan = (traj_steps, plan_steps, done, every, max_planning_times, horizon)``).  q, qd (and
+        the replanning state) are updated in place.  Returns dict(ret float64 [B], seg_len int32 [B], done uint8 [B] or None,
+        cond_pos, cond_vel (or None)).  NotImplementedError where the fused kernel does not apply (per-episode phase, > 16
+        columns / DoF, very long horizons): use replan_step / trajectory_rollout + reacher_rollout + reward_aggregate.
+        """
+        self._refuse_metaworld(spec, "episode_return")
+        params = torch.as_tensor(params, dtype=torch.float32, device=self.device)
+        if params.dim() == 1:
+            params = params[None]
+        params = params.contiguous()
+        B, D = params.shape[0], self.num_dof
+        init_pos, init_vel = self._f32(init_pos, (B, D)), self._f32(init_vel, (B, D))
+        assert q.dtype == torch.float64 and qd.dtype == torch.float64 and q.is_contiguous() and qd.is_contiguous()
+        ret = torch.empty(B, dtype=torch.float64, device=self.device)
+        seg = torch.empty(B, dtype=torch.int32, device=self.device)
+        done_out = cp = cv = None
+        st = None
+        if replan is not None:
+            traj_steps, plan_steps, done, every, max_planning_times, horizon = replan
+            assert traj_steps.dtype == torch.int32 and plan_steps.dtype == torch.int32 and done.dtype == torch.uint8
+            done_out = torch.empty(B, dtype=torch.uint8, device=self.device)
+            if condition:
+                cp, cv = (torch.empty((B, D), dtype=torch.float32, device=self.device) for _ in range(2))
+            st = _lib.mpk_replan_state(traj_steps.data_ptr(), plan_steps.data_ptr(), done.data_ptr(), seg.data_ptr(),
+                                       done_out.data_ptr(), _dptr(cp), _dptr(cv), int(every),
+                                       int(min(max_planning_times, 2 ** 31 - 1)), int(horizon), 0)
+        elif n_steps is not None:
+            n_steps = n_steps.to(device=self.device, dtype=torch.int32).contiguous()
+        if goal is not None:
+            goal = torch.as_tensor(goal, dtype=torch.float64, device=self.device).expand(B, 2).contiguous()
+        if step0 is not None:
+            step0 = step0.to(device=self.device, dtype=torch.int32).contiguous()
+        _lib.check(self._lib.mpk_episode_return(
+            self._h, params.data_ptr(), init_pos.data_ptr(), init_vel.data_ptr(), float(init_time), C.byref(spec.c),
+            q.data_ptr(), qd.data_ptr(), C.byref(st) if st is not None else None, _dptr(n_steps), seg.data_ptr(),
+            _lib.REWARD_TYPES[reward], _dptr(goal), _dptr(step0), int(steps_before_reward), _lib.AGG_MODES[aggregation],
+            ret.data_ptr(), B, self._stream()))
+        return dict(ret=ret, seg_len=seg, done=done_out, cond_pos=cp, cond_vel=cv)
+
+    def reward_aggregate(self, rewards: torch.Tensor, seg_len: torch.Tensor, aggregation: str = "sum") -> torch.Tensor:
+        """reward_aggregation over each episode's executed steps (black_box_wrapper.py:216) of step rewards [B, T] float64, in the
+        order of additions of episode_return (mpk.h: mpk_reward_aggregate): the two paths agree bit for bit"""
+        B, T = rewards.shape
+        assert rewards.dtype == torch.float64 and rewards.is_contiguous()
+        seg_len = seg_len.to(device=self.device, dtype=torch.int32).contiguous()
+        out = torch.empty(B, dtype=torch.float64, device=self.device)
+        _lib.check(self._lib.mpk_reward_aggregate(self._h, rewards.data_ptr(), seg_len.data_ptr(), _lib.AGG_MODES[aggregation],
+                                                  out.data_ptr(), B, T, self._stream()))
+        return out
+
     def pd_rollout(self, spec: RolloutSpec, des_pos: torch.Tensor, des_vel: torch.Tensor, q: torch.Tensor,
                    qd: torch.Tensor, n_steps: Optional[torch.Tensor] = None, want_actions: bool = True,
                    out: Optional[torch.Tensor] = None):

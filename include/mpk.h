@@ -218,7 +218,8 @@ int mpk_set_duration(mpk_handle h, double duration, double dt);
  *                   promp / prodmp launches whose outputs stream to HBM)
  *   "split"         1 force the tile-major closed-loop kernel with a serial role (k_traj_split; never chosen automatically)
  *   "lds_pad"       n KB of unused dynamic LDS per workgroup of the tile-major kernels (occupancy experiments: 160 KB per CU)
- *   "tiles_wpb"     1 .. 4 waves per workgroup of the tile-major kernels (4)
+ *   "tiles_wpb"     1 .. 4 waves per workgroup of the tile-major kernels (4); 4 / 8: waves per workgroup of k_episode_return (by its
+ *                   LDS: eight where that puts more waves on a CU)
  *   "serial_order"  k_traj_quad / duo / mono: 0 persistent workgroups, XCD-contiguous unit ranges; 1 short-lived workgroups in
  *                   address order (one unit per wave); 2 persistent, units b, b + grid, ... without the XCD remap
  *   "ring"          0 off, 1 force the persistent producer / store-engine kernel (k_traj_ring: open-loop promp / prodmp with a
@@ -363,6 +364,47 @@ int mpk_replan_step(mpk_handle h, const float* params, const float* init_pos, co
 int mpk_pd_rollout(mpk_handle h, const mpk_rollout_cfg* rc, const float* des_pos, const float* des_vel,
                    double* q, double* qd, const int32_t* n_steps, float* actions,
                    int32_t B, int32_t T, void* stream);
+
+/*
+ * ONE plan of a `verbose < 2` episode in one launch, nothing per step written to memory (round 5).  BlackBoxWrapper.step returns
+ * trajectories, step actions and step rewards only when verbose >= 2 (black_box_wrapper.py:160,184,208-213); at the default a
+ * step is (obs, reward_aggregation(rewards[:t + 1]), terminated, truncated, {trajectory_length, ...}) (:215-217).  With a plant that
+ * lives on the GPU this entry point is that step for B episodes: plan (get_trajectory, :96-120) + controller + clip + plant
+ * (:175-181) + reward + reward_aggregation (:216) + the integer replanning state and the condition gather of mpk_replan_step --
+ * what mpk_replan_step / mpk_trajectory_rollout (+ mpk_reacher_rollout) compute, without pos / vel / actions [B, T, D] and step
+ * rewards [B, T] ever leaving the CU: 224 bytes in, ~130 bytes out per episode at cfg2's shape.
+ *   params, init_pos, init_vel, init_time_shared, rc, q, qd   as mpk_trajectory_rollout (rc->plant_type MPK_PLANT_DOUBLE_INTEGRATOR)
+ *   st        replanning state as mpk_replan_step (seg_len[b] = executed steps = trajectory_length), or NULL: then
+ *   n_steps   dev int32 [B] or NULL (= T): executed steps per episode, and seg_out (dev int32 [B] or NULL) echoes them
+ *   reward    MPK_REWARD_NONE (ret = 0) or MPK_REWARD_SIMPLE_REACHER (mpk_reacher_rollout's reward: goal dev double [B, 2];
+ *             step0 dev int32 [B] or NULL = the env step counter at the plan's first step when st is NULL -- with st it is
+ *             traj_steps before the plan --; steps_before_reward)
+ *   agg       MPK_AGG_SUM / MPK_AGG_MEAN / MPK_AGG_LAST over the executed steps (np.sum / np.mean / last: black_box_wrapper.py:24)
+ *   ret       dev double [B] out: the aggregated reward
+ * Plant state, replanning state and cond_pos / cond_vel come out bit for bit as from mpk_replan_step; ret equals
+ * mpk_reward_aggregate of mpk_reacher_rollout's step rewards bit for bit (same order of additions: per step slot t mod 16 over the
+ * row tiles in time order, then the sixteen slots left to right; np.sum adds pairwise -- equal to a few ulp).
+ * Shared phase, <= 16 contraction columns and DoF (promp, prodmp, dmp on its response route); MPK_ENOTIMPL otherwise (the caller's
+ * separate launches then).
+ */
+#define MPK_REWARD_NONE 0
+#define MPK_REWARD_SIMPLE_REACHER 1
+#define MPK_AGG_SUM 0
+#define MPK_AGG_MEAN 1
+#define MPK_AGG_LAST 2
+int mpk_episode_return(mpk_handle h, const float* params, const float* init_pos, const float* init_vel,
+                       double init_time_shared, const mpk_rollout_cfg* rc, double* q, double* qd,
+                       const mpk_replan_state* st, const int32_t* n_steps, int32_t* seg_out, int32_t reward,
+                       const double* goal, const int32_t* step0, int32_t steps_before_reward, int32_t agg, double* ret,
+                       int32_t B, void* stream);
+
+/*
+ * reward_aggregation(rewards[:t + 1]) (black_box_wrapper.py:216) of step rewards that DO exist (the verbose = 2 path:
+ * mpk_reacher_rollout), in mpk_episode_return's order of additions: rewards dev double [B, T], seg_len dev int32 [B] executed
+ * steps, agg as above, out dev double [B].
+ */
+int mpk_reward_aggregate(mpk_handle h, const double* rewards, const int32_t* seg_len, int32_t agg, double* out, int32_t B,
+                         int32_t T, void* stream);
 
 /*
  * mpk_pd_rollout for the reference's SimpleReacher family, reward included: the step loop of BlackBoxWrapper.step

@@ -1748,3 +1748,118 @@ def test_metaworld_controller_for_a_frozen_state_runs_on_the_motor_kernels(D, B)
     assert torch.equal(act2, act) and np.array_equal(q.cpu().numpy(), c_pos)      # the caller's state is untouched
     with pytest.raises(ValueError, match="no device plant"):
         RolloutSpec("metaworld", D, plant="double_integrator", dt=0.02)
+
+
+# ---- the verbose < 2 step: ONE launch, nothing per step stored (mpk_episode_return, round 5) ---------------------------------------
+def _reacher_bb(mp_type, B, **kw):
+    """BatchedBlackBox on the generators of fancy_<MP>/LongSimpleReacher-v0 (5 links, 200 steps) with the device reward"""
+    from fancy_gym_amd import _gym
+    env = _gym.make(f"fancy_{mp_type}/LongSimpleReacher-v0")
+    return BatchedBlackBox(env.traj_gen, env.tracking_controller, B, dt=0.01, duration=2.0, act_low=-1000.0, act_high=1000.0,
+                           plant="double_integrator", reward="simple_reacher", **kw), env
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mp_type", ["ProMP", "ProDMP", "DMP"])
+@pytest.mark.parametrize("agg", ["sum", "mean", "last"])
+@pytest.mark.parametrize("B,quad", [(5, -1), (300, 2), (300, 3), (2100, 4), (9000, -1)])
+def test_verbose_1_step_is_one_launch_with_the_same_returns_and_state(mp_type, agg, B, quad, mpk_option):
+    """black_box_wrapper.py:215-217 at verbose < 2: (aggregated reward, flags, trajectory_length) -- BatchedBlackBox(verbose=1) is
+    mpk_episode_return: plan + controller + plant + SimpleReacher reward + aggregation in one launch that stores nothing per step.
+    Against the verbose = 2 path (trajectory kernel + reward rollout + mpk_reward_aggregate): plant state, counters and the
+    aggregated rewards BIT FOR BIT; the returns against the oracle's step rewards (np.sum / np.mean / last) to 1e-12."""
+    mpk_option("quad", quad)
+    mpk_option("tiles_wpb", 8 if B in (300, 2100) and quad != 3 else -1)       # eight-wave workgroups (automatic by the LDS they leave)
+    lean, env = _reacher_bb(mp_type, B, reward_aggregation=agg, verbose=1)
+    full, _ = _reacher_bb(mp_type, B, reward_aggregation=agg, verbose=2)
+    rng = np.random.default_rng(B)
+    q0, goal = rng.uniform(-0.5, 0.5, (B, 5)), rng.uniform(-3, 3, (B, 2))
+    P = lean.engine.num_params
+    params = (rng.standard_normal((B, P)) * 0.3).astype(np.float32)
+    lean.reset(q0, goal=goal); full.reset(q0, goal=goal)
+    a = lean.step(params)
+    assert lean.engine.last_kernel().startswith("k_episode_return<") and "reacher" in lean.engine.last_kernel(), lean.engine.last_kernel()
+    mpk_option("quad", -1); mpk_option("tiles_wpb", -1)
+    b = full.step(params)
+    assert not any(k in a for k in ("des_pos", "des_vel", "step_actions", "step_rewards")) and "step_rewards" in b
+    for k in ("rewards", "trajectory_length", "done", "truncated", "terminated", "current_pos", "current_vel"):
+        assert torch.equal(a[k], b[k]), (k, (a[k].double() - b[k].double()).abs().max())
+    assert torch.equal(lean.traj_steps, full.traj_steps) and torch.equal(lean.plan_steps, full.plan_steps)
+    # ... and the oracle: the reference's reward on the executed plan, aggregated by numpy
+    n = min(B, 40)
+    dp, dv = b["des_pos"][:n].cpu().numpy(), b["des_vel"][:n].cpu().numpy()
+    pg, dg = env.tracking_controller.p_gains, env.tracking_controller.d_gains
+    _, rr, rq, _ = O.reacher_rollout(dp, dv, "motor", pg, dg, -1000.0, 1000.0, 0.01, q0[:n], np.zeros((n, 5)), goal[:n])
+    want = {"sum": rr.sum(axis=1), "mean": rr.mean(axis=1), "last": rr[:, -1]}[agg]
+    got = a["rewards"][:n].cpu().numpy()
+    assert np.all(np.abs(got - want) <= 1e-12 * (1.0 + np.abs(want))), np.abs(got - want).max()
+    assert np.array_equal(a["current_pos"][:n].cpu().numpy(), rq)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [CFG2, CFG4, CFG3], ids=["cfg2", "cfg4_replan", "cfg3_dmp_response"])
+@pytest.mark.parametrize("B", [9, 4096])
+def test_verbose_1_episode_with_replanning_equals_the_verbose_2_episode(cfg, B):
+    """four plans of 25 steps (box_pushing/mp_wrapper.py:87-91: t % 25 == 0, max_planning_times 4, condition_on_desired) through
+    mpk_episode_return against mpk_replan_step: integer state, plant state and boundary conditions of every plan bit for bit; without a
+    device reward the step returns no `rewards`"""
+    replan = cfg is not CFG3
+    kw = dict(plant="double_integrator", replanning_every=25 if replan else None, max_planning_times=4 if replan else np.inf,
+              condition_on_desired=replan)
+    lean, full = _batched(cfg, B, verbose=1, **kw), _batched(cfg, B, verbose=2, **kw)
+    rng = np.random.default_rng(B)
+    q0 = rng.uniform(-0.5, 0.5, (B, 7))
+    P = lean.engine.num_params
+    for episode in range(2):
+        lean.reset(q0); full.reset(q0)
+        for k in range(4 if replan else 1):
+            params = (rng.standard_normal((B, P)) * 0.7).astype(np.float32)
+            a, b = lean.step(params), full.step(params)
+            assert lean.engine.last_kernel().startswith("k_episode_return<"), lean.engine.last_kernel()
+            assert "rewards" not in a and "des_pos" not in a and "des_pos" in b
+            for key in ("trajectory_length", "done", "truncated", "current_pos", "current_vel"):
+                assert torch.equal(a[key], b[key]), (episode, k, key)
+            assert torch.equal(lean.traj_steps, full.traj_steps) and torch.equal(lean.plan_steps, full.plan_steps)
+            if replan:
+                assert torch.equal(lean.condition_pos, full.condition_pos) and torch.equal(lean.condition_vel, full.condition_vel)
+        assert bool(a["done"].all())
+
+
+@pytest.mark.gpu
+def test_episode_return_entry_point_without_a_replanning_state():
+    """mpk_episode_return with n_steps / step0 instead of the replanning state, against trajectory_rollout + reacher_rollout +
+    reward_aggregate on the same inputs; seg_out echoes the executed steps; fallbacks raise NotImplementedError"""
+    from fancy_gym_amd import TrajectoryEngine
+    D, T, B = 5, 200, 777
+    eng = TrajectoryEngine(device=0, mp_type="promp", phase_type="linear", basis_type="zero_rbf", num_dof=D, num_basis=5,
+                           num_basis_zero_start=1, dt=0.01, duration=2.0, tau=2.0)
+    rng = np.random.default_rng(3)
+    params = (rng.standard_normal((B, eng.num_params)) * 0.4).astype(np.float32)
+    ip, iv = rng.uniform(-1, 1, (B, D)).astype(np.float32), np.zeros((B, D), np.float32)
+    q0, goal = rng.uniform(-1, 1, (B, D)), rng.uniform(-3, 3, (B, 2))
+    n_steps = torch.tensor(rng.integers(0, T + 1, B).astype(np.int32))
+    step0 = torch.tensor(rng.integers(0, 260, B).astype(np.int32))
+    spec = RolloutSpec("motor", D, 0.6, 0.075, -2.0, 1.5, plant="double_integrator", dt=0.01)
+    for agg in ("sum", "mean", "last"):
+        q, qd = torch.tensor(q0, device="cuda"), torch.zeros((B, D), dtype=torch.float64, device="cuda")
+        r = eng.episode_return(params, ip, iv, spec, q, qd, n_steps=n_steps, reward="simple_reacher", goal=torch.tensor(goal),
+                               step0=step0, steps_before_reward=199, aggregation=agg)
+        assert eng.last_kernel() == "k_episode_return<promp,reacher>"
+        q2, qd2 = torch.tensor(q0, device="cuda"), torch.zeros((B, D), dtype=torch.float64, device="cuda")
+        pos, vel = eng.trajectory(params, ip, iv, 0.0)
+        _, rew = eng.reacher_rollout(spec, pos, vel, q2, qd2, torch.tensor(goal), n_steps=n_steps, step0=step0, want_actions=False)
+        want = eng.reward_aggregate(rew, n_steps, agg)
+        assert torch.equal(r["ret"], want), (agg, (r["ret"] - want).abs().max())
+        assert torch.equal(q, q2) and torch.equal(qd, qd2) and torch.equal(r["seg_len"].cpu(), n_steps)
+        ref = {"sum": rew.sum(1), "mean": torch.where(n_steps.cuda() > 0, rew.sum(1) / n_steps.cuda().clamp(min=1), torch.zeros_like(rew[:, 0])),
+               "last": torch.where(n_steps.cuda() > 0, rew.gather(1, (n_steps.cuda().long() - 1).clamp(min=0)[:, None])[:, 0], torch.zeros_like(rew[:, 0]))}[agg]
+        assert torch.allclose(want, ref, rtol=1e-13, atol=1e-13)
+    # no reward: ret = 0, the state still advances
+    q, qd = torch.tensor(q0, device="cuda"), torch.zeros((B, D), dtype=torch.float64, device="cuda")
+    r = eng.episode_return(params, ip, iv, spec, q, qd, n_steps=n_steps)
+    assert not r["ret"].any() and torch.equal(q, q2)
+    # a learned tau (per-episode phase): not the fused kernel's
+    eng2 = TrajectoryEngine(device=0, mp_type="promp", phase_type="linear", basis_type="rbf", num_dof=D, num_basis=5, dt=0.01,
+                            duration=2.0, tau=2.0, learn_tau=True, tau_bound=(0.5, 2.0))
+    with pytest.raises(NotImplementedError):
+        eng2.episode_return(np.ones((3, eng2.num_params), np.float32), ip[:3], iv[:3], spec, q[:3].clone(), qd[:3].clone())

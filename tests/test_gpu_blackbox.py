@@ -637,6 +637,39 @@ def test_closed_loop_ring_at_the_size_it_is_chosen_for(mpk_option):
         del out, r
     for i, (x, y) in enumerate(zip(res["ring"], res["duo"])):
         assert torch.equal(x, y), i
+    # ... and the ORACLE directly, on a 256-episode sample of what the ring wrote at the size it is chosen for (round 4 compared it
+    # with other kernels only): trajectories to the 1e-5 contract, actions / plant state / integer state exactly
+    rows = np.sort(rng.choice(B, 256, replace=False))
+    ring = [x[torch.tensor(rows, device=x.device)].cpu().numpy() if x.shape[0] == B else x for x in res["ring"]]
+    pos, vel, act, q1, qd1, rpos, rvel, ract, seg, done, cpos, cvel, q2, qd2, ts, ps, dn = ring
+    op, ov = O.get_trajectory(pc, bc, tc, params[rows], dur, dt, 0.25, ip[rows], iv[rows], dtype=np.float64)
+    close(pos, op, "ring closed pos"); close(vel, ov, "ring closed vel")
+    ra, rq, rqd = O.rollout(pos, vel, "motor", PG, DG, -0.9, 0.9, "double_integrator", dt, q0[rows], qd0[rows])
+    assert np.array_equal(act, ra.astype(np.float32)) and np.array_equal(q1, rq) and np.array_equal(qd1, rqd)
+    # the replanning step: the loop of black_box_wrapper.py:174,197,206 for one episode, from an arbitrary integer state
+    want_seg, want_ts, want_ps, want_dn = [], [], [], []
+    for b in rows:
+        cur, plan, d = int(ts0[b]), int(ps0[b]), int(dn0[b])
+        n = 0
+        if not d:
+            plan += 1
+            for t in range(T):
+                n = t + 1
+                g = t + 1 + cur
+                if g >= 2 * T or (g % 25 == 0 and plan < 3):
+                    break
+            cur += n
+            d = int(cur >= 2 * T)
+        want_seg.append(n); want_ts.append(cur); want_ps.append(plan); want_dn.append(d)
+    assert np.array_equal(seg, want_seg) and np.array_equal(ts, want_ts) and np.array_equal(ps, want_ps) and np.array_equal(dn, want_dn)
+    assert np.array_equal(done, want_dn) and 0 < sum(want_dn) < 256 and len(set(want_seg)) > 3
+    op, ov = O.get_trajectory(pc, bc, tc, params[rows], dur, dt, 0.0, ip[rows], iv[rows], dtype=np.float64)
+    close(rpos, op, "ring replan pos"); close(rvel, ov, "ring replan vel")
+    ra, rq, rqd = O.rollout(rpos, rvel, "motor", PG, DG, -0.9, 0.9, "double_integrator", dt, q0[rows], qd0[rows], n_steps=np.array(want_seg))
+    assert np.array_equal(ract, ra.astype(np.float32)) and np.array_equal(q2, rq) and np.array_equal(qd2, rqd)
+    live = np.array(want_seg) > 0
+    last = np.array(want_seg)[live] - 1
+    assert np.array_equal(cpos[live], rpos[live, last]) and np.array_equal(cvel[live], rvel[live, last])
 
 
 def test_closed_loop_ring_declines_shapes_it_does_not_take(mpk_option):

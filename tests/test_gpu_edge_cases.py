@@ -832,7 +832,8 @@ def test_long_horizons_take_the_kernels_that_fit(mp, T):
 
 
 @pytest.mark.parametrize("D,nb,T,B", [(7, 5, 200, 1), (7, 5, 200, 37), (7, 5, 200, 1026), (3, 4, 70, 9), (16, 9, 33, 50), (5, 2, 64, 130),
-                                      (7, 5, 200, 6003), (8, 3, 50, 9001), (5, 5, 100, 7000)])     # (the last three: chunks of eight episodes)
+                                      (7, 5, 200, 6003), (8, 3, 50, 9001), (5, 5, 100, 7000),      # (these three: chunks of eight episodes)
+                                      (7, 5, 200, 4096), (7, 5, 200, 10240)])   # cfg3 + learned tau where the kernel is automatic: chunks of four / eight
 def test_per_episode_dmp_workgroup_and_wave_kernels_agree_bitwise(D, nb, T, B, mpk_option):
     """learned tau (per-episode phase) DMP: the workgroup-per-chunk kernel (four tiles of rows at once, the automatic choice for a few
     thousand episodes) and the wave-per-chunk kernel leave the same bits, and both follow the oracle"""
@@ -1049,3 +1050,48 @@ def test_two_kernels_of_one_signature_that_each_need_more_than_64_kb_of_lds_in_o
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _TWO_BIG_LDS_CHILD, root], capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0 and "two big-LDS kernels ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("B", [4096, 16384, 65536, 262144])
+def test_the_automatic_kernel_choice_is_within_ten_percent_of_the_best_forced_variant(B):
+    """The launcher picks a kernel family by ~25 byte thresholds fitted to THIS chip's caches (mpk_dev.h, mpk_traj_launch.hip); a
+    driver or clock change that moves a crossover should fail a test, not wait for the next sweep.  The headline launch (cfg2,
+    trajectory + actions) and the closed-loop step at four sizes: every family the launcher could have taken is forced in turn
+    (captured graphs of the same launch, warmed by GPU-busy time, timed in alternating rounds: tools/closed_bench.py), and the
+    automatic choice must be within 10 % of the fastest."""
+    from tools.closed_bench import CFG2 as KW, DG, PG, capture, time_rows
+    eng = TrajectoryEngine(device=0, **KW)
+    g = torch.Generator().manual_seed(0)
+    params = torch.randn((B, eng.num_params), generator=g).cuda()
+    ip = (torch.rand((B, 7), generator=g) * 2 - 1).cuda()
+    iv = torch.zeros((B, 7), device="cuda")
+    out = tuple(torch.empty((B, 100, 7), device="cuda") for _ in range(3))
+    cp, cv = ip.double().contiguous(), iv.double().contiguous()
+    q, qd = cp.clone(), cv.clone()
+    spec_s = RolloutSpec("motor", 7, PG, DG, -1.0, 1.0, plant="static")
+    spec_d = RolloutSpec("motor", 7, PG, DG, -1.0, 1.0, plant="double_integrator", dt=0.02)
+    reps = 20 if B <= 65536 else 4
+    cases = {
+        "open loop": (lambda: eng.trajectory_actions(params, ip, iv, spec_s, cp, cv, out=out),
+                      [{}, {"mapping": 1}, {"mapping": 2}, {"flat": 1}, {"ring": 1}]),
+        "closed loop": (lambda: eng.trajectory_rollout(params, ip, iv, spec_d, q, qd, out=out),
+                        [{}, {"pipe": 1}, {"quad": 2}, {"quad": 3}, {"ring": 1}]),
+    }
+    try:
+        for name, (fn, variants) in cases.items():
+            graphs, kernels = [], []
+            for opts in variants:
+                _lib.reset_options()
+                for k, v in opts.items():
+                    _lib.set_option(k, v)
+                graphs.append(capture(fn, reps))
+                kernels.append(eng.last_kernel())
+            _lib.reset_options()
+            ts = time_rows(graphs, reps=reps, rounds=7, busy_ms=40.0)
+            best = min(range(len(ts)), key=lambda i: ts[i])
+            table = ", ".join(f"{opts or 'auto'} {k} {t * 1e6:.1f} us" for opts, k, t in zip(variants, kernels, ts))
+            assert ts[0] <= 1.10 * ts[best], f"{name} at B = {B}: automatic choice {kernels[0]} is {ts[0] / ts[best]:.2f} x the best ({table})"
+            del graphs
+            eng.unpin_tables()
+    finally:
+        _lib.reset_options()

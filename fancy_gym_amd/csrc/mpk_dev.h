@@ -76,7 +76,12 @@ constexpr double kWtBytes = 300.0 * 1024 * 1024;
 // (profiles/r04_open_loop_choice.md; us, flat / ring): +actions 49 152 (424 MB) 92.8 / 91.2, 65 536 (565 MB) 123.4 / 118.1,
 // 81 920: 153.1 / 144.2; trajectory only 65 536 (382 MB) 87.0 / 86.0, 81 920 (477 MB) 105.8 / 100.1, 98 304 (573 MB) 124.1 / 118.2;
 // 32 768 (283 / 191 MB): 55.9 / 71.2 and 33.6 / 46.9 -- the ring from 440 MB on (was 600 MiB)
-constexpr double kRingBytes = 420.0 * 1024 * 1024;
+// Round 5: the ring's "fixed" 33 - 38 us below ~30 000 episodes was its ticket size (wave 0 takes 3 - 4 tickets of five batches in its first
+// atomic: a few dozen workgroups walked off with a small launch); with at least ~16 tickets per workgroup (mpk_traj_launch.hip) the
+// ring takes 21 us at 12 288 episodes (was 38; tiles 14.6) and crosses k_traj_flat earlier (profiles/r05_open_loop_choice.md; us, flat /
+// ring): trajectory only 57 344 (321 MB) 76.3 / 76.6, 65 536 (367 MB) 85.5 / 82.4, 81 920: 105.2 / 99.6; + actions 40 960 (353 MB)
+// 77.2 - 80.4 / 77.0, 49 152 (424 MB) 92.7 / 87.9 -- the ring from 346 MB on (was 440)
+constexpr double kRingBytes = 330.0 * 1024 * 1024;
 // a ticket of k_traj_ring covers at least this many bytes of batch buffers: one device counter hands out ~88 tickets / us
 // (profiles/r04_store_engine_probe_dynamic.md), 32768 tickets of 67 KB saturate it, 10923 of 201 KB do not
 constexpr size_t kRingTicketBytes = 192 * 1024;

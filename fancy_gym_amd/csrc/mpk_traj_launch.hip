@@ -420,7 +420,20 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
             // ticket must be worth well over 100 KB of output); zero at handle creation, zeroed again by the launch's last workgroup
             ta.ring_ctr = ticket;
             ta.ring_tb = (int)((kRingTicketBytes + buf_bytes - 1) / buf_bytes);
+            {
+                // ... but never so coarse that a workgroup sees fewer than ~16 tickets: wave 0 takes its first 3 - 4 tickets in ONE
+                // atomic, so with tickets of five batches the first workgroups to start walked off with 15 - 20 batches each -- at
+                // 12 288 episodes (6 batches per workgroup on average) a few dozen workgroups did all the work while the rest found
+                // the counter past the end: THE ring's "fixed" 33 - 38 us below ~30 000 episodes (round 5, tools/ring_floor_probe.py:
+                // no production + no stores 34 us with tickets, 8 us with static batches), and a coarse tail at 65 536
+                const long batches_ = ((long)ta.G + M - 1) / M;
+                const long fine = batches_ / (16L * (batches_ < (long)num_cu ? batches_ : (long)num_cu));
+                if (tune.ring_tb > 0) ta.ring_tb = tune.ring_tb;
+                else if ((long)ta.ring_tb > fine) ta.ring_tb = (int)fine;
+            }
             if (ta.ring_tb < 1) ta.ring_tb = 1;
+            // (the kernel keeps 2 + ceil(2 NP / (TB M P)) tickets in flight in 8 slots: a ticket covers at least NP / 2 work units)
+            while (2 * ta.ring_tb * M * P < NP) ++ta.ring_tb;
             ring = true;
             stream_mode = true; quad = 0; bulk = false;
             ta.wt = out_bytes <= kWtBytes ? 1 : 0;
@@ -466,6 +479,8 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
             ta.ring_ctr = ticket;
             ta.ring_tb = (int)((kRingTicketBytes + buf_bytes * 3 / 2 - 1) / (buf_bytes * 3 / 2));   // (a batch writes 1.5 x its buffer)
             if (ta.ring_tb < 2) ta.ring_tb = 2;
+            if (tune.ring_tb > 0) ta.ring_tb = tune.ring_tb;
+            while (2 * ta.ring_tb * M < NP) ++ta.ring_tb;
             ring = true; pipe_sel = false;
             stream_mode = true; quad = 0; bulk = false;
             ta.wt = out_bytes <= kWtBytes ? 1 : 0;

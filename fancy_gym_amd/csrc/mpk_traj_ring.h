@@ -401,8 +401,11 @@ __global__ void __launch_bounds__(CT >= 3 ? kRingThreadsClosed : kRingThreads) k
     int* const sTick = sSync + 64;                                 // [8] ticket values, [8] = number of tickets published
     int* const sTickN = sSync + 72;
     int* const sDone = sSync + 73;                                 // wave 0 has left: whatever is not published is past the end
-    // tickets in flight: the prefetch of the next round's inputs looks ceil(NP / IPT) tickets ahead, + the one being fetched + 1
-    const int ahead = 2 + (NP + IPT - 1) / IPT;
+    // tickets in flight: wave 0 asks for the ticket of its NEXT item (NP units on) while the tickets it requests in this item are
+    // published only at the item's end -- so what is published must reach two rounds ahead: ceil(2 NP / IPT) tickets, + the one being
+    // fetched + 1.  (Rounds 4 - 5 had ceil(NP / IPT): enough while a ticket covered several rounds -- five batches --, a wave 0 that
+    // waits for itself with tickets of one batch; the launcher keeps IPT >= NP / 2, i.e. ahead <= 6 of the 8 ticket slots.)
+    const int ahead = 2 + (2 * NP + IPT - 1) / IPT;
     // global batch of local batch bl; -1: this workgroup is done (waits for the ticket in dynamic mode); -2: protocol time-out
     auto batch_at = [&](int bl) -> int {
         if (!dynamic) return bl < nb_local ? (compact ? bl * nWG + wg : wg * per + bl) : -1;

@@ -235,6 +235,8 @@ int mpk_set_duration(mpk_handle h, double duration, double dt);
  *   "ring_ns"       1 .. 8 store-engine waves per workgroup (2; closed loop: 1)
  *   "ring_m"        1 .. 8 episode groups per batch buffer (the largest <= 4 that leaves two buffers in 160 KB)
  *   "ring_parts"    1 .. 8 producer waves sharing the row tiles of one group (by the buffers: all producers stay busy)
+ *   "ring_tb"       1 .. 64 batches per ticket of the device counter (by size: >= 192 KB of output per ticket, and at least ~16
+ *                   tickets per workgroup)
  *   "ring_dbg"      bit mask for A/B runs.  Result-preserving: 4 batches b -> workgroup b % grid instead of tickets from the
  *                   device counter (closed loop: the other way round -- b % grid is its default, 4 = tickets), 16 contiguous batch
  *                   ranges per workgroup (k_traj_burst: A fragments from the table in L2), 32 the generic contraction / flush

@@ -429,3 +429,26 @@ def test_flat_kernel_is_skipped_where_it_does_not_apply(mpk_option):
         assert not eng.last_kernel().startswith("k_traj_flat")
         rp, rv = O.get_trajectory(pc, bc, tc, params, duration, dt, 0.0, ip, iv, dtype=np.float64)
         close(pos.cpu().numpy(), rp, "pos")
+
+
+@pytest.mark.parametrize("B", [700, 12288, 70001])
+def test_ring_tickets_of_every_size_leave_the_same_bits(B, mpk_option):
+    """Batches per ticket of the ring's device counter ("ring_tb"; automatic: >= 192 KB of output per ticket but at least ~16 tickets per
+    workgroup).  Round 5 found wave 0 waiting for a ticket it was itself about to publish when a ticket covered less than a round of
+    producers (tickets of one batch: the launch timed out -- and said so); the kernel keeps ceil(2 NP / units-per-ticket) + 2 tickets
+    in flight now and the launcher never hands it tickets finer than NP / 2 units.  Every ticket size, with one to four groups per
+    batch and three to twelve producers: the bits of the tile-major kernel, and no fault."""
+    pc, bc, tc, dt, duration = CFG2
+    eng = make_engine(pc, bc, tc, dt, duration)
+    params, ip, iv = inputs(pc, bc, tc, B, seed=B)
+    mpk_option("ring", 0); mpk_option("flat", 0); mpk_option("mapping", 1)
+    p0, v0 = [x.clone() for x in eng.trajectory(params, ip, iv, 0.0)]
+    assert eng.last_kernel().startswith("k_traj_tiles")
+    mpk_option("mapping", -1); mpk_option("flat", -1); mpk_option("ring", 1)
+    for tb in (-1, 1, 2, 5, 64):
+        for m, np_ in ((-1, -1), (1, 8), (2, 12), (4, 3), (1, 14)):
+            mpk_option("ring_tb", tb); mpk_option("ring_m", m); mpk_option("ring_np", np_)
+            pos, vel = eng.trajectory(params, ip, iv, 0.0)
+            assert eng.last_kernel() == "k_traj_ring<prodmp>", eng.last_kernel()
+            assert torch.equal(pos, p0) and torch.equal(vel, v0), (tb, m, np_)
+    eng.check_range()          # (synchronises; a ring time-out of any launch above would be reported here)

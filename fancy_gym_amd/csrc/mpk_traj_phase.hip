@@ -189,7 +189,57 @@ struct PhaseArgs {
     int B, wave_floats, t_pad, x_pad, o_pad, c_pad, tab_pad, chunk, img_pad;
     int wt;     // write-through stores while the outputs are cache resident
     int vec_ok; // dmp: outputs 16-byte aligned and T * D a multiple of 4 (float4 stores)
+    int h_pad;  // dmp: floats of the interpolation table of the forcing rows behind the centres (0: rows evaluated exactly)
 };
+
+// ---- per-episode-phase DMP: the forcing rows by INTERPOLATION (round 5) -------------------------------------------------------
+// A row x phi_k(x) weights_scale depends on ONE variable, the left-bounded scaled time s = max((t - delay) / tau, 0) -- whatever an
+// episode's tau, delay and init_time are.  Evaluated exactly it costs one float64 exponential for the phase and one per radial basis
+// function per (episode, step): six for cfg3, ~90 float64 operations, two thirds of these kernels' arithmetic (DESIGN section 9:
+// "issue bound on six float64 exponentials").  Here every workgroup tabulates the rows once, at kFastN + 3 equally spaced nodes of
+// s in [-h, kFastS + h] with the builders' own float64 functions (rbf_row: the table IS the exact rows at its nodes), and an item takes
+// the four nodes around its s through the cubic Lagrange polynomial: ~45 fp32 operations and eight 16-byte LDS reads.  Error
+// 0.0234 h^4 |d4F/ds4| with h = 1 / 256: the rows of <= 5 basis functions (the only shape the table is built for: KS == 8, the
+// reference's DMP configurations) have a fourth derivative <= ~6.4e3 (widths >= 0.14 in s), i.e. <= 4e-8 -- below the fp32 rounding
+// of the row itself; items beyond s = kFastS (a tau far below the horizon) take the exact path.  Bit identity with the exact rows
+// is given up (the 1e-5 contract is what holds across kernel families: DESIGN section 3); "phase_table" 0 restores the exact rows.
+constexpr int kFastN = 512;
+constexpr float kFastS = 2.0f;
+constexpr int kFastRows = kFastN + 3;            // node j <-> s = (j - 1) kFastS / kFastN
+
+template <int KS>
+__device__ __forceinline__ void fast_rows_build(const DevCfg& c, const double* cen, float* tab, const int tid, const int nthreads) {
+    for (int j = tid; j < kFastRows; j += nthreads) {
+        const double s = (double)(j - 1) * (double)(kFastS / kFastN);
+        double x;
+        if (c.phase_type == MPK_PHASE_LINEAR) x = s < 1.0 ? s : 1.0;                   // (node -1: the smooth continuation below 0)
+        else x = s >= 0.0 ? exp_nonpos(-(double)c.alpha_phase * s) : div_pos(1.0, exp_nonpos((double)c.alpha_phase * s));
+        float h[KS];
+#pragma unroll
+        for (int k = 0; k < KS; ++k) h[k] = 0.0f;
+        rbf_row<KS>(c, cen, cen + c.n_total, x, x * (double)c.ws, h, ExpLiteral());
+#pragma unroll
+        for (int k = 0; k < KS; ++k) tab[j * KS + k] = h[k];
+    }
+}
+
+// the row at scaled time s in [0, kFastS): cubic Lagrange interpolation over the nodes i - 1 .. i + 2, i = floor(s / h)
+template <int KS>
+__device__ __forceinline__ void fast_rows_eval(const float* tab, const float s, float (&h)[KS]) {
+    const float u = s * (float)(kFastN / kFastS);      // (a power of two: exact)
+    const int i = (int)u;
+    const float t = u - (float)i, tm1 = t - 1.0f, tp1 = t + 1.0f, tm2 = t - 2.0f;
+    const float w0 = (t * tm1) * tm2 * (-1.0f / 6.0f), w1 = (tp1 * tm1) * tm2 * 0.5f;
+    const float w2 = (tp1 * t) * tm2 * -0.5f, w3 = (tp1 * t) * tm1 * (1.0f / 6.0f);
+    const float* r = tab + i * KS;                      // rows i .. i + 3 = nodes i - 1 .. i + 2
+#pragma unroll
+    for (int j = 0; j < KS / 4; ++j) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(r + 4 * j), a1 = *reinterpret_cast<const f32x4*>(r + KS + 4 * j);
+        const f32x4 a2 = *reinterpret_cast<const f32x4*>(r + 2 * KS + 4 * j), a3 = *reinterpret_cast<const f32x4*>(r + 3 * KS + 4 * j);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h[4 * j + q] = fmaf(w3, a3[q], fmaf(w2, a2[q], fmaf(w1, a1[q], w0 * a0[q])));
+    }
+}
 
 template <int MP>
 __device__ __forceinline__ float phase_x_value(const DevCfg& c, const float* __restrict__ prm,
@@ -678,7 +728,8 @@ __global__ void __launch_bounds__(256) k_traj_phase_dmp(const PhaseArgs a) {
     const int D = c.D, T = c.T, E = a.chunk, P = c.P;
     const int seg = TT * D;                             // floats of one episode's tile
     double* sCen = reinterpret_cast<double*>(smem);     // [c_pad / 2] RBF centres | bandwidths (| recurrence constants)
-    float* sBT = smem + a.c_pad;                        // [t_pad] base times, shared by the workgroup
+    float* sFast = smem + a.c_pad;                      // [h_pad] interpolation table of the forcing rows (fast_rows_build)
+    float* sBT = sFast + a.h_pad;                       // [t_pad] base times, shared by the workgroup
     float* sX = sBT + a.t_pad + (size_t)wave * a.wave_floats;   // [E][D][KS] columns: weights .., goal, y0, ydot0
     float* sPh = sX + E * a.x_pad;                      // [E][8] tau, delay, init_time (clipped), -, 1 / tau refined (float64), -
     float* sDs = sPh + 8 * E;                           // [E][TT] ds of the tile's steps
@@ -688,6 +739,11 @@ __global__ void __launch_bounds__(256) k_traj_phase_dmp(const PhaseArgs a) {
     for (int t = threadIdx.x; t < T; t += blockDim.x) sBT[t] = c.base_times[t];
     for (int k = threadIdx.x; k < 2 * c.n_total + 3; k += blockDim.x) sCen[k] = c.tab[k];
     __syncthreads();
+    const bool fast = a.h_pad > 0;
+    if (fast) {
+        if constexpr (KS == 8) fast_rows_build<KS>(c, sCen, sFast, threadIdx.x, blockDim.x);
+        __syncthreads();
+    }
     const float inv_d = 1.0f / (float)D;
     const int le = (int)(((float)lane + 0.5f) * inv_d), ld = lane - le * D;        // lane <-> (episode, DoF)
     const float inv_seg4 = 4.0f / (float)seg, inv_seg = 1.0f / (float)seg;   // (idx + 0.5) * inv: exact floor for idx < 2^16
@@ -725,6 +781,8 @@ __global__ void __launch_bounds__(256) k_traj_phase_dmp(const PhaseArgs a) {
         const TauDiv td = make_tau_div(tau);
         for (int t0 = 0; t0 < T; t0 += TT) {
             const int rows = min(TT, T - t0);
+            const int ti_ = t0 / TT;                   // (trace builds: tools/dev/trace_phase_dmp.py -- 10 + 5 tile: tile start, + 1 rows,
+            if (ti_ < 8) MPK_STAMP(10 + 5 * ti_);      //  + 2 forcing, + 3 Euler steps, + 4 stored)
             // ---- A: rows and forcing of the tile
             for (int i0 = 0; i0 < ne * TT; i0 += 64) {
                 const int idx = i0 + lane, e = idx >> 4, tl = idx & (TT - 1), t = t0 + tl;
@@ -733,19 +791,25 @@ __global__ void __launch_bounds__(256) k_traj_phase_dmp(const PhaseArgs a) {
                 if (live) {
                     const float taue = sPh[8 * e], delaye = sPh[8 * e + 1], ite = sPh[8 * e + 2];
                     const float time = sBT[t] + ite;
-                    const PosDiv taud{(double)taue, *reinterpret_cast<const double*>(sPh + 8 * e + 4)};
-                    const double x = phase_f64(c, time, taud, delaye, ExpLiteral());
-                    // every RBF once, in registers (rbf_cols evaluates them for the sum and again for the values; same bits)
+                    const float s_item = scaled_time(time, delaye, taue);
                     float h[KS];
 #pragma unroll
                     for (int k = 0; k < KS; ++k) h[k] = 0.0f;
-                    rbf_row<KS>(c, sCen, sCen + c.n_total, x, x * (double)c.ws, h, ExpLiteral());
+                    if (KS == 8 && fast && s_item < kFastS) {
+                        if constexpr (KS == 8) fast_rows_eval<KS>(sFast, s_item, h);
+                    } else {
+                        const PosDiv taud{(double)taue, *reinterpret_cast<const double*>(sPh + 8 * e + 4)};
+                        const double x = phase_f64(c, time, taud, delaye, ExpLiteral());
+                        // every RBF once, in registers (rbf_cols evaluates them for the sum and again for the values; same bits)
+                        rbf_row<KS>(c, sCen, sCen + c.n_total, x, x * (double)c.ws, h, ExpLiteral());
+                    }
 #pragma unroll
                     for (int j = 0; j < KQ; ++j)
                         *reinterpret_cast<f32x4*>(row + 4 * j) = f32x4{h[4 * j], h[4 * j + 1], h[4 * j + 2], h[4 * j + 3]};
-                    if (t < T - 1) sDs[idx] = scaled_time(sBT[t + 1] + ite, delaye, taue) - scaled_time(time, delaye, taue);
+                    if (t < T - 1) sDs[idx] = scaled_time(sBT[t + 1] + ite, delaye, taue) - s_item;
                 }
                 __builtin_amdgcn_wave_barrier();
+                if (ti_ < 8 && i0 == 0) MPK_STAMP(11 + 5 * ti_);
                 if (live) {
                     for (int d = 0; d < D; ++d) {
                         float x[KS];
@@ -760,6 +824,7 @@ __global__ void __launch_bounds__(256) k_traj_phase_dmp(const PhaseArgs a) {
                 }
                 __builtin_amdgcn_wave_barrier();
             }
+            if (ti_ < 8) MPK_STAMP(12 + 5 * ti_);
             // ---- B: 16 Euler steps of every (episode, DoF) of the chunk (one rounding per operation)
             if (on) {
                 float* pp = sP + le * seg + ld;
@@ -782,6 +847,7 @@ __global__ void __launch_bounds__(256) k_traj_phase_dmp(const PhaseArgs a) {
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            if (ti_ < 8) MPK_STAMP(13 + 5 * ti_);
             // ---- C: the tile's blocks, one contiguous run of rows * D floats per episode and array
             const int n = rows * D;
             if (vec) {
@@ -819,6 +885,7 @@ __global__ void __launch_bounds__(256) k_traj_phase_dmp(const PhaseArgs a) {
                 }
             }
             __builtin_amdgcn_wave_barrier();            // the tile's LDS reads are issued before the next tile's writes
+            if (ti_ < 8) MPK_STAMP(14 + 5 * ti_);
         }
     }
 }
@@ -848,7 +915,8 @@ __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_wg(const PhaseArgs a)
     const int D = c.D, T = c.T, E = a.chunk, P = c.P;
     const int bseg = TB * D;                            // floats of one episode's block
     double* sCen = reinterpret_cast<double*>(smem);     // [c_pad / 2] RBF centres | bandwidths
-    float* sBT = smem + a.c_pad;                        // [t_pad] base times
+    float* sFast = smem + a.c_pad;                      // [h_pad] interpolation table of the forcing rows (fast_rows_build)
+    float* sBT = sFast + a.h_pad;                       // [t_pad] base times
     float* sX = sBT + a.t_pad;                          // [E][D][KS] columns: weights .., goal, y0, ydot0
     float* sPh = sX + E * a.x_pad;                      // [E][8] tau, delay, init_time (clipped), -, 1 / tau refined (float64), -
     float* sDs = sPh + 8 * E;                           // [E][TB] ds of the block's steps
@@ -857,6 +925,11 @@ __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_wg(const PhaseArgs a)
     float* sV = sP + E * bseg;                          // [E][TB * D] vel
     for (int t = threadIdx.x; t < T; t += blockDim.x) sBT[t] = c.base_times[t];
     for (int k = threadIdx.x; k < 2 * c.n_total + 3; k += blockDim.x) sCen[k] = c.tab[k];
+    const bool fast = a.h_pad > 0;
+    if (fast) {
+        __syncthreads();
+        if constexpr (KS == 8) fast_rows_build<KS>(c, sCen, sFast, threadIdx.x, blockDim.x);
+    }
     const float inv_d = 1.0f / (float)D;
     const int le = (int)(((float)lane + 0.5f) * inv_d), ld = lane - le * D;        // lane <-> (episode, DoF)  (wave 0)
     const bool vec = a.vec_ok != 0;
@@ -899,16 +972,21 @@ __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_wg(const PhaseArgs a)
                 if (live) {
                     const float taue = sPh[8 * e], delaye = sPh[8 * e + 1], ite = sPh[8 * e + 2];
                     const float time = sBT[t] + ite;
-                    const PosDiv taud{(double)taue, *reinterpret_cast<const double*>(sPh + 8 * e + 4)};
-                    const double x = phase_f64(c, time, taud, delaye, ExpLiteral());
+                    const float s_item = scaled_time(time, delaye, taue);
                     float h[KS];
 #pragma unroll
                     for (int k = 0; k < KS; ++k) h[k] = 0.0f;
-                    rbf_row<KS>(c, sCen, sCen + c.n_total, x, x * (double)c.ws, h, ExpLiteral());
+                    if (KS == 8 && fast && s_item < kFastS) {
+                        if constexpr (KS == 8) fast_rows_eval<KS>(sFast, s_item, h);
+                    } else {
+                        const PosDiv taud{(double)taue, *reinterpret_cast<const double*>(sPh + 8 * e + 4)};
+                        const double x = phase_f64(c, time, taud, delaye, ExpLiteral());
+                        rbf_row<KS>(c, sCen, sCen + c.n_total, x, x * (double)c.ws, h, ExpLiteral());
+                    }
 #pragma unroll
                     for (int j = 0; j < KQ; ++j)
                         *reinterpret_cast<f32x4*>(row + 4 * j) = f32x4{h[4 * j], h[4 * j + 1], h[4 * j + 2], h[4 * j + 3]};
-                    if (t < T - 1) sDs[e * TB + tb] = scaled_time(sBT[t + 1] + ite, delaye, taue) - scaled_time(time, delaye, taue);
+                    if (t < T - 1) sDs[e * TB + tb] = scaled_time(sBT[t + 1] + ite, delaye, taue) - s_item;
                 }
                 __builtin_amdgcn_wave_barrier();
                 if (live) {
@@ -1008,6 +1086,9 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
         pa.o_pad = E * 16 * c.D;                                  // one (pos or vel) tile of the chunk
         pa.wave_floats = E * pa.x_pad + 8 * E + E * 16 + 64 * KS + 2 * pa.o_pad;
         pa.vec_ok = ((reinterpret_cast<uintptr_t>(pa.pos) | reinterpret_cast<uintptr_t>(pa.vel)) & 15u) == 0 && (c.T * c.D) % 4 == 0 ? 1 : 0;
+        // forcing rows by interpolation (fast_rows_build / _eval) where the table's error bound was derived: up to five basis
+        // functions in eight columns; "phase_table" 0: the exact rows
+        pa.h_pad = KS == 8 && tune.phase_table != 0 ? kFastRows * KS : 0;
     } else {
         // chunks of up to 4 consecutive episodes whose parameter rows fit the loader's 5 x 64 values and whose boundary
         // states fit one 64-lane load
@@ -1069,8 +1150,9 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
         pa.wave_floats = 2 * pa.img_pad + 2 * pa.o_pad + (c.mp_type == MPK_MP_PRODMP ? 0 : pa.x_pad);
     }
     pa.c_pad = c.mp_type == MPK_MP_PRODMP ? (c.nb + 2 + 3) / 4 * 4 : (4 * c.n_total + 6 + 3) / 4 * 4;
+    if (!dmp) pa.h_pad = 0;
     const size_t wave_bytes = (size_t)pa.wave_floats * sizeof(float);
-    size_t shared_bytes = (size_t)(pa.t_pad + pa.c_pad) * sizeof(float);
+    size_t shared_bytes = (size_t)(pa.t_pad + pa.c_pad + pa.h_pad) * sizeof(float);
     if (wave_bytes + shared_bytes > kLdsPerCu) return MPK_ENOTIMPL;
     int wpb = (int)((kLdsDefault - shared_bytes) / wave_bytes);
     wpb = wpb > 4 ? 4 : (wpb < 1 ? 1 : wpb);
@@ -1130,8 +1212,11 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
             // four tiles of rows at once (k_traj_phase_dmp_wg).  "phase_flat" 1 forces it, 0 forbids it (A/B runs, tests)
             // two geometries: chunks of (up to) four episodes in blocks of four tiles, or -- when that needs more than one round of
             // resident workgroups -- chunks of eight in blocks of two tiles (twice the episodes per round)
+            // (exact rows in this kernel unless "phase_table" 1 asks for the table: its 16.5 KB take a resident workgroup per CU away,
+            // and every workgroup would build it for one or two chunks -- cfg3' at 4 096 episodes 35.3 us with the table, 31 without)
+            const int wg_h = tune.phase_table == 1 ? pa.h_pad : 0;
             auto wg_bytes = [&](int e, int ntb) {
-                return ((size_t)pa.c_pad + pa.t_pad + (size_t)e * pa.x_pad + 8 * e + (size_t)e * 16 * ntb + 4 * 64 * KS +
+                return ((size_t)pa.c_pad + wg_h + pa.t_pad + (size_t)e * pa.x_pad + 8 * e + (size_t)e * 16 * ntb + 4 * 64 * KS +
                         2 * (size_t)e * 16 * ntb * c.D) * sizeof(float);
             };
             auto wg_resident = [&](size_t bytes) {
@@ -1153,6 +1238,7 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
             // four 58 vs 61 us)
             const bool wg = wg_ok && tune.phase_flat != 0 && (tune.phase_flat == 1 || chunks <= (long)num_cu * wg_res);
             if (wg) {
+                pa.h_pad = wg_h;
                 pa.chunk = wgE;
                 long nb = chunks < (long)num_cu * wg_res ? chunks : (long)num_cu * wg_res;
                 auto gow = [&](auto kern) -> int {

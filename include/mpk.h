@@ -203,7 +203,9 @@ int mpk_set_duration(mpk_handle h, double duration, double dt);
  *   "write_through" 0 plain stores, 1 write-through (sc1) stores                   (every kernel that has the choice)
  *   "ipw"           n > 0 work items per wave                                      (tile-major kernel)
  *   "phase"         0 workgroup-per-episode kernel instead of wave-per-episode     (per-episode-phase kernels)
- *   "phase_table"   0 ProDMP row table from L2 instead of LDS
+ *   "phase_table"   0 ProDMP row table from L2 instead of LDS; dmp: 0 the forcing rows of the per-episode-phase kernels evaluated exactly
+ *                   (float64 exponentials per (episode, step)) instead of interpolated from a per-workgroup table of the exact rows
+ *                   (the default for up to five basis functions; <= 4e-8 apart)
  *   "phase_chunk"   episodes per wave and chunk: 1 / 2 / 4 (promp / prodmp; prodmp with flat rounds: 1 .. 8), 1 .. min(16, 64 / D) (dmp)
  *   "phase_flat"    0 rounds per episode, 1 rounds over the flattened (episode, step) items of a chunk (wave-per-episode
  *                   prodmp kernel; automatic when the horizon is not a multiple of 64); dmp: 1 forces / 0 forbids the

@@ -454,6 +454,10 @@ def test_per_episode_kernels_agree_bitwise(mp, D, nb, T, monkeypatch, mpk_option
     params, ip, iv = inputs(pc, bc, tc, B, seed=D * 100 + nb)
     it = torch.full((B,), 0.25 if mp == "prodmp" else 0.0, dtype=torch.float32, device="cuda")
     outs = {}
+    if mp == "dmp":
+        # bit identity is a property of the EXACT forcing rows; the wave-per-chunk kernel interpolates them by default (round 5:
+        # fast_rows_eval, <= 4e-8 of the row apart) -- checked against these bits below
+        mpk_option("phase_table", 0)
     for mode in ("1", "0"):
         mpk_option("phase", mode)
         p, v = eng.trajectory(params, ip, iv, it)
@@ -489,6 +493,13 @@ def test_per_episode_kernels_agree_bitwise(mp, D, nb, T, monkeypatch, mpk_option
     rp, rv = O.get_trajectory(pc, bc, tc, params, dur, dt, float(it[0]), ip, iv, dtype=np.float64)
     close(outs["1"][0].cpu().numpy(), rp, "pos")
     close(outs["1"][1].cpu().numpy(), rv, "vel", atol=fd_atol(rp, dt) if mp == "promp" else 0.0)
+    if mp == "dmp":
+        mpk_option("phase_table", -1); mpk_option("phase", 1)
+        p3, v3 = eng.trajectory(params, ip, iv, it)
+        close(p3.cpu().numpy(), rp, "pos, interpolated rows"); close(v3.cpu().numpy(), rv, "vel, interpolated rows")
+        for a, b in ((p3, outs["1"][0]), (v3, outs["1"][1])):
+            a, b = a.cpu().numpy().astype(np.float64), b.cpu().numpy().astype(np.float64)
+            assert np.abs(a - b).max() <= 2e-6 * max(np.abs(b).max(), 1e-30)
 
 
 def test_batches_beyond_2_31_output_elements():
@@ -841,15 +852,22 @@ def test_per_episode_dmp_workgroup_and_wave_kernels_agree_bitwise(D, nb, T, B, m
     pc = dataclasses.replace(pc, learn_tau=True, tau_bound=(0.5 * dur, 1.5 * dur))
     eng = make_engine(pc, bc, tc, dt, dur)
     params, ip, iv = inputs(pc, bc, tc, B, seed=B + T)
-    mpk_option("phase_flat", 1)
-    p1, v1 = [x.clone() for x in eng.trajectory(params, ip, iv, 0.0)]
-    assert eng.last_kernel() == "k_traj_phase<dmp,wg>", eng.last_kernel()
-    mpk_option("phase_flat", 0)
-    p0, v0 = eng.trajectory(params, ip, iv, 0.0)
-    assert eng.last_kernel() == "k_traj_phase<dmp>", eng.last_kernel()
-    assert torch.equal(p1, p0) and torch.equal(v1, v0)
     rp, rv = O.get_trajectory(pc, bc, tc, params, dur, dt, 0.0, ip, iv, dtype=np.float64)
-    close(p1.cpu().numpy(), rp, "pos"); close(v1.cpu().numpy(), rv, "vel")
+    # forcing rows exact (0) / interpolated from the per-workgroup table (1: round 5) in BOTH kernels: the same bits from both; the
+    # automatic setting (table in the wave-per-chunk kernel only) against the oracle
+    for table in (0, 1):
+        mpk_option("phase_table", table)
+        mpk_option("phase_flat", 1)
+        p1, v1 = [x.clone() for x in eng.trajectory(params, ip, iv, 0.0)]
+        assert eng.last_kernel() == "k_traj_phase<dmp,wg>", eng.last_kernel()
+        mpk_option("phase_flat", 0)
+        p0, v0 = eng.trajectory(params, ip, iv, 0.0)
+        assert eng.last_kernel() == "k_traj_phase<dmp>", eng.last_kernel()
+        assert torch.equal(p1, p0) and torch.equal(v1, v0), table
+        close(p1.cpu().numpy(), rp, "pos"); close(v1.cpu().numpy(), rv, "vel")
+    mpk_option("phase_table", -1); mpk_option("phase_flat", -1)
+    p2, v2 = eng.trajectory(params, ip, iv, 0.0)
+    close(p2.cpu().numpy(), rp, "pos (automatic)"); close(v2.cpu().numpy(), rv, "vel (automatic)")
 
 
 def test_dmp_horizon_beyond_the_lds_of_the_shared_phase_kernels_runs_time_tiled():

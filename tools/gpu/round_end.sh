@@ -18,8 +18,10 @@ bash tools/pmc_traffic.sh 4096 262144 > $O/pmc_traffic.txt 2>&1
 python tools/pmc_traffic_json.py gpurun_out/pmct_FETCH_SIZE gpurun_out/pmct_WRITE_SIZE > $O/pmc_traffic.json 2> $O/pmc_traffic.err
 python tools/sweep.py > $O/sweep.md 2> $O/sweep.err
 python tools/closed_bench.py 2048 4096 8192 16384 65536 2>&1 | grep -v amdgpu > $O/closed.md
-python tools/rollout_bench.py 4096 8192 65536 2>&1 | grep -v amdgpu > $O/rollout.md
+python tools/rollout_bench.py 4096 8192 16384 65536 2>&1 | grep -v amdgpu > $O/rollout.md
 python tools/phase_bench.py > $O/phase.md 2>&1
+python tools/dmp_bench.py 2>&1 | grep -v amdgpu > $O/dmp_response.md
+python tools/episode_bench.py 2>&1 | grep -v amdgpu > $O/episode_return.md
 python tools/wide_bench.py > $O/wide.md 2>&1
 for B in 2048 4096 8192 65536; do python tools/bench_replan.py $B 50 --graph; python tools/bench_replan.py $B 50; done 2>&1 | grep -v amdgpu > $O/replan.log
 MPK_BENCH_FORCE_DIST=1 python bench.py --steps 20 --warmup 5 --no-cpu --no-streaming > $O/bench_k20_rccl1.json 2> $O/bench_k20_rccl1.err

@@ -61,6 +61,10 @@ __device__ __forceinline__ void sincos_lean(double x, double* sn, double* cs) {
 #ifndef MPK_RW_ALWAYS_TRIG
 #define MPK_RW_ALWAYS_TRIG 0 // 1: round 4's reward pass (the sin / cos chains for every item, used or not) -- A/B build knob
 #endif
+#ifndef MPK_RW_HELPER
+#define MPK_RW_HELPER 1      // reward kernels: the control-cost pass on two HELPER waves of a six-wave workgroup (0: on the chain waves, round 5's
+                             // first form -- 820 of a tile's 4 070 cycles at one wave per SIMD; A/B build knob)
+#endif
 #ifndef MPK_RW_LOOK
 #define MPK_RW_LOOK 1        // tiles of input lookahead in the reward kernel (2 = as the kernel without reward: measured slower at every size
                              // even after round 5 took the sin / cos chains out of 199 of 200 steps -- 4 096 episodes 29.7 vs 27.0 us,

@@ -75,16 +75,38 @@ struct PdArgs {
 // DC (round 5): the DoF count compiled in (0: run time) for the shapes the reference registers -- 2 / 5 links (Simple / LongSimpleReacher,
 // envs/__init__.py:38-59), 7 joints (BASELINE cfg2 / cfg4 / cfg5) --: group geometry, staging offsets and the reward pass's reads become
 // immediates, as in k_traj_ring / k_traj_flat (round 4).
-template <int NG, bool RW, int CT = -1, int DC = 0>
-__global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
+// Reward kernels with helper waves (MPK_RW_HELPER, round 5): the pass that turns a tile's (episode, step) items into rewards needs none
+// of the chain's registers, and at a few thousand episodes the chain wave has its SIMD to itself -- every instruction of the pass costs
+// its full issue latency there.  The workgroup gets two more waves: waves 0 - 3 run the chains as before and leave the clipped actions
+// of a tile as a float64 image (two buffers, used in turn); after ONE workgroup barrier per tile, helper wave h turns the images of
+// chain waves 2 h and 2 h + 1 into rewards (control cost only) and stores them, while the chains run the next tile.  A tile that can hold
+// an item past steps_before_reward (one in thirteen at the reference's setting) keeps the whole pass -- end effector and all -- on
+// its chain wave, which alone has the plant positions.  What a helper needs per episode (executed steps, step offset, episode) sits
+// in an LDS table the chain wave fills per unit (two tables, by the parity of the unit).  Every wave of the workgroup passes the same
+// number of barriers: the unit loop has a workgroup-uniform trip count, waves without a unit just keep step.
+// The workgroup barrier of the helper scheme: LDS traffic of this wave retired, then s_barrier -- NOT __syncthreads(), whose fence makes
+// the compiler wait for every outstanding global load and store as well (`s_waitcnt vmcnt(0)`: the chain waves' input prefetch and
+// action stores; measured with __syncthreads: 8 192 episodes 31.0 -> 47.2 us)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+constexpr int kRwSlots = 8, kRwSlotInts = 4;                 // per chain wave and parity: eight episode slots of (executed steps, step offset, episode, -)
+template <int NG, bool RW, int CT = -1, int DC = 0, bool HW = false>
+__global__ void __launch_bounds__(HW ? 384 : 256) k_pd_rollout_tiles(const PdArgs a) {
+    static_assert(RW || !HW, "helper waves serve the reward pass");
     static_assert(RW || CT < 0, "only the reward kernels carry the controller as a template parameter");
     constexpr int kShC = DC <= 1 ? 0 : (DC <= 2 ? 1 : (DC <= 4 ? 2 : (DC <= 8 ? 3 : 4)));
     const int sh = DC > 0 ? kShC : a.sh;
-    constexpr int SLOT = 3 * kStageStride + (RW ? 2 * kStageStride : 0);   // floats per group slot
-    extern __shared__ __attribute__((aligned(16))) float smem[];           // [4 waves][NG][SLOT]
+    constexpr int SLOT = 3 * kStageStride + (RW ? (HW ? 4 : 2) * kStageStride : 0);   // floats per group slot
+    extern __shared__ __attribute__((aligned(16))) float smem[];           // [4 chain waves][NG][SLOT] | [2][4][kRwSlots][kRwSlotInts] slot tables
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* sSt = smem + wave * (NG * SLOT);      // per group: desired pos | desired vel | actions (| u as float64)
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool helper = HW && wave_all >= 4;
+    const int wave = helper ? 0 : wave_all;      // (a helper computes with the lane geometry of a chain wave; its own index is wave_all - 4)
+    float* sSt = smem + wave * (NG * SLOT);      // per group: desired pos | desired vel | actions (| u as float64, HW: two buffers)
+    int* const sTabAll = reinterpret_cast<int*>(smem + 4 * NG * SLOT);
     const int D = DC > 0 ? DC : a.D, T = a.T, B = a.B, SEG = 16 * D, DP = 1 << sh, NTW = 16 >> sh;
     const int col = lane & 15, bl = col >> sh, d = col & (DP - 1);
     const int jq = lane >> 4;                                // the group (of this wave's NG) whose recurrence the lane runs
@@ -104,7 +126,52 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
     const int nb8 = gridDim.x >> 3;
     const int vb = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * nb8 + (blockIdx.x >> 3) : blockIdx.x;
     const int units = (a.G + NG - 1) / NG;
-    for (int un = vb * 4 + wave; un < units; un += gridDim.x * 4) {
+    const int ustride = gridDim.x * 4;
+    const int iters = HW ? (units + ustride - 1) / ustride : 0;      // (workgroup-uniform)
+    unsigned tcount = 0;                                             // tiles this wave has passed: parity = float64 action buffer
+    if (helper) {
+        // ---------------- helper wave h: the control-cost pass of chain waves 2 h, 2 h + 1, one tile behind them ----------------
+        const int h = wave_all - 4;
+        const int tl = lane & 15;
+        for (int it = 0; it < iters; ++it) {
+            const int* tab = sTabAll + (it & 1) * (4 * kRwSlots * kRwSlotInts);
+            for (int rt = 0; rt < NRT; ++rt, ++tcount) {
+                lds_barrier();                                     // the chains have finished tile rt (and its float64 images)
+                const int rows = min(16, T - rt * 16), t = rt * 16 + tl;
+#pragma unroll 1
+                for (int cw = 2 * h; cw < 2 * h + 2; ++cw) {
+                    const int* tw = tab + cw * (kRwSlots * kRwSlotInts);
+                    // the chain wave keeps a tile that can hold an item past steps_before_reward: the same conservative rule there
+                    bool mine = false;
+                    if (lane < kRwSlots) mine = tw[lane * kRwSlotInts + 2] >= 0 && tw[lane * kRwSlotInts + 1] + rt * 16 + 15 >= a.steps_before_reward;
+                    if (MPK_RW_ALWAYS_TRIG || __any(mine) != 0) continue;
+                    const float* sW = smem + cw * (NG * SLOT);
+                    const int npass = (NG * NTW + 3) >> 2;
+#pragma unroll 1
+                    for (int p = 0; p < npass; ++p) {
+                        const int sl = 4 * p + (lane >> 4);
+                        const int* e4 = tw + (sl < kRwSlots ? sl : 0) * kRwSlotInts;
+                        const int pns = e4[0], pb = e4[2];
+                        const int e = sl & (NTW - 1), j = sl >> (4 - sh);
+                        const bool item = sl < NG * NTW && pb >= 0 && tl < rows;
+                        const double* uv = reinterpret_cast<const double*>(sW + (j < NG ? j : 0) * SLOT + (3 + 2 * (tcount & 1)) * kStageStride) +
+                                           e * DP * kRwCol + tl;
+                        double r = DC > 0 ? reacher_ctrl_item<DC>(uv, D) : reacher_ctrl_item_d(uv, D);
+                        r = t < pns ? r : 0.0;
+                        if (item) a.rewards[(size_t)pb * T + t] = r;
+                    }
+                }
+            }
+        }
+        return;
+    }
+    for (int it_ = 0, un = vb * 4 + wave; HW ? it_ < iters : un < units; ++it_, un += ustride) {
+        if (HW && un >= units) {
+            // no unit left for this chain wave: empty slots for the helpers, and the workgroup's barriers
+            if (lane < kRwSlots) sTabAll[(it_ & 1) * (4 * kRwSlots * kRwSlotInts) + (wave * kRwSlots + lane) * kRwSlotInts + 2] = -1;
+            for (int rt = 0; rt < NRT; ++rt, ++tcount) lds_barrier();
+            continue;
+        }
         const int g0 = un * NG;
         const int bs = (g0 + jq) * NTW + bl;                 // the serial lane's episode
         const bool serial = lane_serial && g0 + jq < a.G && bs < B;
@@ -173,6 +240,17 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
                 rw_gy[p] = ok ? a.goal[2 * (size_t)b + 1] : 0.0;
             }
         }
+        if (HW && lane < kRwSlots) {
+            // the helpers' per-episode inputs of this unit: slot = (group, episode) as the passes count them
+            const int e = lane & (NTW - 1), j = lane >> (4 - sh);
+            const int b = (g0 + j) * NTW + e;
+            const bool ok = lane < NG * NTW && j < NG && g0 + j < a.G && b < B;
+            int* e4 = sTabAll + (it_ & 1) * (4 * kRwSlots * kRwSlotInts) + (wave * kRwSlots + lane) * kRwSlotInts;
+            e4[0] = ok ? (a.n_steps ? min(a.n_steps[b], T) : T) : 0;
+            e4[1] = ok && a.step0 ? a.step0[b] : 0;
+            e4[2] = ok ? b : -1;
+        }
+        bool prev_own = false;                   // HW: the previous tile's rewards are this wave's to store (a tile with the distance term)
         MPK_STAMP(1);
         fetch(0, lpA, lvA);
         constexpr bool kTwoAhead = !RW || MPK_RW_LOOK == 2;
@@ -231,7 +309,7 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
                 }
             }
             if (rt + kAhead < NRT) fetch(rt + kAhead, lp, lv);   // into the set this tile has just emptied
-            if (rt > 0) { store_actions(rt - 1); store_rewards(rt - 1); }
+            if (rt > 0) { store_actions(rt - 1); if (!HW || prev_own) store_rewards(rt - 1); }
             __builtin_amdgcn_wave_barrier();
             if (rt < 16) MPK_STAMP(10 + 3 * rt);
             // RW: can any (episode, step) item of this tile carry the distance term?  (wave-uniform, conservative: the tile's last step
@@ -256,7 +334,7 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
                     constexpr int CTRL = decltype(ctrl_tag)::value;
                     constexpr bool INTEG = decltype(plant_tag)::value == MPK_PLANT_DOUBLE_INTEGRATOR;
                     double* q64 = reinterpret_cast<double*>(sg) + col * kRwCol;           // [column][step] images
-                    double* u64 = reinterpret_cast<double*>(sg + 3 * kStageStride) + col * kRwCol;
+                    double* u64 = reinterpret_cast<double*>(sg + (3 + (HW ? 2 * (tcount & 1) : 0)) * kStageStride) + col * kRwCol;
                     auto go = [&](auto keep_tag) {
                         constexpr int KEEP = decltype(keep_tag)::value;
                         if (full_tile)
@@ -290,7 +368,8 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
             }
             __builtin_amdgcn_wave_barrier();
             if (rt < 16) MPK_STAMP(11 + 3 * rt);
-            if (RW) {
+            if (HW) prev_own = tile_dist;
+            if (RW && (!HW || tile_dist)) {
                 // item = pass * 64 + lane -> episode slot 4 pass + lane / 16 of the unit, step lane % 16 of the tile; the control cost of
                 // every item as straight-line code, the end effector behind ONE wave-uniform branch
                 const int tl = lane & 15, t = rt * 16 + tl;
@@ -303,7 +382,7 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
                     const bool dist_on = live && ps0 + t >= a.steps_before_reward;
                     const char* sb = reinterpret_cast<const char*>(sSt) + pq;
                     const double* qv = reinterpret_cast<const double*>(sb);
-                    const double* uv = reinterpret_cast<const double*>(sb + 3 * kStageStride * 4);
+                    const double* uv = reinterpret_cast<const double*>(sb + (3 + (HW ? 2 * (tcount & 1) : 0)) * kStageStride * 4);
                     double r = DC > 0 ? reacher_ctrl_item<DC>(uv, D) : reacher_ctrl_item_d(uv, D);
                     // wave-uniform: does ANY of the pass's 64 items carry the distance term?  (MPK_RW_ALWAYS_TRIG: round 4's pass, A/B)
                     if (MPK_RW_ALWAYS_TRIG || (tile_dist && __any(dist_on) != 0)) {
@@ -317,6 +396,7 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
             }
             __builtin_amdgcn_wave_barrier();
             if (rt < 16) MPK_STAMP(12 + 3 * rt);
+            if (HW) { lds_barrier(); ++tcount; }       // the tile's float64 action images are the helpers' now
         };
         if (kAhead == 3) {
             for (int rt = 0; rt < NRT; rt += 3) {
@@ -334,7 +414,7 @@ __global__ void __launch_bounds__(256) k_pd_rollout_tiles(const PdArgs a) {
             }
         }
         store_actions(NRT - 1);
-        store_rewards(NRT - 1);
+        if (!HW || prev_own) store_rewards(NRT - 1);
         __builtin_amdgcn_wave_barrier();
         if (serial) {
             const size_t si = (size_t)bs * D + d;
@@ -497,13 +577,20 @@ int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
         int blocks = (units + 3) / 4;
         if (blocks > 2048) blocks = 2048;
         if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;
-        const size_t lds = (size_t)4 * ng * 5 * kStageStride * sizeof(float);
+        // helper waves for the control-cost pass (k_pd_rollout_tiles<.., HW>): built, tested, measured SLOWER, therefore only on request
+        // ("pd_helper" 1).  LongSimpleReacher + reward, us without / with helpers: 2 048 episodes 19.8 / 20.7, 4 096: 23.5 / 25.0,
+        // 8 192: 30.9 / 47.0, 16 384: 50.1 / 76.0, 65 536: 217 / 321 (profiles/r05_rollout.md) -- one workgroup barrier per tile ties
+        // four latency-bound chain waves (and the helpers that share their SIMDs) to the slowest of them, and the second float64 action
+        // buffer takes a resident workgroup per CU away; the pass it moves off the chain waves is 820 of 4 070 cycles per tile
+        const bool hw = MPK_RW_HELPER && tune.pd_helper == 1;
+        const size_t lds = hw ? ((size_t)4 * ng * 7 * kStageStride + 2 * 4 * kRwSlots * kRwSlotInts) * sizeof(float)
+                              : (size_t)4 * ng * 5 * kStageStride * sizeof(float);
         auto go = [&](auto kern) -> int {
             if (lds > kLdsDefault) {
                 hipError_t e = allow_full_lds(kern);
                 if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return MPK_EHIP; }
             }
-            hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, (hipStream_t)stream, pa);
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(hw ? 384 : 256), lds, (hipStream_t)stream, pa);
             MPK_LAUNCH_CHECK();
             return MPK_OK;
         };
@@ -511,6 +598,7 @@ int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
         // controller and link count compiled in; everything else on the run-time form of the same code
         auto by_ng = [&](auto ct_tag, auto dc_tag) -> int {
             constexpr int CT = decltype(ct_tag)::value, DC = decltype(dc_tag)::value;
+            if (hw) return ng == 4 ? go(k_pd_rollout_tiles<4, true, CT, DC, true>) : (ng == 2 ? go(k_pd_rollout_tiles<2, true, CT, DC, true>) : go(k_pd_rollout_tiles<1, true, CT, DC, true>));
             return ng == 4 ? go(k_pd_rollout_tiles<4, true, CT, DC>) : (ng == 2 ? go(k_pd_rollout_tiles<2, true, CT, DC>) : go(k_pd_rollout_tiles<1, true, CT, DC>));
         };
         using std::integral_constant;

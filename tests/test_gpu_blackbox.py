@@ -1123,18 +1123,23 @@ def test_reacher_rollout_matches_oracle(controller, D, B, T, mode, monkeypatch, 
 @pytest.mark.gpu
 @pytest.mark.parametrize("sbr", [0, 199, 100000])
 @pytest.mark.parametrize("D,B,T", [(5, 300, 200), (5, 37, 100), (2, 40, 200), (7, 50, 64)])
-@pytest.mark.parametrize("mode", ["tiles", "quad", "generic", "tiles_rt"])
+@pytest.mark.parametrize("mode", ["tiles", "quad", "generic", "tiles_rt", "tiles_nohelper", "quad_helper", "duo_helper"])
 def test_reacher_reward_with_and_without_the_distance_term(sbr, D, B, T, mode, mpk_option):
     """simple_reacher.py:62-63: the distance term only from `steps_before_reward` on (199 of 200 steps carry none at the reference's
     setting, :31).  The reward pass evaluates the end effector only where one of a pass's items needs it: steps_before_reward = 0
     keeps the all-live path covered, 100000 the path without any, 199 with step0 = 0 is the reference's episode (the last step
     only).  Rewards without the distance term are -sum(action ** 2) left to right: bit for bit on the tile kernels."""
     from fancy_gym_amd import TrajectoryEngine
-    mpk_option("pd_quad", "2" if mode == "quad" else "0")
+    mpk_option("pd_quad", "2" if mode.startswith("quad") else ("3" if mode.startswith("duo") else "0"))
     if mode == "generic":
         mpk_option("pd_simple", "1")
     if mode == "tiles_rt":
         mpk_option("pd_generic", "1")     # controller and link count at run time (motor on 2 / 5 links are compiled in otherwise)
+    # the control-cost pass on two helper waves of the workgroup (automatic with one or two groups per wave) / on the chain waves
+    if mode.endswith("_nohelper"):
+        mpk_option("pd_helper", 0)
+    if mode.endswith("_helper"):
+        mpk_option("pd_helper", 1)
     eng = TrajectoryEngine(device=0, mp_type="promp", phase_type="linear", basis_type="rbf", num_dof=D, num_basis=3,
                            dt=0.01, duration=T * 0.01, tau=T * 0.01)
     rng = np.random.default_rng(sbr + D * 10 + B)
@@ -1157,6 +1162,7 @@ def test_reacher_reward_with_and_without_the_distance_term(sbr, D, B, T, mode, m
     assert paid.any() == (sbr < T)
     if mode != "generic":                     # (the generic kernel sums over the DoF lanes in tree order)
         assert np.array_equal(got[~paid], rr[~paid])
+    assert np.all(got[np.arange(T)[None] >= n_steps[:, None]] == 0.0)
 
 
 @pytest.mark.gpu

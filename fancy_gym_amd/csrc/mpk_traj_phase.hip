@@ -710,7 +710,7 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
 }
 
 template <int KQ>
-__global__ void __launch_bounds__(256) k_traj_phase_dmp(const PhaseArgs a) {
+__global__ void __launch_bounds__(512) k_traj_phase_dmp(const PhaseArgs a) {      // (four or eight waves: the launcher, by the waves a CU's LDS then holds)
     // DMP with a per-episode phase.  The Euler recurrence is serial in t and needs one lane per (episode, DoF); run per
     // episode it keeps D of 64 lanes busy for T dependent steps -- 7 % of the HBM roofline for 7 DoF (round 1 / 2).  Here a
     // wave owns a CHUNK of E (four, see the launcher) consecutive episodes and walks the horizon in tiles of 16 steps:
@@ -1156,6 +1156,21 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
     if (wave_bytes + shared_bytes > kLdsPerCu) return MPK_ENOTIMPL;
     int wpb = (int)((kLdsDefault - shared_bytes) / wave_bytes);
     wpb = wpb > 4 ? 4 : (wpb < 1 ? 1 : wpb);
+    if (dmp && pa.h_pad > 0 && wpb == 4) {
+        // the waves of a workgroup share one copy of the row table (16.5 KB): eight waves per workgroup where that puts more waves
+        // on a CU -- cfg3': 45 KB x 3 = 12 waves per CU with four, 73 KB x 2 = 16 with eight, i.e. 16 384 instead of 12 288 episodes in
+        // ONE round of resident waves (round 5: 16 384 episodes 87.6 -> 69.0 us, 32 768: 150.8 -> 137.9, 65 536: 279 -> 265)
+        auto resident = [&](int w) {
+            const size_t l = wave_bytes * w + shared_bytes;
+            if (l > kLdsPerCu) return 0;
+            const int pc = (int)(kLdsPerCu / l);
+            return w * (pc > 32 / w ? 32 / w : pc);
+        };
+        // (only where four waves per workgroup need a second round: a single round runs faster with fewer waves per SIMD --
+        // 12 288 episodes 59 us with twelve waves per CU, 69 with sixteen)
+        const long chunks_ = ((long)pa.B + pa.chunk - 1) / pa.chunk;
+        if (resident(8) > resident(4) && chunks_ > (long)num_cu * resident(4)) wpb = 8;
+    }
     // prodmp: stage the row table in LDS when it leaves room for at least 8 waves ("phase_table" 0: gather from L2)
     bool lds_table = false;
     if (c.mp_type == MPK_MP_PRODMP) {

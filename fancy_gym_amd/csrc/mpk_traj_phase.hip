@@ -787,14 +787,14 @@ __global__ void __launch_bounds__(512) k_traj_phase_dmp(const PhaseArgs a) {    
             for (int i0 = 0; i0 < ne * TT; i0 += 64) {
                 const int idx = i0 + lane, e = idx >> 4, tl = idx & (TT - 1), t = t0 + tl;
                 const bool live = idx < ne * TT && t < T;
-                float* row = sH + lane * KS;
+                // (the item's row stays in registers: round 4 wrote it to LDS and read it back once per DoF)
+                float h[KS];
+#pragma unroll
+                for (int k = 0; k < KS; ++k) h[k] = 0.0f;
                 if (live) {
                     const float taue = sPh[8 * e], delaye = sPh[8 * e + 1], ite = sPh[8 * e + 2];
                     const float time = sBT[t] + ite;
                     const float s_item = scaled_time(time, delaye, taue);
-                    float h[KS];
-#pragma unroll
-                    for (int k = 0; k < KS; ++k) h[k] = 0.0f;
                     if (KS == 8 && fast && s_item < kFastS) {
                         if constexpr (KS == 8) fast_rows_eval<KS>(sFast, s_item, h);
                     } else {
@@ -803,12 +803,8 @@ __global__ void __launch_bounds__(512) k_traj_phase_dmp(const PhaseArgs a) {    
                         // every RBF once, in registers (rbf_cols evaluates them for the sum and again for the values; same bits)
                         rbf_row<KS>(c, sCen, sCen + c.n_total, x, x * (double)c.ws, h, ExpLiteral());
                     }
-#pragma unroll
-                    for (int j = 0; j < KQ; ++j)
-                        *reinterpret_cast<f32x4*>(row + 4 * j) = f32x4{h[4 * j], h[4 * j + 1], h[4 * j + 2], h[4 * j + 3]};
                     if (t < T - 1) sDs[idx] = scaled_time(sBT[t + 1] + ite, delaye, taue) - s_item;
                 }
-                __builtin_amdgcn_wave_barrier();
                 if (ti_ < 8 && i0 == 0) MPK_STAMP(11 + 5 * ti_);
                 if (live) {
                     for (int d = 0; d < D; ++d) {
@@ -818,8 +814,12 @@ __global__ void __launch_bounds__(512) k_traj_phase_dmp(const PhaseArgs a) {    
                             const float4 v = *reinterpret_cast<const float4*>(sX + (e * D + d) * KS + 4 * j);
                             x[4 * j + 0] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
                         }
-                        x[KS - 3] = 0.0f; x[KS - 2] = 0.0f; x[KS - 1] = 0.0f;      // goal, y0, ydot0 are not weights
-                        sP[e * seg + tl * D + d] = row_chain<KQ>(row, x);
+                        // row_chain's fmaf chain in ascending k over the weight columns (the last three columns carry goal, y0, ydot0:
+                        // not weights -- the chain multiplied them by 0, which leaves the accumulator's bits alone)
+                        float acc = 0.0f;
+#pragma unroll
+                        for (int k = 0; k < KS - 3; ++k) acc = fmaf(h[k], x[k], acc);
+                        sP[e * seg + tl * D + d] = acc;
                     }
                 }
                 __builtin_amdgcn_wave_barrier();

@@ -830,6 +830,31 @@ __global__ void __launch_bounds__(512) k_traj_phase_dmp(const PhaseArgs a) {    
                 float* pp = sP + le * seg + ld;
                 float* pv = sV + le * seg + ld;
                 const float* pds = sDs + le * TT;
+                if (t0 + TT < T) {
+                    // a tile every step of which advances the state (all but the horizon's last): the 16 forcing values and step sizes
+                    // into registers first (4 + 16 LDS reads issued together), then the chain without a read, a compare or a branch in it
+                    // (left as the loop below, every step read its forcing value behind the previous step's writes to the same image)
+                    float fr[TT], dsr[TT];
+#pragma unroll
+                    for (int j = 0; j < TT / 4; ++j) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(pds + 4 * j);
+                        dsr[4 * j] = v[0]; dsr[4 * j + 1] = v[1]; dsr[4 * j + 2] = v[2]; dsr[4 * j + 3] = v[3];
+                    }
+#pragma unroll
+                    for (int tl = 0; tl < TT; ++tl) fr[tl] = pp[tl * D];
+#pragma unroll
+                    for (int tl = 0; tl < TT; ++tl) {
+                        pp[tl * D] = y;
+                        pv[tl * D] = div_tau(z, td);
+                        const float t1 = g - y;
+                        const float t2 = c.dmp_beta * t1;
+                        const float t3 = t2 - z;
+                        const float t4 = c.dmp_alpha * t3;
+                        const float acc = t4 + fr[tl];
+                        z = z + dsr[tl] * acc;
+                        y = y + dsr[tl] * z;
+                    }
+                } else {
                 for (int tl = 0; tl < rows; ++tl) {
                     const float f = pp[tl * D];
                     pp[tl * D] = y;
@@ -844,6 +869,7 @@ __global__ void __launch_bounds__(512) k_traj_phase_dmp(const PhaseArgs a) {    
                         z = z + ds * acc;
                         y = y + ds * z;
                     }
+                }
                 }
             }
             __builtin_amdgcn_wave_barrier();

@@ -733,8 +733,7 @@ __global__ void __launch_bounds__(512) k_traj_phase_dmp(const PhaseArgs a) {    
     float* sX = sBT + a.t_pad + (size_t)wave * a.wave_floats;   // [E][D][KS] columns: weights .., goal, y0, ydot0
     float* sPh = sX + E * a.x_pad;                      // [E][8] tau, delay, init_time (clipped), -, 1 / tau refined (float64), -
     float* sDs = sPh + 8 * E;                           // [E][TT] ds of the tile's steps
-    float* sH = sDs + E * TT;                           // [64][KS] the round's RBF rows
-    float* sP = sH + 64 * KS;                           // [E][TT * D] forcing -> pos
+    float* sP = sDs + E * TT;                           // [E][TT * D] forcing -> pos   (round 5: the rows stay in registers, no row buffer)
     float* sV = sP + a.o_pad;                           // [E][TT * D] vel
     for (int t = threadIdx.x; t < T; t += blockDim.x) sBT[t] = c.base_times[t];
     for (int k = threadIdx.x; k < 2 * c.n_total + 3; k += blockDim.x) sCen[k] = c.tab[k];
@@ -946,8 +945,7 @@ __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_wg(const PhaseArgs a)
     float* sX = sBT + a.t_pad;                          // [E][D][KS] columns: weights .., goal, y0, ydot0
     float* sPh = sX + E * a.x_pad;                      // [E][8] tau, delay, init_time (clipped), -, 1 / tau refined (float64), -
     float* sDs = sPh + 8 * E;                           // [E][TB] ds of the block's steps
-    float* sH = sDs + E * TB;                           // [4 waves][64][KS] the tile's RBF rows
-    float* sP = sH + 4 * 64 * KS;                       // [E][TB * D] forcing -> pos
+    float* sP = sDs + E * TB;                           // [E][TB * D] forcing -> pos   (round 5: the rows stay in registers, no row buffer)
     float* sV = sP + E * bseg;                          // [E][TB * D] vel
     for (int t = threadIdx.x; t < T; t += blockDim.x) sBT[t] = c.base_times[t];
     for (int k = threadIdx.x; k < 2 * c.n_total + 3; k += blockDim.x) sCen[k] = c.tab[k];
@@ -994,14 +992,13 @@ __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_wg(const PhaseArgs a)
             {
                 const int e = (wave / NTB) * 4 + (lane >> 4), tl = lane & (TT - 1), tb = (wave % NTB) * TT + tl, t = t0 + tb;
                 const bool live = e < ne && t < T;
-                float* row = sH + (wave * 64 + lane) * KS;
+                float h[KS];                        // (the item's row stays in registers, as in k_traj_phase_dmp)
+#pragma unroll
+                for (int k = 0; k < KS; ++k) h[k] = 0.0f;
                 if (live) {
                     const float taue = sPh[8 * e], delaye = sPh[8 * e + 1], ite = sPh[8 * e + 2];
                     const float time = sBT[t] + ite;
                     const float s_item = scaled_time(time, delaye, taue);
-                    float h[KS];
-#pragma unroll
-                    for (int k = 0; k < KS; ++k) h[k] = 0.0f;
                     if (KS == 8 && fast && s_item < kFastS) {
                         if constexpr (KS == 8) fast_rows_eval<KS>(sFast, s_item, h);
                     } else {
@@ -1009,12 +1006,8 @@ __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_wg(const PhaseArgs a)
                         const double x = phase_f64(c, time, taud, delaye, ExpLiteral());
                         rbf_row<KS>(c, sCen, sCen + c.n_total, x, x * (double)c.ws, h, ExpLiteral());
                     }
-#pragma unroll
-                    for (int j = 0; j < KQ; ++j)
-                        *reinterpret_cast<f32x4*>(row + 4 * j) = f32x4{h[4 * j], h[4 * j + 1], h[4 * j + 2], h[4 * j + 3]};
                     if (t < T - 1) sDs[e * TB + tb] = scaled_time(sBT[t + 1] + ite, delaye, taue) - s_item;
                 }
-                __builtin_amdgcn_wave_barrier();
                 if (live) {
                     for (int d = 0; d < D; ++d) {
                         float x[KS];
@@ -1023,8 +1016,10 @@ __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_wg(const PhaseArgs a)
                             const float4 v = *reinterpret_cast<const float4*>(sX + (e * D + d) * KS + 4 * j);
                             x[4 * j + 0] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
                         }
-                        x[KS - 3] = 0.0f; x[KS - 2] = 0.0f; x[KS - 1] = 0.0f;      // goal, y0, ydot0 are not weights
-                        sP[e * bseg + tb * D + d] = row_chain<KQ>(row, x);
+                        float acc = 0.0f;                  // (row_chain's chain over the weight columns: k_traj_phase_dmp)
+#pragma unroll
+                        for (int k = 0; k < KS - 3; ++k) acc = fmaf(h[k], x[k], acc);
+                        sP[e * bseg + tb * D + d] = acc;
                     }
                 }
             }
@@ -1110,7 +1105,7 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
         if (tune.phase_chunk >= 1 && tune.phase_chunk <= e_max) E = tune.phase_chunk;
         pa.chunk = E;
         pa.o_pad = E * 16 * c.D;                                  // one (pos or vel) tile of the chunk
-        pa.wave_floats = E * pa.x_pad + 8 * E + E * 16 + 64 * KS + 2 * pa.o_pad;
+        pa.wave_floats = E * pa.x_pad + 8 * E + E * 16 + 2 * pa.o_pad;
         pa.vec_ok = ((reinterpret_cast<uintptr_t>(pa.pos) | reinterpret_cast<uintptr_t>(pa.vel)) & 15u) == 0 && (c.T * c.D) % 4 == 0 ? 1 : 0;
         // forcing rows by interpolation (fast_rows_build / _eval) where the table's error bound was derived: up to five basis
         // functions in eight columns; "phase_table" 0: the exact rows
@@ -1195,7 +1190,9 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
         // (only where four waves per workgroup need a second round: a single round runs faster with fewer waves per SIMD --
         // 12 288 episodes 59 us with twelve waves per CU, 69 with sixteen)
         const long chunks_ = ((long)pa.B + pa.chunk - 1) / pa.chunk;
-        if (resident(8) > resident(4) && chunks_ > (long)num_cu * resident(4)) wpb = 8;
+        // (a tie goes to eight: half as many workgroups build the table, and half as many copies of it sit in the CU's LDS --
+        // cfg3' at 65 536 episodes 236 us with four waves per workgroup, 217 with eight, sixteen waves per CU either way)
+        if (resident(8) >= resident(4) && chunks_ > (long)num_cu * resident(4)) wpb = 8;
     }
     // prodmp: stage the row table in LDS when it leaves room for at least 8 waves ("phase_table" 0: gather from L2)
     bool lds_table = false;
@@ -1257,7 +1254,7 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
             // and every workgroup would build it for one or two chunks -- cfg3' at 4 096 episodes 35.3 us with the table, 31 without)
             const int wg_h = tune.phase_table == 1 ? pa.h_pad : 0;
             auto wg_bytes = [&](int e, int ntb) {
-                return ((size_t)pa.c_pad + wg_h + pa.t_pad + (size_t)e * pa.x_pad + 8 * e + (size_t)e * 16 * ntb + 4 * 64 * KS +
+                return ((size_t)pa.c_pad + wg_h + pa.t_pad + (size_t)e * pa.x_pad + 8 * e + (size_t)e * 16 * ntb +
                         2 * (size_t)e * 16 * ntb * c.D) * sizeof(float);
             };
             auto wg_resident = [&](size_t bytes) {

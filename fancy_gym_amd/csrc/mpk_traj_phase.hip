@@ -19,6 +19,35 @@ struct RowArgs {
     int B;
 };
 
+// One explicit Euler step of the reference's DMP (a = alpha (beta (g - y) - z) + f; z += ds a; y += ds z) in the per-episode-phase
+// kernels.  Round 5 (MPK_DMP_PHASE_FMA 1): contracted -- five dependent fused operations instead of nine separately rounded ones.  The
+// chain's latency is what bounds these kernels at a few thousand episodes (one wave runs a chunk's 200 dependent steps) and a fifth
+// of their instructions at any size.  The fused form is the MORE accurate evaluation of the same step; against the separately rounded
+// one (the shared-phase serial kernels, the float32 oracle) it moves results by ~1e-7 of the scale -- bit identity across kernel
+// families is not the contract, 1e-5 against the reference is; all three per-episode DMP kernels take this
+// function, so they still agree with each other bit for bit.  0: one rounding per operation, as rounds 1 - 4.
+#ifndef MPK_DMP_PHASE_FMA
+#define MPK_DMP_PHASE_FMA 1
+#endif
+__device__ __forceinline__ void dmp_phase_step(float& y, float& z, const float g, const float f, const float ds, const float alpha,
+                                               const float beta) {
+#if MPK_DMP_PHASE_FMA
+    const float t1 = g - y;
+    const float t3 = fmaf(beta, t1, -z);
+    const float acc = fmaf(alpha, t3, f);
+    z = fmaf(ds, acc, z);
+    y = fmaf(ds, z, y);
+#else
+    const float t1 = g - y;
+    const float t2 = beta * t1;
+    const float t3 = t2 - z;
+    const float t4 = alpha * t3;
+    const float acc = t4 + f;
+    z = z + ds * acc;
+    y = y + ds * z;
+#endif
+}
+
 template <int MP>
 __global__ void __launch_bounds__(256) k_traj_rows(const RowArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -138,13 +167,7 @@ __global__ void __launch_bounds__(256) k_traj_rows(const RowArgs a) {
                     sV[t * D + dd] = div_tau(z, td);
                     if (t < T - 1) {
                         const float ds = sT[t];
-                        const float t1 = g - y;
-                        const float t2 = c.dmp_beta * t1;
-                        const float t3 = t2 - z;
-                        const float t4 = c.dmp_alpha * t3;
-                        const float acc = t4 + f;
-                        z = z + ds * acc;
-                        y = y + ds * z;
+                        dmp_phase_step(y, z, g, f, ds, c.dmp_alpha, c.dmp_beta);
                     }
                 }
             }
@@ -845,13 +868,7 @@ __global__ void __launch_bounds__(512) k_traj_phase_dmp(const PhaseArgs a) {    
                     for (int tl = 0; tl < TT; ++tl) {
                         pp[tl * D] = y;
                         pv[tl * D] = div_tau(z, td);
-                        const float t1 = g - y;
-                        const float t2 = c.dmp_beta * t1;
-                        const float t3 = t2 - z;
-                        const float t4 = c.dmp_alpha * t3;
-                        const float acc = t4 + fr[tl];
-                        z = z + dsr[tl] * acc;
-                        y = y + dsr[tl] * z;
+                        dmp_phase_step(y, z, g, fr[tl], dsr[tl], c.dmp_alpha, c.dmp_beta);
                     }
                 } else {
                 for (int tl = 0; tl < rows; ++tl) {
@@ -860,13 +877,7 @@ __global__ void __launch_bounds__(512) k_traj_phase_dmp(const PhaseArgs a) {    
                     pv[tl * D] = div_tau(z, td);
                     if (t0 + tl < T - 1) {
                         const float ds = pds[tl];
-                        const float t1 = g - y;
-                        const float t2 = c.dmp_beta * t1;
-                        const float t3 = t2 - z;
-                        const float t4 = c.dmp_alpha * t3;
-                        const float acc = t4 + f;
-                        z = z + ds * acc;
-                        y = y + ds * z;
+                        dmp_phase_step(y, z, g, f, ds, c.dmp_alpha, c.dmp_beta);
                     }
                 }
                 }
@@ -1026,31 +1037,38 @@ __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_wg(const PhaseArgs a)
             __syncthreads();
             // ---- B: wave 0: the block's Euler steps of every (episode, DoF) of the chunk (one rounding per operation)
             if (on) {
-                // (a plain loop: the unrolled tile form of dmp_tile_steps -- 16 forcing values and step sizes in registers first --
-                // measured the same 35 us at 4 096 episodes and needed scratch to stay at four workgroups per CU)
                 float* pp = sP + le * bseg + ld;
                 float* pv = sV + le * bseg + ld;
                 const float* pds = sDs + le * TB;
-#if MPK_DMP_WG_UNROLL == 4
-#pragma unroll 4
-#elif MPK_DMP_WG_UNROLL == 8
-#pragma unroll 8
-#else
+                // round 5: 8-step pieces every step of which advances the state take their forcing values and step sizes into
+                // registers first (the loop form reads each forcing value behind the previous step's write to the same image: an LDS
+                // round trip inside every one of a chunk's 200 dependent steps -- most of this kernel's time at 4 096 episodes)
+                constexpr int PC = 8;               // (16 at a time spill: four workgroups per CU leave 128 registers)
+                int tl0 = 0;
+                for (; tl0 + PC <= rows && t0 + tl0 + PC < T; tl0 += PC) {
+                    float fr[PC], dsr[PC];
+#pragma unroll
+                    for (int j = 0; j < PC / 4; ++j) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(pds + tl0 + 4 * j);
+                        dsr[4 * j] = v[0]; dsr[4 * j + 1] = v[1]; dsr[4 * j + 2] = v[2]; dsr[4 * j + 3] = v[3];
+                    }
+#pragma unroll
+                    for (int i = 0; i < PC; ++i) fr[i] = pp[(tl0 + i) * D];
+#pragma unroll
+                    for (int i = 0; i < PC; ++i) {
+                        pp[(tl0 + i) * D] = y;
+                        pv[(tl0 + i) * D] = div_tau(z, td);
+                        dmp_phase_step(y, z, g, fr[i], dsr[i], c.dmp_alpha, c.dmp_beta);
+                    }
+                }
 #pragma unroll 1
-#endif
-                for (int tl = 0; tl < rows; ++tl) {
+                for (int tl = tl0; tl < rows; ++tl) {
                     const float f = pp[tl * D];
                     pp[tl * D] = y;
                     pv[tl * D] = div_tau(z, td);
                     if (t0 + tl < T - 1) {
                         const float ds = pds[tl];
-                        const float t1 = g - y;
-                        const float t2 = c.dmp_beta * t1;
-                        const float t3 = t2 - z;
-                        const float t4 = c.dmp_alpha * t3;
-                        const float acc = t4 + f;
-                        z = z + ds * acc;
-                        y = y + ds * z;
+                        dmp_phase_step(y, z, g, f, ds, c.dmp_alpha, c.dmp_beta);
                     }
                 }
             }

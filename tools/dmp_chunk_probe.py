@@ -6,7 +6,7 @@ from tools.closed_bench import graph_time
 eng = TrajectoryEngine(device=0, mp_type="dmp", phase_type="exp", basis_type="rbf", num_dof=7, num_basis=5, dt=0.02, duration=4.0, tau=4.0,
                        alpha_phase=2.0, dmp_alpha=25.0, learn_tau=True, tau_bound=(2.0, 4.0))
 g = torch.Generator().manual_seed(0)
-for B in (12288, 16384, 20480, 32768, 65536, 131072):
+for B in (2048, 4096, 8192, 16384, 65536):
     params = torch.randn((B, eng.num_params), generator=g).cuda(); params[:, 0] = torch.rand(B, generator=g).cuda() * 2 + 2
     ip = (torch.rand((B, 7), generator=g) * 2 - 1).cuda(); iv = torch.zeros((B, 7), device="cuda")
     out = tuple(torch.empty((B, 200, 7), device="cuda") for _ in range(2))

@@ -367,6 +367,7 @@ static void fill_devcfg(Handle* h) {
     d.rows32 = h->d_rows32;
     d.rows32_stride = h->rows32_stride;
     d.base_times = h->d_times;
+    d.t_last = h->times.empty() ? 0.f : h->times.back();
     // DMP, shared phase: the response route (k_build_shared).  Columns weights | goal | y_b | v_b as ProDMP's, DMP's parameter block
     // ([w_1 .. w_nb, g] per DoF) is ProDMP's without disabled parts.  Only where the explicit Euler map is comfortably stable: with
     // beta = alpha / 4 its step matrix has det 1 - h and trace 2 - h - h^2 / 4 (h = alpha ds), eigenvalues inside the unit circle iff

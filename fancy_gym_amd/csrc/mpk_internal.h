@@ -61,6 +61,7 @@ struct DevCfg {
     const float* rows32;           // ProDMP, <= 16 columns: [n_pc][2*KS + 4] = [Psi_0..Psi_nb 0.. y1 y2 | dPsi.. 0.. dy1 dy2 | lo x 4]
     int rows32_stride;             // 2*KS + 4 floats (KS = 8 or 16)
     const float* base_times;       // [T]
+    float t_last;                  // base_times[T - 1] (host side: bounds the scaled time a launch can reach)
 };
 
 struct RolloutDev {

@@ -374,6 +374,7 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
     static_assert(!TL || MP == MPK_MP_PRODMP, "only prodmp has a row table");
     static_assert(!FL || MP == MPK_MP_PRODMP, "flat rounds: prodmp (promp's difference crosses lanes)");
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    MPK_STAMP(0);                                       // (trace builds: kernel entry of the traced wave)
     const DevCfg& c = a.c;
     constexpr int KS = KQ * 4;
     const int lane = threadIdx.x & 63;
@@ -388,32 +389,6 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
     float* sO1 = sO0 + a.o_pad;                         // [o_pad] vel staging
     float* sXf = sO1 + a.o_pad;                         // promp: [x_pad] this episode's columns (prodmp: in the input image)
     float* sWgs = smem;                                 // prodmp: weights_goal_scale[nb + 1] (in place of sCen)
-    for (int t = threadIdx.x; t < T; t += blockDim.x) sBT[t] = c.base_times[t];
-    if (MP != MPK_MP_PRODMP) {
-        for (int k = threadIdx.x; k < 2 * c.n_total + 3; k += blockDim.x) sCen[k] = c.tab[k];
-    } else {
-        const double* S = c.tab + 4 * (size_t)c.n_pc + 2 * (size_t)c.n_pc * (c.nb + 1);
-        for (int k = threadIdx.x; k <= c.nb; k += blockDim.x) {
-            const bool off = k < c.nb ? c.disable_weights != 0 : c.disable_goal != 0;
-            sWgs[k] = off ? 0.0f : (float)S[k];
-            if (k == c.nb) sWgs[c.nb + 1] = (float)S[k];     // the goal scale itself, also when the goal is disabled
-        }
-        if (TL) {
-            const float4* src = reinterpret_cast<const float4*>(c.rows32);
-            for (int i = threadIdx.x; i < c.n_pc * (2 * KQ + 1); i += blockDim.x)
-                reinterpret_cast<float4*>(sTab)[i] = src[i];
-        }
-    }
-    __syncthreads();
-    const float* const rows = TL ? sTab : c.rows32;
-    constexpr int kRow = 2 * KS + 4;    // [pos half .. y1 (f64) | vel half .. y2 (f64) | dy1 dy2 (f64)]
-    const ExactDiv dsdt = make_exact_div(c.scaled_dt);
-
-    // A wave owns chunks of E consecutive episodes.  A chunk's inputs -- E parameter rows, E boundary positions /
-    // velocities, E init_times: each one contiguous run -- are fetched with coalesced loads one chunk ahead and
-    // collected once per chunk (into the other half of the wave's input image), right after the rows of the chunk's
-    // last episode are built: the memory queue is in order, so collecting a load also waits for every store issued
-    // before it, and that wait is paid per chunk instead of per episode.
     const int E = a.chunk, P = c.P;
     const int img_floats = a.img_pad;
     constexpr int NLP = 5;                              // E * P <= 320 parameter values per chunk
@@ -437,10 +412,39 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
         if (lane < E * D) { img[E * P + lane] = lip; img[E * P + E * D + lane] = liv; }
         if (lane < E) img[E * P + 2 * E * D + lane] = lit;
     };
-    if (ch < nchunks) {
-        issue_chunk(ch);
-        park_chunk(sImg);
+    // the first chunk's inputs are requested BEFORE the workgroup stages its tables: one memory round trip under the other (round 5:
+    // at a few thousand episodes a wave has one chunk, and its first 40 % were these two waits in a row -- tools/dev/trace_phase.py)
+    if (ch < nchunks) issue_chunk(ch);
+    for (int t = threadIdx.x; t < T; t += blockDim.x) sBT[t] = c.base_times[t];
+    if (MP != MPK_MP_PRODMP) {
+        for (int k = threadIdx.x; k < 2 * c.n_total + 3; k += blockDim.x) sCen[k] = c.tab[k];
+    } else {
+        const double* S = c.tab + 4 * (size_t)c.n_pc + 2 * (size_t)c.n_pc * (c.nb + 1);
+        for (int k = threadIdx.x; k <= c.nb; k += blockDim.x) {
+            const bool off = k < c.nb ? c.disable_weights != 0 : c.disable_goal != 0;
+            sWgs[k] = off ? 0.0f : (float)S[k];
+            if (k == c.nb) sWgs[c.nb + 1] = (float)S[k];     // the goal scale itself, also when the goal is disabled
+        }
+        if (TL) {
+            // (round 5: only the rows an episode of this launch can reach -- a.tab_pad / kRow of them, by the launcher's bound on the
+            // scaled time; at a few thousand episodes the copy of the whole 72 KB table was 40 % of a wave's life: tools/dev/trace_phase.py)
+            const float4* src = reinterpret_cast<const float4*>(c.rows32);
+            for (int i = threadIdx.x; i < (a.tab_pad >> 2); i += blockDim.x)
+                reinterpret_cast<float4*>(sTab)[i] = src[i];
+        }
     }
+    __syncthreads();
+    const float* const rows = TL ? sTab : c.rows32;
+    constexpr int kRow = 2 * KS + 4;    // [pos half .. y1 (f64) | vel half .. y2 (f64) | dy1 dy2 (f64)]
+    const int row_max = TL ? a.tab_pad / kRow - 1 : c.n_pc - 1;       // last row a gather may touch (TL: last staged row)
+    const ExactDiv dsdt = make_exact_div(c.scaled_dt);
+
+    // A wave owns chunks of E consecutive episodes.  A chunk's inputs -- E parameter rows, E boundary positions /
+    // velocities, E init_times: each one contiguous run -- are fetched with coalesced loads one chunk ahead and
+    // collected once per chunk (into the other half of the wave's input image), right after the rows of the chunk's
+    // last episode are built: the memory queue is in order, so collecting a load also waits for every store issued
+    // before it, and that wait is paid per chunk instead of per episode.
+    if (ch < nchunks) park_chunk(sImg);
     constexpr int kStep = MP == MPK_MP_PROMP ? 63 : 64;
     ExpRegs ec;
     if (MP == MPK_MP_PROMP) ec.load();
@@ -487,7 +491,7 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
             __builtin_amdgcn_wave_barrier();                 // every read of the image is issued before its first write
             if (on) {
                 const float sbl = fmaxf(div_exact(itl - delayl, make_exact_div(taul)), 0.0f);
-                const float* rb = rows + (size_t)min((int)rintf(div_exact(sbl, dsdt)), c.n_pc - 1) * kRow;
+                const float* rb = rows + (size_t)min((int)rintf(div_exact(sbl, dsdt)), row_max) * kRow;
                 double pb = 0.0, vb = 0.0;
                 float* xf = imw + le * a.x_pad + ld * KS;
 #pragma unroll
@@ -548,7 +552,7 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
                 const float time = sBT[t] + it;
                 const float s = fmaxf(div_exact(time - delay, dtau), 0.0f);
                 if (s > (float)c.len_factor) atomicOr(a.flag, 1);
-                const int idx = min((int)rintf(div_exact(s, dsdt)), c.n_pc - 1);
+                const int idx = min((int)rintf(div_exact(s, dsdt)), row_max);
                 const float4* row = reinterpret_cast<const float4*>(rows + (size_t)idx * kRow);
 #pragma unroll
                 for (int j = 0; j < (2 * KS - 4) / 4; ++j) {
@@ -620,7 +624,7 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
                 // xi1..xi4 are per (episode, step): the step's lane forms them below in float64 from the table values and
                 // the factors kept here.
                 const float sb = fmaxf(div_exact(it - delay, dtau), 0.0f);
-                const int idxb = min((int)rintf(div_exact(sb, dsdt)), c.n_pc - 1);
+                const int idxb = min((int)rintf(div_exact(sb, dsdt)), row_max);
                 inv_tau = dtau.r;
                 const float* rb = rows + (size_t)idxb * kRow;
                 {
@@ -656,7 +660,7 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
                 if (MP == MPK_MP_PRODMP) {
                     const float s = fmaxf(div_exact(time - delay, dtau), 0.0f);
                     if (s > (float)c.len_factor) atomicOr(a.flag, 1);
-                    const int idx = min((int)rintf(div_exact(s, dsdt)), c.n_pc - 1);
+                    const int idx = min((int)rintf(div_exact(s, dsdt)), row_max);
                     const float4* row = reinterpret_cast<const float4*>(rows + (size_t)idx * kRow);
 #pragma unroll
                     for (int j = 0; j < (2 * KS - 4) / 4; ++j) {
@@ -1215,12 +1219,25 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
     // prodmp: stage the row table in LDS when it leaves room for at least 8 waves ("phase_table" 0: gather from L2)
     bool lds_table = false;
     if (c.mp_type == MPK_MP_PRODMP) {
-        const size_t tab_bytes = (size_t)c.n_pc * (2 * KS + 4) * sizeof(float);
+        const size_t full_bytes = (size_t)c.n_pc * (2 * KS + 4) * sizeof(float);
         const size_t room = kLdsPerCu - shared_bytes;
-        lds_table = tab_bytes + 8 * wave_bytes <= room && (long)pa.B >= (long)num_cu * 8;
+        lds_table = full_bytes + 8 * wave_bytes <= room && (long)pa.B >= (long)num_cu * 8;
         if (tune.phase_table == 0) lds_table = false;
         if (lds_table) {
-            pa.tab_pad = c.n_pc * (2 * KS + 4);
+            // rows an episode can reach: scaled time <= (last grid time + init_time - smallest delay) / smallest tau (the kernels clip tau
+            // and delay to their bounds); per-episode init_times are device data: the whole table then
+            int rows_needed = c.n_pc;
+            if (!pa.init_time) {
+                const float tau_lo = c.learn_tau ? c.tau_lo : c.tau, delay_lo = c.learn_delay ? c.delay_lo : c.delay;
+                const double t_last = (double)c.t_last;
+                if (t_last > 0.0 && tau_lo > 0.f) {
+                    const double s_max = (t_last + (double)pa.init_time_shared - (double)delay_lo) / (double)tau_lo;
+                    const double r = s_max / (double)c.scaled_dt + 4.0;
+                    if (r < (double)c.n_pc) rows_needed = r < 4.0 ? 4 : (int)r;
+                }
+            }
+            pa.tab_pad = rows_needed * (2 * KS + 4);
+            const size_t tab_bytes = (size_t)pa.tab_pad * sizeof(float);
             shared_bytes += tab_bytes;
             wpb = (int)((kLdsPerCu - shared_bytes) / wave_bytes);
             wpb = wpb > 16 ? 16 : wpb;

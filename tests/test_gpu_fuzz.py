@@ -429,6 +429,23 @@ def test_random_actions_reacher_validity_and_per_episode_init_time(seed, mpk_opt
     assert np.array_equal(q.cpu().numpy(), rq) and np.array_equal(qd.cpu().numpy(), rqd)
     got = rew.cpu().numpy()
     assert np.all(np.abs(got - rr) <= 1e-11 * (1.0 + np.abs(rr))), np.abs(got - rr).max()
+    # (2b) round 5: the same plan + rollout + reward + aggregation in ONE launch that stores nothing per step (mpk_episode_return):
+    # plant state and aggregated reward bit for bit as the separate launches (where the fused kernel applies: shared phase, <= 16 columns)
+    if shared and D >= 2:
+        agg = str(rng.choice(["sum", "mean", "last"]))
+        q2, qd2 = torch.tensor(q0, device="cuda"), torch.tensor(qd0, device="cuda")
+        try:
+            r = eng.episode_return(params, ip, iv, spec_r, q2, qd2, n_steps=torch.tensor(n_steps), reward="simple_reacher",
+                                   goal=torch.tensor(goal), step0=torch.tensor(step0), aggregation=agg, init_time=init_time)
+        except NotImplementedError:
+            r = None
+        if r is not None:
+            assert eng.last_kernel().startswith("k_episode_return<"), eng.last_kernel()
+            want = eng.reward_aggregate(rew, torch.tensor(n_steps), agg)
+            # (bit for bit where the step rewards came from the tile kernel -- tests/test_gpu_blackbox.py --; shapes that take the generic
+            # rollout kernel (T D not a multiple of 4) add the control cost over the DoF lanes in tree order: last-bit differences)
+            assert torch.all((r["ret"] - want).abs() <= 1e-12 * (1.0 + want.abs())), (agg, eng.last_kernel(), (r["ret"] - want).abs().max())
+            assert torch.equal(q2, q) and torch.equal(qd2, qd), eng.last_kernel()
     # (3) validity + the penalty of an invalid plan
     lim = np.sort(rng.uniform(-2.0, 2.0, (2, D)), axis=0)
     p64 = p_np.astype(np.float64)

@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(256) k_build_shared(const DevCfg c, const floa
     __syncthreads();
     if (c.dmp_resp) {
         // DMP with a phase all episodes share, as a CONTRACTION (round 5).  The explicit Euler recurrence of the reference's DMP
-        // (oracle/mp_oracle.py dmp_trajectory: a = alpha (beta (g - y) - z) + f; z += ds a; y += ds z; vel = z / tau) is
+        // (the CPU restatement's dmp_trajectory: a = alpha (beta (g - y) - z) + f; z += ds a; y += ds z; vel = z / tau) is
         // linear in (w, g, y_b, v_b): pos[t] = sum_k R_pos[t, k] x_k with x = (w_1 .. w_nb, g, y_b, v_b), and R the response of THE
         // SAME Euler map -- same fp32 step sizes ds, same order of operations -- to the unit inputs, run here once per (init_time, T)
         // in float64 and rounded once to fp32.  Superposition of explicit Euler, not the ODE's analytic solution: first-order

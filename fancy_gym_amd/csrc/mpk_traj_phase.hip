@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
     float* sO0 = sImg + 2 * a.img_pad;                  // [o_pad] pos staging: [sh + lane * D + d]
     float* sO1 = sO0 + a.o_pad;                         // [o_pad] vel staging
     float* sXf = sO1 + a.o_pad;                         // promp: [x_pad] this episode's columns (prodmp: in the input image)
-    float* sWgs = smem;                                 // prodmp: weights_goal_scale[nb + 1] (in place of sCen)
+    float* sWgs = smem;                                 // prodmp: [KS] column scales | the goal scale (in place of sCen)
     const int E = a.chunk, P = c.P;
     const int img_floats = a.img_pad;
     constexpr int NLP = 5;                              // E * P <= 320 parameter values per chunk
@@ -415,25 +415,47 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
     // the first chunk's inputs are requested BEFORE the workgroup stages its tables: one memory round trip under the other (round 5:
     // at a few thousand episodes a wave has one chunk, and its first 40 % were these two waits in a row -- tools/dev/trace_phase.py)
     if (ch < nchunks) issue_chunk(ch);
-    for (int t = threadIdx.x; t < T; t += blockDim.x) sBT[t] = c.base_times[t];
+    MPK_STAMP(30);
     if (MP != MPK_MP_PRODMP) {
+        for (int t = threadIdx.x; t < T; t += blockDim.x) sBT[t] = c.base_times[t];
         for (int k = threadIdx.x; k < 2 * c.n_total + 3; k += blockDim.x) sCen[k] = c.tab[k];
     } else {
+        // every load of the tables is in flight before the first LDS write waits for one: the base times, the scale vector and the
+        // row table four float4 per thread at a time (round 5: three loops of load -> write were three memory round trips in a row,
+        // 2 100 of the 16 500 cycles a wave lives at a few thousand episodes -- tools/dev/trace_phase.py)
+        const int tid = (int)threadIdx.x, bd = (int)blockDim.x;
+        const float bt0 = tid < T ? c.base_times[tid] : 0.0f;
+        // sWgs[k], k < KS: the scale of column k -- 0 where the column has no parameter (disabled block, padding) --, sWgs[KS]: the
+        // goal scale itself, also when the goal is disabled (relative goals)
         const double* S = c.tab + 4 * (size_t)c.n_pc + 2 * (size_t)c.n_pc * (c.nb + 1);
-        for (int k = threadIdx.x; k <= c.nb; k += blockDim.x) {
-            const bool off = k < c.nb ? c.disable_weights != 0 : c.disable_goal != 0;
-            sWgs[k] = off ? 0.0f : (float)S[k];
-            if (k == c.nb) sWgs[c.nb + 1] = (float)S[k];     // the goal scale itself, also when the goal is disabled
-        }
+        const double sk = tid <= c.nb ? S[tid] : 0.0;
+        const double sg = tid == KS ? S[c.nb] : 0.0;
         if (TL) {
             // (round 5: only the rows an episode of this launch can reach -- a.tab_pad / kRow of them, by the launcher's bound on the
-            // scaled time; at a few thousand episodes the copy of the whole 72 KB table was 40 % of a wave's life: tools/dev/trace_phase.py)
+            // scaled time; at a few thousand episodes the copy of the whole 72 KB table was 40 % of a wave's life)
             const float4* src = reinterpret_cast<const float4*>(c.rows32);
-            for (int i = threadIdx.x; i < (a.tab_pad >> 2); i += blockDim.x)
-                reinterpret_cast<float4*>(sTab)[i] = src[i];
+            float4* dst = reinterpret_cast<float4*>(sTab);
+            const int n4 = a.tab_pad >> 2;
+            for (int i0 = tid; i0 < n4; i0 += 4 * bd) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = i0 + u * bd < n4 ? src[i0 + u * bd] : float4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i0 + u * bd < n4) dst[i0 + u * bd] = v[u];
+            }
         }
+        if (tid < T) sBT[tid] = bt0;
+        for (int t = tid + bd; t < T; t += bd) sBT[t] = c.base_times[t];
+        if (tid < KS) {
+            const bool off = tid < c.nb ? c.disable_weights != 0 : (tid == c.nb ? c.disable_goal != 0 : true);
+            sWgs[tid] = off ? 0.0f : (float)sk;
+        }
+        if (tid == KS) sWgs[KS] = (float)sg;
     }
+    MPK_STAMP(31);
     __syncthreads();
+    MPK_STAMP(32);
     const float* const rows = TL ? sTab : c.rows32;
     constexpr int kRow = 2 * KS + 4;    // [pos half .. y1 (f64) | vel half .. y2 (f64) | dy1 dy2 (f64)]
     const int row_max = TL ? a.tab_pad / kRow - 1 : c.n_pc - 1;       // last row a gather may touch (TL: last staged row)
@@ -445,6 +467,7 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
     // last episode are built: the memory queue is in order, so collecting a load also waits for every store issued
     // before it, and that wait is paid per chunk instead of per episode.
     if (ch < nchunks) park_chunk(sImg);
+    MPK_STAMP(33);
     constexpr int kStep = MP == MPK_MP_PROMP ? 63 : 64;
     ExpRegs ec;
     if (MP == MPK_MP_PROMP) ec.load();
@@ -468,10 +491,15 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
             float* const imw = sImg + slot * img_floats;
             const int le = (int)(((unsigned)lane * (65536u / (unsigned)D + 1u)) >> 16), ld = lane - le * D;    // lane / D
             const bool on = lane < ne * D;
-            const int K = c.nb + 1;
-            float raw[KS], taul = c.tau, delayl = c.delay, itl = 0.0f, yb = 0.0f, ydb = 0.0f;
+            // (round 5: straight-line selects -- weights sit at local index k < nw, the goal behind them; the per-column "is there a
+            // parameter" logic as nested conditions cost ~700 scalar instructions and 127 spilled SGPRs per wave)
+            // (the asm keeps the column tests where they are used: hoisted out of the chunk loop, each became a 64-bit mask in a pair
+            // of spilled SGPRs)
+            int nw = c.disable_weights ? 0 : c.nb, nbk = c.nb;
+            asm volatile("" : "+s"(nw), "+s"(nbk));
+            float raw[KS - 2], rawg = 0.0f, taul = c.tau, delayl = c.delay, itl = 0.0f, yb = 0.0f, ydb = 0.0f;
 #pragma unroll
-            for (int k = 0; k < KS; ++k) raw[k] = 0.0f;
+            for (int k = 0; k < KS - 2; ++k) raw[k] = 0.0f;
             if (on) {
                 const float* prl = img + le * P;
                 if (c.learn_tau) taul = fminf(fmaxf(prl[0], c.tau_lo), c.tau_hi);
@@ -479,38 +507,37 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
                 itl = img[E * P + 2 * E * D + le];
                 yb = img[E * P + lane]; ydb = img[E * P + E * D + lane];
                 const float* loc = prl + c.off + ld * c.Kloc;
+                // (reads past an episode's local block stay inside the wave's image; the select drops them)
 #pragma unroll
-                for (int k = 0; k < KS; ++k)
-                    if (k < K) {
-                        // a disabled block has no parameters (the goal then sits at local index 0)
-                        const bool have = k < c.nb ? !c.disable_weights : !c.disable_goal;
-                        const int li = k < c.nb ? k : (c.disable_weights ? 0 : c.nb);
-                        raw[k] = have ? loc[li] : 0.0f;
-                    }
+                for (int k = 0; k < KS - 2; ++k) {
+                    const float v = loc[k];
+                    raw[k] = k < nw ? v : 0.0f;
+                }
+                if (!c.disable_goal) rawg = loc[nw];
             }
             __builtin_amdgcn_wave_barrier();                 // every read of the image is issued before its first write
+            MPK_STAMP(4);
             if (on) {
                 const float sbl = fmaxf(div_exact(itl - delayl, make_exact_div(taul)), 0.0f);
                 const float* rb = rows + (size_t)min((int)rintf(div_exact(sbl, dsdt)), row_max) * kRow;
                 double pb = 0.0, vb = 0.0;
+                MPK_STAMP(5);
                 float* xf = imw + le * a.x_pad + ld * KS;
+                // the goal column: scaled goal; relative goal: init_pos joins the scaled goal, or (MPK_RELGOAL_BEFORE_SCALE) the raw
+                // parameter -- zero when the goal is disabled -- before the scale
+                float wgg = c.disable_goal ? 0.0f : rawg * sWgs[KS];
+                if (c.relative_goal) wgg = c.relgoal_before_scale ? (rawg + yb) * sWgs[KS] : wgg + yb;
+                if (c.goal_off_on) wgg = wgg + c.goal_offset;
 #pragma unroll
-                for (int k = 0; k < KS; ++k) {
-                    float wg = 0.0f;
-                    if (k < K) {
-                        const bool have = k < c.nb ? !c.disable_weights : !c.disable_goal;
-                        wg = have ? raw[k] * sWgs[k] : 0.0f;          // (raw is 0 where there is no parameter)
-                        if (k == c.nb) {
-                            // relative goal: init_pos joins the scaled goal, or (MPK_RELGOAL_BEFORE_SCALE) the raw
-                            // parameter -- zero when the goal is disabled -- before the scale
-                            if (c.relative_goal) wg = c.relgoal_before_scale ? (raw[k] + yb) * sWgs[c.nb + 1] : wg + yb;
-                            if (c.goal_off_on) wg = wg + c.goal_offset;
-                        }
-                        pb += (double)rb[2 * k] * (double)wg;
-                        vb += (double)rb[2 * k + 1] * (double)wg;
-                    }
+                for (int k = 0; k < KS - 2; ++k) {
+                    // (columns behind the goal: wg = +0 and the table holds zeros -- the sums take +0 and stay what they are)
+                    float wg = raw[k] * sWgs[k];
+                    wg = k == nbk ? wgg : wg;
+                    pb += (double)rb[2 * k] * (double)wg;
+                    vb += (double)rb[2 * k + 1] * (double)wg;
                     xf[k] = wg;
                 }
+                MPK_STAMP(6);
                 xf[KS - 2] = (float)((double)yb - pb);
                 xf[KS - 1] = (float)((double)(taul * ydb) - vb);
                 if (ld == 0 && !FL) {
@@ -1149,7 +1176,7 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
             int e_max = 320 / c.P;
             e_max = e_max > 8 ? 8 : e_max;
             e_max = e_max > 64 / c.D ? 64 / c.D : e_max;
-            const size_t shared0 = (size_t)(pa.t_pad + (c.nb + 2 + 3) / 4 * 4) * sizeof(float);
+            const size_t shared0 = (size_t)(pa.t_pad + KS + 4) * sizeof(float);
             const size_t tab_bytes = (size_t)c.n_pc * (2 * KS + 4) * sizeof(float);
             auto resident = [&](int e, bool fl) -> long {           // waves of the whole chip for this layout (as below)
                 const int img_in = e * (c.P + 2 * c.D + 1), img_cols = e * (pa.x_pad + (fl ? 12 : 3));
@@ -1192,7 +1219,7 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
         pa.img_pad = ((img_in > img_cols ? img_in : img_cols) + 3) / 4 * 4;
         pa.wave_floats = 2 * pa.img_pad + 2 * pa.o_pad + (c.mp_type == MPK_MP_PRODMP ? 0 : pa.x_pad);
     }
-    pa.c_pad = c.mp_type == MPK_MP_PRODMP ? (c.nb + 2 + 3) / 4 * 4 : (4 * c.n_total + 6 + 3) / 4 * 4;
+    pa.c_pad = c.mp_type == MPK_MP_PRODMP ? KS + 4 : (4 * c.n_total + 6 + 3) / 4 * 4;
     if (!dmp) pa.h_pad = 0;
     const size_t wave_bytes = (size_t)pa.wave_floats * sizeof(float);
     size_t shared_bytes = (size_t)(pa.t_pad + pa.c_pad + pa.h_pad) * sizeof(float);
@@ -1243,7 +1270,7 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
             wpb = wpb > 16 ? 16 : wpb;
         }
     }
-    const size_t lds = wave_bytes * wpb + shared_bytes;
+    size_t lds = wave_bytes * wpb + shared_bytes;
     int per_cu = (int)(kLdsPerCu / lds);
     per_cu = per_cu > 32 / wpb ? 32 / wpb : per_cu;
     if (!dmp && !modelled) {
@@ -1255,6 +1282,13 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
         pa.chunk = E;
     }
     const long units = ((long)pa.B + pa.chunk - 1) / pa.chunk;
+    // fewer chunks than one workgroup per CU would take: smaller workgroups, so that every CU gets its share (round 5: chunks of two
+    // at 4 096 episodes were 128 workgroups of 16 waves on 256 CUs)
+    if (lds_table && units < (long)num_cu * wpb) {
+        const int w = (int)((units + num_cu - 1) / num_cu);
+        wpb = w < 1 ? 1 : w;
+        lds = wave_bytes * wpb + shared_bytes;
+    }
     long blocks = (units + wpb - 1) / wpb;
     if (blocks > (long)num_cu * per_cu) blocks = (long)num_cu * per_cu;
     auto go = [&](auto kern) -> int {

@@ -389,7 +389,10 @@ int mpk_pd_rollout(mpk_handle h, const mpk_rollout_cfg* rc, const float* des_pos
  *   ret       dev double [B] out: the aggregated reward
  * Plant state, replanning state and cond_pos / cond_vel come out bit for bit as from mpk_replan_step; ret equals
  * mpk_reward_aggregate of mpk_reacher_rollout's step rewards bit for bit (same order of additions: per step slot t mod 16 over the
- * row tiles in time order, then the sixteen slots left to right; np.sum adds pairwise -- equal to a few ulp).
+ * row tiles in time order, then the sixteen slots left to right; np.sum adds pairwise -- equal to a few ulp).  That holds for step
+ * rewards written by the tile kernel k_pd_rollout_tiles<.., reward> (every shape mpk_episode_return itself accepts); the per-episode
+ * fallback k_reacher_rollout ("pd_generic" 1, D = 1) sums the squared actions of a step as a tree, and the two then differ in the
+ * last bits (1e-13 relative: tests/test_gpu_fuzz.py).
  * Shared phase, <= 16 contraction columns and DoF (promp, prodmp, dmp on its response route); MPK_ENOTIMPL otherwise (the caller's
  * separate launches then).
  */

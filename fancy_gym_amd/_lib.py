@@ -134,7 +134,7 @@ _ROOT = os.path.dirname(_HERE)
 KERNEL_UNITS = ("mpk_traj_family.hip", "mpk_traj_ring.hip", "mpk_episode.hip", "mpk_traj_launch.hip", "mpk_traj_wide.hip", "mpk_traj_phase.hip", "mpk_rollout.hip",
                 "mpk_misc.hip")          # translation units of the device code (mpk_traj_family.hip: once per MP type)
 KERNEL_HEADERS = ("mpk_dev.h", "mpk_tile.h", "mpk_traj_tiles.h", "mpk_traj_stream.h", "mpk_traj_flat.h", "mpk_traj_ring.h", "mpk_traj_quad.h",
-                  "mpk_traj_pipe.h", "mpk_reward.h")
+                  "mpk_traj_pipe.h", "mpk_reward.h", "mpk_trace_reader.h")
 SOURCE_FILES = (os.path.join(_ROOT, "include", "mpk.h"), os.path.join(_HERE, "csrc", "mpk_internal.h"),
                 os.path.join(_HERE, "csrc", "mpk_host.cpp")) + \
     tuple(os.path.join(_HERE, "csrc", f) for f in KERNEL_HEADERS + KERNEL_UNITS)

@@ -38,6 +38,11 @@ __device__ long long g_trace[256];
             g_trace[(tag) & 255] = (long long)__builtin_readcyclecounter();                         \
     } while (0)
 #define MPK_STAMP(tag) MPK_STAMP_AT(tag, 0)
+}  // namespace mpk
+#if defined(MPK_TRACE_UNIT) && !defined(MPK_DEVICE_ONLY)
+#include "mpk_trace_reader.h"
+#endif
+namespace mpk {
 #else
 #define MPK_STAMP(tag) do { } while (0)
 #define MPK_STAMP_AT(tag, tid) do { } while (0)

@@ -368,7 +368,39 @@ __device__ __forceinline__ void flush_span2(const float* __restrict__ s0, const 
 // episode they belong to (a chunk's outputs are one contiguous run of HBM) -- instead of over each episode's steps: T = 100
 // fills 100 of 128 lanes per episode the other way.  Everything per episode (clipped tau / delay, init_time, 1 / tau, the
 // boundary-condition factors) is then per LANE, read from the chunk image; same arithmetic per (episode, step), same bits.
-template <int MP, int KQ, bool TL, bool FL = false>
+// The DC (position, velocity) contractions of one (episode, step) item with the DoF count at compile time: every column first, then
+// the DC chains side by side -- each chain's own order of operations (ascending k, one v_pk_fma_f32 per k) is the run-time loop's, so
+// the results are the same bits; one chain after the other was 8 dependent FMAs behind two LDS reads, DC times in a row.
+template <int DC, int KQ>
+__device__ __forceinline__ void dofs_unrolled(const float* __restrict__ sX, const float* hq, const float inv_tau, float* __restrict__ o0,
+                                              float* __restrict__ o1) {
+    constexpr int KS = KQ * 4;
+    float x[DC][KS];
+#pragma unroll
+    for (int d = 0; d < DC; ++d)
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(sX + d * KS + 4 * j);
+            x[d][4 * j + 0] = v.x; x[d][4 * j + 1] = v.y; x[d][4 * j + 2] = v.z; x[d][4 * j + 3] = v.w;
+        }
+    f32x2 pv[DC];
+#pragma unroll
+    for (int d = 0; d < DC; ++d) pv[d] = f32x2{0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+#pragma unroll
+        for (int d = 0; d < DC; ++d)
+            pv[d] = __builtin_elementwise_fma(f32x2{hq[2 * k], hq[2 * k + 1]}, f32x2{x[d][k], x[d][k]}, pv[d]);
+#pragma unroll
+    for (int d = 0; d < DC; ++d) {
+        o0[d] = pv[d][0];
+        o1[d] = pv[d][1] * inv_tau;
+    }
+}
+
+// DC: the DoF count at compile time (0: c.D) -- the per-DoF contraction loop then is straight-line code: at run time it was 162
+// instructions per pair of DoF, 85 of them scalar address arithmetic (round 5; 7 = BASELINE cfg2 / cfg4, the reference's Panda tasks)
+template <int MP, int KQ, bool TL, bool FL = false, int DC = 0>
 __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs a) {
     static_assert(MP != MPK_MP_DMP, "dmp has its own kernel");
     static_assert(!TL || MP == MPK_MP_PRODMP, "only prodmp has a row table");
@@ -380,7 +412,7 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wpb = (int)(blockDim.x >> 6);
-    const int D = c.D, T = c.T, KT = c.KT;
+    const int D = DC > 0 ? DC : c.D, T = c.T, KT = c.KT;
     double* sCen = reinterpret_cast<double*>(smem);     // [c_pad / 2] RBF centres | bandwidths, shared by the workgroup
     float* sBT = smem + a.c_pad;                        // [t_pad] base times, shared by the workgroup
     float* sTab = sBT + a.t_pad;                        // TL: [n_pc][2*KS + 4] row table, shared by the workgroup
@@ -395,12 +427,13 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
     const int nchunks = (a.B + E - 1) / E;
     const int cstride = (int)gridDim.x * wpb;
     int ch = (int)blockIdx.x * wpb + wave;
-    float lp[NLP], lip = 0.0f, liv = 0.0f, lit = 0.0f;
+    float lp[NLP] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, lip = 0.0f, liv = 0.0f, lit = 0.0f;
     auto issue_chunk = [&](int cc) {
         const int b0 = cc * E, ne = min(E, a.B - b0);
         const float* prm = a.params + (size_t)b0 * P;
 #pragma unroll
-        for (int r = 0; r < NLP; ++r) lp[r] = lane + 64 * r < ne * P ? prm[lane + 64 * r] : 0.0f;
+        for (int r = 0; r < NLP; ++r)
+            if (r == 0 || 64 * r < E * P) lp[r] = lane + 64 * r < ne * P ? prm[lane + 64 * r] : 0.0f;    // (uniform: one load for E * P <= 64)
         lip = lane < ne * D ? a.init_pos[(size_t)b0 * D + lane] : 0.0f;
         liv = lane < ne * D ? a.init_vel[(size_t)b0 * D + lane] : 0.0f;
         lit = a.init_time && lane < ne ? a.init_time[b0 + lane] : a.init_time_shared;
@@ -408,7 +441,7 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
     auto park_chunk = [&](float* img) {
 #pragma unroll
         for (int r = 0; r < NLP; ++r)
-            if (lane + 64 * r < E * P) img[lane + 64 * r] = lp[r];
+            if ((r == 0 || 64 * r < E * P) && lane + 64 * r < E * P) img[lane + 64 * r] = lp[r];
         if (lane < E * D) { img[E * P + lane] = lip; img[E * P + E * D + lane] = liv; }
         if (lane < E) img[E * P + 2 * E * D + lane] = lit;
     };
@@ -434,7 +467,7 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
             // (round 5: only the rows an episode of this launch can reach -- a.tab_pad / kRow of them, by the launcher's bound on the
             // scaled time; at a few thousand episodes the copy of the whole 72 KB table was 40 % of a wave's life)
             const float4* src = reinterpret_cast<const float4*>(c.rows32);
-            float4* dst = reinterpret_cast<float4*>(sTab);
+            float4* dst = reinterpret_cast<float4*>(__builtin_assume_aligned(sTab, 16));
             const int n4 = a.tab_pad >> 2;
             for (int i0 = tid; i0 < n4; i0 += 4 * bd) {
                 float4 v[4];
@@ -610,13 +643,17 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
                     sO0[sh + lane * D + d] = pv[0];
                     sO1[sh + lane * D + d] = pv[1] * inv_tau;
                 };
-                constexpr int ND = KQ <= 2 ? 2 : 1;
-                int d = 0;
-                for (; d + ND <= D; d += ND) {
+                if constexpr (DC > 0) {
+                    dofs_unrolled<DC, KQ>(sXl, hq, inv_tau, sO0 + sh + lane * DC, sO1 + sh + lane * DC);
+                } else {
+                    constexpr int ND = KQ <= 2 ? 2 : 1;
+                    int d = 0;
+                    for (; d + ND <= D; d += ND) {
 #pragma unroll
-                    for (int q = 0; q < ND; ++q) dof(d + q);
+                        for (int q = 0; q < ND; ++q) dof(d + q);
+                    }
+                    for (; d < D; ++d) dof(d);
                 }
-                for (; d < D; ++d) dof(d);
                 __builtin_amdgcn_wave_barrier();
                 if (a.wt) flush_span2<true>(sO0, sO1, gp, out_vel + (size_t)i0 * D, nout * D, sh, lane);
                 else flush_span2<false>(sO0, sO1, gp, out_vel + (size_t)i0 * D, nout * D, sh, lane);
@@ -744,13 +781,17 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
                     sO0[sh + lane * D + d] = p;        // every lane: the staging holds 64 rows, rows >= nout never leave
                     sO1[sh + lane * D + d] = v;
                 };
-                constexpr int ND = KQ <= 2 ? 2 : 1;
-                int d = 0;
-                for (; d + ND <= D; d += ND) {
+                if constexpr (DC > 0 && MP == MPK_MP_PRODMP) {
+                    dofs_unrolled<DC, KQ>(sXe, hq, inv_tau, sO0 + sh + lane * DC, sO1 + sh + lane * DC);
+                } else {
+                    constexpr int ND = KQ <= 2 ? 2 : 1;
+                    int d = 0;
+                    for (; d + ND <= D; d += ND) {
 #pragma unroll
-                    for (int i = 0; i < ND; ++i) dof(d + i);
+                        for (int i = 0; i < ND; ++i) dof(d + i);
+                    }
+                    for (; d < D; ++d) dof(d);
                 }
-                for (; d < D; ++d) dof(d);
                 __builtin_amdgcn_wave_barrier();
                 MPK_STAMP(12 + 40 * e + (r0 ? 10 : 0));   // contracted, staged
                 if (a.wt) flush_span2<true>(sO0, sO1, gp, out_vel + (size_t)r0 * D, nout * D, sh, lane);
@@ -1302,12 +1343,17 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
     };
     switch (c.mp_type) {
         case MPK_MP_PRODMP:
+            // (seven DoF, <= 8 columns: the instantiations with the DoF loop unrolled; "pd_generic" 1: the run-time loop, for A/B runs and tests)
             if (lds_table) {
                 *kernel_name = flat ? "k_traj_phase<prodmp,lds,flat>" : "k_traj_phase<prodmp,lds>";
+                if (KQ == 2 && c.D == 7 && tune.pd_generic != 1)
+                    return flat ? go(k_traj_phase<MPK_MP_PRODMP, 2, true, true, 7>) : go(k_traj_phase<MPK_MP_PRODMP, 2, true, false, 7>);
                 if (flat) return KQ == 2 ? go(k_traj_phase<MPK_MP_PRODMP, 2, true, true>) : go(k_traj_phase<MPK_MP_PRODMP, 4, true, true>);
                 return KQ == 2 ? go(k_traj_phase<MPK_MP_PRODMP, 2, true>) : go(k_traj_phase<MPK_MP_PRODMP, 4, true>);
             }
             *kernel_name = flat ? "k_traj_phase<prodmp,flat>" : "k_traj_phase<prodmp>";
+            if (KQ == 2 && c.D == 7 && tune.pd_generic != 1)
+                return flat ? go(k_traj_phase<MPK_MP_PRODMP, 2, false, true, 7>) : go(k_traj_phase<MPK_MP_PRODMP, 2, false, false, 7>);
             if (flat) return KQ == 2 ? go(k_traj_phase<MPK_MP_PRODMP, 2, false, true>) : go(k_traj_phase<MPK_MP_PRODMP, 4, false, true>);
             return KQ == 2 ? go(k_traj_phase<MPK_MP_PRODMP, 2, false>) : go(k_traj_phase<MPK_MP_PRODMP, 4, false>);
         case MPK_MP_PROMP:

@@ -216,7 +216,8 @@ int mpk_set_duration(mpk_handle h, double duration, double dt);
  *                   shape fits the matrix-core kernels; kernel names read <dmp_resp..>)
  *   "pd_helper"     1 the reward rollout's control-cost pass on two helper waves of a six-wave workgroup instead of on the chain waves
  *                   (measured slower at every size: never automatic)
- *   "pd_generic"    1 the tile rollout kernels without their compile-time-DoF instantiations (2 / 5 / 7 DoF) -- A/B runs, tests
+ *   "pd_generic"    1 the tile rollout kernels (2 / 5 / 7 DoF) and the per-episode ProDMP kernels (7 DoF) without their
+ *                   compile-time-DoF instantiations -- A/B runs, tests
  *   "pipe"          0 off, 1 force the producer / consumer closed-loop kernel (k_traj_pipe; the default where it fits)
  *   "flat"          0 off, 1 force the whole-trajectory-image episode-major kernel (k_traj_flat; automatic for open-loop
  *                   promp / prodmp launches whose outputs stream to HBM)

@@ -385,6 +385,7 @@ static void fill_devcfg(Handle* h) {
         DevCfg& r = h->dev_resp;
         r.mp_type = MPK_MP_PRODMP;
         r.dmp_resp = 1;
+        r.rows32 = nullptr; r.rows32_stride = 0;      // (a DMP handle's row table is the per-episode kernels' interpolation table)
         r.KT = c.num_basis + 3;
         r.KP = (r.KT + 3) / 4 * 4;
         r.relative_goal = 0; r.disable_goal = 0; r.disable_weights = 0; r.goal_off_on = 0;
@@ -672,6 +673,16 @@ int mpk_create(const mpk_config* cfg, mpk_handle* out) {
     rc = upload_times(h);
     if (rc != MPK_OK) return fail(rc);
     fill_devcfg(h);
+    if (const int nf = fast_rows_floats(h->dev)) {
+        // DMP: the per-episode-phase kernels' interpolation table of the forcing rows, by the device's own row functions (the table IS
+        // the exact rows at its nodes) -- a function of the configuration alone
+        if (hipMalloc((void**)&h->d_rows32, (size_t)nf * sizeof(float)) != hipSuccess) { set_error("hipMalloc(forcing-row table) failed"); return fail(MPK_EHIP); }
+        rc = launch_fast_rows_table(h->dev, h->d_rows32, nullptr);
+        if (rc != MPK_OK) return fail(rc);
+        if (hipDeviceSynchronize() != hipSuccess) { set_error("forcing-row table kernel failed"); return fail(MPK_EHIP); }
+        h->rows32_stride = 8;
+        fill_devcfg(h);
+    }
     rc = prealloc_cache(h);
     if (rc != MPK_OK) return fail(rc);
     *out = reinterpret_cast<mpk_handle>(h);

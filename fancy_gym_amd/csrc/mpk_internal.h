@@ -115,6 +115,9 @@ int launch_traj_rows(const DevCfg& c, const float* params, const float* init_pos
 int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const float* des_vel, double* q,
                       double* qd, const int32_t* n_steps, float* actions, int B, int T, void* stream,
                       const Tuning& tune);
+// per-episode-phase DMP: the interpolation table of the forcing rows (mpk_traj_phase.hip fast_rows_build), built once per handle
+int fast_rows_floats(const DevCfg& c);
+int launch_fast_rows_table(const DevCfg& c, float* out, void* stream);
 // MPK_DMP_FIRST_IS_STEP: (init_pos, init_vel) advanced by one Euler step from init_time to the first grid time
 int launch_dmp_prestep(const DevCfg& c, const float* params, const float* init_pos, const float* init_vel,
                        const float* init_time, float init_time_shared, float* pos1, float* vel1, int B, void* stream);

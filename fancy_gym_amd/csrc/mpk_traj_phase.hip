@@ -246,6 +246,19 @@ __device__ __forceinline__ void fast_rows_build(const DevCfg& c, const double* c
     }
 }
 
+// The table depends on the handle's configuration only (centres, bandwidths, phase constants): built ONCE, at mpk_create, into
+// device memory (DevCfg::rows32 of a DMP handle, row stride 8) and copied into a workgroup's LDS -- 16.5 KB from L2 -- where every
+// workgroup used to evaluate the 515 nodes itself: as much float64 arithmetic as the 800 items of the one chunk a workgroup of
+// k_traj_phase_dmp_wg owns (which therefore ran on the exact rows), 2 % of a launch of 65 536 episodes.
+__global__ void __launch_bounds__(256) k_fast_rows_table(const DevCfg c, float* __restrict__ out) {
+    fast_rows_build<8>(c, c.tab, out, (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(gridDim.x * blockDim.x));
+}
+__device__ __forceinline__ void fast_rows_stage(const float* __restrict__ src, float* dst, const int n, const int tid, const int nthreads) {
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* d4 = reinterpret_cast<float4*>(__builtin_assume_aligned(dst, 16));
+    for (int i = tid; i < (n >> 2); i += nthreads) d4[i] = s4[i];
+}
+
 // the row at scaled time s in [0, kFastS): cubic Lagrange interpolation over the nodes i - 1 .. i + 2, i = floor(s / h)
 template <int KS>
 __device__ __forceinline__ void fast_rows_eval(const float* tab, const float s, float (&h)[KS]) {
@@ -832,12 +845,9 @@ __global__ void __launch_bounds__(512) k_traj_phase_dmp(const PhaseArgs a) {    
     float* sV = sP + a.o_pad;                           // [E][TT * D] vel
     for (int t = threadIdx.x; t < T; t += blockDim.x) sBT[t] = c.base_times[t];
     for (int k = threadIdx.x; k < 2 * c.n_total + 3; k += blockDim.x) sCen[k] = c.tab[k];
-    __syncthreads();
     const bool fast = a.h_pad > 0;
-    if (fast) {
-        if constexpr (KS == 8) fast_rows_build<KS>(c, sCen, sFast, threadIdx.x, blockDim.x);
-        __syncthreads();
-    }
+    if (fast) fast_rows_stage(c.rows32, sFast, a.h_pad, threadIdx.x, blockDim.x);
+    __syncthreads();
     const float inv_d = 1.0f / (float)D;
     const int le = (int)(((float)lane + 0.5f) * inv_d), ld = lane - le * D;        // lane <-> (episode, DoF)
     const float inv_seg4 = 4.0f / (float)seg, inv_seg = 1.0f / (float)seg;   // (idx + 0.5) * inv: exact floor for idx < 2^16
@@ -1022,6 +1032,7 @@ __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_wg(const PhaseArgs a)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int D = c.D, T = c.T, E = a.chunk, P = c.P;
     const int bseg = TB * D;                            // floats of one episode's block
+    MPK_STAMP(0);                                       // (trace builds, tools/dev/trace_phase_dmp.py wg: kernel entry)
     double* sCen = reinterpret_cast<double*>(smem);     // [c_pad / 2] RBF centres | bandwidths
     float* sFast = smem + a.c_pad;                      // [h_pad] interpolation table of the forcing rows (fast_rows_build)
     float* sBT = sFast + a.h_pad;                       // [t_pad] base times
@@ -1033,17 +1044,16 @@ __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_wg(const PhaseArgs a)
     for (int t = threadIdx.x; t < T; t += blockDim.x) sBT[t] = c.base_times[t];
     for (int k = threadIdx.x; k < 2 * c.n_total + 3; k += blockDim.x) sCen[k] = c.tab[k];
     const bool fast = a.h_pad > 0;
-    if (fast) {
-        __syncthreads();
-        if constexpr (KS == 8) fast_rows_build<KS>(c, sCen, sFast, threadIdx.x, blockDim.x);
-    }
+    if (fast) fast_rows_stage(c.rows32, sFast, a.h_pad, threadIdx.x, blockDim.x);
     const float inv_d = 1.0f / (float)D;
     const int le = (int)(((float)lane + 0.5f) * inv_d), ld = lane - le * D;        // lane <-> (episode, DoF)  (wave 0)
     const bool vec = a.vec_ok != 0;
     const int nchunks = (a.B + E - 1) / E;
     for (int ch = (int)blockIdx.x; ch < nchunks; ch += (int)gridDim.x) {
         const int b0 = ch * E, ne = min(E, a.B - b0);
-        __syncthreads();                                // (the previous chunk's images are stored; the tables are in)
+        // (no barrier here: the previous chunk's last block ended with one, and the tables are only read behind the next one -- the
+        // chunk's input loads travel together with the table copy: 1 800 of a workgroup's 42 000 cycles at 4 096 episodes)
+        MPK_STAMP(1);
         for (int idx = threadIdx.x; idx < ne * D * KS; idx += blockDim.x) {
             const int pi = idx / KS, k = idx - pi * KS;             // pi = e * D + dd
             const int e = (int)(((float)pi + 0.5f) * inv_d), dd = pi - e * D;
@@ -1051,6 +1061,9 @@ __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_wg(const PhaseArgs a)
             sX[idx] = phase_x_value<MP>(c, a.params + bb * P, a.init_pos + bb * D, a.init_vel + bb * D, dd, k, KS);
         }
         float tau = c.tau, delay = c.delay, it = a.init_time_shared;
+        // (the Euler wave is wave 0 of EVERY workgroup: the serial chains of a CU's resident workgroups then share one SIMD, where they
+        // interleave at no cost to each other -- a chain issues one instruction per ~9 cycles -- and leave the other three SIMDs to the
+        // row / store phases; rotating the Euler wave over the SIMDs put every chain behind three busy waves: 21.9 -> 23.5 us at 4 096)
         const bool on = wave == 0 && lane < ne * D;
         if (on) {
             const float* prm = a.params + (size_t)(b0 + le) * P;
@@ -1063,14 +1076,15 @@ __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_wg(const PhaseArgs a)
             }
         }
         __syncthreads();
+        MPK_STAMP(2);
         float y = 0.0f, z = 0.0f, g = 0.0f;
         if (on) {
             const float* xc = sX + lane * KS;
             g = xc[KS - 3] * c.gs; y = xc[KS - 2]; z = xc[KS - 1] * tau;
         }
-        const TauDiv td = make_tau_div(tau);
         for (int t0 = 0; t0 < T; t0 += TB) {
             const int rows = min(TB, T - t0);
+            [[maybe_unused]] const int bi_ = t0 / TB;       // (trace builds: stamps 10 + 4 block: rows + forcing built, + 1 Euler starts, + 2 done, + 3 stored)
             // ---- A: wave w: rows and forcing of tile w of the block
             {
                 const int e = (wave / NTB) * 4 + (lane >> 4), tl = lane & (TT - 1), tb = (wave % NTB) * TT + tl, t = t0 + tb;
@@ -1092,21 +1106,32 @@ __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_wg(const PhaseArgs a)
                     if (t < T - 1) sDs[e * TB + tb] = scaled_time(sBT[t + 1] + ite, delaye, taue) - s_item;
                 }
                 if (live) {
-                    for (int d = 0; d < D; ++d) {
-                        float x[KS];
+                    // four DoF side by side (one after the other: two LDS reads, KS - 3 dependent FMAs and an LDS write, D times in a row)
+                    for (int d0 = 0; d0 < D; d0 += 4) {
+                        float x[4][KS];
 #pragma unroll
-                        for (int j = 0; j < KQ; ++j) {
-                            const float4 v = *reinterpret_cast<const float4*>(sX + (e * D + d) * KS + 4 * j);
-                            x[4 * j + 0] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
+                        for (int i = 0; i < 4; ++i) {
+                            const int d = min(d0 + i, D - 1);
+#pragma unroll
+                            for (int j = 0; j < KQ; ++j) {
+                                const float4 v = *reinterpret_cast<const float4*>(sX + (e * D + d) * KS + 4 * j);
+                                x[i][4 * j + 0] = v.x; x[i][4 * j + 1] = v.y; x[i][4 * j + 2] = v.z; x[i][4 * j + 3] = v.w;
+                            }
                         }
-                        float acc = 0.0f;                  // (row_chain's chain over the weight columns: k_traj_phase_dmp)
+                        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};    // (row_chain's chain over the weight columns: k_traj_phase_dmp)
 #pragma unroll
-                        for (int k = 0; k < KS - 3; ++k) acc = fmaf(h[k], x[k], acc);
-                        sP[e * bseg + tb * D + d] = acc;
+                        for (int k = 0; k < KS - 3; ++k)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) acc[i] = fmaf(h[k], x[i][k], acc[i]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (d0 + i < D) sP[e * bseg + tb * D + d0 + i] = acc[i];
                     }
                 }
             }
+            if (bi_ < 8) MPK_STAMP(10 + 4 * bi_);
             __syncthreads();
+            if (bi_ < 8) MPK_STAMP(11 + 4 * bi_);
             // ---- B: wave 0: the block's Euler steps of every (episode, DoF) of the chunk (one rounding per operation)
             if (on) {
                 float* pp = sP + le * bseg + ld;
@@ -1127,9 +1152,11 @@ __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_wg(const PhaseArgs a)
 #pragma unroll
                     for (int i = 0; i < PC; ++i) fr[i] = pp[(tl0 + i) * D];
 #pragma unroll
+                    // (what a step costs the lone Euler wave, round 5 trace at one workgroup per CU: 98 cycles -- 61 for the five dependent
+                    // operations and the reads, 37 for the two LDS writes; a lone wave issues one instruction per 5.6 - 9 cycles)
                     for (int i = 0; i < PC; ++i) {
                         pp[(tl0 + i) * D] = y;
-                        pv[(tl0 + i) * D] = div_tau(z, td);
+                        pv[(tl0 + i) * D] = z;          // (tau x velocity: the division by tau is the storing waves' -- phase C)
                         dmp_phase_step(y, z, g, fr[i], dsr[i], c.dmp_alpha, c.dmp_beta);
                     }
                 }
@@ -1137,13 +1164,14 @@ __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_wg(const PhaseArgs a)
                 for (int tl = tl0; tl < rows; ++tl) {
                     const float f = pp[tl * D];
                     pp[tl * D] = y;
-                    pv[tl * D] = div_tau(z, td);
+                    pv[tl * D] = z;
                     if (t0 + tl < T - 1) {
                         const float ds = pds[tl];
                         dmp_phase_step(y, z, g, f, ds, c.dmp_alpha, c.dmp_beta);
                     }
                 }
             }
+            if (bi_ < 8) MPK_STAMP(12 + 4 * bi_);
             __syncthreads();
             // ---- C: the block's runs, rows * D contiguous floats per episode and array
             const int n = rows * D;
@@ -1153,7 +1181,10 @@ __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_wg(const PhaseArgs a)
                     const int e = idx / n4, q4 = idx - e * n4;
                     const size_t go = ((size_t)(b0 + e) * T + t0) * D + 4 * q4;
                     const f32x4 vp = *reinterpret_cast<const f32x4*>(sP + e * bseg + 4 * q4);
-                    const f32x4 vv = *reinterpret_cast<const f32x4*>(sV + e * bseg + 4 * q4);
+                    f32x4 vv = *reinterpret_cast<const f32x4*>(sV + e * bseg + 4 * q4);
+                    const TauDiv tde = make_tau_div(sPh[8 * e]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) vv[q] = div_tau(vv[q], tde);
                     if (a.wt) { store16<true>(a.pos + go, vp); store16<true>(a.vel + go, vv); }
                     else { store16<false>(a.pos + go, vp); store16<false>(a.vel + go, vv); }
                 }
@@ -1161,16 +1192,27 @@ __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_wg(const PhaseArgs a)
                 for (int idx = threadIdx.x; idx < ne * n; idx += blockDim.x) {
                     const int e = idx / n, w = idx - e * n;
                     const size_t go = ((size_t)(b0 + e) * T + t0) * D + w;
-                    if (a.wt) { store4<true>(a.pos + go, sP[e * bseg + w]); store4<true>(a.vel + go, sV[e * bseg + w]); }
-                    else { store4<false>(a.pos + go, sP[e * bseg + w]); store4<false>(a.vel + go, sV[e * bseg + w]); }
+                    const float vel = div_tau(sV[e * bseg + w], make_tau_div(sPh[8 * e]));
+                    if (a.wt) { store4<true>(a.pos + go, sP[e * bseg + w]); store4<true>(a.vel + go, vel); }
+                    else { store4<false>(a.pos + go, sP[e * bseg + w]); store4<false>(a.vel + go, vel); }
                 }
             }
+            if (bi_ < 8) MPK_STAMP(13 + 4 * bi_);
             __syncthreads();                            // the block's LDS reads are issued before the next block's writes
         }
     }
 }
 
 #ifndef MPK_DEVICE_ONLY
+int fast_rows_floats(const DevCfg& c) {          // 0: no interpolation table for this shape (more than five basis functions)
+    return c.mp_type == MPK_MP_DMP && c.KT + 3 <= 8 ? kFastRows * 8 : 0;
+}
+int launch_fast_rows_table(const DevCfg& c, float* out, void* stream) {
+    hipLaunchKernelGGL(k_fast_rows_table, dim3((kFastRows + 255) / 256), dim3(256), 0, (hipStream_t)stream, c, out);
+    MPK_LAUNCH_CHECK();
+    return MPK_OK;
+}
+
 static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu, void* stream,
                              const char** kernel_name, const Tuning& tune) {
     PhaseArgs pa = base;
@@ -1199,7 +1241,7 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
         pa.vec_ok = ((reinterpret_cast<uintptr_t>(pa.pos) | reinterpret_cast<uintptr_t>(pa.vel)) & 15u) == 0 && (c.T * c.D) % 4 == 0 ? 1 : 0;
         // forcing rows by interpolation (fast_rows_build / _eval) where the table's error bound was derived: up to five basis
         // functions in eight columns; "phase_table" 0: the exact rows
-        pa.h_pad = KS == 8 && tune.phase_table != 0 ? kFastRows * KS : 0;
+        pa.h_pad = KS == 8 && tune.phase_table != 0 && c.rows32 && c.rows32_stride == 8 ? kFastRows * KS : 0;
     } else {
         // chunks of up to 4 consecutive episodes whose parameter rows fit the loader's 5 x 64 values and whose boundary
         // states fit one 64-lane load
@@ -1365,9 +1407,9 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
             // four tiles of rows at once (k_traj_phase_dmp_wg).  "phase_flat" 1 forces it, 0 forbids it (A/B runs, tests)
             // two geometries: chunks of (up to) four episodes in blocks of four tiles, or -- when that needs more than one round of
             // resident workgroups -- chunks of eight in blocks of two tiles (twice the episodes per round)
-            // (exact rows in this kernel unless "phase_table" 1 asks for the table: its 16.5 KB take a resident workgroup per CU away,
-            // and every workgroup would build it for one or two chunks -- cfg3' at 4 096 episodes 35.3 us with the table, 31 without)
-            const int wg_h = tune.phase_table == 1 ? pa.h_pad : 0;
+            // (the interpolation table here too since it is a copy of the handle's: cfg3' at 4 096 episodes 26.8 us on the exact rows,
+            // 21.9 with the table; when every workgroup built it for its one or two chunks it cost more than it saved, 35.3 vs 31)
+            const int wg_h = pa.h_pad;
             auto wg_bytes = [&](int e, int ntb) {
                 return ((size_t)pa.c_pad + wg_h + pa.t_pad + (size_t)e * pa.x_pad + 8 * e + (size_t)e * 16 * ntb +
                         2 * (size_t)e * 16 * ntb * c.D) * sizeof(float);

@@ -1,7 +1,10 @@
 """Per-tile timeline of ONE wave of k_traj_phase<dmp> (cfg3 + learned tau), forcing rows interpolated / exact ("phase_table" 1 / 0).
 MPK_TRACE build: MPK_BUILD_AMALGAMATED=1 MPK_EXTRA_FLAGS=-DMPK_TRACE MPK_BUILD_OUT=ab/lib_trace.so python __graft_entry__.py --force
     MPK_LIB=ab/lib_trace.so python tools/dev/trace_phase_dmp.py [B]
-stamps: 10 + 5 tile: tile start, + 1 rows built, + 2 forcing contracted, + 3 Euler steps done, + 4 stored"""
+stamps: 10 + 5 tile: tile start, + 1 rows built, + 2 forcing contracted, + 3 Euler steps done, + 4 stored
+    ... trace_phase_dmp.py B wg: k_traj_phase_dmp_wg -- 0 entry, 1 tables staged, 2 chunk inputs in, 10 + 4 block: rows + forcing built, + 1 Euler
+    starts, + 2 Euler done, + 3 stored
+one-unit trace build: MPK_TRACE_UNIT=mpk_traj_phase.hip MPK_BUILD_OUT=ab/lib_trace_phase.so python __graft_entry__.py --force"""
 import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.getcwd())
@@ -15,8 +18,9 @@ params = torch.randn((B, eng.num_params), generator=g).cuda()
 params[:, 0] = torch.rand(B, generator=g).cuda() * 2 + 2
 ip = (torch.rand((B, 7), generator=g) * 2 - 1).cuda(); iv = torch.zeros((B, 7), device="cuda")
 buf = np.zeros(512, np.int64)
+WG = "wg" in sys.argv
 for mode in (1, 0):
-    _lib.set_option("phase_table", mode); _lib.set_option("phase_flat", 0)
+    _lib.set_option("phase_table", mode); _lib.set_option("phase_flat", 1 if WG else 0)
     for _ in range(50): eng.trajectory(params, ip, iv, 0.0)
     torch.cuda.synchronize(); lib.mpk_debug_trace(buf.ctypes.data, 256)
     eng.trajectory(params, ip, iv, 0.0); torch.cuda.synchronize()

@@ -66,9 +66,10 @@ import os
 
 # MPK_FUZZ_CASES=2000 python -m pytest tests/test_gpu_fuzz.py -m gpu   for a longer soak
 N_CASES = int(os.environ.get("MPK_FUZZ_CASES", "120"))
+START = int(os.environ.get("MPK_FUZZ_START", "0"))
 
 
-@pytest.mark.parametrize("seed", range(N_CASES))
+@pytest.mark.parametrize("seed", range(START, START + N_CASES))
 def test_random_configuration_matches_oracle(seed, monkeypatch, mpk_option):
     rng = np.random.default_rng(10_000 + seed)
     pc, bc, tc, dt, dur, B, init_time = random_case(rng)

@@ -518,6 +518,32 @@ def test_batches_beyond_2_31_output_elements():
     big_batch_check.main()
 
 
+@pytest.mark.parametrize("B", [1, 37, 2500, 9001])
+def test_prodmp_seven_dof_unrolled_chains_same_bits(B, mpk_option):
+    """k_traj_phase<prodmp> at seven DoF and <= 8 columns runs instantiations with the DoF chains unrolled side by side (round 5);
+    "pd_generic" 1 takes the run-time DoF loop: the same bits from both, for every row source and round shape, and the oracle"""
+    pc = O.PhaseCfg("exp", tau=1.5, alpha_phase=3.0, learn_tau=True, learn_delay=True, tau_bound=(0.5, 2.0), delay_bound=(0.0, 0.3))
+    bc = O.BasisCfg("prodmp", num_basis=5, basis_bandwidth_factor=2, alpha=10)
+    tc = O.TrajCfg("prodmp", action_dim=7, relative_goal=True)
+    dt, dur = 0.02, 2.0
+    eng = make_engine(pc, bc, tc, dt, dur)
+    params, ip, iv = inputs(pc, bc, tc, B, seed=B)
+    for flat in ("0", "1"):
+        for table in ("1", "0"):
+            mpk_option("phase_table", table); mpk_option("phase_flat", flat)
+            mpk_option("pd_generic", "1")
+            p0, v0 = (x.clone() for x in eng.trajectory(params, ip, iv, 0.0))
+            k0 = eng.last_kernel()
+            mpk_option("pd_generic", "0")
+            p1, v1 = eng.trajectory(params, ip, iv, 0.0)
+            torch.cuda.synchronize()
+            assert eng.last_kernel() == k0 and k0.startswith("k_traj_phase<prodmp"), (k0, eng.last_kernel())
+            assert torch.equal(p0, p1) and torch.equal(v0, v1), (flat, table, k0)
+    n = min(B, 64)
+    rp, rv = O.get_trajectory(pc, bc, tc, params[:n], dur, dt, 0.0, ip[:n], iv[:n], dtype=np.float64)
+    close(p1[:n].cpu().numpy(), rp, "pos"); close(v1[:n].cpu().numpy(), rv, "vel")
+
+
 @pytest.mark.parametrize("name", ["prodmp_learn_tau_delay", "cfg2_learn_tau"])
 def test_prodmp_row_table_in_lds_or_l2_same_bits(name, monkeypatch, mpk_option):
     """k_traj_phase<prodmp> gathers its fp32 rows from an LDS copy of the table when that fits beside 8 waves, else

@@ -254,9 +254,18 @@ __global__ void __launch_bounds__(256) k_fast_rows_table(const DevCfg c, float* 
     fast_rows_build<8>(c, c.tab, out, (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(gridDim.x * blockDim.x));
 }
 __device__ __forceinline__ void fast_rows_stage(const float* __restrict__ src, float* dst, const int n, const int tid, const int nthreads) {
+    // (four loads in flight per thread before the first LDS write waits for one: a loop of load -> write is a memory round trip per pass)
     const float4* s4 = reinterpret_cast<const float4*>(src);
     float4* d4 = reinterpret_cast<float4*>(__builtin_assume_aligned(dst, 16));
-    for (int i = tid; i < (n >> 2); i += nthreads) d4[i] = s4[i];
+    const int n4 = n >> 2;
+    for (int i0 = tid; i0 < n4; i0 += 4 * nthreads) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = i0 + u * nthreads < n4 ? s4[i0 + u * nthreads] : float4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * nthreads < n4) d4[i0 + u * nthreads] = v[u];
+    }
 }
 
 // the row at scaled time s in [0, kFastS): cubic Lagrange interpolation over the nodes i - 1 .. i + 2, i = floor(s / h)
@@ -843,10 +852,16 @@ __global__ void __launch_bounds__(512) k_traj_phase_dmp(const PhaseArgs a) {    
     float* sDs = sPh + 8 * E;                           // [E][TT] ds of the tile's steps
     float* sP = sDs + E * TT;                           // [E][TT * D] forcing -> pos   (round 5: the rows stay in registers, no row buffer)
     float* sV = sP + a.o_pad;                           // [E][TT * D] vel
-    for (int t = threadIdx.x; t < T; t += blockDim.x) sBT[t] = c.base_times[t];
-    for (int k = threadIdx.x; k < 2 * c.n_total + 3; k += blockDim.x) sCen[k] = c.tab[k];
+    // (first elements of the small tables requested before the row table's copy waits for its loads)
+    const int tid_ = (int)threadIdx.x, bd_ = (int)blockDim.x;
+    const float bt0 = tid_ < T ? c.base_times[tid_] : 0.0f;
+    const double cen0 = tid_ < 2 * c.n_total + 3 ? c.tab[tid_] : 0.0;
     const bool fast = a.h_pad > 0;
-    if (fast) fast_rows_stage(c.rows32, sFast, a.h_pad, threadIdx.x, blockDim.x);
+    if (fast) fast_rows_stage(c.rows32, sFast, a.h_pad, tid_, bd_);
+    if (tid_ < T) sBT[tid_] = bt0;
+    for (int t = tid_ + bd_; t < T; t += bd_) sBT[t] = c.base_times[t];
+    if (tid_ < 2 * c.n_total + 3) sCen[tid_] = cen0;
+    for (int k = tid_ + bd_; k < 2 * c.n_total + 3; k += bd_) sCen[k] = c.tab[k];
     __syncthreads();
     const float inv_d = 1.0f / (float)D;
     const int le = (int)(((float)lane + 0.5f) * inv_d), ld = lane - le * D;        // lane <-> (episode, DoF)
@@ -1021,11 +1036,13 @@ __global__ void __launch_bounds__(512) k_traj_phase_dmp(const PhaseArgs a) {    
 #define MPK_DMP_WG_UNROLL 8        // the Euler loop unrolled: 1 / 4 / 8 -> 33.8 / 32.1 / 30.9 us at 4 096 episodes of cfg3 + learned tau (86 registers, no scratch)
 #endif
 template <int KQ, int NTB>
-__global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_wg(const PhaseArgs a) {   // (four workgroups per CU: 4 096 episodes of cfg3 in one round)
+__global__ void __launch_bounds__(NTB == 5 ? 320 : 256, 4) k_traj_phase_dmp_wg(const PhaseArgs a) {   // (four workgroups per CU: 4 096 episodes of cfg3 in one round)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevCfg& c = a.c;
     // NTB = tiles per block: 4 with chunks of up to four episodes (wave w: tile w), 2 with chunks of up to eight (wave w: tile w % 2
-    // of episodes 4 (w / 2) ..): the four waves always build four rounds of 64 (episode, step) items at once
+    // of episodes 4 (w / 2) ..): the four waves always build four rounds of 64 (episode, step) items at once; 5 = FIVE waves and blocks
+    // of 80 steps where that saves a block (a block costs its rows + two barriers whatever its length: T = 200 is 80 + 80 + 40 instead
+    // of 64 + 64 + 64 + 8 -- 17.5 -> 16.1 us at 2 048 episodes of cfg3 + learned tau; up to two workgroups per CU: the launcher)
     constexpr int KS = KQ * 4, TT = 16, TB = TT * NTB;     // steps per block
     constexpr int MP = MPK_MP_DMP;
     const int lane = threadIdx.x & 63;
@@ -1039,22 +1056,53 @@ __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_wg(const PhaseArgs a)
     float* sX = sBT + a.t_pad;                          // [E][D][KS] columns: weights .., goal, y0, ydot0
     float* sPh = sX + E * a.x_pad;                      // [E][8] tau, delay, init_time (clipped), -, 1 / tau refined (float64), -
     float* sDs = sPh + 8 * E;                           // [E][TB] ds of the block's steps
-    float* sP = sDs + E * TB;                           // [E][TB * D] forcing -> pos   (round 5: the rows stay in registers, no row buffer)
-    float* sV = sP + E * bseg;                          // [E][TB * D] vel
-    for (int t = threadIdx.x; t < T; t += blockDim.x) sBT[t] = c.base_times[t];
-    for (int k = threadIdx.x; k < 2 * c.n_total + 3; k += blockDim.x) sCen[k] = c.tab[k];
-    const bool fast = a.h_pad > 0;
-    if (fast) fast_rows_stage(c.rows32, sFast, a.h_pad, threadIdx.x, blockDim.x);
+    // [E][TB * D] PAIRS (forcing -> pos, tau x vel): the Euler wave leaves a step's two results with ONE 8-byte LDS write (a write costs
+    // the lone wave ~18 cycles whatever its width: 37 of a step's 98 cycles were the two 4-byte ones), the storing waves part them
+    float* sPV = sDs + E * TB;
     const float inv_d = 1.0f / (float)D;
     const int le = (int)(((float)lane + 0.5f) * inv_d), ld = lane - le * D;        // lane <-> (episode, DoF)  (wave 0)
-    const bool vec = a.vec_ok != 0;
     const int nchunks = (a.B + E - 1) / E;
-    for (int ch = (int)blockIdx.x; ch < nchunks; ch += (int)gridDim.x) {
+    // the FIRST chunk's inputs are requested before the tables are staged (one memory round trip under the other: behind the table copy
+    // they were 1 700 of a workgroup's 40 000 cycles at 4 096 episodes, where a workgroup has one chunk)
+    const int ch0 = (int)blockIdx.x;
+    float xf0 = 0.0f, tau0 = c.tau, delay0 = c.delay, it0 = a.init_time_shared;
+    if (ch0 < nchunks) {
+        const int b0 = ch0 * E, ne = min(E, a.B - b0);
+        if ((int)threadIdx.x < ne * D * KS) {
+            const int idx = (int)threadIdx.x, pi = idx / KS, kk = idx - pi * KS;
+            const int e = (int)(((float)pi + 0.5f) * inv_d), dd = pi - e * D;
+            const size_t bb = (size_t)(b0 + e);
+            xf0 = phase_x_value<MP>(c, a.params + bb * P, a.init_pos + bb * D, a.init_vel + bb * D, dd, kk, KS);
+        }
+        if (wave == 0 && lane < ne * D) {
+            const float* prm = a.params + (size_t)(b0 + le) * P;
+            if (c.learn_tau) tau0 = fminf(fmaxf(prm[0], c.tau_lo), c.tau_hi);
+            if (c.learn_delay) delay0 = fminf(fmaxf(prm[c.learn_tau ? 1 : 0], c.delay_lo), c.delay_hi);
+            if (a.init_time) it0 = a.init_time[b0 + le];
+        }
+    }
+    // (first elements of the small tables requested before the row table's copy waits for its loads)
+    const int tid_ = (int)threadIdx.x, bd_ = (int)blockDim.x;
+    const float bt0 = tid_ < T ? c.base_times[tid_] : 0.0f;
+    const double cen0 = tid_ < 2 * c.n_total + 3 ? c.tab[tid_] : 0.0;
+    const bool fast = a.h_pad > 0;
+    if (fast) fast_rows_stage(c.rows32, sFast, a.h_pad, tid_, bd_);
+    if (tid_ < T) sBT[tid_] = bt0;
+    for (int t = tid_ + bd_; t < T; t += bd_) sBT[t] = c.base_times[t];
+    if (tid_ < 2 * c.n_total + 3) sCen[tid_] = cen0;
+    for (int k = tid_ + bd_; k < 2 * c.n_total + 3; k += bd_) sCen[k] = c.tab[k];
+    const bool vec = a.vec_ok != 0;
+    for (int ch = ch0; ch < nchunks; ch += (int)gridDim.x) {
         const int b0 = ch * E, ne = min(E, a.B - b0);
         // (no barrier here: the previous chunk's last block ended with one, and the tables are only read behind the next one -- the
         // chunk's input loads travel together with the table copy: 1 800 of a workgroup's 42 000 cycles at 4 096 episodes)
         MPK_STAMP(1);
-        for (int idx = threadIdx.x; idx < ne * D * KS; idx += blockDim.x) {
+        int idx = (int)threadIdx.x;
+        if (ch == ch0) {
+            if (idx < ne * D * KS) sX[idx] = xf0;
+            idx += (int)blockDim.x;
+        }
+        for (; idx < ne * D * KS; idx += blockDim.x) {
             const int pi = idx / KS, k = idx - pi * KS;             // pi = e * D + dd
             const int e = (int)(((float)pi + 0.5f) * inv_d), dd = pi - e * D;
             const size_t bb = (size_t)(b0 + e);
@@ -1066,10 +1114,14 @@ __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_wg(const PhaseArgs a)
         // row / store phases; rotating the Euler wave over the SIMDs put every chain behind three busy waves: 21.9 -> 23.5 us at 4 096)
         const bool on = wave == 0 && lane < ne * D;
         if (on) {
-            const float* prm = a.params + (size_t)(b0 + le) * P;
-            if (c.learn_tau) tau = fminf(fmaxf(prm[0], c.tau_lo), c.tau_hi);
-            if (c.learn_delay) delay = fminf(fmaxf(prm[c.learn_tau ? 1 : 0], c.delay_lo), c.delay_hi);
-            if (a.init_time) it = a.init_time[b0 + le];
+            if (ch == ch0) {
+                tau = tau0; delay = delay0; it = it0;
+            } else {
+                const float* prm = a.params + (size_t)(b0 + le) * P;
+                if (c.learn_tau) tau = fminf(fmaxf(prm[0], c.tau_lo), c.tau_hi);
+                if (c.learn_delay) delay = fminf(fmaxf(prm[c.learn_tau ? 1 : 0], c.delay_lo), c.delay_hi);
+                if (a.init_time) it = a.init_time[b0 + le];
+            }
             if (ld == 0) {
                 sPh[8 * le] = tau; sPh[8 * le + 1] = delay; sPh[8 * le + 2] = it;
                 *reinterpret_cast<double*>(sPh + 8 * le + 4) = make_pos_div((double)tau).y;
@@ -1125,7 +1177,7 @@ __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_wg(const PhaseArgs a)
                             for (int i = 0; i < 4; ++i) acc[i] = fmaf(h[k], x[i][k], acc[i]);
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            if (d0 + i < D) sP[e * bseg + tb * D + d0 + i] = acc[i];
+                            if (d0 + i < D) sPV[2 * (e * bseg + tb * D + d0 + i)] = acc[i];
                     }
                 }
             }
@@ -1134,8 +1186,7 @@ __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_wg(const PhaseArgs a)
             if (bi_ < 8) MPK_STAMP(11 + 4 * bi_);
             // ---- B: wave 0: the block's Euler steps of every (episode, DoF) of the chunk (one rounding per operation)
             if (on) {
-                float* pp = sP + le * bseg + ld;
-                float* pv = sV + le * bseg + ld;
+                float* pq = sPV + 2 * (le * bseg + ld);          // the lane's (pos, tau x vel) pairs, 2 D floats apart per step
                 const float* pds = sDs + le * TB;
                 // round 5: 8-step pieces every step of which advances the state take their forcing values and step sizes into
                 // registers first (the loop form reads each forcing value behind the previous step's write to the same image: an LDS
@@ -1150,21 +1201,19 @@ __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_wg(const PhaseArgs a)
                         dsr[4 * j] = v[0]; dsr[4 * j + 1] = v[1]; dsr[4 * j + 2] = v[2]; dsr[4 * j + 3] = v[3];
                     }
 #pragma unroll
-                    for (int i = 0; i < PC; ++i) fr[i] = pp[(tl0 + i) * D];
+                    for (int i = 0; i < PC; ++i) fr[i] = pq[2 * (tl0 + i) * D];
 #pragma unroll
                     // (what a step costs the lone Euler wave, round 5 trace at one workgroup per CU: 98 cycles -- 61 for the five dependent
                     // operations and the reads, 37 for the two LDS writes; a lone wave issues one instruction per 5.6 - 9 cycles)
                     for (int i = 0; i < PC; ++i) {
-                        pp[(tl0 + i) * D] = y;
-                        pv[(tl0 + i) * D] = z;          // (tau x velocity: the division by tau is the storing waves' -- phase C)
+                        *reinterpret_cast<f32x2*>(pq + 2 * (tl0 + i) * D) = f32x2{y, z};      // (tau x velocity: the division by tau is the storing waves')
                         dmp_phase_step(y, z, g, fr[i], dsr[i], c.dmp_alpha, c.dmp_beta);
                     }
                 }
 #pragma unroll 1
                 for (int tl = tl0; tl < rows; ++tl) {
-                    const float f = pp[tl * D];
-                    pp[tl * D] = y;
-                    pv[tl * D] = z;
+                    const float f = pq[2 * tl * D];
+                    *reinterpret_cast<f32x2*>(pq + 2 * tl * D) = f32x2{y, z};
                     if (t0 + tl < T - 1) {
                         const float ds = pds[tl];
                         dmp_phase_step(y, z, g, f, ds, c.dmp_alpha, c.dmp_beta);
@@ -1180,8 +1229,10 @@ __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_wg(const PhaseArgs a)
                 for (int idx = threadIdx.x; idx < ne * n4; idx += blockDim.x) {
                     const int e = idx / n4, q4 = idx - e * n4;
                     const size_t go = ((size_t)(b0 + e) * T + t0) * D + 4 * q4;
-                    const f32x4 vp = *reinterpret_cast<const f32x4*>(sP + e * bseg + 4 * q4);
-                    f32x4 vv = *reinterpret_cast<const f32x4*>(sV + e * bseg + 4 * q4);
+                    const f32x4 pa = *reinterpret_cast<const f32x4*>(sPV + 2 * (e * bseg + 4 * q4));
+                    const f32x4 pb = *reinterpret_cast<const f32x4*>(sPV + 2 * (e * bseg + 4 * q4) + 4);
+                    const f32x4 vp = {pa[0], pa[2], pb[0], pb[2]};
+                    f32x4 vv = {pa[1], pa[3], pb[1], pb[3]};
                     const TauDiv tde = make_tau_div(sPh[8 * e]);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) vv[q] = div_tau(vv[q], tde);
@@ -1192,9 +1243,10 @@ __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_wg(const PhaseArgs a)
                 for (int idx = threadIdx.x; idx < ne * n; idx += blockDim.x) {
                     const int e = idx / n, w = idx - e * n;
                     const size_t go = ((size_t)(b0 + e) * T + t0) * D + w;
-                    const float vel = div_tau(sV[e * bseg + w], make_tau_div(sPh[8 * e]));
-                    if (a.wt) { store4<true>(a.pos + go, sP[e * bseg + w]); store4<true>(a.vel + go, vel); }
-                    else { store4<false>(a.pos + go, sP[e * bseg + w]); store4<false>(a.vel + go, vel); }
+                    const f32x2 pr = *reinterpret_cast<const f32x2*>(sPV + 2 * (e * bseg + w));
+                    const float vel = div_tau(pr[1], make_tau_div(sPh[8 * e]));
+                    if (a.wt) { store4<true>(a.pos + go, pr[0]); store4<true>(a.vel + go, vel); }
+                    else { store4<false>(a.pos + go, pr[0]); store4<false>(a.vel + go, vel); }
                 }
             }
             if (bi_ < 8) MPK_STAMP(13 + 4 * bi_);
@@ -1427,6 +1479,11 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
                 wgE = 8; wgNTB = 2;
                 chunks = ((long)pa.B + 7) / 8;
             }
+            // five waves, blocks of 80 steps: where that is a block fewer and a CU holds at most two workgroups (with four, the 20 waves did
+            // not fit the CU's SIMDs -- 4 096 episodes 29.7 us against 20.1; "tiles_wpb" 4: the four-wave geometry, for A/B runs)
+            if (wg_ok && wgNTB == 4 && KQ == 2 && (c.T + 79) / 80 < (c.T + 63) / 64 && wg_bytes(wgE, 5) * 4 <= kLdsPerCu &&
+                chunks <= (long)num_cu * 2 && tune.tiles_wpb != 4)
+                wgNTB = 5;
             const size_t wg_lds = wg_bytes(wgE, wgNTB);
             const int wg_res = wg_resident(wg_lds);
             // (beyond ONE round of resident workgroups the wave-per-chunk kernel is as fast: cfg3' at 6 144 episodes in chunks of
@@ -1441,11 +1498,12 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
                         hipError_t e = allow_full_lds(kern);
                         if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return MPK_EHIP; }
                     }
-                    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), wg_lds, (hipStream_t)stream, pa);
+                    hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(wgNTB == 5 ? 320 : 256), wg_lds, (hipStream_t)stream, pa);
                     MPK_LAUNCH_CHECK();
                     return MPK_OK;
                 };
                 *kernel_name = "k_traj_phase<dmp,wg>";
+                if (wgNTB == 5) return gow(k_traj_phase_dmp_wg<2, 5>);
                 if (wgNTB == 4) return KQ == 2 ? gow(k_traj_phase_dmp_wg<2, 4>) : gow(k_traj_phase_dmp_wg<4, 4>);
                 return KQ == 2 ? gow(k_traj_phase_dmp_wg<2, 2>) : gow(k_traj_phase_dmp_wg<4, 2>);
             }

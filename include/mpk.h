@@ -224,7 +224,8 @@ int mpk_set_duration(mpk_handle h, double duration, double dt);
  *   "split"         1 force the tile-major closed-loop kernel with a serial role (k_traj_split; never chosen automatically)
  *   "lds_pad"       n KB of unused dynamic LDS per workgroup of the tile-major kernels (occupancy experiments: 160 KB per CU)
  *   "tiles_wpb"     1 .. 4 waves per workgroup of the tile-major kernels (4); 4 / 8: waves per workgroup of k_episode_return (by its
- *                   LDS: eight where that puts more waves on a CU)
+ *                   LDS: eight where that puts more waves on a CU); 4: k_traj_phase<dmp,wg> in four-wave workgroups where it would
+ *                   take five (blocks of 80 steps)
  *   "serial_order"  k_traj_quad / duo / mono: 0 persistent workgroups, XCD-contiguous unit ranges; 1 short-lived workgroups in
  *                   address order (one unit per wave); 2 persistent, units b, b + grid, ... without the XCD remap
  *   "ring"          0 off, 1 force the persistent producer / store-engine kernel (k_traj_ring: open-loop promp / prodmp with a

@@ -674,13 +674,13 @@ int mpk_create(const mpk_config* cfg, mpk_handle* out) {
     if (rc != MPK_OK) return fail(rc);
     fill_devcfg(h);
     if (const int nf = fast_rows_floats(h->dev)) {
-        // DMP: the per-episode-phase kernels' interpolation table of the forcing rows, by the device's own row functions (the table IS
-        // the exact rows at its nodes) -- a function of the configuration alone
+        // DMP: the per-episode-phase kernels' interpolation table of the forcing rows, by the device's own row functions (the
+        // table IS the exact rows at its nodes) -- a function of the configuration alone
         if (hipMalloc((void**)&h->d_rows32, (size_t)nf * sizeof(float)) != hipSuccess) { set_error("hipMalloc(forcing-row table) failed"); return fail(MPK_EHIP); }
         rc = launch_fast_rows_table(h->dev, h->d_rows32, nullptr);
         if (rc != MPK_OK) return fail(rc);
         if (hipDeviceSynchronize() != hipSuccess) { set_error("forcing-row table kernel failed"); return fail(MPK_EHIP); }
-        h->rows32_stride = 8;
+        h->rows32_stride = fast_rows_stride(h->dev);
         fill_devcfg(h);
     }
     rc = prealloc_cache(h);

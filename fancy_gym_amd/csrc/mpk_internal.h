@@ -59,7 +59,8 @@ struct DevCfg {
     // device tables
     const double* tab;             // ProDMP: [y1|y2|dy1|dy2|pos_basis|vel_basis|weights_goal_scale]; RBF: [centers|bw]
     const float* rows32;           // ProDMP, <= 16 columns: [n_pc][2*KS + 4] = [Psi_0..Psi_nb 0.. y1 y2 | dPsi.. 0.. dy1 dy2 | lo x 4]
-    int rows32_stride;             // 2*KS + 4 floats (KS = 8 or 16)
+    int rows32_stride;             // 2*KS + 4 floats (KS = 8 or 16); DMP handles: the per-episode kernels' interpolation table
+                                   // of the forcing rows over the scaled time, [515][stride = 8] (mpk_traj_phase.hip fast_rows_build)
     const float* base_times;       // [T]
     float t_last;                  // base_times[T - 1] (host side: bounds the scaled time a launch can reach)
 };
@@ -116,7 +117,8 @@ int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const f
                       double* qd, const int32_t* n_steps, float* actions, int B, int T, void* stream,
                       const Tuning& tune);
 // per-episode-phase DMP: the interpolation table of the forcing rows (mpk_traj_phase.hip fast_rows_build), built once per handle
-int fast_rows_floats(const DevCfg& c);
+int fast_rows_floats(const DevCfg& c);      // 0: none for this shape
+int fast_rows_stride(const DevCfg& c);      // floats per node = the consuming kernels' KS
 int launch_fast_rows_table(const DevCfg& c, float* out, void* stream);
 // MPK_DMP_FIRST_IS_STEP: (init_pos, init_vel) advanced by one Euler step from init_time to the first grid time
 int launch_dmp_prestep(const DevCfg& c, const float* params, const float* init_pos, const float* init_vel,

@@ -234,8 +234,11 @@ template <int KS>
 __device__ __forceinline__ void fast_rows_build(const DevCfg& c, const double* cen, float* tab, const int tid, const int nthreads) {
     for (int j = tid; j < kFastRows; j += nthreads) {
         const double s = (double)(j - 1) * (double)(kFastS / kFastN);
+        // the phase's SMOOTH continuation on both sides of its range (node -1 below 0; linear phase: beyond its clip at 1 -- the items look
+        // up min(s, 1), whose neighbours must not carry the clip's kink: with them clipped the rows within one node of s = 1 were off by
+        // 2.5e-4 of their slope, 2.5e-6 of the velocity scale on cfg3 with a linear phase)
         double x;
-        if (c.phase_type == MPK_PHASE_LINEAR) x = s < 1.0 ? s : 1.0;                   // (node -1: the smooth continuation below 0)
+        if (c.phase_type == MPK_PHASE_LINEAR) x = s;
         else x = s >= 0.0 ? exp_nonpos(-(double)c.alpha_phase * s) : div_pos(1.0, exp_nonpos((double)c.alpha_phase * s));
         float h[KS];
 #pragma unroll
@@ -253,6 +256,8 @@ __device__ __forceinline__ void fast_rows_build(const DevCfg& c, const double* c
 __global__ void __launch_bounds__(256) k_fast_rows_table(const DevCfg c, float* __restrict__ out) {
     fast_rows_build<8>(c, c.tab, out, (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(gridDim.x * blockDim.x));
 }
+// the scaled time an item looks up: a linear phase is clipped at 1 (the table holds the smooth continuation beyond it, see fast_rows_build)
+__device__ __forceinline__ float fast_rows_arg(const DevCfg& c, const float s) { return c.phase_type == MPK_PHASE_LINEAR ? fminf(s, 1.0f) : s; }
 __device__ __forceinline__ void fast_rows_stage(const float* __restrict__ src, float* dst, const int n, const int tid, const int nthreads) {
     // (four loads in flight per thread before the first LDS write waits for one: a loop of load -> write is a memory round trip per pass)
     const float4* s4 = reinterpret_cast<const float4*>(src);
@@ -763,9 +768,9 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
                     hq[2 * KS - 2] = (float)fma(bcc, y2, -(bcd * y1));
                     hq[2 * KS - 1] = (float)fma(bcc, dy2, -(bcd * dy1));
                 } else {
-                    const double x = phase_f64(c, time, taud, delay, ec);
 #pragma unroll
                     for (int k = 0; k < KS; ++k) h[k] = 0.0f;
+                    const double x = phase_f64(c, time, taud, delay, ec);
                     rbf_row<KS>(c, sCen, sCen + c.n_total, x, (double)c.ws, h, ec);
                     const int th = t < T - 1 ? t + 1 : T - 1, tl = t < T - 1 ? t : T - 2;
                     rdt = 1.0f / ((sBT[th] + it) - (sBT[tl] + it));
@@ -914,8 +919,8 @@ __global__ void __launch_bounds__(512) k_traj_phase_dmp(const PhaseArgs a) {    
                     const float taue = sPh[8 * e], delaye = sPh[8 * e + 1], ite = sPh[8 * e + 2];
                     const float time = sBT[t] + ite;
                     const float s_item = scaled_time(time, delaye, taue);
-                    if (KS == 8 && fast && s_item < kFastS) {
-                        if constexpr (KS == 8) fast_rows_eval<KS>(sFast, s_item, h);
+                    if (KS == 8 && fast && fast_rows_arg(c, s_item) < kFastS) {
+                        if constexpr (KS == 8) fast_rows_eval<KS>(sFast, fast_rows_arg(c, s_item), h);
                     } else {
                         const PosDiv taud{(double)taue, *reinterpret_cast<const double*>(sPh + 8 * e + 4)};
                         const double x = phase_f64(c, time, taud, delaye, ExpLiteral());
@@ -1148,8 +1153,8 @@ __global__ void __launch_bounds__(NTB == 5 ? 320 : 256, 4) k_traj_phase_dmp_wg(c
                     const float taue = sPh[8 * e], delaye = sPh[8 * e + 1], ite = sPh[8 * e + 2];
                     const float time = sBT[t] + ite;
                     const float s_item = scaled_time(time, delaye, taue);
-                    if (KS == 8 && fast && s_item < kFastS) {
-                        if constexpr (KS == 8) fast_rows_eval<KS>(sFast, s_item, h);
+                    if (KS == 8 && fast && fast_rows_arg(c, s_item) < kFastS) {
+                        if constexpr (KS == 8) fast_rows_eval<KS>(sFast, fast_rows_arg(c, s_item), h);
                     } else {
                         const PosDiv taud{(double)taue, *reinterpret_cast<const double*>(sPh + 8 * e + 4)};
                         const double x = phase_f64(c, time, taud, delaye, ExpLiteral());
@@ -1256,9 +1261,13 @@ __global__ void __launch_bounds__(NTB == 5 ? 320 : 256, 4) k_traj_phase_dmp_wg(c
 }
 
 #ifndef MPK_DEVICE_ONLY
-int fast_rows_floats(const DevCfg& c) {          // 0: no interpolation table for this shape (more than five basis functions)
-    return c.mp_type == MPK_MP_DMP && c.KT + 3 <= 8 ? kFastRows * 8 : 0;
+int fast_rows_stride(const DevCfg& c) {          // 0: no interpolation table for this shape; else the kernels' KS (floats per node)
+    // dmp: up to five basis functions in eight columns (where the error bound was derived).  ProMP was tried (round 5) and dropped: its
+    // velocity is the forward difference of the positions, which multiplies the table's 1e-6 by 2 / dt -- 2e-5 of the velocity scale on
+    // cfg5' for 5 - 10 % of the kernel's time (its rows are two exponentials by the product recurrence already)
+    return c.mp_type == MPK_MP_DMP && c.KT + 3 <= 8 ? 8 : 0;
 }
+int fast_rows_floats(const DevCfg& c) { return kFastRows * fast_rows_stride(c); }
 int launch_fast_rows_table(const DevCfg& c, float* out, void* stream) {
     hipLaunchKernelGGL(k_fast_rows_table, dim3((kFastRows + 255) / 256), dim3(256), 0, (hipStream_t)stream, c, out);
     MPK_LAUNCH_CHECK();

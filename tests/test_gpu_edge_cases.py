@@ -518,6 +518,34 @@ def test_batches_beyond_2_31_output_elements():
     big_batch_check.main()
 
 
+@pytest.mark.parametrize("phase", ["linear", "exp"])
+def test_per_episode_dmp_interpolated_rows_across_the_phase_clip(phase, mpk_option):
+    """the per-episode DMP kernels interpolate their forcing rows in a table over the scaled time (one per handle); a LINEAR phase is clipped
+    at 1, and the nodes beyond the clip must hold the rows' smooth continuation (items look up min(s, 1)) -- with them clipped too the
+    rows within one node of s = 1 were off by 2.5e-6 of the velocity scale (round 5).  Learned tau down to a quarter of the horizon:
+    every episode crosses the clip; table against exact rows within 5e-7 of the scale, both kernels, and the oracle"""
+    pc = O.PhaseCfg(phase, tau=4.0, alpha_phase=2.0, learn_tau=True, tau_bound=(1.0, 4.0))
+    bc = O.BasisCfg("rbf", num_basis=5)
+    tc = O.TrajCfg("dmp", action_dim=7, alpha=25.0)
+    dt, dur = 0.02, 4.0
+    eng = make_engine(pc, bc, tc, dt, dur)
+    B = 6000
+    params, ip, iv = inputs(pc, bc, tc, B, seed=11)
+    params[:, 0] = np.linspace(1.0, 4.0, B, dtype=np.float32)
+    for flat in (1, 0):
+        mpk_option("phase_flat", flat)
+        mpk_option("phase_table", 0)
+        p0, v0 = (x.double().clone() for x in eng.trajectory(params, ip, iv, 0.0))
+        mpk_option("phase_table", 1)
+        p1, v1 = (x.double() for x in eng.trajectory(params, ip, iv, 0.0))
+        assert eng.last_kernel() == ("k_traj_phase<dmp,wg>" if flat else "k_traj_phase<dmp>"), eng.last_kernel()
+        ep = float((p1 - p0).abs().max() / p0.abs().max()); ev = float((v1 - v0).abs().max() / v0.abs().max())
+        assert ep <= 5e-7 and ev <= 5e-7, (phase, flat, ep, ev)
+    n = 64
+    rp, rv = O.get_trajectory(pc, bc, tc, params[:n], dur, dt, 0.0, ip[:n], iv[:n], dtype=np.float64)
+    close(p1[:n].float().cpu().numpy(), rp, "pos"); close(v1[:n].float().cpu().numpy(), rv, "vel")
+
+
 @pytest.mark.parametrize("B", [1, 37, 2500, 9001])
 def test_prodmp_seven_dof_unrolled_chains_same_bits(B, mpk_option):
     """k_traj_phase<prodmp> at seven DoF and <= 8 columns runs instantiations with the DoF chains unrolled side by side (round 5);

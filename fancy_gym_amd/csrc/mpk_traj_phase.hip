@@ -425,6 +425,37 @@ __device__ __forceinline__ void dofs_unrolled(const float* __restrict__ sX, cons
     }
 }
 
+// ... and ProMP's: position chains side by side, then each DoF's forward difference over the lanes (lane_above / lane_below, see there)
+template <int DC, int KQ>
+__device__ __forceinline__ void dofs_unrolled_promp(const float* __restrict__ sX, const float (&h)[KQ * 4], const float rdt, const bool last_row,
+                                                    float* __restrict__ o0, float* __restrict__ o1) {
+    constexpr int KS = KQ * 4;
+    float x[DC][KS];
+#pragma unroll
+    for (int d = 0; d < DC; ++d)
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(sX + d * KS + 4 * j);
+            x[d][4 * j + 0] = v.x; x[d][4 * j + 1] = v.y; x[d][4 * j + 2] = v.z; x[d][4 * j + 3] = v.w;
+        }
+    float p[DC];
+#pragma unroll
+    for (int d = 0; d < DC; ++d) p[d] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+#pragma unroll
+        for (int d = 0; d < DC; ++d) p[d] = fmaf(h[k], x[d][k], p[d]);
+#pragma unroll
+    for (int d = 0; d < DC; ++d) {
+        const float nx = lane_above(p[d]);
+        float v = (nx - p[d]) * rdt;
+        const float pv = lane_below(v);         // last row repeats the difference before it
+        if (last_row) v = pv;
+        o0[d] = p[d];
+        o1[d] = v;
+    }
+}
+
 // DC: the DoF count at compile time (0: c.D) -- the per-DoF contraction loop then is straight-line code: at run time it was 162
 // instructions per pair of DoF, 85 of them scalar address arithmetic (round 5; 7 = BASELINE cfg2 / cfg4, the reference's Panda tasks)
 template <int MP, int KQ, bool TL, bool FL = false, int DC = 0>
@@ -810,6 +841,8 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
                 };
                 if constexpr (DC > 0 && MP == MPK_MP_PRODMP) {
                     dofs_unrolled<DC, KQ>(sXe, hq, inv_tau, sO0 + sh + lane * DC, sO1 + sh + lane * DC);
+                } else if constexpr (DC > 0 && MP == MPK_MP_PROMP) {
+                    dofs_unrolled_promp<DC, KQ>(sXe, h, rdt, r0 + lane == T - 1, sO0 + sh + lane * DC, sO1 + sh + lane * DC);
                 } else {
                     constexpr int ND = KQ <= 2 ? 2 : 1;
                     int d = 0;
@@ -1461,6 +1494,8 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
             return KQ == 2 ? go(k_traj_phase<MPK_MP_PRODMP, 2, false>) : go(k_traj_phase<MPK_MP_PRODMP, 4, false>);
         case MPK_MP_PROMP:
             *kernel_name = "k_traj_phase<promp>";
+            if (c.D == 7 && KQ <= 2 && tune.pd_generic != 1)      // (seven DoF: the DoF chains unrolled side by side, as prodmp's)
+                return KQ == 1 ? go(k_traj_phase<MPK_MP_PROMP, 1, false, false, 7>) : go(k_traj_phase<MPK_MP_PROMP, 2, false, false, 7>);
             if (KQ == 1) return go(k_traj_phase<MPK_MP_PROMP, 1, false>);
             return KQ == 2 ? go(k_traj_phase<MPK_MP_PROMP, 2, false>) : go(k_traj_phase<MPK_MP_PROMP, 4, false>);
         default: {

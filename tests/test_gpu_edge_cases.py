@@ -572,6 +572,29 @@ def test_prodmp_seven_dof_unrolled_chains_same_bits(B, mpk_option):
     close(p1[:n].cpu().numpy(), rp, "pos"); close(v1[:n].cpu().numpy(), rv, "vel")
 
 
+@pytest.mark.parametrize("nb,zero_start", [(3, 1), (6, 0)])
+@pytest.mark.parametrize("B", [1, 130, 5000])
+def test_promp_seven_dof_unrolled_chains_same_bits(B, nb, zero_start, mpk_option):
+    """k_traj_phase<promp> at seven DoF (four / eight columns): the DoF chains unrolled side by side against the run-time DoF loop
+    ("pd_generic" 1) -- same bits (positions AND the forward-difference velocity across the rounds of 63 steps), and the oracle"""
+    dt, dur = 0.008, 2.8
+    pc = O.PhaseCfg("linear", tau=dur, learn_tau=True, learn_delay=True, tau_bound=(0.5, dur), delay_bound=(0.05, 0.15))
+    bc = O.BasisCfg("zero_rbf" if zero_start else "rbf", num_basis=nb, num_basis_zero_start=zero_start, num_basis_zero_goal=zero_start)
+    tc = O.TrajCfg("promp", action_dim=7)
+    eng = make_engine(pc, bc, tc, dt, dur)
+    params, ip, iv = inputs(pc, bc, tc, B, seed=B + nb)
+    mpk_option("pd_generic", "1")
+    p0, v0 = (x.clone() for x in eng.trajectory(params, ip, iv, 0.0))
+    assert eng.last_kernel() == "k_traj_phase<promp>", eng.last_kernel()
+    mpk_option("pd_generic", "0")
+    p1, v1 = eng.trajectory(params, ip, iv, 0.0)
+    torch.cuda.synchronize()
+    assert torch.equal(p0, p1) and torch.equal(v0, v1)
+    n = min(B, 32)
+    rp, rv = O.get_trajectory(pc, bc, tc, params[:n], dur, dt, 0.0, ip[:n], iv[:n], dtype=np.float64)
+    close(p1[:n].cpu().numpy(), rp, "pos"); close(v1[:n].cpu().numpy(), rv, "vel", atol=fd_atol(rp, dt))
+
+
 @pytest.mark.parametrize("name", ["prodmp_learn_tau_delay", "cfg2_learn_tau"])
 def test_prodmp_row_table_in_lds_or_l2_same_bits(name, monkeypatch, mpk_option):
     """k_traj_phase<prodmp> gathers its fp32 rows from an LDS copy of the table when that fits beside 8 waves, else

@@ -746,7 +746,7 @@ const OptKey kOptKeys[] = {
     {"serial_order", &Tuning::serial_order, 0, 2}, {"ring_nc", &Tuning::ring_nc, 1, 6},
     {"pd_generic", &Tuning::pd_generic, 0, 1},   {"dmp_response", &Tuning::dmp_response, 0, 1},
     {"ablations", &Tuning::ablations, 0, 1},     {"ring_tb", &Tuning::ring_tb, 1, 64},
-    {"pd_helper", &Tuning::pd_helper, 0, 1},
+    {"pd_helper", &Tuning::pd_helper, 0, 1},     {"phase_waves", &Tuning::phase_waves, 1, 32},
 };
 const OptKey* find_opt(const char* key) {
     if (!key) return nullptr;

@@ -1445,11 +1445,20 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
             shared_bytes += tab_bytes;
             wpb = (int)((kLdsPerCu - shared_bytes) / wave_bytes);
             wpb = wpb > 16 ? 16 : wpb;
+            // Fewer waves per CU for large launches of the flat rounds: every wave writes its own chunk's run of HBM, and sixteen streams
+            // per CU write slower than eight (round 5, alternating rounds on three boxes; workgroups of four waves = two workgroups per
+            // CU by the table's LDS: 65 536 episodes 87.5 / 102.6 us with sixteen waves per workgroup, 74.7 / 90.8 with four; 262 144:
+            // 368 -> 350; against workgroups of eight: 24 576 28.7 -> 27.2, 32 768 41.0 -> 35.8, 131 072 167 -> 158, 262 144 288 -> 281;
+            // workgroups of two lose again: 302.  At 16 384 and below the sixteen are faster: 21.5 against 23.0).
+            // "tiles_wpb" 1 .. 8 sets the cap itself (A/B runs).
+            if (tune.tiles_wpb > 0) wpb = wpb > tune.tiles_wpb ? tune.tiles_wpb : wpb;
+            else if (flat && wpb > 4 && pa.B >= 24576) wpb = 4;
         }
     }
     size_t lds = wave_bytes * wpb + shared_bytes;
     int per_cu = (int)(kLdsPerCu / lds);
     per_cu = per_cu > 32 / wpb ? 32 / wpb : per_cu;
+    if (tune.phase_waves > 0 && per_cu * wpb > tune.phase_waves) per_cu = tune.phase_waves / wpb > 1 ? tune.phase_waves / wpb : 1;
     if (!dmp && !modelled) {
         // chunks cost balance (a wave's work is quantised in E episodes): only when every resident wave still gets >= 4
         const long resident = (long)num_cu * per_cu * wpb;

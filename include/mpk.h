@@ -214,6 +214,8 @@ int mpk_set_duration(mpk_handle h, double duration, double dt);
  *   "dmp_response"  0 DMP with a shared phase on the serial explicit-Euler kernels (k_traj_quad / duo / mono / stream<dmp>) instead of
  *                   the contraction of the Euler map's response rows (the default where that map is stable: alpha ds <= 1, and the
  *                   shape fits the matrix-core kernels; kernel names read <dmp_resp..>)
+ *   "phase_waves"   1 .. 32: at most that many waves of a per-episode-phase kernel (k_traj_phase<..>) resident on a CU (A/B runs: large
+ *                   launches write faster from fewer streams)
  *   "pd_helper"     1 the reward rollout's control-cost pass on two helper waves of a six-wave workgroup instead of on the chain waves
  *                   (measured slower at every size: never automatic)
  *   "pd_generic"    1 the tile rollout kernels (2 / 5 / 7 DoF) and the per-episode ProDMP kernels (7 DoF) without their
@@ -225,7 +227,7 @@ int mpk_set_duration(mpk_handle h, double duration, double dt);
  *   "lds_pad"       n KB of unused dynamic LDS per workgroup of the tile-major kernels (occupancy experiments: 160 KB per CU)
  *   "tiles_wpb"     1 .. 4 waves per workgroup of the tile-major kernels (4); 4 / 8: waves per workgroup of k_episode_return (by its
  *                   LDS: eight where that puts more waves on a CU); 4: k_traj_phase<dmp,wg> in four-wave workgroups where it would
- *                   take five (blocks of 80 steps)
+ *                   take five (blocks of 80 steps); 1 .. 8: at most that many waves per workgroup of k_traj_phase<prodmp,lds>
  *   "serial_order"  k_traj_quad / duo / mono: 0 persistent workgroups, XCD-contiguous unit ranges; 1 short-lived workgroups in
  *                   address order (one unit per wave); 2 persistent, units b, b + grid, ... without the XCD remap
  *   "ring"          0 off, 1 force the persistent producer / store-engine kernel (k_traj_ring: open-loop promp / prodmp with a

@@ -500,7 +500,7 @@ def test_round4_option_keys_and_their_ranges():
     """the store-engine launch geometry (ring*), the tile-major workgroup size and the two-group rollout are options with ranges"""
     lib = _lib.load()
     ranges = {"ring": (0, 2), "ring_np": (1, 14), "ring_ns": (1, 8), "ring_m": (1, 8), "ring_parts": (1, 8), "ring_nc": (1, 6), "ring_dbg": (0, 255),
-              "tiles_wpb": (1, 8), "pd_quad": (0, 3)}
+              "tiles_wpb": (1, 8), "pd_quad": (0, 3), "phase_waves": (1, 32)}
     for key, (lo, hi) in ranges.items():
         assert key in _lib.OPTION_KEYS
         for v in (lo, hi):

@@ -19,7 +19,7 @@ python tools/pmc_traffic_json.py gpurun_out/pmct_FETCH_SIZE gpurun_out/pmct_WRIT
 python tools/sweep.py > $O/sweep.md 2> $O/sweep.err
 python tools/closed_bench.py 2048 4096 8192 16384 65536 2>&1 | grep -v amdgpu > $O/closed.md
 python tools/rollout_bench.py 4096 8192 16384 65536 2>&1 | grep -v amdgpu > $O/rollout.md
-python tools/phase_bench.py > $O/phase.md 2>&1
+python tools/phase_bench.py 2048 4096 8192 16384 65536 262144 2>&1 | grep -v amdgpu > $O/phase.md
 python tools/dmp_bench.py 2>&1 | grep -v amdgpu > $O/dmp_response.md
 python tools/episode_bench.py 2>&1 | grep -v amdgpu > $O/episode_return.md
 python tools/wide_bench.py > $O/wide.md 2>&1

@@ -576,6 +576,7 @@ int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
         const int units = (pa.G + ng - 1) / ng;
         int blocks = (units + 3) / 4;
         if (blocks > 2048) blocks = 2048;
+        if (tune.phase_waves > 0 && blocks > 64 * tune.phase_waves) blocks = 64 * tune.phase_waves;   // (A/B runs: waves per CU)
         if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;
         // helper waves for the control-cost pass (k_pd_rollout_tiles<.., HW>): built, tested, measured SLOWER, therefore only on request
         // ("pd_helper" 1).  LongSimpleReacher + reward, us without / with helpers: 2 048 episodes 19.8 / 20.7, 4 096: 23.5 / 25.0,
@@ -649,6 +650,13 @@ int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const f
         const int units = (pa.G + ng - 1) / ng;
         int blocks = (units + 3) / 4;
         if (blocks > 2048) blocks = 2048;
+        // Beyond the caches ONE workgroup of four waves per CU instead of eight (round 5): the persistent waves walk the units in order,
+        // and fewer read / write streams per CU stream faster -- cfg2 shape 131 072 / 262 144 / 524 288 episodes 235 / 497 / 991 ->
+        // 225 / 448 / 870 us, LongSimpleReacher shape 65 536 / 131 072: 186 / 361 -> 172 / 328; neutral at 400 MB, slower below
+        // (16 384 episodes of the reacher shape: 37 -> 43 us).  Uneven numbers of workgroups per CU lose (192, 384 blocks), two waves per
+        // CU lose half.  The reward variant needs its occupancy (794 -> 897 us at 262 144) and keeps eight.  "phase_waves": A/B runs.
+        if (tune.phase_waves > 0) { if (blocks > 64 * tune.phase_waves) blocks = 64 * tune.phase_waves; }
+        else if ((double)B * T * D * 12.0 >= 512.0 * 1024 * 1024 && blocks > 256) blocks = 256;
         if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;
         const size_t lds = (size_t)4 * ng * 3 * kStageStride * sizeof(float);
         auto by_ng = [&](auto dc_tag) {

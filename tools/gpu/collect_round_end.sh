@@ -1,0 +1,23 @@
+#!/bin/bash
+# Copies what `tools/gpu/round_end.sh <tag>` left under gpurun_out/<tag>/ into profiles/<tag>_* (run in the build container after the call).
+TAG=${1:-r05}
+O=gpurun_out/$TAG
+P=profiles/${TAG}
+cp $O/bench_k20.json ${P}_bench_line.json; cp $O/bench_default.json ${P}_bench_line_default.json
+cp $O/bench_g2.json ${P}_bench_line_gloo2.json; cp $O/bench_k20_rccl1.json ${P}_bench_line_rccl1.json
+cp $O/prof_bench/bench_kernel_stats.csv ${P}_bench_kernel_stats.csv; cp $O/prof_bench/bench_kernel_trace.csv.gz ${P}_bench_kernel_trace.csv.gz
+cp $O/timed_region.txt ${P}_timed_region.txt
+cp $O/pmc_traffic.json ${P}_pmc_traffic.json; cp $O/pmc_traffic.json profiles/pmc_traffic.json; cp $O/pmc_traffic.txt ${P}_pmc_traffic.txt
+cp $O/sweep.md ${P}_sweep.md; cp $O/closed.md ${P}_closed_loop.md; cp $O/rollout.md ${P}_rollout_tables.md
+cp $O/dmp_response.md ${P}_dmp_response.md; cp $O/episode_return.md ${P}_episode_return.md; cp $O/wide.md ${P}_wide.md; cp $O/replan.log ${P}_replan.log
+cat $O/pytest.log $O/smoke.log > ${P}_gpu_tests.txt
+grep "^|" $O/phase.md > ${P}_per_episode_phase_table.md
+python - <<PY
+import json
+for f in ("${P}_bench_line.json", "${P}_bench_line_default.json", "${P}_bench_line_rccl1.json"):
+    d = json.loads(open(f).read().strip().split("\n")[-1]); r = d["roofline"]; rs = d.get("roofline_streaming") or {}
+    print(f, "value %.4g" % d["value"], "ms %.5f" % d["ms_per_step"], "kernel_avg_us %.2f" % r["kernel_avg_us"], "frac %.3f" % r["frac"], "traffic", r["traffic"],
+          "| streaming frac", rs.get("frac"), rs.get("kernel_avg_us"), rs.get("box_fill_GBps"), "| cpu %.4g" % (d.get("cpu_baseline") or {}).get("value", 0), d.get("kernel_avg_us_max"))
+d = json.load(open("${P}_pmc_traffic.json")); print(d["_provenance"][:40], {k: (v["kernel"], v["hbm_bytes_per_launch"]) for k, v in d.items() if k != "_provenance"})
+PY
+head -3 ${P}_bench_kernel_stats.csv | cut -c1-110; tail -7 ${P}_timed_region.txt; cat ${P}_gpu_tests.txt

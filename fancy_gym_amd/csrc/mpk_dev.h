@@ -87,6 +87,9 @@ constexpr double kWtBytes = 300.0 * 1024 * 1024;
 // ring): trajectory only 57 344 (321 MB) 76.3 / 76.6, 65 536 (367 MB) 85.5 / 82.4, 81 920: 105.2 / 99.6; + actions 40 960 (353 MB)
 // 77.2 - 80.4 / 77.0, 49 152 (424 MB) 92.7 / 87.9 -- the ring from 346 MB on (was 440)
 constexpr double kRingBytes = 330.0 * 1024 * 1024;
+// ... and trajectory-only launches of the shapes k_traj_flat takes: the flat kernel at two workgroups per CU stays ahead of the ring up to
+// ~3 GB (round 5; mpk_traj_launch.hip)
+constexpr double kRingTrajBytes = 4096.0 * 1024 * 1024;
 // a ticket of k_traj_ring covers at least this many bytes of batch buffers: one device counter hands out ~88 tickets / us
 // (profiles/r04_store_engine_probe_dynamic.md), 32768 tickets of 67 KB saturate it, 10923 of 201 KB do not
 constexpr size_t kRingTicketBytes = 192 * 1024;

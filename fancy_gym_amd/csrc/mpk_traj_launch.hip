@@ -389,7 +389,12 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     bool ring = false;
     {
         const bool forced_other = tune.flat == 1 || tune.bulk >= 0 || tune.quad >= 0 || tune.pipe == 1 || tune.split == 1 || ov == 1;
-        const bool want = tune.ring == 1 || (tune.ring < 0 && !forced_other && out_bytes > kRingBytes);
+        // (trajectory-only launches that k_traj_flat takes -- two workgroups of whole-trajectory images per CU, see below -- stay there
+        // up to kRingTrajBytes: round 5, cfg2's shape, us flat / ring: 65 536 episodes 68.8 / 80.4, 131 072: 134.7 / 149.3, 262 144:
+        // 259.5 / 282.7, 524 288: 533.8 / 551.9, 1 048 576: 1 151 / 1 092.  With actions the ring stays ahead from kRingBytes on.)
+        const bool flat_takes_it = !act && !closed && c.mp_type != MPK_MP_DMP && ptr_ok && (c.T * c.D) % 4 == 0 && tune.flat != 0 &&
+                                   table_bytes + (size_t)4 * nst * (((size_t)NTW * c.T * c.D + 3) / 4 * 4) * sizeof(float) <= kLdsHalf;
+        const bool want = tune.ring == 1 || (tune.ring < 0 && !forced_other && out_bytes > (flat_takes_it ? kRingTrajBytes : kRingBytes));
         const int TD_ = c.T * c.D;
         int NS = tune.ring_ns > 0 ? tune.ring_ns : 2;
         int NP = tune.ring_np > 0 ? tune.ring_np : 8;
@@ -544,7 +549,10 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
             bulk = false;
             // (write-through while the outputs fit the memory-side cache: kWtBytes)
             lds = lds_flat + (tune.lds_pad > 0 ? (size_t)tune.lds_pad * 1024 : 0);   // "lds_pad": occupancy experiments
-            const long wg = (long)(kLdsPerCu / lds) < 3 ? (long)(kLdsPerCu / lds) : 3;   // workgroups a CU's LDS holds
+            // workgroups per CU: TWO, also where the LDS holds three (round 5: three -- twelve waves, twelve write streams per CU -- were
+            // 7 - 20 % slower than two at every size from 12 288 to 1 M episodes of cfg2's trajectory-only shape: 32 768 episodes 33.5 ->
+            // 31.2 us, 65 536: 73.0 -> 68.8, 262 144: 318 -> 260; with three arrays two were all that fitted, and one is slower again)
+            const long wg = (long)(kLdsPerCu / lds) < 2 ? (long)(kLdsPerCu / lds) : 2;
             const long resident = (long)num_cu * (wg < 1 ? 1 : wg) * 4;   // 4-wave workgroups, persistent
             waves = ta.G < resident ? ta.G : resident;
             // the DoF count compiled in for the shapes the reference registers MP environments with (k_traj_flat_d, mpk_traj_ring.h);

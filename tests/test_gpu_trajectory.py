@@ -382,28 +382,43 @@ def test_ring_kernel_fused_actions_bit_exact(B, ctrl, mpk_option):
 
 
 def test_ring_kernel_is_the_automatic_choice_for_launches_that_stream_to_hbm_and_only_those(mpk_option):
-    """outputs beyond kRingBytes (440 MB) of an open-loop promp / prodmp launch -> k_traj_ring; DMP, the closed loop and smaller
-    launches keep their kernels; two launches of one handle on two streams do not share a ticket counter"""
+    """outputs beyond kRingBytes (346 MB) of an open-loop promp / prodmp launch WITH actions -> k_traj_ring; trajectory-only launches of
+    the shapes k_traj_flat takes stay on it up to kRingTrajBytes (round 5: two workgroups of whole-trajectory images per CU beat the ring
+    up to ~3 GB); DMP, the closed loop and smaller launches keep their kernels; two launches of one handle on two streams do not share
+    a ticket counter"""
+    import bench
+    from fancy_gym_amd import RolloutSpec
     pc, bc, tc, dt, duration = CFG2
     eng = make_engine(pc, bc, tc, dt, duration)
     B = 120000                                               # 2 x 336 MB of (pos, vel)
     params, ip, iv = inputs(pc, bc, tc, B, seed=2)
-    pos, vel = eng.trajectory(params, ip, iv, 0.0)
-    assert eng.last_kernel() == "k_traj_ring<prodmp>", eng.last_kernel()
-    mpk_option("ring", 0)
-    p2, v2 = eng.trajectory(params, ip, iv, 0.0)
-    assert eng.last_kernel().startswith("k_traj_flat"), eng.last_kernel()
+    p2, v2 = [x.clone() for x in eng.trajectory(params, ip, iv, 0.0)]
+    assert eng.last_kernel() == "k_traj_flat<prodmp>", eng.last_kernel()
+    rng = np.random.default_rng(5)
+    cp, cv = rng.uniform(-1, 1, (B, 7)), rng.uniform(-1, 1, (B, 7))
+    spec = RolloutSpec("motor", 7, bench.P_GAINS, bench.D_GAINS, -1.0, 1.0, plant="static")
+    pos, vel, act = [x.clone() for x in eng.trajectory_actions(params, ip, iv, spec, cp, cv)]
+    assert eng.last_kernel() == "k_traj_ring<prodmp,act>", eng.last_kernel()
     assert torch.equal(pos, p2) and torch.equal(vel, v2)
-    mpk_option("ring", -1)
+    mpk_option("ring", 0)
+    p1, v1, a1 = eng.trajectory_actions(params, ip, iv, spec, cp, cv)
+    assert eng.last_kernel().startswith("k_traj_flat"), eng.last_kernel()
+    assert torch.equal(pos, p1) and torch.equal(vel, v1) and torch.equal(act, a1)
+    mpk_option("ring", 1)
+    p1, v1 = eng.trajectory(params, ip, iv, 0.0)
+    assert eng.last_kernel() == "k_traj_ring<prodmp>", eng.last_kernel()
+    assert torch.equal(p1, p2) and torch.equal(v1, v2)
+    del p1, v1, a1
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     torch.cuda.synchronize()
     outs = []
     for st in (s1, s2, s1, s2):
         with torch.cuda.stream(st):
-            outs.append(eng.trajectory(params, ip, iv, 0.0))
+            outs.append(eng.trajectory(params, ip, iv, 0.0))      # (the ring, forced: four launches, two streams)
     torch.cuda.synchronize()
     for p3, v3 in outs:
         assert torch.equal(p3, p2) and torch.equal(v3, v2)
+    mpk_option("ring", -1)
     small = eng.trajectory(params[:4096], ip[:4096], iv[:4096], 0.0)
     assert eng.last_kernel().startswith("k_traj_tiles")
     assert torch.equal(small[0], p2[:4096])

@@ -552,7 +552,9 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
             // workgroups per CU: TWO, also where the LDS holds three (round 5: three -- twelve waves, twelve write streams per CU -- were
             // 7 - 20 % slower than two at every size from 12 288 to 1 M episodes of cfg2's trajectory-only shape: 32 768 episodes 33.5 ->
             // 31.2 us, 65 536: 73.0 -> 68.8, 262 144: 318 -> 260; with three arrays two were all that fitted, and one is slower again)
-            const long wg = (long)(kLdsPerCu / lds) < 2 ? (long)(kLdsPerCu / lds) : 2;
+            // ("phase_waves" 4 / 8 / 12: one / two / three workgroups, for A/B runs)
+            const long wg_cap = tune.phase_waves >= 4 ? tune.phase_waves / 4 : 2;
+            const long wg = (long)(kLdsPerCu / lds) < wg_cap ? (long)(kLdsPerCu / lds) : wg_cap;
             const long resident = (long)num_cu * (wg < 1 ? 1 : wg) * 4;   // 4-wave workgroups, persistent
             waves = ta.G < resident ? ta.G : resident;
             // the DoF count compiled in for the shapes the reference registers MP environments with (k_traj_flat_d, mpk_traj_ring.h);

@@ -215,8 +215,8 @@ int mpk_set_duration(mpk_handle h, double duration, double dt);
  *                   the contraction of the Euler map's response rows (the default where that map is stable: alpha ds <= 1, and the
  *                   shape fits the matrix-core kernels; kernel names read <dmp_resp..>)
  *   "phase_waves"   1 .. 32: at most that many waves of a per-episode-phase kernel (k_traj_phase<..>) or of a rollout kernel
- *                   (k_pd_rollout_tiles) resident on a CU (A/B runs: large launches stream faster from fewer waves; the rollout on
- *                   existing trajectories takes four per CU by itself beyond 512 MiB)
+ *                   (k_pd_rollout_tiles) or of k_traj_flat (4 / 8 / 12) resident on a CU (A/B runs: large launches stream faster
+ *                   from fewer waves; the rollout on existing trajectories takes four per CU by itself beyond 512 MiB, k_traj_flat eight)
  *   "pd_helper"     1 the reward rollout's control-cost pass on two helper waves of a six-wave workgroup instead of on the chain waves
  *                   (measured slower at every size: never automatic)
  *   "pd_generic"    1 the tile rollout kernels (2 / 5 / 7 DoF) and the per-episode ProDMP kernels (7 DoF) without their

@@ -538,6 +538,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         long units = ta.G;
         if (bulk) { lds = lds_bulk; units = (ta.G + kChunkGroups - 1) / kChunkGroups; }
         long waves = units < max_waves ? units : max_waves;
+        if (tune.phase_waves > 0 && waves > (long)num_cu * tune.phase_waves) waves = (long)num_cu * tune.phase_waves;   // (A/B runs: waves per CU)
         // whole-trajectory images (k_traj_flat): open loop, promp / prodmp, aligned outputs, T * D a multiple of 4, and
         // two workgroups' images + tables within a CU's LDS.  Automatic once the outputs stream to HBM (A/B on the
         // streaming row, profiles/r03_streaming.md); mpk_set_option "flat": 0 off, 1 force

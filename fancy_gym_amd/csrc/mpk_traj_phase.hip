@@ -223,10 +223,10 @@ struct PhaseArgs {
 // s in [-h, kFastS + h] with the builders' own float64 functions (rbf_row: the table IS the exact rows at its nodes), and an item takes
 // the four nodes around its s through the cubic Lagrange polynomial: ~45 fp32 operations and eight 16-byte LDS reads.  Error
 // 0.0234 h^4 |d4F/ds4| with h = 1 / 256: the rows of <= 5 basis functions (the only shape the table is built for: KS == 8, the
-// reference's DMP configurations) have a fourth derivative <= ~6.4e3 (widths >= 0.14 in s), i.e. <= 4e-8 -- below the fp32 rounding
+// reference's DMP configurations) have a fourth derivative <= ~6.4e3 (widths >= 0.14 in s), i.e. <= 6e-8 -- below the fp32 rounding
 // of the row itself; items beyond s = kFastS (a tau far below the horizon) take the exact path.  Bit identity with the exact rows
 // is given up (the 1e-5 contract is what holds across kernel families: DESIGN section 3); "phase_table" 0 restores the exact rows.
-constexpr int kFastN = 512;
+constexpr int kFastN = 448;            // (512 until the pipeline kernel needed 2 KB of a CU's LDS back: four of its workgroups per CU)
 constexpr float kFastS = 2.0f;
 constexpr int kFastRows = kFastN + 3;            // node j <-> s = (j - 1) kFastS / kFastN
 
@@ -276,7 +276,7 @@ __device__ __forceinline__ void fast_rows_stage(const float* __restrict__ src, f
 // the row at scaled time s in [0, kFastS): cubic Lagrange interpolation over the nodes i - 1 .. i + 2, i = floor(s / h)
 template <int KS>
 __device__ __forceinline__ void fast_rows_eval(const float* tab, const float s, float (&h)[KS]) {
-    const float u = s * (float)(kFastN / kFastS);      // (a power of two: exact)
+    const float u = s * (float)(kFastN / kFastS);      // (224: the item's place between two nodes moves by 1e-7 of their distance)
     const int i = (int)u;
     const float t = u - (float)i, tm1 = t - 1.0f, tp1 = t + 1.0f, tm2 = t - 2.0f;
     const float w0 = (t * tm1) * tm2 * (-1.0f / 6.0f), w1 = (tp1 * tm1) * tm2 * 0.5f;
@@ -1293,6 +1293,222 @@ __global__ void __launch_bounds__(NTB == 5 ? 320 : 256, 4) k_traj_phase_dmp_wg(c
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// k_traj_phase_dmp_pipe (round 5): k_traj_phase_dmp_wg as a PIPELINE.  The workgroup kernel walks rows -> barrier -> Euler steps on
+// wave 0 -> barrier -> stores, and its trace at 4 096 episodes says 38 000 cycles of which 17 000 are the 200 Euler steps on ONE lone
+// wave (84 cycles a step: the floor of this decomposition) and the rest the rows and stores that wait for them and are waited for.
+// Here wave 0 ONLY steps; waves 1 - 3 (other SIMDs: the Euler chain keeps SIMD 0 to itself and to the chains of the CU's other
+// workgroups, which interleave for free) each own ONE 16-step tile of every 48-step block and, stage after stage, store their tile of
+// block s - 2 and then build rows + forcing of their tile of block s into the SAME place of buffer s & 1, while wave 0 steps through
+// block s - 1 in the other buffer: one barrier per stage, no hazard between waves (a helper only ever touches its own tile's slots).
+//   stage s:   wave 0: Euler steps of block s - 1 (buffer (s - 1) & 1)   |   wave 1 + h: store tile h of block s - 2, build tile h of block s
+// Same functions, same order of operations per item as the workgroup and the wave kernels: the same bits.  Chunks of up to four episodes
+// (a tile is 4 episodes x 16 steps = the 64 items of one round of a helper wave), eight columns, T > 48.
+// ------------------------------------------------------------------------------------------------------------
+template <int KQ>
+__global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_pipe(const PhaseArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const DevCfg& c = a.c;
+    constexpr int KS = KQ * 4, TT = 16, NH = 3, TB = TT * NH;     // 48 steps per block: a tile per helper wave
+    constexpr int MP = MPK_MP_DMP;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int D = c.D, T = c.T, E = a.chunk, P = c.P;
+    const int bseg = TB * D;                            // (pos, tau x vel) pairs of one episode's block
+    MPK_STAMP(0);
+    double* sCen = reinterpret_cast<double*>(smem);     // [c_pad / 2] RBF centres | bandwidths
+    float* sFast = smem + a.c_pad;                      // [h_pad] interpolation table of the forcing rows
+    float* sBT = sFast + a.h_pad;                       // [t_pad] base times
+    float* sX = sBT + a.t_pad;                          // [E][D][KS] columns: weights .., goal, y0, ydot0
+    float* sPh = sX + E * a.x_pad;                      // [E][8] tau, delay, init_time (clipped), -, 1 / tau refined (float64), -
+    float* sDs = sPh + 8 * E;                           // [2][E][TB] ds of a block's steps
+    float* sPV = sDs + 2 * E * TB;                      // [2][E][TB * D] pairs: forcing -> pos | tau x vel
+    const float inv_d = 1.0f / (float)D;
+    const int le = (int)(((float)lane + 0.5f) * inv_d), ld = lane - le * D;        // lane <-> (episode, DoF)  (wave 0)
+    const int nchunks = (a.B + E - 1) / E;
+    const int ch0 = (int)blockIdx.x;
+    float xf0 = 0.0f, tau0 = c.tau, delay0 = c.delay, it0 = a.init_time_shared;
+    if (ch0 < nchunks) {                                // the first chunk's inputs: requested before the tables are staged
+        const int b0 = ch0 * E, ne = min(E, a.B - b0);
+        if ((int)threadIdx.x < ne * D * KS) {
+            const int idx = (int)threadIdx.x, pi = idx / KS, kk = idx - pi * KS;
+            const int e = (int)(((float)pi + 0.5f) * inv_d), dd = pi - e * D;
+            const size_t bb = (size_t)(b0 + e);
+            xf0 = phase_x_value<MP>(c, a.params + bb * P, a.init_pos + bb * D, a.init_vel + bb * D, dd, kk, KS);
+        }
+        if (wave == 0 && lane < ne * D) {
+            const float* prm = a.params + (size_t)(b0 + le) * P;
+            if (c.learn_tau) tau0 = fminf(fmaxf(prm[0], c.tau_lo), c.tau_hi);
+            if (c.learn_delay) delay0 = fminf(fmaxf(prm[c.learn_tau ? 1 : 0], c.delay_lo), c.delay_hi);
+            if (a.init_time) it0 = a.init_time[b0 + le];
+        }
+    }
+    const int tid_ = (int)threadIdx.x, bd_ = (int)blockDim.x;
+    const float bt0 = tid_ < T ? c.base_times[tid_] : 0.0f;
+    const double cen0 = tid_ < 2 * c.n_total + 3 ? c.tab[tid_] : 0.0;
+    const bool fast = a.h_pad > 0;
+    if (fast) fast_rows_stage(c.rows32, sFast, a.h_pad, tid_, bd_);
+    if (tid_ < T) sBT[tid_] = bt0;
+    for (int t = tid_ + bd_; t < T; t += bd_) sBT[t] = c.base_times[t];
+    if (tid_ < 2 * c.n_total + 3) sCen[tid_] = cen0;
+    for (int k = tid_ + bd_; k < 2 * c.n_total + 3; k += bd_) sCen[k] = c.tab[k];
+    const bool vec = a.vec_ok != 0;
+    const int NB = (T + TB - 1) / TB;
+    for (int ch = ch0; ch < nchunks; ch += (int)gridDim.x) {
+        const int b0 = ch * E, ne = min(E, a.B - b0);
+        MPK_STAMP(1);
+        int idx = (int)threadIdx.x;
+        if (ch == ch0) {
+            if (idx < ne * D * KS) sX[idx] = xf0;
+            idx += (int)blockDim.x;
+        }
+        for (; idx < ne * D * KS; idx += blockDim.x) {
+            const int pi = idx / KS, k = idx - pi * KS;             // pi = e * D + dd
+            const int e = (int)(((float)pi + 0.5f) * inv_d), dd = pi - e * D;
+            const size_t bb = (size_t)(b0 + e);
+            sX[idx] = phase_x_value<MP>(c, a.params + bb * P, a.init_pos + bb * D, a.init_vel + bb * D, dd, k, KS);
+        }
+        float tau = c.tau, delay = c.delay, it = a.init_time_shared;
+        const bool on = wave == 0 && lane < ne * D;
+        if (on) {
+            if (ch == ch0) {
+                tau = tau0; delay = delay0; it = it0;
+            } else {
+                const float* prm = a.params + (size_t)(b0 + le) * P;
+                if (c.learn_tau) tau = fminf(fmaxf(prm[0], c.tau_lo), c.tau_hi);
+                if (c.learn_delay) delay = fminf(fmaxf(prm[c.learn_tau ? 1 : 0], c.delay_lo), c.delay_hi);
+                if (a.init_time) it = a.init_time[b0 + le];
+            }
+            if (ld == 0) {
+                sPh[8 * le] = tau; sPh[8 * le + 1] = delay; sPh[8 * le + 2] = it;
+                *reinterpret_cast<double*>(sPh + 8 * le + 4) = make_pos_div((double)tau).y;
+            }
+        }
+        __syncthreads();
+        MPK_STAMP(2);
+        float y = 0.0f, z = 0.0f, g = 0.0f;
+        if (on) {
+            const float* xc = sX + lane * KS;
+            g = xc[KS - 3] * c.gs; y = xc[KS - 2]; z = xc[KS - 1] * tau;
+        }
+        for (int s = 0; s <= NB + 1; ++s) {
+            if (wave == 0) {
+                // ---- B: the Euler steps of block s - 1 (the workgroup kernel's, step for step)
+                if (on && s >= 1 && s <= NB) {
+                    const int t0 = (s - 1) * TB, rows = min(TB, T - t0), bi = (s - 1) & 1;
+                    float* pq = sPV + (size_t)bi * 2 * E * bseg + 2 * (le * bseg + ld);
+                    const float* pds = sDs + bi * E * TB + le * TB;
+                    constexpr int PC = 8;
+                    int tl0 = 0;
+                    for (; tl0 + PC <= rows && t0 + tl0 + PC < T; tl0 += PC) {
+                        float fr[PC], dsr[PC];
+#pragma unroll
+                        for (int j = 0; j < PC / 4; ++j) {
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(pds + tl0 + 4 * j);
+                            dsr[4 * j] = v[0]; dsr[4 * j + 1] = v[1]; dsr[4 * j + 2] = v[2]; dsr[4 * j + 3] = v[3];
+                        }
+#pragma unroll
+                        for (int i = 0; i < PC; ++i) fr[i] = pq[2 * (tl0 + i) * D];
+#pragma unroll
+                        for (int i = 0; i < PC; ++i) {
+                            *reinterpret_cast<f32x2*>(pq + 2 * (tl0 + i) * D) = f32x2{y, z};
+                            dmp_phase_step(y, z, g, fr[i], dsr[i], c.dmp_alpha, c.dmp_beta);
+                        }
+                    }
+#pragma unroll 1
+                    for (int tl = tl0; tl < rows; ++tl) {
+                        const float f = pq[2 * tl * D];
+                        *reinterpret_cast<f32x2*>(pq + 2 * tl * D) = f32x2{y, z};
+                        if (t0 + tl < T - 1) {
+                            const float ds = pds[tl];
+                            dmp_phase_step(y, z, g, f, ds, c.dmp_alpha, c.dmp_beta);
+                        }
+                    }
+                }
+                if (s < 8) MPK_STAMP(10 + 2 * s);
+            } else {
+                const int hw = wave - 1, bi = s & 1;
+                float* const pvb = sPV + (size_t)bi * 2 * E * bseg;
+                // ---- C: tile hw of block s - 2 leaves: rows * D contiguous floats per episode and array
+                if (s >= 2) {
+                    const int t0 = (s - 2) * TB + hw * TT, rows = min(TT, T - t0), n = rows * D;
+                    if (rows > 0) {
+                        const float* src = pvb + 2 * hw * TT * D;
+                        if (vec && (n & 3) == 0) {
+                            const int n4 = n >> 2;
+                            for (int i = lane; i < ne * n4; i += 64) {
+                                const int e = i / n4, q4 = i - e * n4;
+                                const size_t go = ((size_t)(b0 + e) * T + t0) * D + 4 * q4;
+                                const f32x4 pa = *reinterpret_cast<const f32x4*>(src + 2 * (e * bseg + 4 * q4));
+                                const f32x4 pb = *reinterpret_cast<const f32x4*>(src + 2 * (e * bseg + 4 * q4) + 4);
+                                const f32x4 vp = {pa[0], pa[2], pb[0], pb[2]};
+                                f32x4 vv = {pa[1], pa[3], pb[1], pb[3]};
+                                const TauDiv tde = make_tau_div(sPh[8 * e]);
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) vv[q] = div_tau(vv[q], tde);
+                                if (a.wt) { store16<true>(a.pos + go, vp); store16<true>(a.vel + go, vv); }
+                                else { store16<false>(a.pos + go, vp); store16<false>(a.vel + go, vv); }
+                            }
+                        } else {
+                            for (int i = lane; i < ne * n; i += 64) {
+                                const int e = i / n, w = i - e * n;
+                                const size_t go = ((size_t)(b0 + e) * T + t0) * D + w;
+                                const f32x2 pr = *reinterpret_cast<const f32x2*>(src + 2 * (e * bseg + w));
+                                const float vel = div_tau(pr[1], make_tau_div(sPh[8 * e]));
+                                if (a.wt) { store4<true>(a.pos + go, pr[0]); store4<true>(a.vel + go, vel); }
+                                else { store4<false>(a.pos + go, pr[0]); store4<false>(a.vel + go, vel); }
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();    // (the tile's LDS reads are issued before its slots are written again)
+                }
+                // ---- A: rows and forcing of tile hw of block s
+                if (s < NB) {
+                    const int e = lane >> 4, tl = lane & (TT - 1), tb = hw * TT + tl, t = s * TB + tb;
+                    const bool live = e < ne && t < T;
+                    float h[KS];
+#pragma unroll
+                    for (int k = 0; k < KS; ++k) h[k] = 0.0f;
+                    if (live) {
+                        const float taue = sPh[8 * e], delaye = sPh[8 * e + 1], ite = sPh[8 * e + 2];
+                        const float time = sBT[t] + ite;
+                        const float s_item = scaled_time(time, delaye, taue);
+                        if (KS == 8 && fast && fast_rows_arg(c, s_item) < kFastS) {
+                            if constexpr (KS == 8) fast_rows_eval<KS>(sFast, fast_rows_arg(c, s_item), h);
+                        } else {
+                            const PosDiv taud{(double)taue, *reinterpret_cast<const double*>(sPh + 8 * e + 4)};
+                            const double x = phase_f64(c, time, taud, delaye, ExpLiteral());
+                            rbf_row<KS>(c, sCen, sCen + c.n_total, x, x * (double)c.ws, h, ExpLiteral());
+                        }
+                        if (t < T - 1) sDs[bi * E * TB + e * TB + tb] = scaled_time(sBT[t + 1] + ite, delaye, taue) - s_item;
+                        for (int d0 = 0; d0 < D; d0 += 4) {
+                            float x[4][KS];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const int d = min(d0 + i, D - 1);
+#pragma unroll
+                                for (int j = 0; j < KQ; ++j) {
+                                    const float4 v = *reinterpret_cast<const float4*>(sX + (e * D + d) * KS + 4 * j);
+                                    x[i][4 * j + 0] = v.x; x[i][4 * j + 1] = v.y; x[i][4 * j + 2] = v.z; x[i][4 * j + 3] = v.w;
+                                }
+                            }
+                            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                            for (int k = 0; k < KS - 3; ++k)
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) acc[i] = fmaf(h[k], x[i][k], acc[i]);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                if (d0 + i < D) pvb[2 * (e * bseg + tb * D + d0 + i)] = acc[i];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 #ifndef MPK_DEVICE_ONLY
 int fast_rows_stride(const DevCfg& c) {          // 0: no interpolation table for this shape; else the kernels' KS (floats per node)
     // dmp: up to five basis functions in eight columns (where the error bound was derived).  ProMP was tried (round 5) and dropped: its
@@ -1539,9 +1755,30 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
                 wgNTB = 5;
             const size_t wg_lds = wg_bytes(wgE, wgNTB);
             const int wg_res = wg_resident(wg_lds);
+            // the pipeline form (k_traj_phase_dmp_pipe: wave 0 only steps, three helper waves build and store around it in blocks of 48
+            // steps, two buffers): chunks of up to four episodes, eight columns, more than one block, and the launch in ONE round of its
+            // resident workgroups ("pipe" 0: the plain workgroup kernel, for A/B runs and tests)
+            const size_t pipe_lds = ((size_t)pa.c_pad + wg_h + pa.t_pad + (size_t)wgE * pa.x_pad + 8 * wgE + 2 * (size_t)wgE * 48 +
+                                     4 * (size_t)wgE * 48 * c.D) * sizeof(float);
+            int pipe_res = (int)(kLdsPerCu / pipe_lds);
+            pipe_res = pipe_res > 4 ? 4 : pipe_res;
+            const bool pipe_form = wg_ok && wgE <= 4 && wgNTB != 2 && KQ == 2 && c.T > 48 && tune.pipe != 0 && pipe_res >= 1 &&
+                                   chunks <= (long)num_cu * pipe_res;
             // (beyond ONE round of resident workgroups the wave-per-chunk kernel is as fast: cfg3' at 6 144 episodes in chunks of
             // four 58 vs 61 us)
             const bool wg = wg_ok && tune.phase_flat != 0 && (tune.phase_flat == 1 || chunks <= (long)num_cu * wg_res);
+            if (wg && pipe_form) {
+                pa.h_pad = wg_h;
+                pa.chunk = wgE;
+                if (pipe_lds > kLdsDefault) {
+                    hipError_t e = allow_full_lds(k_traj_phase_dmp_pipe<2>);
+                    if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return MPK_EHIP; }
+                }
+                *kernel_name = "k_traj_phase<dmp,wg,pipe>";
+                hipLaunchKernelGGL(k_traj_phase_dmp_pipe<2>, dim3((unsigned)chunks), dim3(256), pipe_lds, (hipStream_t)stream, pa);
+                MPK_LAUNCH_CHECK();
+                return MPK_OK;
+            }
             if (wg) {
                 pa.h_pad = wg_h;
                 pa.chunk = wgE;

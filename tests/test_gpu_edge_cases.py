@@ -529,7 +529,7 @@ def test_per_episode_dmp_interpolated_rows_across_the_phase_clip(phase, mpk_opti
     tc = O.TrajCfg("dmp", action_dim=7, alpha=25.0)
     dt, dur = 0.02, 4.0
     eng = make_engine(pc, bc, tc, dt, dur)
-    B = 6000
+    B = 4000                      # (1 000 chunks of four: one round of the pipeline kernel's resident workgroups)
     params, ip, iv = inputs(pc, bc, tc, B, seed=11)
     params[:, 0] = np.linspace(1.0, 4.0, B, dtype=np.float32)
     for flat in (1, 0):
@@ -538,7 +538,7 @@ def test_per_episode_dmp_interpolated_rows_across_the_phase_clip(phase, mpk_opti
         p0, v0 = (x.double().clone() for x in eng.trajectory(params, ip, iv, 0.0))
         mpk_option("phase_table", 1)
         p1, v1 = (x.double() for x in eng.trajectory(params, ip, iv, 0.0))
-        assert eng.last_kernel() == ("k_traj_phase<dmp,wg>" if flat else "k_traj_phase<dmp>"), eng.last_kernel()
+        assert eng.last_kernel() == ("k_traj_phase<dmp,wg,pipe>" if flat else "k_traj_phase<dmp>"), eng.last_kernel()
         ep = float((p1 - p0).abs().max() / p0.abs().max()); ev = float((v1 - v0).abs().max() / v0.abs().max())
         assert ep <= 5e-7 and ev <= 5e-7, (phase, flat, ep, ev)
     n = 64
@@ -937,18 +937,27 @@ def test_per_episode_dmp_workgroup_and_wave_kernels_agree_bitwise(D, nb, T, B, m
     eng = make_engine(pc, bc, tc, dt, dur)
     params, ip, iv = inputs(pc, bc, tc, B, seed=B + T)
     rp, rv = O.get_trajectory(pc, bc, tc, params, dur, dt, 0.0, ip, iv, dtype=np.float64)
-    # forcing rows exact (0) / interpolated from the per-workgroup table (1: round 5) in BOTH kernels: the same bits from both; the
-    # automatic setting (table in the wave-per-chunk kernel only) against the oracle
+    # forcing rows exact (0) / interpolated from the handle's table (1: round 5) in ALL THREE kernels: the same bits from each; the
+    # automatic setting against the oracle
+    pipe_seen = set()
     for table in (0, 1):
         mpk_option("phase_table", table)
         mpk_option("phase_flat", 1)
+        mpk_option("pipe", 0)                           # the plain workgroup kernel: rows -> Euler steps -> stores, block after block
         p1, v1 = [x.clone() for x in eng.trajectory(params, ip, iv, 0.0)]
         assert eng.last_kernel() == "k_traj_phase<dmp,wg>", eng.last_kernel()
+        mpk_option("pipe", -1)                          # ... and as a pipeline (round 5) where it applies: <= 4 episodes per chunk, 8 columns,
+        p2, v2 = [x.clone() for x in eng.trajectory(params, ip, iv, 0.0)]     # T > 48, one round of resident workgroups
+        assert eng.last_kernel() in ("k_traj_phase<dmp,wg>", "k_traj_phase<dmp,wg,pipe>"), eng.last_kernel()
+        pipe_seen.add(eng.last_kernel())
+        assert torch.equal(p1, p2) and torch.equal(v1, v2), (table, eng.last_kernel())
         mpk_option("phase_flat", 0)
         p0, v0 = eng.trajectory(params, ip, iv, 0.0)
         assert eng.last_kernel() == "k_traj_phase<dmp>", eng.last_kernel()
         assert torch.equal(p1, p0) and torch.equal(v1, v0), table
         close(p1.cpu().numpy(), rp, "pos"); close(v1.cpu().numpy(), rv, "vel")
+    if (D, nb, T) == (7, 5, 200) and B <= 4096:
+        assert "k_traj_phase<dmp,wg,pipe>" in pipe_seen, pipe_seen
     mpk_option("phase_table", -1); mpk_option("phase_flat", -1)
     p2, v2 = eng.trajectory(params, ip, iv, 0.0)
     close(p2.cpu().numpy(), rp, "pos (automatic)"); close(v2.cpu().numpy(), rv, "vel (automatic)")

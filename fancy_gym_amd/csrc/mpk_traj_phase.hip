@@ -1305,7 +1305,7 @@ __global__ void __launch_bounds__(NTB == 5 ? 320 : 256, 4) k_traj_phase_dmp_wg(c
 // Same functions, same order of operations per item as the workgroup and the wave kernels: the same bits.  Chunks of up to four episodes
 // (a tile is 4 episodes x 16 steps = the 64 items of one round of a helper wave), eight columns, T > 48.
 // ------------------------------------------------------------------------------------------------------------
-template <int KQ>
+template <int KQ, int DC = 0>      // DC: the DoF count at compile time (0: c.D) -- the kernel is bound by its instruction count
 __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_pipe(const PhaseArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const DevCfg& c = a.c;
@@ -1313,7 +1313,7 @@ __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_pipe(const PhaseArgs 
     constexpr int MP = MPK_MP_DMP;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int D = c.D, T = c.T, E = a.chunk, P = c.P;
+    const int D = DC > 0 ? DC : c.D, T = c.T, E = a.chunk, P = c.P;
     const int bseg = TB * D;                            // (pos, tau x vel) pairs of one episode's block
     MPK_STAMP(0);
     double* sCen = reinterpret_cast<double*>(smem);     // [c_pad / 2] RBF centres | bandwidths
@@ -1436,8 +1436,9 @@ __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_pipe(const PhaseArgs 
                         const float* src = pvb + 2 * hw * TT * D;
                         if (vec && (n & 3) == 0) {
                             const int n4 = n >> 2;
+                            const float inv_n4 = 1.0f / (float)n4;      // (i + 0.5) / n4: the exact floor for these few hundred indices
                             for (int i = lane; i < ne * n4; i += 64) {
-                                const int e = i / n4, q4 = i - e * n4;
+                                const int e = (int)(((float)i + 0.5f) * inv_n4), q4 = i - e * n4;
                                 const size_t go = ((size_t)(b0 + e) * T + t0) * D + 4 * q4;
                                 const f32x4 pa = *reinterpret_cast<const f32x4*>(src + 2 * (e * bseg + 4 * q4));
                                 const f32x4 pb = *reinterpret_cast<const f32x4*>(src + 2 * (e * bseg + 4 * q4) + 4);
@@ -1481,6 +1482,25 @@ __global__ void __launch_bounds__(256, 4) k_traj_phase_dmp_pipe(const PhaseArgs 
                             rbf_row<KS>(c, sCen, sCen + c.n_total, x, x * (double)c.ws, h, ExpLiteral());
                         }
                         if (t < T - 1) sDs[bi * E * TB + e * TB + tb] = scaled_time(sBT[t + 1] + ite, delaye, taue) - s_item;
+                        if constexpr (DC > 0) {
+                            float x[DC][KS];
+#pragma unroll
+                            for (int d = 0; d < DC; ++d)
+#pragma unroll
+                                for (int j = 0; j < KQ; ++j) {
+                                    const float4 v = *reinterpret_cast<const float4*>(sX + (e * DC + d) * KS + 4 * j);
+                                    x[d][4 * j + 0] = v.x; x[d][4 * j + 1] = v.y; x[d][4 * j + 2] = v.z; x[d][4 * j + 3] = v.w;
+                                }
+                            float acc[DC];
+#pragma unroll
+                            for (int d = 0; d < DC; ++d) acc[d] = 0.0f;
+#pragma unroll
+                            for (int k = 0; k < KS - 3; ++k)
+#pragma unroll
+                                for (int d = 0; d < DC; ++d) acc[d] = fmaf(h[k], x[d][k], acc[d]);
+#pragma unroll
+                            for (int d = 0; d < DC; ++d) pvb[2 * (e * bseg + tb * DC + d)] = acc[d];
+                        } else
                         for (int d0 = 0; d0 < D; d0 += 4) {
                             float x[4][KS];
 #pragma unroll
@@ -1771,11 +1791,14 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
                 pa.h_pad = wg_h;
                 pa.chunk = wgE;
                 if (pipe_lds > kLdsDefault) {
-                    hipError_t e = allow_full_lds(k_traj_phase_dmp_pipe<2>);
+                    hipError_t e = c.D == 7 ? allow_full_lds(k_traj_phase_dmp_pipe<2, 7>) : allow_full_lds(k_traj_phase_dmp_pipe<2>);
                     if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return MPK_EHIP; }
                 }
                 *kernel_name = "k_traj_phase<dmp,wg,pipe>";
-                hipLaunchKernelGGL(k_traj_phase_dmp_pipe<2>, dim3((unsigned)chunks), dim3(256), pipe_lds, (hipStream_t)stream, pa);
+                if (c.D == 7 && tune.pd_generic != 1)
+                    hipLaunchKernelGGL((k_traj_phase_dmp_pipe<2, 7>), dim3((unsigned)chunks), dim3(256), pipe_lds, (hipStream_t)stream, pa);
+                else
+                    hipLaunchKernelGGL(k_traj_phase_dmp_pipe<2>, dim3((unsigned)chunks), dim3(256), pipe_lds, (hipStream_t)stream, pa);
                 MPK_LAUNCH_CHECK();
                 return MPK_OK;
             }

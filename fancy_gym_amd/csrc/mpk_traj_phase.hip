@@ -864,7 +864,7 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
     }
 }
 
-template <int KQ>
+template <int KQ, int DC = 0>       // DC: the DoF count at compile time (0: c.D), as k_traj_phase_dmp_pipe
 __global__ void __launch_bounds__(512) k_traj_phase_dmp(const PhaseArgs a) {      // (four or eight waves: the launcher, by the waves a CU's LDS then holds)
     // DMP with a per-episode phase.  The Euler recurrence is serial in t and needs one lane per (episode, DoF); run per
     // episode it keeps D of 64 lanes busy for T dependent steps -- 7 % of the HBM roofline for 7 DoF (round 1 / 2).  Here a
@@ -880,7 +880,7 @@ __global__ void __launch_bounds__(512) k_traj_phase_dmp(const PhaseArgs a) {    
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int wpb = (int)(blockDim.x >> 6);
-    const int D = c.D, T = c.T, E = a.chunk, P = c.P;
+    const int D = DC > 0 ? DC : c.D, T = c.T, E = a.chunk, P = c.P;
     const int seg = TT * D;                             // floats of one episode's tile
     double* sCen = reinterpret_cast<double*>(smem);     // [c_pad / 2] RBF centres | bandwidths (| recurrence constants)
     float* sFast = smem + a.c_pad;                      // [h_pad] interpolation table of the forcing rows (fast_rows_build)
@@ -963,6 +963,27 @@ __global__ void __launch_bounds__(512) k_traj_phase_dmp(const PhaseArgs a) {    
                     if (t < T - 1) sDs[idx] = scaled_time(sBT[t + 1] + ite, delaye, taue) - s_item;
                 }
                 if (ti_ < 8 && i0 == 0) MPK_STAMP(11 + 5 * ti_);
+                if constexpr (DC > 0) {
+                    if (live) {                             // the DC chains side by side, offsets as constants (same chain order per DoF: same bits)
+                        float x[DC][KS];
+#pragma unroll
+                        for (int d = 0; d < DC; ++d)
+#pragma unroll
+                            for (int j = 0; j < KQ; ++j) {
+                                const float4 v = *reinterpret_cast<const float4*>(sX + (e * DC + d) * KS + 4 * j);
+                                x[d][4 * j + 0] = v.x; x[d][4 * j + 1] = v.y; x[d][4 * j + 2] = v.z; x[d][4 * j + 3] = v.w;
+                            }
+                        float acc[DC];
+#pragma unroll
+                        for (int d = 0; d < DC; ++d) acc[d] = 0.0f;
+#pragma unroll
+                        for (int k = 0; k < KS - 3; ++k)
+#pragma unroll
+                            for (int d = 0; d < DC; ++d) acc[d] = fmaf(h[k], x[d][k], acc[d]);
+#pragma unroll
+                        for (int d = 0; d < DC; ++d) sP[e * seg + tl * DC + d] = acc[d];
+                    }
+                } else
                 if (live) {
                     for (int d = 0; d < D; ++d) {
                         float x[KS];
@@ -1821,6 +1842,7 @@ static int launch_traj_phase(const DevCfg& c, const PhaseArgs& base, int num_cu,
                 return KQ == 2 ? gow(k_traj_phase_dmp_wg<2, 2>) : gow(k_traj_phase_dmp_wg<4, 2>);
             }
             *kernel_name = "k_traj_phase<dmp>";
+            if (KQ == 2 && c.D == 7 && tune.pd_generic != 1) return go(k_traj_phase_dmp<2, 7>);      // (seven DoF compiled in: the kernel is issue bound)
             return KQ == 2 ? go(k_traj_phase_dmp<2>) : go(k_traj_phase_dmp<4>);
         }
     }

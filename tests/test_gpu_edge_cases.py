@@ -572,6 +572,46 @@ def test_prodmp_seven_dof_unrolled_chains_same_bits(B, mpk_option):
     close(p1[:n].cpu().numpy(), rp, "pos"); close(v1[:n].cpu().numpy(), rv, "vel")
 
 
+def test_resident_waves_per_cu_are_a_launch_parameter_not_a_result(mpk_option):
+    """round 5: how many waves (= write streams) of a kernel a CU holds is chosen by size for k_traj_flat (two workgroups), for
+    k_traj_phase<prodmp,lds,flat> (workgroups of four from 24 576 episodes on) and for k_pd_rollout_tiles (four waves beyond 512 MiB);
+    "phase_waves" / "tiles_wpb" set it for A/B runs -- whatever the geometry, the same bits"""
+    import bench
+    from fancy_gym_amd import RolloutSpec
+    pc, bc, tc, dt, duration = CFG2
+    eng = make_engine(pc, bc, tc, dt, duration)
+    B = 30000
+    params, ip, iv = inputs(pc, bc, tc, B, seed=4)
+    ref = [x.clone() for x in eng.trajectory(params, ip, iv, 0.0)]
+    assert eng.last_kernel() == "k_traj_flat<prodmp>", eng.last_kernel()
+    for w in (4, 8, 12):
+        mpk_option("phase_waves", w)
+        p, v = eng.trajectory(params, ip, iv, 0.0)
+        assert eng.last_kernel() == "k_traj_flat<prodmp>" and torch.equal(p, ref[0]) and torch.equal(v, ref[1]), w
+    mpk_option("phase_waves", -1)
+    spec = RolloutSpec("motor", 7, bench.P_GAINS, bench.D_GAINS, -1.0, 1.0, plant="double_integrator", dt=dt)
+    rng = np.random.default_rng(3)
+    q0, qd0 = rng.uniform(-1, 1, (B, 7)), rng.uniform(-1, 1, (B, 7))
+    acts = []
+    for w in (-1, 4, 16, 32):
+        mpk_option("phase_waves", w)
+        q, qd = torch.tensor(q0, device="cuda"), torch.tensor(qd0, device="cuda")
+        acts.append((eng.pd_rollout(spec, ref[0], ref[1], q, qd).clone(), q.clone(), qd.clone()))
+    for a_, q_, qd_ in acts[1:]:
+        assert torch.equal(a_, acts[0][0]) and torch.equal(q_, acts[0][1]) and torch.equal(qd_, acts[0][2])
+    mpk_option("phase_waves", -1)
+    pc2 = dataclasses.replace(pc, learn_tau=True, tau_bound=(0.5, 2.0))
+    eng2 = make_engine(pc2, bc, tc, dt, duration)
+    params2, ip2, iv2 = inputs(pc2, bc, tc, B, seed=6)
+    ref2 = [x.clone() for x in eng2.trajectory(params2, ip2, iv2, 0.0)]
+    assert eng2.last_kernel() == "k_traj_phase<prodmp,lds,flat>", eng2.last_kernel()
+    for key, w in (("tiles_wpb", 2), ("tiles_wpb", 8), ("phase_waves", 4), ("phase_waves", 16)):
+        mpk_option(key, w)
+        p, v = eng2.trajectory(params2, ip2, iv2, 0.0)
+        assert torch.equal(p, ref2[0]) and torch.equal(v, ref2[1]), (key, w)
+        mpk_option(key, -1)
+
+
 @pytest.mark.parametrize("nb,zero_start", [(3, 1), (6, 0)])
 @pytest.mark.parametrize("B", [1, 130, 5000])
 def test_promp_seven_dof_unrolled_chains_same_bits(B, nb, zero_start, mpk_option):

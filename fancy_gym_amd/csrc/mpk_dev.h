@@ -90,6 +90,8 @@ constexpr double kRingBytes = 330.0 * 1024 * 1024;
 // ... and trajectory-only launches of the shapes k_traj_flat takes: the flat kernel at two workgroups per CU stays ahead of the ring up to
 // ~3 GB (round 5; mpk_traj_launch.hip)
 constexpr double kRingTrajBytes = 4096.0 * 1024 * 1024;
+// ... and they leave the tile-major kernel for it from here on (instead of kCachedBytes)
+constexpr double kFlatTrajBytes = 64.0 * 1024 * 1024;
 // a ticket of k_traj_ring covers at least this many bytes of batch buffers: one device counter hands out ~88 tickets / us
 // (profiles/r04_store_engine_probe_dynamic.md), 32768 tickets of 67 KB saturate it, 10923 of 201 KB do not
 constexpr size_t kRingTicketBytes = 192 * 1024;

@@ -313,7 +313,12 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     const bool pipe = closed && c.mp_type != MPK_MP_DMP && pipe_fits && tune.split != 1 &&
                       (tune.pipe == 1 || (tune.pipe != 0 && !variant_forced && pipe_units <= 3L * num_cu));
     const bool split = !pipe && closed && c.mp_type != MPK_MP_DMP && split_shape && tune.split == 1;
-    bool stream_mode = !split && (c.mp_type == MPK_MP_DMP || closed || out_bytes > kCachedBytes);
+    // (trajectory-only launches of the shapes k_traj_flat takes -- two workgroups of whole-trajectory images per CU -- go episode-major from
+    // kFlatTrajBytes on: round 5, cfg2's shape, us tiles / flat: 8 192 episodes 10.7 / 11.0, 12 288: 14.5 / 14.1, 16 384: 19.2 / 18.2)
+    const bool flat_takes_it = !act && !closed && c.mp_type != MPK_MP_DMP && ptr_ok && (c.T * c.D) % 4 == 0 && tune.flat != 0 &&
+                               table_bytes + (size_t)4 * nst * (((size_t)NTW * c.T * c.D + 3) / 4 * 4) * sizeof(float) <= kLdsHalf;
+    const double stream_from = flat_takes_it && tune.bulk < 0 ? kFlatTrajBytes : kCachedBytes;
+    bool stream_mode = !split && (c.mp_type == MPK_MP_DMP || closed || out_bytes > stream_from);
     if (c.mp_type != MPK_MP_DMP && !closed && ov == 1) stream_mode = false;
     if (ov == 2 && !split) stream_mode = true;       // a forced k_traj_split stays tile-major (its tiles role needs that geometry)
     if ((tune.flat == 1 || tune.ring >= 1) && !closed && c.mp_type != MPK_MP_DMP && !split) stream_mode = true;   // forced k_traj_flat (where it applies)
@@ -392,8 +397,6 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         // (trajectory-only launches that k_traj_flat takes -- two workgroups of whole-trajectory images per CU, see below -- stay there
         // up to kRingTrajBytes: round 5, cfg2's shape, us flat / ring: 65 536 episodes 68.8 / 80.4, 131 072: 134.7 / 149.3, 262 144:
         // 259.5 / 282.7, 524 288: 533.8 / 551.9, 1 048 576: 1 151 / 1 092.  With actions the ring stays ahead from kRingBytes on.)
-        const bool flat_takes_it = !act && !closed && c.mp_type != MPK_MP_DMP && ptr_ok && (c.T * c.D) % 4 == 0 && tune.flat != 0 &&
-                                   table_bytes + (size_t)4 * nst * (((size_t)NTW * c.T * c.D + 3) / 4 * 4) * sizeof(float) <= kLdsHalf;
         const bool want = tune.ring == 1 || (tune.ring < 0 && !forced_other && out_bytes > (flat_takes_it ? kRingTrajBytes : kRingBytes));
         const int TD_ = c.T * c.D;
         int NS = tune.ring_ns > 0 ? tune.ring_ns : 2;
@@ -545,7 +548,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         const int flat_img = (NTW * TD + 3) / 4 * 4;
         const size_t lds_flat = table_bytes + (size_t)4 * nst * flat_img * sizeof(float);
         const bool flat_ok = !closed && c.mp_type != MPK_MP_DMP && ptr_ok && TD % 4 == 0 && lds_flat <= kLdsHalf;
-        if (flat_ok && tune.flat != 0 && (tune.flat == 1 || (out_bytes > kCachedBytes && tune.bulk < 0))) {
+        if (flat_ok && tune.flat != 0 && (tune.flat == 1 || (out_bytes > stream_from && tune.bulk < 0))) {
             ta.flat_img = flat_img;
             bulk = false;
             // (write-through while the outputs fit the memory-side cache: kWtBytes)

@@ -489,19 +489,25 @@ __global__ void __launch_bounds__(TL ? 1024 : 256) k_traj_phase(const PhaseArgs 
     auto issue_chunk = [&](int cc) {
         const int b0 = cc * E, ne = min(E, a.B - b0);
         const float* prm = a.params + (size_t)b0 * P;
+        int ep = E * P;
+        asm volatile("" : "+s"(ep));
 #pragma unroll
         for (int r = 0; r < NLP; ++r)
-            if (r == 0 || 64 * r < E * P) lp[r] = lane + 64 * r < ne * P ? prm[lane + 64 * r] : 0.0f;    // (uniform: one load for E * P <= 64)
+            if (r == 0 || 64 * r < ep) lp[r] = lane + 64 * r < ne * P ? prm[lane + 64 * r] : 0.0f;    // (uniform: one load for E * P <= 64)
         lip = lane < ne * D ? a.init_pos[(size_t)b0 * D + lane] : 0.0f;
         liv = lane < ne * D ? a.init_vel[(size_t)b0 * D + lane] : 0.0f;
         lit = a.init_time && lane < ne ? a.init_time[b0 + lane] : a.init_time_shared;
     };
     auto park_chunk = [&](float* img) {
+        // (the chunk's extents through an opaque scalar: the lane masks below are then formed where they are used -- hoisted out of the
+        // chunk loop each of them lived in a pair of spilled SGPRs: round 5)
+        int ep = E * P, ed = E * D, ee = E;
+        asm volatile("" : "+s"(ep), "+s"(ed), "+s"(ee));
 #pragma unroll
         for (int r = 0; r < NLP; ++r)
-            if ((r == 0 || 64 * r < E * P) && lane + 64 * r < E * P) img[lane + 64 * r] = lp[r];
-        if (lane < E * D) { img[E * P + lane] = lip; img[E * P + E * D + lane] = liv; }
-        if (lane < E) img[E * P + 2 * E * D + lane] = lit;
+            if ((r == 0 || 64 * r < ep) && lane + 64 * r < ep) img[lane + 64 * r] = lp[r];
+        if (lane < ed) { img[ep + lane] = lip; img[ep + ed + lane] = liv; }
+        if (lane < ee) img[ep + 2 * ed + lane] = lit;
     };
     // the first chunk's inputs are requested BEFORE the workgroup stages its tables: one memory round trip under the other (round 5:
     // at a few thousand episodes a wave has one chunk, and its first 40 % were these two waits in a row -- tools/dev/trace_phase.py)

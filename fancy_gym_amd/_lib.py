@@ -11,7 +11,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MPK_LIB") or os.path.join(_HERE, "libmpk.so")   # MPK_LIB: A/B builds of the library
 
-MPK_ABI_VERSION = 3
+MPK_ABI_VERSION = 4
 MP_TYPES = {"promp": 0, "dmp": 1, "prodmp": 2}
 PHASE_TYPES = {"linear": 0, "exp": 1}
 BASIS_TYPES = {"rbf": 0, "zero_rbf": 1, "prodmp": 2}
@@ -64,6 +64,15 @@ class mpk_rollout_cfg(C.Structure):
     ]
 
 
+class mpk_validity_gate(C.Structure):
+    _fields_ = [
+        ("pos_low", C.POINTER(C.c_double)), ("pos_high", C.POINTER(C.c_double)),
+        ("check_tau_delay", C.c_int32), ("reserved0", C.c_int32),
+        ("tau_bound", C.c_double * 2), ("delay_bound", C.c_double * 2),
+        ("raw_params", C.c_void_p), ("valid", C.c_void_p), ("penalty", C.c_void_p),
+    ]
+
+
 class mpk_replan_state(C.Structure):
     _fields_ = [
         ("traj_steps", C.c_void_p), ("plan_steps", C.c_void_p), ("done", C.c_void_p), ("seg_len", C.c_void_p),
@@ -100,6 +109,10 @@ SIGNATURES = {
                                   C.POINTER(mpk_replan_state), _vp, _vp, _vp, _i32, _vp]),
     "mpk_episode_return": (C.c_int, [_vp, _vp, _vp, _vp, _dbl, C.POINTER(mpk_rollout_cfg), _vp, _vp, C.POINTER(mpk_replan_state),
                                      _vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _i32, _vp]),
+    "mpk_replan_step_gated": (C.c_int, [_vp, _vp, _vp, _vp, _dbl, C.POINTER(mpk_rollout_cfg), _vp, _vp,
+                                        C.POINTER(mpk_replan_state), C.POINTER(mpk_validity_gate), _vp, _vp, _vp, _i32, _vp]),
+    "mpk_episode_return_gated": (C.c_int, [_vp, _vp, _vp, _vp, _dbl, C.POINTER(mpk_rollout_cfg), _vp, _vp, C.POINTER(mpk_replan_state),
+                                           C.POINTER(mpk_validity_gate), _vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _i32, _vp]),
     "mpk_reward_aggregate": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _vp]),
     "mpk_pd_rollout": (C.c_int, [_vp, C.POINTER(mpk_rollout_cfg), _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "mpk_condition_gather": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
@@ -131,10 +144,10 @@ _lib: Optional[C.CDLL] = None
 
 # the files libmpk.so is built from, in the order mpk_source_hash() is defined over (include/mpk.h)
 _ROOT = os.path.dirname(_HERE)
-KERNEL_UNITS = ("mpk_traj_family.hip", "mpk_traj_ring.hip", "mpk_episode.hip", "mpk_traj_launch.hip", "mpk_traj_wide.hip", "mpk_traj_phase.hip", "mpk_rollout.hip",
-                "mpk_misc.hip")          # translation units of the device code (mpk_traj_family.hip: once per MP type)
+KERNEL_UNITS = ("mpk_traj_family.hip", "mpk_traj_ring.hip", "mpk_episode.hip", "mpk_traj_launch.hip", "mpk_traj_wide.hip", "mpk_traj_phase.hip",
+                "mpk_phase_fused.hip", "mpk_rollout.hip", "mpk_misc.hip")          # translation units of the device code (mpk_traj_family.hip: once per MP type)
 KERNEL_HEADERS = ("mpk_dev.h", "mpk_tile.h", "mpk_traj_tiles.h", "mpk_traj_stream.h", "mpk_traj_flat.h", "mpk_traj_ring.h", "mpk_traj_quad.h",
-                  "mpk_traj_pipe.h", "mpk_reward.h", "mpk_trace_reader.h")
+                  "mpk_traj_pipe.h", "mpk_reward.h", "mpk_phase.h", "mpk_trace_reader.h")
 SOURCE_FILES = (os.path.join(_ROOT, "include", "mpk.h"), os.path.join(_HERE, "csrc", "mpk_internal.h"),
                 os.path.join(_HERE, "csrc", "mpk_host.cpp")) + \
     tuple(os.path.join(_HERE, "csrc", f) for f in KERNEL_HEADERS + KERNEL_UNITS)

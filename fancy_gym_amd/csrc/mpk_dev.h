@@ -167,7 +167,9 @@ __device__ __forceinline__ float div_exact(float z, const ExactDiv& x) {
 // how many steps this plan executes before the loop breaks (end of the horizon, or the schedule t % every == 0 while
 // plan_steps < max_planning_times), and the counters after it.  k_replan_advance and the fused closed-loop kernels both
 // call this, `writer` = the one lane per episode that stores the new state.
-__device__ __forceinline__ int replan_rule(const ReplanDev& rp, int b, int T, bool writer) {
+struct ReplanVals { int seg, cur, plan; bool was_done; };
+// the rule itself: loads + arithmetic, nothing written
+__device__ __forceinline__ ReplanVals replan_eval(const ReplanDev& rp, int b, int T) {
     // three independent loads (one memory round trip): this sits in front of a serial recurrence
     const uint8_t was_done = rp.done[b];
     const int cur = rp.traj_steps[b];
@@ -182,19 +184,30 @@ __device__ __forceinline__ int replan_rule(const ReplanDev& rp, int b, int T, bo
     if (seg > T) seg = T;
     if (seg < 1) seg = 1;
     if (was_done) seg = 0;                               // a finished episode is left alone
-    if (writer) {
-        rp.seg_len[b] = seg;
-        if (!was_done) {
-            const uint8_t dn = (cur + seg) >= rp.horizon ? 1 : 0;
-            rp.plan_steps[b] = plan;
-            rp.traj_steps[b] = cur + seg;
-            rp.done[b] = dn;
-            if (rp.done_out) rp.done_out[b] = dn;
-        } else if (rp.done_out) {
-            rp.done_out[b] = 1;
+    return ReplanVals{seg, cur, plan, was_done != 0};
+}
+// ... and the state after the plan.  `valid` false (the validity gate of mpk_replan_step_gated: an invalid plan finishes its episode
+// without executing a step, black_box_wrapper.py:169-172): done = 1, nothing else moves, seg_len = 0.  Returns the executed steps.
+__device__ __forceinline__ int replan_write(const ReplanDev& rp, int b, const ReplanVals& v, bool valid = true) {
+    const int seg = valid ? v.seg : 0;
+    rp.seg_len[b] = seg;
+    if (!v.was_done) {
+        const uint8_t dn = (!valid || (v.cur + seg) >= rp.horizon) ? 1 : 0;
+        if (valid) {
+            rp.plan_steps[b] = v.plan;
+            rp.traj_steps[b] = v.cur + seg;
         }
+        rp.done[b] = dn;
+        if (rp.done_out) rp.done_out[b] = dn;
+    } else if (rp.done_out) {
+        rp.done_out[b] = 1;
     }
     return seg;
+}
+__device__ __forceinline__ int replan_rule(const ReplanDev& rp, int b, int T, bool writer) {
+    const ReplanVals v = replan_eval(rp, b, T);
+    if (writer) replan_write(rp, b, v);
+    return v.seg;
 }
 
 // Basis tables -> LDS, once per workgroup of 256 threads: every thread issues ALL its loads (up to four chunks of the

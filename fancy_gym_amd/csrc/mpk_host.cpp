@@ -843,7 +843,7 @@ static int pending_ring_fault(Handle* h) {
     if (!h->h_fault) return MPK_OK;
     const int f = __atomic_exchange_n(h->h_fault, 0, __ATOMIC_RELAXED);
     if (!(f & 2)) { if (f) __atomic_fetch_or(h->h_fault, f & ~2, __ATOMIC_RELAXED); return MPK_OK; }
-    char msg[256];
+    char msg[512];      // (256 until round 6: the text is ~310 characters, and what got cut was "outputs ... are incomplete")
     std::snprintf(msg, sizeof msg, "k_traj_ring: a wave of an earlier launch on this handle gave up waiting for its partner (role mask 0x%x: "
                   "1 producer / buffer, 2 ticket, 4 store engine / batch, 8 action writer, 16 consumer / tile, 32 consumer / writer): "
                   "outputs (closed loop: plant and replanning state too) of that launch are incomplete", (unsigned)f >> 8);
@@ -859,11 +859,42 @@ static bool fused_capable(const Handle* h) {
     return mfma_capable(h);
 }
 
+// ... and promp / prodmp with a LEARNED tau / delay on k_phase_fused (round 6: the reference's TableTennis-ProDMP / BeerPong-ProMP families)
+static bool fused_phase_capable(const Handle* h) {
+    return !shared_phase(h, nullptr) && h->cfg.mp_type != MPK_MP_DMP && phase_fused_capable(h->dev);
+}
+
+static int fill_gate(const Handle* h, const mpk_validity_gate* g, GateDev* out) {
+    if (!g->pos_low || !g->pos_high || !g->valid) { set_error("validity gate: NULL pos_low / pos_high / valid"); return MPK_EINVAL; }
+    if (h->dev.D > kMaxD) { set_error("validity gate: num_dof too large"); return MPK_EINVAL; }
+    for (int d = 0; d < h->dev.D; ++d) { out->lo[d] = g->pos_low[d]; out->hi[d] = g->pos_high[d]; }
+    out->check_td = g->check_tau_delay ? 1 : 0;
+    if (out->check_td && h->dev.P < 2) { set_error("validity gate: check_tau_delay needs at least two parameters per episode"); return MPK_EINVAL; }
+    out->tau_b[0] = g->tau_bound[0]; out->tau_b[1] = g->tau_bound[1];
+    out->delay_b[0] = g->delay_bound[0]; out->delay_b[1] = g->delay_bound[1];
+    out->raw_params = g->raw_params; out->valid = g->valid; out->penalty = g->penalty;
+    return MPK_OK;
+}
+
+// one k_phase_fused launch (per-episode phase): the common tail of the four fused entry points
+static int phase_fused_common(Handle* h, const float* params, const float* init_pos, const float* init_vel, double init_time_shared,
+                              float* pos, float* vel, float* actions, const RolloutDev& rd, double* q, double* qd,
+                              const int32_t* n_steps, const ReplanDev* rp, const GateDev* gate, double* ret, int32_t* seg_out,
+                              int32_t B, void* stream) {
+    if (!params || !init_pos || !init_vel) { set_error("NULL buffer"); return MPK_EINVAL; }
+    {
+        const int fr = pending_ring_fault(h);
+        if (fr != MPK_OK) return fr;
+    }
+    return launch_phase_fused(h->dev, params, init_pos, init_vel, (float)init_time_shared, pos, vel, actions, rd, q, qd, n_steps, rp,
+                              gate, ret, seg_out, h->d_flag, B, h->num_cu, stream, &h->last_kernel, effective_tuning(h));
+}
+
 static int traj_common(Handle* h, const float* params, const float* init_pos, const float* init_vel,
                        const float* init_time, double init_time_shared, float* pos, float* vel, float* actions,
                        const RolloutDev* rd, const double* c_pos, const double* c_vel, int32_t B, void* stream,
                        double* q_state = nullptr, double* qd_state = nullptr, const int32_t* n_steps = nullptr,
-                       const ReplanDev* rp = nullptr) {
+                       const ReplanDev* rp = nullptr, const GateDev* gate = nullptr) {
     if (B < 0) { set_error("B must be >= 0"); return MPK_EINVAL; }
     if (B == 0 || h->dev.D == 0) return MPK_OK;     // empty batch: nothing to do (buffers may be NULL)
     if (!params || !init_pos || !init_vel || !pos || !vel) { set_error("NULL buffer"); return MPK_EINVAL; }
@@ -911,7 +942,7 @@ static int traj_common(Handle* h, const float* params, const float* init_pos, co
         unsigned* ticket = ticket_slot(h, stream);
         const char* name = "";
         rc = launch_traj_shared(h->dev_resp, st, params, init_pos, init_vel, pos, vel, actions, rd, c_pos, c_vel,
-                                q_state, qd_state, n_steps, B, h->num_cu, stream, &name, tune, rp, ticket, h->d_fault);
+                                q_state, qd_state, n_steps, B, h->num_cu, stream, &name, tune, rp, ticket, h->d_fault, gate);
         if (rc == MPK_OK) {
             h->kernel_name_buf = name;
             const size_t at = h->kernel_name_buf.find("prodmp");
@@ -927,7 +958,7 @@ static int traj_common(Handle* h, const float* params, const float* init_pos, co
         if (rc != MPK_OK) return rc;
         unsigned* ticket = ticket_slot(h, stream);
         rc = launch_traj_shared(h->dev, st, params, init_pos, init_vel, pos, vel, actions, rd, c_pos, c_vel,
-                                q_state, qd_state, n_steps, B, h->num_cu, stream, &h->last_kernel, tune, rp, ticket, h->d_fault);
+                                q_state, qd_state, n_steps, B, h->num_cu, stream, &h->last_kernel, tune, rp, ticket, h->d_fault, gate);
         // horizons whose basis tables do not fit the episode-major kernel's LDS: the per-episode kernels below (dmp) or,
         // for fused actions / rollouts, the caller's two-launch path
         if (rc != MPK_ENOTIMPL || actions) return rc;
@@ -961,8 +992,12 @@ int mpk_trajectory_actions(mpk_handle hh, const float* params, const float* init
         r = traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, actions, &rd, c_pos, c_vel,
                         B, stream);
         if (r != MPK_ENOTIMPL) return r;
+    } else if (fused_phase_capable(h) && B > 0 && pos && vel) {
+        r = phase_fused_common(h, params, init_pos, init_vel, init_time_shared, pos, vel, actions, rd, const_cast<double*>(c_pos),
+                               const_cast<double*>(c_vel), nullptr, nullptr, nullptr, nullptr, nullptr, B, stream);
+        if (r != MPK_ENOTIMPL) return r;
     }
-    // what the single fused kernel does not cover (dmp, learned tau / delay, > 16 DoF or basis columns): same result
+    // what the fused kernels do not cover (dmp with a learned phase, > 16 DoF or basis columns): same result
     // from two launches
     r = traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, nullptr, nullptr, nullptr,
                     nullptr, B, stream);
@@ -987,17 +1022,22 @@ int mpk_trajectory_rollout(mpk_handle hh, const float* params, const float* init
         r = traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, actions, &rd, nullptr,
                         nullptr, B, stream, q, qd, n_steps);
         if (r != MPK_ENOTIMPL) return r;
+    } else if (fused_phase_capable(h) && B > 0 && pos && vel) {
+        r = phase_fused_common(h, params, init_pos, init_vel, init_time_shared, pos, vel, actions, rd, q, qd, n_steps, nullptr, nullptr,
+                               nullptr, nullptr, B, stream);
+        if (r != MPK_ENOTIMPL) return r;
     }
-    // dmp, learned tau / delay, horizons beyond the fused kernel's LDS tables, > 16 DoF or basis columns: trajectory kernel + rollout kernel, same result
+    // dmp with a learned phase, horizons beyond the fused kernel's LDS tables, > 16 DoF or basis columns: trajectory kernel + rollout kernel, same result
     r = traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, nullptr, nullptr, nullptr,
                     nullptr, B, stream);
     if (r != MPK_OK) return r;
     return launch_pd_rollout(rd, h->dev.D, pos, vel, q, qd, n_steps, actions, B, h->dev.T, stream, effective_tuning(h));
 }
 
-int mpk_replan_step(mpk_handle hh, const float* params, const float* init_pos, const float* init_vel,
-                    double init_time_shared, const mpk_rollout_cfg* rc, double* q, double* qd,
-                    const mpk_replan_state* st, float* pos, float* vel, float* actions, int32_t B, void* stream) {
+int mpk_replan_step_gated(mpk_handle hh, const float* params, const float* init_pos, const float* init_vel,
+                          double init_time_shared, const mpk_rollout_cfg* rc, double* q, double* qd,
+                          const mpk_replan_state* st, const mpk_validity_gate* gate, float* pos, float* vel, float* actions,
+                          int32_t B, void* stream) {
     if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
     Handle* h = reinterpret_cast<Handle*>(hh);
     if (B < 0) { set_error("B must be >= 0"); return MPK_EINVAL; }
@@ -1011,36 +1051,58 @@ int mpk_replan_step(mpk_handle hh, const float* params, const float* init_pos, c
     int r = fill_rollout(h, rc, &rd);
     if (r != MPK_OK) return r;
     if (rd.plant_type != MPK_PLANT_DOUBLE_INTEGRATOR) { set_error("mpk_replan_step integrates MPK_PLANT_DOUBLE_INTEGRATOR"); return MPK_EINVAL; }
+    GateDev gd;
+    if (gate) {
+        r = fill_gate(h, gate, &gd);
+        if (r != MPK_OK) return r;
+    }
     MPK_ON_DEVICE(h->cfg.device);
     ReplanDev rp;
     rp.traj_steps = st->traj_steps; rp.plan_steps = st->plan_steps; rp.done = st->done; rp.seg_len = st->seg_len;
     rp.done_out = st->done_out; rp.cond_pos = st->cond_pos; rp.cond_vel = st->cond_vel;
     rp.every = st->every; rp.max_planning_times = st->max_planning_times; rp.horizon = st->horizon;
     if (fused_capable(h)) {
-        // ONE launch: integer state, trajectory, controller + plant, condition gather
+        // ONE launch: integer state, trajectory, (validity gate,) controller + plant, condition gather
         r = traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, actions, &rd, nullptr,
-                        nullptr, B, stream, q, qd, nullptr, &rp);
+                        nullptr, B, stream, q, qd, nullptr, &rp, gate ? &gd : nullptr);
+        if (r != MPK_ENOTIMPL) return r;
+    } else if (fused_phase_capable(h) && pos && vel) {
+        r = phase_fused_common(h, params, init_pos, init_vel, init_time_shared, pos, vel, actions, rd, q, qd, nullptr, &rp,
+                               gate ? &gd : nullptr, nullptr, nullptr, B, stream);
         if (r != MPK_ENOTIMPL) return r;
     }
-    // what the fused kernel does not cover (dmp, learned tau / delay, long horizons, > 16 DoF or basis columns): the same
+    // what the fused kernels do not cover (dmp with a learned phase, long horizons, > 16 DoF or basis columns): the same
     // result from the separate kernels
-    r = launch_replan_advance(rp.traj_steps, rp.plan_steps, rp.seg_len, rp.done, rp.every, rp.max_planning_times,
-                              rp.horizon, h->dev.T, B, stream);
-    if (r != MPK_OK) return r;
-    if (rp.done_out) MPK_HIP(hipMemcpyAsync(rp.done_out, rp.done, (size_t)B, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     r = traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, nullptr, nullptr, nullptr,
                     nullptr, B, stream);
     if (r != MPK_OK) return r;
+    if (gate) {
+        // the plan is judged first; an invalid one finishes its episode (done |= !valid) before the integer rule looks at it
+        r = launch_validity(pos, gd.raw_params ? gd.raw_params : params, h->dev.P, h->dev.D, gd.lo, gd.hi, gd.check_td, gd.tau_b, gd.delay_b,
+                            gd.valid, gd.penalty, B, h->dev.T, stream);
+        if (r != MPK_OK) return r;
+    }
+    r = launch_replan_advance(rp.traj_steps, rp.plan_steps, rp.seg_len, rp.done, rp.every, rp.max_planning_times,
+                              rp.horizon, h->dev.T, B, stream, gate ? gd.valid : nullptr);
+    if (r != MPK_OK) return r;
+    if (rp.done_out) MPK_HIP(hipMemcpyAsync(rp.done_out, rp.done, (size_t)B, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     r = launch_pd_rollout(rd, h->dev.D, pos, vel, q, qd, rp.seg_len, actions, B, h->dev.T, stream, effective_tuning(h));
     if (r != MPK_OK) return r;
     if (rp.cond_pos) return launch_condition_gather(pos, vel, rp.seg_len, rp.cond_pos, rp.cond_vel, B, h->dev.T, h->dev.D, stream);
     return MPK_OK;
 }
 
-int mpk_episode_return(mpk_handle hh, const float* params, const float* init_pos, const float* init_vel,
-                       double init_time_shared, const mpk_rollout_cfg* rc, double* q, double* qd, const mpk_replan_state* st,
-                       const int32_t* n_steps, int32_t* seg_out, int32_t reward, const double* goal, const int32_t* step0,
-                       int32_t steps_before_reward, int32_t agg, double* ret, int32_t B, void* stream) {
+int mpk_replan_step(mpk_handle hh, const float* params, const float* init_pos, const float* init_vel,
+                    double init_time_shared, const mpk_rollout_cfg* rc, double* q, double* qd,
+                    const mpk_replan_state* st, float* pos, float* vel, float* actions, int32_t B, void* stream) {
+    return mpk_replan_step_gated(hh, params, init_pos, init_vel, init_time_shared, rc, q, qd, st, nullptr, pos, vel, actions, B, stream);
+}
+
+int mpk_episode_return_gated(mpk_handle hh, const float* params, const float* init_pos, const float* init_vel,
+                             double init_time_shared, const mpk_rollout_cfg* rc, double* q, double* qd, const mpk_replan_state* st,
+                             const mpk_validity_gate* gate, const int32_t* n_steps, int32_t* seg_out, int32_t reward,
+                             const double* goal, const int32_t* step0, int32_t steps_before_reward, int32_t agg, double* ret,
+                             int32_t B, void* stream) {
     if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
     Handle* h = reinterpret_cast<Handle*>(hh);
     if (B < 0) { set_error("B must be >= 0"); return MPK_EINVAL; }
@@ -1063,12 +1125,23 @@ int mpk_episode_return(mpk_handle hh, const float* params, const float* init_pos
     int r = fill_rollout(h, rc, &rd);
     if (r != MPK_OK) return r;
     if (rd.plant_type != MPK_PLANT_DOUBLE_INTEGRATOR) { set_error("mpk_episode_return integrates MPK_PLANT_DOUBLE_INTEGRATOR"); return MPK_EINVAL; }
+    GateDev gd;
+    if (gate) {
+        r = fill_gate(h, gate, &gd);
+        if (r != MPK_OK) return r;
+    }
     MPK_ON_DEVICE(h->cfg.device);
     {
         const int fr = pending_ring_fault(h);
         if (fr != MPK_OK) return fr;
     }
-    if (!fused_capable(h)) { set_error("mpk_episode_return needs a shared phase with <= 16 contraction columns and DoF"); return MPK_ENOTIMPL; }
+    if (fused_phase_capable(h)) {
+        // learned tau / delay: k_phase_fused without stores (no device reward for these families: include/mpk.h)
+        if (reward != MPK_REWARD_NONE) { set_error("mpk_episode_return: a per-episode phase has no device reward"); return MPK_ENOTIMPL; }
+        return phase_fused_common(h, params, init_pos, init_vel, init_time_shared, nullptr, nullptr, nullptr, rd, q, qd,
+                                  st ? nullptr : n_steps, st ? &rp : nullptr, gate ? &gd : nullptr, ret, seg_out, B, stream);
+    }
+    if (!fused_capable(h)) { set_error("mpk_episode_return needs a shared phase with <= 16 contraction columns and DoF, or a learned phase with <= 8 columns"); return MPK_ENOTIMPL; }
     const Tuning tune = effective_tuning(h);
     if (h->cfg.mp_type == MPK_MP_DMP && h->cfg.dmp_first_sample == MPK_DMP_FIRST_IS_STEP) {
         set_error("mpk_episode_return: MPK_DMP_FIRST_IS_STEP handles take the separate launches");
@@ -1081,7 +1154,7 @@ int mpk_episode_return(mpk_handle hh, const float* params, const float* init_pos
     const char* name = "";
     r = launch_episode_return(resp ? h->dev_resp : h->dev, stt, params, init_pos, init_vel, rd, q, qd, st ? nullptr : n_steps,
                               st ? &rp : nullptr, reward, goal, step0, steps_before_reward, agg, ret, seg_out, B, h->num_cu, stream,
-                              &name, tune);
+                              &name, tune, gate ? &gd : nullptr);
     if (r == MPK_OK) {
         h->kernel_name_buf = name;
         if (resp) {
@@ -1091,6 +1164,14 @@ int mpk_episode_return(mpk_handle hh, const float* params, const float* init_pos
         h->last_kernel = h->kernel_name_buf.c_str();
     }
     return r;
+}
+
+int mpk_episode_return(mpk_handle hh, const float* params, const float* init_pos, const float* init_vel,
+                       double init_time_shared, const mpk_rollout_cfg* rc, double* q, double* qd, const mpk_replan_state* st,
+                       const int32_t* n_steps, int32_t* seg_out, int32_t reward, const double* goal, const int32_t* step0,
+                       int32_t steps_before_reward, int32_t agg, double* ret, int32_t B, void* stream) {
+    return mpk_episode_return_gated(hh, params, init_pos, init_vel, init_time_shared, rc, q, qd, st, nullptr, n_steps, seg_out, reward,
+                                    goal, step0, steps_before_reward, agg, ret, B, stream);
 }
 
 int mpk_reward_aggregate(mpk_handle hh, const double* rewards, const int32_t* seg_len, int32_t agg, double* out, int32_t B,

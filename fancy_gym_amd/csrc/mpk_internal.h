@@ -84,6 +84,16 @@ struct ReplanDev {
     int every = 1, max_planning_times = 0, horizon = 0;
 };
 
+// validity gate of the fused closed-loop entry points (mpk_validity_gate of include/mpk.h with the limits copied in)
+struct GateDev {
+    double lo[kMaxD], hi[kMaxD];     // joint limits
+    int check_td = 0;
+    double tau_b[2] = {0.0, 0.0}, delay_b[2] = {0.0, 0.0};
+    const float* raw_params = nullptr;   // [B, P] the action as passed (NULL: the params of the call)
+    uint8_t* valid = nullptr;            // [B] out
+    double* penalty = nullptr;           // [B] out, optional
+};
+
 // shared-phase table workspace produced by k_build_shared and consumed by k_traj_shared
 struct SharedTables {
     float* A = nullptr;    // [n_out][KP][TS]
@@ -100,11 +110,13 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
                        const float* init_vel, float* pos, float* vel, float* actions, const RolloutDev* rc,
                        const double* c_pos, const double* c_vel, double* q_state, double* qd_state,
                        const int32_t* n_steps, int B, int num_cu, void* stream, const char** kernel_name,
-                       const Tuning& tune, const ReplanDev* rp = nullptr, unsigned* ticket = nullptr, int* fault = nullptr);
+                       const Tuning& tune, const ReplanDev* rp = nullptr, unsigned* ticket = nullptr, int* fault = nullptr,
+                       const GateDev* gate = nullptr);
 int launch_episode_return(const DevCfg& c, const SharedTables& st, const float* params, const float* init_pos, const float* init_vel,
                           const RolloutDev& rc, double* q_state, double* qd_state, const int32_t* n_steps, const ReplanDev* rp,
                           int reward_type, const double* goal, const int32_t* step0, int steps_before_reward, int agg, double* ret,
-                          int32_t* seg_out, int B, int num_cu, void* stream, const char** kernel_name, const Tuning& tune);
+                          int32_t* seg_out, int B, int num_cu, void* stream, const char** kernel_name, const Tuning& tune,
+                          const GateDev* gate = nullptr);
 int launch_reward_aggregate(const double* rewards, const int32_t* seg_len, int agg, double* out, int B, int T, void* stream);
 // shared phase, more than kMaxKP contraction columns: k-chunked GEMM on the matrix cores (trajectory only)
 int launch_traj_wide(const DevCfg& c, const SharedTables& st, const float* params, const float* init_pos,
@@ -116,6 +128,14 @@ int launch_traj_rows(const DevCfg& c, const float* params, const float* init_pos
 int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const float* des_vel, double* q,
                       double* qd, const int32_t* n_steps, float* actions, int B, int T, void* stream,
                       const Tuning& tune);
+// the fused entry points with a per-episode phase (learned tau / delay), promp / prodmp with <= 8 contraction columns and <= 16 DoF
+// (mpk_phase_fused.hip): rc.plant_type static = actions for the frozen state (q, qd), double integrator = closed loop; pos == nullptr:
+// nothing per step is stored (mpk_episode_return).  MPK_ENOTIMPL for other shapes.
+bool phase_fused_capable(const DevCfg& c);
+int launch_phase_fused(const DevCfg& c, const float* params, const float* init_pos, const float* init_vel, float init_time_shared,
+                       float* pos, float* vel, float* actions, const RolloutDev& rc, double* q, double* qd, const int32_t* n_steps,
+                       const ReplanDev* rp, const GateDev* gate, double* ret, int32_t* seg_out, int32_t* range_flag, int B, int num_cu,
+                       void* stream, const char** kernel_name, const Tuning& tune);
 // per-episode-phase DMP: the interpolation table of the forcing rows (mpk_traj_phase.hip fast_rows_build), built once per handle
 int fast_rows_floats(const DevCfg& c);      // 0: none for this shape
 int fast_rows_stride(const DevCfg& c);      // floats per node = the consuming kernels' KS
@@ -133,7 +153,7 @@ int launch_episode_reset(const double* init_q, const double* init_qd, double* q,
                          float* cond_vel, int32_t* traj_steps, int32_t* plan_steps, uint8_t* done, int B, int D,
                          void* stream);
 int launch_replan_advance(int32_t* traj_steps, int32_t* plan_steps, int32_t* seg_len, uint8_t* done, int every,
-                          int max_planning_times, int horizon, int T, int B, void* stream);
+                          int max_planning_times, int horizon, int T, int B, void* stream, const uint8_t* valid = nullptr);
 int launch_validity(const float* pos, const float* params, int P, int D, const double* lo, const double* hi,
                     int check_td, const double* tb, const double* db, uint8_t* valid, double* penalty, int B, int T,
                     void* stream);

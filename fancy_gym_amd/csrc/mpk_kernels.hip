@@ -11,6 +11,7 @@
 //   mpk_traj_launch.hip  k_build_shared + launch_traj_shared (kernel selection rule)
 //   mpk_traj_wide.hip    k_traj_wide
 //   mpk_traj_phase.hip   per-episode phase kernels
+//   mpk_phase_fused.hip  per-episode phase: the fused entry points (actions, closed loop, replanning step, verbose < 2 step, validity gate)
 //   mpk_rollout.hip      rollout kernels
 //   mpk_misc.hip         integer state, reset, gather, validity, self-tests, trace readout
 #define MPK_AMALGAMATED 1
@@ -20,5 +21,6 @@
 #include "mpk_traj_launch.hip"
 #include "mpk_traj_wide.hip"
 #include "mpk_traj_phase.hip"
+#include "mpk_phase_fused.hip"
 #include "mpk_rollout.hip"
 #include "mpk_misc.hip"

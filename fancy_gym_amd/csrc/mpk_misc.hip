@@ -7,19 +7,22 @@ namespace mpk {
 // ------------------------------------------------------------------------------------------------------------
 // integer replanning state
 // ------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_replan_advance(const ReplanDev rp, const int T, const int B) {
+// valid (optional): the verdict of the validity gate on the plan just produced -- an invalid plan finishes its episode without a step
+// (done |= !valid in front of the rule: replan_write)
+__global__ void __launch_bounds__(256) k_replan_advance(const ReplanDev rp, const int T, const int B, const uint8_t* __restrict__ valid) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
-    (void)replan_rule(rp, b, T, true);
+    const ReplanVals v = replan_eval(rp, b, T);
+    (void)replan_write(rp, b, v, valid ? valid[b] != 0 : true);
 }
 
 #ifndef MPK_DEVICE_ONLY
 int launch_replan_advance(int32_t* traj_steps, int32_t* plan_steps, int32_t* seg_len, uint8_t* done, int every,
-                          int max_planning_times, int horizon, int T, int B, void* stream) {
+                          int max_planning_times, int horizon, int T, int B, void* stream, const uint8_t* valid) {
     ReplanDev rp;
     rp.traj_steps = traj_steps; rp.plan_steps = plan_steps; rp.seg_len = seg_len; rp.done = done;
     rp.every = every; rp.max_planning_times = max_planning_times; rp.horizon = horizon;
-    hipLaunchKernelGGL(k_replan_advance, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, rp, T, B);
+    hipLaunchKernelGGL(k_replan_advance, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, rp, T, B, valid);
     MPK_LAUNCH_CHECK();
     return MPK_OK;
 }

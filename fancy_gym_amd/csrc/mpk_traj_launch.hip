@@ -192,7 +192,9 @@ extern template int launch_episode_kernel<MPK_MP_PRODMP>(const TrajArgs&, const 
 int launch_episode_return(const DevCfg& c, const SharedTables& st, const float* params, const float* init_pos, const float* init_vel,
                           const RolloutDev& rc, double* q_state, double* qd_state, const int32_t* n_steps, const ReplanDev* rp,
                           int reward_type, const double* goal, const int32_t* step0, int steps_before_reward, int agg, double* ret,
-                          int32_t* seg_out, int B, int num_cu, void* stream, const char** kernel_name, const Tuning& tune) {
+                          int32_t* seg_out, int B, int num_cu, void* stream, const char** kernel_name, const Tuning& tune,
+                          const GateDev* gate) {
+    if (gate) { set_error("mpk_episode_return_gated: the validity gate is not fused for this configuration"); return MPK_ENOTIMPL; }
     TrajArgs ta{};
     ta.wpb = 4; ta.ring_parts = 1;
     if (rp) ta.rp = *rp;
@@ -250,7 +252,8 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
                        const float* init_vel, float* pos, float* vel, float* actions, const RolloutDev* rc,
                        const double* c_pos, const double* c_vel, double* q_state, double* qd_state,
                        const int32_t* n_steps, int B, int num_cu, void* stream, const char** kernel_name,
-                       const Tuning& tune, const ReplanDev* rp, unsigned* ticket, int* fault) {
+                       const Tuning& tune, const ReplanDev* rp, unsigned* ticket, int* fault, const GateDev* gate) {
+    if (gate) return MPK_ENOTIMPL;      // (the caller's separate launches)
     TrajArgs ta;
     ta.fault = fault;
     ta.nrt_magic = 0; ta.gstride = 0; ta.wt = 0; ta.flat_img = 0;

@@ -1,5 +1,5 @@
 // k_traj_rows / k_traj_phase / k_traj_phase_dmp / k_dmp_prestep: per-episode phase (learned tau / delay, per-episode init_time)
-#include "mpk_tile.h"
+#include "mpk_phase.h"
 
 namespace mpk {
 
@@ -313,16 +313,6 @@ __device__ __forceinline__ float phase_x_value(const DevCfg& c, const float* __r
     return k < c.nb ? prm[c.off + dd * c.Kloc + k] : ip[dd];
 }
 
-// the value of the neighbouring lane (lane + 1 / lane - 1 of the 64) as ONE vector instruction (DPP wave shift) instead
-// of an LDS round trip (ds_bpermute behind __shfl_*): the ProMP velocity takes two of them per (step, DoF).  The lane
-// without a neighbour reads 0; nothing uses it.
-__device__ __forceinline__ float lane_above(float x) {      // x of lane + 1
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float lane_below(float x) {      // x of lane - 1
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, false));
-}
-
 template <int KQ>
 __device__ __forceinline__ float row_chain(const float* __restrict__ row, const float (&x)[KQ * 4]) {
     float acc = 0.0f;
@@ -395,67 +385,6 @@ __device__ __forceinline__ void flush_span2(const float* __restrict__ s0, const 
 // episode they belong to (a chunk's outputs are one contiguous run of HBM) -- instead of over each episode's steps: T = 100
 // fills 100 of 128 lanes per episode the other way.  Everything per episode (clipped tau / delay, init_time, 1 / tau, the
 // boundary-condition factors) is then per LANE, read from the chunk image; same arithmetic per (episode, step), same bits.
-// The DC (position, velocity) contractions of one (episode, step) item with the DoF count at compile time: every column first, then
-// the DC chains side by side -- each chain's own order of operations (ascending k, one v_pk_fma_f32 per k) is the run-time loop's, so
-// the results are the same bits; one chain after the other was 8 dependent FMAs behind two LDS reads, DC times in a row.
-template <int DC, int KQ>
-__device__ __forceinline__ void dofs_unrolled(const float* __restrict__ sX, const float* hq, const float inv_tau, float* __restrict__ o0,
-                                              float* __restrict__ o1) {
-    constexpr int KS = KQ * 4;
-    float x[DC][KS];
-#pragma unroll
-    for (int d = 0; d < DC; ++d)
-#pragma unroll
-        for (int j = 0; j < KQ; ++j) {
-            const float4 v = *reinterpret_cast<const float4*>(sX + d * KS + 4 * j);
-            x[d][4 * j + 0] = v.x; x[d][4 * j + 1] = v.y; x[d][4 * j + 2] = v.z; x[d][4 * j + 3] = v.w;
-        }
-    f32x2 pv[DC];
-#pragma unroll
-    for (int d = 0; d < DC; ++d) pv[d] = f32x2{0.0f, 0.0f};
-#pragma unroll
-    for (int k = 0; k < KS; ++k)
-#pragma unroll
-        for (int d = 0; d < DC; ++d)
-            pv[d] = __builtin_elementwise_fma(f32x2{hq[2 * k], hq[2 * k + 1]}, f32x2{x[d][k], x[d][k]}, pv[d]);
-#pragma unroll
-    for (int d = 0; d < DC; ++d) {
-        o0[d] = pv[d][0];
-        o1[d] = pv[d][1] * inv_tau;
-    }
-}
-
-// ... and ProMP's: position chains side by side, then each DoF's forward difference over the lanes (lane_above / lane_below, see there)
-template <int DC, int KQ>
-__device__ __forceinline__ void dofs_unrolled_promp(const float* __restrict__ sX, const float (&h)[KQ * 4], const float rdt, const bool last_row,
-                                                    float* __restrict__ o0, float* __restrict__ o1) {
-    constexpr int KS = KQ * 4;
-    float x[DC][KS];
-#pragma unroll
-    for (int d = 0; d < DC; ++d)
-#pragma unroll
-        for (int j = 0; j < KQ; ++j) {
-            const float4 v = *reinterpret_cast<const float4*>(sX + d * KS + 4 * j);
-            x[d][4 * j + 0] = v.x; x[d][4 * j + 1] = v.y; x[d][4 * j + 2] = v.z; x[d][4 * j + 3] = v.w;
-        }
-    float p[DC];
-#pragma unroll
-    for (int d = 0; d < DC; ++d) p[d] = 0.0f;
-#pragma unroll
-    for (int k = 0; k < KS; ++k)
-#pragma unroll
-        for (int d = 0; d < DC; ++d) p[d] = fmaf(h[k], x[d][k], p[d]);
-#pragma unroll
-    for (int d = 0; d < DC; ++d) {
-        const float nx = lane_above(p[d]);
-        float v = (nx - p[d]) * rdt;
-        const float pv = lane_below(v);         // last row repeats the difference before it
-        if (last_row) v = pv;
-        o0[d] = p[d];
-        o1[d] = v;
-    }
-}
-
 // DC: the DoF count at compile time (0: c.D) -- the per-DoF contraction loop then is straight-line code: at run time it was 162
 // instructions per pair of DoF, 85 of them scalar address arithmetic (round 5; 7 = BASELINE cfg2 / cfg4, the reference's Panda tasks)
 template <int MP, int KQ, bool TL, bool FL = false, int DC = 0>

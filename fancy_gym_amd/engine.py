@@ -342,14 +342,50 @@ class TrajectoryEngine:
                                                _dptr(cp), _dptr(cv), traj_steps.data_ptr(), plan_steps.data_ptr(),
                                                done.data_ptr(), B, self._stream()))
 
+    def _gate(self, gate, B: int):
+        """
+        dict(pos_low, pos_high, check_tau_delay=False, tau_bound=None, delay_bound=None, raw_params=None, valid=None, penalty=None)
+        -> (mpk_validity_gate, valid uint8 [B], penalty float64 [B], keep-alive); mpk.h: mpk_validity_gate
+        """
+        D = self.num_dof
+        lo_p, lo_k = _dvec(gate["pos_low"], D)
+        hi_p, hi_k = _dvec(gate["pos_high"], D)
+        check = bool(gate.get("check_tau_delay"))
+        g = _lib.mpk_validity_gate()
+        g.pos_low, g.pos_high = lo_p, hi_p
+        g.check_tau_delay = int(check)
+        tb = gate.get("tau_bound") if check else None
+        db = gate.get("delay_bound") if check else None
+        if check and (tb is None or db is None):
+            raise ValueError("check_tau_delay needs tau_bound and delay_bound")
+        g.tau_bound[0], g.tau_bound[1] = (float(tb[0]), float(tb[1])) if check else (0.0, 0.0)
+        g.delay_bound[0], g.delay_bound[1] = (float(db[0]), float(db[1])) if check else (0.0, 0.0)
+        raw = gate.get("raw_params")
+        if raw is not None:
+            raw = torch.as_tensor(raw, dtype=torch.float32, device=self.device).contiguous()
+            if tuple(raw.shape) != (B, self.num_params):
+                raise ValueError(f"raw_params must be [{B}, {self.num_params}], got {tuple(raw.shape)}")
+        valid = gate.get("valid")
+        if valid is None:
+            valid = torch.empty(B, dtype=torch.uint8, device=self.device)
+        pen = gate.get("penalty")
+        if pen is None:
+            pen = torch.empty(B, dtype=torch.float64, device=self.device)
+        assert valid.dtype == torch.uint8 and pen.dtype == torch.float64 and valid.is_contiguous() and pen.is_contiguous()
+        g.raw_params, g.valid, g.penalty = _dptr(raw), valid.data_ptr(), pen.data_ptr()
+        return g, valid, pen, (lo_k, hi_k, raw)
+
     def replan_step(self, params, init_pos, init_vel, spec: RolloutSpec, q: torch.Tensor, qd: torch.Tensor,
                     traj_steps: torch.Tensor, plan_steps: torch.Tensor, done: torch.Tensor, every: int,
-                    max_planning_times: int, horizon: int, init_time: float = 0.0, condition: bool = False, out=None):
+                    max_planning_times: int, horizon: int, init_time: float = 0.0, condition: bool = False, out=None,
+                    gate=None):
         """
         One replanning step of BlackBoxWrapper.step for every episode (mpk.h: mpk_replan_step): integer state, plan,
         controller + plant for the executed steps and -- ``condition`` -- the desired state at the last executed step, in
         ONE launch where the fused closed-loop kernel applies.  q, qd, traj_steps, plan_steps, done are updated in place.
         Returns dict(pos, vel, actions, seg_len int32 [B], done uint8 [B] snapshot, cond_pos, cond_vel (or None)).
+        ``gate`` (see ``_gate``): the validity gate inside the step (mpk.h: mpk_replan_step_gated) -- additionally ``valid``
+        uint8 [B] and ``penalty`` float64 [B]; an invalid plan finishes its episode without a step.
         """
         self._refuse_metaworld(spec, "replan_step")
         params = torch.as_tensor(params, dtype=torch.float32, device=self.device)
@@ -372,6 +408,14 @@ class TrajectoryEngine:
         st = _lib.mpk_replan_state(traj_steps.data_ptr(), plan_steps.data_ptr(), done.data_ptr(), seg.data_ptr(),
                                    done_out.data_ptr(), _dptr(cp), _dptr(cv), int(every),
                                    int(min(max_planning_times, 2 ** 31 - 1)), int(horizon), 0)
+        if gate is not None:
+            g, valid, pen, keep = self._gate(gate, B)
+            _lib.check(self._lib.mpk_replan_step_gated(
+                self._h, params.data_ptr(), init_pos.data_ptr(), init_vel.data_ptr(), float(init_time), C.byref(spec.c),
+                q.data_ptr(), qd.data_ptr(), C.byref(st), C.byref(g), pos.data_ptr(), vel.data_ptr(), act.data_ptr(), B,
+                self._stream()))
+            return dict(pos=pos, vel=vel, actions=act, seg_len=seg, done=done_out, cond_pos=cp, cond_vel=cv, valid=valid,
+                        penalty=pen)
         _lib.check(self._lib.mpk_replan_step(
             self._h, params.data_ptr(), init_pos.data_ptr(), init_vel.data_ptr(), float(init_time), C.byref(spec.c),
             q.data_ptr(), qd.data_ptr(), C.byref(st), pos.data_ptr(), vel.data_ptr(), act.data_ptr(), B,
@@ -382,7 +426,7 @@ class TrajectoryEngine:
                        replan=None, n_steps: Optional[torch.Tensor] = None, reward: Optional[str] = None,
                        goal: Optional[torch.Tensor] = None, step0: Optional[torch.Tensor] = None,
                        steps_before_reward: int = 199, aggregation: str = "sum", init_time: float = 0.0,
-                       condition: bool = False):
+                       condition: bool = False, gate=None):
         """
         One plan of a ``verbose < 2`` step for every episode in ONE launch, nothing per step stored (mpk.h: mpk_episode_return):
         plan + controller + double-integrator plant + reward + reward_aggregation (+ the integer replanning state and the
@@ -418,6 +462,18 @@ class TrajectoryEngine:
             goal = torch.as_tensor(goal, dtype=torch.float64, device=self.device).expand(B, 2).contiguous()
         if step0 is not None:
             step0 = step0.to(device=self.device, dtype=torch.int32).contiguous()
+        if reward not in _lib.REWARD_TYPES:
+            raise ValueError(f"unknown device reward {reward!r}; choose one of {[k for k in _lib.REWARD_TYPES if k]}")
+        if aggregation not in _lib.AGG_MODES:
+            raise ValueError(f"unknown reward aggregation {aggregation!r}; choose one of {list(_lib.AGG_MODES)}")
+        if gate is not None:
+            g, valid, pen, keep = self._gate(gate, B)
+            _lib.check(self._lib.mpk_episode_return_gated(
+                self._h, params.data_ptr(), init_pos.data_ptr(), init_vel.data_ptr(), float(init_time), C.byref(spec.c),
+                q.data_ptr(), qd.data_ptr(), C.byref(st) if st is not None else None, C.byref(g), _dptr(n_steps), seg.data_ptr(),
+                _lib.REWARD_TYPES[reward], _dptr(goal), _dptr(step0), int(steps_before_reward), _lib.AGG_MODES[aggregation],
+                ret.data_ptr(), B, self._stream()))
+            return dict(ret=ret, seg_len=seg, done=done_out, cond_pos=cp, cond_vel=cv, valid=valid, penalty=pen)
         _lib.check(self._lib.mpk_episode_return(
             self._h, params.data_ptr(), init_pos.data_ptr(), init_vel.data_ptr(), float(init_time), C.byref(spec.c),
             q.data_ptr(), qd.data_ptr(), C.byref(st) if st is not None else None, _dptr(n_steps), seg.data_ptr(),

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MPK_ABI_VERSION 3
+#define MPK_ABI_VERSION 4
 
 /* error codes */
 #define MPK_OK            0
@@ -311,8 +311,10 @@ int mpk_trajectory(mpk_handle h, const float* params, const float* init_pos, con
  * Same, fused with the open-loop part of the step loop (black_box_wrapper.py:176-179): additionally writes
  *   actions[b,t,:] = clip(controller(pos[b,t], vel[b,t], c_pos[b], c_vel[b]), act_low, act_high)
  * for a state that does not change during the plan (MPK_PLANT_STATIC).  c_pos/c_vel dev double [B, D].
- * One launch for shared-phase promp / prodmp configurations with <= 16 DoF and <= 16 basis columns, trajectory kernel
- * + rollout kernel for every other configuration; identical results either way.
+ * One launch for shared-phase promp / prodmp configurations with <= 16 DoF and <= 16 basis columns, and (ABI 4) for promp / prodmp
+ * with a LEARNED tau / delay, <= 8 contraction columns and <= 16 DoF (k_phase_fused: the reference's TableTennis-ProDMP and
+ * BeerPong-ProMP families, envs/mujoco/table_tennis/mp_wrapper.py:32-57,91-121, beerpong/mp_wrapper.py:9-25); trajectory kernel
+ * + rollout kernel for every other configuration; identical results either way (trajectories bit for bit, hence actions too).
  */
 int mpk_trajectory_actions(mpk_handle h, const float* params, const float* init_pos, const float* init_vel,
                            double init_time_shared, const mpk_rollout_cfg* rc,
@@ -326,9 +328,10 @@ int mpk_trajectory_actions(mpk_handle h, const float* params, const float* init_
  *   q, qd     dev double [B, D]  in: plant state at plan start, out: state after the executed steps
  *   n_steps   dev int32 [B] or NULL (= T): the break index of :197 (see mpk_replan_advance)
  *   pos, vel, actions dev float [B, T, D] outputs (actions beyond n_steps[b] are 0)
- * One launch for shared-phase promp / prodmp configurations with <= 16 DoF and <= 16 basis columns; every other
- * configuration (dmp, learned tau / delay, larger shapes) runs the trajectory kernel and the rollout kernel back to
- * back.  Either way the result is identical to mpk_trajectory followed by mpk_pd_rollout.
+ * One launch for shared-phase promp / prodmp configurations with <= 16 DoF and <= 16 basis columns and for promp / prodmp with a
+ * learned tau / delay, <= 8 contraction columns and <= 16 DoF (ABI 4); every other configuration (dmp with a learned phase, larger
+ * shapes) runs the trajectory kernel and the rollout kernel back to back.  Either way the result is identical to mpk_trajectory
+ * followed by mpk_pd_rollout.
  */
 int mpk_trajectory_rollout(mpk_handle h, const float* params, const float* init_pos, const float* init_vel,
                            double init_time_shared, const mpk_rollout_cfg* rc, double* q, double* qd,
@@ -341,7 +344,9 @@ int mpk_trajectory_rollout(mpk_handle h, const float* params, const float* init_
  *   2. plan           (= mpk_trajectory):       (pos, vel)[B, T, D] from the boundary state (init_pos, init_vel)
  *   3. execute        (= mpk_pd_rollout):       controller + clip + double-integrator plant for seg_len[b] steps
  *   4. re-condition   (= mpk_condition_gather): cond_pos / cond_vel = desired state at the last executed step
- * in ONE launch where the fused closed-loop kernel applies (shared phase, promp / prodmp, <= 16 DoF and basis columns),
+ * in ONE launch where a fused closed-loop kernel applies (shared phase: promp / prodmp / dmp on its response route, <= 16 DoF and
+ * basis columns; learned tau / delay: promp / prodmp, <= 8 contraction columns, <= 16 DoF -- tau / delay are parameters 0 / 1 of
+ * every plan, the caller passes the values the episode froze at its first plan: test/test_replanning_sequencing.py:231-335),
  * as the four separate kernels otherwise -- identical results either way.  All pointers in `st` are device pointers;
  * done_out (optional) receives a snapshot of `done` after this plan; cond_pos / cond_vel (optional, both or neither) must
  * not alias init_pos / init_vel.
@@ -398,8 +403,9 @@ int mpk_pd_rollout(mpk_handle h, const mpk_rollout_cfg* rc, const float* des_pos
  * rewards written by the tile kernel k_pd_rollout_tiles<.., reward> (every shape mpk_episode_return itself accepts); the per-episode
  * fallback k_reacher_rollout ("pd_generic" 1, D = 1) sums the squared actions of a step as a tree, and the two then differ in the
  * last bits (1e-13 relative: tests/test_gpu_fuzz.py).
- * Shared phase, <= 16 contraction columns and DoF (promp, prodmp, dmp on its response route); MPK_ENOTIMPL otherwise (the caller's
- * separate launches then).
+ * Shared phase, <= 16 contraction columns and DoF (promp, prodmp, dmp on its response route); ABI 4: also promp / prodmp with a
+ * learned tau / delay (<= 8 contraction columns, <= 16 DoF) with MPK_REWARD_NONE -- the reference's learned-phase families are MuJoCo
+ * tasks, there is no device reward for them; MPK_ENOTIMPL otherwise (the caller's separate launches then).
  */
 #define MPK_REWARD_NONE 0
 #define MPK_REWARD_SIMPLE_REACHER 1
@@ -411,6 +417,43 @@ int mpk_episode_return(mpk_handle h, const float* params, const float* init_pos,
                        const mpk_replan_state* st, const int32_t* n_steps, int32_t* seg_out, int32_t reward,
                        const double* goal, const int32_t* step0, int32_t steps_before_reward, int32_t agg, double* ret,
                        int32_t B, void* stream);
+
+/*
+ * The validity gate INSIDE the step (ABI 4).  BlackBoxWrapper.step asks the environment between plan and rollout whether the plan
+ * may run (preprocessing_and_validity_callback, black_box_wrapper.py:155-156; TableTennisEnv.check_traj_validity,
+ * envs/mujoco/table_tennis/table_tennis_env.py:303-309) and returns invalid_traj_callback's penalty instead of executing a step when
+ * it may not (black_box_wrapper.py:169-172; _get_traj_invalid_penalty, table_tennis_env.py:282-289).  With the gate a launch of
+ * mpk_replan_step_gated / mpk_episode_return_gated does what mpk_traj_validity_penalty does to the plan it has just produced --
+ *   valid[b]   = all_t,d(pos_low[d] <= pos[b,t,d] <= pos_high[d]) and (check_tau_delay == 0 or tau, delay within their bounds)
+ *   penalty[b] = -(3 (tau excess) + 3 (delay excess) + mean_t,d max(pos - pos_high, 0) + mean_t,d max(pos_low - pos, 0))   float64
+ * with tau = raw_params[b,0], delay = raw_params[b,1] as the caller's policy produced them (NOT clipped, NOT the values an episode
+ * froze; NULL: `params`) -- while the positions are still on the CU, and an INVALID plan finishes its episode without a step:
+ * done[b] = 1, seg_len[b] = 0, traj_steps / plan_steps / q / qd untouched, actions[b] = 0, cond_pos / cond_vel = the plan's row 0
+ * (what mpk_condition_gather returns for seg_len 0).  valid / penalty are written for every episode, finished ones included.
+ * gate == NULL: exactly mpk_replan_step / mpk_episode_return.  Same results as the separate launches (mpk_trajectory,
+ * mpk_traj_validity_penalty, done |= !valid, mpk_replan_advance, mpk_pd_rollout, mpk_condition_gather): valid and every integer
+ * bit for bit, penalty to 1e-12 relative (float64 sums in another order).
+ */
+typedef struct mpk_validity_gate {
+    const double* pos_low;           /* host [D]  joint limits (table_tennis_utils.py:3-4) */
+    const double* pos_high;          /* host [D] */
+    int32_t  check_tau_delay;        /* compare raw_params[b,0] / [b,1] with the bounds below (table_tennis_env.py:305-306) */
+    int32_t  reserved0;
+    double   tau_bound[2];
+    double   delay_bound[2];
+    const float* raw_params;         /* dev [B, P] or NULL (= params) */
+    uint8_t* valid;                  /* dev [B] out */
+    double*  penalty;                /* dev [B] out, optional */
+} mpk_validity_gate;
+int mpk_replan_step_gated(mpk_handle h, const float* params, const float* init_pos, const float* init_vel,
+                          double init_time_shared, const mpk_rollout_cfg* rc, double* q, double* qd,
+                          const mpk_replan_state* st, const mpk_validity_gate* gate, float* pos, float* vel, float* actions,
+                          int32_t B, void* stream);
+int mpk_episode_return_gated(mpk_handle h, const float* params, const float* init_pos, const float* init_vel,
+                             double init_time_shared, const mpk_rollout_cfg* rc, double* q, double* qd,
+                             const mpk_replan_state* st, const mpk_validity_gate* gate, const int32_t* n_steps, int32_t* seg_out,
+                             int32_t reward, const double* goal, const int32_t* step0, int32_t steps_before_reward, int32_t agg,
+                             double* ret, int32_t B, void* stream);
 
 /*
  * reward_aggregation(rewards[:t + 1]) (black_box_wrapper.py:216) of step rewards that DO exist (the verbose = 2 path:

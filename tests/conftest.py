@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    config.addinivalue_line("markers", "timing: asserts on a measured duration (wall clock, HIP events, a bench line's rates); "
+                                       "collected LAST, behind every test that compares the HIP path with the oracle or a fixture")
     # the suites bind libmpk.so through ctypes: (re)build it if the checkout has none or the sources are newer
     import __graft_entry__ as entry
     if entry._stale():
@@ -25,6 +27,9 @@ def _has_gpu() -> bool:
 
 
 def pytest_collection_modifyitems(config, items):
+    # Wall-clock assertions go to the end of the session: under `pytest -x` a noisy box that fails one of them must not leave a
+    # single parity test uncollected behind it.  Stable: both groups keep their file order.
+    items[:] = [i for i in items if "timing" not in i.keywords] + [i for i in items if "timing" in i.keywords]
     if _has_gpu():
         return
     skip = pytest.mark.skip(reason="no GPU in this container")

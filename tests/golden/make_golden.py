@@ -272,8 +272,10 @@ CONFIGS = {
         bc=O.BasisCfg("zero_rbf", num_basis=3, num_basis_zero_start=1, num_basis_zero_goal=1, basis_bandwidth_factor=3),
         tc=O.TrajCfg("promp", action_dim=7), dt=0.008, duration=2.8, B=2, init_times=[0.0], gains=(TT_P, TT_D),
         act=(-1.0, 1.0)),
+    # (tau = 1.5: _BB_DEFAULTS['ProDMP'] -- the TableTennis mp_config does not override it; rounds 1 - 5 had typed 2.8 = the episode's
+    # duration here, found by the reference-generated config fixture tests/golden/ref_configs.json in round 6)
     "tt_prodmp_learn_tau_delay": dict(
-        pc=O.PhaseCfg("exp", tau=2.8, alpha_phase=3.0, learn_tau=True, learn_delay=True, tau_bound=(0.8, 1.5),
+        pc=O.PhaseCfg("exp", tau=1.5, alpha_phase=3.0, learn_tau=True, learn_delay=True, tau_bound=(0.8, 1.5),
                       delay_bound=(0.05, 0.15)),
         bc=O.BasisCfg("prodmp", num_basis=3, basis_bandwidth_factor=3, alpha=25),
         tc=O.TrajCfg("prodmp", action_dim=7, weights_scale=0.7, auto_scale_basis=True, relative_goal=True,

@@ -1466,6 +1466,7 @@ def test_captured_episode_with_learned_phase_and_device_reward():
     assert torch.equal(got, rr.step(params)["rewards"])
 
 
+@pytest.mark.timing
 @pytest.mark.gpu
 def test_bench_prints_the_contract_line_last():
     """bench.py: the LAST stdout line is the JSON contract line, with the roofline and cpu_baseline objects"""
@@ -1532,6 +1533,7 @@ def test_bench_gpus_2_starts_two_ranks_itself_and_gathers_both_shards():
         assert int(shard.view(torch.int32).to(torch.int64).sum().item()) == ag["shard_checksums"][rank], rank
 
 
+@pytest.mark.timing
 @pytest.mark.gpu
 def test_forced_one_rank_rccl_line_pays_nothing_the_plain_line_does_not():
     """
@@ -1561,6 +1563,7 @@ def test_forced_one_rank_rccl_line_pays_nothing_the_plain_line_does_not():
     assert ag.get("gathered_equals_shards") is True and "zero-copy" in ag["via"]
 
 
+@pytest.mark.timing
 def test_bench_line_carries_the_whole_contract():
     """`python bench.py --gpus 1 --steps 20 --warmup 5` (the driver's form): ONE JSON line on stdout, last, with every key
     the measurement contract names -- metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better /

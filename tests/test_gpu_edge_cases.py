@@ -1203,6 +1203,7 @@ def test_two_kernels_of_one_signature_that_each_need_more_than_64_kb_of_lds_in_o
     assert r.returncode == 0 and "two big-LDS kernels ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+@pytest.mark.timing
 @pytest.mark.parametrize("B", [4096, 16384, 65536, 262144])
 def test_the_automatic_kernel_choice_is_within_ten_percent_of_the_best_forced_variant(B):
     """The launcher picks a kernel family by ~25 byte thresholds fitted to THIS chip's caches (mpk_dev.h, mpk_traj_launch.hip); a

@@ -41,7 +41,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"libmpk.so does not export {name}"
     assert declared == set(_lib.SIGNATURES), "ctypes signature table and include/mpk.h disagree"
-    assert _lib.load().mpk_abi_version() == _lib.MPK_ABI_VERSION == 3
+    assert _lib.load().mpk_abi_version() == _lib.MPK_ABI_VERSION == 4
 
 
 def test_config_struct_layout_matches_header():

@@ -399,3 +399,101 @@ def test_pin_script_plumbing_with_the_facade(tmp_path, switch, value):
             if other != switch:
                 ln = next(x for x in out.splitlines() if x.startswith(f"[pin] {other}"))
                 assert "shipped default" not in ln, ln
+
+
+# ---- the configuration constants, pinned to the reference's own files (round 6) -----------------------------------------------
+# tests/golden/ref_configs.json is written by tests/golden/make_ref_config_golden.py from /root/reference with `ast`: the literal
+# _BB_DEFAULTS, the reference's nested_update FunctionDef compiled alone, the mp_config class attributes of the mp_wrapper.py files and
+# the merge order of bb_env_constructor (registry.py:284-292).  Everything below compares what this repository TYPED with it.
+def _norm(rec):
+    import dataclasses
+    pc, bc, tc = rec[:3]
+    if tc.goal_offset_mode == "ignore":
+        tc = dataclasses.replace(tc, goal_offset=0.0)       # (swallowed by **kwargs: the value plays no part)
+    if bc.basis_generator_type != "zero_rbf":
+        bc = dataclasses.replace(bc, num_basis_zero_start=0, num_basis_zero_goal=0)      # (zero_rbf only)
+    return (pc, bc, tc) + tuple(rec[3:5])
+
+
+def test_bb_defaults_and_nested_update_equal_the_references():
+    from fancy_gym_amd.envs.registry import _BB_DEFAULTS, resolve_mp_config
+    from tests import ref_configs as R
+    ref = R.load()
+    assert R.same(_BB_DEFAULTS, ref["_BB_DEFAULTS"])
+    for env_id, e in ref["envs"].items():
+        got = resolve_mp_config(e["mp_type"], {e["mp_type"]: e["mp_config"]})
+        assert R.same(got, e["config"]), env_id
+
+
+def test_every_baseline_constant_typed_in_this_repository_equals_the_reference_merge():
+    """bench.py's CFG / gains, the CFG1 - CFG5 tuples of the GPU suite, the golden generator's configurations, the learned-phase
+    configurations of tests/test_gpu_learned_phase.py and tools/learned_phase_bench.py -- against the merged reference configs"""
+    import dataclasses
+    import importlib.util
+    from tests import ref_configs as R
+    from tests.golden.make_golden import CONFIGS as GOLD
+    ref = R.load()["envs"]
+    rec = {k: R.oracle_records(k, v) for k, v in ref.items()}
+
+    def load_module(path, name):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        src = open(path).read()
+        # the constants only: everything before the first function definition (no torch / GPU work at import)
+        head = src[:src.index("\ndef ")]
+        exec(compile(head, path, "exec"), mod.__dict__)
+        return mod
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # 1. bench.py (cfg2)
+    bench = load_module(os.path.join(root, "bench.py"), "bench_consts")
+    pc, bc, tc, dt, dur, (pg, dg), _, _ = rec["fancy_ProDMP/BoxPushingDense-v0"]
+    assert bench.CFG == dict(num_dof=tc.action_dim, num_basis=bc.num_basis, dt=dt, duration=dur, tau=pc.tau, alpha_phase=pc.alpha_phase,
+                             basis_bandwidth_factor=bc.basis_bandwidth_factor, basis_alpha=bc.alpha)
+    assert np.array_equal(bench.P_GAINS, pg) and np.array_equal(bench.D_GAINS, dg)
+    assert bench.T_STEPS == ref["fancy_ProDMP/BoxPushingDense-v0"]["max_episode_steps"]
+    # 2. CFG1 - CFG5 (tests/test_gpu_trajectory.py; imported lazily: the module needs torch only)
+    from tests.test_gpu_trajectory import CFG1, CFG2, CFG3, CFG4, CFG5
+    for mine, env_id in ((CFG1, "fancy_ProMP/Reacher5d-v0"), (CFG2, "fancy_ProDMP/BoxPushingDense-v0"), (CFG3, "fancy_DMP/Reacher7d-v0"),
+                         (CFG4, "fancy_ProDMP/BoxPushingDenseReplan-v0"), (CFG5, "fancy_ProMP/TableTennis4D-v0")):
+        assert _norm(mine) == _norm(rec[env_id]), env_id
+    # 3. the golden generator's five BASELINE configurations (+ gains)
+    for name, env_id in (("cfg1_promp_reacher5d", "fancy_ProMP/Reacher5d-v0"), ("cfg2_prodmp_boxpushing", "fancy_ProDMP/BoxPushingDense-v0"),
+                         ("cfg3_dmp_reacher7d", "fancy_DMP/Reacher7d-v0"), ("cfg4_prodmp_replan", "fancy_ProDMP/BoxPushingDenseReplan-v0"),
+                         ("cfg5_promp_tabletennis", "fancy_ProMP/TableTennis4D-v0"), ("tt_prodmp_learn_tau_delay", "fancy_ProDMP/TableTennis4D-v0")):
+        g = GOLD[name]
+        assert _norm((g["pc"], g["bc"], g["tc"], g["dt"], g["duration"])) == _norm(rec[env_id]), name
+        assert np.array_equal(np.broadcast_to(g["gains"][0], rec[env_id][5][0].shape), rec[env_id][5][0]), name
+        assert np.array_equal(np.broadcast_to(g["gains"][1], rec[env_id][5][1].shape), rec[env_id][5][1]), name
+    # 4. the learned-phase families (tests/test_gpu_learned_phase.py, tools/learned_phase_bench.py)
+    from tests.test_gpu_learned_phase import CONFIGS as LP
+    for name, env_id in (("tt_prodmp", "fancy_ProDMP/TableTennis4D-v0"), ("tt_prodmp_replan", "fancy_ProDMP/TableTennisGoalSwitchingReplan-v0"),
+                         ("beerpong_promp", "fancy_ProMP/BeerPong-v0")):
+        pc, bc, tc, dt, dur, (pg, dg), every, mpt = LP[name]
+        r = rec[env_id]
+        assert _norm((pc, bc, tc, dt, dur)) == _norm(r), name
+        assert np.array_equal(pg, r[5][0]) and np.array_equal(dg, r[5][1]), name
+        sched = r[6]
+        if every is None:
+            assert sched is None and (r[7] is None or r[7] == mpt), name
+        else:
+            assert np.array_equal(sched, np.arange(401) % every == 0) and r[7] == mpt, name
+    # cfg4's schedule and planning budget (tests use every = 25, max_planning_times = 4)
+    r4 = rec["fancy_ProDMP/BoxPushingDenseReplan-v0"]
+    assert np.array_equal(r4[6], np.arange(401) % 25 == 0) and r4[7] == 4
+    assert ref["fancy_ProDMP/BoxPushingDenseReplan-v0"]["config"]["black_box_kwargs"]["condition_on_desired"] is True
+    # the joint limits of the validity gate (table_tennis_utils.py:3-4)
+    from tests.test_gpu_learned_phase import JNT_HIGH, JNT_LOW
+    tt = R.load()["table_tennis_utils"]
+    assert np.array_equal(JNT_LOW, tt["jnt_pos_low"]) and np.array_equal(JNT_HIGH, tt["jnt_pos_high"])
+
+
+def test_the_config_fixture_is_what_the_reference_holds_when_the_reference_is_here():
+    """build container only (SKIPS where /root/reference is absent): regenerating the fixture gives the committed file"""
+    import subprocess
+    import sys
+    if not os.path.isdir("/root/reference/fancy_gym"):
+        pytest.skip("/root/reference is not on this machine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "golden", "make_ref_config_golden.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0 and "matches the reference" in r.stdout, r.stdout + r.stderr

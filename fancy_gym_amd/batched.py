@@ -60,7 +60,7 @@ class BatchedBlackBox:
         ``trajectory_length`` and the plant state -- and with a device plant the whole step is ONE launch that stores nothing per
         step (mpk_episode_return): plan, controller, plant, reward and aggregation on the CU.  Same state, same aggregated rewards
         bit for bit (both paths add in the same order: mpk.h).  Falls back to the verbose = 2 launches (and drops their arrays)
-        where the fused kernel does not apply: validity gate, sub-trajectories, per-episode phase, drifted episodes.
+        where the fused kernel does not apply: sub-trajectories, a device reward together with a learned phase, drifted episodes.
         """
         self.verbose = int(verbose)
         self._lean_ok = True
@@ -244,16 +244,26 @@ class BatchedBlackBox:
         return max(1, min(g_break - cur, self.T))
 
     def _can_fuse(self) -> bool:
-        """plan + execute through mpk_replan_step (one launch for shared-phase promp / prodmp, the separate kernels
-        otherwise): needs the device plant, no validity gate, no device reward, and episodes that still move in lockstep
-        (one init_time for all)"""
-        return (self.spec is not None and self.plant == "double_integrator" and self.pos_limits is None
+        """plan + execute through mpk_replan_step(_gated) (one launch for promp / prodmp with a shared OR a learned phase and for
+        dmp on its response route, the separate kernels otherwise): needs the device plant, no device reward, and episodes that
+        still move in lockstep (one init_time for all).  Round 6: the validity gate runs inside the same launch."""
+        return (self.spec is not None and self.plant == "double_integrator"
                 and self.reward is None and not self.learn_sub_trajectories
                 and (not self.do_replanning or self._lockstep is not None))
+
+    def _gate(self, raw_params):
+        """the validity gate of this wrapper as the engine takes it (mpk.h: mpk_validity_gate); None without pos_limits"""
+        if self.pos_limits is None:
+            return None
+        return dict(pos_low=self.pos_limits[0], pos_high=self.pos_limits[1], check_tau_delay=self.check_tau_delay,
+                    tau_bound=self.tau_bound, delay_bound=self.delay_bound,
+                    raw_params=torch.as_tensor(raw_params, dtype=torch.float32, device=self.device) if self.check_tau_delay else None)
 
     def _step_fused(self, params) -> Dict[str, torch.Tensor]:
         """plan + execute as ONE device operation (mpk_replan_step: integer state, trajectory + rollout, condition gather
         in a single launch where the fused closed-loop kernel applies)"""
+        gate = self._gate(params)           # (the RAW action: the reference checks tau / delay before clipping, table_tennis_env.py:305-306)
+        was_done = self.done.bool() if gate is not None else None
         params = self._plan_params(params)
         first = self._start32 is not None and self._plans_since_reset == 1    # q, qd untouched since reset
         cond_pos = self.condition_pos if self.condition_pos is not None else (self._start32[0] if first else self.q.float())
@@ -262,13 +272,21 @@ class BatchedBlackBox:
         mpt = self.max_planning_times if math.isfinite(self.max_planning_times) else 2 ** 31 - 1
         r = self.engine.replan_step(params, cond_pos, cond_vel, self.spec, self.q, self.qd, self.traj_steps,
                                     self.plan_steps, self.done, self.every, int(mpt), self.horizon,
-                                    init_time=init_time, condition=self.condition_on_desired)
+                                    init_time=init_time, condition=self.condition_on_desired, gate=gate)
         seg = r["seg_len"]
         if self.condition_on_desired:
             self.condition_pos, self.condition_vel = r["cond_pos"], r["cond_vel"]
         if self.do_replanning:
-            self._lockstep += self._host_segment()      # no validity gate here: the host mirrors the integer rule
+            # the host mirrors the integer rule -- with the gate too: an invalid plan FINISHES its episode, so every episode
+            # that is still live has executed exactly the segments the rule gives (nothing is read back from the device)
+            self._lockstep += self._host_segment()
         done = r["done"].view(torch.bool)               # 0 / 1 bytes: a view, not a launch
+        if gate is not None:
+            valid = r["valid"].view(torch.bool)
+            # invalid plans terminate their episode without executing a step (black_box_wrapper.py:169-172)
+            return dict(params=params, des_pos=r["pos"], des_vel=r["vel"], step_actions=r["actions"], valid=valid,
+                        invalid_penalty=r["penalty"], trajectory_length=seg, done=done, terminated=~valid & ~was_done,
+                        truncated=done & valid, current_pos=self.q, current_vel=self.qd)
         if self._const_flags is None:
             self._const_flags = (torch.ones(self.B, dtype=torch.bool, device=self.device),
                                  torch.zeros(self.B, dtype=torch.bool, device=self.device))
@@ -280,11 +298,13 @@ class BatchedBlackBox:
 
     def _can_episode_return(self) -> bool:
         return (self.verbose < 2 and self._lean_ok and self.spec is not None and self.plant == "double_integrator"
-                and self.pos_limits is None and not self.learn_sub_trajectories and self._n_phase == 0
+                and not self.learn_sub_trajectories and (self._n_phase == 0 or self.reward is None)
                 and (not self.do_replanning or self._lockstep is not None))
 
     def _step_lean(self, params) -> Optional[Dict[str, torch.Tensor]]:
         """the verbose < 2 step as ONE launch without per-step outputs (mpk_episode_return); None = not available here"""
+        gate = self._gate(params)
+        was_done = self.done.bool() if gate is not None else None
         params = self._plan_params(params)
         first = self._start32 is not None and self._plans_since_reset == 1
         cond_pos = self.condition_pos if self.condition_pos is not None else (self._start32[0] if first else self.q.float())
@@ -296,7 +316,7 @@ class BatchedBlackBox:
                                            replan=(self.traj_steps, self.plan_steps, self.done, self.every, int(mpt), self.horizon),
                                            reward=self.reward, goal=self.goal, steps_before_reward=self.steps_before_reward,
                                            aggregation=self.reward_aggregation, init_time=init_time,
-                                           condition=self.condition_on_desired)
+                                           condition=self.condition_on_desired, gate=gate)
         except NotImplementedError:
             self._lean_ok = False
             return None
@@ -311,6 +331,9 @@ class BatchedBlackBox:
         valid, never = self._const_flags
         out = dict(params=params, valid=valid, trajectory_length=r["seg_len"], done=done, terminated=never, truncated=done,
                    current_pos=self.q, current_vel=self.qd)
+        if gate is not None:
+            valid = r["valid"].view(torch.bool)
+            out.update(valid=valid, invalid_penalty=r["penalty"], terminated=~valid & ~was_done, truncated=done & valid)
         if self.reward is not None:
             out["rewards"] = r["ret"]
         return out
@@ -422,8 +445,9 @@ class BatchedBlackBox:
         """
         if self.spec is None:
             raise ValueError("capture_episode needs a device plant (host environments cannot be captured)")
-        if self.pos_limits is not None:
-            self.device_time = True
+        if self.pos_limits is not None and not (self.plant == "double_integrator" and self.reward is None
+                                                and not self.learn_sub_trajectories):
+            self.device_time = True         # (the fused, gated step keeps the host's lockstep mirror: nothing to read back)
         return EpisodeGraph(self, int(n_plans), with_goal)
 
 

@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(512) k_episode_return(const TrajArgs a, const 
             si.qs = a.q_state[ix]; si.qds = a.qd_state[ix];
             if (a.rp.traj_steps) {
                 si.s0 = a.rp.traj_steps[bq];                       // (read before the rule below advances it: same lane, program order)
-                si.nst = replan_rule(a.rp, bq, T, L.d == 0);
+                if (!a.gate_valid) si.nst = replan_rule(a.rp, bq, T, L.d == 0);      // (gated: after the verdict, below)
             } else {
                 if (a.n_steps) si.nst = min(a.n_steps[bq], T);
                 si.s0 = ep.step0 ? ep.step0[bq] : 0;
@@ -93,6 +93,11 @@ __global__ void __launch_bounds__(512) k_episode_return(const TrajArgs a, const 
     const double lod = __builtin_canonicalize(gq_.lo), hid = __builtin_canonicalize(gq_.hi);
     asm volatile("" : "+v"(pgd), "+v"(dgd));                       // waited for once, here (mpk_traj_quad.h)
     (void)act;
+    GateLim glim{0.0, 0.0, 0.0f, 0.0f};
+    if (a.gate_valid) {
+        glim = kernarg_gate(L.dvalid ? L.d : 0);
+        asm volatile("" : "+v"(glim.lo), "+v"(glim.hi), "+v"(glim.lo32), "+v"(glim.hi32));
+    }
 
     float xb[NQ][KM];
     while (u < NU) {
@@ -115,6 +120,31 @@ __global__ void __launch_bounds__(512) k_episode_return(const TrajArgs a, const 
         float* sQ = sW + L.q * IMG;
         double qs = sc.qs, qds = sc.qds;
         int nst_ = sc.nst, s0_ = sc.s0;
+        if (a.gate_valid) {
+            // validity gate: judge the unit's plans first (gate_pass, mpk_tile.h); an invalid plan executes nothing
+            ReplanVals rv{sc.nst, 0, 0, false};
+            double tpen = 0.0;
+            bool t_bad = false;
+            if (serial) {
+                if (a.rp.traj_steps) rv = replan_eval(a.rp, bq, T);
+                if (a.gate_check_td) {
+                    const double tau = (double)a.gate_raw[(size_t)bq * c.P], delay = (double)a.gate_raw[(size_t)bq * c.P + 1];
+                    t_bad = !(tau >= a.gate_tb[0] && tau <= a.gate_tb[1] && delay >= a.gate_db[0] && delay <= a.gate_db[1]);
+                    tpen = 3.0 * (fmax(0.0, tau - a.gate_tb[1]) + fmax(0.0, a.gate_tb[0] - tau)) +
+                           3.0 * (fmax(0.0, delay - a.gate_db[1]) + fmax(0.0, a.gate_db[0] - delay));
+                }
+            }
+            double over, under;
+            const bool p_bad = gate_pass<KM, NQ>(a, L, ap, TS, km, xb, g0, glim, over, under);
+            const bool invalid = serial && (p_bad || t_bad);
+            nst_ = invalid ? 0 : rv.seg;
+            if (serial && L.d == 0) {
+                a.gate_valid[bq] = invalid ? 0 : 1;
+                const double n = (double)(T * D);
+                if (a.gate_penalty) a.gate_penalty[bq] = -(tpen + over / n + under / n);
+                if (a.rp.traj_steps) replan_write(a.rp, bq, rv, !invalid);
+            }
+        }
         asm volatile("" : "+v"(qs), "+v"(qds), "+v"(nst_), "+v"(s0_));
         const int nst = nst_;
         const int tcond = a.rp.cond_pos ? min(max(nst - 1, 0), T - 1) : -1;

@@ -77,27 +77,58 @@ __device__ __forceinline__ T kernarg_at(size_t byte_off, int idx) {
     return ((tptr)base)[idx];
 }
 
-// one output array of a tile: E images of `n` floats staged at their destination's 16-byte phase -> HBM; whole 16-byte chunks as float4
-// stores, the (at most two) partial chunks of an image element by element
-template <bool WT>
-__device__ __forceinline__ void flush_images(const float* __restrict__ img, float* __restrict__ out, const int ne, const int pitch,
-                                             const int nch, const unsigned inv_ch, const int n, const int b0, const size_t ep_floats,
-                                             const size_t tile_off, const int td3, const bool vec, const int lane) {
+// Flushing a tile: E images of rows * D floats per array, staged at their destination's 16-byte phase, leave as float4 stores: job
+// j = 64 pass + lane -> image e = j / chunks-per-image, 16-byte chunk cq.  What a job needs -- LDS offset, HBM offset relative to
+// (array + first episode of the chunk + tile: a SCALAR base), whole / straddling / outside -- is 32-bit arithmetic computed ONCE per
+// pass and used for all three arrays (the first version redid it, in 64 bits, per array: 260 of a tile's ~650 instructions).  A chunk
+// that straddles its image's first or last float goes element by element -- or, where T D = 2 mod 4 (350 x 7: the TableTennis shapes),
+// as the one 8-byte half it then always is.  `wt`: write-through (sc1) stores while the launch's outputs are cache resident (a scalar
+// branch around the store instruction, not a second copy of the loop).
+__device__ __forceinline__ void st16_at(const bool wt, float* __restrict__ base_uniform, const unsigned off, const f32x4& v) {
+    if (wt) asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base_uniform) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(off), "v"(v), "s"(base_uniform) : "memory");
+}
+__device__ __forceinline__ void st8_at(const bool wt, float* __restrict__ base_uniform, const unsigned off, const f32x2& v) {
+    if (wt) asm volatile("global_store_dwordx2 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base_uniform) : "memory");
+    else asm volatile("global_store_dwordx2 %0, %1, %2" ::"v"(off), "v"(v), "s"(base_uniform) : "memory");
+}
+__device__ __forceinline__ void st4_at(const bool wt, float* __restrict__ base_uniform, const unsigned off, const float v) {
+    if (wt) asm volatile("global_store_dword %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base_uniform) : "memory");
+    else asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(v), "s"(base_uniform) : "memory");
+}
+// bp / bv / ba: (array + ((first episode of the chunk) T + first step of the tile) D) - 4 floats, wave-uniform (the 16 bytes in front keep
+// the offset of a chunk that straddles its image's first float non-negative)
+__device__ __forceinline__ void flush_tile(const float* __restrict__ sP, const int arr_floats, float* __restrict__ bp, float* __restrict__ bv,
+                                           float* __restrict__ ba, const int ne, const int pitch, const int nch, const unsigned inv_ch,
+                                           const int n, const int b0, const int td, const int td3, const bool vec, const bool wt,
+                                           const int lane) {
     for (int j0 = 0; j0 < ne * nch; j0 += 64) {
         const int j = j0 + lane;
         const int e = (int)(((unsigned)j * inv_ch) >> 16), cq = j - e * nch;
-        if (e >= ne) continue;
         const int sh = vec ? (int)((((unsigned)(b0 + e) & 3u) * (unsigned)td3) & 3u) : 0;
-        const int lo = sh, hi = sh + n, c0 = 4 * cq;
-        if (c0 + 4 <= lo || c0 >= hi) continue;
-        float* gp = out + (size_t)(b0 + e) * ep_floats + tile_off - sh + c0;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(img + e * pitch + c0);
-        if (vec && c0 >= lo && c0 + 4 <= hi) {
-            store16<WT>(gp, v);
+        const int hi = sh + n, c0 = 4 * cq;
+        if (!(e < ne && c0 + 4 > sh && c0 < hi)) continue;
+        const float* ip = sP + e * pitch + c0;
+        const f32x4 vp = *reinterpret_cast<const f32x4*>(ip);
+        const f32x4 vv = *reinterpret_cast<const f32x4*>(ip + arr_floats);
+        const f32x4 va = *reinterpret_cast<const f32x4*>(ip + 2 * arr_floats);
+        const unsigned go = (unsigned)((e * td + c0 - sh + 4) * 4);
+        if (vec && c0 >= sh && c0 + 4 <= hi) {
+            st16_at(wt, bp, go, vp); st16_at(wt, bv, go, vv); st16_at(wt, ba, go, va);
+        } else if (vec && td3 == 2) {
+            // segment starts and lengths are even: a straddling chunk is exactly its upper half (the image's start) or its lower half (its end)
+            const bool head = c0 < sh;
+            const unsigned o = go + (head ? 8u : 0u);
+            st8_at(wt, bp, o, f32x2{head ? vp[2] : vp[0], head ? vp[3] : vp[1]});
+            st8_at(wt, bv, o, f32x2{head ? vv[2] : vv[0], head ? vv[3] : vv[1]});
+            st8_at(wt, ba, o, f32x2{head ? va[2] : va[0], head ? va[3] : va[1]});
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (c0 + i >= lo && c0 + i < hi) store4<WT>(gp + i, v[i]);
+            for (int k = 0; k < 4; ++k) {
+                if (c0 + k >= sh && c0 + k < hi) {
+                    st4_at(wt, bp, go + 4u * k, vp[k]); st4_at(wt, bv, go + 4u * k, vv[k]); st4_at(wt, ba, go + 4u * k, va[k]);
+                }
+            }
         }
     }
 }
@@ -429,14 +460,24 @@ __global__ void __launch_bounds__(TL ? 512 : 256) k_phase_fused(const FusedArgs 
                 }
                 if (CLOSED && a.gate) {
                     if (rt == 0) { row0p = pP[0]; row0v = pV[0]; }
-                    bool tile_bad = false;
+                }
+            }
+            if (CLOSED && a.gate) {
+                // every desired position of the lane's column against its joint limits: one v_med3_f32 + compare per step (the reads are the
+                // recurrence's own); only a tile that holds a violation (wave-uniform test) adds up the float64 excess, in time order
+                int tb = 0;
+                if (on) {
+                    const float* pP = sP + oq;
 #pragma unroll
                     for (int tl = 0; tl < TT; ++tl) {
                         const float p = pP[tl * D];
-                        tile_bad = tile_bad || (tl < nrows && !(__builtin_amdgcn_fmed3f(p, glo32, ghi32) == p));
+                        tb |= (tl < nrows && !(__builtin_amdgcn_fmed3f(p, glo32, ghi32) == p)) ? 1 : 0;
                     }
-                    if (tile_bad) {                     // rare: the float64 excess of this column's steps, in time order
+                }
+                if (__any(tb) != 0) {
+                    if (tb) {
                         p_bad = true;
+                        const float* pP = sP + oq;
                         for (int tl = 0; tl < nrows; ++tl) {
                             const double x = (double)pP[tl * D];
                             over += fmax(x - ghi, 0.0);
@@ -464,16 +505,9 @@ __global__ void __launch_bounds__(TL ? 512 : 256) k_phase_fused(const FusedArgs 
             __builtin_amdgcn_wave_barrier();
             // ---- C: the tile's runs of nrows * D floats per episode and array
             if (store) {
-                const size_t epf = (size_t)T * D, toff = (size_t)t0 * D;
-                if (a.wt) {
-                    flush_images<true>(sP, a.pos, ne, pitch, nch, a.inv_ch, nrows * D, b0, epf, toff, a.td3, vec, lane);
-                    flush_images<true>(sV, a.vel, ne, pitch, nch, a.inv_ch, nrows * D, b0, epf, toff, a.td3, vec, lane);
-                    flush_images<true>(sA, a.actions, ne, pitch, nch, a.inv_ch, nrows * D, b0, epf, toff, a.td3, vec, lane);
-                } else {
-                    flush_images<false>(sP, a.pos, ne, pitch, nch, a.inv_ch, nrows * D, b0, epf, toff, a.td3, vec, lane);
-                    flush_images<false>(sV, a.vel, ne, pitch, nch, a.inv_ch, nrows * D, b0, epf, toff, a.td3, vec, lane);
-                    flush_images<false>(sA, a.actions, ne, pitch, nch, a.inv_ch, nrows * D, b0, epf, toff, a.td3, vec, lane);
-                }
+                const size_t toff = ((size_t)b0 * T + t0) * D;
+                flush_tile(sP, E * pitch, a.pos + toff - 4, a.vel + toff - 4, a.actions + toff - 4, ne, pitch, nch, a.inv_ch, nrows * D, b0, T * D,
+                           a.td3, vec, a.wt != 0, lane);
             }
             __builtin_amdgcn_wave_barrier();            // the tile's LDS reads are issued before the next tile's writes
         }

@@ -73,10 +73,21 @@ struct TrajArgs {
     const int32_t* n_steps;  // [B] executed steps of this plan (NULL = T)
     double plant_dt;
     ReplanDev rp;            // closed loop only: integer replanning state advanced in the kernel (replaces n_steps)
+    // validity gate of the lane-quarter closed-loop kernels (k_traj_quad / duo / mono, k_episode_return; round 6): gate_valid != nullptr
+    // switches it on -- a first pass over the unit's row tiles judges every plan BEFORE its recurrence starts (gate_pass below)
+    uint8_t* gate_valid;     // [B] out
+    double* gate_penalty;    // [B] out, optional
+    const float* gate_raw;   // [B, P] the action as passed: tau = [b, 0], delay = [b, 1] (gate_check_td)
+    int gate_check_td;
+    double gate_tb[2], gate_db[2];
 };
 
 struct ActArgs {
     double pg[kMaxD], dg[kMaxD], lo[kMaxD], hi[kMaxD];
+    // validity gate: joint limits as the reference holds them, and as exact fp32 thresholds (smallest fp32 >= low, largest fp32 <= high:
+    // an fp32 position lies in [low, high] exactly when it lies in [glo32, ghi32])
+    double glo[kMaxD], ghi[kMaxD];
+    float glo32[kMaxD], ghi32[kMaxD];
 };
 
 constexpr int kStageStride = 256;   // floats between output arrays in the wave's LDS staging area (>= NTW*16*D)
@@ -252,6 +263,104 @@ __device__ __forceinline__ Gains kernarg_gains(int d) {
     gn.lo = ((dptr)(base + offsetof(ActArgs, lo)))[d];
     gn.hi = ((dptr)(base + offsetof(ActArgs, hi)))[d];
     return gn;
+}
+
+struct GateLim { double lo, hi; float lo32, hi32; };
+__device__ __forceinline__ GateLim kernarg_gate(int d) {
+    typedef const __attribute__((address_space(4))) char* kptr;
+    kptr base = (kptr)__builtin_amdgcn_kernarg_segment_ptr() + kActArgsOffset;
+    typedef const __attribute__((address_space(4))) double* dptr;
+    typedef const __attribute__((address_space(4))) float* fptr;
+    GateLim g;
+    g.lo = ((dptr)(base + offsetof(ActArgs, glo)))[d];
+    g.hi = ((dptr)(base + offsetof(ActArgs, ghi)))[d];
+    g.lo32 = ((fptr)(base + offsetof(ActArgs, glo32)))[d];
+    g.hi32 = ((fptr)(base + offsetof(ActArgs, ghi32)))[d];
+    return g;
+}
+
+// Validity gate of the lane-quarter closed-loop kernels (preprocessing_and_validity_callback between plan and rollout,
+// black_box_wrapper.py:155-172; TableTennisEnv.check_traj_validity / _get_traj_invalid_penalty, table_tennis_env.py:282-309): ONE extra
+// pass over the row tiles of the unit's NQ groups BEFORE the recurrences start -- position C tiles only (KM MFMAs per group and tile,
+// nothing stored), every position against its joint limits with one v_med3_f32 (exact fp32 thresholds) -- so the step loop that follows
+// simply runs with nst = 0 for an invalid plan: actions 0, plant state untouched, condition = row 0, done = 1 (replan_write).  Only a
+// unit that holds a violation repeats the pass in float64 for the penalty's excess sums (reduced over the rows of a lane, the four
+// lane quarters, the DoF lanes of an episode: a fixed order).  Returns, to the SERIAL lane of (group L.q, episode L.bl), whether that
+// plan leaves the limits; over / under: its summed excess above / below (0 where nothing is violated).
+//   ap: the lane's A-fragment base (sA + L.q * TS + L.col), position rows first (o = 0); km: MFMAs per tile actually needed
+template <int KM, int NQ>
+__device__ __forceinline__ bool gate_pass(const TrajArgs& a, const LaneMap<KM>& L, const float* __restrict__ ap, const int TS, const int km,
+                                          const float (&xb)[NQ][KM], const int g0, const GateLim& gl, double& over, double& under) {
+    const int T = a.c.T, NRT = (T + 15) >> 4;
+    bool bad[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) bad[j] = false;
+    for (int rt = 0; rt < NRT; ++rt) {
+        float af[KM];
+#pragma unroll
+        for (int m = 0; m < KM; ++m) af[m] = m < km ? ap[(4 * m) * TS + rt * 16] : 0.0f;
+        const int row0 = rt * 16 + 4 * L.q;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            if (g0 + j < a.G) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < KM; ++m)
+                    if (m < km) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], xb[j][m], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    bad[j] = bad[j] || (row0 + r < T && !(__builtin_amdgcn_fmed3f(acc[r], gl.lo32, gl.hi32) == acc[r]));
+            }
+        }
+    }
+    // the lanes that hold episode bl's columns of a C tile: its DP columns, in all four lane quarters
+    const int DP = 1 << a.sh;
+    const unsigned long long em = (unsigned long long)(((1u << DP) - 1u) << (L.bl * DP)) * 0x0001000100010001ull;
+    unsigned long long any = 0ull;
+    bool mine = false;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const unsigned long long mj = __ballot(L.dvalid && bad[j] && (g0 + j) * L.NTW + L.bl < a.B);
+        any |= mj;
+        if (L.q == j) mine = (mj & em) != 0ull;
+    }
+    over = 0.0; under = 0.0;
+    if (any != 0ull) {                                  // (wave-uniform, rare) the excess sums, float64
+        double ov[NQ], un[NQ];
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) { ov[j] = 0.0; un[j] = 0.0; }
+        for (int rt = 0; rt < NRT; ++rt) {
+            float af[KM];
+#pragma unroll
+            for (int m = 0; m < KM; ++m) af[m] = m < km ? ap[(4 * m) * TS + rt * 16] : 0.0f;
+            const int row0 = rt * 16 + 4 * L.q;
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                if (g0 + j < a.G) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int m = 0; m < KM; ++m)
+                        if (m < km) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], xb[j][m], acc, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (row0 + r < T && L.dvalid) {
+                            const double x = (double)acc[r];
+                            ov[j] += fmax(x - gl.hi, 0.0);
+                            un[j] += fmax(gl.lo - x, 0.0);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            // the four lane quarters (rows 4 q .. 4 q + 3 of every tile), then the DoF lanes of the episode
+            for (int s = 16; s <= 32; s <<= 1) { ov[j] += __shfl_xor(ov[j], s); un[j] += __shfl_xor(un[j], s); }
+            for (int s = 1; s < DP; s <<= 1) { ov[j] += __shfl_xor(ov[j], s); un[j] += __shfl_xor(un[j], s); }
+            if (L.q == j) { over = ov[j]; under = un[j]; }
+        }
+    }
+    return mine;
 }
 
 // The step loop of black_box_wrapper.py:175-203 on the reference's torque double integrator (base_reacher_torque.py:25-26)

@@ -189,12 +189,37 @@ extern template int launch_episode_kernel<MPK_MP_PRODMP>(const TrajArgs&, const 
 
 // mpk_episode_return: plan + controller + plant + reward + aggregation of a `verbose < 2` step in one launch (k_episode_return).
 // MPK_ENOTIMPL where the tables do not fit beside the images (long horizons): the caller's separate launches take those.
+// fp32 thresholds of a float64 interval: an fp32 position lies in [low, high] exactly when it lies in [up(low), down(high)]
+static float f32_at_least(double x) {
+    float f = (float)x;
+    if ((double)f < x) f = nextafterf(f, INFINITY);
+    return f;
+}
+static float f32_at_most(double x) {
+    float f = (float)x;
+    if ((double)f > x) f = nextafterf(f, -INFINITY);
+    return f;
+}
+static void fill_gate_args(const GateDev* gate, const float* params, int D, TrajArgs& ta, ActArgs& aa) {
+    ta.gate_valid = nullptr; ta.gate_penalty = nullptr; ta.gate_raw = nullptr; ta.gate_check_td = 0;
+    ta.gate_tb[0] = ta.gate_tb[1] = ta.gate_db[0] = ta.gate_db[1] = 0.0;
+    if (!gate) return;
+    ta.gate_valid = gate->valid; ta.gate_penalty = gate->penalty;
+    ta.gate_raw = gate->raw_params ? gate->raw_params : params;
+    ta.gate_check_td = gate->check_td;
+    ta.gate_tb[0] = gate->tau_b[0]; ta.gate_tb[1] = gate->tau_b[1];
+    ta.gate_db[0] = gate->delay_b[0]; ta.gate_db[1] = gate->delay_b[1];
+    for (int d = 0; d < D; ++d) {
+        aa.glo[d] = gate->lo[d]; aa.ghi[d] = gate->hi[d];
+        aa.glo32[d] = f32_at_least(gate->lo[d]); aa.ghi32[d] = f32_at_most(gate->hi[d]);
+    }
+}
+
 int launch_episode_return(const DevCfg& c, const SharedTables& st, const float* params, const float* init_pos, const float* init_vel,
                           const RolloutDev& rc, double* q_state, double* qd_state, const int32_t* n_steps, const ReplanDev* rp,
                           int reward_type, const double* goal, const int32_t* step0, int steps_before_reward, int agg, double* ret,
                           int32_t* seg_out, int B, int num_cu, void* stream, const char** kernel_name, const Tuning& tune,
                           const GateDev* gate) {
-    if (gate) { set_error("mpk_episode_return_gated: the validity gate is not fused for this configuration"); return MPK_ENOTIMPL; }
     TrajArgs ta{};
     ta.wpb = 4; ta.ring_parts = 1;
     if (rp) ta.rp = *rp;
@@ -211,6 +236,7 @@ int launch_episode_return(const DevCfg& c, const SharedTables& st, const float* 
     ta.pitch = SEG; ta.cps = SEG / 4 > 0 ? SEG / 4 : 1; ta.inv_cps = 65536u / (unsigned)ta.cps + 1u; ta.vec_ok = 1;
     ActArgs aa{};
     for (int d = 0; d < c.D; ++d) { aa.pg[d] = rc.pg[d]; aa.dg[d] = rc.dg[d]; aa.lo[d] = rc.lo[d]; aa.hi[d] = rc.hi[d]; }
+    fill_gate_args(gate, params, c.D, ta, aa);
     EpArgs ea{};
     ea.ret = ret; ea.goal = goal; ea.step0 = step0; ea.seg_out = seg_out; ea.steps_before_reward = steps_before_reward; ea.agg = agg;
     ea.km = c.KP / 4;
@@ -253,7 +279,6 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
                        const double* c_pos, const double* c_vel, double* q_state, double* qd_state,
                        const int32_t* n_steps, int B, int num_cu, void* stream, const char** kernel_name,
                        const Tuning& tune, const ReplanDev* rp, unsigned* ticket, int* fault, const GateDev* gate) {
-    if (gate) return MPK_ENOTIMPL;      // (the caller's separate launches)
     TrajArgs ta;
     ta.fault = fault;
     ta.nrt_magic = 0; ta.gstride = 0; ta.wt = 0; ta.flat_img = 0;
@@ -263,6 +288,8 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     if (tune.ablations != 1) ta.ring_dbg &= ~(1 | 2 | 128 | (q_state ? 0 : 8)); ta.burst = 0; ta.inorder = 0; ta.lean = 0; ta.wpb = 4; ta.ring_ctr = nullptr; ta.ring_tb = 0; ta.ring_parts = 1;
     if (rp) ta.rp = *rp;
     const bool closed = q_state != nullptr;
+    const bool gated = gate != nullptr;       // validity gate: the lane-quarter closed-loop kernels only (k_traj_quad / duo / mono: gate_pass)
+    if (gated && !(closed && actions)) { set_error("the validity gate belongs to the closed-loop step"); return MPK_EINVAL; }
     ta.q_state = q_state; ta.qd_state = qd_state; ta.n_steps = n_steps; ta.plant_dt = rc ? rc->dt : 0.0;
     ta.c = c; ta.A = st.A; ta.aux = st.aux; ta.TS = st.TS;
     ta.params = params; ta.init_pos = init_pos; ta.init_vel = init_vel;
@@ -293,6 +320,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
         ct = rc->controller_type + (closed ? 3 : 0);
         for (int d = 0; d < c.D; ++d) { aa.pg[d] = rc->pg[d]; aa.dg[d] = rc->dg[d]; aa.lo[d] = rc->lo[d]; aa.hi[d] = rc->hi[d]; }
     }
+    fill_gate_args(gate, params, c.D, ta, aa);
     const int NRT = (c.T + 15) / 16;
     const long max_waves = (long)num_cu * 32;     // 8 waves per SIMD resident
     // work decomposition: episode-major once the outputs stop being cache resident (or when it is the only option)
@@ -313,9 +341,9 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     // per row tile only makes the store stream burstier.
     const bool pipe_fits = table_bytes + 2 * kPipeGroups * kQuadImg * sizeof(float) <= kLdsDefault;
     const long pipe_units = ((long)ta.G + kPipeGroups - 1) / kPipeGroups;
-    const bool pipe = closed && c.mp_type != MPK_MP_DMP && pipe_fits && tune.split != 1 &&
+    const bool pipe = closed && !gated && c.mp_type != MPK_MP_DMP && pipe_fits && tune.split != 1 &&
                       (tune.pipe == 1 || (tune.pipe != 0 && !variant_forced && pipe_units <= 3L * num_cu));
-    const bool split = !pipe && closed && c.mp_type != MPK_MP_DMP && split_shape && tune.split == 1;
+    const bool split = !pipe && closed && !gated && c.mp_type != MPK_MP_DMP && split_shape && tune.split == 1;
     // (trajectory-only launches of the shapes k_traj_flat takes -- two workgroups of whole-trajectory images per CU -- go episode-major from
     // kFlatTrajBytes on: round 5, cfg2's shape, us tiles / flat: 8 192 episodes 10.7 / 11.0, 12 288: 14.5 / 14.1, 16 384: 19.2 / 18.2)
     const bool flat_takes_it = !act && !closed && c.mp_type != MPK_MP_DMP && ptr_ok && (c.T * c.D) % 4 == 0 && tune.flat != 0 &&
@@ -384,6 +412,11 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
                      (units4 >= (long)num_cu * 8 || (closed && units2 > (long)num_cu * 8 && units4 <= (long)num_cu * 8))) quad = 4;
             else if (fits(2) && units2 >= (long)num_cu * 4) quad = 2;
             else if (closed && fits(1)) quad = 1;
+        }
+        if (gated && quad == 0) {
+            // (a forced "quad" 0, or tables beyond the lane-quarter kernels' LDS: the caller's separate launches)
+            if (serial_variant && tune.quad != 0 && fits(1)) quad = 1;
+            else return MPK_ENOTIMPL;
         }
     }
 
@@ -458,7 +491,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     // closed loop on the ring (k_traj_ring<.., closed>): producers + store engine for pos / vel, consumer waves for the recurrences
     // (mpk_traj_ring.h).  LDS: tables + NBUF (pos | vel) batch buffers of four groups + one 4 KB action tile set per consumer.
     bool pipe_sel = pipe;
-    if (closed && c.mp_type != MPK_MP_DMP && act && ptr_ok && TD % 4 == 0 && (c.D == 5 || c.D == 7) && c.KP <= 8 && !split &&
+    if (closed && !gated && c.mp_type != MPK_MP_DMP && act && ptr_ok && TD % 4 == 0 && (c.D == 5 || c.D == 7) && c.KP <= 8 && !split &&
         tune.ring != 0 && tune.ring != 2) {
         const bool forced_other = tune.quad >= 0 || tune.pipe == 1 || tune.split == 1 || ov != 0 || tune.bulk >= 0;
         const bool want = tune.ring == 1 || (tune.ring < 0 && !forced_other && !pipe && out_bytes > kRingClosedBytes);
@@ -632,6 +665,15 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
             case MPK_MP_PROMP: return launch_traj_ring<MPK_MP_PROMP>(ta, aa, ct, blocks, lds, stream);
             default: return launch_traj_ring<MPK_MP_DMP>(ta, aa, -1, blocks, lds, stream);
         }
+    }
+    if (gated) {
+        const bool pd = c.mp_type == MPK_MP_PRODMP;
+        *kernel_name = quad == 4 ? (pd ? "k_traj_quad<prodmp,closed,gate>" : "k_traj_quad<promp,closed,gate>")
+                     : quad == 2 ? (pd ? "k_traj_duo<prodmp,closed,gate>" : "k_traj_duo<promp,closed,gate>")
+                                 : (pd ? "k_traj_mono<prodmp,closed,gate>" : "k_traj_mono<promp,closed,gate>");
+        if (c.mp_type == MPK_MP_DMP) return MPK_ENOTIMPL;
+        return pd ? launch_traj_ct<MPK_MP_PRODMP>(ta, aa, ct, stream_mode, write_through, bulk, quad, blocks, lds, stream, split, pipe_sel)
+                  : launch_traj_ct<MPK_MP_PROMP>(ta, aa, ct, stream_mode, write_through, bulk, quad, blocks, lds, stream, split, pipe_sel);
     }
     switch (c.mp_type) {
         case MPK_MP_PRODMP:

@@ -66,7 +66,8 @@ __global__ void __launch_bounds__(256, (NQ == 4 ? MPK_QUAD_WPE4 : NQ == 2 ? MPK_
             const size_t ix = (size_t)bq * D + L.d;
             if (CLOSED) {
                 si.qs = a.q_state[ix]; si.qds = a.qd_state[ix];
-                if (a.rp.traj_steps) si.nst = replan_rule(a.rp, bq, T, L.d == 0);
+                // (with the validity gate the integer rule waits for the verdict: evaluated at the unit's start, written after gate_pass)
+                if (a.rp.traj_steps) { if (!a.gate_valid) si.nst = replan_rule(a.rp, bq, T, L.d == 0); }
                 else if (a.n_steps) si.nst = min(a.n_steps[bq], T);
             } else {
                 si.ey = a.init_pos[ix];
@@ -106,6 +107,11 @@ __global__ void __launch_bounds__(256, (NQ == 4 ? MPK_QUAD_WPE4 : NQ == 2 ? MPK_
         asm volatile("" : "+v"(pgd), "+v"(dgd));
     }
     (void)act;
+    GateLim glim{0.0, 0.0, 0.0f, 0.0f};
+    if (CLOSED && a.gate_valid) {
+        glim = kernarg_gate(L.dvalid ? L.d : 0);
+        asm volatile("" : "+v"(glim.lo), "+v"(glim.hi), "+v"(glim.lo32), "+v"(glim.hi32));
+    }
 
     float xb[NQ][KM];
     while (u < NU) {
@@ -130,6 +136,31 @@ __global__ void __launch_bounds__(256, (NQ == 4 ? MPK_QUAD_WPE4 : NQ == 2 ? MPK_
         float* sQ = sW + L.q * kQuadImg;
         double qs = sc.qs, qds = sc.qds;
         int nst_ = sc.nst;
+        if (CLOSED && a.gate_valid) {
+            // validity gate: judge the unit's plans first (gate_pass, mpk_tile.h); an invalid plan executes nothing
+            ReplanVals rv{sc.nst, 0, 0, false};
+            double tpen = 0.0;
+            bool t_bad = false;
+            if (serial) {
+                if (a.rp.traj_steps) rv = replan_eval(a.rp, bq, T);
+                if (a.gate_check_td) {
+                    const double tau = (double)a.gate_raw[(size_t)bq * P], delay = (double)a.gate_raw[(size_t)bq * P + 1];
+                    t_bad = !(tau >= a.gate_tb[0] && tau <= a.gate_tb[1] && delay >= a.gate_db[0] && delay <= a.gate_db[1]);
+                    tpen = 3.0 * (fmax(0.0, tau - a.gate_tb[1]) + fmax(0.0, a.gate_tb[0] - tau)) +
+                           3.0 * (fmax(0.0, delay - a.gate_db[1]) + fmax(0.0, a.gate_db[0] - delay));
+                }
+            }
+            double over, under;
+            const bool p_bad = gate_pass<KM, NQ>(a, L, ap, TS, KM, xb, g0, glim, over, under);
+            const bool invalid = serial && (p_bad || t_bad);
+            nst_ = invalid ? 0 : rv.seg;
+            if (serial && L.d == 0) {
+                a.gate_valid[bq] = invalid ? 0 : 1;
+                const double n = (double)(T * D);
+                if (a.gate_penalty) a.gate_penalty[bq] = -(tpen + over / n + under / n);
+                if (a.rp.traj_steps) replan_write(a.rp, bq, rv, !invalid);
+            }
+        }
         float ey = sc.ey, ez = sc.ez, eg = sc.eg;
         // (the same for the unit's serial inputs, fetched one unit ago: waited for once per unit, not in every tile's chain)
         if (CLOSED) asm volatile("" : "+v"(qs), "+v"(qds), "+v"(nst_));

@@ -50,10 +50,24 @@ CONFIGS = {
                               (1.0, 0.1), None, 1),
 }
 REFERENCE = ["tt_prodmp", "tt_prodmp_replan", "beerpong_promp"]
+# shared-phase configurations for the validity gate's other home, the lane-quarter kernels (gate_pass, csrc/mpk_tile.h): BASELINE cfg5 -- the
+# flow the gate exists for (table_tennis/mp_wrapper.py:11-30, table_tennis_env.py:282-309) --, cfg4 (replanning, condition_on_desired) and a
+# DMP on its response route
+SHARED = {
+    "cfg5_promp_tabletennis": (O.PhaseCfg("linear", tau=2.8),
+                               O.BasisCfg("zero_rbf", num_basis=3, num_basis_zero_start=1, num_basis_zero_goal=1, basis_bandwidth_factor=3),
+                               O.TrajCfg("promp", action_dim=7), 0.008, 2.8, (TT_P, TT_D), None, 1),
+    "cfg4_prodmp_replan": (O.PhaseCfg("exp", tau=1.5, alpha_phase=3.0), O.BasisCfg("prodmp", num_basis=5, basis_bandwidth_factor=3, alpha=10),
+                           O.TrajCfg("prodmp", action_dim=7, weights_scale=0.3, goal_scale=0.3, auto_scale_basis=True, disable_goal=True),
+                           0.02, 2.0, (0.01 * np.array([120., 120., 120., 120., 50., 30., 10.]), 0.01 * np.array([10., 10., 10., 10., 6., 5., 3.])), 25, 4),
+    "dmp_5dof_response": (O.PhaseCfg("exp", tau=2.0, alpha_phase=2.0), O.BasisCfg("rbf", num_basis=5, basis_bandwidth_factor=3),
+                          O.TrajCfg("dmp", action_dim=5, alpha=25.0), 0.02, 2.0, (1.0, 0.1), 40, 3),
+}
+CONFIGS_ALL = dict(CONFIGS, **SHARED)
 
 
 def make_inputs(name, B, seed=0, scale=1.0):
-    pc, bc, tc = CONFIGS[name][:3]
+    pc, bc, tc = CONFIGS_ALL[name][:3]
     rng = np.random.default_rng(seed)
     P = O.num_params(pc, bc, tc)
     params = (scale * rng.standard_normal((B, P))).astype(np.float32)
@@ -70,12 +84,12 @@ def make_inputs(name, B, seed=0, scale=1.0):
 
 
 def engine_of(name, **kw):
-    pc, bc, tc, dt, dur = CONFIGS[name][:5]
+    pc, bc, tc, dt, dur = CONFIGS_ALL[name][:5]
     return make_engine(pc, bc, tc, dt, dur, device=0, **kw)
 
 
 def specs(name, low=-1.0, high=1.0, ctrl="motor"):
-    pc, bc, tc, dt, dur, (pg, dg) = CONFIGS[name][:6]
+    pc, bc, tc, dt, dur, (pg, dg) = CONFIGS_ALL[name][:6]
     D = tc.action_dim
     return (RolloutSpec(ctrl, D, pg, dg, low, high, plant="static"),
             RolloutSpec(ctrl, D, pg, dg, low, high, plant="double_integrator", dt=dt))
@@ -107,11 +121,16 @@ def test_fused_actions_are_one_launch_and_equal_the_two_launches_and_the_oracle(
     act2 = eng.pd_rollout(static, pos2, vel2, cu(cp), cu(cv))
     torch.cuda.synchronize()
     eq(pos, pos2, "pos"); eq(vel, vel2, "vel"); eq(act, act2, "actions")
-    # the oracle: trajectories to 1e-5 (both precisions), actions from ITS loop on the GPU's trajectories exactly
+    # the oracle: trajectories to 1e-5 (both precisions), actions from ITS loop on the GPU's trajectories exactly.  Against the fp32
+    # oracle the tolerance grows by that oracle's own distance from the float64 one where that exceeds 2e-6 of the scale ("within 1e-5
+    # of the reference" cannot be resolved finer than the reference's own fp32 error: DESIGN section 3, tests/test_gpu_fuzz.py)
+    rp64, rv64 = O.get_trajectory(pc, bc, tc, params, dur, dt, 0.0, ip, iv, dtype=np.float64)
     for dtype in (np.float64, np.float32):
         rp, rv = O.get_trajectory(pc, bc, tc, params, dur, dt, 0.0, ip, iv, dtype=dtype)
-        close(pos.cpu().numpy(), rp, f"pos {dtype.__name__}")
-        close(vel.cpu().numpy(), rv, f"vel {dtype.__name__}", atol=fd_atol(rp, dt) if tc.trajectory_generator_type == "promp" else 0.0)
+        fd = fd_atol(rp, dt) if tc.trajectory_generator_type == "promp" else 0.0
+        ep = float(np.abs(rp - rp64).max()); ev = float(np.abs(rv - rv64).max())
+        close(pos.cpu().numpy(), rp, f"pos {dtype.__name__}", atol=ep if ep > 2e-6 * np.abs(rp64).max() else 0.0)
+        close(vel.cpu().numpy(), rv, f"vel {dtype.__name__}", atol=fd + (ev if ev > 2e-6 * np.abs(rv64).max() else 0.0))
     ra, _, _ = O.rollout(pos.cpu().numpy(), vel.cpu().numpy(), "motor", pg, dg, -1.0, 1.0, "static", dt, cp, cv)
     eq(act, ra.astype(np.float32), "actions vs oracle")
 
@@ -217,13 +236,20 @@ def test_whole_episodes_of_replanning_steps_fused_against_separate_launches_and_
     assert int(A["ts"].min()) == horizon and int(A["dn"].min()) == 1 and int(A["ps"].max()) == len(segments)
 
 
-@pytest.mark.parametrize("name", ["tt_prodmp", "tt_prodmp_replan", "promp_5dof_learn_both"])
+@pytest.mark.parametrize("name", ["tt_prodmp", "tt_prodmp_replan", "promp_5dof_learn_both", "cfg5_promp_tabletennis", "cfg4_prodmp_replan",
+                                  "dmp_5dof_response"])
 @pytest.mark.parametrize("lean", [False, True])
-def test_the_validity_gate_inside_the_step_equals_the_separate_launches_and_the_oracle(name, lean):
+@pytest.mark.parametrize("quad", [None, 2, 3, 4])
+def test_the_validity_gate_inside_the_step_equals_the_separate_launches_and_the_oracle(name, lean, quad, mpk_option):
     """joint limits + tau / delay bounds on the RAW action, penalty, and the roll-back of an invalid plan (black_box_wrapper.py:155-172;
     table_tennis_env.py:282-309): mpk_replan_step_gated / mpk_episode_return_gated against trajectory + mpk_traj_validity_penalty +
     done |= !valid + advance + rollout + gather, and valid / penalty against the oracle's restatement of the reference's two functions"""
-    pc, bc, tc, dt, dur, (pg, dg), every, mpt = CONFIGS[name]
+    pc, bc, tc, dt, dur, (pg, dg), every, mpt = CONFIGS_ALL[name]
+    shared = name in SHARED
+    if quad is not None:
+        if not shared:
+            pytest.skip("groups per wave: the shared-phase kernels' option")
+        mpk_option("quad", quad)
     eng = engine_of(name)
     T, D = eng.num_steps, eng.num_dof
     B = 1500
@@ -231,11 +257,18 @@ def test_the_validity_gate_inside_the_step_equals_the_separate_launches_and_the_
     every_ = every or horizon + 1
     _, closed = specs(name)
     n_ph = int(pc.learn_tau) + int(pc.learn_delay)
-    chk = n_ph == 2
+    # cfg5: the reference compares action[0], action[1] with the tau / delay bounds although ProMP-TableTennis learns neither
+    # (table_tennis_env.py:305-306 on learn_tau = False, mp_wrapper.py:13-18) -- there they are the first two WEIGHTS
+    quirk = name == "cfg5_promp_tabletennis"
+    chk = n_ph == 2 or quirk
+    tb, db = ((0.8, 1.5), (0.05, 0.15)) if quirk else (pc.tau_bound, pc.delay_bound)
     lo = JNT_LOW[:D] * 0.45 if D <= 7 else np.full(D, -1.0)
     hi = JNT_HIGH[:D] * 0.45 if D <= 7 else np.full(D, 1.0)
-    gate = dict(pos_low=lo, pos_high=hi, check_tau_delay=chk, tau_bound=pc.tau_bound, delay_bound=pc.delay_bound)
+    gate = dict(pos_low=lo, pos_high=hi, check_tau_delay=chk, tau_bound=tb, delay_bound=db)
     raw0, ip, iv = make_inputs(name, B, seed=3, scale=0.35)
+    if quirk:
+        rq = np.random.default_rng(17)
+        raw0[:, 0] = rq.uniform(0.75, 1.55, B); raw0[:, 1] = rq.uniform(0.04, 0.16, B)
     ip *= 0.3
     lo_hi = O.params_bounds(pc, bc, tc)
     frozen = np.clip(raw0[:, :n_ph], lo_hi[0, :n_ph], lo_hi[1, :n_ph])
@@ -248,6 +281,8 @@ def test_the_validity_gate_inside_the_step_equals_the_separate_launches_and_the_
     for k, (cur, length) in enumerate(segments):
         raw = (0.35 * rng.standard_normal(raw0.shape)).astype(np.float32)
         raw[:, :n_ph] = raw0[:, :n_ph]
+        if quirk:
+            raw[:, :2] = raw0[:, :2]
         params = raw.copy()
         params[:, :n_ph] = frozen
         it = cur * dt
@@ -255,11 +290,11 @@ def test_the_validity_gate_inside_the_step_equals_the_separate_launches_and_the_
         if lean:
             r = eng.episode_return(params, condA[0], condA[1], closed, A["q"], A["qd"], replan=(A["ts"], A["ps"], A["dn"], every_, mpt, horizon),
                                    init_time=it, condition=True, gate=g)
-            assert "lean" in eng.last_kernel(), eng.last_kernel()
+            assert ("k_episode_return" in eng.last_kernel()) if shared else ("lean" in eng.last_kernel()), eng.last_kernel()
         else:
             r = eng.replan_step(params, condA[0], condA[1], closed, A["q"], A["qd"], A["ts"], A["ps"], A["dn"], every_, mpt, horizon,
                                 init_time=it, condition=True, gate=g)
-            assert eng.last_kernel().startswith("k_phase_fused<"), eng.last_kernel()
+            assert eng.last_kernel().endswith("closed,gate>") if shared else eng.last_kernel().startswith("k_phase_fused<"), eng.last_kernel()
         s = _separate_step(eng, params, condS[0], condS[1], closed, S["q"], S["qd"], S["ts"], S["ps"], S["dn"], every_, mpt, horizon, it,
                            gate=gate, raw=raw)
         torch.cuda.synchronize()
@@ -280,9 +315,9 @@ def test_the_validity_gate_inside_the_step_equals_the_separate_launches_and_the_
         inside = np.all((posn.astype(np.float64) >= lo) & (posn.astype(np.float64) <= hi), axis=(1, 2))
         if chk:
             a = raw.astype(np.float64)
-            inside &= (a[:, 0] >= pc.tau_bound[0]) & (a[:, 0] <= pc.tau_bound[1]) & (a[:, 1] >= pc.delay_bound[0]) & (a[:, 1] <= pc.delay_bound[1])
+            inside &= (a[:, 0] >= tb[0]) & (a[:, 0] <= tb[1]) & (a[:, 1] >= db[0]) & (a[:, 1] <= db[1])
         eq(valid, inside, f"plan {k}: valid vs oracle")
-        ref_pen = O.traj_invalid_penalty(raw, posn, lo, hi, pc.tau_bound if chk else None, pc.delay_bound if chk else None)
+        ref_pen = O.traj_invalid_penalty(raw, posn, lo, hi, tb if chk else None, db if chk else None)
         assert np.all(np.abs(pen - ref_pen) <= 1e-12 * np.abs(ref_pen) + 1e-300), np.abs(pen - ref_pen).max()
         live_before = int((r["seg_len"] > 0).sum())
         seen_invalid += int((~valid).sum()); seen_valid += live_before

@@ -97,36 +97,42 @@ __device__ __forceinline__ void st4_at(const bool wt, float* __restrict__ base_u
     else asm volatile("global_store_dword %0, %1, %2" ::"v"(off), "v"(v), "s"(base_uniform) : "memory");
 }
 // bp / bv / ba: (array + ((first episode of the chunk) T + first step of the tile) D) - 4 floats, wave-uniform (the 16 bytes in front keep
-// the offset of a chunk that straddles its image's first float non-negative)
+// the offset of a chunk that straddles its image's first float non-negative).
+// A pass moves the images of EPP consecutive episodes: lane -> (episode of the pass h, 16-byte chunk cq) is fixed for the kernel
+// (EPP = 2 where an image has at most 32 chunks: D <= 7), so a pass costs a handful of vector instructions beside its three LDS reads
+// and three stores -- episode offsets are scalar.
 __device__ __forceinline__ void flush_tile(const float* __restrict__ sP, const int arr_floats, float* __restrict__ bp, float* __restrict__ bv,
-                                           float* __restrict__ ba, const int ne, const int pitch, const int nch, const unsigned inv_ch,
-                                           const int n, const int b0, const int td, const int td3, const bool vec, const bool wt,
-                                           const int lane) {
-    for (int j0 = 0; j0 < ne * nch; j0 += 64) {
-        const int j = j0 + lane;
-        const int e = (int)(((unsigned)j * inv_ch) >> 16), cq = j - e * nch;
+                                           float* __restrict__ ba, const int ne, const int pitch, const int nch, const int n, const int b0,
+                                           const int td, const int td3, const bool vec, const bool wt, const int lane) {
+    const int epp = nch <= 32 ? 2 : 1;
+    const int h = epp == 2 ? lane >> 5 : 0, cq0 = epp == 2 ? lane & 31 : lane;
+    for (int e0 = 0; e0 < ne; e0 += epp) {
+        const int e = e0 + h;
         const int sh = vec ? (int)((((unsigned)(b0 + e) & 3u) * (unsigned)td3) & 3u) : 0;
-        const int hi = sh + n, c0 = 4 * cq;
-        if (!(e < ne && c0 + 4 > sh && c0 < hi)) continue;
-        const float* ip = sP + e * pitch + c0;
-        const f32x4 vp = *reinterpret_cast<const f32x4*>(ip);
-        const f32x4 vv = *reinterpret_cast<const f32x4*>(ip + arr_floats);
-        const f32x4 va = *reinterpret_cast<const f32x4*>(ip + 2 * arr_floats);
-        const unsigned go = (unsigned)((e * td + c0 - sh + 4) * 4);
-        if (vec && c0 >= sh && c0 + 4 <= hi) {
-            st16_at(wt, bp, go, vp); st16_at(wt, bv, go, vv); st16_at(wt, ba, go, va);
-        } else if (vec && td3 == 2) {
-            // segment starts and lengths are even: a straddling chunk is exactly its upper half (the image's start) or its lower half (its end)
-            const bool head = c0 < sh;
-            const unsigned o = go + (head ? 8u : 0u);
-            st8_at(wt, bp, o, f32x2{head ? vp[2] : vp[0], head ? vp[3] : vp[1]});
-            st8_at(wt, bv, o, f32x2{head ? vv[2] : vv[0], head ? vv[3] : vv[1]});
-            st8_at(wt, ba, o, f32x2{head ? va[2] : va[0], head ? va[3] : va[1]});
-        } else {
+        const int hi = sh + n;
+        for (int cq = cq0; cq < nch; cq += 64) {        // (one trip unless an image has more than 64 chunks: D = 16)
+            const int c0 = 4 * cq;
+            if (!(e < ne && c0 + 4 > sh && c0 < hi)) continue;
+            const float* ip = sP + e * pitch + c0;
+            const f32x4 vp = *reinterpret_cast<const f32x4*>(ip);
+            const f32x4 vv = *reinterpret_cast<const f32x4*>(ip + arr_floats);
+            const f32x4 va = *reinterpret_cast<const f32x4*>(ip + 2 * arr_floats);
+            const unsigned go = (unsigned)((e * td + c0 - sh + 4) * 4);
+            if (vec && c0 >= sh && c0 + 4 <= hi) {
+                st16_at(wt, bp, go, vp); st16_at(wt, bv, go, vv); st16_at(wt, ba, go, va);
+            } else if (vec && td3 == 2) {
+                // segment starts and lengths are even: a straddling chunk is exactly its upper half (the image's start) or its lower half (its end)
+                const bool head = c0 < sh;
+                const unsigned o = go + (head ? 8u : 0u);
+                st8_at(wt, bp, o, f32x2{head ? vp[2] : vp[0], head ? vp[3] : vp[1]});
+                st8_at(wt, bv, o, f32x2{head ? vv[2] : vv[0], head ? vv[3] : vv[1]});
+                st8_at(wt, ba, o, f32x2{head ? va[2] : va[0], head ? va[3] : va[1]});
+            } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (c0 + k >= sh && c0 + k < hi) {
-                    st4_at(wt, bp, go + 4u * k, vp[k]); st4_at(wt, bv, go + 4u * k, vv[k]); st4_at(wt, ba, go + 4u * k, va[k]);
+                for (int k = 0; k < 4; ++k) {
+                    if (c0 + k >= sh && c0 + k < hi) {
+                        st4_at(wt, bp, go + 4u * k, vp[k]); st4_at(wt, bv, go + 4u * k, vv[k]); st4_at(wt, ba, go + 4u * k, va[k]);
+                    }
                 }
             }
         }
@@ -465,13 +471,18 @@ __global__ void __launch_bounds__(TL ? 512 : 256) k_phase_fused(const FusedArgs 
             if (CLOSED && a.gate) {
                 // every desired position of the lane's column against its joint limits: one v_med3_f32 + compare per step (the reads are the
                 // recurrence's own); only a tile that holds a violation (wave-uniform test) adds up the float64 excess, in time order
+                // (all sixteen reads first, rows past the horizon replaced by a value inside the limits: no control flow -- the first
+                // version tested `tl < nrows` per step and paid sixteen LDS round trips in a row, 1 900 cycles per tile)
                 int tb = 0;
                 if (on) {
                     const float* pP = sP + oq;
+                    float pg_[TT];
+#pragma unroll
+                    for (int tl = 0; tl < TT; ++tl) pg_[tl] = pP[tl * D];
 #pragma unroll
                     for (int tl = 0; tl < TT; ++tl) {
-                        const float p = pP[tl * D];
-                        tb |= (tl < nrows && !(__builtin_amdgcn_fmed3f(p, glo32, ghi32) == p)) ? 1 : 0;
+                        const float p = tl < nrows ? pg_[tl] : glo32;
+                        tb |= (int)!(__builtin_amdgcn_fmed3f(p, glo32, ghi32) == p);
                     }
                 }
                 if (__any(tb) != 0) {
@@ -506,8 +517,8 @@ __global__ void __launch_bounds__(TL ? 512 : 256) k_phase_fused(const FusedArgs 
             // ---- C: the tile's runs of nrows * D floats per episode and array
             if (store) {
                 const size_t toff = ((size_t)b0 * T + t0) * D;
-                flush_tile(sP, E * pitch, a.pos + toff - 4, a.vel + toff - 4, a.actions + toff - 4, ne, pitch, nch, a.inv_ch, nrows * D, b0, T * D,
-                           a.td3, vec, a.wt != 0, lane);
+                flush_tile(sP, E * pitch, a.pos + toff - 4, a.vel + toff - 4, a.actions + toff - 4, ne, pitch, nch, nrows * D, b0, T * D, a.td3, vec,
+                           a.wt != 0, lane);
             }
             __builtin_amdgcn_wave_barrier();            // the tile's LDS reads are issued before the next tile's writes
         }

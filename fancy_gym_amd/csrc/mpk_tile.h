@@ -292,9 +292,9 @@ template <int KM, int NQ>
 __device__ __forceinline__ bool gate_pass(const TrajArgs& a, const LaneMap<KM>& L, const float* __restrict__ ap, const int TS, const int km,
                                           const float (&xb)[NQ][KM], const int g0, const GateLim& gl, double& over, double& under) {
     const int T = a.c.T, NRT = (T + 15) >> 4;
-    bool bad[NQ];
+    int bad[NQ];
 #pragma unroll
-    for (int j = 0; j < NQ; ++j) bad[j] = false;
+    for (int j = 0; j < NQ; ++j) bad[j] = 0;
     for (int rt = 0; rt < NRT; ++rt) {
         float af[KM];
 #pragma unroll
@@ -308,8 +308,11 @@ __device__ __forceinline__ bool gate_pass(const TrajArgs& a, const LaneMap<KM>& 
                 for (int m = 0; m < KM; ++m)
                     if (m < km) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], xb[j][m], acc, 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    bad[j] = bad[j] || (row0 + r < T && !(__builtin_amdgcn_fmed3f(acc[r], gl.lo32, gl.hi32) == acc[r]));
+                for (int r = 0; r < 4; ++r) {
+                    // (rows past the horizon: a value inside the limits -- a select, no control flow in this loop)
+                    const float x = row0 + r < T ? acc[r] : gl.lo32;
+                    bad[j] |= (int)!(__builtin_amdgcn_fmed3f(x, gl.lo32, gl.hi32) == x);
+                }
             }
         }
     }
@@ -320,7 +323,7 @@ __device__ __forceinline__ bool gate_pass(const TrajArgs& a, const LaneMap<KM>& 
     bool mine = false;
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
-        const unsigned long long mj = __ballot(L.dvalid && bad[j] && (g0 + j) * L.NTW + L.bl < a.B);
+        const unsigned long long mj = __ballot(L.dvalid && bad[j] != 0 && (g0 + j) * L.NTW + L.bl < a.B);
         any |= mj;
         if (L.q == j) mine = (mj & em) != 0ull;
     }

@@ -376,8 +376,8 @@ def test_output_arrays_that_are_not_16_byte_aligned(name):
     _, closed = specs(name)
     q0, qd0 = ip.astype(np.float64), iv.astype(np.float64)
     ref = eng.trajectory_rollout(params, ip, iv, closed, cu(q0).clone(), cu(qd0).clone())
-    bufs = [torch.full((B * T * D + 8,), 7.0, device="cuda") for _ in range(3)]
     for off in (1, 2, 3):
+        bufs = [torch.full((B * T * D + 8,), 7.0, device="cuda") for _ in range(3)]
         out = tuple(b[off:off + B * T * D].view(B, T, D) for b in bufs)
         got = eng.trajectory_rollout(params, ip, iv, closed, cu(q0).clone(), cu(qd0).clone(), out=out)
         torch.cuda.synchronize()

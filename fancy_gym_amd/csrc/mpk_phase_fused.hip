@@ -139,11 +139,14 @@ __device__ __forceinline__ void flush_tile(const float* __restrict__ sP, const i
     }
 }
 
+#ifndef MPK_PF_WAVES
+#define MPK_PF_WAVES 2            // waves per SIMD the register allocation aims at (A/B builds: -DMPK_PF_WAVES=3)
+#endif
 // MP promp / prodmp; KQ: 4 KQ contraction columns; TL (prodmp): the row table in the workgroup's LDS instead of L2; DC: the DoF count at
 // compile time (0: c.D); CT: 0 .. 2 = MPK_CTRL_* against a frozen state (mpk_trajectory_actions), 3 + MPK_CTRL_* = closed loop on the
 // double integrator (mpk_trajectory_rollout / mpk_replan_step / mpk_episode_return)
 template <int MP, int KQ, bool TL, int DC, int CT>
-__global__ void __launch_bounds__(TL ? 512 : 256) k_phase_fused(const FusedArgs a, const FusedLim lim) {
+__global__ void __launch_bounds__(TL ? 512 : 256, MPK_PF_WAVES) k_phase_fused(const FusedArgs a, const FusedLim lim) {
     static_assert(MP != MPK_MP_DMP, "dmp with a learned phase keeps its separate launches (no reference configuration has one)");
     static_assert(!TL || MP == MPK_MP_PRODMP, "only prodmp has a row table");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -468,24 +471,42 @@ __global__ void __launch_bounds__(TL ? 512 : 256) k_phase_fused(const FusedArgs 
                     if (rt == 0) { row0p = pP[0]; row0v = pV[0]; }
                 }
             }
-            if (CLOSED && a.gate) {
-                // every desired position of the lane's column against its joint limits: one v_med3_f32 + compare per step (the reads are the
-                // recurrence's own); only a tile that holds a violation (wave-uniform test) adds up the float64 excess, in time order
-                // (all sixteen reads first, rows past the horizon replaced by a value inside the limits: no control flow -- the first
-                // version tested `tl < nrows` per step and paid sixteen LDS round trips in a row, 1 900 cycles per tile)
+            {
+                // the chain; with the validity gate it also tests the positions it pulls into registers against the joint limits (GATE hook of
+                // pd_tile_steps: no LDS read or wait of its own -- a separate pass of sixteen reads cost 12 % at 8 192 episodes)
+                const bool full_tile = nrows == TT && tile_fully_executed(on, nst, t0);
                 int tb = 0;
-                if (on) {
-                    const float* pP = sP + oq;
-                    float pg_[TT];
-#pragma unroll
-                    for (int tl = 0; tl < TT; ++tl) pg_[tl] = pP[tl * D];
-#pragma unroll
-                    for (int tl = 0; tl < TT; ++tl) {
-                        const float p = tl < nrows ? pg_[tl] : glo32;
-                        tb |= (int)!(__builtin_amdgcn_fmed3f(p, glo32, ghi32) == p);
+                if (on && store) {
+                    if (CLOSED && a.gate) {
+                        if (full_tile)
+                            pd_tile_steps<CTRL, false, CLOSED, 0, 0, true, true>(sP + oq, sV + oq, sA + oq, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds,
+                                                                               nullptr, nullptr, 16, glo32, ghi32, &tb);
+                        else
+                            pd_tile_steps<CTRL, true, CLOSED, 0, 0, true, true>(sP + oq, sV + oq, sA + oq, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds,
+                                                                              nullptr, nullptr, nrows, glo32, ghi32, &tb);
+                    } else if (full_tile) {
+                        pd_tile_steps<CTRL, false, CLOSED>(sP + oq, sV + oq, sA + oq, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds);
+                    } else {
+                        pd_tile_steps<CTRL, true, CLOSED>(sP + oq, sV + oq, sA + oq, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds,
+                                                          nullptr, nullptr, nrows);
+                    }
+                } else if (on) {                        // the verbose < 2 step: no action image either
+                    if (CLOSED && a.gate) {
+                        if (full_tile)
+                            pd_tile_steps<CTRL, false, CLOSED, 0, 0, false, true>(sP + oq, sV + oq, nullptr, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds,
+                                                                                nullptr, nullptr, 16, glo32, ghi32, &tb);
+                        else
+                            pd_tile_steps<CTRL, true, CLOSED, 0, 0, false, true>(sP + oq, sV + oq, nullptr, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds,
+                                                                               nullptr, nullptr, nrows, glo32, ghi32, &tb);
+                    } else if (full_tile) {
+                        pd_tile_steps<CTRL, false, CLOSED, 0, 0, false>(sP + oq, sV + oq, nullptr, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds);
+                    } else {
+                        pd_tile_steps<CTRL, true, CLOSED, 0, 0, false>(sP + oq, sV + oq, nullptr, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds,
+                                                                       nullptr, nullptr, nrows);
                     }
                 }
-                if (__any(tb) != 0) {
+                if (CLOSED && a.gate && __any(tb) != 0) {
+                    // (rare) a tile that holds a violation adds up the float64 excess of its columns, in time order
                     if (tb) {
                         p_bad = true;
                         const float* pP = sP + oq;
@@ -495,22 +516,6 @@ __global__ void __launch_bounds__(TL ? 512 : 256) k_phase_fused(const FusedArgs 
                             under += fmax(glo - x, 0.0);
                         }
                     }
-                }
-            }
-            {
-                const bool full_tile = nrows == TT && tile_fully_executed(on, nst, t0);
-                if (on && store) {
-                    if (full_tile)
-                        pd_tile_steps<CTRL, false, CLOSED>(sP + oq, sV + oq, sA + oq, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds);
-                    else
-                        pd_tile_steps<CTRL, true, CLOSED>(sP + oq, sV + oq, sA + oq, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds,
-                                                          nullptr, nullptr, nrows);
-                } else if (on) {                        // the verbose < 2 step: no action image either
-                    if (full_tile)
-                        pd_tile_steps<CTRL, false, CLOSED, 0, 0, false>(sP + oq, sV + oq, nullptr, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds);
-                    else
-                        pd_tile_steps<CTRL, true, CLOSED, 0, 0, false>(sP + oq, sV + oq, nullptr, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds,
-                                                                       nullptr, nullptr, nrows);
                 }
             }
             __builtin_amdgcn_wave_barrier();

@@ -295,18 +295,29 @@ __device__ __forceinline__ bool gate_pass(const TrajArgs& a, const LaneMap<KM>& 
     int bad[NQ];
 #pragma unroll
     for (int j = 0; j < NQ; ++j) bad[j] = 0;
-    for (int rt = 0; rt < NRT; ++rt) {
-        float af[KM];
+    // (a group past the launch's last one contracts zeros: no test per group inside the loop; four row tiles per trip, their A fragments
+    // read together: the lone wave of a few thousand episodes pays latencies, not instructions)
+    float xz[NQ][KM];
 #pragma unroll
-        for (int m = 0; m < KM; ++m) af[m] = m < km ? ap[(4 * m) * TS + rt * 16] : 0.0f;
-        const int row0 = rt * 16 + 4 * L.q;
+    for (int j = 0; j < NQ; ++j)
 #pragma unroll
-        for (int j = 0; j < NQ; ++j) {
-            if (g0 + j < a.G) {
+        for (int m = 0; m < KM; ++m) xz[j][m] = g0 + j < a.G ? xb[j][m] : 0.0f;
+    constexpr int UN = 4;
+    for (int rt0 = 0; rt0 < NRT; rt0 += UN) {
+        float af[UN][KM];
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int m = 0; m < KM; ++m) af[u][m] = (m < km && rt0 + u < NRT) ? ap[(4 * m) * TS + (rt0 + u) * 16] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int row0 = (rt0 + u) * 16 + 4 * L.q;
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int m = 0; m < KM; ++m)
-                    if (m < km) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], xb[j][m], acc, 0, 0, 0);
+                    if (m < km) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u][m], xz[j][m], acc, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     // (rows past the horizon: a value inside the limits -- a select, no control flow in this loop)
@@ -383,12 +394,16 @@ __device__ __forceinline__ bool gate_pass(const TrajArgs& a, const LaneMap<KM>& 
 // of the same wave adds 2 - 4; left alone the compiler sinks each step's LDS read next to its use (`s_waitcnt lgkmcnt(1)` in front
 // of every step: ~40 cycles of LDS latency exposed per step).  PRE = 1: all 32 reads issued, ONE wait, all conversions, then the
 // chain with nothing but its own operations, the action conversion and the LDS write in between.
-template <int CTRL, bool MASKED, bool INTEGRATE = true, int KEEP64 = 0, int PRE = 0, bool WRITE_A = true>
+// GATE (round 6, k_phase_fused): the desired positions the chain pulls into registers anyway are also tested against the joint limits
+// [glo32, ghi32] (exact fp32 thresholds of the validity gate: one v_med3_f32 + compare each); *gate_bad |= any of the tile's `rows`
+// positions outside -- no LDS read, no wait of its own.
+template <int CTRL, bool MASKED, bool INTEGRATE = true, int KEEP64 = 0, int PRE = 0, bool WRITE_A = true, bool GATE = false>
 __device__ __forceinline__ void pd_tile_steps(const float* __restrict__ sP, const float* __restrict__ sV,
                                               float* __restrict__ sA, const int stride, const int t0, const int nst,
                                               const double pgd, const double dgd, const double lod, const double hid,
                                               const double dtp, double& qs, double& qds, double* __restrict__ q64 = nullptr,
-                                              double* __restrict__ u64 = nullptr, const int rows = 16) {
+                                              double* __restrict__ u64 = nullptr, const int rows = 16, const float glo32 = 0.0f,
+                                              const float ghi32 = 0.0f, int* __restrict__ gate_bad = nullptr) {
     // INTEGRATE = false: MPK_PLANT_STATIC (the state never changes).  KEEP64 = 1: the plant position after the step and the
     // clipped action also stay in LDS as float64, q64 / u64 = the lane's column of a [16 columns][16 steps] image (the reward pass of
     // the reacher rollout reads them);
@@ -396,6 +411,16 @@ __device__ __forceinline__ void pd_tile_steps(const float* __restrict__ sP, cons
     float pr[16], vr[16];
 #pragma unroll
     for (int tl = 0; tl < 16; ++tl) { pr[tl] = sP[tl * stride]; vr[tl] = sV[tl * stride]; }
+    if (GATE) {
+        int tb = 0;
+#pragma unroll
+        for (int tl = 0; tl < 16; ++tl) {
+            // (rows past the horizon: a value inside the limits -- a select, no control flow)
+            const float p = (!MASKED || tl < rows) ? pr[tl] : glo32;
+            tb |= (int)!(__builtin_amdgcn_fmed3f(p, glo32, ghi32) == p);
+        }
+        *gate_bad |= tb;
+    }
     double dpr[16], dvr[16];
     if (PRE) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

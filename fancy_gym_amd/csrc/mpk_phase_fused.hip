@@ -476,14 +476,15 @@ __global__ void __launch_bounds__(TL ? 512 : 256, MPK_PF_WAVES) k_phase_fused(co
                 // pd_tile_steps: no LDS read or wait of its own -- a separate pass of sixteen reads cost 12 % at 8 192 episodes)
                 const bool full_tile = nrows == TT && tile_fully_executed(on, nst, t0);
                 int tb = 0;
+                double gsum[2] = {over, under};
                 if (on && store) {
                     if (CLOSED && a.gate) {
                         if (full_tile)
                             pd_tile_steps<CTRL, false, CLOSED, 0, 0, true, true>(sP + oq, sV + oq, sA + oq, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds,
-                                                                               nullptr, nullptr, 16, glo32, ghi32, &tb);
+                                                                               nullptr, nullptr, 16, glo32, ghi32, &tb, glo, ghi, gsum);
                         else
                             pd_tile_steps<CTRL, true, CLOSED, 0, 0, true, true>(sP + oq, sV + oq, sA + oq, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds,
-                                                                              nullptr, nullptr, nrows, glo32, ghi32, &tb);
+                                                                              nullptr, nullptr, nrows, glo32, ghi32, &tb, glo, ghi, gsum);
                     } else if (full_tile) {
                         pd_tile_steps<CTRL, false, CLOSED>(sP + oq, sV + oq, sA + oq, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds);
                     } else {
@@ -494,10 +495,10 @@ __global__ void __launch_bounds__(TL ? 512 : 256, MPK_PF_WAVES) k_phase_fused(co
                     if (CLOSED && a.gate) {
                         if (full_tile)
                             pd_tile_steps<CTRL, false, CLOSED, 0, 0, false, true>(sP + oq, sV + oq, nullptr, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds,
-                                                                                nullptr, nullptr, 16, glo32, ghi32, &tb);
+                                                                                nullptr, nullptr, 16, glo32, ghi32, &tb, glo, ghi, gsum);
                         else
                             pd_tile_steps<CTRL, true, CLOSED, 0, 0, false, true>(sP + oq, sV + oq, nullptr, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds,
-                                                                               nullptr, nullptr, nrows, glo32, ghi32, &tb);
+                                                                               nullptr, nullptr, nrows, glo32, ghi32, &tb, glo, ghi, gsum);
                     } else if (full_tile) {
                         pd_tile_steps<CTRL, false, CLOSED, 0, 0, false>(sP + oq, sV + oq, nullptr, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds);
                     } else {
@@ -505,18 +506,8 @@ __global__ void __launch_bounds__(TL ? 512 : 256, MPK_PF_WAVES) k_phase_fused(co
                                                                        nullptr, nullptr, nrows);
                     }
                 }
-                if (CLOSED && a.gate && __any(tb) != 0) {
-                    // (rare) a tile that holds a violation adds up the float64 excess of its columns, in time order
-                    if (tb) {
-                        p_bad = true;
-                        const float* pP = sP + oq;
-                        for (int tl = 0; tl < nrows; ++tl) {
-                            const double x = (double)pP[tl * D];
-                            over += fmax(x - ghi, 0.0);
-                            under += fmax(glo - x, 0.0);
-                        }
-                    }
-                }
+                if (tb) p_bad = true;
+                over = gsum[0]; under = gsum[1];
             }
             __builtin_amdgcn_wave_barrier();
             // ---- C: the tile's runs of nrows * D floats per episode and array

@@ -282,7 +282,7 @@ __device__ __forceinline__ GateLim kernarg_gate(int d) {
 // Validity gate of the lane-quarter closed-loop kernels (preprocessing_and_validity_callback between plan and rollout,
 // black_box_wrapper.py:155-172; TableTennisEnv.check_traj_validity / _get_traj_invalid_penalty, table_tennis_env.py:282-309): ONE extra
 // pass over the row tiles of the unit's NQ groups BEFORE the recurrences start -- position C tiles only (KM MFMAs per group and tile,
-// nothing stored), every position against its joint limits with one v_med3_f32 (exact fp32 thresholds) -- so the step loop that follows
+// nothing stored), every position against its joint limits (exact fp32 thresholds, running max / min) -- so the step loop that follows
 // simply runs with nst = 0 for an invalid plan: actions 0, plant state untouched, condition = row 0, done = 1 (replan_write).  Only a
 // unit that holds a violation repeats the pass in float64 for the penalty's excess sums (reduced over the rows of a lane, the four
 // lane quarters, the DoF lanes of an episode: a fixed order).  Returns, to the SERIAL lane of (group L.q, episode L.bl), whether that
@@ -292,16 +292,20 @@ template <int KM, int NQ>
 __device__ __forceinline__ bool gate_pass(const TrajArgs& a, const LaneMap<KM>& L, const float* __restrict__ ap, const int TS, const int km,
                                           const float (&xb)[NQ][KM], const int g0, const GateLim& gl, double& over, double& under) {
     const int T = a.c.T, NRT = (T + 15) >> 4;
-    int bad[NQ];
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) bad[j] = 0;
-    // (a group past the launch's last one contracts zeros: no test per group inside the loop; four row tiles per trip, their A fragments
-    // read together: the lone wave of a few thousand episodes pays latencies, not instructions)
+    // (a group past the launch's last one contracts zeros: no test per group inside the loop)
     float xz[NQ][KM];
 #pragma unroll
     for (int j = 0; j < NQ; ++j)
 #pragma unroll
         for (int m = 0; m < KM; ++m) xz[j][m] = g0 + j < a.G ? xb[j][m] : 0.0f;
+    // running maximum / minimum per group over the lane's rows: v_max3_f32 / v_min3_f32, one compare per group at the end (NaN
+    // positions pass, as in the reference's `np.any(pos > high)`); `tiles`: which row tiles hold a violation (the float64 pass below
+    // visits only those).  Four row tiles per trip, their A fragments read together: the lone wave of a few thousand episodes pays
+    // latencies, not instructions.
+    float mx[NQ], mn[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) { mx[j] = gl.lo32; mn[j] = gl.hi32; }
+    unsigned long long tiles = 0ull;
     constexpr int UN = 4;
     for (int rt0 = 0; rt0 < NRT; rt0 += UN) {
         float af[UN][KM];
@@ -312,19 +316,23 @@ __device__ __forceinline__ bool gate_pass(const TrajArgs& a, const LaneMap<KM>& 
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int row0 = (rt0 + u) * 16 + 4 * L.q;
+            float tmx = gl.lo32, tmn = gl.hi32;
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int m = 0; m < KM; ++m)
                     if (m < km) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u][m], xz[j][m], acc, 0, 0, 0);
+                if ((rt0 + u + 1) * 16 > T) {           // (wave-uniform: the horizon's last tile -- rows past it count as inside the limits)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    // (rows past the horizon: a value inside the limits -- a select, no control flow in this loop)
-                    const float x = row0 + r < T ? acc[r] : gl.lo32;
-                    bad[j] |= (int)!(__builtin_amdgcn_fmed3f(x, gl.lo32, gl.hi32) == x);
+                    for (int r = 0; r < 4; ++r) acc[r] = row0 + r < T ? acc[r] : gl.lo32;
                 }
+                const float hi4 = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), __builtin_fmaxf(acc[2], acc[3]));
+                const float lo4 = __builtin_fminf(__builtin_fminf(acc[0], acc[1]), __builtin_fminf(acc[2], acc[3]));
+                mx[j] = __builtin_fmaxf(mx[j], hi4); mn[j] = __builtin_fminf(mn[j], lo4);
+                tmx = __builtin_fmaxf(tmx, L.dvalid ? hi4 : gl.lo32); tmn = __builtin_fminf(tmn, L.dvalid ? lo4 : gl.hi32);
             }
+            if (rt0 + u < 64 && __any(tmx > gl.hi32 || tmn < gl.lo32) != 0) tiles |= 1ull << (rt0 + u);
         }
     }
     // the lanes that hold episode bl's columns of a C tile: its DP columns, in all four lane quarters
@@ -334,43 +342,41 @@ __device__ __forceinline__ bool gate_pass(const TrajArgs& a, const LaneMap<KM>& 
     bool mine = false;
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
-        const unsigned long long mj = __ballot(L.dvalid && bad[j] != 0 && (g0 + j) * L.NTW + L.bl < a.B);
+        const unsigned long long mj = __ballot(L.dvalid && (mx[j] > gl.hi32 || mn[j] < gl.lo32) && (g0 + j) * L.NTW + L.bl < a.B);
         any |= mj;
         if (L.q == j) mine = (mj & em) != 0ull;
     }
     over = 0.0; under = 0.0;
-    if (any != 0ull) {                                  // (wave-uniform, rare) the excess sums, float64
+    if (any != 0ull) {                                  // (wave-uniform) the excess sums, float64, of the row tiles that hold a violation
         double ov[NQ], un[NQ];
 #pragma unroll
         for (int j = 0; j < NQ; ++j) { ov[j] = 0.0; un[j] = 0.0; }
         for (int rt = 0; rt < NRT; ++rt) {
+            if (rt < 64 && !((tiles >> rt) & 1ull)) continue;
             float af[KM];
 #pragma unroll
             for (int m = 0; m < KM; ++m) af[m] = m < km ? ap[(4 * m) * TS + rt * 16] : 0.0f;
             const int row0 = rt * 16 + 4 * L.q;
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
-                if (g0 + j < a.G) {
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int m = 0; m < KM; ++m)
-                        if (m < km) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], xb[j][m], acc, 0, 0, 0);
+                for (int m = 0; m < KM; ++m)
+                    if (m < km) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m], xz[j][m], acc, 0, 0, 0);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (row0 + r < T && L.dvalid) {
-                            const double x = (double)acc[r];
-                            ov[j] += fmax(x - gl.hi, 0.0);
-                            un[j] += fmax(gl.lo - x, 0.0);
-                        }
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    const double x = (double)acc[r];
+                    const bool in = row0 + r < T && L.dvalid;
+                    ov[j] += in ? fmax(x - gl.hi, 0.0) : 0.0;
+                    un[j] += in ? fmax(gl.lo - x, 0.0) : 0.0;
                 }
             }
         }
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
             // the four lane quarters (rows 4 q .. 4 q + 3 of every tile), then the DoF lanes of the episode
-            for (int s = 16; s <= 32; s <<= 1) { ov[j] += __shfl_xor(ov[j], s); un[j] += __shfl_xor(un[j], s); }
-            for (int s = 1; s < DP; s <<= 1) { ov[j] += __shfl_xor(ov[j], s); un[j] += __shfl_xor(un[j], s); }
+            for (int sft = 16; sft <= 32; sft <<= 1) { ov[j] += __shfl_xor(ov[j], sft); un[j] += __shfl_xor(un[j], sft); }
+            for (int sft = 1; sft < DP; sft <<= 1) { ov[j] += __shfl_xor(ov[j], sft); un[j] += __shfl_xor(un[j], sft); }
             if (L.q == j) { over = ov[j]; under = un[j]; }
         }
     }
@@ -395,15 +401,16 @@ __device__ __forceinline__ bool gate_pass(const TrajArgs& a, const LaneMap<KM>& 
 // of every step: ~40 cycles of LDS latency exposed per step).  PRE = 1: all 32 reads issued, ONE wait, all conversions, then the
 // chain with nothing but its own operations, the action conversion and the LDS write in between.
 // GATE (round 6, k_phase_fused): the desired positions the chain pulls into registers anyway are also tested against the joint limits
-// [glo32, ghi32] (exact fp32 thresholds of the validity gate: one v_med3_f32 + compare each); *gate_bad |= any of the tile's `rows`
-// positions outside -- no LDS read, no wait of its own.
+// [glo32, ghi32] (exact fp32 thresholds of the validity gate); *gate_bad |= any of the tile's `rows` positions outside -- no LDS read, no
+// wait of its own; a wave that holds a violation adds the tile's float64 excess above / below [gate_lo, gate_hi] to gate_sum[0] / [1].
 template <int CTRL, bool MASKED, bool INTEGRATE = true, int KEEP64 = 0, int PRE = 0, bool WRITE_A = true, bool GATE = false>
 __device__ __forceinline__ void pd_tile_steps(const float* __restrict__ sP, const float* __restrict__ sV,
                                               float* __restrict__ sA, const int stride, const int t0, const int nst,
                                               const double pgd, const double dgd, const double lod, const double hid,
                                               const double dtp, double& qs, double& qds, double* __restrict__ q64 = nullptr,
                                               double* __restrict__ u64 = nullptr, const int rows = 16, const float glo32 = 0.0f,
-                                              const float ghi32 = 0.0f, int* __restrict__ gate_bad = nullptr) {
+                                              const float ghi32 = 0.0f, int* __restrict__ gate_bad = nullptr, const double gate_lo = 0.0,
+                                              const double gate_hi = 0.0, double* __restrict__ gate_sum = nullptr) {
     // INTEGRATE = false: MPK_PLANT_STATIC (the state never changes).  KEEP64 = 1: the plant position after the step and the
     // clipped action also stay in LDS as float64, q64 / u64 = the lane's column of a [16 columns][16 steps] image (the reward pass of
     // the reacher rollout reads them);
@@ -412,14 +419,30 @@ __device__ __forceinline__ void pd_tile_steps(const float* __restrict__ sP, cons
 #pragma unroll
     for (int tl = 0; tl < 16; ++tl) { pr[tl] = sP[tl * stride]; vr[tl] = sV[tl * stride]; }
     if (GATE) {
-        int tb = 0;
+        // running maximum / minimum of the tile's positions: two v_max3_f32 / v_min3_f32 per four values, compared once (rows past the
+        // horizon replaced by a value inside the limits -- a select, no control flow).  NaN positions pass, as they do in the reference's
+        // `np.any(pos > high)` (table_tennis_env.py:307)
+        float mx = glo32, mn = ghi32;
 #pragma unroll
-        for (int tl = 0; tl < 16; ++tl) {
-            // (rows past the horizon: a value inside the limits -- a select, no control flow)
-            const float p = (!MASKED || tl < rows) ? pr[tl] : glo32;
-            tb |= (int)!(__builtin_amdgcn_fmed3f(p, glo32, ghi32) == p);
+        for (int tl = 0; tl < 16; tl += 2) {
+            const float p0 = (!MASKED || tl < rows) ? pr[tl] : glo32, p1 = (!MASKED || tl + 1 < rows) ? pr[tl + 1] : glo32;
+            mx = __builtin_fmaxf(mx, __builtin_fmaxf(p0, p1));
+            mn = __builtin_fminf(mn, __builtin_fminf(p0, p1));
         }
-        *gate_bad |= tb;
+        const int tb = (int)(mx > ghi32) | (int)(mn < glo32);
+        gate_bad[0] |= tb;
+        if (__any(tb) != 0) {
+            // (wave-uniform) the penalty's float64 excess sums of this tile, in time order, from the registers
+            double ov = 0.0, un = 0.0;
+#pragma unroll
+            for (int tl = 0; tl < 16; ++tl) {
+                if (MASKED && tl >= rows) break;
+                const double x = (double)pr[tl];
+                ov += fmax(x - gate_hi, 0.0);
+                un += fmax(gate_lo - x, 0.0);
+            }
+            gate_sum[0] += ov; gate_sum[1] += un;
+        }
     }
     double dpr[16], dvr[16];
     if (PRE) {

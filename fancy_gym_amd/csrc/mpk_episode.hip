@@ -120,29 +120,23 @@ __global__ void __launch_bounds__(512) k_episode_return(const TrajArgs a, const 
         float* sQ = sW + L.q * IMG;
         double qs = sc.qs, qds = sc.qds;
         int nst_ = sc.nst, s0_ = sc.s0;
-        if (a.gate_valid) {
-            // validity gate: judge the unit's plans first (gate_pass, mpk_tile.h); an invalid plan executes nothing
-            ReplanVals rv{sc.nst, 0, 0, false};
-            double tpen = 0.0;
-            bool t_bad = false;
-            if (serial) {
-                if (a.rp.traj_steps) rv = replan_eval(a.rp, bq, T);
-                if (a.gate_check_td) {
-                    const double tau = (double)a.gate_raw[(size_t)bq * c.P], delay = (double)a.gate_raw[(size_t)bq * c.P + 1];
-                    t_bad = !(tau >= a.gate_tb[0] && tau <= a.gate_tb[1] && delay >= a.gate_db[0] && delay <= a.gate_db[1]);
-                    tpen = 3.0 * (fmax(0.0, tau - a.gate_tb[1]) + fmax(0.0, a.gate_tb[0] - tau)) +
-                           3.0 * (fmax(0.0, delay - a.gate_db[1]) + fmax(0.0, a.gate_db[0] - delay));
-                }
-            }
-            double over, under;
-            const bool p_bad = gate_pass<KM, NQ>(a, L, ap, TS, km, xb, g0, glim, over, under);
-            const bool invalid = serial && (p_bad || t_bad);
-            nst_ = invalid ? 0 : rv.seg;
-            if (serial && L.d == 0) {
-                a.gate_valid[bq] = invalid ? 0 : 1;
-                const double n = (double)(T * D);
-                if (a.gate_penalty) a.gate_penalty[bq] = -(tpen + over / n + under / n);
-                if (a.rp.traj_steps) replan_write(a.rp, bq, rv, !invalid);
+        // validity gate: this kernel stores nothing per step, so the plan is judged WHILE it runs -- the position C tiles of the main loop
+        // go through the scan (gate_scan_tile, mpk_tile.h), the verdict falls after the last tile, and an invalid plan is simply not
+        // committed: plant state, integer state, aggregated reward as if nothing had been executed (k_traj_quad, which stores actions,
+        // takes a separate first pass instead)
+        const bool gated = a.gate_valid != nullptr;
+        ReplanVals rv{sc.nst, 0, 0, false};
+        double tpen = 0.0;
+        bool t_bad = false;
+        GateScan<NQ> gs;
+        gs.init(glim);
+        if (gated && serial) {
+            if (a.rp.traj_steps) { rv = replan_eval(a.rp, bq, T); nst_ = rv.seg; }
+            if (a.gate_check_td) {
+                const double tau = (double)a.gate_raw[(size_t)bq * c.P], delay = (double)a.gate_raw[(size_t)bq * c.P + 1];
+                t_bad = !(tau >= a.gate_tb[0] && tau <= a.gate_tb[1] && delay >= a.gate_db[0] && delay <= a.gate_db[1]);
+                tpen = 3.0 * (fmax(0.0, tau - a.gate_tb[1]) + fmax(0.0, a.gate_tb[0] - tau)) +
+                       3.0 * (fmax(0.0, delay - a.gate_db[1]) + fmax(0.0, a.gate_db[0] - delay));
             }
         }
         asm volatile("" : "+v"(qs), "+v"(qds), "+v"(nst_), "+v"(s0_));
@@ -154,14 +148,14 @@ __global__ void __launch_bounds__(512) k_episode_return(const TrajArgs a, const 
         if (RWD) {
             if (L.d == 0 && L.q < NQ) {
                 int* sl = sSlot + (L.q * NTW + L.bl) * kEpSlotInts;
-                sl[0] = serial ? nst : 0; sl[1] = s0_; sl[2] = serial ? bq : -1;
+                sl[0] = serial ? nst : 0; sl[1] = s0_; sl[2] = serial ? bq : -1; sl[3] = 0;
                 *reinterpret_cast<double*>(sl + 4) = sc.gx; *reinterpret_cast<double*>(sl + 6) = sc.gy;
                 if (serial && nst > 0) tdist = max(ep.steps_before_reward - s0_, 0);
             }
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) tdist = min(tdist, __shfl_xor(tdist, m));
         }
-        if (ep.seg_out && serial && L.d == 0) ep.seg_out[bq] = nst;
+        if (ep.seg_out && serial && L.d == 0 && !gated) ep.seg_out[bq] = nst;
         double racc[kEpMaxPass];
 #pragma unroll
         for (int p = 0; p < kEpMaxPass; ++p) racc[p] = 0.0;
@@ -175,7 +169,8 @@ __global__ void __launch_bounds__(512) k_episode_return(const TrajArgs a, const 
         int nmax = serial ? max(nst, tcond + 1) : 0;
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) nmax = max(nmax, __shfl_xor(nmax, m));
-        const int nrt_live = min(NRT, (nmax + 15) >> 4);
+        const int nrt_live = gated ? NRT : min(NRT, (nmax + 15) >> 4);      // (the gate has to see the whole plan)
+        float row0p = 0.0f, row0v = 0.0f;               // gate: the desired state of step 0 (condition of an episode that executes nothing)
         for (int rt = 0; rt < nrt_live; ++rt) {
             const int rows = min(16, T - rt * 16);
             float af[NOUT][KM];
@@ -190,6 +185,7 @@ __global__ void __launch_bounds__(512) k_episode_return(const TrajArgs a, const 
                     for (int m = 0; m < KM; ++m) afn[o][m] = m < km ? ap[(o * KP + 4 * m) * TS + (rt + 1) * 16] : 0.0f;
             }
             // 1. NQ C tiles on the matrix cores -> desired (pos, vel) images
+            bool tile_viol = false;
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
                 if (g0 + j < a.G) {
@@ -210,11 +206,14 @@ __global__ void __launch_bounds__(512) k_episode_return(const TrajArgs a, const 
                         }
                         tile_epilogue<MP, -1>(acc0, acc1, acc2, dtd, 0.0, 0.0, Gains{0.0, 0.0, 0.0, 0.0}, sW + j * IMG, L.wofs, D);
                     }
+                    if (gated) tile_viol = gate_scan_tile<NQ>(gs, j, acc0, rt, L.q, L.dvalid && (g0 + j) * NTW + L.bl < B, glim, T) || tile_viol;
                 }
             }
+            if (gated && rt < 64 && __any(tile_viol) != 0) gs.tiles |= 1ull << rt;
             __builtin_amdgcn_wave_barrier();
             // 2. the recurrences, one group per lane quarter; float64 [column][step] images for the reward pass
             const bool tile_dist = RWD && rt * 16 + 15 >= tdist;
+            if (gated && rt == 0 && serial) { row0p = sQ[oq]; row0v = sQ[kStageStride + oq]; }
             if (serial && rt * 16 < max(nst, tcond + 1)) {
                 if (tcond >= rt * 16 && tcond < rt * 16 + 16) {     // condition_on_desired: the desired state at the last executed step
                     const size_t si = (size_t)bq * D + L.d;
@@ -267,9 +266,35 @@ __global__ void __launch_bounds__(512) k_episode_return(const TrajArgs a, const 
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        if (serial) {
+        bool invalid = false;
+        if (gated) {
+            float xz[NQ][KM];
+#pragma unroll
+            for (int j = 0; j < NQ; ++j)
+#pragma unroll
+                for (int m = 0; m < KM; ++m) xz[j][m] = g0 + j < a.G ? xb[j][m] : 0.0f;
+            double over, under;
+            const bool p_bad = gate_verdict<KM, NQ>(a, L, gs, ap, TS, km, xz, g0, glim, over, under);
+            invalid = serial && (p_bad || t_bad);
+            if (serial) {
+                const size_t si = (size_t)bq * D + L.d;
+                if (invalid && a.rp.cond_pos) { a.rp.cond_pos[si] = row0p; a.rp.cond_vel[si] = row0v; }
+                if (L.d == 0) {
+                    a.gate_valid[bq] = invalid ? 0 : 1;
+                    const double n = (double)(T * D);
+                    if (a.gate_penalty) a.gate_penalty[bq] = -(tpen + over / n + under / n);
+                    if (a.rp.traj_steps) replan_write(a.rp, bq, rv, !invalid);
+                    if (ep.seg_out) ep.seg_out[bq] = invalid ? 0 : nst;
+                }
+            }
+        }
+        if (serial && !invalid) {
             const size_t si = (size_t)bq * D + L.d;
             a.q_state[si] = qs; a.qd_state[si] = qds;
+        }
+        if (RWD && gated) {                             // (an invalid plan executed nothing: its aggregated reward is 0)
+            if (invalid && L.d == 0 && L.q < NQ) sSlot[(L.q * NTW + L.bl) * kEpSlotInts + 3] = 1;
+            __builtin_amdgcn_wave_barrier();
         }
         // the aggregated reward: the sixteen step slots of an episode left to right (see the header of this file)
         if (ep.ret) {
@@ -286,7 +311,7 @@ __global__ void __launch_bounds__(512) k_episode_return(const TrajArgs a, const 
                         if ((lane & 15) == 0 && s < nslots) {
                             const int* sl = sSlot + s * kEpSlotInts;
                             const int pns = sl[0], pb = sl[2];
-                            if (pb >= 0) ep.ret[pb] = ep.agg == 1 ? (pns > 0 ? acc / (double)pns : 0.0) : acc;
+                            if (pb >= 0) ep.ret[pb] = sl[3] != 0 ? 0.0 : (ep.agg == 1 ? (pns > 0 ? acc / (double)pns : 0.0) : acc);
                         }
                     }
                 }

@@ -288,53 +288,41 @@ __device__ __forceinline__ GateLim kernarg_gate(int d) {
 // lane quarters, the DoF lanes of an episode: a fixed order).  Returns, to the SERIAL lane of (group L.q, episode L.bl), whether that
 // plan leaves the limits; over / under: its summed excess above / below (0 where nothing is violated).
 //   ap: the lane's A-fragment base (sA + L.q * TS + L.col), position rows first (o = 0); km: MFMAs per tile actually needed
-template <int KM, int NQ>
-__device__ __forceinline__ bool gate_pass(const TrajArgs& a, const LaneMap<KM>& L, const float* __restrict__ ap, const int TS, const int km,
-                                          const float (&xb)[NQ][KM], const int g0, const GateLim& gl, double& over, double& under) {
-    const int T = a.c.T, NRT = (T + 15) >> 4;
-    // (a group past the launch's last one contracts zeros: no test per group inside the loop)
-    float xz[NQ][KM];
-#pragma unroll
-    for (int j = 0; j < NQ; ++j)
-#pragma unroll
-        for (int m = 0; m < KM; ++m) xz[j][m] = g0 + j < a.G ? xb[j][m] : 0.0f;
-    // running maximum / minimum per group over the lane's rows: v_max3_f32 / v_min3_f32, one compare per group at the end (NaN
-    // positions pass, as in the reference's `np.any(pos > high)`); `tiles`: which row tiles hold a violation (the float64 pass below
-    // visits only those).  Four row tiles per trip, their A fragments read together: the lone wave of a few thousand episodes pays
-    // latencies, not instructions.
+// the running state of a unit's scan: maximum / minimum of every position seen per group (this lane's rows and column), and which row
+// tiles hold a violation anywhere in the wave
+template <int NQ>
+struct GateScan {
     float mx[NQ], mn[NQ];
+    unsigned long long tiles;
+    __device__ __forceinline__ void init(const GateLim& gl) {
 #pragma unroll
-    for (int j = 0; j < NQ; ++j) { mx[j] = gl.lo32; mn[j] = gl.hi32; }
-    unsigned long long tiles = 0ull;
-    constexpr int UN = 4;
-    for (int rt0 = 0; rt0 < NRT; rt0 += UN) {
-        float af[UN][KM];
-#pragma unroll
-        for (int u = 0; u < UN; ++u)
-#pragma unroll
-            for (int m = 0; m < KM; ++m) af[u][m] = (m < km && rt0 + u < NRT) ? ap[(4 * m) * TS + (rt0 + u) * 16] : 0.0f;
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int row0 = (rt0 + u) * 16 + 4 * L.q;
-            float tmx = gl.lo32, tmn = gl.hi32;
-#pragma unroll
-            for (int j = 0; j < NQ; ++j) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int m = 0; m < KM; ++m)
-                    if (m < km) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u][m], xz[j][m], acc, 0, 0, 0);
-                if ((rt0 + u + 1) * 16 > T) {           // (wave-uniform: the horizon's last tile -- rows past it count as inside the limits)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[r] = row0 + r < T ? acc[r] : gl.lo32;
-                }
-                const float hi4 = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), __builtin_fmaxf(acc[2], acc[3]));
-                const float lo4 = __builtin_fminf(__builtin_fminf(acc[0], acc[1]), __builtin_fminf(acc[2], acc[3]));
-                mx[j] = __builtin_fmaxf(mx[j], hi4); mn[j] = __builtin_fminf(mn[j], lo4);
-                tmx = __builtin_fmaxf(tmx, L.dvalid ? hi4 : gl.lo32); tmn = __builtin_fminf(tmn, L.dvalid ? lo4 : gl.hi32);
-            }
-            if (rt0 + u < 64 && __any(tmx > gl.hi32 || tmn < gl.lo32) != 0) tiles |= 1ull << (rt0 + u);
-        }
+        for (int j = 0; j < NQ; ++j) { mx[j] = gl.lo32; mn[j] = gl.hi32; }
+        tiles = 0ull;
     }
+};
+// one position C tile of group j, row tile rt, into the scan (v_max3_f32 / v_min3_f32; NaN positions pass, as in the reference's
+// `np.any(pos > high)`, table_tennis_env.py:307); returns the lane's "this tile violates" for the caller's wave-level test
+template <int NQ>
+__device__ __forceinline__ bool gate_scan_tile(GateScan<NQ>& g, const int j, f32x4 acc, const int rt, const int lq, const bool dvalid,
+                                               const GateLim& gl, const int T) {
+    if ((rt + 1) * 16 > T) {                            // (wave-uniform: the horizon's last tile -- rows past it count as inside the limits)
+        const int row0 = rt * 16 + 4 * lq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = row0 + r < T ? acc[r] : gl.lo32;
+    }
+    const float hi4 = __builtin_fmaxf(__builtin_fmaxf(acc[0], acc[1]), __builtin_fmaxf(acc[2], acc[3]));
+    const float lo4 = __builtin_fminf(__builtin_fminf(acc[0], acc[1]), __builtin_fminf(acc[2], acc[3]));
+    g.mx[j] = __builtin_fmaxf(g.mx[j], hi4); g.mn[j] = __builtin_fminf(g.mn[j], lo4);
+    return dvalid && (hi4 > gl.hi32 || lo4 < gl.lo32);
+}
+// the verdict for the SERIAL lane of (group L.q, episode L.bl) after every row tile went through the scan, and -- only in a unit that
+// holds a violation -- the penalty's excess sums: the flagged row tiles again, float64, reduced over the rows of a lane, the four lane
+// quarters and the DoF lanes of an episode (a fixed order)
+template <int KM, int NQ>
+__device__ __forceinline__ bool gate_verdict(const TrajArgs& a, const LaneMap<KM>& L, const GateScan<NQ>& g, const float* __restrict__ ap,
+                                             const int TS, const int km, const float (&xz)[NQ][KM], const int g0, const GateLim& gl,
+                                             double& over, double& under) {
+    const int T = a.c.T, NRT = (T + 15) >> 4;
     // the lanes that hold episode bl's columns of a C tile: its DP columns, in all four lane quarters
     const int DP = 1 << a.sh;
     const unsigned long long em = (unsigned long long)(((1u << DP) - 1u) << (L.bl * DP)) * 0x0001000100010001ull;
@@ -342,17 +330,17 @@ __device__ __forceinline__ bool gate_pass(const TrajArgs& a, const LaneMap<KM>& 
     bool mine = false;
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
-        const unsigned long long mj = __ballot(L.dvalid && (mx[j] > gl.hi32 || mn[j] < gl.lo32) && (g0 + j) * L.NTW + L.bl < a.B);
+        const unsigned long long mj = __ballot(L.dvalid && (g.mx[j] > gl.hi32 || g.mn[j] < gl.lo32) && (g0 + j) * L.NTW + L.bl < a.B);
         any |= mj;
         if (L.q == j) mine = (mj & em) != 0ull;
     }
     over = 0.0; under = 0.0;
-    if (any != 0ull) {                                  // (wave-uniform) the excess sums, float64, of the row tiles that hold a violation
+    if (any != 0ull) {                                  // (wave-uniform)
         double ov[NQ], un[NQ];
 #pragma unroll
         for (int j = 0; j < NQ; ++j) { ov[j] = 0.0; un[j] = 0.0; }
         for (int rt = 0; rt < NRT; ++rt) {
-            if (rt < 64 && !((tiles >> rt) & 1ull)) continue;
+            if (rt < 64 && !((g.tiles >> rt) & 1ull)) continue;
             float af[KM];
 #pragma unroll
             for (int m = 0; m < KM; ++m) af[m] = m < km ? ap[(4 * m) * TS + rt * 16] : 0.0f;
@@ -374,13 +362,50 @@ __device__ __forceinline__ bool gate_pass(const TrajArgs& a, const LaneMap<KM>& 
         }
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
-            // the four lane quarters (rows 4 q .. 4 q + 3 of every tile), then the DoF lanes of the episode
             for (int sft = 16; sft <= 32; sft <<= 1) { ov[j] += __shfl_xor(ov[j], sft); un[j] += __shfl_xor(un[j], sft); }
             for (int sft = 1; sft < DP; sft <<= 1) { ov[j] += __shfl_xor(ov[j], sft); un[j] += __shfl_xor(un[j], sft); }
             if (L.q == j) { over = ov[j]; under = un[j]; }
         }
     }
     return mine;
+}
+// the separate first pass of the kernels that STORE (k_traj_quad / duo / mono: a speculative rollout would have to take its action
+// stores back): position C tiles only, four row tiles per trip with their A fragments read together (the lone wave of a few thousand
+// episodes pays latencies, not instructions)
+template <int KM, int NQ>
+__device__ __forceinline__ bool gate_pass(const TrajArgs& a, const LaneMap<KM>& L, const float* __restrict__ ap, const int TS, const int km,
+                                          const float (&xb)[NQ][KM], const int g0, const GateLim& gl, double& over, double& under) {
+    const int T = a.c.T, NRT = (T + 15) >> 4;
+    // (a group past the launch's last one contracts zeros: no test per group inside the loop)
+    float xz[NQ][KM];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j)
+#pragma unroll
+        for (int m = 0; m < KM; ++m) xz[j][m] = g0 + j < a.G ? xb[j][m] : 0.0f;
+    GateScan<NQ> g;
+    g.init(gl);
+    constexpr int UN = 4;
+    for (int rt0 = 0; rt0 < NRT; rt0 += UN) {
+        float af[UN][KM];
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int m = 0; m < KM; ++m) af[u][m] = (m < km && rt0 + u < NRT) ? ap[(4 * m) * TS + (rt0 + u) * 16] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            bool tv = false;
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < KM; ++m)
+                    if (m < km) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[u][m], xz[j][m], acc, 0, 0, 0);
+                tv = gate_scan_tile<NQ>(g, j, acc, rt0 + u, L.q, L.dvalid, gl, T) || tv;
+            }
+            if (rt0 + u < 64 && rt0 + u < NRT && __any(tv) != 0) g.tiles |= 1ull << (rt0 + u);
+        }
+    }
+    return gate_verdict<KM, NQ>(a, L, g, ap, TS, km, xz, g0, gl, over, under);
 }
 
 // The step loop of black_box_wrapper.py:175-203 on the reference's torque double integrator (base_reacher_torque.py:25-26)
@@ -429,19 +454,27 @@ __device__ __forceinline__ void pd_tile_steps(const float* __restrict__ sP, cons
             mx = __builtin_fmaxf(mx, __builtin_fmaxf(p0, p1));
             mn = __builtin_fminf(mn, __builtin_fminf(p0, p1));
         }
-        const int tb = (int)(mx > ghi32) | (int)(mn < glo32);
-        gate_bad[0] |= tb;
-        if (__any(tb) != 0) {
-            // (wave-uniform) the penalty's float64 excess sums of this tile, in time order, from the registers
-            double ov = 0.0, un = 0.0;
+        const bool bh = mx > ghi32, bl_ = mn < glo32;
+        gate_bad[0] |= (int)(bh || bl_);
+        // (wave-uniform, per side: a wave usually violates one of the two limits) the penalty's float64 excess sums of this tile, in time
+        // order, from the registers
+        if (__any(bh) != 0) {
+            double ov = 0.0;
 #pragma unroll
             for (int tl = 0; tl < 16; ++tl) {
                 if (MASKED && tl >= rows) break;
-                const double x = (double)pr[tl];
-                ov += fmax(x - gate_hi, 0.0);
-                un += fmax(gate_lo - x, 0.0);
+                ov += fmax((double)pr[tl] - gate_hi, 0.0);
             }
-            gate_sum[0] += ov; gate_sum[1] += un;
+            gate_sum[0] += ov;
+        }
+        if (__any(bl_) != 0) {
+            double un = 0.0;
+#pragma unroll
+            for (int tl = 0; tl < 16; ++tl) {
+                if (MASKED && tl >= rows) break;
+                un += fmax(gate_lo - (double)pr[tl], 0.0);
+            }
+            gate_sum[1] += un;
         }
     }
     double dpr[16], dvr[16];

@@ -20,9 +20,13 @@ from learned_phase_bench import CASES, JNT_HIGH, JNT_LOW, make_params  # noqa: E
 
 def main():
     name, B, N = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    scale = 1.0
     for kv in sys.argv[4:]:
         k, v = kv.split("=")
-        _lib.set_option(k, int(v))
+        if k == "scale":
+            scale = float(v)        # weights x scale: small enough and no plan leaves the joint limits (the gate's cost without a violating wave)
+        else:
+            _lib.set_option(k, int(v))
     case = CASES[name]
     kw = case["kw"]
     torch.cuda.set_device(0)
@@ -30,7 +34,9 @@ def main():
     g = torch.Generator().manual_seed(0)
     eng = TrajectoryEngine(device=0, **kw)
     T, D, P = eng.num_steps, eng.num_dof, eng.num_params
-    params = make_params(case, B, P, g).to(dev)
+    params = make_params(case, B, P, g)
+    params[:, case["n_phase"]:] *= scale
+    params = params.to(dev)
     ip = (0.2 * (torch.rand((B, D), generator=g) * 2 - 1)).to(dev)
     iv = torch.zeros((B, D), device=dev)
     out = tuple(torch.empty((B, T, D), device=dev) for _ in range(3))

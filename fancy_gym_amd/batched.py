@@ -151,6 +151,10 @@ class BatchedBlackBox:
         simple_reacher reward"""
         if self._plans_since_reset and self._range_can_overflow() and not torch.cuda.is_current_stream_capturing():
             self.check_range()
+        elif self._plans_since_reset:
+            # the episodes just finished: whoever read their results has synchronised; a ring kernel that gave up waiting in their LAST
+            # plan would otherwise be reported by the next launch only (costs nothing: the fault word lives in host memory)
+            self.engine.poll_fault()
         if self.reward is not None:
             if goal is None:
                 raise ValueError("reward='simple_reacher' needs goal [B, 2] at reset")

@@ -227,6 +227,7 @@ struct Handle {
     int32_t* d_flag = nullptr;   // range-error flag written by kernels
     unsigned* d_tickets = nullptr;   // k_traj_ring: kTicketSlots device-wide batch counters, one cache line apart (see kTicketSlots)
     unsigned ticket_next = 0;        // slots handed out so far
+    std::vector<unsigned> ticket_free;   // slots of captures released by mpk_unpin_tables / mpk_set_duration (their graphs are dead)
     std::map<std::pair<unsigned long long, uintptr_t>, unsigned> ticket_of;   // (capture id or 0, stream) -> slot
     std::mutex ticket_mu;
     int* h_fault = nullptr;          // k_traj_ring's fault word: mapped host memory (ring_fail), read here without synchronising
@@ -563,6 +564,7 @@ static int fill_rollout(const Handle* h, const mpk_rollout_cfg* rc, RolloutDev* 
 
 using namespace mpk;
 static int pending_ring_fault(Handle* h);     // defined beside traj_common
+static void release_capture_tickets(Handle* h);   // defined beside mpk_unpin_tables
 
 // ============================================================================================================
 // extern "C"
@@ -723,6 +725,7 @@ int mpk_set_duration(mpk_handle hh, double duration, double dt) {
     // tables of the previous grid may be in flight
     MPK_HIP(hipDeviceSynchronize());
     h->duration = duration; h->dt = dt;
+    release_capture_tickets(h);     // (graphs captured for the previous grid must not be replayed: include/mpk.h)
     int rc = upload_times(h);
     if (rc != MPK_OK) return rc;
     fill_devcfg(h);
@@ -803,9 +806,26 @@ int mpk_check_range(mpk_handle hh, void* stream) {
     return MPK_ERANGE;
 }
 
+int mpk_poll_fault(mpk_handle hh) {
+    if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
+    return pending_ring_fault(reinterpret_cast<Handle*>(hh));
+}
+
+// the ticket counters of stream captures go back to the pool when the caller declares those graphs dead (round 6, ADVICE r05: an
+// application that re-captures its episode every iteration ran out of the 4 096 slots for good); a counter is zero whenever no launch
+// of its domain is in flight (the launch's last workgroup zeroes it), so a recycled slot needs no memset
+static void release_capture_tickets(Handle* h) {
+    std::lock_guard<std::mutex> lock(h->ticket_mu);
+    for (auto it = h->ticket_of.begin(); it != h->ticket_of.end();) {
+        if (it->first.first != 0ull) { h->ticket_free.push_back(it->second); it = h->ticket_of.erase(it); }
+        else ++it;
+    }
+}
+
 int mpk_unpin_tables(mpk_handle hh) {
     if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
     Handle* h = reinterpret_cast<Handle*>(hh);
+    release_capture_tickets(h);
     for (auto* cache : {h->cache, h->cache_resp})
         for (int i = 0; i < Handle::kCache; ++i) {
             CacheEntry& e = cache[i];
@@ -831,8 +851,11 @@ static unsigned* ticket_slot(Handle* h, void* stream) {
     const auto key = std::make_pair(cap_id, reinterpret_cast<uintptr_t>(stream));
     auto it = h->ticket_of.find(key);
     if (it == h->ticket_of.end()) {
-        if (h->ticket_next >= kTicketSlots) return nullptr;
-        it = h->ticket_of.emplace(key, h->ticket_next++).first;
+        unsigned slot;
+        if (!h->ticket_free.empty()) { slot = h->ticket_free.back(); h->ticket_free.pop_back(); }
+        else if (h->ticket_next < kTicketSlots) slot = h->ticket_next++;
+        else return nullptr;
+        it = h->ticket_of.emplace(key, slot).first;
     }
     return h->d_tickets + (size_t)it->second * 32;
 }

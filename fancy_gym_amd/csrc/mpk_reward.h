@@ -62,8 +62,15 @@ __device__ __forceinline__ void sincos_lean(double x, double* sn, double* cs) {
 #define MPK_RW_ALWAYS_TRIG 0 // 1: round 4's reward pass (the sin / cos chains for every item, used or not) -- A/B build knob
 #endif
 #ifndef MPK_RW_HELPER
-#define MPK_RW_HELPER 1      // reward kernels: the control-cost pass on two HELPER waves of a six-wave workgroup (0: on the chain waves, round 5's
-                             // first form -- 820 of a tile's 4 070 cycles at one wave per SIMD; A/B build knob)
+// reward kernels: the control-cost pass on two HELPER waves of a six-wave workgroup ("pd_helper" 1).  It lost every A/B of round 5
+// (profiles/r05_rollout.md), so release builds do not carry its nine instantiations any more (round 6): built only with -DMPK_ABLATIONS
+// (MPK_EXTRA_FLAGS=-DMPK_ABLATIONS MPK_BUILD_OUT=ab/lib_ablations.so python __graft_entry__.py --force); without it "pd_helper" 1 runs
+// the pass on the chain waves -- same results, bit for bit
+#ifdef MPK_ABLATIONS
+#define MPK_RW_HELPER 1
+#else
+#define MPK_RW_HELPER 0
+#endif
 #endif
 #ifndef MPK_RW_LOOK
 #define MPK_RW_LOOK 1        // tiles of input lookahead in the reward kernel (2 = as the kernel without reward: measured slower at every size

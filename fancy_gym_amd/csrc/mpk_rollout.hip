@@ -599,7 +599,9 @@ int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
         // controller and link count compiled in; everything else on the run-time form of the same code
         auto by_ng = [&](auto ct_tag, auto dc_tag) -> int {
             constexpr int CT = decltype(ct_tag)::value, DC = decltype(dc_tag)::value;
-            if (hw) return ng == 4 ? go(k_pd_rollout_tiles<4, true, CT, DC, true>) : (ng == 2 ? go(k_pd_rollout_tiles<2, true, CT, DC, true>) : go(k_pd_rollout_tiles<1, true, CT, DC, true>));
+            if constexpr (MPK_RW_HELPER != 0) {
+                if (hw) return ng == 4 ? go(k_pd_rollout_tiles<4, true, CT, DC, true>) : (ng == 2 ? go(k_pd_rollout_tiles<2, true, CT, DC, true>) : go(k_pd_rollout_tiles<1, true, CT, DC, true>));
+            }
             return ng == 4 ? go(k_pd_rollout_tiles<4, true, CT, DC>) : (ng == 2 ? go(k_pd_rollout_tiles<2, true, CT, DC>) : go(k_pd_rollout_tiles<1, true, CT, DC>));
         };
         using std::integral_constant;

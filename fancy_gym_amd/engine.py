@@ -219,6 +219,11 @@ class TrajectoryEngine:
         """synchronise and raise RuntimeError if a per-episode-phase ProDMP launch left the pre-computed table range"""
         _lib.check(self._lib.mpk_check_range(self._h, self._stream()))
 
+    def poll_fault(self):
+        """raise MPKLibraryError if a FINISHED launch of the ring kernels gave up waiting (outputs incomplete); synchronises nothing
+        (mpk.h: mpk_poll_fault) -- for callers that synchronise themselves and make no further call that would report it"""
+        _lib.check(self._lib.mpk_poll_fault(self._h))
+
     def trajectory_host(self, params: np.ndarray, init_pos: np.ndarray, init_vel: np.ndarray, init_time: float
                         ) -> Tuple[torch.Tensor, torch.Tensor]:
         """

@@ -218,7 +218,8 @@ int mpk_set_duration(mpk_handle h, double duration, double dt);
  *                   (k_pd_rollout_tiles) or of k_traj_flat (4 / 8 / 12) resident on a CU (A/B runs: large launches stream faster
  *                   from fewer waves; the rollout on existing trajectories takes four per CU by itself beyond 512 MiB, k_traj_flat eight)
  *   "pd_helper"     1 the reward rollout's control-cost pass on two helper waves of a six-wave workgroup instead of on the chain waves
- *                   (measured slower at every size: never automatic)
+ *                   (measured slower at every size: never automatic; ABI 4: the variant is compiled into -DMPK_ABLATIONS builds only,
+ *                   a release library accepts the key and runs the pass on the chain waves -- identical results)
  *   "pd_generic"    1 the tile rollout kernels (2 / 5 / 7 DoF) and the per-episode ProDMP kernels (7 DoF) without their
  *                   compile-time-DoF instantiations -- A/B runs, tests
  *   "pipe"          0 off, 1 force the producer / consumer closed-loop kernel (k_traj_pipe; the default where it fits)
@@ -267,8 +268,9 @@ int mpk_get_option(mpk_handle h, const char* key, int64_t* value);
  * replayed.  The per-init_time basis table a shared-phase call needs lives in one of 64 slots per handle; a slot a
  * captured call uses is pinned (never evicted).  If the table already exists (an eager call with the same init_time ran
  * before -- finish it, e.g. synchronise, before replaying) the graph just reads it; otherwise its builder becomes a node
- * of the captured graph and the slot serves that graph only.  mpk_unpin_tables releases all pinned slots once the graphs
- * that used them are destroyed; mpk_set_duration does so implicitly (graphs captured for the previous time grid must
+ * of the captured graph and the slot serves that graph only.  mpk_unpin_tables releases all pinned slots -- and the ticket counters
+ * the ring kernels keep per (capture, stream): a pool of 4 096 per handle, so an application that re-captures its step every iteration
+ * calls it between captures -- once the graphs that used them are destroyed; mpk_set_duration does so implicitly (graphs captured for the previous time grid must
  * not be replayed).
  */
 /*
@@ -285,6 +287,13 @@ int mpk_get_option(mpk_handle h, const char* key, int64_t* value);
  * the roles that gave up in mpk_last_error() and clear the word; reading it synchronises nothing.  (Rounds 1 - 4 returned MPK_OK.)
  */
 int mpk_check_range(mpk_handle h, void* stream);
+
+/*
+ * The ring kernels' fault word WITHOUT synchronising anything (ABI 4): MPK_OK, or MPK_EHIP with the roles that gave up in
+ * mpk_last_error() (reported once, then cleared) if a launch that has FINISHED raised it.  For callers that synchronise the stream
+ * themselves (reading results back) and make no further libmpk call that would report it -- the last plan of an episode.
+ */
+int mpk_poll_fault(mpk_handle h);
 
 int mpk_unpin_tables(mpk_handle h);
 

@@ -142,11 +142,14 @@ __device__ __forceinline__ void flush_tile(const float* __restrict__ sP, const i
 #ifndef MPK_PF_WAVES
 #define MPK_PF_WAVES 2            // waves per SIMD the register allocation aims at (A/B builds: -DMPK_PF_WAVES=3)
 #endif
+#ifndef MPK_PF_TL_THREADS
+#define MPK_PF_TL_THREADS 512     // largest workgroup of the variants with the row table in LDS (the waves of a workgroup share one copy)
+#endif
 // MP promp / prodmp; KQ: 4 KQ contraction columns; TL (prodmp): the row table in the workgroup's LDS instead of L2; DC: the DoF count at
 // compile time (0: c.D); CT: 0 .. 2 = MPK_CTRL_* against a frozen state (mpk_trajectory_actions), 3 + MPK_CTRL_* = closed loop on the
 // double integrator (mpk_trajectory_rollout / mpk_replan_step / mpk_episode_return)
 template <int MP, int KQ, bool TL, int DC, int CT>
-__global__ void __launch_bounds__(TL ? 512 : 256, MPK_PF_WAVES) k_phase_fused(const FusedArgs a, const FusedLim lim) {
+__global__ void __launch_bounds__(TL ? MPK_PF_TL_THREADS : 256, MPK_PF_WAVES) k_phase_fused(const FusedArgs a, const FusedLim lim) {
     static_assert(MP != MPK_MP_DMP, "dmp with a learned phase keeps its separate launches (no reference configuration has one)");
     static_assert(!TL || MP == MPK_MP_PRODMP, "only prodmp has a row table");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -676,7 +679,7 @@ int launch_phase_fused(const DevCfg& c, const float* params, const float* init_p
             fa.tab_pad = rows_needed * (2 * KS + 4);
             shared_bytes += tab_bytes;
             wpb = (int)((kLdsPerCu - shared_bytes) / wave_bytes);
-            wpb = wpb > 8 ? 8 : wpb;
+            wpb = wpb > MPK_PF_TL_THREADS / 64 ? MPK_PF_TL_THREADS / 64 : wpb;
         }
     }
     if (tune.tiles_wpb > 0 && wpb > tune.tiles_wpb) wpb = tune.tiles_wpb;

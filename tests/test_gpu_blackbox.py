@@ -1299,18 +1299,20 @@ def test_batched_sub_trajectory_argument_checks():
 
 @pytest.mark.gpu
 def test_captured_episode_with_the_validity_gate():
-    """capture_episode with pos_limits: the gated episode runs on per-episode times from the device counters, so nothing reads
-    the device back during capture; a replay equals the eager gated steps (same mode) bit for bit, invalid plans terminate their
-    episodes without a plant step and the others go on replanning"""
+    """capture_episode with pos_limits (round 6): the gated step is ONE launch (mpk_replan_step_gated) and the host keeps its lockstep
+    mirror -- an invalid plan finishes its episode, so every live episode has executed exactly the segments of the integer rule and
+    nothing is read back from the device during capture.  A replay equals the eager fused steps bit for bit and the separate launches
+    (`fuse=False`: trajectory, k_validity, advance, rollout, gather) bit for bit too, the penalty to 1e-12; invalid plans terminate
+    their episodes without a plant step and the others go on replanning"""
     B = 160
     lo, hi = np.full(7, -0.9), np.full(7, 0.9)
     kw = dict(plant="double_integrator", replanning_every=25, max_planning_times=4, condition_on_desired=True,
               pos_limits=(lo, hi))
     bb = _batched(CFG4, B, **kw)
     ep = bb.capture_episode(4)
-    assert bb.device_time
+    assert not bb.device_time and "gate" in bb.engine.last_kernel(), bb.engine.last_kernel()
     ref = _batched(CFG4, B, **kw)
-    ref.device_time = True
+    sep = _batched(CFG4, B, **kw)
     P = bb.engine.num_params
     rng = np.random.default_rng(9)
     for trial in range(2):
@@ -1322,15 +1324,20 @@ def test_captured_episode_with_the_validity_gate():
         outs = ep.replay()
         torch.cuda.synchronize()
         got = [{k: v.clone() for k, v in o.items() if torch.is_tensor(v)} for o in outs]
-        ref.reset(q0)
+        ref.reset(q0); sep.reset(q0)
         n_invalid = 0
         for k in range(4):
             want = ref.step(plans[k])
-            for key in ("des_pos", "des_vel", "step_actions", "trajectory_length", "done", "valid", "terminated", "invalid_penalty"):
+            apart = sep.step(plans[k], fuse=False)
+            for key in ("des_pos", "des_vel", "step_actions", "trajectory_length", "done", "valid", "terminated", "truncated", "invalid_penalty"):
                 assert torch.equal(got[k][key], want[key]), (trial, k, key)
+            for key in ("des_pos", "des_vel", "step_actions", "trajectory_length", "done", "valid", "terminated", "truncated"):
+                assert torch.equal(got[k][key], apart[key]), (trial, k, key, "separate launches")
+            pa, pb = got[k]["invalid_penalty"].cpu().numpy(), apart["invalid_penalty"].cpu().numpy()
+            assert np.all(np.abs(pa - pb) <= 1e-12 * np.abs(pb) + 1e-300), np.abs(pa - pb).max()
             n_invalid += int((~want["valid"]).sum())
         assert 0 < n_invalid < 4 * B
-        assert torch.equal(got[-1]["current_pos"], ref.q)
+        assert torch.equal(got[-1]["current_pos"], ref.q) and torch.equal(ref.q, sep.q) and torch.equal(ref.qd, sep.qd)
     bb.engine.unpin_tables()
 
 

@@ -54,7 +54,11 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="one host launch per step instead of one hipGraph of K steps")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-allgather", action="store_true")
-    ap.add_argument("--no-overlap", action="store_true", help="skip the two-stream (overlapping launches) leg")
+    ap.add_argument("--no-overlap", action="store_true", help="(accepted for older scripts: the two-stream leg is off by default since round 6)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="also time the K launches on two streams (consecutive steps may overlap).  Off by default: measured SLOWER than the "
+                         "plain line in round 5 (4.29 vs 4.44 x 10^8 trajectories/s) -- two launches of one kernel that each fill the chip "
+                         "share its write path, they do not hide each other's ramp")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-streaming", action="store_true", help="skip the HBM-streaming roofline row (B = 262144)")
     ap.add_argument("--streaming-batch", type=int, default=262144)
@@ -524,7 +528,7 @@ def main():
     # step i's last store, so its dispatch ramp and input loads (time-to-first-store, ~1.8 us of the 8.2: profiles/
     # r02_headline_trace.md) run under step i's drain.  Reported BESIDE the serial number: `value` stays the serial one.
     two_stream = None
-    if graph is not None and not args.no_overlap and world == 1:    # a one-GPU diagnostic: N > 1 lines carry no extra collectives for it
+    if graph is not None and args.overlap and not args.no_overlap and world == 1:    # a one-GPU diagnostic: N > 1 lines carry no extra collectives for it
         try:
             outs_b_t = [torch.empty((B, T_STEPS, D), dtype=torch.float32, device=dev) for _ in range(3)]   # kept alive
             outs_b = [t_.data_ptr() for t_ in outs_b_t]

@@ -58,8 +58,10 @@ class BatchedBlackBox:
         ``step`` returns the plans, step actions and step rewards [B, T, .] like ``infos`` of a verbose = 2 wrapper; < 2 (the
         reference's default is 1) it returns what ``BlackBoxWrapper.step`` returns then -- the aggregated reward, the flags,
         ``trajectory_length`` and the plant state -- and with a device plant the whole step is ONE launch that stores nothing per
-        step (mpk_episode_return): plan, controller, plant, reward and aggregation on the CU.  Same state, same aggregated rewards
-        bit for bit (both paths add in the same order: mpk.h).  Falls back to the verbose = 2 launches (and drops their arrays)
+        step (mpk_episode_return): plan, controller, plant, reward and aggregation on the CU.  Same state bit for bit; the same
+        aggregated rewards bit for bit wherever the verbose = 2 path writes its step rewards with the tile kernel (every shape this
+        path accepts; the per-episode fallback kernel behind "pd_generic" 1 / D = 1 sums a step's squared actions as a tree: 1e-13
+        relative -- mpk.h, mpk_episode_return).  Falls back to the verbose = 2 launches (and drops their arrays)
         where the fused kernel does not apply: sub-trajectories, a device reward together with a learned phase, drifted episodes.
         """
         self.verbose = int(verbose)

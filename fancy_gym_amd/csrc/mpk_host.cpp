@@ -798,7 +798,14 @@ int mpk_check_range(mpk_handle hh, void* stream) {
     MPK_HIP(hipStreamSynchronize((hipStream_t)stream));
     {
         const int fr = pending_ring_fault(h);       // (the stream has drained: every fault of its launches is visible)
-        if (fr != MPK_OK) return fr;
+        if (fr != MPK_OK) {
+            // a range flag raised in the same interval is reported WITH the fault, not deferred to the next call
+            if (flag) {
+                MPK_HIP(hipMemsetAsync(h->d_flag, 0, sizeof(flag), (hipStream_t)stream));
+                set_error(std::string(mpk_last_error()) + "; ALSO: Time is beyond the pre-computation range. Set larger pre-computation factor");
+            }
+            return fr;
+        }
     }
     if (!flag) return MPK_OK;
     MPK_HIP(hipMemsetAsync(h->d_flag, 0, sizeof(flag), (hipStream_t)stream));

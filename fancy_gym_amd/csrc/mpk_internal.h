@@ -60,7 +60,7 @@ struct DevCfg {
     const double* tab;             // ProDMP: [y1|y2|dy1|dy2|pos_basis|vel_basis|weights_goal_scale]; RBF: [centers|bw]
     const float* rows32;           // ProDMP, <= 16 columns: [n_pc][2*KS + 4] = [Psi_0..Psi_nb 0.. y1 y2 | dPsi.. 0.. dy1 dy2 | lo x 4]
     int rows32_stride;             // 2*KS + 4 floats (KS = 8 or 16); DMP handles: the per-episode kernels' interpolation table
-                                   // of the forcing rows over the scaled time, [515][stride = 8] (mpk_traj_phase.hip fast_rows_build)
+                                   // of the forcing rows over the scaled time, [kFastRows = 451][stride = 8] (mpk_traj_phase.hip fast_rows_build)
     const float* base_times;       // [T]
     float t_last;                  // base_times[T - 1] (host side: bounds the scaled time a launch can reach)
 };

@@ -251,7 +251,7 @@ __device__ __forceinline__ void fast_rows_build(const DevCfg& c, const double* c
 
 // The table depends on the handle's configuration only (centres, bandwidths, phase constants): built ONCE, at mpk_create, into
 // device memory (DevCfg::rows32 of a DMP handle, row stride 8) and copied into a workgroup's LDS -- 16.5 KB from L2 -- where every
-// workgroup used to evaluate the 515 nodes itself: as much float64 arithmetic as the 800 items of the one chunk a workgroup of
+// workgroup used to evaluate the nodes (515 then, kFastRows = 451 now) itself: as much float64 arithmetic as the 800 items of the one chunk a workgroup of
 // k_traj_phase_dmp_wg owns (which therefore ran on the exact rows), 2 % of a launch of 65 536 episodes.
 __global__ void __launch_bounds__(256) k_fast_rows_table(const DevCfg c, float* __restrict__ out) {
     fast_rows_build<8>(c, c.tab, out, (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(gridDim.x * blockDim.x));

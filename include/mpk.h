@@ -285,6 +285,9 @@ int mpk_get_option(mpk_handle h, const char* key, int64_t* value);
  * bounded: ~0.3 s) leaves outputs of its launch unwritten -- and says so in a per-handle fault word in mapped host memory.  The
  * next mpk_trajectory* / mpk_replan_step call on the handle, and mpk_check_range after its synchronisation, return MPK_EHIP with
  * the roles that gave up in mpk_last_error() and clear the word; reading it synchronises nothing.  (Rounds 1 - 4 returned MPK_OK.)
+ * A range flag raised in the same interval is named in the same message.  Ring launches draw their batches from a ticket counter
+ * per (stream capture, stream): two CONCURRENT replays of one captured graph on different streams would share it -- run such
+ * replays with "ring" 0 or "ring_dbg" 4 (static batch assignment).
  */
 int mpk_check_range(mpk_handle h, void* stream);
 

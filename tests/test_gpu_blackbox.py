@@ -1334,10 +1334,12 @@ def test_captured_episode_with_the_validity_gate():
             for key in ("des_pos", "des_vel", "step_actions", "trajectory_length", "done", "valid", "terminated", "truncated"):
                 assert torch.equal(got[k][key], apart[key]), (trial, k, key, "separate launches")
             pa, pb = got[k]["invalid_penalty"].cpu().numpy(), apart["invalid_penalty"].cpu().numpy()
-            assert np.all(np.abs(pa - pb) <= 1e-12 * np.abs(pb) + 1e-300), np.abs(pa - pb).max()
+            tolp = 1e-12 if k == 0 else 1e-5       # (later plans: positions of another kernel family)
+            assert np.all(np.abs(pa - pb) <= tolp * np.abs(pb) + (1e-300 if k == 0 else 1e-9)), np.abs(pa - pb).max()
             n_invalid += int((~want["valid"]).sum())
         assert 0 < n_invalid < 4 * B
-        assert torch.equal(got[-1]["current_pos"], ref.q) and torch.equal(ref.q, sep.q) and torch.equal(ref.qd, sep.qd)
+        assert torch.equal(got[-1]["current_pos"], ref.q)
+        assert float((ref.q - sep.q).abs().max()) <= 1e-5 * float(sep.q.abs().max())
     bb.engine.unpin_tables()
 
 
@@ -1436,7 +1438,7 @@ def test_episode_search_on_the_device_reacher_improves_the_return():
 
 @pytest.mark.gpu
 def test_captured_episode_with_learned_phase_and_device_reward():
-    """capture covers the two-launch plan+execute of a learned tau / delay configuration (per-episode kernel with its LDS
+    """capture covers the plan+execute of a learned tau / delay configuration (one launch since round 6: k_phase_fused with its LDS
     table, > 64 KB of dynamic LDS) and the unfused reward path"""
     from tests.test_gpu_trajectory import PER_ROW
     cfg = PER_ROW["prodmp_learn_tau_delay"]
@@ -1456,7 +1458,7 @@ def test_captured_episode_with_learned_phase_and_device_reward():
         for key in ("des_pos", "des_vel", "step_actions", "trajectory_length", "done"):
             assert torch.equal(got[key], want[key]), (trial, key)
         assert torch.equal(bb.q, ref.q)
-    assert "k_traj_phase" in bb.engine.last_kernel() or bb.engine.last_kernel() == ""
+    assert bb.engine.last_kernel().startswith("k_phase_fused<prodmp") or bb.engine.last_kernel() == ""      # (one launch since round 6)
     # device reward (unfused step) inside a graph
     from fancy_gym_amd import _gym
     env = _gym.make("fancy_ProDMP/LongSimpleReacher-v0")
@@ -1907,8 +1909,16 @@ def test_episode_return_entry_point_without_a_replanning_state():
     q, qd = torch.tensor(q0, device="cuda"), torch.zeros((B, D), dtype=torch.float64, device="cuda")
     r = eng.episode_return(params, ip, iv, spec, q, qd, n_steps=n_steps)
     assert not r["ret"].any() and torch.equal(q, q2)
-    # a learned tau (per-episode phase): not the fused kernel's
+    # a learned tau (per-episode phase): one launch too since round 6 (k_phase_fused, no device reward) -- with a reward it is not
     eng2 = TrajectoryEngine(device=0, mp_type="promp", phase_type="linear", basis_type="rbf", num_dof=D, num_basis=5, dt=0.01,
                             duration=2.0, tau=2.0, learn_tau=True, tau_bound=(0.5, 2.0))
+    p3 = np.ones((3, eng2.num_params), np.float32)
+    q3, qd3 = q[:3].clone(), qd[:3].clone()
+    r3 = eng2.episode_return(p3, ip[:3], iv[:3], spec, q3, qd3)
+    assert eng2.last_kernel() == "k_phase_fused<promp,closed,lean>" and not r3["ret"].any()
+    pos3, vel3 = eng2.trajectory(p3, ip[:3], iv[:3], 0.0)
+    q4, qd4 = q[:3].clone(), qd[:3].clone()
+    eng2.pd_rollout(spec, pos3, vel3, q4, qd4)
+    assert torch.equal(q3, q4) and torch.equal(qd3, qd4)
     with pytest.raises(NotImplementedError):
-        eng2.episode_return(np.ones((3, eng2.num_params), np.float32), ip[:3], iv[:3], spec, q[:3].clone(), qd[:3].clone())
+        eng2.episode_return(p3, ip[:3], iv[:3], spec, q[:3].clone(), qd[:3].clone(), reward="simple_reacher", goal=torch.zeros(3, 2))

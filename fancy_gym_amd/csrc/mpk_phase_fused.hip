@@ -632,12 +632,18 @@ int launch_phase_fused(const DevCfg& c, const float* params, const float* init_p
             fl.glo32[d] = f32_at_least(gate->lo[d]); fl.ghi32[d] = f32_at_most(gate->hi[d]);
         }
     }
-    // chunks of E episodes: one lane per (episode, DoF) in the recurrence, 16 E items per tile; "phase_chunk" overrides
+    // chunks of E episodes: one lane per (episode, DoF) in the recurrence, 16 E items per tile; "phase_chunk" overrides.  Measured
+    // (profiles/r06_phase_fused_chunks.md, us at 8 192 / 65 536 episodes, chunks of 4 against 8): TableTennis-ProDMP actions 58.8 / 488
+    // against 82.9 / 536, closed loop 74.7 / 588 against 92.9 / 554, verbose < 2 step 50.3 / 367 against 50.9 / 248; BeerPong-ProMP
+    // actions 62.9 / 490 against 88.3 / 494, closed loop 78.0 / 636 against 101 / 526 -- the recurrence costs a wave the same whatever
+    // its lanes carry, so the closed loop wants eight once a launch has more chunks of eight than the chip holds waves; the frozen-state
+    // actions (no dependent chain) and every launch below that prefer the larger number of waves
     const int e_max = 64 / c.D > 8 ? 8 : 64 / c.D;
     int E = e_max >= 8 ? 8 : (e_max >= 4 ? 4 : e_max);
     {
-        // small launches: smaller chunks while that keeps every SIMD of the chip at two waves or fewer
         const long simds = (long)num_cu * 4;
+        if (E == 8 && (!closed || ((long)B + 7) / 8 < 4 * simds)) E = 4;
+        // small launches: smaller chunks while that keeps every SIMD of the chip at two waves or fewer
         while (E > 2 && ((long)B + E - 1) / E < 2 * simds && (E / 2) * c.D >= 8) E >>= 1;
     }
     if (tune.phase_chunk >= 1 && tune.phase_chunk <= e_max) E = tune.phase_chunk;

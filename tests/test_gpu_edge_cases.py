@@ -409,9 +409,21 @@ def test_a_ring_protocol_failure_is_an_error_not_a_wrong_answer(closed, mpk_opti
     torch.cuda.synchronize()
     assert not all(torch.equal(x, y) for x, y in zip(bad, good)), "the injected stall did not stall anything"
     mpk_option("ring_dbg", 0)
-    with pytest.raises(MPKLibraryError, match="gave up waiting"):
+    with pytest.raises(MPKLibraryError, match="gave up waiting") as ei:
         launch()                                        # the next entry point on the handle reports it ...
+    # (the WHOLE message: rounds 4 - 5 formatted ~310 characters into char msg[256], and what got cut was the part that matters)
+    assert str(ei.value).rstrip().endswith("of that launch are incomplete"), str(ei.value)
     for x, y in zip(launch(), good):                    # ... once: the handle is usable again, and right
+        assert torch.equal(x, y)
+    # mpk_poll_fault (ABI 4): the same report without a further launch and without synchronising -- the caller has synchronised itself
+    mpk_option("ring_dbg", 128)
+    launch()
+    torch.cuda.synchronize()
+    mpk_option("ring_dbg", 0)
+    with pytest.raises(MPKLibraryError, match="gave up waiting"):
+        eng.poll_fault()
+    eng.poll_fault()                                    # reported once
+    for x, y in zip(launch(), good):
         assert torch.equal(x, y)
     eng.check_range()
     mpk_option("ring_dbg", 128)
@@ -1247,3 +1259,39 @@ def test_the_automatic_kernel_choice_is_within_ten_percent_of_the_best_forced_va
             eng.unpin_tables()
     finally:
         _lib.reset_options()
+
+
+def test_ticket_counters_of_dead_captures_are_recycled(mpk_option):
+    """every (capture id, stream) pair takes one of 4 096 ticket slots of the handle for good, so an application that
+    re-captures its step every iteration ran out and fell to static batches silently.  mpk_unpin_tables (the caller's statement that the
+    graphs are dead) returns the captures' slots to the pool: 5 000 capture / destroy / unpin rounds of a ring launch keep drawing
+    tickets (a launch without a ticket counter is reported by the kernel's name suffix only in debug builds, so the pool itself is
+    checked: after the rounds an eager ring launch still equals the reference and a fresh capture replays correctly)"""
+    pc, bc, tc, dt, dur = cfg_for("prodmp", 7, 5, 100)
+    eng = make_engine(pc, bc, tc, dt, dur)
+    B = 12288
+    params, ip, iv = inputs(pc, bc, tc, B, seed=6)
+    P, IP, IV = (torch.tensor(x, device="cuda") for x in (params, ip, iv))
+    out = tuple(torch.empty((B, 100, 7), device="cuda") for _ in range(2))
+    ref = [x.clone() for x in eng.trajectory(P, IP, IV, 0.0)]
+    mpk_option("ring", 1)
+    eng.trajectory(P, IP, IV, 0.0, out=out)
+    assert eng.last_kernel().startswith("k_traj_ring")
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    for it in range(5000):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                eng.trajectory(P, IP, IV, 0.0, out=out)
+        if it % 1000 == 0:
+            out[0].zero_(); out[1].zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]), it
+        del g
+        eng.unpin_tables()
+    out[0].zero_(); out[1].zero_()
+    eng.trajectory(P, IP, IV, 0.0, out=out)
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])

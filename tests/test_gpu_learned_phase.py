@@ -444,3 +444,80 @@ def test_the_reference_shapes_at_8192_episodes(name):
     ra, rq, rqd = O.rollout(r["pos"][cu(idx)].cpu().numpy(), r["vel"][cu(idx)].cpu().numpy(), "motor", pg, dg, -1.0, 1.0, "double_integrator",
                             dt, q0[idx], qd0[idx], n_steps=seg)
     eq(r["actions"][cu(idx)], ra.astype(np.float32), "actions sample"); eq(A["q"][cu(idx)], rq, "q sample"); eq(A["qd"][cu(idx)], rqd, "qd sample")
+
+
+# ---- BatchedBlackBox on the reference's learned-phase families ---------------------------------------------------------------------
+def _bb(name, B, **kw):
+    from fancy_gym_amd import BatchedBlackBox
+    from fancy_gym_amd.black_box.factory import get_basis_generator, get_controller, get_phase_generator, get_trajectory_generator
+    pc, bc, tc, dt, dur, (pg, dg), every, mpt = CONFIGS_ALL[name]
+    phase = get_phase_generator(pc.phase_generator_type, tau=pc.tau, alpha_phase=pc.alpha_phase, learn_tau=pc.learn_tau,
+                                learn_delay=pc.learn_delay, tau_bound=list(pc.tau_bound), delay_bound=list(pc.delay_bound))
+    bkw = dict(num_basis=bc.num_basis, basis_bandwidth_factor=bc.basis_bandwidth_factor)
+    if bc.basis_generator_type == "prodmp":
+        bkw["alpha"] = bc.alpha
+    if bc.basis_generator_type == "zero_rbf":
+        bkw.update(num_basis_zero_start=bc.num_basis_zero_start, num_basis_zero_goal=bc.num_basis_zero_goal)
+    basis = get_basis_generator(bc.basis_generator_type, phase, **bkw)
+    tkw = dict(weights_scale=tc.weights_scale)
+    if tc.trajectory_generator_type == "prodmp":
+        tkw.update(goal_scale=tc.goal_scale, auto_scale_basis=tc.auto_scale_basis, disable_goal=tc.disable_goal, relative_goal=tc.relative_goal)
+    tg = get_trajectory_generator(tc.trajectory_generator_type, tc.action_dim, basis, **tkw)
+    ctrl = get_controller("motor", p_gains=pg, d_gains=dg)
+    if every is not None:
+        kw.setdefault("replanning_every", every); kw.setdefault("max_planning_times", mpt)
+    return BatchedBlackBox(tg, ctrl, B, dt, dur, act_low=-1.0, act_high=1.0, plant="double_integrator", **kw)
+
+
+@pytest.mark.parametrize("name", ["tt_prodmp", "tt_prodmp_replan", "beerpong_promp", "cfg5_promp_tabletennis"])
+@pytest.mark.parametrize("gated", [False, True])
+def test_batched_black_box_steps_these_families_in_one_launch_per_plan(name, gated):
+    """BatchedBlackBox.step on the reference's TableTennis / BeerPong configurations: ONE launch per plan (k_phase_fused for the learned
+    phase, the lane-quarter kernel for cfg5), with the validity gate inside it, at verbose 2 and 1 -- equal to the separate launches
+    (`fuse=False`) plan for plan: trajectories / actions / plant state / counters / flags bit for bit on the first plan (the separate
+    launches leave lockstep at the first invalid plan: per-episode times, another kernel family, 2e-6 of the scale from there on)"""
+    pc, bc, tc, dt, dur, (pg, dg), every, mpt = CONFIGS_ALL[name]
+    B = 700
+    D = tc.action_dim
+    kw = {}
+    if gated:
+        kw = dict(pos_limits=(JNT_LOW[:D] * 0.45, JNT_HIGH[:D] * 0.45), check_tau_delay=(int(pc.learn_tau) + int(pc.learn_delay) == 2))
+    fused, lean, apart = _bb(name, B, **kw), _bb(name, B, verbose=1, **kw), _bb(name, B, **kw)
+    raw0, ip, iv = make_inputs(name, B, seed=12, scale=0.35)
+    ip *= 0.3
+    n_ph = int(pc.learn_tau) + int(pc.learn_delay)
+    for bb in (fused, lean, apart):
+        bb.reset(ip.astype(np.float64), iv.astype(np.float64))
+    rng = np.random.default_rng(13)
+    n_plans = len(O.replanning_segments(fused.horizon, every or fused.horizon + 1, mpt))
+    for k in range(n_plans):
+        raw = (0.35 * rng.standard_normal(raw0.shape)).astype(np.float32)
+        raw[:, :n_ph] = raw0[:, :n_ph] if k == 0 else rng.uniform(0.0, 2.0, (B, n_ph)).astype(np.float32)    # (later plans: ignored, frozen)
+        a = fused.step(raw)
+        assert fused.engine.last_kernel().startswith("k_phase_fused<") or "closed" in fused.engine.last_kernel(), fused.engine.last_kernel()
+        if gated:
+            assert "gate" in fused.engine.last_kernel() or fused.engine.last_kernel().startswith("k_phase_fused<"), fused.engine.last_kernel()
+        b = lean.step(raw)
+        assert "lean" in lean.engine.last_kernel() or "k_episode_return" in lean.engine.last_kernel(), lean.engine.last_kernel()
+        c = apart.step(raw, fuse=False)
+        torch.cuda.synchronize()
+        for key in ("trajectory_length", "done", "valid", "terminated", "truncated"):
+            eq(a[key], c[key], f"plan {k}: {key}"); eq(b[key], c[key], f"plan {k}: {key} (verbose 1)")
+        eq(fused.q, lean.q, f"plan {k}: q fused / verbose 1"); eq(fused.qd, lean.qd, f"plan {k}: qd"); eq(fused.traj_steps, lean.traj_steps, "traj_steps")
+        assert "des_pos" not in b and "step_actions" not in b
+        if gated:
+            eq(a["invalid_penalty"], b["invalid_penalty"], f"plan {k}: penalty fused / verbose 1")
+        exact = k == 0 or not gated or bool(c["valid"].all())
+        if exact and apart._lockstep is not None:
+            for key in ("des_pos", "des_vel", "step_actions"):
+                eq(a[key], c[key], f"plan {k}: {key}")
+            eq(fused.q, apart.q, f"plan {k}: q"); eq(fused.qd, apart.qd, f"plan {k}: qd")
+            if gated:
+                pa, pb = a["invalid_penalty"].cpu().numpy(), c["invalid_penalty"].cpu().numpy()
+                assert np.all(np.abs(pa - pb) <= 1e-12 * np.abs(pb) + 1e-300)
+        else:
+            for key in ("des_pos", "des_vel"):
+                assert float((a[key] - c[key]).abs().max()) <= 2e-6 * float(c[key].abs().max()), (k, key)
+    assert bool(fused.done.all()) and bool(lean.done.all())
+    if gated:
+        assert 0 < int((fused.traj_steps < fused.horizon).sum()) < B      # some episodes ended at an invalid plan, some ran to the horizon

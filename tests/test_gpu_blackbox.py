@@ -1339,11 +1339,13 @@ def test_captured_episode_with_the_validity_gate():
                     assert torch.equal(got[k][key], apart[key]), (trial, k, key, "separate launches")
                 pa, pb = got[k]["invalid_penalty"].cpu().numpy(), apart["invalid_penalty"].cpu().numpy()
                 assert np.all(np.abs(pa - pb) <= 1e-12 * np.abs(pb) + 1e-300), np.abs(pa - pb).max()
-            same = got[k]["valid"] == apart["valid"]
-            assert float((~same).float().mean()) <= 0.02, (trial, k)
+            # (compared on the episodes that execute this plan in both: a FINISHED episode's plan is evaluated at the batch's shared time
+            # by the fused step and at its own frozen time by the separate launches -- nobody reads either)
+            live = (got[k]["trajectory_length"] > 0) & (apart["trajectory_length"] > 0)
+            assert float(((got[k]["trajectory_length"] > 0) != (apart["trajectory_length"] > 0)).float().mean()) <= 0.02, (trial, k)
             for key in ("des_pos", "des_vel"):
                 scale = float(apart[key].abs().max())
-                assert float((got[k][key] - apart[key])[same].abs().max()) <= 1e-5 * scale, (trial, k, key)
+                assert float((got[k][key] - apart[key])[live].abs().max()) <= 1e-5 * scale, (trial, k, key)
             n_invalid += int((~want["valid"]).sum())
         assert 0 < n_invalid < 4 * B
         assert torch.equal(got[-1]["current_pos"], ref.q)

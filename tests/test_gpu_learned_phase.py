@@ -505,7 +505,10 @@ def test_batched_black_box_steps_these_families_in_one_launch_per_plan(name, gat
             eq(a[key], b[key], f"plan {k}: {key} (verbose 2 / 1)")
             if apart._lockstep is not None or not gated:
                 eq(a[key], c[key], f"plan {k}: {key}")
-            else:       # (per-episode times since an invalid plan: 2e-6 of the scale may flip the verdict of a plan that touches a limit)
+            elif key != "valid":
+                # (per-episode times since an invalid plan: 2e-6 of the scale may flip the verdict of a plan that touches a limit; the
+                # verdict on a FINISHED episode's plan -- evaluated at the batch's shared time here, at its own frozen time there -- is
+                # nobody's business: `valid` is compared where the plan is executed, below)
                 assert float((a[key] != c[key]).float().mean()) <= 0.02, (k, key)
         eq(fused.q, lean.q, f"plan {k}: q fused / verbose 1"); eq(fused.qd, lean.qd, f"plan {k}: qd"); eq(fused.traj_steps, lean.traj_steps, "traj_steps")
         assert "des_pos" not in b and "step_actions" not in b
@@ -520,9 +523,10 @@ def test_batched_black_box_steps_these_families_in_one_launch_per_plan(name, gat
                 pa, pb = a["invalid_penalty"].cpu().numpy(), c["invalid_penalty"].cpu().numpy()
                 assert np.all(np.abs(pa - pb) <= 1e-12 * np.abs(pb) + 1e-300)
         else:
-            same = (a["valid"] == c["valid"]) & (a["trajectory_length"] == c["trajectory_length"])
+            live = (a["trajectory_length"] > 0) & (c["trajectory_length"] > 0)
+            assert bool(a["valid"][live].all()) and bool(c["valid"][live].all())
             for key in ("des_pos", "des_vel"):
-                assert float((a[key] - c[key])[same].abs().max()) <= 1e-5 * float(c[key].abs().max()), (k, key)
+                assert float((a[key] - c[key])[live].abs().max()) <= 1e-5 * float(c[key].abs().max()), (k, key)
     assert bool(fused.done.all()) and bool(lean.done.all())
     if gated:
         assert 0 < int((fused.traj_steps < fused.horizon).sum()) < B      # some episodes ended at an invalid plan, some ran to the horizon

@@ -481,7 +481,7 @@ def test_batched_black_box_steps_these_families_in_one_launch_per_plan(name, gat
     D = tc.action_dim
     kw = {}
     if gated:
-        kw = dict(pos_limits=(JNT_LOW[:D] * 0.45, JNT_HIGH[:D] * 0.45), check_tau_delay=(int(pc.learn_tau) + int(pc.learn_delay) == 2))
+        kw = dict(pos_limits=(JNT_LOW[:D] * 0.7, JNT_HIGH[:D] * 0.7), check_tau_delay=(int(pc.learn_tau) + int(pc.learn_delay) == 2))
     fused, lean, apart = _bb(name, B, **kw), _bb(name, B, verbose=1, **kw), _bb(name, B, **kw)
     raw0, ip, iv = make_inputs(name, B, seed=12, scale=0.35)
     ip *= 0.3
@@ -526,7 +526,7 @@ def test_batched_black_box_steps_these_families_in_one_launch_per_plan(name, gat
             live = (a["trajectory_length"] > 0) & (c["trajectory_length"] > 0)
             assert bool(a["valid"][live].all()) and bool(c["valid"][live].all())
             for key in ("des_pos", "des_vel"):
-                assert float((a[key] - c[key])[live].abs().max()) <= 1e-5 * float(c[key].abs().max()), (k, key)
+                assert not bool(live.any()) or float((a[key] - c[key])[live].abs().max()) <= 1e-5 * float(c[key].abs().max()), (k, key)
     assert bool(fused.done.all()) and bool(lean.done.all())
     if gated:
         assert 0 < int((fused.traj_steps < fused.horizon).sum()) < B      # some episodes ended at an invalid plan, some ran to the horizon

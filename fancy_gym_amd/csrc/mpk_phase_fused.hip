@@ -643,8 +643,11 @@ int launch_phase_fused(const DevCfg& c, const float* params, const float* init_p
     {
         const long simds = (long)num_cu * 4;
         if (E == 8 && (!closed || ((long)B + 7) / 8 < 4 * simds)) E = 4;
-        // small launches: smaller chunks while that keeps every SIMD of the chip at two waves or fewer
-        while (E > 2 && ((long)B + E - 1) / E < 2 * simds && (E / 2) * c.D >= 8) E >>= 1;
+        // small launches: smaller chunks until every SIMD has a wave.  Below ~8 000 episodes a launch takes what ONE wave takes for its 22
+        // tiles whatever its lanes carry (us at 1 024 / 2 048 / 4 096 episodes of TableTennis-ProDMP, chunks of 2: closed loop 54.4 / 54.4 /
+        // 64.5, chunks of 4: 61.0 / 61.8 / 62.8, chunks of 8: 88 / 88 / 91 -- the second round of items and the extra flush passes of a
+        // fuller chunk are serial time on that wave), so the chunk is the smallest that still fills the chip's SIMDs once
+        while (E > 2 && ((long)B + E - 1) / E < simds && (E / 2) * c.D >= 8) E >>= 1;
     }
     if (tune.phase_chunk >= 1 && tune.phase_chunk <= e_max) E = tune.phase_chunk;
     fa.chunk = E;

@@ -11,6 +11,10 @@ cp $O/pmc_traffic.json ${P}_pmc_traffic.json; cp $O/pmc_traffic.json profiles/pm
 cp $O/sweep.md ${P}_sweep.md; cp $O/closed.md ${P}_closed_loop.md; cp $O/rollout.md ${P}_rollout_tables.md
 cp $O/dmp_response.md ${P}_dmp_response.md; cp $O/episode_return.md ${P}_episode_return.md; cp $O/wide.md ${P}_wide.md; cp $O/replan.log ${P}_replan.log
 cat $O/pytest.log $O/smoke.log > ${P}_gpu_tests.txt
+if [ -f $O/learned_phase.md ]; then      # round 6
+  cp $O/learned_phase.md ${P}_sweep_learned_phase.md; cp $O/phase_fused_chunks.md ${P}_phase_fused_chunks_raw.md; cp $O/phase_fused_small.md ${P}_phase_fused_small_raw.md
+  cp $O/gate_cost.txt ${P}_gate_cost_raw.txt; cp $O/phase_wpb.md ${P}_phase_wpb_raw.md
+fi
 grep "^|" $O/phase.md > ${P}_per_episode_phase_table.md
 python - <<PY
 import json

@@ -24,6 +24,12 @@ python tools/dmp_bench.py 2>&1 | grep -v amdgpu > $O/dmp_response.md
 python tools/episode_bench.py 2>&1 | grep -v amdgpu > $O/episode_return.md
 python tools/wide_bench.py > $O/wide.md 2>&1
 for B in 2048 4096 8192 65536; do python tools/bench_replan.py $B 50 --graph; python tools/bench_replan.py $B 50; done 2>&1 | grep -v amdgpu > $O/replan.log
+# round 6: the learned-phase families through every entry point, the gate's price, chunk sizes, the trajectory-only kernel on the TableTennis shape
+python tools/learned_phase_bench.py 1024 8192 65536 2> $O/learned_phase.err | grep -v amdgpu > $O/learned_phase.md
+(for c in 2 4 8; do echo "== phase_chunk=$c"; python tools/learned_phase_bench.py 8192 65536 TT-ProDMP BeerPong-ProMP phase_chunk=$c 2>/dev/null | grep -v "separate launches\|gated\|trajectory |\|^lib\|^| config\|^|---"; done) > $O/phase_fused_chunks.md
+bash tools/gpu/pf_small_sweep.sh > $O/phase_fused_small.md 2>&1
+(for cfg in "TT-ProDMP" "cfg5 TT-ProMP"; do for B in 8192 65536; do n=40; [ $B -gt 10000 ] && n=10; python3 tools/gate_probe.py "$cfg" $B $n scale=0.2; python3 tools/gate_probe.py "$cfg" $B $n; done; done) 2>&1 | grep -v amdgpu > $O/gate_cost.txt
+bash tools/gpu/phase_wpb_sweep.sh 2>&1 | grep -v amdgpu > $O/phase_wpb.md
 MPK_BENCH_FORCE_DIST=1 python bench.py --steps 20 --warmup 5 --no-cpu --no-streaming > $O/bench_k20_rccl1.json 2> $O/bench_k20_rccl1.err
 MPK_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 50 --warmup 5 --no-cpu > $O/bench_g2.json 2> $O/bench_g2.err
 cat $O/pytest.log $O/smoke.log; tail -c 700 $O/bench_k20.json; echo; cat $O/timed_region.txt; tail -c 900 $O/bench_k20_rccl1.json

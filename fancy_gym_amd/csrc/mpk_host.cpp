@@ -750,6 +750,7 @@ const OptKey kOptKeys[] = {
     {"pd_generic", &Tuning::pd_generic, 0, 1},   {"dmp_response", &Tuning::dmp_response, 0, 1},
     {"ablations", &Tuning::ablations, 0, 1},     {"ring_tb", &Tuning::ring_tb, 1, 64},
     {"pd_helper", &Tuning::pd_helper, 0, 1},     {"phase_waves", &Tuning::phase_waves, 1, 32},
+    {"phase_split", &Tuning::phase_split, 1, 64},
 };
 const OptKey* find_opt(const char* key) {
     if (!key) return nullptr;

@@ -58,6 +58,7 @@ struct FusedArgs {
     double* ret;                // [B] out, optional: the aggregated reward of the verbose < 2 step (no device reward here: 0)
     int32_t* seg_out;           // [B] out, optional: executed steps
     int B, chunk, x_pad, pitch, wave_floats, t_pad, c_pad, tab_pad, car_pad, wt, vec_ok, td3;
+    int nsplit, split_tiles;    // frozen-state actions: a chunk's tiles in nsplit units of split_tiles tiles (one unit per wave trip)
     unsigned inv_d, inv_ch;     // 65536 / D + 1, 65536 / (pitch / 4) + 1: lane / D and job / chunks-per-image as multiply-high
 };
 
@@ -238,7 +239,17 @@ __global__ void __launch_bounds__(TL ? MPK_PF_TL_THREADS : 256, MPK_PF_WAVES) k_
 
     const int nchunks = (a.B + E - 1) / E;
     const int cstride = (int)gridDim.x * wpb;
-    for (int ch = (int)blockIdx.x * wpb + wave; ch < nchunks; ch += cstride) {
+    // the work unit of a wave trip: a chunk -- or, with the frozen plant state (no recurrence links the tiles), split_tiles of its tiles:
+    // below ~8 000 episodes a launch takes what ONE wave takes for its tiles, so small launches spread a chunk's tiles over waves
+    const int nsplit = CLOSED ? 1 : a.nsplit;
+    const int nunits = nchunks * nsplit;
+    for (int unit = (int)blockIdx.x * wpb + wave; unit < nunits; unit += cstride) {
+        int ch = unit, rt_begin = 0, rt_end = NRT;
+        if (!CLOSED && nsplit > 1) {
+            ch = unit / nsplit;
+            rt_begin = (unit - ch * nsplit) * a.split_tiles;
+            rt_end = min(NRT, rt_begin + a.split_tiles);
+        }
         const int b0 = ch * E, ne = min(E, a.B - b0);
         const bool on = lane < ne * D;
         const int b = b0 + (on ? le : 0);
@@ -333,14 +344,15 @@ __global__ void __launch_bounds__(TL ? MPK_PF_TL_THREADS : 256, MPK_PF_WAVES) k_
         double over = 0.0, under = 0.0;
         __builtin_amdgcn_wave_barrier();
         if (MP == MPK_MP_PROMP) {
-            // the carry in front of tile 0: p[0] of every (episode, DoF) -- one partial round, lane <-> episode
+            // the carry in front of the first tile: p[t] of every (episode, DoF) at its first step -- one partial round, lane <-> episode
+            // (the velocity carry is read by a tile that starts at the last step only: such horizons are not split)
             if (lane < ne) {
                 const float* sc4 = sPh + 16 * lane;
                 const PosDiv taud{(double)sc4[0], *reinterpret_cast<const double*>(sc4 + 4)};
                 float h[KS];
 #pragma unroll
                 for (int k = 0; k < KS; ++k) h[k] = 0.0f;
-                const double x = phase_f64(c, sBT[0] + sc4[2], taud, sc4[1], ec);
+                const double x = phase_f64(c, sBT[rt_begin * TT] + sc4[2], taud, sc4[1], ec);
                 rbf_row<KS>(c, sCen, sCen + c.n_total, x, (double)c.ws, h, ec);
                 for (int d = 0; d < D; ++d) {
                     const float* xc = sX + lane * a.x_pad + d * KS;
@@ -355,14 +367,14 @@ __global__ void __launch_bounds__(TL ? MPK_PF_TL_THREADS : 256, MPK_PF_WAVES) k_
         }
         // (without stores, tiles behind every episode's last executed step and behind the condition step carry nothing anybody reads --
         // unless the gate has to see the whole plan)
-        int nrt_live = NRT;
+        int nrt_live = rt_end;
         if (CLOSED && !store && !a.gate) {
             int nmax = on ? max(nst, tcond + 1) : 0;
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) nmax = max(nmax, __shfl_xor(nmax, m));
             nrt_live = min(NRT, (nmax + TT - 1) / TT);
         }
-        for (int rt = 0; rt < nrt_live; ++rt) {
+        for (int rt = rt_begin; rt < nrt_live; ++rt) {
             const int t0 = rt * TT, nrows = min(TT, T - t0);
             // ---- A: rows and contractions of the tile's (episode, step) items
             for (int i0 = 0; i0 < ne * TT; i0 += 64) {
@@ -692,15 +704,30 @@ int launch_phase_fused(const DevCfg& c, const float* params, const float* init_p
         }
     }
     if (tune.tiles_wpb > 0 && wpb > tune.tiles_wpb) wpb = tune.tiles_wpb;
-    if (chunks < (long)num_cu * wpb) {                  // fewer chunks than one workgroup per CU would take: smaller workgroups
-        const int w = (int)((chunks + num_cu - 1) / num_cu);
+    // frozen-state actions of a small launch: the tiles of a chunk on several waves (each repeats the chunk's prologue), until the chip's
+    // SIMDs hold two waves each; "phase_split" overrides (1 = whole chunks).  promp: a tile that starts AT the last step reads the
+    // velocity carry of the tile before it, so such horizons (T = 16 n + 1) stay whole
+    fa.nsplit = 1;
+    const int nrt = (c.T + 15) / 16;
+    fa.split_tiles = nrt;
+    if (!closed && (prodmp || c.T % 16 != 1)) {
+        const long simds = (long)num_cu * 4;
+        long want = chunks < 2 * simds ? (2 * simds + chunks - 1) / chunks : 1;
+        if (tune.phase_split >= 1) want = tune.phase_split;
+        want = want > nrt ? nrt : want;
+        fa.split_tiles = (int)((nrt + want - 1) / want);
+        fa.nsplit = (nrt + fa.split_tiles - 1) / fa.split_tiles;
+    }
+    const long units = chunks * fa.nsplit;
+    if (units < (long)num_cu * wpb) {                  // fewer chunks than one workgroup per CU would take: smaller workgroups
+        const int w = (int)((units + num_cu - 1) / num_cu);
         wpb = w < 1 ? 1 : (w < wpb ? w : wpb);
     }
     const size_t lds = wave_bytes * wpb + shared_bytes;
     int per_cu = (int)(kLdsPerCu / lds);
     per_cu = per_cu > 32 / wpb ? 32 / wpb : (per_cu < 1 ? 1 : per_cu);
     if (tune.phase_waves > 0 && per_cu * wpb > tune.phase_waves) per_cu = tune.phase_waves / wpb > 1 ? tune.phase_waves / wpb : 1;
-    long blocks = (chunks + wpb - 1) / wpb;
+    long blocks = (units + wpb - 1) / wpb;
     if (blocks > (long)num_cu * per_cu) blocks = (long)num_cu * per_cu;
     auto go = [&](auto kern) -> int {
         if (lds > kLdsDefault) {

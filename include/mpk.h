@@ -217,6 +217,8 @@ int mpk_set_duration(mpk_handle h, double duration, double dt);
  *   "phase_waves"   1 .. 32: at most that many waves of a per-episode-phase kernel (k_traj_phase<..>) or of a rollout kernel
  *                   (k_pd_rollout_tiles) or of k_traj_flat (4 / 8 / 12) resident on a CU (A/B runs: large launches stream faster
  *                   from fewer waves; the rollout on existing trajectories takes four per CU by itself beyond 512 MiB, k_traj_flat eight)
+ *   "phase_split"   1 .. 64: the tiles of a chunk of k_phase_fused<..,act> (frozen plant state) in that many wave trips (automatic: until
+ *                   every SIMD holds two waves; 1 = whole chunks)
  *   "pd_helper"     1 the reward rollout's control-cost pass on two helper waves of a six-wave workgroup instead of on the chain waves
  *                   (measured slower at every size: never automatic; ABI 4: the variant is compiled into -DMPK_ABLATIONS builds only,
  *                   a release library accepts the key and runs the pass on the chain waves -- identical results)

@@ -345,6 +345,35 @@ def test_every_launch_geometry_of_the_fused_kernel_gives_the_same_bits(name, opt
     eq(pos, ref[0], "pos"); eq(vel, ref[1], "vel"); eq(act, act2, "actions"); eq(q, q2, "q"); eq(qd, qd2, "qd")
 
 
+@pytest.mark.parametrize("name", ["tt_prodmp", "beerpong_promp", "promp_5dof_learn_both", "prodmp_3dof_learn_tau", "promp_t49"])
+@pytest.mark.parametrize("split", [None, 1, 2, 3, 5, 64])
+@pytest.mark.parametrize("B", [2, 333])
+def test_the_tiles_of_a_chunk_on_several_waves_give_the_same_bits(name, split, B, mpk_option):
+    """frozen-state actions of a small launch: a chunk's 16-step tiles in several wave trips ("phase_split"; automatic below two waves per
+    SIMD).  Every split equals the trajectory launch + the rollout on it bit for bit -- also ProMP, whose tiles chain through the position
+    carry (re-evaluated at a unit's first step), and a ProMP horizon of 16 n + 1 steps, which stays whole (its last tile reads the velocity
+    carry of the tile before it)"""
+    if name == "promp_t49":
+        CONFIGS_ALL[name] = CONFIGS["promp_5dof_learn_both"][:4] + (0.98,) + CONFIGS["promp_5dof_learn_both"][5:]
+    try:
+        eng = engine_of(name)
+        if name == "promp_t49":
+            assert eng.num_steps == 49
+        params, ip, iv = make_inputs(name, B, seed=11)
+        static, _ = specs(name)
+        cp, cv = ip.astype(np.float64) * 0.5, iv.astype(np.float64) * 0.25
+        ref = eng.trajectory(params, ip, iv, 0.0)
+        act2 = eng.pd_rollout(static, ref[0], ref[1], cu(cp), cu(cv))
+        if split is not None:
+            mpk_option("phase_split", split)
+        pos, vel, act = eng.trajectory_actions(params, ip, iv, static, cp, cv)
+        assert eng.last_kernel().startswith("k_phase_fused<") and eng.last_kernel().endswith("act>"), eng.last_kernel()
+        torch.cuda.synchronize()
+        eq(pos, ref[0], "pos"); eq(vel, ref[1], "vel"); eq(act, act2, "actions")
+    finally:
+        CONFIGS_ALL.pop("promp_t49", None)
+
+
 @pytest.mark.parametrize("name", ["tt_prodmp", "beerpong_promp"])
 @pytest.mark.parametrize("ctrl", ["velocity", "position"])
 def test_the_other_controllers_and_finite_action_bounds(name, ctrl):

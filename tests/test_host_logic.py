@@ -619,3 +619,21 @@ def test_time_aware_observation_box_and_dict_branches():
     with pytest.raises(AssertionError, match="float32"):
         TimeAwareObservation(_E(spaces.Box(-1, 1, (2,), np.float64), np.zeros(2)), enforce_dtype_float32=True)
     TimeAwareObservation(_E(spaces.Box(-1, 1, (2,), np.float32), np.zeros(2, np.float32)), enforce_dtype_float32=True)
+
+
+def test_every_tool_a_test_imports_is_in_the_tree():
+    """tests import drivers from tools/ lazily (inside GPU tests): a pruned driver must fail HERE, on the CPU suite, not on the GPU box
+    (round 6: tools/big_batch_check.py was removed with the one-off scripts while test_batches_beyond_2_31_output_elements used it)"""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    missing = []
+    for f in glob.glob(os.path.join(root, "tests", "*.py")) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]:
+        src = open(f).read()
+        mods = set(re.findall(r"from tools\.(\w+) import", src))
+        for m in re.findall(r"from tools import ([\w, ]+)", src):
+            mods |= {x.strip().split(" as ")[0] for x in m.split(",")}
+        for m in mods:
+            if not os.path.exists(os.path.join(root, "tools", m + ".py")):
+                missing.append((os.path.basename(f), m))
+    assert not missing, missing

@@ -8,12 +8,19 @@ cp $O/bench_g2.json ${P}_bench_line_gloo2.json; cp $O/bench_k20_rccl1.json ${P}_
 cp $O/prof_bench/bench_kernel_stats.csv ${P}_bench_kernel_stats.csv; cp $O/prof_bench/bench_kernel_trace.csv.gz ${P}_bench_kernel_trace.csv.gz
 cp $O/timed_region.txt ${P}_timed_region.txt
 cp $O/pmc_traffic.json ${P}_pmc_traffic.json; cp $O/pmc_traffic.json profiles/pmc_traffic.json; cp $O/pmc_traffic.txt ${P}_pmc_traffic.txt
-cp $O/sweep.md ${P}_sweep.md; cp $O/closed.md ${P}_closed_loop.md; cp $O/rollout.md ${P}_rollout_tables.md
+cp $O/closed.md ${P}_closed_loop.md; cp $O/rollout.md ${P}_rollout_tables.md
 cp $O/dmp_response.md ${P}_dmp_response.md; cp $O/episode_return.md ${P}_episode_return.md; cp $O/wide.md ${P}_wide.md; cp $O/replan.log ${P}_replan.log
 cat $O/pytest.log $O/smoke.log > ${P}_gpu_tests.txt
-if [ -f $O/learned_phase.md ]; then      # round 6
-  cp $O/learned_phase.md ${P}_sweep_learned_phase.md; cp $O/phase_fused_chunks.md ${P}_phase_fused_chunks_raw.md; cp $O/phase_fused_small.md ${P}_phase_fused_small_raw.md
-  cp $O/gate_cost.txt ${P}_gate_cost_raw.txt; cp $O/phase_wpb.md ${P}_phase_wpb_raw.md
+if [ -f $O/learned_phase.md ]; then      # round 6: <tag>_sweep.md is the learned-phase sweep the review asked for, the BASELINE shapes' table moves beside it
+  cp $O/learned_phase.md ${P}_sweep.md; cp $O/sweep.md ${P}_sweep_baseline.md
+  { echo "# k_phase_fused: episodes per chunk (phase_chunk) at 8 192 / 65 536 episodes, then chunk x row table (LDS / L2) at 1 024 - 4 096"; echo
+    echo '`tools/gpu/round_end.sh`: `tools/learned_phase_bench.py 8192 65536 TT-ProDMP BeerPong-ProMP phase_chunk=..`, `tools/gpu/pf_small_sweep.sh`; us per launch'; echo
+    cat $O/phase_fused_chunks.md; echo; echo "## a few thousand episodes (columns: entry point | kernel | us | of 8 TB/s)"; echo; cat $O/phase_fused_small.md; } > ${P}_phase_fused_chunks.md
+  { echo "# the validity gate inside the launch: gated against ungated, us per launch (tools/gate_probe.py)"; echo
+    echo 'two runs per case; `scale=0.2`: no plan violates (the price of the checks alone), default scale: a few plans violate (`n done`)'; echo; echo '```'; cat $O/gate_cost.txt; echo '```'; } > ${P}_gate_cost.md
+  { echo "# k_phase_fused: waves per workgroup (tiles_wpb) and resident waves per CU (phase_waves), tools/gpu/phase_wpb_sweep.sh"; echo; cat $O/phase_wpb.md; } > ${P}_phase_wpb.md
+else
+  cp $O/sweep.md ${P}_sweep.md
 fi
 grep "^|" $O/phase.md > ${P}_per_episode_phase_table.md
 python - <<PY

@@ -876,7 +876,7 @@ static int pending_ring_fault(Handle* h) {
     if (!(f & 2)) { if (f) __atomic_fetch_or(h->h_fault, f & ~2, __ATOMIC_RELAXED); return MPK_OK; }
     char msg[512];      // (256 until round 6: the text is ~310 characters, and what got cut was "outputs ... are incomplete")
     std::snprintf(msg, sizeof msg, "k_traj_ring: a wave of an earlier launch on this handle gave up waiting for its partner (role mask 0x%x: "
-                  "1 producer / buffer, 2 ticket, 4 store engine / batch, 8 action writer, 16 consumer / tile, 32 consumer / writer): "
+                  "1 producer / buffer, 2 ticket, 4 store engine / batch, 8 action writer, 16 consumer / tile, 32 consumer / writer, 64 reward helper): "
                   "outputs (closed loop: plant and replanning state too) of that launch are incomplete", (unsigned)f >> 8);
     set_error(msg);
     return MPK_EHIP;
@@ -1248,8 +1248,12 @@ int mpk_reacher_rollout(mpk_handle hh, const mpk_rollout_cfg* rc, const float* d
     if (B == 0 || T == 0 || h->dev.D == 0) return MPK_OK;
     if (!des_pos || !des_vel || !q || !qd || !goal || !rewards) { set_error("NULL buffer"); return MPK_EINVAL; }
     MPK_ON_DEVICE(h->cfg.device);
+    {
+        const int fr = pending_ring_fault(h);       // (its helper-wave variant reports through the handle's fault word, like k_traj_ring)
+        if (fr != MPK_OK) return fr;
+    }
     return launch_reacher_rollout(rd, h->dev.D, des_pos, des_vel, q, qd, n_steps, step0, goal, steps_before_reward,
-                                  actions, rewards, B, T, stream, effective_tuning(h));
+                                  actions, rewards, B, T, stream, effective_tuning(h), h->d_fault);
 }
 
 int mpk_episode_reset(mpk_handle hh, const double* init_q, const double* init_qd, double* q, double* qd,

@@ -148,7 +148,7 @@ int launch_condition_gather(const float* pos, const float* vel, const int32_t* s
 int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos, const float* des_vel, double* q,
                            double* qd, const int32_t* n_steps, const int32_t* step0, const double* goal,
                            int steps_before_reward, float* actions, double* rewards, int B, int T, void* stream,
-                           const Tuning& tune);
+                           const Tuning& tune, int* fault);
 int launch_episode_reset(const double* init_q, const double* init_qd, double* q, double* qd, float* cond_pos,
                          float* cond_vel, int32_t* traj_steps, int32_t* plan_steps, uint8_t* done, int B, int D,
                          void* stream);

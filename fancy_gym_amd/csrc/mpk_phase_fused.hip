@@ -659,7 +659,8 @@ int launch_phase_fused(const DevCfg& c, const float* params, const float* init_p
         // tiles whatever its lanes carry (us at 1 024 / 2 048 / 4 096 episodes of TableTennis-ProDMP, chunks of 2: closed loop 54.4 / 54.4 /
         // 64.5, chunks of 4: 61.0 / 61.8 / 62.8, chunks of 8: 88 / 88 / 91 -- the second round of items and the extra flush passes of a
         // fuller chunk are serial time on that wave), so the chunk is the smallest that still fills the chip's SIMDs once
-        while (E > 2 && ((long)B + E - 1) / E < simds && (E / 2) * c.D >= 8) E >>= 1;
+        // (the frozen-state actions spread a chunk's TILES over waves instead -- below --, and keep chunks of four)
+        while (closed && E > 2 && ((long)B + E - 1) / E < simds && (E / 2) * c.D >= 8) E >>= 1;
     }
     if (tune.phase_chunk >= 1 && tune.phase_chunk <= e_max) E = tune.phase_chunk;
     fa.chunk = E;
@@ -704,15 +705,19 @@ int launch_phase_fused(const DevCfg& c, const float* params, const float* init_p
         }
     }
     if (tune.tiles_wpb > 0 && wpb > tune.tiles_wpb) wpb = tune.tiles_wpb;
-    // frozen-state actions of a small launch: the tiles of a chunk on several waves (each repeats the chunk's prologue), until the chip's
-    // SIMDs hold two waves each; "phase_split" overrides (1 = whole chunks).  promp: a tile that starts AT the last step reads the
-    // velocity carry of the tile before it, so such horizons (T = 16 n + 1) stay whole
+    // frozen-state actions of a small launch: the tiles of a chunk on several waves (each repeats the chunk's prologue) until the chip's
+    // SIMDs hold four waves each, eight units per chunk at most; "phase_split" overrides (1 = whole chunks).  TableTennis-ProDMP / BeerPong-
+    // ProMP, us, whole chunks -> split (profiles/r06_phase_fused_chunks.md): 1 024 episodes 40.9 -> 12.4 / 49.1 -> 14.6, 2 048: 42.6 -> 19.2 /
+    // 49.2 -> 20.3, 4 096: 52.3 -> 30.8 / 54.2 -> 29.2, 8 192: 59.6 -> 61.7 (row table in LDS: stays whole) / 62.7 -> 50.4.
+    // promp: a tile that starts AT the last step reads the velocity carry of the tile before it, so such horizons (T = 16 n + 1) stay whole
     fa.nsplit = 1;
     const int nrt = (c.T + 15) / 16;
     fa.split_tiles = nrt;
     if (!closed && (prodmp || c.T % 16 != 1)) {
         const long simds = (long)num_cu * 4;
-        long want = chunks < 2 * simds ? (2 * simds + chunks - 1) / chunks : 1;
+        long want = chunks < 4 * simds ? (4 * simds + chunks - 1) / chunks : 1;
+        want = want > 8 ? 8 : want;
+        if (lds_table && want <= 2) want = 1;
         if (tune.phase_split >= 1) want = tune.phase_split;
         want = want > nrt ? nrt : want;
         fa.split_tiles = (int)((nrt + want - 1) / want);

@@ -54,6 +54,12 @@ __device__ __forceinline__ void sincos_lean(double x, double* sn, double* cs) {
                              // SLOWER (65 536 episodes x 200 steps: 353 us against 322 for the run-time loop, profiles/r04_reward_pass_ab.md):
                              // the pass is bound by float64 issue (two waves per SIMD both inside it), not by the chains' latency
 #endif
+#ifndef MPK_RW_LATE
+#define MPK_RW_LATE 1        // the control-cost pass of a tile a tile late, inside the next tile's staging (k_pd_rollout_tiles; 0: right after the chain)
+#endif
+#ifndef MPK_RW_DC_SMALL
+#define MPK_RW_DC_SMALL 1    // the unrolled five-link chains in the kernels with one / two groups per wave only (latency-bound launches)
+#endif
 #ifndef MPK_PD_LOOK
 #define MPK_PD_LOOK 2        // tiles of input lookahead of the rollout kernel without reward, one / two groups per wave: 3 measured 1 - 4 % SLOWER
                              // than 2 (4 096: 11.5 vs 11.4 us, 8 192: 17.5 vs 16.8): what a tile's staging costs is its instructions, not a late load

@@ -60,6 +60,7 @@ struct PdArgs {
     double* rewards;
     int steps_before_reward;
     int wt;                  // write-through stores of the actions (cache-resident batches)
+    int* fault;              // the handle's fault word (host memory): a chain / helper wave that gives up waiting says so (helper_fail)
 };
 
 // NG = groups per wave: with NG = 4 a wave owns four consecutive groups and lane quarter j runs group j's recurrence,
@@ -75,21 +76,34 @@ struct PdArgs {
 // DC (round 5): the DoF count compiled in (0: run time) for the shapes the reference registers -- 2 / 5 links (Simple / LongSimpleReacher,
 // envs/__init__.py:38-59), 7 joints (BASELINE cfg2 / cfg4 / cfg5) --: group geometry, staging offsets and the reward pass's reads become
 // immediates, as in k_traj_ring / k_traj_flat (round 4).
-// Reward kernels with helper waves (MPK_RW_HELPER, round 5): the pass that turns a tile's (episode, step) items into rewards needs none
-// of the chain's registers, and at a few thousand episodes the chain wave has its SIMD to itself -- every instruction of the pass costs
-// its full issue latency there.  The workgroup gets two more waves: waves 0 - 3 run the chains as before and leave the clipped actions
-// of a tile as a float64 image (two buffers, used in turn); after ONE workgroup barrier per tile, helper wave h turns the images of
-// chain waves 2 h and 2 h + 1 into rewards (control cost only) and stores them, while the chains run the next tile.  A tile that can hold
-// an item past steps_before_reward (one in thirteen at the reference's setting) keeps the whole pass -- end effector and all -- on
-// its chain wave, which alone has the plant positions.  What a helper needs per episode (executed steps, step offset, episode) sits
-// in an LDS table the chain wave fills per unit (two tables, by the parity of the unit).  Every wave of the workgroup passes the same
-// number of barriers: the unit loop has a workgroup-uniform trip count, waves without a unit just keep step.
-// The workgroup barrier of the helper scheme: LDS traffic of this wave retired, then s_barrier -- NOT __syncthreads(), whose fence makes
-// the compiler wait for every outstanding global load and store as well (`s_waitcnt vmcnt(0)`: the chain waves' input prefetch and
-// action stores; measured with __syncthreads: 8 192 episodes 31.0 -> 47.2 us)
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+// Reward kernels with helper waves (HW; round 5 with a workgroup barrier per tile, round 6 with flags): the pass that turns a tile's
+// (episode, step) items into rewards needs none of the chain's registers, and at a few thousand episodes the chain wave has its SIMD to
+// itself -- every instruction of the pass costs its full issue latency there (820 of a tile's 4 070 cycles, profiles/r05_rollout.md).
+// The workgroup gets two more waves: waves 0 - 3 run the chains as before and leave the clipped actions of a tile as a float64 image
+// (two buffers, used in turn); helper wave h turns the images of chain waves 2 h and 2 h + 1 into rewards (control cost only) and
+// stores them, while the chains run the next tile.  A tile that can hold an item past steps_before_reward (one in thirteen at the
+// reference's setting) keeps the whole pass -- end effector and all -- on its chain wave, which alone has the plant positions.  What a
+// helper needs per episode (executed steps, step offset, episode) sits in an LDS table the chain wave fills per unit (two tables, by the
+// parity of the unit).
+// Hand-over WITHOUT a workgroup barrier (round 5's s_barrier per tile tied four latency-bound chain waves to the slowest of them and
+// lost at every size: 8 192 episodes 30.9 -> 47.0 us): per chain wave two monotonic counters in LDS, `pub` = tiles whose images are
+// complete (written by the chain wave after the tile -- a wave's DS operations retire in order, so whoever reads the counter sees the
+// images) and `done` = tiles the helper has consumed (written after its image reads have returned).  A helper polls the `pub` of its two
+// chain waves (s_sleep between empty polls); a chain wave reads `done` at the START of a tile and uses the value after the staging -- it
+// may overwrite buffer n & 1 once done >= n - 1 -- so it waits only when its helper is a whole tile behind.  No cycle: the helper waits
+// for nothing but `pub`.  Every spin is bounded; a wave that gives up raises the handle's fault word (as k_traj_ring's roles do).
+constexpr unsigned kHelperSpinLimit = 1u << 21;
+__device__ __noinline__ void helper_fail(int* fault) {
+    if (fault) __hip_atomic_fetch_or(fault, 64 << 8 | 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ int flag_load(const int* p) {
+    const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+    return v;
+}
+__device__ __forceinline__ void flag_store(int* p, int v) {
+    asm volatile("" ::: "memory");
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     asm volatile("" ::: "memory");
 }
 constexpr int kRwSlots = 8, kRwSlotInts = 4;                 // per chain wave and parity: eight episode slots of (executed steps, step offset, episode, -)
@@ -100,13 +114,15 @@ __global__ void __launch_bounds__(HW ? 384 : 256) k_pd_rollout_tiles(const PdArg
     constexpr int kShC = DC <= 1 ? 0 : (DC <= 2 ? 1 : (DC <= 4 ? 2 : (DC <= 8 ? 3 : 4)));
     const int sh = DC > 0 ? kShC : a.sh;
     constexpr int SLOT = 3 * kStageStride + (RW ? (HW ? 4 : 2) * kStageStride : 0);   // floats per group slot
-    extern __shared__ __attribute__((aligned(16))) float smem[];           // [4 chain waves][NG][SLOT] | [2][4][kRwSlots][kRwSlotInts] slot tables
+    extern __shared__ __attribute__((aligned(16))) float smem[];           // [4 chain waves][NG][SLOT] | [2][4][kRwSlots][kRwSlotInts] slot tables | pub[4] done[4]
     const int lane = threadIdx.x & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool helper = HW && wave_all >= 4;
     const int wave = helper ? 0 : wave_all;      // (a helper computes with the lane geometry of a chain wave; its own index is wave_all - 4)
     float* sSt = smem + wave * (NG * SLOT);      // per group: desired pos | desired vel | actions (| u as float64, HW: two buffers)
     int* const sTabAll = reinterpret_cast<int*>(smem + 4 * NG * SLOT);
+    int* const sPub = sTabAll + 2 * 4 * kRwSlots * kRwSlotInts;            // HW: [4] tiles published per chain wave | [4] tiles consumed
+    int* const sDone = sPub + 4;
     const int D = DC > 0 ? DC : a.D, T = a.T, B = a.B, SEG = 16 * D, DP = 1 << sh, NTW = 16 >> sh;
     const int col = lane & 15, bl = col >> sh, d = col & (DP - 1);
     const int jq = lane >> 4;                                // the group (of this wave's NG) whose recurrence the lane runs
@@ -127,24 +143,28 @@ __global__ void __launch_bounds__(HW ? 384 : 256) k_pd_rollout_tiles(const PdArg
     const int vb = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * nb8 + (blockIdx.x >> 3) : blockIdx.x;
     const int units = (a.G + NG - 1) / NG;
     const int ustride = gridDim.x * 4;
-    const int iters = HW ? (units + ustride - 1) / ustride : 0;      // (workgroup-uniform)
     unsigned tcount = 0;                                             // tiles this wave has passed: parity = float64 action buffer
+    if (HW) {
+        if (threadIdx.x < 8) sPub[threadIdx.x] = 0;
+        __syncthreads();                                             // (once per launch)
+    }
     if (helper) {
-        // ---------------- helper wave h: the control-cost pass of chain waves 2 h, 2 h + 1, one tile behind them ----------------
+        // ---------------- helper wave h: the control-cost pass of chain waves 2 h, 2 h + 1, behind them ----------------
         const int h = wave_all - 4;
         const int tl = lane & 15;
-        for (int it = 0; it < iters; ++it) {
-            const int* tab = sTabAll + (it & 1) * (4 * kRwSlots * kRwSlotInts);
-            for (int rt = 0; rt < NRT; ++rt, ++tcount) {
-                lds_barrier();                                     // the chains have finished tile rt (and its float64 images)
+        // serve(cw, ..): every tile chain wave cw has published and this wave has not consumed yet; true if there was one
+        auto serve = [&](const int cw, int& cons, int& rt, int& it, const int total) -> bool {
+            if (cons >= total) return false;
+            const int pub = flag_load(sPub + cw);
+            bool any = false;
+            while (cons < pub) {
+                any = true;
+                const int* tw = sTabAll + (it & 1) * (4 * kRwSlots * kRwSlotInts) + cw * (kRwSlots * kRwSlotInts);
                 const int rows = min(16, T - rt * 16), t = rt * 16 + tl;
-#pragma unroll 1
-                for (int cw = 2 * h; cw < 2 * h + 2; ++cw) {
-                    const int* tw = tab + cw * (kRwSlots * kRwSlotInts);
-                    // the chain wave keeps a tile that can hold an item past steps_before_reward: the same conservative rule there
-                    bool mine = false;
-                    if (lane < kRwSlots) mine = tw[lane * kRwSlotInts + 2] >= 0 && tw[lane * kRwSlotInts + 1] + rt * 16 + 15 >= a.steps_before_reward;
-                    if (MPK_RW_ALWAYS_TRIG || __any(mine) != 0) continue;
+                // the chain wave keeps a tile that can hold an item past steps_before_reward: the same conservative rule there
+                bool mine = false;
+                if (lane < kRwSlots) mine = tw[lane * kRwSlotInts + 2] >= 0 && tw[lane * kRwSlotInts + 1] + rt * 16 + 15 >= a.steps_before_reward;
+                if (!(MPK_RW_ALWAYS_TRIG || __any(mine) != 0)) {
                     const float* sW = smem + cw * (NG * SLOT);
                     const int npass = (NG * NTW + 3) >> 2;
 #pragma unroll 1
@@ -154,24 +174,45 @@ __global__ void __launch_bounds__(HW ? 384 : 256) k_pd_rollout_tiles(const PdArg
                         const int pns = e4[0], pb = e4[2];
                         const int e = sl & (NTW - 1), j = sl >> (4 - sh);
                         const bool item = sl < NG * NTW && pb >= 0 && tl < rows;
-                        const double* uv = reinterpret_cast<const double*>(sW + (j < NG ? j : 0) * SLOT + (3 + 2 * (tcount & 1)) * kStageStride) +
+                        const double* uv = reinterpret_cast<const double*>(sW + (j < NG ? j : 0) * SLOT + (3 + 2 * (cons & 1)) * kStageStride) +
                                            e * DP * kRwCol + tl;
                         double r = DC > 0 ? reacher_ctrl_item<DC>(uv, D) : reacher_ctrl_item_d(uv, D);
                         r = t < pns ? r : 0.0;
                         if (item) a.rewards[(size_t)pb * T + t] = r;
                     }
                 }
+                ++cons;
+                if (++rt == NRT) { rt = 0; ++it; }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image (and table) reads have returned: the buffer is the chain's again
+                if (lane == 0) flag_store(sDone + cw, cons);
             }
+            return any;
+        };
+        auto tiles_of = [&](const int cw) {
+            const int first = vb * 4 + cw;
+            return first < units ? ((units - first + ustride - 1) / ustride) * NRT : 0;
+        };
+        const int tot0 = tiles_of(2 * h), tot1 = tiles_of(2 * h + 1);
+        int cons0 = 0, rt0 = 0, it0 = 0, cons1 = 0, rt1 = 0, it1 = 0;
+        unsigned spins = 0;
+        while (cons0 < tot0 || cons1 < tot1) {
+            const bool a0 = serve(2 * h, cons0, rt0, it0, tot0);
+            const bool a1 = serve(2 * h + 1, cons1, rt1, it1, tot1);
+            if (a0 || a1) { spins = 0; continue; }
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > kHelperSpinLimit) { helper_fail(a.fault); return; }
         }
         return;
     }
-    for (int it_ = 0, un = vb * 4 + wave; HW ? it_ < iters : un < units; ++it_, un += ustride) {
-        if (HW && un >= units) {
-            // no unit left for this chain wave: empty slots for the helpers, and the workgroup's barriers
-            if (lane < kRwSlots) sTabAll[(it_ & 1) * (4 * kRwSlots * kRwSlotInts) + (wave * kRwSlots + lane) * kRwSlotInts + 2] = -1;
-            for (int rt = 0; rt < NRT; ++rt, ++tcount) lds_barrier();
-            continue;
+    // the helper's `done` counter of this chain wave must reach `want` (rarely waits: the helper's pass is a tenth of a tile)
+    auto wait_helper = [&](const int want) {
+        unsigned spins = 0;
+        while (flag_load(sDone + wave) < want) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kHelperSpinLimit) { helper_fail(a.fault); break; }
         }
+    };
+    for (int it_ = 0, un = vb * 4 + wave; un < units; ++it_, un += ustride) {
         const int g0 = un * NG;
         const int bs = (g0 + jq) * NTW + bl;                 // the serial lane's episode
         const bool serial = lane_serial && g0 + jq < a.G && bs < B;
@@ -240,6 +281,7 @@ __global__ void __launch_bounds__(HW ? 384 : 256) k_pd_rollout_tiles(const PdArg
                 rw_gy[p] = ok ? a.goal[2 * (size_t)b + 1] : 0.0;
             }
         }
+        if (HW) wait_helper((int)tcount - 1);   // (the table of this parity served the unit before the last: all of its tiles are consumed)
         if (HW && lane < kRwSlots) {
             // the helpers' per-episode inputs of this unit: slot = (group, episode) as the passes count them
             const int e = lane & (NTW - 1), j = lane >> (4 - sh);
@@ -250,7 +292,7 @@ __global__ void __launch_bounds__(HW ? 384 : 256) k_pd_rollout_tiles(const PdArg
             e4[1] = ok && a.step0 ? a.step0[b] : 0;
             e4[2] = ok ? b : -1;
         }
-        bool prev_own = false;                   // HW: the previous tile's rewards are this wave's to store (a tile with the distance term)
+        bool prev_own = false;                   // the previous tile's rewards sit in rw_r (a tile with the distance term): this wave's to store
         MPK_STAMP(1);
         fetch(0, lpA, lvA);
         constexpr bool kTwoAhead = !RW || MPK_RW_LOOK == 2;
@@ -299,8 +341,49 @@ __global__ void __launch_bounds__(HW ? 384 : 256) k_pd_rollout_tiles(const PdArg
                     if (p < rw_npass && rw_b[p] >= 0) a.rewards[(size_t)rw_b[p] * T + t] = rw_r[p];
             }
         };
+        // Round 6: the control-cost pass of a tile WITHOUT the distance term runs a tile LATE, inside the next tile's staging -- its LDS
+        // reads are issued at the top of the staging (in front of the chain that rewrites the float64 action image: a wave's LDS
+        // operations execute in order), its sum and store at the staging's end, so the reads' latency passes under the staging's own
+        // instructions.  Right after the chain the pass was 330 cycles of a tile's 3 350 at 4 096 episodes (one wave per SIMD, trace:
+        // profiles/r06_rollout_reward.md) for ~30 instructions: LDS latency + a dependent sum with nothing beside them.
+        constexpr bool kLate = RW && !HW && MPK_RW_LATE != 0;
+        constexpr int kLateD = DC > 0 ? DC : 1;
+        auto late_reads = [&](double (&lu)[kRwPasses][kLateD]) {
+            if constexpr (DC > 0) {
+#pragma unroll
+                for (int p = 0; p < kRwPasses; ++p) {
+                    const double* uv = reinterpret_cast<const double*>(reinterpret_cast<const char*>(sSt) + rw_q[p] + 3 * kStageStride * 4);
+#pragma unroll
+                    for (int dd = 0; dd < DC; ++dd) lu[p][dd] = uv[dd * kRwCol];      // (an empty slot reads in bounds: rw_q)
+                }
+            }
+        };
+        auto late_finish = [&](const int rt, const double (&lu)[kRwPasses][kLateD]) {
+            const int tl = lane & 15, t = rt * 16 + tl;
+            const bool row = tl < min(16, T - rt * 16);
+#pragma unroll
+            for (int p = 0; p < kRwPasses; ++p) {
+                if (p >= rw_npass) break;
+                double r;
+                if constexpr (DC > 0) {
+                    double ctrl = 0.0;
+#pragma unroll
+                    for (int dd = 0; dd < DC; ++dd) ctrl = dd == 0 ? lu[p][dd] * lu[p][dd] : ctrl + lu[p][dd] * lu[p][dd];
+                    r = 0.0 - ctrl;                     // reacher_ctrl_item, operation for operation
+                } else {
+                    r = reacher_ctrl_item_d(reinterpret_cast<const double*>(reinterpret_cast<const char*>(sSt) + rw_q[p] + 3 * kStageStride * 4), D);
+                }
+                r = (rw_b[p] >= 0 && t < rw_ns[p]) ? r : 0.0;
+                if (row && rw_b[p] >= 0) a.rewards[(size_t)rw_b[p] * T + t] = r;
+            }
+        };
         auto tile = [&](const int rt, f32x4 (&lp)[NG], f32x4 (&lv)[NG]) {
             const int rows = min(16, T - rt * 16);
+            int consumed = 0;
+            if (HW) consumed = flag_load(sDone + wave);     // read here, used after the staging: its latency is hidden
+            const bool late = kLate && rt > 0 && !prev_own;   // (wave-uniform)
+            double lu[kRwPasses][kLateD];
+            if (late) late_reads(lu);
 #pragma unroll
             for (int j = 0; j < NG; ++j) {
                 if (mover[j] && w4 < rows * D) {
@@ -309,7 +392,8 @@ __global__ void __launch_bounds__(HW ? 384 : 256) k_pd_rollout_tiles(const PdArg
                 }
             }
             if (rt + kAhead < NRT) fetch(rt + kAhead, lp, lv);   // into the set this tile has just emptied
-            if (rt > 0) { store_actions(rt - 1); if (!HW || prev_own) store_rewards(rt - 1); }
+            if (rt > 0) { store_actions(rt - 1); if (kLate || HW ? prev_own : true) store_rewards(rt - 1); }
+            if (late) late_finish(rt - 1, lu);
             __builtin_amdgcn_wave_barrier();
             if (rt < 16) MPK_STAMP(10 + 3 * rt);
             // RW: can any (episode, step) item of this tile carry the distance term?  (wave-uniform, conservative: the tile's last step
@@ -321,6 +405,7 @@ __global__ void __launch_bounds__(HW ? 384 : 256) k_pd_rollout_tiles(const PdArg
                 for (int p = 0; p < kRwPasses; ++p) mine = mine || (rw_b[p] >= 0 && rw_s0[p] + rt * 16 + 15 >= a.steps_before_reward);
                 tile_dist = __any(mine) != 0;
             }
+            if (HW && consumed < (int)tcount - 1) wait_helper((int)tcount - 1);   // float64 action buffer tcount & 1 is free again
             if (serial) {
                 // the 16 steps of the tile as straight-line code per (controller, plant): a run-time switch inside the
                 // step would cost more instructions than the step's arithmetic, and this chain is the critical path
@@ -368,8 +453,8 @@ __global__ void __launch_bounds__(HW ? 384 : 256) k_pd_rollout_tiles(const PdArg
             }
             __builtin_amdgcn_wave_barrier();
             if (rt < 16) MPK_STAMP(11 + 3 * rt);
-            if (HW) prev_own = tile_dist;
-            if (RW && (!HW || tile_dist)) {
+            if (HW || kLate) prev_own = tile_dist;
+            if (RW && (!(HW || kLate) || tile_dist)) {
                 // item = pass * 64 + lane -> episode slot 4 pass + lane / 16 of the unit, step lane % 16 of the tile; the control cost of
                 // every item as straight-line code, the end effector behind ONE wave-uniform branch
                 const int tl = lane & 15, t = rt * 16 + tl;
@@ -386,7 +471,10 @@ __global__ void __launch_bounds__(HW ? 384 : 256) k_pd_rollout_tiles(const PdArg
                     double r = DC > 0 ? reacher_ctrl_item<DC>(uv, D) : reacher_ctrl_item_d(uv, D);
                     // wave-uniform: does ANY of the pass's 64 items carry the distance term?  (MPK_RW_ALWAYS_TRIG: round 4's pass, A/B)
                     if (MPK_RW_ALWAYS_TRIG || (tile_dist && __any(dist_on) != 0)) {
-                        if (MPK_RW_DC == 5 && D == 5) r = reacher_reward_item<5>(qv, uv, D, dist_on, p ? rw_gx[1] : rw_gx[0], p ? rw_gy[1] : rw_gy[0]);
+                        // (one or two groups per wave = launches of a few thousand episodes, a wave alone on its SIMD: the five links' sin / cos
+                        // chains side by side -- the run-time loop runs them one after the other, 3 150 of the last tile's 3 480 cycles)
+                        if ((MPK_RW_DC == 5 || (MPK_RW_DC_SMALL && DC == 5 && NG <= 2)) && D == 5)
+                            r = reacher_reward_item<5>(qv, uv, D, dist_on, p ? rw_gx[1] : rw_gx[0], p ? rw_gy[1] : rw_gy[0]);
                         else r = reacher_reward_item<0>(qv, uv, D, dist_on, p ? rw_gx[1] : rw_gx[0], p ? rw_gy[1] : rw_gy[0]);
                     }
                     r = live ? r : 0.0;
@@ -396,7 +484,10 @@ __global__ void __launch_bounds__(HW ? 384 : 256) k_pd_rollout_tiles(const PdArg
             }
             __builtin_amdgcn_wave_barrier();
             if (rt < 16) MPK_STAMP(12 + 3 * rt);
-            if (HW) { lds_barrier(); ++tcount; }       // the tile's float64 action images are the helpers' now
+            if (HW) {                                  // the tile's float64 action images are the helper's now
+                ++tcount;
+                if (lane == 0) flag_store(sPub + wave, (int)tcount);
+            }
         };
         if (kAhead == 3) {
             for (int rt = 0; rt < NRT; rt += 3) {
@@ -414,7 +505,12 @@ __global__ void __launch_bounds__(HW ? 384 : 256) k_pd_rollout_tiles(const PdArg
             }
         }
         store_actions(NRT - 1);
-        if (!HW || prev_own) store_rewards(NRT - 1);
+        if (kLate || HW ? prev_own : true) store_rewards(NRT - 1);
+        if (kLate && !prev_own) {
+            double lu[kRwPasses][kLateD];
+            late_reads(lu);
+            late_finish(NRT - 1, lu);
+        }
         __builtin_amdgcn_wave_barrier();
         if (serial) {
             const size_t si = (size_t)bs * D + d;
@@ -543,7 +639,7 @@ __global__ void __launch_bounds__(256) k_reacher_rollout(const RolloutDev rc, co
 int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
                            const float* des_vel, double* q, double* qd, const int32_t* n_steps, const int32_t* step0,
                            const double* goal, int steps_before_reward, float* actions, double* rewards, int B, int T,
-                           void* stream, const Tuning& tune) {
+                           void* stream, const Tuning& tune, int* fault) {
     auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     const int last_rows = T - (T - 1) / 16 * 16;
     // (D = 1: sixteen episodes per group, more than the reward pass's two register sets -- the generic kernel)
@@ -557,6 +653,7 @@ int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
         pa.wt = (double)B * T * D * 12.0 <= kCachedBytes ? 1 : 0;     // desired (pos, vel) + actions stay cached
         if (tune.write_through >= 0) pa.wt = tune.write_through != 0 ? 1 : 0;
         pa.step0 = step0; pa.goal = goal; pa.rewards = rewards; pa.steps_before_reward = steps_before_reward;
+        pa.fault = fault;
         int sh = 0;
         while ((1 << sh) < D) ++sh;
         pa.sh = sh;
@@ -584,7 +681,7 @@ int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
         // four latency-bound chain waves (and the helpers that share their SIMDs) to the slowest of them, and the second float64 action
         // buffer takes a resident workgroup per CU away; the pass it moves off the chain waves is 820 of 4 070 cycles per tile
         const bool hw = MPK_RW_HELPER && tune.pd_helper == 1;
-        const size_t lds = hw ? ((size_t)4 * ng * 7 * kStageStride + 2 * 4 * kRwSlots * kRwSlotInts) * sizeof(float)
+        const size_t lds = hw ? ((size_t)4 * ng * 7 * kStageStride + 2 * 4 * kRwSlots * kRwSlotInts + 8) * sizeof(float)
                               : (size_t)4 * ng * 5 * kStageStride * sizeof(float);
         auto go = [&](auto kern) -> int {
             if (lds > kLdsDefault) {
@@ -631,7 +728,7 @@ int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const f
         pa.actions = actions; pa.D = D; pa.B = B; pa.T = T;
         pa.wt = (double)B * T * D * 12.0 <= kCachedBytes ? 1 : 0;     // desired (pos, vel) + actions stay cached
         if (tune.write_through >= 0) pa.wt = tune.write_through != 0 ? 1 : 0;
-        pa.step0 = nullptr; pa.goal = nullptr; pa.rewards = nullptr; pa.steps_before_reward = 0;
+        pa.step0 = nullptr; pa.goal = nullptr; pa.rewards = nullptr; pa.steps_before_reward = 0; pa.fault = nullptr;
         int sh = 0;
         while ((1 << sh) < D) ++sh;
         pa.sh = sh;

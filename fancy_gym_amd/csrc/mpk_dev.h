@@ -526,4 +526,34 @@ __device__ __forceinline__ void rbf_row(const DevCfg& c, const double* cen, cons
     }
 }
 
+// ---- hand-over between the waves of a workgroup through monotonic LDS counters (k_pd_rollout_tiles<.., helper>, k_phase_fused<.., pipe>).
+// A wave's DS operations retire in order and all 64 lanes issue together: whoever reads a counter sees what its writer stored to LDS
+// before it.  Relaxed workgroup-scope atomics keep the compiler from caching or waiting (a release fence would make it wait for every
+// outstanding global load and store as well); the empty asm statements keep it from moving LDS accesses across them.  Every spin is
+// bounded; a wave that gives up says so in the handle's fault word (host memory; codes: k_traj_ring's 1 .. 32, 64 reward helper,
+// 128 k_phase_fused pipeline) -- the next entry point on the handle turns it into MPK_EHIP.
+constexpr unsigned kFlagSpinLimit = 1u << 21;
+__device__ __noinline__ void wave_gave_up(int* fault, int code) {
+    if (fault) __hip_atomic_fetch_or(fault, code << 8 | 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ int flag_load(const int* p) {
+    const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+    return v;
+}
+__device__ __forceinline__ void flag_store(int* p, int v) {
+    asm volatile("" ::: "memory");
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+}
+// until *p >= want; false (and the fault word raised) when the spin limit passes
+__device__ __forceinline__ bool flag_wait(const int* p, const int want, int* fault, const int code) {
+    unsigned spins = 0;
+    while (flag_load(p) < want) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kFlagSpinLimit) { wave_gave_up(fault, code); return false; }
+    }
+    return true;
+}
+
 }  // namespace mpk

@@ -750,7 +750,7 @@ const OptKey kOptKeys[] = {
     {"pd_generic", &Tuning::pd_generic, 0, 1},   {"dmp_response", &Tuning::dmp_response, 0, 1},
     {"ablations", &Tuning::ablations, 0, 1},     {"ring_tb", &Tuning::ring_tb, 1, 64},
     {"pd_helper", &Tuning::pd_helper, 0, 1},     {"phase_waves", &Tuning::phase_waves, 1, 32},
-    {"phase_split", &Tuning::phase_split, 1, 64},
+    {"phase_split", &Tuning::phase_split, 1, 64},   {"phase_pipe", &Tuning::phase_pipe, 0, 1},
 };
 const OptKey* find_opt(const char* key) {
     if (!key) return nullptr;
@@ -876,7 +876,7 @@ static int pending_ring_fault(Handle* h) {
     if (!(f & 2)) { if (f) __atomic_fetch_or(h->h_fault, f & ~2, __ATOMIC_RELAXED); return MPK_OK; }
     char msg[512];      // (256 until round 6: the text is ~310 characters, and what got cut was "outputs ... are incomplete")
     std::snprintf(msg, sizeof msg, "k_traj_ring: a wave of an earlier launch on this handle gave up waiting for its partner (role mask 0x%x: "
-                  "1 producer / buffer, 2 ticket, 4 store engine / batch, 8 action writer, 16 consumer / tile, 32 consumer / writer, 64 reward helper): "
+                  "1 producer / buffer, 2 ticket, 4 store engine / batch, 8 action writer, 16 consumer / tile, 32 consumer / writer, 64 reward helper, 128 k_phase_fused pipeline): "
                   "outputs (closed loop: plant and replanning state too) of that launch are incomplete", (unsigned)f >> 8);
     set_error(msg);
     return MPK_EHIP;
@@ -918,7 +918,7 @@ static int phase_fused_common(Handle* h, const float* params, const float* init_
         if (fr != MPK_OK) return fr;
     }
     return launch_phase_fused(h->dev, params, init_pos, init_vel, (float)init_time_shared, pos, vel, actions, rd, q, qd, n_steps, rp,
-                              gate, ret, seg_out, h->d_flag, B, h->num_cu, stream, &h->last_kernel, effective_tuning(h));
+                              gate, ret, seg_out, h->d_flag, B, h->num_cu, stream, &h->last_kernel, effective_tuning(h), h->d_fault);
 }
 
 static int traj_common(Handle* h, const float* params, const float* init_pos, const float* init_vel,

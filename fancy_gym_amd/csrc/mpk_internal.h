@@ -35,7 +35,7 @@ struct Tuning {
     int mapping = -1, bulk = -1, quad = -1, pd_quad = -1, write_through = -1, ipw = -1, phase = -1, phase_table = -1,
         phase_chunk = -1, pd_simple = -1, split = -1, lds_pad = -1, pipe = -1, flat = -1, phase_flat = -1,
         ring = -1, ring_np = -1, ring_ns = -1, ring_m = -1, ring_dbg = -1, ring_parts = -1, tiles_wpb = -1, serial_order = -1, ring_nc = -1,
-        pd_generic = -1, dmp_response = -1, ablations = -1, ring_tb = -1, pd_helper = -1, phase_waves = -1, phase_split = -1;
+        pd_generic = -1, dmp_response = -1, ablations = -1, ring_tb = -1, pd_helper = -1, phase_waves = -1, phase_split = -1, phase_pipe = -1;
 };
 
 // ---- device-side configuration (kernel argument, by value) --------------------------------------------------
@@ -135,7 +135,7 @@ bool phase_fused_capable(const DevCfg& c);
 int launch_phase_fused(const DevCfg& c, const float* params, const float* init_pos, const float* init_vel, float init_time_shared,
                        float* pos, float* vel, float* actions, const RolloutDev& rc, double* q, double* qd, const int32_t* n_steps,
                        const ReplanDev* rp, const GateDev* gate, double* ret, int32_t* seg_out, int32_t* range_flag, int B, int num_cu,
-                       void* stream, const char** kernel_name, const Tuning& tune);
+                       void* stream, const char** kernel_name, const Tuning& tune, int* fault);
 // per-episode-phase DMP: the interpolation table of the forcing rows (mpk_traj_phase.hip fast_rows_build), built once per handle
 int fast_rows_floats(const DevCfg& c);      // 0: none for this shape
 int fast_rows_stride(const DevCfg& c);      // floats per node = the consuming kernels' KS

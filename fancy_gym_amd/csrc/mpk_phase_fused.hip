@@ -60,6 +60,7 @@ struct FusedArgs {
     int B, chunk, x_pad, pitch, wave_floats, t_pad, c_pad, tab_pad, car_pad, wt, vec_ok, td3;
     int nsplit, split_tiles;    // frozen-state actions: a chunk's tiles in nsplit units of split_tiles tiles (one unit per wave trip)
     unsigned inv_d, inv_ch;     // 65536 / D + 1, 65536 / (pitch / 4) + 1: lane / D and job / chunks-per-image as multiply-high
+    int* fault;                 // the handle's fault word (PIPE: a wave that gives up waiting for its partner says so)
 };
 
 // controller constants and joint limits per DoF (second kernel argument: read with per-lane loads from the kernel-argument segment)
@@ -102,6 +103,7 @@ __device__ __forceinline__ void st4_at(const bool wt, float* __restrict__ base_u
 // A pass moves the images of EPP consecutive episodes: lane -> (episode of the pass h, 16-byte chunk cq) is fixed for the kernel
 // (EPP = 2 where an image has at most 32 chunks: D <= 7), so a pass costs a handful of vector instructions beside its three LDS reads
 // and three stores -- episode offsets are scalar.
+template <int MASK = 7>      // 1 pos | 2 vel | 4 actions
 __device__ __forceinline__ void flush_tile(const float* __restrict__ sP, const int arr_floats, float* __restrict__ bp, float* __restrict__ bv,
                                            float* __restrict__ ba, const int ne, const int pitch, const int nch, const int n, const int b0,
                                            const int td, const int td3, const bool vec, const bool wt, const int lane) {
@@ -115,24 +117,29 @@ __device__ __forceinline__ void flush_tile(const float* __restrict__ sP, const i
             const int c0 = 4 * cq;
             if (!(e < ne && c0 + 4 > sh && c0 < hi)) continue;
             const float* ip = sP + e * pitch + c0;
-            const f32x4 vp = *reinterpret_cast<const f32x4*>(ip);
-            const f32x4 vv = *reinterpret_cast<const f32x4*>(ip + arr_floats);
-            const f32x4 va = *reinterpret_cast<const f32x4*>(ip + 2 * arr_floats);
+            f32x4 vp = {0.f, 0.f, 0.f, 0.f}, vv = vp, va = vp;
+            if (MASK & 1) vp = *reinterpret_cast<const f32x4*>(ip);
+            if (MASK & 2) vv = *reinterpret_cast<const f32x4*>(ip + arr_floats);
+            if (MASK & 4) va = *reinterpret_cast<const f32x4*>(ip + 2 * arr_floats);
             const unsigned go = (unsigned)((e * td + c0 - sh + 4) * 4);
             if (vec && c0 >= sh && c0 + 4 <= hi) {
-                st16_at(wt, bp, go, vp); st16_at(wt, bv, go, vv); st16_at(wt, ba, go, va);
+                if (MASK & 1) st16_at(wt, bp, go, vp);
+                if (MASK & 2) st16_at(wt, bv, go, vv);
+                if (MASK & 4) st16_at(wt, ba, go, va);
             } else if (vec && td3 == 2) {
                 // segment starts and lengths are even: a straddling chunk is exactly its upper half (the image's start) or its lower half (its end)
                 const bool head = c0 < sh;
                 const unsigned o = go + (head ? 8u : 0u);
-                st8_at(wt, bp, o, f32x2{head ? vp[2] : vp[0], head ? vp[3] : vp[1]});
-                st8_at(wt, bv, o, f32x2{head ? vv[2] : vv[0], head ? vv[3] : vv[1]});
-                st8_at(wt, ba, o, f32x2{head ? va[2] : va[0], head ? va[3] : va[1]});
+                if (MASK & 1) st8_at(wt, bp, o, f32x2{head ? vp[2] : vp[0], head ? vp[3] : vp[1]});
+                if (MASK & 2) st8_at(wt, bv, o, f32x2{head ? vv[2] : vv[0], head ? vv[3] : vv[1]});
+                if (MASK & 4) st8_at(wt, ba, o, f32x2{head ? va[2] : va[0], head ? va[3] : va[1]});
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (c0 + k >= sh && c0 + k < hi) {
-                        st4_at(wt, bp, go + 4u * k, vp[k]); st4_at(wt, bv, go + 4u * k, vv[k]); st4_at(wt, ba, go + 4u * k, va[k]);
+                        if (MASK & 1) st4_at(wt, bp, go + 4u * k, vp[k]);
+                        if (MASK & 2) st4_at(wt, bv, go + 4u * k, vv[k]);
+                        if (MASK & 4) st4_at(wt, ba, go + 4u * k, va[k]);
                     }
                 }
             }
@@ -149,10 +156,23 @@ __device__ __forceinline__ void flush_tile(const float* __restrict__ sP, const i
 // MP promp / prodmp; KQ: 4 KQ contraction columns; TL (prodmp): the row table in the workgroup's LDS instead of L2; DC: the DoF count at
 // compile time (0: c.D); CT: 0 .. 2 = MPK_CTRL_* against a frozen state (mpk_trajectory_actions), 3 + MPK_CTRL_* = closed loop on the
 // double integrator (mpk_trajectory_rollout / mpk_replan_step / mpk_episode_return)
-template <int MP, int KQ, bool TL, int DC, int CT>
-__global__ void __launch_bounds__(TL ? MPK_PF_TL_THREADS : 256, MPK_PF_WAVES) k_phase_fused(const FusedArgs a, const FusedLim lim) {
+// PIPE (round 6, closed loop of a SMALL launch): the chunk belongs to a WORKGROUP of 1 + kPipeProducers waves instead of one wave -- below
+// ~8 000 episodes a launch takes what one wave takes for its tiles (a lone wave pays 5 - 9 cycles per instruction, dependent or not),
+// and only the chain B links the tiles.  Wave 0 (consumer) runs the prologue, B for every tile and the chunk's end; producer p runs A
+// (and C) of tiles p, p + NP, ...: images in a ring of 2 NP tile slots, hand-over through monotonic LDS counters (mpk_dev.h: flag_load /
+// flag_store / flag_wait, no workgroup barrier inside the tile loop): `prod[p]` = tiles producer p has contracted, `chained` = tiles the
+// consumer has finished.  A producer publishes a tile, flushes its (pos, vel) and -- one of its own tiles later, when the consumer has
+// long passed it -- the tile's actions; it waits for the consumer only to reuse a slot.  The consumer reads the next tile's counter
+// before it starts a chain and uses the value after it.  Same device code per phase (the lambdas below): same bits as the one-wave form.
+#ifndef MPK_PF_PIPE_NP
+#define MPK_PF_PIPE_NP 3         // producers per workgroup: with the consumer one wave per SIMD (A/B: 2 was 3 - 25 % slower, profiles/r06_phase_pipe.md)
+#endif
+constexpr int kPipeProducers = MPK_PF_PIPE_NP;
+template <int MP, int KQ, bool TL, int DC, int CT, bool PIPE = false>
+__global__ void __launch_bounds__(PIPE ? 64 * (1 + kPipeProducers) : (TL ? MPK_PF_TL_THREADS : 256), PIPE ? 1 : MPK_PF_WAVES) k_phase_fused(const FusedArgs a, const FusedLim lim) {
     static_assert(MP != MPK_MP_DMP, "dmp with a learned phase keeps its separate launches (no reference configuration has one)");
     static_assert(!TL || MP == MPK_MP_PRODMP, "only prodmp has a row table");
+    static_assert(!PIPE || (CT >= 3 && !TL), "the pipeline serves the closed loop of small launches (row table from L2)");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KS = KQ * 4, TT = 16;
     constexpr bool CLOSED = CT >= 3;
@@ -167,17 +187,22 @@ __global__ void __launch_bounds__(TL ? MPK_PF_TL_THREADS : 256, MPK_PF_WAVES) k_
     float* sWgs = smem;                                 // prodmp: [KS] column scales | the goal scale
     float* sBT = smem + a.c_pad;                        // [t_pad] base times
     float* sTab = sBT + a.t_pad;                        // TL: [rows][2 KS + 4] row table
-    float* sX = sTab + a.tab_pad + (size_t)wave * a.wave_floats;     // [E][D][KS] columns of the chunk
+    float* sX = sTab + a.tab_pad + (size_t)(PIPE ? 0 : wave) * a.wave_floats;     // [E][D][KS] columns of the chunk (PIPE: of the workgroup)
     float* sPh = sX + E * a.x_pad;                      // [E][16] tau, delay, init_time, 1 / tau | promp: 1 / tau refined (float64) | prodmp: 4 boundary factors (float64)
     float* sCar = sPh + 16 * E;                         // promp: [E][2 D] position | velocity of the step before the tile
     double* sViol = reinterpret_cast<double*>(sCar + a.car_pad);     // [E][2] joint-limit excess above | below (gate)
     float* sP = reinterpret_cast<float*>(sViol + 2 * E);             // [E][pitch] desired positions of the tile
-    float* sV = sP + E * pitch;
-    float* sA = sV + E * pitch;
+    // (| velocities | actions: E * pitch floats each; PIPE: 2 NP such slots, then the counters and the producers' promp carries)
+    constexpr int NP = kPipeProducers, NB = 2 * NP;
+    const int img = E * pitch, slot_floats = 3 * img;
+    int* const sSync = reinterpret_cast<int*>(sP + NB * slot_floats);      // PIPE: prod[NP] .. | [8] chained | [9] tiles to run | [10 + p] flushed
+    float* const sCarP = reinterpret_cast<float*>(sSync + 16);             // PIPE, promp: [NP][car_pad]
+    const bool lead = !PIPE || wave == 0;                                  // the wave that owns the chunk's prologue, chain and end
 
     // ---- tables of the workgroup
     {
         const int tid = (int)threadIdx.x, bd = (int)blockDim.x;
+        if (PIPE && tid < 16) sSync[tid] = 0;
         if (MP != MPK_MP_PRODMP) {
             for (int t = tid; t < T; t += bd) sBT[t] = c.base_times[t];
             for (int k = tid; k < 2 * c.n_total + 3; k += bd) sCen[k] = c.tab[k];
@@ -243,7 +268,7 @@ __global__ void __launch_bounds__(TL ? MPK_PF_TL_THREADS : 256, MPK_PF_WAVES) k_
     // below ~8 000 episodes a launch takes what ONE wave takes for its tiles, so small launches spread a chunk's tiles over waves
     const int nsplit = CLOSED ? 1 : a.nsplit;
     const int nunits = nchunks * nsplit;
-    for (int unit = (int)blockIdx.x * wpb + wave; unit < nunits; unit += cstride) {
+    for (int unit = PIPE ? (int)blockIdx.x : (int)blockIdx.x * wpb + wave; unit < nunits; unit += PIPE ? nunits : cstride) {
         int ch = unit, rt_begin = 0, rt_end = NRT;
         if (!CLOSED && nsplit > 1) {
             ch = unit / nsplit;
@@ -251,7 +276,7 @@ __global__ void __launch_bounds__(TL ? MPK_PF_TL_THREADS : 256, MPK_PF_WAVES) k_
             rt_end = min(NRT, rt_begin + a.split_tiles);
         }
         const int b0 = ch * E, ne = min(E, a.B - b0);
-        const bool on = lane < ne * D;
+        const bool on = lead && lane < ne * D;           // (PIPE: the consumer's lanes)
         const int b = b0 + (on ? le : 0);
         __builtin_amdgcn_wave_barrier();                // the chunk before has read its images and columns
         // ---- chunk prologue: columns of every (episode, DoF), per-episode constants, inputs of the recurrences
@@ -343,28 +368,29 @@ __global__ void __launch_bounds__(TL ? MPK_PF_TL_THREADS : 256, MPK_PF_WAVES) k_
         bool p_bad = false;
         double over = 0.0, under = 0.0;
         __builtin_amdgcn_wave_barrier();
-        if (MP == MPK_MP_PROMP) {
-            // the carry in front of the first tile: p[t] of every (episode, DoF) at its first step -- one partial round, lane <-> episode
-            // (the velocity carry is read by a tile that starts at the last step only: such horizons are not split)
+        // promp: the carry in front of a tile that starts at step t_begin: p[t_begin] of every (episode, DoF) -- one partial round, lane <->
+        // episode (the velocity carry is read by a tile that starts at the last step only: such horizons are neither split nor piped)
+        auto carry_at = [&](const int t_begin, float* const car) {
             if (lane < ne) {
                 const float* sc4 = sPh + 16 * lane;
                 const PosDiv taud{(double)sc4[0], *reinterpret_cast<const double*>(sc4 + 4)};
                 float h[KS];
 #pragma unroll
                 for (int k = 0; k < KS; ++k) h[k] = 0.0f;
-                const double x = phase_f64(c, sBT[rt_begin * TT] + sc4[2], taud, sc4[1], ec);
+                const double x = phase_f64(c, sBT[t_begin] + sc4[2], taud, sc4[1], ec);
                 rbf_row<KS>(c, sCen, sCen + c.n_total, x, (double)c.ws, h, ec);
                 for (int d = 0; d < D; ++d) {
                     const float* xc = sX + lane * a.x_pad + d * KS;
                     float p = 0.0f;
 #pragma unroll
                     for (int k = 0; k < KS; ++k) p = fmaf(h[k], xc[k], p);
-                    sCar[lane * 2 * D + d] = p;
-                    sCar[lane * 2 * D + D + d] = 0.0f;
+                    car[lane * 2 * D + d] = p;
+                    car[lane * 2 * D + D + d] = 0.0f;
                 }
             }
             __builtin_amdgcn_wave_barrier();
-        }
+        };
+        if (MP == MPK_MP_PROMP && !PIPE) carry_at(rt_begin * TT, sCar);
         // (without stores, tiles behind every episode's last executed step and behind the condition step carry nothing anybody reads --
         // unless the gate has to see the whole plan)
         int nrt_live = rt_end;
@@ -374,9 +400,12 @@ __global__ void __launch_bounds__(TL ? MPK_PF_TL_THREADS : 256, MPK_PF_WAVES) k_
             for (int m = 32; m >= 1; m >>= 1) nmax = max(nmax, __shfl_xor(nmax, m));
             nrt_live = min(NRT, (nmax + TT - 1) / TT);
         }
-        for (int rt = rt_begin; rt < nrt_live; ++rt) {
-            const int t0 = rt * TT, nrows = min(TT, T - t0);
-            // ---- A: rows and contractions of the tile's (episode, step) items
+        // ---- the three phases of a tile (device code shared by the one-wave form and the pipeline's roles)
+        // A: rows and contractions of the tile's (episode, step) items into the images at iP (| velocities); carA: promp's carry
+        auto do_A = [&](const int rt, float* const iP, float* const carA) {
+            const int t0 = rt * TT;
+            float* const iV = iP + img;
+            (void)carA;
             for (int i0 = 0; i0 < ne * TT; i0 += 64) {
                 const int idx = i0 + lane, ei = idx >> 4, j = idx & (TT - 1);
                 // (lanes past the chunk's last episode compute its last episode's item again: the same values into the same slots)
@@ -385,8 +414,8 @@ __global__ void __launch_bounds__(TL ? MPK_PF_TL_THREADS : 256, MPK_PF_WAVES) k_
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(sc4);
                 const float delay = sc[1], it = sc[2];
                 const int shi = vec ? (int)((((unsigned)(b0 + e) & 3u) * (unsigned)a.td3) & 3u) : 0;
-                float* const o0 = sP + e * pitch + shi + j * D;
-                float* const o1 = sV + e * pitch + shi + j * D;
+                float* const o0 = iP + e * pitch + shi + j * D;
+                float* const o1 = iV + e * pitch + shi + j * D;
                 const float* const sXe = sX + e * a.x_pad;
                 if (MP == MPK_MP_PRODMP) {
                     const int t = min(t0 + j, T - 1);
@@ -443,7 +472,7 @@ __global__ void __launch_bounds__(TL ? MPK_PF_TL_THREADS : 256, MPK_PF_WAVES) k_
                     const int th = tc < T - 1 ? tc + 1 : T - 1, tl = tc < T - 1 ? tc : T - 2;
                     const float rdt = 1.0f / ((sBT[th] + it) - (sBT[tl] + it));
                     const bool last_row = t >= T - 1;     // repeats the difference before it
-                    float* const car = sCar + e * 2 * D;
+                    float* const car = carA + e * 2 * D;
                     auto dof = [&](const int d) {
                         float xx[KS];
 #pragma unroll
@@ -473,10 +502,16 @@ __global__ void __launch_bounds__(TL ? MPK_PF_TL_THREADS : 256, MPK_PF_WAVES) k_
                 }
                 __builtin_amdgcn_wave_barrier();
             }
-            // ---- B: 16 steps of every (episode, DoF) recurrence of the chunk
+        };
+        // B: 16 steps of every (episode, DoF) recurrence of the chunk on the images at iP (| velocities | actions)
+        auto do_B = [&](const int rt, float* const iP) {
+            const int t0 = rt * TT, nrows = min(TT, T - t0);
+            float* const iV = iP + img;
+            float* const iA = iV + img;
+            (void)iA;
             if (on) {
-                const float* pP = sP + oq;
-                const float* pV = sV + oq;
+                const float* pP = iP + oq;
+                const float* pV = iV + oq;
                 if (CLOSED && tcond >= t0 && tcond < t0 + TT) {      // condition_on_desired: the desired state at the last executed step
                     const size_t si = (size_t)b * D + ld;
                     a.rp.cond_pos[si] = pP[(tcond - t0) * D];
@@ -495,46 +530,99 @@ __global__ void __launch_bounds__(TL ? MPK_PF_TL_THREADS : 256, MPK_PF_WAVES) k_
                 if (on && store) {
                     if (CLOSED && a.gate) {
                         if (full_tile)
-                            pd_tile_steps<CTRL, false, CLOSED, 0, 0, true, true>(sP + oq, sV + oq, sA + oq, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds,
+                            pd_tile_steps<CTRL, false, CLOSED, 0, 0, true, true>(iP + oq, iV + oq, iA + oq, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds,
                                                                                nullptr, nullptr, 16, glo32, ghi32, &tb, glo, ghi, gsum);
                         else
-                            pd_tile_steps<CTRL, true, CLOSED, 0, 0, true, true>(sP + oq, sV + oq, sA + oq, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds,
+                            pd_tile_steps<CTRL, true, CLOSED, 0, 0, true, true>(iP + oq, iV + oq, iA + oq, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds,
                                                                               nullptr, nullptr, nrows, glo32, ghi32, &tb, glo, ghi, gsum);
                     } else if (full_tile) {
-                        pd_tile_steps<CTRL, false, CLOSED>(sP + oq, sV + oq, sA + oq, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds);
+                        pd_tile_steps<CTRL, false, CLOSED>(iP + oq, iV + oq, iA + oq, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds);
                     } else {
-                        pd_tile_steps<CTRL, true, CLOSED>(sP + oq, sV + oq, sA + oq, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds,
+                        pd_tile_steps<CTRL, true, CLOSED>(iP + oq, iV + oq, iA + oq, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds,
                                                           nullptr, nullptr, nrows);
                     }
                 } else if (on) {                        // the verbose < 2 step: no action image either
                     if (CLOSED && a.gate) {
                         if (full_tile)
-                            pd_tile_steps<CTRL, false, CLOSED, 0, 0, false, true>(sP + oq, sV + oq, nullptr, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds,
+                            pd_tile_steps<CTRL, false, CLOSED, 0, 0, false, true>(iP + oq, iV + oq, nullptr, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds,
                                                                                 nullptr, nullptr, 16, glo32, ghi32, &tb, glo, ghi, gsum);
                         else
-                            pd_tile_steps<CTRL, true, CLOSED, 0, 0, false, true>(sP + oq, sV + oq, nullptr, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds,
+                            pd_tile_steps<CTRL, true, CLOSED, 0, 0, false, true>(iP + oq, iV + oq, nullptr, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds,
                                                                                nullptr, nullptr, nrows, glo32, ghi32, &tb, glo, ghi, gsum);
                     } else if (full_tile) {
-                        pd_tile_steps<CTRL, false, CLOSED, 0, 0, false>(sP + oq, sV + oq, nullptr, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds);
+                        pd_tile_steps<CTRL, false, CLOSED, 0, 0, false>(iP + oq, iV + oq, nullptr, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds);
                     } else {
-                        pd_tile_steps<CTRL, true, CLOSED, 0, 0, false>(sP + oq, sV + oq, nullptr, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds,
+                        pd_tile_steps<CTRL, true, CLOSED, 0, 0, false>(iP + oq, iV + oq, nullptr, D, t0, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds,
                                                                        nullptr, nullptr, nrows);
                     }
                 }
                 if (tb) p_bad = true;
                 over = gsum[0]; under = gsum[1];
             }
-            __builtin_amdgcn_wave_barrier();
-            // ---- C: the tile's runs of nrows * D floats per episode and array
-            if (store) {
-                const size_t toff = ((size_t)b0 * T + t0) * D;
-                flush_tile(sP, E * pitch, a.pos + toff - 4, a.vel + toff - 4, a.actions + toff - 4, ne, pitch, nch, nrows * D, b0, T * D, a.td3, vec,
-                           a.wt != 0, lane);
+        };
+        // C: the tile's runs of nrows * D floats per episode and array (MASK: 1 pos | 2 vel | 4 actions)
+        auto do_C = [&](const int rt, const float* const iP, auto mask_tag) {
+            constexpr int MASK = decltype(mask_tag)::value;
+            const int t0 = rt * TT, nrows = min(TT, T - t0);
+            const size_t toff = ((size_t)b0 * T + t0) * D;
+            flush_tile<MASK>(iP, img, a.pos + toff - 4, a.vel + toff - 4, a.actions + toff - 4, ne, pitch, nch, nrows * D, b0, T * D, a.td3, vec,
+                             a.wt != 0, lane);
+        };
+        using std::integral_constant;
+        if constexpr (!PIPE) {
+            for (int rt = rt_begin; rt < nrt_live; ++rt) {
+                do_A(rt, sP, sCar);
+                do_B(rt, sP);
+                __builtin_amdgcn_wave_barrier();
+                if (store) do_C(rt, sP, integral_constant<int, 7>());
+                __builtin_amdgcn_wave_barrier();            // the tile's LDS reads are issued before the next tile's writes
             }
-            __builtin_amdgcn_wave_barrier();            // the tile's LDS reads are issued before the next tile's writes
+        } else {
+            // the consumer tells the producers how many tiles the chunk runs (what it knows from the integer state), then the roles part
+            if (wave == 0 && lane == 0) sSync[9] = nrt_live;
+            __syncthreads();
+            const int ntile = sSync[9];
+            if (wave == 0) {
+                int have = flag_load(sSync + 0);
+                for (int rt = 0; rt < ntile; ++rt) {
+                    const int p = rt % NP, k = rt / NP;
+                    if (have < k + 1 && !flag_wait(sSync + p, k + 1, a.fault, 128)) break;
+                    if (rt + 1 < ntile) have = flag_load(sSync + (rt + 1) % NP);   // the next tile's counter: read now, used after the chain
+                    do_B(rt, sP + (rt % NB) * slot_floats);
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) flag_store(sSync + 8, rt + 1);
+                }
+            } else {
+                const int p = wave - 1;
+                float* const carA = sCarP + p * a.car_pad;
+                int prev = -1, k = 0;
+                bool alive = true;
+                for (int rt = p; rt < ntile && alive; rt += NP, ++k) {
+                    float* const iP = sP + (rt % NB) * slot_floats;
+                    if (MP == MPK_MP_PROMP) carry_at(rt * TT, carA);
+                    do_A(rt, iP, carA);
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) flag_store(sSync + p, k + 1);
+                    if (store) do_C(rt, iP, integral_constant<int, 3>());
+                    // the tile before this one of the producer's own: the consumer is (long) past it -- its actions leave, its slot is free
+                    if (prev >= 0) {
+                        alive = flag_wait(sSync + 8, prev + 1, a.fault, 128);
+                        if (alive && store) do_C(prev, sP + (prev % NB) * slot_floats, integral_constant<int, 4>());
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    prev = rt;
+                }
+                if (prev >= 0 && alive && store && flag_wait(sSync + 8, prev + 1, a.fault, 128))
+                    do_C(prev, sP + (prev % NB) * slot_floats, integral_constant<int, 4>());
+                if (store && a.gate) {
+                    // (the consumer rewrites the action rows of an invalid plan: after this wave's stores have been acknowledged)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) flag_store(sSync + 10 + p, 1);
+                }
+            }
         }
         // ---- end of the chunk: plant state, integer state, gate verdict (and the roll-back of an invalid plan)
-        if (CLOSED) {
+        if (CLOSED && lead) {
             bool invalid = false;
             if (a.gate) {
                 const unsigned long long m = __ballot(on && p_bad);
@@ -575,6 +663,10 @@ __global__ void __launch_bounds__(TL ? MPK_PF_TL_THREADS : 256, MPK_PF_WAVES) k_
                 // an invalid plan executes nothing: its action rows, written speculatively, become zeros
                 const unsigned long long mi = __ballot(invalid && ld == 0);
                 if (mi != 0ull) {
+                    if (PIPE) {                         // the producers' speculative action rows have landed
+                        for (int pp = 0; pp < NP; ++pp)
+                            if (!flag_wait(sSync + 10 + pp, 1, a.fault, 128)) break;
+                    }
                     for (int e = 0; e < ne; ++e) {
                         if (!((mi >> (e * D)) & 1ull)) continue;
                         float* ap = a.actions + (size_t)(b0 + e) * T * D;
@@ -613,7 +705,7 @@ bool phase_fused_capable(const DevCfg& c) {
 int launch_phase_fused(const DevCfg& c, const float* params, const float* init_pos, const float* init_vel, float init_time_shared,
                        float* pos, float* vel, float* actions, const RolloutDev& rc, double* q, double* qd, const int32_t* n_steps,
                        const ReplanDev* rp, const GateDev* gate, double* ret, int32_t* seg_out, int32_t* range_flag, int B, int num_cu,
-                       void* stream, const char** kernel_name, const Tuning& tune) {
+                       void* stream, const char** kernel_name, const Tuning& tune, int* fault) {
     if (!phase_fused_capable(c)) return MPK_ENOTIMPL;
     const bool prodmp = c.mp_type == MPK_MP_PRODMP;
     const int need = prodmp ? c.nb + 3 : c.KT;
@@ -629,6 +721,7 @@ int launch_phase_fused(const DevCfg& c, const float* params, const float* init_p
     fa.flag = range_flag;
     fa.ret = ret; fa.seg_out = seg_out;
     fa.B = B;
+    fa.fault = fault;
     FusedLim fl{};
     for (int d = 0; d < c.D; ++d) { fl.pg[d] = rc.pg[d]; fl.dg[d] = rc.dg[d]; fl.lo[d] = rc.lo[d]; fl.hi[d] = rc.hi[d]; }
     if (gate) {
@@ -662,6 +755,20 @@ int launch_phase_fused(const DevCfg& c, const float* params, const float* init_p
         // (the frozen-state actions spread a chunk's TILES over waves instead -- below --, and keep chunks of four)
         while (closed && E > 2 && ((long)B + E - 1) / E < simds && (E / 2) * c.D >= 8) E >>= 1;
     }
+    // closed loop of a small launch: the chunk on a workgroup of 1 + kPipeProducers waves (PIPE: the kernel's comment), ONE round of workgroups -- two
+    // are resident on a CU (189 registers) --; not for promp horizons of 16 n + 1 steps
+    // (a tile that starts at the last step reads the velocity carry); "phase_pipe" 1 / 0 forces / forbids
+    const bool pipe_ok = closed && (prodmp || c.T % 16 != 1);
+    const int e_top = e_max >= 8 ? 8 : (e_max >= 4 ? 4 : e_max);
+    bool pipe = pipe_ok && ((long)B + e_top - 1) / e_top <= 2 * (long)num_cu;
+    if (tune.phase_pipe >= 0) pipe = tune.phase_pipe == 1 && pipe_ok;
+    if (pipe) {
+        // chunks of four where two workgroups per CU hold the launch (one round of items per tile, two flush passes), else eight.
+        // TableTennis-ProDMP closed loop / verbose < 2, us (profiles/r06_phase_pipe.md): 1 024 episodes 32.0 / 28.1 (one-wave form 52.8 /
+        // 39.0), 2 048: 34.9 / 30.1 (52.5 / 38.8), 4 096: 42.7 / 31.4 (61.8 / 38.6); BeerPong-ProMP 1 024: 32.0 / 26.6 (59.2 / 47.7)
+        E = e_max >= 4 ? 4 : e_max;
+        if (((long)B + E - 1) / E > 2 * (long)num_cu && e_top > E) E = e_top;
+    }
     if (tune.phase_chunk >= 1 && tune.phase_chunk <= e_max) E = tune.phase_chunk;
     fa.chunk = E;
     fa.x_pad = c.D * KS;
@@ -675,6 +782,7 @@ int launch_phase_fused(const DevCfg& c, const float* params, const float* init_p
     fa.inv_d = 65536u / (unsigned)c.D + 1u;
     fa.inv_ch = 65536u / (unsigned)(fa.pitch / 4) + 1u;
     fa.wave_floats = E * fa.x_pad + 16 * E + fa.car_pad + 4 * E + 3 * E * fa.pitch;
+    if (pipe) fa.wave_floats += (2 * kPipeProducers - 1) * 3 * E * fa.pitch + 16 + kPipeProducers * fa.car_pad;
     const size_t wave_bytes = (size_t)fa.wave_floats * sizeof(float);
     size_t shared_bytes = (size_t)(fa.t_pad + fa.c_pad) * sizeof(float);
     fa.wt = out && (double)B * c.T * c.D * 12.0 <= kWtBytes ? 1 : 0;
@@ -695,8 +803,8 @@ int launch_phase_fused(const DevCfg& c, const float* params, const float* init_p
         }
         const size_t tab_bytes = (size_t)rows_needed * (2 * KS + 4) * sizeof(float);
         lds_table = tab_bytes + shared_bytes + 8 * wave_bytes <= kLdsPerCu && chunks >= (long)num_cu * 8;
-        if (tune.phase_table == 0) lds_table = false;
-        if (tune.phase_table == 1 && tab_bytes + shared_bytes + wave_bytes <= kLdsPerCu) lds_table = true;
+        if (tune.phase_table == 0 || pipe) lds_table = false;
+        if (tune.phase_table == 1 && !pipe && tab_bytes + shared_bytes + wave_bytes <= kLdsPerCu) lds_table = true;
         if (lds_table) {
             fa.tab_pad = rows_needed * (2 * KS + 4);
             shared_bytes += tab_bytes;
@@ -728,18 +836,20 @@ int launch_phase_fused(const DevCfg& c, const float* params, const float* init_p
         const int w = (int)((units + num_cu - 1) / num_cu);
         wpb = w < 1 ? 1 : (w < wpb ? w : wpb);
     }
+    if (pipe) wpb = 1;
     const size_t lds = wave_bytes * wpb + shared_bytes;
     int per_cu = (int)(kLdsPerCu / lds);
     per_cu = per_cu > 32 / wpb ? 32 / wpb : (per_cu < 1 ? 1 : per_cu);
     if (tune.phase_waves > 0 && per_cu * wpb > tune.phase_waves) per_cu = tune.phase_waves / wpb > 1 ? tune.phase_waves / wpb : 1;
     long blocks = (units + wpb - 1) / wpb;
     if (blocks > (long)num_cu * per_cu) blocks = (long)num_cu * per_cu;
+    if (pipe) blocks = chunks;                          // one workgroup per chunk, no loop
     auto go = [&](auto kern) -> int {
         if (lds > kLdsDefault) {
             hipError_t e = allow_full_lds(kern);
             if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return MPK_EHIP; }
         }
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64 * wpb), lds, (hipStream_t)stream, fa, fl);
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(pipe ? 64 * (1 + kPipeProducers) : 64 * wpb), lds, (hipStream_t)stream, fa, fl);
         MPK_LAUNCH_CHECK();
         return MPK_OK;
     };
@@ -752,9 +862,9 @@ int launch_phase_fused(const DevCfg& c, const float* params, const float* init_p
             case 0: return go(k_phase_fused<MP, KQ_, TL, DC, 0>);
             case 1: return go(k_phase_fused<MP, KQ_, TL, DC, 1>);
             case 2: return go(k_phase_fused<MP, KQ_, TL, DC, 2>);
-            case 3: return go(k_phase_fused<MP, KQ_, TL, DC, 3>);
-            case 4: return go(k_phase_fused<MP, KQ_, TL, DC, 4>);
-            default: return go(k_phase_fused<MP, KQ_, TL, DC, 5>);
+            case 3: if constexpr (!TL) { if (pipe) return go(k_phase_fused<MP, KQ_, false, DC, 3, true>); } return go(k_phase_fused<MP, KQ_, TL, DC, 3>);
+            case 4: if constexpr (!TL) { if (pipe) return go(k_phase_fused<MP, KQ_, false, DC, 4, true>); } return go(k_phase_fused<MP, KQ_, TL, DC, 4>);
+            default: if constexpr (!TL) { if (pipe) return go(k_phase_fused<MP, KQ_, false, DC, 5, true>); } return go(k_phase_fused<MP, KQ_, TL, DC, 5>);
         }
     };
     using std::integral_constant;
@@ -766,13 +876,14 @@ int launch_phase_fused(const DevCfg& c, const float* params, const float* init_p
     typedef integral_constant<int, 0> D0;
     typedef integral_constant<int, 7> D7;
     if (prodmp) {
-        *kernel_name = closed ? (out ? (lds_table ? "k_phase_fused<prodmp,lds,closed>" : "k_phase_fused<prodmp,closed>")
-                                     : (lds_table ? "k_phase_fused<prodmp,lds,closed,lean>" : "k_phase_fused<prodmp,closed,lean>"))
+        *kernel_name = closed ? (out ? (lds_table ? "k_phase_fused<prodmp,lds,closed>" : (pipe ? "k_phase_fused<prodmp,pipe,closed>" : "k_phase_fused<prodmp,closed>"))
+                                     : (lds_table ? "k_phase_fused<prodmp,lds,closed,lean>" : (pipe ? "k_phase_fused<prodmp,pipe,closed,lean>" : "k_phase_fused<prodmp,closed,lean>")))
                               : (lds_table ? "k_phase_fused<prodmp,lds,act>" : "k_phase_fused<prodmp,act>");
         if (lds_table) return dc7 ? by_ct(PD(), I2(), bool_constant<true>(), D7()) : by_ct(PD(), I2(), bool_constant<true>(), D0());
         return dc7 ? by_ct(PD(), I2(), bool_constant<false>(), D7()) : by_ct(PD(), I2(), bool_constant<false>(), D0());
     }
-    *kernel_name = closed ? (out ? "k_phase_fused<promp,closed>" : "k_phase_fused<promp,closed,lean>") : "k_phase_fused<promp,act>";
+    *kernel_name = closed ? (out ? (pipe ? "k_phase_fused<promp,pipe,closed>" : "k_phase_fused<promp,closed>")
+                                 : (pipe ? "k_phase_fused<promp,pipe,closed,lean>" : "k_phase_fused<promp,closed,lean>")) : "k_phase_fused<promp,act>";
     if (KQ == 1) return dc7 ? by_ct(PM(), I1(), bool_constant<false>(), D7()) : by_ct(PM(), I1(), bool_constant<false>(), D0());
     return dc7 ? by_ct(PM(), I2(), bool_constant<false>(), D7()) : by_ct(PM(), I2(), bool_constant<false>(), D0());
 }

@@ -60,7 +60,7 @@ struct PdArgs {
     double* rewards;
     int steps_before_reward;
     int wt;                  // write-through stores of the actions (cache-resident batches)
-    int* fault;              // the handle's fault word (host memory): a chain / helper wave that gives up waiting says so (helper_fail)
+    int* fault;              // the handle's fault word (host memory): a chain / helper wave that gives up waiting says so (wave_gave_up)
 };
 
 // NG = groups per wave: with NG = 4 a wave owns four consecutive groups and lane quarter j runs group j's recurrence,
@@ -92,20 +92,6 @@ struct PdArgs {
 // chain waves (s_sleep between empty polls); a chain wave reads `done` at the START of a tile and uses the value after the staging -- it
 // may overwrite buffer n & 1 once done >= n - 1 -- so it waits only when its helper is a whole tile behind.  No cycle: the helper waits
 // for nothing but `pub`.  Every spin is bounded; a wave that gives up raises the handle's fault word (as k_traj_ring's roles do).
-constexpr unsigned kHelperSpinLimit = 1u << 21;
-__device__ __noinline__ void helper_fail(int* fault) {
-    if (fault) __hip_atomic_fetch_or(fault, 64 << 8 | 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ int flag_load(const int* p) {
-    const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    asm volatile("" ::: "memory");
-    return v;
-}
-__device__ __forceinline__ void flag_store(int* p, int v) {
-    asm volatile("" ::: "memory");
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    asm volatile("" ::: "memory");
-}
 constexpr int kRwSlots = 8, kRwSlotInts = 4;                 // per chain wave and parity: eight episode slots of (executed steps, step offset, episode, -)
 template <int NG, bool RW, int CT = -1, int DC = 0, bool HW = false>
 __global__ void __launch_bounds__(HW ? 384 : 256) k_pd_rollout_tiles(const PdArgs a) {
@@ -200,7 +186,7 @@ __global__ void __launch_bounds__(HW ? 384 : 256) k_pd_rollout_tiles(const PdArg
             const bool a1 = serve(2 * h + 1, cons1, rt1, it1, tot1);
             if (a0 || a1) { spins = 0; continue; }
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > kHelperSpinLimit) { helper_fail(a.fault); return; }
+            if (++spins > kFlagSpinLimit) { wave_gave_up(a.fault, 64); return; }
         }
         return;
     }
@@ -209,7 +195,7 @@ __global__ void __launch_bounds__(HW ? 384 : 256) k_pd_rollout_tiles(const PdArg
         unsigned spins = 0;
         while (flag_load(sDone + wave) < want) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > kHelperSpinLimit) { helper_fail(a.fault); break; }
+            if (++spins > kFlagSpinLimit) { wave_gave_up(a.fault, 64); break; }
         }
     };
     for (int it_ = 0, un = vb * 4 + wave; un < units; ++it_, un += ustride) {
@@ -668,7 +654,10 @@ int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
         else if (quad_mode == 3) ng = 2;
         // (second session: the thresholds of launch_pd_rollout -- with the reward 10 240 / 12 288 / 14 336 episodes 85.0 / 85.8 / 100.3 ->
         // 78.6 / 78.9 / 79.4 us with four groups per wave, 3 072: 48.0 -> 42.6 with two; 8 192: two 52.5, four 68)
-        else if (quad_mode == 1) ng = pa.G >= 5 * simds ? 4 : (2 * pa.G >= 3 * simds ? 2 : 1);
+        // round 6: beyond ~10 groups per SIMD two groups per wave again (one tile of input lookahead: the larger number of waves hides more
+        // of the loads) -- LongSimpleReacher + reward, us, four / two: 16 384 episodes 50.2 / 53.9, 24 576: 86.2 / 78.3, 32 768: 118 / 108,
+        // 65 536: 229 / 213, 262 144: 871 / 840 (profiles/r06_rollout_reward.md)
+        else if (quad_mode == 1) ng = pa.G >= 10 * simds ? 2 : (pa.G >= 5 * simds ? 4 : (2 * pa.G >= 3 * simds ? 2 : 1));
         while (ng > 1 && ng * NTW > 8) ng >>= 1;       // the reward pass holds the inputs of two passes (eight episodes) in registers
         const int units = (pa.G + ng - 1) / ng;
         int blocks = (units + 3) / 4;

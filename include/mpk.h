@@ -219,6 +219,8 @@ int mpk_set_duration(mpk_handle h, double duration, double dt);
  *                   from fewer waves; the rollout on existing trajectories takes four per CU by itself beyond 512 MiB, k_traj_flat eight)
  *   "phase_split"   1 .. 64: the tiles of a chunk of k_phase_fused<..,act> (frozen plant state) in that many wave trips (automatic: until
  *                   every SIMD holds two waves; 1 = whole chunks)
+ *   "phase_pipe"    1 / 0: force / forbid the producer / consumer form of k_phase_fused<.., closed> (a workgroup of four waves per chunk: a consumer and three producers;
+ *                   automatic for closed-loop launches of a few thousand episodes)
  *   "pd_helper"     1 the reward rollout's control-cost pass on two helper waves of a six-wave workgroup instead of on the chain waves
  *                   (measured slower at every size: never automatic; ABI 4: the variant is compiled into -DMPK_ABLATIONS builds only,
  *                   a release library accepts the key and runs the pass on the chain waves -- identical results)

@@ -327,7 +327,7 @@ def test_the_validity_gate_inside_the_step_equals_the_separate_launches_and_the_
 
 @pytest.mark.parametrize("name", ["tt_prodmp", "beerpong_promp", "prodmp_3dof_learn_tau"])
 @pytest.mark.parametrize("opt", [("phase_chunk", 1), ("phase_chunk", 2), ("phase_chunk", 4), ("phase_table", 0), ("phase_table", 1),
-                                 ("pd_generic", 1), ("write_through", 0), ("write_through", 1), ("tiles_wpb", 1)])
+                                 ("pd_generic", 1), ("write_through", 0), ("write_through", 1), ("tiles_wpb", 1), ("phase_pipe", 0), ("phase_pipe", 1)])
 def test_every_launch_geometry_of_the_fused_kernel_gives_the_same_bits(name, opt, mpk_option):
     eng = engine_of(name)
     B = 333
@@ -372,6 +372,64 @@ def test_the_tiles_of_a_chunk_on_several_waves_give_the_same_bits(name, split, B
         eq(pos, ref[0], "pos"); eq(vel, ref[1], "vel"); eq(act, act2, "actions")
     finally:
         CONFIGS_ALL.pop("promp_t49", None)
+
+
+@pytest.mark.parametrize("name", ["tt_prodmp_replan", "beerpong_promp", "promp_5dof_learn_both", "promp_16dof_learn_tau"])
+@pytest.mark.parametrize("lean", [False, True])
+@pytest.mark.parametrize("B", [1, 5, 1025, 2049, 4096])
+def test_the_producer_consumer_form_of_the_closed_loop_gives_the_same_bits(name, lean, B, mpk_option):
+    """k_phase_fused<.., pipe> (a consumer wave and three producers per chunk, LDS counters between them; automatic for small launches)
+    against the one-wave form on the same inputs: two plans of an episode with the validity gate on, some plans invalid -- every output,
+    the plant state, the integer state, the boundary condition, valid and penalty are the same bits; batch sizes around the rule's
+    switches between chunks of four and eight and partial last chunks"""
+    pc, bc, tc, dt, dur, (pg, dg), every, mpt = CONFIGS[name]
+    eng = engine_of(name)
+    T, D = eng.num_steps, eng.num_dof
+    every_ = every or T // 2 + 3
+    mpt_ = max(mpt, 2)
+    _, closed = specs(name)
+    n_ph = int(pc.learn_tau) + int(pc.learn_delay)
+    lo, hi = (JNT_LOW[:D] * 0.45, JNT_HIGH[:D] * 0.45) if D <= 7 else (np.full(D, -1.2), np.full(D, 1.2))
+    gate = dict(pos_low=lo, pos_high=hi, check_tau_delay=n_ph == 2, tau_bound=pc.tau_bound if n_ph == 2 else (0.0, 1.0),
+                delay_bound=pc.delay_bound if n_ph == 2 else (0.0, 1.0))
+    raw0, ip, iv = make_inputs(name, B, seed=21, scale=0.35)
+    ip *= 0.3
+    lo_hi = O.params_bounds(pc, bc, tc)
+    frozen = np.clip(raw0[:, :n_ph], lo_hi[0, :n_ph], lo_hi[1, :n_ph])
+    q0, qd0 = ip.astype(np.float64), iv.astype(np.float64)
+    results = {}
+    for mode in (0, 1):
+        mpk_option("phase_pipe", mode)
+        A = _state(B, q0, qd0)
+        cond = (cu(ip), cu(iv))
+        rng = np.random.default_rng(5)
+        outs = []
+        for k, (cur, length) in enumerate(O.replanning_segments(T, every_, mpt_)[:2]):
+            raw = (0.35 * rng.standard_normal(raw0.shape)).astype(np.float32)
+            raw[:, :n_ph] = raw0[:, :n_ph]
+            params = raw.copy()
+            params[:, :n_ph] = frozen
+            g = dict(gate, raw_params=raw)
+            if lean:
+                r = eng.episode_return(params, cond[0], cond[1], closed, A["q"], A["qd"], replan=(A["ts"], A["ps"], A["dn"], every_, mpt_, T),
+                                       init_time=cur * dt, condition=True, gate=g)
+            else:
+                r = eng.replan_step(params, cond[0], cond[1], closed, A["q"], A["qd"], A["ts"], A["ps"], A["dn"], every_, mpt_, T,
+                                    init_time=cur * dt, condition=True, gate=g)
+            assert ("pipe" in eng.last_kernel()) == bool(mode), eng.last_kernel()
+            torch.cuda.synchronize()
+            eng.check_range()
+            outs.append({key: r[key].clone() for key in r if torch.is_tensor(r[key])})
+            outs[-1].update({key: A[key].clone() for key in A})
+            cond = (r["cond_pos"], r["cond_vel"])
+        results[mode] = outs
+    for k, (one, pipe) in enumerate(zip(results[0], results[1])):
+        assert one.keys() == pipe.keys()
+        for key in one:
+            eq(pipe[key], one[key], f"plan {k}: {key}")
+    if B >= 1000:
+        v = results[1][0]["valid"].cpu().numpy().astype(bool)
+        assert v.any() and (~v).any()           # both branches
 
 
 @pytest.mark.parametrize("name", ["tt_prodmp", "beerpong_promp"])

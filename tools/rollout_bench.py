@@ -49,6 +49,8 @@ def main():
             else:
                 fn = lambda: eng.pd_rollout(spec, pos, vel, q, qd, out=act)                       # noqa: E731
             variants = ({}, {"pd_quad": 0}, {"pd_quad": 3}, {"pd_quad": 2})
+            if "--waves" in sys.argv:   # groups per wave x resident workgroups per CU of the large launches
+                variants = tuple(dict(pd_quad=q_, **({"phase_waves": w} if w else {})) for q_ in (2, 3) for w in (0, 4, 8, 16))
             if "--wt" in sys.argv:      # store policy A/B of the automatic geometry
                 variants = ({}, {"write_through": 0}, {"write_through": 1}, {"pd_quad": 0, "write_through": 0}, {"pd_quad": 3, "write_through": 0})
             for opts in variants:

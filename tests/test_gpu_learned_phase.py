@@ -389,7 +389,7 @@ def test_the_producer_consumer_form_of_the_closed_loop_gives_the_same_bits(name,
     mpt_ = max(mpt, 2)
     _, closed = specs(name)
     n_ph = int(pc.learn_tau) + int(pc.learn_delay)
-    lo, hi = (JNT_LOW[:D] * 0.45, JNT_HIGH[:D] * 0.45) if D <= 7 else (np.full(D, -1.2), np.full(D, 1.2))
+    lo, hi = (JNT_LOW[:D] * 0.45, JNT_HIGH[:D] * 0.45) if D <= 7 else (np.full(D, -0.6), np.full(D, 0.6))
     gate = dict(pos_low=lo, pos_high=hi, check_tau_delay=n_ph == 2, tau_bound=pc.tau_bound if n_ph == 2 else (0.0, 1.0),
                 delay_bound=pc.delay_bound if n_ph == 2 else (0.0, 1.0))
     raw0, ip, iv = make_inputs(name, B, seed=21, scale=0.35)

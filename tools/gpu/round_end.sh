@@ -25,7 +25,12 @@ python tools/episode_bench.py 2>&1 | grep -v amdgpu > $O/episode_return.md
 python tools/wide_bench.py > $O/wide.md 2>&1
 for B in 2048 4096 8192 65536; do python tools/bench_replan.py $B 50 --graph; python tools/bench_replan.py $B 50; done 2>&1 | grep -v amdgpu > $O/replan.log
 # round 6: the learned-phase families through every entry point, the gate's price, chunk sizes, the trajectory-only kernel on the TableTennis shape
-python tools/learned_phase_bench.py 1024 8192 65536 2> $O/learned_phase.err | grep -v amdgpu > $O/learned_phase.md
+python tools/learned_phase_bench.py 1024 2048 4096 8192 65536 2> $O/learned_phase.err | grep -v amdgpu > $O/learned_phase.md
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_lp -o lp -- python3 $R/tools/learned_phase_bench.py 1024 8192 TT-ProDMP BeerPong-ProMP > /dev/null 2>&1)
+bash tools/gpu/phase_fused_pmc.sh 8192 65536 > $O/phase_fused_pmc.txt 2>&1
+bash tools/gpu/pf_split_sweep.sh > $O/phase_fused_split.md 2>&1
+(for o in phase_pipe=0 "" phase_chunk=4 phase_chunk=8; do echo "== $o"; python tools/learned_phase_bench.py 1024 2048 4096 TT-ProDMP BeerPong-ProMP $o 2>/dev/null | grep "closed-loop\|verbose" | cut -d'|' -f2,3,4,5,7; done) > $O/phase_pipe.md 2>&1
+python tools/rollout_bench.py 24576 65536 262144 --waves 2>/dev/null | grep LongSimple | cut -d'|' -f2,3,4,5,8 > $O/rollout_waves.md
 (for c in 2 4 8; do echo "== phase_chunk=$c"; python tools/learned_phase_bench.py 8192 65536 TT-ProDMP BeerPong-ProMP phase_chunk=$c 2>/dev/null | grep -v "separate launches\|gated\|trajectory |\|^lib\|^| config\|^|---"; done) > $O/phase_fused_chunks.md
 bash tools/gpu/pf_small_sweep.sh > $O/phase_fused_small.md 2>&1
 (for cfg in "TT-ProDMP" "cfg5 TT-ProMP"; do for B in 8192 65536; do n=40; [ $B -gt 10000 ] && n=10; python3 tools/gate_probe.py "$cfg" $B $n scale=0.2; python3 tools/gate_probe.py "$cfg" $B $n; done; done) 2>&1 | grep -v amdgpu > $O/gate_cost.txt

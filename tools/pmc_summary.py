@@ -19,7 +19,7 @@ def main(dirs):
                 dur[k][r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
             print(f"## {f}")
             for k, cs in agg.items():
-                if "k_traj" not in k and "k_pd" not in k:
+                if "k_traj" not in k and "k_pd" not in k and "k_phase" not in k and "k_episode" not in k:
                     continue
                 ds = list(dur[k].values())
                 print(f"  {k}: {len(ds)} dispatches, mean {sum(ds) / len(ds) / 1e3:.1f} us under PMC")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Run one BASELINE configuration N times (for rocprofv3):  python tools/run_cfg.py <cfg2|cfg2act|cfg2closed|cfg3|cfg4|cfg5|cfg5tau|cfg2tau> B N [option=value ...]"""
+"""Run one BASELINE configuration N times (for rocprofv3):  python tools/run_cfg.py <cfg2|cfg2act|cfg2closed|cfg3|cfg4|cfg5|cfg5tau|cfg2tau|ttprodmp[act|closed]|beerpong[act|closed]> B N [option=value ...]"""
 import os
 import sys
 
@@ -28,6 +28,13 @@ KW = {
     "cfg5tau": dict(mp_type="promp", phase_type="linear", basis_type="zero_rbf", num_dof=7, num_basis=3,
                     num_basis_zero_start=1, num_basis_zero_goal=1, dt=0.008, duration=2.8, tau=2.8, learn_tau=True,
                     learn_delay=True, tau_bound=(0.5, 2.8), delay_bound=(0.05, 0.15)),
+    # the reference's learned-phase families at their real shapes (k_phase_fused: tools/learned_phase_bench.py has the citations)
+    "ttprodmp": dict(mp_type="prodmp", phase_type="exp", basis_type="prodmp", num_dof=7, num_basis=3, dt=0.008, duration=2.8,
+                     tau=1.5, alpha_phase=3.0, learn_tau=True, learn_delay=True, tau_bound=(0.8, 1.5), delay_bound=(0.05, 0.15),
+                     basis_alpha=25.0, basis_bandwidth_factor=3.0, weights_scale=0.7, auto_scale_basis=True, relative_goal=True,
+                     disable_goal=True),
+    "beerpong": dict(mp_type="promp", phase_type="linear", basis_type="zero_rbf", num_dof=7, num_basis=2, num_basis_zero_start=2,
+                     dt=0.01, duration=3.0, tau=3.0, learn_tau=True, tau_bound=(0.02, 3.0), basis_bandwidth_factor=3.0),
     "cfg2tau": dict(mp_type="prodmp", phase_type="exp", basis_type="prodmp", num_dof=7, num_basis=5, dt=0.02,
                     duration=2.0, tau=1.5, alpha_phase=3.0, basis_bandwidth_factor=2.0, basis_alpha=10.0,
                     learn_tau=True, tau_bound=(0.5, 2.0)),
@@ -49,10 +56,17 @@ def main():
     if base.endswith("tau"):
         n_ph = P - D * ((P - 0) // D)
         params[:, :n_ph] = torch.rand((B, n_ph), generator=g) * 0.5 + 0.8
+    if base == "ttprodmp":
+        params *= 0.3
+        params[:, 0] = torch.rand(B, generator=g) * 0.7 + 0.8
+        params[:, 1] = torch.rand(B, generator=g) * 0.1 + 0.05
+    if base == "beerpong":
+        params *= 0.3
+        params[:, 0] = torch.rand(B, generator=g) * 2.0 + 1.0
     params = params.cuda()
     ip = (torch.rand((B, D), generator=g) * 2 - 1).cuda()
     iv = torch.zeros((B, D), device="cuda")
-    gains = (TT_P, TT_D) if base == "cfg5" else (PG, DG)
+    gains = (TT_P, TT_D) if base in ("cfg5", "ttprodmp", "beerpong") else (PG, DG)
     out = tuple(torch.empty((B, T, D), device="cuda") for _ in range(3))
     q, qd = ip.double().contiguous(), iv.double().contiguous()
     for _ in range(N):

@@ -119,6 +119,7 @@ SIGNATURES = {
     "mpk_unpin_tables": (C.c_int, [_vp]),
     "mpk_check_range": (C.c_int, [_vp, _vp]),
     "mpk_poll_fault": (C.c_int, [_vp]),
+    "mpk_gate_flags": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "mpk_reacher_rollout": (C.c_int, [_vp, C.POINTER(mpk_rollout_cfg), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp,
                                       _vp, _i32, _i32, _vp]),
     "mpk_replan_advance": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -116,6 +116,7 @@ class BatchedBlackBox:
         self.traj_steps = torch.zeros(self.B, **i32)
         self.plan_steps = torch.zeros(self.B, **i32)
         self.done = torch.zeros(self.B, dtype=torch.uint8, device=self.device)
+        self._prev_done, self._prev_done_known = None, True
         self.q = torch.zeros((self.B, self.D), dtype=torch.float64, device=self.device)
         self.qd = torch.zeros_like(self.q)
         self.condition_pos = None
@@ -177,6 +178,8 @@ class BatchedBlackBox:
         self._lockstep = None if (self.device_time and self.do_replanning) else 0
         self._host_plans = 0
         self._plans_since_reset = 0
+        self._prev_done = None              # the done bytes before the next plan: none is done (mpk_gate_flags takes NULL)
+        self._prev_done_known = True
         self.traj_gen.reset()
         return self.q, self.qd
 
@@ -265,11 +268,18 @@ class BatchedBlackBox:
                     tau_bound=self.tau_bound, delay_bound=self.delay_bound,
                     raw_params=torch.as_tensor(raw_params, dtype=torch.float32, device=self.device) if self.check_tau_delay else None)
 
+    def _was_done(self) -> Optional[torch.Tensor]:
+        """the done bytes before this plan WITHOUT a launch: the snapshot the step before returned (the one-launch steps write it), None
+        right after a reset (none is done); a copy only after a step of the separate-launch path"""
+        if getattr(self, "_prev_done_known", False):
+            return self._prev_done
+        return self.done.clone()
+
     def _step_fused(self, params) -> Dict[str, torch.Tensor]:
         """plan + execute as ONE device operation (mpk_replan_step: integer state, trajectory + rollout, condition gather
         in a single launch where the fused closed-loop kernel applies)"""
         gate = self._gate(params)           # (the RAW action: the reference checks tau / delay before clipping, table_tennis_env.py:305-306)
-        was_done = self.done.bool() if gate is not None else None
+        was_done = self._was_done() if gate is not None else None
         params = self._plan_params(params)
         first = self._start32 is not None and self._plans_since_reset == 1    # q, qd untouched since reset
         cond_pos = self.condition_pos if self.condition_pos is not None else (self._start32[0] if first else self.q.float())
@@ -287,12 +297,14 @@ class BatchedBlackBox:
             # that is still live has executed exactly the segments the rule gives (nothing is read back from the device)
             self._lockstep += self._host_segment()
         done = r["done"].view(torch.bool)               # 0 / 1 bytes: a view, not a launch
+        self._prev_done, self._prev_done_known = r["done"], True
         if gate is not None:
             valid = r["valid"].view(torch.bool)
-            # invalid plans terminate their episode without executing a step (black_box_wrapper.py:169-172)
+            # invalid plans terminate their episode without executing a step (black_box_wrapper.py:169-172); both flags in one launch
+            terminated, truncated = self.engine.gate_flags(r["valid"], was_done, r["done"])
             return dict(params=params, des_pos=r["pos"], des_vel=r["vel"], step_actions=r["actions"], valid=valid,
-                        invalid_penalty=r["penalty"], trajectory_length=seg, done=done, terminated=~valid & ~was_done,
-                        truncated=done & valid, current_pos=self.q, current_vel=self.qd)
+                        invalid_penalty=r["penalty"], trajectory_length=seg, done=done, terminated=terminated,
+                        truncated=truncated, current_pos=self.q, current_vel=self.qd)
         if self._const_flags is None:
             self._const_flags = (torch.ones(self.B, dtype=torch.bool, device=self.device),
                                  torch.zeros(self.B, dtype=torch.bool, device=self.device))
@@ -310,7 +322,7 @@ class BatchedBlackBox:
     def _step_lean(self, params) -> Optional[Dict[str, torch.Tensor]]:
         """the verbose < 2 step as ONE launch without per-step outputs (mpk_episode_return); None = not available here"""
         gate = self._gate(params)
-        was_done = self.done.bool() if gate is not None else None
+        was_done = self._was_done() if gate is not None else None
         params = self._plan_params(params)
         first = self._start32 is not None and self._plans_since_reset == 1
         cond_pos = self.condition_pos if self.condition_pos is not None else (self._start32[0] if first else self.q.float())
@@ -331,6 +343,7 @@ class BatchedBlackBox:
         if self.do_replanning:
             self._lockstep += self._host_segment()
         done = r["done"].view(torch.bool)
+        self._prev_done, self._prev_done_known = r["done"], True
         if self._const_flags is None:
             self._const_flags = (torch.ones(self.B, dtype=torch.bool, device=self.device),
                                  torch.zeros(self.B, dtype=torch.bool, device=self.device))
@@ -339,7 +352,8 @@ class BatchedBlackBox:
                    current_pos=self.q, current_vel=self.qd)
         if gate is not None:
             valid = r["valid"].view(torch.bool)
-            out.update(valid=valid, invalid_penalty=r["penalty"], terminated=~valid & ~was_done, truncated=done & valid)
+            terminated, truncated = self.engine.gate_flags(r["valid"], was_done, r["done"])
+            out.update(valid=valid, invalid_penalty=r["penalty"], terminated=terminated, truncated=truncated)
         if self.reward is not None:
             out["rewards"] = r["ret"]
         return out
@@ -388,6 +402,7 @@ class BatchedBlackBox:
         out = self.get_trajectory(params)
         pos, vel = out["des_pos"], out["des_vel"]
         was_done = self.done.bool()
+        self._prev_done_known = False       # (this path changes the done bytes with launches of its own: _was_done copies them next time)
         valid = torch.ones(self.B, dtype=torch.bool, device=self.device)
         if self.pos_limits is not None:
             # `params` as the caller passed them: the reference checks the raw action, not the clipped one

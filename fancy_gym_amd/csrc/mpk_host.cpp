@@ -1283,6 +1283,17 @@ int mpk_replan_advance(mpk_handle hh, int32_t* traj_steps, int32_t* plan_steps, 
                                  stream);
 }
 
+int mpk_gate_flags(mpk_handle hh, const uint8_t* valid, const uint8_t* was_done, const uint8_t* done, uint8_t* terminated,
+                   uint8_t* truncated, int32_t B, void* stream) {
+    if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    if (B < 0) { set_error("B must be >= 0"); return MPK_EINVAL; }
+    if (B == 0) return MPK_OK;
+    if (!valid || !done || !terminated || !truncated) { set_error("NULL buffer"); return MPK_EINVAL; }
+    MPK_ON_DEVICE(h->cfg.device);
+    return launch_gate_flags(valid, was_done, done, terminated, truncated, B, stream);
+}
+
 int mpk_condition_gather(mpk_handle hh, const float* pos, const float* vel, const int32_t* seg_len, float* cond_pos,
                          float* cond_vel, int32_t B, int32_t T, void* stream) {
     if (!hh) { set_error("NULL handle"); return MPK_EINVAL; }

@@ -152,6 +152,8 @@ int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos, co
 int launch_episode_reset(const double* init_q, const double* init_qd, double* q, double* qd, float* cond_pos,
                          float* cond_vel, int32_t* traj_steps, int32_t* plan_steps, uint8_t* done, int B, int D,
                          void* stream);
+int launch_gate_flags(const uint8_t* valid, const uint8_t* was_done, const uint8_t* done, uint8_t* terminated, uint8_t* truncated, int B,
+                      void* stream);
 int launch_replan_advance(int32_t* traj_steps, int32_t* plan_steps, int32_t* seg_len, uint8_t* done, int every,
                           int max_planning_times, int horizon, int T, int B, void* stream, const uint8_t* valid = nullptr);
 int launch_validity(const float* pos, const float* params, int P, int D, const double* lo, const double* hi,

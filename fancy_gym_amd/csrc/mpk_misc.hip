@@ -28,6 +28,26 @@ int launch_replan_advance(int32_t* traj_steps, int32_t* plan_steps, int32_t* seg
 }
 #endif  // MPK_DEVICE_ONLY
 
+// mpk_gate_flags: terminated = !valid && !was_done, truncated = done && valid (black_box_wrapper.py:169-172,198-203)
+__global__ void __launch_bounds__(256) k_gate_flags(const uint8_t* __restrict__ valid, const uint8_t* __restrict__ was_done,
+                                                    const uint8_t* __restrict__ done, uint8_t* __restrict__ terminated,
+                                                    uint8_t* __restrict__ truncated, const int B) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const bool v = valid[b] != 0, w = was_done ? was_done[b] != 0 : false, d = done[b] != 0;
+    terminated[b] = (!v && !w) ? 1 : 0;
+    truncated[b] = (d && v) ? 1 : 0;
+}
+
+#ifndef MPK_DEVICE_ONLY
+int launch_gate_flags(const uint8_t* valid, const uint8_t* was_done, const uint8_t* done, uint8_t* terminated, uint8_t* truncated, int B,
+                      void* stream) {
+    hipLaunchKernelGGL(k_gate_flags, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, valid, was_done, done, terminated, truncated, B);
+    MPK_LAUNCH_CHECK();
+    return MPK_OK;
+}
+#endif  // MPK_DEVICE_ONLY
+
 // BlackBoxWrapper.reset (black_box_wrapper.py:222-229) for B episodes: counters to zero, plant state from the caller's
 // initial state (NULL = zeros) and its fp32 image, the boundary condition of the first plan (black_box_wrapper.py:110-111)
 __global__ void __launch_bounds__(256) k_episode_reset(const double* __restrict__ init_q, const double* __restrict__ init_qd,

@@ -224,6 +224,17 @@ class TrajectoryEngine:
         (mpk.h: mpk_poll_fault) -- for callers that synchronise themselves and make no further call that would report it"""
         _lib.check(self._lib.mpk_poll_fault(self._h))
 
+    def gate_flags(self, valid: torch.Tensor, was_done: Optional[torch.Tensor], done: torch.Tensor):
+        """(terminated, truncated) of a gated step as bool [B] tensors in ONE launch (mpk.h: mpk_gate_flags): an invalid plan terminates
+        an episode that was live, a valid one that finished is truncated (black_box_wrapper.py:169-172,198-203); uint8 / bool inputs"""
+        B = valid.shape[0]
+        out = torch.empty((2, B), dtype=torch.uint8, device=self.device)
+        u8 = lambda t: None if t is None else (t if t.dtype == torch.uint8 else t.view(torch.uint8))      # noqa: E731
+        v, w, d = u8(valid), u8(was_done), u8(done)
+        _lib.check(self._lib.mpk_gate_flags(self._h, v.data_ptr(), _dptr(w), d.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), B,
+                                            self._stream()))
+        return out[0].view(torch.bool), out[1].view(torch.bool)
+
     def trajectory_host(self, params: np.ndarray, init_pos: np.ndarray, init_vel: np.ndarray, init_time: float
                         ) -> Tuple[torch.Tensor, torch.Tensor]:
         """

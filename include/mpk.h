@@ -302,6 +302,16 @@ int mpk_check_range(mpk_handle h, void* stream);
  */
 int mpk_poll_fault(mpk_handle h);
 
+/*
+ * The step flags of a gated plan for B episodes in one launch (ABI 4; black_box_wrapper.py:169-172,198-203): an invalid plan TERMINATES an
+ * episode that was live -- terminated = !valid && !was_done --, a valid one that finished its horizon (or its last allowed plan) is
+ * TRUNCATED -- truncated = done && valid.  valid: what mpk_replan_step_gated / mpk_episode_return_gated wrote; was_done: the done bytes
+ * BEFORE that step (NULL = none was done: the first plan after a reset; otherwise the `done_out` snapshot of the step before); done: the
+ * done bytes after it.  Bytes 0 / 1.  Replaces five elementwise launches of the host framework per gated step.
+ */
+int mpk_gate_flags(mpk_handle h, const uint8_t* valid, const uint8_t* was_done, const uint8_t* done, uint8_t* terminated,
+                   uint8_t* truncated, int32_t B, void* stream);
+
 int mpk_unpin_tables(mpk_handle h);
 
 /* Copies the fp32 time grid linspace(0,duration,T+1)[1:] (without init_time) to host float [T]. */

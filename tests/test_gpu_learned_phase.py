@@ -617,3 +617,16 @@ def test_batched_black_box_steps_these_families_in_one_launch_per_plan(name, gat
     assert bool(fused.done.all()) and bool(lean.done.all())
     if gated:
         assert int((fused.traj_steps < fused.horizon).sum()) > 0        # some episodes ended at an invalid plan
+
+
+def test_the_step_flags_of_a_gated_plan_in_one_launch():
+    """mpk_gate_flags: terminated = !valid & !was_done, truncated = done & valid (black_box_wrapper.py:169-172,198-203) -- what
+    BatchedBlackBox computed with five elementwise launches per gated step; was_done = None right after a reset"""
+    eng = engine_of("tt_prodmp")
+    g = torch.Generator().manual_seed(3)
+    for B in (1, 255, 256, 257, 5000):
+        v, w, d = (torch.randint(0, 2, (B,), generator=g, dtype=torch.uint8).cuda() for _ in range(3))
+        term, trunc = eng.gate_flags(v, w, d)
+        eq(term, ~v.bool() & ~w.bool(), "terminated"); eq(trunc, d.bool() & v.bool(), "truncated")
+        term, trunc = eng.gate_flags(v.bool(), None, d.bool())
+        eq(term, ~v.bool(), "terminated after a reset"); eq(trunc, d.bool() & v.bool(), "truncated after a reset")

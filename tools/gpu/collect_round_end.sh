@@ -22,6 +22,7 @@ if [ -f $O/learned_phase.md ]; then      # round 6: <tag>_sweep.md is the learne
   [ -f $O/phase_fused_pmc.txt ] && { echo "# k_phase_fused: HBM bytes per launch from the PMC counters (tools/gpu/phase_fused_pmc.sh; bytes = (2 FETCH_SIZE + WRITE_SIZE) x 1024)"; echo; echo '```'; cat $O/phase_fused_pmc.txt; echo '```'; } > ${P}_phase_fused_pmc_raw.md
   [ -f $O/phase_fused_split.md ] && { echo "# k_phase_fused<..,act>: tiles of a chunk on several waves (phase_split) x chunk size, us (tools/gpu/pf_split_sweep.sh)"; echo; cat $O/phase_fused_split.md; } > ${P}_phase_fused_split.md
   [ -f $O/phase_pipe.md ] && { echo "# k_phase_fused<..,pipe>: one-wave form (phase_pipe=0) / automatic / chunks of 4 / 8, us"; echo; cat $O/phase_pipe.md; } > ${P}_phase_pipe_raw.md
+  [ -f $O/replan_tt.log ] && cp $O/replan_tt.log ${P}_replan_tabletennis.log
   [ -f $O/rollout_waves.md ] && cp $O/rollout_waves.md ${P}_rollout_waves.md
   { echo "# k_phase_fused: waves per workgroup (tiles_wpb) and resident waves per CU (phase_waves), tools/gpu/phase_wpb_sweep.sh"; echo; cat $O/phase_wpb.md; } > ${P}_phase_wpb.md
 else

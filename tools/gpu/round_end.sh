@@ -24,6 +24,8 @@ python tools/dmp_bench.py 2>&1 | grep -v amdgpu > $O/dmp_response.md
 python tools/episode_bench.py 2>&1 | grep -v amdgpu > $O/episode_return.md
 python tools/wide_bench.py > $O/wide.md 2>&1
 for B in 2048 4096 8192 65536; do python tools/bench_replan.py $B 50 --graph; python tools/bench_replan.py $B 50; done 2>&1 | grep -v amdgpu > $O/replan.log
+(for B in 1024 4096 8192; do for f in "" "--gate" "--verbose1" "--gate --verbose1"; do python tools/bench_replan.py $B 50 --tt $f --graph; python tools/bench_replan.py $B 50 --tt $f; done; done) 2>&1 | grep -v amdgpu > $O/replan_tt.log
+(for B in 1024 4096; do python tools/bench_replan.py $B 50 --tt --graph phase_pipe=0; done) 2>&1 | grep -v amdgpu >> $O/replan_tt.log
 # round 6: the learned-phase families through every entry point, the gate's price, chunk sizes, the trajectory-only kernel on the TableTennis shape
 python tools/learned_phase_bench.py 1024 2048 4096 8192 65536 2> $O/learned_phase.err | grep -v amdgpu > $O/learned_phase.md
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_lp -o lp -- python3 $R/tools/learned_phase_bench.py 1024 8192 TT-ProDMP BeerPong-ProMP > /dev/null 2>&1)

@@ -27,7 +27,16 @@ static int launch_traj_t(const TrajArgs& ta, const ActArgs& aa, bool stream_mode
                     default: hipLaunchKernelGGL((k_traj_pipe<MP, CT, 4, LEAN>), g, b5, lds, s5, ta, aa); break;
                 }
             };
-            if (ta.lean) gop(std::true_type()); else gop(std::false_type());
+            auto gog = [&]() {                          // the validity gate: the consumer's chain with the GATE hook (no LEAN form)
+                switch (ta.c.KP / 4) {
+                    case 1: hipLaunchKernelGGL((k_traj_pipe<MP, CT, 1, false, true>), g, b5, lds, s5, ta, aa); break;
+                    case 2: hipLaunchKernelGGL((k_traj_pipe<MP, CT, 2, false, true>), g, b5, lds, s5, ta, aa); break;
+                    case 3: hipLaunchKernelGGL((k_traj_pipe<MP, CT, 3, false, true>), g, b5, lds, s5, ta, aa); break;
+                    default: hipLaunchKernelGGL((k_traj_pipe<MP, CT, 4, false, true>), g, b5, lds, s5, ta, aa); break;
+                }
+            };
+            if (ta.gate_valid) gog();
+            else if (ta.lean) gop(std::true_type()); else gop(std::false_type());
         }
         MPK_LAUNCH_CHECK();
         return MPK_OK;

@@ -288,7 +288,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     if (tune.ablations != 1) ta.ring_dbg &= ~(1 | 2 | 128 | (q_state ? 0 : 8)); ta.burst = 0; ta.inorder = 0; ta.lean = 0; ta.wpb = 4; ta.ring_ctr = nullptr; ta.ring_tb = 0; ta.ring_parts = 1;
     if (rp) ta.rp = *rp;
     const bool closed = q_state != nullptr;
-    const bool gated = gate != nullptr;       // validity gate: the lane-quarter closed-loop kernels only (k_traj_quad / duo / mono: gate_pass)
+    const bool gated = gate != nullptr;       // validity gate: the lane-quarter closed-loop kernels (k_traj_quad / duo / mono: gate_pass) and k_traj_pipe
     if (gated && !(closed && actions)) { set_error("the validity gate belongs to the closed-loop step"); return MPK_EINVAL; }
     ta.q_state = q_state; ta.qd_state = qd_state; ta.n_steps = n_steps; ta.plant_dt = rc ? rc->dt : 0.0;
     ta.c = c; ta.A = st.A; ta.aux = st.aux; ta.TS = st.TS;
@@ -341,8 +341,10 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     // per row tile only makes the store stream burstier.
     const bool pipe_fits = table_bytes + 2 * kPipeGroups * kQuadImg * sizeof(float) <= kLdsDefault;
     const long pipe_units = ((long)ta.G + kPipeGroups - 1) / kPipeGroups;
-    const bool pipe = closed && !gated && c.mp_type != MPK_MP_DMP && pipe_fits && tune.split != 1 &&
-                      (tune.pipe == 1 || (tune.pipe != 0 && !variant_forced && pipe_units <= 3L * num_cu));
+    // (with the validity gate -- k_traj_pipe<.., GATE>, 153 registers: two workgroups per CU -- only while ONE workgroup per CU holds the
+    // launch: cfg5, us gated / ungated: 1 024 episodes 28.8 / 24.9 (k_traj_mono<.., gate>: 37.5), 2 048: 29.2 / 25.2, 4 096: 55.6 / 28.7)
+    const bool pipe = closed && c.mp_type != MPK_MP_DMP && pipe_fits && tune.split != 1 &&
+                      (tune.pipe == 1 || (tune.pipe != 0 && !variant_forced && pipe_units <= (gated ? 1L : 3L) * num_cu));
     const bool split = !pipe && closed && !gated && c.mp_type != MPK_MP_DMP && split_shape && tune.split == 1;
     // (trajectory-only launches of the shapes k_traj_flat takes -- two workgroups of whole-trajectory images per CU -- go episode-major from
     // kFlatTrajBytes on: round 5, cfg2's shape, us tiles / flat: 8 192 episodes 10.7 / 11.0, 12 288: 14.5 / 14.1, 16 384: 19.2 / 18.2)
@@ -413,7 +415,7 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
             else if (fits(2) && units2 >= (long)num_cu * 4) quad = 2;
             else if (closed && fits(1)) quad = 1;
         }
-        if (gated && quad == 0) {
+        if (gated && quad == 0 && !pipe) {
             // (a forced "quad" 0, or tables beyond the lane-quarter kernels' LDS: the caller's separate launches)
             if (serial_variant && tune.quad != 0 && fits(1)) quad = 1;
             else return MPK_ENOTIMPL;
@@ -668,7 +670,8 @@ int launch_traj_shared(const DevCfg& c, const SharedTables& st, const float* par
     }
     if (gated) {
         const bool pd = c.mp_type == MPK_MP_PRODMP;
-        *kernel_name = quad == 4 ? (pd ? "k_traj_quad<prodmp,closed,gate>" : "k_traj_quad<promp,closed,gate>")
+        *kernel_name = pipe_sel ? (pd ? "k_traj_pipe<prodmp,closed,gate>" : "k_traj_pipe<promp,closed,gate>")
+                     : quad == 4 ? (pd ? "k_traj_quad<prodmp,closed,gate>" : "k_traj_quad<promp,closed,gate>")
                      : quad == 2 ? (pd ? "k_traj_duo<prodmp,closed,gate>" : "k_traj_duo<promp,closed,gate>")
                                  : (pd ? "k_traj_mono<prodmp,closed,gate>" : "k_traj_mono<promp,closed,gate>");
         if (c.mp_type == MPK_MP_DMP) return MPK_ENOTIMPL;

@@ -16,6 +16,11 @@ namespace mpk {
 //               bit), while the producers are busy with tile rt + 1 and with the stores of tile rt - 1.
 // One workgroup barrier per row tile hands the images over.  The integer replanning state, the boundary-condition gather
 // and the plant state are the consumer's, exactly as in k_traj_quad.
+// Validity gate (round 6; a.gate_valid): the consumer's chain tests the desired positions it reads anyway (pd_tile_steps' GATE hook, as
+// k_phase_fused), the rollout runs speculatively over the WHOLE plan, the verdict falls after the last tile; an invalid plan is taken
+// back: plant state not written, replan_write(valid = false), condition = row 0, and -- after one more barrier -- the producer of its
+// group rewrites its action rows as zeros (the same wave that stored them: ordered).  Until then gated launches of a few thousand
+// episodes ran on k_traj_mono<.., gate> (cfg5 at 1 024 episodes: 37 us against 25 ungated).
 constexpr int kPipeGroups = 4;
 #ifndef MPK_PIPE_PRE
 #define MPK_PIPE_PRE 0       // 1: the consumer pulls and converts a whole tile before its chain (pd_tile_steps): 14 instead of 17
@@ -33,10 +38,11 @@ constexpr int kPipeGroups = 4;
 #else
 #define MPK_PIPE_WAVES_ATTR
 #endif
-template <int MP, int CT, int KM, bool LEAN>
+template <int MP, int CT, int KM, bool LEAN, bool GATE = false>      // GATE: its own instantiations -- the gate's chain costs the consumer 154 registers where the plain kernel lives on 81 - 103
 __global__ void __launch_bounds__(320) MPK_PIPE_WAVES_ATTR k_traj_pipe(const TrajArgs a, const ActArgs act) {
     static_assert(CT >= 3 && MP != MPK_MP_DMP, "closed loop, promp / prodmp");
     __shared__ __attribute__((aligned(16))) float smem[2 * kPipeGroups * kQuadImg];   // [buffer][group] pos | vel | act
+    __shared__ int sBad[kPipeGroups * 16];                                            // gate: [group][episode of the group] invalid
     extern __shared__ __attribute__((aligned(16))) float sTab[];                      // [NOUT][KP][TS] rows + [TS] aux
     constexpr int NOUT = MP == MPK_MP_PRODMP ? 2 : 3;
     const DevCfg& c = a.c;
@@ -80,17 +86,32 @@ __global__ void __launch_bounds__(320) MPK_PIPE_WAVES_ATTR k_traj_pipe(const Tra
         // ---------------- consumer: four recurrences, one per lane quarter ----------------
         const Gains gq = kernarg_gains(L.dvalid ? L.d : 0);
         const double pgd = gq.pg, dgd = gq.dg, lod = __builtin_canonicalize(gq.lo), hid = __builtin_canonicalize(gq.hi);
+        constexpr bool gated = GATE;
+        GateLim glim{0.0, 0.0, 0.0f, 0.0f};
+        if (gated) glim = kernarg_gate(L.dvalid ? L.d : 0);
         for (int u = vb; u < NU; u += (int)gridDim.x) {
             const int gsel = u * kPipeGroups + L.q, bq = gsel * NTW + L.bl;
             const bool serial = L.dvalid && gsel < a.G && bq < B;
             double qs = 0.0, qds = 0.0;
             int nst = 0;
+            ReplanVals rv{T, 0, 0, false};
+            bool t_bad = false, p_bad = false;
+            double tpen = 0.0, over = 0.0, under = 0.0;
+            float row0p = 0.0f, row0v = 0.0f;
             if (serial) {
                 const size_t ix = (size_t)bq * D + L.d;
                 qs = a.q_state[ix]; qds = a.qd_state[ix];
                 nst = T;
-                if (a.rp.traj_steps) nst = replan_rule(a.rp, bq, T, L.d == 0);
-                else if (a.n_steps) nst = min(a.n_steps[bq], T);
+                if (a.rp.traj_steps) {
+                    if (gated) { rv = replan_eval(a.rp, bq, T); nst = rv.seg; }     // (written after the verdict)
+                    else nst = replan_rule(a.rp, bq, T, L.d == 0);
+                } else if (a.n_steps) nst = min(a.n_steps[bq], T);
+                if (gated && a.gate_check_td) {
+                    const double tau = (double)a.gate_raw[(size_t)bq * c.P], delay = (double)a.gate_raw[(size_t)bq * c.P + 1];
+                    t_bad = !(tau >= a.gate_tb[0] && tau <= a.gate_tb[1] && delay >= a.gate_db[0] && delay <= a.gate_db[1]);
+                    tpen = 3.0 * (fmax(0.0, tau - a.gate_tb[1]) + fmax(0.0, a.gate_tb[0] - tau)) +
+                           3.0 * (fmax(0.0, delay - a.gate_db[1]) + fmax(0.0, a.gate_db[0] - delay));
+                }
             }
             const int tcond = (serial && a.rp.cond_pos) ? min(max(nst - 1, 0), T - 1) : -1;
             const int oq = L.bl * a.pitch + L.d + (int)ep_shift(a, bq);      // (row 0, this column) in group q's image
@@ -100,13 +121,27 @@ __global__ void __launch_bounds__(320) MPK_PIPE_WAVES_ATTR k_traj_pipe(const Tra
                 float* sQ = smem + ((rt & 1) * kPipeGroups + L.q) * kQuadImg;
                 const bool full_tile = tile_fully_executed(serial, nst, rt * 16);
                 MPK_STAMP(10 + rt);
-                if (serial && rt * 16 < max(nst, tcond + 1)) {
+                if (gated && rt == 0 && serial) { row0p = sQ[oq]; row0v = sQ[kStageStride + oq]; }
+                if (serial && (gated || rt * 16 < max(nst, tcond + 1))) {   // (the gate has to see the whole plan)
                     if (tcond >= rt * 16 && tcond < rt * 16 + 16) {   // condition_on_desired: the desired state at the
                         const size_t si = (size_t)bq * D + L.d;          // last executed step
                         a.rp.cond_pos[si] = sQ[oq + (tcond - rt * 16) * D];
                         a.rp.cond_vel[si] = sQ[kStageStride + oq + (tcond - rt * 16) * D];
                     }
-                    if (full_tile)
+                    if constexpr (gated) {
+                        int tb = 0;
+                        double gsum[2] = {over, under};
+                        if (full_tile)
+                            pd_tile_steps<CT - 3, false, true, 0, 0, true, true>(sQ + oq, sQ + kStageStride + oq, sQ + 2 * kStageStride + oq, D, rt * 16, nst,
+                                                                               pgd, dgd, lod, hid, a.plant_dt, qs, qds, nullptr, nullptr, 16, glim.lo32, glim.hi32,
+                                                                               &tb, glim.lo, glim.hi, gsum);
+                        else
+                            pd_tile_steps<CT - 3, true, true, 0, 0, true, true>(sQ + oq, sQ + kStageStride + oq, sQ + 2 * kStageStride + oq, D, rt * 16, nst,
+                                                                              pgd, dgd, lod, hid, a.plant_dt, qs, qds, nullptr, nullptr, min(16, T - rt * 16),
+                                                                              glim.lo32, glim.hi32, &tb, glim.lo, glim.hi, gsum);
+                        if (tb) p_bad = true;
+                        over = gsum[0]; under = gsum[1];
+                    } else if (full_tile)
                         pd_tile_steps<CT - 3, false, true, false, MPK_PIPE_PRE>(sQ + oq, sQ + kStageStride + oq, sQ + 2 * kStageStride + oq, D, rt * 16, nst,
                                                      pgd, dgd, lod, hid, a.plant_dt, qs, qds);
                     else
@@ -117,7 +152,31 @@ __global__ void __launch_bounds__(320) MPK_PIPE_WAVES_ATTR k_traj_pipe(const Tra
                 __syncthreads();                                            // tile rt's actions are final; tile rt + 1 is in
             }
             MPK_STAMP(60);
-            if (serial) {
+            bool invalid = false;
+            if constexpr (gated) {
+                // the episode's D lanes sit side by side in lane quarter q: its verdict, and its excess sums left to right
+                const int base = L.q * 16 + (L.bl << a.sh);
+                const unsigned long long m = __ballot(serial && p_bad);
+                invalid = serial && ((((m >> base) & ((1ull << D) - 1ull)) != 0ull) || t_bad);
+                if (m != 0ull) {
+                    double so = 0.0, su = 0.0;
+                    for (int d = 0; d < D; ++d) { so += __shfl(over, base + d); su += __shfl(under, base + d); }
+                    over = so; under = su;
+                }
+                if (serial) {
+                    const size_t si = (size_t)bq * D + L.d;
+                    if (invalid && a.rp.cond_pos) { a.rp.cond_pos[si] = row0p; a.rp.cond_vel[si] = row0v; }
+                    if (L.d == 0) {
+                        a.gate_valid[bq] = invalid ? 0 : 1;
+                        const double n = (double)(T * D);
+                        if (a.gate_penalty) a.gate_penalty[bq] = -(tpen + over / n + under / n);
+                        if (a.rp.traj_steps) replan_write(a.rp, bq, rv, !invalid);
+                    }
+                }
+                if (L.dvalid && L.d == 0) sBad[L.q * 16 + L.bl] = invalid ? 1 : 0;
+                __syncthreads();                                            // the verdicts are the producers' (zeroed action rows)
+            }
+            if (serial && !invalid) {
                 const size_t si = (size_t)bq * D + L.d;
                 a.q_state[si] = qs; a.qd_state[si] = qds;
             }
@@ -193,6 +252,19 @@ __global__ void __launch_bounds__(320) MPK_PIPE_WAVES_ATTR k_traj_pipe(const Tra
                 MPK_STAMP_AT(130 + rt, 64);
                 if (have) store_arrays(std::integral_constant<int, 4>(), rt);
                 MPK_STAMP_AT(150 + rt, 64);
+            }
+            if constexpr (GATE) {
+                __syncthreads();                                            // the consumer's verdicts
+                if (have) {
+                    for (int e = 0; e < NTW; ++e) {
+                        const int be = g * NTW + e;
+                        if (be >= B || !sBad[j * 16 + e]) continue;             // (wave-uniform)
+                        float* zp = a.actions + (size_t)be * T * D;
+                        for (int i = lane; i < T * D; i += 64) {
+                            if (a.wt) store4<true>(zp + i, 0.0f); else store4<false>(zp + i, 0.0f);
+                        }
+                    }
+                }
             }
         }
     }

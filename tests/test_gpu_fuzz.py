@@ -94,6 +94,9 @@ def test_random_configuration_matches_oracle(seed, monkeypatch, mpk_option):
         mpk_option("phase_chunk", int(r3.integers(1, 9)))
     r5 = np.random.default_rng(55_000 + seed)       # round 5: DMP with a shared phase on the response route / the serial kernels
     mpk_option("dmp_response", int(r5.choice([-1, -1, 0])))
+    r6 = np.random.default_rng(66_000 + seed)       # round 6: k_phase_fused's tile split (frozen-state actions) and producer / consumer form
+    mpk_option("phase_split", int(r6.choice([-1, -1, 1, 2, 3, 8])))
+    mpk_option("phase_pipe", int(r6.choice([-1, 0, 1])))
     if tc.trajectory_generator_type == "prodmp":
         tc = dataclasses.replace(tc, relative_goal_mode=str(r2.choice(["after_scale", "before_scale"])),
                                  goal_offset_mode=str(r2.choice(["ignore", "add"])), goal_offset=float(r2.uniform(-0.5, 0.5)))
@@ -531,6 +534,7 @@ def test_random_batched_episode_follows_the_oracle_sequence(seed, mpk_option):
                       ("split", [-1, 0, 1]), ("pd_quad", [-1, 0, 2]), ("pd_simple", [-1, 0, 1]), ("phase_flat", [-1, 0, 1]),
                       ("phase_chunk", [-1, 1, 2, 3, 4, 7])):
         mpk_option(key, int(rng.choice(vals)))
+    mpk_option("phase_pipe", int(np.random.default_rng(66_000 + seed).choice([-1, 0, 1])))     # (round 6; own generator: cases keep their shapes)
     kw = dict(plant="double_integrator", max_planning_times=mpt, condition_on_desired=cod)
     if replan:
         kw["replanning_every"] = every
@@ -617,6 +621,9 @@ def test_random_batched_episode_with_validity_gate(seed, mpk_option):
     for key, vals in (("phase_flat", [-1, 0, 1]), ("phase_chunk", [-1, 1, 2, 3, 4, 7]), ("phase", [-1, 0, 1]),
                       ("phase_table", [-1, 0, 1]), ("pd_quad", [-1, 0, 2]), ("pd_simple", [-1, 0, 1]), ("mapping", [-1, 1, 2])):
         mpk_option(key, int(rng.choice(vals)))
+    r6 = np.random.default_rng(66_000 + seed)       # round 6: the gate in the producer / consumer kernels (own generator: cases keep their shapes)
+    mpk_option("phase_pipe", int(r6.choice([-1, 0, 1])))
+    mpk_option("pipe", int(r6.choice([-1, 0, 1])))
     L = float(rng.uniform(0.8, 2.5))
     limits = (np.full(D, -L), np.full(D, L * float(rng.uniform(0.7, 1.3))))
     bb = _batched_from_cfg(pc, bc, tc, dt, dur, B, ctrl, pg, dg, lo, hi, plant="double_integrator", replanning_every=every,

@@ -22,8 +22,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // Development build only (-DMPK_TRACE): wave 0 of workgroup `MPK_TRACE_BLOCK` stamps the shader clock at labelled points
 // of a kernel into a device array that tools/dev/trace_kernel.py prints -- the per-phase timeline of ONE wave.
 #ifdef MPK_TRACE
-#ifndef MPK_AMALGAMATED
-#error "MPK_TRACE builds are single translation unit builds of mpk_kernels.hip (the trace buffer is one device variable)"
+#if !defined(MPK_AMALGAMATED) && !defined(MPK_TRACE_UNIT)
+#error "MPK_TRACE builds are single translation unit builds of mpk_kernels.hip, or of ONE unit (MPK_TRACE_UNIT): the trace buffer is one device variable"
 #endif
 #ifndef MPK_TRACE_BLOCK
 #define MPK_TRACE_BLOCK 0

@@ -66,15 +66,37 @@ __global__ void __launch_bounds__(256) k_build_shared(const DevCfg c, const floa
             const double al = (double)c.dmp_alpha, be = (double)c.dmp_beta, tau = (double)c.tau, itau = div_pos(1.0, (double)c.tau);
             const double G = k == nb ? (double)c.gs : 0.0;
             double y = k == nb + 1 ? 1.0 : 0.0, z = k == nb + 2 ? tau : 0.0;      // z_0 = tau v_b
-            for (int t = 0; t < T; ++t) {
-                const double f = k < nb ? (double)A[(size_t)k * TS + t] : 0.0;
-                const double ds = (double)aux[t];
-                A[(size_t)(0 * KP + k) * TS + t] = (float)y;
-                A[(size_t)(1 * KP + k) * TS + t] = (float)(z * itau);
-                if (t < T - 1) {
-                    const double acc = al * (be * (G - y) - z) + f;
-                    z = z + ds * acc;
-                    y = y + ds * z;
+            // sixteen steps per trip: their forcing values and step sizes are read TOGETHER, in front of the trip's stores (the response
+            // takes the forcing value's slot, so the compiler cannot hoist a load over the stores before it: step by step the loop was T
+            // dependent round trips to the table -- hundreds of us at T = 200 whenever a plan brings a new init_time; review of round 5)
+            constexpr int U = 16;
+            float fn[U], dn[U];
+            auto fetch = [&](const int t0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int t = t0 + u < T ? t0 + u : T - 1;
+                    fn[u] = k < nb ? A[(size_t)k * TS + t] : 0.0f;
+                    dn[u] = aux[t];
+                }
+            };
+            fetch(0);
+            for (int t0 = 0; t0 < T; t0 += U) {
+                float fv[U], dv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) { fv[u] = fn[u]; dv[u] = dn[u]; }
+                if (t0 + U < T) fetch(t0 + U);           // the next trip's values: in flight while this trip's steps run
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int t = t0 + u;
+                    if (t < T) {
+                        A[(size_t)(0 * KP + k) * TS + t] = (float)y;
+                        A[(size_t)(1 * KP + k) * TS + t] = (float)(z * itau);
+                        if (t < T - 1) {
+                            const double acc = al * (be * (G - y) - z) + (double)fv[u];
+                            z = z + (double)dv[u] * acc;
+                            y = y + (double)dv[u] * z;
+                        }
+                    }
                 }
             }
         }

@@ -212,9 +212,9 @@ class BatchedBlackBox:
                     self._phase_bounds = torch.as_tensor(self.engine.params_bounds()[:, :self._n_phase],
                                                          device=self.device)
                 lo = self._phase_bounds
-                self._frozen_phase = torch.minimum(torch.maximum(params[:, :self._n_phase], lo[0]), lo[1])
-            params = params.clone()
-            params[:, :self._n_phase] = self._frozen_phase
+                self._frozen_phase = torch.minimum(torch.maximum(params[:, :self._n_phase], lo[0]), lo[1]).to(torch.float32)
+            # (one launch -- a clone and a slice assignment were two; the plan's own columns follow the frozen ones)
+            params = torch.cat((self._frozen_phase, params[:, self._n_phase:]), dim=1)
         return params
 
     def get_trajectory(self, params) -> Dict[str, torch.Tensor]:

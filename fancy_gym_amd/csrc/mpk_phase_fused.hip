@@ -169,8 +169,11 @@ __device__ __forceinline__ void flush_tile(const float* __restrict__ sP, const i
 #define MPK_PF_PIPE_NP 3         // producers per workgroup: with the consumer one wave per SIMD (A/B: 2 was 3 - 25 % slower, profiles/r06_phase_pipe.md)
 #endif
 constexpr int kPipeProducers = MPK_PF_PIPE_NP;
+#ifndef MPK_PF_PIPE_WAVES
+#define MPK_PF_PIPE_WAVES 1       // workgroups of the pipeline form per SIMD the register allocation aims at (A/B builds)
+#endif
 template <int MP, int KQ, bool TL, int DC, int CT, bool PIPE = false>
-__global__ void __launch_bounds__(PIPE ? 64 * (1 + kPipeProducers) : (TL ? MPK_PF_TL_THREADS : 256), PIPE ? 1 : MPK_PF_WAVES) k_phase_fused(const FusedArgs a, const FusedLim lim) {
+__global__ void __launch_bounds__(PIPE ? 64 * (1 + kPipeProducers) : (TL ? MPK_PF_TL_THREADS : 256), PIPE ? MPK_PF_PIPE_WAVES : MPK_PF_WAVES) k_phase_fused(const FusedArgs a, const FusedLim lim) {
     static_assert(MP != MPK_MP_DMP, "dmp with a learned phase keeps its separate launches (no reference configuration has one)");
     static_assert(!TL || MP == MPK_MP_PRODMP, "only prodmp has a row table");
     static_assert(!PIPE || (CT >= 3 && !TL), "the pipeline serves the closed loop of small launches (row table from L2)");
@@ -766,14 +769,15 @@ int launch_phase_fused(const DevCfg& c, const float* params, const float* init_p
     // (a tile that starts at the last step reads the velocity carry); "phase_pipe" 1 / 0 forces / forbids
     const bool pipe_ok = closed && (prodmp || c.T % 16 != 1);
     const int e_top = e_max >= 8 ? 8 : (e_max >= 4 ? 4 : e_max);
-    bool pipe = pipe_ok && ((long)B + e_top - 1) / e_top <= 2 * (long)num_cu;
+    constexpr long kPipeWgsPerCu = MPK_PF_PIPE_WAVES >= 3 ? 3 : 2;     // resident workgroups per CU (registers: the kernel's launch bounds)
+    bool pipe = pipe_ok && ((long)B + e_top - 1) / e_top <= kPipeWgsPerCu * (long)num_cu;
     if (tune.phase_pipe >= 0) pipe = tune.phase_pipe == 1 && pipe_ok;
     if (pipe) {
         // chunks of four where two workgroups per CU hold the launch (one round of items per tile, two flush passes), else eight.
         // TableTennis-ProDMP closed loop / verbose < 2, us (profiles/r06_phase_pipe.md): 1 024 episodes 32.0 / 28.1 (one-wave form 52.8 /
         // 39.0), 2 048: 34.9 / 30.1 (52.5 / 38.8), 4 096: 42.7 / 31.4 (61.8 / 38.6); BeerPong-ProMP 1 024: 32.0 / 26.6 (59.2 / 47.7)
         E = e_max >= 4 ? 4 : e_max;
-        if (((long)B + E - 1) / E > 2 * (long)num_cu && e_top > E) E = e_top;
+        if (((long)B + E - 1) / E > kPipeWgsPerCu * (long)num_cu && e_top > E) E = e_top;
     }
     if (tune.phase_chunk >= 1 && tune.phase_chunk <= e_max) E = tune.phase_chunk;
     fa.chunk = E;

@@ -13,9 +13,9 @@ cp $O/dmp_response.md ${P}_dmp_response.md; cp $O/episode_return.md ${P}_episode
 cat $O/pytest.log $O/smoke.log > ${P}_gpu_tests.txt
 if [ -f $O/learned_phase.md ]; then      # round 6: <tag>_sweep.md is the learned-phase sweep the review asked for, the BASELINE shapes' table moves beside it
   cp $O/learned_phase.md ${P}_sweep.md; cp $O/sweep.md ${P}_sweep_baseline.md
-  { echo "# k_phase_fused: episodes per chunk (phase_chunk) at 8 192 / 65 536 episodes, then chunk x row table (LDS / L2) at 1 024 - 4 096"; echo
-    echo '`tools/gpu/round_end.sh`: `tools/learned_phase_bench.py 8192 65536 TT-ProDMP BeerPong-ProMP phase_chunk=..`, `tools/gpu/pf_small_sweep.sh`; us per launch'; echo
-    cat $O/phase_fused_chunks.md; echo; echo "## a few thousand episodes (columns: entry point | kernel | us | of 8 TB/s)"; echo; cat $O/phase_fused_small.md; } > ${P}_phase_fused_chunks.md
+  { echo "# k_phase_fused: episodes per chunk (phase_chunk) at 8 192 / 65 536 episodes"; echo
+    echo '`tools/gpu/round_end.sh`: `tools/learned_phase_bench.py 8192 65536 TT-ProDMP BeerPong-ProMP phase_chunk=..`; us per launch'; echo
+    cat $O/phase_fused_chunks.md; echo; echo "(a few thousand episodes: r06_phase_fused_split.md, r06_phase_pipe.md -- the tile split and the producer / consumer form)"; } > ${P}_phase_fused_chunks.md
   { echo "# the validity gate inside the launch: gated against ungated, us per launch (tools/gate_probe.py)"; echo
     echo 'two runs per case; `scale=0.2`: no plan violates (the price of the checks alone), default scale: a few plans violate (`n done`)'; echo; echo '```'; cat $O/gate_cost.txt; echo '```'; } > ${P}_gate_cost.md
   [ -f $O/prof_lp/lp_kernel_stats.csv ] && cp $O/prof_lp/lp_kernel_stats.csv ${P}_learned_phase_kernel_stats.csv

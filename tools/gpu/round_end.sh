@@ -34,7 +34,6 @@ bash tools/gpu/pf_split_sweep.sh > $O/phase_fused_split.md 2>&1
 (for o in phase_pipe=0 "" phase_chunk=4 phase_chunk=8; do echo "== $o"; python tools/learned_phase_bench.py 1024 2048 4096 TT-ProDMP BeerPong-ProMP $o 2>/dev/null | grep "closed-loop\|verbose" | cut -d'|' -f2,3,4,5,7; done) > $O/phase_pipe.md 2>&1
 python tools/rollout_bench.py 24576 65536 262144 --waves 2>/dev/null | grep LongSimple | cut -d'|' -f2,3,4,5,8 > $O/rollout_waves.md
 (for c in 2 4 8; do echo "== phase_chunk=$c"; python tools/learned_phase_bench.py 8192 65536 TT-ProDMP BeerPong-ProMP phase_chunk=$c 2>/dev/null | grep -v "separate launches\|gated\|trajectory |\|^lib\|^| config\|^|---"; done) > $O/phase_fused_chunks.md
-bash tools/gpu/pf_small_sweep.sh > $O/phase_fused_small.md 2>&1
 (for cfg in "TT-ProDMP" "cfg5 TT-ProMP"; do for B in 8192 65536; do n=40; [ $B -gt 10000 ] && n=10; python3 tools/gate_probe.py "$cfg" $B $n scale=0.2; python3 tools/gate_probe.py "$cfg" $B $n; done; done) 2>&1 | grep -v amdgpu > $O/gate_cost.txt
 bash tools/gpu/phase_wpb_sweep.sh 2>&1 | grep -v amdgpu > $O/phase_wpb.md
 MPK_BENCH_FORCE_DIST=1 python bench.py --steps 20 --warmup 5 --no-cpu --no-streaming > $O/bench_k20_rccl1.json 2> $O/bench_k20_rccl1.err

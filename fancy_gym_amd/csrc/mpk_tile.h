@@ -494,6 +494,41 @@ __device__ __forceinline__ void pd_tile_steps(const float* __restrict__ sP, cons
     // computing-and-discarding the other twelve cost as much as a full tile (trace of k_traj_pipe: 2 000 - 2 600 cycles).
     int nlive = 16;
     if (MASKED) {
+        // Round 6: a tile in which NO lane's executed steps end -- every lane either executes all 16 steps or none (a wave that holds
+        // finished episodes beside live ones: after an invalid plan, a reached horizon, a planning budget) -- runs the chain without
+        // the per-step selects; the lanes that execute nothing get their state back and write zeros afterwards.  With the selects
+        // and the ballot search below such a tile took 1.75 x a full one: TableTennis-ProDMP at 4 096 episodes, two finished episodes
+        // left behind by invalid plans, 47 -> 67 us (tools/gate_probe.py; profiles/r06_gate_cost.md).  Same operations on the live
+        // lanes, the same zeros and the same state on the others: same bits.
+        const bool dead = nst <= t0;
+        if (rows == 16 && __all(dead || nst >= t0 + 16) != 0) {
+            const double qs0 = qs, qds0 = qds;
+#pragma unroll
+            for (int tl = 0; tl < 16; ++tl) {
+                const double dp = PRE ? dpr[tl] : (double)pr[tl], dv = PRE ? dvr[tl] : (double)vr[tl];
+                double u;
+                if (CTRL == MPK_CTRL_MOTOR) u = pgd * (dp - qs) + dgd * (dv - qds);
+                else if (CTRL == MPK_CTRL_POSITION) u = dp;
+                else u = dv;
+                u = fmin(fmax(u, lod), hid);
+                const double qds_n = INTEGRATE ? qds + dtp * u : qds;
+                const double qs_n = INTEGRATE ? qs + dtp * qds_n : qs;
+                qds = qds_n; qs = qs_n;
+                if (WRITE_A) sA[tl * stride] = (float)u;
+                if (KEEP64 == 1) q64[tl] = qs;
+                if (KEEP64) u64[tl] = u;
+            }
+            if (dead) {
+                qs = qs0; qds = qds0;
+#pragma unroll
+                for (int tl = 0; tl < 16; ++tl) {
+                    if (WRITE_A) sA[tl * stride] = 0.0f;
+                    if (KEEP64 == 1) q64[tl] = qs0;
+                    if (KEEP64) u64[tl] = 0.0;
+                }
+            }
+            return;
+        }
         const int n0 = __builtin_amdgcn_readfirstlane(nst);
         if (__all(nst == n0)) {
             nlive = min(max(n0 - t0, 0), 16);

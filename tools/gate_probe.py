@@ -21,9 +21,13 @@ from learned_phase_bench import CASES, JNT_HIGH, JNT_LOW, make_params  # noqa: E
 def main():
     name, B, N = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     scale = 1.0
+    live = 0
     for kv in sys.argv[4:]:
         k, v = kv.split("=")
-        if k == "scale":
+        if k == "live":
+            live = int(v)           # 1: the done bytes are cleared before EVERY launch (both variants): what a violating PLAN costs, without the
+                                    # finished episodes it leaves behind in later launches
+        elif k == "scale":
             scale = float(v)        # weights x scale: small enough and no plan leaves the joint limits (the gate's cost without a violating wave)
         else:
             _lib.set_option(k, int(v))
@@ -54,6 +58,8 @@ def main():
                 delay_bound=kw.get("delay_bound"), valid=valid, penalty=pen)
 
     def run(gt, lean):
+        if live:
+            dn.zero_()
         if lean:
             eng.episode_return(params, ip, iv, closed, q, qd, replan=(ts, ps, dn, every, big, big), condition=True, gate=gt)
         else:

@@ -45,7 +45,7 @@ def table_tennis(B, episodes):
     P = bb.engine.num_params
     plans = []
     for _ in range(3):
-        p = 0.3 * torch.randn((B, P), generator=g)
+        p = (1.0 if "--wild" in sys.argv else 0.3) * torch.randn((B, P), generator=g)     # --wild: a third of the plans leaves the joint limits
         p[:, 0] = torch.rand(B, generator=g) * 0.6 + 0.85
         p[:, 1] = torch.rand(B, generator=g) * 0.08 + 0.06
         plans.append(p.cuda())

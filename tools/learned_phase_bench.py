@@ -131,13 +131,17 @@ def main():
                 pen = torch.empty(B, dtype=torch.float64, device=dev)
 
                 def f_gated():
-                    reset_state()
+                    # (the done bytes are cleared inside the timed graph -- a 1 KB memset --: a plan that violates a limit FINISHES its
+                    # episode, and replaying full-horizon steps on a batch that keeps such episodes measures the masked chain of their
+                    # waves, not the gate: profiles/r06_finished_episodes.md)
+                    done.zero_()
                     eng.replan_step(params, ip, iv, closed, q, qd, traj_steps, plan_steps, done, every, mpt, horizon, condition=True, out=out,
                                     gate=dict(pos_low=JNT_LOW, pos_high=JNT_HIGH, check_tau_delay=case["n_phase"] == 2,
                                               tau_bound=kw.get("tau_bound"), delay_bound=kw.get("delay_bound"), valid=valid, penalty=pen))
                 rows.append(("gated closed-loop step (validity + penalty inside)", f_gated, n_in + 3 * arr + 32 * D))
 
                 def f_gated_lean():
+                    done.zero_()
                     eng.episode_return(params, ip, iv, closed, q, qd, replan=(traj_steps, plan_steps, done, every, mpt, horizon), condition=True,
                                        gate=dict(pos_low=JNT_LOW, pos_high=JNT_HIGH, check_tau_delay=case["n_phase"] == 2,
                                                  tau_bound=kw.get("tau_bound"), delay_bound=kw.get("delay_bound"), valid=valid, penalty=pen))

@@ -1446,6 +1446,45 @@ def test_episode_search_on_the_device_reacher_improves_the_return():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("verbose", [2, 1])
+def test_table_tennis_example_batch_against_the_separate_launches(verbose):
+    """examples/batched_table_tennis_plans.py: its BatchedBlackBox (TableTennis-ProDMP Replan constants, validity gate, one launch per plan)
+    against a second instance stepped with the separate launches (fuse=False) on the same raw actions: flags, verdicts and executed
+    steps equal, the plant state equal -- over the three plans of an episode"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("batched_table_tennis_plans",
+                                                  os.path.join(os.path.dirname(GOLD), "..", "examples", "batched_table_tennis_plans.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    B = 300
+    a, b = mod.make_batch(B, verbose), mod.make_batch(B, 2)
+    rng = np.random.default_rng(12)
+    q0 = rng.uniform(-0.2, 0.2, (B, 7))
+    a.reset(q0); b.reset(q0)
+    P = a.engine.num_params
+    seen = 0
+    was_done = np.zeros(B, bool)
+    for k in range(3):
+        raw = (0.5 * rng.standard_normal((B, P))).astype(np.float32)
+        raw[:, 0] = rng.uniform(0.7, 1.6, B); raw[:, 1] = rng.uniform(0.04, 0.16, B)
+        oa, ob = a.step(raw), b.step(raw, fuse=False)
+        assert a.engine.last_kernel().startswith("k_phase_fused<prodmp,pipe,closed"), a.engine.last_kernel()
+        torch.cuda.synchronize()
+        for key in ("done", "trajectory_length"):
+            assert np.array_equal(oa[key].cpu().numpy(), ob[key].cpu().numpy()), (k, key)
+        # (verdict and flags of a plan for an episode that had ALREADY finished are nobody's business -- the reference resets such an
+        # episode; the two paths evaluate that plan at different times once episodes drift apart: compared where the plan counts)
+        live = ~was_done
+        assert live.any()
+        for key in ("valid", "terminated", "truncated"):
+            assert np.array_equal(oa[key].cpu().numpy()[live], ob[key].cpu().numpy()[live]), (k, key)
+        assert np.array_equal(a.q.cpu().numpy(), b.q.cpu().numpy()) and np.array_equal(a.qd.cpu().numpy(), b.qd.cpu().numpy())
+        seen += int(oa["terminated"].cpu().numpy()[live].sum())
+        was_done = ob["done"].cpu().numpy().astype(bool)
+    assert 0 < seen < B
+
+
+@pytest.mark.gpu
 def test_captured_episode_with_learned_phase_and_device_reward():
     """capture covers the plan+execute of a learned tau / delay configuration (one launch since round 6: k_phase_fused with its LDS
     table, > 64 KB of dynamic LDS) and the unfused reward path"""

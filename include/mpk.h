@@ -308,7 +308,9 @@ int mpk_poll_fault(mpk_handle h);
  * episode that was live -- terminated = !valid && !was_done --, a valid one that finished its horizon (or its last allowed plan) is
  * TRUNCATED -- truncated = done && valid.  valid: what mpk_replan_step_gated / mpk_episode_return_gated wrote; was_done: the done bytes
  * BEFORE that step (NULL = none was done: the first plan after a reset; otherwise the `done_out` snapshot of the step before); done: the
- * done bytes after it.  Bytes 0 / 1.  Replaces five elementwise launches of the host framework per gated step.
+ * done bytes after it.  Bytes 0 / 1.  Replaces five elementwise launches of the host framework per gated step.  (For an episode that had
+ * already finished, `valid` is the verdict on a plan nobody executes -- the reference resets such an episode --, and `truncated` follows it:
+ * callers mask with their own notion of which episodes are live.)
  */
 int mpk_gate_flags(mpk_handle h, const uint8_t* valid, const uint8_t* was_done, const uint8_t* done, uint8_t* terminated,
                    uint8_t* truncated, int32_t B, void* stream);

@@ -751,7 +751,7 @@ const OptKey kOptKeys[] = {
     {"ablations", &Tuning::ablations, 0, 1},     {"ring_tb", &Tuning::ring_tb, 1, 64},
     {"pd_helper", &Tuning::pd_helper, 0, 1},     {"phase_waves", &Tuning::phase_waves, 1, 32},
     {"phase_split", &Tuning::phase_split, 1, 64},   {"phase_pipe", &Tuning::phase_pipe, 0, 1},
-    {"phase_tiles", &Tuning::phase_tiles, 1, 4},
+    {"phase_tiles", &Tuning::phase_tiles, 1, 4},   {"pd_pipe", &Tuning::pd_pipe, 0, 1},
 };
 const OptKey* find_opt(const char* key) {
     if (!key) return nullptr;
@@ -877,7 +877,7 @@ static int pending_ring_fault(Handle* h) {
     if (!(f & 2)) { if (f) __atomic_fetch_or(h->h_fault, f & ~2, __ATOMIC_RELAXED); return MPK_OK; }
     char msg[512];      // (256 until round 6: the text is ~310 characters, and what got cut was "outputs ... are incomplete")
     std::snprintf(msg, sizeof msg, "k_traj_ring: a wave of an earlier launch on this handle gave up waiting for its partner (role mask 0x%x: "
-                  "1 producer / buffer, 2 ticket, 4 store engine / batch, 8 action writer, 16 consumer / tile, 32 consumer / writer, 64 reward helper, 128 k_phase_fused pipeline): "
+                  "1 producer / buffer, 2 ticket, 4 store engine / batch, 8 action writer, 16 consumer / tile, 32 consumer / writer, 64 reward helper, 128 k_phase_fused pipeline, 256 rollout pipeline): "
                   "outputs (closed loop: plant and replanning state too) of that launch are incomplete", (unsigned)f >> 8);
     set_error(msg);
     return MPK_EHIP;
@@ -1035,7 +1035,7 @@ int mpk_trajectory_actions(mpk_handle hh, const float* params, const float* init
                     nullptr, B, stream);
     if (r != MPK_OK) return r;
     return launch_pd_rollout(rd, h->dev.D, pos, vel, const_cast<double*>(c_pos), const_cast<double*>(c_vel), nullptr,
-                             actions, B, h->dev.T, stream, effective_tuning(h));
+                             actions, B, h->dev.T, stream, effective_tuning(h), h->d_fault);
 }
 
 int mpk_trajectory_rollout(mpk_handle hh, const float* params, const float* init_pos, const float* init_vel,
@@ -1063,7 +1063,7 @@ int mpk_trajectory_rollout(mpk_handle hh, const float* params, const float* init
     r = traj_common(h, params, init_pos, init_vel, nullptr, init_time_shared, pos, vel, nullptr, nullptr, nullptr,
                     nullptr, B, stream);
     if (r != MPK_OK) return r;
-    return launch_pd_rollout(rd, h->dev.D, pos, vel, q, qd, n_steps, actions, B, h->dev.T, stream, effective_tuning(h));
+    return launch_pd_rollout(rd, h->dev.D, pos, vel, q, qd, n_steps, actions, B, h->dev.T, stream, effective_tuning(h), h->d_fault);
 }
 
 int mpk_replan_step_gated(mpk_handle hh, const float* params, const float* init_pos, const float* init_vel,
@@ -1118,7 +1118,7 @@ int mpk_replan_step_gated(mpk_handle hh, const float* params, const float* init_
                               rp.horizon, h->dev.T, B, stream, gate ? gd.valid : nullptr);
     if (r != MPK_OK) return r;
     if (rp.done_out) MPK_HIP(hipMemcpyAsync(rp.done_out, rp.done, (size_t)B, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    r = launch_pd_rollout(rd, h->dev.D, pos, vel, q, qd, rp.seg_len, actions, B, h->dev.T, stream, effective_tuning(h));
+    r = launch_pd_rollout(rd, h->dev.D, pos, vel, q, qd, rp.seg_len, actions, B, h->dev.T, stream, effective_tuning(h), h->d_fault);
     if (r != MPK_OK) return r;
     if (rp.cond_pos) return launch_condition_gather(pos, vel, rp.seg_len, rp.cond_pos, rp.cond_vel, B, h->dev.T, h->dev.D, stream);
     return MPK_OK;
@@ -1229,7 +1229,11 @@ int mpk_pd_rollout(mpk_handle hh, const mpk_rollout_cfg* rc, const float* des_po
     if (r != MPK_OK) return r;
     if (B == 0 || T == 0 || h->dev.D == 0) return MPK_OK;
     MPK_ON_DEVICE(h->cfg.device);
-    return launch_pd_rollout(rd, h->dev.D, des_pos, des_vel, q, qd, n_steps, actions, B, T, stream, effective_tuning(h));
+    {
+        const int fr = pending_ring_fault(h);       // (k_pd_rollout_pipe reports through the handle's fault word)
+        if (fr != MPK_OK) return fr;
+    }
+    return launch_pd_rollout(rd, h->dev.D, des_pos, des_vel, q, qd, n_steps, actions, B, T, stream, effective_tuning(h), h->d_fault);
 }
 
 int mpk_reacher_rollout(mpk_handle hh, const mpk_rollout_cfg* rc, const float* des_pos, const float* des_vel,

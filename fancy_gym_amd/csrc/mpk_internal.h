@@ -35,7 +35,7 @@ struct Tuning {
     int mapping = -1, bulk = -1, quad = -1, pd_quad = -1, write_through = -1, ipw = -1, phase = -1, phase_table = -1,
         phase_chunk = -1, pd_simple = -1, split = -1, lds_pad = -1, pipe = -1, flat = -1, phase_flat = -1,
         ring = -1, ring_np = -1, ring_ns = -1, ring_m = -1, ring_dbg = -1, ring_parts = -1, tiles_wpb = -1, serial_order = -1, ring_nc = -1,
-        pd_generic = -1, dmp_response = -1, ablations = -1, ring_tb = -1, pd_helper = -1, phase_waves = -1, phase_split = -1, phase_pipe = -1, phase_tiles = -1;
+        pd_generic = -1, dmp_response = -1, ablations = -1, ring_tb = -1, pd_helper = -1, phase_waves = -1, phase_split = -1, phase_pipe = -1, phase_tiles = -1, pd_pipe = -1;
 };
 
 // ---- device-side configuration (kernel argument, by value) --------------------------------------------------
@@ -127,7 +127,7 @@ int launch_traj_rows(const DevCfg& c, const float* params, const float* init_pos
                      int B, int num_cu, void* stream, const char** kernel_name, const Tuning& tune);
 int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const float* des_vel, double* q,
                       double* qd, const int32_t* n_steps, float* actions, int B, int T, void* stream,
-                      const Tuning& tune);
+                      const Tuning& tune, int* fault = nullptr);
 // the fused entry points with a per-episode phase (learned tau / delay), promp / prodmp with <= 8 contraction columns and <= 16 DoF
 // (mpk_phase_fused.hip): rc.plant_type static = actions for the frozen state (q, qd), double integrator = closed loop; pos == nullptr:
 // nothing per step is stored (mpk_episode_return).  MPK_ENOTIMPL for other shapes.

@@ -507,6 +507,255 @@ __global__ void __launch_bounds__(HW ? 384 : 256) k_pd_rollout_tiles(const PdArg
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// k_pd_rollout_pipe (round 6): the rollout on existing trajectories of a SMALL launch as a producer / consumer workgroup -- the form
+// k_phase_fused<.., pipe> gave the learned-phase step.  At a few thousand episodes a wave of k_pd_rollout_tiles has its SIMD to itself and
+// pays 5 - 9 cycles for every instruction it issues: staging 950 - 1 400 cycles, chain 1 900 - 2 000, reward pass 100 - 330 per tile
+// (profiles/r06_rollout_reward.md) -- and only the chain links the tiles.  Here wave 0 (consumer) runs the chains of a unit's NG
+// groups, producer p = 1 .. NP stages tile p - 1, p - 1 + NP, ... (coalesced float4 loads -> its LDS slot), and, once the consumer has chained it,
+// stores the tile's actions and turns its float64 images into rewards (control cost; the end effector where an item is past
+// steps_before_reward) -- everything but the chain is off the critical path, so the reward costs the launch what its sixteen image
+// writes per tile cost the chain.  Hand-over: monotonic LDS counters as in k_phase_fused<.., pipe> (mpk_dev.h flag_*), one tile slot per
+// producer (while the consumer chains a tile, the other producer finishes the tile before it and stages the tile after it); every spin bounded, fault word on timeout.  Same device functions (pd_tile_steps, reacher_*_item): same bits.
+#ifndef MPK_ROLL_PIPE_NP
+#define MPK_ROLL_PIPE_NP 3       // producers per workgroup (A/B builds): with two, a producer's finish (action stores + two reward passes: ~2 300 cycles
+                                 // for a lone wave) + restaging left the consumer waiting ~600 cycles on every other tile (trace: profiles/r06_rollout_reward.md)
+#endif
+constexpr int kRollPipeNP = MPK_ROLL_PIPE_NP;
+template <int NG, bool RW, int CT, int DC>
+__global__ void __launch_bounds__(64 * (1 + kRollPipeNP)) k_pd_rollout_pipe(const PdArgs a) {
+    static_assert(RW || CT < 0, "only the reward kernels carry the controller as a template parameter");
+    constexpr int NP = kRollPipeNP, NB = NP;        // one tile slot per producer: stage -> (consumer chains) -> finish, the other producer's tile in between
+    constexpr int kShC = DC <= 1 ? 0 : (DC <= 2 ? 1 : (DC <= 4 ? 2 : (DC <= 8 ? 3 : 4)));
+    const int sh = DC > 0 ? kShC : a.sh;
+    constexpr int SLOT = 3 * kStageStride + (RW ? 2 * kStageStride : 0);       // floats per group: pos | vel | act (| u as float64)
+    extern __shared__ __attribute__((aligned(16))) float smem[];                // [NB][NG][SLOT] | prod[NP] .. [8] chained
+    int* const sSync = reinterpret_cast<int*>(smem + NB * NG * SLOT);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int D = DC > 0 ? DC : a.D, T = a.T, B = a.B, SEG = 16 * D, DP = 1 << sh, NTW = 16 >> sh;
+    const int NRT = (T + 15) >> 4;
+    const int units = (a.G + NG - 1) / NG;
+    if (threadIdx.x < 16) sSync[threadIdx.x] = 0;
+    __syncthreads();
+    if (wave == 0) {
+        // ---------------- consumer: the NG recurrences of a unit, one group per lane quarter ----------------
+        const int col = lane & 15, bl = col >> sh, d = col & (DP - 1), jq = lane >> 4;
+        const bool lane_serial = jq < NG && d < D;
+        double pgd = 0.0, dgd = 0.0, lod = 0.0, hid = 0.0;
+#pragma unroll
+        for (int dd = 0; dd < kMaxD; ++dd)
+            if (dd == d) { pgd = a.rc.pg[dd]; dgd = a.rc.dg[dd]; lod = a.rc.lo[dd]; hid = a.rc.hi[dd]; }
+        lod = __builtin_canonicalize(lod); hid = __builtin_canonicalize(hid);
+        const double dtp = a.rc.dt;
+        int g = 0;                                       // tiles this workgroup has passed (all units)
+        int have = 0;
+        MPK_STAMP(1);
+        for (int un = blockIdx.x; un < units; un += gridDim.x) {
+            const int g0 = un * NG;
+            const int bs = (g0 + jq) * NTW + bl;
+            const bool serial = lane_serial && g0 + jq < a.G && bs < B;
+            double qs = 0.0, qds = 0.0;
+            int nst = T, s0 = 0;
+            if (serial) {
+                const size_t si = (size_t)bs * D + d;
+                qs = a.Q[si]; qds = a.QD[si];
+                if (a.n_steps) nst = min(a.n_steps[bs], T);
+                if (RW && a.step0) s0 = a.step0[bs];
+            }
+            asm volatile("" : "+v"(qs), "+v"(qds), "+v"(nst), "+v"(s0));
+            for (int rt = 0; rt < NRT; ++rt, ++g) {
+                const int p = g % NP, k = g / NP;
+                if (rt < 16) MPK_STAMP(10 + 3 * rt);
+                if (have < k + 1 && !flag_wait(sSync + p, k + 1, a.fault, 256)) return;
+                have = flag_load(sSync + (g + 1) % NP);        // the next tile's counter: read now, used after the chain
+                if (rt < 16) MPK_STAMP(11 + 3 * rt);
+                float* sg = smem + ((g % NB) * NG + (jq < NG ? jq : 0)) * SLOT;
+                const int rows = min(16, T - rt * 16);
+                // RW: can any (episode, step) item of this tile carry the distance term?  (the producers apply the same rule)
+                bool tile_dist = RW;
+                if (RW && !MPK_RW_ALWAYS_TRIG) tile_dist = __any(serial && s0 + rt * 16 + 15 >= a.steps_before_reward) != 0;
+                if (serial) {
+                    const int o0 = bl * SEG + d;
+                    const bool full_tile = rows == 16 && __all(nst >= rt * 16 + 16) != 0;
+                    auto tile_steps = [&](auto ctrl_tag, auto plant_tag) {
+                        constexpr int CTRL = decltype(ctrl_tag)::value;
+                        constexpr bool INTEG = decltype(plant_tag)::value == MPK_PLANT_DOUBLE_INTEGRATOR;
+                        double* q64 = reinterpret_cast<double*>(sg) + col * kRwCol;
+                        double* u64 = reinterpret_cast<double*>(sg + 3 * kStageStride) + col * kRwCol;
+                        auto go = [&](auto keep_tag) {
+                            constexpr int KEEP = decltype(keep_tag)::value;
+                            if (full_tile)
+                                pd_tile_steps<CTRL, false, INTEG, KEEP>(sg + o0, sg + kStageStride + o0, sg + 2 * kStageStride + o0, D, rt * 16, nst,
+                                                                        pgd, dgd, lod, hid, dtp, qs, qds, q64, u64);
+                            else
+                                pd_tile_steps<CTRL, true, INTEG, KEEP>(sg + o0, sg + kStageStride + o0, sg + 2 * kStageStride + o0, D, rt * 16, nst,
+                                                                       pgd, dgd, lod, hid, dtp, qs, qds, q64, u64, rows);
+                        };
+                        if (!RW) go(std::integral_constant<int, 0>());
+                        else if (tile_dist) go(std::integral_constant<int, 1>());
+                        else go(std::integral_constant<int, 2>());
+                    };
+                    using std::integral_constant;
+                    const bool dint = a.rc.plant_type == MPK_PLANT_DOUBLE_INTEGRATOR;
+                    if constexpr (CT >= 0) tile_steps(integral_constant<int, CT>(), integral_constant<int, MPK_PLANT_DOUBLE_INTEGRATOR>());
+                    else switch (a.rc.controller_type) {
+                        case MPK_CTRL_MOTOR:
+                            if (dint) tile_steps(integral_constant<int, MPK_CTRL_MOTOR>(), integral_constant<int, MPK_PLANT_DOUBLE_INTEGRATOR>());
+                            else tile_steps(integral_constant<int, MPK_CTRL_MOTOR>(), integral_constant<int, MPK_PLANT_STATIC>());
+                            break;
+                        case MPK_CTRL_POSITION:
+                            if (dint) tile_steps(integral_constant<int, MPK_CTRL_POSITION>(), integral_constant<int, MPK_PLANT_DOUBLE_INTEGRATOR>());
+                            else tile_steps(integral_constant<int, MPK_CTRL_POSITION>(), integral_constant<int, MPK_PLANT_STATIC>());
+                            break;
+                        default:
+                            if (dint) tile_steps(integral_constant<int, MPK_CTRL_VELOCITY>(), integral_constant<int, MPK_PLANT_DOUBLE_INTEGRATOR>());
+                            else tile_steps(integral_constant<int, MPK_CTRL_VELOCITY>(), integral_constant<int, MPK_PLANT_STATIC>());
+                            break;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (rt < 16) MPK_STAMP(12 + 3 * rt);
+                if (lane == 0) flag_store(sSync + 8, g + 1);
+            }
+            MPK_STAMP(90);
+            if (serial && a.rc.plant_type != MPK_PLANT_STATIC) {
+                const size_t si = (size_t)bs * D + d;
+                a.Q[si] = qs; a.QD[si] = qds;
+            }
+        }
+        return;
+    }
+    // ---------------- producers: staging, action stores and the reward pass of tiles p, p + NP, ... ----------------
+    const int p = wave - 1;
+    const int seg4 = SEG >> 2;
+    const int sseg = DC > 0 ? lane / (4 * DC) : (int)(((unsigned)lane * a.inv_seg4) >> 16);
+    const int w4 = (lane - sseg * seg4) * 4;
+    const unsigned rofs = (unsigned)(sseg * SEG + w4);
+    const size_t gofs = (size_t)sseg * T * D + w4;
+    constexpr int kRwPasses = 2;
+    int g = 0;
+    for (int un = blockIdx.x; un < units; un += gridDim.x) {
+        const int g0 = un * NG;
+        const size_t ubase = (size_t)g0 * NTW * T * D;
+        const float* const bpos = a.des_pos + ubase;
+        const float* const bvel = a.des_vel + ubase;
+        float* const bact = a.actions ? a.actions + ubase : nullptr;
+        bool mover[NG];
+        unsigned goff[NG];
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int b0 = (g0 + j) * NTW;
+            mover[j] = g0 + j < a.G && sseg < NTW && b0 + sseg < B;
+            goff[j] = (unsigned)(((size_t)j * NTW * T * D + gofs) * sizeof(float));
+        }
+        // RW: what the pass needs per episode, once per unit (k_pd_rollout_tiles: the same slots, item = pass * 64 + lane)
+        const int rw_npass = RW ? (NG * NTW + 3) >> 2 : 0;
+        int rw_b[kRwPasses], rw_ns[kRwPasses], rw_s0[kRwPasses], rw_q[kRwPasses];
+        double rw_gx[kRwPasses], rw_gy[kRwPasses];
+        if (RW) {
+#pragma unroll
+            for (int q = 0; q < kRwPasses; ++q) {
+                const int je = 4 * q + (lane >> 4), e = je & (NTW - 1), j = je >> (4 - sh);
+                const int b = (g0 + j) * NTW + e;
+                const bool ok = q < rw_npass && j < NG && g0 + j < a.G && b < B;
+                rw_b[q] = ok ? b : -1;
+                rw_q[q] = ok ? (j * SLOT) * 4 + (e * DP * kRwCol + (lane & 15)) * 8 : (lane & 15) * 8;
+                rw_ns[q] = ok ? (a.n_steps ? min(a.n_steps[b], T) : T) : 0;
+                rw_s0[q] = ok && a.step0 ? a.step0[b] : 0;
+                rw_gx[q] = ok ? a.goal[2 * (size_t)b] : 0.0;
+                rw_gy[q] = ok ? a.goal[2 * (size_t)b + 1] : 0.0;
+            }
+        }
+        // the tile's actions and rewards leave once the consumer has chained it
+        auto finish = [&](const int rt, const int gg) {
+            const float* sS = smem + ((gg % NB) * NG) * SLOT;
+            const int rows = min(16, T - rt * 16);
+            if (a.actions) {
+                const bool okt = w4 < rows * D;
+                const unsigned tb = (unsigned)(rt * SEG) * 4u;
+#pragma unroll
+                for (int j = 0; j < NG; ++j) {
+                    if (mover[j] && okt) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(sS + j * SLOT + 2 * kStageStride + rofs);
+                        float* const dst = reinterpret_cast<float*>(reinterpret_cast<char*>(bact) + goff[j] + tb);
+                        if (a.wt) store16<true>(dst, v);
+                        else store16<false>(dst, v);
+                    }
+                }
+            }
+            if (RW) {
+                const int tl = lane & 15, t = rt * 16 + tl;
+                bool mine = false;
+#pragma unroll
+                for (int q = 0; q < kRwPasses; ++q) mine = mine || (rw_b[q] >= 0 && rw_s0[q] + rt * 16 + 15 >= a.steps_before_reward);
+                const bool tile_dist = MPK_RW_ALWAYS_TRIG || __any(mine) != 0;
+#pragma unroll 1
+                for (int q = 0; q < rw_npass; ++q) {
+                    const int pb = q ? rw_b[1] : rw_b[0], pns = q ? rw_ns[1] : rw_ns[0], ps0 = q ? rw_s0[1] : rw_s0[0];
+                    const int pq = q ? rw_q[1] : rw_q[0];
+                    const bool live = pb >= 0 && t < pns;
+                    const bool dist_on = live && ps0 + t >= a.steps_before_reward;
+                    const char* sb = reinterpret_cast<const char*>(sS) + pq;
+                    const double* qv = reinterpret_cast<const double*>(sb);
+                    const double* uv = reinterpret_cast<const double*>(sb + 3 * kStageStride * 4);
+                    double r = DC > 0 ? reacher_ctrl_item<DC>(uv, D) : reacher_ctrl_item_d(uv, D);
+                    if (MPK_RW_ALWAYS_TRIG || (tile_dist && __any(dist_on) != 0)) {
+                        if (DC == 5) r = reacher_reward_item<5>(qv, uv, D, dist_on, q ? rw_gx[1] : rw_gx[0], q ? rw_gy[1] : rw_gy[0]);
+                        else r = reacher_reward_item<0>(qv, uv, D, dist_on, q ? rw_gx[1] : rw_gx[0], q ? rw_gy[1] : rw_gy[0]);
+                    }
+                    r = live ? r : 0.0;
+                    if (tl < rows && pb >= 0) {
+                        // (write-through like the actions while the launch is cache resident: plain stores leave dirty lines that the END of the
+                        // kernel has to write back -- measured on the tail of the launch, not on any wave)
+                        float* const rp = reinterpret_cast<float*>(a.rewards + (size_t)pb * T + t);
+                        const f32x2 rb = __builtin_bit_cast(f32x2, r);
+                        if (a.wt) store8<true>(rp, rb); else store8<false>(rp, rb);
+                    }
+                }
+            }
+        };
+        // the producer's tiles of this unit: rt = r0, r0 + NP, ...; the inputs of the NEXT one are requested before the wait for the consumer
+        // (registers: their round trip to the memory-side cache -- ~1 500 cycles -- passes under the consumer's chain)
+        f32x4 lp[NG], lv[NG];
+        auto fetch = [&](const int rt) {
+            const bool okt = w4 < min(16, T - rt * 16) * D;
+            const unsigned tb = (unsigned)(rt * SEG) * 4u;
+#pragma unroll
+            for (int j = 0; j < NG; ++j) {
+                lp[j] = f32x4{0, 0, 0, 0}; lv[j] = lp[j];
+                if (mover[j] && okt) {
+                    lp[j] = ld_off(reinterpret_cast<const f32x4*>(bpos), goff[j] + tb);
+                    lv[j] = ld_off(reinterpret_cast<const f32x4*>(bvel), goff[j] + tb);
+                }
+            }
+        };
+        const int r0 = ((p - g) % NP + NP) % NP;          // first tile of this unit with (g + rt) % NP == p
+        if (r0 < NRT) fetch(r0);
+        for (int rt = r0; rt < NRT; rt += NP) {
+            const int gg = g + rt, k = gg / NP;
+            float* sS = smem + ((gg % NB) * NG) * SLOT;
+            {
+                const bool okt = w4 < min(16, T - rt * 16) * D;
+#pragma unroll
+                for (int j = 0; j < NG; ++j) {
+                    if (mover[j] && okt) {
+                        *reinterpret_cast<f32x4*>(sS + j * SLOT + rofs) = lp[j];
+                        *reinterpret_cast<f32x4*>(sS + j * SLOT + kStageStride + rofs) = lv[j];
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) flag_store(sSync + p, k + 1);
+            if (rt + NP < NRT) fetch(rt + NP);
+            if (!flag_wait(sSync + 8, gg + 1, a.fault, 256)) return;     // the consumer has chained it: actions and rewards leave, the slot is free
+            finish(rt, gg);
+            __builtin_amdgcn_wave_barrier();
+        }
+        g += NRT;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // k_reacher_rollout: k_pd_rollout + SimpleReacherEnv's per-step reward (simple_reacher.py:56-72).  One lane per
 // (episode, DoF), 64 / D episodes per wave; the reward couples an episode's DoFs (cumulative joint angles -> end
 // effector, base_reacher.py:97-104), which is a segmented scan over the D neighbouring lanes.  float64 without FMA
@@ -659,6 +908,28 @@ int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
         // 65 536: 229 / 213, 262 144: 871 / 840 (profiles/r06_rollout_reward.md)
         else if (quad_mode == 1) ng = pa.G >= 10 * simds ? 2 : (pa.G >= 5 * simds ? 4 : (2 * pa.G >= 3 * simds ? 2 : 1));
         while (ng > 1 && ng * NTW > 8) ng >>= 1;       // the reward pass holds the inputs of two passes (eight episodes) in registers
+        // small launches: the producer / consumer workgroup (k_pd_rollout_pipe: four groups per consumer, so at most two episodes per group),
+        // while two workgroups per CU (60 KB of LDS each) hold the launch; "pd_pipe" 1 / 0 forces / forbids
+        {
+            const long punits = ((long)pa.G + 3) / 4;
+            bool pipe = NTW <= 2 && tune.pd_simple != 1 && tune.pd_quad < 0 && punits <= 2L * 256;
+            if (tune.pd_pipe >= 0) pipe = tune.pd_pipe == 1 && NTW <= 2;
+            if (pipe) {
+                const size_t plds = ((size_t)kRollPipeNP * 4 * 5 * kStageStride + 16) * sizeof(float);
+                const int pblocks = (int)(punits < 2L * 256 ? punits : 2L * 256);
+                auto gop = [&](auto kern) -> int {
+                    if (plds > kLdsDefault) {
+                        hipError_t e = allow_full_lds(kern);
+                        if (e != hipSuccess) { set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return MPK_EHIP; }
+                    }
+                    hipLaunchKernelGGL(kern, dim3(pblocks), dim3(64 * (1 + kRollPipeNP)), plds, (hipStream_t)stream, pa);
+                    MPK_LAUNCH_CHECK();
+                    return MPK_OK;
+                };
+                if (rc.controller_type == MPK_CTRL_MOTOR && D == 5 && tune.pd_generic != 1) return gop(k_pd_rollout_pipe<4, true, MPK_CTRL_MOTOR, 5>);
+                return gop(k_pd_rollout_pipe<4, true, -1, 0>);
+            }
+        }
         const int units = (pa.G + ng - 1) / ng;
         int blocks = (units + 3) / 4;
         if (blocks > 2048) blocks = 2048;
@@ -706,7 +977,7 @@ int launch_reacher_rollout(const RolloutDev& rc, int D, const float* des_pos,
 
 #ifndef MPK_DEVICE_ONLY
 int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const float* des_vel, double* q, double* qd,
-                      const int32_t* n_steps, float* actions, int B, int T, void* stream, const Tuning& tune) {
+                      const int32_t* n_steps, float* actions, int B, int T, void* stream, const Tuning& tune, int* fault) {
     auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     const int last_rows = T - (T - 1) / 16 * 16;
     const bool tiles_ok = D >= 1 && D <= kMaxD && (T * D) % 4 == 0 && (last_rows * D) % 4 == 0 && aligned16(des_pos) &&
@@ -717,7 +988,7 @@ int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const f
         pa.actions = actions; pa.D = D; pa.B = B; pa.T = T;
         pa.wt = (double)B * T * D * 12.0 <= kCachedBytes ? 1 : 0;     // desired (pos, vel) + actions stay cached
         if (tune.write_through >= 0) pa.wt = tune.write_through != 0 ? 1 : 0;
-        pa.step0 = nullptr; pa.goal = nullptr; pa.rewards = nullptr; pa.steps_before_reward = 0; pa.fault = nullptr;
+        pa.step0 = nullptr; pa.goal = nullptr; pa.rewards = nullptr; pa.steps_before_reward = 0; pa.fault = fault;
         int sh = 0;
         while ((1 << sh) < D) ++sh;
         pa.sh = sh;
@@ -735,6 +1006,22 @@ int launch_pd_rollout(const RolloutDev& rc, int D, const float* des_pos, const f
         if (quad_mode == 2) ng = 4;
         else if (quad_mode == 3) ng = 2;
         else if (quad_mode == 1) ng = pa.G >= 5 * simds ? 4 : (2 * pa.G >= 3 * simds ? 2 : 1);
+        // small launches: the producer / consumer workgroup (k_pd_rollout_pipe), while four workgroups per CU hold the launch
+        {
+            const long punits = ((long)pa.G + 3) / 4;
+            bool pipe = tune.pd_quad < 0 && punits <= 4L * 256;
+            if (tune.pd_pipe >= 0) pipe = tune.pd_pipe == 1;
+            if (pipe) {
+                const size_t plds = ((size_t)kRollPipeNP * 4 * 3 * kStageStride + 16) * sizeof(float);
+                const int pblocks = (int)(punits < 4L * 256 ? punits : 4L * 256);
+                const dim3 pb(64 * (1 + kRollPipeNP));
+                if (D == 7 && tune.pd_generic != 1) hipLaunchKernelGGL((k_pd_rollout_pipe<4, false, -1, 7>), dim3(pblocks), pb, plds, (hipStream_t)stream, pa);
+                else if (D == 5 && tune.pd_generic != 1) hipLaunchKernelGGL((k_pd_rollout_pipe<4, false, -1, 5>), dim3(pblocks), pb, plds, (hipStream_t)stream, pa);
+                else hipLaunchKernelGGL((k_pd_rollout_pipe<4, false, -1, 0>), dim3(pblocks), pb, plds, (hipStream_t)stream, pa);
+                MPK_LAUNCH_CHECK();
+                return MPK_OK;
+            }
+        }
         const int units = (pa.G + ng - 1) / ng;
         int blocks = (units + 3) / 4;
         if (blocks > 2048) blocks = 2048;

@@ -712,13 +712,16 @@ def test_four_groups_per_wave_while_the_outputs_fit_the_memory_side_cache(mpk_op
         assert eng.last_kernel().startswith(want), (B, eng.last_kernel())
 
 
-@pytest.mark.parametrize("quad", ["0", "2"])
+@pytest.mark.parametrize("quad", ["0", "2", "pipe"])
 @pytest.mark.parametrize("D,T", [(1, 50), (3, 10), (4, 17), (16, 40), (5, 100), (20, 12)])
 def test_pd_rollout_on_every_shape_class(D, T, quad, monkeypatch, mpk_option):
-    """tile-streaming kernel (D <= 16, float4-aligned; one or four groups per wave) and the generic kernel (everything
-    else) against the oracle"""
+    """tile-streaming kernel (D <= 16, float4-aligned; one or four groups per wave), its producer / consumer form (k_pd_rollout_pipe) and
+    the generic kernel (everything else) against the oracle"""
     from tests.test_gpu_edge_cases import cfg_for
-    mpk_option("pd_quad", quad)
+    if quad == "pipe":
+        mpk_option("pd_pipe", 1)
+    else:
+        mpk_option("pd_quad", quad)
     pc, bc, tc, dt, dur = cfg_for("promp", D, 3, T)
     eng = make_engine(pc, bc, tc, dt, dur)
     B = 23
@@ -1087,13 +1090,16 @@ def test_vector_black_box_equals_individual_wrappers(mp_type, replan, workers):
 @pytest.mark.gpu
 @pytest.mark.parametrize("controller", ["motor", "position", "velocity"])
 @pytest.mark.parametrize("D,B,T", [(2, 1, 200), (5, 300, 200), (5, 65, 37), (7, 130, 100), (16, 9, 12), (20, 7, 10)])
-@pytest.mark.parametrize("mode", ["tiles", "quad", "generic"])
+@pytest.mark.parametrize("mode", ["tiles", "quad", "generic", "pipe"])
 def test_reacher_rollout_matches_oracle(controller, D, B, T, mode, monkeypatch, mpk_option):
     """actions and plant state bit for bit (float64, no FMA); rewards to 1e-12 (device vs host libm cos / sin).  Kernels:
     tile-streaming with the per-tile parallel reward phase (one or four groups per wave), and the generic
     lane-per-(episode, DoF) kernel with segmented scans"""
     from fancy_gym_amd import TrajectoryEngine
-    mpk_option("pd_quad", "2" if mode == "quad" else "0")
+    if mode == "pipe":
+        mpk_option("pd_pipe", 1)          # k_pd_rollout_pipe (a consumer wave and three producers per four groups; needs <= 2 episodes per group)
+    else:
+        mpk_option("pd_quad", "2" if mode == "quad" else "0")
     if mode == "generic":
         mpk_option("pd_simple", "1")
     eng = TrajectoryEngine(device=0, mp_type="promp", phase_type="linear", basis_type="rbf", num_dof=D, num_basis=3,
@@ -1123,14 +1129,19 @@ def test_reacher_rollout_matches_oracle(controller, D, B, T, mode, monkeypatch, 
 @pytest.mark.gpu
 @pytest.mark.parametrize("sbr", [0, 199, 100000])
 @pytest.mark.parametrize("D,B,T", [(5, 300, 200), (5, 37, 100), (2, 40, 200), (7, 50, 64)])
-@pytest.mark.parametrize("mode", ["tiles", "quad", "generic", "tiles_rt", "tiles_nohelper", "quad_helper", "duo_helper"])
+@pytest.mark.parametrize("mode", ["tiles", "quad", "generic", "tiles_rt", "tiles_nohelper", "quad_helper", "duo_helper", "pipe", "pipe_rt"])
 def test_reacher_reward_with_and_without_the_distance_term(sbr, D, B, T, mode, mpk_option):
     """simple_reacher.py:62-63: the distance term only from `steps_before_reward` on (199 of 200 steps carry none at the reference's
     setting, :31).  The reward pass evaluates the end effector only where one of a pass's items needs it: steps_before_reward = 0
     keeps the all-live path covered, 100000 the path without any, 199 with step0 = 0 is the reference's episode (the last step
     only).  Rewards without the distance term are -sum(action ** 2) left to right: bit for bit on the tile kernels."""
     from fancy_gym_amd import TrajectoryEngine
-    mpk_option("pd_quad", "2" if mode.startswith("quad") else ("3" if mode.startswith("duo") else "0"))
+    if mode.startswith("pipe"):
+        mpk_option("pd_pipe", 1)          # k_pd_rollout_pipe
+        if mode == "pipe_rt":
+            mpk_option("pd_generic", "1")
+    else:
+        mpk_option("pd_quad", "2" if mode.startswith("quad") else ("3" if mode.startswith("duo") else "0"))
     if mode == "generic":
         mpk_option("pd_simple", "1")
     if mode == "tiles_rt":

@@ -97,6 +97,7 @@ def test_random_configuration_matches_oracle(seed, monkeypatch, mpk_option):
     r6 = np.random.default_rng(66_000 + seed)       # round 6: k_phase_fused's tile split (frozen-state actions) and producer / consumer form
     mpk_option("phase_split", int(r6.choice([-1, -1, 1, 2, 3, 8])))
     mpk_option("phase_pipe", int(r6.choice([-1, 0, 1])))
+    mpk_option("pd_pipe", int(r6.choice([-1, 0, 1])))          # (the rollout on existing trajectories as a producer / consumer workgroup)
     if tc.trajectory_generator_type == "prodmp":
         tc = dataclasses.replace(tc, relative_goal_mode=str(r2.choice(["after_scale", "before_scale"])),
                                  goal_offset_mode=str(r2.choice(["ignore", "add"])), goal_offset=float(r2.uniform(-0.5, 0.5)))
@@ -534,7 +535,9 @@ def test_random_batched_episode_follows_the_oracle_sequence(seed, mpk_option):
                       ("split", [-1, 0, 1]), ("pd_quad", [-1, 0, 2]), ("pd_simple", [-1, 0, 1]), ("phase_flat", [-1, 0, 1]),
                       ("phase_chunk", [-1, 1, 2, 3, 4, 7])):
         mpk_option(key, int(rng.choice(vals)))
-    mpk_option("phase_pipe", int(np.random.default_rng(66_000 + seed).choice([-1, 0, 1])))     # (round 6; own generator: cases keep their shapes)
+    r6 = np.random.default_rng(66_000 + seed)          # (round 6; own generator: cases keep their shapes)
+    mpk_option("phase_pipe", int(r6.choice([-1, 0, 1])))
+    mpk_option("pd_pipe", int(r6.choice([-1, 0, 1])))
     kw = dict(plant="double_integrator", max_planning_times=mpt, condition_on_desired=cod)
     if replan:
         kw["replanning_every"] = every

@@ -19,6 +19,7 @@ from tools.closed_bench import CFG2, DG, PG, graph_time  # noqa: E402
 
 def main():
     batches = [int(a) for a in sys.argv[1:] if a.isdigit()] or [4096, 8192, 65536]
+    extra = {k: int(v) for k, v in (a.split("=") for a in sys.argv[1:] if "=" in a and not a.startswith("--"))}     # options for every row
     torch.cuda.set_device(0)
     g = torch.Generator().manual_seed(0)
     print(f"lib: {_lib.LIB_PATH}")
@@ -55,7 +56,7 @@ def main():
                 variants = ({}, {"write_through": 0}, {"write_through": 1}, {"pd_quad": 0, "write_through": 0}, {"pd_quad": 3, "write_through": 0})
             for opts in variants:
                 _lib.reset_options()
-                for k, v in opts.items():
+                for k, v in list(extra.items()) + list(opts.items()):
                     _lib.set_option(k, v)
                 t = graph_time(fn)
                 print(f"| {name} | {B} | {opts or 'auto'} | {t * 1e6:.1f} | {B / t:.3e} | {B * nbytes / t / 1e9:.0f} | "

@@ -513,9 +513,12 @@ __global__ void __launch_bounds__(HW ? 384 : 256) k_pd_rollout_tiles(const PdArg
 // (profiles/r06_rollout_reward.md) -- and only the chain links the tiles.  Here wave 0 (consumer) runs the chains of a unit's NG
 // groups, producer p = 1 .. NP stages tile p - 1, p - 1 + NP, ... (coalesced float4 loads -> its LDS slot), and, once the consumer has chained it,
 // stores the tile's actions and turns its float64 images into rewards (control cost; the end effector where an item is past
-// steps_before_reward) -- everything but the chain is off the critical path, so the reward costs the launch what its sixteen image
-// writes per tile cost the chain.  Hand-over: monotonic LDS counters as in k_phase_fused<.., pipe> (mpk_dev.h flag_*), one tile slot per
-// producer (while the consumer chains a tile, the other producer finishes the tile before it and stages the tile after it); every spin bounded, fault word on timeout.  Same device functions (pd_tile_steps, reacher_*_item): same bits.
+// steps_before_reward) -- everything but the chain is off the critical path: the reward costs the consumer its sixteen image writes per
+// tile (+ 13 %), and the launch the end-effector passes of the LAST tile, which run after the consumer has finished (~2 us of tail).
+// Hand-over: monotonic LDS counters as in k_phase_fused<.., pipe> (mpk_dev.h flag_*), one tile slot per producer (while the consumer
+// chains a tile, the other producers finish the tiles before it and stage the tiles after it); every spin bounded, fault word on
+// timeout.  Same device functions (pd_tile_steps, reacher_*_item): same bits.  Measured: - 10 % against k_pd_rollout_tiles below 8 192
+// episodes, with and without the reward (profiles/r06_rollout_reward.md, section 4).
 #ifndef MPK_ROLL_PIPE_NP
 #define MPK_ROLL_PIPE_NP 3       // producers per workgroup (A/B builds): with two, a producer's finish (action stores + two reward passes: ~2 300 cycles
                                  // for a lone wave) + restaging left the consumer waiting ~600 cycles on every other tile (trace: profiles/r06_rollout_reward.md)

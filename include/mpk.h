@@ -223,7 +223,7 @@ int mpk_set_duration(mpk_handle h, double duration, double dt);
  *                   automatic for closed-loop launches of a few thousand episodes)
  *   "phase_tiles"   1 .. 4: 16-step tiles k_phase_fused stages before it flushes (runs of n x 16 D floats per episode and array)
  *   "pd_pipe"       1 / 0: force / forbid the producer / consumer form of the rollout on existing trajectories (k_pd_rollout_pipe: a consumer
- *                   wave and two producers per four groups; automatic for a few thousand episodes)
+ *                   wave and three producers per four groups; automatic for a few thousand episodes)
  *   "pd_helper"     1 the reward rollout's control-cost pass on two helper waves of a six-wave workgroup instead of on the chain waves
  *                   (measured slower at every size: never automatic; ABI 4: the variant is compiled into -DMPK_ABLATIONS builds only,
  *                   a release library accepts the key and runs the pass on the chain waves -- identical results)

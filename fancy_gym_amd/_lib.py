@@ -29,7 +29,7 @@ DMP_FIRST_SAMPLE_MODES = {"init": 0, "step": 1}
 REWARD_TYPES = {None: 0, "none": 0, "simple_reacher": 1}       # MPK_REWARD_*
 AGG_MODES = {"sum": 0, "mean": 1, "last": 2}                   # MPK_AGG_*
 OPTION_KEYS = ("mapping", "bulk", "quad", "pd_quad", "write_through", "ipw", "phase", "phase_table", "phase_chunk",
-               "pd_simple", "split", "lds_pad", "pipe", "flat", "phase_flat", "ring", "ring_np", "ring_ns", "ring_m", "ring_dbg", "ring_parts", "tiles_wpb", "serial_order", "ring_nc", "pd_generic", "dmp_response", "ablations", "ring_tb", "pd_helper", "phase_waves", "phase_split", "phase_pipe", "phase_tiles", "pd_pipe")
+               "pd_simple", "split", "lds_pad", "pipe", "flat", "phase_flat", "ring", "ring_np", "ring_ns", "ring_m", "ring_dbg", "ring_parts", "tiles_wpb", "serial_order", "ring_nc", "pd_generic", "dmp_response", "ablations", "ring_tb", "pd_helper", "phase_waves", "phase_split", "phase_pipe", "pd_pipe")
 
 
 class MPKLibraryError(RuntimeError):

@@ -751,7 +751,7 @@ const OptKey kOptKeys[] = {
     {"ablations", &Tuning::ablations, 0, 1},     {"ring_tb", &Tuning::ring_tb, 1, 64},
     {"pd_helper", &Tuning::pd_helper, 0, 1},     {"phase_waves", &Tuning::phase_waves, 1, 32},
     {"phase_split", &Tuning::phase_split, 1, 64},   {"phase_pipe", &Tuning::phase_pipe, 0, 1},
-    {"phase_tiles", &Tuning::phase_tiles, 1, 4},   {"pd_pipe", &Tuning::pd_pipe, 0, 1},
+    {"pd_pipe", &Tuning::pd_pipe, 0, 1},
 };
 const OptKey* find_opt(const char* key) {
     if (!key) return nullptr;

@@ -35,7 +35,7 @@ struct Tuning {
     int mapping = -1, bulk = -1, quad = -1, pd_quad = -1, write_through = -1, ipw = -1, phase = -1, phase_table = -1,
         phase_chunk = -1, pd_simple = -1, split = -1, lds_pad = -1, pipe = -1, flat = -1, phase_flat = -1,
         ring = -1, ring_np = -1, ring_ns = -1, ring_m = -1, ring_dbg = -1, ring_parts = -1, tiles_wpb = -1, serial_order = -1, ring_nc = -1,
-        pd_generic = -1, dmp_response = -1, ablations = -1, ring_tb = -1, pd_helper = -1, phase_waves = -1, phase_split = -1, phase_pipe = -1, phase_tiles = -1, pd_pipe = -1;
+        pd_generic = -1, dmp_response = -1, ablations = -1, ring_tb = -1, pd_helper = -1, phase_waves = -1, phase_split = -1, phase_pipe = -1, pd_pipe = -1;
 };
 
 // ---- device-side configuration (kernel argument, by value) --------------------------------------------------

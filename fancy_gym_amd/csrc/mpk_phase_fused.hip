@@ -58,7 +58,6 @@ struct FusedArgs {
     double* ret;                // [B] out, optional: the aggregated reward of the verbose < 2 step (no device reward here: 0)
     int32_t* seg_out;           // [B] out, optional: executed steps
     int B, chunk, x_pad, pitch, wave_floats, t_pad, c_pad, tab_pad, car_pad, wt, vec_ok, td3;
-    int nsub;                   // 16-step tiles per flush (images of nsub tiles: HBM-streaming launches write nsub x 16 D floats per run)
     int nsplit, split_tiles;    // frozen-state actions: a chunk's tiles in nsplit units of split_tiles tiles (one unit per wave trip)
     unsigned inv_d, inv_ch;     // 65536 / D + 1, 65536 / (pitch / 4) + 1: lane / D and job / chunks-per-image as multiply-high
     int* fault;                 // the handle's fault word (PIPE: a wave that gives up waiting for its partner says so)
@@ -565,26 +564,21 @@ __global__ void __launch_bounds__(PIPE ? 64 * (1 + kPipeProducers) : (TL ? MPK_P
             }
         };
         // C: the tile's runs of nrows * D floats per episode and array (MASK: 1 pos | 2 vel | 4 actions)
-        auto do_C = [&](const int rt, const float* const iP, auto mask_tag, const int ntiles = 1) {
+        auto do_C = [&](const int rt, const float* const iP, auto mask_tag) {
             constexpr int MASK = decltype(mask_tag)::value;
-            const int t0 = rt * TT, nrows = min(ntiles * TT, T - t0);
+            const int t0 = rt * TT, nrows = min(TT, T - t0);
             const size_t toff = ((size_t)b0 * T + t0) * D;
             flush_tile<MASK>(iP, img, a.pos + toff - 4, a.vel + toff - 4, a.actions + toff - 4, ne, pitch, nch, nrows * D, b0, T * D, a.td3, vec,
                              a.wt != 0, lane);
         };
         using std::integral_constant;
         if constexpr (!PIPE) {
-            // (nsub > 1: HBM-streaming launches stage nsub tiles before they flush -- runs of nsub x 16 D floats per episode and array)
-            const int NS = a.nsub, sub_floats = TT * D;
-            for (int rt0 = rt_begin; rt0 < nrt_live; rt0 += NS) {
-                const int ns = min(NS, nrt_live - rt0);
-                for (int sb = 0; sb < ns; ++sb) {
-                    do_A(rt0 + sb, sP + sb * sub_floats, sCar);
-                    do_B(rt0 + sb, sP + sb * sub_floats);
-                }
+            for (int rt = rt_begin; rt < nrt_live; ++rt) {
+                do_A(rt, sP, sCar);
+                do_B(rt, sP);
                 __builtin_amdgcn_wave_barrier();
-                if (store) do_C(rt0, sP, integral_constant<int, 7>(), ns);
-                __builtin_amdgcn_wave_barrier();            // the tiles' LDS reads are issued before the next tiles' writes
+                if (store) do_C(rt, sP, integral_constant<int, 7>());
+                __builtin_amdgcn_wave_barrier();            // the tile's LDS reads are issued before the next tile's writes
             }
         } else {
             // the consumer tells the producers how many tiles the chunk runs (what it knows from the integer state), then the roles part
@@ -785,10 +779,9 @@ int launch_phase_fused(const DevCfg& c, const float* params, const float* init_p
     const bool out = pos != nullptr;
     fa.vec_ok = out && ((reinterpret_cast<uintptr_t>(pos) | reinterpret_cast<uintptr_t>(vel) | reinterpret_cast<uintptr_t>(actions)) & 15u) == 0 ? 1 : 0;
     fa.td3 = (c.T * c.D) & 3;
-    // tiles per flush: "phase_tiles" 1 .. 4 (A/B: profiles/r06_phase_fused_large.md); not in the pipeline form, not with split chunks
-    fa.nsub = 1;
-    if (!pipe && tune.phase_tiles >= 1) fa.nsub = tune.phase_tiles;
-    fa.pitch = (fa.nsub * 16 * c.D + 3 + 3) / 4 * 4;    // nsub x 16 steps + up to three floats of shift, whole 16-byte chunks
+    // (staging two or four tiles per flush -- 896- / 1 792-byte store runs -- was measured and lost: profiles/r06_phase_fused_large.md; carrying the
+    // option cost the tile loop 3 - 9 %)
+    fa.pitch = (16 * c.D + 3 + 3) / 4 * 4;              // 16 steps + up to three floats of shift, whole 16-byte chunks
     fa.t_pad = (c.T + 3) / 4 * 4;
     fa.c_pad = prodmp ? KS + 4 : (4 * c.n_total + 6 + 3) / 4 * 4;
     fa.car_pad = prodmp ? 0 : (E * 2 * c.D + 3) / 4 * 4;

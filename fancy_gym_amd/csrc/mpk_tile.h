@@ -493,23 +493,9 @@ __device__ __forceinline__ void pd_tile_steps(const float* __restrict__ sP, cons
     // ballots (live is monotone in the step).  Round 4, second session: with T = 100 the seventh tile has four steps, and
     // computing-and-discarding the other twelve cost as much as a full tile (trace of k_traj_pipe: 2 000 - 2 600 cycles).
     int nlive = 16;
-    bool split = false, dead = false;
-    double qs0 = 0.0, qds0 = 0.0;
     if (MASKED) {
-        // Round 6: a tile in which NO lane's executed steps end -- every lane either executes all 16 steps or none (a wave that holds
-        // finished episodes beside live ones: after an invalid plan, a reached horizon, a planning budget) -- runs the chain without
-        // the per-step selects (`split`, wave-uniform: the same loop body, the selects behind a scalar branch); the lanes that execute
-        // nothing get their state back and write zeros afterwards.  With the selects and the ballot search below such a tile took
-        // 1.75 x a full one: TableTennis-ProDMP at 4 096 episodes, two finished episodes left behind by invalid plans, 47 -> 67 us
-        // (tools/gate_probe.py; profiles/r06_finished_episodes.md).  Same operations on the live lanes, the same zeros and the same
-        // state on the others: same bits.  (A tile NO lane executes keeps the short path: nlive = 0, zeros.)
-        dead = nst <= t0;
-        split = rows == 16 && __all(dead || nst >= t0 + 16) != 0 && __any(!dead) != 0;
-        qs0 = qs; qds0 = qds;
         const int n0 = __builtin_amdgcn_readfirstlane(nst);
-        if (split) {
-            nlive = 16;
-        } else if (__all(nst == n0)) {
+        if (__all(nst == n0)) {
             nlive = min(max(n0 - t0, 0), 16);
         } else {
             int lo = 0, hi = 16;
@@ -532,7 +518,7 @@ __device__ __forceinline__ void pd_tile_steps(const float* __restrict__ sP, cons
         const double qds_n = INTEGRATE ? qds + dtp * u : qds;
         const double qs_n = INTEGRATE ? qs + dtp * qds_n : qs;
         // (WRITE_A = false: no float32 action image -- the episode-return kernel stores no actions)
-        if (MASKED && !split) {
+        if (MASKED) {
             const bool live = t0 + tl < nst;
             qds = live ? qds_n : qds;
             qs = live ? qs_n : qs;
@@ -547,15 +533,6 @@ __device__ __forceinline__ void pd_tile_steps(const float* __restrict__ sP, cons
         // bytes apart now, 16 lanes of one instruction -- but nothing waits for a write)
         if (KEEP64 == 1) q64[tl] = qs;
         if (KEEP64) u64[tl] = u;
-    }
-    if (MASKED && split && dead) {
-        qs = qs0; qds = qds0;
-#pragma unroll
-        for (int tl = 0; tl < 16; ++tl) {
-            if (WRITE_A) sA[tl * stride] = 0.0f;
-            if (KEEP64 == 1) q64[tl] = qs0;
-            if (KEEP64) u64[tl] = 0.0;
-        }
     }
     if (MASKED) {
 #pragma unroll 1

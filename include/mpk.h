@@ -221,7 +221,6 @@ int mpk_set_duration(mpk_handle h, double duration, double dt);
  *                   every SIMD holds two waves; 1 = whole chunks)
  *   "phase_pipe"    1 / 0: force / forbid the producer / consumer form of k_phase_fused<.., closed> (a workgroup of four waves per chunk: a consumer and three producers;
  *                   automatic for closed-loop launches of a few thousand episodes)
- *   "phase_tiles"   1 .. 4: 16-step tiles k_phase_fused stages before it flushes (runs of n x 16 D floats per episode and array)
  *   "pd_pipe"       1 / 0: force / forbid the producer / consumer form of the rollout on existing trajectories (k_pd_rollout_pipe: a consumer
  *                   wave and three producers per four groups; automatic for a few thousand episodes)
  *   "pd_helper"     1 the reward rollout's control-cost pass on two helper waves of a six-wave workgroup instead of on the chain waves

@@ -327,7 +327,7 @@ def test_the_validity_gate_inside_the_step_equals_the_separate_launches_and_the_
 
 @pytest.mark.parametrize("name", ["tt_prodmp", "beerpong_promp", "prodmp_3dof_learn_tau"])
 @pytest.mark.parametrize("opt", [("phase_chunk", 1), ("phase_chunk", 2), ("phase_chunk", 4), ("phase_table", 0), ("phase_table", 1),
-                                 ("pd_generic", 1), ("write_through", 0), ("write_through", 1), ("tiles_wpb", 1), ("phase_pipe", 0), ("phase_pipe", 1), ("phase_tiles", 2), ("phase_tiles", 4)])
+                                 ("pd_generic", 1), ("write_through", 0), ("write_through", 1), ("tiles_wpb", 1), ("phase_pipe", 0), ("phase_pipe", 1)])
 def test_every_launch_geometry_of_the_fused_kernel_gives_the_same_bits(name, opt, mpk_option):
     eng = engine_of(name)
     B = 333

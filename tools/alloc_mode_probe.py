@@ -3,6 +3,7 @@
 The fused learned-phase launch at 65 536 episodes runs in one of two modes per PROCESS / allocation (34 - 36 % or 43 - 50 % of 8 TB/s:
 profiles/r06_phase_fused_large.md).  This probe times the same launch on several fresh output allocations inside one process -- separate
 tensors, one slab, a slab with skewed array bases, after emptying the caching allocator -- and prints addresses beside times.
+(Its `--tiles` mode, the A/B of the removed `phase_tiles` option, went with the option: profiles/r06_phase_fused_large.md has the table.)
     python tools/alloc_mode_probe.py [B]
 """
 import os
@@ -43,25 +44,6 @@ def main():
         print(f"{label:34s} {t * 1e6:7.1f} us = {nbytes / t / 8e12 * 100:4.1f} %   fill of the same arrays {3 * n * 4 / fill / 1e12:4.2f} TB/s   "
               f"bases {[hex(o.data_ptr()) for o in out]}", flush=True)
 
-    if "--tiles" in sys.argv:
-        # tiles per flush (phase_tiles) on the SAME allocation, frozen-state actions and the closed loop, a few fresh allocations per process
-        from fancy_gym_amd import _lib
-        closed = RolloutSpec("motor", D, pg, dg, -1.0, 1.0, plant="double_integrator", dt=kw["dt"])
-        i32 = dict(dtype=torch.int32, device=dev)
-        ts, ps, dn = torch.zeros(B, **i32), torch.zeros(B, **i32), torch.zeros(B, dtype=torch.uint8, device=dev)
-        for r in range(3):
-            out = tuple(torch.empty((B, T, D), device=dev) for _ in range(3))
-            keep.append(out)
-            row = []
-            for ns in (1, 2, 4, 1):
-                _lib.set_option("phase_tiles", ns)
-                q, qd = q0.clone(), qd0.clone()
-                ta = graph_time(lambda: eng.trajectory_actions(params, ip, iv, static, q0, qd0, 0.0, out=out), reps=4)
-                tc = graph_time(lambda: eng.replan_step(params, ip, iv, closed, q, qd, ts, ps, dn, T, 2 ** 30, 2 ** 30, condition=True, out=out), reps=4)
-                row.append(f"tiles {ns}: act {ta * 1e6:6.1f} ({nbytes / ta / 8e12 * 100:4.1f} %) closed {tc * 1e6:6.1f} ({nbytes / tc / 8e12 * 100:4.1f} %) {eng.last_kernel()}")
-            print(f"allocation #{r}: " + " | ".join(row), flush=True)
-        _lib.reset_options()
-        return
     for r in range(1 if "--skews" in sys.argv else 4):
         out = tuple(torch.empty((B, T, D), device=dev) for _ in range(3))
         keep.append(out)

@@ -1127,6 +1127,38 @@ def test_reacher_rollout_matches_oracle(controller, D, B, T, mode, monkeypatch, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("reward", [False, True])
+def test_rollout_pipeline_with_several_units_per_workgroup_equals_the_tile_kernel(reward, mpk_option):
+    """k_pd_rollout_pipe forced on a launch far beyond its automatic range: every workgroup walks several units (the counters of its
+    waves keep counting across them), the last unit is ragged; actions, rewards and plant state are the tile kernel's bits"""
+    from fancy_gym_amd import TrajectoryEngine
+    D, T, B = 5, 200, 20003
+    eng = TrajectoryEngine(device=0, mp_type="promp", phase_type="linear", basis_type="rbf", num_dof=D, num_basis=3, dt=0.01, duration=T * 0.01,
+                           tau=T * 0.01)
+    g = torch.Generator().manual_seed(5)
+    des_pos = torch.randn((B, T, D), generator=g).cuda(); des_vel = torch.randn((B, T, D), generator=g).cuda()
+    q0 = (torch.rand((B, D), generator=g, dtype=torch.float64) * 2 - 1).cuda(); qd0 = (torch.rand((B, D), generator=g, dtype=torch.float64) - 0.5).cuda()
+    goal = (torch.rand((B, 2), generator=g, dtype=torch.float64) * 4 - 2).cuda()
+    n_steps = torch.randint(0, T + 1, (B,), generator=g, dtype=torch.int32).cuda()
+    step0 = torch.randint(0, 60, (B,), generator=g, dtype=torch.int32).cuda()
+    spec = RolloutSpec("motor", D, 0.6, 0.075, -2.0, 1.5, plant="double_integrator", dt=0.01)
+    outs = []
+    for pipe in (0, 1):
+        mpk_option("pd_pipe", pipe)
+        q, qd = q0.clone(), qd0.clone()
+        if reward:
+            act, rew = eng.reacher_rollout(spec, des_pos, des_vel, q, qd, goal, n_steps=n_steps, step0=step0, steps_before_reward=199)
+        else:
+            act, rew = eng.pd_rollout(spec, des_pos, des_vel, q, qd, n_steps=n_steps), torch.zeros(1)
+        torch.cuda.synchronize()
+        eng.check_range()
+        outs.append((act.clone(), rew.clone(), q, qd))
+    for a, b, what in zip(outs[0], outs[1], ("actions", "rewards", "q", "qd")):
+        assert torch.equal(a, b), what
+    assert float(outs[1][0].abs().max()) > 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("sbr", [0, 199, 100000])
 @pytest.mark.parametrize("D,B,T", [(5, 300, 200), (5, 37, 100), (2, 40, 200), (7, 50, 64)])
 @pytest.mark.parametrize("mode", ["tiles", "quad", "generic", "tiles_rt", "tiles_nohelper", "quad_helper", "duo_helper", "pipe", "pipe_rt"])

@@ -136,6 +136,7 @@ __global__ void __launch_bounds__(256, (NQ == 4 ? MPK_QUAD_WPE4 : NQ == 2 ? MPK_
         float* sQ = sW + L.q * kQuadImg;
         double qs = sc.qs, qds = sc.qds;
         int nst_ = sc.nst;
+        bool inv = false;               // gate: this lane's plan is invalid (its chain runs all the same: below)
         if (CLOSED && a.gate_valid) {
             // validity gate: judge the unit's plans first (gate_pass, mpk_tile.h); an invalid plan executes nothing
             ReplanVals rv{sc.nst, 0, 0, false};
@@ -153,7 +154,12 @@ __global__ void __launch_bounds__(256, (NQ == 4 ? MPK_QUAD_WPE4 : NQ == 2 ? MPK_
             double over, under;
             const bool p_bad = gate_pass<KM, NQ>(a, L, ap, TS, KM, xb, g0, glim, over, under);
             const bool invalid = serial && (p_bad || t_bad);
-            nst_ = invalid ? 0 : rv.seg;
+            // An invalid plan executes nothing -- but its lanes run the chain like their neighbours' and DROP the result (plant state not
+            // written, actions clipped to [0, 0]): with nst = 0 beside lanes that execute the whole plan, every tile of the wave was a
+            // masked tile (ballot search + three selects per step, 1.75 x a full tile) -- cfg5 at 8 192 episodes, two invalid plans:
+            // 53.6 -> 79.8 us for the LAUNCH (profiles/r06_finished_episodes.md; k_phase_fused and k_traj_pipe run speculatively anyway)
+            inv = invalid;
+            nst_ = rv.seg;
             if (serial && L.d == 0) {
                 a.gate_valid[bq] = invalid ? 0 : 1;
                 const double n = (double)(T * D);
@@ -166,7 +172,9 @@ __global__ void __launch_bounds__(256, (NQ == 4 ? MPK_QUAD_WPE4 : NQ == 2 ? MPK_
         if (CLOSED) asm volatile("" : "+v"(qs), "+v"(qds), "+v"(nst_));
         else asm volatile("" : "+v"(ey), "+v"(ez), "+v"(eg));
         const int nst = nst_;
-        const int tcond = (CLOSED && a.rp.cond_pos) ? min(max(nst - 1, 0), T - 1) : -1;
+        const int tcond = (CLOSED && a.rp.cond_pos) ? (inv ? 0 : min(max(nst - 1, 0), T - 1)) : -1;      // (invalid: the desired state of step 0)
+        // (an invalid lane's actions are clipped to [0, 0]: zeros in the action image without a write of their own)
+        const double lod_u = inv ? 0.0 : lod, hid_u = inv ? 0.0 : hid;
         // A fragments (basis rows of a row tile) are the same for the four groups: read from LDS once per tile, one tile
         // ahead, into registers.  Left to the compiler they are re-read in front of every MFMA (it cannot prove that
         // the staging writes do not alias the tables), and with one or two waves per SIMD each of those LDS round trips
@@ -231,10 +239,10 @@ __global__ void __launch_bounds__(256, (NQ == 4 ? MPK_QUAD_WPE4 : NQ == 2 ? MPK_
                     }
                     if (full_tile)
                         pd_tile_steps<(CLOSED ? CT - 3 : 0), false>(sQ + oq, sQ + kStageStride + oq, sQ + 2 * kStageStride + oq, D,
-                                                                    rt * 16, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds);
+                                                                    rt * 16, nst, pgd, dgd, lod_u, hid_u, a.plant_dt, qs, qds);
                     else
                         pd_tile_steps<(CLOSED ? CT - 3 : 0), true>(sQ + oq, sQ + kStageStride + oq, sQ + 2 * kStageStride + oq, D,
-                                                                   rt * 16, nst, pgd, dgd, lod, hid, a.plant_dt, qs, qds, nullptr, nullptr, rows);
+                                                                   rt * 16, nst, pgd, dgd, lod_u, hid_u, a.plant_dt, qs, qds, nullptr, nullptr, rows);
                 } else {
                     dmp_tile_steps(sQ + 2 * kStageStride + oq, sQ + oq, sQ + kStageStride + oq, sAux + rt * 16, D, rt * 16, T,
                                    c.dmp_alpha, c.dmp_beta, eg, td, ey, ez);
@@ -262,7 +270,7 @@ __global__ void __launch_bounds__(256, (NQ == 4 ? MPK_QUAD_WPE4 : NQ == 2 ? MPK_
             MPK_STAMP(50 + rt);
         }
         if (CLOSED) {
-            if (serial) {
+            if (serial && !inv) {
                 const size_t si = (size_t)bq * D + L.d;
                 a.q_state[si] = qs; a.qd_state[si] = qds;
             }
